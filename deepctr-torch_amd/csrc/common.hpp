@@ -1,0 +1,98 @@
+// common.hpp -- shared device helpers for the gfx950 kernels of libdctr_hip.so.
+// Wave size is 64 on CDNA4; every kernel here is written for 64-lane wavefronts.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dctr.h"
+
+namespace dctr {
+
+constexpr int kWave = 64;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// A short per-lane strip of VEC consecutive floats (VEC in {1,2,4}); loads/stores are one
+// global_load/store_dword{,x2,x4}.
+template <int VEC>
+struct Strip {
+  float v[VEC];
+};
+
+template <int VEC>
+__device__ __forceinline__ Strip<VEC> strip_zero() {
+  Strip<VEC> r;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) r.v[i] = 0.f;
+  return r;
+}
+
+// Every pointer these helpers see addresses global (HBM) memory, but pointers that were parked in
+// LDS come back as generic pointers and would be accessed with FLAT instructions, which tick the
+// LGKM counter as well and so serialise against every later LDS read.  Casting to address space 1
+// makes them global_load / global_store / global_atomic.
+#define DCTR_GLOBAL __attribute__((address_space(1)))
+
+__device__ __forceinline__ float ldg_f32(const float* p) {
+  return *(const DCTR_GLOBAL float*)p;
+}
+__device__ __forceinline__ int32_t ldg_i32(const int32_t* p) {
+  return *(const DCTR_GLOBAL int32_t*)p;
+}
+__device__ __forceinline__ void stg_f32(float* p, float v) { *(DCTR_GLOBAL float*)p = v; }
+
+template <int VEC>
+__device__ __forceinline__ Strip<VEC> strip_load(const float* p) {
+  Strip<VEC> r;
+  if constexpr (VEC == 4) {
+    f32x4 t = *(const DCTR_GLOBAL f32x4*)p;
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+  } else if constexpr (VEC == 2) {
+    f32x2 t = *(const DCTR_GLOBAL f32x2*)p;
+    r.v[0] = t.x; r.v[1] = t.y;
+  } else {
+    r.v[0] = *(const DCTR_GLOBAL float*)p;
+  }
+  return r;
+}
+
+template <int VEC>
+__device__ __forceinline__ void strip_store(float* p, const Strip<VEC>& s) {
+  if constexpr (VEC == 4) {
+    f32x4 t = {s.v[0], s.v[1], s.v[2], s.v[3]};
+    *(DCTR_GLOBAL f32x4*)p = t;
+  } else if constexpr (VEC == 2) {
+    f32x2 t = {s.v[0], s.v[1]};
+    *(DCTR_GLOBAL f32x2*)p = t;
+  } else {
+    *(DCTR_GLOBAL float*)p = s.v[0];
+  }
+}
+
+// fp32 hardware atomic add without return (global_atomic_add_f32; needs -munsafe-fp-atomics).
+// Tables are ordinary coarse-grained hipMalloc memory owned by PyTorch, where it is valid.
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+  __hip_atomic_fetch_add((DCTR_GLOBAL float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float atomic_xchg_f32(float* p, float v) {
+  return __hip_atomic_exchange((DCTR_GLOBAL float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// sum over the LPR consecutive lanes that form one sample group (LPR is a power of two <= 64)
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int m = LPR / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+
+inline int hip_status(hipError_t e) { return e == hipSuccess ? DCTR_OK : static_cast<int>(e); }
+
+inline int launch_status() { return hip_status(hipGetLastError()); }
+
+}  // namespace dctr

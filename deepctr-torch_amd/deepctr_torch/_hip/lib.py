@@ -1,0 +1,105 @@
+"""Loader for ``libdctr_hip.so``.
+
+The product path has no CPU fallback: if the library is missing, fails to load, or a tensor is not
+on a GPU, the call raises.  (The CPU restatement of these ops lives in ``oracle/`` and is test
+infrastructure only.)
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdctr_hip.so")
+ABI_VERSION = 1
+
+c_float_p = ctypes.c_void_p  # device pointers travel as integers
+
+
+class Field(ctypes.Structure):
+    """``dctr_field_t`` (include/dctr.h) -- 64 bytes."""
+    _fields_ = [("table", ctypes.c_void_p), ("gacc", ctypes.c_void_p), ("state", ctypes.c_void_p),
+                ("vocab", ctypes.c_int64), ("dim", ctypes.c_int32), ("col", ctypes.c_int32),
+                ("len", ctypes.c_int32), ("pool", ctypes.c_int32), ("len_col", ctypes.c_int32),
+                ("out_off", ctypes.c_int32), ("pad_", ctypes.c_int32 * 2)]
+
+
+class Plan(ctypes.Structure):
+    """``dctr_plan_t`` (include/dctr.h) -- host struct, device arrays."""
+    _fields_ = [("deep", ctypes.c_void_p), ("wide", ctypes.c_void_p), ("dense_cols", ctypes.c_void_p),
+                ("wdense_cols", ctypes.c_void_p), ("wdense_w", ctypes.c_void_p),
+                ("n_deep", ctypes.c_int32), ("n_deep_fixed", ctypes.c_int32), ("n_wide", ctypes.c_int32),
+                ("n_dense", ctypes.c_int32), ("n_wdense", ctypes.c_int32), ("dense_off", ctypes.c_int32),
+                ("emb_dim", ctypes.c_int32), ("n_xcols", ctypes.c_int32), ("n_wide_fixed", ctypes.c_int32),
+                ("max_dim", ctypes.c_int32), ("vec", ctypes.c_int32), ("flags", ctypes.c_int32)]
+
+
+PLAN_HAS_GACC, PLAN_HAS_STATE, PLAN_HAS_MAXPOOL = 1, 2, 4
+POOL_CODE = {None: 0, "sum": 1, "mean": 2, "max": 3}
+BWD_ACCUM, BWD_SGD = 0, 1
+OPT_SGD, OPT_ADAGRAD = 0, 1
+
+_I32, _I64, _F32, _P = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+# name -> (restype, argtypes): every symbol include/dctr.h declares.  tests/test_abi.py parses the
+# header and checks this table and the built library against it.
+SIGNATURES = {
+    "dctr_abi_version": (ctypes.c_int, []),
+    "dctr_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "dctr_sizeof_field": (ctypes.c_size_t, []),
+    "dctr_sizeof_plan": (ctypes.c_size_t, []),
+    "dctr_embed_fwd": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _P, _I64, _P, _P, _P, _P]),
+    "dctr_embed_bwd": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P,
+                                      _I32, _F32, _P]),
+    "dctr_embed_apply": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _I32, _F32, _F32, _P]),
+    "dctr_fm_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P]),
+    "dctr_fm_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _I64, _I32, _P]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it cannot be used."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libdctr_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C deepctr-torch_amd/csrc`; there is no CPU fallback for the HIP hot path." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here == header and library disagree
+            fn.restype, fn.argtypes = res, args
+        if handle.dctr_abi_version() != ABI_VERSION:
+            raise RuntimeError("libdctr_hip.so ABI %d != binding ABI %d" % (handle.dctr_abi_version(), ABI_VERSION))
+        if handle.dctr_sizeof_field() != ctypes.sizeof(Field) or handle.dctr_sizeof_plan() != ctypes.sizeof(Plan):
+            raise RuntimeError("dctr_field_t / dctr_plan_t layout mismatch between header and binding")
+        _lib = handle
+    return _lib
+
+
+def check(rc, what="dctr call"):
+    if rc != 0:
+        msg = lib().dctr_strerror(int(rc))
+        raise RuntimeError("%s failed: %s (code %d)" % (what, msg.decode() if msg else "?", rc))
+
+
+def stream_handle(device=None):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(
+            "%s: tensor lives on %s -- the DeepCTR hot path runs only on an AMD GPU through libdctr_hip.so; "
+            "there is no CPU fallback (build the model with device='cuda:0')." % (what, t.device))

@@ -1,0 +1,196 @@
+"""autograd.Function wrappers over the C-ABI (include/dctr.h).
+
+Embedding tables never enter autograd as inputs: the reference's dense ``[V, D]`` gradient
+(``aten::embedding_dense_backward``, triggered from basemodel.py:261) is replaced by an O(batch)
+scatter executed inside ``EmbedFunction.backward``.  What that scatter does is selected by
+``plan.update``:
+
+  ``("dense",)``            add the row gradients into the table's zero-at-rest ``gacc`` slab and expose
+                            it as ``param.grad`` -- bit-for-bit the tensor the reference hands to ANY
+                            optimizer / regulariser (default; O(V) only if the optimizer is).
+  ``("sgd", lr)``           ``table[row] -= lr * g`` straight from the scatter kernel.
+  ``("sgd2", lr)``          two-pass SGD (needed when a max-pooled field re-reads the table).
+  ``("adagrad", lr, eps)``  scatter into ``gacc``, then ``dctr_embed_apply`` consumes the touched rows.
+"""
+import ctypes
+
+import torch
+
+from . import lib as L
+from .plan import EmbeddingPlan
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _rows_f32(t, what):
+    """2-D float32 tensor with unit inner stride (a row-strided view is fine)."""
+    L.require_gpu(t, what)
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1) or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t
+
+
+def _aligned_rows(t, vec, ld_min):
+    """Rows usable with ``vec``-wide loads: base pointer and row stride multiples of ``vec`` floats."""
+    if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % vec or t.data_ptr() % (4 * vec) or t.stride(0) < ld_min:
+        ld = (max(t.shape[1], ld_min) + 3) // 4 * 4
+        buf = torch.empty((t.shape[0], ld), dtype=torch.float32, device=t.device)
+        buf[:, :t.shape[1]].copy_(t)
+        return buf, ld
+    return t, t.stride(0)
+
+
+class EmbedFunction(torch.autograd.Function):
+    """Fused lookup: see ``dctr_embed_fwd`` / ``dctr_embed_bwd`` in include/dctr.h."""
+
+    @staticmethod
+    def forward(ctx, plan, X, anchor, wdense_w, want_fm):
+        lib = L.lib()
+        X = _rows_f32(X, "model input X")
+        if X.shape[1] < plan.n_xcols:
+            raise ValueError("X has %d columns, the feature columns need %d" % (X.shape[1], plan.n_xcols))
+        B = X.shape[0]
+        cplan = plan.bind(X.device)
+        out = torch.empty((B, plan.ld_out), dtype=torch.float32, device=X.device) if plan.has_lookup else None
+        wide = torch.empty((B,), dtype=torch.float32, device=X.device) if plan.has_wide else None
+        fm = torch.empty((B,), dtype=torch.float32, device=X.device) if want_fm else None
+        if want_fm and (plan.emb_dim <= 0 or not plan.deep):
+            raise ValueError("FM needs sparse features that share one embedding_dim")
+        L.check(lib.dctr_embed_fwd(cplan, _ptr(X), X.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), _ptr(fm),
+                                   _ptr(plan.err_flag(X.device)), L.stream_handle(X.device)), "dctr_embed_fwd")
+        ctx.plan, ctx.want_fm = plan, want_fm
+        ctx.save_for_backward(X, out if want_fm else None)
+        ctx.set_materialize_grads(False)
+        outs = (out if out is not None else X.new_zeros((B, 0)),
+                wide if wide is not None else X.new_zeros((B,)),
+                fm if fm is not None else X.new_zeros((B,)))
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_out, g_wide, g_fm):
+        lib = L.lib()
+        plan = ctx.plan
+        X, out = ctx.saved_tensors
+        B = X.shape[0]
+        if not plan.has_lookup:
+            g_out = None
+        if not plan.has_wide:
+            g_wide = None
+        if not ctx.want_fm:
+            g_fm = None
+        g_w = None
+        if g_wide is not None:
+            g_wide = g_wide.contiguous()
+            if plan.wide_dense_weight is not None and ctx.needs_input_grad[3]:
+                # d wide / d Linear.weight = X_dense^T g  (basemodel.py:88-90)
+                g_w = plan.dense_matrix(X, plan.wdense_cols).t().mv(g_wide).unsqueeze(1)
+        if g_fm is not None:
+            g_fm = g_fm.contiguous()
+        ld_g = 0
+        if g_out is not None:
+            g_out, ld_g = _aligned_rows(g_out, plan.vec, 0)
+        if (g_out is None and g_fm is None and g_wide is None) or not plan.table_params:
+            return None, None, None, g_w, None
+
+        update = plan.update
+        kind = update[0]
+        stream = L.stream_handle(X.device)
+        if kind == "sgd" and not plan.has_maxpool:
+            cplan = plan.bind(X.device)
+            L.check(lib.dctr_embed_bwd(cplan, _ptr(X), X.stride(0), B, _ptr(g_out), ld_g, _ptr(out), plan.ld_out,
+                                       _ptr(g_fm), _ptr(g_wide), L.BWD_SGD, float(update[1]), stream),
+                    "dctr_embed_bwd(sgd)")
+            return None, None, None, g_w, None
+
+        plan.ensure_gacc()
+        if kind == "dense":
+            plan.prepare_dense_grads()
+        cplan = plan.bind(X.device)
+        L.check(lib.dctr_embed_bwd(cplan, _ptr(X), X.stride(0), B, _ptr(g_out), ld_g, _ptr(out), plan.ld_out,
+                                   _ptr(g_fm), _ptr(g_wide), L.BWD_ACCUM, 0.0, stream), "dctr_embed_bwd(accum)")
+        if kind in ("sgd", "sgd2"):
+            L.check(lib.dctr_embed_apply(cplan, _ptr(X), X.stride(0), B, L.OPT_SGD, float(update[1]), 0.0, stream),
+                    "dctr_embed_apply(sgd)")
+        elif kind == "adagrad":
+            L.check(lib.dctr_embed_apply(cplan, _ptr(X), X.stride(0), B, L.OPT_ADAGRAD, float(update[1]),
+                                         float(update[2]), stream), "dctr_embed_apply(adagrad)")
+        elif kind != "dense":
+            raise RuntimeError("unknown sparse update mode %r" % (kind,))
+        return None, None, None, g_w, None
+
+
+def embed(plan, X, want_fm=False):
+    """(out [B, width] view, wide [B], fm [B]) for model input ``X`` under ``plan``."""
+    L.require_gpu(X, "model input X")
+    plan.bind(X.device)
+    out, wide, fm = EmbedFunction.apply(plan, X, plan.anchor, plan.wide_dense_weight, bool(want_fm))
+    if plan.has_lookup:
+        out = out[:, :plan.width]
+    return out, wide, fm
+
+
+_PLAN_CACHE_ATTR = "_dctr_plans"
+
+
+def gather_columns(X, embedding_dict, feature_index, columns, pooled=True):
+    """Per-column embeddings as views of ONE fused gather: ``[B, 1, D]`` per SparseFeat (and per pooled
+    VarLenSparseFeat), ``[B, maxlen, D]`` per un-pooled VarLenSparseFeat.  Backs the reference-shaped
+    helpers (``embedding_lookup``, ``varlen_embedding_lookup``, ``input_from_feature_columns``)."""
+    cache = embedding_dict.__dict__.setdefault(_PLAN_CACHE_ATTR, {})
+    key = (tuple(c.name for c in columns), bool(pooled), id(feature_index))
+    plan = cache.get(key)
+    if plan is None:
+        plan = EmbeddingPlan(feature_index, deep_columns=list(columns), deep_tables=embedding_dict,
+                             unpooled=not pooled, with_dense=False)
+        owner = getattr(embedding_dict, "_dctr_owner_plan", None)
+        if owner is not None:
+            plan.share_update_with(owner)
+        cache[key] = plan
+    out, _, _ = embed(plan, X)
+    B = X.shape[0]
+    sparse_cols = [c for c in columns if not hasattr(c, "maxlen")]
+    varlen_cols = [c for c in columns if hasattr(c, "maxlen")]
+    views, off = {}, 0
+    for c in sparse_cols:
+        d = embedding_dict[c.embedding_name].weight.shape[1]
+        views[c.name] = out[:, off:off + d].unsqueeze(1)
+        off += d
+    for c in varlen_cols:
+        d = embedding_dict[c.embedding_name].weight.shape[1]
+        t = 1 if pooled else c.maxlen
+        views[c.name] = out[:, off:off + t * d].reshape(B, t, d)
+        off += t * d
+    return [views[c.name] for c in columns]
+
+
+# ---- FM on explicit tensors (interaction.py:26-34) --------------------------------------------------
+class FMFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, E):
+        lib = L.lib()
+        L.require_gpu(E, "FM input")
+        if E.dim() != 3:
+            raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % E.dim())
+        B, F, D = E.shape
+        if E.dtype != torch.float32 or E.stride(2) != 1 or E.stride(1) != D:
+            E = E.float().contiguous()
+        y = torch.empty((B,), dtype=torch.float32, device=E.device)
+        L.check(lib.dctr_fm_fwd(_ptr(E), E.stride(0) if B > 1 else F * D, B, F, D, _ptr(y),
+                                L.stream_handle(E.device)), "dctr_fm_fwd")
+        ctx.save_for_backward(E)
+        return y.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = L.lib()
+        (E,) = ctx.saved_tensors
+        B, F, D = E.shape
+        gy = gy.reshape(B).contiguous().float()
+        gE = torch.empty((B, F, D), dtype=torch.float32, device=E.device)
+        L.check(lib.dctr_fm_bwd(_ptr(E), E.stride(0) if B > 1 else F * D, B, F, D, _ptr(gy), _ptr(gE), F * D, 0,
+                                L.stream_handle(E.device)), "dctr_fm_bwd")
+        return gE

@@ -1,0 +1,311 @@
+"""Feature columns -> ``dctr_plan_t``: the compiled schema the gather / scatter kernels run on.
+
+One :class:`EmbeddingPlan` plays the role of everything ``build_input_features``,
+``create_embedding_matrix`` and ``Linear.__init__`` set up in the reference (inputs.py:99-180,
+basemodel.py:34-61): which X column feeds which table, how a VarLen feature is pooled, and where each
+field lands in the DNN-input row (``combined_dnn_input`` order, inputs.py:126-138).
+
+HBM layout (sized for 288 GB): every table is its own ``[V, D]`` fp32 tensor (the ``nn.Embedding``
+weight, so ``state_dict`` keys stay the reference's); next to a table may sit two same-shaped slabs,
+``gacc`` (gradient accumulator, ZERO AT REST: the scatter kernel adds into it and the optimizer pass
+re-zeroes exactly the rows it consumed, so no O(V) memset ever runs) and ``state`` (Adagrad sum).
+"""
+import ctypes
+import weakref
+
+import torch
+
+from . import lib as L
+from ..inputs import DenseFeat, SparseFeat, VarLenSparseFeat, split_columns
+
+
+# Slabs are keyed by the table Parameter itself (not by plan): every plan over a table shares them, they
+# die with the parameter, and they never travel inside ``torch.save(model)``.
+class _ParamMap(object):
+    """Weak map Parameter -> tensor keyed by identity (tensor ``==`` is elementwise, which rules out
+    ``weakref.WeakKeyDictionary``)."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, p, default=None):
+        hit = self._d.get(id(p))
+        return hit[1] if hit is not None and hit[0]() is p else default
+
+    def __contains__(self, p):
+        return self.get(p) is not None
+
+    def __getitem__(self, p):
+        v = self.get(p)
+        if v is None:
+            raise KeyError("no slab for this parameter")
+        return v
+
+    def __setitem__(self, p, value):
+        key = id(p)
+        self._d[key] = (weakref.ref(p, lambda _r, k=key, d=self._d: d.pop(k, None)), value)
+
+    def __delitem__(self, p):
+        self._d.pop(id(p), None)
+
+
+_GACC = _ParamMap()
+_STATE = _ParamMap()
+
+
+class _FieldSpec(object):
+    __slots__ = ("name", "param", "col", "len", "pool", "len_col", "out_off", "dim", "vocab")
+
+    def __init__(self, name, param, col, length, pool, len_col, out_off):
+        self.name, self.param, self.col, self.len = name, param, col, length
+        self.pool, self.len_col, self.out_off = pool, len_col, out_off
+        self.vocab, self.dim = int(param.shape[0]), int(param.shape[1])
+
+
+def _fields_for(columns, tables, feature_index, unpooled):
+    """Fixed-length fields first, then VarLen ones (the order of
+    ``sparse_embedding_list + varlen_sparse_embedding_list``, basemodel.py:380)."""
+    sparse_cols, varlen_cols, _ = split_columns(columns)
+    fixed, pooled = [], []
+    off = 0
+    for fc in sparse_cols:
+        w = tables[fc.embedding_name].weight
+        fixed.append(_FieldSpec(fc.name, w, feature_index[fc.name][0], 1, 0, -1, off))
+        off += int(w.shape[1])
+    for fc in varlen_cols:
+        w = tables[fc.embedding_name].weight
+        lo, hi = feature_index[fc.name]
+        if unpooled:  # [B, maxlen, D]: every position is its own fixed field
+            for t in range(hi - lo):
+                fixed.append(_FieldSpec("%s[%d]" % (fc.name, t), w, lo + t, 1, 0, -1, off))
+                off += int(w.shape[1])
+        else:
+            if fc.combiner not in ("sum", "mean", "max"):
+                raise ValueError('parameter mode should in [sum, mean, max]')
+            len_col = -1 if fc.length_name is None else feature_index[fc.length_name][0]
+            pooled.append(_FieldSpec(fc.name, w, lo, hi - lo, L.POOL_CODE[fc.combiner], len_col, off))
+            off += int(w.shape[1])
+    return fixed, pooled, off
+
+
+class EmbeddingPlan(object):
+    """Host mirror of ``dctr_plan_t`` + the device arrays it points to.
+
+    deep side  = ``dnn_feature_columns`` over ``embedding_dict``          (basemodel.py:354-380)
+    wide side  = ``linear_feature_columns`` over ``Linear.embedding_dict`` (basemodel.py:63-92)
+    """
+
+    def __init__(self, feature_index, deep_columns=(), deep_tables=None, wide_columns=(), wide_tables=None,
+                 wide_dense_weight=None, unpooled=False, with_dense=True):
+        self.feature_index = feature_index
+        self.n_xcols = max([hi for (_, hi) in feature_index.values()] + [1])
+        dfix, dpool, emb_width = _fields_for(deep_columns, deep_tables, feature_index, unpooled) \
+            if deep_tables is not None else ([], [], 0)
+        wfix, wpool, _ = _fields_for(wide_columns, wide_tables, feature_index, False) \
+            if wide_tables is not None else ([], [], 0)
+        self.deep = dfix + dpool
+        self.wide = wfix + wpool
+        self.n_deep_fixed, self.n_wide_fixed = len(dfix), len(wfix)
+        self.emb_width = emb_width
+        dims = sorted(set(f.dim for f in self.deep))
+        self.emb_dim = dims[0] if len(dims) == 1 else 0
+        self.max_dim = max(dims) if dims else 0
+        self.vec = 4 if all(d % 4 == 0 for d in dims) else (2 if all(d % 2 == 0 for d in dims) else 1)
+        self.has_maxpool = any(f.pool == 3 for f in self.deep + self.wide)
+
+        _, _, ddense = split_columns(deep_columns)
+        _, _, wdense = split_columns(wide_columns)
+        self.dense_cols = [c for fc in ddense for c in range(*feature_index[fc.name])] if with_dense else []
+        self.wdense_cols = [c for fc in wdense for c in range(*feature_index[fc.name])]
+        self.wide_dense_weight = wide_dense_weight if self.wdense_cols else None
+        self.dense_off = emb_width if self.dense_cols else -1
+        self.width = emb_width + len(self.dense_cols)      # logical row width (combined_dnn_input)
+        self.ld_out = max(4, (self.width + 3) // 4 * 4)     # padded leading dimension of `out`
+
+        self._params = []  # unique table parameters, first-use order
+        seen = set()
+        for f in self.deep + self.wide:
+            if id(f.param) not in seen:
+                seen.add(id(f.param))
+                self._params.append(f.param)
+        self.version = 0   # bumps whenever device pointers were re-baked (HIP graphs must re-capture)
+        self._owner = None
+        self._update = ("dense",)
+        self._reset_device_image()
+
+    def _reset_device_image(self):
+        self._key = None
+        self._dev = {}
+        self.cplan = L.Plan()
+        self.anchor = None
+        self._err = None
+        self._wd_idx = None
+
+    # models holding a plan stay picklable (tests/utils.py:162-170 of the reference pickle whole models):
+    # raw ctypes / device handles are dropped and re-baked lazily
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        for k in ("_key", "_dev", "cplan", "anchor", "_err", "_wd_idx"):
+            d.pop(k, None)
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self._reset_device_image()
+
+    # ---- sparse-update mode (see ops.py) ---------------------------------------------------------
+    @property
+    def update(self):
+        return self._owner.update if self._owner is not None else self._update
+
+    @update.setter
+    def update(self, value):
+        self._update = tuple(value)
+
+    def share_update_with(self, owner):
+        """Secondary plans over the same tables follow the owner plan's sparse-update mode."""
+        self._owner = owner
+
+    # ---- slabs ---------------------------------------------------------------------------------
+    @property
+    def table_params(self):
+        return list(self._params)
+
+    def ensure_gacc(self):
+        """Allocate the zero-at-rest gradient slab of every table (idempotent)."""
+        for p in self._params:
+            g = _GACC.get(p)
+            if g is None or g.device != p.device or g.shape != p.shape:
+                _GACC[p] = torch.zeros_like(p.data)
+        return self
+
+    def gacc_of(self, param):
+        return _GACC.get(param)
+
+    def set_state(self, mapping):
+        """``{param: slab}`` -- optimizer state tensors (e.g. ``optimizer.state[p]['sum']``)."""
+        for p in self._params:
+            slab = None
+            for q, s in (mapping or {}).items():
+                if q is p:
+                    slab = s
+            if slab is not None:
+                _STATE[p] = slab
+            elif p in _STATE:
+                del _STATE[p]
+
+    def prepare_dense_grads(self):
+        """``param.grad`` := the gacc slab (autograd semantics: the first backward after zero_grad starts
+        from zero, later backwards accumulate)."""
+        for p in self._params:
+            slab = _GACC[p]
+            if p.grad is None:
+                if getattr(slab, "_dctr_dirty", False):
+                    slab.zero_()
+                p.grad = slab
+            elif p.grad.data_ptr() != slab.data_ptr():
+                raise RuntimeError("embedding parameter .grad was replaced by a foreign tensor; "
+                                   "call optimizer.zero_grad() before backward")
+            slab._dctr_dirty = True
+
+    def err_flag(self, device):
+        if self._err is None or self._err.device != torch.device(device):
+            self._err = torch.zeros(1, dtype=torch.int32, device=device)
+        return self._err
+
+    def check_ids(self):
+        """Poll the out-of-range flag (one device sync).  The reference raises IndexError at once on CPU."""
+        if self._err is not None and int(self._err.item()) != 0:
+            self._err.zero_()
+            raise IndexError("index out of range in self: a sparse id in X is outside [0, vocabulary_size)")
+
+    def dense_matrix(self, X, cols):
+        lo, hi = cols[0], cols[-1] + 1
+        if list(cols) == list(range(lo, hi)):
+            return X[:, lo:hi]
+        if self._wd_idx is None or self._wd_idx.device != X.device:
+            self._wd_idx = torch.tensor(list(cols), dtype=torch.long, device=X.device)
+        return X.index_select(1, self._wd_idx)
+
+    # ---- device image --------------------------------------------------------------------------
+    def _pointer_key(self, device):
+        key = [str(device)]
+        for p in self._params:
+            g, s = _GACC.get(p), _STATE.get(p)
+            key.append((p.data_ptr(), g.data_ptr() if g is not None else 0, s.data_ptr() if s is not None else 0))
+        w = self.wide_dense_weight
+        key.append(w.data_ptr() if w is not None else 0)
+        return tuple(key)
+
+    def _field_bytes(self, specs):
+        arr = (L.Field * max(1, len(specs)))()
+        for i, f in enumerate(specs):
+            g, s = _GACC.get(f.param), _STATE.get(f.param)
+            arr[i].table = f.param.data_ptr()
+            arr[i].gacc = g.data_ptr() if g is not None else None
+            arr[i].state = s.data_ptr() if s is not None else None
+            arr[i].vocab, arr[i].dim, arr[i].col, arr[i].len = f.vocab, f.dim, f.col, f.len
+            arr[i].pool, arr[i].len_col, arr[i].out_off = f.pool, f.len_col, f.out_off
+        return bytes(arr)
+
+    def bind(self, device):
+        """Return ``ctypes.byref(dctr_plan_t)`` valid for the tables' CURRENT device pointers."""
+        device = torch.device(device)
+        key = self._pointer_key(device)
+        if key == self._key:
+            return ctypes.byref(self.cplan)
+        for p in self._params:
+            L.require_gpu(p, "embedding table")
+            if not p.is_contiguous() or p.dtype != torch.float32:
+                raise RuntimeError("embedding tables must be contiguous float32")
+        if self.wide_dense_weight is not None:
+            L.require_gpu(self.wide_dense_weight, "Linear.weight")
+
+        def up(raw, dtype):
+            return torch.frombuffer(bytearray(raw), dtype=dtype).to(device)
+
+        import numpy as np
+        self._dev = {
+            "deep": up(self._field_bytes(self.deep), torch.uint8),
+            "wide": up(self._field_bytes(self.wide), torch.uint8),
+            "dense": up(np.asarray(self.dense_cols or [0], dtype=np.int32).tobytes(), torch.int32),
+            "wdense": up(np.asarray(self.wdense_cols or [0], dtype=np.int32).tobytes(), torch.int32),
+        }
+        c = self.cplan
+        c.deep = self._dev["deep"].data_ptr() if self.deep else None
+        c.wide = self._dev["wide"].data_ptr() if self.wide else None
+        c.dense_cols = self._dev["dense"].data_ptr()
+        c.wdense_cols = self._dev["wdense"].data_ptr()
+        w = self.wide_dense_weight
+        c.wdense_w = w.data_ptr() if w is not None else None
+        c.n_deep, c.n_deep_fixed = len(self.deep), self.n_deep_fixed
+        c.n_wide, c.n_wide_fixed = len(self.wide), self.n_wide_fixed
+        c.n_dense, c.n_wdense = len(self.dense_cols), (len(self.wdense_cols) if w is not None else 0)
+        c.dense_off, c.emb_dim, c.n_xcols = self.dense_off, self.emb_dim, self.n_xcols
+        c.max_dim, c.vec = self.max_dim, self.vec
+        flags = 0
+        if self._params and all(p in _GACC for p in self._params):
+            flags |= L.PLAN_HAS_GACC
+        if self._params and all(p in _STATE for p in self._params):
+            flags |= L.PLAN_HAS_STATE
+        if self.has_maxpool:
+            flags |= L.PLAN_HAS_MAXPOOL
+        c.flags = flags
+        self._key = key
+        self.version += 1
+        if self.anchor is None or self.anchor.device != device:
+            # a leaf that requires grad: makes autograd call EmbedFunction.backward even when no
+            # differentiable tensor enters the lookup (tables are updated in place, not via autograd)
+            self.anchor = torch.zeros(1, device=device, requires_grad=True)
+        return ctypes.byref(self.cplan)
+
+    @property
+    def has_lookup(self):
+        return bool(self.deep or self.dense_cols)
+
+    @property
+    def has_wide(self):
+        return bool(self.wide or (self.wdense_cols and self.wide_dense_weight is not None))
+
+
+__all__ = ["EmbeddingPlan", "DenseFeat", "SparseFeat", "VarLenSparseFeat"]

@@ -1,0 +1,6 @@
+"""Drop-in model classes of the MI355X hot path.  Constructor signatures
+and ``state_dict`` keys are the reference's (``deepctr_torch/models/*.py``)."""
+from .basemodel import BaseModel, Linear
+from .deepfm import DeepFM
+
+__all__ = ["BaseModel", "Linear", "DeepFM"]

@@ -1,0 +1,468 @@
+# -*- coding: utf-8 -*-
+"""``Linear`` + ``BaseModel``: the Keras-style surface of the reference (models/basemodel.py:34-527)
+over the MI355X hot path.
+
+Kept verbatim: constructor / ``compile`` / ``fit`` / ``evaluate`` / ``predict`` signatures, attribute
+names touched by callbacks and tests (``embedding_dict``, ``linear_model``, ``feature_index``,
+``history``, ``stop_training``, ``regularization_weight`` ...) and every ``state_dict`` key.
+
+Re-designed underneath:
+  * lookups, pooling, the wide logit and FM run as ONE gfx950 kernel per direction (``_hip.ops.embed``);
+  * the embedding backward is an O(batch) scatter; with ``compile('sgd'|'adagrad')`` and
+    ``l2_reg_embedding = l2_reg_linear = 0`` the optimizer update of the touched rows is fused into it
+    (identical result to the reference's dense update, because rows with zero gradient do not move under
+    those optimizers); every other optimizer / regulariser gets the exact dense gradient in ``param.grad``;
+  * ``fit`` keeps the whole dataset resident in HBM (a 45 M-row Criteo day is 7 GB of 288), batches are
+    index-selected on the device, the loss is accumulated on the device and read back once per epoch.
+"""
+from __future__ import print_function
+
+import os
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from sklearn.metrics import accuracy_score, log_loss, mean_squared_error, roc_auc_score
+
+try:  # tqdm is optional: only the verbose=1 progress bar needs it
+    from tqdm import tqdm
+except ImportError:  # pragma: no cover
+    tqdm = None
+
+from .. import callbacks as _cb
+from .._hip import ops as _ops
+from .._hip.plan import EmbeddingPlan
+from ..inputs import (DenseFeat, SparseFeat, VarLenSparseFeat, build_input_features, create_embedding_matrix,
+                      split_columns)
+from ..layers import PredictionLayer
+from ..layers.utils import slice_arrays
+
+
+class Linear(nn.Module):
+    """First-order ("wide") logit: sum of 1-dim embeddings (+ pooled VarLen) + dense . weight
+    (reference basemodel.py:34-92).  Computed by the gather kernel's wide path."""
+
+    def __init__(self, feature_columns, feature_index, init_std=0.0001, device='cpu'):
+        super(Linear, self).__init__()
+        self.feature_index = feature_index
+        self.device = device
+        self.sparse_feature_columns, self.varlen_sparse_feature_columns, self.dense_feature_columns = \
+            split_columns(feature_columns)
+        self._columns = list(feature_columns)
+        self.embedding_dict = create_embedding_matrix(feature_columns, init_std, linear=True, sparse=False,
+                                                      device=device)
+        # the reference initialises these tables a second time (basemodel.py:55-56); doing the same keeps
+        # same-seed initial weights identical to the reference's
+        for tensor in self.embedding_dict.values():
+            nn.init.normal_(tensor.weight, mean=0, std=init_std)
+        if len(self.dense_feature_columns) > 0:
+            self.weight = nn.Parameter(
+                torch.Tensor(sum(fc.dimension for fc in self.dense_feature_columns), 1).to(device))
+            torch.nn.init.normal_(self.weight, mean=0, std=init_std)
+        self._plan = None
+
+    def plan(self):
+        if self._plan is None:
+            self._plan = EmbeddingPlan(self.feature_index, wide_columns=self._columns,
+                                       wide_tables=self.embedding_dict,
+                                       wide_dense_weight=getattr(self, "weight", None))
+            owner = getattr(self.embedding_dict, "_dctr_owner_plan", None)
+            if owner is not None:
+                self._plan.share_update_with(owner)
+        return self._plan
+
+    def forward(self, X, sparse_feat_refine_weight=None):
+        if sparse_feat_refine_weight is not None:
+            raise NotImplementedError("sparse_feat_refine_weight (IFM / DIFM) is outside the MI355X hot path "
+                                      "(SURVEY.md 2.1 #11)")
+        plan = self.plan()
+        if not plan.has_wide:
+            return torch.zeros([X.shape[0], 1], device=X.device)
+        _, wide, _ = _ops.embed(plan, X)
+        return wide.unsqueeze(1)
+
+
+class BaseModel(nn.Module):
+    def __init__(self, linear_feature_columns, dnn_feature_columns, l2_reg_linear=1e-5, l2_reg_embedding=1e-5,
+                 init_std=0.0001, seed=1024, task='binary', device='cpu', gpus=None):
+        super(BaseModel, self).__init__()
+        torch.manual_seed(seed)
+        self.dnn_feature_columns = dnn_feature_columns
+        self.reg_loss = torch.zeros((1,), device=device)
+        self.aux_loss = torch.zeros((1,), device=device)
+        self.device = device
+        self.gpus = gpus
+        if gpus and str(self.gpus[0]) not in self.device:
+            raise ValueError("`gpus[0]` should be the same gpu with `device`")
+
+        self.feature_index = build_input_features(linear_feature_columns + dnn_feature_columns)
+        self._linear_feature_columns = list(linear_feature_columns)
+        self.embedding_dict = create_embedding_matrix(dnn_feature_columns, init_std, sparse=False, device=device)
+        self.linear_model = Linear(linear_feature_columns, self.feature_index, device=device)
+
+        self.regularization_weight = []
+        self._n_embedding_reg_groups = 2
+        self.add_regularization_weight(self.embedding_dict.parameters(), l2=l2_reg_embedding)
+        self.add_regularization_weight(self.linear_model.parameters(), l2=l2_reg_linear)
+
+        self.out = PredictionLayer(task, )
+        self.to(device)
+
+        self._is_graph_network = True   # attributes Keras-style callbacks look for
+        self._ckpt_saved_epoch = False
+        self.history = _cb.History()
+        self.stop_training = False
+        self._plan = None
+
+    # ------------------------------------------------------------------------------------------------
+    # hot path entry points
+    # ------------------------------------------------------------------------------------------------
+    def model_plan(self):
+        """The model-wide compiled schema: deep side = ``dnn_feature_columns`` over ``embedding_dict``,
+        wide side = ``linear_feature_columns`` over ``linear_model.embedding_dict``."""
+        if self._plan is None:
+            lm = self.linear_model
+            self._plan = EmbeddingPlan(self.feature_index, deep_columns=self.dnn_feature_columns,
+                                       deep_tables=self.embedding_dict,
+                                       wide_columns=self._linear_feature_columns, wide_tables=lm.embedding_dict,
+                                       wide_dense_weight=getattr(lm, "weight", None))
+            object.__setattr__(self.embedding_dict, "_dctr_owner_plan", self._plan)
+            object.__setattr__(lm.embedding_dict, "_dctr_owner_plan", self._plan)
+            if lm._plan is not None:
+                lm._plan.share_update_with(self._plan)
+            self._apply_update_mode()
+        return self._plan
+
+    def fused_inputs(self, X, want_fm=False):
+        """One kernel launch -> (dnn_input ``[B, sum(D)+n_dense]``, linear logit ``[B, 1]``, FM ``[B, 1]``).
+
+        ``dnn_input`` is exactly ``combined_dnn_input(*input_from_feature_columns(...))`` of the reference
+        (its first ``sum(D)`` columns viewed ``[B, F, D]`` are the ``torch.cat(sparse_embedding_list, 1)``
+        every interaction layer consumes), the logit is ``self.linear_model(X)``, and FM is
+        ``FM()(that view)`` (deepfm.py:69-82)."""
+        plan = self.model_plan()
+        out, wide, fm = _ops.embed(plan, X, want_fm=want_fm)
+        return out, wide.unsqueeze(1), fm.unsqueeze(1)
+
+    def input_from_feature_columns(self, X, feature_columns, embedding_dict, support_dense=True):
+        """Reference-shaped accessor (basemodel.py:354-380): list of ``[B, 1, D]`` embeddings (fixed-length
+        features, then pooled VarLen features) and list of dense ``[B, dim]`` slices of X."""
+        sparse_cols, varlen_cols, dense_cols = split_columns(feature_columns)
+        if not support_dense and len(dense_cols) > 0:
+            raise ValueError("DenseFeat is not supported in dnn_feature_columns")
+        emb_cols = sparse_cols + varlen_cols
+        emb_list = _ops.gather_columns(X, embedding_dict, self.feature_index, emb_cols, pooled=True) \
+            if emb_cols else []
+        dense_value_list = [X[:, self.feature_index[fc.name][0]:self.feature_index[fc.name][1]] for fc in dense_cols]
+        return emb_list, dense_value_list
+
+    def compute_input_dim(self, feature_columns, include_sparse=True, include_dense=True, feature_group=False):
+        sparse_cols, varlen_cols, dense_cols = split_columns(feature_columns)
+        emb_cols = [c for c in feature_columns if isinstance(c, (SparseFeat, VarLenSparseFeat))] \
+            if len(feature_columns) else []
+        dense_dim = sum(c.dimension for c in dense_cols)
+        sparse_dim = len(emb_cols) if feature_group else sum(c.embedding_dim for c in emb_cols)
+        return (sparse_dim if include_sparse else 0) + (dense_dim if include_dense else 0)
+
+    @property
+    def embedding_size(self):
+        dims = set(c.embedding_dim for c in self.dnn_feature_columns
+                   if isinstance(c, (SparseFeat, VarLenSparseFeat))) if len(self.dnn_feature_columns) else set()
+        if len(dims) > 1:
+            raise ValueError("embedding_dim of SparseFeat and VarlenSparseFeat must be same in this model!")
+        return list(dims)[0]
+
+    # ------------------------------------------------------------------------------------------------
+    # regularisation / auxiliary loss (reference basemodel.py:402-431)
+    # ------------------------------------------------------------------------------------------------
+    def add_regularization_weight(self, weight_list, l1=0.0, l2=0.0):
+        if isinstance(weight_list, torch.nn.parameter.Parameter):
+            weight_list = [weight_list]
+        else:  # generators / filters must become lists so the model stays picklable
+            weight_list = list(weight_list)
+        self.regularization_weight.append((weight_list, l1, l2))
+
+    def get_regularization_loss(self):
+        total = torch.zeros((1,), device=self.device)
+        for weight_list, l1, l2 in self.regularization_weight:
+            if not (l1 > 0 or l2 > 0):
+                continue
+            for w in weight_list:
+                p = w[1] if isinstance(w, tuple) else w  # named_parameters() yields (name, tensor)
+                if l1 > 0:
+                    total = total + torch.sum(l1 * torch.abs(p))
+                if l2 > 0:
+                    total = total + torch.sum(l2 * torch.square(p))
+        return total
+
+    def add_auxiliary_loss(self, aux_loss, alpha):
+        self.aux_loss = aux_loss * alpha
+
+    # ------------------------------------------------------------------------------------------------
+    # compile (reference basemodel.py:433-516)
+    # ------------------------------------------------------------------------------------------------
+    def compile(self, optimizer, loss=None, metrics=None):
+        self.metrics_names = ["loss"]
+        self.optim = self._get_optim(optimizer)
+        self.loss_func = self._get_loss_func(loss)
+        self.metrics = self._get_metrics(metrics)
+        self._apply_update_mode()
+
+    def _get_optim(self, optimizer):
+        if not isinstance(optimizer, str):
+            return optimizer
+        if optimizer == "sgd":
+            return torch.optim.SGD(self.parameters(), lr=0.01)
+        if optimizer == "adam":
+            return torch.optim.Adam(self.parameters())  # 0.001
+        if optimizer == "adagrad":
+            return torch.optim.Adagrad(self.parameters())  # 0.01
+        if optimizer == "rmsprop":
+            return torch.optim.RMSprop(self.parameters())
+        raise NotImplementedError
+
+    def _get_loss_func(self, loss):
+        if isinstance(loss, str):
+            return self._get_loss_func_single(loss)
+        if isinstance(loss, list):
+            return [self._get_loss_func_single(l) for l in loss]
+        return loss
+
+    def _get_loss_func_single(self, loss):
+        table = {"binary_crossentropy": F.binary_cross_entropy, "mse": F.mse_loss, "mae": F.l1_loss}
+        if loss not in table:
+            raise NotImplementedError
+        return table[loss]
+
+    def _log_loss(self, y_true, y_pred, eps=1e-7, normalize=True, sample_weight=None, labels=None):
+        y_pred = np.clip(np.asarray(y_pred, dtype=np.float64), eps, 1 - eps)
+        return log_loss(y_true, y_pred, normalize=normalize, sample_weight=sample_weight, labels=labels)
+
+    @staticmethod
+    def _accuracy_score(y_true, y_pred):
+        return accuracy_score(y_true, np.where(y_pred > 0.5, 1, 0))
+
+    def _get_metrics(self, metrics, set_eps=False):
+        chosen = {}
+        for metric in (metrics or []):
+            if metric in ("binary_crossentropy", "logloss"):
+                chosen[metric] = self._log_loss if set_eps else log_loss
+            if metric == "auc":
+                chosen[metric] = roc_auc_score
+            if metric == "mse":
+                chosen[metric] = mean_squared_error
+            if metric in ("accuracy", "acc"):
+                chosen[metric] = self._accuracy_score
+            self.metrics_names.append(metric)
+        return chosen
+
+    def _in_multi_worker_mode(self):
+        return None
+
+    # ------------------------------------------------------------------------------------------------
+    # which embedding update runs inside backward
+    # ------------------------------------------------------------------------------------------------
+    def _embedding_reg_active(self):
+        return any((l1 > 0 or l2 > 0) for (_, l1, l2) in self.regularization_weight[:self._n_embedding_reg_groups])
+
+    def _sparse_update_mode(self):
+        """("sgd", lr) / ("adagrad", lr, eps) when the fused O(batch) update is EXACTLY the reference's dense
+        update, otherwise ("dense",)."""
+        opt = getattr(self, "optim", None)
+        if opt is None or self._plan is None or os.environ.get("DCTR_SPARSE_UPDATE", "1") == "0":
+            return ("dense",), {}
+        tables = self._plan.table_params
+        if not tables or self._embedding_reg_active():
+            return ("dense",), {}
+        group_of = {}
+        for grp in opt.param_groups:
+            for p in grp["params"]:
+                group_of[id(p)] = grp
+        groups = [group_of.get(id(p)) for p in tables]
+        if any(g is None for g in groups):
+            return ("dense",), {}
+        g0 = groups[0]
+
+        def same(key):
+            return all(g.get(key) == g0.get(key) for g in groups)
+
+        if type(opt) is torch.optim.SGD:
+            ok = same("lr") and all(g.get("momentum", 0) == 0 and g.get("weight_decay", 0) == 0 and
+                                    not g.get("nesterov", False) and not g.get("maximize", False) for g in groups)
+            if ok:
+                return ("sgd", float(g0["lr"])), {}
+        if type(opt) is torch.optim.Adagrad:
+            ok = same("lr") and same("eps") and all(g.get("lr_decay", 0) == 0 and g.get("weight_decay", 0) == 0 and
+                                                    not g.get("maximize", False) for g in groups)
+            if ok and all("sum" in opt.state.get(p, {}) for p in tables):
+                return ("adagrad", float(g0["lr"]), float(g0["eps"])), {p: opt.state[p]["sum"] for p in tables}
+        return ("dense",), {}
+
+    def _apply_update_mode(self):
+        if self._plan is None:
+            return
+        mode, state = self._sparse_update_mode()
+        self._plan.set_state(state)
+        if mode[0] != "sgd" or self._plan.has_maxpool:
+            self._plan.ensure_gacc()
+        self._plan.update = mode
+
+    # ------------------------------------------------------------------------------------------------
+    # data plumbing shared by fit / evaluate / predict
+    # ------------------------------------------------------------------------------------------------
+    def _as_matrix(self, x):
+        """dict / list of per-feature arrays -> one float32 ``[N, sum(widths)]`` matrix on ``self.device``
+        (reference basemodel.py:155-156,191-198: np.concatenate in ``feature_index`` order)."""
+        if isinstance(x, dict):
+            x = [x[feature] for feature in self.feature_index]
+        x = list(x)
+        for i in range(len(x)):
+            if len(x[i].shape) == 1:
+                x[i] = np.expand_dims(x[i], axis=1)
+        return torch.from_numpy(np.concatenate(x, axis=-1)).to(self.device).float()
+
+    def _train_step(self, xb, yb):
+        """forward -> loss(sum) + reg + aux -> backward (fused sparse update inside) -> dense optimizer step
+        (reference basemodel.py:242-262).  Returns device tensors; nothing is synchronised."""
+        y_pred = self(xb).squeeze()
+        self.optim.zero_grad()
+        if isinstance(self.loss_func, list):
+            assert len(self.loss_func) == self.num_tasks, \
+                "the length of `loss_func` should be equal with `self.num_tasks`"
+            loss = sum([self.loss_func[i](y_pred[:, i], yb[:, i], reduction='sum') for i in range(self.num_tasks)])
+        else:
+            loss = self.loss_func(y_pred, yb.squeeze(), reduction='sum')
+        total_loss = loss + self.get_regularization_loss() + self.aux_loss
+        total_loss.backward()
+        self.optim.step()
+        return loss.detach(), total_loss.detach(), y_pred.detach()
+
+    def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, initial_epoch=0, validation_split=0.,
+            validation_data=None, shuffle=True, callbacks=None):
+        """Same contract as the reference (basemodel.py:137-309); returns ``self.history``."""
+        if isinstance(x, dict):
+            x = [x[feature] for feature in self.feature_index]
+        do_validation = False
+        val_x, val_y = [], []
+        if validation_data:
+            do_validation = True
+            if len(validation_data) == 2:
+                val_x, val_y = validation_data
+            elif len(validation_data) == 3:
+                val_x, val_y, _ = validation_data
+            else:
+                raise ValueError('When passing a `validation_data` argument, it must contain either 2 items '
+                                 '(x_val, y_val), or 3 items (x_val, y_val, val_sample_weights). '
+                                 'However we received `validation_data=%s`' % (validation_data,))
+            if isinstance(val_x, dict):
+                val_x = [val_x[feature] for feature in self.feature_index]
+        elif validation_split and 0. < validation_split < 1.:
+            do_validation = True
+            n0 = x[0].shape[0] if hasattr(x[0], 'shape') else len(x[0])
+            split_at = int(n0 * (1. - validation_split))
+            x, val_x = slice_arrays(x, 0, split_at), slice_arrays(x, split_at)
+            y, val_y = slice_arrays(y, 0, split_at), slice_arrays(y, split_at)
+
+        X_all = self._as_matrix(x)                                   # resident in HBM for the whole fit
+        y_all = torch.from_numpy(np.asarray(y)).to(self.device).float()
+        if batch_size is None:
+            batch_size = 256
+        self.train()
+        if self.gpus:
+            print('parallel running on these gpus:', self.gpus,
+                  '-- nn.DataParallel is not used; launch one process per GPU (see deepctr_torch.parallel)')
+        else:
+            print(self.device)
+        sample_num = X_all.shape[0]
+        steps_per_epoch = (sample_num - 1) // batch_size + 1
+
+        cbs = _cb.CallbackList((callbacks or []) + [self.history])
+        cbs.set_model(self)
+        cbs.on_train_begin()
+        cbs.set_model(self)
+        self.stop_training = False
+
+        print("Train on {0} samples, validate on {1} samples, {2} steps per epoch".format(
+            sample_num, len(val_y), steps_per_epoch))
+        plan = self.model_plan()
+        for epoch in range(initial_epoch, epochs):
+            cbs.on_epoch_begin(epoch)
+            epoch_logs = {}
+            start_time = time.time()
+            if shuffle:
+                # the permutation torch's RandomSampler would draw (DataLoader(shuffle=True), reference :213)
+                seed = int(torch.empty((), dtype=torch.int64).random_().item())
+                gen = torch.Generator()
+                gen.manual_seed(seed)
+                order = torch.randperm(sample_num, generator=gen).to(self.device)
+            else:
+                order = None
+            loss_acc = torch.zeros((), device=self.device, dtype=torch.float64)
+            total_acc = torch.zeros((), device=self.device, dtype=torch.float64)
+            preds = [] if (verbose > 0 and self.metrics) else None
+            bar = tqdm(total=steps_per_epoch, disable=verbose != 1) if tqdm is not None else None
+            try:
+                for step in range(steps_per_epoch):
+                    lo, hi = step * batch_size, min((step + 1) * batch_size, sample_num)
+                    if order is not None:
+                        idx = order[lo:hi]
+                        xb, yb = X_all.index_select(0, idx), y_all.index_select(0, idx)
+                    else:
+                        xb, yb = X_all[lo:hi], y_all[lo:hi]
+                    loss, total_loss, y_pred = self._train_step(xb, yb)
+                    loss_acc += loss.double()
+                    total_acc += total_loss.double().sum()
+                    if preds is not None:
+                        preds.append((yb, y_pred))
+                    if bar is not None:
+                        bar.update(1)
+            finally:
+                if bar is not None:
+                    bar.close()
+            plan.check_ids()
+            epoch_logs["loss"] = float(total_acc.item()) / sample_num
+            if preds is not None:
+                # reference: metric of every batch, averaged over steps (basemodel.py:264-269,280)
+                per_batch = {name: [] for name in self.metrics}
+                for yb, y_pred in preds:
+                    yt, yp = yb.cpu().numpy(), y_pred.cpu().numpy().astype("float64")
+                    for name, fun in self.metrics.items():
+                        per_batch[name].append(fun(yt, yp))
+                for name, vals in per_batch.items():
+                    epoch_logs[name] = np.sum(vals) / steps_per_epoch
+            if do_validation:
+                for name, result in self.evaluate(val_x, val_y, batch_size).items():
+                    epoch_logs["val_" + name] = result
+            if verbose > 0:
+                epoch_time = int(time.time() - start_time)
+                print('Epoch {0}/{1}'.format(epoch + 1, epochs))
+                eval_str = "{0}s - loss: {1: .4f}".format(epoch_time, epoch_logs["loss"])
+                for name in self.metrics:
+                    eval_str += " - " + name + ": {0: .4f}".format(epoch_logs[name])
+                if do_validation:
+                    for name in self.metrics:
+                        eval_str += " - " + "val_" + name + ": {0: .4f}".format(epoch_logs["val_" + name])
+                print(eval_str)
+            cbs.on_epoch_end(epoch, epoch_logs)
+            if self.stop_training:
+                break
+        cbs.on_train_end()
+        return self.history
+
+    def evaluate(self, x, y, batch_size=256):
+        pred_ans = self.predict(x, batch_size)
+        return {name: fun(y, pred_ans) for name, fun in self.metrics.items()}
+
+    def predict(self, x, batch_size=256):
+        """float64 ``[N, 1]`` predictions, input order preserved (reference basemodel.py:325-352)."""
+        self.eval()  # like the reference (:331), predict leaves the model in eval mode
+        X_all = self._as_matrix(x)
+        chunks = []
+        with torch.no_grad():
+            for lo in range(0, X_all.shape[0], batch_size):
+                chunks.append(self(X_all[lo:lo + batch_size]))
+        if self._plan is not None:
+            self._plan.check_ids()
+        return torch.cat(chunks).cpu().numpy().astype("float64")

@@ -1,0 +1,148 @@
+/*
+ * dctr.h -- C-ABI of libdctr_hip.so: the MI355X (gfx950) hot path of DeepCTR-Torch.
+ *
+ * The reference (shenweichen/DeepCTR-Torch v0.2.9) has no native seam: every op on this path is a
+ * chain of ATen calls issued from Python.  This header is the seam a maintainer would bind instead
+ * (ctypes stub in INTEGRATION.md).  Each entry point names the reference lines it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (a PyTorch tensor) unless stated
+ *     otherwise; the library never allocates, frees or retains memory.
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued, never synchronised, so every
+ *     call is hipGraph-capturable.
+ *   - return value: 0 ok, <0 a DCTR_E* code (bad argument; nothing was launched), >0 the hipError_t
+ *     of the failed launch.  Nothing throws.
+ *   - all arithmetic is fp32 (the reference computes in fp32).
+ *   - ids travel as float32 inside X exactly as in the reference (basemodel.py:242) and are
+ *     truncated toward zero like Tensor.long() (basemodel.py:369).
+ */
+#ifndef DCTR_H
+#define DCTR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCTR_ABI_VERSION 1
+
+#define DCTR_OK 0
+#define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
+#define DCTR_ENOSUP (-2) /* shape outside what the kernels are built for        */
+#define DCTR_EALIGN (-3) /* pointer or leading dimension violates an alignment  */
+
+typedef void* dctr_stream_t; /* hipStream_t */
+
+/* pooling of a VarLenSparseFeat (inputs.py:41-46, sequence.py:49-77); 0 = plain SparseFeat */
+#define DCTR_POOL_NONE 0
+#define DCTR_POOL_SUM 1
+#define DCTR_POOL_MEAN 2
+#define DCTR_POOL_MAX 3
+
+/* One embedding "field": a SparseFeat / VarLenSparseFeat bound to its table.  64 bytes.
+ * A deep field gathers dim-wide rows (inputs.py:158-180, basemodel.py:368-375); a wide field is the
+ * same thing with dim == 1 (Linear's 1-dim tables, basemodel.py:45-46,65-67).                      */
+typedef struct dctr_field {
+  float* table;    /* [vocab, dim] row-major, embedding_dict[embedding_name].weight                 */
+  float* gacc;     /* [vocab, dim] gradient slab, zero at rest (may be NULL when never accumulated)  */
+  float* state;    /* [vocab, dim] optimizer state (Adagrad sum) or NULL                             */
+  int64_t vocab;   /* rows                                                                           */
+  int32_t dim;     /* embedding_dim (1 for wide)                                                     */
+  int32_t col;     /* first column of X holding the id(s)        (inputs.py:99-123)                  */
+  int32_t len;     /* 1 for SparseFeat, maxlen for VarLenSparseFeat                                  */
+  int32_t pool;    /* DCTR_POOL_*                                                                    */
+  int32_t len_col; /* column of X holding the valid length, or -1: mask = (id != 0) (inputs.py:146)  */
+  int32_t out_off; /* float offset of this field's slice inside one output row (deep only)          */
+  int32_t pad_[2];
+} dctr_field_t;
+
+/* The compiled feature-column schema of one model: what build_input_features + create_embedding_matrix
+ * + Linear.__init__ establish in the reference (inputs.py:99-180, basemodel.py:34-61).
+ * The struct itself lives in HOST memory; the arrays it points to live on the device.              */
+typedef struct dctr_plan {
+  const dctr_field_t* deep;   /* [n_deep] fixed-length fields first, then VarLen (basemodel.py:380)  */
+  const dctr_field_t* wide;   /* [n_wide]                                                            */
+  const int32_t* dense_cols;  /* [n_dense]  X column of every dense scalar of dnn_feature_columns    */
+  const int32_t* wdense_cols; /* [n_wdense] X column of every dense scalar of linear_feature_columns */
+  const float* wdense_w;      /* [n_wdense] Linear.weight (basemodel.py:58-61), may be NULL          */
+  int32_t n_deep;
+  int32_t n_deep_fixed;       /* leading deep fields with len == 1                                   */
+  int32_t n_wide;
+  int32_t n_dense;
+  int32_t n_wdense;
+  int32_t dense_off;          /* float offset in an output row where the dense block goes, -1: skip  */
+  int32_t emb_dim;            /* common dim of all deep fields, 0 if they differ (then no FM)        */
+  int32_t n_xcols;            /* number of columns of X (width of the staged tile)                   */
+  int32_t n_wide_fixed;       /* leading wide fields with len == 1                                   */
+  int32_t max_dim;            /* max dim over deep fields (0 if none)                                */
+  int32_t vec;                /* 4, 2 or 1: every deep dim, out_off, ld and base pointer is a        */
+                              /* multiple of `vec` floats -- lets rows move as dwordx4/x2            */
+  int32_t flags;              /* DCTR_PLAN_* : facts about the device arrays the host cannot see     */
+} dctr_plan_t;
+
+#define DCTR_PLAN_HAS_GACC 1    /* every field has a gacc slab                       */
+#define DCTR_PLAN_HAS_STATE 2   /* every field has an optimizer state slab           */
+#define DCTR_PLAN_HAS_MAXPOOL 4 /* some VarLen field uses DCTR_POOL_MAX              */
+
+int dctr_abi_version(void);
+const char* dctr_strerror(int code);
+size_t dctr_sizeof_field(void); /* binding self-check */
+size_t dctr_sizeof_plan(void);
+
+/* ---- fused multi-table lookup (+VarLen pooling, +wide logit, +FM, +DNN-input layout) -------------
+ * Replaces, in ONE launch: BaseModel.input_from_feature_columns (basemodel.py:354-380),
+ * varlen_embedding_lookup + get_varlen_pooling_list + SequencePoolingLayer (inputs.py:141-155,213-227,
+ * sequence.py:49-77), Linear.forward (basemodel.py:63-92), FM.forward (interaction.py:26-34) and
+ * combined_dnn_input (inputs.py:126-138).
+ *   X     [B, ldx]   the model input matrix (ids as float32)
+ *   out   [B, ld_out] row b = [ deep field slices at field.out_off | dense block at plan.dense_off ]
+ *   wide  [B]  sum_f w_f[id] (+pooled VarLen) + dense . Linear.weight     (nullable)
+ *   fm    [B]  0.5 * sum_d ((sum_f e)^2 - sum_f e^2) over ALL deep fields (nullable; needs emb_dim)
+ *   err   int32 flag; bit0 is set when an id falls outside [0, vocab) -- such a row reads as row 0
+ *         (the reference raises IndexError on CPU; here the flag is polled by the host) (nullable)  */
+int dctr_embed_fwd(const dctr_plan_t* plan, const float* X, int64_t ldx, int32_t B, float* out,
+                   int64_t ld_out, float* wide, float* fm, int32_t* err, dctr_stream_t stream);
+
+/* ---- backward of the above = embedding_dense_backward + FM backward, as an O(batch) scatter -------
+ * Replaces autograd's aten::embedding_dense_backward x(n_deep+n_wide), the pooling backward and
+ * FM's backward (called from basemodel.py:261).  Duplicate ids add (atomics).
+ *   g_out  [B, ld_g]  gradient w.r.t. `out` (deep slices are read; dense block ignored)  (nullable)
+ *   out    [B, ld_out] the forward output (read only when g_fm != NULL: FM backward needs e and sum e)
+ *   g_fm   [B]  gradient w.r.t. fm          (nullable)
+ *   g_wide [B]  gradient w.r.t. wide        (nullable)
+ *   mode   DCTR_BWD_ACCUM: field.gacc[row] += g          (exact dense-gradient semantics, or pass 1
+ *                          of a two-pass sparse optimizer)
+ *          DCTR_BWD_SGD  : field.table[row] -= lr * g    (torch.optim.SGD(lr), basemodel.py:449-450;
+ *                          only legal without max-pooled fields, whose backward re-reads the table) */
+#define DCTR_BWD_ACCUM 0
+#define DCTR_BWD_SGD 1
+int dctr_embed_bwd(const dctr_plan_t* plan, const float* X, int64_t ldx, int32_t B,
+                   const float* g_out, int64_t ld_g, const float* out, int64_t ld_out,
+                   const float* g_fm, const float* g_wide, int32_t mode, float lr,
+                   dctr_stream_t stream);
+
+/* ---- pass 2 of the sparse optimizers: consume + re-zero gacc rows touched by this batch -----------
+ * For every id occurrence in X: G = exchange(gacc[row], 0); then per element with G != 0
+ *   DCTR_OPT_SGD     p -= lr * G                                   (torch.optim.SGD, basemodel.py:450)
+ *   DCTR_OPT_ADAGRAD s += G*G ; p -= lr * G / (sqrt(s) + eps)      (torch.optim.Adagrad, :454)
+ * Rows whose gradient is zero do not move under these two optimizers, so the result equals the
+ * reference's dense update.                                                      */
+#define DCTR_OPT_SGD 0
+#define DCTR_OPT_ADAGRAD 1
+int dctr_embed_apply(const dctr_plan_t* plan, const float* X, int64_t ldx, int32_t B, int32_t opt,
+                     float lr, float eps, dctr_stream_t stream);
+
+/* ---- FM on an explicit [B, F, D] tensor (interaction.py:26-34) ------------------------------------
+ * E is addressed as E[b*ld_b + f*D + d].  y[b] = 0.5 * sum_d((sum_f e)^2 - sum_f e^2).
+ * backward: gE[b,f,d] (+)= gy[b] * (S[b,d] - E[b,f,d]);  accumulate != 0 adds into gE.             */
+int dctr_fm_fwd(const float* E, int64_t ld_b, int32_t B, int32_t F, int32_t D, float* y,
+                dctr_stream_t stream);
+int dctr_fm_bwd(const float* E, int64_t ld_b, int32_t B, int32_t F, int32_t D, const float* gy,
+                float* gE, int64_t ld_gb, int32_t accumulate, dctr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCTR_H */

@@ -1,0 +1,62 @@
+"""Pin the numpy oracle (oracle/np_oracle.py) to the fixtures produced by the real reference.
+
+CPU only.  Forward: logits / predictions / loss; backward: the gradient of EVERY parameter (dense [V, D]
+embedding gradients included); trajectories: 3 reference training steps under SGD and Adagrad."""
+import numpy as np
+import pytest
+
+from helpers import golden_names, load_golden, max_abs
+from np_oracle import Oracle, bce_sum
+
+LOGIT_TOL = 1e-5   # north_star: logits within 1e-5 of the reference's fp32-CPU logits
+GRAD_TOL = 2e-5    # fp32 re-association noise on sums over the batch
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_forward_matches_reference(name):
+    g = load_golden(name)
+    o = Oracle(g["spec"], g["params"])
+    logit, y_pred = o.forward(g["X"])
+    assert max_abs(logit, g["logit"]) <= LOGIT_TOL
+    assert max_abs(y_pred, g["y_pred"]) <= LOGIT_TOL
+    loss = bce_sum(y_pred.astype(np.float64), g["y"].reshape(-1, 1).astype(np.float64))
+    assert abs(loss - g["loss"]) <= 1e-4 * max(1.0, abs(g["loss"]))
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_backward_matches_reference(name):
+    g = load_golden(name)
+    # fp64: numpy's fp32 einsum accumulates naively and is noisier than the reference itself (whose fp32
+    # gradients sit within ~3e-6 relative of this fp64 evaluation)
+    o = Oracle(g["spec"], g["params"], dtype=np.float64)
+    _, y_pred = o.forward(g["X"])
+    grads = o.backward(y_pred - g["y"].reshape(-1, 1))       # d BCE(sum) / d logit
+    assert set(g["grads"]) <= set(grads) | {k for k, v in g["grads"].items() if not np.any(v)}
+    for k, ref in g["grads"].items():
+        got = np.asarray(grads.get(k, np.zeros_like(ref))).reshape(ref.shape)
+        scale = max(1.0, float(np.max(np.abs(ref))))
+        assert max_abs(got, ref) <= GRAD_TOL * scale, k
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names("deepfm") if "X_steps" in load_golden(n)["extra"]])
+@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
+def test_training_trajectory_matches_reference(name, opt):
+    g = load_golden(name)
+    o = Oracle(g["spec"], g["params"])
+    state = None
+    losses = []
+    for Xb, yb in zip(g["extra"]["X_steps"], g["extra"]["y_steps"]):
+        loss, state = o.train_step(Xb, yb, optimizer=opt, lr=0.01, eps=1e-10, state=state)
+        losses.append(loss)
+    np.testing.assert_allclose(losses, g["extra"][opt + "3_loss"], rtol=2e-5)
+    for k, v in g["extra"].items():
+        if k.startswith(opt + "3/"):
+            key = k[len(opt) + 2:]
+            assert max_abs(o.P[key], v) <= 2e-5, key
+
+
+def test_fp64_oracle_brackets_fp32_noise():
+    """The fp32 reference is within ~1e-6 of an fp64 evaluation at |logit| ~ 4."""
+    g = load_golden("deepfm_criteo")
+    l64, _ = Oracle(g["spec"], g["params"], dtype=np.float64).forward(g["X"])
+    assert max_abs(l64, g["logit"]) <= 5e-6
