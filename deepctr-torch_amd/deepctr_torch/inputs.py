@@ -85,16 +85,16 @@ def build_input_features(feature_columns):
     layout = OrderedDict()
     cursor = 0
     for col in feature_columns:
+        if not isinstance(col, (SparseFeat, DenseFeat, VarLenSparseFeat)):
+            raise TypeError("Invalid feature column type,got", type(col))
         if col.name in layout:
             continue
         if isinstance(col, SparseFeat):
             width = 1
         elif isinstance(col, DenseFeat):
             width = col.dimension
-        elif isinstance(col, VarLenSparseFeat):
-            width = col.maxlen
         else:
-            raise TypeError("Invalid feature column type,got", type(col))
+            width = col.maxlen
         layout[col.name] = (cursor, cursor + width)
         cursor += width
         if isinstance(col, VarLenSparseFeat) and col.length_name is not None and col.length_name not in layout:

@@ -305,9 +305,9 @@ class BaseModel(nn.Module):
             return
         mode, state = self._sparse_update_mode()
         self._plan.set_state(state)
-        if mode[0] != "sgd" or self._plan.has_maxpool:
-            self._plan.ensure_gacc()
-        self._plan.update = mode
+        if mode[0] == "adagrad" or (mode[0] == "sgd" and self._plan.has_maxpool):
+            self._plan.ensure_gacc()   # two-pass updates: allocate the slabs now (outside any graph capture)
+        self._plan.update = mode       # ("dense",) allocates its slabs lazily at the first backward
 
     # ------------------------------------------------------------------------------------------------
     # data plumbing shared by fit / evaluate / predict

@@ -1,0 +1,60 @@
+"""CPU: the C-ABI library builds, loads, and exports exactly what include/dctr.h declares."""
+import ctypes
+import os
+import re
+
+from helpers import GOLDEN_DIR  # noqa: F401  (path setup via conftest)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "dctr.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dctr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_hot_path():
+    names = declared_functions()
+    for must in ("dctr_embed_fwd", "dctr_embed_bwd", "dctr_embed_apply", "dctr_fm_fwd", "dctr_fm_bwd"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from deepctr_torch._hip import lib as L
+    assert L.available(), "run __graft_entry__.build() first"
+    handle = ctypes.CDLL(L.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(handle, name), "libdctr_hip.so lacks %s declared in include/dctr.h" % name
+
+
+def test_binding_matches_header():
+    from deepctr_torch._hip import lib as L
+    assert sorted(L.SIGNATURES) == declared_functions()
+    lib = L.lib()  # loads, checks ABI version and struct sizes; no compute call
+    assert lib.dctr_abi_version() == L.ABI_VERSION
+    assert lib.dctr_sizeof_field() == ctypes.sizeof(L.Field) == 64
+    assert lib.dctr_sizeof_plan() == ctypes.sizeof(L.Plan)
+    assert b"invalid" in lib.dctr_strerror(-1)
+
+
+def test_product_path_has_no_cpu_fallback():
+    """A CPU tensor must raise, never silently compute."""
+    import pytest
+    import torch
+    from deepctr_torch.inputs import SparseFeat
+    from deepctr_torch.models import DeepFM
+    cols = [SparseFeat("a", 5, 4), SparseFeat("b", 6, 4)]
+    m = DeepFM(cols, cols, dnn_hidden_units=(4,), device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(2, 2))
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "deepctr-torch_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "np_oracle" not in text and "import oracle" not in text and "from oracle" not in text, f

@@ -1,0 +1,93 @@
+"""CPU: feature-column API, X layout, plan compilation, state_dict keys, update-mode selection, pickling."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_model, feature_columns, golden_names, load_golden
+from np_oracle import build_input_features as oracle_layout
+
+
+def test_feature_column_api():
+    from deepctr_torch.inputs import (DenseFeat, SparseFeat, VarLenSparseFeat, build_input_features,
+                                      get_feature_names)
+    s = SparseFeat("c", 100, "auto")
+    assert s.embedding_dim == 6 * int(pow(100, 0.25)) and s.embedding_name == "c" and s.group_name == "default_group"
+    assert SparseFeat("c", 3) == SparseFeat("c", 3) and hash(SparseFeat("c", 3)) == hash("c")
+    v = VarLenSparseFeat(SparseFeat("h", 10, 8, embedding_name="item"), maxlen=4, combiner="sum", length_name="hl")
+    assert (v.name, v.vocabulary_size, v.embedding_dim, v.embedding_name, v.maxlen) == ("h", 10, 8, "item", 4)
+    d = DenseFeat("p", 3)
+    cols = [s, d, v, SparseFeat("c", 100, 8)]                     # duplicate name: first wins
+    assert build_input_features(cols) == {"c": (0, 1), "p": (1, 4), "h": (4, 8), "hl": (8, 9)}
+    assert get_feature_names(cols) == ["c", "p", "h", "hl"]
+    with pytest.raises(TypeError):
+        build_input_features([object()])
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_layout_and_state_dict_keys_match_reference(name):
+    g = load_golden(name)
+    spec = g["spec"]
+    model = build_model(spec, "cpu")
+    assert dict(model.feature_index) == dict(oracle_layout(spec["linear_columns"] + spec["dnn_columns"]))
+    sd = model.state_dict()
+    assert sorted(sd.keys()) == sorted(g["params"].keys())
+    for k, v in g["params"].items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in g["params"].items()})
+
+
+def test_plan_layout_is_combined_dnn_input_order():
+    g = load_golden("deepfm_mixed")
+    model = build_model(g["spec"], "cpu")
+    plan = model.model_plan()
+    names = [f.name for f in plan.deep]
+    assert names == ["user", "item", "cate", "hist_sum", "tags_mean", "kw_max", "seq_len_mean"]
+    assert [f.out_off for f in plan.deep] == [0, 4, 8, 12, 16, 20, 24]
+    assert plan.n_deep_fixed == 3 and plan.emb_dim == 4 and plan.vec == 4 and plan.has_maxpool
+    assert plan.dense_off == 28 and plan.width == 32 and plan.ld_out % 4 == 0
+    hist = plan.deep[3]
+    assert hist.param is model.embedding_dict["item"].weight and hist.pool == 1 and hist.len == 4
+    lenf = plan.deep[6]
+    assert lenf.len_col == model.feature_index["seq_len_mean_length"][0] and lenf.pool == 2
+    assert len(plan.table_params) == 6 + 6          # `item` is shared by two fields on both sides
+
+
+def test_update_mode_selection():
+    g = load_golden("deepfm_criteo")
+    m = build_model(g["spec"], "cpu", l2=0.0)
+    m.model_plan()
+    m.compile("sgd", "binary_crossentropy")
+    assert m._plan.update == ("sgd", 0.01)
+    m.compile("adagrad", "binary_crossentropy")
+    assert m._plan.update[0] == "adagrad" and m._plan.update[1:] == (0.01, 1e-10)
+    m.compile("adam", "binary_crossentropy")
+    assert m._plan.update == ("dense",)
+    m.compile(torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9), "binary_crossentropy")
+    assert m._plan.update == ("dense",)
+    m2 = build_model(g["spec"], "cpu", l2=1e-5)       # reference default: dense L2 gradient on every row
+    m2.model_plan()
+    m2.compile("adagrad", "binary_crossentropy")
+    assert m2._plan.update == ("dense",)
+
+
+def test_model_pickles_with_plan():
+    g = load_golden("deepfm_mixed")
+    m = build_model(g["spec"], "cpu")
+    m.model_plan()
+    m.compile("adagrad", "binary_crossentropy")
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    m2 = torch.load(io.BytesIO(buf.getvalue()), weights_only=False)
+    assert sorted(m2.state_dict()) == sorted(m.state_dict())
+    assert m2._plan.cplan.n_deep == 0 and m2._plan.width == m._plan.width   # device image re-baked lazily
+
+
+def test_fit_rejects_nothing_silently_on_cpu():
+    g = load_golden("deepfm_fm_only")
+    m = build_model(g["spec"], "cpu")
+    m.compile("sgd", "binary_crossentropy")
+    x = {c["name"]: g["X"][:, i] for i, c in enumerate(g["spec"]["dnn_columns"])}
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.fit(x, g["y"], batch_size=8, epochs=1, verbose=0)

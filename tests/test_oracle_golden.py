@@ -60,3 +60,24 @@ def test_fp64_oracle_brackets_fp32_noise():
     g = load_golden("deepfm_criteo")
     l64, _ = Oracle(g["spec"], g["params"], dtype=np.float64).forward(g["X"])
     assert max_abs(l64, g["logit"]) <= 5e-6
+
+
+def test_torch_port_matches_reference():
+    """The torch-CPU restatement used as bench.py's cpu_baseline reproduces the reference's logits and
+    3-step Adagrad trajectory on the Criteo-shaped fixture."""
+    import torch
+    from torch_port import DeepFMPort, make_optimizer, train_step
+    g = load_golden("deepfm_criteo")
+    cols = g["spec"]["dnn_columns"]
+    sparse = [c for c in cols if c["kind"] == "sparse"]
+    port = DeepFMPort(len(sparse), [c["vocab"] for c in sparse], sparse[0]["dim"],
+                      len(cols) - len(sparse), hidden=g["spec"]["kwargs"]["dnn_hidden_units"])
+    port.load_reference_state(g["params"], [c["name"] for c in sparse])
+    with torch.no_grad():
+        logit = port.logit(torch.from_numpy(g["X"]))
+    assert max_abs(logit.numpy(), g["logit"]) <= LOGIT_TOL
+    opt = make_optimizer(port, "adagrad")
+    losses = [train_step(port, opt, torch.from_numpy(Xb), torch.from_numpy(yb)).item()
+              for Xb, yb in zip(g["extra"]["X_steps"], g["extra"]["y_steps"])]
+    np.testing.assert_allclose(losses, g["extra"]["adagrad3_loss"], rtol=2e-5)
+    assert max_abs(port.emb[0].weight.detach().numpy(), g["extra"]["adagrad3/embedding_dict.C1.weight"]) <= 2e-5
