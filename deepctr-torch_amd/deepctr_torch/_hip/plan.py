@@ -204,8 +204,13 @@ class EmbeddingPlan(object):
                     slab.zero_()
                 p.grad = slab
             elif p.grad.data_ptr() != slab.data_ptr():
-                raise RuntimeError("embedding parameter .grad was replaced by a foreign tensor; "
-                                   "call optimizer.zero_grad() before backward")
+                # autograd got there first (e.g. the L2 term of get_regularization_loss deposited its dense
+                # gradient before the lookup's backward ran): adopt it -- O(V), but so was that gradient
+                if p.grad.shape != slab.shape or p.grad.is_sparse:
+                    raise RuntimeError("embedding parameter .grad was replaced by an incompatible tensor; "
+                                       "call optimizer.zero_grad() before backward")
+                slab.copy_(p.grad)
+                p.grad = slab
             slab._dctr_dirty = True
 
     def err_flag(self, device):

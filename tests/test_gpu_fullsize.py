@@ -65,7 +65,7 @@ def test_sparse_update_touches_only_batch_rows_and_matches_dense_torch(big, opt)
     E = torch.cat([E[:, :f], ref_t[ids[:, f]].unsqueeze(1), E[:, f + 1:]], dim=1)
     dnn_in = torch.cat([E.reshape(BATCH, -1), X[:, F_SPARSE:]], dim=1)
     fm_ref = 0.5 * (E.sum(1).pow(2) - E.pow(2).sum(1)).sum(1, keepdim=True)
-    wide_ref = wide.unsqueeze(1) - wbefore[ids[:, f]] + ref_w[ids[:, f]]
+    wide_ref = wide.reshape(BATCH, 1) - wbefore[ids[:, f]] + ref_w[ids[:, f]]
     logit = wide_ref + fm_ref + m.dnn_linear(m.dnn(dnn_in))
     loss_ref = torch.nn.functional.binary_cross_entropy(m.out(logit).squeeze(), y, reduction="sum")
     g_t, g_w = torch.autograd.grad(loss_ref, [ref_t, ref_w])
@@ -105,8 +105,8 @@ def test_sgd_round_trip(big):
     before = table.detach().clone()
     g_out = torch.randn(BATCH, plan.ld_out, device=DEV)
     g_wide = torch.randn(BATCH, device=DEV)
-    for lr in (0.5, -0.5):
+    for lr in (0.01, -0.01):
         L.check(lib.dctr_embed_bwd(plan.bind(X.device), _ptr(X), X.stride(0), BATCH, _ptr(g_out), plan.ld_out, None, 0,
                                    None, _ptr(g_wide), L.BWD_SGD, lr, L.stream_handle(X.device)))
     torch.cuda.synchronize()
-    assert (table.detach() - before).abs().max().item() <= 1e-5
+    assert (table.detach() - before).abs().max().item() <= 2e-6

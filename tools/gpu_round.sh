@@ -13,5 +13,5 @@ cat $OUT/bench.json
 ( timeout 600 python bench.py --steps 200 --warmup 20 --optimizer sgd --no-cpu-baseline ) > $OUT/bench_sgd.json 2> $OUT/bench_sgd.err
 ( timeout 600 python bench.py --steps 100 --warmup 10 --no-graph --no-cpu-baseline ) > $OUT/bench_eager.json 2> $OUT/bench_eager.err
 ( timeout 900 python tools/microbench.py ) > $OUT/microbench.json 2> $OUT/microbench.err; echo "microbench rc=$?" | tee -a $OUT/summary.log
-( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o deepfm -- python $OLDPWD/bench.py --steps 100 --warmup 10 --no-cpu-baseline ) > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?" | tee -a $OUT/summary.log
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o deepfm -- python $OLDPWD/bench.py --steps 100 --warmup 10 --no-cpu-baseline ) > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?" | tee -a $OUT/summary.log
 find $OUT/prof -name "*stats*" | head
