@@ -67,15 +67,16 @@ def synth(args, device, rank):
 
 
 def algorithmic_bytes(B, opt):
-    """Per-launch algorithmic HBM bytes of the three hand-written kernels."""
+    """Per-launch algorithmic HBM bytes of the hand-written kernels."""
     ld = (F_SPARSE * DIM + N_DENSE + 3) // 4 * 4
     x_row = (F_SPARSE + N_DENSE) * 4
     rows, wrows = F_SPARSE * DIM * 4, F_SPARSE * 4
-    fwd = B * (x_row + rows + wrows + ld * 4 + 8)
-    bwd = B * (x_row + 2 * ld * 4 + 8 + 2 * (rows + wrows))                    # g_out + saved out + RMW rows
-    n_state = 3 if opt == "adagrad" else 2                                     # gacc, (state,) param: read+write
-    apply_ = B * (x_row + 2 * n_state * (rows + wrows))
-    return {"embed_fwd": fwd, "embed_bwd": bwd, "embed_apply": apply_}
+    side = F_SPARSE * 4 + DIM * 4                                              # ids_t + fm_s side outputs
+    fwd = B * (x_row + rows + wrows + ld * 4 + 8 + side)
+    n_rw = 4 if opt == "adagrad" else 2                                        # table (+state): read + write
+    # ids_t + g_out + saved out + fm_s + g_fm + g_wide, then the row read-modify-writes
+    upd = B * (F_SPARSE * 4 + 2 * rows + DIM * 4 + 8 + n_rw * (rows + wrows))
+    return {"embed_fwd": fwd, "embed_update": upd}
 
 
 def time_hot_kernels(model, X, y, iters, opt):
@@ -84,32 +85,30 @@ def time_hot_kernels(model, X, y, iters, opt):
     from deepctr_torch._hip.ops import _ptr
     lib = L.lib()
     plan = model.model_plan()
-    plan.ensure_gacc()
     B = X.shape[0]
     dev = X.device
     out = torch.empty(B, plan.ld_out, device=dev)
     wide, fm = torch.empty(B, device=dev), torch.empty(B, device=dev)
     g_out = torch.randn(B, plan.ld_out, device=dev) * 1e-3
     g_fm, g_wide = torch.randn(B, device=dev) * 1e-3, torch.randn(B, device=dev) * 1e-3
+    ids_t = torch.empty(len(plan.units), B, dtype=torch.int32, device=dev)
+    fm_s = torch.empty(B, DIM, device=dev)
     cplan = plan.bind(dev)
+    assert plan.update_kernel_ok(B), "bench shape must take the deterministic update kernel"
     s = L.stream_handle(dev)
-    two_pass = plan.update[0] != "sgd"
     lr = float(plan.update[1])
     eps = float(plan.update[2]) if opt == "adagrad" else 0.0
 
     def fwd():
         L.check(lib.dctr_embed_fwd(cplan, _ptr(X), X.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), _ptr(fm),
-                                   None, s))
+                                   None, plan.units_ptr(), len(plan.units), _ptr(ids_t), _ptr(fm_s), DIM, s))
 
-    def bwd():
-        L.check(lib.dctr_embed_bwd(cplan, _ptr(X), X.stride(0), B, _ptr(g_out), plan.ld_out, _ptr(out), plan.ld_out,
-                                   _ptr(g_fm), _ptr(g_wide), L.BWD_ACCUM if two_pass else L.BWD_SGD, lr, s))
+    def upd():
+        L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t), B,
+                                      _ptr(g_out), plan.ld_out, _ptr(out), plan.ld_out, _ptr(fm_s), DIM, _ptr(g_fm),
+                                      _ptr(g_wide), L.UPD_ADAGRAD if opt == "adagrad" else L.UPD_SGD, lr, eps, s))
 
-    def apply_():
-        L.check(lib.dctr_embed_apply(cplan, _ptr(X), X.stride(0), B, L.OPT_ADAGRAD if opt == "adagrad" else L.OPT_SGD,
-                                     lr, eps, s))
-
-    stages = [("embed_fwd", fwd), ("embed_bwd", bwd)] + ([("embed_apply", apply_)] if two_pass else [])
+    stages = [("embed_fwd", fwd), ("embed_update", upd)]
     for _, fn in stages * 3:
         fn()
     torch.cuda.synchronize()

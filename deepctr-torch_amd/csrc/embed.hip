@@ -128,7 +128,10 @@ template <int VEC, int LPR>
 __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const float* __restrict__ X,
                                                         int64_t ldx, int B, float* __restrict__ out,
                                                         int64_t ldo, float* __restrict__ wide,
-                                                        float* __restrict__ fm, int32_t* err) {
+                                                        float* __restrict__ fm, int32_t* err,
+                                                        const int32_t* __restrict__ units, int n_units,
+                                                        int32_t* __restrict__ ids_t,
+                                                        float* __restrict__ fm_s, int64_t lds_) {
   constexpr int SPB = kWave / LPR;
   constexpr int CH = 8;   // row loads in flight per lane and per pass (x4 waves = 32 fields)
   constexpr int WCH = 2;  // wide loads in flight per lane and per pass
@@ -146,6 +149,15 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
   const int e0 = gl * VEC;
   int bad = 0;
   float* orow = out ? out + static_cast<int64_t>(b) * ldo : nullptr;
+
+  // side output for dctr_embed_update: the ids of this tile, transposed to [unit][b] (64-byte runs)
+  if (ids_t) {
+    for (int k = tid; k < n_units * nrows; k += kThreads) {
+      const int u = k / nrows, r = k - u * nrows;
+      ids_t[static_cast<int64_t>(u) * B + b0 + r] =
+          static_cast<int32_t>(T.xs[r * P.n_xcols + ldg_i32(units + 4 * u + 2)]);
+    }
+  }
 
   // ---- wide (1-dim) tables: (wave, lane-in-group) pairs split the fields; loads issued first ----
   // Branch-free: slots past the last field re-read the last field and are masked when summed, so
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
   }
 
   // ---- the 4 waves' partials meet in LDS; wave 0 finishes --------------------------------------
-  if (fm || wide) {
+  if (fm || wide || fm_s) {
     float* mine = T.red + (wv_id * kWave + lane) * RED;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -250,6 +262,12 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
           qt[i] += o[VEC + i];
         }
         wt += o[2 * VEC];
+      }
+      if (fm_s && valid && e0 < P.emb_dim) {
+        Strip<VEC> sv;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) sv.v[i] = st[i];
+        strip_store<VEC>(fm_s + static_cast<int64_t>(b) * lds_ + e0, sv);
       }
       if (fm) {
         float t = 0.f;
@@ -521,10 +539,16 @@ int check_plan(const dctr_plan_t* p, const float* X, int64_t ldx, int32_t B) {
 
 extern "C" int dctr_embed_fwd(const dctr_plan_t* plan, const float* X, int64_t ldx, int32_t B,
                               float* out, int64_t ld_out, float* wide, float* fm, int32_t* err,
-                              dctr_stream_t stream) {
+                              const int32_t* units, int32_t n_units, int32_t* ids_t, float* fm_s,
+                              int64_t ld_s, dctr_stream_t stream) {
   if (int rc = check_plan(plan, X, ldx, B)) return rc;
   if (B == 0) return DCTR_OK;
   if (fm && (plan->emb_dim <= 0 || !out)) return DCTR_EINVAL;  // FM needs the deep rows
+  if (fm_s && (plan->emb_dim <= 0 || !out || ld_s < plan->emb_dim)) return DCTR_EINVAL;
+  if (ids_t && (!units || n_units <= 0)) return DCTR_EINVAL;
+  if (fm_s && plan->vec > 1 &&
+      (ld_s % plan->vec != 0 || reinterpret_cast<uintptr_t>(fm_s) % (4 * plan->vec) != 0))
+    return DCTR_EALIGN;
   const int vec = plan->vec;
   if (out && vec > 1 && (ld_out % vec != 0 || reinterpret_cast<uintptr_t>(out) % (4 * vec) != 0))
     return DCTR_EALIGN;
@@ -535,7 +559,8 @@ extern "C" int dctr_embed_fwd(const dctr_plan_t* plan, const float* X, int64_t l
   const dim3 grid((B + spb - 1) / spb), block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
   DCTR_DISPATCH(vec, lpr, k_embed_fwd<VEC, LPR><<<grid, block, lds, s>>>(*plan, X, ldx, B, out, ld_out,
-                                                                        wide, fm, err));
+                                                                        wide, fm, err, units, n_units,
+                                                                        ids_t, fm_s, ld_s));
   return launch_status();
 }
 

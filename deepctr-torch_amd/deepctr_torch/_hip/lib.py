@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdctr_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 
@@ -37,6 +37,7 @@ PLAN_HAS_GACC, PLAN_HAS_STATE, PLAN_HAS_MAXPOOL = 1, 2, 4
 POOL_CODE = {None: 0, "sum": 1, "mean": 2, "max": 3}
 BWD_ACCUM, BWD_SGD = 0, 1
 OPT_SGD, OPT_ADAGRAD = 0, 1
+UPD_SGD, UPD_ADAGRAD, UPD_ACCUM = 0, 1, 2
 
 _I32, _I64, _F32, _P = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -47,7 +48,12 @@ SIGNATURES = {
     "dctr_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "dctr_sizeof_field": (ctypes.c_size_t, []),
     "dctr_sizeof_plan": (ctypes.c_size_t, []),
-    "dctr_embed_fwd": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _P, _I64, _P, _P, _P, _P]),
+    "dctr_embed_fwd": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _P, _I64, _P, _P, _P, _P, _I32, _P, _P,
+                                      _I64, _P]),
+    "dctr_embed_update_supported": (ctypes.c_int, [ctypes.POINTER(Plan), _I64, _I32]),
+    "dctr_embed_ids": (ctypes.c_int, [_P, _I32, _P, _I64, _I32, _P, _P]),
+    "dctr_embed_update": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I32, _I64, _P, _I32, _P, _I64, _P, _I64, _P, _I64,
+                                         _P, _P, _I32, _F32, _F32, _P]),
     "dctr_embed_bwd": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P,
                                       _I32, _F32, _P]),
     "dctr_embed_apply": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _I32, _F32, _F32, _P]),

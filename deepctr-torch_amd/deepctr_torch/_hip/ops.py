@@ -48,7 +48,7 @@ class EmbedFunction(torch.autograd.Function):
     """Fused lookup: see ``dctr_embed_fwd`` / ``dctr_embed_bwd`` in include/dctr.h."""
 
     @staticmethod
-    def forward(ctx, plan, X, anchor, wdense_w, want_fm):
+    def forward(ctx, plan, X, anchor, wdense_w, want_fm, for_backward=False):
         lib = L.lib()
         X = _rows_f32(X, "model input X")
         if X.shape[1] < plan.n_xcols:
@@ -60,10 +60,19 @@ class EmbedFunction(torch.autograd.Function):
         fm = torch.empty((B,), dtype=torch.float32, device=X.device) if want_fm else None
         if want_fm and (plan.emb_dim <= 0 or not plan.deep):
             raise ValueError("FM needs sparse features that share one embedding_dim")
+        # side outputs for the deterministic fused update (only when a backward can follow)
+        ids_t = fm_s = None
+        ld_s = 0
+        if for_backward and plan.table_params and plan.update_kernel_ok(B):
+            ids_t = torch.empty((len(plan.units), B), dtype=torch.int32, device=X.device)
+            if want_fm:
+                ld_s = (plan.emb_dim + 3) // 4 * 4
+                fm_s = torch.empty((B, ld_s), dtype=torch.float32, device=X.device)
         L.check(lib.dctr_embed_fwd(cplan, _ptr(X), X.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), _ptr(fm),
-                                   _ptr(plan.err_flag(X.device)), L.stream_handle(X.device)), "dctr_embed_fwd")
+                                   _ptr(plan.err_flag(X.device)), plan.units_ptr(), len(plan.units), _ptr(ids_t),
+                                   _ptr(fm_s), ld_s, L.stream_handle(X.device)), "dctr_embed_fwd")
         ctx.plan, ctx.want_fm = plan, want_fm
-        ctx.save_for_backward(X, out if want_fm else None)
+        ctx.save_for_backward(X, out if want_fm else None, ids_t, fm_s)
         ctx.set_materialize_grads(False)
         outs = (out if out is not None else X.new_zeros((B, 0)),
                 wide if wide is not None else X.new_zeros((B,)),
@@ -74,7 +83,7 @@ class EmbedFunction(torch.autograd.Function):
     def backward(ctx, g_out, g_wide, g_fm):
         lib = L.lib()
         plan = ctx.plan
-        X, out = ctx.saved_tensors
+        X, out, ids_t, fm_s = ctx.saved_tensors
         B = X.shape[0]
         if not plan.has_lookup:
             g_out = None
@@ -94,17 +103,38 @@ class EmbedFunction(torch.autograd.Function):
         if g_out is not None:
             g_out, ld_g = _aligned_rows(g_out, plan.vec, 0)
         if (g_out is None and g_fm is None and g_wide is None) or not plan.table_params:
-            return None, None, None, g_w, None
+            return None, None, None, g_w, None, None
 
         update = plan.update
         kind = update[0]
         stream = L.stream_handle(X.device)
+
+        if ids_t is not None:
+            # deterministic single-pass path (csrc/update.hip): no atomics, optimizer fused in
+            if kind == "dense":
+                plan.ensure_gacc()
+                plan.prepare_dense_grads()
+                opt, lr, eps = L.UPD_ACCUM, 0.0, 0.0
+            elif kind in ("sgd", "sgd2"):
+                opt, lr, eps = L.UPD_SGD, float(update[1]), 0.0
+            elif kind == "adagrad":
+                opt, lr, eps = L.UPD_ADAGRAD, float(update[1]), float(update[2])
+            else:
+                raise RuntimeError("unknown sparse update mode %r" % (kind,))
+            cplan = plan.bind(X.device)
+            L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t), B,
+                                          _ptr(g_out), ld_g, _ptr(out), plan.ld_out, _ptr(fm_s),
+                                          fm_s.stride(0) if fm_s is not None else 0, _ptr(g_fm), _ptr(g_wide),
+                                          opt, lr, eps, stream), "dctr_embed_update")
+            return None, None, None, g_w, None, None
+
+        # general path (pooled VarLen fields, shared tables, very large batches): atomic scatter (+ consume pass)
         if kind == "sgd" and not plan.has_maxpool:
             cplan = plan.bind(X.device)
             L.check(lib.dctr_embed_bwd(cplan, _ptr(X), X.stride(0), B, _ptr(g_out), ld_g, _ptr(out), plan.ld_out,
                                        _ptr(g_fm), _ptr(g_wide), L.BWD_SGD, float(update[1]), stream),
                     "dctr_embed_bwd(sgd)")
-            return None, None, None, g_w, None
+            return None, None, None, g_w, None, None
 
         plan.ensure_gacc()
         if kind == "dense":
@@ -120,14 +150,15 @@ class EmbedFunction(torch.autograd.Function):
                                          float(update[2]), stream), "dctr_embed_apply(adagrad)")
         elif kind != "dense":
             raise RuntimeError("unknown sparse update mode %r" % (kind,))
-        return None, None, None, g_w, None
+        return None, None, None, g_w, None, None
 
 
 def embed(plan, X, want_fm=False):
     """(out [B, width] view, wide [B], fm [B]) for model input ``X`` under ``plan``."""
     L.require_gpu(X, "model input X")
     plan.bind(X.device)
-    out, wide, fm = EmbedFunction.apply(plan, X, plan.anchor, plan.wide_dense_weight, bool(want_fm))
+    out, wide, fm = EmbedFunction.apply(plan, X, plan.anchor, plan.wide_dense_weight, bool(want_fm),
+                                        torch.is_grad_enabled())
     if plan.has_lookup:
         out = out[:, :plan.width]
     return out, wide, fm

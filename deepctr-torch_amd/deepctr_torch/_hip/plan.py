@@ -122,6 +122,24 @@ class EmbeddingPlan(object):
         self.width = emb_width + len(self.dense_cols)      # logical row width (combined_dnn_input)
         self.ld_out = max(4, (self.width + 3) // 4 * 4)     # padded leading dimension of `out`
 
+        # units of the deterministic update kernel (csrc/update.hip): one id column of X with the deep and / or
+        # wide table it feeds.  Usable when every field is fixed-length and no table is shared.
+        self.units = []
+        used_wide = set()
+        for i, f in enumerate(self.deep):
+            j = next((k for k, w in enumerate(self.wide) if k not in used_wide and w.col == f.col and
+                      w.vocab == f.vocab and w.len == 1), -1)
+            if j >= 0:
+                used_wide.add(j)
+            self.units.append((i, j, f.col, 0))
+        for k, w in enumerate(self.wide):
+            if k not in used_wide:
+                self.units.append((-1, k, w.col, 0))
+        all_fields = self.deep + self.wide
+        self.max_vocab = max([f.vocab for f in all_fields] + [1])
+        self.unit_path = (len(all_fields) > 0 and all(f.len == 1 and f.pool == 0 for f in all_fields) and
+                          len(set(id(f.param) for f in all_fields)) == len(all_fields))
+
         self._params = []  # unique table parameters, first-use order
         seen = set()
         for f in self.deep + self.wide:
@@ -275,6 +293,7 @@ class EmbeddingPlan(object):
             "wide": up(self._field_bytes(self.wide), torch.uint8),
             "dense": up(np.asarray(self.dense_cols or [0], dtype=np.int32).tobytes(), torch.int32),
             "wdense": up(np.asarray(self.wdense_cols or [0], dtype=np.int32).tobytes(), torch.int32),
+            "units": up(np.asarray(self.units or [(-1, -1, 0, 0)], dtype=np.int32).tobytes(), torch.int32),
         }
         c = self.cplan
         c.deep = self._dev["deep"].data_ptr() if self.deep else None
@@ -303,6 +322,15 @@ class EmbeddingPlan(object):
             # differentiable tensor enters the lookup (tables are updated in place, not via autograd)
             self.anchor = torch.zeros(1, device=device, requires_grad=True)
         return ctypes.byref(self.cplan)
+
+    def units_ptr(self):
+        return ctypes.c_void_p(self._dev["units"].data_ptr())
+
+    def update_kernel_ok(self, B):
+        """True when the deterministic fused update (dctr_embed_update) can run this plan at batch ``B``."""
+        if not self.unit_path or B <= 0:
+            return False
+        return bool(L.lib().dctr_embed_update_supported(ctypes.byref(self.cplan), self.max_vocab, int(B)))
 
     @property
     def has_lookup(self):

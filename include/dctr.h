@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 1
+#define DCTR_ABI_VERSION 2
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -101,9 +101,13 @@ size_t dctr_sizeof_plan(void);
  *   wide  [B]  sum_f w_f[id] (+pooled VarLen) + dense . Linear.weight     (nullable)
  *   fm    [B]  0.5 * sum_d ((sum_f e)^2 - sum_f e^2) over ALL deep fields (nullable; needs emb_dim)
  *   err   int32 flag; bit0 is set when an id falls outside [0, vocab) -- such a row reads as row 0
- *         (the reference raises IndexError on CPU; here the flag is polled by the host) (nullable)  */
+ *         (the reference raises IndexError on CPU; here the flag is polled by the host) (nullable)
+ * Two optional side outputs feed dctr_embed_update (both nullable):
+ *   ids_t [n_units, B] int32: ids_t[u][b] = (int) X[b, units[u].col]  (units: see dctr_embed_update)
+ *   fm_s  [B, ld_s]    S[b, d] = sum_f e[b, f, d], the per-sample field sum FM's backward needs      */
 int dctr_embed_fwd(const dctr_plan_t* plan, const float* X, int64_t ldx, int32_t B, float* out,
-                   int64_t ld_out, float* wide, float* fm, int32_t* err, dctr_stream_t stream);
+                   int64_t ld_out, float* wide, float* fm, int32_t* err, const int32_t* units,
+                   int32_t n_units, int32_t* ids_t, float* fm_s, int64_t ld_s, dctr_stream_t stream);
 
 /* ---- backward of the above = embedding_dense_backward + FM backward, as an O(batch) scatter -------
  * Replaces autograd's aten::embedding_dense_backward x(n_deep+n_wide), the pooling backward and
@@ -133,6 +137,32 @@ int dctr_embed_bwd(const dctr_plan_t* plan, const float* X, int64_t ldx, int32_t
 #define DCTR_OPT_ADAGRAD 1
 int dctr_embed_apply(const dctr_plan_t* plan, const float* X, int64_t ldx, int32_t B, int32_t opt,
                      float lr, float eps, dctr_stream_t stream);
+
+/* ---- deterministic fused backward + optimizer (csrc/update.hip) ------------------------------------
+ * The O(batch) replacement of embedding_dense_backward + FM backward + the optimizer's walk over the
+ * tables (basemodel.py:261-262) for plans of fixed-length fields over distinct tables.  No atomics:
+ * workgroup (unit, partition) owns rows {id : id mod P == partition}, sorts its (id, b) entries in LDS
+ * and read-modify-writes each touched row exactly once, summing duplicate ids in (id, b) order, so the
+ * result is bit-reproducible (needed for replica equality under data parallelism).
+ *   units  [n_units][4] int32 (device): {deep field index | -1, wide field index | -1, X column, 0};
+ *          a unit is one id column with the deep and/or wide table it feeds
+ *   ids_t  [n_units, B] int32 from dctr_embed_fwd / dctr_embed_ids
+ *   g_out / out / fm_s / g_fm / g_wide as in dctr_embed_bwd (fm_s = side output of dctr_embed_fwd)
+ *   opt    DCTR_UPD_SGD      table[row] -= lr * G                          (torch.optim.SGD)
+ *          DCTR_UPD_ADAGRAD  state[row] += G*G ; table[row] -= lr*G/(sqrt(state[row])+eps)
+ *          DCTR_UPD_ACCUM    gacc[row]  += G          (exact dense-gradient semantics: param.grad)
+ *   max_vocab  largest vocab over the plan's fields (sizes the 32-bit sort keys)
+ * dctr_embed_update_supported returns 1 when the plan / batch fit (B <= 32768, keys fit 32 bits).    */
+#define DCTR_UPD_SGD 0
+#define DCTR_UPD_ADAGRAD 1
+#define DCTR_UPD_ACCUM 2
+int dctr_embed_update_supported(const dctr_plan_t* plan, int64_t max_vocab, int32_t B);
+int dctr_embed_ids(const int32_t* units, int32_t n_units, const float* X, int64_t ldx, int32_t B,
+                   int32_t* ids_t, dctr_stream_t stream);
+int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, int32_t n_units, int64_t max_vocab,
+                      const int32_t* ids_t, int32_t B, const float* g_out, int64_t ld_g, const float* out,
+                      int64_t ld_out, const float* fm_s, int64_t ld_s, const float* g_fm,
+                      const float* g_wide, int32_t opt, float lr, float eps, dctr_stream_t stream);
 
 /* ---- FM on an explicit [B, F, D] tensor (interaction.py:26-34) ------------------------------------
  * E is addressed as E[b*ld_b + f*D + d].  y[b] = 0.5 * sum_d((sum_f e)^2 - sum_f e^2).
