@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--optimizer", default="adagrad", choices=["adagrad", "sgd"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-parallel", action="store_true", help="use the data-parallel trainer even with 1 rank")
     ap.add_argument("--kernel-iters", type=int, default=50, help="event-timed launches per hot-path kernel")
     ap.add_argument("--cpu-steps", type=int, default=3)
     return ap.parse_args()
@@ -162,9 +163,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
     dist = None
-    if world > 1:
+    if world > 1 or args.force_parallel:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
     model = build_model(args, device)
@@ -172,7 +174,7 @@ def main():
     B = args.batch
     n_batches = X.shape[0] // B
     parallel = None
-    if world > 1:
+    if dist is not None:
         from deepctr_torch import parallel as par
         parallel = par.DataParallelTrainer(model)
 

@@ -1,0 +1,497 @@
+// cin.hip -- Compressed Interaction Network layer (xDeepFM) on the gfx950 matrix cores, fp32 in / fp32 out.
+//
+// Reference (interaction.py:207-248), one layer:
+//     Z[b, h*M + m, d] = H[b, h, d] * X0[b, m, d]                 (einsum 'bhd,bmd->bhmd', MATERIALISED: 436 MB at
+//     Y[b, o, d]       = sum_k W[o, k] Z[b, k, d] + bias[o]        the Criteo shape for layer 1)
+//     A                = relu(Y)
+// GEMM view: columns c = (b, d) (B*D = 65536 of them), K = h*M (676 / 1664), rows o (128).  It is genuinely dense,
+// so it runs on v_mfma_f32_32x32x2_f32 -- exact fp32 (the 1e-5 logit bar rules out bf16 inputs).
+// Z is never formed in memory: the B operand of every MFMA is produced by ONE v_mul per lane,
+//     Z[k = (h, m), c] = H[b, h, d] * X0[b, m, d],
+// with the lane's column fixed for the whole kernel, H[b, h, d] held in a register per h and X0[b, :, d] in LDS.
+//
+// Forward mapping: workgroup = 4 waves = 256 columns (16 samples at D=16), one wave per SIMD; a wave owns 2 column
+// tiles x OT row tiles of 32x32 (8 independent accumulators at O=128 -> the matrix pipe issues back to back).
+// Loop over h: the 13 KB weight slice Wt[h] (prepared as [h][M_pad][O_pad] so rows are contiguous) is double
+// buffered in LDS, fetched for h+1 while h computes; one barrier per h.  B=4096 -> 256 workgroups = one per CU.
+#include "common.hpp"
+
+using namespace dctr;
+
+namespace {
+
+constexpr int kT = 256;       // threads per workgroup
+constexpr int kCols = 256;    // columns per workgroup
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// row of accumulator register r held by a lane of half p (32x32 C/D layout)
+__device__ __forceinline__ int acc_row(int r, int p) { return (r & 3) + 8 * (r >> 2) + 4 * p; }
+
+// W [O, h*M] (conv1ds.k.weight squeezed) -> Wt [h][M_pad][O_pad], zero padded
+__global__ __launch_bounds__(kT) void k_cin_prep_w(const float* __restrict__ W, int O, int h, int M, int M_pad,
+                                                   int O_pad, float* __restrict__ Wt) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+  const int64_t total = static_cast<int64_t>(h) * M_pad * O_pad;
+  if (idx >= total) return;
+  const int o = static_cast<int>(idx % O_pad);
+  const int mm = static_cast<int>((idx / O_pad) % M_pad);
+  const int hh = static_cast<int>(idx / (static_cast<int64_t>(O_pad) * M_pad));
+  Wt[idx] = (o < O && mm < M) ? W[static_cast<int64_t>(o) * h * M + hh * M + mm] : 0.f;
+}
+
+template <int OT>
+__global__ __launch_bounds__(kT, 1) void k_cin_fwd(const float* __restrict__ X0, int64_t ldx0,
+                                                   const float* __restrict__ H, int64_t ldh, int h, int M,
+                                                   int M_pad, int D, int B, const float* __restrict__ Wt,
+                                                   int O_pad, int O, const float* __restrict__ bias, int relu,
+                                                   float* __restrict__ A, int64_t lda) {
+  constexpr int OB = OT * 32;
+  extern __shared__ __align__(16) float smem[];
+  float* x0s = smem;                    // [M_pad][256]
+  float* ws = x0s + M_pad * kCols;      // [2][M_pad][OB]
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, p = lane >> 5, jl = lane & 31;
+  const int64_t c_base = static_cast<int64_t>(blockIdx.x) * kCols;
+  const int o_base = blockIdx.y * 128;
+  const int64_t ncol = static_cast<int64_t>(B) * D;
+  const int chunk = M_pad * OB;
+
+  int64_t hoff[2];
+  bool cv[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int64_t c = c_base + wv * 64 + t * 32 + jl;
+    cv[t] = c < ncol;
+    const int64_t b = cv[t] ? c / D : 0;
+    const int d = cv[t] ? static_cast<int>(c - b * D) : 0;
+    hoff[t] = b * ldh + d;
+  }
+  {  // stage X0[b, :, d] of this thread's column
+    const int64_t c = c_base + tid;
+    const bool v = c < ncol;
+    const int64_t b = v ? c / D : 0;
+    const int d = v ? static_cast<int>(c - b * D) : 0;
+    const float* src = X0 + b * ldx0 + d;
+    for (int mm = 0; mm < M_pad; ++mm) x0s[mm * kCols + tid] = (v && mm < M) ? ldg_f32(src + mm * D) : 0.f;
+  }
+  // weight slice of h = 0
+  f32x4 wreg[OT];
+  auto fetch_w = [&](int hh) {
+    const float* src = Wt + static_cast<int64_t>(hh) * M_pad * O_pad + o_base;
+#pragma unroll
+    for (int q = 0; q < OT; ++q) {
+      const int e = q * kT + tid;  // float4 index inside the slice
+      const int row = e / (OB / 4), c4 = e - row * (OB / 4);
+      wreg[q] = (row < M_pad) ? *(const DCTR_GLOBAL f32x4*)(src + static_cast<int64_t>(row) * O_pad + c4 * 4)
+                              : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto park_w = [&](int buf) {
+    float* dst = ws + buf * chunk;
+#pragma unroll
+    for (int q = 0; q < OT; ++q) {
+      const int e = q * kT + tid;
+      const int row = e / (OB / 4);
+      if (row < M_pad) *reinterpret_cast<f32x4*>(dst + e * 4) = wreg[q];
+    }
+  };
+  fetch_w(0);
+  park_w(0);
+  float hv[2], hnext[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) hv[t] = cv[t] ? ldg_f32(H + hoff[t]) : 0.f;
+  __syncthreads();
+
+  f32x16 acc[OT][2];
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ot][t][r] = 0.f;
+
+  const int xoff = wv * 64 + jl;
+  for (int hh = 0; hh < h; ++hh) {
+    const bool more = hh + 1 < h;
+    if (more) {
+      fetch_w(hh + 1);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) hnext[t] = cv[t] ? ldg_f32(H + hoff[t] + static_cast<int64_t>(hh + 1) * D) : 0.f;
+    }
+    const float* wc = ws + (hh & 1) * chunk;
+    for (int s = 0; s < M_pad / 2; ++s) {
+      const int mm = 2 * s + p;
+      const float z0 = hv[0] * x0s[mm * kCols + xoff];
+      const float z1 = hv[1] * x0s[mm * kCols + xoff + 32];
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        const float a = wc[mm * OB + ot * 32 + jl];
+        acc[ot][0] = mfma32(a, z0, acc[ot][0]);
+        acc[ot][1] = mfma32(a, z1, acc[ot][1]);
+      }
+    }
+    if (more) {
+      park_w((hh + 1) & 1);
+      hv[0] = hnext[0];
+      hv[1] = hnext[1];
+    }
+    __syncthreads();
+  }
+
+  // epilogue: + bias, activation, store A[b, o, d]
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = o_base + ot * 32 + acc_row(r, p);
+      if (o < O) {
+        const float bo = bias ? ldg_f32(bias + o) : 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          if (cv[t]) {
+            const int64_t c = c_base + wv * 64 + t * 32 + jl;
+            const int64_t b = c / D;
+            const int d = static_cast<int>(c - b * D);
+            float y = acc[ot][t][r] + bo;
+            if (relu) y = y > 0.f ? y : 0.f;
+            stg_f32(A + b * lda + static_cast<int64_t>(o) * D + d, y);
+          }
+        }
+      }
+    }
+  }
+}
+
+
+// -------------------------------------------------------------------------------------------------------------
+// backward, data side:  gZ[k, c] = sum_o W[o, k] gY[o, c]  (never stored), then per column c = (b, d)
+//     gH[b, h, d]   = sum_m gZ[(h, m), c] X0[b, m, d]          gX0[b, m, d] += sum_h gZ[(h, m), c] H[b, h, d]
+// MFMA roles: rows i = m (the 26 fields of one h, padded to 32), reduction = o, columns = c.  The lane's gY values
+// (B operand, reused by every h) live in registers for the whole kernel; the weight slice W[:, h*M .. h*M+M) is
+// double buffered in LDS as [o][32].  The product-rule tails are per-lane FMAs on the accumulator registers.
+// -------------------------------------------------------------------------------------------------------------
+template <int OT>
+__global__ __launch_bounds__(kT, 1) void k_cin_bwd_data(const float* __restrict__ gA, const float* __restrict__ Asv,
+                                                        int64_t lda, int relu, const float* __restrict__ X0,
+                                                        int64_t ldx0, const float* __restrict__ H, int64_t ldh,
+                                                        int h, int M, int D, int B, const float* __restrict__ W,
+                                                        int O, float* __restrict__ gH, int64_t ldgh, int acc_h,
+                                                        float* __restrict__ gX0, int64_t ldgx, int acc_x) {
+  constexpr int OB = OT * 32, NS = OT * 16, NW = OT * 4;  // NW dwords of the weight slice per thread
+  extern __shared__ __align__(16) float smem[];
+  float* wl = smem;  // [2][OB][32]
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, p = lane >> 5, jl = lane & 31;
+  const int64_t c_base = static_cast<int64_t>(blockIdx.x) * kCols;
+  const int64_t ncol = static_cast<int64_t>(B) * D;
+  const int K = h * M;
+
+  int64_t bb[2];
+  int dd[2];
+  bool cv[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int64_t c = c_base + wv * 64 + t * 32 + jl;
+    cv[t] = c < ncol;
+    bb[t] = cv[t] ? c / D : 0;
+    dd[t] = cv[t] ? static_cast<int>(c - bb[t] * D) : 0;
+  }
+  // gY of this lane's columns: o = 2*s + p
+  float gy[2][NS];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int o = 2 * s + p;
+      float v = 0.f;
+      if (cv[t] && o < O) {
+        const int64_t off = bb[t] * lda + static_cast<int64_t>(o) * D + dd[t];
+        v = ldg_f32(gA + off);
+        if (relu && !(ldg_f32(Asv + off) > 0.f)) v = 0.f;
+      }
+      gy[t][s] = v;
+    }
+  }
+  // X0 rows matching this lane's accumulator rows
+  float x0r[2][16], gxa[2][16];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int mm = acc_row(r, p);
+      x0r[t][r] = (cv[t] && mm < M) ? ldg_f32(X0 + bb[t] * ldx0 + mm * D + dd[t]) : 0.f;
+      gxa[t][r] = 0.f;
+    }
+
+  float wreg[NW];
+  auto fetch_w = [&](int hh) {
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const int e = q * kT + tid;  // = o_local * 32 + m
+      const int ol = e >> 5, mm = e & 31;
+      wreg[q] = (ol < O && mm < M) ? ldg_f32(W + static_cast<int64_t>(ol) * K + hh * M + mm) : 0.f;
+    }
+  };
+  auto park_w = [&](int buf) {
+    float* dst = wl + buf * (OB * 32);
+#pragma unroll
+    for (int q = 0; q < NW; ++q) dst[q * kT + tid] = wreg[q];
+  };
+  fetch_w(0);
+  park_w(0);
+  float hv[2], hnext[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) hv[t] = cv[t] ? ldg_f32(H + bb[t] * ldh + dd[t]) : 0.f;
+  __syncthreads();
+
+  for (int hh = 0; hh < h; ++hh) {
+    const bool more = hh + 1 < h;
+    if (more) {
+      fetch_w(hh + 1);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        hnext[t] = cv[t] ? ldg_f32(H + bb[t] * ldh + static_cast<int64_t>(hh + 1) * D + dd[t]) : 0.f;
+    }
+    const float* wc = wl + (hh & 1) * (OB * 32);
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float a = wc[(2 * s + p) * 32 + jl];
+      acc[0] = mfma32(a, gy[0][s], acc[0]);
+      acc[1] = mfma32(a, gy[1][s], acc[1]);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float part = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        part += acc[t][r] * x0r[t][r];
+        gxa[t][r] += acc[t][r] * hv[t];
+      }
+      part += __shfl_xor(part, 32, kWave);
+      if (p == 0 && cv[t]) {
+        float* dst = gH + bb[t] * ldgh + static_cast<int64_t>(hh) * D + dd[t];
+        stg_f32(dst, acc_h ? ldg_f32(dst) + part : part);
+      }
+    }
+    if (more) {
+      park_w((hh + 1) & 1);
+      hv[0] = hnext[0];
+      hv[1] = hnext[1];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int mm = acc_row(r, p);
+      if (cv[t] && mm < M) {
+        float* dst = gX0 + bb[t] * ldgx + mm * D + dd[t];
+        stg_f32(dst, acc_x ? ldg_f32(dst) + gxa[t][r] : gxa[t][r]);
+      }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// backward, weight side:  gW[o, (h, m)] = sum_c gY[o, c] H[b, h, d] X0[b, m, d]
+// MFMA roles: rows i = o, columns j = m (padded to 32), reduction = c.  Workgroup (hg, q): its 4 waves own 4
+// consecutive h and walk the column blocks q, q+Q, ... of 64 columns staged in LDS (gY transposed to [c][o], X0 as
+// [c][32], H as [4][c]); every wave keeps gW[0:OB, (h, 0:32)] in 4 accumulators and adds it to gW once at the end.
+// -------------------------------------------------------------------------------------------------------------
+template <int OT>
+__global__ __launch_bounds__(kT, 1) void k_cin_bwd_weight(const float* __restrict__ gA,
+                                                          const float* __restrict__ Asv, int64_t lda, int relu,
+                                                          const float* __restrict__ X0, int64_t ldx0,
+                                                          const float* __restrict__ H, int64_t ldh, int h, int M,
+                                                          int D, int B, int O, float* __restrict__ gW,
+                                                          float* __restrict__ gbias) {
+  constexpr int OB = OT * 32, OBP = OB + 1, CB = 64;
+  extern __shared__ __align__(16) float smem[];
+  float* gys = smem;             // [CB][OBP]
+  float* x0s = gys + CB * OBP;   // [CB][32]
+  float* hs = x0s + CB * 32;     // [4][CB]
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, p = lane >> 5, jl = lane & 31;
+  const int hh = blockIdx.x * 4 + wv;
+  const int64_t ncol = static_cast<int64_t>(B) * D;
+  const int64_t nblk = (ncol + CB - 1) / CB;
+  const int K = h * M;
+
+  f32x16 acc[OT];
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ot][r] = 0.f;
+  float bsum = 0.f;  // gbias partial of row o = tid (only block row 0 of the grid contributes)
+
+  for (int64_t blk = blockIdx.y; blk < nblk; blk += gridDim.y) {
+    const int64_t c0 = blk * CB;
+    // stage gY^T, X0, H of this column block
+    for (int e = tid; e < CB * OB; e += kT) {
+      const int cl = e & (CB - 1), o = e >> 6;
+      const int64_t c = c0 + cl;
+      float v = 0.f;
+      if (c < ncol && o < O) {
+        const int64_t b = c / D;
+        const int d = static_cast<int>(c - b * D);
+        const int64_t off = b * lda + static_cast<int64_t>(o) * D + d;
+        v = ldg_f32(gA + off);
+        if (relu && !(ldg_f32(Asv + off) > 0.f)) v = 0.f;
+      }
+      gys[cl * OBP + o] = v;
+    }
+    for (int e = tid; e < CB * 32; e += kT) {
+      const int cl = e & (CB - 1), mm = e >> 6;
+      const int64_t c = c0 + cl;
+      float v = 0.f;
+      if (c < ncol && mm < M) {
+        const int64_t b = c / D;
+        v = ldg_f32(X0 + b * ldx0 + mm * D + (c - b * D));
+      }
+      x0s[cl * 32 + mm] = v;
+    }
+    {
+      const int cl = tid & (CB - 1), hl = tid >> 6;
+      const int64_t c = c0 + cl;
+      const int hq = blockIdx.x * 4 + hl;
+      float v = 0.f;
+      if (c < ncol && hq < h) {
+        const int64_t b = c / D;
+        v = ldg_f32(H + b * ldh + static_cast<int64_t>(hq) * D + (c - b * D));
+      }
+      hs[hl * CB + cl] = v;
+    }
+    __syncthreads();
+    if (gbias && blockIdx.x == 0 && tid < OB) {
+#pragma unroll 8
+      for (int cl = 0; cl < CB; ++cl) bsum += gys[cl * OBP + tid];
+    }
+    if (hh < h) {
+#pragma unroll 4
+      for (int ks = 0; ks < CB / 2; ++ks) {
+        const int cl = 2 * ks + p;
+        const float z = hs[wv * CB + cl] * x0s[cl * 32 + jl];
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma32(gys[cl * OBP + ot * 32 + jl], z, acc[ot]);
+      }
+    }
+    __syncthreads();
+  }
+  if (hh < h && jl < M) {
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = ot * 32 + acc_row(r, p);
+        if (o < O) atomic_add_f32(gW + static_cast<int64_t>(o) * K + hh * M + jl, acc[ot][r]);
+      }
+  }
+  if (gbias && blockIdx.x == 0 && tid < OB && tid < O) atomic_add_f32(gbias + tid, bsum);
+}
+
+}  // namespace
+
+extern "C" size_t dctr_cin_workspace_floats(int32_t h, int32_t M, int32_t O) {
+  const size_t M_pad = (M + 1) / 2 * 2, O_pad = (O + 31) / 32 * 32;
+  return static_cast<size_t>(h) * M_pad * O_pad;
+}
+
+extern "C" int dctr_cin_layer_fwd(const float* H, int64_t ld_h, const float* X0, int64_t ld_x0, const float* W,
+                                  const float* bias, int32_t B, int32_t h, int32_t M, int32_t D, int32_t O,
+                                  int32_t relu, float* A, int64_t ld_a, float* workspace,
+                                  dctr_stream_t stream) {
+  if (!H || !X0 || !W || !A || !workspace || B < 0 || h <= 0 || M <= 0 || D <= 0 || O <= 0) return DCTR_EINVAL;
+  if (ld_h < static_cast<int64_t>(h) * D || ld_x0 < static_cast<int64_t>(M) * D ||
+      ld_a < static_cast<int64_t>(O) * D)
+    return DCTR_EINVAL;
+  if (M > 32) return DCTR_ENOSUP;
+  if (B == 0) return DCTR_OK;
+  const int M_pad = (M + 1) / 2 * 2, O_pad = (O + 31) / 32 * 32;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t total = static_cast<int64_t>(h) * M_pad * O_pad;
+  k_cin_prep_w<<<dim3(static_cast<unsigned>((total + kT - 1) / kT)), dim3(kT), 0, s>>>(W, O, h, M, M_pad, O_pad,
+                                                                                       workspace);
+  const int64_t ncol = static_cast<int64_t>(B) * D;
+  const int ychunks = (O_pad + 127) / 128;
+  const dim3 grid(static_cast<unsigned>((ncol + kCols - 1) / kCols), ychunks);
+  // every y-chunk but the last has 4 row tiles; launch the last one separately if it is narrower
+  const int ot_last = (O_pad - (ychunks - 1) * 128) / 32;
+  auto launch = [&](int ot, dim3 g, int ybase) {
+    const size_t lds = (static_cast<size_t>(M_pad) * kCols + 2u * M_pad * ot * 32) * sizeof(float);
+    const float* wt = workspace + ybase * 128;
+    const float* bs = bias ? bias + ybase * 128 : nullptr;
+    float* a = A + static_cast<int64_t>(ybase) * 128 * D;
+    const int o_here = O - ybase * 128;
+    switch (ot) {
+      case 1: k_cin_fwd<1><<<g, dim3(kT), lds, s>>>(X0, ld_x0, H, ld_h, h, M, M_pad, D, B, wt, O_pad, o_here, bs, relu, a, ld_a); break;
+      case 2: k_cin_fwd<2><<<g, dim3(kT), lds, s>>>(X0, ld_x0, H, ld_h, h, M, M_pad, D, B, wt, O_pad, o_here, bs, relu, a, ld_a); break;
+      case 3: k_cin_fwd<3><<<g, dim3(kT), lds, s>>>(X0, ld_x0, H, ld_h, h, M, M_pad, D, B, wt, O_pad, o_here, bs, relu, a, ld_a); break;
+      default: k_cin_fwd<4><<<g, dim3(kT), lds, s>>>(X0, ld_x0, H, ld_h, h, M, M_pad, D, B, wt, O_pad, o_here, bs, relu, a, ld_a); break;
+    }
+  };
+  if (ychunks > 1) launch(4, dim3(grid.x, ychunks - 1), 0);
+  launch(ot_last, dim3(grid.x, 1), ychunks - 1);
+  return launch_status();
+}
+
+extern "C" int dctr_cin_layer_bwd(const float* gA, const float* A, int64_t ld_a, int32_t relu, const float* H,
+                                  int64_t ld_h, const float* X0, int64_t ld_x0, const float* W, int32_t B,
+                                  int32_t h, int32_t M, int32_t D, int32_t O, float* gH, int64_t ld_gh,
+                                  float* gX0, int64_t ld_gx, int32_t accumulate_x0, float* gW, float* gbias,
+                                  dctr_stream_t stream) {
+  if (!gA || !H || !X0 || !W || !gH || !gX0 || !gW || B < 0 || h <= 0 || M <= 0 || D <= 0 || O <= 0)
+    return DCTR_EINVAL;
+  if (relu && !A) return DCTR_EINVAL;
+  if (M > 32) return DCTR_ENOSUP;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int K = h * M;
+  hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * static_cast<size_t>(O) * K, s);
+  if (e != hipSuccess) return static_cast<int>(e);
+  if (gbias) {
+    e = hipMemsetAsync(gbias, 0, sizeof(float) * static_cast<size_t>(O), s);
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  if (B == 0) return DCTR_OK;
+  const int64_t ncol = static_cast<int64_t>(B) * D;
+  const int chunks = (O + 127) / 128;
+  for (int ch = 0; ch < chunks; ++ch) {
+    const int o0 = ch * 128;
+    const int o_here = (O - o0) < 128 ? (O - o0) : 128;
+    const int ot = (o_here + 31) / 32;
+    const float* gA_c = gA + static_cast<int64_t>(o0) * D;
+    const float* A_c = A ? A + static_cast<int64_t>(o0) * D : nullptr;
+    const float* W_c = W + static_cast<int64_t>(o0) * K;
+    // data side: the chunks of o add up in gH / gX0
+    {
+      const dim3 grid(static_cast<unsigned>((ncol + kCols - 1) / kCols));
+      const size_t lds = 2u * ot * 32 * 32 * sizeof(float);
+      const int acc_h = ch > 0, acc_x = (ch > 0) || accumulate_x0;
+#define DCTR_CIN_BD(OT_) k_cin_bwd_data<OT_><<<grid, dim3(kT), lds, s>>>(gA_c, A_c, ld_a, relu, X0, ld_x0, H, ld_h, h, M, \
+                                                                       D, B, W_c, o_here, gH, ld_gh, acc_h, gX0, ld_gx, acc_x)
+      switch (ot) { case 1: DCTR_CIN_BD(1); break; case 2: DCTR_CIN_BD(2); break; case 3: DCTR_CIN_BD(3); break; default: DCTR_CIN_BD(4); break; }
+#undef DCTR_CIN_BD
+    }
+    // weight side
+    {
+      const int hgroups = (h + 3) / 4;
+      const int64_t nblk = (ncol + 63) / 64;
+      int64_t q = 512 / hgroups;
+      if (q < 1) q = 1;
+      if (q > nblk) q = nblk;
+      const dim3 grid(hgroups, static_cast<unsigned>(q));
+      const size_t lds = (64u * (ot * 32 + 1) + 64u * 32 + 4u * 64) * sizeof(float);
+      float* gW_c = gW + static_cast<int64_t>(o0) * K;
+      float* gb_c = gbias ? gbias + o0 : nullptr;
+#define DCTR_CIN_BW(OT_) k_cin_bwd_weight<OT_><<<grid, dim3(kT), lds, s>>>(gA_c, A_c, ld_a, relu, X0, ld_x0, H, ld_h, h, M, \
+                                                                         D, B, o_here, gW_c, gb_c)
+      switch (ot) { case 1: DCTR_CIN_BW(1); break; case 2: DCTR_CIN_BW(2); break; case 3: DCTR_CIN_BW(3); break; default: DCTR_CIN_BW(4); break; }
+#undef DCTR_CIN_BW
+    }
+  }
+  return launch_status();
+}

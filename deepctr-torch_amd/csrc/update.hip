@@ -111,37 +111,75 @@ __global__ __launch_bounds__(kThreads) void k_embed_update(UpdArgs A) {
   __syncthreads();
 
   // ---- 1. scan: collect this partition's entries -------------------------------------------------
+  // All id loads of a chunk are issued before any is consumed (16 ids per thread in flight at B=4096):
+  // the scan costs one L2 round trip, not one per iteration.
   const int32_t* ids = A.ids_t + static_cast<int64_t>(u) * B;
-  for (int b = tid; b < B; b += kThreads) {
-    const int32_t id = clamp_id(ldg_i32(ids + b), vocab);
+  auto take = [&](int32_t raw, int b) {
+    const int32_t id = clamp_id(raw, vocab);
     if ((id & (P - 1)) == p) {
       const int slot = atomicAdd(&n_sh, 1);  // LDS atomic; the order is fixed by the sort below
       keys[slot] = (static_cast<uint32_t>(id >> A.log2p) << A.bbits) | static_cast<uint32_t>(b);
     }
+  };
+  if ((B & 3) == 0) {
+    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+    const DCTR_GLOBAL i32x4* idv = (const DCTR_GLOBAL i32x4*)ids;
+    const int nvec = B >> 2;
+    for (int c0 = 0; c0 < nvec; c0 += 4 * kThreads) {
+      i32x4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int idx = c0 + q * kThreads + tid;
+        v[q] = idv[idx < nvec ? idx : 0];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int idx = c0 + q * kThreads + tid;
+        if (idx < nvec) {
+          take(v[q].x, 4 * idx);
+          take(v[q].y, 4 * idx + 1);
+          take(v[q].z, 4 * idx + 2);
+          take(v[q].w, 4 * idx + 3);
+        }
+      }
+    }
+  } else {
+    for (int b = tid; b < B; b += kThreads) take(ldg_i32(ids + b), b);
   }
   __syncthreads();
   const int n = n_sh;
   if (n == 0) return;
 
   // ---- 2. sort by (id, b) ------------------------------------------------------------------------
-  int m = 2;
-  while (m < n) m <<= 1;
-  for (int i = n + tid; i < m; i += kThreads) keys[i] = 0xFFFFFFFFu;
-  __syncthreads();
-  for (int k = 2; k <= m; k <<= 1) {
-    for (int s = k >> 1; s > 0; s >>= 1) {
-      for (int i = tid; i < m; i += kThreads) {
-        const int ixs = i ^ s;
-        if (ixs > i) {
-          const uint32_t a = keys[i], b2 = keys[ixs];
-          const bool up = (i & k) == 0;
-          if ((a > b2) == up) {
-            keys[i] = b2;
-            keys[ixs] = a;
+  if (n <= kThreads) {
+    // rank sort: keys are unique, so rank = #smaller is a permutation; 2 barriers instead of ~21-36
+    const uint32_t mine = tid < n ? keys[tid] : 0u;
+    int rank = 0;
+#pragma unroll 8
+    for (int q = 0; q < n; ++q) rank += (keys[q] < mine) ? 1 : 0;  // broadcast LDS reads
+    __syncthreads();
+    if (tid < n) keys[rank] = mine;
+    __syncthreads();
+  } else {
+    int m = 2;
+    while (m < n) m <<= 1;
+    for (int i = n + tid; i < m; i += kThreads) keys[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (int k = 2; k <= m; k <<= 1) {
+      for (int s = k >> 1; s > 0; s >>= 1) {
+        for (int i = tid; i < m; i += kThreads) {
+          const int ixs = i ^ s;
+          if (ixs > i) {
+            const uint32_t a = keys[i], b2 = keys[ixs];
+            const bool up = (i & k) == 0;
+            if ((a > b2) == up) {
+              keys[i] = b2;
+              keys[ixs] = a;
+            }
           }
         }
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
 
@@ -255,6 +293,15 @@ __global__ __launch_bounds__(kThreads) void k_embed_ids(const int32_t* __restric
   ids_t[i] = static_cast<int32_t>(X[static_cast<int64_t>(b) * ldx + units[4 * u + 2]]);
 }
 
+// ~64 entries (one tile) per workgroup up to B = 8192; beyond that every partition's workgroup would
+// re-scan too many ids, so partitions grow to ~256 entries (4 tiles).
+int pick_log2p(int B) {
+  const int per = B > 8192 ? 256 : 64;
+  int l = 0;
+  while ((B >> l) > per && l < 10) ++l;
+  return l;
+}
+
 int ceil_log2(int64_t x) {
   int l = 0;
   while ((int64_t(1) << l) < x) ++l;
@@ -279,8 +326,7 @@ extern "C" int dctr_embed_update_supported(const dctr_plan_t* plan, int64_t max_
   if (plan->vec != 1 && plan->vec != 2 && plan->vec != 4) return 0;
   if (plan->n_deep > 0 && plan->max_dim > 64 * plan->vec) return 0;
   if (B > 32768) return 0;
-  int log2p = 0;
-  while ((B >> log2p) > 64 && log2p < 8) ++log2p;
+  const int log2p = pick_log2p(B);
   const int bbits = ceil_log2(B < 2 ? 2 : B);
   if (ceil_log2(((max_vocab > 0 ? max_vocab : 1) >> log2p) + 1) + bbits > 32) return 0;
   return 1;
@@ -310,8 +356,7 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
   a.gout = g_out; a.out = out; a.fm_s = fm_s; a.gfm = g_fm; a.gwide = g_wide;
   a.ldg = ld_g; a.ldo = ld_out; a.lds_ = ld_s;
   a.n_units = n_units; a.B = B;
-  int log2p = 0;
-  while ((B >> log2p) > 64 && log2p < 8) ++log2p;  // ~64 entries (one tile) per workgroup
+  const int log2p = pick_log2p(B);
   a.log2p = log2p;
   a.bbits = ceil_log2(B < 2 ? 2 : B);
   a.lr = lr; a.eps = eps;

@@ -57,6 +57,11 @@ SIGNATURES = {
     "dctr_embed_bwd": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P,
                                       _I32, _F32, _P]),
     "dctr_embed_apply": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _I32, _F32, _F32, _P]),
+    "dctr_cin_workspace_floats": (ctypes.c_size_t, [_I32, _I32, _I32]),
+    "dctr_cin_layer_fwd": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I64, _P,
+                                          _P]),
+    "dctr_cin_layer_bwd": (ctypes.c_int, [_P, _P, _I64, _I32, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _P, _I64,
+                                          _P, _I64, _I32, _P, _P, _P]),
     "dctr_fm_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P]),
     "dctr_fm_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _I64, _I32, _P]),
 }

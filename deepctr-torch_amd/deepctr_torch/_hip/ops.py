@@ -105,6 +105,11 @@ class EmbedFunction(torch.autograd.Function):
         if (g_out is None and g_fm is None and g_wide is None) or not plan.table_params:
             return None, None, None, g_w, None, None
 
+        if getattr(plan, "exchange", None) is not None:
+            # data-parallel: the trainer all-gathers the row gradients and applies the global update
+            plan.exchange(X=X, g_out=g_out, out=out, fm_s=fm_s, g_fm=g_fm, g_wide=g_wide)
+            return None, None, None, g_w, None, None
+
         update = plan.update
         kind = update[0]
         stream = L.stream_handle(X.device)
@@ -225,3 +230,66 @@ class FMFunction(torch.autograd.Function):
         L.check(lib.dctr_fm_bwd(_ptr(E), E.stride(0) if B > 1 else F * D, B, F, D, _ptr(gy), _ptr(gE), F * D, 0,
                                 L.stream_handle(E.device)), "dctr_fm_bwd")
         return gE
+
+
+# ---- CIN layer (interaction.py:207-248) ----------------------------------------------------------------
+def _rows3(t, what):
+    """[B, R, D] float32 with contiguous (R, D) rows; the batch stride may be anything >= R*D (views of the
+    gather's output and of a previous layer's feature maps pass through without a copy)."""
+    L.require_gpu(t, what)
+    if t.dtype != torch.float32:
+        t = t.float()
+    B, R, D = t.shape
+    if (D > 1 and t.stride(2) != 1) or (R > 1 and t.stride(1) != D) or (B > 1 and t.stride(0) < R * D):
+        t = t.contiguous()
+    return t, (t.stride(0) if B > 1 else R * D)
+
+
+def cin_layer_forward(H, X0, W2d, bias, relu):
+    """A = act(W . (H (x) X0) + bias): ``[B, h, D], [B, M, D] -> [B, O, D]`` (no autograd; see CINLayerFunction)."""
+    lib = L.lib()
+    H, ldh = _rows3(H, "CIN hidden input")
+    X0, ldx = _rows3(X0, "CIN field input")
+    B, h, D = H.shape
+    M = X0.shape[1]
+    O = W2d.shape[0]
+    if M > 32:
+        raise NotImplementedError("the gfx950 CIN kernels support at most 32 fields (got %d)" % M)
+    W2d = W2d.contiguous()
+    A = torch.empty((B, O, D), dtype=torch.float32, device=H.device)
+    ws = torch.empty((lib.dctr_cin_workspace_floats(h, M, O),), dtype=torch.float32, device=H.device)
+    L.check(lib.dctr_cin_layer_fwd(_ptr(H), ldh, _ptr(X0), ldx, _ptr(W2d), _ptr(bias), B, h, M, D, O, int(bool(relu)),
+                                   _ptr(A), O * D, _ptr(ws), L.stream_handle(H.device)), "dctr_cin_layer_fwd")
+    return A
+
+
+class CINLayerFunction(torch.autograd.Function):
+    """One CIN layer with the activation (relu or none) fused: ``dctr_cin_layer_fwd`` / ``dctr_cin_layer_bwd``."""
+
+    @staticmethod
+    def forward(ctx, H, X0, W2d, bias, relu):
+        A = cin_layer_forward(H, X0, W2d, bias, relu)
+        ctx.relu = bool(relu)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(H, X0, W2d, A if relu else None)
+        return A
+
+    @staticmethod
+    def backward(ctx, gA):
+        lib = L.lib()
+        H, X0, W2d, A = ctx.saved_tensors
+        H, ldh = _rows3(H, "CIN hidden input")
+        X0, ldx = _rows3(X0, "CIN field input")
+        B, h, D = H.shape
+        M, O = X0.shape[1], W2d.shape[0]
+        gA = gA.contiguous().float()
+        W2d = W2d.contiguous()
+        dev = H.device
+        gH = torch.empty((B, h, D), dtype=torch.float32, device=dev)
+        gX0 = torch.empty((B, M, D), dtype=torch.float32, device=dev)
+        gW = torch.empty((O, h * M), dtype=torch.float32, device=dev)
+        gb = torch.empty((O,), dtype=torch.float32, device=dev) if ctx.has_bias else None
+        L.check(lib.dctr_cin_layer_bwd(_ptr(gA), _ptr(A), O * D, int(ctx.relu), _ptr(H), ldh, _ptr(X0), ldx, _ptr(W2d),
+                                       B, h, M, D, O, _ptr(gH), h * D, _ptr(gX0), M * D, 0, _ptr(gW), _ptr(gb),
+                                       L.stream_handle(dev)), "dctr_cin_layer_bwd")
+        return gH, gX0, gW, gb, None

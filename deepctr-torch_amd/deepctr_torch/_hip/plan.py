@@ -149,6 +149,7 @@ class EmbeddingPlan(object):
         self.version = 0   # bumps whenever device pointers were re-baked (HIP graphs must re-capture)
         self._owner = None
         self._update = ("dense",)
+        self.exchange = None   # set by parallel.DataParallelTrainer: backward hands row gradients over
         self._reset_device_image()
 
     def _reset_device_image(self):
@@ -165,6 +166,7 @@ class EmbeddingPlan(object):
         d = dict(self.__dict__)
         for k in ("_key", "_dev", "cplan", "anchor", "_err", "_wd_idx"):
             d.pop(k, None)
+        d["exchange"] = None
         return d
 
     def __setstate__(self, d):

@@ -2,5 +2,6 @@
 and ``state_dict`` keys are the reference's (``deepctr_torch/models/*.py``)."""
 from .basemodel import BaseModel, Linear
 from .deepfm import DeepFM
+from .xdeepfm import xDeepFM
 
-__all__ = ["BaseModel", "Linear", "DeepFM"]
+__all__ = ["BaseModel", "Linear", "DeepFM", "xDeepFM"]

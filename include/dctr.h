@@ -172,6 +172,28 @@ int dctr_fm_fwd(const float* E, int64_t ld_b, int32_t B, int32_t F, int32_t D, f
 int dctr_fm_bwd(const float* E, int64_t ld_b, int32_t B, int32_t F, int32_t D, const float* gy,
                 float* gE, int64_t ld_gb, int32_t accumulate, dctr_stream_t stream);
 
+/* ---- CIN layer (interaction.py:207-248) on fp32 MFMA (csrc/cin.hip) -------------------------------
+ * One Compressed-Interaction layer without ever materialising Z = H (x) X0:
+ *     Y[b, o, d] = sum_{h, m} W[o, h*M + m] * H[b, h, d] * X0[b, m, d] + bias[o];   A = relu(Y) if relu
+ *   H    [B, h, D]  rows at H  + b*ld_h   (previous layer's "next_hidden", or X0 for layer 0)
+ *   X0   [B, M, D]  rows at X0 + b*ld_x0  (the field embeddings; a view of dctr_embed_fwd's `out`)
+ *   W    [O, h*M]   conv1ds.<k>.weight with its trailing 1 squeezed;  bias [O] (nullable)
+ *   A    [B, O, D]  rows at A + b*ld_a
+ *   workspace  dctr_cin_workspace_floats(h, M, O) floats (the kernel's re-laid-out copy of W)
+ * Needs M <= 32.  The split_half / sum over d / concat of the reference stay with the caller.
+ * Backward, given gA = d loss / d A (and the saved A when relu):
+ *   gH   [B, h, D]  (written)      gX0 [B, M, D] (accumulated: += when accumulate_x0 != 0)
+ *   gW   [O, h*M]   (written)      gbias [O]     (written, nullable)
+ * gA and A share the leading dimension ld_a.                                                         */
+size_t dctr_cin_workspace_floats(int32_t h, int32_t M, int32_t O);
+int dctr_cin_layer_fwd(const float* H, int64_t ld_h, const float* X0, int64_t ld_x0, const float* W,
+                       const float* bias, int32_t B, int32_t h, int32_t M, int32_t D, int32_t O, int32_t relu,
+                       float* A, int64_t ld_a, float* workspace, dctr_stream_t stream);
+int dctr_cin_layer_bwd(const float* gA, const float* A, int64_t ld_a, int32_t relu, const float* H, int64_t ld_h,
+                       const float* X0, int64_t ld_x0, const float* W, int32_t B, int32_t h, int32_t M, int32_t D,
+                       int32_t O, float* gH, int64_t ld_gh, float* gX0, int64_t ld_gx, int32_t accumulate_x0,
+                       float* gW, float* gbias, dctr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

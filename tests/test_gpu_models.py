@@ -1,0 +1,79 @@
+"""GPU parity of the other drop-in model families (xDeepFM / FiBiNET / DCN / PNN) against the golden vectors the
+real reference produced (tests/golden, oracle/make_golden.py) and the numpy oracle: pre-sigmoid logits within 1e-5
+(north_star), every parameter gradient, and 3-step SGD / Adagrad trajectories with the fused sparse update."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_model, golden_names, load_golden, max_abs
+from np_oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LOGIT_TOL, GRAD_TOL, TRAJ_TOL = 1e-5, 2e-5, 2e-5
+NAMES = [n for n in golden_names() if not n.startswith("deepfm")]
+
+
+def _loaded(name, l2=0.0):
+    g = load_golden(name)
+    m = build_model(g["spec"], DEV, l2=l2)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in g["params"].items()})
+    return g, m
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_forward_logits_match_reference(name):
+    g, m = _loaded(name)
+    m.eval()
+    cap = {}
+    h = m.out.register_forward_pre_hook(lambda mod, inp: cap.__setitem__("logit", inp[0].detach()))
+    with torch.no_grad():
+        y = m(torch.from_numpy(g["X"]).to(DEV))
+    h.remove()
+    torch.cuda.synchronize()
+    m.model_plan().check_ids()
+    err = max_abs(cap["logit"].cpu().numpy(), g["logit"])
+    assert err <= LOGIT_TOL, "logit max|d|=%.3e" % err
+    assert max_abs(y.cpu().numpy(), g["y_pred"]) <= LOGIT_TOL
+    l64, _ = Oracle(g["spec"], g["params"], dtype=np.float64).forward(g["X"])
+    assert max_abs(cap["logit"].cpu().numpy(), l64) <= LOGIT_TOL
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_gradients_match_reference(name):
+    g, m = _loaded(name)
+    m.train()
+    X, y = torch.from_numpy(g["X"]).to(DEV), torch.from_numpy(g["y"]).to(DEV)
+    loss = torch.nn.functional.binary_cross_entropy(m(X).squeeze(), y, reduction="sum")
+    m.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - g["loss"]) <= 1e-4 * max(1.0, abs(g["loss"]))
+    for k, p in m.named_parameters():
+        ref = g["grads"][k]
+        got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(ref)
+        scale = max(1.0, float(np.max(np.abs(ref))))
+        err = max_abs(got, ref)
+        assert err <= GRAD_TOL * scale, "%s: max|d|=%.3e scale %.3g" % (k, err, scale)
+
+
+@pytest.mark.parametrize("name", [n for n in NAMES if "X_steps" in load_golden(n)["extra"]])
+@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
+def test_training_trajectory_matches_reference(name, opt):
+    g, m = _loaded(name)
+    if (opt + "3_loss") not in g["extra"]:
+        pytest.skip("no %s trajectory in this fixture" % opt)
+    m.compile(opt, "binary_crossentropy", metrics=[])
+    m.train()
+    losses = []
+    for Xb, yb in zip(g["extra"]["X_steps"], g["extra"]["y_steps"]):
+        loss, _, _ = m._train_step(torch.from_numpy(Xb).to(DEV), torch.from_numpy(yb).to(DEV))
+        losses.append(loss.item())
+    m.model_plan().check_ids()
+    np.testing.assert_allclose(losses, g["extra"][opt + "3_loss"], rtol=2e-5)
+    sd = m.state_dict()
+    for k, v in g["extra"].items():
+        if k.startswith(opt + "3/"):
+            key = k[len(opt) + 2:]
+            err = max_abs(sd[key].cpu().numpy(), v)
+            assert err <= TRAJ_TOL, "%s: %.3e" % (key, err)
