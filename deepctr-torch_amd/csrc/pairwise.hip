@@ -1,0 +1,631 @@
+// pairwise.hip -- the pair-structured interaction layers of FiBiNET and PNN on gfx950:
+//   SENETLayer          (interaction.py:93-101)   z = mean_d E ; a = relu(W2 relu(W1 z)) ; V = E * a
+//   BilinearInteraction (interaction.py:140-156)  p_k = (x_i W_k^T) (.) x_j   for the F(F-1)/2 pairs, types all/each/interaction
+//   InnerProductLayer   (interaction.py:557-577)  p_k = sum_d e_i e_j  (or the un-reduced product)
+//
+// The reference issues 325 tiny nn.Linear calls + 325 muls + a 650-way cat per Bilinear call (10.8 k launches per
+// FiBiNET step, 62 % of its time in aten::cat).  Here a workgroup owns 16 samples, keeps their [16, F*D] embedding
+// tile in LDS, and walks the pairs; the 16x16 weight tiles go through v_mfma_f32_16x16x4_f32 (exact fp32) with the
+// 16 samples as the row dimension.  FiBiNET applies the SAME weights to the SENET output V and to the raw E
+// (fibinet.py:82-83): both passes share one weight-tile load, and the kernel writes straight into the reference's
+// DNN-input layout  [ V pairs | E pairs | dense ]  (fibinet.py:86-87) -- nothing is concatenated afterwards.
+//
+// Determinism: pairs are visited in round-robin-tournament order -- every round is a perfect matching, so the four
+// waves of a workgroup never touch the same field inside a round and the per-field gradient tiles in LDS are
+// accumulated with plain read-modify-writes in round order (no float atomics, bit-reproducible).  Parameter
+// gradients (reductions over the batch) go to per-workgroup partial slabs that a second kernel sums in fixed order.
+#include "common.hpp"
+
+using namespace dctr;
+
+namespace {
+
+constexpr int kT = 256;
+constexpr int kSB = 16;  // samples per workgroup (= MFMA rows)
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int row_stride(int F, int D) {
+  // floats per sample row in LDS; (RS mod 32) == 16 spreads consecutive samples over both bank halves
+  int rs = F * D;
+  rs += (16 - (rs & 31)) & 31;
+  return rs;
+}
+
+// copy the [16, F*D] tile of samples b0.. into LDS (zeros past B)
+__device__ __forceinline__ void stage_rows(float* dst, int RS, const float* __restrict__ src, int64_t ld, int b0,
+                                           int B, int W) {
+  for (int e = threadIdx.x; e < kSB * W; e += kT) {
+    const int r = e / W, c = e - r * W;
+    dst[r * RS + c] = (b0 + r < B) ? ldg_f32(src + static_cast<int64_t>(b0 + r) * ld + c) : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// SENET
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kSS = 8;  // samples per workgroup in the SENET kernels
+
+__global__ __launch_bounds__(kT) void k_senet_fwd(const float* __restrict__ E, int64_t lde, int B, int F, int D,
+                                                  const float* __restrict__ W1, const float* __restrict__ W2, int R,
+                                                  float* __restrict__ V, float* __restrict__ a_out,
+                                                  float* __restrict__ a1_out) {
+  extern __shared__ __align__(16) float smem[];
+  const int W = F * D;
+  float* es = smem;             // [kSS][W]
+  float* z = es + kSS * W;      // [kSS][F]
+  float* a1 = z + kSS * F;      // [kSS][R]
+  float* a = a1 + kSS * R;      // [kSS][F]
+  const int tid = threadIdx.x, b0 = blockIdx.x * kSS;
+  for (int e = tid; e < kSS * W; e += kT) {
+    const int r = e / W, c = e - r * W;
+    es[e] = (b0 + r < B) ? ldg_f32(E + static_cast<int64_t>(b0 + r) * lde + c) : 0.f;
+  }
+  __syncthreads();
+  for (int e = tid; e < kSS * F; e += kT) {  // torch.mean(inputs, dim=-1)
+    const int r = e / F, f = e - r * F;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s += es[r * W + f * D + d];
+    z[e] = s / static_cast<float>(D);
+  }
+  __syncthreads();
+  for (int e = tid; e < kSS * R; e += kT) {  // relu(Linear(F -> R, no bias))
+    const int r = e / R, q = e - r * R;
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) s += z[r * F + f] * ldg_f32(W1 + q * F + f);
+    a1[e] = s > 0.f ? s : 0.f;
+  }
+  __syncthreads();
+  for (int e = tid; e < kSS * F; e += kT) {  // relu(Linear(R -> F, no bias))
+    const int r = e / F, f = e - r * F;
+    float s = 0.f;
+    for (int q = 0; q < R; ++q) s += a1[r * R + q] * ldg_f32(W2 + f * R + q);
+    a[e] = s > 0.f ? s : 0.f;
+  }
+  __syncthreads();
+  for (int e = tid; e < kSS * W; e += kT) {
+    const int r = e / W, c = e - r * W;
+    if (b0 + r < B) stg_f32(V + static_cast<int64_t>(b0 + r) * W + c, es[e] * a[r * F + c / D]);
+  }
+  for (int e = tid; e < kSS * F; e += kT) {
+    const int r = e / F;
+    if (b0 + r < B) stg_f32(a_out + static_cast<int64_t>(b0) * F + e, a[e]);
+  }
+  for (int e = tid; e < kSS * R; e += kT) {
+    const int r = e / R;
+    if (b0 + r < B) stg_f32(a1_out + static_cast<int64_t>(b0) * R + e, a1[e]);
+  }
+}
+
+// gE = gV*a + (1/D) * W1^T ga1' ;  partial gW1 / gW2 of this workgroup's samples go to part[blockIdx.x]
+__global__ __launch_bounds__(kT) void k_senet_bwd(const float* __restrict__ gV, const float* __restrict__ E,
+                                                  int64_t lde, int B, int F, int D, const float* __restrict__ W1,
+                                                  const float* __restrict__ W2, int R,
+                                                  const float* __restrict__ a_in, const float* __restrict__ a1_in,
+                                                  float* __restrict__ gE, float* __restrict__ part) {
+  extern __shared__ __align__(16) float smem[];
+  const int W = F * D;
+  float* es = smem;              // [kSS][W]
+  float* gv = es + kSS * W;      // [kSS][W]
+  float* z = gv + kSS * W;       // [kSS][F]
+  float* ga = z + kSS * F;       // [kSS][F]  masked
+  float* ga1 = ga + kSS * F;     // [kSS][R]  masked
+  float* gz = ga1 + kSS * R;     // [kSS][F]
+  const int tid = threadIdx.x, b0 = blockIdx.x * kSS;
+  for (int e = tid; e < kSS * W; e += kT) {
+    const int r = e / W, c = e - r * W;
+    const bool v = b0 + r < B;
+    es[e] = v ? ldg_f32(E + static_cast<int64_t>(b0 + r) * lde + c) : 0.f;
+    gv[e] = v ? ldg_f32(gV + static_cast<int64_t>(b0 + r) * W + c) : 0.f;
+  }
+  __syncthreads();
+  for (int e = tid; e < kSS * F; e += kT) {
+    const int r = e / F, f = e - r * F;
+    float s = 0.f, g = 0.f;
+    for (int d = 0; d < D; ++d) {
+      s += es[r * W + f * D + d];
+      g += gv[r * W + f * D + d] * es[r * W + f * D + d];
+    }
+    z[e] = s / static_cast<float>(D);
+    const float av = (b0 + r < B) ? ldg_f32(a_in + static_cast<int64_t>(b0) * F + e) : 0.f;
+    ga[e] = av > 0.f ? g : 0.f;
+  }
+  __syncthreads();
+  for (int e = tid; e < kSS * R; e += kT) {
+    const int r = e / R, q = e - r * R;
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) s += ga[r * F + f] * ldg_f32(W2 + f * R + q);
+    const float a1v = (b0 + r < B) ? ldg_f32(a1_in + static_cast<int64_t>(b0) * R + e) : 0.f;
+    ga1[e] = a1v > 0.f ? s : 0.f;
+  }
+  __syncthreads();
+  for (int e = tid; e < kSS * F; e += kT) {
+    const int r = e / F, f = e - r * F;
+    float s = 0.f;
+    for (int q = 0; q < R; ++q) s += ga1[r * R + q] * ldg_f32(W1 + q * F + f);
+    gz[e] = s / static_cast<float>(D);
+  }
+  __syncthreads();
+  for (int e = tid; e < kSS * W; e += kT) {
+    const int r = e / W, c = e - r * W, f = c / D;
+    if (b0 + r < B) {
+      const float av = ldg_f32(a_in + static_cast<int64_t>(b0 + r) * F + f);
+      stg_f32(gE + static_cast<int64_t>(b0 + r) * W + c, gv[e] * av + gz[r * F + f]);
+    }
+  }
+  // parameter-gradient partials: gW1[q][f] = sum_r ga1[r][q] z[r][f] ; gW2[f][q] = sum_r ga[r][f] a1[r][q]
+  float* mine = part + static_cast<int64_t>(blockIdx.x) * (2 * R * F);
+  for (int e = tid; e < R * F; e += kT) {
+    const int q = e / F, f = e - q * F;
+    float s1 = 0.f;
+    for (int r = 0; r < kSS; ++r) s1 += ga1[r * R + q] * z[r * F + f];
+    mine[e] = s1;
+  }
+  for (int e = tid; e < F * R; e += kT) {
+    const int f = e / R, q = e - f * R;
+    float s2 = 0.f;
+    for (int r = 0; r < kSS; ++r) {
+      const float a1v = (b0 + r < B) ? ldg_f32(a1_in + static_cast<int64_t>(b0 + r) * R + q) : 0.f;
+      s2 += ga[r * F + f] * a1v;
+    }
+    mine[R * F + e] = s2;
+  }
+}
+
+// out[i] = sum_g part[g * stride + i], i < count  (fixed order)
+__global__ __launch_bounds__(kT) void k_reduce_partials(const float* __restrict__ part, int64_t stride,
+                                                        int64_t count, int groups, float* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int g = 0; g < groups; ++g) s += ldg_f32(part + static_cast<int64_t>(g) * stride + i);
+  out[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Bilinear.  sched: [n_sched][4] int32 = {i, j, weight index, pair index k}, i = -1 for an idle slot; entries are
+// in round-robin order, `slots` entries per round (a perfect matching of the fields).
+// MFMA contraction index: d = 4*g + s  (g = lane >> 4, s = step), identical on both operands.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void k_bilinear_fwd(const float* __restrict__ E, int64_t lde,
+                                                     const float* __restrict__ V, int64_t ldv,
+                                                     const float* __restrict__ Wf, const int32_t* __restrict__ sched,
+                                                     int n_sched, int P, int F, int D, int B,
+                                                     float* __restrict__ out, int64_t ldo,
+                                                     const float* __restrict__ dense, int64_t ldd, int n_dense,
+                                                     int dense_off) {
+  extern __shared__ __align__(16) float smem[];
+  const int RS = row_stride(F, D), W = F * D;
+  float* xs0 = smem;               // V tile (pass 0), or E when V == nullptr
+  float* xs1 = xs0 + kSB * RS;     // E tile (pass 1)
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int b0 = blockIdx.x * kSB;
+  const int npass = V ? 2 : 1;
+  stage_rows(xs0, RS, V ? V : E, V ? ldv : lde, b0, B, W);
+  if (V) stage_rows(xs1, RS, E, lde, b0, B, W);
+  if (dense)
+    for (int e = tid; e < kSB * n_dense; e += kT) {
+      const int r = e / n_dense, q = e - r * n_dense;
+      if (b0 + r < B)
+        stg_f32(out + static_cast<int64_t>(b0 + r) * ldo + dense_off + q,
+                ldg_f32(dense + static_cast<int64_t>(b0 + r) * ldd + q));
+    }
+  __syncthreads();
+  for (int q = wv; q < n_sched; q += 4) {
+    const int i = ldg_i32(sched + 4 * q);
+    if (i < 0) continue;
+    const int j = ldg_i32(sched + 4 * q + 1), wi = ldg_i32(sched + 4 * q + 2), k = ldg_i32(sched + 4 * q + 3);
+    float wreg[4];  // B operand: W[e = c][d = 4g + s]
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int d = 4 * g + s;
+      wreg[s] = (c < D && d < D) ? ldg_f32(Wf + (static_cast<int64_t>(wi) * D + c) * D + d) : 0.f;
+    }
+    for (int ps = 0; ps < npass; ++ps) {
+      const float* xs = ps ? xs1 : xs0;
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int d = 4 * g + s;
+        const float a = d < D ? xs[c * RS + i * D + d] : 0.f;  // A operand: x_i[b = c][d]
+        t = mfma16(a, wreg[s], t);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {  // t[r] = (x_i W^T)[b = 4g + r][e = c]
+        const int b = 4 * g + r;
+        if (c < D && b0 + b < B)
+          stg_f32(out + static_cast<int64_t>(b0 + b) * ldo + (static_cast<int64_t>(ps) * P + k) * D + c,
+                  t[r] * xs[b * RS + j * D + c]);
+      }
+    }
+  }
+}
+
+// gradient w.r.t. the inputs: gX_j += gp (.) t ; gX_i += (gp (.) x_j) W    (per pass: V then E)
+__global__ __launch_bounds__(kT) void k_bilinear_bwd_data(const float* __restrict__ E, int64_t lde,
+                                                          const float* __restrict__ V, int64_t ldv,
+                                                          const float* __restrict__ Wf,
+                                                          const int32_t* __restrict__ sched, int n_sched, int slots,
+                                                          int P, int F, int D, int B, const float* __restrict__ gout,
+                                                          int64_t ldg, float* __restrict__ gE, float* __restrict__ gV) {
+  extern __shared__ __align__(16) float smem[];
+  const int RS = row_stride(F, D), W = F * D;
+  float* xs0 = smem;
+  float* xs1 = xs0 + kSB * RS;
+  float* gx0 = xs1 + kSB * RS;
+  float* gx1 = gx0 + kSB * RS;
+  float* tb = gx1 + kSB * RS;  // [4 waves][16][17] layout-change scratch
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int b0 = blockIdx.x * kSB;
+  const int npass = V ? 2 : 1;
+  stage_rows(xs0, RS, V ? V : E, V ? ldv : lde, b0, B, W);
+  if (V) stage_rows(xs1, RS, E, lde, b0, B, W);
+  for (int e = tid; e < 2 * kSB * RS; e += kT) gx0[e] = 0.f;
+  __syncthreads();
+  float* mytb = tb + wv * (16 * 17);
+  const int nrounds = (n_sched + slots - 1) / slots;
+  for (int rd = 0; rd < nrounds; ++rd) {
+    for (int sl = wv; sl < slots; sl += 4) {
+      const int q = rd * slots + sl;
+      if (q >= n_sched) break;
+      const int i = ldg_i32(sched + 4 * q);
+      if (i < 0) continue;
+      const int j = ldg_i32(sched + 4 * q + 1), wi = ldg_i32(sched + 4 * q + 2), k = ldg_i32(sched + 4 * q + 3);
+      float wreg[4], wT[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int d = 4 * g + s;
+        wreg[s] = (c < D && d < D) ? ldg_f32(Wf + (static_cast<int64_t>(wi) * D + c) * D + d) : 0.f;  // W[e=c][d]
+        wT[s] = (c < D && d < D) ? ldg_f32(Wf + (static_cast<int64_t>(wi) * D + d) * D + c) : 0.f;    // W[e=d'][d=c]
+      }
+      for (int ps = 0; ps < npass; ++ps) {
+        const float* xs = ps ? xs1 : xs0;
+        float* gx = ps ? gx1 : gx0;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int d = 4 * g + s;
+          t = mfma16(d < D ? xs[c * RS + i * D + d] : 0.f, wreg[s], t);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int b = 4 * g + r;
+          float gp = 0.f;
+          if (c < D && b0 + b < B)
+            gp = ldg_f32(gout + static_cast<int64_t>(b0 + b) * ldg + (static_cast<int64_t>(ps) * P + k) * D + c);
+          if (c < D) gx[b * RS + j * D + c] += gp * t[r];            // gX_j[b][e]
+          mytb[b * 17 + c] = (c < D) ? gp * xs[b * RS + j * D + c] : 0.f;  // g_t[b][e] in C layout
+        }
+        // g_xi[b][d] = sum_e g_t[b][e] W[e][d]: A operand g_t[b = c][e = 4g + s], B operand W[e = 4g + s][d = c]
+        f32x4 u = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) u = mfma16(mytb[c * 17 + 4 * g + s], wT[s], u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int b = 4 * g + r;
+          if (c < D) gx[b * RS + i * D + c] += u[r];
+        }
+      }
+    }
+    __syncthreads();  // next round touches other (field) columns of gx; rounds are perfect matchings
+  }
+  for (int e = tid; e < kSB * W; e += kT) {
+    const int r = e / W, cc = e - r * W;
+    if (b0 + r < B) {
+      if (V) {
+        stg_f32(gV + static_cast<int64_t>(b0 + r) * W + cc, gx0[r * RS + cc]);
+        stg_f32(gE + static_cast<int64_t>(b0 + r) * W + cc, gx1[r * RS + cc]);
+      } else {
+        stg_f32(gE + static_cast<int64_t>(b0 + r) * W + cc, gx0[r * RS + cc]);
+      }
+    }
+  }
+}
+
+// gradient w.r.t. the weights: gW_k[e][d] = sum_b (gp (.) x_j)[b][e] x_i[b][d], both passes.
+// Workgroup (sample group sg, pair slice): partial[sg][k][e][d]; rows = e, columns = d, reduction = samples.
+__global__ __launch_bounds__(kT) void k_bilinear_bwd_weight(const float* __restrict__ E, int64_t lde,
+                                                            const float* __restrict__ V, int64_t ldv,
+                                                            const int32_t* __restrict__ sched, int n_sched, int P,
+                                                            int F, int D, int B, const float* __restrict__ gout,
+                                                            int64_t ldg, int tiles_per_group,
+                                                            float* __restrict__ part) {
+  extern __shared__ __align__(16) float smem[];
+  const int RS = row_stride(F, D), W = F * D;
+  float* xs0 = smem;
+  float* xs1 = xs0 + kSB * RS;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int sg = blockIdx.x;
+  const int npass = V ? 2 : 1;
+  // this wave's pairs: q = blockIdx.y*4 + wv, stepping by 4*gridDim.y; at most 8 live accumulators
+  constexpr int MAXQ = 8;
+  f32x4 acc[MAXQ];
+  const int qstep = 4 * gridDim.y, q0 = blockIdx.y * 4 + wv;
+  for (int base = 0; base < n_sched; base += qstep * MAXQ) {
+#pragma unroll
+    for (int a = 0; a < MAXQ; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tl = 0; tl < tiles_per_group; ++tl) {
+      const int b0 = (sg * tiles_per_group + tl) * kSB;
+      __syncthreads();
+      if (b0 < B) {
+        stage_rows(xs0, RS, V ? V : E, V ? ldv : lde, b0, B, W);
+        if (V) stage_rows(xs1, RS, E, lde, b0, B, W);
+      }
+      __syncthreads();
+      if (b0 >= B) continue;
+#pragma unroll
+      for (int a = 0; a < MAXQ; ++a) {
+        const int q = base + q0 + a * qstep;
+        if (q >= n_sched) continue;
+        const int i = ldg_i32(sched + 4 * q);
+        if (i < 0) continue;
+        const int j = ldg_i32(sched + 4 * q + 1), k = ldg_i32(sched + 4 * q + 3);
+        for (int ps = 0; ps < npass; ++ps) {
+          const float* xs = ps ? xs1 : xs0;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int b = 4 * g + s;  // reduction index = sample
+            float gp = 0.f;
+            if (c < D && b0 + b < B)
+              gp = ldg_f32(gout + static_cast<int64_t>(b0 + b) * ldg + (static_cast<int64_t>(ps) * P + k) * D + c);
+            const float gt = (c < D) ? gp * xs[b * RS + j * D + c] : 0.f;   // A: g_t[b][e = c]
+            const float xi = (c < D) ? xs[b * RS + i * D + c] : 0.f;        // B: x_i[b][d = c]
+            acc[a] = mfma16(gt, xi, acc[a]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < MAXQ; ++a) {
+      const int q = base + q0 + a * qstep;
+      if (q >= n_sched) continue;
+      if (ldg_i32(sched + 4 * q) < 0) continue;
+      const int k = ldg_i32(sched + 4 * q + 3);
+      float* dst = part + (static_cast<int64_t>(sg) * P + k) * D * D;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = 4 * g + r;  // row = e, column = d = c
+        if (e < D && c < D) stg_f32(dst + e * D + c, acc[a][r]);
+      }
+    }
+  }
+}
+
+// gW[w][e][d] = sum over the pairs k with weight index w, over sample groups:  fixed order
+__global__ __launch_bounds__(kT) void k_bilinear_reduce_w(const float* __restrict__ part, int groups, int P, int DD,
+                                                          const int32_t* __restrict__ pair_w, int n_w,
+                                                          float* __restrict__ gW) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+  if (idx >= static_cast<int64_t>(n_w) * DD) return;
+  const int w = static_cast<int>(idx / DD), el = static_cast<int>(idx - static_cast<int64_t>(w) * DD);
+  float s = 0.f;
+  for (int k = 0; k < P; ++k) {
+    if (ldg_i32(pair_w + k) != w) continue;
+    for (int gq = 0; gq < groups; ++gq) s += ldg_f32(part + (static_cast<int64_t>(gq) * P + k) * DD + el);
+  }
+  gW[idx] = s;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// InnerProduct:  p[b, k] = sum_d e_i e_j  (reduce) or p[b, k, :] = e_i (.) e_j;  pair k = (i, j), i < j, i outer
+// ------------------------------------------------------------------------------------------------------------
+template <int kSB>
+__global__ __launch_bounds__(kT) void k_inner_fwd(const float* __restrict__ E, int64_t lde, int B, int F, int D,
+                                                  int reduce, float* __restrict__ out, int64_t ldo) {
+  extern __shared__ __align__(16) float smem[];
+  const int W = F * D, P = F * (F - 1) / 2;
+  float* es = smem;  // [kSB][W + 1]
+  const int b0 = blockIdx.x * kSB;
+  for (int e = threadIdx.x; e < kSB * W; e += kT) {
+    const int r = e / W, c = e - r * W;
+    es[r * (W + 1) + c] = (b0 + r < B) ? ldg_f32(E + static_cast<int64_t>(b0 + r) * lde + c) : 0.f;
+  }
+  __syncthreads();
+  const int per = reduce ? 1 : D;
+  for (int e = threadIdx.x; e < kSB * P * per; e += kT) {
+    const int r = e / (P * per), rem = e - r * (P * per), k = rem / per, d0 = rem - k * per;
+    // pair index -> (i, j)
+    int i = 0, kk = k;
+    while (kk >= F - 1 - i) {
+      kk -= F - 1 - i;
+      ++i;
+    }
+    const int j = i + 1 + kk;
+    const float* xi = es + r * (W + 1) + i * D;
+    const float* xj = es + r * (W + 1) + j * D;
+    float s;
+    if (reduce) {
+      s = 0.f;
+      for (int d = 0; d < D; ++d) s += xi[d] * xj[d];
+    } else {
+      s = xi[d0] * xj[d0];
+    }
+    if (b0 + r < B) stg_f32(out + static_cast<int64_t>(b0 + r) * ldo + rem, s);
+  }
+}
+
+// gE[b, f, d] = sum_{g != f} gp[b, pair(f, g)] (* per-d if not reduced) * E[b, g, d]
+template <int kSB>
+__global__ __launch_bounds__(kT) void k_inner_bwd(const float* __restrict__ E, int64_t lde, int B, int F, int D,
+                                                  int reduce, const float* __restrict__ gp, int64_t ldg,
+                                                  float* __restrict__ gE, int64_t ldge) {
+  extern __shared__ __align__(16) float smem[];
+  const int W = F * D, P = F * (F - 1) / 2, per = reduce ? 1 : D;
+  float* es = smem;                    // [kSB][W + 1]
+  float* gs = es + kSB * (W + 1);      // [kSB][P*per + 1]
+  const int GS = P * per + 1;
+  const int b0 = blockIdx.x * kSB;
+  for (int e = threadIdx.x; e < kSB * W; e += kT) {
+    const int r = e / W, c = e - r * W;
+    es[r * (W + 1) + c] = (b0 + r < B) ? ldg_f32(E + static_cast<int64_t>(b0 + r) * lde + c) : 0.f;
+  }
+  for (int e = threadIdx.x; e < kSB * P * per; e += kT) {
+    const int r = e / (P * per), c = e - r * (P * per);
+    gs[r * GS + c] = (b0 + r < B) ? ldg_f32(gp + static_cast<int64_t>(b0 + r) * ldg + c) : 0.f;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < kSB * W; e += kT) {
+    const int r = e / W, c = e - r * W, f = c / D, d = c - f * D;
+    float s = 0.f;
+    for (int o = 0; o < F; ++o) {
+      if (o == f) continue;
+      const int i = o < f ? o : f, j = o < f ? f : o;
+      const int k = i * F - i * (i + 1) / 2 + (j - i - 1);
+      s += gs[r * GS + k * per + (reduce ? 0 : d)] * es[r * (W + 1) + o * D + d];
+    }
+    if (b0 + r < B) stg_f32(gE + static_cast<int64_t>(b0 + r) * ldge + c, s);
+  }
+}
+
+size_t tile_bytes(int F, int D, int tiles) {
+  int rs = F * D;
+  rs += (16 - (rs & 31)) & 31;
+  return static_cast<size_t>(tiles) * kSB * rs * sizeof(float);
+}
+
+}  // namespace
+
+extern "C" int dctr_senet_fwd(const float* E, int64_t ld_e, int32_t B, int32_t F, int32_t D, const float* W1,
+                              const float* W2, int32_t R, float* V, float* a, float* a1, dctr_stream_t stream) {
+  if (!E || !W1 || !W2 || !V || !a || !a1 || B < 0 || F <= 0 || D <= 0 || R <= 0 || ld_e < static_cast<int64_t>(F) * D)
+    return DCTR_EINVAL;
+  if (B == 0) return DCTR_OK;
+  const size_t lds = (static_cast<size_t>(kSS) * F * D + 2u * kSS * F + static_cast<size_t>(kSS) * R) * sizeof(float);
+  if (lds > 64 * 1024) return DCTR_ENOSUP;
+  k_senet_fwd<<<dim3((B + kSS - 1) / kSS), dim3(kT), lds, static_cast<hipStream_t>(stream)>>>(E, ld_e, B, F, D, W1, W2,
+                                                                                            R, V, a, a1);
+  return launch_status();
+}
+
+extern "C" size_t dctr_senet_bwd_workspace_floats(int32_t B, int32_t F, int32_t R) {
+  return static_cast<size_t>((B + kSS - 1) / kSS) * 2u * R * F;
+}
+
+extern "C" int dctr_senet_bwd(const float* gV, const float* E, int64_t ld_e, int32_t B, int32_t F, int32_t D,
+                              const float* W1, const float* W2, int32_t R, const float* a, const float* a1,
+                              float* gE, float* gW1, float* gW2, float* workspace, dctr_stream_t stream) {
+  if (!gV || !E || !W1 || !W2 || !a || !a1 || !gE || !gW1 || !gW2 || !workspace || B < 0 || F <= 0 || D <= 0 || R <= 0)
+    return DCTR_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (B == 0) {
+    (void)hipMemsetAsync(gW1, 0, sizeof(float) * R * F, s);
+    (void)hipMemsetAsync(gW2, 0, sizeof(float) * R * F, s);
+    return DCTR_OK;
+  }
+  const int groups = (B + kSS - 1) / kSS;
+  const size_t lds = (2u * kSS * F * D + 3u * kSS * F + static_cast<size_t>(kSS) * R) * sizeof(float);
+  if (lds > 64 * 1024) return DCTR_ENOSUP;
+  k_senet_bwd<<<dim3(groups), dim3(kT), lds, s>>>(gV, E, ld_e, B, F, D, W1, W2, R, a, a1, gE, workspace);
+  // workspace[g] = [gW1 (R*F) | gW2 (F*R)]
+  const int64_t n = 2LL * R * F, half = static_cast<int64_t>(R) * F;
+  const dim3 rg(static_cast<unsigned>((half + kT - 1) / kT));
+  k_reduce_partials<<<rg, dim3(kT), 0, s>>>(workspace, n, half, groups, gW1);
+  k_reduce_partials<<<rg, dim3(kT), 0, s>>>(workspace + half, n, half, groups, gW2);
+  return launch_status();
+}
+
+extern "C" int dctr_bilinear_fwd(const float* E, int64_t ld_e, const float* V, int64_t ld_v, const float* Wf,
+                                 const int32_t* sched, int32_t n_sched, int32_t P, int32_t F, int32_t D, int32_t B,
+                                 float* out, int64_t ld_o, const float* dense, int64_t ld_d, int32_t n_dense,
+                                 int32_t dense_off, dctr_stream_t stream) {
+  if (!E || !Wf || !sched || !out || B < 0 || F < 2 || D <= 0 || P <= 0 || n_sched <= 0) return DCTR_EINVAL;
+  if (D > 16) return DCTR_ENOSUP;
+  if (B == 0) return DCTR_OK;
+  const size_t lds = tile_bytes(F, D, 2);
+  if (lds > 150 * 1024) return DCTR_ENOSUP;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bilinear_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(lds));
+  k_bilinear_fwd<<<dim3((B + kSB - 1) / kSB), dim3(kT), lds, static_cast<hipStream_t>(stream)>>>(
+      E, ld_e, V, ld_v, Wf, sched, n_sched, P, F, D, B, out, ld_o, n_dense > 0 ? dense : nullptr, ld_d, n_dense,
+      dense_off);
+  return launch_status();
+}
+
+static int bilinear_groups(int B) {
+  const int tiles = (B + kSB - 1) / kSB;
+  return tiles < 32 ? tiles : 32;
+}
+
+extern "C" size_t dctr_bilinear_bwd_workspace_floats(int32_t B, int32_t P, int32_t D) {
+  return static_cast<size_t>(bilinear_groups(B > 0 ? B : 1)) * P * D * D;
+}
+
+extern "C" int dctr_bilinear_bwd(const float* E, int64_t ld_e, const float* V, int64_t ld_v, const float* Wf,
+                                 const int32_t* sched, int32_t n_sched, int32_t slots, const int32_t* pair_w,
+                                 int32_t n_w, int32_t P, int32_t F, int32_t D, int32_t B, const float* gout,
+                                 int64_t ld_g, float* gE, float* gV, float* gW, float* workspace,
+                                 dctr_stream_t stream) {
+  if (!E || !Wf || !sched || !pair_w || !gout || !gE || !gW || !workspace || (V && !gV) || B < 0 || F < 2 || D <= 0 ||
+      P <= 0 || n_sched <= 0 || slots <= 0 || n_w <= 0)
+    return DCTR_EINVAL;
+  if (D > 16) return DCTR_ENOSUP;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (B == 0) {
+    (void)hipMemsetAsync(gW, 0, sizeof(float) * n_w * D * D, s);
+    return DCTR_OK;
+  }
+  {
+    const size_t lds = tile_bytes(F, D, 4) + 4u * 16 * 17 * sizeof(float);
+    if (lds > 158 * 1024) return DCTR_ENOSUP;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bilinear_bwd_data),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    k_bilinear_bwd_data<<<dim3((B + kSB - 1) / kSB), dim3(kT), lds, s>>>(E, ld_e, V, ld_v, Wf, sched, n_sched, slots, P,
+                                                                        F, D, B, gout, ld_g, gE, gV);
+  }
+  {
+    const int tiles = (B + kSB - 1) / kSB;
+    const int groups = bilinear_groups(B);
+    const int tpg = (tiles + groups - 1) / groups;
+    int py = (n_sched + 3) / 4;
+    if (py > 16) py = 16;
+    const size_t lds = tile_bytes(F, D, 2);
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bilinear_bwd_weight),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    // groups whose tiles all fall past B still own a slab: clear the workspace first so they contribute zeros
+    (void)hipMemsetAsync(workspace, 0, sizeof(float) * static_cast<size_t>(groups) * P * D * D, s);
+    k_bilinear_bwd_weight<<<dim3(groups, py), dim3(kT), lds, s>>>(E, ld_e, V, ld_v, sched, n_sched, P, F, D, B, gout,
+                                                                 ld_g, tpg, workspace);
+    const int64_t total = static_cast<int64_t>(n_w) * D * D;
+    k_bilinear_reduce_w<<<dim3(static_cast<unsigned>((total + kT - 1) / kT)), dim3(kT), 0, s>>>(workspace, groups, P,
+                                                                                              D * D, pair_w, n_w, gW);
+  }
+  return launch_status();
+}
+
+extern "C" int dctr_inner_product_fwd(const float* E, int64_t ld_e, int32_t B, int32_t F, int32_t D, int32_t reduce,
+                                      float* out, int64_t ld_o, dctr_stream_t stream) {
+  if (!E || !out || B < 0 || F < 2 || D <= 0) return DCTR_EINVAL;
+  if (B == 0) return DCTR_OK;
+  const size_t row = static_cast<size_t>(F * D + 1) * sizeof(float);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (16 * row <= 60 * 1024) {
+    k_inner_fwd<16><<<dim3((B + 15) / 16), dim3(kT), 16 * row, s>>>(E, ld_e, B, F, D, reduce, out, ld_o);
+  } else if (row <= 60 * 1024) {
+    k_inner_fwd<1><<<dim3(B), dim3(kT), row, s>>>(E, ld_e, B, F, D, reduce, out, ld_o);
+  } else {
+    return DCTR_ENOSUP;
+  }
+  return launch_status();
+}
+
+extern "C" int dctr_inner_product_bwd(const float* E, int64_t ld_e, int32_t B, int32_t F, int32_t D, int32_t reduce,
+                                      const float* gp, int64_t ld_g, float* gE, int64_t ld_ge, dctr_stream_t stream) {
+  if (!E || !gp || !gE || B < 0 || F < 2 || D <= 0) return DCTR_EINVAL;
+  if (B == 0) return DCTR_OK;
+  const int P = F * (F - 1) / 2, per = reduce ? 1 : D;
+  const size_t row = static_cast<size_t>(F * D + 1 + P * per + 1) * sizeof(float);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (16 * row <= 60 * 1024) {
+    k_inner_bwd<16><<<dim3((B + 15) / 16), dim3(kT), 16 * row, s>>>(E, ld_e, B, F, D, reduce, gp, ld_g, gE, ld_ge);
+  } else if (row <= 60 * 1024) {
+    k_inner_bwd<1><<<dim3(B), dim3(kT), row, s>>>(E, ld_e, B, F, D, reduce, gp, ld_g, gE, ld_ge);
+  } else {
+    return DCTR_ENOSUP;
+  }
+  return launch_status();
+}

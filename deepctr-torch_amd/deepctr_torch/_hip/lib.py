@@ -62,6 +62,19 @@ SIGNATURES = {
                                           _P]),
     "dctr_cin_layer_bwd": (ctypes.c_int, [_P, _P, _I64, _I32, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _P, _I64,
                                           _P, _I64, _I32, _P, _P, _P]),
+    "dctr_senet_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P, _P]),
+    "dctr_senet_bwd_workspace_floats": (ctypes.c_size_t, [_I32, _I32, _I32]),
+    "dctr_senet_bwd": (ctypes.c_int, [_P, _P, _I64, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P]),
+    "dctr_bilinear_fwd": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _I64, _P, _I64,
+                                         _I32, _I32, _P]),
+    "dctr_bilinear_bwd_workspace_floats": (ctypes.c_size_t, [_I32, _I32, _I32]),
+    "dctr_bilinear_bwd": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P,
+                                         _I64, _P, _P, _P, _P, _P]),
+    "dctr_inner_product_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P]),
+    "dctr_inner_product_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P, _I64, _P]),
+    "dctr_crossnet_vec_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _P, _I64, _P]),
+    "dctr_crossnet_vec_bwd_workspace_floats": (ctypes.c_size_t, [_I32, _I32, _I32]),
+    "dctr_crossnet_vec_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P]),
     "dctr_fm_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P]),
     "dctr_fm_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _I64, _I32, _P]),
 }

@@ -293,3 +293,230 @@ class CINLayerFunction(torch.autograd.Function):
                                        B, h, M, D, O, _ptr(gH), h * D, _ptr(gX0), M * D, 0, _ptr(gW), _ptr(gb),
                                        L.stream_handle(dev)), "dctr_cin_layer_bwd")
         return gH, gX0, gW, gb, None
+
+
+# ---- SENET / Bilinear / InnerProduct (csrc/pairwise.hip) -------------------------------------------------
+class SENETFunction(torch.autograd.Function):
+    """V = E * relu(W2 relu(W1 mean_d(E)))  (interaction.py:93-101)."""
+
+    @staticmethod
+    def forward(ctx, E, W1, W2):
+        lib = L.lib()
+        E, lde = _rows3(E, "SENET input")
+        B, F, D = E.shape
+        R = W1.shape[0]
+        W1, W2 = W1.contiguous(), W2.contiguous()
+        V = torch.empty((B, F, D), dtype=torch.float32, device=E.device)
+        a = torch.empty((B, F), dtype=torch.float32, device=E.device)
+        a1 = torch.empty((B, R), dtype=torch.float32, device=E.device)
+        L.check(lib.dctr_senet_fwd(_ptr(E), lde, B, F, D, _ptr(W1), _ptr(W2), R, _ptr(V), _ptr(a), _ptr(a1),
+                                   L.stream_handle(E.device)), "dctr_senet_fwd")
+        ctx.save_for_backward(E, W1, W2, a, a1)
+        return V
+
+    @staticmethod
+    def backward(ctx, gV):
+        lib = L.lib()
+        E, W1, W2, a, a1 = ctx.saved_tensors
+        E, lde = _rows3(E, "SENET input")
+        B, F, D = E.shape
+        R = W1.shape[0]
+        gV = gV.contiguous().float()
+        gE = torch.empty((B, F, D), dtype=torch.float32, device=E.device)
+        gW1, gW2 = torch.empty_like(W1), torch.empty_like(W2)
+        ws = torch.empty((max(1, lib.dctr_senet_bwd_workspace_floats(B, F, R)),), dtype=torch.float32, device=E.device)
+        L.check(lib.dctr_senet_bwd(_ptr(gV), _ptr(E), lde, B, F, D, _ptr(W1), _ptr(W2), R, _ptr(a), _ptr(a1), _ptr(gE),
+                                   _ptr(gW1), _ptr(gW2), _ptr(ws), L.stream_handle(E.device)), "dctr_senet_bwd")
+        return gE, gW1, gW2
+
+
+def tournament_schedule(F, bilinear_type):
+    """Pairs (i < j) of F fields in round-robin-tournament order: every round is a perfect matching, so workers
+    handling different slots of a round never share a field.  Returns (rows [n, 4] = {i, j, w, k}, slots per round,
+    pair_w [P], n_w).  k is the reference's pair index (itertools.combinations order)."""
+    n = F + (F & 1)
+    ring = list(range(n))
+    rows = []
+    for _ in range(n - 1):
+        for s in range(n // 2):
+            a, b = ring[s], ring[n - 1 - s]
+            i, j = min(a, b), max(a, b)
+            if j >= F:       # the dummy of an odd field count: idle slot
+                rows.append((-1, -1, 0, 0))
+                continue
+            k = i * F - i * (i + 1) // 2 + (j - i - 1)
+            w = 0 if bilinear_type == "all" else (i if bilinear_type == "each" else k)
+            rows.append((i, j, w, k))
+        ring = [ring[0]] + [ring[-1]] + ring[1:-1]
+    P = F * (F - 1) // 2
+    pair_w = [0] * P
+    for (i, j, w, k) in rows:
+        if i >= 0:
+            pair_w[k] = w
+    n_w = 1 if bilinear_type == "all" else (F if bilinear_type == "each" else P)
+    return rows, n // 2, pair_w, n_w
+
+
+class BilinearFunction(torch.autograd.Function):
+    """(x_i W^T) * x_j for every pair, on E and optionally on a second input V with the same weights; the result is
+    written in the DNN-input layout ``[V pairs | E pairs | dense]`` (fibinet.py:82-87)."""
+
+    @staticmethod
+    def forward(ctx, meta, E, V, dense, *weights):
+        lib = L.lib()
+        E, lde = _rows3(E, "Bilinear input")
+        B, F, D = E.shape
+        if D > 16:
+            raise NotImplementedError("the gfx950 bilinear kernels support embedding_dim <= 16 (got %d)" % D)
+        ldv = 0
+        if V is not None:
+            V, ldv = _rows3(V, "Bilinear second input")
+        Wf = meta.flat_weights(weights)
+        P = F * (F - 1) // 2
+        npass = 2 if V is not None else 1
+        n_dense = dense.shape[1] if dense is not None else 0
+        if dense is not None and (dense.stride(1) != 1 or dense.dtype != torch.float32):
+            dense = dense.float().contiguous()
+        width = npass * P * D + n_dense
+        out = torch.empty((B, width), dtype=torch.float32, device=E.device)
+        sched = meta.device_tables(E.device)
+        L.check(lib.dctr_bilinear_fwd(_ptr(E), lde, _ptr(V), ldv, _ptr(Wf), _ptr(sched[0]), meta.n_sched, P, F, D, B,
+                                      _ptr(out), width, _ptr(dense), dense.stride(0) if dense is not None else 0,
+                                      n_dense, npass * P * D, L.stream_handle(E.device)), "dctr_bilinear_fwd")
+        ctx.meta, ctx.n_w_in = meta, len(weights)
+        ctx.has_v, ctx.has_dense = V is not None, dense is not None
+        ctx.save_for_backward(E, V, Wf)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = L.lib()
+        meta = ctx.meta
+        E, V, Wf = ctx.saved_tensors
+        E, lde = _rows3(E, "Bilinear input")
+        B, F, D = E.shape
+        ldv = 0
+        if V is not None:
+            V, ldv = _rows3(V, "Bilinear second input")
+        P = F * (F - 1) // 2
+        npass = 2 if V is not None else 1
+        gout = gout.float()
+        if gout.stride(1) != 1:
+            gout = gout.contiguous()
+        dev = E.device
+        gE = torch.empty((B, F, D), dtype=torch.float32, device=dev)
+        gV = torch.empty((B, F, D), dtype=torch.float32, device=dev) if V is not None else None
+        gW = torch.empty((meta.n_w, D, D), dtype=torch.float32, device=dev)
+        ws = torch.empty((max(1, lib.dctr_bilinear_bwd_workspace_floats(B, P, D)),), dtype=torch.float32, device=dev)
+        sched = meta.device_tables(dev)
+        L.check(lib.dctr_bilinear_bwd(_ptr(E), lde, _ptr(V), ldv, _ptr(Wf), _ptr(sched[0]), meta.n_sched, meta.slots,
+                                      _ptr(sched[1]), meta.n_w, P, F, D, B, _ptr(gout), gout.stride(0), _ptr(gE), _ptr(gV),
+                                      _ptr(gW), _ptr(ws), L.stream_handle(dev)), "dctr_bilinear_bwd")
+        g_dense = gout[:, npass * P * D:] if ctx.has_dense else None
+        return (None, gE, gV, g_dense) + tuple(gW[i] for i in range(ctx.n_w_in))
+
+
+class BilinearMeta(object):
+    """Host-side tables of a BilinearInteraction layer: the tournament schedule and the flat weight slab."""
+
+    def __init__(self, F, bilinear_type):
+        rows, self.slots, pair_w, self.n_w = tournament_schedule(F, bilinear_type)
+        self.n_sched = len(rows)
+        self._rows, self._pair_w = rows, pair_w
+        self._dev = None
+        self._slab = None
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_dev"] = None
+        d["_slab"] = None
+        return d
+
+    def device_tables(self, device):
+        if self._dev is None or self._dev[0].device != torch.device(device):
+            self._dev = (torch.tensor(self._rows, dtype=torch.int32, device=device).reshape(-1, 4).contiguous(),
+                         torch.tensor(self._pair_w, dtype=torch.int32, device=device))
+        return self._dev
+
+    def flat_weights(self, weights):
+        """``[n_w, D, D]`` slab holding the layer's nn.Linear weights.  The parameters are re-seated ONCE as slices of
+        one contiguous slab (values preserved), after which this is a pointer check; the slab pointer stays stable
+        (hipGraph-safe) until someone re-allocates the parameters (``.to()``), which is detected here."""
+        slab = self._slab
+        D = weights[0].shape[0]
+        step = D * D * 4
+        if slab is not None and slab.shape[0] == len(weights) and slab.device == weights[0].device and \
+                all(w.data_ptr() == slab.data_ptr() + i * step for i, w in enumerate(weights)):
+            return slab
+        slab = torch.stack([w.detach() for w in weights]).contiguous()
+        for i, w in enumerate(weights):
+            w.data = slab[i]
+        self._slab = slab
+        return slab
+
+
+class InnerProductFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, E, reduce_sum):
+        lib = L.lib()
+        E, lde = _rows3(E, "InnerProduct input")
+        B, F, D = E.shape
+        P = F * (F - 1) // 2
+        per = 1 if reduce_sum else D
+        out = torch.empty((B, P, per), dtype=torch.float32, device=E.device)
+        if P > 0:
+            L.check(lib.dctr_inner_product_fwd(_ptr(E), lde, B, F, D, int(bool(reduce_sum)), _ptr(out), P * per,
+                                               L.stream_handle(E.device)), "dctr_inner_product_fwd")
+        ctx.reduce_sum = bool(reduce_sum)
+        ctx.save_for_backward(E)
+        return out
+
+    @staticmethod
+    def backward(ctx, gp):
+        lib = L.lib()
+        (E,) = ctx.saved_tensors
+        E, lde = _rows3(E, "InnerProduct input")
+        B, F, D = E.shape
+        P = F * (F - 1) // 2
+        per = 1 if ctx.reduce_sum else D
+        gp = gp.contiguous().float()
+        gE = torch.zeros((B, F, D), dtype=torch.float32, device=E.device)
+        if P > 0:
+            L.check(lib.dctr_inner_product_bwd(_ptr(E), lde, B, F, D, int(ctx.reduce_sum), _ptr(gp), P * per, _ptr(gE),
+                                               F * D, L.stream_handle(E.device)), "dctr_inner_product_bwd")
+        return gE, None
+
+
+# ---- CrossNet, vector parameterisation (csrc/cross.hip) -----------------------------------------------------
+class CrossNetVecFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, kernels, bias):
+        lib = L.lib()
+        X = _rows_f32(X, "CrossNet input")
+        B, W = X.shape
+        Lyr = kernels.shape[0]
+        if W > 2048:
+            raise NotImplementedError("the gfx950 CrossNet kernel supports in_features <= 2048 (got %d)" % W)
+        k2, b2 = kernels.reshape(Lyr, W).contiguous(), bias.reshape(Lyr, W).contiguous()
+        Y = torch.empty((B, W), dtype=torch.float32, device=X.device)
+        L.check(lib.dctr_crossnet_vec_fwd(_ptr(X), X.stride(0) if B > 1 else W, B, W, Lyr, _ptr(k2), _ptr(b2), _ptr(Y), W,
+                                          L.stream_handle(X.device)), "dctr_crossnet_vec_fwd")
+        ctx.save_for_backward(X, k2, b2)
+        ctx.kshape, ctx.bshape = kernels.shape, bias.shape
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        lib = L.lib()
+        X, k2, b2 = ctx.saved_tensors
+        B, W = X.shape
+        Lyr = k2.shape[0]
+        gY = _rows_f32(gY, "CrossNet output gradient")
+        gX = torch.empty((B, W), dtype=torch.float32, device=X.device)
+        gk, gb = torch.empty_like(k2), torch.empty_like(b2)
+        ws = torch.empty((max(1, lib.dctr_crossnet_vec_bwd_workspace_floats(B, W, Lyr)),), dtype=torch.float32,
+                         device=X.device)
+        L.check(lib.dctr_crossnet_vec_bwd(_ptr(X), X.stride(0) if B > 1 else W, B, W, Lyr, _ptr(k2), _ptr(b2), _ptr(gY),
+                                          gY.stride(0) if B > 1 else W, _ptr(gX), W, _ptr(gk), _ptr(gb), _ptr(ws),
+                                          L.stream_handle(X.device)), "dctr_crossnet_vec_bwd")
+        return gX, gk.reshape(ctx.kshape), gb.reshape(ctx.bshape)

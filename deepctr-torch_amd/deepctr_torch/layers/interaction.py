@@ -9,7 +9,7 @@ import torch.nn as nn
 from .._hip import ops as _ops
 from .activation import activation_layer
 
-__all__ = ["FM", "CIN"]
+__all__ = ["FM", "CIN", "SENETLayer", "BilinearInteraction", "InnerProductLayer", "CrossNet"]
 
 
 class FM(nn.Module):
@@ -75,3 +75,118 @@ class CIN(nn.Module):
                 direct_connect, hidden = curr_out, curr_out
             final_result.append(direct_connect)
         return torch.sum(torch.cat(final_result, dim=1), -1)
+
+
+class SENETLayer(nn.Module):
+    """Squeeze-and-excitation over fields: ``[B, F, D] -> [B, F, D]`` (reference interaction.py:64-101; parameters
+    ``excitation.0.weight [F//r, F]``, ``excitation.2.weight [F, F//r]``).  One kernel each way (csrc/pairwise.hip)."""
+
+    def __init__(self, filed_size, reduction_ratio=3, seed=1024, device='cpu'):
+        super(SENETLayer, self).__init__()
+        self.seed = seed
+        self.filed_size = filed_size
+        self.reduction_size = max(1, filed_size // reduction_ratio)
+        self.excitation = nn.Sequential(
+            nn.Linear(self.filed_size, self.reduction_size, bias=False), nn.ReLU(),
+            nn.Linear(self.reduction_size, self.filed_size, bias=False), nn.ReLU())
+        self.to(device)
+
+    def forward(self, inputs):
+        if len(inputs.shape) != 3:
+            raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % (len(inputs.shape)))
+        return _ops.SENETFunction.apply(inputs, self.excitation[0].weight, self.excitation[2].weight)
+
+
+class BilinearInteraction(nn.Module):
+    """``p_k = (v_i W) * v_j`` for every field pair: ``[B, F, D] -> [B, F(F-1)/2, D]`` (reference
+    interaction.py:104-156; parameters ``bilinear.weight`` / ``bilinear.<i>.weight`` / ``bilinear.<k>.weight``).
+    All pairs run in one fp32-MFMA kernel instead of 325 ``nn.Linear`` calls and a 325-way ``cat``."""
+
+    def __init__(self, filed_size, embedding_size, bilinear_type="interaction", seed=1024, device='cpu'):
+        super(BilinearInteraction, self).__init__()
+        self.bilinear_type = bilinear_type
+        self.seed = seed
+        self.filed_size = filed_size
+        self.bilinear = nn.ModuleList()
+        if self.bilinear_type == "all":
+            self.bilinear = nn.Linear(embedding_size, embedding_size, bias=False)
+        elif self.bilinear_type == "each":
+            for _ in range(filed_size):
+                self.bilinear.append(nn.Linear(embedding_size, embedding_size, bias=False))
+        elif self.bilinear_type == "interaction":
+            for _, _ in itertools.combinations(range(filed_size), 2):
+                self.bilinear.append(nn.Linear(embedding_size, embedding_size, bias=False))
+        else:
+            raise NotImplementedError
+        self._meta = None
+        self.to(device)
+
+    def _weights(self):
+        if self.bilinear_type == "all":
+            return [self.bilinear.weight]
+        return [lin.weight for lin in self.bilinear]
+
+    def meta(self, n_fields):
+        if self._meta is None or self._meta[0] != n_fields:
+            self._meta = (n_fields, _ops.BilinearMeta(n_fields, self.bilinear_type))
+        return self._meta[1]
+
+    def forward(self, inputs):
+        if len(inputs.shape) != 3:
+            raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % (len(inputs.shape)))
+        B, F, D = inputs.shape
+        out = _ops.BilinearFunction.apply(self.meta(F), inputs, None, None, *self._weights())
+        return out.reshape(B, F * (F - 1) // 2, D)
+
+    def fused_pair(self, raw, senet, dense=None):
+        """FiBiNET's ``cat(Bilinear(senet), Bilinear(raw))`` flattened, followed by the dense features: the DNN input
+        of fibinet.py:82-87 produced by one launch that loads every weight tile once for both passes."""
+        return _ops.BilinearFunction.apply(self.meta(raw.shape[1]), raw, senet, dense, *self._weights())
+
+
+class InnerProductLayer(nn.Module):
+    """Pairwise inner (or element-wise) products of field embeddings (reference interaction.py:537-577):
+    list of ``[B, 1, D]`` (or one ``[B, F, D]`` tensor) -> ``[B, F(F-1)/2, 1]`` (``[.., D]`` without reduce_sum)."""
+
+    def __init__(self, reduce_sum=True, device='cpu'):
+        super(InnerProductLayer, self).__init__()
+        self.reduce_sum = reduce_sum
+        self.to(device)
+
+    def forward(self, inputs):
+        E = inputs if torch.is_tensor(inputs) else torch.cat(list(inputs), dim=1)
+        return _ops.InnerProductFunction.apply(E, self.reduce_sum)
+
+
+class CrossNet(nn.Module):
+    """Cross network of DCN / DCN-M: ``[B, W] -> [B, W]`` (reference interaction.py:397-453; parameters
+    ``kernels [L, W, 1 | W]``, ``bias [L, W, 1]``).  The vector form runs all layers in one wave-per-sample kernel
+    (csrc/cross.hip); the matrix form is a ``[B, W] x [W, W]`` GEMM per layer and goes to hipBLASLt."""
+
+    def __init__(self, in_features, layer_num=2, parameterization='vector', seed=1024, device='cpu'):
+        super(CrossNet, self).__init__()
+        self.layer_num = layer_num
+        self.parameterization = parameterization
+        if self.parameterization == 'vector':
+            self.kernels = nn.Parameter(torch.Tensor(self.layer_num, in_features, 1))
+        elif self.parameterization == 'matrix':
+            self.kernels = nn.Parameter(torch.Tensor(self.layer_num, in_features, in_features))
+        else:
+            raise ValueError("parameterization should be 'vector' or 'matrix'")
+        self.bias = nn.Parameter(torch.Tensor(self.layer_num, in_features, 1))
+        for i in range(self.kernels.shape[0]):
+            nn.init.xavier_normal_(self.kernels[i])
+        for i in range(self.bias.shape[0]):
+            nn.init.zeros_(self.bias[i])
+        self.to(device)
+
+    def forward(self, inputs):
+        if self.layer_num == 0:
+            return inputs
+        if self.parameterization == 'vector':
+            return _ops.CrossNetVecFunction.apply(inputs, self.kernels, self.bias)
+        x_0 = inputs
+        x_l = x_0
+        for i in range(self.layer_num):   # x0 * (W x_l + b) + x_l
+            x_l = x_0 * (torch.addmm(self.bias[i].t(), x_l, self.kernels[i].t())) + x_l
+        return x_l

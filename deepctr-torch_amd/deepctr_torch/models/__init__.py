@@ -1,7 +1,10 @@
 """Drop-in model classes of the MI355X hot path.  Constructor signatures
 and ``state_dict`` keys are the reference's (``deepctr_torch/models/*.py``)."""
 from .basemodel import BaseModel, Linear
+from .dcn import DCN
 from .deepfm import DeepFM
+from .fibinet import FiBiNET
+from .pnn import PNN
 from .xdeepfm import xDeepFM
 
-__all__ = ["BaseModel", "Linear", "DeepFM", "xDeepFM"]
+__all__ = ["BaseModel", "Linear", "DeepFM", "xDeepFM", "FiBiNET", "DCN", "PNN"]

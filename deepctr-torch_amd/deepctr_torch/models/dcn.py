@@ -1,0 +1,50 @@
+# -*- coding: utf-8 -*-
+"""DCN / DCN-M (reference models/dcn.py:20-96): cross network + DNN over the fused gather's output."""
+import torch
+import torch.nn as nn
+
+from .basemodel import BaseModel
+from ..layers import DNN, CrossNet
+
+
+class DCN(BaseModel):
+    """Same arguments as the reference (models/dcn.py:44-47).  Like the reference, ``l2_reg_linear`` is NOT forwarded
+    to the linear part (``BaseModel`` keeps its own default there, dcn.py:49-51); it regularises ``dnn_linear``."""
+
+    def __init__(self, linear_feature_columns, dnn_feature_columns, cross_num=2, cross_parameterization='vector',
+                 dnn_hidden_units=(128, 128), l2_reg_linear=0.00001, l2_reg_embedding=0.00001, l2_reg_cross=0.00001,
+                 l2_reg_dnn=0, init_std=0.0001, seed=1024, dnn_dropout=0, dnn_activation='relu', dnn_use_bn=False,
+                 task='binary', device='cpu', gpus=None):
+        super(DCN, self).__init__(linear_feature_columns=linear_feature_columns,
+                                  dnn_feature_columns=dnn_feature_columns, l2_reg_embedding=l2_reg_embedding,
+                                  init_std=init_std, seed=seed, task=task, device=device, gpus=gpus)
+        self.dnn_hidden_units = dnn_hidden_units
+        self.cross_num = cross_num
+        self.dnn = DNN(self.compute_input_dim(dnn_feature_columns), dnn_hidden_units,
+                       activation=dnn_activation, use_bn=dnn_use_bn, l2_reg=l2_reg_dnn, dropout_rate=dnn_dropout,
+                       init_std=init_std, device=device)
+        if len(self.dnn_hidden_units) > 0 and self.cross_num > 0:
+            dnn_linear_in_feature = self.compute_input_dim(dnn_feature_columns) + dnn_hidden_units[-1]
+        elif len(self.dnn_hidden_units) > 0:
+            dnn_linear_in_feature = dnn_hidden_units[-1]
+        elif self.cross_num > 0:
+            dnn_linear_in_feature = self.compute_input_dim(dnn_feature_columns)
+        self.dnn_linear = nn.Linear(dnn_linear_in_feature, 1, bias=False).to(device)
+        self.crossnet = CrossNet(in_features=self.compute_input_dim(dnn_feature_columns),
+                                 layer_num=cross_num, parameterization=cross_parameterization, device=device)
+        self.add_regularization_weight(
+            filter(lambda x: 'weight' in x[0] and 'bn' not in x[0], self.dnn.named_parameters()), l2=l2_reg_dnn)
+        self.add_regularization_weight(self.dnn_linear.weight, l2=l2_reg_linear)
+        self.add_regularization_weight(self.crossnet.kernels, l2=l2_reg_cross)
+        self.to(device)
+
+    def forward(self, X):
+        dnn_input, logit, _ = self.fused_inputs(X, want_fm=False)
+        if len(self.dnn_hidden_units) > 0 and self.cross_num > 0:      # Deep & Cross
+            stack_out = torch.cat((self.crossnet(dnn_input), self.dnn(dnn_input)), dim=-1)
+            logit = logit + self.dnn_linear(stack_out)
+        elif len(self.dnn_hidden_units) > 0:                           # only Deep
+            logit = logit + self.dnn_linear(self.dnn(dnn_input))
+        elif self.cross_num > 0:                                       # only Cross
+            logit = logit + self.dnn_linear(self.crossnet(dnn_input))
+        return self.out(logit)

@@ -194,6 +194,57 @@ int dctr_cin_layer_bwd(const float* gA, const float* A, int64_t ld_a, int32_t re
                        int32_t O, float* gH, int64_t ld_gh, float* gX0, int64_t ld_gx, int32_t accumulate_x0,
                        float* gW, float* gbias, dctr_stream_t stream);
 
+/* ---- SENET / Bilinear / InnerProduct (csrc/pairwise.hip) ----------------------------------------------
+ * SENETLayer (interaction.py:93-101): z = mean_d E; a1 = relu(z W1^T); a = relu(a1 W2^T); V = E * a[:, :, None]
+ *   E [B, F, D] rows at E + b*ld_e;  W1 [R, F], W2 [F, R] (excitation.0 / .2 weights);  V [B, F*D] contiguous;
+ *   a [B, F] and a1 [B, R] are saved for the backward.  Backward writes gE [B, F*D], gW1, gW2
+ *   (workspace: dctr_senet_bwd_workspace_floats(B, F, R) floats of per-workgroup partials, summed in fixed order). */
+int dctr_senet_fwd(const float* E, int64_t ld_e, int32_t B, int32_t F, int32_t D, const float* W1, const float* W2,
+                   int32_t R, float* V, float* a, float* a1, dctr_stream_t stream);
+size_t dctr_senet_bwd_workspace_floats(int32_t B, int32_t F, int32_t R);
+int dctr_senet_bwd(const float* gV, const float* E, int64_t ld_e, int32_t B, int32_t F, int32_t D, const float* W1,
+                   const float* W2, int32_t R, const float* a, const float* a1, float* gE, float* gW1, float* gW2,
+                   float* workspace, dctr_stream_t stream);
+
+/* BilinearInteraction (interaction.py:140-156): p_k = (x_i W_w^T) (.) x_j for the pairs k = (i, j), i < j.
+ *   Wf    [n_w, D, D]  the nn.Linear weights stacked: n_w = 1 ("all"), F ("each", w = i), P ("interaction", w = k)
+ *   sched [n_sched][4] int32 (device): {i, j, w, k} in round-robin-tournament order, `slots` entries per round,
+ *         i = -1 for an idle slot;  pair_w [P] int32: weight index of pair k
+ *   V     optional second input (FiBiNET's SENET output, fibinet.py:82-83).  With V: out row =
+ *         [ V pairs (P*D) | E pairs (P*D) ], else [ E pairs ].  `dense` (nullable): n_dense floats per sample copied
+ *         to out[:, dense_off ...) so that `out` IS the reference's DNN input (fibinet.py:86-87).  D <= 16.
+ *   backward: gout has out's layout; writes gE (and gV) [B, F*D] and gW [n_w, D, D];
+ *         workspace = dctr_bilinear_bwd_workspace_floats(B, P, D) floats.                                     */
+int dctr_bilinear_fwd(const float* E, int64_t ld_e, const float* V, int64_t ld_v, const float* Wf,
+                      const int32_t* sched, int32_t n_sched, int32_t P, int32_t F, int32_t D, int32_t B, float* out,
+                      int64_t ld_o, const float* dense, int64_t ld_d, int32_t n_dense, int32_t dense_off,
+                      dctr_stream_t stream);
+size_t dctr_bilinear_bwd_workspace_floats(int32_t B, int32_t P, int32_t D);
+int dctr_bilinear_bwd(const float* E, int64_t ld_e, const float* V, int64_t ld_v, const float* Wf,
+                      const int32_t* sched, int32_t n_sched, int32_t slots, const int32_t* pair_w, int32_t n_w,
+                      int32_t P, int32_t F, int32_t D, int32_t B, const float* gout, int64_t ld_g, float* gE,
+                      float* gV, float* gW, float* workspace, dctr_stream_t stream);
+
+/* InnerProductLayer (interaction.py:557-577): out[b, k] = sum_d e_i e_j (reduce != 0) or out[b, k*D + d] = e_i e_j;
+ * pair order i < j, i outer.  Backward: gE[b, f, :] = sum_{g != f} gp[b, pair(f, g)] e_g.                    */
+int dctr_inner_product_fwd(const float* E, int64_t ld_e, int32_t B, int32_t F, int32_t D, int32_t reduce, float* out,
+                           int64_t ld_o, dctr_stream_t stream);
+int dctr_inner_product_bwd(const float* E, int64_t ld_e, int32_t B, int32_t F, int32_t D, int32_t reduce,
+                           const float* gp, int64_t ld_g, float* gE, int64_t ld_ge, dctr_stream_t stream);
+
+/* ---- CrossNet, vector parameterisation (interaction.py:438-447; csrc/cross.hip) --------------------------
+ *     x_{l+1} = x_0 * (x_l . w_l) + b_l + x_l ,  l = 0..L-1
+ *   X [B, W] rows at X + b*ld_x;  kernels [L, W] (crossnet.kernels [L, W, 1]);  bias [L, W];  Y [B, W].  W <= 2048.
+ * Backward writes gX [B, W], g_kernels [L, W], g_bias [L, W];
+ * workspace = dctr_crossnet_vec_bwd_workspace_floats(B, W, L) floats (per-workgroup partials, fixed-order sum).
+ * (The matrix parameterisation is a [B, W] x [W, W] GEMM per layer and stays on hipBLASLt.)                    */
+int dctr_crossnet_vec_fwd(const float* X, int64_t ld_x, int32_t B, int32_t W, int32_t L, const float* kernels,
+                          const float* bias, float* Y, int64_t ld_y, dctr_stream_t stream);
+size_t dctr_crossnet_vec_bwd_workspace_floats(int32_t B, int32_t W, int32_t L);
+int dctr_crossnet_vec_bwd(const float* X, int64_t ld_x, int32_t B, int32_t W, int32_t L, const float* kernels,
+                          const float* bias, const float* gY, int64_t ld_g, float* gX, int64_t ld_gx,
+                          float* g_kernels, float* g_bias, float* workspace, dctr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,170 @@
+"""GPU: SENET / Bilinear / InnerProduct / CrossNet kernels (csrc/pairwise.hip, cross.hip) against plain PyTorch
+references of the same ops (what the reference's layers compute, interaction.py:93-101,140-156,438-453,557-577),
+values and every gradient, in fp64."""
+import itertools
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _close(a, r, what, tol=2e-5):
+    if r is None:                      # torch leaves the gradient of an unused parameter undefined; we return zeros
+        assert a is None or float(a.abs().max()) == 0.0, what
+        return
+    scale = max(1.0, float(r.abs().max())) if r.numel() else 1.0
+    err = float((a.double() - r).abs().max()) if r.numel() else 0.0
+    assert err <= tol * scale, "%s: max|d|=%.3e (scale %.3g)" % (what, err, scale)
+
+
+@pytest.mark.parametrize("B,F,D,ratio", [(5, 3, 4, 1), (37, 26, 16, 3), (64, 10, 16, 3), (9, 5, 8, 2), (1, 2, 3, 5)])
+def test_senet(B, F, D, ratio):
+    from deepctr_torch.layers import SENETLayer
+    torch.manual_seed(B + F)
+    layer = SENETLayer(F, ratio, device=DEV)
+    for p in layer.parameters():
+        torch.nn.init.normal_(p, 0, 0.5)
+    E = torch.randn(B, F, D, device=DEV, requires_grad=True)
+    R = torch.randn(B, F, D, device=DEV)
+    V = layer(E)
+    (V * R).sum().backward()
+    E2 = E.detach().double().requires_grad_(True)
+    W1, W2 = (layer.excitation[i].weight.detach().double().requires_grad_(True) for i in (0, 2))
+    A = torch.relu(torch.relu(E2.mean(-1) @ W1.t()) @ W2.t())
+    V2 = E2 * A.unsqueeze(2)
+    (V2 * R.double()).sum().backward()
+    _close(V.detach(), V2.detach(), "V")
+    _close(E.grad, E2.grad, "gE")
+    _close(layer.excitation[0].weight.grad, W1.grad, "gW1")
+    _close(layer.excitation[2].weight.grad, W2.grad, "gW2")
+
+
+def _bilinear_ref(X, Ws, btype):
+    F = X.shape[1]
+    outs = []
+    for k, (i, j) in enumerate(itertools.combinations(range(F), 2)):
+        W = Ws[0] if btype == "all" else (Ws[i] if btype == "each" else Ws[k])
+        outs.append((X[:, i] @ W.t()) * X[:, j])
+    return torch.stack(outs, 1)
+
+
+@pytest.mark.parametrize("btype", ["interaction", "each", "all"])
+@pytest.mark.parametrize("B,F,D", [(7, 3, 4), (33, 5, 8), (48, 10, 16), (100, 26, 16), (16, 4, 5), (257, 7, 16)])
+def test_bilinear_single_input(B, F, D, btype):
+    from deepctr_torch.layers import BilinearInteraction
+    torch.manual_seed(F * 31 + D)
+    layer = BilinearInteraction(F, D, btype, device=DEV)
+    for p in layer.parameters():
+        torch.nn.init.normal_(p, 0, 0.3)
+    X = torch.randn(B, F, D, device=DEV, requires_grad=True)
+    P = F * (F - 1) // 2
+    R = torch.randn(B, P, D, device=DEV)
+    out = layer(X)
+    assert out.shape == (B, P, D)
+    (out * R).sum().backward()
+    params = list(layer.parameters())
+    X2 = X.detach().double().requires_grad_(True)
+    Ws = [p.detach().double().requires_grad_(True) for p in params]
+    ref = _bilinear_ref(X2, Ws, btype)
+    (ref * R.double()).sum().backward()
+    _close(out.detach(), ref.detach(), "out")
+    _close(X.grad, X2.grad, "gX")
+    for k, (p, w) in enumerate(zip(params, Ws)):
+        _close(p.grad, w.grad, "gW%d" % k)
+
+
+@pytest.mark.parametrize("btype", ["interaction", "each", "all"])
+def test_bilinear_fused_pair_is_the_fibinet_dnn_input(btype):
+    from deepctr_torch.layers import BilinearInteraction
+    B, F, D, nd = 50, 6, 16, 3
+    torch.manual_seed(3)
+    layer = BilinearInteraction(F, D, btype, device=DEV)
+    for p in layer.parameters():
+        torch.nn.init.normal_(p, 0, 0.3)
+    buf = torch.randn(B, F * D + nd + 1, device=DEV)          # like the gather's padded output
+    E = buf[:, :F * D].reshape(B, F, D).detach().requires_grad_(True)
+    V = torch.randn(B, F, D, device=DEV, requires_grad=True)
+    dense = buf[:, F * D:F * D + nd].detach().requires_grad_(True)
+    out = layer.fused_pair(E, V, dense)
+    P = F * (F - 1) // 2
+    assert out.shape == (B, 2 * P * D + nd)
+    R = torch.randn_like(out)
+    (out * R).sum().backward()
+    params = list(layer.parameters())
+    E2, V2, d2 = (t.detach().double().requires_grad_(True) for t in (E, V, dense))
+    Ws = [p.detach().double().requires_grad_(True) for p in params]
+    ref = torch.cat([_bilinear_ref(V2, Ws, btype).flatten(1), _bilinear_ref(E2, Ws, btype).flatten(1), d2], 1)
+    (ref * R.double()).sum().backward()
+    _close(out.detach(), ref.detach(), "out")
+    _close(E.grad, E2.grad, "gE")
+    _close(V.grad, V2.grad, "gV")
+    _close(dense.grad, d2.grad, "gdense")
+    for k, (p, w) in enumerate(zip(params, Ws)):
+        _close(p.grad, w.grad, "gW%d" % k)
+    # bit-reproducible
+    for p in params:
+        p.grad = None
+    E.grad = V.grad = None
+    out2 = layer.fused_pair(E, V, dense)
+    (out2 * R).sum().backward()
+    assert torch.equal(out2, out)
+    E3g = E.grad.clone()
+    E.grad = None
+    for p in params:
+        p.grad = None
+    (layer.fused_pair(E, V, dense) * R).sum().backward()
+    assert torch.equal(E.grad, E3g)
+
+
+@pytest.mark.parametrize("reduce_sum", [True, False])
+@pytest.mark.parametrize("B,F,D", [(5, 2, 4), (33, 8, 8), (100, 26, 16), (17, 5, 3)])
+def test_inner_product(B, F, D, reduce_sum):
+    from deepctr_torch.layers import InnerProductLayer
+    torch.manual_seed(B)
+    E = torch.randn(B, F, D, device=DEV, requires_grad=True)
+    layer = InnerProductLayer(reduce_sum=reduce_sum, device=DEV)
+    out = layer([E[:, f:f + 1] for f in range(F)])
+    P = F * (F - 1) // 2
+    assert out.shape == (B, P, 1 if reduce_sum else D)
+    R = torch.randn_like(out)
+    (out * R).sum().backward()
+    E2 = E.detach().double().requires_grad_(True)
+    row, col = zip(*itertools.combinations(range(F), 2))
+    ref = E2[:, list(row)] * E2[:, list(col)]
+    if reduce_sum:
+        ref = ref.sum(2, keepdim=True)
+    (ref * R.double()).sum().backward()
+    _close(out.detach(), ref.detach(), "out")
+    _close(E.grad, E2.grad, "gE")
+
+
+@pytest.mark.parametrize("param", ["vector", "matrix"])
+@pytest.mark.parametrize("B,W,L", [(3, 5, 1), (48, 69, 3), (100, 429, 2), (1000, 429, 2), (7, 845, 4)])
+def test_crossnet(B, W, L, param):
+    from deepctr_torch.layers import CrossNet
+    torch.manual_seed(W)
+    layer = CrossNet(W, L, param, device=DEV)
+    with torch.no_grad():
+        layer.bias.normal_(0, 0.1)
+        layer.kernels.mul_(0.5)
+    X = (torch.randn(B, W, device=DEV) * 0.5).requires_grad_(True)
+    R = torch.randn(B, W, device=DEV)
+    Y = layer(X)
+    (Y * R).sum().backward()
+    X2 = X.detach().double().requires_grad_(True)
+    K, Bs = layer.kernels.detach().double().requires_grad_(True), layer.bias.detach().double().requires_grad_(True)
+    x0 = X2.unsqueeze(2)
+    xl = x0
+    for i in range(L):
+        if param == "vector":
+            xl = torch.matmul(x0, torch.tensordot(xl, K[i], dims=([1], [0]))) + Bs[i] + xl
+        else:
+            xl = x0 * (torch.matmul(K[i], xl) + Bs[i]) + xl
+    ref = xl.squeeze(2)
+    (ref * R.double()).sum().backward()
+    _close(Y.detach(), ref.detach(), "Y")
+    _close(X.grad, X2.grad, "gX")
+    _close(layer.kernels.grad, K.grad, "gK", tol=5e-5)
+    _close(layer.bias.grad, Bs.grad, "gb")
