@@ -102,7 +102,7 @@ class A:
 for opt in ("adagrad", "sgd"):
     A.optimizer = opt
     model = bench.build_model(A, dev)
-    for Bsz in (4096, 262_144):
+    for Bsz in (4096, 32_768):
         A.batch = Bsz
         gen = torch.Generator().manual_seed(0)
         X = torch.cat([torch.randint(0, A.vocab, (Bsz, 26), generator=gen).float(), torch.rand(Bsz, 13, generator=gen)],
