@@ -107,7 +107,7 @@ def time_hot_kernels(model, X, y, iters, opt):
     def upd():
         L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t), B,
                                       _ptr(g_out), plan.ld_out, _ptr(out), plan.ld_out, _ptr(fm_s), DIM, _ptr(g_fm),
-                                      _ptr(g_wide), L.UPD_ADAGRAD if opt == "adagrad" else L.UPD_SGD, lr, eps, s))
+                                      _ptr(g_wide), L.UPD_ADAGRAD if opt == "adagrad" else L.UPD_SGD, lr, eps, None, 0, None, s))
 
     stages = [("embed_fwd", fwd), ("embed_update", upd)]
     for _, fn in stages * 3:

@@ -1,0 +1,130 @@
+// head.hip -- the prediction head + loss of a binary CTR model, and the dense optimizer step (gfx950).
+//
+// k_bce_head replaces, per train step, the reference's chain (deepfm.py:78-86, core.py:154-160,
+// basemodel.py:254-261):  logit adds, PredictionLayer (bias add + sigmoid), F.binary_cross_entropy(reduction=
+// 'sum') and its autograd backward (binary_cross_entropy_backward, sigmoid_backward, the bias column-sum) -- about
+// a dozen elementwise / reduce launches over 4096 floats, each 1.5-5 us of pure launch latency.
+//
+// k_dense_opt replaces torch.optim's foreach walk over the dense parameters (Adagrad: addcmul, sqrt, add, div /
+// addcdiv = 5-8 launches) with one pass over one flat slab (deepctr_torch/_hip/dense.py re-seats the parameters
+// as views of that slab).
+#include "common.hpp"
+
+using namespace dctr;
+
+namespace {
+
+constexpr int kTH = 1024;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();  // red may still be read from a previous call
+  if (lane == 0) red[wv] = v;
+  __syncthreads();
+  float t = (threadIdx.x < kTH / 64) ? red[threadIdx.x] : 0.f;
+  if (wv == 0) t = wave_sum(t);
+  return t;  // valid in wave 0
+}
+
+__global__ __launch_bounds__(kTH) void k_bce_head(const float* __restrict__ p0, const float* __restrict__ p1,
+                                                  const float* __restrict__ p2, const float* __restrict__ p3,
+                                                  const float* __restrict__ bias, const float* __restrict__ y,
+                                                  int B, float* __restrict__ y_pred, float* __restrict__ loss,
+                                                  float* __restrict__ g_logit, float* __restrict__ g_bias) {
+  __shared__ float red[kTH / 64];
+  const float bv = bias ? ldg_f32(bias) : 0.f;
+  float lsum = 0.f, gsum = 0.f;
+  for (int b = threadIdx.x; b < B; b += kTH) {
+    float z = 0.f;
+    if (p0) z += ldg_f32(p0 + b);   // same association order as the reference: ((linear + fm) + dnn) + bias
+    if (p1) z += ldg_f32(p1 + b);
+    if (p2) z += ldg_f32(p2 + b);
+    if (p3) z += ldg_f32(p3 + b);
+    z += bv;
+    const float p = 1.f / (1.f + expf(-z));                     // at::sigmoid
+    const float t = ldg_f32(y + b);
+    const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);
+    lsum += (t - 1.f) * l1p - t * lp;                            // at::binary_cross_entropy
+    const float q = (1.f - p) * p;
+    const float gp = (p - t) / fmaxf(q, 1e-12f);                 // binary_cross_entropy_backward (grad = 1)
+    const float gz = gp * q;                                     // sigmoid_backward
+    if (y_pred) stg_f32(y_pred + b, p);
+    if (g_logit) stg_f32(g_logit + b, gz);
+    gsum += gz;
+  }
+  const float L = block_sum(lsum, red);
+  const float G = block_sum(gsum, red);
+  if (threadIdx.x == 0) {
+    if (loss) stg_f32(loss, L);
+    if (g_bias) stg_f32(g_bias, G);
+  }
+}
+
+template <int OPT>
+__global__ __launch_bounds__(256) void k_dense_opt(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ st, int64_t n4, int64_t n, float lr,
+                                                   float eps) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n4) {
+    f32x4 pv = *(const DCTR_GLOBAL f32x4*)(p + 4 * i);
+    const f32x4 gv = *(const DCTR_GLOBAL f32x4*)(g + 4 * i);
+    if (OPT == DCTR_UPD_ADAGRAD) {
+      f32x4 sv = *(const DCTR_GLOBAL f32x4*)(st + 4 * i);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        sv[k] = sv[k] + gv[k] * gv[k];
+        pv[k] = pv[k] - lr * (gv[k] / (sqrtf(sv[k]) + eps));
+      }
+      *(DCTR_GLOBAL f32x4*)(st + 4 * i) = sv;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pv[k] = pv[k] - lr * gv[k];
+    }
+    *(DCTR_GLOBAL f32x4*)(p + 4 * i) = pv;
+  } else {
+    const int64_t j = 4 * n4 + (i - n4);
+    if (j < n) {
+      const float gv = ldg_f32(g + j);
+      float pv = ldg_f32(p + j);
+      if (OPT == DCTR_UPD_ADAGRAD) {
+        const float sv = ldg_f32(st + j) + gv * gv;
+        stg_f32(st + j, sv);
+        pv = pv - lr * (gv / (sqrtf(sv) + eps));
+      } else {
+        pv = pv - lr * gv;
+      }
+      stg_f32(p + j, pv);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int dctr_bce_head(const float* part0, const float* part1, const float* part2, const float* part3,
+                             const float* bias, const float* y, int32_t B, float* y_pred, float* loss,
+                             float* g_logit, float* g_bias, dctr_stream_t stream) {
+  if (!y || B < 0 || (!part0 && !part1 && !part2 && !part3)) return DCTR_EINVAL;
+  k_bce_head<<<dim3(1), dim3(kTH), 0, static_cast<hipStream_t>(stream)>>>(part0, part1, part2, part3, bias, y, B,
+                                                                         y_pred, loss, g_logit, g_bias);
+  return launch_status();
+}
+
+extern "C" int dctr_dense_opt(float* p, const float* g, float* state, int64_t n, int32_t opt, float lr, float eps,
+                              dctr_stream_t stream) {
+  if (!p || !g || n < 0) return DCTR_EINVAL;
+  if (opt != DCTR_UPD_SGD && opt != DCTR_UPD_ADAGRAD) return DCTR_EINVAL;
+  if (opt == DCTR_UPD_ADAGRAD && !state) return DCTR_EINVAL;
+  if (n == 0) return DCTR_OK;
+  const bool aligned = reinterpret_cast<uintptr_t>(p) % 16 == 0 && reinterpret_cast<uintptr_t>(g) % 16 == 0 &&
+                       (!state || reinterpret_cast<uintptr_t>(state) % 16 == 0);
+  const int64_t n4 = aligned ? n / 4 : 0;
+  const int64_t items = n4 + (n - 4 * n4);
+  const dim3 grid(static_cast<unsigned>((items + 255) / 256)), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (opt == DCTR_UPD_ADAGRAD)
+    k_dense_opt<DCTR_UPD_ADAGRAD><<<grid, block, 0, s>>>(p, g, state, n4, n, lr, eps);
+  else
+    k_dense_opt<DCTR_UPD_SGD><<<grid, block, 0, s>>>(p, g, state, n4, n, lr, eps);
+  return launch_status();
+}

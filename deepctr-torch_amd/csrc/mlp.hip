@@ -1,0 +1,730 @@
+// mlp.hip -- the DNN tower (layers/core.py:120-134: Linear -> ReLU per hidden layer, no BN, dropout inactive)
+// plus the [N_last -> 1] projection `dnn_linear` (deepfm.py:61,84) on the gfx950 matrix cores, fp32 in / fp32 out.
+//
+// The reference issues, per train step, 3 GEMMs forward and 6 backward through ATen (hipBLASLt picks a
+// different macro-tile per shape: 9 GEMM launches + bias / relu / threshold / column-sum launches, ~25 kernels,
+// ~250 us at batch 4096 where the math is 3.5 GFLOP = 22 us at the fp32 MFMA peak).  Here the whole tower is
+//     k_mlp_fwd       1 launch: every layer + the projection, activations handed on through LDS
+//     k_mlp_bwd_data  1 launch: d loss / d pre-activation of every layer and d loss / d input
+//     k_mlp_wgrad     1 launch: every dW, dbias, dw_out as split-batch partials (no atomics)
+//     k_mlp_reduce    1 launch: fixed-order sum of the partials -> the gradient tensors
+// v_mfma_f32_16x16x4_f32 / 32x32x2_f32 are exact fp32 (an fmaf chain), so the 1e-5 logit bar holds.
+//
+// Forward / backward-data mapping: a workgroup (8 waves) owns 16 samples -- the MFMA row dimension -- for the
+// whole tower, so a layer's output never leaves the CU: it is written to LDS in the accumulator layout and read
+// back as the next layer's A operand.  The weights are the B operand and are used by exactly one wave of the
+// workgroup, so they are not staged: each lane fetches them from L2 straight into registers as dwordx4,
+//   forward   W[n][k..k+3]   (4 consecutive k of one output column; the k -> (MFMA step, lane group) assignment
+//                             is a permutation of the reduction index, applied to A and B alike)
+//   backward  W[n][c..c+3]   (4 consecutive OUTPUT columns: the lane's four accumulators are four interleaved
+//                             16-column tiles, written back as one dwordx4)
+// Both read the native nn.Linear layout [N, K]; no transposed copy exists.  B=4096 -> 256 workgroups, one per CU.
+//
+// Weight-gradient mapping: dW_l = dH_l^T . In_l is a [N_l, K_l] GEMM reduced over the batch.  A wave owns a
+// 64x64 output tile (2x2 MFMA 32x32x2) over a slice of the batch; the four waves of a workgroup take four batch
+// slices of the same tile and are summed through LDS in wave order; S workgroups per tile write S partial slabs
+// that k_mlp_reduce adds in slab order: bit-reproducible, which keeps data-parallel replicas identical.
+#include "common.hpp"
+
+using namespace dctr;
+
+namespace {
+
+constexpr int kTM = 16;        // samples per workgroup (forward / backward-data)
+constexpr int kT = 512;        // threads per workgroup (forward / backward-data)
+constexpr int kWaves = kT / 64;
+constexpr int kKC = 512;       // columns of the tower input staged in LDS at a time
+constexpr int kNTMax = 4;      // output tiles a wave carries at once (forward)
+constexpr int kTW = 256;       // threads per workgroup (wgrad)
+constexpr int kMaxL = DCTR_MLP_MAX_LAYERS;
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int acc_row32(int r, int p) { return (r & 3) + 8 * (r >> 2) + 4 * p; }
+
+__host__ __device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+struct LayerDev {
+  const float* W;
+  const float* bias;
+  float* h;
+  float* dh;
+  int K, N, ldw, ldh, relu;
+};
+
+struct MlpArgs {
+  LayerDev L[kMaxL];
+  int n_layers;
+  int B;
+  const float* x;
+  int64_t ldx;
+  const float* w_out;
+  float* logit;      // forward: [B] (with w_out)
+  const float* g;    // backward: [B] (with w_out) or [B, ldg]
+  int64_t ldg;
+  float* gx;         // backward: [B, ldgx] nullable
+  int64_t ldgx;
+  int rsx, rsh;      // LDS row strides (floats)
+};
+
+__device__ __forceinline__ f32x4 ldg_f4(const float* p) { return *(const DCTR_GLOBAL f32x4*)p; }
+
+// ------------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------------
+// NT output tiles (16 columns each) of one layer over the K range [kg0, kg0 + klen) whose A rows sit in LDS.
+// No load in the loop is predicated (a predicated load becomes a branch and serialises the loop on memory
+// latency): columns past N re-read row N-1 (their results are dropped by the epilogue) and a dwordx4 that would
+// leave the row is pulled back inside it (its A elements are zero, and weights are finite).  The weight stream
+// runs kPD iterations ahead of the matrix pipe in a register ring.
+constexpr int kPD = 4;
+
+template <int NT>
+__device__ __forceinline__ void fwd_tiles(const float* As, int rs, int kg0, int klen, const LayerDev& Ld,
+                                          int tile0, f32x4* acc, int g, int c) {
+  const float* wrow[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    int n = (tile0 + t * kWaves) * 16 + c;
+    n = n < Ld.N ? n : Ld.N - 1;
+    wrow[t] = Ld.W + static_cast<int64_t>(n) * Ld.ldw + kg0 + 4 * g;
+  }
+  const float* ap = As + c * rs + 4 * g;
+  const int n_it = klen >> 4;
+  const int omax = Ld.ldw - kg0 - 4 * g - 4;  // largest in-row offset of a dwordx4 from wrow
+  auto woff = [&](int it) {
+    it = it < n_it ? it : n_it - 1;
+    const int o = it << 4;
+    return o < omax ? o : omax;
+  };
+  // ring slot (it % kPD) holds the weights of iteration `it`; at step `it` the slot freed by step it-1 is
+  // refilled with iteration it + kPD - 1, so no live register is ever a load destination.
+  f32x4 ring[kPD][NT];
+#pragma unroll
+  for (int d = 0; d < kPD - 1; ++d) {
+    const int o = woff(d);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) ring[d][t] = ldg_f4(wrow[t] + o);
+  }
+  const int n_grp = n_it / kPD, rem = n_it - n_grp * kPD;
+  f32x4 a_nxt = *reinterpret_cast<const f32x4*>(ap);
+  for (int gi = 0; gi < n_grp; ++gi) {
+#pragma unroll
+    for (int d = 0; d < kPD; ++d) {
+      const int it = gi * kPD + d;
+      const int o = woff(it + kPD - 1);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) ring[(d + kPD - 1) % kPD][t] = ldg_f4(wrow[t] + o);
+      const f32x4 a4 = a_nxt;
+      const int itn = (it + 1 < n_it) ? it + 1 : it;
+      a_nxt = *reinterpret_cast<const f32x4*>(ap + (itn << 4));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mfma16(a4[j], ring[d][t][j], acc[t]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < kPD - 1; ++d) {
+    if (d < rem) {
+      const int it = n_grp * kPD + d;
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + (it << 4));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mfma16(a4[j], ring[d][t][j], acc[t]);
+    }
+  }
+}
+
+__device__ __forceinline__ void fwd_dispatch(int nt, const float* As, int rs, int kg0, int klen, const LayerDev& Ld,
+                                             int tile0, f32x4* acc, int g, int c) {
+  switch (nt) {
+    case 1: fwd_tiles<1>(As, rs, kg0, klen, Ld, tile0, acc, g, c); break;
+    case 2: fwd_tiles<2>(As, rs, kg0, klen, Ld, tile0, acc, g, c); break;
+    case 3: fwd_tiles<3>(As, rs, kg0, klen, Ld, tile0, acc, g, c); break;
+    case 4: fwd_tiles<4>(As, rs, kg0, klen, Ld, tile0, acc, g, c); break;
+    default: break;
+  }
+}
+
+__global__ __launch_bounds__(kT) void k_mlp_fwd(MlpArgs A) {
+  extern __shared__ __align__(16) float smem[];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int b0 = blockIdx.x * kTM;
+  const int rsx = A.rsx, rsh = A.rsh;
+  float* xs = smem;               // [16][rsx]  chunk of the tower input
+  float* hb0 = xs + kTM * rsx;    // [16][rsh]  ping
+  float* hb1 = hb0 + kTM * rsh;   // [16][rsh]  pong
+  const int K0 = A.L[0].K, K0p = round_up(K0, 16);
+  const int kcw = K0p < kKC ? K0p : kKC;
+
+  const float* in = nullptr;
+  for (int l = 0; l < A.n_layers; ++l) {
+    const LayerDev& Ld = A.L[l];
+    const int ntile = (Ld.N + 15) >> 4;
+    float* outb = (l & 1) ? hb1 : hb0;
+    for (int tbase = 0; tbase < ntile; tbase += kWaves * kNTMax) {
+      const int tile0 = tbase + wv;
+      int nt = 0;
+#pragma unroll
+      for (int t = 0; t < kNTMax; ++t) nt += (tile0 + t * kWaves < ntile) ? 1 : 0;
+      f32x4 acc[kNTMax];
+#pragma unroll
+      for (int t = 0; t < kNTMax; ++t) {
+        const int n = (tile0 + t * kWaves) * 16 + c;
+        const float bv = (t < nt && n < Ld.N && Ld.bias) ? ldg_f32(Ld.bias + n) : 0.f;
+        acc[t] = f32x4{bv, bv, bv, bv};
+      }
+      if (l == 0) {
+        for (int kc = 0; kc < K0p; kc += kcw) {
+          const int klen = (K0p - kc) < kcw ? (K0p - kc) : kcw;
+          __syncthreads();  // the previous chunk (or pass) is consumed
+          for (int e = tid; e < kTM * (klen >> 2); e += kT) {
+            const int r = e / (klen >> 2), q = e - r * (klen >> 2);
+            const int k = kc + 4 * q;
+            const int64_t b = b0 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b < A.B) {
+              const float* src = A.x + b * A.ldx + k;
+              if (k + 3 < K0) {
+                v = ldg_f4(src);
+              } else {
+                if (k < K0) v.x = ldg_f32(src);
+                if (k + 1 < K0) v.y = ldg_f32(src + 1);
+                if (k + 2 < K0) v.z = ldg_f32(src + 2);
+              }
+            }
+            *reinterpret_cast<f32x4*>(xs + r * rsx + 4 * q) = v;
+          }
+          __syncthreads();
+          fwd_dispatch(nt, xs, rsx, kc, klen, Ld, tile0, acc, g, c);
+        }
+      } else {
+        fwd_dispatch(nt, in, rsh, 0, round_up(Ld.K, 16), Ld, tile0, acc, g, c);
+      }
+      // epilogue: activation; keep the tile in LDS for the next layer, save it for the backward
+#pragma unroll
+      for (int t = 0; t < kNTMax; ++t) {
+        if (t < nt) {
+          const int n = (tile0 + t * kWaves) * 16 + c;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 4 * g + r;
+            float v = acc[t][r];
+            if (Ld.relu) v = v > 0.f ? v : 0.f;
+            if (n >= Ld.N) v = 0.f;
+            outb[row * rsh + n] = v;
+            if (Ld.h && n < Ld.N && b0 + row < A.B) stg_f32(Ld.h + static_cast<int64_t>(b0 + row) * Ld.ldh + n, v);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    in = outb;
+  }
+  if (A.w_out && A.logit) {  // dnn_linear: logit[b] = h_last[b, :] . w_out
+    const LayerDev& Lt = A.L[A.n_layers - 1];
+    for (int row = wv; row < kTM; row += kWaves) {
+      float s = 0.f;
+      for (int n = lane; n < Lt.N; n += 64) s += in[row * rsh + n] * ldg_f32(A.w_out + n);
+      s = wave_sum(s);
+      if (lane == 0 && b0 + row < A.B) stg_f32(A.logit + b0 + row, s);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward, data path: dH_l (gradient w.r.t. the pre-activation of layer l) for every layer, then d/d input
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void k_mlp_bwd_data(MlpArgs A) {
+  extern __shared__ __align__(16) float smem[];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int b0 = blockIdx.x * kTM;
+  const int rs = A.rsh;
+  float* d0 = smem;
+  float* d1 = d0 + kTM * rs;
+  const int top = A.n_layers - 1;
+  {
+    const LayerDev& Lt = A.L[top];
+    const int Np = round_up(Lt.N, 16);
+    for (int e = tid; e < kTM * Np; e += kT) {
+      const int r = e / Np, n = e - r * Np;
+      const int64_t b = b0 + r;
+      float v = 0.f;
+      if (b < A.B && n < Lt.N) {
+        const float gv = A.w_out ? ldg_f32(A.g + b) * ldg_f32(A.w_out + n) : ldg_f32(A.g + b * A.ldg + n);
+        v = gv;
+        if (Lt.relu) v = ldg_f32(Lt.h + b * Lt.ldh + n) > 0.f ? gv : 0.f;
+        if (Lt.dh) stg_f32(Lt.dh + b * Lt.ldh + n, v);
+      }
+      d0[r * rs + n] = v;
+    }
+  }
+  __syncthreads();
+  float* din = d0;
+  float* dout = d1;
+  for (int l = top; l >= 0; --l) {
+    const LayerDev& Ld = A.L[l];
+    const int Np = round_up(Ld.N, 16);      // reduction length
+    const int Kp = round_up(Ld.K, 16);      // output columns kept in LDS for the next (lower) layer
+    const int ngroups = (Ld.K + 63) >> 6;
+    if (l > 0 || A.gx) {
+      for (int gb = wv; gb < ngroups; gb += kWaves) {
+        const int col0 = 64 * gb + 4 * c;
+        // ldw % 4 == 0: a dwordx4 at col0 < ldw stays inside the row.  Columns past it re-read column 0 and
+        // rows past N re-read row N-1 (the A operand is zero there): no predicated loads in the loop.
+        const int colc = col0 < Ld.ldw ? col0 : 0;
+        f32x4 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* ap = din + c * rs + 4 * g;
+        const float* wp = Ld.W + colc;
+        const int n_it = Np >> 4;
+        auto wld = [&](int it, f32x4* dst) {
+          it = it < n_it ? it : n_it - 1;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            int n = (it << 4) + 4 * g + j;
+            n = n < Ld.N ? n : Ld.N - 1;
+            dst[j] = ldg_f4(wp + static_cast<int64_t>(n) * Ld.ldw);
+          }
+        };
+        constexpr int PD = 3;
+        f32x4 ring[PD][4];
+#pragma unroll
+        for (int d = 0; d < PD - 1; ++d) wld(d, ring[d]);
+        const int n_grp = n_it / PD, rem = n_it - n_grp * PD;
+        f32x4 a_nxt = *reinterpret_cast<const f32x4*>(ap);
+        for (int gi = 0; gi < n_grp; ++gi) {
+#pragma unroll
+          for (int d = 0; d < PD; ++d) {
+            const int it = gi * PD + d;
+            wld(it + PD - 1, ring[(d + PD - 1) % PD]);
+            const f32x4 a4 = a_nxt;
+            const int itn = (it + 1 < n_it) ? it + 1 : it;
+            a_nxt = *reinterpret_cast<const f32x4*>(ap + (itn << 4));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[q] = mfma16(a4[j], ring[d][j][q], acc[q]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+#pragma unroll
+        for (int d = 0; d < PD - 1; ++d) {
+          if (d < rem) {
+            const int it = n_grp * PD + d;
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + (it << 4));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[q] = mfma16(a4[j], ring[d][j][q], acc[q]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * g + r;
+          const int64_t b = b0 + row;
+          f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+          if (l > 0) {
+            const LayerDev& Lp = A.L[l - 1];  // Lp.N == Ld.K
+            if (col0 < Kp) {
+              f32x4 hv = {1.f, 1.f, 1.f, 1.f};
+              const bool full = b < A.B && col0 + 3 < Lp.N;
+              if (Lp.relu && full) hv = ldg_f4(Lp.h + b * Lp.ldh + col0);
+              else if (Lp.relu && b < A.B) {
+                hv.x = col0 < Lp.N ? ldg_f32(Lp.h + b * Lp.ldh + col0) : 0.f;
+                hv.y = col0 + 1 < Lp.N ? ldg_f32(Lp.h + b * Lp.ldh + col0 + 1) : 0.f;
+                hv.z = col0 + 2 < Lp.N ? ldg_f32(Lp.h + b * Lp.ldh + col0 + 2) : 0.f;
+                hv.w = 0.f;
+              }
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                float o = v[q];
+                if (Lp.relu && !(hv[q] > 0.f)) o = 0.f;
+                if (col0 + q >= Lp.N || b >= A.B) o = 0.f;
+                v[q] = o;
+              }
+              *reinterpret_cast<f32x4*>(dout + row * rs + col0) = v;
+              if (Lp.dh && b < A.B) {
+                if (col0 + 3 < Lp.N) *(DCTR_GLOBAL f32x4*)(Lp.dh + b * Lp.ldh + col0) = v;
+                else
+                  for (int q = 0; q < 4; ++q)
+                    if (col0 + q < Lp.N) stg_f32(Lp.dh + b * Lp.ldh + col0 + q, v[q]);
+              }
+            }
+          } else if (b < A.B) {
+            if (col0 + 3 < Ld.K && col0 + 3 < A.ldgx) *(DCTR_GLOBAL f32x4*)(A.gx + b * A.ldgx + col0) = v;
+            else
+              for (int q = 0; q < 4; ++q)
+                if (col0 + q < Ld.K) stg_f32(A.gx + b * A.ldgx + col0 + q, v[q]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    float* t = din;
+    din = dout;
+    dout = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// weight gradients
+// ------------------------------------------------------------------------------------------------------------
+struct WgradArgs {
+  LayerDev L[kMaxL];
+  int n_layers, B, S, bs;      // S batch splits of bs rows each (bs % 8 == 0)
+  int blk0[kMaxL + 2];         // first block of layer l; [n_layers] = projection blocks; [n_layers + 1] = end
+  int64_t off_w[kMaxL], off_b[kMaxL], off_o, slab;  // float offsets inside one partial slab; slab = its size
+  const float* x;
+  int64_t ldx;
+  const float* w_out;
+  const float* g;  // [B] when w_out
+  float* part;     // [S][slab]
+};
+
+__global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
+  __shared__ float red[3 * 64 * 64];  // waves 1..3 park their 64x64 tile (48 KB)
+  __shared__ float redb[3 * 64];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, p = lane >> 5, jl = lane & 31;
+  const int blk = blockIdx.x;
+  int l = 0;
+  while (l < A.n_layers && blk >= A.blk0[l + 1]) ++l;
+  const int local = blk - A.blk0[l];
+  const int s = local % A.S;
+  const int64_t rb0 = static_cast<int64_t>(s) * A.bs;
+  const int64_t rb1 = (rb0 + A.bs < A.B) ? rb0 + A.bs : A.B;
+  float* part = A.part + static_cast<int64_t>(s) * A.slab;
+
+  if (l == A.n_layers) {  // d w_out[n] = sum_b g[b] * h_top[b, n]
+    const LayerDev& Lt = A.L[A.n_layers - 1];
+    for (int n = tid; n < Lt.N; n += kTW) {
+      float acc = 0.f;
+#pragma unroll 8
+      for (int64_t b = rb0; b < rb1; ++b) acc += ldg_f32(A.g + b) * ldg_f32(Lt.h + b * Lt.ldh + n);
+      stg_f32(part + A.off_o + n, acc);
+    }
+    return;
+  }
+
+  const LayerDev& Ld = A.L[l];
+  const float* in = (l == 0) ? A.x : A.L[l - 1].h;
+  const int64_t ldi = (l == 0) ? A.ldx : A.L[l - 1].ldh;
+  const int kt = (Ld.K + 63) >> 6;
+  const int tile = local / A.S;
+  const int m0 = (tile / kt) * 64, k0 = (tile % kt) * 64;
+  // the workgroup's rows are dealt to its four waves in contiguous quarters (even sizes: 2 rows per MFMA)
+  const int bq = round_up(static_cast<int>((rb1 - rb0 + 3) / 4), 2);
+  const int64_t wb0 = rb0 + static_cast<int64_t>(wv) * bq;
+  const int64_t wb1 = (wb0 + bq < rb1) ? wb0 + bq : rb1;
+
+  const int ma = m0 + jl, mb = m0 + 32 + jl, ka = k0 + jl, kb = k0 + 32 + jl;
+  const bool va = ma < Ld.N, vb = mb < Ld.N, vka = ka < Ld.K, vkb = kb < Ld.K;
+  f32x16 c00, c01, c10, c11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c00[r] = c01[r] = c10[r] = c11[r] = 0.f;
+  float sa = 0.f, sb = 0.f;
+  const bool want_bias = (k0 == 0);
+  // Unpredicated loads (clamped row / column, value masked afterwards), U row pairs per group, the loads of the
+  // next PD groups in flight while the matrix pipe works on the current one.
+  constexpr int U = 4, PD = 3;
+  const int mac = va ? ma : 0, mbc = vb ? mb : 0, kac = vka ? ka : 0, kbc = vkb ? kb : 0;
+  const int64_t blast = (wb1 > wb0) ? wb1 - 1 : wb0;
+  // 32-bit byte offsets from uniform bases (the host checks the tensors are < 4 GB): one VGPR per address
+  const DCTR_GLOBAL char* dbase = (const DCTR_GLOBAL char*)Ld.dh;
+  const DCTR_GLOBAL char* ibase = (const DCTR_GLOBAL char*)in;
+  const uint32_t ldh4 = static_cast<uint32_t>(Ld.ldh) * 4u, ldi4 = static_cast<uint32_t>(ldi) * 4u;
+  auto gload = [&](int64_t bb, float (*v)[4]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t b = bb + 2 * u + p;
+      b = b < wb1 ? b : blast;
+      const uint32_t od = static_cast<uint32_t>(b) * ldh4, oi = static_cast<uint32_t>(b) * ldi4;
+      v[u][0] = *(const DCTR_GLOBAL float*)(dbase + (od + 4u * mac));
+      v[u][1] = *(const DCTR_GLOBAL float*)(dbase + (od + 4u * mbc));
+      v[u][2] = *(const DCTR_GLOBAL float*)(ibase + (oi + 4u * kac));
+      v[u][3] = *(const DCTR_GLOBAL float*)(ibase + (oi + 4u * kbc));
+    }
+  };
+  if (wb1 > wb0) {
+    float ring[PD][U][4];
+#pragma unroll
+    for (int d = 0; d < PD - 1; ++d) gload(wb0 + d * 2 * U, ring[d]);
+    for (int64_t bb = wb0; bb < wb1; bb += 2 * U * PD) {
+#pragma unroll
+      for (int dd = 0; dd < PD; ++dd) {
+        const int64_t b0g = bb + dd * 2 * U;
+        gload(b0g + 2 * U * (PD - 1), ring[(dd + PD - 1) % PD]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (b0g < wb1) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const bool vr = (b0g + 2 * u + p) < wb1;
+            const float a0 = (vr && va) ? ring[dd][u][0] : 0.f;
+            const float a1 = (vr && vb) ? ring[dd][u][1] : 0.f;
+            const float x0 = (vr && vka) ? ring[dd][u][2] : 0.f;
+            const float x1 = (vr && vkb) ? ring[dd][u][3] : 0.f;
+            c00 = mfma32(a0, x0, c00);
+            c01 = mfma32(a0, x1, c01);
+            c10 = mfma32(a1, x0, c10);
+            c11 = mfma32(a1, x1, c11);
+            sa += a0;
+            sb += a1;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // combine the four waves in wave order
+  if (wv > 0) {
+    float* dst = red + (wv - 1) * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dst[(0 * 16 + r) * 64 + lane] = c00[r];
+      dst[(1 * 16 + r) * 64 + lane] = c01[r];
+      dst[(2 * 16 + r) * 64 + lane] = c10[r];
+      dst[(3 * 16 + r) * 64 + lane] = c11[r];
+    }
+  }
+  sa += __shfl_xor(sa, 32, kWave);
+  sb += __shfl_xor(sb, 32, kWave);
+  if (want_bias && wv > 0 && p == 0) {
+    redb[(wv - 1) * 64 + jl] = sa;
+    redb[(wv - 1) * 64 + 32 + jl] = sb;
+  }
+  __syncthreads();
+  if (wv != 0) return;
+  for (int w = 0; w < 3; ++w) {
+    const float* src = red + w * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      c00[r] += src[(0 * 16 + r) * 64 + lane];
+      c01[r] += src[(1 * 16 + r) * 64 + lane];
+      c10[r] += src[(2 * 16 + r) * 64 + lane];
+      c11[r] += src[(3 * 16 + r) * 64 + lane];
+    }
+    if (want_bias && p == 0) {
+      sa += redb[w * 64 + jl];
+      sb += redb[w * 64 + 32 + jl];
+    }
+  }
+  float* pw = part + A.off_w[l];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int ra = m0 + acc_row32(r, p), rb = ra + 32;
+    if (ra < Ld.N) {
+      if (ka < Ld.ldw) stg_f32(pw + static_cast<int64_t>(ra) * Ld.ldw + ka, c00[r]);
+      if (kb < Ld.ldw) stg_f32(pw + static_cast<int64_t>(ra) * Ld.ldw + kb, c01[r]);
+    }
+    if (rb < Ld.N) {
+      if (ka < Ld.ldw) stg_f32(pw + static_cast<int64_t>(rb) * Ld.ldw + ka, c10[r]);
+      if (kb < Ld.ldw) stg_f32(pw + static_cast<int64_t>(rb) * Ld.ldw + kb, c11[r]);
+    }
+  }
+  if (want_bias && p == 0) {
+    if (va) stg_f32(part + A.off_b[l] + ma, sa);
+    if (vb) stg_f32(part + A.off_b[l] + mb, sb);
+  }
+}
+
+struct ReduceArgs {
+  int n_seg, S;
+  int64_t slab;
+  int64_t seg_off[2 * kMaxL + 2];  // float offset of segment i inside a slab; [n_seg] = end
+  int64_t seg_len[2 * kMaxL + 1];  // floats of the segment that belong to the destination tensor
+  float* seg_dst[2 * kMaxL + 1];   // nullable: skipped
+  const float* part;
+};
+
+__global__ __launch_bounds__(256) void k_mlp_reduce(ReduceArgs A) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= A.seg_off[A.n_seg]) return;
+  int sg = 0;
+  while (i >= A.seg_off[sg + 1]) ++sg;
+  float* dst = A.seg_dst[sg];
+  if (!dst || i - A.seg_off[sg] >= A.seg_len[sg]) return;
+  float acc = 0.f;
+  for (int s = 0; s < A.S; ++s) acc += ldg_f32(A.part + static_cast<int64_t>(s) * A.slab + i);
+  stg_f32(dst + (i - A.seg_off[sg]), acc);
+}
+
+// ---- host helpers ---------------------------------------------------------------------------------------------
+int check_mlp(const dctr_mlp_t* m, int32_t B) {
+  if (!m || B < 0 || m->n_layers <= 0 || m->n_layers > kMaxL) return DCTR_EINVAL;
+  for (int l = 0; l < m->n_layers; ++l) {
+    const dctr_mlp_layer_t& L = m->layer[l];
+    if (!L.W || L.K <= 0 || L.N <= 0 || L.ld_w < L.K) return DCTR_EINVAL;
+    if (L.ld_w % 4 != 0 || reinterpret_cast<uintptr_t>(L.W) % 16 != 0) return DCTR_EALIGN;
+    if (l > 0 && L.K != m->layer[l - 1].N) return DCTR_EINVAL;
+    if (L.N > 2048) return DCTR_ENOSUP;
+  }
+  return DCTR_OK;
+}
+
+void fill_layers(const dctr_mlp_t* m, LayerDev* L) {
+  for (int l = 0; l < m->n_layers; ++l) {
+    const dctr_mlp_layer_t& s = m->layer[l];
+    L[l].W = s.W; L[l].bias = s.bias; L[l].h = s.h; L[l].dh = s.dh;
+    L[l].K = s.K; L[l].N = s.N; L[l].ldw = s.ld_w; L[l].ldh = s.ld_h; L[l].relu = s.relu;
+  }
+}
+
+int max_width(const dctr_mlp_t* m) {
+  int w = 0;
+  for (int l = 0; l < m->n_layers; ++l) w = m->layer[l].N > w ? m->layer[l].N : w;
+  return w;
+}
+
+struct WgradPlan {
+  int S, bs;
+  int blk0[kMaxL + 2];
+  int64_t off_w[kMaxL], off_b[kMaxL], off_o, slab;
+};
+
+WgradPlan plan_wgrad(const dctr_mlp_t* m, int32_t B) {
+  WgradPlan P;
+  int S = B / 512;
+  if (S < 1) S = 1;
+  if (S > 8) S = 8;
+  P.S = S;
+  P.bs = round_up((B + S - 1) / S, 8);
+  int64_t off = 0;
+  int blk = 0;
+  for (int l = 0; l < m->n_layers; ++l) {
+    const dctr_mlp_layer_t& L = m->layer[l];
+    P.blk0[l] = blk;
+    blk += ((L.N + 63) / 64) * ((L.K + 63) / 64) * S;
+    P.off_w[l] = off;
+    off += static_cast<int64_t>(L.N) * L.ld_w;
+    P.off_b[l] = off;
+    off += round_up(L.N, 4);
+  }
+  P.blk0[m->n_layers] = blk;
+  P.off_o = off;
+  if (m->w_out) {
+    blk += S;
+    off += round_up(m->layer[m->n_layers - 1].N, 4);
+  }
+  P.blk0[m->n_layers + 1] = blk;
+  P.slab = off;
+  return P;
+}
+
+}  // namespace
+
+extern "C" int dctr_mlp_fwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, float* logit,
+                            dctr_stream_t stream) {
+  const int rc = check_mlp(m, B);
+  if (rc != DCTR_OK) return rc;
+  if (!x || ld_x < m->layer[0].K) return DCTR_EINVAL;
+  if (ld_x % 4 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0) return DCTR_EALIGN;
+  if (m->w_out && !logit) return DCTR_EINVAL;
+  if (!m->w_out && !m->layer[m->n_layers - 1].h) return DCTR_EINVAL;  // nowhere to put the result
+  for (int l = 0; l < m->n_layers; ++l)
+    if (m->layer[l].h && (m->layer[l].ld_h < m->layer[l].N)) return DCTR_EINVAL;
+  if (B == 0) return DCTR_OK;
+  MlpArgs a;
+  fill_layers(m, a.L);
+  a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = m->w_out; a.logit = logit;
+  a.g = nullptr; a.ldg = 0; a.gx = nullptr; a.ldgx = 0;
+  const int K0p = round_up(m->layer[0].K, 16);
+  a.rsx = (K0p < kKC ? K0p : kKC) + 4;
+  a.rsh = round_up(max_width(m), 16) + 4;
+  const size_t lds = static_cast<size_t>(kTM) * (a.rsx + 2 * a.rsh) * 4;
+  if (lds > 160 * 1024) return DCTR_ENOSUP;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(lds));
+  k_mlp_fwd<<<dim3((B + kTM - 1) / kTM), dim3(kT), lds, static_cast<hipStream_t>(stream)>>>(a);
+  return launch_status();
+}
+
+extern "C" size_t dctr_mlp_bwd_workspace_floats(const dctr_mlp_t* m, int32_t B) {
+  if (check_mlp(m, B) != DCTR_OK) return 0;
+  const WgradPlan P = plan_wgrad(m, B);
+  return static_cast<size_t>(P.slab) * P.S;
+}
+
+extern "C" int dctr_mlp_bwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g,
+                            int64_t ld_g, float* gx, int64_t ld_gx, float* workspace, dctr_stream_t stream) {
+  const int rc = check_mlp(m, B);
+  if (rc != DCTR_OK) return rc;
+  if (!x || !g || !workspace || ld_x < m->layer[0].K) return DCTR_EINVAL;
+  if (!m->w_out && ld_g < m->layer[m->n_layers - 1].N) return DCTR_EINVAL;
+  if (gx && (ld_gx < m->layer[0].K)) return DCTR_EINVAL;
+  if (gx && (ld_gx % 4 != 0 || reinterpret_cast<uintptr_t>(gx) % 16 != 0)) return DCTR_EALIGN;
+  for (int l = 0; l < m->n_layers; ++l) {
+    const dctr_mlp_layer_t& L = m->layer[l];
+    if (!L.h || !L.dh || L.ld_h < L.N) return DCTR_EINVAL;
+    if (L.ld_h % 4 != 0 || reinterpret_cast<uintptr_t>(L.h) % 16 != 0 || reinterpret_cast<uintptr_t>(L.dh) % 16 != 0)
+      return DCTR_EALIGN;
+  }
+  if (B == 0) return DCTR_OK;
+  // k_mlp_wgrad addresses its operands with 32-bit byte offsets
+  for (int l = 0; l < m->n_layers; ++l)
+    if (static_cast<int64_t>(B) * m->layer[l].ld_h * 4 >= (int64_t(1) << 32)) return DCTR_ENOSUP;
+  if (static_cast<int64_t>(B) * ld_x * 4 >= (int64_t(1) << 32)) return DCTR_ENOSUP;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    MlpArgs a;
+    fill_layers(m, a.L);
+    a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = m->w_out; a.logit = nullptr;
+    a.g = g; a.ldg = ld_g; a.gx = gx; a.ldgx = ld_gx;
+    a.rsx = 0;
+    int w = max_width(m);
+    for (int l = 1; l < m->n_layers; ++l) w = m->layer[l].K > w ? m->layer[l].K : w;
+    a.rsh = round_up(w, 64) + 4;
+    const size_t lds = static_cast<size_t>(kTM) * 2 * a.rsh * 4;
+    if (lds > 160 * 1024) return DCTR_ENOSUP;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd_data),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    k_mlp_bwd_data<<<dim3((B + kTM - 1) / kTM), dim3(kT), lds, s>>>(a);
+    const int st = launch_status();
+    if (st != DCTR_OK) return st;
+  }
+  const WgradPlan P = plan_wgrad(m, B);
+  {
+    WgradArgs a;
+    fill_layers(m, a.L);
+    a.n_layers = m->n_layers; a.B = B; a.S = P.S; a.bs = P.bs;
+    for (int i = 0; i < kMaxL + 2; ++i) a.blk0[i] = i <= m->n_layers + 1 ? P.blk0[i] : 0;
+    for (int l = 0; l < kMaxL; ++l) {
+      a.off_w[l] = l < m->n_layers ? P.off_w[l] : 0;
+      a.off_b[l] = l < m->n_layers ? P.off_b[l] : 0;
+    }
+    a.off_o = P.off_o; a.slab = P.slab; a.x = x; a.ldx = ld_x; a.w_out = m->w_out; a.g = g; a.part = workspace;
+    k_mlp_wgrad<<<dim3(P.blk0[m->n_layers + 1]), dim3(kTW), 0, s>>>(a);
+    const int st = launch_status();
+    if (st != DCTR_OK) return st;
+  }
+  {
+    ReduceArgs r;
+    r.S = P.S; r.slab = P.slab; r.part = workspace;
+    int ns = 0;
+    for (int l = 0; l < m->n_layers; ++l) {
+      r.seg_off[ns] = P.off_w[l]; r.seg_len[ns] = static_cast<int64_t>(m->layer[l].N) * m->layer[l].ld_w;
+      r.seg_dst[ns++] = m->layer[l].gW;
+      r.seg_off[ns] = P.off_b[l]; r.seg_len[ns] = m->layer[l].N;
+      r.seg_dst[ns++] = m->layer[l].bias ? m->layer[l].gbias : nullptr;
+    }
+    if (m->w_out) {
+      r.seg_off[ns] = P.off_o; r.seg_len[ns] = m->layer[m->n_layers - 1].N;
+      r.seg_dst[ns++] = m->g_w_out;
+    }
+    r.seg_off[ns] = P.slab;
+    r.n_seg = ns;
+    k_mlp_reduce<<<dim3(static_cast<unsigned>((P.slab + 255) / 256)), dim3(256), 0, s>>>(r);
+  }
+  return launch_status();
+}

@@ -43,6 +43,12 @@ struct UpdArgs {
   int64_t ldg, ldo, lds_;
   int32_t n_units, B, log2p, bbits;
   float lr, eps;
+  // optional extra role (last block): d loss / d Linear.weight = X_dense^T g_wide  (basemodel.py:88-90)
+  const float* X;
+  int64_t ldx;
+  const int32_t* wdense_cols;
+  int32_t n_wdense;
+  float* g_wdense;
 };
 
 __device__ __forceinline__ int32_t clamp_id(int32_t id, int64_t vocab) {
@@ -82,6 +88,27 @@ __global__ __launch_bounds__(kThreads) void k_embed_update(UpdArgs A) {
   __shared__ int carry_id;
   const int tid = threadIdx.x;
   const int P = 1 << A.log2p;
+
+  if (A.g_wdense && blockIdx.x == gridDim.x - 1) {
+    // the dense half of Linear (basemodel.py:86-90): g_w[j] = sum_b g_wide[b] * X[b, col_j], fixed-order tree
+    __shared__ float red[kThreads / 64];
+    for (int j = 0; j < A.n_wdense; ++j) {
+      const int col = ldg_i32(A.wdense_cols + j);
+      float acc = 0.f;
+      for (int b = tid; b < A.B; b += kThreads)
+        acc += ldg_f32(A.gwide + b) * ldg_f32(A.X + static_cast<int64_t>(b) * A.ldx + col);
+      acc = wave_sum(acc);
+      if ((tid & 63) == 0) red[tid >> 6] = acc;
+      __syncthreads();
+      if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < kThreads / 64; ++w) t += red[w];
+        stg_f32(A.g_wdense + j, t);
+      }
+      __syncthreads();
+    }
+    return;
+  }
 
   // XCD-aware decode: block b runs on XCD b % 8 (observed); keep all partitions of a unit on one XCD
   // so the unit's id row is fetched into one L2 only.
@@ -336,8 +363,10 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
                                  int64_t max_vocab, const int32_t* ids_t, int32_t B, const float* g_out,
                                  int64_t ld_g, const float* out, int64_t ld_out, const float* fm_s,
                                  int64_t ld_s, const float* g_fm, const float* g_wide, int32_t opt,
-                                 float lr, float eps, dctr_stream_t stream) {
+                                 float lr, float eps, const float* X, int64_t ld_x, float* g_wdense,
+                                 dctr_stream_t stream) {
   if (!plan || !units || !ids_t || n_units <= 0 || B < 0) return DCTR_EINVAL;
+  if (g_wdense && (!X || !g_wide || plan->n_wdense <= 0 || !plan->wdense_cols)) return DCTR_EINVAL;
   if (B == 0) return DCTR_OK;
   if (opt != DCTR_UPD_SGD && opt != DCTR_UPD_ADAGRAD && opt != DCTR_UPD_ACCUM) return DCTR_EINVAL;
   if (!dctr_embed_update_supported(plan, max_vocab, B)) return DCTR_ENOSUP;
@@ -360,6 +389,7 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
   a.log2p = log2p;
   a.bbits = ceil_log2(B < 2 ? 2 : B);
   a.lr = lr; a.eps = eps;
+  a.X = X; a.ldx = ld_x; a.wdense_cols = plan->wdense_cols; a.n_wdense = plan->n_wdense; a.g_wdense = g_wdense;
 
   int lpr = 1;
   const int need = plan->n_deep > 0 ? (plan->max_dim + vec - 1) / vec : 1;
@@ -370,7 +400,7 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
   const size_t lds = static_cast<size_t>(cap) * 4 + (static_cast<size_t>(g) * lpr * vec + g + lpr * vec + 4) * 4;
   if (lds > 150 * 1024) return DCTR_ENOSUP;
   const int units8 = (n_units + 7) / 8 * 8;
-  const dim3 grid(static_cast<unsigned>(units8) << log2p), block(kThreads);
+  const dim3 grid((static_cast<unsigned>(units8) << log2p) + (g_wdense ? 1u : 0u)), block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
 
 #define DCTR_UPD_LAUNCH(VEC_, LPR_)                                                                   \

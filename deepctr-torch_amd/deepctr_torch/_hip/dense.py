@@ -1,0 +1,111 @@
+"""One flat slab for every dense (non-table) parameter, its gradient and its optimizer state.
+
+The reference steps ``torch.optim`` over the parameter list: for Adagrad that is addcmul / sqrt / add /
+addcdiv ``foreach`` launches plus a ``zero_grad`` per step (basemodel.py:244,262) -- ~8 launches of pure latency
+for 143 k dense parameters.  Here the parameters are re-seated ONCE as views of one contiguous fp32 slab (values
+preserved, ``state_dict`` keys and shapes unchanged), the gradient kernels write into a second slab with the same
+layout, and ``dctr_dense_opt`` (csrc/head.hip) applies SGD / Adagrad to the whole slab in one launch.
+
+Weights consumed by the MFMA tower (csrc/mlp.hip) get their rows padded to a multiple of 4 floats inside the
+slab (the parameter becomes a strided view ``slab[N, ld][:, :K]``); the padding stays zero because its
+gradient is written as zero.
+"""
+import ctypes
+
+import torch
+
+from . import lib as L
+
+
+def _r4(n):
+    return (int(n) + 3) // 4 * 4
+
+
+class DenseSlab(object):
+    def __init__(self, params, pad_rows=()):
+        """params: list of nn.Parameter (fp32, same device); pad_rows: parameters whose rows are padded."""
+        self.params = list(params)
+        pad = set(id(p) for p in pad_rows)
+        dev = self.params[0].device
+        self._lay = {}
+        off = 0
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise RuntimeError("the dense slab holds float32 parameters of one device")
+            if id(p) in pad and p.dim() == 2 and p.shape[1] > 1:
+                rows, cols, ld = p.shape[0], p.shape[1], _r4(p.shape[1])
+            else:
+                rows, cols, ld = 1, p.numel(), p.numel()
+            self._lay[id(p)] = (off, rows, cols, ld)
+            off += _r4(rows * ld)
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.state = None
+        with torch.no_grad():
+            for p in self.params:
+                v = self._view(self.flat, p)
+                v.copy_(p.detach())
+                p.data = v
+                p.grad = None
+        self._ptrs = [p.data_ptr() for p in self.params]
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_lay"] = [self._lay[id(p)] for p in self.params]     # id() keys do not survive pickling
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self._lay = {id(p): lay for p, lay in zip(self.params, d["_lay"])}
+
+    def _rows(self, buf, p):
+        off, rows, cols, ld = self._lay[id(p)]
+        return buf[off:off + rows * ld].view(rows, ld)
+
+    def _view(self, buf, p):
+        off, rows, cols, ld = self._lay[id(p)]
+        if rows > 1 or ld != cols:
+            return buf[off:off + rows * ld].view(rows, ld)[:, :cols]
+        return buf[off:off + cols].view(p.shape)
+
+    def intact(self):
+        """False once somebody re-allocated a parameter (``model.to()``, ``p.data = ...``): re-adopt then."""
+        return all(p.data_ptr() == q for p, q in zip(self.params, self._ptrs))
+
+    def grad_of(self, p):
+        """Where the gradient kernels write: the padded ``[rows, ld]`` block for padded weights, else a view
+        shaped like the parameter."""
+        if id(p) not in self._lay:
+            return None
+        off, rows, cols, ld = self._lay[id(p)]
+        if rows > 1 or ld != cols:
+            return self._rows(self.grad, p)
+        return self.grad[off:off + cols].view(p.shape)
+
+    def attach_grads(self):
+        """``param.grad`` = its view of the gradient slab (what a user or a generic optimizer would read)."""
+        for p in self.params:
+            p.grad = self._view(self.grad, p)
+
+    def adopt_adagrad_state(self, optimizer):
+        """Move ``optimizer.state[p]['sum']`` of every slab parameter into a third slab (values kept), so that
+        ``optimizer.state_dict()`` keeps working and the fused kernel updates the very same memory."""
+        self.state = torch.zeros_like(self.flat)
+        for p in self.params:
+            st = optimizer.state.get(p)
+            if st is None or "sum" not in st:
+                raise RuntimeError("Adagrad state missing for a dense parameter")
+            v = self._view(self.state, p)
+            v.copy_(st["sum"])
+            st["sum"] = v
+        # the padding of the state stays 0; its gradient is 0, so sqrt(0) + eps never divides anything but 0
+
+    def step(self, kind, lr, eps=0.0):
+        opt = L.UPD_ADAGRAD if kind == "adagrad" else L.UPD_SGD
+        st = self.state
+        if opt == L.UPD_ADAGRAD and st is None:
+            raise RuntimeError("adopt_adagrad_state() first")
+        L.check(L.lib().dctr_dense_opt(ctypes.c_void_p(self.flat.data_ptr()), ctypes.c_void_p(self.grad.data_ptr()),
+                                       ctypes.c_void_p(st.data_ptr()) if st is not None else None, self.numel, opt,
+                                       float(lr), float(eps), L.stream_handle(self.flat.device)), "dctr_dense_opt")

@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdctr_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 
@@ -33,6 +33,22 @@ class Plan(ctypes.Structure):
                 ("max_dim", ctypes.c_int32), ("vec", ctypes.c_int32), ("flags", ctypes.c_int32)]
 
 
+MLP_MAX_LAYERS = 8
+
+
+class MlpLayer(ctypes.Structure):
+    """``dctr_mlp_layer_t`` (include/dctr.h)."""
+    _fields_ = [("W", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("h", ctypes.c_void_p), ("dh", ctypes.c_void_p),
+                ("gW", ctypes.c_void_p), ("gbias", ctypes.c_void_p), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
+                ("ld_w", ctypes.c_int32), ("ld_h", ctypes.c_int32), ("relu", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
+class Mlp(ctypes.Structure):
+    """``dctr_mlp_t`` (include/dctr.h) -- host struct, device pointers."""
+    _fields_ = [("layer", MlpLayer * MLP_MAX_LAYERS), ("w_out", ctypes.c_void_p), ("g_w_out", ctypes.c_void_p),
+                ("n_layers", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
 PLAN_HAS_GACC, PLAN_HAS_STATE, PLAN_HAS_MAXPOOL = 1, 2, 4
 POOL_CODE = {None: 0, "sum": 1, "mean": 2, "max": 3}
 BWD_ACCUM, BWD_SGD = 0, 1
@@ -53,7 +69,7 @@ SIGNATURES = {
     "dctr_embed_update_supported": (ctypes.c_int, [ctypes.POINTER(Plan), _I64, _I32]),
     "dctr_embed_ids": (ctypes.c_int, [_P, _I32, _P, _I64, _I32, _P, _P]),
     "dctr_embed_update": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I32, _I64, _P, _I32, _P, _I64, _P, _I64, _P, _I64,
-                                         _P, _P, _I32, _F32, _F32, _P]),
+                                         _P, _P, _I32, _F32, _F32, _P, _I64, _P, _P]),
     "dctr_embed_bwd": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P,
                                       _I32, _F32, _P]),
     "dctr_embed_apply": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _I32, _F32, _F32, _P]),
@@ -75,6 +91,12 @@ SIGNATURES = {
     "dctr_crossnet_vec_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _P, _I64, _P]),
     "dctr_crossnet_vec_bwd_workspace_floats": (ctypes.c_size_t, [_I32, _I32, _I32]),
     "dctr_crossnet_vec_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P]),
+    "dctr_sizeof_mlp": (ctypes.c_size_t, []),
+    "dctr_mlp_fwd": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _P]),
+    "dctr_mlp_bwd_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(Mlp), _I32]),
+    "dctr_mlp_bwd": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P]),
+    "dctr_bce_head": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P]),
+    "dctr_dense_opt": (ctypes.c_int, [_P, _P, _P, _I64, _I32, _F32, _F32, _P]),
     "dctr_fm_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P]),
     "dctr_fm_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _I64, _I32, _P]),
 }
@@ -105,8 +127,9 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if handle.dctr_abi_version() != ABI_VERSION:
             raise RuntimeError("libdctr_hip.so ABI %d != binding ABI %d" % (handle.dctr_abi_version(), ABI_VERSION))
-        if handle.dctr_sizeof_field() != ctypes.sizeof(Field) or handle.dctr_sizeof_plan() != ctypes.sizeof(Plan):
-            raise RuntimeError("dctr_field_t / dctr_plan_t layout mismatch between header and binding")
+        if handle.dctr_sizeof_field() != ctypes.sizeof(Field) or handle.dctr_sizeof_plan() != ctypes.sizeof(Plan) \
+                or handle.dctr_sizeof_mlp() != ctypes.sizeof(Mlp):
+            raise RuntimeError("dctr_field_t / dctr_plan_t / dctr_mlp_t layout mismatch between header and binding")
         _lib = handle
     return _lib
 

@@ -1,0 +1,266 @@
+"""The DNN tower (+ ``dnn_linear``) and the BCE prediction head on the C-ABI kernels of csrc/mlp.hip / head.hip.
+
+``tower(dnn, dnn_linear, x)`` == ``dnn_linear(dnn(x))`` of the reference (layers/core.py:120-134 followed by
+deepfm.py:84) whenever the tower is relu / linear without BatchNorm and with inactive dropout -- the only
+configuration the BASELINE models use.  Anything else (BatchNorm, Dice, PReLU, active dropout) keeps the module
+path on PyTorch-ROCm; that is a different GPU implementation, not a CPU fallback.
+
+Gradients take one of two routes:
+  * autograd route (default): ``TowerFunction.backward`` returns dW / dbias / dw_out like any Function;
+  * sink route (fused train step, ``dense.DenseSlab``): the kernels write the gradients straight into the flat
+    gradient slab the fused dense optimizer consumes and autograd sees ``None``.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from ..layers.activation import Identity
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _r4(n):
+    return (int(n) + 3) // 4 * 4
+
+
+def tower_layers(dnn, dnn_linear=None):
+    """[(weight, bias, relu)], w_out  -- or None when the module combination is outside the kernels."""
+    if dnn is None or getattr(dnn, "use_bn", False):
+        return None
+    if dnn.dropout_rate and dnn.training:
+        return None
+    if len(dnn.linears) > L.MLP_MAX_LAYERS:
+        return None
+    layers = []
+    for fc, act in zip(dnn.linears, dnn.activation_layers):
+        if type(act) is nn.ReLU:
+            relu = 1
+        elif type(act) is Identity:
+            relu = 0
+        else:
+            return None
+        if fc.out_features > 2048 or fc.weight.dtype != torch.float32:
+            return None
+        layers.append((fc.weight, fc.bias, relu))
+    w_out = None
+    if dnn_linear is not None:
+        if dnn_linear.bias is not None or dnn_linear.out_features != 1 or \
+                dnn_linear.in_features != dnn.linears[-1].out_features:
+            return None
+        w_out = dnn_linear.weight
+    return layers, w_out
+
+
+def _rows4(W):
+    """(tensor usable as a [N, K] weight with a 16-byte aligned base and ld % 4 == 0, ld).  A slab-seated
+    parameter (dense.DenseSlab) already is; anything else gets a zero-padded copy."""
+    if W.dim() == 2 and (W.shape[1] == 1 or W.stride(1) == 1) and W.stride(0) % 4 == 0 and W.stride(0) >= W.shape[1] \
+            and W.data_ptr() % 16 == 0:
+        return W, W.stride(0)
+    ld = _r4(W.shape[1])
+    buf = torch.zeros((W.shape[0], ld), dtype=torch.float32, device=W.device)
+    buf[:, :W.shape[1]].copy_(W.detach())
+    return buf, ld
+
+
+class _Meta(object):
+    """Static description of one tower call (kept out of autograd's tensor arguments)."""
+
+    def __init__(self, relus, has_out, K, sink=None, param_refs=None):
+        self.relus, self.has_out, self.K, self.sink = list(relus), bool(has_out), int(K), sink
+        self.param_refs = param_refs     # the nn.Parameters, for the sink route
+
+
+def _fill(desc, meta, Ws, lds, biases, hs, dhs, gWs, gbs, w_out, g_w_out):
+    desc.n_layers = len(Ws)
+    K = meta.K
+    for l, W in enumerate(Ws):
+        e = desc.layer[l]
+        e.W = W.data_ptr()
+        e.bias = biases[l].data_ptr() if biases[l] is not None else None
+        e.h = hs[l].data_ptr() if hs[l] is not None else None
+        e.dh = dhs[l].data_ptr() if dhs is not None else None
+        e.gW = gWs[l].data_ptr() if gWs is not None and gWs[l] is not None else None
+        e.gbias = gbs[l].data_ptr() if gbs is not None and gbs[l] is not None else None
+        e.K, e.N, e.ld_w = K, W.shape[0], lds[l]
+        e.ld_h = hs[l].stride(0) if hs[l] is not None else _r4(W.shape[0])
+        e.relu = meta.relus[l]
+        K = W.shape[0]
+    desc.w_out = w_out.data_ptr() if w_out is not None else None
+    desc.g_w_out = g_w_out.data_ptr() if g_w_out is not None else None
+
+
+class TowerFunction(torch.autograd.Function):
+    """x [B, ld_x] (first ``meta.K`` columns are the tower input) -> logit [B, 1] (with w_out) or h_L [B, N_L]."""
+
+    @staticmethod
+    def forward(ctx, x, meta, *params):
+        lib = L.lib()
+        L.require_gpu(x, "DNN input")
+        n = len(meta.relus)
+        ctx.x_cols = x.shape[1]
+        Wp = [params[2 * l] for l in range(n)]
+        bp = [params[2 * l + 1] for l in range(n)]
+        w_out = params[2 * n] if meta.has_out else None
+        if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16 \
+                or x.stride(0) < meta.K:
+            buf = torch.zeros((x.shape[0], _r4(meta.K)), dtype=torch.float32, device=x.device)
+            buf[:, :meta.K].copy_(x[:, :meta.K])
+            x = buf
+        B = x.shape[0]
+        keep = torch.is_grad_enabled() and (x.requires_grad or any(p is not None and p.requires_grad for p in params))
+        Ws, lds = [], []
+        for W in Wp:
+            w, ld = _rows4(W)
+            Ws.append(w)
+            lds.append(ld)
+        hs = []
+        for l, W in enumerate(Wp):
+            need = keep or (l == n - 1 and not meta.has_out)
+            hs.append(torch.empty((B, _r4(W.shape[0])), dtype=torch.float32, device=x.device) if need else None)
+        logit = torch.empty((B,), dtype=torch.float32, device=x.device) if meta.has_out else None
+        wo = w_out.reshape(-1) if w_out is not None else None
+        if wo is not None and not wo.is_contiguous():
+            wo = wo.contiguous()
+        desc = L.Mlp()
+        _fill(desc, meta, Ws, lds, bp, hs, None, None, None, wo, None)
+        L.check(lib.dctr_mlp_fwd(ctypes.byref(desc), _ptr(x), x.stride(0), B, _ptr(logit), L.stream_handle(x.device)),
+                "dctr_mlp_fwd")
+        ctx.meta, ctx.n = meta, n
+        ctx.lds = lds
+        ctx.padded = [w is not W for w, W in zip(Ws, Wp)]
+        if keep:
+            ctx.save_for_backward(x, wo, *(Ws + bp + hs))
+        ctx.set_materialize_grads(False)
+        if meta.has_out:
+            return logit.unsqueeze(1)
+        return hs[-1][:, :Wp[-1].shape[0]]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.lib()
+        meta, n = ctx.meta, ctx.n
+        saved = ctx.saved_tensors
+        x, wo = saved[0], saved[1]
+        Ws, bp, hs = list(saved[2:2 + n]), list(saved[2 + n:2 + 2 * n]), list(saved[2 + 2 * n:2 + 3 * n])
+        n_ret = 2 + 2 * n + (1 if meta.has_out else 0)
+        if g is None:
+            return (None,) * n_ret
+        B, dev = x.shape[0], x.device
+        if meta.has_out:
+            g = g.reshape(B)
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                g = g.float().contiguous()
+            ld_g = 0
+        else:
+            if g.dtype != torch.float32 or g.stride(1) != 1:
+                g = g.float().contiguous()
+            ld_g = g.stride(0)
+        sink = meta.sink
+        dhs = [torch.empty_like(h) for h in hs]
+        need_gx = ctx.needs_input_grad[0]
+        gx = torch.empty((B, x.stride(0)), dtype=torch.float32, device=dev) if need_gx else None
+        gWs, gbs, rets = [], [], []
+        for l in range(n):
+            W, b = Ws[l], bp[l]
+            N, Kl, ld = W.shape[0], (meta.K if l == 0 else Ws[l - 1].shape[0]), ctx.lds[l]
+            gw_sink = sink.grad_of(meta.param_refs[2 * l]) if sink is not None else None
+            gb_sink = sink.grad_of(meta.param_refs[2 * l + 1]) if (sink is not None and b is not None) else None
+            if gw_sink is not None and (gw_sink.dim() != 2 or gw_sink.stride(0) != ld):
+                raise RuntimeError("dense slab and tower disagree on a weight's leading dimension")
+            gW = gw_sink if gw_sink is not None else torch.empty((N, ld), dtype=torch.float32, device=dev)
+            gb = None
+            if b is not None:
+                gb = gb_sink if gb_sink is not None else torch.empty((N,), dtype=torch.float32, device=dev)
+            gWs.append(gW)
+            gbs.append(gb)
+            rets.append(None if gw_sink is not None else (gW if ld == Kl else gW[:, :Kl]))
+            rets.append(None if (b is None or gb_sink is not None) else gb)
+        g_wo = None
+        if meta.has_out:
+            go_sink = sink.grad_of(meta.param_refs[2 * n]) if sink is not None else None
+            if go_sink is not None:
+                go_sink = go_sink.reshape(-1)
+            g_wo = go_sink if go_sink is not None else torch.empty((wo.shape[0],), dtype=torch.float32, device=dev)
+            rets.append(None if go_sink is not None else g_wo.reshape(1, -1))
+        desc = L.Mlp()
+        _fill(desc, meta, Ws, ctx.lds, bp, hs, dhs, gWs, gbs, wo, g_wo)
+        ws = torch.empty((max(1, lib.dctr_mlp_bwd_workspace_floats(ctypes.byref(desc), B)),), dtype=torch.float32,
+                         device=dev)
+        L.check(lib.dctr_mlp_bwd(ctypes.byref(desc), _ptr(x), x.stride(0), B, _ptr(g), ld_g, _ptr(gx),
+                                 gx.stride(0) if gx is not None else 0, _ptr(ws), L.stream_handle(dev)), "dctr_mlp_bwd")
+        if gx is not None and gx.shape[1] != ctx.x_cols:
+            gx = gx[:, :ctx.x_cols]
+        return (gx, None) + tuple(rets)
+
+
+def tower(dnn, dnn_linear, x, K=None, sink=None):
+    """``dnn_linear(dnn(x[:, :K]))`` (or ``dnn(x[:, :K])`` when ``dnn_linear`` is None)."""
+    spec = tower_layers(dnn, dnn_linear)
+    K = x.shape[1] if K is None else K
+    if spec is None or not x.is_cuda or K > 4096:   # very wide inputs (FiBiNET's 10 k) stay on hipBLASLt for now
+        h = dnn(x[:, :K] if K != x.shape[1] else x)
+        return dnn_linear(h) if dnn_linear is not None else h
+    layers, w_out = spec
+    params = []
+    for (W, b, _) in layers:
+        params += [W, b]
+    if w_out is not None:
+        params.append(w_out)
+    meta = _Meta([r for (_, _, r) in layers], w_out is not None, K, sink, params)
+    return TowerFunction.apply(x, meta, *params)
+
+
+class BCEHeadFunction(torch.autograd.Function):
+    """(loss, y_pred) = BCE(sum)(sigmoid(sum(parts) + bias), y) in ONE launch; the launch also produces
+    d loss / d logit, which ``backward`` hands to every part (valid because the train step differentiates
+    ``loss + regularisation + aux`` -- d total / d loss is exactly 1; ``backward`` still scales by the incoming
+    gradient unless ``unit`` says it is known to be 1)."""
+
+    @staticmethod
+    def forward(ctx, y, bias, unit, g_bias_sink, *parts):
+        lib = L.lib()
+        ps = []
+        for p in parts:
+            L.require_gpu(p, "logit part")
+            q = p.reshape(-1)
+            if q.dtype != torch.float32 or not q.is_contiguous():
+                q = q.float().contiguous()
+            ps.append(q)
+        B, dev = ps[0].shape[0], ps[0].device
+        if len(ps) > 4:
+            raise NotImplementedError("the fused head takes at most 4 logit parts")
+        y = y.reshape(-1)
+        if y.dtype != torch.float32 or not y.is_contiguous():
+            y = y.float().contiguous()
+        y_pred = torch.empty((B,), dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        g_logit = torch.empty((B,), dtype=torch.float32, device=dev)
+        g_bias = g_bias_sink if g_bias_sink is not None else (
+            torch.empty((1,), dtype=torch.float32, device=dev) if bias is not None else None)
+        pp = [_ptr(p) for p in ps] + [None] * (4 - len(ps))
+        L.check(lib.dctr_bce_head(pp[0], pp[1], pp[2], pp[3], _ptr(bias), _ptr(y), B, _ptr(y_pred), _ptr(loss),
+                                  _ptr(g_logit), _ptr(g_bias), L.stream_handle(dev)), "dctr_bce_head")
+        ctx.unit, ctx.sunk = bool(unit), g_bias_sink is not None
+        ctx.shapes = [tuple(p.shape) for p in parts]
+        ctx.save_for_backward(g_logit, g_bias if (bias is not None and g_bias_sink is None) else None)
+        ctx.mark_non_differentiable(y_pred)
+        return loss, y_pred
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_pred):
+        g_logit, g_bias = ctx.saved_tensors
+        if not ctx.unit:
+            g_logit = g_logit * g_loss
+            if g_bias is not None:
+                g_bias = g_bias * g_loss
+        gb = None if (ctx.sunk or g_bias is None) else g_bias
+        return (None, gb, None, None) + tuple(g_logit.view(s) for s in ctx.shapes)
+
+
+def bce_head(parts, bias, y, unit=False, g_bias_sink=None):
+    return BCEHeadFunction.apply(y, bias, unit, g_bias_sink, *parts)

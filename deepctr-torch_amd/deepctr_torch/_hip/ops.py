@@ -85,6 +85,7 @@ class EmbedFunction(torch.autograd.Function):
         plan = ctx.plan
         X, out, ids_t, fm_s = ctx.saved_tensors
         B = X.shape[0]
+        g_wd = None
         if not plan.has_lookup:
             g_out = None
         if not plan.has_wide:
@@ -95,8 +96,16 @@ class EmbedFunction(torch.autograd.Function):
         if g_wide is not None:
             g_wide = g_wide.contiguous()
             if plan.wide_dense_weight is not None and ctx.needs_input_grad[3]:
-                # d wide / d Linear.weight = X_dense^T g  (basemodel.py:88-90)
-                g_w = plan.dense_matrix(X, plan.wdense_cols).t().mv(g_wide).unsqueeze(1)
+                # d wide / d Linear.weight = X_dense^T g  (basemodel.py:88-90): an extra workgroup of the
+                # deterministic update kernel when that runs, else a GEMV
+                if ids_t is not None and getattr(plan, "exchange", None) is None and plan.table_params:
+                    sink = getattr(plan, "dense_sink", None)
+                    g_wd = sink.grad_of(plan.wide_dense_weight) if sink is not None else None
+                    if g_wd is None:
+                        g_wd = torch.empty((len(plan.wdense_cols), 1), dtype=torch.float32, device=X.device)
+                        g_w = g_wd
+                else:
+                    g_w = plan.dense_matrix(X, plan.wdense_cols).t().mv(g_wide).unsqueeze(1)
         if g_fm is not None:
             g_fm = g_fm.contiguous()
         ld_g = 0
@@ -130,7 +139,8 @@ class EmbedFunction(torch.autograd.Function):
             L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t), B,
                                           _ptr(g_out), ld_g, _ptr(out), plan.ld_out, _ptr(fm_s),
                                           fm_s.stride(0) if fm_s is not None else 0, _ptr(g_fm), _ptr(g_wide),
-                                          opt, lr, eps, stream), "dctr_embed_update")
+                                          opt, lr, eps, _ptr(X), X.stride(0), _ptr(g_wd), stream),
+                    "dctr_embed_update")
             return None, None, None, g_w, None, None
 
         # general path (pooled VarLen fields, shared tables, very large batches): atomic scatter (+ consume pass)
@@ -158,13 +168,15 @@ class EmbedFunction(torch.autograd.Function):
         return None, None, None, g_w, None, None
 
 
-def embed(plan, X, want_fm=False):
-    """(out [B, width] view, wide [B], fm [B]) for model input ``X`` under ``plan``."""
+def embed(plan, X, want_fm=False, full=False):
+    """(out [B, width] view, wide [B], fm [B]) for model input ``X`` under ``plan``.  ``full`` returns the
+    un-sliced ``[B, ld_out]`` buffer (the MFMA tower reads the first ``plan.width`` columns of it and hands back
+    a gradient of the same shape, so no slice / zero-fill kernels appear in the autograd graph)."""
     L.require_gpu(X, "model input X")
     plan.bind(X.device)
     out, wide, fm = EmbedFunction.apply(plan, X, plan.anchor, plan.wide_dense_weight, bool(want_fm),
                                         torch.is_grad_enabled())
-    if plan.has_lookup:
+    if plan.has_lookup and not full:
         out = out[:, :plan.width]
     return out, wide, fm
 

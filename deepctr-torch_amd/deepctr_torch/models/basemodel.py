@@ -32,6 +32,8 @@ except ImportError:  # pragma: no cover
     tqdm = None
 
 from .. import callbacks as _cb
+from .._hip import dense as _dense
+from .._hip import mlp as _mlp
 from .._hip import ops as _ops
 from .._hip.plan import EmbeddingPlan
 from ..inputs import (DenseFeat, SparseFeat, VarLenSparseFeat, build_input_features, create_embedding_matrix,
@@ -115,6 +117,8 @@ class BaseModel(nn.Module):
         self.history = _cb.History()
         self.stop_training = False
         self._plan = None
+        self._grad_sink = None    # dense.DenseSlab while a fused train step runs
+        self._fused = None        # cached state of the fused train step (see _fused_step_state)
 
     # ------------------------------------------------------------------------------------------------
     # hot path entry points
@@ -135,7 +139,7 @@ class BaseModel(nn.Module):
             self._apply_update_mode()
         return self._plan
 
-    def fused_inputs(self, X, want_fm=False):
+    def fused_inputs(self, X, want_fm=False, full=False):
         """One kernel launch -> (dnn_input ``[B, sum(D)+n_dense]``, linear logit ``[B, 1]``, FM ``[B, 1]``).
 
         ``dnn_input`` is exactly ``combined_dnn_input(*input_from_feature_columns(...))`` of the reference
@@ -143,8 +147,29 @@ class BaseModel(nn.Module):
         every interaction layer consumes), the logit is ``self.linear_model(X)``, and FM is
         ``FM()(that view)`` (deepfm.py:69-82)."""
         plan = self.model_plan()
-        out, wide, fm = _ops.embed(plan, X, want_fm=want_fm)
+        out, wide, fm = _ops.embed(plan, X, want_fm=want_fm, full=full)
         return out, wide.unsqueeze(1), fm.unsqueeze(1)
+
+    def tower_logit(self, x, K=None):
+        """``self.dnn_linear(self.dnn(x[:, :K]))`` on the MFMA tower kernels (csrc/mlp.hip) when the tower is
+        relu / linear without BatchNorm and dropout is inactive, else through the modules."""
+        return _mlp.tower(self.dnn, self.dnn_linear, x, K, sink=self._grad_sink)
+
+    def tower_hidden(self, x, K=None):
+        """``self.dnn(x[:, :K])`` (no projection) on the same kernels."""
+        return _mlp.tower(self.dnn, None, x, K)
+
+    def logit_parts(self, X):
+        """The summands of the final logit, in the reference's order of addition.  Models override this;
+        ``forward`` is ``self.out(sum(parts))``."""
+        raise NotImplementedError
+
+    def forward(self, X):
+        parts = self.logit_parts(X)
+        logit = parts[0]
+        for p in parts[1:]:
+            logit = logit + p
+        return self.out(logit)
 
     def input_from_feature_columns(self, X, feature_columns, embedding_dict, support_dense=True):
         """Reference-shaped accessor (basemodel.py:354-380): list of ``[B, 1, D]`` embeddings (fixed-length
@@ -199,6 +224,10 @@ class BaseModel(nn.Module):
 
     def add_auxiliary_loss(self, aux_loss, alpha):
         self.aux_loss = aux_loss * alpha
+        self._aux_default = False
+
+    def _aux_is_default(self):
+        return getattr(self, "_aux_default", True)
 
     # ------------------------------------------------------------------------------------------------
     # compile (reference basemodel.py:433-516)
@@ -323,9 +352,109 @@ class BaseModel(nn.Module):
                 x[i] = np.expand_dims(x[i], axis=1)
         return torch.from_numpy(np.concatenate(x, axis=-1)).to(self.device).float()
 
+    # ------------------------------------------------------------------------------------------------
+    # fused train step: tower + head + dense optimizer on the C-ABI kernels (launch count)
+    # ------------------------------------------------------------------------------------------------
+    def _dense_update_mode(self, params):
+        """("sgd", lr) / ("adagrad", lr, eps) when one fused pass over the dense slab is EXACTLY what the
+        compiled torch optimizer would do to ``params``, else None."""
+        opt = getattr(self, "optim", None)
+        if opt is None or not params:
+            return None
+        group_of = {}
+        for grp in opt.param_groups:
+            for p in grp["params"]:
+                group_of[id(p)] = grp
+        groups = [group_of.get(id(p)) for p in params]
+        if any(g is None for g in groups):
+            return None
+        g0 = groups[0]
+
+        def same(key):
+            return all(g.get(key) == g0.get(key) for g in groups)
+
+        if type(opt) is torch.optim.SGD:
+            if same("lr") and all(g.get("momentum", 0) == 0 and g.get("weight_decay", 0) == 0 and
+                                  not g.get("nesterov", False) and not g.get("maximize", False) for g in groups):
+                return ("sgd", float(g0["lr"]))
+        if type(opt) is torch.optim.Adagrad:
+            if same("lr") and same("eps") and all(g.get("lr_decay", 0) == 0 and g.get("weight_decay", 0) == 0 and
+                                                  not g.get("maximize", False) for g in groups) and \
+                    all("sum" in opt.state.get(p, {}) for p in params):
+                return ("adagrad", float(g0["lr"]), float(g0["eps"]))
+        return None
+
+    def _fused_step_state(self):
+        """The fused train step applies when every piece of the step is one of our kernels: binary task with
+        BCE(sum), no regulariser / auxiliary loss, tables on the fused sparse update, and every dense parameter
+        is a tower weight, ``dnn_linear``, ``linear_model.weight`` or the prediction bias, all under one plain
+        SGD / Adagrad.  Returns None otherwise (the step then runs through autograd + torch.optim, still on the
+        GPU kernels for the lookups / interactions / tower)."""
+        if os.environ.get("DCTR_FUSED_STEP", "1") == "0":
+            return None
+        if self._fused is not None and self._fused.get("optim") is getattr(self, "optim", None) and \
+                (self._fused["slab"] is None or self._fused["slab"].intact()):
+            return self._fused if self._fused["ok"] else None
+        st = {"ok": False, "slab": None, "optim": getattr(self, "optim", None)}
+        self._fused = st
+        plan = self.model_plan()
+        dnn, dnn_linear = getattr(self, "dnn", None), getattr(self, "dnn_linear", None)
+        if not (getattr(self, "use_dnn", dnn is not None) and dnn is not None and dnn_linear is not None):
+            return None
+        if not getattr(self, "_fused_step_ok", False):    # the model's logit_parts() routes through tower_logit()
+            return None
+        if self.out.task != "binary" or not self.out.use_bias or self.loss_func is not F.binary_cross_entropy:
+            return None
+        if any((l1 > 0 or l2 > 0) for (_, l1, l2) in self.regularization_weight):
+            return None
+        if not plan.unit_path or plan.update[0] not in ("sgd", "adagrad") or not plan.table_params:
+            return None
+        spec = _mlp.tower_layers(dnn, dnn_linear)
+        if spec is None:
+            return None
+        layers, w_out = spec
+        known = [w for (w, b, r) in layers] + [b for (w, b, r) in layers if b is not None] + [w_out, self.out.bias]
+        lw = getattr(self.linear_model, "weight", None)
+        if lw is not None:
+            if plan.wide_dense_weight is not lw:
+                return None
+            known.append(lw)
+        tables = set(id(p) for p in plan.table_params)
+        dense = [p for p in self.parameters() if id(p) not in tables]
+        if set(id(p) for p in dense) != set(id(p) for p in known) or any(not p.requires_grad for p in dense):
+            return None
+        mode = self._dense_update_mode(dense)
+        if mode is None or mode[0] != plan.update[0]:
+            return None
+        slab = _dense.DenseSlab(dense, pad_rows=[w for (w, b, r) in layers])
+        if mode[0] == "adagrad":
+            slab.adopt_adagrad_state(self.optim)
+        slab.attach_grads()
+        st.update(ok=True, slab=slab, mode=mode)
+        return st
+
+    def _train_step_fused(self, st, xb, yb):
+        slab, mode = st["slab"], st["mode"]
+        plan = self.model_plan()
+        self._grad_sink = slab
+        plan.dense_sink = slab
+        try:
+            parts = self.logit_parts(xb)
+            loss, y_pred = _mlp.bce_head(parts, self.out.bias, yb, unit=True, g_bias_sink=slab.grad_of(self.out.bias))
+            loss.backward()
+        finally:
+            self._grad_sink = None
+            plan.dense_sink = None
+        slab.step(*mode)
+        return loss.detach(), loss.detach().reshape(1), y_pred
+
     def _train_step(self, xb, yb):
         """forward -> loss(sum) + reg + aux -> backward (fused sparse update inside) -> dense optimizer step
         (reference basemodel.py:242-262).  Returns device tensors; nothing is synchronised."""
+        if self.training and self._aux_is_default():
+            st = self._fused_step_state()
+            if st is not None:
+                return self._train_step_fused(st, xb, yb)
         y_pred = self(xb).squeeze()
         self.optim.zero_grad()
         if isinstance(self.loss_func, list):

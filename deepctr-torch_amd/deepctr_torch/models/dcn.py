@@ -38,13 +38,16 @@ class DCN(BaseModel):
         self.add_regularization_weight(self.crossnet.kernels, l2=l2_reg_cross)
         self.to(device)
 
-    def forward(self, X):
-        dnn_input, logit, _ = self.fused_inputs(X, want_fm=False)
+    def logit_parts(self, X):
+        plan = self.model_plan()
+        full, logit, _ = self.fused_inputs(X, want_fm=False, full=True)
+        dnn_input = full[:, :plan.width]
+        parts = [logit]
         if len(self.dnn_hidden_units) > 0 and self.cross_num > 0:      # Deep & Cross
-            stack_out = torch.cat((self.crossnet(dnn_input), self.dnn(dnn_input)), dim=-1)
-            logit = logit + self.dnn_linear(stack_out)
+            stack_out = torch.cat((self.crossnet(dnn_input), self.tower_hidden(full, plan.width)), dim=-1)
+            parts.append(self.dnn_linear(stack_out))
         elif len(self.dnn_hidden_units) > 0:                           # only Deep
-            logit = logit + self.dnn_linear(self.dnn(dnn_input))
+            parts.append(self.tower_logit(full, plan.width))
         elif self.cross_num > 0:                                       # only Cross
-            logit = logit + self.dnn_linear(self.crossnet(dnn_input))
-        return self.out(logit)
+            parts.append(self.dnn_linear(self.crossnet(dnn_input)))
+        return parts

@@ -12,6 +12,7 @@ from ..layers import DNN, FM
 
 class DeepFM(BaseModel):
     """Same arguments as the reference (models/deepfm.py:38-43)."""
+    _fused_step_ok = True
 
     def __init__(self, linear_feature_columns, dnn_feature_columns, use_fm=True, dnn_hidden_units=(256, 128),
                  l2_reg_linear=0.00001, l2_reg_embedding=0.00001, l2_reg_dnn=0, init_std=0.0001, seed=1024,
@@ -33,12 +34,13 @@ class DeepFM(BaseModel):
             self.add_regularization_weight(self.dnn_linear.weight, l2=l2_reg_dnn)
         self.to(device)
 
-    def forward(self, X):
+    def logit_parts(self, X):
         plan = self.model_plan()
         want_fm = self.use_fm and len(plan.deep) > 0
-        dnn_input, logit, fm_logit = self.fused_inputs(X, want_fm=want_fm)
+        dnn_input, logit, fm_logit = self.fused_inputs(X, want_fm=want_fm, full=self.use_dnn)
+        parts = [logit]
         if want_fm:
-            logit = logit + fm_logit
+            parts.append(fm_logit)
         if self.use_dnn:
-            logit = logit + self.dnn_linear(self.dnn(dnn_input))
-        return self.out(logit)
+            parts.append(self.tower_logit(dnn_input, plan.width))
+        return parts

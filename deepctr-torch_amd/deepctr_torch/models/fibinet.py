@@ -38,7 +38,7 @@ class FiBiNET(BaseModel):
         sparse_input_dim = field_size * (field_size - 1) * emb_cols[0].embedding_dim
         return (sparse_input_dim if include_sparse else 0) + (dense_input_dim if include_dense else 0)
 
-    def forward(self, X):
+    def logit_parts(self, X):
         plan = self.model_plan()
         gathered, linear_logit, _ = self.fused_inputs(X, want_fm=False)
         B, nf = X.shape[0], len(plan.deep)
@@ -47,11 +47,9 @@ class FiBiNET(BaseModel):
         dnn_input = self.Bilinear.fused_pair(emb, self.SE(emb), dense)
         dnn_logit = self.dnn_linear(self.dnn(dnn_input))
         if len(self.linear_feature_columns) > 0 and len(self.dnn_feature_columns) > 0:
-            final_logit = linear_logit + dnn_logit
+            return [linear_logit, dnn_logit]
         elif len(self.linear_feature_columns) == 0:
-            final_logit = dnn_logit
+            return [dnn_logit]
         elif len(self.dnn_feature_columns) == 0:
-            final_logit = linear_logit
-        else:
-            raise NotImplementedError
-        return self.out(final_logit)
+            return [linear_logit]
+        raise NotImplementedError

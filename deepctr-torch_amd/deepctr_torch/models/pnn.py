@@ -40,7 +40,7 @@ class PNN(BaseModel):
         self.add_regularization_weight(self.dnn_linear.weight, l2=l2_reg_dnn)
         self.to(device)
 
-    def forward(self, X):
+    def logit_parts(self, X):
         plan = self.model_plan()
         gathered, _, _ = self.fused_inputs(X, want_fm=False)      # [B, F*D | dense]
         B, nf = X.shape[0], len(plan.deep)
@@ -53,4 +53,4 @@ class PNN(BaseModel):
         if plan.dense_cols:
             parts.append(gathered[:, plan.emb_width:])
         dnn_input = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
-        return self.out(self.dnn_linear(self.dnn(dnn_input)))
+        return [self.tower_logit(dnn_input)]

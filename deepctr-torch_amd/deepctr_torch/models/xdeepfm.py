@@ -42,16 +42,16 @@ class xDeepFM(BaseModel):
                                            l2=l2_reg_cin)
         self.to(device)
 
-    def forward(self, X):
+    def logit_parts(self, X):
         plan = self.model_plan()
-        dnn_input, linear_logit, _ = self.fused_inputs(X, want_fm=False)
-        final_logit = linear_logit
+        dnn_input, linear_logit, _ = self.fused_inputs(X, want_fm=False, full=True)
+        parts = [linear_logit]
         if self.use_cin:
             if plan.emb_dim <= 0:
                 raise ValueError("embedding_dim of SparseFeat and VarlenSparseFeat must be same in this model!")
             B, nf = X.shape[0], len(plan.deep)
             cin_input = dnn_input[:, :plan.emb_width].reshape(B, nf, plan.emb_dim)   # view of the gather's output
-            final_logit = final_logit + self.cin_linear(self.cin(cin_input))
+            parts.append(self.cin_linear(self.cin(cin_input)))
         if self.use_dnn:
-            final_logit = final_logit + self.dnn_linear(self.dnn(dnn_input))
-        return self.out(final_logit)
+            parts.append(self.tower_logit(dnn_input, plan.width))
+        return parts

@@ -179,7 +179,7 @@ class DataParallelTrainer(object):
                                        _ptr(ids_t), stream), "dctr_embed_ids")
             L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t), NB,
                                           _ptr(G_all) if plan.deep else None, gathered.stride(0), None, 0, None, 0,
-                                          None, _ptr(gw_all) if plan.wide else None, opt, lr, eps, stream),
+                                          None, _ptr(gw_all) if plan.wide else None, opt, lr, eps, None, 0, None, stream),
                     "dctr_embed_update(global)")
         work.wait()
         model.optim.step()

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 2
+#define DCTR_ABI_VERSION 3
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -152,6 +152,9 @@ int dctr_embed_apply(const dctr_plan_t* plan, const float* X, int64_t ldx, int32
  *          DCTR_UPD_ADAGRAD  state[row] += G*G ; table[row] -= lr*G/(sqrt(state[row])+eps)
  *          DCTR_UPD_ACCUM    gacc[row]  += G          (exact dense-gradient semantics: param.grad)
  *   max_vocab  largest vocab over the plan's fields (sizes the 32-bit sort keys)
+ *   g_wdense [plan.n_wdense] (nullable): when given, one extra workgroup also writes the gradient of the dense
+ *          half of Linear, g_wdense[j] = sum_b g_wide[b] * X[b, wdense_cols[j]] (basemodel.py:86-90), in a
+ *          fixed order; X / ld_x are only read for this.
  * dctr_embed_update_supported returns 1 when the plan / batch fit (B <= 32768, keys fit 32 bits).    */
 #define DCTR_UPD_SGD 0
 #define DCTR_UPD_ADAGRAD 1
@@ -162,7 +165,8 @@ int dctr_embed_ids(const int32_t* units, int32_t n_units, const float* X, int64_
 int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, int32_t n_units, int64_t max_vocab,
                       const int32_t* ids_t, int32_t B, const float* g_out, int64_t ld_g, const float* out,
                       int64_t ld_out, const float* fm_s, int64_t ld_s, const float* g_fm,
-                      const float* g_wide, int32_t opt, float lr, float eps, dctr_stream_t stream);
+                      const float* g_wide, int32_t opt, float lr, float eps, const float* X, int64_t ld_x,
+                      float* g_wdense, dctr_stream_t stream);
 
 /* ---- FM on an explicit [B, F, D] tensor (interaction.py:26-34) ------------------------------------
  * E is addressed as E[b*ld_b + f*D + d].  y[b] = 0.5 * sum_d((sum_f e)^2 - sum_f e^2).
@@ -244,6 +248,65 @@ size_t dctr_crossnet_vec_bwd_workspace_floats(int32_t B, int32_t W, int32_t L);
 int dctr_crossnet_vec_bwd(const float* X, int64_t ld_x, int32_t B, int32_t W, int32_t L, const float* kernels,
                           const float* bias, const float* gY, int64_t ld_g, float* gX, int64_t ld_gx,
                           float* g_kernels, float* g_bias, float* workspace, dctr_stream_t stream);
+
+/* ---- DNN tower + dnn_linear on fp32 MFMA (csrc/mlp.hip) ---------------------------------------------------
+ * DNN.forward (layers/core.py:120-134) with relu (or linear) activations, no BatchNorm, dropout inactive:
+ *     h_0 = x ;  h_{l+1} = act(h_l W_l^T + bias_l)            W_l = dnn.linears.<l>.weight [N_l, K_l]
+ * optionally followed by the bias-free projection of deepfm.py:61,84 (xdeepfm / fibinet / pnn alike):
+ *     logit[b] = h_L[b, :] . w_out                              w_out = dnn_linear.weight [1, N_L]
+ * The struct lives in HOST memory.  W rows are addressed W + n*ld_w with ld_w % 4 == 0 and a 16-byte aligned
+ * base; floats in the row padding [K, ld_w) must be finite (they are multiplied by zero).  gW is written with
+ * the same leading dimension (padding columns receive 0).
+ *   h   [B, ld_h] post-activation output of the layer: written by dctr_mlp_fwd when non-NULL (needed by the
+ *                 backward for every layer; without w_out the last layer's h IS the result)
+ *   dh  [B, ld_h] backward scratch: d loss / d pre-activation, written by dctr_mlp_bwd
+ * dctr_mlp_bwd takes g = d loss / d logit [B] (with w_out) or d loss / d h_L [B, ld_g] (without) and writes
+ *   gx [B, ld_gx] = d loss / d x (nullable), layer[l].gW, layer[l].gbias, g_w_out.
+ * Replaces autograd's mm / addmm / threshold_backward / sum chains under basemodel.py:261.  Everything is
+ * summed in a fixed order (no atomics): results are bit-reproducible.
+ *   workspace  dctr_mlp_bwd_workspace_floats(m, B) floats (split-batch partials of the weight gradients)   */
+#define DCTR_MLP_MAX_LAYERS 8
+typedef struct dctr_mlp_layer {
+  const float* W;
+  const float* bias; /* [N] nullable                   */
+  float* h;
+  float* dh;
+  float* gW;         /* [N, ld_w] nullable: not written */
+  float* gbias;      /* [N] nullable                    */
+  int32_t K, N;
+  int32_t ld_w, ld_h;
+  int32_t relu;      /* 1: relu, 0: identity            */
+  int32_t pad_;
+} dctr_mlp_layer_t;
+typedef struct dctr_mlp {
+  dctr_mlp_layer_t layer[DCTR_MLP_MAX_LAYERS];
+  const float* w_out; /* [N_last] nullable */
+  float* g_w_out;     /* [N_last] nullable */
+  int32_t n_layers;
+  int32_t pad_;
+} dctr_mlp_t;
+size_t dctr_sizeof_mlp(void);
+int dctr_mlp_fwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, float* logit, dctr_stream_t stream);
+size_t dctr_mlp_bwd_workspace_floats(const dctr_mlp_t* m, int32_t B);
+int dctr_mlp_bwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g, int64_t ld_g,
+                 float* gx, int64_t ld_gx, float* workspace, dctr_stream_t stream);
+
+/* ---- prediction head + loss (layers/core.py:154-160, basemodel.py:254, F.binary_cross_entropy(reduction='sum'))
+ *     z = sum_i part_i[b] + bias ;  y_pred = sigmoid(z) ;  loss = sum_b -(y log p + (1-y) log(1-p))   (logs clamped
+ *     at -100 like ATen) ;  g_logit = d loss / d z as autograd computes it:
+ *     (p - y) / max((1-p) p, 1e-12) * (1-p) p ;  g_bias = sum_b g_logit.
+ * Up to four logit parts (linear, FM, DNN, CIN ...), each [B], nullable.  One workgroup, tree reductions:
+ * deterministic.  Replaces ~12 elementwise / reduce launches per step.                                      */
+int dctr_bce_head(const float* part0, const float* part1, const float* part2, const float* part3, const float* bias,
+                  const float* y, int32_t B, float* y_pred, float* loss, float* g_logit, float* g_bias,
+                  dctr_stream_t stream);
+
+/* ---- dense optimizer over one flat parameter slab (torch.optim.SGD / Adagrad, basemodel.py:447-461) --------
+ *   DCTR_UPD_SGD      p -= lr * g
+ *   DCTR_UPD_ADAGRAD  state += g*g ; p -= lr * g / (sqrt(state) + eps)
+ * One launch for every dense parameter of the model (the reference's optimizer issues ~8 foreach launches).  */
+int dctr_dense_opt(float* p, const float* g, float* state, int64_t n, int32_t opt, float lr, float eps,
+                   dctr_stream_t stream);
 
 #ifdef __cplusplus
 }

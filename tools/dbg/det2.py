@@ -22,7 +22,7 @@ g_out=torch.randn(B, plan.ld_out, device=DEV, generator=gen); g_fm=torch.randn(B
 def run(use_out, use_fm):
     for p in plan.table_params: plan.gacc_of(p).zero_()
     L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t), B,
-        _ptr(g_out) if use_out else None, plan.ld_out, _ptr(out), plan.ld_out, _ptr(fm_s), 16, _ptr(g_fm) if use_fm else None, _ptr(g_w), L.UPD_ACCUM, 0.0, 0.0, s))
+        _ptr(g_out) if use_out else None, plan.ld_out, _ptr(out), plan.ld_out, _ptr(fm_s), 16, _ptr(g_fm) if use_fm else None, _ptr(g_w), L.UPD_ACCUM, 0.0, 0.0, None, 0, None, s))
     torch.cuda.synchronize()
     return [plan.gacc_of(p).clone() for p in plan.table_params]
 for use_out, use_fm in ((True, False), (False, True), (True, True)):
