@@ -70,9 +70,10 @@ def _rows4(W):
 class _Meta(object):
     """Static description of one tower call (kept out of autograd's tensor arguments)."""
 
-    def __init__(self, relus, has_out, K, sink=None, param_refs=None):
+    def __init__(self, relus, has_out, K, sink=None, param_refs=None, keep=False):
         self.relus, self.has_out, self.K, self.sink = list(relus), bool(has_out), int(K), sink
         self.param_refs = param_refs     # the nn.Parameters, for the sink route
+        self.keep = bool(keep)           # a backward can follow (grad mode is off inside Function.forward)
 
 
 def _fill(desc, meta, Ws, lds, biases, hs, dhs, gWs, gbs, w_out, g_w_out):
@@ -112,7 +113,7 @@ class TowerFunction(torch.autograd.Function):
             buf[:, :meta.K].copy_(x[:, :meta.K])
             x = buf
         B = x.shape[0]
-        keep = torch.is_grad_enabled() and (x.requires_grad or any(p is not None and p.requires_grad for p in params))
+        keep = meta.keep
         Ws, lds = [], []
         for W in Wp:
             w, ld = _rows4(W)
@@ -211,7 +212,8 @@ def tower(dnn, dnn_linear, x, K=None, sink=None):
         params += [W, b]
     if w_out is not None:
         params.append(w_out)
-    meta = _Meta([r for (_, _, r) in layers], w_out is not None, K, sink, params)
+    keep = torch.is_grad_enabled() and (x.requires_grad or any(p is not None and p.requires_grad for p in params))
+    meta = _Meta([r for (_, _, r) in layers], w_out is not None, K, sink, params, keep)
     return TowerFunction.apply(x, meta, *params)
 
 

@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
-( timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider ) > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee $OUT/summary.log
+( timeout 1200 python -m pytest tests/test_gpu_mlp.py tests/test_gpu_deepfm.py tests/test_gpu_models.py tests/test_gpu_update.py tests/test_gpu_parallel.py tests/test_gpu_fullsize.py -m gpu -q --tb=short -p no:cacheprovider ) > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee $OUT/summary.log
 tail -40 $OUT/pytest_gpu.log
 ( timeout 600 python bench.py --steps 200 --warmup 20 ) > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/summary.log
 cat $OUT/bench.json; tail -5 $OUT/bench.err
