@@ -362,10 +362,16 @@ __global__ __launch_bounds__(kT) void k_mlp_bwd_data(MlpArgs A) {
               }
             }
           } else if (b < A.B) {
-            if (col0 + 3 < Ld.K && col0 + 3 < A.ldgx) *(DCTR_GLOBAL f32x4*)(A.gx + b * A.ldgx + col0) = v;
-            else
+            // columns [K, ldgx) of gx are padding: written as zeros so that no garbage is ever handed on
+            if (col0 + 3 < A.ldgx) {
+#pragma unroll
               for (int q = 0; q < 4; ++q)
-                if (col0 + q < Ld.K) stg_f32(A.gx + b * A.ldgx + col0 + q, v[q]);
+                if (col0 + q >= Ld.K) v[q] = 0.f;
+              *(DCTR_GLOBAL f32x4*)(A.gx + b * A.ldgx + col0) = v;
+            } else {
+              for (int q = 0; q < 4; ++q)
+                if (col0 + q < A.ldgx) stg_f32(A.gx + b * A.ldgx + col0 + q, col0 + q < Ld.K ? v[q] : 0.f);
+            }
           }
         }
       }

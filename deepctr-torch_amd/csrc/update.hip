@@ -49,7 +49,16 @@ struct UpdArgs {
   const int32_t* wdense_cols;
   int32_t n_wdense;
   float* g_wdense;
+  unsigned long long* trace;  // diagnostics (tools/upd_trace.py): 8 timestamps per workgroup, or NULL
 };
+
+unsigned long long* g_trace = nullptr;  // host-side: set by dctr_dbg_update_trace
+int g_force_log2p = -1;
+
+#define DCTR_TRACE(slot)                                                     \
+  do {                                                                       \
+    if (A.trace && tid == 0) A.trace[blockIdx.x * 8ull + (slot)] = wall_clock64(); \
+  } while (0)
 
 __device__ __forceinline__ int32_t clamp_id(int32_t id, int64_t vocab) {
   return (static_cast<uint64_t>(static_cast<int64_t>(id)) >= static_cast<uint64_t>(vocab)) ? 0 : id;
@@ -88,6 +97,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_update(UpdArgs A) {
   __shared__ int carry_id;
   const int tid = threadIdx.x;
   const int P = 1 << A.log2p;
+  DCTR_TRACE(0);
 
   if (A.g_wdense && blockIdx.x == gridDim.x - 1) {
     // the dense half of Linear (basemodel.py:86-90): g_w[j] = sum_b g_wide[b] * X[b, col_j], fixed-order tree
@@ -175,6 +185,8 @@ __global__ __launch_bounds__(kThreads) void k_embed_update(UpdArgs A) {
   }
   __syncthreads();
   const int n = n_sh;
+  DCTR_TRACE(1);
+  if (A.trace && tid == 0) A.trace[blockIdx.x * 8ull + 7] = static_cast<unsigned long long>(n);
   if (n == 0) return;
 
   // ---- 2. sort by (id, b) ------------------------------------------------------------------------
@@ -210,6 +222,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_update(UpdArgs A) {
     }
   }
 
+  DCTR_TRACE(2);
   // ---- 3. tiles of G entries ---------------------------------------------------------------------
   const int grp = tid / LPR, gl = tid % LPR;
   const int e0 = gl * VEC;
@@ -255,7 +268,9 @@ __global__ __launch_bounds__(kThreads) void k_embed_update(UpdArgs A) {
       for (int k = 0; k < VEC; ++k) gbuf[grp * (LPR * VEC) + e0 + k] = g.v[k];
     }
     if (gl == 0) gwbuf[grp] = gw;
+    if (t0 == 0) DCTR_TRACE(3);
     __syncthreads();
+    if (t0 == 0) DCTR_TRACE(4);
 
     // the last entry of an id segment (or of the tile) sums the segment's members inside this tile
     const bool last_of_tile = have && ((grp == G - 1) || (i == n - 1));
@@ -307,7 +322,9 @@ __global__ __launch_bounds__(kThreads) void k_embed_update(UpdArgs A) {
       }
     }
     __syncthreads();
+    if (t0 == 0) DCTR_TRACE(5);
   }
+  DCTR_TRACE(6);
 }
 
 // ---- X -> ids_t (standalone; the forward kernel fuses the same thing) -------------------------------
@@ -323,6 +340,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_ids(const int32_t* __restric
 // ~64 entries (one tile) per workgroup up to B = 8192; beyond that every partition's workgroup would
 // re-scan too many ids, so partitions grow to ~256 entries (4 tiles).
 int pick_log2p(int B) {
+  if (g_force_log2p >= 0) return g_force_log2p;
   const int per = B > 8192 ? 256 : 64;
   int l = 0;
   while ((B >> l) > per && l < 10) ++l;
@@ -345,6 +363,12 @@ extern "C" int dctr_embed_ids(const int32_t* units, int32_t n_units, const float
   k_embed_ids<<<dim3(static_cast<unsigned>((n + kThreads - 1) / kThreads)), dim3(kThreads), 0,
                 static_cast<hipStream_t>(stream)>>>(units, n_units, X, ldx, B, ids_t);
   return launch_status();
+}
+
+// diagnostics: per-workgroup phase timestamps (8 x u64 per workgroup, wall_clock64 ticks) and a partition override
+extern "C" void dctr_dbg_update_trace(unsigned long long* buf, int32_t force_log2p) {
+  g_trace = buf;
+  g_force_log2p = force_log2p;
 }
 
 extern "C" int dctr_embed_update_supported(const dctr_plan_t* plan, int64_t max_vocab, int32_t B) {
@@ -389,6 +413,7 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
   a.log2p = log2p;
   a.bbits = ceil_log2(B < 2 ? 2 : B);
   a.lr = lr; a.eps = eps;
+  a.trace = g_trace;
   a.X = X; a.ldx = ld_x; a.wdense_cols = plan->wdense_cols; a.n_wdense = plan->n_wdense; a.g_wdense = g_wdense;
 
   int lpr = 1;

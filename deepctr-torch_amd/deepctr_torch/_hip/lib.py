@@ -67,6 +67,7 @@ SIGNATURES = {
     "dctr_embed_fwd": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _P, _I64, _P, _P, _P, _P, _I32, _P, _P,
                                       _I64, _P]),
     "dctr_embed_update_supported": (ctypes.c_int, [ctypes.POINTER(Plan), _I64, _I32]),
+    "dctr_dbg_update_trace": (None, [_P, _I32]),
     "dctr_embed_ids": (ctypes.c_int, [_P, _I32, _P, _I64, _I32, _P, _P]),
     "dctr_embed_update": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I32, _I64, _P, _I32, _P, _I64, _P, _I64, _P, _I64,
                                          _P, _P, _I32, _F32, _F32, _P, _I64, _P, _P]),

@@ -251,11 +251,14 @@ class BCEHeadFunction(torch.autograd.Function):
         ctx.shapes = [tuple(p.shape) for p in parts]
         ctx.save_for_backward(g_logit, g_bias if (bias is not None and g_bias_sink is None) else None)
         ctx.mark_non_differentiable(y_pred)
+        ctx.set_materialize_grads(False)
         return loss, y_pred
 
     @staticmethod
     def backward(ctx, g_loss, _g_pred):
         g_logit, g_bias = ctx.saved_tensors
+        if g_loss is None:
+            return (None,) * (4 + len(ctx.shapes))
         if not ctx.unit:
             g_logit = g_logit * g_loss
             if g_bias is not None:

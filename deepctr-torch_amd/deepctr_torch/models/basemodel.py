@@ -430,7 +430,7 @@ class BaseModel(nn.Module):
         if mode[0] == "adagrad":
             slab.adopt_adagrad_state(self.optim)
         slab.attach_grads()
-        st.update(ok=True, slab=slab, mode=mode)
+        st.update(ok=True, slab=slab, mode=mode, one=torch.ones((), dtype=torch.float32, device=slab.flat.device))
         return st
 
     def _train_step_fused(self, st, xb, yb):
@@ -441,7 +441,7 @@ class BaseModel(nn.Module):
         try:
             parts = self.logit_parts(xb)
             loss, y_pred = _mlp.bce_head(parts, self.out.bias, yb, unit=True, g_bias_sink=slab.grad_of(self.out.bias))
-            loss.backward()
+            loss.backward(gradient=st["one"])       # a resident 1.0: no fill launch per step
         finally:
             self._grad_sink = None
             plan.dense_sink = None
