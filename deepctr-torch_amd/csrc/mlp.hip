@@ -81,11 +81,13 @@ __device__ __forceinline__ f32x4 ldg_f4(const float* p) { return *(const DCTR_GL
 // latency): columns past N re-read row N-1 (their results are dropped by the epilogue) and a dwordx4 that would
 // leave the row is pulled back inside it (its A elements are zero, and weights are finite).  The weight stream
 // runs kPD iterations ahead of the matrix pipe in a register ring.
-constexpr int kPD = 4;
-
+// (The ring must cover the L2 latency: one iteration is 4*NT MFMAs = 128*NT cycles, so fewer tiles => deeper ring.)
+// Every workgroup walks K from a different starting iteration (`rot`): without it all 256 workgroups request
+// the same weight lines at the same moment and queue up on the same L2 channels.
 template <int NT>
 __device__ __forceinline__ void fwd_tiles(const float* As, int rs, int kg0, int klen, const LayerDev& Ld,
-                                          int tile0, f32x4* acc, int g, int c) {
+                                          int tile0, f32x4* acc, int g, int c, int rot) {
+  constexpr int kPD = NT == 1 ? 12 : (NT == 2 ? 8 : (NT == 3 ? 6 : 4));
   const float* wrow[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -96,9 +98,14 @@ __device__ __forceinline__ void fwd_tiles(const float* As, int rs, int kg0, int 
   const float* ap = As + c * rs + 4 * g;
   const int n_it = klen >> 4;
   const int omax = Ld.ldw - kg0 - 4 * g - 4;  // largest in-row offset of a dwordx4 from wrow
-  auto woff = [&](int it) {
+  const int r0 = rot % n_it;
+  auto phys = [&](int it) {                   // logical iteration -> K block (rotated, clamped past the end)
     it = it < n_it ? it : n_it - 1;
-    const int o = it << 4;
+    const int q = it + r0;
+    return q < n_it ? q : q - n_it;
+  };
+  auto woff = [&](int it) {
+    const int o = phys(it) << 4;
     return o < omax ? o : omax;
   };
   // ring slot (it % kPD) holds the weights of iteration `it`; at step `it` the slot freed by step it-1 is
@@ -111,7 +118,7 @@ __device__ __forceinline__ void fwd_tiles(const float* As, int rs, int kg0, int 
     for (int t = 0; t < NT; ++t) ring[d][t] = ldg_f4(wrow[t] + o);
   }
   const int n_grp = n_it / kPD, rem = n_it - n_grp * kPD;
-  f32x4 a_nxt = *reinterpret_cast<const f32x4*>(ap);
+  f32x4 a_nxt = *reinterpret_cast<const f32x4*>(ap + (phys(0) << 4));
   for (int gi = 0; gi < n_grp; ++gi) {
 #pragma unroll
     for (int d = 0; d < kPD; ++d) {
@@ -120,8 +127,7 @@ __device__ __forceinline__ void fwd_tiles(const float* As, int rs, int kg0, int 
 #pragma unroll
       for (int t = 0; t < NT; ++t) ring[(d + kPD - 1) % kPD][t] = ldg_f4(wrow[t] + o);
       const f32x4 a4 = a_nxt;
-      const int itn = (it + 1 < n_it) ? it + 1 : it;
-      a_nxt = *reinterpret_cast<const f32x4*>(ap + (itn << 4));
+      a_nxt = *reinterpret_cast<const f32x4*>(ap + (phys(it + 1) << 4));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -134,7 +140,7 @@ __device__ __forceinline__ void fwd_tiles(const float* As, int rs, int kg0, int 
   for (int d = 0; d < kPD - 1; ++d) {
     if (d < rem) {
       const int it = n_grp * kPD + d;
-      const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + (it << 4));
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + (phys(it) << 4));
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -144,12 +150,12 @@ __device__ __forceinline__ void fwd_tiles(const float* As, int rs, int kg0, int 
 }
 
 __device__ __forceinline__ void fwd_dispatch(int nt, const float* As, int rs, int kg0, int klen, const LayerDev& Ld,
-                                             int tile0, f32x4* acc, int g, int c) {
+                                             int tile0, f32x4* acc, int g, int c, int rot) {
   switch (nt) {
-    case 1: fwd_tiles<1>(As, rs, kg0, klen, Ld, tile0, acc, g, c); break;
-    case 2: fwd_tiles<2>(As, rs, kg0, klen, Ld, tile0, acc, g, c); break;
-    case 3: fwd_tiles<3>(As, rs, kg0, klen, Ld, tile0, acc, g, c); break;
-    case 4: fwd_tiles<4>(As, rs, kg0, klen, Ld, tile0, acc, g, c); break;
+    case 1: fwd_tiles<1>(As, rs, kg0, klen, Ld, tile0, acc, g, c, rot); break;
+    case 2: fwd_tiles<2>(As, rs, kg0, klen, Ld, tile0, acc, g, c, rot); break;
+    case 3: fwd_tiles<3>(As, rs, kg0, klen, Ld, tile0, acc, g, c, rot); break;
+    case 4: fwd_tiles<4>(As, rs, kg0, klen, Ld, tile0, acc, g, c, rot); break;
     default: break;
   }
 }
@@ -164,6 +170,7 @@ __global__ __launch_bounds__(kT) void k_mlp_fwd(MlpArgs A) {
   float* hb1 = hb0 + kTM * rsh;   // [16][rsh]  pong
   const int K0 = A.L[0].K, K0p = round_up(K0, 16);
   const int kcw = K0p < kKC ? K0p : kKC;
+  const int rot = static_cast<int>(blockIdx.x) * 5;
 
   const float* in = nullptr;
   for (int l = 0; l < A.n_layers; ++l) {
@@ -204,10 +211,10 @@ __global__ __launch_bounds__(kT) void k_mlp_fwd(MlpArgs A) {
             *reinterpret_cast<f32x4*>(xs + r * rsx + 4 * q) = v;
           }
           __syncthreads();
-          fwd_dispatch(nt, xs, rsx, kc, klen, Ld, tile0, acc, g, c);
+          fwd_dispatch(nt, xs, rsx, kc, klen, Ld, tile0, acc, g, c, rot);
         }
       } else {
-        fwd_dispatch(nt, in, rsh, 0, round_up(Ld.K, 16), Ld, tile0, acc, g, c);
+        fwd_dispatch(nt, in, rsh, 0, round_up(Ld.K, 16), Ld, tile0, acc, g, c, rot);
       }
       // epilogue: activation; keep the tile in LDS for the next layer, save it for the backward
 #pragma unroll
@@ -287,8 +294,14 @@ __global__ __launch_bounds__(kT) void k_mlp_bwd_data(MlpArgs A) {
         const float* ap = din + c * rs + 4 * g;
         const float* wp = Ld.W + colc;
         const int n_it = Np >> 4;
-        auto wld = [&](int it, f32x4* dst) {
+        const int r0 = (static_cast<int>(blockIdx.x) * 5) % n_it;
+        auto phys = [&](int it) {
           it = it < n_it ? it : n_it - 1;
+          const int q = it + r0;
+          return q < n_it ? q : q - n_it;
+        };
+        auto wld = [&](int it, f32x4* dst) {
+          it = phys(it);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             int n = (it << 4) + 4 * g + j;
@@ -296,20 +309,19 @@ __global__ __launch_bounds__(kT) void k_mlp_bwd_data(MlpArgs A) {
             dst[j] = ldg_f4(wp + static_cast<int64_t>(n) * Ld.ldw);
           }
         };
-        constexpr int PD = 3;
+        constexpr int PD = 5;
         f32x4 ring[PD][4];
 #pragma unroll
         for (int d = 0; d < PD - 1; ++d) wld(d, ring[d]);
         const int n_grp = n_it / PD, rem = n_it - n_grp * PD;
-        f32x4 a_nxt = *reinterpret_cast<const f32x4*>(ap);
+        f32x4 a_nxt = *reinterpret_cast<const f32x4*>(ap + (phys(0) << 4));
         for (int gi = 0; gi < n_grp; ++gi) {
 #pragma unroll
           for (int d = 0; d < PD; ++d) {
             const int it = gi * PD + d;
             wld(it + PD - 1, ring[(d + PD - 1) % PD]);
             const f32x4 a4 = a_nxt;
-            const int itn = (it + 1 < n_it) ? it + 1 : it;
-            a_nxt = *reinterpret_cast<const f32x4*>(ap + (itn << 4));
+            a_nxt = *reinterpret_cast<const f32x4*>(ap + (phys(it + 1) << 4));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -322,7 +334,7 @@ __global__ __launch_bounds__(kT) void k_mlp_bwd_data(MlpArgs A) {
         for (int d = 0; d < PD - 1; ++d) {
           if (d < rem) {
             const int it = n_grp * PD + d;
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + (it << 4));
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + (phys(it) << 4));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -442,7 +454,7 @@ __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
   const bool want_bias = (k0 == 0);
   // Unpredicated loads (clamped row / column, value masked afterwards), U row pairs per group, the loads of the
   // next PD groups in flight while the matrix pipe works on the current one.
-  constexpr int U = 4, PD = 3;
+  constexpr int U = 4, PD = 5;
   const int mac = va ? ma : 0, mbc = vb ? mb : 0, kac = vka ? ka : 0, kbc = vkb ? kb : 0;
   const int64_t blast = (wb1 > wb0) ? wb1 - 1 : wb0;
   // 32-bit byte offsets from uniform bases (the host checks the tensors are < 4 GB): one VGPR per address

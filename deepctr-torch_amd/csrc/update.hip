@@ -99,23 +99,24 @@ __global__ __launch_bounds__(kThreads) void k_embed_update(UpdArgs A) {
   const int P = 1 << A.log2p;
   DCTR_TRACE(0);
 
-  if (A.g_wdense && blockIdx.x == gridDim.x - 1) {
-    // the dense half of Linear (basemodel.py:86-90): g_w[j] = sum_b g_wide[b] * X[b, col_j], fixed-order tree
+  if (A.g_wdense && static_cast<int>(blockIdx.x) >= static_cast<int>(gridDim.x) - A.n_wdense) {
+    // the dense half of Linear (basemodel.py:86-90): g_w[j] = sum_b g_wide[b] * X[b, col_j].  One extra
+    // workgroup per dense column, hidden behind the row updates; per-thread partial sums over a strided row set,
+    // then a fixed-order tree => deterministic.  (Kept tiny on purpose: its registers bound the whole kernel.)
     __shared__ float red[kThreads / 64];
-    for (int j = 0; j < A.n_wdense; ++j) {
-      const int col = ldg_i32(A.wdense_cols + j);
-      float acc = 0.f;
-      for (int b = tid; b < A.B; b += kThreads)
-        acc += ldg_f32(A.gwide + b) * ldg_f32(A.X + static_cast<int64_t>(b) * A.ldx + col);
-      acc = wave_sum(acc);
-      if ((tid & 63) == 0) red[tid >> 6] = acc;
-      __syncthreads();
-      if (tid == 0) {
-        float t = 0.f;
-        for (int w = 0; w < kThreads / 64; ++w) t += red[w];
-        stg_f32(A.g_wdense + j, t);
-      }
-      __syncthreads();
+    const int j = static_cast<int>(blockIdx.x) - (static_cast<int>(gridDim.x) - A.n_wdense);
+    const int col = ldg_i32(A.wdense_cols + j);
+    float acc = 0.f;
+#pragma unroll 8
+    for (int b = tid; b < A.B; b += kThreads)
+      acc += ldg_f32(A.gwide + b) * ldg_f32(A.X + static_cast<int64_t>(b) * A.ldx + col);
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+      for (int w = 0; w < kThreads / 64; ++w) t += red[w];
+      stg_f32(A.g_wdense + j, t);
     }
     return;
   }
@@ -425,7 +426,7 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
   const size_t lds = static_cast<size_t>(cap) * 4 + (static_cast<size_t>(g) * lpr * vec + g + lpr * vec + 4) * 4;
   if (lds > 150 * 1024) return DCTR_ENOSUP;
   const int units8 = (n_units + 7) / 8 * 8;
-  const dim3 grid((static_cast<unsigned>(units8) << log2p) + (g_wdense ? 1u : 0u)), block(kThreads);
+  const dim3 grid((static_cast<unsigned>(units8) << log2p) + (g_wdense ? static_cast<unsigned>(plan->n_wdense) : 0u)), block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
 
 #define DCTR_UPD_LAUNCH(VEC_, LPR_)                                                                   \

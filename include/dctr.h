@@ -152,7 +152,7 @@ int dctr_embed_apply(const dctr_plan_t* plan, const float* X, int64_t ldx, int32
  *          DCTR_UPD_ADAGRAD  state[row] += G*G ; table[row] -= lr*G/(sqrt(state[row])+eps)
  *          DCTR_UPD_ACCUM    gacc[row]  += G          (exact dense-gradient semantics: param.grad)
  *   max_vocab  largest vocab over the plan's fields (sizes the 32-bit sort keys)
- *   g_wdense [plan.n_wdense] (nullable): when given, one extra workgroup also writes the gradient of the dense
+ *   g_wdense [plan.n_wdense] (nullable): when given, n_wdense extra workgroups also write the gradient of the dense
  *          half of Linear, g_wdense[j] = sum_b g_wide[b] * X[b, wdense_cols[j]] (basemodel.py:86-90), in a
  *          fixed order; X / ld_x are only read for this.
  * dctr_embed_update_supported returns 1 when the plan / batch fit (B <= 32768, keys fit 32 bits).    */

@@ -105,9 +105,9 @@ for opt in ("adagrad", "sgd"):
     for Bsz in (4096, 32_768):
         A.batch = Bsz
         gen = torch.Generator().manual_seed(0)
-        X = torch.cat([torch.randint(0, A.vocab, (Bsz, 26), generator=gen).float(), torch.rand(Bsz, 13, generator=gen)],
+        X = torch.cat([torch.randint(0, A.vocab, (8 * Bsz, 26), generator=gen).float(), torch.rand(8 * Bsz, 13, generator=gen)],
                       1).to(dev)
-        k = bench.time_hot_kernels(model, X, None, 20, opt)
+        k = bench.time_hot_kernels(model, X, Bsz, 20, opt, ring=8)
         alg = bench.algorithmic_bytes(Bsz, opt)
         for name in k:
             k[name]["gbs"] = alg[name] / (k[name]["min_us"] * 1e-6) / 1e9

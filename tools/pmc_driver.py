@@ -44,9 +44,9 @@ for opt in ("adagrad", "sgd"):
     model = bench.build_model(A, dev)
     for Bsz in (4096, 32768):
         gen = torch.Generator().manual_seed(0)
-        X = torch.cat([torch.randint(0, A.vocab, (Bsz, 26), generator=gen).float(),
-                       torch.rand(Bsz, 13, generator=gen)], 1).to(dev)
-        bench.time_hot_kernels(model, X, None, 5, opt)
+        X = torch.cat([torch.randint(0, A.vocab, (8 * Bsz, 26), generator=gen).float(),
+                       torch.rand(8 * Bsz, 13, generator=gen)], 1).to(dev)
+        bench.time_hot_kernels(model, X, Bsz, 5, opt, ring=8)
     del model
     torch.cuda.empty_cache()
 torch.cuda.synchronize()
