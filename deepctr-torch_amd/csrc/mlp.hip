@@ -69,9 +69,17 @@ struct MlpArgs {
   float* gx;         // backward: [B, ldgx] nullable
   int64_t ldgx;
   int rsx, rsh;      // LDS row strides (floats)
+  unsigned long long* trace;
 };
 
 __device__ __forceinline__ f32x4 ldg_f4(const float* p) { return *(const DCTR_GLOBAL f32x4*)p; }
+
+// diagnostics (tools/mlp_trace.py): 16 wall_clock64 stamps per workgroup, or NULL
+unsigned long long* g_mlp_trace = nullptr;
+#define MLP_TRACE(T, slot)                                                                   \
+  do {                                                                                       \
+    if ((T) && threadIdx.x == 0) (T)[blockIdx.x * 16ull + (slot)] = wall_clock64();          \
+  } while (0)
 
 // ------------------------------------------------------------------------------------------------------------
 // forward
@@ -171,6 +179,7 @@ __global__ __launch_bounds__(kT) void k_mlp_fwd(MlpArgs A) {
   const int K0 = A.L[0].K, K0p = round_up(K0, 16);
   const int kcw = K0p < kKC ? K0p : kKC;
   const int rot = static_cast<int>(blockIdx.x) * 5;
+  MLP_TRACE(A.trace, 0);
 
   const float* in = nullptr;
   for (int l = 0; l < A.n_layers; ++l) {
@@ -211,11 +220,13 @@ __global__ __launch_bounds__(kT) void k_mlp_fwd(MlpArgs A) {
             *reinterpret_cast<f32x4*>(xs + r * rsx + 4 * q) = v;
           }
           __syncthreads();
+          if (kc == 0 && tbase == 0) MLP_TRACE(A.trace, 1);
           fwd_dispatch(nt, xs, rsx, kc, klen, Ld, tile0, acc, g, c, rot);
         }
       } else {
         fwd_dispatch(nt, in, rsh, 0, round_up(Ld.K, 16), Ld, tile0, acc, g, c, rot);
       }
+      if (tbase == 0) MLP_TRACE(A.trace, 2 + 3 * l);
       // epilogue: activation; keep the tile in LDS for the next layer, save it for the backward
 #pragma unroll
       for (int t = 0; t < kNTMax; ++t) {
@@ -233,7 +244,9 @@ __global__ __launch_bounds__(kT) void k_mlp_fwd(MlpArgs A) {
         }
       }
     }
+    MLP_TRACE(A.trace, 3 + 3 * l);
     __syncthreads();
+    MLP_TRACE(A.trace, 4 + 3 * l);
     in = outb;
   }
   if (A.w_out && A.logit) {  // dnn_linear: logit[b] = h_last[b, :] . w_out
@@ -245,6 +258,7 @@ __global__ __launch_bounds__(kT) void k_mlp_fwd(MlpArgs A) {
       if (lane == 0 && b0 + row < A.B) stg_f32(A.logit + b0 + row, s);
     }
   }
+  MLP_TRACE(A.trace, 15);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -258,6 +272,7 @@ __global__ __launch_bounds__(kT) void k_mlp_bwd_data(MlpArgs A) {
   float* d0 = smem;
   float* d1 = d0 + kTM * rs;
   const int top = A.n_layers - 1;
+  MLP_TRACE(A.trace, 0);
   {
     const LayerDev& Lt = A.L[top];
     const int Np = round_up(Lt.N, 16);
@@ -275,6 +290,7 @@ __global__ __launch_bounds__(kT) void k_mlp_bwd_data(MlpArgs A) {
     }
   }
   __syncthreads();
+  MLP_TRACE(A.trace, 1);
   float* din = d0;
   float* dout = d1;
   for (int l = top; l >= 0; --l) {
@@ -388,11 +404,14 @@ __global__ __launch_bounds__(kT) void k_mlp_bwd_data(MlpArgs A) {
         }
       }
     }
+    MLP_TRACE(A.trace, 2 + 2 * (top - l));
     __syncthreads();
+    MLP_TRACE(A.trace, 3 + 2 * (top - l));
     float* t = din;
     din = dout;
     dout = t;
   }
+  MLP_TRACE(A.trace, 15);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -408,6 +427,7 @@ struct WgradArgs {
   const float* w_out;
   const float* g;  // [B] when w_out
   float* part;     // [S][slab]
+  unsigned long long* trace;
 };
 
 __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
@@ -415,6 +435,7 @@ __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
   __shared__ float redb[3 * 64];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, p = lane >> 5, jl = lane & 31;
   const int blk = blockIdx.x;
+  MLP_TRACE(A.trace, 0);
   int l = 0;
   while (l < A.n_layers && blk >= A.blk0[l + 1]) ++l;
   const int local = blk - A.blk0[l];
@@ -503,6 +524,7 @@ __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
       }
     }
   }
+  MLP_TRACE(A.trace, 1);
   // combine the four waves in wave order
   if (wv > 0) {
     float* dst = red + (wv - 1) * 4096;
@@ -521,6 +543,7 @@ __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
     redb[(wv - 1) * 64 + 32 + jl] = sb;
   }
   __syncthreads();
+  MLP_TRACE(A.trace, 2);
   if (wv != 0) return;
   for (int w = 0; w < 3; ++w) {
     const float* src = red + w * 4096;
@@ -553,6 +576,8 @@ __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
     if (va) stg_f32(part + A.off_b[l] + ma, sa);
     if (vb) stg_f32(part + A.off_b[l] + mb, sb);
   }
+  MLP_TRACE(A.trace, 3);
+  if (A.trace && threadIdx.x == 0) A.trace[blockIdx.x * 16ull + 14] = static_cast<unsigned long long>(l);
 }
 
 struct ReduceArgs {
@@ -640,6 +665,9 @@ WgradPlan plan_wgrad(const dctr_mlp_t* m, int32_t B) {
 
 }  // namespace
 
+// diagnostics: buf holds 3 x 4096 x 16 u64 (forward | backward-data | wgrad workgroups); NULL switches it off
+extern "C" void dctr_dbg_mlp_trace(unsigned long long* buf) { g_mlp_trace = buf; }
+
 extern "C" int dctr_mlp_fwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, float* logit,
                             dctr_stream_t stream) {
   const int rc = check_mlp(m, B);
@@ -655,6 +683,7 @@ extern "C" int dctr_mlp_fwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, i
   fill_layers(m, a.L);
   a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = m->w_out; a.logit = logit;
   a.g = nullptr; a.ldg = 0; a.gx = nullptr; a.ldgx = 0;
+  a.trace = g_mlp_trace;
   const int K0p = round_up(m->layer[0].K, 16);
   a.rsx = (K0p < kKC ? K0p : kKC) + 4;
   a.rsh = round_up(max_width(m), 16) + 4;
@@ -698,6 +727,7 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, i
     fill_layers(m, a.L);
     a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = m->w_out; a.logit = nullptr;
     a.g = g; a.ldg = ld_g; a.gx = gx; a.ldgx = ld_gx;
+    a.trace = g_mlp_trace ? g_mlp_trace + 16ull * 4096 : nullptr;
     a.rsx = 0;
     int w = max_width(m);
     for (int l = 1; l < m->n_layers; ++l) w = m->layer[l].K > w ? m->layer[l].K : w;
@@ -722,6 +752,7 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, i
       a.off_b[l] = l < m->n_layers ? P.off_b[l] : 0;
     }
     a.off_o = P.off_o; a.slab = P.slab; a.x = x; a.ldx = ld_x; a.w_out = m->w_out; a.g = g; a.part = workspace;
+    a.trace = g_mlp_trace ? g_mlp_trace + 16ull * 8192 : nullptr;
     k_mlp_wgrad<<<dim3(P.blk0[m->n_layers + 1]), dim3(kTW), 0, s>>>(a);
     const int st = launch_status();
     if (st != DCTR_OK) return st;

@@ -290,6 +290,9 @@ typedef struct dctr_mlp {
   int32_t pad_;
 } dctr_mlp_t;
 size_t dctr_sizeof_mlp(void);
+/* diagnostics (tools/mlp_trace.py): buf = 3 x 4096 x 16 u64 of per-workgroup wall_clock64 stamps (forward |
+ * backward-data | wgrad); NULL switches tracing off.  Batches above 65536 samples are not traced correctly.  */
+void dctr_dbg_mlp_trace(unsigned long long* buf);
 int dctr_mlp_fwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, float* logit, dctr_stream_t stream);
 size_t dctr_mlp_bwd_workspace_floats(const dctr_mlp_t* m, int32_t B);
 int dctr_mlp_bwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g, int64_t ld_g,
