@@ -104,14 +104,14 @@ def time_hot_kernels(model, X_all, B, iters, opt, ring=16):
 
     def fwd(j):
         Xb, out, ids_t, fm_s = slots[j % ring]
-        L.check(lib.dctr_embed_fwd(cplan, _ptr(Xb), Xb.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), _ptr(fm),
+        L.check(lib.dctr_embed_fwd(cplan, _ptr(Xb), Xb.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), 1, _ptr(fm),
                                    None, plan.units_ptr(), len(plan.units), _ptr(ids_t), _ptr(fm_s), DIM, s))
 
     def upd(j):
         Xb, out, ids_t, fm_s = slots[j % ring]
         L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t), B,
                                       _ptr(g_out), plan.ld_out, _ptr(out), plan.ld_out, _ptr(fm_s), DIM, _ptr(g_fm),
-                                      _ptr(g_wide), L.UPD_ADAGRAD if opt == "adagrad" else L.UPD_SGD, lr, eps,
+                                      _ptr(g_wide), 1, L.UPD_ADAGRAD if opt == "adagrad" else L.UPD_SGD, lr, eps,
                                       None, 0, None, s))
 
     stages = [("embed_fwd", fwd), ("embed_update", upd)]
@@ -182,8 +182,10 @@ def main():
     n_batches = X.shape[0] // B
     parallel = None
     if dist is not None:
+        # table-sharded embeddings + data-parallel tower (SURVEY.md 8(e) option S): 3 all-to-alls + 1 all-reduce per
+        # step; the compute between the collectives is captured as hipGraph segments after a few eager steps
         from deepctr_torch import parallel as par
-        parallel = par.DataParallelTrainer(model)
+        parallel = par.ShardedTrainer(model, use_graphs=False)
 
     def batch(i):
         j = i % n_batches
@@ -191,7 +193,7 @@ def main():
 
     step_fn = (lambda xb, yb: parallel.train_step(xb, yb)) if parallel else (lambda xb, yb: model._train_step(xb, yb))
     use_graph = (not args.no_graph) and parallel is None
-    n_eager = min(3, args.warmup) if use_graph else args.warmup
+    n_eager = min(3, args.warmup) if not args.no_graph else args.warmup
     i = 0
     for _ in range(n_eager):
         step_fn(*batch(i))
@@ -206,6 +208,10 @@ def main():
             print("hipGraph capture failed (%s: %s); running eager" % (type(exc).__name__, exc), file=sys.stderr)
             graphed = None
             torch.cuda.synchronize()
+    if parallel is not None and not args.no_graph:
+        parallel.use_graphs = True       # segments re-capture on the next step
+        parallel._shape = None
+        graphed = "segments"
     for _ in range(max(0, args.warmup - n_eager)):
         step_fn(*batch(i))
         i += 1
@@ -247,7 +253,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DeepFM synthetic Criteo (26 sparse x %d vocab, 13 dense, emb_dim=16, batch=%d) "
                                    "fwd+bwd+%s, l2=0, dnn=(256,128)" % (args.vocab, B, args.optimizer),
-                       "global_batch": world * B, "parallelism": "dp%d" % world if world > 1 else "single",
+                       "global_batch": world * B, "parallelism": ("tables sharded x%d + dp%d tower" % (world, world)) if parallel is not None else "single",
                        "hip_graph": graphed is not None, "optimizer": args.optimizer},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": None,

@@ -128,7 +128,7 @@ template <int VEC, int LPR>
 __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const float* __restrict__ X,
                                                         int64_t ldx, int B, float* __restrict__ out,
                                                         int64_t ldo, float* __restrict__ wide,
-                                                        float* __restrict__ fm, int32_t* err,
+                                                        int64_t ldw, float* __restrict__ fm, int32_t* err,
                                                         const int32_t* __restrict__ units, int n_units,
                                                         int32_t* __restrict__ ids_t,
                                                         float* __restrict__ fm_s, int64_t lds_) {
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
       }
       if (wide) {
         wt = group_sum<LPR>(wt);
-        if (gl == 0 && valid) stg_f32(wide + b, wt);
+        if (gl == 0 && valid) stg_f32(wide + static_cast<int64_t>(b) * ldw, wt);
       }
     }
   }
@@ -538,10 +538,11 @@ int check_plan(const dctr_plan_t* p, const float* X, int64_t ldx, int32_t B) {
 }  // namespace
 
 extern "C" int dctr_embed_fwd(const dctr_plan_t* plan, const float* X, int64_t ldx, int32_t B,
-                              float* out, int64_t ld_out, float* wide, float* fm, int32_t* err,
-                              const int32_t* units, int32_t n_units, int32_t* ids_t, float* fm_s,
-                              int64_t ld_s, dctr_stream_t stream) {
+                              float* out, int64_t ld_out, float* wide, int64_t ld_wide, float* fm,
+                              int32_t* err, const int32_t* units, int32_t n_units, int32_t* ids_t,
+                              float* fm_s, int64_t ld_s, dctr_stream_t stream) {
   if (int rc = check_plan(plan, X, ldx, B)) return rc;
+  if (wide && ld_wide < 1) return DCTR_EINVAL;
   if (B == 0) return DCTR_OK;
   if (fm && (plan->emb_dim <= 0 || !out)) return DCTR_EINVAL;  // FM needs the deep rows
   if (fm_s && (plan->emb_dim <= 0 || !out || ld_s < plan->emb_dim)) return DCTR_EINVAL;
@@ -559,7 +560,7 @@ extern "C" int dctr_embed_fwd(const dctr_plan_t* plan, const float* X, int64_t l
   const dim3 grid((B + spb - 1) / spb), block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
   DCTR_DISPATCH(vec, lpr, k_embed_fwd<VEC, LPR><<<grid, block, lds, s>>>(*plan, X, ldx, B, out, ld_out,
-                                                                        wide, fm, err, units, n_units,
+                                                                        wide, ld_wide, fm, err, units, n_units,
                                                                         ids_t, fm_s, ld_s));
   return launch_status();
 }

@@ -39,7 +39,8 @@ struct UpdArgs {
   const float* out;      // [B, ldo]   forward output (e), needed with gfm
   const float* fm_s;     // [B, lds_]  S[b, :] = sum_f e[b, f, :], needed with gfm
   const float* gfm;      // [B] nullable
-  const float* gwide;    // [B] nullable
+  const float* gwide;    // [B] (stride ldgw) nullable
+  int64_t ldgw;
   int64_t ldg, ldo, lds_;
   int32_t n_units, B, log2p, bbits;
   float lr, eps;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_update(UpdArgs A) {
     float acc = 0.f;
 #pragma unroll 8
     for (int b = tid; b < A.B; b += kThreads)
-      acc += ldg_f32(A.gwide + b) * ldg_f32(A.X + static_cast<int64_t>(b) * A.ldx + col);
+      acc += ldg_f32(A.gwide + static_cast<int64_t>(b) * A.ldgw) * ldg_f32(A.X + static_cast<int64_t>(b) * A.ldx + col);
     acc = wave_sum(acc);
     if ((tid & 63) == 0) red[tid >> 6] = acc;
     __syncthreads();
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_update(UpdArgs A) {
         if (OPT == DCTR_UPD_ADAGRAD) s = strip_load<VEC>(fd.state + off);
       }
       if (wide_on && gl == 0) {
-        gw = ldg_f32(A.gwide + b);
+        gw = ldg_f32(A.gwide + static_cast<int64_t>(b) * A.ldgw);
         ww = ldg_f32((OPT == DCTR_UPD_ACCUM ? fw.gacc : fw.table) + row);
         if (OPT == DCTR_UPD_ADAGRAD) sw = ldg_f32(fw.state + row);
       }
@@ -387,10 +388,11 @@ extern "C" int dctr_embed_update_supported(const dctr_plan_t* plan, int64_t max_
 extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, int32_t n_units,
                                  int64_t max_vocab, const int32_t* ids_t, int32_t B, const float* g_out,
                                  int64_t ld_g, const float* out, int64_t ld_out, const float* fm_s,
-                                 int64_t ld_s, const float* g_fm, const float* g_wide, int32_t opt,
-                                 float lr, float eps, const float* X, int64_t ld_x, float* g_wdense,
+                                 int64_t ld_s, const float* g_fm, const float* g_wide, int64_t ld_gw,
+                                 int32_t opt, float lr, float eps, const float* X, int64_t ld_x, float* g_wdense,
                                  dctr_stream_t stream) {
   if (!plan || !units || !ids_t || n_units <= 0 || B < 0) return DCTR_EINVAL;
+  if (g_wide && ld_gw < 1) return DCTR_EINVAL;
   if (g_wdense && (!X || !g_wide || plan->n_wdense <= 0 || !plan->wdense_cols)) return DCTR_EINVAL;
   if (B == 0) return DCTR_OK;
   if (opt != DCTR_UPD_SGD && opt != DCTR_UPD_ADAGRAD && opt != DCTR_UPD_ACCUM) return DCTR_EINVAL;
@@ -407,7 +409,7 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
   }
   UpdArgs a;
   a.deep = plan->deep; a.wide = plan->wide; a.units = units; a.ids_t = ids_t;
-  a.gout = g_out; a.out = out; a.fm_s = fm_s; a.gfm = g_fm; a.gwide = g_wide;
+  a.gout = g_out; a.out = out; a.fm_s = fm_s; a.gfm = g_fm; a.gwide = g_wide; a.ldgw = ld_gw;
   a.ldg = ld_g; a.ldo = ld_out; a.lds_ = ld_s;
   a.n_units = n_units; a.B = B;
   const int log2p = pick_log2p(B);

@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdctr_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 
@@ -64,13 +64,13 @@ SIGNATURES = {
     "dctr_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "dctr_sizeof_field": (ctypes.c_size_t, []),
     "dctr_sizeof_plan": (ctypes.c_size_t, []),
-    "dctr_embed_fwd": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _P, _I64, _P, _P, _P, _P, _I32, _P, _P,
-                                      _I64, _P]),
+    "dctr_embed_fwd": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P, _P, _I32, _P,
+                                      _P, _I64, _P]),
     "dctr_embed_update_supported": (ctypes.c_int, [ctypes.POINTER(Plan), _I64, _I32]),
     "dctr_dbg_update_trace": (None, [_P, _I32]),
     "dctr_embed_ids": (ctypes.c_int, [_P, _I32, _P, _I64, _I32, _P, _P]),
     "dctr_embed_update": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I32, _I64, _P, _I32, _P, _I64, _P, _I64, _P, _I64,
-                                         _P, _P, _I32, _F32, _F32, _P, _I64, _P, _P]),
+                                         _P, _P, _I64, _I32, _F32, _F32, _P, _I64, _P, _P]),
     "dctr_embed_bwd": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P,
                                       _I32, _F32, _P]),
     "dctr_embed_apply": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _I32, _F32, _F32, _P]),
@@ -99,6 +99,10 @@ SIGNATURES = {
     "dctr_mlp_bwd": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P]),
     "dctr_bce_head": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P]),
     "dctr_dense_opt": (ctypes.c_int, [_P, _P, _P, _I64, _I32, _F32, _F32, _P]),
+    "dctr_shard_assemble_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _I64, _P, _I32, _I32, _P, _P,
+                                               _I32, _P, _I64, _P, _P, _P, _I64, _P]),
+    "dctr_shard_assemble_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _I64, _P, _P, _P, _I64, _P,
+                                               _I64, _P, _I64, _P, _I32, _P, _P]),
     "dctr_fm_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P]),
     "dctr_fm_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _I64, _I32, _P]),
 }

@@ -68,7 +68,7 @@ class EmbedFunction(torch.autograd.Function):
             if want_fm:
                 ld_s = (plan.emb_dim + 3) // 4 * 4
                 fm_s = torch.empty((B, ld_s), dtype=torch.float32, device=X.device)
-        L.check(lib.dctr_embed_fwd(cplan, _ptr(X), X.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), _ptr(fm),
+        L.check(lib.dctr_embed_fwd(cplan, _ptr(X), X.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), 1, _ptr(fm),
                                    _ptr(plan.err_flag(X.device)), plan.units_ptr(), len(plan.units), _ptr(ids_t),
                                    _ptr(fm_s), ld_s, L.stream_handle(X.device)), "dctr_embed_fwd")
         ctx.plan, ctx.want_fm = plan, want_fm
@@ -138,7 +138,7 @@ class EmbedFunction(torch.autograd.Function):
             cplan = plan.bind(X.device)
             L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t), B,
                                           _ptr(g_out), ld_g, _ptr(out), plan.ld_out, _ptr(fm_s),
-                                          fm_s.stride(0) if fm_s is not None else 0, _ptr(g_fm), _ptr(g_wide),
+                                          fm_s.stride(0) if fm_s is not None else 0, _ptr(g_fm), _ptr(g_wide), 1,
                                           opt, lr, eps, _ptr(X), X.stride(0), _ptr(g_wd), stream),
                     "dctr_embed_update")
             return None, None, None, g_w, None, None
@@ -173,6 +173,9 @@ def embed(plan, X, want_fm=False, full=False):
     un-sliced ``[B, ld_out]`` buffer (the MFMA tower reads the first ``plan.width`` columns of it and hands back
     a gradient of the same shape, so no slice / zero-fill kernels appear in the autograd graph)."""
     L.require_gpu(X, "model input X")
+    sharder = getattr(plan, "sharder", None)
+    if sharder is not None:          # table-sharded multi-GPU training (parallel.ShardedTrainer)
+        return sharder.embed(X, want_fm, full)
     plan.bind(X.device)
     out, wide, fm = EmbedFunction.apply(plan, X, plan.anchor, plan.wide_dense_weight, bool(want_fm),
                                         torch.is_grad_enabled())

@@ -150,6 +150,8 @@ class EmbeddingPlan(object):
         self._owner = None
         self._update = ("dense",)
         self.exchange = None   # set by parallel.DataParallelTrainer: backward hands row gradients over
+        self.sharder = None    # set by parallel.ShardedTrainer: lookups go through the table-sharded exchange
+        self.dense_sink = None
         self._reset_device_image()
 
     def _reset_device_image(self):
@@ -167,6 +169,8 @@ class EmbeddingPlan(object):
         for k in ("_key", "_dev", "cplan", "anchor", "_err", "_wd_idx"):
             d.pop(k, None)
         d["exchange"] = None
+        d["sharder"] = None
+        d["dense_sink"] = None
         return d
 
     def __setstate__(self, d):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 3
+#define DCTR_ABI_VERSION 4
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -98,7 +98,8 @@ size_t dctr_sizeof_plan(void);
  * combined_dnn_input (inputs.py:126-138).
  *   X     [B, ldx]   the model input matrix (ids as float32)
  *   out   [B, ld_out] row b = [ deep field slices at field.out_off | dense block at plan.dense_off ]
- *   wide  [B]  sum_f w_f[id] (+pooled VarLen) + dense . Linear.weight     (nullable)
+ *   wide  [B]  sum_f w_f[id] (+pooled VarLen) + dense . Linear.weight     (nullable); element b lives at
+ *         wide[b * ld_wide] (ld_wide = 1 for a plain vector; a column of `out` for the sharded exchange)
  *   fm    [B]  0.5 * sum_d ((sum_f e)^2 - sum_f e^2) over ALL deep fields (nullable; needs emb_dim)
  *   err   int32 flag; bit0 is set when an id falls outside [0, vocab) -- such a row reads as row 0
  *         (the reference raises IndexError on CPU; here the flag is polled by the host) (nullable)
@@ -106,8 +107,9 @@ size_t dctr_sizeof_plan(void);
  *   ids_t [n_units, B] int32: ids_t[u][b] = (int) X[b, units[u].col]  (units: see dctr_embed_update)
  *   fm_s  [B, ld_s]    S[b, d] = sum_f e[b, f, d], the per-sample field sum FM's backward needs      */
 int dctr_embed_fwd(const dctr_plan_t* plan, const float* X, int64_t ldx, int32_t B, float* out,
-                   int64_t ld_out, float* wide, float* fm, int32_t* err, const int32_t* units,
-                   int32_t n_units, int32_t* ids_t, float* fm_s, int64_t ld_s, dctr_stream_t stream);
+                   int64_t ld_out, float* wide, int64_t ld_wide, float* fm, int32_t* err,
+                   const int32_t* units, int32_t n_units, int32_t* ids_t, float* fm_s, int64_t ld_s,
+                   dctr_stream_t stream);
 
 /* ---- backward of the above = embedding_dense_backward + FM backward, as an O(batch) scatter -------
  * Replaces autograd's aten::embedding_dense_backward x(n_deep+n_wide), the pooling backward and
@@ -147,7 +149,8 @@ int dctr_embed_apply(const dctr_plan_t* plan, const float* X, int64_t ldx, int32
  *   units  [n_units][4] int32 (device): {deep field index | -1, wide field index | -1, X column, 0};
  *          a unit is one id column with the deep and/or wide table it feeds
  *   ids_t  [n_units, B] int32 from dctr_embed_fwd / dctr_embed_ids
- *   g_out / out / fm_s / g_fm / g_wide as in dctr_embed_bwd (fm_s = side output of dctr_embed_fwd)
+ *   g_out / out / fm_s / g_fm / g_wide as in dctr_embed_bwd (fm_s = side output of dctr_embed_fwd);
+ *          g_wide[b] lives at g_wide[b * ld_gw]
  *   opt    DCTR_UPD_SGD      table[row] -= lr * G                          (torch.optim.SGD)
  *          DCTR_UPD_ADAGRAD  state[row] += G*G ; table[row] -= lr*G/(sqrt(state[row])+eps)
  *          DCTR_UPD_ACCUM    gacc[row]  += G          (exact dense-gradient semantics: param.grad)
@@ -169,8 +172,8 @@ int dctr_embed_ids(const int32_t* units, int32_t n_units, const float* X, int64_
 int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, int32_t n_units, int64_t max_vocab,
                       const int32_t* ids_t, int32_t B, const float* g_out, int64_t ld_g, const float* out,
                       int64_t ld_out, const float* fm_s, int64_t ld_s, const float* g_fm,
-                      const float* g_wide, int32_t opt, float lr, float eps, const float* X, int64_t ld_x,
-                      float* g_wdense, dctr_stream_t stream);
+                      const float* g_wide, int64_t ld_gw, int32_t opt, float lr, float eps, const float* X,
+                      int64_t ld_x, float* g_wdense, dctr_stream_t stream);
 
 /* ---- FM on an explicit [B, F, D] tensor (interaction.py:26-34) ------------------------------------
  * E is addressed as E[b*ld_b + f*D + d].  y[b] = 0.5 * sum_d((sum_f e)^2 - sum_f e^2).
@@ -314,6 +317,28 @@ int dctr_bce_head(const float* part0, const float* part1, const float* part2, co
  * One launch for every dense parameter of the model (the reference's optimizer issues ~8 foreach launches).  */
 int dctr_dense_opt(float* p, const float* g, float* state, int64_t n, int32_t opt, float lr, float eps,
                    dctr_stream_t stream);
+
+/* ---- table-sharded multi-GPU exchange: the two "assemble" kernels (csrc/shard.hip, deepctr_torch/parallel.py) ---
+ * Rank q of N owns units q, q+N, q+2N, ... (a unit = one id column with its deep and/or wide table).  Owners gather
+ * with dctr_embed_fwd over the N*B global samples and update with dctr_embed_update; what travels between ranks
+ * are chunks [B, ld_chunk] whose row b is [ slot 0 | slot 1 | ... (slot j = unit q + j*N, D floats each) | pad |
+ * wide partial sum at column wide_col | pad ].
+ * dctr_shard_assemble_fwd: recv [N][B][ld_chunk] (chunk q from owner q) -> the single-GPU outputs of
+ *   dctr_embed_fwd: out [B, ld_out] = [ e_0 | ... | e_{F-1} | dense block at dense_off ], wide [B] (sum of the owners'
+ *   partials in rank order + X[:, wdense_cols] . wdense_w), fm [B], fm_s [B, ld_s]  (wide / fm / fm_s nullable).
+ * dctr_shard_assemble_bwd: the adjoint; send [N][B][ld_chunk] with G[b, f] = g_out[b, f] + g_fm[b] * (S[b] - e[b, f])
+ *   in unit f's slot and g_wide[b] at wide_col; g_wdense [n_wdense] (nullable) = X[:, wdense_cols]^T g_wide.
+ * Deterministic (no atomics).  D <= 64.                                                                          */
+int dctr_shard_assemble_fwd(const float* recv, int64_t ld_chunk, int32_t n_ranks, int32_t B, int32_t F, int32_t D,
+                            int32_t wide_col, const float* X, int64_t ld_x, const int32_t* dense_cols,
+                            int32_t n_dense, int32_t dense_off, const int32_t* wdense_cols, const float* wdense_w,
+                            int32_t n_wdense, float* out, int64_t ld_out, float* wide, float* fm, float* fm_s,
+                            int64_t ld_s, dctr_stream_t stream);
+int dctr_shard_assemble_bwd(float* send, int64_t ld_chunk, int32_t n_ranks, int32_t B, int32_t F, int32_t D,
+                            int32_t wide_col, const float* g_out, int64_t ld_g, const float* g_wide, const float* g_fm,
+                            const float* out, int64_t ld_out, const float* fm_s, int64_t ld_s, const float* X,
+                            int64_t ld_x, const int32_t* wdense_cols, int32_t n_wdense, float* g_wdense,
+                            dctr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -43,7 +43,7 @@ def main():
     for j in range(nb):     # forward once per batch to get ids_t / out / fm_s (kept per batch)
         o = torch.empty(B, plan.ld_out, device=dev)
         fs = torch.empty(B, 16, device=dev)
-        L.check(lib.dctr_embed_fwd(cplan, _ptr(X[j * B:]), X.stride(0), B, _ptr(o), plan.ld_out, _ptr(wide), _ptr(fm),
+        L.check(lib.dctr_embed_fwd(cplan, _ptr(X[j * B:]), X.stride(0), B, _ptr(o), plan.ld_out, _ptr(wide), 1, _ptr(fm),
                                    None, plan.units_ptr(), len(plan.units), _ptr(ids[j]), _ptr(fs), 16, s))
         outs.append((o, fs))
     g_out = torch.randn(B, plan.ld_out, device=dev) * 1e-3
@@ -56,10 +56,10 @@ def main():
         o, fs = outs[j]
         L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids[j]), B,
                                       _ptr(g_out), plan.ld_out, _ptr(o), plan.ld_out, _ptr(fs), 16, _ptr(g_fm),
-                                      _ptr(g_wide), code, lr, eps, None, 0, None, s))
+                                      _ptr(g_wide), 1, code, lr, eps, None, 0, None, s))
 
     def fwd(j):
-        L.check(lib.dctr_embed_fwd(cplan, _ptr(X[j * B:]), X.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), _ptr(fm),
+        L.check(lib.dctr_embed_fwd(cplan, _ptr(X[j * B:]), X.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), 1, _ptr(fm),
                                    None, plan.units_ptr(), len(plan.units), _ptr(ids[j]), _ptr(fm_s), 16, s))
 
     def timed(fn, rot, n=48):
