@@ -131,6 +131,127 @@ __global__ __launch_bounds__(kT) void k_assemble_bwd(AsmArgs A) {
   }
 }
 
+// ---- vectorised variants (D % 4 == 0, every pointer / leading dimension 16-byte aligned) -------------------------
+// 32 lanes per sample: lane = (fl = lane / (D/4) ..., d4): each lane moves whole dwordx4 pieces of field rows, all of
+// its loads in flight at once; the FM sums are reduced across the sample's lanes with DPP shuffles.
+template <int D4>   // D / 4, a power of two <= 16
+__global__ __launch_bounds__(kT) void k_assemble_fwd_v4(AsmArgs A) {
+  constexpr int LPS = 32;                 // lanes per sample
+  constexpr int FL = LPS / D4;            // fields walked in parallel
+  constexpr int SPB = kT / LPS;           // samples per workgroup
+  const int tid = threadIdx.x, sl = tid / LPS, l = tid % LPS, d4 = l % D4, fl = l / D4;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * SPB + sl;
+  const bool valid = b < A.B;
+  const int64_t bb = valid ? b : 0;
+  const int D = 4 * D4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+  for (int f0 = 0; f0 < A.F; f0 += 4 * FL) {
+    f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int f = f0 + k * FL + fl;
+      const int fc = f < A.F ? f : 0;
+      const int q = fc % A.N, j = fc / A.N;
+      v[k] = *(const DCTR_GLOBAL f32x4*)(A.recv + (static_cast<int64_t>(q) * A.B + bb) * A.ldc + j * D + 4 * d4);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int f = f0 + k * FL + fl;
+      if (f < A.F) {
+        if (valid) *(DCTR_GLOBAL f32x4*)(A.out + b * A.ldo + f * D + 4 * d4) = v[k];
+        s += v[k];
+        sq += v[k] * v[k];
+      }
+    }
+  }
+  if (A.fm || A.fm_s) {
+#pragma unroll
+    for (int m = D4; m < LPS; m <<= 1) {     // across the FL field lanes that share d4
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        s[c] += __shfl_xor(s[c], m, kWave);
+        sq[c] += __shfl_xor(sq[c], m, kWave);
+      }
+    }
+    if (A.fm_s && valid && fl == 0) *(DCTR_GLOBAL f32x4*)(A.fm_s + b * A.lds_ + 4 * d4) = s;
+    float tot = (s[0] * s[0] - sq[0]) + (s[1] * s[1] - sq[1]) + (s[2] * s[2] - sq[2]) + (s[3] * s[3] - sq[3]);
+#pragma unroll
+    for (int m = 1; m < D4; m <<= 1) tot += __shfl_xor(tot, m, kWave);
+    if (A.fm && valid && l == 0) stg_f32(A.fm + b, 0.5f * tot);
+  }
+  for (int k = l; k < A.n_dense; k += LPS)
+    if (valid) stg_f32(A.out + b * A.ldo + A.dense_off + k, ldg_f32(A.X + b * A.ldx + ldg_i32(A.dense_cols + k)));
+  if (A.wide) {
+    float w = 0.f;
+    if (A.wide_col >= 0)
+      for (int q = l; q < A.N; q += LPS) w += ldg_f32(A.recv + (static_cast<int64_t>(q) * A.B + bb) * A.ldc + A.wide_col);
+    for (int k = l; k < A.n_wdense; k += LPS)
+      w += ldg_f32(A.X + bb * A.ldx + ldg_i32(A.wdense_cols + k)) * ldg_f32(A.wdense_w + k);
+    w = group_sum<LPS>(w);
+    if (l == 0 && valid) stg_f32(A.wide + b, w);
+  }
+}
+
+template <int D4>
+__global__ __launch_bounds__(kT) void k_assemble_bwd_v4(AsmArgs A) {
+  constexpr int LPS = 32, FL = LPS / D4, SPB = kT / LPS;
+  const int tid = threadIdx.x;
+  const int nblk = (A.B + SPB - 1) / SPB;
+  if (static_cast<int>(blockIdx.x) >= nblk) {   // d loss / d Linear.weight, one workgroup per dense column
+    __shared__ float red[kT / 64];
+    const int j = static_cast<int>(blockIdx.x) - nblk;
+    const int col = ldg_i32(A.wdense_cols + j);
+    float acc = 0.f;
+#pragma unroll 8
+    for (int b = tid; b < A.B; b += kT) acc += ldg_f32(A.g_wide + b) * ldg_f32(A.X + static_cast<int64_t>(b) * A.ldx + col);
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+      for (int w = 0; w < kT / 64; ++w) t += red[w];
+      stg_f32(A.g_wdense + j, t);
+    }
+    return;
+  }
+  const int sl = tid / LPS, l = tid % LPS, d4 = l % D4, fl = l / D4;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * SPB + sl;
+  if (b >= A.B) return;
+  const int D = 4 * D4;
+  const float gf = A.g_fm ? ldg_f32(A.g_fm + b) : 0.f;
+  f32x4 S = {0.f, 0.f, 0.f, 0.f};
+  if (A.g_fm) S = *(const DCTR_GLOBAL f32x4*)(A.fm_s + b * A.lds_ + 4 * d4);
+  for (int f0 = 0; f0 < A.F; f0 += 4 * FL) {
+    f32x4 g[4], e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int f = f0 + k * FL + fl;
+      const int fc = f < A.F ? f : 0;
+      g[k] = A.g_out ? *(const DCTR_GLOBAL f32x4*)(A.g_out + b * A.ldg + fc * D + 4 * d4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      e[k] = A.g_fm ? *(const DCTR_GLOBAL f32x4*)(A.out + b * A.ldo + fc * D + 4 * d4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int f = f0 + k * FL + fl;
+      if (f < A.F) {
+        const int q = f % A.N, j = f / A.N;
+        f32x4 o = g[k];
+        if (A.g_fm) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) o[c] += gf * (S[c] - e[k][c]);
+        }
+        *(DCTR_GLOBAL f32x4*)(A.send + (static_cast<int64_t>(q) * A.B + b) * A.ldc + j * D + 4 * d4) = o;
+      }
+    }
+  }
+  if (A.wide_col >= 0) {
+    const float gw = A.g_wide ? ldg_f32(A.g_wide + b) : 0.f;
+    for (int q = l; q < A.N; q += LPS) stg_f32(A.send + (static_cast<int64_t>(q) * A.B + b) * A.ldc + A.wide_col, gw);
+  }
+}
+
+inline bool al16(const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
+
 }  // namespace
 
 extern "C" int dctr_shard_assemble_fwd(const float* recv, int64_t ld_chunk, int32_t n_ranks, int32_t B, int32_t F,
@@ -151,7 +272,16 @@ extern "C" int dctr_shard_assemble_fwd(const float* recv, int64_t ld_chunk, int3
   a.X = X; a.ldx = ld_x; a.dense_cols = dense_cols; a.n_dense = n_dense; a.dense_off = dense_off;
   a.wdense_cols = wdense_cols; a.wdense_w = wdense_w; a.n_wdense = n_wdense;
   a.out = out; a.ldo = ld_out; a.wide = wide; a.fm = fm; a.fm_s = fm_s; a.lds_ = ld_s;
-  k_assemble_fwd<<<dim3((B + 15) / 16), dim3(kT), 0, static_cast<hipStream_t>(stream)>>>(a);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool vec = D % 4 == 0 && ld_chunk % 4 == 0 && ld_out % 4 == 0 && al16(recv) && al16(out) &&
+                   (!fm_s || (ld_s % 4 == 0 && al16(fm_s)));
+  const dim3 g8((B + 7) / 8), blk(kT);
+  if (vec && D == 16) k_assemble_fwd_v4<4><<<g8, blk, 0, st>>>(a);
+  else if (vec && D == 8) k_assemble_fwd_v4<2><<<g8, blk, 0, st>>>(a);
+  else if (vec && D == 32) k_assemble_fwd_v4<8><<<g8, blk, 0, st>>>(a);
+  else if (vec && D == 4) k_assemble_fwd_v4<1><<<g8, blk, 0, st>>>(a);
+  else if (vec && D == 64) k_assemble_fwd_v4<16><<<g8, blk, 0, st>>>(a);
+  else k_assemble_fwd<<<dim3((B + 15) / 16), blk, 0, st>>>(a);
   return launch_status();
 }
 
@@ -169,7 +299,16 @@ extern "C" int dctr_shard_assemble_bwd(float* send, int64_t ld_chunk, int32_t n_
   a.g_out = g_out; a.ldg = ld_g; a.g_wide = g_wide; a.g_fm = g_fm; a.out = const_cast<float*>(out); a.ldo = ld_out;
   a.fm_s = const_cast<float*>(fm_s); a.lds_ = ld_s; a.X = X; a.ldx = ld_x; a.wdense_cols = wdense_cols;
   a.n_wdense = n_wdense; a.g_wdense = g_wdense;
-  const unsigned nblk = (B + 15) / 16 + (g_wdense ? static_cast<unsigned>(n_wdense) : 0u);
-  k_assemble_bwd<<<dim3(nblk), dim3(kT), 0, static_cast<hipStream_t>(stream)>>>(a);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned extra = g_wdense ? static_cast<unsigned>(n_wdense) : 0u;
+  const bool vec = D % 4 == 0 && ld_chunk % 4 == 0 && al16(send) && (!g_out || (ld_g % 4 == 0 && al16(g_out))) &&
+                   (!g_fm || (ld_out % 4 == 0 && al16(out) && ld_s % 4 == 0 && al16(fm_s)));
+  const dim3 g8((B + 7) / 8 + extra), blk(kT);
+  if (vec && D == 16) k_assemble_bwd_v4<4><<<g8, blk, 0, st>>>(a);
+  else if (vec && D == 8) k_assemble_bwd_v4<2><<<g8, blk, 0, st>>>(a);
+  else if (vec && D == 32) k_assemble_bwd_v4<8><<<g8, blk, 0, st>>>(a);
+  else if (vec && D == 4) k_assemble_bwd_v4<1><<<g8, blk, 0, st>>>(a);
+  else if (vec && D == 64) k_assemble_bwd_v4<16><<<g8, blk, 0, st>>>(a);
+  else k_assemble_bwd<<<dim3((B + 15) / 16 + extra), blk, 0, st>>>(a);
   return launch_status();
 }

@@ -334,9 +334,13 @@ class _Segment(object):
     def __init__(self, fn, use_graph):
         self.fn, self.use_graph = fn, use_graph
         self.graph, self.result = None, None
+        self.primed = False
 
     def __call__(self):
         if not self.use_graph:
+            return self.fn()
+        if not self.primed:         # first call runs eagerly: descriptor uploads / lazy buffers are not capturable
+            self.primed = True
             return self.fn()
         if self.graph is None:
             torch.cuda.synchronize()
