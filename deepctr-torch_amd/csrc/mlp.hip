@@ -85,62 +85,70 @@ unsigned long long* g_mlp_trace = nullptr;
 // forward
 // ------------------------------------------------------------------------------------------------------------
 // NT output tiles (16 columns each) of one layer over the K range [kg0, kg0 + klen) whose A rows sit in LDS.
-// No load in the loop is predicated (a predicated load becomes a branch and serialises the loop on memory
-// latency): columns past N re-read row N-1 (their results are dropped by the epilogue) and a dwordx4 that would
-// leave the row is pulled back inside it (its A elements are zero, and weights are finite).  The weight stream
-// runs kPD iterations ahead of the matrix pipe in a register ring.
-// (The ring must cover the L2 latency: one iteration is 4*NT MFMAs = 128*NT cycles, so fewer tiles => deeper ring.)
-// Every workgroup walks K from a different starting iteration (`rot`): without it all 256 workgroups request
-// the same weight lines at the same moment and queue up on the same L2 channels.
-template <int NT>
+//  * No load in the loop is predicated (a predicated load becomes a branch and serialises the loop on memory
+//    latency): columns past N re-read row N-1 (their results are dropped by the epilogue) and a dwordx4 that
+//    would leave the row is pulled back inside it (its A elements are zero, and weights are finite).
+//  * The weight stream runs kPD-1 iterations ahead of the matrix pipe in a register ring (one iteration is
+//    4*NT MFMAs = 128*NT cycles, so fewer tiles => deeper ring to cover the L2 latency).
+//  * Addresses are a uniform base + one 32-bit lane offset per tile (+ a per-iteration byte offset shared by the
+//    tiles): ~NT+2 vector ALU instructions per iteration next to 4*NT MFMAs.
+//  * A tile's k-steps alternate between KS accumulators so that at least four independent MFMA chains are in
+//    flight per wave (a dependent 16x16x4 chain leaves the matrix pipe idle between issues).
+//  * `between()` runs after the ring prologue has been issued: the kernel stages the A chunk there, so the
+//    first weight loads overlap the staging's own memory latency.
+template <int NT, typename Between>
 __device__ __forceinline__ void fwd_tiles(const float* As, int rs, int kg0, int klen, const LayerDev& Ld,
-                                          int tile0, f32x4* acc, int g, int c, int rot) {
+                                          int tile0, f32x4* acc, int g, int c, Between between) {
   constexpr int kPD = NT == 1 ? 12 : (NT == 2 ? 8 : (NT == 3 ? 6 : 4));
-  const float* wrow[NT];
+  constexpr int KS = NT >= 4 ? 1 : (NT >= 2 ? 2 : 4);
+  const DCTR_GLOBAL char* wbase = (const DCTR_GLOBAL char*)Ld.W;
+  uint32_t voff[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     int n = (tile0 + t * kWaves) * 16 + c;
     n = n < Ld.N ? n : Ld.N - 1;
-    wrow[t] = Ld.W + static_cast<int64_t>(n) * Ld.ldw + kg0 + 4 * g;
+    voff[t] = (static_cast<uint32_t>(n) * static_cast<uint32_t>(Ld.ldw) + kg0 + 4 * g) * 4u;
   }
   const float* ap = As + c * rs + 4 * g;
   const int n_it = klen >> 4;
-  const int omax = Ld.ldw - kg0 - 4 * g - 4;  // largest in-row offset of a dwordx4 from wrow
-  const int r0 = rot % n_it;
-  auto phys = [&](int it) {                   // logical iteration -> K block (rotated, clamped past the end)
-    it = it < n_it ? it : n_it - 1;
-    const int q = it + r0;
-    return q < n_it ? q : q - n_it;
-  };
-  auto woff = [&](int it) {
-    const int o = phys(it) << 4;
+  const uint32_t omax = static_cast<uint32_t>(Ld.ldw - kg0 - 4 * g - 4) * 4u;  // largest in-row byte offset
+  auto woff = [&](int it) -> uint32_t {
+    it = it < n_it ? it : n_it - 1;                       // scalar: `it` is wave-uniform
+    const uint32_t o = static_cast<uint32_t>(it) << 6;
     return o < omax ? o : omax;
   };
-  // ring slot (it % kPD) holds the weights of iteration `it`; at step `it` the slot freed by step it-1 is
-  // refilled with iteration it + kPD - 1, so no live register is ever a load destination.
   f32x4 ring[kPD][NT];
 #pragma unroll
   for (int d = 0; d < kPD - 1; ++d) {
-    const int o = woff(d);
+    const uint32_t o = woff(d);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) ring[d][t] = ldg_f4(wrow[t] + o);
+    for (int t = 0; t < NT; ++t) ring[d][t] = *(const DCTR_GLOBAL f32x4*)(wbase + (voff[t] + o));
+  }
+  between();
+  f32x4 accs[NT][KS];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    accs[t][0] = acc[t];
+#pragma unroll
+    for (int k = 1; k < KS; ++k) accs[t][k] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int n_grp = n_it / kPD, rem = n_it - n_grp * kPD;
-  f32x4 a_nxt = *reinterpret_cast<const f32x4*>(ap + (phys(0) << 4));
+  f32x4 a_nxt = *reinterpret_cast<const f32x4*>(ap);
   for (int gi = 0; gi < n_grp; ++gi) {
 #pragma unroll
     for (int d = 0; d < kPD; ++d) {
       const int it = gi * kPD + d;
-      const int o = woff(it + kPD - 1);
+      const uint32_t o = woff(it + kPD - 1);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) ring[(d + kPD - 1) % kPD][t] = ldg_f4(wrow[t] + o);
+      for (int t = 0; t < NT; ++t) ring[(d + kPD - 1) % kPD][t] = *(const DCTR_GLOBAL f32x4*)(wbase + (voff[t] + o));
       const f32x4 a4 = a_nxt;
-      a_nxt = *reinterpret_cast<const f32x4*>(ap + (phys(it + 1) << 4));
+      const int itn = it + 1 < n_it ? it + 1 : it;
+      a_nxt = *reinterpret_cast<const f32x4*>(ap + (itn << 4));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = mfma16(a4[j], ring[d][t][j], acc[t]);
+        for (int t = 0; t < NT; ++t) accs[t][j % KS] = mfma16(a4[j], ring[d][t][j], accs[t][j % KS]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -148,23 +156,31 @@ __device__ __forceinline__ void fwd_tiles(const float* As, int rs, int kg0, int 
   for (int d = 0; d < kPD - 1; ++d) {
     if (d < rem) {
       const int it = n_grp * kPD + d;
-      const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + (phys(it) << 4));
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + (it << 4));
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = mfma16(a4[j], ring[d][t][j], acc[t]);
+        for (int t = 0; t < NT; ++t) accs[t][j % KS] = mfma16(a4[j], ring[d][t][j], accs[t][j % KS]);
     }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    f32x4 r = accs[t][0];
+#pragma unroll
+    for (int k = 1; k < KS; ++k) r += accs[t][k];
+    acc[t] = r;
   }
 }
 
+template <typename Between>
 __device__ __forceinline__ void fwd_dispatch(int nt, const float* As, int rs, int kg0, int klen, const LayerDev& Ld,
-                                             int tile0, f32x4* acc, int g, int c, int rot) {
+                                             int tile0, f32x4* acc, int g, int c, Between between) {
   switch (nt) {
-    case 1: fwd_tiles<1>(As, rs, kg0, klen, Ld, tile0, acc, g, c, rot); break;
-    case 2: fwd_tiles<2>(As, rs, kg0, klen, Ld, tile0, acc, g, c, rot); break;
-    case 3: fwd_tiles<3>(As, rs, kg0, klen, Ld, tile0, acc, g, c, rot); break;
-    case 4: fwd_tiles<4>(As, rs, kg0, klen, Ld, tile0, acc, g, c, rot); break;
-    default: break;
+    case 1: fwd_tiles<1>(As, rs, kg0, klen, Ld, tile0, acc, g, c, between); break;
+    case 2: fwd_tiles<2>(As, rs, kg0, klen, Ld, tile0, acc, g, c, between); break;
+    case 3: fwd_tiles<3>(As, rs, kg0, klen, Ld, tile0, acc, g, c, between); break;
+    case 4: fwd_tiles<4>(As, rs, kg0, klen, Ld, tile0, acc, g, c, between); break;
+    default: between(); break;   // a wave without tiles still takes part in the staging barriers
   }
 }
 
@@ -178,7 +194,6 @@ __global__ __launch_bounds__(kT) void k_mlp_fwd(MlpArgs A) {
   float* hb1 = hb0 + kTM * rsh;   // [16][rsh]  pong
   const int K0 = A.L[0].K, K0p = round_up(K0, 16);
   const int kcw = K0p < kKC ? K0p : kKC;
-  const int rot = static_cast<int>(blockIdx.x) * 5;
   MLP_TRACE(A.trace, 0);
 
   const float* in = nullptr;
@@ -201,30 +216,32 @@ __global__ __launch_bounds__(kT) void k_mlp_fwd(MlpArgs A) {
       if (l == 0) {
         for (int kc = 0; kc < K0p; kc += kcw) {
           const int klen = (K0p - kc) < kcw ? (K0p - kc) : kcw;
-          __syncthreads();  // the previous chunk (or pass) is consumed
-          for (int e = tid; e < kTM * (klen >> 2); e += kT) {
-            const int r = e / (klen >> 2), q = e - r * (klen >> 2);
-            const int k = kc + 4 * q;
-            const int64_t b = b0 + r;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (b < A.B) {
-              const float* src = A.x + b * A.ldx + k;
-              if (k + 3 < K0) {
-                v = ldg_f4(src);
-              } else {
-                if (k < K0) v.x = ldg_f32(src);
-                if (k + 1 < K0) v.y = ldg_f32(src + 1);
-                if (k + 2 < K0) v.z = ldg_f32(src + 2);
+          auto stage = [&]() {
+            __syncthreads();  // the previous chunk (or pass) is consumed
+            for (int e = tid; e < kTM * (klen >> 2); e += kT) {
+              const int r = e / (klen >> 2), q = e - r * (klen >> 2);
+              const int k = kc + 4 * q;
+              const int64_t b = b0 + r;
+              f32x4 v = {0.f, 0.f, 0.f, 0.f};
+              if (b < A.B) {
+                const float* src = A.x + b * A.ldx + k;
+                if (k + 3 < K0) {
+                  v = ldg_f4(src);
+                } else {
+                  if (k < K0) v.x = ldg_f32(src);
+                  if (k + 1 < K0) v.y = ldg_f32(src + 1);
+                  if (k + 2 < K0) v.z = ldg_f32(src + 2);
+                }
               }
+              *reinterpret_cast<f32x4*>(xs + r * rsx + 4 * q) = v;
             }
-            *reinterpret_cast<f32x4*>(xs + r * rsx + 4 * q) = v;
-          }
-          __syncthreads();
-          if (kc == 0 && tbase == 0) MLP_TRACE(A.trace, 1);
-          fwd_dispatch(nt, xs, rsx, kc, klen, Ld, tile0, acc, g, c, rot);
+            __syncthreads();
+            if (kc == 0 && tbase == 0) MLP_TRACE(A.trace, 1);
+          };
+          fwd_dispatch(nt, xs, rsx, kc, klen, Ld, tile0, acc, g, c, stage);
         }
       } else {
-        fwd_dispatch(nt, in, rsh, 0, round_up(Ld.K, 16), Ld, tile0, acc, g, c, rot);
+        fwd_dispatch(nt, in, rsh, 0, round_up(Ld.K, 16), Ld, tile0, acc, g, c, []() {});
       }
       if (tbase == 0) MLP_TRACE(A.trace, 2 + 3 * l);
       // epilogue: activation; keep the tile in LDS for the next layer, save it for the backward
@@ -308,21 +325,22 @@ __global__ __launch_bounds__(kT) void k_mlp_bwd_data(MlpArgs A) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* ap = din + c * rs + 4 * g;
-        const float* wp = Ld.W + colc;
         const int n_it = Np >> 4;
-        const int r0 = (static_cast<int>(blockIdx.x) * 5) % n_it;
-        auto phys = [&](int it) {
-          it = it < n_it ? it : n_it - 1;
-          const int q = it + r0;
-          return q < n_it ? q : q - n_it;
-        };
+        // uniform base + 32-bit lane offsets: row n = 16 it + 4 g + j of W starts at byte (n * ldw + colc) * 4
+        const DCTR_GLOBAL char* wbase = (const DCTR_GLOBAL char*)Ld.W;
+        const uint32_t ldw4 = static_cast<uint32_t>(Ld.ldw) * 4u;
+        const uint32_t vlast = static_cast<uint32_t>(Ld.N - 1) * ldw4 + static_cast<uint32_t>(colc) * 4u;
+        uint32_t vrow[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vrow[j] = static_cast<uint32_t>(4 * g + j) * ldw4 + static_cast<uint32_t>(colc) * 4u;
         auto wld = [&](int it, f32x4* dst) {
-          it = phys(it);
+          it = it < n_it ? it : n_it - 1;                               // scalar
+          const uint32_t so = static_cast<uint32_t>(it) * 16u * ldw4;  // scalar
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            int n = (it << 4) + 4 * g + j;
-            n = n < Ld.N ? n : Ld.N - 1;
-            dst[j] = ldg_f4(wp + static_cast<int64_t>(n) * Ld.ldw);
+            uint32_t o = vrow[j] + so;
+            o = o < vlast ? o : vlast;                                  // rows past N re-read row N-1 (A is 0 there)
+            dst[j] = *(const DCTR_GLOBAL f32x4*)(wbase + o);
           }
         };
         constexpr int PD = 5;
@@ -330,14 +348,15 @@ __global__ __launch_bounds__(kT) void k_mlp_bwd_data(MlpArgs A) {
 #pragma unroll
         for (int d = 0; d < PD - 1; ++d) wld(d, ring[d]);
         const int n_grp = n_it / PD, rem = n_it - n_grp * PD;
-        f32x4 a_nxt = *reinterpret_cast<const f32x4*>(ap + (phys(0) << 4));
+        f32x4 a_nxt = *reinterpret_cast<const f32x4*>(ap);
         for (int gi = 0; gi < n_grp; ++gi) {
 #pragma unroll
           for (int d = 0; d < PD; ++d) {
             const int it = gi * PD + d;
             wld(it + PD - 1, ring[(d + PD - 1) % PD]);
             const f32x4 a4 = a_nxt;
-            a_nxt = *reinterpret_cast<const f32x4*>(ap + (phys(it + 1) << 4));
+            const int itn = it + 1 < n_it ? it + 1 : it;
+            a_nxt = *reinterpret_cast<const f32x4*>(ap + (itn << 4));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -350,7 +369,7 @@ __global__ __launch_bounds__(kT) void k_mlp_bwd_data(MlpArgs A) {
         for (int d = 0; d < PD - 1; ++d) {
           if (d < rem) {
             const int it = n_grp * PD + d;
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + (phys(it) << 4));
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + (it << 4));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -473,45 +492,46 @@ __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
   for (int r = 0; r < 16; ++r) c00[r] = c01[r] = c10[r] = c11[r] = 0.f;
   float sa = 0.f, sb = 0.f;
   const bool want_bias = (k0 == 0);
-  // Unpredicated loads (clamped row / column, value masked afterwards), U row pairs per group, the loads of the
-  // next PD groups in flight while the matrix pipe works on the current one.
+  // Main loop over FULL groups of 2U rows: no predicates, no masks.  Column indices past N / K are clamped (the
+  // garbage only reaches output rows / columns that are dropped or zeroed at the store); addresses are a uniform
+  // base + a per-lane 32-bit offset + a scalar row offset: one v_add per load.  The loads of the next PD-1 groups
+  // are in flight while the matrix pipe works on the current one.  A last partial group takes the masked path.
   constexpr int U = 4, PD = 5;
   const int mac = va ? ma : 0, mbc = vb ? mb : 0, kac = vka ? ka : 0, kbc = vkb ? kb : 0;
-  const int64_t blast = (wb1 > wb0) ? wb1 - 1 : wb0;
-  // 32-bit byte offsets from uniform bases (the host checks the tensors are < 4 GB): one VGPR per address
   const DCTR_GLOBAL char* dbase = (const DCTR_GLOBAL char*)Ld.dh;
   const DCTR_GLOBAL char* ibase = (const DCTR_GLOBAL char*)in;
   const uint32_t ldh4 = static_cast<uint32_t>(Ld.ldh) * 4u, ldi4 = static_cast<uint32_t>(ldi) * 4u;
-  auto gload = [&](int64_t bb, float (*v)[4]) {
+  const uint32_t va0 = static_cast<uint32_t>(p) * ldh4 + 4u * mac, va1 = static_cast<uint32_t>(p) * ldh4 + 4u * mbc;
+  const uint32_t vx0 = static_cast<uint32_t>(p) * ldi4 + 4u * kac, vx1 = static_cast<uint32_t>(p) * ldi4 + 4u * kbc;
+  const int nrow = static_cast<int>(wb1 > wb0 ? wb1 - wb0 : 0);
+  const int n_full = nrow / (2 * U);                  // full groups
+  const uint32_t row0 = static_cast<uint32_t>(wb0);
+  auto gload = [&](int gidx, float (*v)[4]) {          // group index -> its 2U rows (clamped to the last full group)
+    gidx = gidx < n_full ? gidx : n_full - 1;          // scalar
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      int64_t b = bb + 2 * u + p;
-      b = b < wb1 ? b : blast;
-      const uint32_t od = static_cast<uint32_t>(b) * ldh4, oi = static_cast<uint32_t>(b) * ldi4;
-      v[u][0] = *(const DCTR_GLOBAL float*)(dbase + (od + 4u * mac));
-      v[u][1] = *(const DCTR_GLOBAL float*)(dbase + (od + 4u * mbc));
-      v[u][2] = *(const DCTR_GLOBAL float*)(ibase + (oi + 4u * kac));
-      v[u][3] = *(const DCTR_GLOBAL float*)(ibase + (oi + 4u * kbc));
+      const uint32_t r = row0 + static_cast<uint32_t>(gidx * 2 * U + 2 * u);   // scalar
+      const uint32_t sd = r * ldh4, si = r * ldi4;                               // scalar
+      v[u][0] = *(const DCTR_GLOBAL float*)(dbase + (va0 + sd));
+      v[u][1] = *(const DCTR_GLOBAL float*)(dbase + (va1 + sd));
+      v[u][2] = *(const DCTR_GLOBAL float*)(ibase + (vx0 + si));
+      v[u][3] = *(const DCTR_GLOBAL float*)(ibase + (vx1 + si));
     }
   };
-  if (wb1 > wb0) {
+  if (n_full > 0) {
     float ring[PD][U][4];
 #pragma unroll
-    for (int d = 0; d < PD - 1; ++d) gload(wb0 + d * 2 * U, ring[d]);
-    for (int64_t bb = wb0; bb < wb1; bb += 2 * U * PD) {
+    for (int d = 0; d < PD - 1; ++d) gload(d, ring[d]);
+    for (int g0 = 0; g0 < n_full; g0 += PD) {
 #pragma unroll
       for (int dd = 0; dd < PD; ++dd) {
-        const int64_t b0g = bb + dd * 2 * U;
-        gload(b0g + 2 * U * (PD - 1), ring[(dd + PD - 1) % PD]);
+        const int gi = g0 + dd;
+        gload(gi + PD - 1, ring[(dd + PD - 1) % PD]);
         __builtin_amdgcn_sched_barrier(0);
-        if (b0g < wb1) {
+        if (gi < n_full) {
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            const bool vr = (b0g + 2 * u + p) < wb1;
-            const float a0 = (vr && va) ? ring[dd][u][0] : 0.f;
-            const float a1 = (vr && vb) ? ring[dd][u][1] : 0.f;
-            const float x0 = (vr && vka) ? ring[dd][u][2] : 0.f;
-            const float x1 = (vr && vkb) ? ring[dd][u][3] : 0.f;
+            const float a0 = ring[dd][u][0], a1 = ring[dd][u][1], x0 = ring[dd][u][2], x1 = ring[dd][u][3];
             c00 = mfma32(a0, x0, c00);
             c01 = mfma32(a0, x1, c01);
             c10 = mfma32(a1, x0, c10);
@@ -523,6 +543,21 @@ __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+  }
+  for (int64_t bb = wb0 + static_cast<int64_t>(n_full) * 2 * U; bb < wb1; bb += 2) {   // ragged tail, masked
+    const int64_t b = bb + p;
+    const bool vr = b < wb1;
+    const int64_t bc = vr ? b : wb0;
+    const float* dr = Ld.dh + bc * Ld.ldh;
+    const float* ir = in + bc * ldi;
+    const float a0 = vr ? ldg_f32(dr + mac) : 0.f, a1 = vr ? ldg_f32(dr + mbc) : 0.f;
+    const float x0 = vr ? ldg_f32(ir + kac) : 0.f, x1 = vr ? ldg_f32(ir + kbc) : 0.f;
+    c00 = mfma32(a0, x0, c00);
+    c01 = mfma32(a0, x1, c01);
+    c10 = mfma32(a1, x0, c10);
+    c11 = mfma32(a1, x1, c11);
+    sa += a0;
+    sb += a1;
   }
   MLP_TRACE(A.trace, 1);
   // combine the four waves in wave order
@@ -564,12 +599,12 @@ __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
   for (int r = 0; r < 16; ++r) {
     const int ra = m0 + acc_row32(r, p), rb = ra + 32;
     if (ra < Ld.N) {
-      if (ka < Ld.ldw) stg_f32(pw + static_cast<int64_t>(ra) * Ld.ldw + ka, c00[r]);
-      if (kb < Ld.ldw) stg_f32(pw + static_cast<int64_t>(ra) * Ld.ldw + kb, c01[r]);
+      if (ka < Ld.ldw) stg_f32(pw + static_cast<int64_t>(ra) * Ld.ldw + ka, vka ? c00[r] : 0.f);
+      if (kb < Ld.ldw) stg_f32(pw + static_cast<int64_t>(ra) * Ld.ldw + kb, vkb ? c01[r] : 0.f);
     }
     if (rb < Ld.N) {
-      if (ka < Ld.ldw) stg_f32(pw + static_cast<int64_t>(rb) * Ld.ldw + ka, c10[r]);
-      if (kb < Ld.ldw) stg_f32(pw + static_cast<int64_t>(rb) * Ld.ldw + kb, c11[r]);
+      if (ka < Ld.ldw) stg_f32(pw + static_cast<int64_t>(rb) * Ld.ldw + ka, vka ? c10[r] : 0.f);
+      if (kb < Ld.ldw) stg_f32(pw + static_cast<int64_t>(rb) * Ld.ldw + kb, vkb ? c11[r] : 0.f);
     }
   }
   if (want_bias && p == 0) {
@@ -610,6 +645,7 @@ int check_mlp(const dctr_mlp_t* m, int32_t B) {
     if (L.ld_w % 4 != 0 || reinterpret_cast<uintptr_t>(L.W) % 16 != 0) return DCTR_EALIGN;
     if (l > 0 && L.K != m->layer[l - 1].N) return DCTR_EINVAL;
     if (L.N > 2048) return DCTR_ENOSUP;
+    if (static_cast<int64_t>(L.N) * L.ld_w * 4 >= (int64_t(1) << 31)) return DCTR_ENOSUP;  // 32-bit weight offsets
   }
   return DCTR_OK;
 }
