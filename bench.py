@@ -135,6 +135,36 @@ def time_hot_kernels(model, X_all, B, iters, opt, ring=16):
     return res
 
 
+def pmc_traffic(kernel, opt, B):
+    """HBM bytes per launch of a hand-written kernel from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh:
+    FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB units, corrected with factors calibrated on launches of
+    known byte counts as MI355X_MICROARCH.md prescribes for access patterns other than wide streaming reads).
+    Returns None when no PMC summary for this kernel / launch size is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        d = json.load(fh)
+    tag = "embed_fwd" if kernel == "embed_fwd" else "embed_update_%s" % opt
+    grid = (B // 16 * 256) if kernel == "embed_fwd" else None
+    best = None
+    for k, v in d.get("kernels", {}).items():
+        name, g = k.split("@grid")
+        if name != tag:
+            continue
+        if grid is not None and int(g) != grid:
+            continue
+        if grid is None and int(g) // 256 not in (32 << 6, (32 << 6) + 13):   # update kernel at B = 4096
+            continue
+        best = v
+    if best is None or B != 4096:
+        return None
+    return {"bytes": best["fetch_bytes_gather_corrected"] + best["write_bytes_corrected"],
+            "fetch_raw": best["fetch_raw_bytes"], "fetch_gather_calibrated": best["fetch_bytes_gather_corrected"],
+            "fetch_x2_streaming_rule": best["fetch_bytes_x2"], "write": best["write_bytes_corrected"],
+            "source": "profiles/r01_pmc_traffic.json"}
+
+
 def cpu_baseline(args):
     """The reference's dense-gradient algorithm (torch-CPU port) on this box's host cores, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -245,6 +275,7 @@ def main():
             kern[k]["alg_bytes"] = alg[k]
             kern[k]["gbs"] = alg[k] / (kern[k]["avg_us"] * 1e-6) / 1e9
         dom = max(kern, key=lambda k: kern[k]["avg_us"])
+        traffic = pmc_traffic(dom, args.optimizer, B)
         hot_us = sum(v["avg_us"] for v in kern.values())
         step_alg = sum(alg[k] for k in kern)
         result = {
@@ -256,7 +287,8 @@ def main():
                        "global_batch": world * B, "parallelism": ("tables sharded x%d + dp%d tower" % (world, world)) if parallel is not None else "single",
                        "hip_graph": graphed is not None, "optimizer": args.optimizer},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": kern[dom]["gbs"] / HBM_PEAK_GBS,
+                         "traffic": (traffic or {}).get("bytes"), "traffic_detail": traffic,
                          "alg_bytes_per_launch": alg[dom], "avg_us": kern[dom]["avg_us"]},
             "hot_path": {"kernels": kern, "sum_us": hot_us,
                          "frac_of_hbm_peak": step_alg / (hot_us * 1e-6) / 1e9 / HBM_PEAK_GBS,

@@ -277,3 +277,36 @@ def test_fused_step_keeps_state_dict_optimizer_state_and_pickle():
     assert m._fused["slab"].intact()
     m._train_step(X, y)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("double_buffer", [False, True])
+def test_graphed_train_step_equals_eager(double_buffer):
+    """One hipGraph per static buffer set (copies of the next batch overlap the running graph): bit-identical to the
+    eager fused step on the same sequence of batches (every kernel on the path is deterministic)."""
+    from deepctr_torch._hip.graph import GraphedTrainStep
+    g = load_golden("deepfm_criteo")
+    gen = torch.Generator().manual_seed(5)
+    Xs = [torch.from_numpy(g["extra"]["X_steps"][i % 3]).to(DEV)[torch.randperm(g["extra"]["X_steps"][0].shape[0], generator=gen).to(DEV)]
+          for i in range(7)]
+    ys = [torch.randint(0, 2, (Xs[0].shape[0],), generator=gen).float().to(DEV) for _ in range(7)]
+    finals = []
+    for mode in ("eager", "graph"):
+        m = build_model(g["spec"], DEV)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in g["params"].items()})
+        m.compile("adagrad", "binary_crossentropy", metrics=[])
+        m.train()
+        losses = []
+        m._train_step(Xs[0], ys[0])
+        m._train_step(Xs[1], ys[1])
+        step = m._train_step
+        if mode == "graph":
+            step = GraphedTrainStep(m, Xs[0], ys[0], double_buffer=double_buffer).capture(Xs[2], ys[2])
+        for i in range(2, 7):
+            out = step(Xs[i], ys[i])
+            losses.append(float(out[0].item()))
+        torch.cuda.synchronize()
+        finals.append(({k: v.clone() for k, v in m.state_dict().items()}, losses))
+    (a, la), (b, lb) = finals
+    assert la == lb
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
