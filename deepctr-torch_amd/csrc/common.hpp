@@ -15,8 +15,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// A short per-lane strip of VEC consecutive floats (VEC in {1,2,4}); loads/stores are one
-// global_load/store_dword{,x2,x4}.
+// A short per-lane strip of VEC consecutive floats (VEC in {1,2,4,8}); loads/stores are one
+// global_load/store_dword{,x2,x4} (two dwordx4 for VEC = 8).
 template <int VEC>
 struct Strip {
   float v[VEC];
@@ -47,7 +47,12 @@ __device__ __forceinline__ void stg_f32(float* p, float v) { *(DCTR_GLOBAL float
 template <int VEC>
 __device__ __forceinline__ Strip<VEC> strip_load(const float* p) {
   Strip<VEC> r;
-  if constexpr (VEC == 4) {
+  if constexpr (VEC == 8) {
+    f32x4 t = *(const DCTR_GLOBAL f32x4*)p;
+    f32x4 u = *(const DCTR_GLOBAL f32x4*)(p + 4);
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    r.v[4] = u.x; r.v[5] = u.y; r.v[6] = u.z; r.v[7] = u.w;
+  } else if constexpr (VEC == 4) {
     f32x4 t = *(const DCTR_GLOBAL f32x4*)p;
     r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
   } else if constexpr (VEC == 2) {
@@ -61,7 +66,12 @@ __device__ __forceinline__ Strip<VEC> strip_load(const float* p) {
 
 template <int VEC>
 __device__ __forceinline__ void strip_store(float* p, const Strip<VEC>& s) {
-  if constexpr (VEC == 4) {
+  if constexpr (VEC == 8) {
+    f32x4 t = {s.v[0], s.v[1], s.v[2], s.v[3]};
+    f32x4 u = {s.v[4], s.v[5], s.v[6], s.v[7]};
+    *(DCTR_GLOBAL f32x4*)p = t;
+    *(DCTR_GLOBAL f32x4*)(p + 4) = u;
+  } else if constexpr (VEC == 4) {
     f32x4 t = {s.v[0], s.v[1], s.v[2], s.v[3]};
     *(DCTR_GLOBAL f32x4*)p = t;
   } else if constexpr (VEC == 2) {

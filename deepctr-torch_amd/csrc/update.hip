@@ -141,7 +141,9 @@ __global__ __launch_bounds__(kThreads) void k_embed_update(UpdArgs A) {
   uint32_t* keys = reinterpret_cast<uint32_t*>(smem);           // [cap]
   float* gbuf = reinterpret_cast<float*>(keys + cap);            // [G][LPR*VEC] deep gradient strips
   float* gwbuf = gbuf + G * LPR * VEC;                           // [G] wide gradients
-  float* carry = gwbuf + G;                                      // [LPR*VEC + 1]
+  float* carry = gwbuf + G;                                      // [LPR*VEC + 4]
+  float* gfbuf = carry + LPR * VEC + 4;                          // [G]  single-tile path: g_fm of the entry
+  uint32_t* skeys = reinterpret_cast<uint32_t*>(gfbuf + G);      // [G]  single-tile path: keys in sorted order
 
   if (tid == 0) {
     n_sh = 0;
@@ -190,6 +192,103 @@ __global__ __launch_bounds__(kThreads) void k_embed_update(UpdArgs A) {
   DCTR_TRACE(1);
   if (A.trace && tid == 0) A.trace[blockIdx.x * 8ull + 7] = static_cast<unsigned long long>(n);
   if (n == 0) return;
+
+  if (n <= G) {
+    // ---- single tile (the common case: P is chosen so that a partition holds ~G/2 entries) -------------------
+    // Lane group i takes the i-th entry in SCAN order and issues its loads at once; the rank sort runs in their
+    // shadow; gradients are parked in LDS at their SORTED position; the last entry of every id segment sums its
+    // segment backwards (fixed order) and applies the update to the row strips it already holds.
+    // FM's backward is folded algebraically: sum_seg [g + gf (S - e)] = sum_seg (g + gf S) - (sum_seg gf) e, and e
+    // IS the table row this lane is about to update -- the forward's copy of it is not re-read.
+    const int grp = tid / LPR, gl = tid % LPR, e0 = gl * VEC;
+    const uint32_t bmask = (1u << A.bbits) - 1u;
+    const bool deep_on = (di >= 0) && (A.gout || A.gfm);
+    const bool wide_on = (wi >= 0) && A.gwide;
+    const bool lane_on = deep_on && (e0 < fd.dim);
+    const int goff = deep_on ? fd.out_off + (lane_on ? e0 : 0) : 0;
+    const bool have = grp < n;
+    const uint32_t key = have ? keys[grp] : 0xFFFFFFFFu;
+    const int b = static_cast<int>(key & bmask);
+    const int idq = static_cast<int>(key >> A.bbits);
+    const int64_t row = (static_cast<int64_t>(idq) << A.log2p) | p;
+    Strip<VEC> h = strip_zero<VEC>(), S = strip_zero<VEC>(), w = strip_zero<VEC>(), s = strip_zero<VEC>();
+    Strip<VEC> e = strip_zero<VEC>();
+    float gf = 0.f, gw = 0.f, ww = 0.f, sw = 0.f;
+    if (have) {
+      if (lane_on) {
+        if (A.gout) h = strip_load<VEC>(A.gout + static_cast<int64_t>(b) * A.ldg + goff);
+        if (A.gfm) {
+          S = strip_load<VEC>(A.fm_s + static_cast<int64_t>(b) * A.lds_ + e0);
+          gf = ldg_f32(A.gfm + b);
+          if (OPT == DCTR_UPD_ACCUM) e = strip_load<VEC>(fd.table + row * fd.dim + e0);
+        }
+        const int64_t off = row * fd.dim + e0;
+        w = strip_load<VEC>((OPT == DCTR_UPD_ACCUM ? fd.gacc : fd.table) + off);
+        if (OPT == DCTR_UPD_ADAGRAD) s = strip_load<VEC>(fd.state + off);
+      }
+      if (wide_on && gl == 0) {
+        gw = ldg_f32(A.gwide + static_cast<int64_t>(b) * A.ldgw);
+        ww = ldg_f32((OPT == DCTR_UPD_ACCUM ? fw.gacc : fw.table) + row);
+        if (OPT == DCTR_UPD_ADAGRAD) sw = ldg_f32(fw.state + row);
+      }
+    }
+    int rank = 0;  // keys are unique: rank = number of smaller keys
+#pragma unroll 8
+    for (int q = 0; q < n; ++q) rank += (keys[q] < key) ? 1 : 0;
+    DCTR_TRACE(2);
+    if (have) {
+      if (gl == 0) {
+        skeys[rank] = key;
+        gfbuf[rank] = gf;
+        gwbuf[rank] = gw;
+      }
+      if (lane_on) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          float v = h.v[k] + gf * S.v[k];
+          if (OPT == DCTR_UPD_ACCUM) v = h.v[k] + gf * (S.v[k] - e.v[k]);
+          gbuf[rank * (LPR * VEC) + e0 + k] = v;
+        }
+      }
+    }
+    DCTR_TRACE(3);
+    __syncthreads();
+    DCTR_TRACE(4);
+    if (have) {
+      const bool seg_end = (rank == n - 1) || (static_cast<int>(skeys[rank + 1] >> A.bbits) != idq);
+      if (seg_end) {
+        Strip<VEC> acc = strip_zero<VEC>();
+        float accf = 0.f, accw = 0.f;
+        int r = rank;
+        while (r >= 0 && static_cast<int>(skeys[r] >> A.bbits) == idq) {
+          if (lane_on) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc.v[k] += gbuf[r * (LPR * VEC) + e0 + k];
+          }
+          accf += gfbuf[r];
+          if (gl == 0) accw += gwbuf[r];
+          --r;
+        }
+        if (lane_on) {
+          if (OPT != DCTR_UPD_ACCUM && A.gfm) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc.v[k] -= accf * w.v[k];
+          }
+          apply_strip<VEC, OPT>(fd, row * fd.dim + e0, acc, w, s, A.lr, A.eps);
+        }
+        if (wide_on && gl == 0) {
+          Strip<1> a1, w1, s1;
+          a1.v[0] = accw;
+          w1.v[0] = ww;
+          s1.v[0] = sw;
+          apply_strip<1, OPT>(fw, row, a1, w1, s1, A.lr, A.eps);
+        }
+      }
+    }
+    DCTR_TRACE(5);
+    DCTR_TRACE(6);
+    return;
+  }
 
   // ---- 2. sort by (id, b) ------------------------------------------------------------------------
   if (n <= kThreads) {
@@ -400,8 +499,11 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
   if (opt == DCTR_UPD_ACCUM && !(plan->flags & DCTR_PLAN_HAS_GACC)) return DCTR_EINVAL;
   if (opt == DCTR_UPD_ADAGRAD && !(plan->flags & DCTR_PLAN_HAS_STATE)) return DCTR_EINVAL;
   if (g_fm && (!out || !fm_s || plan->emb_dim <= 0)) return DCTR_EINVAL;
-  const int vec = plan->n_deep > 0 ? plan->vec : 1;
-  if (vec > 1) {
+  int vec = plan->n_deep > 0 ? plan->vec : 1;
+  const int avec = vec;  // alignment granule the caller guarantees
+  if (vec == 4 && plan->emb_dim > 0 && plan->emb_dim % 8 == 0 && plan->emb_dim <= 64) vec = 8;  // two dwordx4 per lane
+  if (avec > 1) {
+    const int vec = avec;
     if (g_out && (ld_g % vec != 0 || reinterpret_cast<uintptr_t>(g_out) % (4 * vec) != 0)) return DCTR_EALIGN;
     if (g_fm && (ld_out % vec != 0 || reinterpret_cast<uintptr_t>(out) % (4 * vec) != 0 ||
                  ld_s % vec != 0 || reinterpret_cast<uintptr_t>(fm_s) % (4 * vec) != 0))
@@ -425,7 +527,7 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
   int cap = 2;
   while (cap < B) cap <<= 1;
   const int g = kThreads / lpr;
-  const size_t lds = static_cast<size_t>(cap) * 4 + (static_cast<size_t>(g) * lpr * vec + g + lpr * vec + 4) * 4;
+  const size_t lds = static_cast<size_t>(cap) * 4 + (static_cast<size_t>(g) * lpr * vec + 3 * g + lpr * vec + 4) * 4;
   if (lds > 150 * 1024) return DCTR_ENOSUP;
   const int units8 = (n_units + 7) / 8 * 8;
   const dim3 grid((static_cast<unsigned>(units8) << log2p) + (g_wdense ? static_cast<unsigned>(plan->n_wdense) : 0u)), block(kThreads);
@@ -462,6 +564,13 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
     default: DCTR_UPD_LAUNCH(VEC_, 64); break;  \
   }
 
-  if (vec == 4) { DCTR_UPD_LPR(4) } else if (vec == 2) { DCTR_UPD_LPR(2) } else { DCTR_UPD_LPR(1) }
+#define DCTR_UPD_LPR8()                       \
+  switch (lpr) {                              \
+    case 1: DCTR_UPD_LAUNCH(8, 1); break;     \
+    case 2: DCTR_UPD_LAUNCH(8, 2); break;     \
+    case 4: DCTR_UPD_LAUNCH(8, 4); break;     \
+    default: DCTR_UPD_LAUNCH(8, 8); break;    \
+  }
+  if (vec == 8) { DCTR_UPD_LPR8() } else if (vec == 4) { DCTR_UPD_LPR(4) } else if (vec == 2) { DCTR_UPD_LPR(2) } else { DCTR_UPD_LPR(1) }
   return launch_status();
 }
