@@ -38,7 +38,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--vocab", type=int, default=1_000_000)
     ap.add_argument("--optimizer", default="adagrad", choices=["adagrad", "sgd"])
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replays")
+    ap.add_argument("--steps-per-graph", type=int, default=4,
+                    help="train steps captured per hipGraph (the ~15 us launch gap is paid once per graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-parallel", action="store_true", help="use the data-parallel trainer even with 1 rank")
     ap.add_argument("--kernel-iters", type=int, default=50, help="event-timed launches per hot-path kernel")
@@ -232,7 +234,7 @@ def main():
     if use_graph:
         from deepctr_torch._hip.graph import GraphedTrainStep
         try:
-            graphed = GraphedTrainStep(model, *batch(0)).capture(*batch(i))
+            graphed = GraphedTrainStep(model, *batch(0), steps_per_graph=args.steps_per_graph).capture(*batch(i))
             step_fn = graphed
         except Exception as exc:  # capture is an optimisation: report and continue eagerly
             print("hipGraph capture failed (%s: %s); running eager" % (type(exc).__name__, exc), file=sys.stderr)
@@ -246,6 +248,8 @@ def main():
         step_fn(*batch(i))
         i += 1
 
+    if use_graph and graphed is not None and graphed != "segments":
+        graphed.flush()                  # the timed region starts on a group boundary
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -254,6 +258,9 @@ def main():
     for _ in range(args.steps):
         out = step_fn(*batch(i))
         i += 1
+    if use_graph and graphed is not None and graphed != "segments":
+        tail = graphed.flush()           # K % steps_per_graph leftover steps run eagerly, inside the timed region
+        out = tail if tail is not None else out
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -285,7 +292,8 @@ def main():
             "config": {"workload": "DeepFM synthetic Criteo (26 sparse x %d vocab, 13 dense, emb_dim=16, batch=%d) "
                                    "fwd+bwd+%s, l2=0, dnn=(256,128)" % (args.vocab, B, args.optimizer),
                        "global_batch": world * B, "parallelism": ("tables sharded x%d + dp%d tower" % (world, world)) if parallel is not None else "single",
-                       "hip_graph": graphed is not None, "optimizer": args.optimizer},
+                       "hip_graph": graphed is not None, "steps_per_graph": (args.steps_per_graph if use_graph and graphed is not None else None),
+                       "optimizer": args.optimizer},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": kern[dom]["gbs"] / HBM_PEAK_GBS,
                          "traffic": (traffic or {}).get("bytes"), "traffic_detail": traffic,

@@ -1,15 +1,19 @@
-"""Whole-train-step HIP graph.
+"""Whole-train-step HIP graphs.
 
 At batch 4096 one DeepFM step is ~16 MB of compulsory HBM traffic (2 us at 8 TB/s) but 10-40 kernel
 launches; eager PyTorch-ROCm pays 5-10 us of host time per launch.  Capturing forward + loss + backward
 (with the fused sparse embedding update inside it) + the dense optimizer step into one hipGraph removes the
-host from the loop: a step becomes one ``hipGraphLaunch``.  The kernels of
+host from the loop: a step becomes (part of) one ``hipGraphLaunch``.  The kernels of
 ``libdctr_hip.so`` are enqueued on the caller's stream and never synchronise, so they are captured like
 any ATen kernel.
 
-The batch reaches the graph through static input buffers.  There are TWO buffer sets with one captured graph
-each (sharing one memory pool): the copy of batch k+1 into set B runs on a side stream while the graph of batch k
-still reads set A, so the two device-to-device copies (~10 us, 6 % of a DeepFM step) leave the critical path.
+Two measured facts shape this file (profiles/, MI355X):
+  * a graph launch itself leaves the GPU idle for ~15-20 us between two replays -- 10 % of a 150 us step.  A graph
+    therefore holds ``steps_per_graph`` consecutive train steps (each on its own static input buffers): the launch
+    gap is paid once per group;
+  * the batch reaches a graph through static buffers; there are TWO groups of buffers with one captured graph each
+    (sharing one memory pool), and the copies of the next group's batches run on a side stream while the current
+    graph executes, so they never sit on the critical path.
 """
 import torch
 
@@ -17,73 +21,102 @@ import torch
 class GraphedTrainStep(object):
     """Captures ``model._train_step`` for a fixed batch shape.
 
-    ``__call__`` copies a batch into the next static buffer set (side stream) and replays that set's graph.
-    Returned tensors are static: read them before the next call.
+    ``step(xb, yb)`` (also ``__call__``) stages one batch; every ``steps_per_graph`` calls the staged group is
+    launched as one graph.  The returned tensors are that step's static outputs: they hold the step's values once
+    its group has been launched (``flush()`` launches / runs whatever is staged) and until the same slot is reused
+    two groups later.
     """
 
-    def __init__(self, model, x_example, y_example, double_buffer=True):
+    def __init__(self, model, x_example, y_example, steps_per_graph=1, double_buffer=True):
         self.model = model
+        self.S = max(1, int(steps_per_graph))
         self.n_slots = 2 if double_buffer else 1
-        self.x = [torch.empty_like(x_example) for _ in range(self.n_slots)]
-        self.y = [torch.empty_like(y_example) for _ in range(self.n_slots)]
+        self.x = [[torch.empty_like(x_example) for _ in range(self.S)] for _ in range(self.n_slots)]
+        self.y = [[torch.empty_like(y_example) for _ in range(self.S)] for _ in range(self.n_slots)]
         self.graphs, self.outputs = [], []
         self.plan_version = None
-        self._i = 0
-        self._side = None
-        self._ready = None
-        self._free = None
+        self._slot, self._j = 0, 0
+        self._side = self._ready = self._free = self._free_ev = None
 
-    # kept for callers that look at the first slot
     @property
     def graph(self):
         return self.graphs[0] if self.graphs else None
 
     def capture(self, xb, yb):
-        """Capture one step per buffer set on (xb, yb).  Capture does not execute: call the object afterwards."""
+        """Capture ``steps_per_graph`` steps per buffer group on (xb, yb).  Capture does not execute."""
         model = self.model
         plan = model.model_plan()
         plan.bind(xb.device)
         pool = None
         self.graphs, self.outputs = [], []
         for s in range(self.n_slots):
-            self.x[s].copy_(xb)
-            self.y[s].copy_(yb)
+            for j in range(self.S):
+                self.x[s][j].copy_(xb)
+                self.y[s][j].copy_(yb)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
+            outs = []
             with torch.cuda.graph(g, pool=pool):
-                out = model._train_step(self.x[s], self.y[s])
+                for j in range(self.S):
+                    outs.append(model._train_step(self.x[s][j], self.y[s][j]))
             if pool is None:
                 pool = g.pool()
             self.graphs.append(g)
-            self.outputs.append(out)
+            self.outputs.append(outs)
         self.plan_version = plan.version
         self._side = torch.cuda.Stream(device=xb.device)
         self._ready = [torch.cuda.Event() for _ in range(self.n_slots)]
-        self._free = [None] * self.n_slots
         self._free_ev = [torch.cuda.Event() for _ in range(self.n_slots)]
-        self._i = 0
+        self._free = [None] * self.n_slots
+        self._slot, self._j = 0, 0
         return self
 
     def valid_for(self, xb):
-        return (bool(self.graphs) and tuple(xb.shape) == tuple(self.x[0].shape) and
+        return (bool(self.graphs) and tuple(xb.shape) == tuple(self.x[0][0].shape) and
                 self.plan_version == self.model.model_plan().version)
 
-    def __call__(self, xb, yb):
-        s = self._i % self.n_slots
-        self._i += 1
-        main = torch.cuda.current_stream(xb.device)
+    def step(self, xb, yb):
+        s, j = self._slot, self._j
         side = self._side
-        if self._free[s] is not None:
-            side.wait_event(self._free[s])          # the graph that last read this buffer set is done
+        if j == 0 and self._free[s] is not None:
+            side.wait_event(self._free[s])          # the graph that last read this buffer group is done
         with torch.cuda.stream(side):
-            self.x[s].copy_(xb, non_blocking=True)
-            self.y[s].copy_(yb, non_blocking=True)
-            self._ready[s].record(side)
+            self.x[s][j].copy_(xb, non_blocking=True)
+            self.y[s][j].copy_(yb, non_blocking=True)
+        out = self.outputs[s][j]
+        self._j += 1
+        if self._j == self.S:
+            self._launch()
+        return out
+
+    __call__ = step
+
+    def _launch(self):
+        s = self._slot
+        main = torch.cuda.current_stream(self.x[s][0].device)
+        self._ready[s].record(self._side)
         main.wait_event(self._ready[s])
         self.graphs[s].replay()
         self._free_ev[s].record(main)
         self._free[s] = self._free_ev[s]
-        return self.outputs[s]
+        self._slot, self._j = (s + 1) % self.n_slots, 0
+
+    def flush(self):
+        """Run the steps staged so far (an incomplete group runs eagerly on the staged buffers).  Returns the last
+        step's outputs, or None when nothing was staged."""
+        s, j = self._slot, self._j
+        if j == 0:
+            return None
+        main = torch.cuda.current_stream(self.x[s][0].device)
+        self._ready[s].record(self._side)
+        main.wait_event(self._ready[s])
+        out = None
+        for k in range(j):
+            out = self.model._train_step(self.x[s][k], self.y[s][k])
+        self._free_ev[s].record(main)
+        self._free[s] = self._free_ev[s]
+        self._slot, self._j = (s + 1) % self.n_slots, 0
+        return out
 
 
 def eager_warmup(model, batches):
