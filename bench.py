@@ -77,8 +77,9 @@ def algorithmic_bytes(B, opt):
     side = F_SPARSE * 4 + DIM * 4                                              # ids_t + fm_s side outputs
     fwd = B * (x_row + rows + wrows + ld * 4 + 8 + side)
     n_rw = 4 if opt == "adagrad" else 2                                        # table (+state): read + write
-    # ids_t + g_out + saved out + fm_s + g_fm + g_wide, then the row read-modify-writes
-    upd = B * (F_SPARSE * 4 + 2 * rows + DIM * 4 + 8 + n_rw * (rows + wrows))
+    # ids_t + g_out + fm_s + g_fm + g_wide, then the row read-modify-writes (FM's backward is folded algebraically:
+    # the forward's copy of the rows is not re-read)
+    upd = B * (F_SPARSE * 4 + rows + DIM * 4 + 8 + n_rw * (rows + wrows))
     return {"embed_fwd": fwd, "embed_update": upd}
 
 
