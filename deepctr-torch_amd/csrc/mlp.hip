@@ -450,8 +450,9 @@ struct WgradArgs {
 };
 
 __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
-  __shared__ float red[3 * 64 * 64];  // waves 1..3 park their 64x64 tile (48 KB)
-  __shared__ float redb[3 * 64];
+  extern __shared__ __align__(16) float wsm[];
+  float* red = wsm;                    // [4 waves][64x64 tile] (64 KB)
+  float* redb = wsm + 4 * 4096;        // [4][64] bias partials
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, p = lane >> 5, jl = lane & 31;
   const int blk = blockIdx.x;
   MLP_TRACE(A.trace, 0);
@@ -560,9 +561,9 @@ __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
     sb += a1;
   }
   MLP_TRACE(A.trace, 1);
-  // combine the four waves in wave order
-  if (wv > 0) {
-    float* dst = red + (wv - 1) * 4096;
+  // combine the four waves in wave order: every wave parks its 64x64 tile, then wave w sums and stores quadrant w
+  {
+    float* dst = red + wv * 4096;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       dst[(0 * 16 + r) * 64 + lane] = c00[r];
@@ -573,43 +574,32 @@ __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
   }
   sa += __shfl_xor(sa, 32, kWave);
   sb += __shfl_xor(sb, 32, kWave);
-  if (want_bias && wv > 0 && p == 0) {
-    redb[(wv - 1) * 64 + jl] = sa;
-    redb[(wv - 1) * 64 + 32 + jl] = sb;
+  if (want_bias && p == 0) {
+    redb[wv * 64 + jl] = sa;
+    redb[wv * 64 + 32 + jl] = sb;
   }
   __syncthreads();
   MLP_TRACE(A.trace, 2);
-  if (wv != 0) return;
-  for (int w = 0; w < 3; ++w) {
-    const float* src = red + w * 4096;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      c00[r] += src[(0 * 16 + r) * 64 + lane];
-      c01[r] += src[(1 * 16 + r) * 64 + lane];
-      c10[r] += src[(2 * 16 + r) * 64 + lane];
-      c11[r] += src[(3 * 16 + r) * 64 + lane];
-    }
-    if (want_bias && p == 0) {
-      sa += redb[w * 64 + jl];
-      sb += redb[w * 64 + 32 + jl];
-    }
-  }
-  float* pw = part + A.off_w[l];
+  f32x16 q;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int ra = m0 + acc_row32(r, p), rb = ra + 32;
-    if (ra < Ld.N) {
-      if (ka < Ld.ldw) stg_f32(pw + static_cast<int64_t>(ra) * Ld.ldw + ka, vka ? c00[r] : 0.f);
-      if (kb < Ld.ldw) stg_f32(pw + static_cast<int64_t>(ra) * Ld.ldw + kb, vkb ? c01[r] : 0.f);
-    }
-    if (rb < Ld.N) {
-      if (ka < Ld.ldw) stg_f32(pw + static_cast<int64_t>(rb) * Ld.ldw + ka, vka ? c10[r] : 0.f);
-      if (kb < Ld.ldw) stg_f32(pw + static_cast<int64_t>(rb) * Ld.ldw + kb, vkb ? c11[r] : 0.f);
-    }
+    const int o = (wv * 16 + r) * 64 + lane;
+    q[r] = ((red[o] + red[4096 + o]) + red[2 * 4096 + o]) + red[3 * 4096 + o];
   }
-  if (want_bias && p == 0) {
-    if (va) stg_f32(part + A.off_b[l] + ma, sa);
-    if (vb) stg_f32(part + A.off_b[l] + mb, sb);
+  float* pw = part + A.off_w[l];
+  const int rowbase = m0 + 32 * (wv >> 1);
+  const int kq = (wv & 1) ? kb : ka;
+  const bool vkq = (wv & 1) ? vkb : vka;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = rowbase + acc_row32(r, p);
+    if (row < Ld.N && kq < Ld.ldw) stg_f32(pw + static_cast<int64_t>(row) * Ld.ldw + kq, vkq ? q[r] : 0.f);
+  }
+  if (want_bias && wv == 0 && p == 0) {
+    const float ta = ((redb[jl] + redb[64 + jl]) + redb[128 + jl]) + redb[192 + jl];
+    const float tb = ((redb[32 + jl] + redb[96 + jl]) + redb[160 + jl]) + redb[224 + jl];
+    if (va) stg_f32(part + A.off_b[l] + ma, ta);
+    if (vb) stg_f32(part + A.off_b[l] + mb, tb);
   }
   MLP_TRACE(A.trace, 3);
   if (A.trace && threadIdx.x == 0) A.trace[blockIdx.x * 16ull + 14] = static_cast<unsigned long long>(l);
@@ -789,7 +779,10 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, i
     }
     a.off_o = P.off_o; a.slab = P.slab; a.x = x; a.ldx = ld_x; a.w_out = m->w_out; a.g = g; a.part = workspace;
     a.trace = g_mlp_trace ? g_mlp_trace + 16ull * 8192 : nullptr;
-    k_mlp_wgrad<<<dim3(P.blk0[m->n_layers + 1]), dim3(kTW), 0, s>>>(a);
+    constexpr int kWgLds = (4 * 4096 + 256) * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kWgLds);
+    k_mlp_wgrad<<<dim3(P.blk0[m->n_layers + 1]), dim3(kTW), kWgLds, s>>>(a);
     const int st = launch_status();
     if (st != DCTR_OK) return st;
   }

@@ -43,6 +43,7 @@ struct UpdArgs {
   int64_t ldgw;
   int64_t ldg, ldo, lds_;
   int32_t n_units, B, log2p, bbits;
+  int32_t gt;            // entries per tile (<= lane groups per workgroup; sized by the host so that 7 WGs fit a CU)
   float lr, eps;
   // optional extra role (last block): d loss / d Linear.weight = X_dense^T g_wide  (basemodel.py:88-90)
   const float* X;
@@ -92,7 +93,8 @@ __device__ __forceinline__ void apply_strip(const dctr_field_t& fd, int64_t off,
 
 template <int VEC, int LPR, int OPT>
 __global__ __launch_bounds__(kThreads) void k_embed_update(UpdArgs A) {
-  constexpr int G = kThreads / LPR;  // lane groups per workgroup = entries per tile
+  constexpr int GMAX = kThreads / LPR;  // lane groups per workgroup
+  const int G = A.gt < GMAX ? A.gt : GMAX;  // entries per tile
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int n_sh;
   __shared__ int carry_id;
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_update(UpdArgs A) {
 
   for (int t0 = 0; t0 < n; t0 += G) {
     const int i = t0 + grp;
-    const bool have = i < n;
+    const bool have = i < n && grp < G;
     const uint32_t key = have ? keys[i] : 0u;
     const int b = static_cast<int>(key & bmask);
     const int idq = static_cast<int>(key >> A.bbits);           // id / P
@@ -527,7 +529,20 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
   int cap = 2;
   while (cap < B) cap <<= 1;
   const int g = kThreads / lpr;
-  const size_t lds = static_cast<size_t>(cap) * 4 + (static_cast<size_t>(g) * lpr * vec + 3 * g + lpr * vec + 4) * 4;
+  auto lds_for = [&](int gt) {
+    return static_cast<size_t>(cap) * 4 + (static_cast<size_t>(gt) * lpr * vec + 3 * gt + lpr * vec + 4) * 4;
+  };
+  // 160 KB of LDS / 7 workgroups: with all of a launch's workgroups resident at once the kernel is one round of
+  // ~15 us workgroups instead of two.  Shrink the tile (never below half the lane groups) if that gets us there.
+  int gt = g;
+  constexpr size_t kBudget = 160 * 1024 / 7 - 64;
+  if (lds_for(g) > kBudget) {
+    int t = g;
+    while (t - 8 >= g / 2 && lds_for(t) > kBudget) t -= 8;
+    if (lds_for(t) <= kBudget) gt = t;
+  }
+  a.gt = gt;
+  const size_t lds = lds_for(gt);
   if (lds > 150 * 1024) return DCTR_ENOSUP;
   const int units8 = (n_units + 7) / 8 * 8;
   const dim3 grid((static_cast<unsigned>(units8) << log2p) + (g_wdense ? static_cast<unsigned>(plan->n_wdense) : 0u)), block(kThreads);
