@@ -366,11 +366,11 @@ __global__ __launch_bounds__(kThreads) void k_embed_update(UpdArgs A) {
         if (OPT == DCTR_UPD_ADAGRAD) sw = ldg_f32(fw.state + row);
       }
     }
-    if (lane_on) {
+    if (lane_on && grp < G) {
 #pragma unroll
       for (int k = 0; k < VEC; ++k) gbuf[grp * (LPR * VEC) + e0 + k] = g.v[k];
     }
-    if (gl == 0) gwbuf[grp] = gw;
+    if (gl == 0 && grp < G) gwbuf[grp] = gw;
     if (t0 == 0) DCTR_TRACE(3);
     __syncthreads();
     if (t0 == 0) DCTR_TRACE(4);
