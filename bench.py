@@ -242,7 +242,8 @@ def main():
             graphed = None
             torch.cuda.synchronize()
     if parallel is not None and not args.no_graph:
-        parallel.use_graphs = True       # segments re-capture on the next step
+        # "full" (collectives captured too) is opt-in: DCTR_SHARD_GRAPH=full
+        parallel.use_graphs = "full" if os.environ.get("DCTR_SHARD_GRAPH", "segments") == "full" else True
         parallel._shape = None
         graphed = "segments"
     for _ in range(max(0, args.warmup - n_eager)):

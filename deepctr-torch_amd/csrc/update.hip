@@ -91,8 +91,9 @@ __device__ __forceinline__ void apply_strip(const dctr_field_t& fd, int64_t off,
   }
 }
 
+// (7 workgroups of 4 waves per CU: <= 72 VGPRs)
 template <int VEC, int LPR, int OPT>
-__global__ __launch_bounds__(kThreads) void k_embed_update(UpdArgs A) {
+__global__ __launch_bounds__(kThreads, 7) void k_embed_update(UpdArgs A) {
   constexpr int GMAX = kThreads / LPR;  // lane groups per workgroup
   const int G = A.gt < GMAX ? A.gt : GMAX;  // entries per tile
   extern __shared__ __align__(16) unsigned char smem[];

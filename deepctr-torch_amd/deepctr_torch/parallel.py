@@ -389,7 +389,8 @@ class ShardedTrainer(object):
         self.slab = st["slab"]
         self.layout = ShardLayout(self.plan, self.world, self.rank)
         self.ops = ops if ops is not None else HipShardOps(model, self.layout)
-        self.use_graphs = bool(use_graphs)
+        self.use_graphs = use_graphs if use_graphs == "full" else bool(use_graphs)
+        self._full, self._full_primed, self._full_out = None, 0, None
         self._shape = None
         self._leaves = None
         self.plan.sharder = self
@@ -420,7 +421,7 @@ class ShardedTrainer(object):
         self._recv = torch.empty((lay.world * B, lay.ldc), dtype=torch.float32, device=dev)
         self._grads_all = torch.empty((lay.world * B, lay.ldc), dtype=torch.float32, device=dev)
         self._ids_t = None
-        g = self.use_graphs and xb.is_cuda
+        g = bool(self.use_graphs) and self.use_graphs != "full" and xb.is_cuda
         self._segA = _Segment(lambda: self.ops.pack_ids(self._x), g)
         self._segB = _Segment(lambda: self.ops.gather(self._ids_all.view(lay.world * B, lay.n_slots)), g)
         self._segC = _Segment(self._compute, g)
@@ -449,14 +450,46 @@ class ShardedTrainer(object):
                                      g_wd if g_wide is not None else None)
         return send, loss.detach(), y_pred
 
+    def _body(self):
+        """Everything between the input copies and the return: segments + collectives (eager calls here)."""
+        lay = self.layout
+        B = self._x.shape[0]
+        ids_send = self.ops.pack_ids(self._x)
+        dist.all_to_all_single(self._ids_all, ids_send, group=self.group)
+        chunks, self._ids_t = self.ops.gather(self._ids_all.view(lay.world * B, lay.n_slots))
+        dist.all_to_all_single(self._recv, chunks, group=self.group)
+        send, loss, y_pred = self._compute()
+        dist.all_to_all_single(self._grads_all, send, group=self.group)
+        work = dist.all_reduce(self.slab.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.ops.update(self._grads_all, self._ids_t)
+        work.wait()
+        self.slab.step(*self.state["mode"])
+        return loss, y_pred
+
     def train_step(self, xb, yb):
         """One optimizer step on the gradient of the loss summed over every rank's batch."""
         if not self.slab.intact():
             raise RuntimeError("a dense parameter was re-allocated; build a new ShardedTrainer")
         if self._shape != (tuple(xb.shape), tuple(yb.shape)):
             self._build(xb, yb)
+            self._full, self._full_primed = None, 0
         self._x.copy_(xb)
         self._y.copy_(yb)
+        if self.use_graphs == "full" and xb.is_cuda:
+            # EXPERIMENTAL: the whole step, RCCL collectives included, as ONE hipGraph (one launch per step)
+            if self._full_primed < 2:
+                self._full_primed += 1
+                loss, y_pred = self._body()
+                return loss, loss.reshape(1), y_pred
+            if self._full is None:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._full_out = self._body()
+                self._full = g
+            self._full.replay()
+            loss, y_pred = self._full_out
+            return loss, loss.reshape(1), y_pred
         ids_send = self._segA()
         dist.all_to_all_single(self._ids_all, ids_send, group=self.group)            # 1: ids -> owners
         chunks, self._ids_t = self._segB()
