@@ -242,8 +242,7 @@ def main():
             graphed = None
             torch.cuda.synchronize()
     if parallel is not None and not args.no_graph:
-        # "full" (collectives captured too) is opt-in: DCTR_SHARD_GRAPH=full
-        parallel.use_graphs = "full" if os.environ.get("DCTR_SHARD_GRAPH", "segments") == "full" else True
+        parallel.use_graphs = True       # segments re-capture on the next step
         parallel._shape = None
         graphed = "segments"
     for _ in range(max(0, args.warmup - n_eager)):

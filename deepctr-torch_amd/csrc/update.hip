@@ -125,10 +125,10 @@ __global__ __launch_bounds__(kThreads, 7) void k_embed_update(UpdArgs A) {
     return;
   }
 
-  // XCD-aware decode: block b runs on XCD b % 8 (observed); keep all partitions of a unit on one XCD
-  // so the unit's id row is fetched into one L2 only.
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int u = (j >> A.log2p) * 8 + xcd, p = j & (P - 1);
+  // Work item w = (unit, partition) in plain launch order: consecutive workgroups go to consecutive XCDs, so every
+  // XCD gets the same number of working workgroups.  (Keeping a unit's partitions on one XCD -- to fetch its id row
+  // into one L2 only -- left XCDs 0-1 with 4 units and the others with 3 at F = 26: a second round on two XCDs.)
+  const int u = static_cast<int>(blockIdx.x) >> A.log2p, p = static_cast<int>(blockIdx.x) & (P - 1);
   if (u >= A.n_units) return;
 
   const int32_t* un = A.units + 4 * u;
@@ -545,8 +545,7 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
   a.gt = gt;
   const size_t lds = lds_for(gt);
   if (lds > 150 * 1024) return DCTR_ENOSUP;
-  const int units8 = (n_units + 7) / 8 * 8;
-  const dim3 grid((static_cast<unsigned>(units8) << log2p) + (g_wdense ? static_cast<unsigned>(plan->n_wdense) : 0u)), block(kThreads);
+  const dim3 grid((static_cast<unsigned>(n_units) << log2p) + (g_wdense ? static_cast<unsigned>(plan->n_wdense) : 0u)), block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
 
 #define DCTR_UPD_LAUNCH(VEC_, LPR_)                                                                   \

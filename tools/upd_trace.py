@@ -82,7 +82,7 @@ def main():
         res["upd_log2p_%d_rotating" % lp] = timed(upd, True)
     # phase trace at the default partitioning, rotating batches
     for lp in (-1, 7):
-        nwg = (32 << (6 if lp < 0 else lp)) + 16
+        nwg = (26 << (6 if lp < 0 else lp)) + 16
         buf = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
         lib.dctr_dbg_update_trace(ctypes.c_void_p(buf.data_ptr()), lp)
         for j in range(8, 12):
