@@ -225,11 +225,18 @@ def main():
         return X[j * B:(j + 1) * B], y[j * B:(j + 1) * B]
 
     step_fn = (lambda xb, yb: parallel.train_step(xb, yb)) if parallel else (lambda xb, yb: model._train_step(xb, yb))
+
+    def run(k):
+        """Step on batch k.  The sharded trainer is told the next batch: its ids travel with this step's gradients."""
+        if parallel is not None:
+            return parallel.train_step(*batch(k), next_xb=batch(k + 1)[0])
+        return step_fn(*batch(k))
+
     use_graph = (not args.no_graph) and parallel is None
     n_eager = min(3, args.warmup) if not args.no_graph else args.warmup
     i = 0
     for _ in range(n_eager):
-        step_fn(*batch(i))
+        run(i)
         i += 1
     graphed = None
     if use_graph:
@@ -246,7 +253,7 @@ def main():
         parallel._shape = None
         graphed = "segments"
     for _ in range(max(0, args.warmup - n_eager)):
-        step_fn(*batch(i))
+        run(i)
         i += 1
 
     if use_graph and graphed is not None and graphed != "segments":
@@ -257,7 +264,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step_fn(*batch(i))
+        out = run(i)
         i += 1
     if use_graph and graphed is not None and graphed != "segments":
         tail = graphed.flush()           # K % steps_per_graph leftover steps run eagerly, inside the timed region

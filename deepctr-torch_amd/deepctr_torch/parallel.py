@@ -194,9 +194,11 @@ class ShardLayout(object):
     """Who owns what, and how a chunk row looks.
 
     Unit ``u`` (one id column with its deep + wide table, ``plan.units``) is owned by rank ``u % N`` and sits in slot
-    ``u // N`` of that owner's chunk.  A chunk row = ``[slot 0 | slot 1 | ... | pad to 4 | wide | pad to 4]`` floats;
-    every rank uses ``n_slots = ceil(F / N)`` slots so that all all-to-alls have equal splits (an owner with fewer
-    units leaves its last slot unused)."""
+    ``u // N`` of that owner's chunk.  A chunk row is
+        ``[slot 0 | slot 1 | ... | pad to 4 | wide, pad to 4 | n_slots id columns of the NEXT batch | pad to 4]``
+    floats; every rank uses ``n_slots = ceil(F / N)`` slots so that all all-to-alls have equal splits (an owner with
+    fewer units leaves its last slot unused).  The id columns ride along with the row gradients: the ids the owners
+    need for step k+1 travel in step k's gradient all-to-all, which removes one collective per step."""
 
     def __init__(self, plan, world, rank):
         if not plan.unit_path or plan.emb_dim <= 0 or not plan.deep:
@@ -212,7 +214,8 @@ class ShardLayout(object):
         self.has_wide = bool(has_wide and has_wide[0])
         self.n_slots = (self.F + self.world - 1) // self.world
         self.wide_col = (self.n_slots * self.D + 3) // 4 * 4
-        self.ldc = self.wide_col + 4
+        self.ids_col = self.wide_col + 4
+        self.ldc = (self.ids_col + self.n_slots + 3) // 4 * 4
         self.owned = [u for u in range(self.F) if u % self.world == self.rank]
         # X columns every destination needs from a sender: [N * n_slots] (unused slots repeat column 0)
         cols = []
@@ -220,6 +223,11 @@ class ShardLayout(object):
             mine = [plan.units[u][2] for u in range(self.F) if u % self.world == q]
             cols += mine + [plan.units[0][2]] * (self.n_slots - len(mine))
         self.id_cols = cols
+
+    def pack_ids(self, X, idx):
+        """[N][B][n_slots] float ids: what each owner needs of this rank's B samples (``idx`` = id_cols on X's device)."""
+        B = X.shape[0]
+        return X.index_select(1, idx).view(B, self.world, self.n_slots).permute(1, 0, 2)
 
 
 class HipShardOps(object):
@@ -249,15 +257,15 @@ class HipShardOps(object):
         return None if t is None else ctypes.c_void_p(t.data_ptr() + 4 * off)
 
     def pack_ids(self, X):
-        """[N][B][n_slots] float ids: what each owner needs of this rank's B samples."""
+        """[N][B][n_slots] float ids (a permuted view): what each owner needs of this rank's B samples."""
         lay = self.lay
         if self._idx is None or self._idx.device != X.device:
             self._idx = torch.tensor(lay.id_cols, dtype=torch.long, device=X.device)
-        B = X.shape[0]
-        return X.index_select(1, self._idx).view(B, lay.world, lay.n_slots).permute(1, 0, 2).contiguous()
+        return lay.pack_ids(X, self._idx)
 
     def gather(self, ids_all):
-        """ids_all [N*B, n_slots] -> (chunks [N*B, ldc] = rows of MY tables for every global sample, ids_t)."""
+        """ids_all [N*B, n_slots] (any row stride) -> (chunks [N*B, ldc] = rows of MY tables for every global sample,
+        ids_t)."""
         L, lay, sub = self.L, self.lay, self.sub
         NB, dev = ids_all.shape[0], ids_all.device
         chunks = torch.empty((NB, lay.ldc), dtype=torch.float32, device=dev)
@@ -328,7 +336,7 @@ class HipShardOps(object):
 
 class _Segment(object):
     """A piece of the step between two collectives: run eagerly, or captured once into a hipGraph and replayed
-    (collectives stay OUTSIDE the graphs: the host issues 5 graph launches + 4 collectives per step instead of
+    (collectives stay OUTSIDE the graphs: the host issues 4 graph launches + 3 collectives per step instead of
     ~40 kernel launches through Python)."""
 
     def __init__(self, fn, use_graph):
@@ -357,17 +365,20 @@ class ShardedTrainer(object):
     """Multi-GPU training of a fused-step model (``BaseModel._fused_step_state``): one process per GPU.
 
       tables   sharded by table (rank u % N owns unit u: its deep table, wide table and their Adagrad state);
-               forward = ids all-to-all + owner-side gather + rows all-to-all, backward = row-gradient all-to-all
-               (the sparse reduce-scatter) + the owner's deterministic fused update.  Each row is updated once,
-               by its owner, from the gradients of ALL N*B samples -- the same step as one GPU on the global batch.
+               forward = owner-side gather + rows all-to-all, backward = row-gradient all-to-all (the sparse
+               reduce-scatter, which also carries the NEXT batch's ids to the owners) + the owner's deterministic
+               fused update.  Each row is updated once, by its owner, from the gradients of ALL N*B samples -- the
+               same step as one GPU on the global batch.
       dense    replicated; ONE all-reduce(SUM) of the flat gradient slab (SUM: the loss is a sum over the global
                batch, basemodel.py:209,254), overlapped with the sparse update; every rank then applies the same
                fused dense optimizer step, so replicas stay bit-identical.
 
-    The step is five compute segments separated by the four collectives; with ``use_graphs`` each segment is one
-    hipGraph (fixed batch shape), the collectives are issued by the host between the replays.  (Capturing the
-    RCCL collectives inside one whole-step graph was tried on MI355X / ROCm 7.2 / RCCL 2.26 and deadlocks at the
-    first replay, so collectives stay outside the graphs.)
+    Per step: ``[gather] -a2a-> [assemble, tower, head, tower backward, assemble^T] -a2a-> [update] || all-reduce ->
+    [dense step]``: four compute segments and three collectives (an extra ids all-to-all only when the caller did
+    not announce the batch in the previous step's ``next_xb``).  With ``use_graphs`` each segment is one hipGraph
+    (fixed batch shape), the collectives are issued by the host between the replays.  (Capturing the RCCL
+    collectives inside one whole-step graph was tried on MI355X / ROCm 7.2 / RCCL 2.26 and deadlocks at the first
+    replay, so collectives stay outside the graphs.)
 
     Only the owner's copy of a table is current during training; ``gather_tables()`` broadcasts the owners' copies
     (and optimizer state) so that ``state_dict()`` is complete on every rank -- call it before saving / predicting."""
@@ -413,25 +424,28 @@ class ShardedTrainer(object):
         o = out if (full or not plan.has_lookup) else out[:, :plan.width]
         return (o, wide if wide is not None else X.new_zeros((B,)), fm if fm is not None else X.new_zeros((B,)))
 
-    # ---- the five segments ------------------------------------------------------------------------------------------
+    # ---- the segments -----------------------------------------------------------------------------------------------
     def _build(self, xb, yb):
         lay, dev, B = self.layout, xb.device, xb.shape[0]
         self._shape = (tuple(xb.shape), tuple(yb.shape))
         self._x, self._y = torch.empty_like(xb), torch.empty_like(yb)
-        self._ids_all = torch.empty((lay.world, B, lay.n_slots), dtype=torch.float32, device=dev)
+        self._ids_next = torch.zeros((lay.world, B, lay.n_slots), dtype=torch.float32, device=dev)
+        self._ids_tmp = torch.empty((lay.world, B, lay.n_slots), dtype=torch.float32, device=dev)
         self._recv = torch.empty((lay.world * B, lay.ldc), dtype=torch.float32, device=dev)
-        self._grads_all = torch.empty((lay.world * B, lay.ldc), dtype=torch.float32, device=dev)
+        # what arrives in the gradient all-to-all: row gradients of step k AND the ids of step k+1
+        self._grads_all = torch.zeros((lay.world * B, lay.ldc), dtype=torch.float32, device=dev)
+        self._ids_view = self._grads_all[:, lay.ids_col:lay.ids_col + lay.n_slots]
+        self._announced = None          # identity of the batch whose ids already sit in _ids_view
         self._ids_t = None
         g = bool(self.use_graphs) and xb.is_cuda
-        self._segA = _Segment(lambda: self.ops.pack_ids(self._x), g)
-        self._segB = _Segment(lambda: self.ops.gather(self._ids_all.view(lay.world * B, lay.n_slots)), g)
+        self._segB = _Segment(lambda: self.ops.gather(self._ids_view), g)
         self._segC = _Segment(self._compute, g)
         self._segD = _Segment(lambda: self.ops.update(self._grads_all, self._ids_t), g)
         self._segE = _Segment(lambda: self.slab.step(*self.state["mode"]), g)
 
     def _compute(self):
         from ._hip import mlp as _mlp
-        model, st, slab, plan = self.model, self.state, self.slab, self.plan
+        model, st, slab, plan, lay = self.model, self.state, self.slab, self.plan, self.layout
         model._grad_sink = slab
         self._leaves = None
         try:
@@ -449,356 +463,38 @@ class ShardedTrainer(object):
         g_fm = lv["fm"].grad if lv["fm"] is not None else None
         send = self.ops.assemble_bwd(self._x, lv["out"].grad, g_wide, g_fm, lv["out"].detach(), lv["fm_s"],
                                      g_wd if g_wide is not None else None)
-        return send, loss.detach(), y_pred
-
-    def train_step(self, xb, yb):
-        from ._hip import lib as L
-        from ._hip.ops import _ptr
-        model, plan = self.model, self.plan
-        y_pred = model(xb).squeeze()
-        model.optim.zero_grad()
-        self.bucket.attach()
-        if isinstance(model.loss_func, list):
-            loss = sum([model.loss_func[i](y_pred[:, i], yb[:, i], reduction='sum') for i in range(model.num_tasks)])
-        else:
-            loss = model.loss_func(y_pred, yb.squeeze(), reduction='sum')
-        total_loss = loss + model.get_regularization_loss() + model.aux_loss
-        self._stash = None
-        total_loss.backward()
-        work = self.bucket.all_reduce(self.group, async_op=True)      # overlaps with the embedding exchange
-
-        st = self._stash
-        self._stash = None
-        if st is not None:
-            X = st["X"]
-            G = fold_fm(st["g_out"], plan.emb_width, st["out"], st["fm_s"], st["g_fm"], plan.emb_dim) \
-                if plan.deep else None
-            gathered = self.payload.gather(self.payload.pack(X, G, st["g_wide"]), self.group)
-            X_all, G_all, gw_all = self.payload.views(gathered)
-            NB = gathered.shape[0]
-            lib = L.lib()
-            stream = L.stream_handle(X.device)
-            kind = plan.update[0]
-            if kind == "dense":
-                plan.ensure_gacc()
-                plan.prepare_dense_grads()
-                opt, lr, eps = L.UPD_ACCUM, 0.0, 0.0
-            elif kind in ("sgd", "sgd2"):
-                opt, lr, eps = L.UPD_SGD, float(plan.update[1]), 0.0
-            else:
-                opt, lr, eps = L.UPD_ADAGRAD, float(plan.update[1]), float(plan.update[2])
-            cplan = plan.bind(X.device)
-            if not plan.update_kernel_ok(NB):
-                raise RuntimeError("global batch %d is beyond the deterministic update kernel" % NB)
-            ids_t = torch.empty((len(plan.units), NB), dtype=torch.int32, device=X.device)
-            L.check(lib.dctr_embed_ids(plan.units_ptr(), len(plan.units), _ptr(X_all), gathered.stride(0), NB,
-                                       _ptr(ids_t), stream), "dctr_embed_ids")
-            L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t), NB,
-                                          _ptr(G_all) if plan.deep else None, gathered.stride(0), None, 0, None, 0,
-                                          None, _ptr(gw_all) if plan.wide else None, 1, opt, lr, eps, None, 0, None, stream),
-                    "dctr_embed_update(global)")
-        work.wait()
-        model.optim.step()
-        return loss.detach(), total_loss.detach(), y_pred.detach()
-
-
-# =====================================================================================================================
-# Table-sharded training (the scalable path): embedding tables sharded by table across the GPUs of one node, the
-# dense tower data-parallel.  SURVEY.md 8(e) option S.
-# =====================================================================================================================
-class ShardLayout(object):
-    """Who owns what, and how a chunk row looks.
-
-    Unit ``u`` (one id column with its deep + wide table, ``plan.units``) is owned by rank ``u % N`` and sits in slot
-    ``u // N`` of that owner's chunk.  A chunk row = ``[slot 0 | slot 1 | ... | pad to 4 | wide | pad to 4]`` floats;
-    every rank uses ``n_slots = ceil(F / N)`` slots so that all all-to-alls have equal splits (an owner with fewer
-    units leaves its last slot unused)."""
-
-    def __init__(self, plan, world, rank):
-        if not plan.unit_path or plan.emb_dim <= 0 or not plan.deep:
-            raise NotImplementedError("table-sharded training needs fixed-length sparse features over distinct "
-                                      "tables that share one embedding_dim (pooled VarLen features: single GPU)")
-        if any(di < 0 for (di, wi, col, _) in plan.units):
-            raise NotImplementedError("every linear sparse feature must also be a DNN feature for the sharded path")
-        has_wide = [wi >= 0 for (di, wi, col, _) in plan.units]
-        if any(has_wide) and not all(has_wide):
-            raise NotImplementedError("linear sparse features must cover all or none of the DNN sparse features")
-        self.world, self.rank = int(world), int(rank)
-        self.F, self.D = len(plan.units), int(plan.emb_dim)
-        self.has_wide = bool(has_wide and has_wide[0])
-        self.n_slots = (self.F + self.world - 1) // self.world
-        self.wide_col = (self.n_slots * self.D + 3) // 4 * 4
-        self.ldc = self.wide_col + 4
-        self.owned = [u for u in range(self.F) if u % self.world == self.rank]
-        # X columns every destination needs from a sender: [N * n_slots] (unused slots repeat column 0)
-        cols = []
-        for q in range(self.world):
-            mine = [plan.units[u][2] for u in range(self.F) if u % self.world == q]
-            cols += mine + [plan.units[0][2]] * (self.n_slots - len(mine))
-        self.id_cols = cols
-
-
-class HipShardOps(object):
-    """The four device steps of the sharded exchange on the C-ABI (embed.hip / update.hip / shard.hip)."""
-
-    def __init__(self, model, layout):
-        from ._hip import lib as L
-        from ._hip.plan import EmbeddingPlan
-        from .inputs import SparseFeat
-        self.L, self.lay = L, layout
-        plan = model.model_plan()
-        self.plan = plan
-        deep_cols = [c for c in model.dnn_feature_columns if isinstance(c, SparseFeat) and not hasattr(c, "maxlen")]
-        by_name = {c.name: c for c in model._linear_feature_columns if isinstance(c, SparseFeat)}
-        mine = [deep_cols[u] for u in layout.owned]
-        fi = {c.name: (j, j + 1) for j, c in enumerate(mine)}
-        wide_cols = [by_name[c.name] for c in mine] if layout.has_wide else []
-        self.sub = EmbeddingPlan(fi, deep_columns=mine, deep_tables=model.embedding_dict, wide_columns=wide_cols,
-                                 wide_tables=model.linear_model.embedding_dict if wide_cols else None,
-                                 wide_dense_weight=None, with_dense=False) if mine else None
-        if self.sub is not None:
-            self.sub.share_update_with(plan)
-        self._idx = None
-
-    def _ptr(self, t, off=0):
-        import ctypes
-        return None if t is None else ctypes.c_void_p(t.data_ptr() + 4 * off)
-
-    def pack_ids(self, X):
-        """[N][B][n_slots] float ids: what each owner needs of this rank's B samples."""
-        lay = self.lay
-        if self._idx is None or self._idx.device != X.device:
-            self._idx = torch.tensor(lay.id_cols, dtype=torch.long, device=X.device)
-        B = X.shape[0]
-        return X.index_select(1, self._idx).view(B, lay.world, lay.n_slots).permute(1, 0, 2).contiguous()
-
-    def gather(self, ids_all):
-        """ids_all [N*B, n_slots] -> (chunks [N*B, ldc] = rows of MY tables for every global sample, ids_t)."""
-        L, lay, sub = self.L, self.lay, self.sub
-        NB, dev = ids_all.shape[0], ids_all.device
-        chunks = torch.empty((NB, lay.ldc), dtype=torch.float32, device=dev)
-        if sub is None:
-            return chunks, None
-        cplan = sub.bind(dev)
-        ids_t = torch.empty((len(sub.units), NB), dtype=torch.int32, device=dev)
-        wide = self._ptr(chunks, lay.wide_col) if lay.has_wide else None
-        L.check(L.lib().dctr_embed_fwd(cplan, self._ptr(ids_all), ids_all.stride(0), NB, self._ptr(chunks), lay.ldc,
-                                       wide, lay.ldc, None, self._ptr(self.plan.err_flag(dev)), sub.units_ptr(),
-                                       len(sub.units), self._ptr(ids_t), None, 0, L.stream_handle(dev)),
-                "dctr_embed_fwd(owned tables, global batch)")
-        return chunks, ids_t
-
-    def assemble_fwd(self, recv, X, want_fm):
-        L, lay, plan = self.L, self.lay, self.plan
-        B, dev = X.shape[0], X.device
-        plan.bind(dev)
-        out = torch.empty((B, plan.ld_out), dtype=torch.float32, device=dev)
-        wide = torch.empty((B,), dtype=torch.float32, device=dev) if plan.has_wide else None
-        fm = torch.empty((B,), dtype=torch.float32, device=dev) if want_fm else None
-        ld_s = (lay.D + 3) // 4 * 4
-        fm_s = torch.empty((B, ld_s), dtype=torch.float32, device=dev) if want_fm else None
-        w = plan.wide_dense_weight
-        L.check(L.lib().dctr_shard_assemble_fwd(
-            self._ptr(recv), lay.ldc, lay.world, B, lay.F, lay.D, lay.wide_col if lay.has_wide else -1, self._ptr(X),
-            X.stride(0), self._ptr(plan._dev["dense"]), len(plan.dense_cols), max(plan.dense_off, 0),
-            self._ptr(plan._dev["wdense"]), self._ptr(w), len(plan.wdense_cols) if w is not None else 0,
-            self._ptr(out), plan.ld_out, self._ptr(wide), self._ptr(fm), self._ptr(fm_s), ld_s,
-            L.stream_handle(dev)), "dctr_shard_assemble_fwd")
-        return out, wide, fm, fm_s
-
-    def assemble_bwd(self, X, g_out, g_wide, g_fm, out, fm_s, g_wdense):
-        L, lay, plan = self.L, self.lay, self.plan
-        B, dev = X.shape[0], X.device
-        send = torch.empty((lay.world * B, lay.ldc), dtype=torch.float32, device=dev)
-        w = plan.wide_dense_weight
-        L.check(L.lib().dctr_shard_assemble_bwd(
-            self._ptr(send), lay.ldc, lay.world, B, lay.F, lay.D, lay.wide_col if lay.has_wide else -1,
-            self._ptr(g_out), g_out.stride(0) if g_out is not None else 0, self._ptr(g_wide), self._ptr(g_fm),
-            self._ptr(out), plan.ld_out, self._ptr(fm_s), fm_s.stride(0) if fm_s is not None else 0, self._ptr(X),
-            X.stride(0), self._ptr(plan._dev["wdense"]), len(plan.wdense_cols) if (w is not None and g_wdense is not None) else 0,
-            self._ptr(g_wdense), L.stream_handle(dev)), "dctr_shard_assemble_bwd")
-        return send
-
-    def update(self, grads_all, ids_t):
-        """grads_all [N*B, ldc]: apply the fused optimizer step to MY tables over the global batch."""
-        L, lay, sub, plan = self.L, self.lay, self.sub, self.plan
-        if sub is None:
-            return
-        NB, dev = grads_all.shape[0], grads_all.device
-        kind = plan.update[0]
-        if kind in ("sgd", "sgd2"):
-            opt, lr, eps = L.UPD_SGD, float(plan.update[1]), 0.0
-        elif kind == "adagrad":
-            opt, lr, eps = L.UPD_ADAGRAD, float(plan.update[1]), float(plan.update[2])
-        else:
-            raise RuntimeError("table-sharded training needs the fused sparse update (compile('sgd' | 'adagrad'), "
-                               "l2_reg_embedding = l2_reg_linear = 0)")
-        cplan = sub.bind(dev)
-        if not sub.update_kernel_ok(NB):
-            raise RuntimeError("global batch %d is beyond the deterministic update kernel" % NB)
-        gw = self._ptr(grads_all, lay.wide_col) if lay.has_wide else None
-        L.check(L.lib().dctr_embed_update(cplan, sub.units_ptr(), len(sub.units), sub.max_vocab, self._ptr(ids_t), NB,
-                                          self._ptr(grads_all), lay.ldc, None, 0, None, 0, None, gw, lay.ldc, opt, lr,
-                                          eps, None, 0, None, L.stream_handle(dev)), "dctr_embed_update(owned tables)")
-
-
-class _Segment(object):
-    """A piece of the step between two collectives: run eagerly, or captured once into a hipGraph and replayed
-    (collectives stay OUTSIDE the graphs: the host issues 5 graph launches + 4 collectives per step instead of
-    ~40 kernel launches through Python)."""
-
-    def __init__(self, fn, use_graph):
-        self.fn, self.use_graph = fn, use_graph
-        self.graph, self.result = None, None
-        self.primed = False
-
-    def __call__(self):
-        if not self.use_graph:
-            return self.fn()
-        if not self.primed:         # first call runs eagerly: descriptor uploads / lazy buffers are not capturable
-            self.primed = True
-            return self.fn()
-        if self.graph is None:
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            # thread-local capture mode: RCCL's watchdog thread keeps polling events while we capture
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                self.result = self.fn()
-            self.graph = g
-        self.graph.replay()
-        return self.result
-
-
-class ShardedTrainer(object):
-    """Multi-GPU training of a fused-step model (``BaseModel._fused_step_state``): one process per GPU.
-
-      tables   sharded by table (rank u % N owns unit u: its deep table, wide table and their Adagrad state);
-               forward = ids all-to-all + owner-side gather + rows all-to-all, backward = row-gradient all-to-all
-               (the sparse reduce-scatter) + the owner's deterministic fused update.  Each row is updated once,
-               by its owner, from the gradients of ALL N*B samples -- the same step as one GPU on the global batch.
-      dense    replicated; ONE all-reduce(SUM) of the flat gradient slab (SUM: the loss is a sum over the global
-               batch, basemodel.py:209,254), overlapped with the sparse update; every rank then applies the same
-               fused dense optimizer step, so replicas stay bit-identical.
-
-    The step is five compute segments separated by the four collectives; with ``use_graphs`` each segment is one
-    hipGraph (fixed batch shape), the collectives are issued by the host between the replays.  (Capturing the
-    RCCL collectives inside one whole-step graph was tried on MI355X / ROCm 7.2 / RCCL 2.26 and deadlocks at the
-    first replay, so collectives stay outside the graphs.)
-
-    Only the owner's copy of a table is current during training; ``gather_tables()`` broadcasts the owners' copies
-    (and optimizer state) so that ``state_dict()`` is complete on every rank -- call it before saving / predicting."""
-
-    def __init__(self, model, process_group=None, ops=None, broadcast_parameters=True, use_graphs=False):
-        if not dist.is_initialized():
-            raise RuntimeError("initialise torch.distributed first (backend 'nccl' = RCCL on ROCm)")
-        self.model, self.group = model, process_group
-        self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
-        self.plan = model.model_plan()
-        if broadcast_parameters:
-            with torch.no_grad():
-                for p in model.parameters():
-                    dist.broadcast(p.data, 0, group=process_group)
-        st = model._fused_step_state()
-        if st is None:
-            raise NotImplementedError(
-                "table-sharded training runs the fused train step: a binary model with a relu DNN tower, "
-                "compile('sgd' | 'adagrad', 'binary_crossentropy'), no L1/L2 regularisers")
-        self.state = st
-        self.slab = st["slab"]
-        self.layout = ShardLayout(self.plan, self.world, self.rank)
-        self.ops = ops if ops is not None else HipShardOps(model, self.layout)
-        self.use_graphs = bool(use_graphs)
-        self._shape = None
-        self._leaves = None
-        self.plan.sharder = self
-
-    def close(self):
-        self.plan.sharder = None
-
-    # ---- called by _ops.embed (from model.logit_parts) in place of the single-GPU lookup ----------------------------
-    def embed(self, X, want_fm, full):
-        plan = self.plan
-        if not torch.is_grad_enabled():
-            raise RuntimeError("a table-sharded model predicts after trainer.gather_tables(); trainer.close()")
-        out, wide, fm, fm_s = self.ops.assemble_fwd(self._recv, X, want_fm)
-        leaves = {"out": out.requires_grad_(), "fm_s": fm_s, "want_fm": bool(want_fm)}
-        leaves["wide"] = wide.requires_grad_() if wide is not None else None
-        leaves["fm"] = fm.requires_grad_() if fm is not None else None
-        self._leaves = leaves
-        B = X.shape[0]
-        o = out if (full or not plan.has_lookup) else out[:, :plan.width]
-        return (o, wide if wide is not None else X.new_zeros((B,)), fm if fm is not None else X.new_zeros((B,)))
-
-    # ---- the five segments ------------------------------------------------------------------------------------------
-    def _build(self, xb, yb):
-        lay, dev, B = self.layout, xb.device, xb.shape[0]
-        self._shape = (tuple(xb.shape), tuple(yb.shape))
-        self._x, self._y = torch.empty_like(xb), torch.empty_like(yb)
-        self._ids_all = torch.empty((lay.world, B, lay.n_slots), dtype=torch.float32, device=dev)
-        self._recv = torch.empty((lay.world * B, lay.ldc), dtype=torch.float32, device=dev)
-        self._grads_all = torch.empty((lay.world * B, lay.ldc), dtype=torch.float32, device=dev)
-        self._ids_t = None
-        g = bool(self.use_graphs) and xb.is_cuda
-        self._segA = _Segment(lambda: self.ops.pack_ids(self._x), g)
-        self._segB = _Segment(lambda: self.ops.gather(self._ids_all.view(lay.world * B, lay.n_slots)), g)
-        self._segC = _Segment(self._compute, g)
-        self._segD = _Segment(lambda: self.ops.update(self._grads_all, self._ids_t), g)
-        self._segE = _Segment(lambda: self.slab.step(*self.state["mode"]), g)
-
-    def _compute(self):
-        from ._hip import mlp as _mlp
-        model, st, slab, plan = self.model, self.state, self.slab, self.plan
-        model._grad_sink = slab
-        self._leaves = None
-        try:
-            parts = model.logit_parts(self._x)
-            loss, y_pred = _mlp.bce_head(parts, model.out.bias, self._y, unit=True,
-                                         g_bias_sink=slab.grad_of(model.out.bias))
-            loss.backward(gradient=st["one"])
-        finally:
-            model._grad_sink = None
-        lv = self._leaves
-        if lv is None:
-            raise RuntimeError("the model's logit_parts() did not go through the fused lookup")
-        g_wd = slab.grad_of(plan.wide_dense_weight) if plan.wide_dense_weight is not None else None
-        g_wide = lv["wide"].grad if lv["wide"] is not None else None
-        g_fm = lv["fm"].grad if lv["fm"] is not None else None
-        send = self.ops.assemble_bwd(self._x, lv["out"].grad, g_wide, g_fm, lv["out"].detach(), lv["fm_s"],
-                                     g_wd if g_wide is not None else None)
-        return send, loss.detach(), y_pred
-
-    def _body(self):
-        """Everything between the input copies and the return: segments + collectives (eager calls here)."""
-        lay = self.layout
         B = self._x.shape[0]
-        ids_send = self.ops.pack_ids(self._x)
-        dist.all_to_all_single(self._ids_all, ids_send, group=self.group)
-        chunks, self._ids_t = self.ops.gather(self._ids_all.view(lay.world * B, lay.n_slots))
-        dist.all_to_all_single(self._recv, chunks, group=self.group)
-        send, loss, y_pred = self._compute()
-        dist.all_to_all_single(self._grads_all, send, group=self.group)
-        work = dist.all_reduce(self.slab.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self.ops.update(self._grads_all, self._ids_t)
-        work.wait()
-        self.slab.step(*self.state["mode"])
-        return loss, y_pred
+        send.view(lay.world, B, lay.ldc)[:, :, lay.ids_col:lay.ids_col + lay.n_slots].copy_(self._ids_next)
+        return send, loss.detach(), y_pred
 
-    def train_step(self, xb, yb):
-        """One optimizer step on the gradient of the loss summed over every rank's batch."""
+    def train_step(self, xb, yb, next_xb=None):
+        """One optimizer step on the gradient of the loss summed over every rank's batch.  ``next_xb`` (optional):
+        the batch of the NEXT call -- its ids are shipped to the owners together with this step's row gradients,
+        which saves that step's ids all-to-all.  Every rank must announce (or not) consistently."""
         if not self.slab.intact():
             raise RuntimeError("a dense parameter was re-allocated; build a new ShardedTrainer")
         if self._shape != (tuple(xb.shape), tuple(yb.shape)):
             self._build(xb, yb)
+        lay, B = self.layout, xb.shape[0]
         self._x.copy_(xb)
         self._y.copy_(yb)
-        ids_send = self._segA()
-        dist.all_to_all_single(self._ids_all, ids_send, group=self.group)            # 1: ids -> owners
+        key = (xb.data_ptr(), xb._version)
+        if self._announced != key:                       # ids not here yet: the explicit exchange
+            self._ids_tmp.copy_(self.ops.pack_ids(self._x))
+            ids_all = torch.empty_like(self._ids_tmp)
+            dist.all_to_all_single(ids_all, self._ids_tmp, group=self.group)
+            self._ids_view.copy_(ids_all.view(lay.world * B, lay.n_slots))
+        if next_xb is not None and tuple(next_xb.shape) == tuple(xb.shape):
+            self._ids_next.copy_(self.ops.pack_ids(next_xb))
+            self._announced = (next_xb.data_ptr(), next_xb._version)
+        else:
+            self._announced = None
         chunks, self._ids_t = self._segB()
-        dist.all_to_all_single(self._recv, chunks, group=self.group)                 # 2: rows -> samples' ranks
+        dist.all_to_all_single(self._recv, chunks, group=self.group)                 # rows -> samples' ranks
         send, loss, y_pred = self._segC()
-        dist.all_to_all_single(self._grads_all, send, group=self.group)              # 3: row gradients -> owners
-        work = dist.all_reduce(self.slab.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)  # 4: dense
-        self._segD()                                                                  # overlaps with 4
+        dist.all_to_all_single(self._grads_all, send, group=self.group)              # row gradients (+ next ids)
+        work = dist.all_reduce(self.slab.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._segD()                                                                  # overlaps with the all-reduce
         work.wait()
         self._segE()
         return loss, loss.reshape(1), y_pred

@@ -13,10 +13,7 @@ class TorchShardOps(object):
             self.fields.append((plan.deep[di].param, plan.wide[wi].param if wi >= 0 else None))
 
     def pack_ids(self, X):
-        lay = self.lay
-        idx = torch.tensor(lay.id_cols, dtype=torch.long)
-        B = X.shape[0]
-        return X.index_select(1, idx).view(B, lay.world, lay.n_slots).permute(1, 0, 2).contiguous()
+        return self.lay.pack_ids(X, torch.tensor(self.lay.id_cols, dtype=torch.long))
 
     def gather(self, ids_all):
         lay = self.lay

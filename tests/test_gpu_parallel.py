@@ -75,9 +75,13 @@ def test_sharded_trainer_one_rank_matches_single_gpu_and_reference(one_rank_grou
         tr = ShardedTrainer(m, use_graphs=graphs) if use_trainer else None
         losses = []
         steps = list(zip(g["extra"]["X_steps"], g["extra"]["y_steps"]))
-        for Xb, yb in steps:
-            xb, yb = torch.from_numpy(Xb).to(DEV), torch.from_numpy(yb).to(DEV)
-            loss = (tr.train_step(xb, yb) if tr else m._train_step(xb, yb))[0]
+        dev_steps = [(torch.from_numpy(Xb).to(DEV), torch.from_numpy(yb).to(DEV)) for Xb, yb in steps]
+        for k, (xb, yb) in enumerate(dev_steps):
+            if tr:   # announce the next batch on the first step only: both id routes are exercised
+                nxt = dev_steps[k + 1][0] if k == 0 else None
+                loss = tr.train_step(xb, yb, next_xb=nxt)[0]
+            else:
+                loss = m._train_step(xb, yb)[0]
             losses.append(loss.item())
         if tr:
             tr.gather_tables()

@@ -75,9 +75,12 @@ def _worker(rank, world, port, opt_name, out_dir):
         lay = ShardLayout(m.model_plan(), world, rank)
         tr = ShardedTrainer(m, ops=TorchShardOps(m, lay))
         assert tr.layout.n_slots == (F_ + world - 1) // world
-        for step in range(3):
-            Xg, yg = _batch(step, world)
-            tr.train_step(Xg[rank * B_:(rank + 1) * B_], yg[rank * B_:(rank + 1) * B_])
+        batches = [_batch(step, world) for step in range(4)]
+        mine = [(Xg[rank * B_:(rank + 1) * B_].contiguous(), yg[rank * B_:(rank + 1) * B_].contiguous()) for Xg, yg in batches]
+        for step in range(4):
+            # steps 0 -> 1 and 2 -> 3 announce the next batch (ids ride in the gradient all-to-all); step 2 does not
+            nxt = mine[step + 1][0] if step in (0, 2) else None
+            tr.train_step(mine[step][0], mine[step][1], next_xb=nxt)
         tr.gather_tables()
         tr.close()
         torch.save({k: v.detach().clone() for k, v in m.state_dict().items()}, os.path.join(out_dir, "rank%d.pt" % rank))
@@ -105,7 +108,7 @@ def test_sharded_training_equals_single_process_on_the_global_batch(tmp_path, op
     ref = DeepFMPort(F_, V_, D_, ND_, hidden=(16, 8))
     ref.load_reference_state({k: v.numpy() for k, v in init.items()}, ["C%d" % i for i in range(F_)])
     opt = (torch.optim.SGD(ref.parameters(), lr=0.01) if opt_name == "sgd" else torch.optim.Adagrad(ref.parameters()))
-    for step in range(3):
+    for step in range(4):
         Xg, yg = _batch(step, world)
         train_step(ref, opt, Xg, yg)
     got = ranks[0]
@@ -129,7 +132,7 @@ def test_shard_layout():
     m = _model()
     plan = m.model_plan()
     lay = ShardLayout(plan, 8, 3)
-    assert lay.F == 5 and lay.n_slots == 1 and lay.owned == [3] and lay.wide_col == 8 and lay.ldc == 12
+    assert lay.F == 5 and lay.n_slots == 1 and lay.owned == [3] and lay.wide_col == 8 and lay.ids_col == 12 and lay.ldc == 16
     lay = ShardLayout(plan, 2, 1)
-    assert lay.owned == [1, 3] and lay.n_slots == 3 and lay.wide_col == 24 and lay.ldc == 28
+    assert lay.owned == [1, 3] and lay.n_slots == 3 and lay.wide_col == 24 and lay.ids_col == 28 and lay.ldc == 32
     assert len(lay.id_cols) == 2 * 3 and lay.id_cols[:3] == [0, 2, 4] and lay.id_cols[3:5] == [1, 3]
