@@ -315,3 +315,29 @@ def test_graphed_train_step_equals_eager(double_buffer, spg):
         assert la == lb
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_fit_replays_graphs_for_full_batches_and_matches_eager_fit(monkeypatch):
+    """fit(): full-size batches replay the captured step, the ragged last batch runs eagerly; the trained parameters
+    and the History are identical to a fit with graphs switched off (DCTR_FIT_GRAPH=0)."""
+    g = load_golden("deepfm_criteo")
+    names = [c["name"] for c in g["spec"]["dnn_columns"]]
+    Xs = np.concatenate(list(g["extra"]["X_steps"]) + [g["X"]], axis=0)
+    ys = np.concatenate(list(g["extra"]["y_steps"]) + [g["y"]], axis=0)
+    n = (Xs.shape[0] // 48) * 48 + 17                     # 48-row batches + a ragged tail
+    n = min(n, Xs.shape[0])
+    x = {nm: Xs[:n, i] for i, nm in enumerate(names)}
+    runs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DCTR_FIT_GRAPH", flag)
+        m = build_model(g["spec"], DEV)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in g["params"].items()})
+        m.compile("adagrad", "binary_crossentropy", metrics=["binary_crossentropy"])
+        hist = m.fit(x, ys[:n], batch_size=48, epochs=2, verbose=2, shuffle=False)
+        used = m._fit_graph is not None and m._fit_graph.get("graph") is not None
+        runs.append(({k: v.clone() for k, v in m.state_dict().items()}, dict(hist.history), used))
+    (a, ha, ua), (b, hb, ub) = runs
+    assert ua and not ub
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert ha["loss"] == hb["loss"] and ha["binary_crossentropy"] == hb["binary_crossentropy"]
