@@ -438,10 +438,12 @@ class ShardedTrainer(object):
         self._announced = None          # identity of the batch whose ids already sit in _ids_view
         self._ids_t = None
         g = bool(self.use_graphs) and xb.is_cuda
-        self._segB = _Segment(lambda: self.ops.gather(self._ids_view), g)
+        # Only the multi-kernel segment is worth a graph: a hipGraph launch leaves the GPU idle for ~12 us before its
+        # first kernel, a plain launch ~2 us, and the host has slack (it is not the bottleneck of this step).
+        self._segB = _Segment(lambda: self.ops.gather(self._ids_view), False)
         self._segC = _Segment(self._compute, g)
-        self._segD = _Segment(lambda: self.ops.update(self._grads_all, self._ids_t), g)
-        self._segE = _Segment(lambda: self.slab.step(*self.state["mode"]), g)
+        self._segD = _Segment(lambda: self.ops.update(self._grads_all, self._ids_t), False)
+        self._segE = _Segment(lambda: self.slab.step(*self.state["mode"]), False)
 
     def _compute(self):
         from ._hip import mlp as _mlp
