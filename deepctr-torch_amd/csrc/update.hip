@@ -7,21 +7,29 @@
 //
 // Why not atomics: measured on MI355X at B=4096 (profiles/r01_*), the scatter (1.7 M dword atomics)
 // took 36 us and the xchg-consume pass 59 us -- 9 % of the HBM roofline -- and float atomics make
-// duplicate-row sums order-dependent, so data-parallel replicas drift apart.
+// duplicate-row sums order-dependent, so replicas / shards drift apart.
 //
-// Mapping: a "unit" is one id column of X with the deep table and/or the wide (1-dim) table it
-// feeds.  Workgroup (unit u, partition p) owns the rows {id : id mod P == p} of u's tables, so no two
-// workgroups ever touch the same row:
-//   1. scan   the unit's B ids (ids_t[u][0..B), contiguous int32 written by the forward kernel) and
-//             collect the entries of this partition as 32-bit keys (id / P) << bbits | b in LDS;
-//   2. sort   the keys (bitonic, in LDS; typically 64 of them) -> entries ordered by (id, b);
-//   3. reduce tiles of G entries: every lane group fetches ITS entry's gradient strip
-//             g = g_out[b, f] + g_fm[b] * (S[b] - e[b, f]) (all loads of a tile in flight at once) and
-//             the table / state strips of its row, parks g in LDS; the last entry of each id segment
-//             sums its segment in fixed order (carry across tiles) and applies the update with plain
-//             coalesced 64-byte row stores.
-// Every row is read-modify-written exactly once, by one lane group, in an order that depends only on
-// (id, b): results are bit-reproducible run to run and rank to rank.
+// Mapping: a "unit" is one id column of X with the deep table and/or the wide (1-dim) table it feeds.
+// Workgroup (unit u, partition p) owns the rows {id : id mod P == p} of u's tables, so no two workgroups
+// ever touch the same row.  P is chosen so that a partition holds ~64 entries.  A workgroup
+//   1. scans  the unit's B ids (ids_t[u][0..B), contiguous int32 written by the forward kernel) and collects
+//             its entries as 32-bit keys (id / P) << bbits | b in LDS -- at most kCap of them;
+//   2. if they fit one tile (<= G entries, the common case): every lane group takes one entry in SCAN order
+//             and issues its loads at once (gradient strip, sum_f e strip, table + state row strips); the
+//             rank sort of the keys runs in the shadow of those loads; gradients are parked in LDS at their
+//             SORTED position; the last entry of every id segment sums its segment backwards and
+//             read-modify-writes the row strips it already holds;
+//      else if they fit kCap: bitonic / rank sort, then tiles of G sorted entries with a carry;
+//   3. a partition with MORE than kCap entries (skewed ids) is split by the next bit of id / P and the two
+//             halves are processed one after the other (re-scanning the ids; LDS stays small); a half that still
+//             overflows but holds ONE id -- a hot id -- is summed by streaming over the batch in sample order.
+// FM's backward is folded algebraically: sum_seg [g + gf (S - e)] = sum_seg (g + gf S) - (sum_seg gf) e, and e IS
+// the table row about to be updated -- the forward's copy of it is not re-read.
+// Every row is read-modify-written exactly once, by one lane group, in an order that depends only on the data
+// (counts, ids, sample indices): results are bit-reproducible run to run and rank to rank.
+//
+// LDS per workgroup is ~12 KB whatever B is (the previous revision kept B keys -- 16 KB at B = 4096: six
+// workgroups per CU and a second round; 128 KB at the 32 768-sample global batch of 8-GPU sharded training).
 #include "common.hpp"
 
 using namespace dctr;
@@ -29,6 +37,8 @@ using namespace dctr;
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kCap = 512;     // sort keys held in LDS
+constexpr int kStack = 40;    // pending (id bits fixed, their value) splits of an overflowing partition
 
 struct UpdArgs {
   const dctr_field_t* deep;
@@ -36,16 +46,14 @@ struct UpdArgs {
   const int32_t* units;  // [n_units][4] = {deep index | -1, wide index | -1, X column, 0}
   const int32_t* ids_t;  // [n_units][B] truncated ids
   const float* gout;     // [B, ldg]   d loss / d out (deep slices), nullable
-  const float* out;      // [B, ldo]   forward output (e), needed with gfm
   const float* fm_s;     // [B, lds_]  S[b, :] = sum_f e[b, f, :], needed with gfm
   const float* gfm;      // [B] nullable
   const float* gwide;    // [B] (stride ldgw) nullable
   int64_t ldgw;
-  int64_t ldg, ldo, lds_;
+  int64_t ldg, lds_;
   int32_t n_units, B, log2p, bbits;
-  int32_t gt;            // entries per tile (<= lane groups per workgroup; sized by the host so that 7 WGs fit a CU)
   float lr, eps;
-  // optional extra role (last block): d loss / d Linear.weight = X_dense^T g_wide  (basemodel.py:88-90)
+  // optional extra role (last blocks): d loss / d Linear.weight = X_dense^T g_wide  (basemodel.py:88-90)
   const float* X;
   int64_t ldx;
   const int32_t* wdense_cols;
@@ -57,8 +65,8 @@ struct UpdArgs {
 unsigned long long* g_trace = nullptr;  // host-side: set by dctr_dbg_update_trace
 int g_force_log2p = -1;
 
-#define DCTR_TRACE(slot)                                                     \
-  do {                                                                       \
+#define DCTR_TRACE(slot)                                                           \
+  do {                                                                             \
     if (A.trace && tid == 0) A.trace[blockIdx.x * 8ull + (slot)] = wall_clock64(); \
   } while (0)
 
@@ -94,11 +102,16 @@ __device__ __forceinline__ void apply_strip(const dctr_field_t& fd, int64_t off,
 // (7 workgroups of 4 waves per CU: <= 72 VGPRs)
 template <int VEC, int LPR, int OPT>
 __global__ __launch_bounds__(kThreads, 7) void k_embed_update(UpdArgs A) {
-  constexpr int GMAX = kThreads / LPR;  // lane groups per workgroup
-  const int G = A.gt < GMAX ? A.gt : GMAX;  // entries per tile
-  extern __shared__ __align__(16) unsigned char smem[];
-  __shared__ int n_sh;
-  __shared__ int carry_id;
+  constexpr int G = kThreads / LPR;   // lane groups per workgroup = entries per tile (a power of two)
+  constexpr int RW = LPR * VEC;       // floats of one parked gradient row
+  __shared__ uint32_t keys[kCap];     // this pass's entries; sorted in place by the tiled path
+  __shared__ uint32_t skeys[G];       // single-tile path: keys in sorted order; streaming path: sample list
+  __shared__ __align__(16) float gbuf[G * RW];  // gradient tile
+  __shared__ float gfbuf[G];          // g_fm of the tile's entries
+  __shared__ float gwbuf[G];          // wide gradient of the tile's entries
+  __shared__ float carry[RW + 4];     // open segment of the tiled path: deep strip | g_fm sum | wide sum
+  __shared__ int stack[kStack][2];
+  __shared__ int n_sh, mn_sh, mx_sh, carry_id, sp_sh, wcnt[kThreads / 64];
   const int tid = threadIdx.x;
   const int P = 1 << A.log2p;
   DCTR_TRACE(0);
@@ -125,9 +138,8 @@ __global__ __launch_bounds__(kThreads, 7) void k_embed_update(UpdArgs A) {
     return;
   }
 
-  // Work item w = (unit, partition) in plain launch order: consecutive workgroups go to consecutive XCDs, so every
-  // XCD gets the same number of working workgroups.  (Keeping a unit's partitions on one XCD -- to fetch its id row
-  // into one L2 only -- left XCDs 0-1 with 4 units and the others with 3 at F = 26: a second round on two XCDs.)
+  // Work item (unit, partition) in plain launch order: consecutive workgroups go to consecutive XCDs, so every
+  // XCD gets the same number of working workgroups.
   const int u = static_cast<int>(blockIdx.x) >> A.log2p, p = static_cast<int>(blockIdx.x) & (P - 1);
   if (u >= A.n_units) return;
 
@@ -138,297 +150,410 @@ __global__ __launch_bounds__(kThreads, 7) void k_embed_update(UpdArgs A) {
   if (wi >= 0) fw = A.wide[wi];
   const int64_t vocab = (di >= 0) ? fd.vocab : fw.vocab;
   const int B = A.B;
-  int cap = 2;
-  while (cap < B) cap <<= 1;
-
-  uint32_t* keys = reinterpret_cast<uint32_t*>(smem);           // [cap]
-  float* gbuf = reinterpret_cast<float*>(keys + cap);            // [G][LPR*VEC] deep gradient strips
-  float* gwbuf = gbuf + G * LPR * VEC;                           // [G] wide gradients
-  float* carry = gwbuf + G;                                      // [LPR*VEC + 4]
-  float* gfbuf = carry + LPR * VEC + 4;                          // [G]  single-tile path: g_fm of the entry
-  uint32_t* skeys = reinterpret_cast<uint32_t*>(gfbuf + G);      // [G]  single-tile path: keys in sorted order
-
-  if (tid == 0) {
-    n_sh = 0;
-    carry_id = -1;
-  }
-  __syncthreads();
-
-  // ---- 1. scan: collect this partition's entries -------------------------------------------------
-  // All id loads of a chunk are issued before any is consumed (16 ids per thread in flight at B=4096):
-  // the scan costs one L2 round trip, not one per iteration.
   const int32_t* ids = A.ids_t + static_cast<int64_t>(u) * B;
-  auto take = [&](int32_t raw, int b) {
-    const int32_t id = clamp_id(raw, vocab);
-    if ((id & (P - 1)) == p) {
-      const int slot = atomicAdd(&n_sh, 1);  // LDS atomic; the order is fixed by the sort below
-      keys[slot] = (static_cast<uint32_t>(id >> A.log2p) << A.bbits) | static_cast<uint32_t>(b);
-    }
-  };
-  if ((B & 3) == 0) {
-    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
-    const DCTR_GLOBAL i32x4* idv = (const DCTR_GLOBAL i32x4*)ids;
-    const int nvec = B >> 2;
-    for (int c0 = 0; c0 < nvec; c0 += 4 * kThreads) {
-      i32x4 v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int idx = c0 + q * kThreads + tid;
-        v[q] = idv[idx < nvec ? idx : 0];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int idx = c0 + q * kThreads + tid;
-        if (idx < nvec) {
-          take(v[q].x, 4 * idx);
-          take(v[q].y, 4 * idx + 1);
-          take(v[q].z, 4 * idx + 2);
-          take(v[q].w, 4 * idx + 3);
-        }
-      }
-    }
-  } else {
-    for (int b = tid; b < B; b += kThreads) take(ldg_i32(ids + b), b);
-  }
-  __syncthreads();
-  const int n = n_sh;
-  DCTR_TRACE(1);
-  if (A.trace && tid == 0) A.trace[blockIdx.x * 8ull + 7] = static_cast<unsigned long long>(n);
-  if (n == 0) return;
 
-  if (n <= G) {
-    // ---- single tile (the common case: P is chosen so that a partition holds ~G/2 entries) -------------------
-    // Lane group i takes the i-th entry in SCAN order and issues its loads at once; the rank sort runs in their
-    // shadow; gradients are parked in LDS at their SORTED position; the last entry of every id segment sums its
-    // segment backwards (fixed order) and applies the update to the row strips it already holds.
-    // FM's backward is folded algebraically: sum_seg [g + gf (S - e)] = sum_seg (g + gf S) - (sum_seg gf) e, and e
-    // IS the table row this lane is about to update -- the forward's copy of it is not re-read.
-    const int grp = tid / LPR, gl = tid % LPR, e0 = gl * VEC;
-    const uint32_t bmask = (1u << A.bbits) - 1u;
-    const bool deep_on = (di >= 0) && (A.gout || A.gfm);
-    const bool wide_on = (wi >= 0) && A.gwide;
-    const bool lane_on = deep_on && (e0 < fd.dim);
-    const int goff = deep_on ? fd.out_off + (lane_on ? e0 : 0) : 0;
-    const bool have = grp < n;
-    const uint32_t key = have ? keys[grp] : 0xFFFFFFFFu;
-    const int b = static_cast<int>(key & bmask);
-    const int idq = static_cast<int>(key >> A.bbits);
-    const int64_t row = (static_cast<int64_t>(idq) << A.log2p) | p;
-    Strip<VEC> h = strip_zero<VEC>(), S = strip_zero<VEC>(), w = strip_zero<VEC>(), s = strip_zero<VEC>();
-    Strip<VEC> e = strip_zero<VEC>();
-    float gf = 0.f, gw = 0.f, ww = 0.f, sw = 0.f;
-    if (have) {
-      if (lane_on) {
-        if (A.gout) h = strip_load<VEC>(A.gout + static_cast<int64_t>(b) * A.ldg + goff);
-        if (A.gfm) {
-          S = strip_load<VEC>(A.fm_s + static_cast<int64_t>(b) * A.lds_ + e0);
-          gf = ldg_f32(A.gfm + b);
-          if (OPT == DCTR_UPD_ACCUM) e = strip_load<VEC>(fd.table + row * fd.dim + e0);
-        }
-        const int64_t off = row * fd.dim + e0;
-        w = strip_load<VEC>((OPT == DCTR_UPD_ACCUM ? fd.gacc : fd.table) + off);
-        if (OPT == DCTR_UPD_ADAGRAD) s = strip_load<VEC>(fd.state + off);
-      }
-      if (wide_on && gl == 0) {
-        gw = ldg_f32(A.gwide + static_cast<int64_t>(b) * A.ldgw);
-        ww = ldg_f32((OPT == DCTR_UPD_ACCUM ? fw.gacc : fw.table) + row);
-        if (OPT == DCTR_UPD_ADAGRAD) sw = ldg_f32(fw.state + row);
-      }
-    }
-    int rank = 0;  // keys are unique: rank = number of smaller keys
-#pragma unroll 8
-    for (int q = 0; q < n; ++q) rank += (keys[q] < key) ? 1 : 0;
-    DCTR_TRACE(2);
-    if (have) {
-      if (gl == 0) {
-        skeys[rank] = key;
-        gfbuf[rank] = gf;
-        gwbuf[rank] = gw;
-      }
-      if (lane_on) {
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-          float v = h.v[k] + gf * S.v[k];
-          if (OPT == DCTR_UPD_ACCUM) v = h.v[k] + gf * (S.v[k] - e.v[k]);
-          gbuf[rank * (LPR * VEC) + e0 + k] = v;
-        }
-      }
-    }
-    DCTR_TRACE(3);
-    __syncthreads();
-    DCTR_TRACE(4);
-    if (have) {
-      const bool seg_end = (rank == n - 1) || (static_cast<int>(skeys[rank + 1] >> A.bbits) != idq);
-      if (seg_end) {
-        Strip<VEC> acc = strip_zero<VEC>();
-        float accf = 0.f, accw = 0.f;
-        int r = rank;
-        while (r >= 0 && static_cast<int>(skeys[r] >> A.bbits) == idq) {
-          if (lane_on) {
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) acc.v[k] += gbuf[r * (LPR * VEC) + e0 + k];
-          }
-          accf += gfbuf[r];
-          if (gl == 0) accw += gwbuf[r];
-          --r;
-        }
-        if (lane_on) {
-          if (OPT != DCTR_UPD_ACCUM && A.gfm) {
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) acc.v[k] -= accf * w.v[k];
-          }
-          apply_strip<VEC, OPT>(fd, row * fd.dim + e0, acc, w, s, A.lr, A.eps);
-        }
-        if (wide_on && gl == 0) {
-          Strip<1> a1, w1, s1;
-          a1.v[0] = accw;
-          w1.v[0] = ww;
-          s1.v[0] = sw;
-          apply_strip<1, OPT>(fw, row, a1, w1, s1, A.lr, A.eps);
-        }
-      }
-    }
-    DCTR_TRACE(5);
-    DCTR_TRACE(6);
-    return;
-  }
-
-  // ---- 2. sort by (id, b) ------------------------------------------------------------------------
-  if (n <= kThreads) {
-    // rank sort: keys are unique, so rank = #smaller is a permutation; 2 barriers instead of ~21-36
-    const uint32_t mine = tid < n ? keys[tid] : 0u;
-    int rank = 0;
-#pragma unroll 8
-    for (int q = 0; q < n; ++q) rank += (keys[q] < mine) ? 1 : 0;  // broadcast LDS reads
-    __syncthreads();
-    if (tid < n) keys[rank] = mine;
-    __syncthreads();
-  } else {
-    int m = 2;
-    while (m < n) m <<= 1;
-    for (int i = n + tid; i < m; i += kThreads) keys[i] = 0xFFFFFFFFu;
-    __syncthreads();
-    for (int k = 2; k <= m; k <<= 1) {
-      for (int s = k >> 1; s > 0; s >>= 1) {
-        for (int i = tid; i < m; i += kThreads) {
-          const int ixs = i ^ s;
-          if (ixs > i) {
-            const uint32_t a = keys[i], b2 = keys[ixs];
-            const bool up = (i & k) == 0;
-            if ((a > b2) == up) {
-              keys[i] = b2;
-              keys[ixs] = a;
-            }
-          }
-        }
-        __syncthreads();
-      }
-    }
-  }
-
-  DCTR_TRACE(2);
-  // ---- 3. tiles of G entries ---------------------------------------------------------------------
-  const int grp = tid / LPR, gl = tid % LPR;
-  const int e0 = gl * VEC;
+  const int grp = tid / LPR, gl = tid % LPR, e0 = gl * VEC;
   const uint32_t bmask = (1u << A.bbits) - 1u;
   const bool deep_on = (di >= 0) && (A.gout || A.gfm);
   const bool wide_on = (wi >= 0) && A.gwide;
   const bool lane_on = deep_on && (e0 < fd.dim);
   const int goff = deep_on ? fd.out_off + (lane_on ? e0 : 0) : 0;
+  const bool fold = (A.gfm != nullptr);
 
-  for (int t0 = 0; t0 < n; t0 += G) {
-    const int i = t0 + grp;
-    const bool have = i < n && grp < G;
-    const uint32_t key = have ? keys[i] : 0u;
-    const int b = static_cast<int>(key & bmask);
-    const int idq = static_cast<int>(key >> A.bbits);           // id / P
-    const int64_t row = (static_cast<int64_t>(idq) << A.log2p) | p;
-
-    // issue every load of this entry: gradient pieces, then the row strips it may update
-    Strip<VEC> g = strip_zero<VEC>(), w = strip_zero<VEC>(), s = strip_zero<VEC>();
-    float gw = 0.f, ww = 0.f, sw = 0.f;
-    if (have) {
-      if (lane_on) {
-        if (A.gout) g = strip_load<VEC>(A.gout + static_cast<int64_t>(b) * A.ldg + goff);
-        if (A.gfm) {
-          const Strip<VEC> e = strip_load<VEC>(A.out + static_cast<int64_t>(b) * A.ldo + goff);
-          const Strip<VEC> S = strip_load<VEC>(A.fm_s + static_cast<int64_t>(b) * A.lds_ + e0);
-          const float gf = ldg_f32(A.gfm + b);
+  // everything an entry contributes: h = g_out + g_fm * S (deep strip), g_fm, g_wide
+  auto load_entry = [&](int b, Strip<VEC>& h, float& gf, float& gw) {
+    h = strip_zero<VEC>();
+    gf = 0.f;
+    gw = 0.f;
+    if (lane_on) {
+      if (A.gout) h = strip_load<VEC>(A.gout + static_cast<int64_t>(b) * A.ldg + goff);
+      if (fold) {
+        const Strip<VEC> S = strip_load<VEC>(A.fm_s + static_cast<int64_t>(b) * A.lds_ + e0);
+        gf = ldg_f32(A.gfm + b);
 #pragma unroll
-          for (int k = 0; k < VEC; ++k) g.v[k] += gf * (S.v[k] - e.v[k]);
-        }
-        const int64_t off = row * fd.dim + e0;
-        w = strip_load<VEC>((OPT == DCTR_UPD_ACCUM ? fd.gacc : fd.table) + off);
-        if (OPT == DCTR_UPD_ADAGRAD) s = strip_load<VEC>(fd.state + off);
-      }
-      if (wide_on && gl == 0) {
-        gw = ldg_f32(A.gwide + static_cast<int64_t>(b) * A.ldgw);
-        ww = ldg_f32((OPT == DCTR_UPD_ACCUM ? fw.gacc : fw.table) + row);
-        if (OPT == DCTR_UPD_ADAGRAD) sw = ldg_f32(fw.state + row);
+        for (int k = 0; k < VEC; ++k) h.v[k] += gf * S.v[k];
       }
     }
-    if (lane_on && grp < G) {
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) gbuf[grp * (LPR * VEC) + e0 + k] = g.v[k];
+    if (wide_on && gl == 0) gw = ldg_f32(A.gwide + static_cast<int64_t>(b) * A.ldgw);
+  };
+  // the strips of a row this lane may update: w (table, or gacc in accumulate mode), s (Adagrad state), e (the
+  // table strip FM's fold needs; = w unless accumulating)
+  auto load_row = [&](int64_t row, Strip<VEC>& w, Strip<VEC>& s, Strip<VEC>& e, float& ww, float& sw) {
+    w = strip_zero<VEC>();
+    s = strip_zero<VEC>();
+    e = strip_zero<VEC>();
+    ww = 0.f;
+    sw = 0.f;
+    if (lane_on) {
+      const int64_t off = row * fd.dim + e0;
+      w = strip_load<VEC>((OPT == DCTR_UPD_ACCUM ? fd.gacc : fd.table) + off);
+      if (OPT == DCTR_UPD_ADAGRAD) s = strip_load<VEC>(fd.state + off);
+      if (OPT == DCTR_UPD_ACCUM) {
+        if (fold) e = strip_load<VEC>(fd.table + off);
+      } else {
+        e = w;
+      }
     }
-    if (gl == 0 && grp < G) gwbuf[grp] = gw;
-    if (t0 == 0) DCTR_TRACE(3);
+    if (wide_on && gl == 0) {
+      ww = ldg_f32((OPT == DCTR_UPD_ACCUM ? fw.gacc : fw.table) + row);
+      if (OPT == DCTR_UPD_ADAGRAD) sw = ldg_f32(fw.state + row);
+    }
+  };
+  auto apply_row = [&](int64_t row, Strip<VEC> acc, float accf, float accw, const Strip<VEC>& w, const Strip<VEC>& s,
+                       const Strip<VEC>& e, float ww, float sw) {
+    if (lane_on) {
+      if (fold) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc.v[k] -= accf * e.v[k];
+      }
+      apply_strip<VEC, OPT>(fd, row * fd.dim + e0, acc, w, s, A.lr, A.eps);
+    }
+    if (wide_on && gl == 0) {
+      Strip<1> a1, w1, s1;
+      a1.v[0] = accw;
+      w1.v[0] = ww;
+      s1.v[0] = sw;
+      apply_strip<1, OPT>(fw, row, a1, w1, s1, A.lr, A.eps);
+    }
+  };
+
+  if (tid == 0) {
+    sp_sh = 1;
+    stack[0][0] = 0;   // number of extra id bits fixed
+    stack[0][1] = 0;   // their value
+  }
+  bool first_pass = true;
+  for (;;) {
     __syncthreads();
-    if (t0 == 0) DCTR_TRACE(4);
-
-    // the last entry of an id segment (or of the tile) sums the segment's members inside this tile
-    const bool last_of_tile = have && ((grp == G - 1) || (i == n - 1));
-    const bool seg_end = have && ((i == n - 1) || (static_cast<int>(keys[i + 1] >> A.bbits) != idq));
-    const bool summer = seg_end || last_of_tile;
-    Strip<VEC> acc = strip_zero<VEC>();
-    float accw = 0.f;
-    if (summer) {
-      int jj = grp;  // walk back: fixed order => deterministic
-      while (jj >= 0 && static_cast<int>(keys[t0 + jj] >> A.bbits) == idq) {
-        if (lane_on) {
-#pragma unroll
-          for (int k = 0; k < VEC; ++k) acc.v[k] += gbuf[jj * (LPR * VEC) + e0 + k];
-        }
-        if (gl == 0) accw += gwbuf[jj];
-        --jj;
-      }
-      if (jj < 0 && carry_id == idq) {  // the segment began in an earlier tile
-        if (lane_on) {
-#pragma unroll
-          for (int k = 0; k < VEC; ++k) acc.v[k] += carry[e0 + k];
-        }
-        if (gl == 0) accw += carry[LPR * VEC];
-      }
-      if (seg_end) {
-        if (lane_on) apply_strip<VEC, OPT>(fd, row * fd.dim + e0, acc, w, s, A.lr, A.eps);
-        if (wide_on && gl == 0) {
-          Strip<1> a1, w1, s1;
-          a1.v[0] = accw;
-          w1.v[0] = ww;
-          s1.v[0] = sw;
-          apply_strip<1, OPT>(fw, row, a1, w1, s1, A.lr, A.eps);
-        }
-      }
+    const int sp = sp_sh;
+    if (sp == 0) break;
+    const int mbits = stack[sp - 1][0], mres = stack[sp - 1][1];
+    __syncthreads();
+    if (tid == 0) {
+      sp_sh = sp - 1;
+      n_sh = 0;
+      mn_sh = 0x7FFFFFFF;
+      mx_sh = -1;
+      carry_id = -1;
     }
-    __syncthreads();  // every read of gbuf / carry of this tile is done
-    if (last_of_tile) {  // exactly one group: park an open segment's partial, or clear the carry
-      if (!seg_end) {
+    __syncthreads();
+
+    // ---- scan: collect the entries of (partition p, id/P mod 2^mbits == mres) ------------------------------------
+    // All id loads of a chunk are issued before any is consumed: the scan costs one L2 round trip per chunk.
+    const uint32_t mmask = (1u << mbits) - 1u;
+    auto take = [&](int32_t raw, int b) {
+      const int32_t id = clamp_id(raw, vocab);
+      const uint32_t idq = static_cast<uint32_t>(id) >> A.log2p;
+      if ((id & (P - 1)) == p && (idq & mmask) == static_cast<uint32_t>(mres)) {
+        const int slot = atomicAdd(&n_sh, 1);  // LDS atomic; the order is fixed by the sort below
+        if (slot < kCap) keys[slot] = (idq << A.bbits) | static_cast<uint32_t>(b);
+        atomicMin(&mn_sh, static_cast<int>(idq));   // the id range decides what an overflowing pass does
+        atomicMax(&mx_sh, static_cast<int>(idq));
+      }
+    };
+    if ((B & 3) == 0) {
+      typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+      const DCTR_GLOBAL i32x4* idv = (const DCTR_GLOBAL i32x4*)ids;
+      const int nvec = B >> 2;
+      for (int c0 = 0; c0 < nvec; c0 += 4 * kThreads) {
+        i32x4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int idx = c0 + q * kThreads + tid;
+          v[q] = idv[idx < nvec ? idx : 0];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int idx = c0 + q * kThreads + tid;
+          if (idx < nvec) {
+            take(v[q].x, 4 * idx);
+            take(v[q].y, 4 * idx + 1);
+            take(v[q].z, 4 * idx + 2);
+            take(v[q].w, 4 * idx + 3);
+          }
+        }
+      }
+    } else {
+      for (int b = tid; b < B; b += kThreads) take(ldg_i32(ids + b), b);
+    }
+    __syncthreads();
+    const int n = n_sh;
+    if (first_pass) {
+      DCTR_TRACE(1);
+      if (A.trace && tid == 0) A.trace[blockIdx.x * 8ull + 7] = static_cast<unsigned long long>(n);
+    }
+    if (n == 0) {
+      first_pass = false;
+      continue;
+    }
+
+    if (n <= G) {
+      // ---- single tile --------------------------------------------------------------------------------------------
+      const bool have = grp < n;
+      const uint32_t key = have ? keys[grp] : 0xFFFFFFFFu;
+      const int b = static_cast<int>(key & bmask);
+      const int idq = static_cast<int>(key >> A.bbits);
+      const int64_t row = (static_cast<int64_t>(idq) << A.log2p) | p;
+      Strip<VEC> h, w, s, e;
+      float gf, gw, ww, sw;
+      if (have) {
+        load_entry(b, h, gf, gw);
+        load_row(row, w, s, e, ww, sw);
+      } else {
+        h = w = s = e = strip_zero<VEC>();
+        gf = gw = ww = sw = 0.f;
+      }
+      int rank = 0;  // keys are unique: rank = number of smaller keys
+#pragma unroll 8
+      for (int q = 0; q < n; ++q) rank += (keys[q] < key) ? 1 : 0;
+      if (first_pass) DCTR_TRACE(2);
+      if (have) {
+        if (gl == 0) {
+          skeys[rank] = key;
+          gfbuf[rank] = gf;
+          gwbuf[rank] = gw;
+        }
         if (lane_on) {
 #pragma unroll
-          for (int k = 0; k < VEC; ++k) carry[e0 + k] = acc.v[k];
+          for (int k = 0; k < VEC; ++k) gbuf[rank * RW + e0 + k] = h.v[k];
+        }
+      }
+      if (first_pass) DCTR_TRACE(3);
+      __syncthreads();
+      if (first_pass) DCTR_TRACE(4);
+      if (have) {
+        const bool seg_end = (rank == n - 1) || (static_cast<int>(skeys[rank + 1] >> A.bbits) != idq);
+        if (seg_end) {
+          Strip<VEC> acc = strip_zero<VEC>();
+          float accf = 0.f, accw = 0.f;
+          int r = rank;  // walk back: fixed order => deterministic
+          while (r >= 0 && static_cast<int>(skeys[r] >> A.bbits) == idq) {
+            if (lane_on) {
+#pragma unroll
+              for (int k = 0; k < VEC; ++k) acc.v[k] += gbuf[r * RW + e0 + k];
+            }
+            accf += gfbuf[r];
+            if (gl == 0) accw += gwbuf[r];
+            --r;
+          }
+          apply_row(row, acc, accf, accw, w, s, e, ww, sw);
+        }
+      }
+      if (first_pass) {
+        DCTR_TRACE(5);
+        DCTR_TRACE(6);
+      }
+      first_pass = false;
+      continue;
+    }
+
+    if (n <= kCap) {
+      // ---- sort by (id, b), then tiles of G sorted entries with a carry ---------------------------------------------
+      if (n <= kThreads) {
+        // rank sort: keys are unique, so rank = #smaller is a permutation; 2 barriers
+        const uint32_t mine = tid < n ? keys[tid] : 0u;
+        int rank = 0;
+#pragma unroll 8
+        for (int q = 0; q < n; ++q) rank += (keys[q] < mine) ? 1 : 0;
+        __syncthreads();
+        if (tid < n) keys[rank] = mine;
+        __syncthreads();
+      } else {
+        int m = 2;
+        while (m < n) m <<= 1;
+        for (int i = n + tid; i < m; i += kThreads) keys[i] = 0xFFFFFFFFu;
+        __syncthreads();
+        for (int k = 2; k <= m; k <<= 1) {
+          for (int st = k >> 1; st > 0; st >>= 1) {
+            for (int i = tid; i < m; i += kThreads) {
+              const int ixs = i ^ st;
+              if (ixs > i) {
+                const uint32_t a = keys[i], b2 = keys[ixs];
+                const bool up = (i & k) == 0;
+                if ((a > b2) == up) {
+                  keys[i] = b2;
+                  keys[ixs] = a;
+                }
+              }
+            }
+            __syncthreads();
+          }
+        }
+      }
+      for (int t0 = 0; t0 < n; t0 += G) {
+        const int i = t0 + grp;
+        const bool have = i < n;
+        const uint32_t key = have ? keys[i] : 0u;
+        const int b = static_cast<int>(key & bmask);
+        const int idq = static_cast<int>(key >> A.bbits);
+        const int64_t row = (static_cast<int64_t>(idq) << A.log2p) | p;
+        const bool last_of_tile = have && ((grp == G - 1) || (i == n - 1));
+        const bool seg_end = have && ((i == n - 1) || (static_cast<int>(keys[i + 1] >> A.bbits) != idq));
+        Strip<VEC> h, w, s, e;
+        float gf, gw, ww, sw;
+        h = w = s = e = strip_zero<VEC>();
+        gf = gw = ww = sw = 0.f;
+        if (have) {
+          load_entry(b, h, gf, gw);
+          if (seg_end) load_row(row, w, s, e, ww, sw);
+        }
+        if (lane_on) {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) gbuf[grp * RW + e0 + k] = h.v[k];
         }
         if (gl == 0) {
-          carry[LPR * VEC] = accw;
-          carry_id = idq;
+          gfbuf[grp] = gf;
+          gwbuf[grp] = gw;
         }
-      } else if (gl == 0) {
-        carry_id = -1;
+        __syncthreads();
+        const bool summer = seg_end || last_of_tile;
+        Strip<VEC> acc = strip_zero<VEC>();
+        float accf = 0.f, accw = 0.f;
+        if (summer) {
+          int jj = grp;  // walk back: fixed order => deterministic
+          while (jj >= 0 && static_cast<int>(keys[t0 + jj] >> A.bbits) == idq) {
+            if (lane_on) {
+#pragma unroll
+              for (int k = 0; k < VEC; ++k) acc.v[k] += gbuf[jj * RW + e0 + k];
+            }
+            accf += gfbuf[jj];
+            if (gl == 0) accw += gwbuf[jj];
+            --jj;
+          }
+          if (jj < 0 && carry_id == idq) {  // the segment began in an earlier tile
+            if (lane_on) {
+#pragma unroll
+              for (int k = 0; k < VEC; ++k) acc.v[k] += carry[e0 + k];
+            }
+            accf += carry[RW];
+            if (gl == 0) accw += carry[RW + 1];
+          }
+          if (seg_end) apply_row(row, acc, accf, accw, w, s, e, ww, sw);
+        }
+        __syncthreads();  // every read of gbuf / carry of this tile is done
+        if (last_of_tile) {  // exactly one group: park an open segment's partial, or clear the carry
+          if (!seg_end) {
+            if (lane_on) {
+#pragma unroll
+              for (int k = 0; k < VEC; ++k) carry[e0 + k] = acc.v[k];
+            }
+            if (gl == 0) {
+              carry[RW] = accf;
+              carry[RW + 1] = accw;
+              carry_id = idq;
+            }
+          } else if (gl == 0) {
+            carry_id = -1;
+          }
+        }
+        __syncthreads();
       }
+      first_pass = false;
+      continue;
     }
-    __syncthreads();
-    if (t0 == 0) DCTR_TRACE(5);
+
+    // ---- more entries than LDS keys ----------------------------------------------------------------------------
+    first_pass = false;
+    if (mn_sh != mx_sh) {
+      // several ids: fix one more bit of id / P and do the two halves one after the other
+      if (tid == 0) {
+        const int spn = sp_sh;
+        if (spn + 2 <= kStack) {
+          stack[spn][0] = mbits + 1;
+          stack[spn][1] = mres | (1 << mbits);
+          stack[spn + 1][0] = mbits + 1;
+          stack[spn + 1][1] = mres;
+          sp_sh = spn + 2;
+        }
+      }
+      continue;
+    }
+    // a hot id: all n > kCap entries hit ONE row.  Stream over the batch in sample order, G matching samples at a
+    // time; each tile is reduced by a fixed tree and added to the running sum kept by lane group 0.
+    const int idq_hot = mn_sh;
+    const int64_t row_hot = (static_cast<int64_t>(idq_hot) << A.log2p) | p;
+    const int32_t id_hot = static_cast<int32_t>(row_hot);
+    Strip<VEC> tot = strip_zero<VEC>();
+    float totf = 0.f, totw = 0.f;
+    auto flush_tile = [&](int cnt) {   // cnt sample indices sit in skeys[0..cnt)
+      Strip<VEC> h;
+      float gf, gw;
+      if (grp < cnt) {
+        load_entry(static_cast<int>(skeys[grp]), h, gf, gw);
+      } else {
+        h = strip_zero<VEC>();
+        gf = gw = 0.f;
+      }
+      if (lane_on) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) gbuf[grp * RW + e0 + k] = h.v[k];
+      }
+      if (gl == 0) {
+        gfbuf[grp] = gf;
+        gwbuf[grp] = gw;
+      }
+      __syncthreads();
+      for (int st = G >> 1; st > 0; st >>= 1) {
+        if (grp < st) {
+          if (lane_on) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) gbuf[grp * RW + e0 + k] += gbuf[(grp + st) * RW + e0 + k];
+          }
+          if (gl == 0) {
+            gfbuf[grp] += gfbuf[grp + st];
+            gwbuf[grp] += gwbuf[grp + st];
+          }
+        }
+        __syncthreads();
+      }
+      if (grp == 0) {
+        if (lane_on) {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) tot.v[k] += gbuf[e0 + k];
+        }
+        totf += gfbuf[0];
+        if (gl == 0) totw += gwbuf[0];
+      }
+      __syncthreads();
+    };
+    int pending = 0;   // matches parked in skeys[] (uniform over the workgroup)
+    for (int c0 = 0; c0 < B; c0 += kThreads) {
+      const int b = c0 + tid;
+      const bool m = b < B && clamp_id(ldg_i32(ids + (b < B ? b : 0)), vocab) == id_hot;
+      const unsigned long long bal = __ballot(m);
+      const int lane = tid & 63, wv = tid >> 6;
+      if (lane == 0) wcnt[wv] = __popcll(bal);
+      __syncthreads();
+      int before = 0, total = 0;
+      for (int w2 = 0; w2 < kThreads / 64; ++w2) {
+        const int cw = wcnt[w2];
+        if (w2 < wv) before += cw;
+        total += cw;
+      }
+      const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));   // rank of this match in sample order
+      int done = 0;  // matches of this chunk already parked
+      while (done < total) {
+        const int room = G - pending;
+        const int takec = (total - done) < room ? (total - done) : room;
+        if (m && pos >= done && pos < done + takec) skeys[pending + pos - done] = static_cast<uint32_t>(b);
+        __syncthreads();
+        pending += takec;
+        done += takec;
+        if (pending == G) {
+          flush_tile(G);
+          pending = 0;
+        }
+      }
+      __syncthreads();   // wcnt is rewritten by the next chunk
+    }
+    if (pending > 0) flush_tile(pending);
+    if (grp == 0) {
+      Strip<VEC> w, s, e;
+      float ww, sw;
+      load_row(row_hot, w, s, e, ww, sw);
+      apply_row(row_hot, tot, totf, totw, w, s, e, ww, sw);
+    }
   }
-  DCTR_TRACE(6);
 }
 
 // ---- X -> ids_t (standalone; the forward kernel fuses the same thing) -------------------------------
@@ -441,13 +566,11 @@ __global__ __launch_bounds__(kThreads) void k_embed_ids(const int32_t* __restric
   ids_t[i] = static_cast<int32_t>(X[static_cast<int64_t>(b) * ldx + units[4 * u + 2]]);
 }
 
-// ~64 entries (one tile) per workgroup up to B = 8192; beyond that every partition's workgroup would
-// re-scan too many ids, so partitions grow to ~256 entries (4 tiles).
+// ~64 entries per workgroup whatever the batch: one tile for the common lane layouts
 int pick_log2p(int B) {
   if (g_force_log2p >= 0) return g_force_log2p;
-  const int per = B > 8192 ? 256 : 64;
   int l = 0;
-  while ((B >> l) > per && l < 10) ++l;
+  while ((B >> l) > 64 && l < 12) ++l;
   return l;
 }
 
@@ -480,7 +603,7 @@ extern "C" int dctr_embed_update_supported(const dctr_plan_t* plan, int64_t max_
   if (plan->n_deep != plan->n_deep_fixed || plan->n_wide != plan->n_wide_fixed) return 0;
   if (plan->vec != 1 && plan->vec != 2 && plan->vec != 4) return 0;
   if (plan->n_deep > 0 && plan->max_dim > 64 * plan->vec) return 0;
-  if (B > 32768) return 0;
+  if (B > (1 << 20)) return 0;
   const int log2p = pick_log2p(B);
   const int bbits = ceil_log2(B < 2 ? 2 : B);
   if (ceil_log2(((max_vocab > 0 ? max_vocab : 1) >> log2p) + 1) + bbits > 32) return 0;
@@ -493,6 +616,8 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
                                  int64_t ld_s, const float* g_fm, const float* g_wide, int64_t ld_gw,
                                  int32_t opt, float lr, float eps, const float* X, int64_t ld_x, float* g_wdense,
                                  dctr_stream_t stream) {
+  (void)out;
+  (void)ld_out;  // kept in the signature: the forward's rows are no longer re-read (FM is folded algebraically)
   if (!plan || !units || !ids_t || n_units <= 0 || B < 0) return DCTR_EINVAL;
   if (g_wide && ld_gw < 1) return DCTR_EINVAL;
   if (g_wdense && (!X || !g_wide || plan->n_wdense <= 0 || !plan->wdense_cols)) return DCTR_EINVAL;
@@ -501,21 +626,18 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
   if (!dctr_embed_update_supported(plan, max_vocab, B)) return DCTR_ENOSUP;
   if (opt == DCTR_UPD_ACCUM && !(plan->flags & DCTR_PLAN_HAS_GACC)) return DCTR_EINVAL;
   if (opt == DCTR_UPD_ADAGRAD && !(plan->flags & DCTR_PLAN_HAS_STATE)) return DCTR_EINVAL;
-  if (g_fm && (!out || !fm_s || plan->emb_dim <= 0)) return DCTR_EINVAL;
+  if (g_fm && (!fm_s || plan->emb_dim <= 0)) return DCTR_EINVAL;
   int vec = plan->n_deep > 0 ? plan->vec : 1;
   const int avec = vec;  // alignment granule the caller guarantees
   if (vec == 4 && plan->emb_dim > 0 && plan->emb_dim % 8 == 0 && plan->emb_dim <= 64) vec = 8;  // two dwordx4 per lane
   if (avec > 1) {
-    const int vec = avec;
-    if (g_out && (ld_g % vec != 0 || reinterpret_cast<uintptr_t>(g_out) % (4 * vec) != 0)) return DCTR_EALIGN;
-    if (g_fm && (ld_out % vec != 0 || reinterpret_cast<uintptr_t>(out) % (4 * vec) != 0 ||
-                 ld_s % vec != 0 || reinterpret_cast<uintptr_t>(fm_s) % (4 * vec) != 0))
-      return DCTR_EALIGN;
+    if (g_out && (ld_g % avec != 0 || reinterpret_cast<uintptr_t>(g_out) % (4 * avec) != 0)) return DCTR_EALIGN;
+    if (g_fm && (ld_s % avec != 0 || reinterpret_cast<uintptr_t>(fm_s) % (4 * avec) != 0)) return DCTR_EALIGN;
   }
   UpdArgs a;
   a.deep = plan->deep; a.wide = plan->wide; a.units = units; a.ids_t = ids_t;
-  a.gout = g_out; a.out = out; a.fm_s = fm_s; a.gfm = g_fm; a.gwide = g_wide; a.ldgw = ld_gw;
-  a.ldg = ld_g; a.ldo = ld_out; a.lds_ = ld_s;
+  a.gout = g_out; a.fm_s = fm_s; a.gfm = g_fm; a.gwide = g_wide; a.ldgw = ld_gw;
+  a.ldg = ld_g; a.lds_ = ld_s;
   a.n_units = n_units; a.B = B;
   const int log2p = pick_log2p(B);
   a.log2p = log2p;
@@ -527,45 +649,19 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
   int lpr = 1;
   const int need = plan->n_deep > 0 ? (plan->max_dim + vec - 1) / vec : 1;
   while (lpr < need) lpr <<= 1;
-  int cap = 2;
-  while (cap < B) cap <<= 1;
-  const int g = kThreads / lpr;
-  auto lds_for = [&](int gt) {
-    return static_cast<size_t>(cap) * 4 + (static_cast<size_t>(gt) * lpr * vec + 3 * gt + lpr * vec + 4) * 4;
-  };
-  // 160 KB of LDS / 7 workgroups: with all of a launch's workgroups resident at once the kernel is one round of
-  // ~15 us workgroups instead of two.  Shrink the tile (never below half the lane groups) if that gets us there.
-  int gt = g;
-  constexpr size_t kBudget = 160 * 1024 / 7 - 64;
-  if (lds_for(g) > kBudget) {
-    int t = g;
-    while (t - 8 >= g / 2 && lds_for(t) > kBudget) t -= 8;
-    if (lds_for(t) <= kBudget) gt = t;
-  }
-  a.gt = gt;
-  const size_t lds = lds_for(gt);
-  if (lds > 150 * 1024) return DCTR_ENOSUP;
-  const dim3 grid((static_cast<unsigned>(n_units) << log2p) + (g_wdense ? static_cast<unsigned>(plan->n_wdense) : 0u)), block(kThreads);
+  const dim3 grid((static_cast<unsigned>(n_units) << log2p) + (g_wdense ? static_cast<unsigned>(plan->n_wdense) : 0u)),
+      block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
 
-#define DCTR_UPD_LAUNCH(VEC_, LPR_)                                                                   \
-  do {                                                                                                \
-    if (opt == DCTR_UPD_ADAGRAD) {                                                                    \
-      if (lds > 64 * 1024)                                                                            \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_embed_update<VEC_, LPR_, 1>),     \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
-      k_embed_update<VEC_, LPR_, 1><<<grid, block, lds, s>>>(a);                                      \
-    } else if (opt == DCTR_UPD_SGD) {                                                                 \
-      if (lds > 64 * 1024)                                                                            \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_embed_update<VEC_, LPR_, 0>),     \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
-      k_embed_update<VEC_, LPR_, 0><<<grid, block, lds, s>>>(a);                                      \
-    } else {                                                                                          \
-      if (lds > 64 * 1024)                                                                            \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_embed_update<VEC_, LPR_, 2>),     \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
-      k_embed_update<VEC_, LPR_, 2><<<grid, block, lds, s>>>(a);                                      \
-    }                                                                                                 \
+#define DCTR_UPD_LAUNCH(VEC_, LPR_)                               \
+  do {                                                            \
+    if (opt == DCTR_UPD_ADAGRAD) {                                \
+      k_embed_update<VEC_, LPR_, 1><<<grid, block, 0, s>>>(a);    \
+    } else if (opt == DCTR_UPD_SGD) {                             \
+      k_embed_update<VEC_, LPR_, 0><<<grid, block, 0, s>>>(a);    \
+    } else {                                                      \
+      k_embed_update<VEC_, LPR_, 2><<<grid, block, 0, s>>>(a);    \
+    }                                                             \
   } while (0)
 
 #define DCTR_UPD_LPR(VEC_)                      \
@@ -578,7 +674,6 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
     case 32: DCTR_UPD_LAUNCH(VEC_, 32); break;  \
     default: DCTR_UPD_LAUNCH(VEC_, 64); break;  \
   }
-
 #define DCTR_UPD_LPR8()                       \
   switch (lpr) {                              \
     case 1: DCTR_UPD_LAUNCH(8, 1); break;     \
