@@ -70,6 +70,34 @@ int g_force_log2p = -1;
     if (A.trace && tid == 0) A.trace[blockIdx.x * 8ull + (slot)] = wall_clock64(); \
   } while (0)
 
+// Values that are the same for every lane of the workgroup (descriptor fields fetched through a pointer the
+// compiler cannot prove uniform): pin them to scalar registers, 64-byte descriptors otherwise cost ~30 VGPRs.
+__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uni(int64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32));
+  return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+template <typename T>
+__device__ __forceinline__ T* uni(T* p) {
+  return reinterpret_cast<T*>(uni(static_cast<int64_t>(reinterpret_cast<uintptr_t>(p))));
+}
+__device__ __forceinline__ dctr_field_t uni_field(const dctr_field_t& f) {
+  dctr_field_t r;
+  r.table = uni(f.table);
+  r.gacc = uni(f.gacc);
+  r.state = uni(f.state);
+  r.vocab = uni(f.vocab);
+  r.dim = uni(f.dim);
+  r.col = 0;
+  r.len = 1;
+  r.pool = 0;
+  r.len_col = -1;
+  r.out_off = uni(f.out_off);
+  r.pad_[0] = r.pad_[1] = 0;
+  return r;
+}
+
 __device__ __forceinline__ int32_t clamp_id(int32_t id, int64_t vocab) {
   return (static_cast<uint64_t>(static_cast<int64_t>(id)) >= static_cast<uint64_t>(vocab)) ? 0 : id;
 }
@@ -99,9 +127,9 @@ __device__ __forceinline__ void apply_strip(const dctr_field_t& fd, int64_t off,
   }
 }
 
-// (7 workgroups of 4 waves per CU: <= 72 VGPRs)
+// (6 workgroups of 4 waves per CU: <= 80 VGPRs; a bound of 7 spills ~40 registers in the Adagrad variant)
 template <int VEC, int LPR, int OPT>
-__global__ __launch_bounds__(kThreads, 7) void k_embed_update(UpdArgs A) {
+__global__ __launch_bounds__(kThreads, 6) void k_embed_update(UpdArgs A) {
   constexpr int G = kThreads / LPR;   // lane groups per workgroup = entries per tile (a power of two)
   constexpr int RW = LPR * VEC;       // floats of one parked gradient row
   __shared__ uint32_t keys[kCap];     // this pass's entries; sorted in place by the tiled path
@@ -144,10 +172,10 @@ __global__ __launch_bounds__(kThreads, 7) void k_embed_update(UpdArgs A) {
   if (u >= A.n_units) return;
 
   const int32_t* un = A.units + 4 * u;
-  const int di = un[0], wi = un[1];
-  dctr_field_t fd, fw;
-  if (di >= 0) fd = A.deep[di];
-  if (wi >= 0) fw = A.wide[wi];
+  const int di = uni(un[0]), wi = uni(un[1]);
+  dctr_field_t fd = {}, fw = {};
+  if (di >= 0) fd = uni_field(A.deep[di]);
+  if (wi >= 0) fw = uni_field(A.wide[wi]);
   const int64_t vocab = (di >= 0) ? fd.vocab : fw.vocab;
   const int B = A.B;
   const int32_t* ids = A.ids_t + static_cast<int64_t>(u) * B;
@@ -247,8 +275,6 @@ __global__ __launch_bounds__(kThreads, 7) void k_embed_update(UpdArgs A) {
       if ((id & (P - 1)) == p && (idq & mmask) == static_cast<uint32_t>(mres)) {
         const int slot = atomicAdd(&n_sh, 1);  // LDS atomic; the order is fixed by the sort below
         if (slot < kCap) keys[slot] = (idq << A.bbits) | static_cast<uint32_t>(b);
-        atomicMin(&mn_sh, static_cast<int>(idq));   // the id range decides what an overflowing pass does
-        atomicMax(&mx_sh, static_cast<int>(idq));
       }
     };
     if ((B & 3) == 0) {
@@ -454,6 +480,27 @@ __global__ __launch_bounds__(kThreads, 7) void k_embed_update(UpdArgs A) {
 
     // ---- more entries than LDS keys ----------------------------------------------------------------------------
     first_pass = false;
+    {  // the id range of this pass decides what happens next (a second scan: only overflowing passes pay for it)
+      int lo = 0x7FFFFFFF, hi = -1;
+      for (int b = tid; b < B; b += kThreads) {
+        const int32_t id = clamp_id(ldg_i32(ids + b), vocab);
+        const uint32_t idq = static_cast<uint32_t>(id) >> A.log2p;
+        if ((id & (P - 1)) == p && (idq & mmask) == static_cast<uint32_t>(mres)) {
+          lo = min(lo, static_cast<int>(idq));
+          hi = max(hi, static_cast<int>(idq));
+        }
+      }
+#pragma unroll
+      for (int m2 = 32; m2 >= 1; m2 >>= 1) {
+        lo = min(lo, __shfl_xor(lo, m2, kWave));
+        hi = max(hi, __shfl_xor(hi, m2, kWave));
+      }
+      if ((tid & 63) == 0) {
+        atomicMin(&mn_sh, lo);
+        atomicMax(&mx_sh, hi);
+      }
+      __syncthreads();
+    }
     if (mn_sh != mx_sh) {
       // several ids: fix one more bit of id / P and do the two halves one after the other
       if (tid == 0) {
