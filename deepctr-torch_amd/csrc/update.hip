@@ -51,7 +51,9 @@ struct UpdArgs {
   const float* gwide;    // [B] (stride ldgw) nullable
   int64_t ldgw;
   int64_t ldg, lds_;
-  int32_t n_units, B, log2p, bbits;
+  int32_t n_units, B, P, bbits;   // P partitions per unit (any positive number)
+  uint64_t pmagic;                // floor(2^pshift / P) + 1: id / P == (id * pmagic) >> pshift for 0 <= id < 2^31
+  int32_t pshift;
   float lr, eps;
   // optional extra role (last blocks): d loss / d Linear.weight = X_dense^T g_wide  (basemodel.py:88-90)
   const float* X;
@@ -63,7 +65,7 @@ struct UpdArgs {
 };
 
 unsigned long long* g_trace = nullptr;  // host-side: set by dctr_dbg_update_trace
-int g_force_log2p = -1;
+int g_force_p = -1;
 
 #define DCTR_TRACE(slot)                                                           \
   do {                                                                             \
@@ -96,6 +98,12 @@ __device__ __forceinline__ dctr_field_t uni_field(const dctr_field_t& f) {
   r.out_off = uni(f.out_off);
   r.pad_[0] = r.pad_[1] = 0;
   return r;
+}
+
+// id / P and id % P for a runtime P through a host-computed reciprocal (exact for 0 <= id < 2^31)
+__device__ __forceinline__ uint32_t div_p(uint32_t id, uint64_t magic, int shift) {
+  const uint64_t lo = (magic & 0xFFFFFFFFull) * id, hi = (magic >> 32) * id;
+  return static_cast<uint32_t>(((lo >> 32) + hi) >> (shift - 32));
 }
 
 __device__ __forceinline__ int32_t clamp_id(int32_t id, int64_t vocab) {
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_embed_update(UpdArgs A) {
   __shared__ int stack[kStack][2];
   __shared__ int n_sh, mn_sh, mx_sh, carry_id, sp_sh, wcnt[kThreads / 64];
   const int tid = threadIdx.x;
-  const int P = 1 << A.log2p;
+  const int P = A.P;
   DCTR_TRACE(0);
 
   if (A.g_wdense && static_cast<int>(blockIdx.x) >= static_cast<int>(gridDim.x) - A.n_wdense) {
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_embed_update(UpdArgs A) {
 
   // Work item (unit, partition) in plain launch order: consecutive workgroups go to consecutive XCDs, so every
   // XCD gets the same number of working workgroups.
-  const int u = static_cast<int>(blockIdx.x) >> A.log2p, p = static_cast<int>(blockIdx.x) & (P - 1);
+  const int u = static_cast<int>(blockIdx.x) / P, p = static_cast<int>(blockIdx.x) - u * P;
   if (u >= A.n_units) return;
 
   const int32_t* un = A.units + 4 * u;
@@ -271,8 +279,9 @@ __global__ __launch_bounds__(kThreads, 6) void k_embed_update(UpdArgs A) {
     const uint32_t mmask = (1u << mbits) - 1u;
     auto take = [&](int32_t raw, int b) {
       const int32_t id = clamp_id(raw, vocab);
-      const uint32_t idq = static_cast<uint32_t>(id) >> A.log2p;
-      if ((id & (P - 1)) == p && (idq & mmask) == static_cast<uint32_t>(mres)) {
+      const uint32_t idq = div_p(static_cast<uint32_t>(id), A.pmagic, A.pshift);
+      if (static_cast<int>(static_cast<uint32_t>(id) - idq * static_cast<uint32_t>(P)) == p &&
+          (idq & mmask) == static_cast<uint32_t>(mres)) {
         const int slot = atomicAdd(&n_sh, 1);  // LDS atomic; the order is fixed by the sort below
         if (slot < kCap) keys[slot] = (idq << A.bbits) | static_cast<uint32_t>(b);
       }
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_embed_update(UpdArgs A) {
       const uint32_t key = have ? keys[grp] : 0xFFFFFFFFu;
       const int b = static_cast<int>(key & bmask);
       const int idq = static_cast<int>(key >> A.bbits);
-      const int64_t row = (static_cast<int64_t>(idq) << A.log2p) | p;
+      const int64_t row = static_cast<int64_t>(idq) * P + p;
       Strip<VEC> h, w, s, e;
       float gf, gw, ww, sw;
       if (have) {
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_embed_update(UpdArgs A) {
         const uint32_t key = have ? keys[i] : 0u;
         const int b = static_cast<int>(key & bmask);
         const int idq = static_cast<int>(key >> A.bbits);
-        const int64_t row = (static_cast<int64_t>(idq) << A.log2p) | p;
+        const int64_t row = static_cast<int64_t>(idq) * P + p;
         const bool last_of_tile = have && ((grp == G - 1) || (i == n - 1));
         const bool seg_end = have && ((i == n - 1) || (static_cast<int>(keys[i + 1] >> A.bbits) != idq));
         Strip<VEC> h, w, s, e;
@@ -484,8 +493,9 @@ __global__ __launch_bounds__(kThreads, 6) void k_embed_update(UpdArgs A) {
       int lo = 0x7FFFFFFF, hi = -1;
       for (int b = tid; b < B; b += kThreads) {
         const int32_t id = clamp_id(ldg_i32(ids + b), vocab);
-        const uint32_t idq = static_cast<uint32_t>(id) >> A.log2p;
-        if ((id & (P - 1)) == p && (idq & mmask) == static_cast<uint32_t>(mres)) {
+        const uint32_t idq = div_p(static_cast<uint32_t>(id), A.pmagic, A.pshift);
+        if (static_cast<int>(static_cast<uint32_t>(id) - idq * static_cast<uint32_t>(P)) == p &&
+            (idq & mmask) == static_cast<uint32_t>(mres)) {
           lo = min(lo, static_cast<int>(idq));
           hi = max(hi, static_cast<int>(idq));
         }
@@ -518,7 +528,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_embed_update(UpdArgs A) {
     // a hot id: all n > kCap entries hit ONE row.  Stream over the batch in sample order, G matching samples at a
     // time; each tile is reduced by a fixed tree and added to the running sum kept by lane group 0.
     const int idq_hot = mn_sh;
-    const int64_t row_hot = (static_cast<int64_t>(idq_hot) << A.log2p) | p;
+    const int64_t row_hot = static_cast<int64_t>(idq_hot) * P + p;
     const int32_t id_hot = static_cast<int32_t>(row_hot);
     Strip<VEC> tot = strip_zero<VEC>();
     float totf = 0.f, totw = 0.f;
@@ -613,12 +623,14 @@ __global__ __launch_bounds__(kThreads) void k_embed_ids(const int32_t* __restric
   ids_t[i] = static_cast<int32_t>(X[static_cast<int64_t>(b) * ldx + units[4 * u + 2]]);
 }
 
-// ~64 entries per workgroup whatever the batch: one tile for the common lane layouts
-int pick_log2p(int B) {
-  if (g_force_log2p >= 0) return g_force_log2p;
-  int l = 0;
-  while ((B >> l) > 64 && l < 12) ++l;
-  return l;
+// Partitions per unit: ~3/4 of a tile per workgroup (a partition's size is Poisson-like: mean 96 of 128 leaves
+// 3.3 sigma of head room), whatever the batch.  P need not be a power of two.
+int pick_p(int B, int tile) {
+  if (g_force_p > 0) return g_force_p;
+  int per = tile * 3 / 4;
+  if (per < 1) per = 1;
+  int P = (B + per - 1) / per;
+  return P < 1 ? 1 : P;
 }
 
 int ceil_log2(int64_t x) {
@@ -640,9 +652,9 @@ extern "C" int dctr_embed_ids(const int32_t* units, int32_t n_units, const float
 }
 
 // diagnostics: per-workgroup phase timestamps (8 x u64 per workgroup, wall_clock64 ticks) and a partition override
-extern "C" void dctr_dbg_update_trace(unsigned long long* buf, int32_t force_log2p) {
+extern "C" void dctr_dbg_update_trace(unsigned long long* buf, int32_t force_p) {
   g_trace = buf;
-  g_force_log2p = force_log2p;
+  g_force_p = force_p;
 }
 
 extern "C" int dctr_embed_update_supported(const dctr_plan_t* plan, int64_t max_vocab, int32_t B) {
@@ -651,9 +663,10 @@ extern "C" int dctr_embed_update_supported(const dctr_plan_t* plan, int64_t max_
   if (plan->vec != 1 && plan->vec != 2 && plan->vec != 4) return 0;
   if (plan->n_deep > 0 && plan->max_dim > 64 * plan->vec) return 0;
   if (B > (1 << 20)) return 0;
-  const int log2p = pick_log2p(B);
+  if (max_vocab >= (int64_t(1) << 31)) return 0;
+  const int P = pick_p(B, kThreads);   // the smallest P any lane layout would use: the widest keys
   const int bbits = ceil_log2(B < 2 ? 2 : B);
-  if (ceil_log2(((max_vocab > 0 ? max_vocab : 1) >> log2p) + 1) + bbits > 32) return 0;
+  if (ceil_log2((max_vocab > 0 ? max_vocab : 1) / P + 2) + bbits > 32) return 0;
   return 1;
 }
 
@@ -686,8 +699,6 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
   a.gout = g_out; a.fm_s = fm_s; a.gfm = g_fm; a.gwide = g_wide; a.ldgw = ld_gw;
   a.ldg = ld_g; a.lds_ = ld_s;
   a.n_units = n_units; a.B = B;
-  const int log2p = pick_log2p(B);
-  a.log2p = log2p;
   a.bbits = ceil_log2(B < 2 ? 2 : B);
   a.lr = lr; a.eps = eps;
   a.trace = g_trace;
@@ -696,7 +707,12 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
   int lpr = 1;
   const int need = plan->n_deep > 0 ? (plan->max_dim + vec - 1) / vec : 1;
   while (lpr < need) lpr <<= 1;
-  const dim3 grid((static_cast<unsigned>(n_units) << log2p) + (g_wdense ? static_cast<unsigned>(plan->n_wdense) : 0u)),
+  const int P = pick_p(B, kThreads / lpr);
+  a.P = P;
+  a.pshift = 32 + ceil_log2(P);
+  a.pmagic = static_cast<uint64_t>((static_cast<unsigned __int128>(1) << a.pshift) / static_cast<unsigned>(P)) + 1;
+  const dim3 grid(static_cast<unsigned>(n_units) * static_cast<unsigned>(P) +
+                      (g_wdense ? static_cast<unsigned>(plan->n_wdense) : 0u)),
       block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
 

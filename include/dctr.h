@@ -165,8 +165,8 @@ int dctr_embed_apply(const dctr_plan_t* plan, const float* X, int64_t ldx, int32
 int dctr_embed_update_supported(const dctr_plan_t* plan, int64_t max_vocab, int32_t B);
 /* diagnostics (tools/upd_trace.py): buf != NULL makes every workgroup of dctr_embed_update record 8 u64
  * (wall_clock64 at start / scan / sort / loads issued / loads landed / tile 0 done / end, then its entry count);
- * force_log2p >= 0 overrides the partition count.  dctr_dbg_update_trace(NULL, -1) restores normal operation.  */
-void dctr_dbg_update_trace(unsigned long long* buf, int32_t force_log2p);
+ * force_p > 0 overrides the number of partitions per unit.  dctr_dbg_update_trace(NULL, -1) restores normal operation.  */
+void dctr_dbg_update_trace(unsigned long long* buf, int32_t force_p);
 int dctr_embed_ids(const int32_t* units, int32_t n_units, const float* X, int64_t ldx, int32_t B,
                    int32_t* ids_t, dctr_stream_t stream);
 int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, int32_t n_units, int64_t max_vocab,

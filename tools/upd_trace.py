@@ -76,13 +76,13 @@ def main():
         return {"avg_us": sum(ts) / n, "min_us": ts[0], "med_us": ts[n // 2], "max_us": ts[-1]}
 
     res = {"B": B, "opt": a.opt, "fwd_same_batch": timed(fwd, False), "fwd_rotating": timed(fwd, True)}
-    for lp in (-1, 5, 6, 7, 8):
+    for lp in (-1, 32, 43, 64, 128):      # partitions per unit (-1: the library's choice)
         lib.dctr_dbg_update_trace(None, lp)
-        res["upd_log2p_%d_same_batch" % lp] = timed(upd, False)
-        res["upd_log2p_%d_rotating" % lp] = timed(upd, True)
+        res["upd_P_%d_same_batch" % lp] = timed(upd, False)
+        res["upd_P_%d_rotating" % lp] = timed(upd, True)
     # phase trace at the default partitioning, rotating batches
-    for lp in (-1, 7):
-        nwg = (26 << (6 if lp < 0 else lp)) + 16
+    for lp in (-1, 64):
+        nwg = 26 * ((B + 95) // 96 if lp < 0 else lp) + 16
         buf = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
         lib.dctr_dbg_update_trace(ctypes.c_void_p(buf.data_ptr()), lp)
         for j in range(8, 12):
@@ -100,7 +100,7 @@ def main():
             v = np.asarray(v, dtype="float64") * tick
             return {"mean": float(v.mean()), "p10": float(np.percentile(v, 10)), "p50": float(np.percentile(v, 50)),
                     "p90": float(np.percentile(v, 90)), "max": float(v.max())}
-        res["trace_log2p_%d" % lp] = {
+        res["trace_P_%d" % lp] = {
             "n_wg": int(len(live)), "n_working": int(len(work)),
             "entries": st(work[:, 7] / tick),
             "start_after_first": st(work[:, 0] - t0),
