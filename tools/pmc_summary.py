@@ -32,8 +32,11 @@ def load(counter):
 
 
 def short(name):
-    for key, tag in (("k_embed_fwd", "embed_fwd"), ("k_embed_update<4, 4, 1>", "embed_update_adagrad"),
-                     ("k_embed_update<4, 4, 0>", "embed_update_sgd"), ("k_embed_update", "embed_update"),
+    import re
+    m = re.search(r"k_embed_update<\d+, \d+, (\d)>", name)
+    if m:      # last template argument = the optimizer (0 SGD, 1 Adagrad, 2 accumulate)
+        return {"0": "embed_update_sgd", "1": "embed_update_adagrad"}.get(m.group(1), "embed_update_accum")
+    for key, tag in (("k_embed_fwd", "embed_fwd"), ("k_embed_update", "embed_update"),
                      ("CUDAFunctorOnSelf_add", "calib_stream"), ("sum_functor", "calib_reduce"),
                      ("vectorized_gather_kernel", "calib_gather")):
         if key in name:
