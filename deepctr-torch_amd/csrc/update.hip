@@ -135,9 +135,10 @@ __device__ __forceinline__ void apply_strip(const dctr_field_t& fd, int64_t off,
   }
 }
 
-// (6 workgroups of 4 waves per CU: <= 80 VGPRs; a bound of 7 spills ~40 registers in the Adagrad variant)
+// (5 workgroups of 4 waves per CU = 1280 resident, more than the ~1100 a launch has: <= 96 VGPRs, no spills;
+// tighter bounds spill 8-40 registers in the Adagrad variant, which shows up as +8 MB of scratch writes per launch)
 template <int VEC, int LPR, int OPT>
-__global__ __launch_bounds__(kThreads, 6) void k_embed_update(UpdArgs A) {
+__global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
   constexpr int G = kThreads / LPR;   // lane groups per workgroup = entries per tile (a power of two)
   constexpr int RW = LPR * VEC;       // floats of one parked gradient row
   __shared__ uint32_t keys[kCap];     // this pass's entries; sorted in place by the tiled path
