@@ -102,12 +102,12 @@ class A:
 for opt in ("adagrad", "sgd"):
     A.optimizer = opt
     model = bench.build_model(A, dev)
-    for Bsz in (4096, 32_768):
+    for Bsz in (4096, 32_768, 262_144):     # 262 144 = the saturating launch of SURVEY 8(d)
         A.batch = Bsz
         gen = torch.Generator().manual_seed(0)
-        X = torch.cat([torch.randint(0, A.vocab, (8 * Bsz, 26), generator=gen).float(), torch.rand(8 * Bsz, 13, generator=gen)],
+        X = torch.cat([torch.randint(0, A.vocab, ((8 if Bsz <= 32_768 else 2) * Bsz, 26), generator=gen).float(), torch.rand((8 if Bsz <= 32_768 else 2) * Bsz, 13, generator=gen)],
                       1).to(dev)
-        k = bench.time_hot_kernels(model, X, Bsz, 20, opt, ring=8)
+        k = bench.time_hot_kernels(model, X, Bsz, 20 if Bsz <= 32_768 else 6, opt, ring=8 if Bsz <= 32_768 else 2)
         alg = bench.algorithmic_bytes(Bsz, opt)
         for name in k:
             k[name]["gbs"] = alg[name] / (k[name]["min_us"] * 1e-6) / 1e9
