@@ -68,8 +68,21 @@ struct MlpArgs {
   int64_t ldg;
   float* gx;         // backward: [B, ldgx] nullable
   int64_t ldgx;
-  int rsx, rsh;      // LDS row strides (floats)
+  int rsx, rsh;      // LDS row strides (floats) of the forward
+  int rsd;           // LDS row stride of the backward-data pass
   unsigned long long* trace;
+};
+
+// head + loss of the fused train kernel (csrc/head.hip has the stand-alone version)
+struct HeadArgs {
+  const float* part0;   // [B] logit parts added before the tower's (nullable): linear, FM / CIN
+  const float* part1;
+  const float* bias;    // [1] nullable
+  const float* y;       // [B]
+  float* y_pred;        // [B]
+  float* g_logit;       // [B]
+  float* part_loss;     // [n workgroups] per-workgroup partial sums
+  float* part_gbias;    // [n workgroups]
 };
 
 __device__ __forceinline__ f32x4 ldg_f4(const float* p) { return *(const DCTR_GLOBAL f32x4*)p; }
@@ -184,8 +197,8 @@ __device__ __forceinline__ void fwd_dispatch(int nt, const float* As, int rs, in
   }
 }
 
-__global__ __launch_bounds__(kT) void k_mlp_fwd(MlpArgs A) {
-  extern __shared__ __align__(16) float smem[];
+// the forward of one 16-sample row tile; `logit_lds` (nullable): [16] LDS floats that receive the projection
+__device__ __forceinline__ void mlp_fwd_body(const MlpArgs& A, float* smem, float* logit_lds) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * kTM;
   const int rsx = A.rsx, rsh = A.rsh;
@@ -266,26 +279,35 @@ __global__ __launch_bounds__(kT) void k_mlp_fwd(MlpArgs A) {
     MLP_TRACE(A.trace, 4 + 3 * l);
     in = outb;
   }
-  if (A.w_out && A.logit) {  // dnn_linear: logit[b] = h_last[b, :] . w_out
+  if (A.w_out && (A.logit || logit_lds)) {  // dnn_linear: logit[b] = h_last[b, :] . w_out
     const LayerDev& Lt = A.L[A.n_layers - 1];
     for (int row = wv; row < kTM; row += kWaves) {
       float s = 0.f;
       for (int n = lane; n < Lt.N; n += 64) s += in[row * rsh + n] * ldg_f32(A.w_out + n);
       s = wave_sum(s);
-      if (lane == 0 && b0 + row < A.B) stg_f32(A.logit + b0 + row, s);
+      if (lane == 0) {
+        if (A.logit && b0 + row < A.B) stg_f32(A.logit + b0 + row, s);
+        if (logit_lds) logit_lds[row] = s;
+      }
     }
   }
   MLP_TRACE(A.trace, 15);
 }
 
+__global__ __launch_bounds__(kT) void k_mlp_fwd(MlpArgs A) {
+  extern __shared__ __align__(16) float smem[];
+  mlp_fwd_body(A, smem, nullptr);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // backward, data path: dH_l (gradient w.r.t. the pre-activation of layer l) for every layer, then d/d input
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kT) void k_mlp_bwd_data(MlpArgs A) {
-  extern __shared__ __align__(16) float smem[];
+// the backward-data pass of one row tile; `g_lds` (nullable): [16] LDS floats holding d loss / d logit of the tile's
+// rows (the fused train kernel) instead of A.g
+__device__ __forceinline__ void mlp_bwd_body(const MlpArgs& A, float* smem, const float* g_lds) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * kTM;
-  const int rs = A.rsh;
+  const int rs = A.rsd;
   float* d0 = smem;
   float* d1 = d0 + kTM * rs;
   const int top = A.n_layers - 1;
@@ -298,7 +320,8 @@ __global__ __launch_bounds__(kT) void k_mlp_bwd_data(MlpArgs A) {
       const int64_t b = b0 + r;
       float v = 0.f;
       if (b < A.B && n < Lt.N) {
-        const float gv = A.w_out ? ldg_f32(A.g + b) * ldg_f32(A.w_out + n) : ldg_f32(A.g + b * A.ldg + n);
+        const float gv = A.w_out ? (g_lds ? g_lds[r] : ldg_f32(A.g + b)) * ldg_f32(A.w_out + n)
+                                 : ldg_f32(A.g + b * A.ldg + n);
         v = gv;
         if (Lt.relu) v = ldg_f32(Lt.h + b * Lt.ldh + n) > 0.f ? gv : 0.f;
         if (Lt.dh) stg_f32(Lt.dh + b * Lt.ldh + n, v);
@@ -431,6 +454,52 @@ __global__ __launch_bounds__(kT) void k_mlp_bwd_data(MlpArgs A) {
     dout = t;
   }
   MLP_TRACE(A.trace, 15);
+}
+
+__global__ __launch_bounds__(kT) void k_mlp_bwd_data(MlpArgs A) {
+  extern __shared__ __align__(16) float smem[];
+  mlp_bwd_body(A, smem, nullptr);
+}
+
+// forward + prediction head + BCE(sum) + backward-data of one row tile in ONE launch (the fused train step): the
+// logits never leave the workgroup, d loss / d logit goes to the backward through LDS, and the head's own launch,
+// the backward's staging round trip and two kernel boundaries disappear.  Per-workgroup partial sums of the loss and
+// of d loss / d bias are reduced in fixed order by k_mlp_reduce.
+__global__ __launch_bounds__(kT) void k_mlp_train(MlpArgs A, HeadArgs Hd) {
+  extern __shared__ __align__(16) float smem[];
+  __shared__ float zl[kTM], gl[kTM];
+  mlp_fwd_body(A, smem, zl);
+  __syncthreads();
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * kTM + tid;
+    float li = 0.f, gz = 0.f;
+    if (tid < kTM && b < A.B) {
+      float z = 0.f;                       // ((linear + fm) + dnn) + bias: the reference's order of additions
+      if (Hd.part0) z += ldg_f32(Hd.part0 + b);
+      if (Hd.part1) z += ldg_f32(Hd.part1 + b);
+      z += zl[tid];
+      if (Hd.bias) z += ldg_f32(Hd.bias);
+      const float p = 1.f / (1.f + expf(-z));                     // at::sigmoid
+      const float t = ldg_f32(Hd.y + b);
+      const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);
+      li = (t - 1.f) * l1p - t * lp;                              // at::binary_cross_entropy
+      const float q = (1.f - p) * p;
+      gz = ((p - t) / fmaxf(q, 1e-12f)) * q;                      // bce backward (grad 1) x sigmoid backward
+      stg_f32(Hd.y_pred + b, p);
+      stg_f32(Hd.g_logit + b, gz);
+    }
+    if (tid < kTM) gl[tid] = gz;
+    li = group_sum<16>(li);
+    float gs = group_sum<16>(gz);
+    if (tid == 0) {
+      stg_f32(Hd.part_loss + blockIdx.x, li);
+      stg_f32(Hd.part_gbias + blockIdx.x, gs);
+    }
+  }
+  __threadfence_block();   // the saved activations written above are re-read as relu masks below
+  __syncthreads();
+  mlp_bwd_body(A, smem, gl);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -612,9 +681,35 @@ struct ReduceArgs {
   int64_t seg_len[2 * kMaxL + 1];  // floats of the segment that belong to the destination tensor
   float* seg_dst[2 * kMaxL + 1];   // nullable: skipped
   const float* part;
+  // fused train step: one extra workgroup sums the per-row-tile partials of the head
+  const float* head_loss;          // [n_head] nullable
+  const float* head_gbias;         // [n_head]
+  int n_head;
+  float* loss;                     // [1]
+  float* g_bias;                   // [1] nullable
 };
 
 __global__ __launch_bounds__(256) void k_mlp_reduce(ReduceArgs A) {
+  if (A.head_loss && blockIdx.x == gridDim.x - 1) {   // fixed-order tree over the row tiles' partial sums
+    __shared__ float red[2][4];
+    float l = 0.f, gsum = 0.f;
+    for (int k = threadIdx.x; k < A.n_head; k += 256) {
+      l += ldg_f32(A.head_loss + k);
+      gsum += ldg_f32(A.head_gbias + k);
+    }
+    l = wave_sum(l);
+    gsum = wave_sum(gsum);
+    if ((threadIdx.x & 63) == 0) {
+      red[0][threadIdx.x >> 6] = l;
+      red[1][threadIdx.x >> 6] = gsum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      stg_f32(A.loss, ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]);
+      if (A.g_bias) stg_f32(A.g_bias, ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]);
+    }
+    return;
+  }
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= A.seg_off[A.n_seg]) return;
   int sg = 0;
@@ -713,6 +808,7 @@ extern "C" int dctr_mlp_fwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, i
   const int K0p = round_up(m->layer[0].K, 16);
   a.rsx = (K0p < kKC ? K0p : kKC) + 4;
   a.rsh = round_up(max_width(m), 16) + 4;
+  a.rsd = 0;
   const size_t lds = static_cast<size_t>(kTM) * (a.rsx + 2 * a.rsh) * 4;
   if (lds > 160 * 1024) return DCTR_ENOSUP;
   if (lds > 64 * 1024)
@@ -728,12 +824,10 @@ extern "C" size_t dctr_mlp_bwd_workspace_floats(const dctr_mlp_t* m, int32_t B) 
   return static_cast<size_t>(P.slab) * P.S;
 }
 
-extern "C" int dctr_mlp_bwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g,
-                            int64_t ld_g, float* gx, int64_t ld_gx, float* workspace, dctr_stream_t stream) {
-  const int rc = check_mlp(m, B);
-  if (rc != DCTR_OK) return rc;
-  if (!x || !g || !workspace || ld_x < m->layer[0].K) return DCTR_EINVAL;
-  if (!m->w_out && ld_g < m->layer[m->n_layers - 1].N) return DCTR_EINVAL;
+namespace {
+
+int check_bwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* gx, int64_t ld_gx) {
+  if (!x || ld_x < m->layer[0].K) return DCTR_EINVAL;
   if (gx && (ld_gx < m->layer[0].K)) return DCTR_EINVAL;
   if (gx && (ld_gx % 4 != 0 || reinterpret_cast<uintptr_t>(gx) % 16 != 0)) return DCTR_EALIGN;
   for (int l = 0; l < m->n_layers; ++l) {
@@ -741,32 +835,23 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, i
     if (!L.h || !L.dh || L.ld_h < L.N) return DCTR_EINVAL;
     if (L.ld_h % 4 != 0 || reinterpret_cast<uintptr_t>(L.h) % 16 != 0 || reinterpret_cast<uintptr_t>(L.dh) % 16 != 0)
       return DCTR_EALIGN;
+    // k_mlp_wgrad addresses its operands with 32-bit byte offsets
+    if (static_cast<int64_t>(B) * L.ld_h * 4 >= (int64_t(1) << 32)) return DCTR_ENOSUP;
   }
-  if (B == 0) return DCTR_OK;
-  // k_mlp_wgrad addresses its operands with 32-bit byte offsets
-  for (int l = 0; l < m->n_layers; ++l)
-    if (static_cast<int64_t>(B) * m->layer[l].ld_h * 4 >= (int64_t(1) << 32)) return DCTR_ENOSUP;
   if (static_cast<int64_t>(B) * ld_x * 4 >= (int64_t(1) << 32)) return DCTR_ENOSUP;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  {
-    MlpArgs a;
-    fill_layers(m, a.L);
-    a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = m->w_out; a.logit = nullptr;
-    a.g = g; a.ldg = ld_g; a.gx = gx; a.ldgx = ld_gx;
-    a.trace = g_mlp_trace ? g_mlp_trace + 16ull * 4096 : nullptr;
-    a.rsx = 0;
-    int w = max_width(m);
-    for (int l = 1; l < m->n_layers; ++l) w = m->layer[l].K > w ? m->layer[l].K : w;
-    a.rsh = round_up(w, 64) + 4;
-    const size_t lds = static_cast<size_t>(kTM) * 2 * a.rsh * 4;
-    if (lds > 160 * 1024) return DCTR_ENOSUP;
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd_data),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    k_mlp_bwd_data<<<dim3((B + kTM - 1) / kTM), dim3(kT), lds, s>>>(a);
-    const int st = launch_status();
-    if (st != DCTR_OK) return st;
-  }
+  return DCTR_OK;
+}
+
+int bwd_stride(const dctr_mlp_t* m) {
+  int w = max_width(m);
+  for (int l = 1; l < m->n_layers; ++l) w = m->layer[l].K > w ? m->layer[l].K : w;
+  return round_up(w, 64) + 4;
+}
+
+// weight gradients (split-batch partials) + their fixed-order reduction (+ the head's partials, fused step only)
+int launch_wgrad_reduce(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g,
+                        float* workspace, const float* head_loss, const float* head_gbias, int n_head, float* loss,
+                        float* g_bias, hipStream_t s) {
   const WgradPlan P = plan_wgrad(m, B);
   {
     WgradArgs a;
@@ -786,23 +871,104 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, i
     const int st = launch_status();
     if (st != DCTR_OK) return st;
   }
-  {
-    ReduceArgs r;
-    r.S = P.S; r.slab = P.slab; r.part = workspace;
-    int ns = 0;
-    for (int l = 0; l < m->n_layers; ++l) {
-      r.seg_off[ns] = P.off_w[l]; r.seg_len[ns] = static_cast<int64_t>(m->layer[l].N) * m->layer[l].ld_w;
-      r.seg_dst[ns++] = m->layer[l].gW;
-      r.seg_off[ns] = P.off_b[l]; r.seg_len[ns] = m->layer[l].N;
-      r.seg_dst[ns++] = m->layer[l].bias ? m->layer[l].gbias : nullptr;
-    }
-    if (m->w_out) {
-      r.seg_off[ns] = P.off_o; r.seg_len[ns] = m->layer[m->n_layers - 1].N;
-      r.seg_dst[ns++] = m->g_w_out;
-    }
-    r.seg_off[ns] = P.slab;
-    r.n_seg = ns;
-    k_mlp_reduce<<<dim3(static_cast<unsigned>((P.slab + 255) / 256)), dim3(256), 0, s>>>(r);
+  ReduceArgs r;
+  r.S = P.S; r.slab = P.slab; r.part = workspace;
+  int ns = 0;
+  for (int l = 0; l < m->n_layers; ++l) {
+    r.seg_off[ns] = P.off_w[l]; r.seg_len[ns] = static_cast<int64_t>(m->layer[l].N) * m->layer[l].ld_w;
+    r.seg_dst[ns++] = m->layer[l].gW;
+    r.seg_off[ns] = P.off_b[l]; r.seg_len[ns] = m->layer[l].N;
+    r.seg_dst[ns++] = m->layer[l].bias ? m->layer[l].gbias : nullptr;
   }
+  if (m->w_out) {
+    r.seg_off[ns] = P.off_o; r.seg_len[ns] = m->layer[m->n_layers - 1].N;
+    r.seg_dst[ns++] = m->g_w_out;
+  }
+  r.seg_off[ns] = P.slab;
+  r.n_seg = ns;
+  r.head_loss = head_loss; r.head_gbias = head_gbias; r.n_head = n_head; r.loss = loss; r.g_bias = g_bias;
+  const unsigned nblk = static_cast<unsigned>((P.slab + 255) / 256) + (head_loss ? 1u : 0u);
+  k_mlp_reduce<<<dim3(nblk), dim3(256), 0, s>>>(r);
   return launch_status();
+}
+
+}  // namespace
+
+extern "C" int dctr_mlp_bwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g,
+                            int64_t ld_g, float* gx, int64_t ld_gx, float* workspace, dctr_stream_t stream) {
+  const int rc = check_mlp(m, B);
+  if (rc != DCTR_OK) return rc;
+  if (!g || !workspace) return DCTR_EINVAL;
+  if (!m->w_out && ld_g < m->layer[m->n_layers - 1].N) return DCTR_EINVAL;
+  const int rb = check_bwd(m, x, ld_x, B, gx, ld_gx);
+  if (rb != DCTR_OK) return rb;
+  if (B == 0) return DCTR_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    MlpArgs a;
+    fill_layers(m, a.L);
+    a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = m->w_out; a.logit = nullptr;
+    a.g = g; a.ldg = ld_g; a.gx = gx; a.ldgx = ld_gx;
+    a.trace = g_mlp_trace ? g_mlp_trace + 16ull * 4096 : nullptr;
+    a.rsx = 0; a.rsh = 0;
+    a.rsd = bwd_stride(m);
+    const size_t lds = static_cast<size_t>(kTM) * 2 * a.rsd * 4;
+    if (lds > 160 * 1024) return DCTR_ENOSUP;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd_data),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    k_mlp_bwd_data<<<dim3((B + kTM - 1) / kTM), dim3(kT), lds, s>>>(a);
+    const int st = launch_status();
+    if (st != DCTR_OK) return st;
+  }
+  return launch_wgrad_reduce(m, x, ld_x, B, g, workspace, nullptr, nullptr, 0, nullptr, nullptr, s);
+}
+
+extern "C" size_t dctr_mlp_train_workspace_floats(const dctr_mlp_t* m, int32_t B) {
+  if (check_mlp(m, B) != DCTR_OK) return 0;
+  const WgradPlan P = plan_wgrad(m, B);
+  return static_cast<size_t>(P.slab) * P.S + 2 * static_cast<size_t>((B + kTM - 1) / kTM);
+}
+
+extern "C" int dctr_mlp_train_step(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* part0,
+                                   const float* part1, const float* bias, const float* y, float* y_pred, float* loss,
+                                   float* g_logit, float* g_bias, float* gx, int64_t ld_gx, float* workspace,
+                                   dctr_stream_t stream) {
+  const int rc = check_mlp(m, B);
+  if (rc != DCTR_OK) return rc;
+  if (!m->w_out || !y || !y_pred || !loss || !g_logit || !workspace) return DCTR_EINVAL;
+  if (ld_x % 4 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0) return DCTR_EALIGN;
+  const int rb = check_bwd(m, x, ld_x, B, gx, ld_gx);
+  if (rb != DCTR_OK) return rb;
+  if (B == 0) return DCTR_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const WgradPlan P = plan_wgrad(m, B);
+  const int n_tiles = (B + kTM - 1) / kTM;
+  float* part_loss = workspace + static_cast<size_t>(P.slab) * P.S;
+  float* part_gb = part_loss + n_tiles;
+  {
+    MlpArgs a;
+    fill_layers(m, a.L);
+    a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = m->w_out; a.logit = nullptr;
+    a.g = nullptr; a.ldg = 0; a.gx = gx; a.ldgx = ld_gx;
+    a.trace = g_mlp_trace;
+    const int K0p = round_up(m->layer[0].K, 16);
+    a.rsx = (K0p < kKC ? K0p : kKC) + 4;
+    a.rsh = round_up(max_width(m), 16) + 4;
+    a.rsd = bwd_stride(m);
+    const size_t lds_f = static_cast<size_t>(kTM) * (a.rsx + 2 * a.rsh) * 4;
+    const size_t lds_b = static_cast<size_t>(kTM) * 2 * a.rsd * 4;
+    const size_t lds = lds_f > lds_b ? lds_f : lds_b;
+    if (lds > 150 * 1024) return DCTR_ENOSUP;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_train), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(lds));
+    HeadArgs hd;
+    hd.part0 = part0; hd.part1 = part1; hd.bias = bias; hd.y = y; hd.y_pred = y_pred; hd.g_logit = g_logit;
+    hd.part_loss = part_loss; hd.part_gbias = part_gb;
+    k_mlp_train<<<dim3(n_tiles), dim3(kT), lds, s>>>(a, hd);
+    const int st = launch_status();
+    if (st != DCTR_OK) return st;
+  }
+  return launch_wgrad_reduce(m, x, ld_x, B, g_logit, workspace, part_loss, part_gb, n_tiles, loss, g_bias, s);
 }

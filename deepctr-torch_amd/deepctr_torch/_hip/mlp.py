@@ -217,6 +217,107 @@ def tower(dnn, dnn_linear, x, K=None, sink=None):
     return TowerFunction.apply(x, meta, *params)
 
 
+class PendingTower(object):
+    """What ``BaseModel.tower_logit`` returns while a fused train step is being assembled: the tower is not run yet,
+    it will run together with the head and its own backward in ``tower_head`` (one launch per row tile)."""
+
+    def __init__(self, dnn, dnn_linear, x, K, sink):
+        self.dnn, self.dnn_linear, self.x, self.K, self.sink = dnn, dnn_linear, x, K, sink
+
+
+class TowerHeadFunction(torch.autograd.Function):
+    """loss, y_pred = BCE(sum)(sigmoid(part0 + part1 + tower(x) + bias), y) with EVERYTHING of the tower done in the
+    forward call: tower forward, head, backward-data, weight gradients (written to the dense gradient slab).
+    ``backward`` only hands out the stored input gradients; valid because the train step differentiates
+    loss (+ regularisers that do not touch these inputs): the incoming gradient is exactly 1."""
+
+    @staticmethod
+    def forward(ctx, x, y, bias, meta, n_parts, *rest):
+        lib = L.lib()
+        parts, params = list(rest[:n_parts]), rest[n_parts:]
+        n = len(meta.relus)
+        Wp = [params[2 * l] for l in range(n)]
+        bp = [params[2 * l + 1] for l in range(n)]
+        w_out = params[2 * n]
+        sink = meta.sink
+        B, dev = x.shape[0], x.device
+        ctx.x_cols = x.shape[1]
+        if x.dtype != torch.float32 or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16 or x.stride(0) < meta.K:
+            buf = torch.zeros((B, _r4(meta.K)), dtype=torch.float32, device=dev)
+            buf[:, :meta.K].copy_(x[:, :meta.K])
+            x = buf
+        Ws, lds = [], []
+        for W in Wp:
+            w, ld = _rows4(W)
+            if w is not W:
+                raise RuntimeError("the fused train step needs slab-seated tower weights")
+            Ws.append(w)
+            lds.append(ld)
+        hs = [torch.empty((B, _r4(W.shape[0])), dtype=torch.float32, device=dev) for W in Wp]
+        dhs = [torch.empty_like(h) for h in hs]
+        gWs = [sink.grad_of(meta.param_refs[2 * l]) for l in range(n)]
+        gbs = [sink.grad_of(meta.param_refs[2 * l + 1]) if bp[l] is not None else None for l in range(n)]
+        g_wo = sink.grad_of(meta.param_refs[2 * n]).reshape(-1)
+        g_bias = sink.grad_of(meta.bias_ref) if bias is not None else None
+        ps = []
+        for p in parts:
+            q = p.reshape(-1)
+            if q.dtype != torch.float32 or not q.is_contiguous():
+                q = q.float().contiguous()
+            ps.append(q)
+        y = y.reshape(-1)
+        if y.dtype != torch.float32 or not y.is_contiguous():
+            y = y.float().contiguous()
+        wo = w_out.reshape(-1)
+        y_pred = torch.empty((B,), dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        g_logit = torch.empty((B,), dtype=torch.float32, device=dev)
+        gx = torch.empty((B, x.stride(0)), dtype=torch.float32, device=dev)
+        desc = L.Mlp()
+        _fill(desc, meta, Ws, lds, bp, hs, dhs, gWs, gbs, wo, g_wo)
+        ws = torch.empty((max(1, lib.dctr_mlp_train_workspace_floats(ctypes.byref(desc), B)),), dtype=torch.float32,
+                         device=dev)
+        pp = [_ptr(p) for p in ps] + [None] * (2 - len(ps))
+        L.check(lib.dctr_mlp_train_step(ctypes.byref(desc), _ptr(x), x.stride(0), B, pp[0], pp[1], _ptr(bias), _ptr(y),
+                                        _ptr(y_pred), _ptr(loss), _ptr(g_logit), _ptr(g_bias), _ptr(gx), gx.stride(0),
+                                        _ptr(ws), L.stream_handle(dev)), "dctr_mlp_train_step")
+        ctx.shapes = [tuple(p.shape) for p in parts]
+        ctx.n_rest = len(rest)
+        ctx.save_for_backward(gx, g_logit)
+        ctx.mark_non_differentiable(y_pred)
+        ctx.set_materialize_grads(False)
+        return loss, y_pred
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_pred):
+        gx, g_logit = ctx.saved_tensors
+        if g_loss is None:
+            return (None,) * (5 + ctx.n_rest)
+        if gx.shape[1] != ctx.x_cols:
+            gx = gx[:, :ctx.x_cols]
+        grads = [g_logit.view(s) for s in ctx.shapes]
+        return (gx, None, None, None, None) + tuple(grads) + (None,) * (ctx.n_rest - len(grads))
+
+
+def tower_head(pending, parts, bias, y):
+    """The fused tower + head + loss (see TowerHeadFunction).  ``parts``: at most two other logit parts."""
+    spec = tower_layers(pending.dnn, pending.dnn_linear)
+    layers, w_out = spec
+    params = []
+    for (W, b, _) in layers:
+        params += [W, b]
+    params.append(w_out)
+    meta = _Meta([r for (_, _, r) in layers], True, pending.K, pending.sink, params, True)
+    meta.bias_ref = bias
+    return TowerHeadFunction.apply(pending.x, y, bias, meta, len(parts), *(list(parts) + params))
+
+
+def fusable_head(pending, parts):
+    return (pending is not None and pending.sink is not None and len(parts) <= 2 and
+            tower_layers(pending.dnn, pending.dnn_linear) is not None and pending.dnn_linear is not None and
+            pending.x.is_cuda and pending.K <= 4096)
+
+
 class BCEHeadFunction(torch.autograd.Function):
     """(loss, y_pred) = BCE(sum)(sigmoid(sum(parts) + bias), y) in ONE launch; the launch also produces
     d loss / d logit, which ``backward`` hands to every part (valid because the train step differentiates

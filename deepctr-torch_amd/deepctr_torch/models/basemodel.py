@@ -118,6 +118,7 @@ class BaseModel(nn.Module):
         self.stop_training = False
         self._plan = None
         self._fit_graph = None    # hipGraph of the train step used by fit() for full-size batches
+        self._defer_tower = False
         self._grad_sink = None    # dense.DenseSlab while a fused train step runs
         self._fused = None        # cached state of the fused train step (see _fused_step_state)
 
@@ -160,7 +161,28 @@ class BaseModel(nn.Module):
     def tower_logit(self, x, K=None):
         """``self.dnn_linear(self.dnn(x[:, :K]))`` on the MFMA tower kernels (csrc/mlp.hip) when the tower is
         relu / linear without BatchNorm and dropout is inactive, else through the modules."""
+        if self._defer_tower and self._grad_sink is not None:
+            # fused train step: the tower runs later, together with the head and its own backward
+            return _mlp.PendingTower(self.dnn, self.dnn_linear, x, x.shape[1] if K is None else K, self._grad_sink)
         return _mlp.tower(self.dnn, self.dnn_linear, x, K, sink=self._grad_sink)
+
+    def fused_loss(self, xb, yb, slab):
+        """(loss, y_pred) of the fused train step: ``logit_parts`` with the tower deferred, then tower + head + BCE
+        (+ the tower's whole backward) as one op when the tower is the LAST summand and at most two parts precede
+        it (every model of this package), else tower and head as two ops."""
+        self._defer_tower = os.environ.get("DCTR_FUSED_HEAD", "1") != "0"
+        try:
+            parts = self.logit_parts(xb)
+        finally:
+            self._defer_tower = False
+        pend = parts[-1] if isinstance(parts[-1], _mlp.PendingTower) else None
+        if any(isinstance(p, _mlp.PendingTower) for p in parts[:-1]):
+            raise RuntimeError("logit_parts() must list the tower's logit last")
+        if pend is not None and _mlp.fusable_head(pend, parts[:-1]):
+            return _mlp.tower_head(pend, parts[:-1], self.out.bias, yb)
+        if pend is not None:
+            parts = list(parts[:-1]) + [_mlp.tower(pend.dnn, pend.dnn_linear, pend.x, pend.K, sink=pend.sink)]
+        return _mlp.bce_head(parts, self.out.bias, yb, unit=True, g_bias_sink=slab.grad_of(self.out.bias))
 
     def tower_hidden(self, x, K=None):
         """``self.dnn(x[:, :K])`` (no projection) on the same kernels."""
@@ -446,8 +468,7 @@ class BaseModel(nn.Module):
         self._grad_sink = slab
         plan.dense_sink = slab
         try:
-            parts = self.logit_parts(xb)
-            loss, y_pred = _mlp.bce_head(parts, self.out.bias, yb, unit=True, g_bias_sink=slab.grad_of(self.out.bias))
+            loss, y_pred = self.fused_loss(xb, yb, slab)
             loss.backward(gradient=st["one"])       # a resident 1.0: no fill launch per step
         finally:
             self._grad_sink = None

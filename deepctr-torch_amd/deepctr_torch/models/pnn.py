@@ -9,6 +9,7 @@ from ..layers import DNN, InnerProductLayer
 
 
 class PNN(BaseModel):
+    _fused_step_ok = True
     """Same arguments as the reference (models/pnn.py:38-40)."""
 
     def __init__(self, dnn_feature_columns, dnn_hidden_units=(128, 128), l2_reg_embedding=1e-5, l2_reg_dnn=0,

@@ -451,9 +451,7 @@ class ShardedTrainer(object):
         model._grad_sink = slab
         self._leaves = None
         try:
-            parts = model.logit_parts(self._x)
-            loss, y_pred = _mlp.bce_head(parts, model.out.bias, self._y, unit=True,
-                                         g_bias_sink=slab.grad_of(model.out.bias))
+            loss, y_pred = model.fused_loss(self._x, self._y, slab)
             loss.backward(gradient=st["one"])
         finally:
             model._grad_sink = None

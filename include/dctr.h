@@ -301,6 +301,18 @@ size_t dctr_mlp_bwd_workspace_floats(const dctr_mlp_t* m, int32_t B);
 int dctr_mlp_bwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g, int64_t ld_g,
                  float* gx, int64_t ld_gx, float* workspace, dctr_stream_t stream);
 
+/* The fused train step of a binary model whose logit is part0 + part1 + tower(x) + bias: tower forward, prediction
+ * head, BCE(sum), backward-data (ONE launch per 16-sample row tile: the logits never leave the workgroup), then the
+ * weight gradients and their reduction -- 3 launches for what dctr_mlp_fwd + dctr_bce_head + dctr_mlp_bwd do in 5.
+ * Outputs: y_pred [B], loss [1], g_logit [B] (= d loss / d part0 = d loss / d part1), g_bias [1] (nullable), gx,
+ * layer[l].gW / gbias, g_w_out.  Needs w_out and every layer's h / dh.
+ * workspace: dctr_mlp_train_workspace_floats(m, B) floats.                                                      */
+size_t dctr_mlp_train_workspace_floats(const dctr_mlp_t* m, int32_t B);
+int dctr_mlp_train_step(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* part0,
+                        const float* part1, const float* bias, const float* y, float* y_pred, float* loss,
+                        float* g_logit, float* g_bias, float* gx, int64_t ld_gx, float* workspace,
+                        dctr_stream_t stream);
+
 /* ---- prediction head + loss (layers/core.py:154-160, basemodel.py:254, F.binary_cross_entropy(reduction='sum'))
  *     z = sum_i part_i[b] + bias ;  y_pred = sigmoid(z) ;  loss = sum_b -(y log p + (1-y) log(1-p))   (logs clamped
  *     at -100 like ATen) ;  g_logit = d loss / d z as autograd computes it:

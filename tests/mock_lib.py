@@ -85,6 +85,20 @@ class MockLib(object):
             _arr(gx, (B, layers[0].K), ld_gx)[...] = gh
         return 0
 
+    def dctr_mlp_train_workspace_floats(self, mref, B):
+        return 16
+
+    def dctr_mlp_train_step(self, mref, x, ld_x, B, p0, p1, bias, y, y_pred, loss, g_logit, g_bias, gx, ld_gx, ws, stream):
+        """forward + head + backward in one call, composed from the pieces above."""
+        import torch
+        logit = torch.zeros(B)
+        lp = ctypes.c_void_p(logit.data_ptr())
+        self.dctr_mlp_fwd(mref, x, ld_x, B, lp, stream)
+        self.dctr_bce_head(p0, p1, lp, None, bias, y, B, y_pred, loss, g_logit, g_bias, stream)
+        self.dctr_mlp_bwd(mref, x, ld_x, B, g_logit, 0, gx, ld_gx, ws, stream)
+        self.calls = self.calls[:-3] + ["mlp_train_step"]
+        return 0
+
     # ---- head ---------------------------------------------------------------------------------------------
     def dctr_bce_head(self, p0, p1, p2, p3, bias, y, B, y_pred, loss, g_logit, g_bias, stream):
         self.calls.append("bce_head")

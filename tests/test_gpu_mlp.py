@@ -210,8 +210,9 @@ def test_fused_step_equals_autograd_step_and_reference(name, opt, monkeypatch):
     reference's 3-step trajectory, and equals the autograd + torch.optim step it replaces."""
     g = load_golden(name)
     runs = {}
-    for fused in ("1", "0"):
-        monkeypatch.setenv("DCTR_FUSED_STEP", fused)
+    for fused in ("1", "1h", "0"):      # fused step with the tower+head kernel, with separate tower / head, autograd
+        monkeypatch.setenv("DCTR_FUSED_STEP", fused[0])
+        monkeypatch.setenv("DCTR_FUSED_HEAD", "0" if fused == "1h" else "1")
         m = build_model(g["spec"], DEV)
         m.load_state_dict({k: torch.from_numpy(v) for k, v in g["params"].items()})
         m.compile(opt, "binary_crossentropy", metrics=[])
@@ -229,9 +230,10 @@ def test_fused_step_equals_autograd_step_and_reference(name, opt, monkeypatch):
     assert not f0
     if not f1:
         pytest.skip("%s is outside the fused step's envelope (no DNN / pooled fields)" % name)
-    sd1, sd0 = m1.state_dict(), m0.state_dict()
+    sd1, sd0, sdh = m1.state_dict(), m0.state_dict(), runs["1h"][0].state_dict()
     for k in sd0:
         _close("fused vs autograd: " + k, sd1[k].cpu().numpy(), sd0[k].cpu().numpy(), 2e-5)
+        _close("fused (separate head) vs autograd: " + k, sdh[k].cpu().numpy(), sd0[k].cpu().numpy(), 2e-5)
     ref = g["extra"]
     key = opt + "3/"
     n_ref = 0
