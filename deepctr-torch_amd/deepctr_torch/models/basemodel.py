@@ -438,6 +438,8 @@ class BaseModel(nn.Module):
             return None
         if not plan.unit_path or plan.update[0] not in ("sgd", "adagrad") or not plan.table_params:
             return None
+        if getattr(dnn, "dropout_rate", 0):     # the fused step is cached across train() / eval() switches
+            return None
         spec = _mlp.tower_layers(dnn, dnn_linear)
         if spec is None:
             return None
@@ -479,7 +481,9 @@ class BaseModel(nn.Module):
     def _train_step(self, xb, yb):
         """forward -> loss(sum) + reg + aux -> backward (fused sparse update inside) -> dense optimizer step
         (reference basemodel.py:242-262).  Returns device tensors; nothing is synchronised."""
-        if self.training and self._aux_is_default():
+        # (not tied to self.training: like the reference, fit() keeps training in eval mode after the first validation
+        # pass, basemodel.py:215,331; the fused step has no mode-dependent layer -- dropout / BatchNorm rule it out)
+        if self._aux_is_default():
             st = self._fused_step_state()
             if st is not None:
                 return self._train_step_fused(st, xb, yb)
@@ -502,8 +506,7 @@ class BaseModel(nn.Module):
         shape); everything else -- the ragged last batch, models outside the fused step, CPU-side debugging with
         DCTR_FIT_GRAPH=0 -- runs ``_train_step`` directly.  Same arithmetic either way (bit-identical results)."""
         g = self._fit_graph
-        if (xb.shape[0] != batch_size or not xb.is_cuda or not self.training or
-                os.environ.get("DCTR_FIT_GRAPH", "1") == "0"):
+        if xb.shape[0] != batch_size or not xb.is_cuda or os.environ.get("DCTR_FIT_GRAPH", "1") == "0":
             return self._train_step(xb, yb)
         if g is not None and g["graph"] is not None and g["graph"].valid_for(xb) and g["fused"] is self._fused:
             return g["graph"](xb, yb)
