@@ -110,12 +110,14 @@ def time_hot_kernels(model, X_all, B, iters, opt, ring=16):
         L.check(lib.dctr_embed_fwd(cplan, _ptr(Xb), Xb.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), 1, _ptr(fm),
                                    None, plan.units_ptr(), len(plan.units), _ptr(ids_t), _ptr(fm_s), DIM, s))
 
+    ws, ws_n = plan.update_workspace(B, dev)
+
     def upd(j):
         Xb, out, ids_t, fm_s = slots[j % ring]
         L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t), B,
                                       _ptr(g_out), plan.ld_out, _ptr(out), plan.ld_out, _ptr(fm_s), DIM, _ptr(g_fm),
                                       _ptr(g_wide), 1, L.UPD_ADAGRAD if opt == "adagrad" else L.UPD_SGD, lr, eps,
-                                      None, 0, None, s))
+                                      None, 0, None, _ptr(ws), ws_n, s))
 
     stages = [("embed_fwd", fwd), ("embed_update", upd)]
     for j in range(ring):       # every slot's side outputs exist before any update is timed

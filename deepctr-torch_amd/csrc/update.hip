@@ -39,6 +39,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kCap = 512;     // sort keys held in LDS
 constexpr int kStack = 40;    // pending (id bits fixed, their value) splits of an overflowing partition
+constexpr int kBucket = 256;  // keys per (unit, partition) bucket of the optional pre-pass (<= kCap)
 
 struct UpdArgs {
   const dctr_field_t* deep;
@@ -62,6 +63,9 @@ struct UpdArgs {
   int32_t n_wdense;
   float* g_wdense;
   unsigned long long* trace;  // diagnostics (tools/upd_trace.py): 8 timestamps per workgroup, or NULL
+  // optional pre-bucketed entries (k_bucket): bcnt [n_units * P] (zero at rest), bkeys [n_units * P][kBucket]
+  int32_t* bcnt;
+  uint32_t* bkeys;
 };
 
 unsigned long long* g_trace = nullptr;  // host-side: set by dctr_dbg_update_trace
@@ -275,9 +279,31 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
     }
     __syncthreads();
 
+    const uint32_t mmask = (1u << mbits) - 1u;
+    bool bucketed = false;
+    if (first_pass && A.bcnt) {
+      // the pre-pass (k_bucket) already collected this partition's keys: no scan over the unit's B ids.  The counter
+      // is left at zero for the next launch.  A bucket that overflowed falls back to the scan.
+      int32_t* cnt = A.bcnt + static_cast<int64_t>(u) * P + p;
+      if (tid == 0) {
+        const int nb = *(DCTR_GLOBAL int32_t*)cnt;
+        *(DCTR_GLOBAL int32_t*)cnt = 0;
+        n_sh = nb <= kBucket ? nb : -1;
+      }
+      __syncthreads();
+      const int nb = n_sh;
+      if (nb >= 0) {
+        const uint32_t* src = A.bkeys + (static_cast<int64_t>(u) * P + p) * kBucket;
+        for (int i = tid; i < nb; i += kThreads) keys[i] = *(const DCTR_GLOBAL uint32_t*)(src + i);
+        bucketed = true;
+      } else if (tid == 0) {
+        n_sh = 0;
+      }
+      __syncthreads();
+    }
     // ---- scan: collect the entries of (partition p, id/P mod 2^mbits == mres) ------------------------------------
     // All id loads of a chunk are issued before any is consumed: the scan costs one L2 round trip per chunk.
-    const uint32_t mmask = (1u << mbits) - 1u;
+    if (!bucketed) {
     auto take = [&](int32_t raw, int b) {
       const int32_t id = clamp_id(raw, vocab);
       const uint32_t idq = div_p(static_cast<uint32_t>(id), A.pmagic, A.pshift);
@@ -311,6 +337,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
       }
     } else {
       for (int b = tid; b < B; b += kThreads) take(ldg_i32(ids + b), b);
+    }
     }
     __syncthreads();
     const int n = n_sh;
@@ -614,6 +641,24 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
   }
 }
 
+// ---- optional pre-pass: bucket the (unit, sample) entries by partition ---------------------------------------------
+// One thread per entry; a bucket's fill order is whatever the atomics give (the update kernel sorts the keys).
+// Pays off when a workgroup's scan over the unit's B ids is the expensive part, i.e. for large (global) batches.
+__global__ __launch_bounds__(kThreads) void k_bucket(UpdArgs A) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (i >= static_cast<int64_t>(A.n_units) * A.B) return;
+  const int u = static_cast<int>(i / A.B), b = static_cast<int>(i - static_cast<int64_t>(u) * A.B);
+  const int32_t* un = A.units + 4 * u;
+  const int di = un[0], wi = un[1];
+  const int64_t vocab = (di >= 0) ? A.deep[di].vocab : A.wide[wi].vocab;
+  const int32_t id = clamp_id(ldg_i32(A.ids_t + i), vocab);
+  const uint32_t idq = div_p(static_cast<uint32_t>(id), A.pmagic, A.pshift);
+  const int p = static_cast<int>(static_cast<uint32_t>(id) - idq * static_cast<uint32_t>(A.P));
+  const int64_t bucket = static_cast<int64_t>(u) * A.P + p;
+  const int slot = atomicAdd(A.bcnt + bucket, 1);
+  if (slot < kBucket) A.bkeys[bucket * kBucket + slot] = (idq << A.bbits) | static_cast<uint32_t>(b);
+}
+
 // ---- X -> ids_t (standalone; the forward kernel fuses the same thing) -------------------------------
 __global__ __launch_bounds__(kThreads) void k_embed_ids(const int32_t* __restrict__ units, int n_units,
                                                         const float* __restrict__ X, int64_t ldx, int B,
@@ -671,12 +716,25 @@ extern "C" int dctr_embed_update_supported(const dctr_plan_t* plan, int64_t max_
   return 1;
 }
 
+// ints of the optional bucket workspace of dctr_embed_update for this plan / batch (must be zero before its first use;
+// the kernels leave the counters at zero)
+extern "C" int64_t dctr_embed_update_workspace_ints(const dctr_plan_t* plan, int32_t n_units, int32_t B) {
+  if (!plan || n_units <= 0 || B <= 0) return 0;
+  int vec = plan->n_deep > 0 ? plan->vec : 1;
+  if (vec == 4 && plan->emb_dim > 0 && plan->emb_dim % 8 == 0 && plan->emb_dim <= 64) vec = 8;
+  int lpr = 1;
+  const int need = plan->n_deep > 0 ? (plan->max_dim + vec - 1) / vec : 1;
+  while (lpr < need) lpr <<= 1;
+  const int P = pick_p(B, kThreads / lpr);
+  return static_cast<int64_t>(n_units) * P * (1 + kBucket);
+}
+
 extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, int32_t n_units,
                                  int64_t max_vocab, const int32_t* ids_t, int32_t B, const float* g_out,
                                  int64_t ld_g, const float* out, int64_t ld_out, const float* fm_s,
                                  int64_t ld_s, const float* g_fm, const float* g_wide, int64_t ld_gw,
                                  int32_t opt, float lr, float eps, const float* X, int64_t ld_x, float* g_wdense,
-                                 dctr_stream_t stream) {
+                                 int32_t* workspace, int64_t workspace_ints, dctr_stream_t stream) {
   (void)out;
   (void)ld_out;  // kept in the signature: the forward's rows are no longer re-read (FM is folded algebraically)
   if (!plan || !units || !ids_t || n_units <= 0 || B < 0) return DCTR_EINVAL;
@@ -716,6 +774,17 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
                       (g_wdense ? static_cast<unsigned>(plan->n_wdense) : 0u)),
       block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  a.bcnt = nullptr;
+  a.bkeys = nullptr;
+  const int64_t nbuckets = static_cast<int64_t>(n_units) * P;
+  if (workspace && workspace_ints >= nbuckets * (1 + kBucket)) {
+    a.bcnt = workspace;
+    a.bkeys = reinterpret_cast<uint32_t*>(workspace + nbuckets);
+    const int64_t ne = static_cast<int64_t>(n_units) * B;
+    k_bucket<<<dim3(static_cast<unsigned>((ne + kThreads - 1) / kThreads)), block, 0, s>>>(a);
+    const int st = launch_status();
+    if (st != DCTR_OK) return st;
+  }
 
 #define DCTR_UPD_LAUNCH(VEC_, LPR_)                               \
   do {                                                            \

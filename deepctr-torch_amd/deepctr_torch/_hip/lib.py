@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdctr_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 
@@ -70,7 +70,8 @@ SIGNATURES = {
     "dctr_dbg_update_trace": (None, [_P, _I32]),
     "dctr_embed_ids": (ctypes.c_int, [_P, _I32, _P, _I64, _I32, _P, _P]),
     "dctr_embed_update": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I32, _I64, _P, _I32, _P, _I64, _P, _I64, _P, _I64,
-                                         _P, _P, _I64, _I32, _F32, _F32, _P, _I64, _P, _P]),
+                                         _P, _P, _I64, _I32, _F32, _F32, _P, _I64, _P, _P, _I64, _P]),
+    "dctr_embed_update_workspace_ints": (ctypes.c_int64, [ctypes.POINTER(Plan), _I32, _I32]),
     "dctr_embed_bwd": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P,
                                       _I32, _F32, _P]),
     "dctr_embed_apply": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _I32, _F32, _F32, _P]),

@@ -136,10 +136,11 @@ class EmbedFunction(torch.autograd.Function):
             else:
                 raise RuntimeError("unknown sparse update mode %r" % (kind,))
             cplan = plan.bind(X.device)
+            ws, ws_n = plan.update_workspace(B, X.device)
             L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t), B,
                                           _ptr(g_out), ld_g, _ptr(out), plan.ld_out, _ptr(fm_s),
                                           fm_s.stride(0) if fm_s is not None else 0, _ptr(g_fm), _ptr(g_wide), 1,
-                                          opt, lr, eps, _ptr(X), X.stride(0), _ptr(g_wd), stream),
+                                          opt, lr, eps, _ptr(X), X.stride(0), _ptr(g_wd), _ptr(ws), ws_n, stream),
                     "dctr_embed_update")
             return None, None, None, g_w, None, None
 

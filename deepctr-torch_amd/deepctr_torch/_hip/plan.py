@@ -161,12 +161,13 @@ class EmbeddingPlan(object):
         self.anchor = None
         self._err = None
         self._wd_idx = None
+        self._upd_ws = {}
 
     # models holding a plan stay picklable (tests/utils.py:162-170 of the reference pickle whole models):
     # raw ctypes / device handles are dropped and re-baked lazily
     def __getstate__(self):
         d = dict(self.__dict__)
-        for k in ("_key", "_dev", "cplan", "anchor", "_err", "_wd_idx"):
+        for k in ("_key", "_dev", "cplan", "anchor", "_err", "_wd_idx", "_upd_ws"):
             d.pop(k, None)
         d["exchange"] = None
         d["sharder"] = None
@@ -331,6 +332,23 @@ class EmbeddingPlan(object):
 
     def units_ptr(self):
         return ctypes.c_void_p(self._dev["units"].data_ptr())
+
+    def update_workspace(self, B, device):
+        """(int32 tensor | None, n_ints): the optional bucket workspace of ``dctr_embed_update`` -- zero before its
+        first use, left zeroed by the kernels, so one tensor per (batch, device) serves every step.  Used for large
+        batches, where a workgroup's scan over the unit's B ids is the expensive part (DCTR_UPD_BUCKET=1 / 0 forces
+        it on / off)."""
+        import os
+        mode = os.environ.get("DCTR_UPD_BUCKET", "auto")
+        if mode == "0" or (mode != "1" and B < 8192):
+            return None, 0
+        key = (int(B), str(device))
+        ws = self._upd_ws.get(key)
+        if ws is None:
+            n = int(L.lib().dctr_embed_update_workspace_ints(ctypes.byref(self.cplan), len(self.units), int(B)))
+            ws = torch.zeros(max(n, 1), dtype=torch.int32, device=device)
+            self._upd_ws = {key: ws}          # one live workspace per plan
+        return ws, ws.numel()
 
     def update_kernel_ok(self, B):
         """True when the deterministic fused update (dctr_embed_update) can run this plan at batch ``B``."""

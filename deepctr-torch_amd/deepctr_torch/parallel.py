@@ -179,7 +179,7 @@ class DataParallelTrainer(object):
                                        _ptr(ids_t), stream), "dctr_embed_ids")
             L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t), NB,
                                           _ptr(G_all) if plan.deep else None, gathered.stride(0), None, 0, None, 0,
-                                          None, _ptr(gw_all) if plan.wide else None, 1, opt, lr, eps, None, 0, None, stream),
+                                          None, _ptr(gw_all) if plan.wide else None, 1, opt, lr, eps, None, 0, None, None, 0, stream),
                     "dctr_embed_update(global)")
         work.wait()
         model.optim.step()
@@ -329,9 +329,11 @@ class HipShardOps(object):
         if not sub.update_kernel_ok(NB):
             raise RuntimeError("global batch %d is beyond the deterministic update kernel" % NB)
         gw = self._ptr(grads_all, lay.wide_col) if lay.has_wide else None
+        ws, ws_n = sub.update_workspace(NB, dev)
         L.check(L.lib().dctr_embed_update(cplan, sub.units_ptr(), len(sub.units), sub.max_vocab, self._ptr(ids_t), NB,
                                           self._ptr(grads_all), lay.ldc, None, 0, None, 0, None, gw, lay.ldc, opt, lr,
-                                          eps, None, 0, None, L.stream_handle(dev)), "dctr_embed_update(owned tables)")
+                                          eps, None, 0, None, self._ptr(ws), ws_n, L.stream_handle(dev)),
+                "dctr_embed_update(owned tables)")
 
 
 class _Segment(object):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 4
+#define DCTR_ABI_VERSION 5
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -173,7 +173,12 @@ int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, int32_t n_u
                       const int32_t* ids_t, int32_t B, const float* g_out, int64_t ld_g, const float* out,
                       int64_t ld_out, const float* fm_s, int64_t ld_s, const float* g_fm,
                       const float* g_wide, int64_t ld_gw, int32_t opt, float lr, float eps, const float* X,
-                      int64_t ld_x, float* g_wdense, dctr_stream_t stream);
+                      int64_t ld_x, float* g_wdense, int32_t* workspace, int64_t workspace_ints,
+                      dctr_stream_t stream);
+/* workspace (nullable): dctr_embed_update_workspace_ints(plan, n_units, B) int32, ZERO before the first use (the
+ * kernels leave it ready for the next launch).  With it a pre-pass buckets the (unit, sample) entries by partition,
+ * so no workgroup scans a unit's B ids: worth it for large (global) batches; without it every workgroup scans.   */
+int64_t dctr_embed_update_workspace_ints(const dctr_plan_t* plan, int32_t n_units, int32_t B);
 
 /* ---- FM on an explicit [B, F, D] tensor (interaction.py:26-34) ------------------------------------
  * E is addressed as E[b*ld_b + f*D + d].  y[b] = 0.5 * sum_d((sum_f e)^2 - sum_f e^2).

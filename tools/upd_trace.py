@@ -52,11 +52,13 @@ def main():
     eps = float(plan.update[2]) if a.opt == "adagrad" else 0.0
     code = L.UPD_ADAGRAD if a.opt == "adagrad" else L.UPD_SGD
 
+    ws, ws_n = plan.update_workspace(B, dev)
+
     def upd(j):
         o, fs = outs[j]
         L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids[j]), B,
                                       _ptr(g_out), plan.ld_out, _ptr(o), plan.ld_out, _ptr(fs), 16, _ptr(g_fm),
-                                      _ptr(g_wide), 1, code, lr, eps, None, 0, None, s))
+                                      _ptr(g_wide), 1, code, lr, eps, None, 0, None, _ptr(ws), ws_n, s))
 
     def fwd(j):
         L.check(lib.dctr_embed_fwd(cplan, _ptr(X[j * B:]), X.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), 1, _ptr(fm),
