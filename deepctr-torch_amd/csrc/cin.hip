@@ -299,99 +299,212 @@ __global__ __launch_bounds__(kT, 1) void k_cin_bwd_data(const float* __restrict_
 }
 
 // -------------------------------------------------------------------------------------------------------------
-// backward, weight side:  gW[o, (h, m)] = sum_c gY[o, c] H[b, h, d] X0[b, m, d]
-// MFMA roles: rows i = o, columns j = m (padded to 32), reduction = c.  Workgroup (hg, q): its 4 waves own 4
-// consecutive h and walk the column blocks q, q+Q, ... of 64 columns staged in LDS (gY transposed to [c][o], X0 as
-// [c][32], H as [4][c]); every wave keeps gW[0:OB, (h, 0:32)] in 4 accumulators and adds it to gW once at the end.
+// backward, weight side:  gW[o, k = (h, m)] = sum_c gY[o, c] H[b, h, d] X0[b, m, d]        (c = (b, d))
+// A GEMM with 128 rows (o), K = h*M columns and a reduction over the B*D = 65536 batch columns: 27.9 GFLOP for
+// layer 1 of the Criteo shape.  MFMA roles (v_mfma_f32_32x32x2_f32): rows i = o, columns j = k, reduction = c.
+//   * k runs over the FLATTENED (h, m) index, so M = 26 is not padded to 32 (52 column tiles instead of 64);
+//     the B operand of an MFMA is still one v_mul per lane:  Z[c, k] = H[c, k / M] * X0[c, k % M].
+//   * a wave owns kWgNT = 2 column tiles x OT row tiles (8 independent accumulators at O = 128: the matrix pipe
+//     issues back to back); the 4 waves of a workgroup own 8 consecutive column tiles and share the staged gY block,
+//     so gY (the big operand, B*O*D floats + its relu mask) is re-read ceil(K / 256) times instead of h / 4 times.
+//   * workgroup (kx, q) walks the 64-column blocks q, q + Q, ...; Q is chosen so that two workgroups sit on every CU
+//     (one stages while the other multiplies).  Staging: a thread owns ONE column (b, d) of the block and walks o /
+//     m / h, a half-wave therefore writes 32 consecutive columns of an odd-pitch LDS row: conflict-free
+//     ds_write_b32, and a wave's load covers 64-byte runs of gA.
+//   * no atomics: every workgroup stores its partial [O, K] tile set to the workspace and k_cin_wgrad_reduce adds
+//     the Q partials in a fixed order (deterministic; 2 x 60 MB of traffic at the Criteo shape, ~10 % of the GEMM).
 // -------------------------------------------------------------------------------------------------------------
-template <int OT>
-__global__ __launch_bounds__(kT, 1) void k_cin_bwd_weight(const float* __restrict__ gA,
-                                                          const float* __restrict__ Asv, int64_t lda, int relu,
-                                                          const float* __restrict__ X0, int64_t ldx0,
-                                                          const float* __restrict__ H, int64_t ldh, int h, int M,
-                                                          int D, int B, int O, float* __restrict__ gW,
-                                                          float* __restrict__ gbias) {
-  constexpr int OB = OT * 32, OBP = OB + 1, CB = 64;
-  extern __shared__ __align__(16) float smem[];
-  float* gys = smem;             // [CB][OBP]
-  float* x0s = gys + CB * OBP;   // [CB][32]
-  float* hs = x0s + CB * 32;     // [4][CB]
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, p = lane >> 5, jl = lane & 31;
-  const int hh = blockIdx.x * 4 + wv;
-  const int64_t ncol = static_cast<int64_t>(B) * D;
-  const int64_t nblk = (ncol + CB - 1) / CB;
-  const int K = h * M;
+constexpr int kWgCB = 64;    // batch columns per staged block
+constexpr int kWgP = 129;    // floats per gys row  [c][o]   (odd pitch)
+constexpr int kWgPX = 33;    // floats per x0s row  [c][m]
+constexpr int kWgNT = 2;     // column tiles per wave
+constexpr int kWgKW = 4 * kWgNT * 32;   // k columns per workgroup
 
-  f32x16 acc[OT];
+template <int OT>
+__global__ __launch_bounds__(kT, 2) void k_cin_wgrad(const float* __restrict__ gA, const float* __restrict__ Asv,
+                                                     int64_t lda, int relu, const float* __restrict__ X0,
+                                                     int64_t ldx0, const float* __restrict__ H, int64_t ldh, int h,
+                                                     int M, int D, int B, int O, int hspan, int PH,
+                                                     float* __restrict__ part, float* __restrict__ bpart) {
+  constexpr int OB = OT * 32;
+  extern __shared__ __align__(16) float smem[];
+  float* gys = smem;                  // [CB][kWgP]
+  float* x0s = gys + kWgCB * kWgP;    // [CB][kWgPX]
+  float* hs = x0s + kWgCB * kWgPX;    // [CB][PH]
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, p = lane >> 5, jl = lane & 31;
+  const int64_t ncol = static_cast<int64_t>(B) * D;
+  const int64_t nblk = (ncol + kWgCB - 1) / kWgCB;
+  const int K = h * M;
+  const int k0 = blockIdx.x * kWgKW;
+  const int h0 = k0 / M;
+
+  // this lane's column of each of the wave's tiles
+  int hk[kWgNT], mk[kWgNT], kk[kWgNT];
+#pragma unroll
+  for (int nt = 0; nt < kWgNT; ++nt) {
+    const int k = k0 + (wv * kWgNT + nt) * 32 + jl;
+    kk[nt] = k;
+    const int kc = k < K ? k : k0;          // out-of-range columns read valid LDS and are never stored
+    const int hq = kc / M;
+    hk[nt] = hq - h0;
+    mk[nt] = kc - hq * M;
+  }
+  const bool wave_active = (k0 + wv * kWgNT * 32) < K;
+
+  f32x16 acc[OT][kWgNT];
 #pragma unroll
   for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[ot][r] = 0.f;
-  float bsum = 0.f;  // gbias partial of row o = tid (only block row 0 of the grid contributes)
+    for (int nt = 0; nt < kWgNT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ot][nt][r] = 0.f;
+  float bsum = 0.f;  // gbias partial of row o = tid (workgroup column 0 only)
 
+  const int cl = tid & (kWgCB - 1), q4 = tid >> 6;   // staging role: column cl, rows q4, q4 + 4, ...
   for (int64_t blk = blockIdx.y; blk < nblk; blk += gridDim.y) {
-    const int64_t c0 = blk * CB;
-    // stage gY^T, X0, H of this column block
-    for (int e = tid; e < CB * OB; e += kT) {
-      const int cl = e & (CB - 1), o = e >> 6;
-      const int64_t c = c0 + cl;
-      float v = 0.f;
-      if (c < ncol && o < O) {
-        const int64_t b = c / D;
-        const int d = static_cast<int>(c - b * D);
-        const int64_t off = b * lda + static_cast<int64_t>(o) * D + d;
-        v = ldg_f32(gA + off);
-        if (relu && !(ldg_f32(Asv + off) > 0.f)) v = 0.f;
-      }
-      gys[cl * OBP + o] = v;
+    const int64_t c = blk * kWgCB + cl;
+    const bool cvalid = c < ncol;
+    const int64_t b = cvalid ? c / D : 0;
+    const int d = cvalid ? static_cast<int>(c - b * D) : 0;
+    // Every load below is UNCONDITIONAL on a clamped address and masked afterwards with a select: predicated loads
+    // compile to a branch + s_waitcnt vmcnt(0) each, which serialises the staging into one memory round trip per row.
+    // X0[b, :, d] and H[b, h0 .. h0 + hspan, d]: issued first, parked in LDS after the gY loop (one round trip shared)
+    const float* xsrc = X0 + b * ldx0 + d;
+    const float* hsrc = H + b * ldh + d;
+    float x[8], hv[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int mm = q4 + 4 * i;
+      x[i] = ldg_f32(xsrc + (mm < M ? mm : M - 1) * D);
     }
-    for (int e = tid; e < CB * 32; e += kT) {
-      const int cl = e & (CB - 1), mm = e >> 6;
-      const int64_t c = c0 + cl;
-      float v = 0.f;
-      if (c < ncol && mm < M) {
-        const int64_t b = c / D;
-        v = ldg_f32(X0 + b * ldx0 + mm * D + (c - b * D));
-      }
-      x0s[cl * 32 + mm] = v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int hq = h0 + q4 + 4 * i;
+      hv[i] = ldg_f32(hsrc + static_cast<int64_t>(hq < h ? hq : h - 1) * D);
     }
-    {
-      const int cl = tid & (CB - 1), hl = tid >> 6;
-      const int64_t c = c0 + cl;
-      const int hq = blockIdx.x * 4 + hl;
-      float v = 0.f;
-      if (c < ncol && hq < h) {
-        const int64_t b = c / D;
-        v = ldg_f32(H + b * ldh + static_cast<int64_t>(hq) * D + (c - b * D));
+    {  // gY^T (masked by the saved activation when relu)
+      constexpr int CH = 8;   // 16 loads in flight per thread; 16 rows would spill at OT = 4
+      const float* ga = gA + b * lda + d;
+      const float* as = relu ? Asv + b * lda + d : ga;
+#pragma unroll 1
+      for (int i0 = 0; i0 < OB / 4; i0 += CH) {
+        float g[CH], a[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int o = q4 + 4 * (i0 + i);
+          const int oc = o < O ? o : O - 1;
+          g[i] = ldg_f32(ga + static_cast<int64_t>(oc) * D);
+        }
+        if (relu) {
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            const int o = q4 + 4 * (i0 + i);
+            const int oc = o < O ? o : O - 1;
+            a[i] = ldg_f32(as + static_cast<int64_t>(oc) * D);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < CH; ++i) a[i] = 1.f;
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int o = q4 + 4 * (i0 + i);
+          const bool keep = cvalid && o < O && a[i] > 0.f;
+          gys[cl * kWgP + o] = keep ? g[i] : 0.f;
+        }
       }
-      hs[hl * CB + cl] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x0s[cl * kWgPX + q4 + 4 * i] = cvalid ? x[i] : 0.f;   // rows m >= M are never read
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int hl = q4 + 4 * i;
+      if (hl < hspan) hs[cl * PH + hl] = (cvalid && h0 + hl < h) ? hv[i] : 0.f;
+    }
+    for (int hl = q4 + 16; hl < hspan; hl += 4) {     // only when M is small (hspan > 16)
+      const int hq = h0 + hl < h ? h0 + hl : h - 1;
+      const float v = ldg_f32(hsrc + static_cast<int64_t>(hq) * D);
+      hs[cl * PH + hl] = (cvalid && h0 + hl < h) ? v : 0.f;
     }
     __syncthreads();
-    if (gbias && blockIdx.x == 0 && tid < OB) {
+    if (bpart && blockIdx.x == 0 && tid < OB) {
 #pragma unroll 8
-      for (int cl = 0; cl < CB; ++cl) bsum += gys[cl * OBP + tid];
+      for (int cc = 0; cc < kWgCB; ++cc) bsum += gys[cc * kWgP + tid];
     }
-    if (hh < h) {
+    if (wave_active) {
 #pragma unroll 4
-      for (int ks = 0; ks < CB / 2; ++ks) {
-        const int cl = 2 * ks + p;
-        const float z = hs[wv * CB + cl] * x0s[cl * 32 + jl];
+      for (int ks = 0; ks < kWgCB / 2; ++ks) {
+        const int cc = 2 * ks + p;
+        float a[OT], z[kWgNT];
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma32(gys[cl * OBP + ot * 32 + jl], z, acc[ot]);
+        for (int ot = 0; ot < OT; ++ot) a[ot] = gys[cc * kWgP + ot * 32 + jl];
+#pragma unroll
+        for (int nt = 0; nt < kWgNT; ++nt) z[nt] = hs[cc * PH + hk[nt]] * x0s[cc * kWgPX + mk[nt]];
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+          for (int nt = 0; nt < kWgNT; ++nt) acc[ot][nt] = mfma32(a[ot], z[nt], acc[ot][nt]);
       }
     }
     __syncthreads();
   }
-  if (hh < h && jl < M) {
+  // partial tiles of this workgroup: part[q][o][k]
+  float* dst = part + static_cast<int64_t>(blockIdx.y) * O * K;
+  if (wave_active) {
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot)
+    for (int nt = 0; nt < kWgNT; ++nt) {
+      if (kk[nt] < K) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = ot * 32 + acc_row(r, p);
-        if (o < O) atomic_add_f32(gW + static_cast<int64_t>(o) * K + hh * M + jl, acc[ot][r]);
+        for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = ot * 32 + acc_row(r, p);
+            if (o < O) stg_f32(dst + static_cast<int64_t>(o) * K + kk[nt], acc[ot][nt][r]);
+          }
       }
+    }
   }
-  if (gbias && blockIdx.x == 0 && tid < OB && tid < O) atomic_add_f32(gbias + tid, bsum);
+  if (bpart && blockIdx.x == 0 && tid < O) stg_f32(bpart + static_cast<int64_t>(blockIdx.y) * O + tid, bsum);
+}
+
+// out[i] = sum_q part[q][i], q ascending (four interleaved chains, combined in a fixed order)
+__global__ __launch_bounds__(kT) void k_cin_wgrad_reduce(const float* __restrict__ part, int Q, int64_t n,
+                                                         float* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+  if (i >= n) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int q = 0;
+  for (; q + 4 <= Q; q += 4) {
+    s0 += ldg_f32(part + (q + 0) * n + i);
+    s1 += ldg_f32(part + (q + 1) * n + i);
+    s2 += ldg_f32(part + (q + 2) * n + i);
+    s3 += ldg_f32(part + (q + 3) * n + i);
+  }
+  for (; q < Q; ++q) s0 += ldg_f32(part + q * n + i);
+  stg_f32(out + i, (s0 + s1) + (s2 + s3));
+}
+
+// launch geometry of the weight-side kernels (shared by the workspace query and the launcher)
+struct WgradGeom {
+  int gx, q, hspan, ph;
+  size_t lds;
+};
+inline WgradGeom wgrad_geom(int B, int h, int M, int D) {
+  WgradGeom g;
+  const int K = h * M;
+  g.gx = (K + kWgKW - 1) / kWgKW;
+  const int64_t nblk = (static_cast<int64_t>(B) * D + kWgCB - 1) / kWgCB;
+  int64_t q = 512 / g.gx;
+  if (q < 1) q = 1;
+  if (q > nblk) q = nblk;
+  if (q < 1) q = 1;
+  g.q = static_cast<int>(q);
+  int hs = (kWgKW - 1) / M + 2;
+  if (hs > h) hs = h;
+  g.hspan = hs;
+  g.ph = hs | 1;
+  g.lds = (static_cast<size_t>(kWgCB) * (kWgP + kWgPX + g.ph)) * sizeof(float);
+  return g;
 }
 
 }  // namespace
@@ -399,6 +512,13 @@ __global__ __launch_bounds__(kT, 1) void k_cin_bwd_weight(const float* __restric
 extern "C" size_t dctr_cin_workspace_floats(int32_t h, int32_t M, int32_t O) {
   const size_t M_pad = (M + 1) / 2 * 2, O_pad = (O + 31) / 32 * 32;
   return static_cast<size_t>(h) * M_pad * O_pad;
+}
+
+extern "C" size_t dctr_cin_bwd_workspace_floats(int32_t B, int32_t h, int32_t M, int32_t D, int32_t O) {
+  if (B <= 0 || h <= 0 || M <= 0 || D <= 0 || O <= 0) return 0;
+  const WgradGeom g = wgrad_geom(B, h, M, D);
+  const size_t o_chunk = O < 128 ? O : 128;
+  return static_cast<size_t>(g.q) * o_chunk * (static_cast<size_t>(h) * M + 1);
 }
 
 extern "C" int dctr_cin_layer_fwd(const float* H, int64_t ld_h, const float* X0, int64_t ld_x0, const float* W,
@@ -443,20 +563,25 @@ extern "C" int dctr_cin_layer_bwd(const float* gA, const float* A, int64_t ld_a,
                                   int64_t ld_h, const float* X0, int64_t ld_x0, const float* W, int32_t B,
                                   int32_t h, int32_t M, int32_t D, int32_t O, float* gH, int64_t ld_gh,
                                   float* gX0, int64_t ld_gx, int32_t accumulate_x0, float* gW, float* gbias,
-                                  dctr_stream_t stream) {
+                                  float* workspace, dctr_stream_t stream) {
   if (!gA || !H || !X0 || !W || !gH || !gX0 || !gW || B < 0 || h <= 0 || M <= 0 || D <= 0 || O <= 0)
     return DCTR_EINVAL;
+  if (B > 0 && !workspace) return DCTR_EINVAL;
   if (relu && !A) return DCTR_EINVAL;
   if (M > 32) return DCTR_ENOSUP;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int K = h * M;
-  hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * static_cast<size_t>(O) * K, s);
-  if (e != hipSuccess) return static_cast<int>(e);
-  if (gbias) {
-    e = hipMemsetAsync(gbias, 0, sizeof(float) * static_cast<size_t>(O), s);
+  if (B == 0) {   // an empty batch has zero gradients
+    hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * static_cast<size_t>(O) * K, s);
     if (e != hipSuccess) return static_cast<int>(e);
+    if (gbias) {
+      e = hipMemsetAsync(gbias, 0, sizeof(float) * static_cast<size_t>(O), s);
+      if (e != hipSuccess) return static_cast<int>(e);
+    }
+    return DCTR_OK;
   }
-  if (B == 0) return DCTR_OK;
+  const WgradGeom geo = wgrad_geom(B, h, M, D);
+  if (geo.lds > 160u * 1024u) return DCTR_ENOSUP;
   const int64_t ncol = static_cast<int64_t>(B) * D;
   const int chunks = (O + 127) / 128;
   for (int ch = 0; ch < chunks; ++ch) {
@@ -476,21 +601,26 @@ extern "C" int dctr_cin_layer_bwd(const float* gA, const float* A, int64_t ld_a,
       switch (ot) { case 1: DCTR_CIN_BD(1); break; case 2: DCTR_CIN_BD(2); break; case 3: DCTR_CIN_BD(3); break; default: DCTR_CIN_BD(4); break; }
 #undef DCTR_CIN_BD
     }
-    // weight side
+    // weight side: Q partial [o_here, K] tile sets (+ bias partials) in the workspace, then a fixed-order sum
     {
-      const int hgroups = (h + 3) / 4;
-      const int64_t nblk = (ncol + 63) / 64;
-      int64_t q = 512 / hgroups;
-      if (q < 1) q = 1;
-      if (q > nblk) q = nblk;
-      const dim3 grid(hgroups, static_cast<unsigned>(q));
-      const size_t lds = (64u * (ot * 32 + 1) + 64u * 32 + 4u * 64) * sizeof(float);
-      float* gW_c = gW + static_cast<int64_t>(o0) * K;
-      float* gb_c = gbias ? gbias + o0 : nullptr;
-#define DCTR_CIN_BW(OT_) k_cin_bwd_weight<OT_><<<grid, dim3(kT), lds, s>>>(gA_c, A_c, ld_a, relu, X0, ld_x0, H, ld_h, h, M, \
-                                                                         D, B, o_here, gW_c, gb_c)
+      const dim3 grid(geo.gx, geo.q);
+      float* part = workspace;
+      float* bpart = gbias ? workspace + static_cast<size_t>(geo.q) * o_here * K : nullptr;
+#define DCTR_CIN_BW(OT_)                                                                                              \
+  do {                                                                                                                \
+    if (geo.lds > 64u * 1024u)                                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cin_wgrad<OT_>),                                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(geo.lds));               \
+    k_cin_wgrad<OT_><<<grid, dim3(kT), geo.lds, s>>>(gA_c, A_c, ld_a, relu, X0, ld_x0, H, ld_h, h, M, D, B, o_here,   \
+                                                     geo.hspan, geo.ph, part, bpart);                                 \
+  } while (0)
       switch (ot) { case 1: DCTR_CIN_BW(1); break; case 2: DCTR_CIN_BW(2); break; case 3: DCTR_CIN_BW(3); break; default: DCTR_CIN_BW(4); break; }
 #undef DCTR_CIN_BW
+      const int64_t n = static_cast<int64_t>(o_here) * K;
+      k_cin_wgrad_reduce<<<dim3(static_cast<unsigned>((n + kT - 1) / kT)), dim3(kT), 0, s>>>(
+          part, geo.q, n, gW + static_cast<int64_t>(o0) * K);
+      if (gbias)
+        k_cin_wgrad_reduce<<<dim3(1), dim3(kT), 0, s>>>(bpart, geo.q, o_here, gbias + o0);
     }
   }
   return launch_status();

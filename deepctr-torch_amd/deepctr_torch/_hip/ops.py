@@ -305,9 +305,10 @@ class CINLayerFunction(torch.autograd.Function):
         gX0 = torch.empty((B, M, D), dtype=torch.float32, device=dev)
         gW = torch.empty((O, h * M), dtype=torch.float32, device=dev)
         gb = torch.empty((O,), dtype=torch.float32, device=dev) if ctx.has_bias else None
+        ws = torch.empty((max(1, lib.dctr_cin_bwd_workspace_floats(B, h, M, D, O)),), dtype=torch.float32, device=dev)
         L.check(lib.dctr_cin_layer_bwd(_ptr(gA), _ptr(A), O * D, int(ctx.relu), _ptr(H), ldh, _ptr(X0), ldx, _ptr(W2d),
                                        B, h, M, D, O, _ptr(gH), h * D, _ptr(gX0), M * D, 0, _ptr(gW), _ptr(gb),
-                                       L.stream_handle(dev)), "dctr_cin_layer_bwd")
+                                       _ptr(ws), L.stream_handle(dev)), "dctr_cin_layer_bwd")
         return gH, gX0, gW, gb, None
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 5
+#define DCTR_ABI_VERSION 6
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -200,15 +200,18 @@ int dctr_fm_bwd(const float* E, int64_t ld_b, int32_t B, int32_t F, int32_t D, c
  * Backward, given gA = d loss / d A (and the saved A when relu):
  *   gH   [B, h, D]  (written)      gX0 [B, M, D] (accumulated: += when accumulate_x0 != 0)
  *   gW   [O, h*M]   (written)      gbias [O]     (written, nullable)
- * gA and A share the leading dimension ld_a.                                                         */
+ * gA and A share the leading dimension ld_a.  The backward needs dctr_cin_bwd_workspace_floats(B, h, M, D, O)
+ * floats of scratch: the weight gradient is a [O, h*M] x (B*D) GEMM whose batch reduction is split over
+ * workgroups; their partial tiles go to the workspace and are summed in a fixed order (no atomics).     */
 size_t dctr_cin_workspace_floats(int32_t h, int32_t M, int32_t O);
+size_t dctr_cin_bwd_workspace_floats(int32_t B, int32_t h, int32_t M, int32_t D, int32_t O);
 int dctr_cin_layer_fwd(const float* H, int64_t ld_h, const float* X0, int64_t ld_x0, const float* W,
                        const float* bias, int32_t B, int32_t h, int32_t M, int32_t D, int32_t O, int32_t relu,
                        float* A, int64_t ld_a, float* workspace, dctr_stream_t stream);
 int dctr_cin_layer_bwd(const float* gA, const float* A, int64_t ld_a, int32_t relu, const float* H, int64_t ld_h,
                        const float* X0, int64_t ld_x0, const float* W, int32_t B, int32_t h, int32_t M, int32_t D,
                        int32_t O, float* gH, int64_t ld_gh, float* gX0, int64_t ld_gx, int32_t accumulate_x0,
-                       float* gW, float* gbias, dctr_stream_t stream);
+                       float* gW, float* gbias, float* workspace, dctr_stream_t stream);
 
 /* ---- SENET / Bilinear / InnerProduct (csrc/pairwise.hip) ----------------------------------------------
  * SENETLayer (interaction.py:93-101): z = mean_d E; a1 = relu(z W1^T); a = relu(a1 W2^T); V = E * a[:, :, None]
