@@ -74,7 +74,17 @@ __global__ __launch_bounds__(kT, 1) void k_cin_fwd(const float* __restrict__ X0,
     const int64_t b = v ? c / D : 0;
     const int d = v ? static_cast<int>(c - b * D) : 0;
     const float* src = X0 + b * ldx0 + d;
-    for (int mm = 0; mm < M_pad; ++mm) x0s[mm * kCols + tid] = (v && mm < M) ? ldg_f32(src + mm * D) : 0.f;
+    // unconditional loads on clamped rows, 16 in flight, masked afterwards: a predicated load compiles to a branch
+    // with its own s_waitcnt vmcnt(0), i.e. one memory round trip per field
+#pragma unroll 1
+    for (int m0 = 0; m0 < M_pad; m0 += 16) {
+      float t[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] = ldg_f32(src + (m0 + i < M ? m0 + i : M - 1) * D);
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (m0 + i < M_pad) x0s[(m0 + i) * kCols + tid] = (v && m0 + i < M) ? t[i] : 0.f;
+    }
   }
   // weight slice of h = 0
   f32x4 wreg[OT];
@@ -99,9 +109,13 @@ __global__ __launch_bounds__(kT, 1) void k_cin_fwd(const float* __restrict__ X0,
   };
   fetch_w(0);
   park_w(0);
+  // (columns past the end sit on b = 0, d = 0: their loads are valid, their results are never stored)
   float hv[2], hnext[2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) hv[t] = cv[t] ? ldg_f32(H + hoff[t]) : 0.f;
+  for (int t = 0; t < 2; ++t) hv[t] = ldg_f32(H + hoff[t]);
+  // hv must have ARRIVED before the loop: if its first use sits inside the loop, the s_waitcnt vmcnt(0) for it is
+  // placed there and then also waits, in every iteration, for the prefetch of the next weight slice
+  asm volatile("" : "+v"(hv[0]), "+v"(hv[1]));
   __syncthreads();
 
   f32x16 acc[OT][2];
@@ -118,7 +132,7 @@ __global__ __launch_bounds__(kT, 1) void k_cin_fwd(const float* __restrict__ X0,
     if (more) {
       fetch_w(hh + 1);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) hnext[t] = cv[t] ? ldg_f32(H + hoff[t] + static_cast<int64_t>(hh + 1) * D) : 0.f;
+      for (int t = 0; t < 2; ++t) hnext[t] = ldg_f32(H + hoff[t] + static_cast<int64_t>(hh + 1) * D);
     }
     const float* wc = ws + (hh & 1) * chunk;
     for (int s = 0; s < M_pad / 2; ++s) {
@@ -140,23 +154,31 @@ __global__ __launch_bounds__(kT, 1) void k_cin_fwd(const float* __restrict__ X0,
     __syncthreads();
   }
 
-  // epilogue: + bias, activation, store A[b, o, d]
+  // epilogue: + bias, activation, store A[b, o, d].  The bias goes through LDS (the loop's last barrier has retired
+  // every read of x0s): 64 dependent scalar loads in this epilogue would be 64 serial round trips.
+  if (tid < OB) x0s[tid] = (bias && o_base + tid < O) ? ldg_f32(bias + o_base + tid) : 0.f;
+  __syncthreads();
+  int64_t bcol[2];
+  int dcol[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int64_t c = c_base + wv * 64 + t * 32 + jl;
+    bcol[t] = cv[t] ? c / D : 0;
+    dcol[t] = cv[t] ? static_cast<int>(c - bcol[t] * D) : 0;
+  }
 #pragma unroll
   for (int ot = 0; ot < OT; ++ot) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int o = o_base + ot * 32 + acc_row(r, p);
       if (o < O) {
-        const float bo = bias ? ldg_f32(bias + o) : 0.f;
+        const float bo = x0s[ot * 32 + acc_row(r, p)];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           if (cv[t]) {
-            const int64_t c = c_base + wv * 64 + t * 32 + jl;
-            const int64_t b = c / D;
-            const int d = static_cast<int>(c - b * D);
             float y = acc[ot][t][r] + bo;
             if (relu) y = y > 0.f ? y : 0.f;
-            stg_f32(A + b * lda + static_cast<int64_t>(o) * D + d, y);
+            stg_f32(A + bcol[t] * lda + static_cast<int64_t>(o) * D + dcol[t], y);
           }
         }
       }
@@ -197,20 +219,36 @@ __global__ __launch_bounds__(kT, 1) void k_cin_bwd_data(const float* __restrict_
     bb[t] = cv[t] ? c / D : 0;
     dd[t] = cv[t] ? static_cast<int>(c - bb[t] * D) : 0;
   }
-  // gY of this lane's columns: o = 2*s + p
+  // gY of this lane's columns: o = 2*s + p.  Unconditional loads on clamped addresses, masked afterwards (a
+  // predicated load is a branch with its own s_waitcnt vmcnt(0): 128 serial round trips in this prologue otherwise).
   float gy[2][NS];
+  const float* mask_src = relu ? Asv : gA;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
+    const int64_t base = bb[t] * lda + dd[t];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int o = 2 * s + p;
-      float v = 0.f;
-      if (cv[t] && o < O) {
-        const int64_t off = bb[t] * lda + static_cast<int64_t>(o) * D + dd[t];
-        v = ldg_f32(gA + off);
-        if (relu && !(ldg_f32(Asv + off) > 0.f)) v = 0.f;
+    for (int s0 = 0; s0 < NS; s0 += 16) {
+      float a[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int o = 2 * (s0 + i) + p;
+        gy[t][s0 + i] = ldg_f32(gA + base + static_cast<int64_t>(o < O ? o : O - 1) * D);
       }
-      gy[t][s] = v;
+      if (relu) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int o = 2 * (s0 + i) + p;
+          a[i] = ldg_f32(mask_src + base + static_cast<int64_t>(o < O ? o : O - 1) * D);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = 1.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int o = 2 * (s0 + i) + p;
+        gy[t][s0 + i] = (cv[t] && o < O && a[i] > 0.f) ? gy[t][s0 + i] : 0.f;
+      }
     }
   }
   // X0 rows matching this lane's accumulator rows
@@ -220,7 +258,8 @@ __global__ __launch_bounds__(kT, 1) void k_cin_bwd_data(const float* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int mm = acc_row(r, p);
-      x0r[t][r] = (cv[t] && mm < M) ? ldg_f32(X0 + bb[t] * ldx0 + mm * D + dd[t]) : 0.f;
+      const float v = ldg_f32(X0 + bb[t] * ldx0 + (mm < M ? mm : M - 1) * D + dd[t]);
+      x0r[t][r] = (cv[t] && mm < M) ? v : 0.f;
       gxa[t][r] = 0.f;
     }
 
@@ -242,7 +281,8 @@ __global__ __launch_bounds__(kT, 1) void k_cin_bwd_data(const float* __restrict_
   park_w(0);
   float hv[2], hnext[2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) hv[t] = cv[t] ? ldg_f32(H + bb[t] * ldh + dd[t]) : 0.f;
+  for (int t = 0; t < 2; ++t) hv[t] = ldg_f32(H + bb[t] * ldh + dd[t]);
+  asm volatile("" : "+v"(hv[0]), "+v"(hv[1]));   // arrived before the loop (see k_cin_fwd)
   __syncthreads();
 
   for (int hh = 0; hh < h; ++hh) {
@@ -250,8 +290,7 @@ __global__ __launch_bounds__(kT, 1) void k_cin_bwd_data(const float* __restrict_
     if (more) {
       fetch_w(hh + 1);
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-        hnext[t] = cv[t] ? ldg_f32(H + bb[t] * ldh + static_cast<int64_t>(hh + 1) * D + dd[t]) : 0.f;
+      for (int t = 0; t < 2; ++t) hnext[t] = ldg_f32(H + bb[t] * ldh + static_cast<int64_t>(hh + 1) * D + dd[t]);
     }
     const float* wc = wl + (hh & 1) * (OB * 32);
     f32x16 acc[2];

@@ -34,12 +34,67 @@ __device__ __forceinline__ int row_stride(int F, int D) {
   return rs;
 }
 
-// copy the [16, F*D] tile of samples b0.. into LDS (zeros past B)
+// copy the [16, F*D] tile of samples b0.. (b0 < B) into LDS (zeros past B).  Eight UNCONDITIONAL loads per thread are
+// in flight at a time (rows past B are clamped to B-1 and masked afterwards): a predicated load compiles to a
+// branch with its own s_waitcnt vmcnt(0), which made this copy 26 serial memory round trips.
 __device__ __forceinline__ void stage_rows(float* dst, int RS, const float* __restrict__ src, int64_t ld, int b0,
                                            int B, int W) {
-  for (int e = threadIdx.x; e < kSB * W; e += kT) {
-    const int r = e / W, c = e - r * W;
-    dst[r * RS + c] = (b0 + r < B) ? ldg_f32(src + static_cast<int64_t>(b0 + r) * ld + c) : 0.f;
+  const int n = kSB * W;
+  for (int e0 = threadIdx.x; e0 < n; e0 += 8 * kT) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * kT;
+      const int ec = e < n ? e : 0;
+      const int r = ec / W, c = ec - r * W;
+      const int rr = b0 + r < B ? b0 + r : B - 1;
+      v[u] = ldg_f32(src + static_cast<int64_t>(rr) * ld + c);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * kT;
+      if (e < n) {
+        const int r = e / W, c = e - r * W;
+        dst[r * RS + c] = (b0 + r < B) ? v[u] : 0.f;
+      }
+    }
+  }
+}
+
+// One pair of the tournament schedule: {i, j, weight index, pair index k}; i < 0 = idle slot (its w and k are 0).
+struct PairEnt {
+  int i, j, wi, k;
+};
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// entry q of the schedule as ONE 16-byte load; q past the end reads the last entry and is marked idle
+__device__ __forceinline__ PairEnt load_pair(const int32_t* __restrict__ sched, int q, int n_sched) {
+  const int qc = q < n_sched ? q : n_sched - 1;
+  const i32x4 v = *(const DCTR_GLOBAL i32x4*)(sched + 4 * qc);
+  PairEnt e;
+  e.i = q < n_sched ? v.x : -1;
+  e.j = v.y;
+  e.wi = v.z;
+  e.k = v.w;
+  return e;
+}
+// raw weight-tile operands of a pair for lane (g, c): w[s] = W[e = c][d = 4g + s], wt[s] = W[e = 4g + s][d = c];
+// lanes / steps outside D read element 0 of the tile and are masked by the consumer
+__device__ __forceinline__ void load_w_raw(const float* __restrict__ Wf, const PairEnt& e, int D, int g, int c,
+                                           float (&w)[4]) {
+  const float* base = Wf + static_cast<int64_t>(e.wi) * D * D;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int d = 4 * g + s;
+    w[s] = ldg_f32(base + ((c < D && d < D) ? c * D + d : 0));
+  }
+}
+__device__ __forceinline__ void load_wt_raw(const float* __restrict__ Wf, const PairEnt& e, int D, int g, int c,
+                                            float (&wt)[4]) {
+  const float* base = Wf + static_cast<int64_t>(e.wi) * D * D;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int d = 4 * g + s;
+    wt[s] = ldg_f32(base + ((c < D && d < D) ? d * D + c : 0));
   }
 }
 
@@ -213,16 +268,21 @@ __global__ __launch_bounds__(kT) void k_bilinear_fwd(const float* __restrict__ E
                 ldg_f32(dense + static_cast<int64_t>(b0 + r) * ldd + q));
     }
   __syncthreads();
+  // software pipeline over this wave's pairs: the schedule entry of pair q + 8 and the weight tile of pair q + 4 are in
+  // flight while pair q computes (three dependent L2 round trips per pair otherwise)
+  PairEnt e1 = load_pair(sched, wv, n_sched), e2 = load_pair(sched, wv + 4, n_sched);
+  float w1[4];
+  load_w_raw(Wf, e1, D, g, c, w1);
   for (int q = wv; q < n_sched; q += 4) {
-    const int i = ldg_i32(sched + 4 * q);
-    if (i < 0) continue;
-    const int j = ldg_i32(sched + 4 * q + 1), wi = ldg_i32(sched + 4 * q + 2), k = ldg_i32(sched + 4 * q + 3);
+    const PairEnt en = e1;
     float wreg[4];  // B operand: W[e = c][d = 4g + s]
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int d = 4 * g + s;
-      wreg[s] = (c < D && d < D) ? ldg_f32(Wf + (static_cast<int64_t>(wi) * D + c) * D + d) : 0.f;
-    }
+    for (int s = 0; s < 4; ++s) wreg[s] = (c < D && 4 * g + s < D) ? w1[s] : 0.f;
+    e1 = e2;
+    load_w_raw(Wf, e1, D, g, c, w1);
+    e2 = load_pair(sched, q + 8, n_sched);
+    if (en.i < 0) continue;
+    const int i = en.i, j = en.j, k = en.k;
     for (int ps = 0; ps < npass; ++ps) {
       const float* xs = ps ? xs1 : xs0;
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
@@ -266,20 +326,56 @@ __global__ __launch_bounds__(kT) void k_bilinear_bwd_data(const float* __restric
   __syncthreads();
   float* mytb = tb + wv * (16 * 17);
   const int nrounds = (n_sched + slots - 1) / slots;
-  for (int rd = 0; rd < nrounds; ++rd) {
-    for (int sl = wv; sl < slots; sl += 4) {
-      const int q = rd * slots + sl;
-      if (q >= n_sched) break;
-      const int i = ldg_i32(sched + 4 * q);
-      if (i < 0) continue;
-      const int j = ldg_i32(sched + 4 * q + 1), wi = ldg_i32(sched + 4 * q + 2), k = ldg_i32(sched + 4 * q + 3);
-      float wreg[4], wT[4];
+  // Flat iteration space of a wave: it -> (round rd = it / spw, slot sl = wv + 4 * (it % spw)); every wave runs the
+  // same number of iterations, so the barrier after a round's last iteration is uniform.  One-ahead pipeline: while
+  // pair `it` computes, the weight tiles and the 8 incoming-gradient values of pair it + 1 and the schedule entry of
+  // pair it + 2 are in flight (all loads unconditional on clamped addresses, masked by the consumer; the gradient
+  // slab is streamed from HBM, 170 MB at the Criteo shape -- with predicated loads every value was its own round trip).
+  const int spw = (slots + 3) / 4, nit = nrounds * spw;
+  auto pair_of = [&](int it) -> int {     // schedule index of iteration `it`, or n_sched (= idle) for an empty slot
+    const int rd = it / spw, sl = wv + 4 * (it - rd * spw);
+    const int q = rd * slots + sl;
+    return (it < nit && sl < slots && q < n_sched) ? q : n_sched;
+  };
+  const int ccl = c < D ? c : 0;
+  int64_t grow[4];                         // clamped gout row offsets of this lane's 4 samples
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int d = 4 * g + s;
-        wreg[s] = (c < D && d < D) ? ldg_f32(Wf + (static_cast<int64_t>(wi) * D + c) * D + d) : 0.f;  // W[e=c][d]
-        wT[s] = (c < D && d < D) ? ldg_f32(Wf + (static_cast<int64_t>(wi) * D + d) * D + c) : 0.f;    // W[e=d'][d=c]
-      }
+  for (int r = 0; r < 4; ++r) {
+    const int b = b0 + 4 * g + r;
+    grow[r] = static_cast<int64_t>(b < B ? b : B - 1) * ldg + ccl;
+  }
+  auto load_gp = [&](const PairEnt& e, float (&gp)[2][4]) {
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        gp[ps][r] = ldg_f32(gout + grow[r] + (static_cast<int64_t>(ps < npass ? ps : 0) * P + e.k) * D);
+  };
+  PairEnt e1 = load_pair(sched, pair_of(0), n_sched), e2 = load_pair(sched, pair_of(1), n_sched);
+  float w1[4], wt1[4], gp1[2][4];
+  load_w_raw(Wf, e1, D, g, c, w1);
+  load_wt_raw(Wf, e1, D, g, c, wt1);
+  load_gp(e1, gp1);
+  for (int it = 0; it < nit; ++it) {
+    const PairEnt en = e1;
+    float wreg[4], wT[4], gpc[2][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bool in = c < D && 4 * g + s < D;
+      wreg[s] = in ? w1[s] : 0.f;     // W[e = c][d]
+      wT[s] = in ? wt1[s] : 0.f;      // W[e = d'][d = c]
+    }
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gpc[ps][r] = (c < D && b0 + 4 * g + r < B) ? gp1[ps][r] : 0.f;
+    e1 = e2;
+    load_w_raw(Wf, e1, D, g, c, w1);
+    load_wt_raw(Wf, e1, D, g, c, wt1);
+    load_gp(e1, gp1);
+    e2 = load_pair(sched, pair_of(it + 2), n_sched);
+    if (en.i >= 0) {
+      const int i = en.i, j = en.j;
       for (int ps = 0; ps < npass; ++ps) {
         const float* xs = ps ? xs1 : xs0;
         float* gx = ps ? gx1 : gx0;
@@ -292,9 +388,7 @@ __global__ __launch_bounds__(kT) void k_bilinear_bwd_data(const float* __restric
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int b = 4 * g + r;
-          float gp = 0.f;
-          if (c < D && b0 + b < B)
-            gp = ldg_f32(gout + static_cast<int64_t>(b0 + b) * ldg + (static_cast<int64_t>(ps) * P + k) * D + c);
+          const float gp = ps ? gpc[1][r] : gpc[0][r];
           if (c < D) gx[b * RS + j * D + c] += gp * t[r];            // gX_j[b][e]
           mytb[b * 17 + c] = (c < D) ? gp * xs[b * RS + j * D + c] : 0.f;  // g_t[b][e] in C layout
         }
@@ -309,7 +403,7 @@ __global__ __launch_bounds__(kT) void k_bilinear_bwd_data(const float* __restric
         }
       }
     }
-    __syncthreads();  // next round touches other (field) columns of gx; rounds are perfect matchings
+    if ((it + 1) % spw == 0) __syncthreads();  // next round touches other (field) columns of gx; rounds are perfect matchings
   }
   for (int e = tid; e < kSB * W; e += kT) {
     const int r = e / W, cc = e - r * W;
@@ -343,33 +437,48 @@ __global__ __launch_bounds__(kT) void k_bilinear_bwd_weight(const float* __restr
   constexpr int MAXQ = 8;
   f32x4 acc[MAXQ];
   const int qstep = 4 * gridDim.y, q0 = blockIdx.y * 4 + wv;
+  const int ccl = c < D ? c : 0;
   for (int base = 0; base < n_sched; base += qstep * MAXQ) {
+    // this wave's (at most MAXQ) pairs of the sweep: schedule entries loaded ONCE, not once per tile
+    PairEnt ent[MAXQ];
 #pragma unroll
-    for (int a = 0; a < MAXQ; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < MAXQ; ++a) {
+      acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+      ent[a] = load_pair(sched, base + q0 + a * qstep, n_sched);
+    }
     for (int tl = 0; tl < tiles_per_group; ++tl) {
       const int b0 = (sg * tiles_per_group + tl) * kSB;
+      if (b0 >= B) break;                  // uniform: later tiles of the group are past B as well
+      // the incoming gradients of every live pair of this tile, all in flight together (unconditional loads on
+      // clamped addresses, masked below), issued BEFORE the tile is staged so that both share one round trip
+      float gpr[MAXQ][2][4];
+#pragma unroll
+      for (int a = 0; a < MAXQ; ++a)
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int b = b0 + 4 * g + r;
+            // (an idle entry has k = 0 and a single-pass call re-reads pass 0: valid addresses, values unused)
+            gpr[a][ps][r] = ldg_f32(gout + static_cast<int64_t>(b < B ? b : B - 1) * ldg +
+                                    (static_cast<int64_t>(ps < npass ? ps : 0) * P + ent[a].k) * D + ccl);
+          }
       __syncthreads();
-      if (b0 < B) {
-        stage_rows(xs0, RS, V ? V : E, V ? ldv : lde, b0, B, W);
-        if (V) stage_rows(xs1, RS, E, lde, b0, B, W);
-      }
+      stage_rows(xs0, RS, V ? V : E, V ? ldv : lde, b0, B, W);
+      if (V) stage_rows(xs1, RS, E, lde, b0, B, W);
       __syncthreads();
-      if (b0 >= B) continue;
 #pragma unroll
       for (int a = 0; a < MAXQ; ++a) {
-        const int q = base + q0 + a * qstep;
-        if (q >= n_sched) continue;
-        const int i = ldg_i32(sched + 4 * q);
-        if (i < 0) continue;
-        const int j = ldg_i32(sched + 4 * q + 1), k = ldg_i32(sched + 4 * q + 3);
-        for (int ps = 0; ps < npass; ++ps) {
+        if (ent[a].i < 0) continue;
+        const int i = ent[a].i, j = ent[a].j;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          if (ps >= npass) break;
           const float* xs = ps ? xs1 : xs0;
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const int b = 4 * g + s;  // reduction index = sample
-            float gp = 0.f;
-            if (c < D && b0 + b < B)
-              gp = ldg_f32(gout + static_cast<int64_t>(b0 + b) * ldg + (static_cast<int64_t>(ps) * P + k) * D + c);
+            const float gp = (c < D && b0 + b < B) ? gpr[a][ps][s] : 0.f;
             const float gt = (c < D) ? gp * xs[b * RS + j * D + c] : 0.f;   // A: g_t[b][e = c]
             const float xi = (c < D) ? xs[b * RS + i * D + c] : 0.f;        // B: x_i[b][d = c]
             acc[a] = mfma16(gt, xi, acc[a]);
@@ -379,11 +488,8 @@ __global__ __launch_bounds__(kT) void k_bilinear_bwd_weight(const float* __restr
     }
 #pragma unroll
     for (int a = 0; a < MAXQ; ++a) {
-      const int q = base + q0 + a * qstep;
-      if (q >= n_sched) continue;
-      if (ldg_i32(sched + 4 * q) < 0) continue;
-      const int k = ldg_i32(sched + 4 * q + 3);
-      float* dst = part + (static_cast<int64_t>(sg) * P + k) * D * D;
+      if (ent[a].i < 0) continue;
+      float* dst = part + (static_cast<int64_t>(sg) * P + ent[a].k) * D * D;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int e = 4 * g + r;  // row = e, column = d = c
