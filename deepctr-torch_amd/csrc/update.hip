@@ -201,29 +201,21 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
   const int goff = deep_on ? fd.out_off + (lane_on ? e0 : 0) : 0;
   const bool fold = (A.gfm != nullptr);
 
-  // everything an entry contributes: h = g_out + g_fm * S (deep strip), g_fm, g_wide.  In two halves, because the
-  // compiler puts the s_waitcnt vmcnt(0) of the FMA (the first USE of a loaded value) right where the FMA stands and
-  // every load issued after it starts a second, dependent round trip: load_entry_g issues g_out / g_wide, the caller
-  // issues its row loads, and only then fold_entry loads S, g_fm (an L2 hit: the forward kernel just wrote them)
-  // and runs the FMA.
-  auto load_entry_g = [&](int b, Strip<VEC>& h, float& gw) {
-    h = strip_zero<VEC>();
-    gw = 0.f;
-    if (lane_on && A.gout) h = strip_load<VEC>(A.gout + static_cast<int64_t>(b) * A.ldg + goff);
-    if (wide_on && gl == 0) gw = ldg_f32(A.gwide + static_cast<int64_t>(b) * A.ldgw);
-  };
-  auto fold_entry = [&](int b, Strip<VEC>& h, float& gf) {
-    gf = 0.f;
-    if (lane_on && fold) {
-      const Strip<VEC> S = strip_load<VEC>(A.fm_s + static_cast<int64_t>(b) * A.lds_ + e0);
-      gf = ldg_f32(A.gfm + b);
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) h.v[k] += gf * S.v[k];
-    }
-  };
+  // everything an entry contributes: h = g_out + g_fm * S (deep strip), g_fm, g_wide
   auto load_entry = [&](int b, Strip<VEC>& h, float& gf, float& gw) {
-    load_entry_g(b, h, gw);
-    fold_entry(b, h, gf);
+    h = strip_zero<VEC>();
+    gf = 0.f;
+    gw = 0.f;
+    if (lane_on) {
+      if (A.gout) h = strip_load<VEC>(A.gout + static_cast<int64_t>(b) * A.ldg + goff);
+      if (fold) {
+        const Strip<VEC> S = strip_load<VEC>(A.fm_s + static_cast<int64_t>(b) * A.lds_ + e0);
+        gf = ldg_f32(A.gfm + b);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) h.v[k] += gf * S.v[k];
+      }
+    }
+    if (wide_on && gl == 0) gw = ldg_f32(A.gwide + static_cast<int64_t>(b) * A.ldgw);
   };
   // the strips of a row this lane may update: w (table, or gacc in accumulate mode), s (Adagrad state), e (the
   // table strip FM's fold needs; = w unless accumulating)
@@ -366,18 +358,17 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
       const int idq = static_cast<int>(key >> A.bbits);
       const int64_t row = static_cast<int64_t>(idq) * P + p;
       Strip<VEC> h, w, s, e;
-      float gf = 0.f, gw, ww, sw;
-      if (have) {   // the random row reads go first; nothing loaded is USED before the sort is done
+      float gf, gw, ww, sw;
+      if (have) {
+        load_entry(b, h, gf, gw);
         load_row(row, w, s, e, ww, sw);
-        load_entry_g(b, h, gw);
       } else {
         h = w = s = e = strip_zero<VEC>();
-        gw = ww = sw = 0.f;
+        gf = gw = ww = sw = 0.f;
       }
       int rank = 0;  // keys are unique: rank = number of smaller keys
 #pragma unroll 8
       for (int q = 0; q < n; ++q) rank += (keys[q] < key) ? 1 : 0;
-      if (have) fold_entry(b, h, gf);   // S, g_fm: an L2 round trip inside the row loads' HBM round trip
       if (first_pass) DCTR_TRACE(2);
       if (have) {
         if (gl == 0) {
@@ -466,9 +457,8 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
         h = w = s = e = strip_zero<VEC>();
         gf = gw = ww = sw = 0.f;
         if (have) {
+          load_entry(b, h, gf, gw);
           if (seg_end) load_row(row, w, s, e, ww, sw);
-          load_entry_g(b, h, gw);
-          fold_entry(b, h, gf);
         }
         if (lane_on) {
 #pragma unroll
