@@ -933,7 +933,7 @@ extern "C" size_t dctr_mlp_train_workspace_floats(const dctr_mlp_t* m, int32_t B
 extern "C" int dctr_mlp_train_step(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* part0,
                                    const float* part1, const float* bias, const float* y, float* y_pred, float* loss,
                                    float* g_logit, float* g_bias, float* gx, int64_t ld_gx, float* workspace,
-                                   dctr_stream_t stream) {
+                                   int32_t defer_wgrad, dctr_stream_t stream) {
   const int rc = check_mlp(m, B);
   if (rc != DCTR_OK) return rc;
   if (!m->w_out || !y || !y_pred || !loss || !g_logit || !workspace) return DCTR_EINVAL;
@@ -970,5 +970,21 @@ extern "C" int dctr_mlp_train_step(const dctr_mlp_t* m, const float* x, int64_t 
     const int st = launch_status();
     if (st != DCTR_OK) return st;
   }
+  if (defer_wgrad) return DCTR_OK;   // the caller enqueues dctr_mlp_train_wgrad (possibly on another stream)
   return launch_wgrad_reduce(m, x, ld_x, B, g_logit, workspace, part_loss, part_gb, n_tiles, loss, g_bias, s);
+}
+
+extern "C" int dctr_mlp_train_wgrad(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g_logit,
+                                    float* workspace, float* loss, float* g_bias, dctr_stream_t stream) {
+  const int rc = check_mlp(m, B);
+  if (rc != DCTR_OK) return rc;
+  if (!m->w_out || !x || !loss || !g_logit || !workspace) return DCTR_EINVAL;
+  if (ld_x % 4 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0) return DCTR_EALIGN;
+  if (B == 0) return DCTR_OK;
+  const WgradPlan P = plan_wgrad(m, B);
+  const int n_tiles = (B + kTM - 1) / kTM;
+  float* part_loss = workspace + static_cast<size_t>(P.slab) * P.S;
+  float* part_gb = part_loss + n_tiles;
+  return launch_wgrad_reduce(m, x, ld_x, B, g_logit, workspace, part_loss, part_gb, n_tiles, loss, g_bias,
+                             static_cast<hipStream_t>(stream));
 }

@@ -49,11 +49,42 @@ class DenseSlab(object):
                 p.data = v
                 p.grad = None
         self._ptrs = [p.data_ptr() for p in self.params]
+        # fork / join of the weight-gradient kernels (mlp.TowerHeadFunction): see fork_stream()
+        self.overlap = False
+        self._fork = None
+        self._pending = None
 
     def __getstate__(self):
         d = dict(self.__dict__)
         d["_lay"] = [self._lay[id(p)] for p in self.params]     # id() keys do not survive pickling
+        d["_fork"] = d["_pending"] = None                       # streams / events are per process
+        d["overlap"] = False
         return d
+
+    # ---- fork / join ------------------------------------------------------------------------------------------------
+    # The dense gradients are consumed by nothing but step(); the kernels that produce them may therefore run on a
+    # second stream beside the embedding update (two latency-bound kernels of ~30 us each at batch 4096).  The
+    # producer asks for the stream with fork_stream() (None unless the train step switched `overlap` on), reports what
+    # it enqueued with forked(), and join() -- called by step() and by whoever else reads the gradient slab -- makes
+    # the current stream wait for it.  Inside a hipGraph capture the fork and the join become graph edges.
+    def fork_stream(self, device):
+        if not self.overlap or torch.device(device).type != "cuda":
+            return None
+        if self._pending is not None:
+            self.join()
+        if self._fork is None:
+            self._fork = torch.cuda.Stream(device=device)
+        return self._fork
+
+    def forked(self, stream, keep_alive):
+        self._pending = (stream, keep_alive)
+
+    def join(self):
+        p = self._pending
+        if p is not None:
+            self._pending = None
+            torch.cuda.current_stream(self.flat.device).wait_stream(p[0])
+        # (the tensors of keep_alive are released only now, on the stream that has just waited for their last reader)
 
     def __setstate__(self, d):
         self.__dict__.update(d)
@@ -102,6 +133,7 @@ class DenseSlab(object):
         # the padding of the state stays 0; its gradient is 0, so sqrt(0) + eps never divides anything but 0
 
     def step(self, kind, lr, eps=0.0):
+        self.join()
         opt = L.UPD_ADAGRAD if kind == "adagrad" else L.UPD_SGD
         st = self.state
         if opt == L.UPD_ADAGRAD and st is None:

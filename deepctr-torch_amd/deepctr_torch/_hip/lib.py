@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdctr_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 
@@ -101,7 +101,8 @@ SIGNATURES = {
     "dctr_mlp_bwd": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P]),
     "dctr_mlp_train_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(Mlp), _I32]),
     "dctr_mlp_train_step": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64,
-                                           _P, _P]),
+                                           _P, _I32, _P]),
+    "dctr_mlp_train_wgrad": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _P, _P, _P, _P]),
     "dctr_bce_head": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P]),
     "dctr_dense_opt": (ctypes.c_int, [_P, _P, _P, _I64, _I32, _F32, _F32, _P]),
     "dctr_shard_assemble_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _I64, _P, _I32, _I32, _P, _P,

@@ -278,9 +278,22 @@ class TowerHeadFunction(torch.autograd.Function):
         ws = torch.empty((max(1, lib.dctr_mlp_train_workspace_floats(ctypes.byref(desc), B)),), dtype=torch.float32,
                          device=dev)
         pp = [_ptr(p) for p in ps] + [None] * (2 - len(ps))
+        # The weight gradients need only what the first launch leaves behind (x, h, dh, g_logit) and nothing but the
+        # dense optimizer needs THEM: with a fork stream on the sink they run beside the embedding update (which needs
+        # only gx / g_logit) instead of in front of it.  The sink joins the fork before the dense optimizer step.
+        fork = sink.fork_stream(dev) if hasattr(sink, "fork_stream") else None
         L.check(lib.dctr_mlp_train_step(ctypes.byref(desc), _ptr(x), x.stride(0), B, pp[0], pp[1], _ptr(bias), _ptr(y),
                                         _ptr(y_pred), _ptr(loss), _ptr(g_logit), _ptr(g_bias), _ptr(gx), gx.stride(0),
-                                        _ptr(ws), L.stream_handle(dev)), "dctr_mlp_train_step")
+                                        _ptr(ws), 1 if fork is not None else 0, L.stream_handle(dev)),
+                "dctr_mlp_train_step")
+        if fork is not None:
+            side = fork
+            side.wait_stream(torch.cuda.current_stream(dev))     # fork point: right behind the tower kernel
+            L.check(lib.dctr_mlp_train_wgrad(ctypes.byref(desc), _ptr(x), x.stride(0), B, _ptr(g_logit), _ptr(ws),
+                                             _ptr(loss), _ptr(g_bias), ctypes.c_void_p(side.cuda_stream)),
+                    "dctr_mlp_train_wgrad")
+            # everything the forked kernels touch stays allocated until the join (no record_stream bookkeeping)
+            sink.forked(side, (x, hs, dhs, ws, g_logit, loss, ps, y, wo))
         ctx.shapes = [tuple(p.shape) for p in parts]
         ctx.n_rest = len(rest)
         ctx.save_for_backward(gx, g_logit)

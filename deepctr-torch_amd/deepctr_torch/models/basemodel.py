@@ -469,12 +469,16 @@ class BaseModel(nn.Module):
         plan = self.model_plan()
         self._grad_sink = slab
         plan.dense_sink = slab
+        # the tower's weight gradients run on a fork stream beside the embedding update (DCTR_OVERLAP_WGRAD=0: in line)
+        slab.overlap = xb.is_cuda and os.environ.get("DCTR_OVERLAP_WGRAD", "1") != "0"
         try:
             loss, y_pred = self.fused_loss(xb, yb, slab)
             loss.backward(gradient=st["one"])       # a resident 1.0: no fill launch per step
         finally:
             self._grad_sink = None
             plan.dense_sink = None
+            slab.overlap = False
+            slab.join()
         slab.step(*mode)
         return loss.detach(), loss.detach().reshape(1), y_pred
 

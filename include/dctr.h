@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 6
+#define DCTR_ABI_VERSION 7
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -314,12 +314,18 @@ int dctr_mlp_bwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, c
  * weight gradients and their reduction -- 3 launches for what dctr_mlp_fwd + dctr_bce_head + dctr_mlp_bwd do in 5.
  * Outputs: y_pred [B], loss [1], g_logit [B] (= d loss / d part0 = d loss / d part1), g_bias [1] (nullable), gx,
  * layer[l].gW / gbias, g_w_out.  Needs w_out and every layer's h / dh.
- * workspace: dctr_mlp_train_workspace_floats(m, B) floats.                                                      */
+ * workspace: dctr_mlp_train_workspace_floats(m, B) floats.
+ * defer_wgrad != 0: only the first launch is enqueued (y_pred, g_logit, gx, the h / dh activations are then
+ * complete); the caller enqueues the weight-gradient half itself with dctr_mlp_train_wgrad (same m, x, workspace)
+ * -- on another stream if it wants it to overlap with work that needs only gx / g_logit (the embedding update).
+ * loss, g_bias, layer[l].gW / gbias and g_w_out are written by that second call.                               */
 size_t dctr_mlp_train_workspace_floats(const dctr_mlp_t* m, int32_t B);
 int dctr_mlp_train_step(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* part0,
                         const float* part1, const float* bias, const float* y, float* y_pred, float* loss,
                         float* g_logit, float* g_bias, float* gx, int64_t ld_gx, float* workspace,
-                        dctr_stream_t stream);
+                        int32_t defer_wgrad, dctr_stream_t stream);
+int dctr_mlp_train_wgrad(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g_logit,
+                         float* workspace, float* loss, float* g_bias, dctr_stream_t stream);
 
 /* ---- prediction head + loss (layers/core.py:154-160, basemodel.py:254, F.binary_cross_entropy(reduction='sum'))
  *     z = sum_i part_i[b] + bias ;  y_pred = sigmoid(z) ;  loss = sum_b -(y log p + (1-y) log(1-p))   (logs clamped

@@ -88,7 +88,11 @@ class MockLib(object):
     def dctr_mlp_train_workspace_floats(self, mref, B):
         return 16
 
-    def dctr_mlp_train_step(self, mref, x, ld_x, B, p0, p1, bias, y, y_pred, loss, g_logit, g_bias, gx, ld_gx, ws, stream):
+    def dctr_mlp_train_wgrad(self, mref, x, ld_x, B, g_logit, ws, loss, g_bias, stream):
+        return 0    # the mock's train step has already produced the weight gradients
+
+    def dctr_mlp_train_step(self, mref, x, ld_x, B, p0, p1, bias, y, y_pred, loss, g_logit, g_bias, gx, ld_gx, ws,
+                            defer_wgrad, stream):
         """forward + head + backward in one call, composed from the pieces above."""
         import torch
         logit = torch.zeros(B)
