@@ -1,0 +1,14 @@
+#!/bin/bash
+# pipelined dense optimizer (fork stream across steps of a graph group): parity + bench
+set +e
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out
+( timeout 900 python -m pytest tests/test_gpu_mlp.py tests/test_gpu_deepfm.py tests/test_gpu_models.py tests/test_gpu_parallel.py -m gpu -q --tb=short -p no:cacheprovider -x ) > $OUT/pytest_r14.log 2>&1; echo "pytest rc=$?"
+grep -E "passed|failed|Error|assert" $OUT/pytest_r14.log | tail -12
+for spg in 4 8 16; do
+( timeout 300 python bench.py --steps 208 --warmup 24 --no-cpu-baseline --steps-per-graph $spg ) 2> $OUT/bench.err | grep '^{' > $OUT/bench_r14_$spg.json; echo "bench spg=$spg rc=$?"; tail -2 $OUT/bench.err | grep -v amdgpu.ids
+python -c "
+import json;d=json.load(open('$OUT/bench_r14_$spg.json'));print(d['value'],d['ms_per_step'],d['final_loss'])"
+done
