@@ -84,20 +84,10 @@ class DenseSlab(object):
             self._fork = torch.cuda.Stream(device=device)
         return self._fork
 
-    def forked(self, stream, keep_alive, event, launch):
-        """``launch(stream)`` enqueues the forked kernels; it runs when the train step reaches the dense optimizer
-        (or a join), i.e. after the work that shares the producer's stream has been enqueued."""
-        self._pending = [stream, keep_alive, event, launch]
-
-    def _flush_deferred(self):
-        p = self._pending
-        if p is not None and p[3] is not None:
-            launch, p[3] = p[3], None
-            p[0].wait_event(p[2])
-            launch(p[0])
+    def forked(self, stream, keep_alive):
+        self._pending = (stream, keep_alive)
 
     def join(self):
-        self._flush_deferred()
         p = self._pending
         if p is not None:
             self._pending = None
@@ -168,7 +158,6 @@ class DenseSlab(object):
         if opt == L.UPD_ADAGRAD and self.state is None:
             raise RuntimeError("adopt_adagrad_state() first")
         dev = self.flat.device
-        self._flush_deferred()
         if self.pipeline and self._pending is not None:
             side = self._pending[0]
             if self.head_numel:

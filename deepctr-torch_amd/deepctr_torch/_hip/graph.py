@@ -75,9 +75,7 @@ class GraphedTrainStep(object):
             self.graphs.append(g)
             self.outputs.append(outs)
         self.plan_version = plan.version
-        # (high priority: a separate hardware queue, so that the next group's batch copies are not parked behind the
-        # running graph's packets on the queue they would otherwise share with it)
-        self._side = torch.cuda.Stream(device=xb.device, priority=-1)
+        self._side = torch.cuda.Stream(device=xb.device)
         self._ready = [torch.cuda.Event() for _ in range(self.n_slots)]
         self._free_ev = [torch.cuda.Event() for _ in range(self.n_slots)]
         self._free = [None] * self.n_slots

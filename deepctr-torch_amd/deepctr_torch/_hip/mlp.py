@@ -289,19 +289,13 @@ class TowerHeadFunction(torch.autograd.Function):
                                         _ptr(ws), 1 if fork is not None else 0, L.stream_handle(dev)),
                 "dctr_mlp_train_step")
         if fork is not None:
-            # fork POINT: right behind the tower kernel.  The forked launches themselves are handed to the sink and
-            # enqueued later (DenseSlab.step / join), after the embedding update has been enqueued on this stream:
-            # inside a hipGraph the first successor of a node keeps its hardware queue and a cross-queue dependency
-            # costs ~6-10 us on MI355X -- the critical chain (tower -> update -> next gather) must be that successor.
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
-
-            def launch(side, desc=desc, x=x, g_logit=g_logit, ws=ws, loss=loss, g_bias=g_bias, B=B):
-                L.check(lib.dctr_mlp_train_wgrad(ctypes.byref(desc), _ptr(x), x.stride(0), B, _ptr(g_logit), _ptr(ws),
-                                                 _ptr(loss), _ptr(g_bias), ctypes.c_void_p(side.cuda_stream)),
-                        "dctr_mlp_train_wgrad")
+            side = fork
+            side.wait_stream(torch.cuda.current_stream(dev))     # fork point: right behind the tower kernel
+            L.check(lib.dctr_mlp_train_wgrad(ctypes.byref(desc), _ptr(x), x.stride(0), B, _ptr(g_logit), _ptr(ws),
+                                             _ptr(loss), _ptr(g_bias), ctypes.c_void_p(side.cuda_stream)),
+                    "dctr_mlp_train_wgrad")
             # everything the forked kernels touch stays allocated until the join (no record_stream bookkeeping)
-            sink.forked(fork, (x, hs, dhs, ws, g_logit, loss, ps, y, wo, gx), ev, launch)
+            sink.forked(side, (x, hs, dhs, ws, g_logit, loss, ps, y, wo))
         ctx.shapes = [tuple(p.shape) for p in parts]
         ctx.n_rest = len(rest)
         ctx.save_for_backward(gx, g_logit)
