@@ -22,14 +22,9 @@ def _r4(n):
 
 
 class DenseSlab(object):
-    def __init__(self, params, pad_rows=(), head=()):
-        """params: list of nn.Parameter (fp32, same device); pad_rows: parameters whose rows are padded; head:
-        parameters laid out FIRST (the slab's "head" range, stepped on the main stream in pipelined mode: the dense
-        half of ``Linear``, which the next step's gather kernel reads)."""
-        params = list(params)
-        hd = set(id(p) for p in head)
-        self.params = [p for p in params if id(p) in hd] + [p for p in params if id(p) not in hd]
-        self.head_numel = 0
+    def __init__(self, params, pad_rows=()):
+        """params: list of nn.Parameter (fp32, same device); pad_rows: parameters whose rows are padded."""
+        self.params = list(params)
         pad = set(id(p) for p in pad_rows)
         dev = self.params[0].device
         self._lay = {}
@@ -43,8 +38,6 @@ class DenseSlab(object):
                 rows, cols, ld = 1, p.numel(), p.numel()
             self._lay[id(p)] = (off, rows, cols, ld)
             off += _r4(rows * ld)
-            if id(p) in hd:
-                self.head_numel = off
         self.numel = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -58,7 +51,6 @@ class DenseSlab(object):
         self._ptrs = [p.data_ptr() for p in self.params]
         # fork / join of the weight-gradient kernels (mlp.TowerHeadFunction): see fork_stream()
         self.overlap = False
-        self.pipeline = False
         self._fork = None
         self._pending = None
 
@@ -66,7 +58,7 @@ class DenseSlab(object):
         d = dict(self.__dict__)
         d["_lay"] = [self._lay[id(p)] for p in self.params]     # id() keys do not survive pickling
         d["_fork"] = d["_pending"] = None                       # streams / events are per process
-        d["overlap"] = d["pipeline"] = False
+        d["overlap"] = False
         return d
 
     # ---- fork / join ------------------------------------------------------------------------------------------------
@@ -140,29 +132,12 @@ class DenseSlab(object):
             st["sum"] = v
         # the padding of the state stays 0; its gradient is 0, so sqrt(0) + eps never divides anything but 0
 
-    def _opt(self, lo, hi, opt, lr, eps, stream):
-        st = self.state
-        L.check(L.lib().dctr_dense_opt(ctypes.c_void_p(self.flat.data_ptr() + 4 * lo),
-                                       ctypes.c_void_p(self.grad.data_ptr() + 4 * lo),
-                                       ctypes.c_void_p(st.data_ptr() + 4 * lo) if st is not None else None, hi - lo, opt,
-                                       float(lr), float(eps), stream), "dctr_dense_opt")
-
     def step(self, kind, lr, eps=0.0):
-        """One optimizer step over the slab.  Pipelined mode (``pipeline`` on and a fork pending: a captured group of
-        train steps, graph.GraphedTrainStep): the tower half of the slab is stepped ON THE FORK STREAM behind the weight
-        gradients and nobody joins here -- the next step's gather and the embedding update run meanwhile, the join
-        happens where the next tower launch needs the weights (mlp.TowerHeadFunction) or when the group ends.  Only
-        the head range (the dense half of Linear, read by the next gather; its gradient comes from the update kernel
-        on the main stream) is stepped here on the main stream."""
-        opt = L.UPD_ADAGRAD if kind == "adagrad" else L.UPD_SGD
-        if opt == L.UPD_ADAGRAD and self.state is None:
-            raise RuntimeError("adopt_adagrad_state() first")
-        dev = self.flat.device
-        if self.pipeline and self._pending is not None:
-            side = self._pending[0]
-            if self.head_numel:
-                self._opt(0, self.head_numel, opt, lr, eps, L.stream_handle(dev))
-            self._opt(self.head_numel, self.numel, opt, lr, eps, ctypes.c_void_p(side.cuda_stream))
-            return
         self.join()
-        self._opt(0, self.numel, opt, lr, eps, L.stream_handle(dev))
+        opt = L.UPD_ADAGRAD if kind == "adagrad" else L.UPD_SGD
+        st = self.state
+        if opt == L.UPD_ADAGRAD and st is None:
+            raise RuntimeError("adopt_adagrad_state() first")
+        L.check(L.lib().dctr_dense_opt(ctypes.c_void_p(self.flat.data_ptr()), ctypes.c_void_p(self.grad.data_ptr()),
+                                       ctypes.c_void_p(st.data_ptr()) if st is not None else None, self.numel, opt,
+                                       float(lr), float(eps), L.stream_handle(self.flat.device)), "dctr_dense_opt")

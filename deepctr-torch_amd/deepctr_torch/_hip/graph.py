@@ -56,20 +56,9 @@ class GraphedTrainStep(object):
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             outs = []
-            st = model._fused_step_state() if hasattr(model, "_fused_step_state") else None
-            slab = st["slab"] if st else None
             with torch.cuda.graph(g, pool=pool):
-                # inside a group the dense optimizer of step k runs on the fork stream beside step k+1's gather and
-                # step k's embedding update; the group ends joined (DenseSlab.step)
-                if slab is not None:
-                    slab.pipeline = True
-                try:
-                    for j in range(self.S):
-                        outs.append(model._train_step(self.x[s][j], self.y[s][j]))
-                finally:
-                    if slab is not None:
-                        slab.pipeline = False
-                        slab.join()
+                for j in range(self.S):
+                    outs.append(model._train_step(self.x[s][j], self.y[s][j]))
             if pool is None:
                 pool = g.pool()
             self.graphs.append(g)

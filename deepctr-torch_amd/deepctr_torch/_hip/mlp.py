@@ -281,8 +281,6 @@ class TowerHeadFunction(torch.autograd.Function):
         # The weight gradients need only what the first launch leaves behind (x, h, dh, g_logit) and nothing but the
         # dense optimizer needs THEM: with a fork stream on the sink they run beside the embedding update (which needs
         # only gx / g_logit) instead of in front of it.  The sink joins the fork before the dense optimizer step.
-        if hasattr(sink, "join"):
-            sink.join()          # a pipelined previous step may still be stepping the tower weights on the fork stream
         fork = sink.fork_stream(dev) if hasattr(sink, "fork_stream") else None
         L.check(lib.dctr_mlp_train_step(ctypes.byref(desc), _ptr(x), x.stride(0), B, pp[0], pp[1], _ptr(bias), _ptr(y),
                                         _ptr(y_pred), _ptr(loss), _ptr(g_logit), _ptr(g_bias), _ptr(gx), gx.stride(0),

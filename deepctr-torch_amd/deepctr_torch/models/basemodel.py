@@ -457,7 +457,7 @@ class BaseModel(nn.Module):
         mode = self._dense_update_mode(dense)
         if mode is None or mode[0] != plan.update[0]:
             return None
-        slab = _dense.DenseSlab(dense, pad_rows=[w for (w, b, r) in layers], head=[lw] if lw is not None else [])
+        slab = _dense.DenseSlab(dense, pad_rows=[w for (w, b, r) in layers])
         if mode[0] == "adagrad":
             slab.adopt_adagrad_state(self.optim)
         slab.attach_grads()
@@ -474,14 +474,12 @@ class BaseModel(nn.Module):
         try:
             loss, y_pred = self.fused_loss(xb, yb, slab)
             loss.backward(gradient=st["one"])       # a resident 1.0: no fill launch per step
-        except BaseException:
-            slab.join()
-            raise
         finally:
             self._grad_sink = None
             plan.dense_sink = None
             slab.overlap = False
-        slab.step(*mode)        # joins the fork, unless a pipelined group of steps defers that (DenseSlab.step)
+            slab.join()
+        slab.step(*mode)
         return loss.detach(), loss.detach().reshape(1), y_pred
 
     def _train_step(self, xb, yb):
