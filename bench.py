@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--vocab", type=int, default=1_000_000)
     ap.add_argument("--optimizer", default="adagrad", choices=["adagrad", "sgd"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replays")
-    ap.add_argument("--steps-per-graph", type=int, default=4,
+    ap.add_argument("--steps-per-graph", type=int, default=8,
                     help="train steps captured per hipGraph (the ~15 us launch gap is paid once per graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-parallel", action="store_true", help="use the data-parallel trainer even with 1 rank")
