@@ -1,0 +1,23 @@
+#!/bin/bash
+# verification set: smoke, full GPU suite, bench (+cpu baseline), rocprof kernel stats of the bench command, sharded 1-rank
+set +e
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out
+( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $OUT/smoke.log
+( timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider ) > $OUT/pytest_gpu_full.log 2>&1; echo "pytest rc=$?"
+grep -E "passed|failed" $OUT/pytest_gpu_full.log | tail -2
+( timeout 600 python bench.py ) 2> $OUT/bench.err | grep '^{' > $OUT/bench.json; echo "bench rc=$?"
+python -c "import json;d=json.load(open('$OUT/bench.json'));print(d['value'],d['ms_per_step'],d['roofline']['frac'],d['cpu_baseline']['value'],d['cpu_baseline']['cores'])"
+( timeout 300 python bench.py --steps 200 --warmup 24 --no-cpu-baseline --optimizer sgd ) 2> /dev/null | grep '^{' > $OUT/bench_sgd.json
+( timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-graph ) 2> /dev/null | grep '^{' > $OUT/bench_eager.json
+( timeout 300 python bench.py --steps 200 --warmup 24 --no-cpu-baseline --force-parallel ) 2> /dev/null | grep '^{' > $OUT/bench_shard1.json
+python -c "
+import json
+for f in ('bench_sgd','bench_eager','bench_shard1'):
+    d=json.load(open('$OUT/'+f+'.json')); print(f, d['value'], d['ms_per_step'])"
+rm -rf $OUT/prof
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o deepfm -- python $OUT/../bench.py --steps 96 --warmup 16 --no-cpu-baseline ) > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?"
+f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); head -12 $f | cut -c1-150
+t=$(find $OUT/prof -name "*kernel_trace.csv" | head -1); python tools/timeline.py $t 9 | tail -42
