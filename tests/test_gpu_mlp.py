@@ -319,6 +319,43 @@ def test_graphed_train_step_equals_eager(double_buffer, spg):
         assert torch.equal(a[k], b[k]), k
 
 
+def test_graphed_step_block_equals_eager():
+    """step_block(): a whole group of consecutive batches staged with two copies -- same parameters, bit for bit, as
+    the eager fused step over the same batches (the weight gradients run on the fork stream in both)."""
+    from deepctr_torch._hip.graph import GraphedTrainStep
+    g = load_golden("deepfm_criteo")
+    gen = torch.Generator().manual_seed(11)
+    n = g["extra"]["X_steps"][0].shape[0]
+    S = 3
+    X_all = torch.cat([torch.from_numpy(g["extra"]["X_steps"][i % 3]) for i in range(2 + 2 * S)]).to(DEV)
+    X_all = X_all[torch.randperm(X_all.shape[0], generator=gen).to(DEV)].contiguous()
+    y_all = torch.randint(0, 2, (X_all.shape[0],), generator=gen).float().to(DEV)
+    batch = lambda i: (X_all[i * n:(i + 1) * n], y_all[i * n:(i + 1) * n])
+    finals = []
+    for mode in ("eager", "graph"):
+        m = build_model(g["spec"], DEV)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in g["params"].items()})
+        m.compile("adagrad", "binary_crossentropy", metrics=[])
+        m.train()
+        m._train_step(*batch(0))
+        m._train_step(*batch(1))
+        last = None
+        if mode == "eager":
+            for i in range(2, 2 + 2 * S):
+                last = m._train_step(*batch(i))
+        else:
+            gs = GraphedTrainStep(m, *batch(0), steps_per_graph=S).capture(*batch(2))
+            for grp in range(2):
+                lo = 2 + grp * S
+                last = gs.step_block(X_all[lo * n:(lo + S) * n], y_all[lo * n:(lo + S) * n])
+        torch.cuda.synchronize()
+        finals.append(({k: v.clone() for k, v in m.state_dict().items()}, float(last[0].item())))
+    (a, la), (b, lb) = finals
+    assert la == lb
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_fit_replays_graphs_for_full_batches_and_matches_eager_fit(monkeypatch):
     """fit(): full-size batches replay the captured step, the ragged last batch runs eagerly; the trained parameters
     and the History are identical to a fit with graphs switched off (DCTR_FIT_GRAPH=0)."""
