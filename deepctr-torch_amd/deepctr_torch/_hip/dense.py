@@ -53,11 +53,12 @@ class DenseSlab(object):
         self.overlap = False
         self._fork = None
         self._pending = None
+        self.deferred = None      # overlap == "defer": the closure that enqueues the weight-gradient kernels
 
     def __getstate__(self):
         d = dict(self.__dict__)
         d["_lay"] = [self._lay[id(p)] for p in self.params]     # id() keys do not survive pickling
-        d["_fork"] = d["_pending"] = None                       # streams / events are per process
+        d["_fork"] = d["_pending"] = d["deferred"] = None       # streams / events / closures are per process
         d["overlap"] = False
         return d
 
@@ -67,8 +68,13 @@ class DenseSlab(object):
     # producer asks for the stream with fork_stream() (None unless the train step switched `overlap` on), reports what
     # it enqueued with forked(), and join() -- called by step() and by whoever else reads the gradient slab -- makes
     # the current stream wait for it.  Inside a hipGraph capture the fork and the join become graph edges.
+    # ``overlap == "defer"`` (parallel.ShardedTrainer): the producer enqueues nothing and leaves a closure in
+    # ``deferred``; the trainer calls it with a stream of its choice AFTER its graph segment, so that the weight
+    # gradients overlap the gradient all-to-all and the embedding update, and joins before the dense all-reduce.  The
+    # closure addresses the tensors of the run that created it -- under a hipGraph those are the capture's static
+    # buffers, so the closure of the capture stays valid for every replay.
     def fork_stream(self, device):
-        if not self.overlap or torch.device(device).type != "cuda":
+        if not self.overlap or self.overlap == "defer" or torch.device(device).type != "cuda":
             return None
         if self._pending is not None:
             self.join()

@@ -282,10 +282,20 @@ class TowerHeadFunction(torch.autograd.Function):
         # dense optimizer needs THEM: with a fork stream on the sink they run beside the embedding update (which needs
         # only gx / g_logit) instead of in front of it.  The sink joins the fork before the dense optimizer step.
         fork = sink.fork_stream(dev) if hasattr(sink, "fork_stream") else None
+        defer = fork is None and getattr(sink, "overlap", False) == "defer" and x.device.type == "cuda"
         L.check(lib.dctr_mlp_train_step(ctypes.byref(desc), _ptr(x), x.stride(0), B, pp[0], pp[1], _ptr(bias), _ptr(y),
                                         _ptr(y_pred), _ptr(loss), _ptr(g_logit), _ptr(g_bias), _ptr(gx), gx.stride(0),
-                                        _ptr(ws), 1 if fork is not None else 0, L.stream_handle(dev)),
+                                        _ptr(ws), 1 if (fork is not None or defer) else 0, L.stream_handle(dev)),
                 "dctr_mlp_train_step")
+        if defer:
+            keep = (x, hs, dhs, ws, g_logit, loss, ps, y, wo, gx, desc)
+
+            def launch(stream, keep=keep, B=B, g_bias=g_bias):
+                x_, ws_, g_logit_, loss_, desc_ = keep[0], keep[3], keep[4], keep[5], keep[10]
+                L.check(lib.dctr_mlp_train_wgrad(ctypes.byref(desc_), _ptr(x_), x_.stride(0), B, _ptr(g_logit_),
+                                                 _ptr(ws_), _ptr(loss_), _ptr(g_bias),
+                                                 ctypes.c_void_p(stream.cuda_stream)), "dctr_mlp_train_wgrad")
+            sink.deferred = launch
         if fork is not None:
             side = fork
             side.wait_stream(torch.cuda.current_stream(dev))     # fork point: right behind the tower kernel

@@ -22,6 +22,8 @@ Semantics = the reference's: one optimizer step on the gradient summed over ``wo
 The exchange logic (payload layout, bucket views, collectives) is plain torch and is exercised on CPU with the
 ``gloo`` backend in ``tests/test_parallel_gloo.py``; only the kernels need a GPU.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -405,6 +407,8 @@ class ShardedTrainer(object):
         self.layout = ShardLayout(self.plan, self.world, self.rank)
         self.ops = ops if ops is not None else HipShardOps(model, self.layout)
         self.use_graphs = bool(use_graphs)
+        self.overlap_wgrad = os.environ.get("DCTR_OVERLAP_WGRAD", "1") != "0"
+        self._side = None
         self._shape = None
         self._leaves = None
         self.plan.sharder = self
@@ -452,11 +456,16 @@ class ShardedTrainer(object):
         model, st, slab, plan, lay = self.model, self.state, self.slab, self.plan, self.layout
         model._grad_sink = slab
         self._leaves = None
+        # the tower's weight gradients are not enqueued here: TowerHeadFunction leaves a closure in slab.deferred and
+        # train_step() runs it on a second stream behind this segment, beside the gradient all-to-all and the update
+        slab.overlap = "defer" if (self._x.device.type == "cuda" and self.overlap_wgrad) else False
+        slab.deferred = None
         try:
             loss, y_pred = model.fused_loss(self._x, self._y, slab)
             loss.backward(gradient=st["one"])
         finally:
             model._grad_sink = None
+            slab.overlap = False
         lv = self._leaves
         if lv is None:
             raise RuntimeError("the model's logit_parts() did not go through the fused lookup")
@@ -494,7 +503,16 @@ class ShardedTrainer(object):
         chunks, self._ids_t = self._segB()
         dist.all_to_all_single(self._recv, chunks, group=self.group)                 # rows -> samples' ranks
         send, loss, y_pred = self._segC()
+        wgrad = self.slab.deferred if xb.device.type == "cuda" else None    # (of the capture, when the segment is a graph replay)
+        if wgrad is not None:
+            main = torch.cuda.current_stream(xb.device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=xb.device)
+            self._side.wait_stream(main)
+            wgrad(self._side)
         dist.all_to_all_single(self._grads_all, send, group=self.group)              # row gradients (+ next ids)
+        if wgrad is not None:
+            main.wait_stream(self._side)                                              # the dense gradients are complete
         work = dist.all_reduce(self.slab.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._segD()                                                                  # overlaps with the all-reduce
         work.wait()
