@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdctr_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 
@@ -50,6 +50,22 @@ class Mlp(ctypes.Structure):
 
 
 PLAN_HAS_GACC, PLAN_HAS_STATE, PLAN_HAS_MAXPOOL = 1, 2, 4
+LAZY_SGD, LAZY_ADAGRAD, LAZY_ADAM = 0, 1, 2
+
+
+class LazyUnit(ctypes.Structure):
+    """dctr_lazy_unit_t (include/dctr.h)"""
+    _fields_ = [("deep", ctypes.c_void_p), ("deep_s1", ctypes.c_void_p), ("deep_s2", ctypes.c_void_p),
+                ("deep_g", ctypes.c_void_p), ("wide", ctypes.c_void_p), ("wide_s1", ctypes.c_void_p),
+                ("wide_s2", ctypes.c_void_p), ("wide_g", ctypes.c_void_p), ("stamp", ctypes.c_void_p),
+                ("vocab", ctypes.c_int64), ("dim", ctypes.c_int32), ("col", ctypes.c_int32),
+                ("l2_deep", ctypes.c_float), ("l2_wide", ctypes.c_float)]
+
+
+class LazyOpt(ctypes.Structure):
+    """dctr_lazy_opt_t"""
+    _fields_ = [("kind", ctypes.c_int32), ("lr", ctypes.c_float), ("eps", ctypes.c_float),
+                ("beta1", ctypes.c_float), ("beta2", ctypes.c_float)]
 POOL_CODE = {None: 0, "sum": 1, "mean": 2, "max": 3}
 BWD_ACCUM, BWD_SGD = 0, 1
 OPT_SGD, OPT_ADAGRAD = 0, 1
@@ -75,6 +91,11 @@ SIGNATURES = {
     "dctr_embed_bwd": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P,
                                       _I32, _F32, _P]),
     "dctr_embed_apply": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _I32, _F32, _F32, _P]),
+    "dctr_sizeof_lazy_unit": (ctypes.c_size_t, []),
+    "dctr_lazy_catchup": (ctypes.c_int, [_P, _I32, _P, _I32, _P, _P, _I32, _I32, _P]),
+    "dctr_lazy_apply": (ctypes.c_int, [_P, _I32, _P, _I32, _P, _P, _I32, _I32, _P]),
+    "dctr_lazy_flush": (ctypes.c_int, [_P, _I32, _I64, _P, _P, _I32, _I32, _P]),
+    "dctr_lazy_step_inc": (ctypes.c_int, [_P, _P]),
     "dctr_cin_workspace_floats": (ctypes.c_size_t, [_I32, _I32, _I32]),
     "dctr_cin_layer_fwd": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I64, _P,
                                           _P]),
@@ -140,7 +161,8 @@ def lib():
         if handle.dctr_abi_version() != ABI_VERSION:
             raise RuntimeError("libdctr_hip.so ABI %d != binding ABI %d" % (handle.dctr_abi_version(), ABI_VERSION))
         if handle.dctr_sizeof_field() != ctypes.sizeof(Field) or handle.dctr_sizeof_plan() != ctypes.sizeof(Plan) \
-                or handle.dctr_sizeof_mlp() != ctypes.sizeof(Mlp):
+                or handle.dctr_sizeof_mlp() != ctypes.sizeof(Mlp) \
+                or handle.dctr_sizeof_lazy_unit() != ctypes.sizeof(LazyUnit):
             raise RuntimeError("dctr_field_t / dctr_plan_t / dctr_mlp_t layout mismatch between header and binding")
         _lib = handle
     return _lib

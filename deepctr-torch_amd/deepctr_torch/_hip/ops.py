@@ -60,6 +60,14 @@ class EmbedFunction(torch.autograd.Function):
         fm = torch.empty((B,), dtype=torch.float32, device=X.device) if want_fm else None
         if want_fm and (plan.emb_dim <= 0 or not plan.deep):
             raise ValueError("FM needs sparse features that share one embedding_dim")
+        # exact lazy regularised / Adam update (csrc/lazy.hip): a training gather first replays the batch's rows to
+        # the current step; any other reader of the tables gets them flushed
+        lazy = plan.lazy if plan.update[0] == "lazy" else None
+        if lazy is not None:
+            if for_backward and lazy.plan is plan:
+                lazy.catchup(X)
+            else:
+                lazy.flush()
         # side outputs for the deterministic fused update (only when a backward can follow)
         ids_t = fm_s = None
         ld_s = 0
@@ -122,6 +130,23 @@ class EmbedFunction(torch.autograd.Function):
         update = plan.update
         kind = update[0]
         stream = L.stream_handle(X.device)
+
+        if kind == "lazy":
+            lazy = plan.lazy
+            if lazy is None or lazy.plan is not plan or ids_t is None:
+                raise NotImplementedError("the lazy regularised / Adam table update needs lookups through the model's "
+                                          "own plan and a batch the deterministic update kernel supports "
+                                          "(DCTR_LAZY_UPDATE=0 selects the exact dense path)")
+            lazy._ensure(X.device)
+            cplan = plan.bind(X.device)
+            ws, ws_n = plan.update_workspace(B, X.device)
+            L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t), B,
+                                          _ptr(g_out), ld_g, _ptr(out), plan.ld_out, _ptr(fm_s),
+                                          fm_s.stride(0) if fm_s is not None else 0, _ptr(g_fm), _ptr(g_wide), 1,
+                                          L.UPD_ACCUM, 0.0, 0.0, _ptr(X), X.stride(0), _ptr(g_wd), _ptr(ws), ws_n,
+                                          stream), "dctr_embed_update(accumulate)")
+            lazy.apply(ids_t)
+            return None, None, None, g_w, None, None
 
         if ids_t is not None:
             # deterministic single-pass path (csrc/update.hip): no atomics, optimizer fused in

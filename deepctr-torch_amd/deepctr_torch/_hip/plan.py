@@ -88,6 +88,150 @@ def _fields_for(columns, tables, feature_index, unpooled):
     return fixed, pooled, off
 
 
+class LazyState(object):
+    """Host side of csrc/lazy.hip: the reference's regularised / Adam table update replayed lazily, exactly.
+
+    ``l2`` maps a table parameter to its lambda (0 when unregularised), ``s1`` / ``s2`` to its optimizer state
+    tensors (Adagrad ``sum`` | Adam ``exp_avg``, Adam ``exp_avg_sq``).  Owns the per-unit stamps, the device step
+    counter and the gradient slabs' use; see include/dctr.h for the protocol."""
+
+    # tables up to this many elements in total get their logged regularisation term recomputed EXACTLY at every
+    # step (flush + one reduction, cheap when small); bigger models log the value of the last flush
+    EXACT_REG_ELEMS = 1 << 22
+
+    def __init__(self, plan, kind, lr, eps, beta1, beta2, l2, s1, s2, optimizer=None):
+        self.plan, self.kind = plan, kind
+        self.hyper = (float(lr), float(eps), float(beta1), float(beta2))
+        self.l2 = dict((id(p), float(v)) for p, v in l2.items())
+        self.s1 = dict((id(p), v) for p, v in (s1 or {}).items())
+        self.s2 = dict((id(p), v) for p, v in (s2 or {}).items())
+        self.optimizer = optimizer
+        self.stamps = None
+        self.step = None
+        self.dirty = False
+        self._units_dev = None
+        self._key = None
+        self._reg = None
+        self.opt = L.LazyOpt()
+        self.opt.kind = {"sgd": L.LAZY_SGD, "adagrad": L.LAZY_ADAGRAD, "adam": L.LAZY_ADAM}[kind]
+        self.opt.lr, self.opt.eps, self.opt.beta1, self.opt.beta2 = self.hyper
+        self.vec = 4 if plan.vec == 4 else 1
+        self.max_dim = max(plan.max_dim, 1)
+        self.n_elems = sum(p.numel() for p in plan.table_params)
+
+    def signature(self):
+        return (self.kind, self.hyper, tuple(sorted(self.l2.items())))
+
+    def _ensure(self, device):
+        plan = self.plan
+        if self.step is None or self.step.device != torch.device(device):
+            t0 = 0
+            if self.optimizer is not None and self.kind == "adam":      # resume: Adam's bias correction needs t
+                for p in plan.table_params:
+                    st = self.optimizer.state.get(p, {})
+                    if "step" in st:
+                        t0 = max(t0, int(float(st["step"])))
+            self.step = torch.full((1,), t0, dtype=torch.int32, device=device)
+            self.stamps = [torch.full((int(self._unit_vocab(u)),), t0, dtype=torch.int32, device=device)
+                           for u in range(len(plan.units))]
+            self._key = None
+        plan.ensure_gacc()
+        key = [str(device)]
+        for p in plan.table_params:
+            key.append((p.data_ptr(), _GACC[p].data_ptr()) + tuple(
+                d[id(p)].data_ptr() if id(p) in d else 0 for d in (self.s1, self.s2)))
+        key = tuple(key)
+        if key != self._key:
+            arr = (L.LazyUnit * len(plan.units))()
+            for u, (di, wi, col, _) in enumerate(plan.units):
+                e = arr[u]
+                fd = plan.deep[di] if di >= 0 else None
+                fw = plan.wide[wi] if wi >= 0 else None
+                if fd is not None:
+                    p = fd.param
+                    e.deep, e.deep_g = p.data_ptr(), _GACC[p].data_ptr()
+                    e.deep_s1 = self.s1[id(p)].data_ptr() if id(p) in self.s1 else None
+                    e.deep_s2 = self.s2[id(p)].data_ptr() if id(p) in self.s2 else None
+                    e.l2_deep = self.l2.get(id(p), 0.0)
+                if fw is not None:
+                    p = fw.param
+                    e.wide, e.wide_g = p.data_ptr(), _GACC[p].data_ptr()
+                    e.wide_s1 = self.s1[id(p)].data_ptr() if id(p) in self.s1 else None
+                    e.wide_s2 = self.s2[id(p)].data_ptr() if id(p) in self.s2 else None
+                    e.l2_wide = self.l2.get(id(p), 0.0)
+                e.stamp = self.stamps[u].data_ptr()
+                e.vocab = self._unit_vocab(u)
+                e.dim = fd.dim if fd is not None else 1
+                e.col = col
+            self._units_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+            self._key = key
+
+    def _unit_vocab(self, u):
+        di, wi, _, _ = self.plan.units[u]
+        return self.plan.deep[di].vocab if di >= 0 else self.plan.wide[wi].vocab
+
+    def _call(self, fn, name, *mid):
+        dev = self.step.device
+        L.check(fn(ctypes.c_void_p(self._units_dev.data_ptr()), len(self.plan.units), *mid,
+                   ctypes.c_void_p(self.step.data_ptr()), ctypes.byref(self.opt), self.vec, self.max_dim,
+                   L.stream_handle(dev)), name)
+
+    def catchup(self, X):
+        """Before the gather of a train step: bring the batch's rows to the current step.  Returns ids_t."""
+        plan = self.plan
+        self._ensure(X.device)
+        B = X.shape[0]
+        ids_t = torch.empty((len(plan.units), B), dtype=torch.int32, device=X.device)
+        L.check(L.lib().dctr_embed_ids(plan.units_ptr(), len(plan.units), ctypes.c_void_p(X.data_ptr()), X.stride(0), B,
+                                       ctypes.c_void_p(ids_t.data_ptr()), L.stream_handle(X.device)), "dctr_embed_ids")
+        self._call(L.lib().dctr_lazy_catchup, "dctr_lazy_catchup", ctypes.c_void_p(ids_t.data_ptr()), B)
+        return ids_t
+
+    def apply(self, ids_t):
+        """After dctr_embed_update(ACCUM): step t+1 on the batch's rows, then t += 1."""
+        self._ensure(ids_t.device)
+        self._call(L.lib().dctr_lazy_apply, "dctr_lazy_apply", ctypes.c_void_p(ids_t.data_ptr()), ids_t.shape[1])
+        L.check(L.lib().dctr_lazy_step_inc(ctypes.c_void_p(self.step.data_ptr()), L.stream_handle(ids_t.device)),
+                "dctr_lazy_step_inc")
+        self.dirty = True
+        self._reg = None
+
+    def flush(self, device=None):
+        """Bring EVERY row to the current step (before predict / evaluate / state_dict read the tables)."""
+        if not self.dirty or self.step is None:
+            return
+        self._ensure(self.step.device)
+        self._call(L.lib().dctr_lazy_flush, "dctr_lazy_flush", int(self.plan.max_vocab))
+        self.dirty = False
+        if self.optimizer is not None and self.kind == "adam" and not torch.cuda.is_current_stream_capturing():
+            t = float(int(self.step.item()))
+            for p in self.plan.table_params:
+                st = self.optimizer.state.get(p)
+                if st is not None and "step" in st:
+                    st["step"] = torch.tensor(t, dtype=st["step"].dtype) if torch.is_tensor(st["step"]) else t
+
+    def reg_value(self, device):
+        """lambda * sum(w^2) over the lazily regularised tables (the term get_regularization_loss adds to the LOGGED
+        loss): exact at every call for small models, the value of the last flush otherwise."""
+        if not any(v > 0 for v in self.l2.values()):
+            return None
+        if self.n_elems <= self.EXACT_REG_ELEMS:
+            self.flush()
+            self._reg = None
+        if self._reg is None:
+            if self.dirty and self.n_elems > self.EXACT_REG_ELEMS:
+                return self._last_reg if getattr(self, "_last_reg", None) is not None else \
+                    torch.zeros((1,), device=device)
+            tot = torch.zeros((1,), device=device)
+            for p in self.plan.table_params:
+                lam = self.l2.get(id(p), 0.0)
+                if lam > 0:
+                    tot = tot + torch.sum(lam * torch.square(p.detach()))
+            self._reg = tot
+            self._last_reg = tot
+        return self._reg
+
+
 class EmbeddingPlan(object):
     """Host mirror of ``dctr_plan_t`` + the device arrays it points to.
 
@@ -152,7 +296,16 @@ class EmbeddingPlan(object):
         self.exchange = None   # set by parallel.DataParallelTrainer: backward hands row gradients over
         self.sharder = None    # set by parallel.ShardedTrainer: lookups go through the table-sharded exchange
         self.dense_sink = None
+        self._lazy = None      # LazyState when the tables take the exact lazy regularised / Adam update
         self._reset_device_image()
+
+    @property
+    def lazy(self):
+        return self._owner.lazy if self._owner is not None else self._lazy
+
+    @lazy.setter
+    def lazy(self, value):
+        self._lazy = value
 
     def _reset_device_image(self):
         self._key = None
@@ -172,6 +325,7 @@ class EmbeddingPlan(object):
         d["exchange"] = None
         d["sharder"] = None
         d["dense_sink"] = None
+        d["_lazy"] = None          # re-created by the model's compile() / first train step
         return d
 
     def __setstate__(self, d):

@@ -124,9 +124,21 @@ class BaseModel(nn.Module):
 
     def __getstate__(self):
         # captured hipGraphs hold raw device handles: never pickled, re-captured on demand
+        self._flush_lazy()       # the pickled tables are the reference's tables
         d = dict(self.__dict__)
         d["_fit_graph"] = None
         return d
+
+    def _flush_lazy(self):
+        """Tables on the exact lazy update (csrc/lazy.hip) hold rows that are behind the optimizer's step count:
+        bring them up to date before anything outside the train step looks at them."""
+        plan = self.__dict__.get("_plan")
+        if plan is not None and plan._lazy is not None:
+            plan._lazy.flush()
+
+    def state_dict(self, *args, **kwargs):
+        self._flush_lazy()
+        return super(BaseModel, self).state_dict(*args, **kwargs)
 
     # ------------------------------------------------------------------------------------------------
     # hot path entry points
@@ -145,6 +157,8 @@ class BaseModel(nn.Module):
             if lm._plan is not None:
                 lm._plan.share_update_with(self._plan)
             self._apply_update_mode()
+        elif self._plan.update[0] == "lazy" and self._plan._lazy is None:
+            self._apply_update_mode()        # an unpickled model: the lazy state is rebuilt from the optimizer
         return self._plan
 
     def fused_inputs(self, X, want_fm=False, full=False):
@@ -240,11 +254,21 @@ class BaseModel(nn.Module):
 
     def get_regularization_loss(self):
         total = torch.zeros((1,), device=self.device)
+        # tables on the exact lazy update (csrc/lazy.hip): their L2 GRADIENT is applied by the kernels, their term of
+        # the logged loss comes from LazyState.reg_value -- never a dense O(vocabulary) autograd node
+        lazy = self._plan.lazy if (self._plan is not None and self._plan.update[0] == "lazy") else None
+        lazy_ids = set(id(p) for p in self._plan.table_params) if lazy is not None else ()
+        if lazy is not None:
+            rv = lazy.reg_value(self.device)
+            if rv is not None:
+                total = total + rv
         for weight_list, l1, l2 in self.regularization_weight:
             if not (l1 > 0 or l2 > 0):
                 continue
             for w in weight_list:
                 p = w[1] if isinstance(w, tuple) else w  # named_parameters() yields (name, tensor)
+                if id(p) in lazy_ids:
+                    continue
                 if l1 > 0:
                     total = total + torch.sum(l1 * torch.abs(p))
                 if l2 > 0:
@@ -358,10 +382,87 @@ class BaseModel(nn.Module):
                 return ("adagrad", float(g0["lr"]), float(g0["eps"])), {p: opt.state[p]["sum"] for p in tables}
         return ("dense",), {}
 
+    def _lazy_update_mode(self):
+        """("lazy", kind) + the LazyState arguments when the tables can take the EXACT lazy form of the reference's
+        dense regularised / Adam update (csrc/lazy.hip): fixed-length fields over distinct tables, a plain SGD /
+        Adagrad / Adam over all tables, L2-only regularisation of the tables.  None otherwise."""
+        opt = getattr(self, "optim", None)
+        plan = self._plan
+        if opt is None or plan is None or os.environ.get("DCTR_LAZY_UPDATE", "1") == "0" or \
+                os.environ.get("DCTR_SPARSE_UPDATE", "1") == "0":
+            return None
+        tables = plan.table_params
+        if not tables or not plan.unit_path or plan.max_dim > 64 * (4 if plan.vec == 4 else 1):
+            return None
+        l2 = {}
+        tids = set(id(p) for p in tables)
+        for weight_list, l1, l2v in self.regularization_weight:
+            for w in weight_list:
+                p = w[1] if isinstance(w, tuple) else w
+                if id(p) in tids:
+                    if l1 > 0:
+                        return None
+                    l2[p] = l2.get(p, 0.0) + float(l2v)
+        group_of = {}
+        for grp in opt.param_groups:
+            for p in grp["params"]:
+                group_of[id(p)] = grp
+        groups = [group_of.get(id(p)) for p in tables]
+        if any(g is None for g in groups):
+            return None
+        g0 = groups[0]
+
+        def same(key):
+            return all(g.get(key) == g0.get(key) for g in groups)
+
+        plain = all(g.get("weight_decay", 0) == 0 and not g.get("maximize", False) for g in groups)
+        if not plain or not same("lr"):
+            return None
+        if type(opt) is torch.optim.SGD:
+            if all(g.get("momentum", 0) == 0 and not g.get("nesterov", False) for g in groups):
+                return dict(kind="sgd", lr=g0["lr"], eps=0.0, beta1=0.0, beta2=0.0, l2=l2, s1={}, s2={})
+        if type(opt) is torch.optim.Adagrad:
+            if same("eps") and all(g.get("lr_decay", 0) == 0 for g in groups) and \
+                    all("sum" in opt.state.get(p, {}) for p in tables):
+                return dict(kind="adagrad", lr=g0["lr"], eps=g0["eps"], beta1=0.0, beta2=0.0, l2=l2,
+                            s1={p: opt.state[p]["sum"] for p in tables}, s2={})
+        if type(opt) is torch.optim.Adam:
+            if same("eps") and same("betas") and all(not g.get("amsgrad", False) and not g.get("capturable", False) and
+                                                       not g.get("fused", False) for g in groups):
+                for p in tables:      # torch creates Adam's state at the first step(); the kernels need it now
+                    st = opt.state[p]
+                    if "exp_avg" not in st:
+                        st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                        st["exp_avg"] = torch.zeros_like(p.data)
+                        st["exp_avg_sq"] = torch.zeros_like(p.data)
+                return dict(kind="adam", lr=g0["lr"], eps=g0["eps"], beta1=g0["betas"][0], beta2=g0["betas"][1], l2=l2,
+                            s1={p: opt.state[p]["exp_avg"] for p in tables},
+                            s2={p: opt.state[p]["exp_avg_sq"] for p in tables})
+        return None
+
     def _apply_update_mode(self):
         if self._plan is None:
             return
         mode, state = self._sparse_update_mode()
+        lazy = self._lazy_update_mode() if mode[0] == "dense" else None
+        if lazy is not None:
+            from .._hip.plan import LazyState
+            new = LazyState(self._plan, optimizer=self.optim, **lazy)
+            old = self._plan._lazy
+            if old is not None and old.signature() == new.signature() and old.optimizer is self.optim:
+                old.s1, old.s2 = new.s1, new.s2       # same schedule: keep the stamps and the step counter
+                old._key = None
+            else:
+                if old is not None:
+                    old.flush()
+                self._plan._lazy = new
+            self._plan.set_state({})
+            self._plan.ensure_gacc()
+            self._plan.update = ("lazy", lazy["kind"])
+            return
+        if self._plan._lazy is not None:
+            self._plan._lazy.flush()
+            self._plan._lazy = None
         self._plan.set_state(state)
         if mode[0] == "adagrad" or (mode[0] == "sgd" and self._plan.has_maxpool):
             self._plan.ensure_gacc()   # two-pass updates: allocate the slabs now (outside any graph capture)

@@ -113,6 +113,9 @@ class DataParallelTrainer(object):
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
         self.plan = model.model_plan()
+        if self.plan.update[0] == "lazy":
+            raise NotImplementedError("the lazy regularised / Adam table update is single-GPU; compile with plain "
+                                      "sgd / adagrad and l2_reg_embedding = l2_reg_linear = 0 for multi-GPU training")
         if not self.plan.unit_path:
             raise NotImplementedError("data-parallel training needs fixed-length sparse features over distinct "
                                       "tables (the deterministic update kernel); pooled VarLen features are "

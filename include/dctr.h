@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 7
+#define DCTR_ABI_VERSION 8
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -187,6 +187,53 @@ int dctr_fm_fwd(const float* E, int64_t ld_b, int32_t B, int32_t F, int32_t D, f
                 dctr_stream_t stream);
 int dctr_fm_bwd(const float* E, int64_t ld_b, int32_t B, int32_t F, int32_t D, const float* gy,
                 float* gE, int64_t ld_gb, int32_t accumulate, dctr_stream_t stream);
+
+/* ---- exact lazy regularised / Adam embedding update (csrc/lazy.hip) ------------------------------------------
+ * Replaces, in O(batch) per step, what the reference does in O(vocabulary) whenever every row of a table moves at
+ * every step: the dense L2 gradient 2*lambda*w of get_regularization_loss (basemodel.py:412-428; l2_reg_embedding /
+ * l2_reg_linear default to 1e-5) and torch.optim.Adam's moment-driven updates of untouched rows
+ * (basemodel.py:447-461).  A row's trajectory between two batches that touch it depends on the row alone, so it is
+ * replayed -- the same recurrence, step by step -- when the row is next needed.  One "unit" = one id column of X with
+ * the deep and / or wide table it feeds (as in dctr_embed_update); `stamp[row]` = optimizer steps already applied
+ * to the row, `*step` (device) = steps completed so far.  Per train step the caller enqueues
+ *   dctr_embed_ids -> dctr_lazy_catchup -> dctr_embed_fwd -> ... -> dctr_embed_update(DCTR_UPD_ACCUM)
+ *   -> dctr_lazy_apply -> dctr_lazy_step_inc,
+ * and dctr_lazy_flush before anything else reads the tables (predict / evaluate / state_dict).
+ *   *_s1  Adagrad `sum` | Adam `exp_avg`     *_s2  Adam `exp_avg_sq`     *_g  gradient slab, zero at rest
+ *   vec   1 or 4: every deep dim and base pointer is a multiple of `vec` floats;  max_dim <= 64*vec                */
+#define DCTR_LAZY_SGD 0
+#define DCTR_LAZY_ADAGRAD 1
+#define DCTR_LAZY_ADAM 2
+typedef struct dctr_lazy_unit {
+  float* deep;    /* [vocab, dim] or NULL */
+  float* deep_s1;
+  float* deep_s2;
+  float* deep_g;
+  float* wide;    /* [vocab] or NULL */
+  float* wide_s1;
+  float* wide_s2;
+  float* wide_g;
+  int32_t* stamp; /* [vocab] */
+  int64_t vocab;
+  int32_t dim;
+  int32_t col;
+  float l2_deep;  /* lambda of the L2 term lambda * sum(w^2) on the deep table */
+  float l2_wide;
+} dctr_lazy_unit_t;
+typedef struct dctr_lazy_opt {
+  int32_t kind; /* DCTR_LAZY_* */
+  float lr, eps, beta1, beta2;
+} dctr_lazy_opt_t;
+size_t dctr_sizeof_lazy_unit(void);
+int dctr_lazy_catchup(const dctr_lazy_unit_t* units, int32_t n_units, const int32_t* ids_t, int32_t B,
+                      const int32_t* step, const dctr_lazy_opt_t* opt, int32_t vec, int32_t max_dim,
+                      dctr_stream_t stream);
+int dctr_lazy_apply(const dctr_lazy_unit_t* units, int32_t n_units, const int32_t* ids_t, int32_t B,
+                    const int32_t* step, const dctr_lazy_opt_t* opt, int32_t vec, int32_t max_dim,
+                    dctr_stream_t stream);
+int dctr_lazy_flush(const dctr_lazy_unit_t* units, int32_t n_units, int64_t max_vocab, const int32_t* step,
+                    const dctr_lazy_opt_t* opt, int32_t vec, int32_t max_dim, dctr_stream_t stream);
+int dctr_lazy_step_inc(int32_t* step, dctr_stream_t stream);
 
 /* ---- CIN layer (interaction.py:207-248) on fp32 MFMA (csrc/cin.hip) -------------------------------
  * One Compressed-Interaction layer without ever materialising Z = H (x) X0:

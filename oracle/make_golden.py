@@ -122,8 +122,8 @@ def mixed_columns(dim=4):
 CASES = []
 
 
-def case(name, model, lin, dnn, batch=64, seed=0, steps=False, **kwargs):
-    CASES.append({"name": name, "batch": batch, "seed": seed, "steps": steps,
+def case(name, model, lin, dnn, batch=64, seed=0, steps=False, lazy=False, **kwargs):
+    CASES.append({"name": name, "batch": batch, "seed": seed, "steps": steps, "lazy": lazy,
                   "spec": {"model": model, "linear_columns": lin, "dnn_columns": dnn, "kwargs": kwargs}})
 
 
@@ -155,6 +155,16 @@ case("pnn_inner", "PNN", [], _d, batch=48, dnn_hidden_units=(32, 16), use_inner=
 _pm = mixed_columns(8)
 case("pnn_inner_varlen", "PNN", [], [c for c in _pm if c["kind"] != "dense"], batch=29, dnn_hidden_units=(16,),
      use_inner=True, use_outter=False)
+
+
+# regularised / Adam trajectories (the reference's DEFAULT kind of training: l2 > 0 on every table, basemodel.py:412-428,
+# and torch.optim.Adam, basemodel.py:447-461): small batches over small vocabularies, so that most rows are NOT touched
+# by a given step and are touched again a few steps later -- what the exact lazy update (csrc/lazy.hip) must replay
+_l = criteo_columns(8, 3, 20, 8)
+case("lazy_deepfm", "DeepFM", _l, _l, batch=24, lazy=True, dnn_hidden_units=(16, 8))
+_ld = criteo_columns(6, 2, 16, 8)
+case("lazy_dcn", "DCN", _ld, _ld, batch=24, lazy=True, dnn_hidden_units=(16,), cross_num=2)
+LAZY_STEPS, LAZY_L2 = 8, 1e-3
 
 
 # --------------------------------------------------------------------------------------------------
@@ -282,6 +292,40 @@ def run_case(ref, case_):
             out[opt_name + "3_loss"] = np.array(losses, np.float64)
             for k, v in model.state_dict().items():
                 out[opt_name + "3/" + k] = v.detach().numpy().copy()
+    if case_.get("lazy"):
+        Xs, ys = zip(*[synth_inputs(spec, batch, rng) for _ in range(LAZY_STEPS)])
+        out["lazy_X"], out["lazy_y"] = np.stack(Xs), np.stack(ys)
+        start = {k: v.clone() for k, v in model.state_dict().items()}
+        for tag, opt_name, l2 in (("sgd", "sgd", LAZY_L2), ("adagrad", "adagrad", LAZY_L2), ("adam", "adam", LAZY_L2),
+                                  ("adam0", "adam", 0.0)):
+            torch.manual_seed(case_["seed"])
+            m = build_reference_model(ref, spec, l2=l2)
+            m.load_state_dict(start)
+            m.compile(opt_name, "binary_crossentropy", metrics=[])
+            m.train()
+            bce, tot = [], []
+            for Xb, yb in zip(Xs, ys):  # the reference's own step, basemodel.py:242-262
+                yp = m(torch.from_numpy(Xb)).squeeze()
+                m.optim.zero_grad()
+                ls = m.loss_func(yp, torch.from_numpy(yb), reduction="sum")
+                total = ls + m.get_regularization_loss() + m.aux_loss
+                total.backward()
+                m.optim.step()
+                bce.append(ls.item())
+                tot.append(total.item())
+            out["lazy_%s_bce" % tag] = np.array(bce, np.float64)
+            out["lazy_%s_total" % tag] = np.array(tot, np.float64)
+            for k, v in m.state_dict().items():
+                out["lazy_%s/%s" % (tag, k)] = v.detach().numpy().copy()
+            m.eval()
+            with torch.no_grad():
+                out["lazy_%s_pred" % tag] = m(torch.from_numpy(Xs[0])).numpy().reshape(-1, 1)
+            # optimizer state of the first deep table (state_dict compatibility of the lazily updated state)
+            p0 = m.embedding_dict[spec["dnn_columns"][0]["embedding_name"]].weight
+            st = m.optim.state[p0]
+            for key in ("sum", "exp_avg", "exp_avg_sq"):
+                if key in st:
+                    out["lazy_%s_state_%s" % (tag, key)] = st[key].detach().numpy().copy()
     return out
 
 

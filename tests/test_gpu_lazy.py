@@ -1,0 +1,127 @@
+"""GPU: the exact lazy regularised / Adam table update (csrc/lazy.hip) against trajectories of the REAL reference.
+
+The fixtures (oracle/make_golden.py, ``lazy_*``) hold 8 training steps of the reference with its default kind of
+configuration -- an L2 term on every table (l2 = 1e-3 here) under SGD / Adagrad / Adam, and Adam without L2 -- on
+small batches over small vocabularies: most rows are untouched by a step and touched again a few steps later.  The
+reference updates every row at every step (dense gradients, O(vocabulary)); the drop-in replays each row's steps when
+it is next needed (O(batch)) and must land on the same parameters, losses, predictions and optimizer state.
+Tolerance: 2e-5 x max|reference| (fp32 re-association; the recurrences are the same)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_model, load_golden, max_abs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CASES = [("lazy_deepfm", t) for t in ("sgd", "adagrad", "adam", "adam0")] + \
+        [("lazy_dcn", t) for t in ("sgd", "adagrad", "adam", "adam0")]
+
+
+def _close(tag, got, ref, tol=2e-5):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    scale = max(1.0, float(np.max(np.abs(ref))) if ref.size else 1.0)
+    err = max_abs(got, ref)
+    assert err <= tol * scale, "%s: max|d| = %.3e (scale %.3e)" % (tag, err, scale)
+
+
+def _run(name, tag, steps=None):
+    g = load_golden(name)
+    ex = g["extra"]
+    l2 = 0.0 if tag == "adam0" else 1e-3
+    m = build_model(g["spec"], DEV, l2=l2)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in g["params"].items()})
+    m.compile("adam" if tag == "adam0" else tag, "binary_crossentropy", metrics=[])
+    m.train()
+    plan = m.model_plan()
+    assert plan.update == ("lazy", "adam" if tag == "adam0" else tag), plan.update
+    bce, tot = [], []
+    Xs, ys = ex["lazy_X"], ex["lazy_y"]
+    for i in range(len(Xs) if steps is None else steps):
+        loss, total, _ = m._train_step(torch.from_numpy(Xs[i]).to(DEV), torch.from_numpy(ys[i]).to(DEV))
+        bce.append(float(loss.item()))
+        tot.append(float(total.item()))
+    return g, m, bce, tot
+
+
+@pytest.mark.parametrize("name,tag", CASES)
+def test_lazy_trajectory_matches_reference(name, tag):
+    g, m, bce, tot = _run(name, tag)
+    ex = g["extra"]
+    np.testing.assert_allclose(bce, ex["lazy_%s_bce" % tag], rtol=2e-5)
+    np.testing.assert_allclose(tot, ex["lazy_%s_total" % tag], rtol=2e-5)
+    sd = m.state_dict()                     # flushes: every row replayed to the current step
+    for k, v in ex.items():
+        if k.startswith("lazy_%s/" % tag):
+            _close(k, sd[k[len("lazy_%s/" % tag):]].cpu().numpy(), v)
+    # predict() on the flushed tables
+    m.eval()
+    with torch.no_grad():
+        pred = m(torch.from_numpy(ex["lazy_X"][0]).to(DEV))
+    _close("pred", pred.cpu().numpy().reshape(-1, 1), ex["lazy_%s_pred" % tag])
+    # the torch optimizer's state tensors ARE the kernels' state: optimizer.state_dict() stays meaningful
+    p0 = m.embedding_dict[g["spec"]["dnn_columns"][0]["embedding_name"]].weight
+    st = m.optim.state[p0]
+    for key in ("sum", "exp_avg", "exp_avg_sq"):
+        ref = ex.get("lazy_%s_state_%s" % (tag, key))
+        if ref is not None:
+            _close("state." + key, st[key].cpu().numpy(), ref)
+    if tag.startswith("adam"):
+        assert float(st["step"]) == len(ex["lazy_X"])
+
+
+def test_lazy_mid_run_predict_and_resume():
+    """A flush in the middle of training (predict between steps) must not disturb the trajectory."""
+    name, tag = "lazy_deepfm", "adam"
+    g = load_golden(name)
+    ex = g["extra"]
+    m = build_model(g["spec"], DEV, l2=1e-3)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in g["params"].items()})
+    m.compile(tag, "binary_crossentropy", metrics=[])
+    Xs, ys = ex["lazy_X"], ex["lazy_y"]
+    for i in range(len(Xs)):
+        m.train()
+        m._train_step(torch.from_numpy(Xs[i]).to(DEV), torch.from_numpy(ys[i]).to(DEV))
+        if i in (2, 5):
+            m.eval()
+            with torch.no_grad():
+                m(torch.from_numpy(Xs[0]).to(DEV))
+    sd = m.state_dict()
+    for k, v in ex.items():
+        if k.startswith("lazy_adam/"):
+            _close(k, sd[k[len("lazy_adam/"):]].cpu().numpy(), v)
+
+
+def test_lazy_equals_dense_path(monkeypatch):
+    """Same model, same steps, DCTR_LAZY_UPDATE=0 (exact dense gradients + torch.optim): same parameters."""
+    g, m, bce, tot = _run("lazy_deepfm", "adagrad")
+    monkeypatch.setenv("DCTR_LAZY_UPDATE", "0")
+    g2 = load_golden("lazy_deepfm")
+    m2 = build_model(g2["spec"], DEV, l2=1e-3)
+    m2.load_state_dict({k: torch.from_numpy(v) for k, v in g2["params"].items()})
+    m2.compile("adagrad", "binary_crossentropy", metrics=[])
+    m2.train()
+    assert m2.model_plan().update == ("dense",)
+    for i in range(len(g2["extra"]["lazy_X"])):
+        m2._train_step(torch.from_numpy(g2["extra"]["lazy_X"][i]).to(DEV), torch.from_numpy(g2["extra"]["lazy_y"][i]).to(DEV))
+    a, b = m.state_dict(), m2.state_dict()
+    for k in a:
+        _close(k, a[k].cpu().numpy(), b[k].cpu().numpy())
+
+
+def test_default_kwargs_fit_runs_lazy():
+    """Reference defaults (l2_reg_embedding = l2_reg_linear = 1e-5, 'adam') through fit / predict."""
+    g = load_golden("lazy_deepfm")
+    from helpers import feature_columns
+    from deepctr_torch.models import DeepFM
+    cols = feature_columns(g["spec"]["dnn_columns"])
+    m = DeepFM(cols, cols, dnn_hidden_units=(16, 8), device=DEV)        # default l2 = 1e-5
+    m.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy"])
+    X = np.concatenate(list(g["extra"]["lazy_X"]), 0)
+    y = np.concatenate(list(g["extra"]["lazy_y"]), 0)
+    x = {c["name"]: X[:, i] for i, c in enumerate(g["spec"]["dnn_columns"])}
+    hist = m.fit(x, y, batch_size=32, epochs=2, verbose=0, validation_split=0.2)
+    assert m.model_plan().update == ("lazy", "adam")
+    assert len(hist.history["loss"]) == 2 and np.isfinite(hist.history["loss"]).all()
+    pred = m.predict(x, batch_size=64)
+    assert pred.shape == (X.shape[0], 1) and np.all((pred > 0) & (pred < 1))

@@ -62,14 +62,27 @@ def test_update_mode_selection():
     assert m._plan.update == ("sgd", 0.01)
     m.compile("adagrad", "binary_crossentropy")
     assert m._plan.update[0] == "adagrad" and m._plan.update[1:] == (0.01, 1e-10)
-    m.compile("adam", "binary_crossentropy")
-    assert m._plan.update == ("dense",)
+    m.compile("adam", "binary_crossentropy")          # every row moves every step: the exact lazy replay
+    assert m._plan.update == ("lazy", "adam") and m._plan.lazy.kind == "adam"
+    assert all("exp_avg" in m.optim.state[p] for p in m._plan.table_params)
     m.compile(torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9), "binary_crossentropy")
-    assert m._plan.update == ("dense",)
-    m2 = build_model(g["spec"], "cpu", l2=1e-5)       # reference default: dense L2 gradient on every row
+    assert m._plan.update == ("dense",) and m._plan.lazy is None
+    m2 = build_model(g["spec"], "cpu", l2=1e-5)       # reference default: an L2 gradient on every row of every table
     m2.model_plan()
     m2.compile("adagrad", "binary_crossentropy")
-    assert m2._plan.update == ("dense",)
+    assert m2._plan.update == ("lazy", "adagrad")
+    assert set(m2._plan.lazy.l2.values()) == {1e-5}
+    m2.compile("sgd", "binary_crossentropy")
+    assert m2._plan.update == ("lazy", "sgd")
+
+
+def test_lazy_update_can_be_switched_off(monkeypatch):
+    monkeypatch.setenv("DCTR_LAZY_UPDATE", "0")
+    g = load_golden("deepfm_criteo")
+    m = build_model(g["spec"], "cpu", l2=1e-5)
+    m.model_plan()
+    m.compile("adam", "binary_crossentropy")
+    assert m._plan.update == ("dense",)
 
 
 def test_model_pickles_with_plan():
