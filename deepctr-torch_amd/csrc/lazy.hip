@@ -203,6 +203,30 @@ __global__ __launch_bounds__(kT) void k_lazy(const dctr_lazy_unit_t* __restrict_
 
 __global__ void k_lazy_inc(int32_t* step) { *step += 1; }
 
+// the same optimizer step over a flat DENSE slab (tower weights, Linear.weight, the prediction bias), with an optional
+// per-element lambda: g = grad + 2*lambda*p.  T = *step + 1.
+__global__ __launch_bounds__(kT) void k_dense_opt_reg(float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ s1, float* __restrict__ s2,
+                                                      const float* __restrict__ lam, int64_t n,
+                                                      const int32_t* __restrict__ step_ptr, OptConst o) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+  if (i >= n) return;
+  float ss = 0.f, bc = 1.f;
+  if (o.kind == DCTR_LAZY_ADAM) {
+    AdamClock ck;
+    ck.start(o, *(const DCTR_GLOBAL int32_t*)step_ptr + 1);
+    ss = ck.step_size();
+    bc = ck.bc2_sqrt();
+  }
+  float w = ldg_f32(p + i);
+  float a = s1 ? ldg_f32(s1 + i) : 0.f, b = s2 ? ldg_f32(s2 + i) : 0.f;
+  const float gt = ldg_f32(g + i) + (lam ? 2.f * ldg_f32(lam + i) * w : 0.f);
+  opt_step(o, gt, w, a, b, ss, bc);
+  stg_f32(p + i, w);
+  if (s1) stg_f32(s1 + i, a);
+  if (s2) stg_f32(s2 + i, b);
+}
+
 int check(const dctr_lazy_unit_t* units, int n_units, const int32_t* step, const dctr_lazy_opt_t* opt, int vec,
           int max_dim) {
   if (!units || n_units <= 0 || !step || !opt) return DCTR_EINVAL;
@@ -256,6 +280,20 @@ extern "C" int dctr_lazy_flush(const dctr_lazy_unit_t* units, int32_t n_units, i
                                const dctr_lazy_opt_t* opt, int32_t vec, int32_t max_dim, dctr_stream_t stream) {
   if (max_vocab < 0) return DCTR_EINVAL;
   return launch<2>(units, n_units, nullptr, max_vocab, step, opt, vec, max_dim, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int dctr_dense_opt_reg(float* p, const float* g, float* s1, float* s2, const float* lam, int64_t n,
+                                  const dctr_lazy_opt_t* opt, const int32_t* step, dctr_stream_t stream) {
+  if (!p || !g || n < 0 || !opt || !step) return DCTR_EINVAL;
+  if (opt->kind == DCTR_LAZY_ADAGRAD && !s1) return DCTR_EINVAL;
+  if (opt->kind == DCTR_LAZY_ADAM && (!s1 || !s2)) return DCTR_EINVAL;
+  if (opt->kind != DCTR_LAZY_SGD && opt->kind != DCTR_LAZY_ADAGRAD && opt->kind != DCTR_LAZY_ADAM) return DCTR_EINVAL;
+  if (n == 0) return DCTR_OK;
+  OptConst o;
+  o.kind = opt->kind; o.lr = opt->lr; o.eps = opt->eps; o.beta1 = opt->beta1; o.beta2 = opt->beta2;
+  k_dense_opt_reg<<<dim3(static_cast<unsigned>((n + kT - 1) / kT)), dim3(kT), 0, static_cast<hipStream_t>(stream)>>>(
+      p, g, s1, s2, lam, n, step, o);
+  return launch_status();
 }
 
 extern "C" int dctr_lazy_step_inc(int32_t* step, dctr_stream_t stream) {

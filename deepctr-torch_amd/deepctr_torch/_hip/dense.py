@@ -42,6 +42,10 @@ class DenseSlab(object):
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
         self.state = None
+        self.state2 = None       # Adam: exp_avg_sq (state = exp_avg)
+        self.lam = None          # per-element lambda of the L2 terms on slab parameters (set_l2), or None
+        self.steps = None        # device int32: optimizer steps completed (Adam's bias correction; graph-replay safe)
+        self._optimizer = None
         with torch.no_grad():
             for p in self.params:
                 v = self._view(self.flat, p)
@@ -138,8 +142,77 @@ class DenseSlab(object):
             st["sum"] = v
         # the padding of the state stays 0; its gradient is 0, so sqrt(0) + eps never divides anything but 0
 
-    def step(self, kind, lr, eps=0.0):
+    def adopt_adam_state(self, optimizer):
+        """``exp_avg`` / ``exp_avg_sq`` of every slab parameter become views of two state slabs (torch creates Adam's
+        state at its first step(): it is created here, zeros, when missing); ``step`` is kept in ``self.steps`` on the
+        device and written back to the optimizer's state by ``sync_optimizer_state()``."""
+        self.state = torch.zeros_like(self.flat)
+        self.state2 = torch.zeros_like(self.flat)
+        t0 = 0
+        for p in self.params:
+            st = optimizer.state[p]
+            for key, slab in (("exp_avg", self.state), ("exp_avg_sq", self.state2)):
+                v = self._view(slab, p)
+                if key in st:
+                    v.copy_(st[key])
+                st[key] = v
+            if "step" in st:
+                t0 = max(t0, int(float(st["step"])))
+            else:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+        self.steps = torch.full((1,), t0, dtype=torch.int32, device=self.flat.device)
+        self._optimizer = optimizer
+
+    def sync_optimizer_state(self):
+        """Adam's per-parameter ``step`` entries follow the device counter (call outside graph capture)."""
+        if self._optimizer is None or self.steps is None:
+            return
+        t = float(int(self.steps.item()))
+        for p in self.params:
+            st = self._optimizer.state.get(p)
+            if st is not None and "step" in st:
+                st["step"] = torch.tensor(t, dtype=torch.float32)
+
+    def set_l2(self, lam_of):
+        """``{param: lambda}`` of the L2 terms on slab parameters: applied inside the optimizer kernel as
+        g += 2*lambda*p (what autograd adds for ``lambda * sum(p^2)``, basemodel.py:412-428)."""
+        lam_of = dict((id(p), float(v)) for p, v in lam_of.items() if v > 0)
+        if not lam_of:
+            self.lam = None
+            return
+        self.lam = torch.zeros_like(self.flat)
+        for p in self.params:
+            if id(p) in lam_of:
+                self._view(self.lam, p).fill_(lam_of[id(p)])
+
+    def reg_value(self):
+        """sum(lambda * p^2) over the slab (the dense parameters' share of get_regularization_loss), or None."""
+        if self.lam is None:
+            return None
+        return torch.dot(self.lam * self.flat, self.flat).reshape(1)
+
+    def _opt_reg(self, kind, lr, eps, beta1, beta2, stream):
+        o = L.LazyOpt()
+        o.kind = {"sgd": L.LAZY_SGD, "adagrad": L.LAZY_ADAGRAD, "adam": L.LAZY_ADAM}[kind]
+        o.lr, o.eps, o.beta1, o.beta2 = float(lr), float(eps), float(beta1), float(beta2)
+        if self.steps is None:
+            self.steps = torch.zeros((1,), dtype=torch.int32, device=self.flat.device)
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        L.check(L.lib().dctr_dense_opt_reg(ptr(self.flat), ptr(self.grad), ptr(self.state), ptr(self.state2),
+                                           ptr(self.lam), self.numel, ctypes.byref(o), ptr(self.steps), stream),
+                "dctr_dense_opt_reg")
+        L.check(L.lib().dctr_lazy_step_inc(ptr(self.steps), stream), "dctr_lazy_step_inc")
+
+    def step(self, kind, lr, eps=0.0, beta1=0.0, beta2=0.0):
         self.join()
+        if kind == "adam" or self.lam is not None:
+            # Adam, or L2 terms on slab parameters: the regularised kernel of csrc/lazy.hip (one launch + a counter)
+            if kind == "adagrad" and self.state is None:
+                raise RuntimeError("adopt_adagrad_state() first")
+            if kind == "adam" and self.state2 is None:
+                raise RuntimeError("adopt_adam_state() first")
+            self._opt_reg(kind, lr, eps, beta1, beta2, L.stream_handle(self.flat.device))
+            return
         opt = L.UPD_ADAGRAD if kind == "adagrad" else L.UPD_SGD
         st = self.state
         if opt == L.UPD_ADAGRAD and st is None:

@@ -96,6 +96,7 @@ SIGNATURES = {
     "dctr_lazy_apply": (ctypes.c_int, [_P, _I32, _P, _I32, _P, _P, _I32, _I32, _P]),
     "dctr_lazy_flush": (ctypes.c_int, [_P, _I32, _I64, _P, _P, _I32, _I32, _P]),
     "dctr_lazy_step_inc": (ctypes.c_int, [_P, _P]),
+    "dctr_dense_opt_reg": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P, _P]),
     "dctr_cin_workspace_floats": (ctypes.c_size_t, [_I32, _I32, _I32]),
     "dctr_cin_layer_fwd": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I64, _P,
                                           _P]),

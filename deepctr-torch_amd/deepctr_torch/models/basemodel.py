@@ -135,6 +135,9 @@ class BaseModel(nn.Module):
         plan = self.__dict__.get("_plan")
         if plan is not None and plan._lazy is not None:
             plan._lazy.flush()
+        fused = self.__dict__.get("_fused")
+        if fused and fused.get("slab") is not None and not torch.cuda.is_current_stream_capturing():
+            fused["slab"].sync_optimizer_state()      # Adam's per-parameter `step` entries
 
     def state_dict(self, *args, **kwargs):
         self._flush_lazy()
@@ -512,6 +515,11 @@ class BaseModel(nn.Module):
                                                   not g.get("maximize", False) for g in groups) and \
                     all("sum" in opt.state.get(p, {}) for p in params):
                 return ("adagrad", float(g0["lr"]), float(g0["eps"]))
+        if type(opt) is torch.optim.Adam:
+            if same("lr") and same("eps") and same("betas") and \
+                    all(g.get("weight_decay", 0) == 0 and not g.get("maximize", False) and not g.get("amsgrad", False)
+                        and not g.get("capturable", False) and not g.get("fused", False) for g in groups):
+                return ("adam", float(g0["lr"]), float(g0["eps"]), float(g0["betas"][0]), float(g0["betas"][1]))
         return None
 
     def _fused_step_state(self):
@@ -535,10 +543,24 @@ class BaseModel(nn.Module):
             return None
         if self.out.task != "binary" or not self.out.use_bias or self.loss_func is not F.binary_cross_entropy:
             return None
-        if any((l1 > 0 or l2 > 0) for (_, l1, l2) in self.regularization_weight):
+        if not plan.unit_path or plan.update[0] not in ("sgd", "adagrad", "lazy") or not plan.table_params:
             return None
-        if not plan.unit_path or plan.update[0] not in ("sgd", "adagrad") or not plan.table_params:
-            return None
+        # regularisers: L2 only; on tables they belong to the lazy update (csrc/lazy.hip), on dense parameters they are
+        # applied inside the slab optimizer kernel (DenseSlab.set_l2) -- never as dense autograd nodes
+        table_ids = set(id(p) for p in plan.table_params)
+        lam_of = {}
+        for weight_list, l1, l2 in self.regularization_weight:
+            if not (l1 > 0 or l2 > 0):
+                continue
+            for w in weight_list:
+                p = w[1] if isinstance(w, tuple) else w
+                if l1 > 0:
+                    return None
+                if id(p) in table_ids:
+                    if plan.update[0] != "lazy":
+                        return None
+                else:
+                    lam_of[p] = lam_of.get(p, 0.0) + float(l2)
         if getattr(dnn, "dropout_rate", 0):     # the fused step is cached across train() / eval() switches
             return None
         spec = _mlp.tower_layers(dnn, dnn_linear)
@@ -556,11 +578,17 @@ class BaseModel(nn.Module):
         if set(id(p) for p in dense) != set(id(p) for p in known) or any(not p.requires_grad for p in dense):
             return None
         mode = self._dense_update_mode(dense)
-        if mode is None or mode[0] != plan.update[0]:
+        table_kind = plan.update[1] if plan.update[0] == "lazy" else plan.update[0]
+        if mode is None or mode[0] != table_kind:
+            return None
+        if any(id(p) not in set(id(q) for q in dense) for p in lam_of):
             return None
         slab = _dense.DenseSlab(dense, pad_rows=[w for (w, b, r) in layers])
         if mode[0] == "adagrad":
             slab.adopt_adagrad_state(self.optim)
+        elif mode[0] == "adam":
+            slab.adopt_adam_state(self.optim)
+        slab.set_l2(lam_of)
         slab.attach_grads()
         st.update(ok=True, slab=slab, mode=mode, one=torch.ones((), dtype=torch.float32, device=slab.flat.device))
         return st
@@ -581,7 +609,15 @@ class BaseModel(nn.Module):
             slab.overlap = False
             slab.join()
         slab.step(*mode)
-        return loss.detach(), loss.detach().reshape(1), y_pred
+        total = loss.detach().reshape(1)
+        rv = slab.reg_value()                       # L2 terms: part of the LOGGED loss only (their gradients are applied
+        if rv is not None:                          # inside the optimizer kernels)
+            total = total + rv
+        if plan.update[0] == "lazy":
+            rv = plan.lazy.reg_value(xb.device)
+            if rv is not None:
+                total = total + rv
+        return loss.detach(), total, y_pred
 
     def _train_step(self, xb, yb):
         """forward -> loss(sum) + reg + aux -> backward (fused sparse update inside) -> dense optimizer step

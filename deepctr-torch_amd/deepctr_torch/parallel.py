@@ -401,6 +401,8 @@ class ShardedTrainer(object):
                 for p in model.parameters():
                     dist.broadcast(p.data, 0, group=process_group)
         st = model._fused_step_state()
+        if st is not None and (self.plan.update[0] not in ("sgd", "adagrad") or st["slab"].lam is not None):
+            st = None        # the lazy regularised / Adam update is single-GPU
         if st is None:
             raise NotImplementedError(
                 "table-sharded training runs the fused train step: a binary model with a relu DNN tower, "

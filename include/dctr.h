@@ -234,6 +234,11 @@ int dctr_lazy_apply(const dctr_lazy_unit_t* units, int32_t n_units, const int32_
 int dctr_lazy_flush(const dctr_lazy_unit_t* units, int32_t n_units, int64_t max_vocab, const int32_t* step,
                     const dctr_lazy_opt_t* opt, int32_t vec, int32_t max_dim, dctr_stream_t stream);
 int dctr_lazy_step_inc(int32_t* step, dctr_stream_t stream);
+/* The same optimizer step (number *step + 1) over a flat dense slab with an optional per-element lambda
+ * (g = grad + 2*lambda*p): what torch.optim.SGD / Adagrad / Adam do to the dense parameters when the model carries
+ * L2 terms (l2_reg_linear on Linear.weight, l2_reg_dnn) -- one launch, no dense autograd node for the L2 term.  */
+int dctr_dense_opt_reg(float* p, const float* g, float* s1, float* s2, const float* lam, int64_t n,
+                       const dctr_lazy_opt_t* opt, const int32_t* step, dctr_stream_t stream);
 
 /* ---- CIN layer (interaction.py:207-248) on fp32 MFMA (csrc/cin.hip) -------------------------------
  * One Compressed-Interaction layer without ever materialising Z = H (x) X0:
