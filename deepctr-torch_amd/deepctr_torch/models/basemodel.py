@@ -136,7 +136,8 @@ class BaseModel(nn.Module):
         if plan is not None and plan._lazy is not None:
             plan._lazy.flush()
         fused = self.__dict__.get("_fused")
-        if fused and fused.get("slab") is not None and not torch.cuda.is_current_stream_capturing():
+        if fused and fused.get("slab") is not None and fused["slab"].flat.device.type == "cuda" and \
+                not torch.cuda.is_current_stream_capturing():
             fused["slab"].sync_optimizer_state()      # Adam's per-parameter `step` entries
 
     def state_dict(self, *args, **kwargs):
@@ -600,8 +601,16 @@ class BaseModel(nn.Module):
         plan.dense_sink = slab
         # the tower's weight gradients run on a fork stream beside the embedding update (DCTR_OVERLAP_WGRAD=0: in line)
         slab.overlap = xb.is_cuda and os.environ.get("DCTR_OVERLAP_WGRAD", "1") != "0"
+        reg = None
         try:
             loss, y_pred = self.fused_loss(xb, yb, slab)
+            # L2 terms: part of the LOGGED loss only (their gradients are applied inside the optimizer kernels);
+            # evaluated on the weights the forward used, like the reference (basemodel.py:255-257)
+            reg = slab.reg_value()
+            if plan.update[0] == "lazy":
+                rv = plan.lazy.reg_value(xb.device)
+                if rv is not None:
+                    reg = rv if reg is None else reg + rv
             loss.backward(gradient=st["one"])       # a resident 1.0: no fill launch per step
         finally:
             self._grad_sink = None
@@ -610,13 +619,8 @@ class BaseModel(nn.Module):
             slab.join()
         slab.step(*mode)
         total = loss.detach().reshape(1)
-        rv = slab.reg_value()                       # L2 terms: part of the LOGGED loss only (their gradients are applied
-        if rv is not None:                          # inside the optimizer kernels)
-            total = total + rv
-        if plan.update[0] == "lazy":
-            rv = plan.lazy.reg_value(xb.device)
-            if rv is not None:
-                total = total + rv
+        if reg is not None:
+            total = total + reg
         return loss.detach(), total, y_pred
 
     def _train_step(self, xb, yb):
