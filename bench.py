@@ -236,7 +236,9 @@ def main():
     if use_graph:
         from deepctr_torch._hip.graph import GraphedTrainStep
         try:
-            graphed = GraphedTrainStep(model, *batch(0), steps_per_graph=args.steps_per_graph).capture(*batch(i))
+            # (the synthetic dataset was uploaded and synchronised long before: its slices are complete)
+            graphed = GraphedTrainStep(model, *batch(0), steps_per_graph=args.steps_per_graph,
+                                       inputs_ready=True).capture(*batch(i))
             step_fn = graphed
         except Exception as exc:  # capture is an optimisation: report and continue eagerly
             print("hipGraph capture failed (%s: %s); running eager" % (type(exc).__name__, exc), file=sys.stderr)

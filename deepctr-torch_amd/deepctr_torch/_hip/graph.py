@@ -27,8 +27,12 @@ class GraphedTrainStep(object):
     two groups later.
     """
 
-    def __init__(self, model, x_example, y_example, steps_per_graph=1, double_buffer=True):
+    def __init__(self, model, x_example, y_example, steps_per_graph=1, double_buffer=True, inputs_ready=False):
+        """``inputs_ready``: the caller guarantees that every batch it passes was COMPLETE on the device before the call
+        (slices of a resident dataset).  Otherwise (default) the staging copies first wait for the caller's stream --
+        a batch produced by an ``index_select`` that is still queued there must not be copied early."""
         self.model = model
+        self.inputs_ready = bool(inputs_ready)
         self.S = max(1, int(steps_per_graph))
         self.n_slots = 2 if double_buffer else 1
         # one block per buffer group: the S batches of a group are rows of ONE tensor, so that a caller holding S
@@ -86,9 +90,14 @@ class GraphedTrainStep(object):
         side = self._side
         if j == 0 and self._free[s] is not None:
             side.wait_event(self._free[s])          # the graph that last read this buffer group is done
+        if not self.inputs_ready:
+            side.wait_stream(torch.cuda.current_stream(xb.device))      # whatever produces xb / yb has run
         with torch.cuda.stream(side):
             self.x[s][j].copy_(xb, non_blocking=True)
             self.y[s][j].copy_(yb, non_blocking=True)
+        if not self.inputs_ready:
+            xb.record_stream(side)       # the caller may drop the batch right away: its memory must not be handed out
+            yb.record_stream(side)       # again before the copy on the side stream has read it
         out = self.outputs[s][j]
         self._j += 1
         if self._j == self.S:
@@ -107,9 +116,14 @@ class GraphedTrainStep(object):
         s, side = self._slot, self._side
         if self._free[s] is not None:
             side.wait_event(self._free[s])
+        if not self.inputs_ready:
+            side.wait_stream(torch.cuda.current_stream(x_block.device))
         with torch.cuda.stream(side):
             self.xg[s].copy_(x_block.reshape(self.xg[s].shape), non_blocking=True)
             self.yg[s].copy_(y_block.reshape(self.yg[s].shape), non_blocking=True)
+        if not self.inputs_ready:
+            x_block.record_stream(side)
+            y_block.record_stream(side)
         out = self.outputs[s][self.S - 1]
         self._j = self.S
         self._launch()
