@@ -49,12 +49,32 @@ for name, make, opt in CASES:
                 m._train_step(*batch(3 + i))
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps
+            r = {"mode": m.model_plan().update[0], "fused_step": bool(m._fused and m._fused.get("ok")),
+                 "ms_per_step": dt * 1e3, "samples_per_s": B / dt}
+            if lazy == "1" and r["fused_step"]:
+                try:                                # hipGraph replay of the fused lazy step (what fit() does)
+                    from deepctr_torch._hip.graph import GraphedTrainStep
+                    gs = GraphedTrainStep(m, *batch(0), steps_per_graph=4, inputs_ready=True).capture(*batch(0))
+                    for i in range(8):
+                        gs(*batch(i))
+                    gs.flush()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(96):
+                        gs(*batch(i))
+                    gs.flush()
+                    torch.cuda.synchronize()
+                    gt = (time.perf_counter() - t0) / 96
+                    r.update(graph_ms_per_step=gt * 1e3, graph_samples_per_s=B / gt)
+                except Exception as exc:  # noqa: BLE001
+                    r["graph_error"] = "%s: %s" % (type(exc).__name__, str(exc)[:200])
+                    torch.cuda.synchronize()
             t1 = time.perf_counter()
             m.state_dict()                         # includes the flush of every row in lazy mode
             torch.cuda.synchronize()
-            res["%s | lazy=%s" % (name, lazy)] = {"mode": m.model_plan().update[0], "ms_per_step": dt * 1e3,
-                                                  "samples_per_s": B / dt,
-                                                  "state_dict_ms": (time.perf_counter() - t1) * 1e3}
+            r["state_dict_ms"] = (time.perf_counter() - t1) * 1e3
+            m.model_plan().check_ids()
+            res["%s | lazy=%s" % (name, lazy)] = r
             del m
             torch.cuda.empty_cache()
         except Exception as exc:  # noqa: BLE001
