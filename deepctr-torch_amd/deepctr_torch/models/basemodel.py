@@ -144,6 +144,10 @@ class BaseModel(nn.Module):
         self._flush_lazy()
         return super(BaseModel, self).state_dict(*args, **kwargs)
 
+    def load_state_dict(self, *args, **kwargs):
+        self._flush_lazy()       # every stamp == the step counter: the loaded rows are current by definition
+        return super(BaseModel, self).load_state_dict(*args, **kwargs)
+
     # ------------------------------------------------------------------------------------------------
     # hot path entry points
     # ------------------------------------------------------------------------------------------------
