@@ -125,3 +125,32 @@ def test_default_kwargs_fit_runs_lazy():
     assert len(hist.history["loss"]) == 2 and np.isfinite(hist.history["loss"]).all()
     pred = m.predict(x, batch_size=64)
     assert pred.shape == (X.shape[0], 1) and np.all((pred > 0) & (pred < 1))
+
+
+@pytest.mark.parametrize("opt", ["adam", "adagrad"])
+def test_lazy_long_gaps_equal_dense_path(opt, monkeypatch):
+    """200 steps of batch 8 over 3000-row vocabularies: most rows wait tens to hundreds of steps between two touches
+    (the steady state of a big table).  The replayed trajectories must equal the exact dense path's."""
+    from deepctr_torch.inputs import DenseFeat, SparseFeat
+    from deepctr_torch.models import DeepFM
+    gen = torch.Generator().manual_seed(3)
+    V, B, steps = 3000, 8, 200
+    cols = [SparseFeat("a", V, 8), SparseFeat("b", V + 7, 8), DenseFeat("d", 2)]
+    X = torch.cat([torch.randint(0, V, (steps * B, 2), generator=gen).float(), torch.rand(steps * B, 2, generator=gen)], 1)
+    # a few hot ids so that some rows ARE touched often
+    X[::3, 0] = 5.0
+    y = torch.randint(0, 2, (steps * B,), generator=gen).float()
+    X, y = X.to(DEV), y.to(DEV)
+    finals = []
+    for lazy in ("1", "0"):
+        monkeypatch.setenv("DCTR_LAZY_UPDATE", lazy)
+        m = DeepFM(cols, cols, dnn_hidden_units=(8,), l2_reg_embedding=1e-3, l2_reg_linear=1e-3, init_std=0.1, seed=7,
+                   device=DEV)
+        m.compile(opt, "binary_crossentropy", metrics=[])
+        m.train()
+        assert m.model_plan().update[0] == ("lazy" if lazy == "1" else "dense")
+        for i in range(steps):
+            m._train_step(X[i * B:(i + 1) * B], y[i * B:(i + 1) * B])
+        finals.append({k: v.clone() for k, v in m.state_dict().items()})
+    for k in finals[0]:
+        _close(k, finals[0][k].cpu().numpy(), finals[1][k].cpu().numpy(), tol=1e-4)
