@@ -131,6 +131,30 @@ __global__ __launch_bounds__(kT) void k_lazy(const dctr_lazy_unit_t* __restrict_
     const int32_t id = ldg_i32(ids_t + static_cast<int64_t>(u) * n_entries + grp);
     row = (static_cast<uint64_t>(static_cast<int64_t>(id)) >= static_cast<uint64_t>(un.vocab)) ? 0 : id;
   }
+  // The row's strips are loaded BEFORE the claim is known (a row has one claimant per launch except for duplicate ids,
+  // whose losers simply drop what they loaded): the claim's atomic round trip and the row's HBM round trip overlap
+  // instead of following each other.  A winner's early loads are valid: nobody else writes its row in this launch.
+  const int e0 = gl * VEC;
+  const bool deep_on = un.deep != nullptr && e0 < un.dim;
+  const bool wide_on = un.wide != nullptr && gl == 0;
+  const float lam2d = 2.f * un.l2_deep, lam2w = 2.f * un.l2_wide;
+  const int64_t off = deep_on ? row * un.dim + e0 : 0;
+  float w[VEC], a[VEC], b[VEC], g[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) w[i] = a[i] = b[i] = g[i] = 0.f;
+  if (deep_on) {
+    load_vec<VEC>(un.deep + off, w);
+    if (un.deep_s1) load_vec<VEC>(un.deep_s1 + off, a);
+    if (un.deep_s2) load_vec<VEC>(un.deep_s2 + off, b);
+    if (MODE == 1) load_vec<VEC>(un.deep_g + off, g);
+  }
+  float ww[1] = {0.f}, wa[1] = {0.f}, wb[1] = {0.f}, wg = 0.f;
+  if (wide_on) {
+    ww[0] = ldg_f32(un.wide + row);
+    if (un.wide_s1) wa[0] = ldg_f32(un.wide_s1 + row);
+    if (un.wide_s2) wb[0] = ldg_f32(un.wide_s2 + row);
+    if (MODE == 1) wg = ldg_f32(un.wide_g + row);
+  }
   // claim the row: the winner is the only group that touches it in this launch
   const int target = (MODE == 1) ? t + 1 : t;
   int prev = 0;
@@ -145,59 +169,36 @@ __global__ __launch_bounds__(kT) void k_lazy(const dctr_lazy_unit_t* __restrict_
   prev = __shfl(prev, (threadIdx.x & 63) & ~(lpr - 1), kWave);
   if (prev >= target) return;
 
-  const int e0 = gl * VEC;
-  const bool deep_on = un.deep != nullptr && e0 < un.dim;
-  const bool wide_on = un.wide != nullptr && gl == 0;
-  const float lam2d = 2.f * un.l2_deep, lam2w = 2.f * un.l2_wide;
+  float ss1 = 0.f, bc1 = 1.f;        // Adam scalars of step t + 1 (apply)
+  if (MODE == 1 && o.kind == DCTR_LAZY_ADAM) {
+    AdamClock ck;
+    ck.start(o, t + 1);
+    ss1 = ck.step_size();
+    bc1 = ck.bc2_sqrt();
+  }
   if (deep_on) {
-    const int64_t off = row * un.dim + e0;
-    float w[VEC], a[VEC], b[VEC];
-    load_vec<VEC>(un.deep + off, w);
-    load_vec<VEC>(un.deep_s1 ? un.deep_s1 + off : nullptr, a);
-    load_vec<VEC>(un.deep_s2 ? un.deep_s2 + off : nullptr, b);
     replay<VEC>(o, lam2d, prev, t, w, a, b);          // (apply after a catch-up: prev == t, nothing to replay)
     if (MODE == 1) {
-      float g[VEC];
-      load_vec<VEC>(un.deep_g + off, g);
       float z[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) z[i] = 0.f;
       store_vec<VEC>(un.deep_g + off, z);             // zero at rest
-      AdamClock ck;
-      float ss = 0.f, bc = 1.f;
-      if (o.kind == DCTR_LAZY_ADAM) {
-        ck.start(o, t + 1);
-        ss = ck.step_size();
-        bc = ck.bc2_sqrt();
-      }
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) opt_step(o, g[i] + lam2d * w[i], w[i], a[i], b[i], ss, bc);
+      for (int i = 0; i < VEC; ++i) opt_step(o, g[i] + lam2d * w[i], w[i], a[i], b[i], ss1, bc1);
     }
     store_vec<VEC>(un.deep + off, w);
-    store_vec<VEC>(un.deep_s1 ? un.deep_s1 + off : nullptr, a);
-    store_vec<VEC>(un.deep_s2 ? un.deep_s2 + off : nullptr, b);
+    if (un.deep_s1) store_vec<VEC>(un.deep_s1 + off, a);
+    if (un.deep_s2) store_vec<VEC>(un.deep_s2 + off, b);
   }
   if (wide_on) {
-    float w[1], a[1], b[1];
-    load_vec<1>(un.wide + row, w);
-    load_vec<1>(un.wide_s1 ? un.wide_s1 + row : nullptr, a);
-    load_vec<1>(un.wide_s2 ? un.wide_s2 + row : nullptr, b);
-    replay<1>(o, lam2w, prev, t, w, a, b);
+    replay<1>(o, lam2w, prev, t, ww, wa, wb);
     if (MODE == 1) {
-      const float g = ldg_f32(un.wide_g + row);
       stg_f32(un.wide_g + row, 0.f);
-      AdamClock ck;
-      float ss = 0.f, bc = 1.f;
-      if (o.kind == DCTR_LAZY_ADAM) {
-        ck.start(o, t + 1);
-        ss = ck.step_size();
-        bc = ck.bc2_sqrt();
-      }
-      opt_step(o, g + lam2w * w[0], w[0], a[0], b[0], ss, bc);
+      opt_step(o, wg + lam2w * ww[0], ww[0], wa[0], wb[0], ss1, bc1);
     }
-    store_vec<1>(un.wide + row, w);
-    store_vec<1>(un.wide_s1 ? un.wide_s1 + row : nullptr, a);
-    store_vec<1>(un.wide_s2 ? un.wide_s2 + row : nullptr, b);
+    stg_f32(un.wide + row, ww[0]);
+    if (un.wide_s1) stg_f32(un.wide_s1 + row, wa[0]);
+    if (un.wide_s2) stg_f32(un.wide_s2 + row, wb[0]);
   }
 }
 
