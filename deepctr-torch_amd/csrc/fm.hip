@@ -51,6 +51,52 @@ __global__ __launch_bounds__(256) void k_fm_bwd(const float* __restrict__ E, int
   }
 }
 
+// BiInteractionPooling (interaction.py:54-61): the FM term BEFORE its sum over d,
+//     bi[b, d] = 0.5 * ((sum_f e[b,f,d])^2 - sum_f e[b,f,d]^2),
+// written straight into the NFM tower's input row [ bi (D) | dense (n_dense) ] (nfm.py:71: combined_dnn_input([bi_out],
+// dense_value_list)) -- the dense values are copied from the gather's row, nothing is concatenated afterwards.
+// G is the gather's output [B, ld_g]: row b = [ e_0 | ... | e_{F-1} | ... dense at dense_off ].  One lane per (b, d).
+__global__ __launch_bounds__(256) void k_bi_fwd(const float* __restrict__ G, int64_t ldg, int B, int F, int D,
+                                                int dense_off, int n_dense, float* __restrict__ out, int64_t ldo) {
+  const int W = D + n_dense;
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= static_cast<int64_t>(B) * W) return;
+  const int64_t b = idx / W;
+  const int c = static_cast<int>(idx - b * W);
+  const float* row = G + b * ldg;
+  if (c < D) {
+    float s = 0.f, q = 0.f;
+    for (int f = 0; f < F; ++f) {
+      const float v = ldg_f32(row + f * D + c);
+      s += v;
+      q += v * v;
+    }
+    out[b * ldo + c] = 0.5f * (s * s - q);
+  } else {
+    out[b * ldo + c] = ldg_f32(row + dense_off + (c - D));
+  }
+}
+
+// gG[b, f*D + d] = g[b, d] * (S[b, d] - e[b, f, d]) ;  gG[b, dense_off + j] = g[b, D + j]   (gG has G's layout)
+__global__ __launch_bounds__(256) void k_bi_bwd(const float* __restrict__ G, int64_t ldg, int B, int F, int D,
+                                                int dense_off, int n_dense, const float* __restrict__ go, int64_t ldgo,
+                                                float* __restrict__ gG, int64_t ldgg) {
+  const int W = D + n_dense;
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= static_cast<int64_t>(B) * W) return;
+  const int64_t b = idx / W;
+  const int c = static_cast<int>(idx - b * W);
+  const float g = ldg_f32(go + b * ldgo + c);
+  if (c < D) {
+    const float* row = G + b * ldg;
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) s += ldg_f32(row + f * D + c);
+    for (int f = 0; f < F; ++f) gG[b * ldgg + f * D + c] = g * (s - ldg_f32(row + f * D + c));
+  } else {
+    gG[b * ldgg + dense_off + (c - D)] = g;
+  }
+}
+
 int pick_lpr(int D) {
   int lpr = 1;
   while (lpr < D && lpr < 64) lpr <<= 1;
@@ -93,5 +139,31 @@ extern "C" int dctr_fm_bwd(const float* E, int64_t ld_b, int32_t B, int32_t F, i
   hipStream_t s = static_cast<hipStream_t>(stream);
   FM_DISPATCH(lpr, k_fm_bwd<LPR><<<dim3((B + spb - 1) / spb), dim3(256), 0, s>>>(
                        E, ld_b, B, F, D, gy, gE, ld_gb, accumulate));
+  return launch_status();
+}
+
+extern "C" int dctr_bi_pooling_fwd(const float* G, int64_t ld_g, int32_t B, int32_t F, int32_t D, int32_t dense_off,
+                                   int32_t n_dense, float* out, int64_t ld_o, dctr_stream_t stream) {
+  if (!G || !out || B < 0 || F <= 0 || D <= 0 || n_dense < 0 || ld_g < static_cast<int64_t>(F) * D ||
+      ld_o < D + n_dense || (n_dense > 0 && (dense_off < F * D || ld_g < dense_off + n_dense)))
+    return DCTR_EINVAL;
+  if (B == 0) return DCTR_OK;
+  const int64_t n = static_cast<int64_t>(B) * (D + n_dense);
+  k_bi_fwd<<<dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(
+      G, ld_g, B, F, D, dense_off, n_dense, out, ld_o);
+  return launch_status();
+}
+
+extern "C" int dctr_bi_pooling_bwd(const float* G, int64_t ld_g, int32_t B, int32_t F, int32_t D, int32_t dense_off,
+                                   int32_t n_dense, const float* gout, int64_t ld_go, float* gG, int64_t ld_gg,
+                                   dctr_stream_t stream) {
+  if (!G || !gout || !gG || B < 0 || F <= 0 || D <= 0 || n_dense < 0 || ld_g < static_cast<int64_t>(F) * D ||
+      ld_gg < static_cast<int64_t>(F) * D || ld_go < D + n_dense ||
+      (n_dense > 0 && (dense_off < F * D || ld_gg < dense_off + n_dense)))
+    return DCTR_EINVAL;
+  if (B == 0) return DCTR_OK;
+  const int64_t n = static_cast<int64_t>(B) * (D + n_dense);
+  k_bi_bwd<<<dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(
+      G, ld_g, B, F, D, dense_off, n_dense, gout, ld_go, gG, ld_gg);
   return launch_status();
 }

@@ -273,6 +273,42 @@ class FMFunction(torch.autograd.Function):
         return gE
 
 
+class BiPoolFunction(torch.autograd.Function):
+    """BiInteractionPooling on the gather's rows (csrc/fm.hip): ``G [B, ld]`` (fields first, dense block at
+    ``dense_off``) -> ``[B, r4(D + n_dense)]`` = ``[bi | dense]``, the NFM tower's input; the backward hands back a
+    gradient with G's layout."""
+
+    @staticmethod
+    def forward(ctx, G, F, D, dense_off, n_dense):
+        lib = L.lib()
+        L.require_gpu(G, "BiInteractionPooling input")
+        if G.dtype != torch.float32 or G.dim() != 2 or G.stride(1) != 1:
+            G = G.float().contiguous()
+        B = G.shape[0]
+        ld_o = (D + n_dense + 3) // 4 * 4
+        out = torch.zeros((B, ld_o), dtype=torch.float32, device=G.device) if ld_o != D + n_dense else \
+            torch.empty((B, ld_o), dtype=torch.float32, device=G.device)
+        L.check(lib.dctr_bi_pooling_fwd(_ptr(G), G.stride(0), B, F, D, dense_off, n_dense, _ptr(out), ld_o,
+                                        L.stream_handle(G.device)), "dctr_bi_pooling_fwd")
+        ctx.save_for_backward(G)
+        ctx.dims = (F, D, dense_off, n_dense)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = L.lib()
+        (G,) = ctx.saved_tensors
+        F, D, dense_off, n_dense = ctx.dims
+        B = G.shape[0]
+        if gout.dtype != torch.float32 or gout.stride(1) != 1:
+            gout = gout.float().contiguous()
+        gG = torch.zeros_like(G) if G.shape[1] != F * D + n_dense or (n_dense and dense_off != F * D) else \
+            torch.empty_like(G)
+        L.check(lib.dctr_bi_pooling_bwd(_ptr(G), G.stride(0), B, F, D, dense_off, n_dense, _ptr(gout), gout.stride(0),
+                                        _ptr(gG), gG.stride(0), L.stream_handle(G.device)), "dctr_bi_pooling_bwd")
+        return gG, None, None, None, None
+
+
 # ---- CIN layer (interaction.py:207-248) ----------------------------------------------------------------
 def _rows3(t, what):
     """[B, R, D] float32 with contiguous (R, D) rows; the batch stride may be anything >= R*D (views of the

@@ -9,7 +9,7 @@ import torch.nn as nn
 from .._hip import ops as _ops
 from .activation import activation_layer
 
-__all__ = ["FM", "CIN", "SENETLayer", "BilinearInteraction", "InnerProductLayer", "CrossNet"]
+__all__ = ["FM", "BiInteractionPooling", "CIN", "SENETLayer", "BilinearInteraction", "InnerProductLayer", "CrossNet"]
 
 
 class FM(nn.Module):
@@ -22,6 +22,28 @@ class FM(nn.Module):
 
     def forward(self, inputs):
         return _ops.FMFunction.apply(inputs)
+
+
+class BiInteractionPooling(nn.Module):
+    """Bi-Interaction layer of Neural FM: the pairwise element-wise products of the fields compressed into one
+    vector, ``0.5 * ((sum_f e)^2 - sum_f e^2)`` -- ``[B, F, D] -> [B, 1, D]`` (reference interaction.py:37-61).
+    Kernel: ``dctr_bi_pooling_fwd`` / ``dctr_bi_pooling_bwd`` (csrc/fm.hip); NFM calls the fused form that also
+    appends the dense features (``fused``)."""
+
+    def __init__(self):
+        super(BiInteractionPooling, self).__init__()
+
+    def forward(self, inputs):
+        if inputs.dim() != 3:
+            raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % inputs.dim())
+        B, F, D = inputs.shape
+        flat = inputs.reshape(B, F * D)
+        return _ops.BiPoolFunction.apply(flat, F, D, F * D, 0)[:, :D].unsqueeze(1)
+
+    @staticmethod
+    def fused(gathered, F, D, dense_off, n_dense):
+        """``gathered`` = the fused lookup's ``[B, ld]`` rows -> ``[B, r4(D + n_dense)]`` = ``[bi | dense]``."""
+        return _ops.BiPoolFunction.apply(gathered, F, D, dense_off, n_dense)
 
 
 class CIN(nn.Module):

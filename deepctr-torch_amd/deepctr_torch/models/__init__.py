@@ -4,7 +4,8 @@ from .basemodel import BaseModel, Linear
 from .dcn import DCN
 from .deepfm import DeepFM
 from .fibinet import FiBiNET
+from .nfm import NFM
 from .pnn import PNN
 from .xdeepfm import xDeepFM
 
-__all__ = ["BaseModel", "Linear", "DeepFM", "xDeepFM", "FiBiNET", "DCN", "PNN"]
+__all__ = ["BaseModel", "Linear", "DeepFM", "xDeepFM", "FiBiNET", "DCN", "PNN", "NFM"]

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 8
+#define DCTR_ABI_VERSION 9
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -187,6 +187,17 @@ int dctr_fm_fwd(const float* E, int64_t ld_b, int32_t B, int32_t F, int32_t D, f
                 dctr_stream_t stream);
 int dctr_fm_bwd(const float* E, int64_t ld_b, int32_t B, int32_t F, int32_t D, const float* gy,
                 float* gE, int64_t ld_gb, int32_t accumulate, dctr_stream_t stream);
+
+/* ---- BiInteractionPooling (interaction.py:54-61) + NFM's combined_dnn_input (nfm.py:66-71) ---------------------
+ *   bi[b, d] = 0.5 * ((sum_f e[b,f,d])^2 - sum_f e[b,f,d]^2)           out row b = [ bi (D) | dense (n_dense) ]
+ * G is dctr_embed_fwd's `out` ([B, ld_g], fields first, the dense block at dense_off); the backward writes a gradient
+ * with G's layout (what dctr_embed_update consumes): gG[b, f*D+d] = g[b,d] * (S[b,d] - e[b,f,d]), gG[b, dense_off+j]
+ * = g[b, D+j].  Columns of gG outside the field / dense blocks are not written.                                  */
+int dctr_bi_pooling_fwd(const float* G, int64_t ld_g, int32_t B, int32_t F, int32_t D, int32_t dense_off,
+                        int32_t n_dense, float* out, int64_t ld_o, dctr_stream_t stream);
+int dctr_bi_pooling_bwd(const float* G, int64_t ld_g, int32_t B, int32_t F, int32_t D, int32_t dense_off,
+                        int32_t n_dense, const float* gout, int64_t ld_go, float* gG, int64_t ld_gg,
+                        dctr_stream_t stream);
 
 /* ---- exact lazy regularised / Adam embedding update (csrc/lazy.hip) ------------------------------------------
  * Replaces, in O(batch) per step, what the reference does in O(vocabulary) whenever every row of a table moves at

@@ -157,6 +157,11 @@ case("pnn_inner_varlen", "PNN", [], [c for c in _pm if c["kind"] != "dense"], ba
      use_inner=True, use_outter=False)
 
 
+_n = criteo_columns(9, 4, 22, 8)
+case("nfm_criteo", "NFM", _n, _n, batch=40, steps=True, dnn_hidden_units=(32, 16))
+case("nfm_sparse_only", "NFM", [c for c in _n if c["kind"] == "sparse"], [c for c in _n if c["kind"] == "sparse"],
+     batch=24, dnn_hidden_units=(16,))
+
 # regularised / Adam trajectories (the reference's DEFAULT kind of training: l2 > 0 on every table, basemodel.py:412-428,
 # and torch.optim.Adam, basemodel.py:447-461): small batches over small vocabularies, so that most rows are NOT touched
 # by a given step and are touched again a few steps later -- what the exact lazy update (csrc/lazy.hip) must replay

@@ -11,7 +11,7 @@ numpy.  The oracle is PINNED: ``tests/test_oracle_golden.py`` checks it against 
 its own, so those fixtures are the pin.
 
 Parameters are addressed by the reference's ``state_dict`` keys.  A model is described by a ``spec``:
-    {"model": "DeepFM" | "xDeepFM" | "FiBiNET" | "DCN" | "PNN",
+    {"model": "DeepFM" | "xDeepFM" | "FiBiNET" | "DCN" | "PNN" | "NFM",
      "linear_columns": [col...], "dnn_columns": [col...], "kwargs": {...}}
 with ``col`` = {"kind": "sparse"|"varlen"|"dense", "name", "vocab", "dim", "embedding_name",
                 "maxlen", "combiner", "length_name", "dimension"}.
@@ -436,6 +436,11 @@ class Oracle(object):
             if parts:
                 c["stack"] = np.concatenate(parts, axis=1)
                 logit = logit + c["stack"] @ P["dnn_linear.weight"].T
+        elif m == "NFM":     # nfm.py:60-80: linear + DNN([BiInteractionPooling(E) | dense])
+            s = E.sum(axis=1)
+            bi = 0.5 * (s * s - (E * E).sum(axis=1))                       # interaction.py:54-61
+            h, c["acts"] = dnn_forward(np.concatenate([bi, dense_x], axis=1), P, "dnn.", self.n_dnn)
+            logit = lin + h @ P["dnn_linear.weight"].T
         elif m == "PNN":
             ip, c["pairs"] = inner_product_forward(E)
             c["n_ip"] = ip.shape[1]
@@ -513,6 +518,11 @@ class Oracle(object):
                 if g_deep is not None:
                     gx0 += dnn_backward(g_deep, c["acts"], P, "dnn.", self.n_dnn, grads)
                 g_flat += gx0[:, :W_emb]
+        elif m == "NFM":
+            g_lin = g
+            gin = dnn_head(g)
+            D = E.shape[2]
+            g_flat += (gin[:, None, :D] * (E.sum(axis=1, keepdims=True) - E)).reshape(B, -1)
         elif m == "PNN":
             gin = dnn_head(g)
             g_flat += gin[:, :W_emb]

@@ -168,3 +168,22 @@ def test_crossnet(B, W, L, param):
     _close(X.grad, X2.grad, "gX")
     _close(layer.kernels.grad, K.grad, "gK", tol=5e-5)
     _close(layer.bias.grad, Bs.grad, "gb")
+
+
+@pytest.mark.parametrize("B,F,D", [(7, 3, 4), (64, 26, 16), (33, 5, 7)])
+def test_bi_interaction_pooling_matches_torch(B, F, D):
+    """BiInteractionPooling (interaction.py:54-61) standalone: forward and gradient against the reference's formula."""
+    from deepctr_torch.layers import BiInteractionPooling
+    g = torch.Generator(device=DEV).manual_seed(B + F)
+    E = torch.randn(B, F, D, device=DEV, generator=g).requires_grad_(True)
+    R = torch.randn(B, 1, D, device=DEV, generator=g)
+    y = BiInteractionPooling()(E)
+    assert y.shape == (B, 1, D)
+    (y * R).sum().backward()
+    E2 = E.detach().double().requires_grad_(True)
+    y2 = 0.5 * (torch.pow(E2.sum(dim=1, keepdim=True), 2) - (E2 * E2).sum(dim=1, keepdim=True))
+    (y2 * R.double()).sum().backward()
+    assert float((y.double() - y2).abs().max()) <= 1e-5 * max(1.0, float(y2.abs().max()))
+    assert float((E.grad.double() - E2.grad).abs().max()) <= 1e-5 * max(1.0, float(E2.grad.abs().max()))
+    with pytest.raises(ValueError):
+        BiInteractionPooling()(torch.randn(4, 8, device=DEV))
