@@ -273,6 +273,44 @@ class FMFunction(torch.autograd.Function):
         return gE
 
 
+class AFMFunction(torch.autograd.Function):
+    """AFMLayer on ``E [B, F, D]`` (csrc/afm.hip): ``(E, W [D, A], b [A], h [A, 1], p [D, 1]) -> [B, 1]``."""
+
+    @staticmethod
+    def forward(ctx, E, W, b, h, p):
+        lib = L.lib()
+        E, lde = _rows3(E, "AFM input")
+        B, F, D = E.shape
+        A = W.shape[1]
+        if D > 64 or A > 32 or F > 64 or F < 2:
+            raise NotImplementedError("the gfx950 AFM kernel supports 2 <= fields <= 64, embedding_dim <= 64, "
+                                      "attention_factor <= 32 (got F=%d, D=%d, A=%d)" % (F, D, A))
+        Wc, bc, hc, pc = (t.detach().float().contiguous() for t in (W, b, h.reshape(-1), p.reshape(-1)))
+        y = torch.empty((B,), dtype=torch.float32, device=E.device)
+        L.check(lib.dctr_afm_fwd(_ptr(E), lde, B, F, D, A, _ptr(Wc), _ptr(bc), _ptr(hc), _ptr(pc), _ptr(y),
+                                 L.stream_handle(E.device)), "dctr_afm_fwd")
+        ctx.save_for_backward(E, Wc, bc, hc, pc)
+        ctx.shapes = (tuple(h.shape), tuple(p.shape))
+        return y.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = L.lib()
+        E, W, b, h, p = ctx.saved_tensors
+        E, lde = _rows3(E, "AFM input")
+        B, F, D = E.shape
+        A = W.shape[1]
+        dev = E.device
+        gy = gy.reshape(B).contiguous().float()
+        gE = torch.empty((B, F, D), dtype=torch.float32, device=dev)
+        gW, gb = torch.empty_like(W), torch.empty_like(b)
+        gh, gp = torch.empty_like(h), torch.empty_like(p)
+        ws = torch.empty((max(1, lib.dctr_afm_bwd_workspace_floats(B, D, A)),), dtype=torch.float32, device=dev)
+        L.check(lib.dctr_afm_bwd(_ptr(E), lde, B, F, D, A, _ptr(W), _ptr(b), _ptr(h), _ptr(p), _ptr(gy), _ptr(gE), F * D,
+                                 _ptr(gW), _ptr(gb), _ptr(gh), _ptr(gp), _ptr(ws), L.stream_handle(dev)), "dctr_afm_bwd")
+        return gE, gW, gb, gh.reshape(ctx.shapes[0]), gp.reshape(ctx.shapes[1])
+
+
 class BiPoolFunction(torch.autograd.Function):
     """BiInteractionPooling on the gather's rows (csrc/fm.hip): ``G [B, ld]`` (fields first, dense block at
     ``dense_off``) -> ``[B, r4(D + n_dense)]`` = ``[bi | dense]``, the NFM tower's input; the backward hands back a

@@ -9,7 +9,7 @@ import torch.nn as nn
 from .._hip import ops as _ops
 from .activation import activation_layer
 
-__all__ = ["FM", "BiInteractionPooling", "CIN", "SENETLayer", "BilinearInteraction", "InnerProductLayer", "CrossNet"]
+__all__ = ["FM", "BiInteractionPooling", "AFMLayer", "CIN", "SENETLayer", "BilinearInteraction", "InnerProductLayer", "CrossNet"]
 
 
 class FM(nn.Module):
@@ -44,6 +44,47 @@ class BiInteractionPooling(nn.Module):
     def fused(gathered, F, D, dense_off, n_dense):
         """``gathered`` = the fused lookup's ``[B, ld]`` rows -> ``[B, r4(D + n_dense)]`` = ``[bi | dense]``."""
         return _ops.BiPoolFunction.apply(gathered, F, D, dense_off, n_dense)
+
+
+class AFMLayer(nn.Module):
+    """Attentional Factorization Machine pooling: ``softmax``-weighted sum of the pairwise element-wise products,
+    projected to one logit -- list of F ``[B, 1, D]`` tensors (or one ``[B, F, D]`` tensor) ``-> [B, 1]`` (reference
+    interaction.py:251-325; same constructor, same parameters ``attention_W [D, A]``, ``attention_b [A]``,
+    ``projection_h [A, 1]``, ``projection_p [D, 1]``).  One kernel forward, one backward (``csrc/afm.hip``); with an
+    active dropout on the attention output the same math runs as PyTorch-ROCm ops (the mask sits between two fused
+    stages)."""
+
+    def __init__(self, in_features, attention_factor=4, l2_reg_w=0, dropout_rate=0, seed=1024, device='cpu'):
+        super(AFMLayer, self).__init__()
+        self.attention_factor = attention_factor
+        self.l2_reg_w = l2_reg_w
+        self.dropout_rate = dropout_rate
+        self.seed = seed
+        embedding_size = in_features
+        self.attention_W = nn.Parameter(torch.Tensor(embedding_size, self.attention_factor))
+        self.attention_b = nn.Parameter(torch.Tensor(self.attention_factor))
+        self.projection_h = nn.Parameter(torch.Tensor(self.attention_factor, 1))
+        self.projection_p = nn.Parameter(torch.Tensor(embedding_size, 1))
+        for tensor in [self.attention_W, self.projection_h, self.projection_p]:
+            nn.init.xavier_normal_(tensor, )
+        for tensor in [self.attention_b]:
+            nn.init.zeros_(tensor, )
+        self.dropout = nn.Dropout(dropout_rate)
+        self.to(device)
+
+    def forward(self, inputs):
+        E = torch.cat(list(inputs), dim=1) if isinstance(inputs, (list, tuple)) else inputs
+        if E.dim() != 3:
+            raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % E.dim())
+        if self.dropout_rate and self.training:
+            F_ = E.shape[1]
+            idx = torch.triu_indices(F_, F_, 1, device=E.device)
+            bi = E[:, idx[0]] * E[:, idx[1]]
+            att = torch.relu(torch.tensordot(bi, self.attention_W, dims=([-1], [0])) + self.attention_b)
+            score = torch.softmax(torch.tensordot(att, self.projection_h, dims=([-1], [0])), dim=1)
+            out = self.dropout(torch.sum(score * bi, dim=1))
+            return torch.tensordot(out, self.projection_p, dims=([-1], [0]))
+        return _ops.AFMFunction.apply(E, self.attention_W, self.attention_b, self.projection_h, self.projection_p)
 
 
 class CIN(nn.Module):

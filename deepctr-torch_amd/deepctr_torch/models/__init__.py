@@ -1,5 +1,6 @@
 """Drop-in model classes of the MI355X hot path.  Constructor signatures
 and ``state_dict`` keys are the reference's (``deepctr_torch/models/*.py``)."""
+from .afm import AFM
 from .basemodel import BaseModel, Linear
 from .dcn import DCN
 from .deepfm import DeepFM
@@ -8,4 +9,4 @@ from .nfm import NFM
 from .pnn import PNN
 from .xdeepfm import xDeepFM
 
-__all__ = ["BaseModel", "Linear", "DeepFM", "xDeepFM", "FiBiNET", "DCN", "PNN", "NFM"]
+__all__ = ["BaseModel", "Linear", "DeepFM", "xDeepFM", "FiBiNET", "DCN", "PNN", "NFM", "AFM"]

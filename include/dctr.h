@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 9
+#define DCTR_ABI_VERSION 10
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -198,6 +198,20 @@ int dctr_bi_pooling_fwd(const float* G, int64_t ld_g, int32_t B, int32_t F, int3
 int dctr_bi_pooling_bwd(const float* G, int64_t ld_g, int32_t B, int32_t F, int32_t D, int32_t dense_off,
                         int32_t n_dense, const float* gout, int64_t ld_go, float* gG, int64_t ld_gg,
                         dctr_stream_t stream);
+
+/* ---- AFMLayer (interaction.py:251-325): attentional pooling of the pairwise products (csrc/afm.hip) -----------
+ *   bi_k = e_i (.) e_j (pairs i < j, itertools.combinations order);  t_k = relu(bi_k W + bias);  s_k = t_k . h;
+ *   a = softmax_k(s);  out = sum_k a_k bi_k;  y[b] = out . p
+ *   E [B, F, D] rows at E + b*ld_e;  W [D, A] (attention_W), bias [A] (attention_b), h [A] (projection_h), p [D]
+ *   (projection_p).  One wave per sample, everything between E and y stays in LDS.  The backward recomputes the
+ *   forward, writes gE [B, F*D] rows at gE + b*ld_ge and the four parameter gradients (fixed-order sums, no
+ *   atomics); workspace: dctr_afm_bwd_workspace_floats(B, D, A) floats.  Needs D <= 64, A <= 32, F <= 64.      */
+size_t dctr_afm_bwd_workspace_floats(int32_t B, int32_t D, int32_t A);
+int dctr_afm_fwd(const float* E, int64_t ld_e, int32_t B, int32_t F, int32_t D, int32_t A, const float* W,
+                 const float* bias, const float* h, const float* p, float* y, dctr_stream_t stream);
+int dctr_afm_bwd(const float* E, int64_t ld_e, int32_t B, int32_t F, int32_t D, int32_t A, const float* W,
+                 const float* bias, const float* h, const float* p, const float* gy, float* gE, int64_t ld_ge,
+                 float* gW, float* gbias, float* gh, float* gp, float* workspace, dctr_stream_t stream);
 
 /* ---- exact lazy regularised / Adam embedding update (csrc/lazy.hip) ------------------------------------------
  * Replaces, in O(batch) per step, what the reference does in O(vocabulary) whenever every row of a table moves at

@@ -162,6 +162,12 @@ case("nfm_criteo", "NFM", _n, _n, batch=40, steps=True, dnn_hidden_units=(32, 16
 case("nfm_sparse_only", "NFM", [c for c in _n if c["kind"] == "sparse"], [c for c in _n if c["kind"] == "sparse"],
      batch=24, dnn_hidden_units=(16,))
 
+_a = criteo_columns(9, 3, 18, 8)
+_as = [c for c in _a if c["kind"] == "sparse"]        # AFM rejects dense features on the deep side (afm.py:62-63)
+case("afm_criteo", "AFM", _a, _as, batch=40, steps=True, attention_factor=8)
+case("afm_wide_factor", "AFM", criteo_columns(5, 0, 12, 4), criteo_columns(5, 0, 12, 4), batch=24, attention_factor=5)
+case("afm_no_attention", "AFM", _a, _as, batch=24, use_attention=False)
+
 # regularised / Adam trajectories (the reference's DEFAULT kind of training: l2 > 0 on every table, basemodel.py:412-428,
 # and torch.optim.Adam, basemodel.py:447-461): small batches over small vocabularies, so that most rows are NOT touched
 # by a given step and are touched again a few steps later -- what the exact lazy update (csrc/lazy.hip) must replay
@@ -245,6 +251,8 @@ def build_reference_model(ref, spec, l2=0.0):
     cls = getattr(ref_models, spec["model"])
     if spec["model"] == "PNN":
         return cls(dnn, l2_reg_embedding=l2, device="cpu", **kw)
+    if spec["model"] == "AFM":
+        return cls(lin, dnn, l2_reg_linear=l2, l2_reg_embedding=l2, l2_reg_att=l2, device="cpu", **kw)
     if spec["model"] == "DCN":
         return cls(lin, dnn, l2_reg_linear=l2, l2_reg_embedding=l2, l2_reg_cross=l2, device="cpu", **kw)
     return cls(lin, dnn, l2_reg_linear=l2, l2_reg_embedding=l2, device="cpu", **kw)

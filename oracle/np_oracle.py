@@ -11,7 +11,7 @@ numpy.  The oracle is PINNED: ``tests/test_oracle_golden.py`` checks it against 
 its own, so those fixtures are the pin.
 
 Parameters are addressed by the reference's ``state_dict`` keys.  A model is described by a ``spec``:
-    {"model": "DeepFM" | "xDeepFM" | "FiBiNET" | "DCN" | "PNN" | "NFM",
+    {"model": "DeepFM" | "xDeepFM" | "FiBiNET" | "DCN" | "PNN" | "NFM" | "AFM",
      "linear_columns": [col...], "dnn_columns": [col...], "kwargs": {...}}
 with ``col`` = {"kind": "sparse"|"varlen"|"dense", "name", "vocab", "dim", "embedding_name",
                 "maxlen", "combiner", "length_name", "dimension"}.
@@ -436,6 +436,24 @@ class Oracle(object):
             if parts:
                 c["stack"] = np.concatenate(parts, axis=1)
                 logit = logit + c["stack"] @ P["dnn_linear.weight"].T
+        elif m == "AFM":     # afm.py:60-75: linear + AFMLayer (interaction.py:299-325), or FM without attention
+            logit = logit + lin
+            c["use_att"] = kw.get("use_attention", True)
+            if E is not None and len(embs) > 0:
+                if c["use_att"]:
+                    F_ = E.shape[1]
+                    ii, jj = np.triu_indices(F_, 1)
+                    bi = E[:, ii] * E[:, jj]                                         # [B, P, D]
+                    pre = bi @ P["fm.attention_W"] + P["fm.attention_b"]
+                    t = np.maximum(pre, 0)
+                    s = t @ P["fm.projection_h"]                                    # [B, P, 1]
+                    ex = np.exp(s - s.max(axis=1, keepdims=True))
+                    a = ex / ex.sum(axis=1, keepdims=True)
+                    o = (a * bi).sum(axis=1)                                         # [B, D]
+                    c["afm"] = (ii, jj, bi, pre, t, a, o)
+                    logit = logit + o @ P["fm.projection_p"]
+                else:
+                    logit = logit + fm_forward(E)
         elif m == "NFM":     # nfm.py:60-80: linear + DNN([BiInteractionPooling(E) | dense])
             s = E.sum(axis=1)
             bi = 0.5 * (s * s - (E * E).sum(axis=1))                       # interaction.py:54-61
@@ -518,6 +536,27 @@ class Oracle(object):
                 if g_deep is not None:
                     gx0 += dnn_backward(g_deep, c["acts"], P, "dnn.", self.n_dnn, grads)
                 g_flat += gx0[:, :W_emb]
+        elif m == "AFM":
+            g_lin = g
+            if E is not None and len(c["embs"]) > 0:
+                if c["use_att"]:
+                    ii, jj, bi, pre, t, a, o = c["afm"]
+                    grads["fm.projection_p"] = o.T @ g
+                    go = g @ P["fm.projection_p"].T                                  # [B, D]
+                    ga = (bi * go[:, None, :]).sum(axis=2, keepdims=True)            # [B, P, 1]
+                    gbi = a * go[:, None, :]
+                    gs = a * (ga - (a * ga).sum(axis=1, keepdims=True))
+                    grads["fm.projection_h"] = np.einsum("bpa,bpo->ao", t, gs)
+                    gpre = (gs @ P["fm.projection_h"].T) * (pre > 0)
+                    grads["fm.attention_b"] = gpre.sum(axis=(0, 1))
+                    grads["fm.attention_W"] = np.einsum("bpd,bpa->da", bi, gpre)
+                    gbi = gbi + gpre @ P["fm.attention_W"].T
+                    gE = np.zeros_like(E)
+                    np.add.at(gE, (slice(None), ii), gbi * E[:, jj])
+                    np.add.at(gE, (slice(None), jj), gbi * E[:, ii])
+                    g_flat += gE.reshape(B, -1)
+                else:
+                    g_flat += fm_backward(E, g).reshape(B, -1)
         elif m == "NFM":
             g_lin = g
             gin = dnn_head(g)

@@ -52,6 +52,8 @@ def build_model(spec, device, l2=0.0):
     cls = getattr(M, spec["model"])
     if spec["model"] == "PNN":
         return cls(dnn, l2_reg_embedding=l2, device=device, **kw)
+    if spec["model"] == "AFM":
+        return cls(lin, dnn, l2_reg_linear=l2, l2_reg_embedding=l2, l2_reg_att=l2, device=device, **kw)
     if spec["model"] == "DCN":
         return cls(lin, dnn, l2_reg_linear=l2, l2_reg_embedding=l2, l2_reg_cross=l2, device=device, **kw)
     return cls(lin, dnn, l2_reg_linear=l2, l2_reg_embedding=l2, device=device, **kw)

@@ -187,3 +187,43 @@ def test_bi_interaction_pooling_matches_torch(B, F, D):
     assert float((E.grad.double() - E2.grad).abs().max()) <= 1e-5 * max(1.0, float(E2.grad.abs().max()))
     with pytest.raises(ValueError):
         BiInteractionPooling()(torch.randn(4, 8, device=DEV))
+
+
+@pytest.mark.parametrize("B,F,D,A", [(9, 3, 4, 4), (64, 26, 16, 8), (33, 7, 5, 3), (1100, 10, 8, 8), (5, 2, 64, 32)])
+def test_afm_layer_matches_torch(B, F, D, A):
+    """AFMLayer (interaction.py:299-325): forward, input gradient and the four parameter gradients against the
+    reference's own sequence of torch ops evaluated in fp64."""
+    from deepctr_torch.layers import AFMLayer
+    torch.manual_seed(B + F + D)
+    layer = AFMLayer(D, attention_factor=A, device=DEV)
+    with torch.no_grad():
+        layer.attention_b.normal_(0, 0.3)
+    g = torch.Generator(device=DEV).manual_seed(B)
+    E = (torch.randn(B, F, D, device=DEV, generator=g) * 0.7).requires_grad_(True)
+    R = torch.randn(B, 1, device=DEV, generator=g)
+    y = layer([E[:, f:f + 1] for f in range(F)])            # the reference's calling convention: a list of [B, 1, D]
+    assert y.shape == (B, 1)
+    (y * R).sum().backward()
+    got = [y.detach(), E.grad] + [p.grad for p in (layer.attention_W, layer.attention_b, layer.projection_h, layer.projection_p)]
+    E2 = E.detach().double().requires_grad_(True)
+    W, b, h, p = (t.detach().double().requires_grad_(True) for t in
+                  (layer.attention_W, layer.attention_b, layer.projection_h, layer.projection_p))
+    idx = torch.triu_indices(F, F, 1, device=DEV)
+    bi = E2[:, idx[0]] * E2[:, idx[1]]
+    att = torch.relu(torch.tensordot(bi, W, dims=([-1], [0])) + b)
+    score = torch.softmax(torch.tensordot(att, h, dims=([-1], [0])), dim=1)
+    y2 = torch.tensordot(torch.sum(score * bi, dim=1), p, dims=([-1], [0]))
+    (y2 * R.double()).sum().backward()
+    want = [y2.detach(), E2.grad, W.grad, b.grad, h.grad, p.grad]
+    for name, a, r in zip(["y", "gE", "gW", "gb", "gh", "gp"], got, want):
+        scale = max(1.0, float(r.abs().max()))
+        err = float((a.double() - r).abs().max())
+        assert err <= 2e-5 * scale, "%s: max|d|=%.3e (scale %.3g)" % (name, err, scale)
+
+
+def test_afm_rejects_dense_on_the_deep_side():
+    from deepctr_torch.inputs import DenseFeat, SparseFeat
+    from deepctr_torch.models import AFM
+    cols = [SparseFeat("a", 5, 4), SparseFeat("b", 6, 4), DenseFeat("d", 1)]
+    with pytest.raises(ValueError, match="DenseFeat is not supported"):
+        AFM(cols, cols, device=DEV)
