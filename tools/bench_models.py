@@ -28,6 +28,9 @@ spec = {
     "FiBiNET": lambda: M.FiBiNET(cols, cols, dnn_hidden_units=(128, 128), l2_reg_linear=0, l2_reg_embedding=0, device=dev),
     "DCN": lambda: M.DCN(cols, cols, dnn_hidden_units=(256, 128), l2_reg_linear=0, l2_reg_embedding=0, device=dev),
     "PNN": lambda: M.PNN(cols, dnn_hidden_units=(256, 128), l2_reg_embedding=0, device=dev),
+    "NFM": lambda: M.NFM(cols, cols, dnn_hidden_units=(256, 128), l2_reg_linear=0, l2_reg_embedding=0, device=dev),
+    "AFM": lambda: M.AFM(cols, cols[:26], attention_factor=8, l2_reg_linear=0, l2_reg_embedding=0, l2_reg_att=0,
+                         device=dev),
 }
 res = {}
 for name, make in spec.items():
