@@ -9,7 +9,7 @@ import torch.nn as nn
 from .._hip import ops as _ops
 from .activation import activation_layer
 
-__all__ = ["FM", "BiInteractionPooling", "AFMLayer", "CIN", "SENETLayer", "BilinearInteraction", "InnerProductLayer", "CrossNet"]
+__all__ = ["FM", "BiInteractionPooling", "AFMLayer", "InteractingLayer", "CrossNetMix", "CIN", "SENETLayer", "BilinearInteraction", "InnerProductLayer", "CrossNet"]
 
 
 class FM(nn.Module):
@@ -85,6 +85,91 @@ class AFMLayer(nn.Module):
             out = self.dropout(torch.sum(score * bi, dim=1))
             return torch.tensordot(out, self.projection_p, dims=([-1], [0]))
         return _ops.AFMFunction.apply(E, self.attention_W, self.attention_b, self.projection_h, self.projection_p)
+
+
+class InteractingLayer(nn.Module):
+    """Multi-head self-attention over the fields (AutoInt): ``[B, F, D] -> [B, F, D]`` (reference
+    interaction.py:328-394; same constructor, same ``W_Query / W_key / W_Value / W_Res [D, D]`` parameters).
+
+    The layer is dense matrix work per sample (four ``[F, D] x [D, D]`` projections, ``H`` score matrices ``[F, F]``):
+    it runs as batched GEMMs + one softmax on PyTorch-ROCm (rocBLAS), with the reference's stack / split / cat
+    reshuffles replaced by views -- a different GPU implementation of the same arithmetic, not a hand-written
+    kernel yet (a one-wave-per-sample LDS kernel like csrc/afm.hip is the obvious next step)."""
+
+    def __init__(self, embedding_size, head_num=2, use_res=True, scaling=False, seed=1024, device='cpu'):
+        super(InteractingLayer, self).__init__()
+        if head_num <= 0:
+            raise ValueError('head_num must be a int > 0')
+        if embedding_size % head_num != 0:
+            raise ValueError('embedding_size is not an integer multiple of head_num!')
+        self.att_embedding_size = embedding_size // head_num
+        self.head_num = head_num
+        self.use_res = use_res
+        self.scaling = scaling
+        self.seed = seed
+        self.W_Query = nn.Parameter(torch.Tensor(embedding_size, embedding_size))
+        self.W_key = nn.Parameter(torch.Tensor(embedding_size, embedding_size))
+        self.W_Value = nn.Parameter(torch.Tensor(embedding_size, embedding_size))
+        if self.use_res:
+            self.W_Res = nn.Parameter(torch.Tensor(embedding_size, embedding_size))
+        for tensor in self.parameters():
+            nn.init.normal_(tensor, mean=0.0, std=0.05)
+        self.to(device)
+
+    def forward(self, inputs):
+        if len(inputs.shape) != 3:
+            raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % (len(inputs.shape)))
+        B, F_, D = inputs.shape
+        H, A = self.head_num, self.att_embedding_size
+        # [B, F, D] -> [B, H, F, A]: head n = columns n*A .. (n+1)*A (torch.split(..., dim=2) of the reference)
+        q = torch.matmul(inputs, self.W_Query).view(B, F_, H, A).transpose(1, 2)
+        k = torch.matmul(inputs, self.W_key).view(B, F_, H, A).transpose(1, 2)
+        v = torch.matmul(inputs, self.W_Value).view(B, F_, H, A).transpose(1, 2)
+        inner = torch.matmul(q, k.transpose(2, 3))                       # [B, H, F, F]
+        if self.scaling:
+            inner = inner / self.att_embedding_size ** 0.5
+        self.normalized_att_scores = torch.softmax(inner, dim=-1)
+        result = torch.matmul(self.normalized_att_scores, v)             # [B, H, F, A]
+        result = result.transpose(1, 2).reshape(B, F_, D)                # heads side by side (torch.cat(..., dim=-1))
+        if self.use_res:
+            result = result + torch.matmul(inputs, self.W_Res)
+        return torch.relu(result)
+
+
+class CrossNetMix(nn.Module):
+    """Cross network of DCN-Mix: a mixture of low-rank experts per layer, ``[B, W] -> [B, W]`` (reference
+    interaction.py:456-534; same constructor, same ``U_list / V_list / C_list [L, E, ...]``, ``gating.<e>.weight``,
+    ``bias [L, W, 1]`` parameters).  Skinny GEMMs ([B, W] x [W, r]): batched over the experts on PyTorch-ROCm
+    (hipBLASLt), the reference's per-expert Python loop and stack replaced by one einsum per stage."""
+
+    def __init__(self, in_features, low_rank=32, num_experts=4, layer_num=2, device='cpu'):
+        super(CrossNetMix, self).__init__()
+        self.layer_num = layer_num
+        self.num_experts = num_experts
+        self.U_list = nn.Parameter(torch.Tensor(self.layer_num, num_experts, in_features, low_rank))
+        self.V_list = nn.Parameter(torch.Tensor(self.layer_num, num_experts, in_features, low_rank))
+        self.C_list = nn.Parameter(torch.Tensor(self.layer_num, num_experts, low_rank, low_rank))
+        self.gating = nn.ModuleList([nn.Linear(in_features, 1, bias=False) for i in range(self.num_experts)])
+        self.bias = nn.Parameter(torch.Tensor(self.layer_num, in_features, 1))
+        for para in [self.U_list, self.V_list, self.C_list]:
+            for i in range(self.layer_num):
+                nn.init.xavier_normal_(para[i])
+        for i in range(len(self.bias)):
+            nn.init.zeros_(self.bias[i])
+        self.to(device)
+
+    def forward(self, inputs):
+        x_0 = inputs                                                     # [B, W]
+        x_l = x_0
+        gate_w = torch.cat([g.weight for g in self.gating], dim=0)       # [E, W]
+        for i in range(self.layer_num):
+            score = torch.softmax(torch.matmul(x_l, gate_w.t()), dim=1)  # [B, E]   G(x_l)
+            v_x = torch.tanh(torch.einsum("bw,ewr->ber", x_l, self.V_list[i]))          # project to R^r
+            v_x = torch.tanh(torch.einsum("ers,bes->ber", self.C_list[i], v_x))
+            uv_x = torch.einsum("ewr,ber->bew", self.U_list[i], v_x)                    # back to R^W
+            dot_ = x_0.unsqueeze(1) * (uv_x + self.bias[i].squeeze(1))                  # Hadamard product, [B, E, W]
+            x_l = torch.einsum("bew,be->bw", dot_, score) + x_l                         # mixture of the experts
+        return x_l
 
 
 class CIN(nn.Module):

@@ -1,0 +1,55 @@
+# -*- coding: utf-8 -*-
+"""DCN-Mix (reference models/dcnmix.py:18-100): mixture-of-low-rank-experts cross network + DNN over the fused gather.
+The gather, the tower and the table update are this package's kernels; the cross network's skinny GEMMs run on
+PyTorch-ROCm (layers.CrossNetMix)."""
+import torch
+import torch.nn as nn
+
+from .basemodel import BaseModel
+from ..layers import DNN, CrossNetMix
+
+
+class DCNMix(BaseModel):
+    """Same arguments as the reference (models/dcnmix.py:44-49).  Like the reference, ``l2_reg_linear`` is NOT forwarded
+    to the linear part; it regularises ``dnn_linear``."""
+
+    def __init__(self, linear_feature_columns, dnn_feature_columns, cross_num=2, dnn_hidden_units=(128, 128),
+                 l2_reg_linear=0.00001, l2_reg_embedding=0.00001, l2_reg_cross=0.00001, l2_reg_dnn=0, init_std=0.0001,
+                 seed=1024, dnn_dropout=0, low_rank=32, num_experts=4, dnn_activation='relu', dnn_use_bn=False,
+                 task='binary', device='cpu', gpus=None):
+        super(DCNMix, self).__init__(linear_feature_columns=linear_feature_columns,
+                                     dnn_feature_columns=dnn_feature_columns, l2_reg_embedding=l2_reg_embedding,
+                                     init_std=init_std, seed=seed, task=task, device=device, gpus=gpus)
+        self.dnn_hidden_units = dnn_hidden_units
+        self.cross_num = cross_num
+        self.dnn = DNN(self.compute_input_dim(dnn_feature_columns), dnn_hidden_units, activation=dnn_activation,
+                       use_bn=dnn_use_bn, l2_reg=l2_reg_dnn, dropout_rate=dnn_dropout, init_std=init_std, device=device)
+        if len(self.dnn_hidden_units) > 0 and self.cross_num > 0:
+            dnn_linear_in_feature = self.compute_input_dim(dnn_feature_columns) + dnn_hidden_units[-1]
+        elif len(self.dnn_hidden_units) > 0:
+            dnn_linear_in_feature = dnn_hidden_units[-1]
+        elif self.cross_num > 0:
+            dnn_linear_in_feature = self.compute_input_dim(dnn_feature_columns)
+        self.dnn_linear = nn.Linear(dnn_linear_in_feature, 1, bias=False).to(device)
+        self.crossnet = CrossNetMix(in_features=self.compute_input_dim(dnn_feature_columns), low_rank=low_rank,
+                                    num_experts=num_experts, layer_num=cross_num, device=device)
+        self.add_regularization_weight(
+            filter(lambda x: 'weight' in x[0] and 'bn' not in x[0], self.dnn.named_parameters()), l2=l2_reg_dnn)
+        self.add_regularization_weight(self.dnn_linear.weight, l2=l2_reg_linear)
+        for module in [self.crossnet.U_list, self.crossnet.V_list, self.crossnet.C_list]:
+            self.add_regularization_weight(module, l2=l2_reg_cross)
+        self.to(device)
+
+    def logit_parts(self, X):
+        plan = self.model_plan()
+        full, logit, _ = self.fused_inputs(X, want_fm=False, full=True)
+        dnn_input = full[:, :plan.width]
+        parts = [logit]
+        if len(self.dnn_hidden_units) > 0 and self.cross_num > 0:      # Deep & Cross
+            stack_out = torch.cat((self.crossnet(dnn_input), self.tower_hidden(full, plan.width)), dim=-1)
+            parts.append(self.dnn_linear(stack_out))
+        elif len(self.dnn_hidden_units) > 0:                           # only Deep
+            parts.append(self.tower_logit(full, plan.width))
+        elif self.cross_num > 0:                                       # only Cross
+            parts.append(self.dnn_linear(self.crossnet(dnn_input)))
+        return parts

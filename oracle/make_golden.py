@@ -168,6 +168,17 @@ case("afm_criteo", "AFM", _a, _as, batch=40, steps=True, attention_factor=8)
 case("afm_wide_factor", "AFM", criteo_columns(5, 0, 12, 4), criteo_columns(5, 0, 12, 4), batch=24, attention_factor=5)
 case("afm_no_attention", "AFM", _a, _as, batch=24, use_attention=False)
 
+case("wdl_criteo", "WDL", _a, _a, batch=40, steps=True, dnn_hidden_units=(32, 16))
+case("wdl_mixed", "WDL", _m, _m, batch=33, dnn_hidden_units=(16,))
+
+_ai = criteo_columns(7, 3, 20, 8)
+case("autoint_deep", "AutoInt", _ai, _ai, batch=40, steps=True, att_layer_num=2, att_head_num=2, dnn_hidden_units=(32, 16))
+case("autoint_only_att", "AutoInt", _ai, _ai, batch=24, att_layer_num=3, att_head_num=4, att_res=False, dnn_hidden_units=())
+case("dcnmix_deep", "DCNMix", _d, _d, batch=48, steps=True, dnn_hidden_units=(32, 16), cross_num=2, low_rank=8,
+     num_experts=3)
+# (DCNMix with dnn_hidden_units=() cannot be built in the reference either: dcnmix.py:56 constructs DNN unconditionally)
+case("dcnmix_wide_experts", "DCNMix", _d, _d, batch=24, dnn_hidden_units=(8,), cross_num=3, low_rank=4, num_experts=2)
+
 # regularised / Adam trajectories (the reference's DEFAULT kind of training: l2 > 0 on every table, basemodel.py:412-428,
 # and torch.optim.Adam, basemodel.py:447-461): small batches over small vocabularies, so that most rows are NOT touched
 # by a given step and are touched again a few steps later -- what the exact lazy update (csrc/lazy.hip) must replay
@@ -253,7 +264,9 @@ def build_reference_model(ref, spec, l2=0.0):
         return cls(dnn, l2_reg_embedding=l2, device="cpu", **kw)
     if spec["model"] == "AFM":
         return cls(lin, dnn, l2_reg_linear=l2, l2_reg_embedding=l2, l2_reg_att=l2, device="cpu", **kw)
-    if spec["model"] == "DCN":
+    if spec["model"] == "AutoInt":
+        return cls(lin, dnn, l2_reg_embedding=l2, device="cpu", **kw)
+    if spec["model"] in ("DCN", "DCNMix"):
         return cls(lin, dnn, l2_reg_linear=l2, l2_reg_embedding=l2, l2_reg_cross=l2, device="cpu", **kw)
     return cls(lin, dnn, l2_reg_linear=l2, l2_reg_embedding=l2, device="cpu", **kw)
 

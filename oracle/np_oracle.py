@@ -11,7 +11,7 @@ numpy.  The oracle is PINNED: ``tests/test_oracle_golden.py`` checks it against 
 its own, so those fixtures are the pin.
 
 Parameters are addressed by the reference's ``state_dict`` keys.  A model is described by a ``spec``:
-    {"model": "DeepFM" | "xDeepFM" | "FiBiNET" | "DCN" | "PNN" | "NFM" | "AFM",
+    {"model": "DeepFM" | "xDeepFM" | "FiBiNET" | "DCN" | "PNN" | "NFM" | "AFM" | "WDL" | "AutoInt" | "DCNMix",
      "linear_columns": [col...], "dnn_columns": [col...], "kwargs": {...}}
 with ``col`` = {"kind": "sparse"|"varlen"|"dense", "name", "vocab", "dim", "embedding_name",
                 "maxlen", "combiner", "length_name", "dimension"}.
@@ -318,6 +318,95 @@ def bilinear_backward(gp, V, P, prefix, btype, grads):
     return gV
 
 
+def interacting_forward(E, P, prefix, head_num, use_res=True, scaling=False):
+    """InteractingLayer (interaction.py:366-394): multi-head self-attention over the fields.  E [B, F, D]."""
+    B, F, D = E.shape
+    A = D // head_num
+    q, k, v = E @ P[prefix + "W_Query"], E @ P[prefix + "W_key"], E @ P[prefix + "W_Value"]
+    split = lambda t: t.reshape(B, F, head_num, A).transpose(0, 2, 1, 3)      # [B, H, F, A]  # noqa: E731
+    qh, kh, vh = split(q), split(k), split(v)
+    inner = qh @ kh.transpose(0, 1, 3, 2)
+    if scaling:
+        inner = inner / (A ** 0.5)
+    ex = np.exp(inner - inner.max(axis=-1, keepdims=True))
+    att = ex / ex.sum(axis=-1, keepdims=True)
+    res = (att @ vh).transpose(0, 2, 1, 3).reshape(B, F, D)
+    if use_res:
+        res = res + E @ P[prefix + "W_Res"]
+    return np.maximum(res, 0), (E, qh, kh, vh, att, res)
+
+
+def interacting_backward(g, cache, P, prefix, head_num, grads, use_res=True, scaling=False):
+    E, qh, kh, vh, att, pre = cache
+    B, F, D = E.shape
+    A = D // head_num
+    gpre = g * (pre > 0)
+    gE = np.zeros_like(E)
+    if use_res:
+        grads[prefix + "W_Res"] = np.einsum("bfd,bfe->de", E, gpre)
+        gE += gpre @ P[prefix + "W_Res"].T
+    go = gpre.reshape(B, F, head_num, A).transpose(0, 2, 1, 3)                  # [B, H, F, A]
+    gatt = go @ vh.transpose(0, 1, 3, 2)
+    gv = att.transpose(0, 1, 3, 2) @ go
+    gs = att * (gatt - (att * gatt).sum(axis=-1, keepdims=True))
+    if scaling:
+        gs = gs / (A ** 0.5)
+    gq, gk = gs @ kh, gs.transpose(0, 1, 3, 2) @ qh
+    join = lambda t: t.transpose(0, 2, 1, 3).reshape(B, F, D)                   # noqa: E731
+    for name, gt in (("W_Query", join(gq)), ("W_key", join(gk)), ("W_Value", join(gv))):
+        grads[prefix + name] = np.einsum("bfd,bfe->de", E, gt)
+        gE += gt @ P[prefix + name].T
+    return gE
+
+
+def crossnet_mix_forward(x0, P, prefix, n_experts):
+    """CrossNetMix (interaction.py:499-534).  x0 [B, W]."""
+    U, V, C, bias = P[prefix + "U_list"], P[prefix + "V_list"], P[prefix + "C_list"], P[prefix + "bias"]
+    gw = np.concatenate([P[prefix + "gating.%d.weight" % e] for e in range(n_experts)], axis=0)   # [E, W]
+    xl, caches = x0, []
+    for i in range(U.shape[0]):
+        s = xl @ gw.T
+        ex = np.exp(s - s.max(axis=1, keepdims=True))
+        score = ex / ex.sum(axis=1, keepdims=True)                              # [B, E]
+        v1 = np.tanh(np.einsum("bw,ewr->ber", xl, V[i]))
+        v2 = np.tanh(np.einsum("ers,bes->ber", C[i], v1))
+        uv = np.einsum("ewr,ber->bew", U[i], v2)
+        dot = x0[:, None, :] * (uv + bias[i][:, 0])
+        caches.append((xl, score, v1, v2, uv, dot))
+        xl = np.einsum("bew,be->bw", dot, score) + xl
+    return xl, (x0, gw, caches)
+
+
+def crossnet_mix_backward(g, cache, P, prefix, n_experts, grads):
+    x0, gw, caches = cache
+    U, V, C, bias = P[prefix + "U_list"], P[prefix + "V_list"], P[prefix + "C_list"], P[prefix + "bias"]
+    gU, gV, gC, gb = np.zeros_like(U), np.zeros_like(V), np.zeros_like(C), np.zeros_like(bias)
+    ggw = np.zeros_like(gw)
+    gx0 = np.zeros_like(x0)
+    gxl = g
+    for i in reversed(range(U.shape[0])):
+        xl, score, v1, v2, uv, dot = caches[i]
+        gdot = gxl[:, None, :] * score[:, :, None]                              # [B, E, W]
+        gscore = np.einsum("bew,bw->be", dot, gxl)
+        gs = score * (gscore - (score * gscore).sum(axis=1, keepdims=True))
+        ggw += gs.T @ xl
+        gprev = gxl + gs @ gw
+        gx0 += (gdot * (uv + bias[i][:, 0])).sum(axis=1)
+        guv = gdot * x0[:, None, :]
+        gb[i][:, 0] = guv.sum(axis=(0, 1))
+        gU[i] = np.einsum("bew,ber->ewr", guv, v2)
+        gv2 = np.einsum("ewr,bew->ber", U[i], guv) * (1 - v2 * v2)
+        gC[i] = np.einsum("ber,bes->ers", gv2, v1)
+        gv1 = np.einsum("ers,ber->bes", C[i], gv2) * (1 - v1 * v1)
+        gV[i] = np.einsum("bw,ber->ewr", xl, gv1)
+        gprev = gprev + np.einsum("ewr,ber->bw", V[i], gv1)
+        gxl = gprev
+    grads[prefix + "U_list"], grads[prefix + "V_list"], grads[prefix + "C_list"], grads[prefix + "bias"] = gU, gV, gC, gb
+    for e in range(n_experts):
+        grads[prefix + "gating.%d.weight" % e] = ggw[e:e + 1]
+    return gxl + gx0
+
+
 def linear_forward(X, columns, fi, P):
     """Linear.forward, basemodel.py:63-92."""
     embs, cache = lookup_forward(X, columns, fi, P, "linear_model.embedding_dict.")
@@ -382,9 +471,9 @@ class Oracle(object):
         lin, c["lin_cache"] = linear_forward(X, self.lin_cols, fi, P)
         logit = np.zeros((X.shape[0], 1), self.dt)
         m = self.model
-        if m == "DeepFM":
+        if m in ("DeepFM", "WDL"):       # WDL (wdl.py:57-75) = DeepFM without the FM term
             logit = logit + lin
-            c["use_fm"] = kw.get("use_fm", True) and len(embs) > 0
+            c["use_fm"] = m == "DeepFM" and kw.get("use_fm", True) and len(embs) > 0
             if c["use_fm"]:
                 logit = logit + fm_forward(E)
             c["use_dnn"] = self.n_dnn > 0 and len(self.dnn_cols) > 0
@@ -428,6 +517,39 @@ class Oracle(object):
             if cross_num > 0:
                 co, c["cross_xs"] = crossnet_forward(x0, P["crossnet.kernels"], P["crossnet.bias"],
                                                      kw.get("cross_parameterization", "vector"))
+                parts.append(co)
+            if self.n_dnn > 0:
+                h, c["acts"] = dnn_forward(x0, P, "dnn.", self.n_dnn)
+                parts.append(h)
+            c["stack_split"] = parts[0].shape[1] if len(parts) == 2 else None
+            if parts:
+                c["stack"] = np.concatenate(parts, axis=1)
+                logit = logit + c["stack"] @ P["dnn_linear.weight"].T
+        elif m == "AutoInt":   # autoint.py:80-112
+            logit = logit + lin
+            n_att = len([k for k in P if k.startswith("int_layers.") and k.endswith("W_Query")])
+            heads = kw.get("att_head_num", 2)
+            att, c["att_caches"] = E, []
+            for l in range(n_att):
+                att, cc = interacting_forward(att, P, "int_layers.%d." % l, heads, kw.get("att_res", True))
+                c["att_caches"].append(cc)
+            parts = []
+            if n_att > 0:
+                parts.append(att.reshape(X.shape[0], -1))
+            if self.n_dnn > 0:
+                h, c["acts"] = dnn_forward(np.concatenate([flat, dense_x], axis=1), P, "dnn.", self.n_dnn)
+                parts.append(h)
+            c["stack_split"] = parts[0].shape[1] if len(parts) == 2 else None
+            c["n_att"] = n_att
+            c["stack"] = np.concatenate(parts, axis=1)
+            logit = logit + c["stack"] @ P["dnn_linear.weight"].T
+        elif m == "DCNMix":    # dcnmix.py:80-100
+            logit = logit + lin
+            x0 = np.concatenate([flat, dense_x], axis=1)
+            cross_num = kw.get("cross_num", 2)
+            parts = []
+            if cross_num > 0:
+                co, c["mix_cache"] = crossnet_mix_forward(x0, P, "crossnet.", kw.get("num_experts", 4))
                 parts.append(co)
             if self.n_dnn > 0:
                 h, c["acts"] = dnn_forward(x0, P, "dnn.", self.n_dnn)
@@ -488,7 +610,7 @@ class Oracle(object):
             grads["dnn_linear.weight"] = g_logit_part.T @ acts[-1]
             return dnn_backward(g_logit_part @ P["dnn_linear.weight"], acts, P, name, self.n_dnn, grads)
 
-        if m == "DeepFM":
+        if m in ("DeepFM", "WDL"):
             g_lin = g
             if c["use_fm"]:
                 g_flat += fm_backward(E, g).reshape(B, -1)
@@ -533,6 +655,36 @@ class Oracle(object):
                                                    kw.get("cross_parameterization", "vector"))
                     grads["crossnet.kernels"], grads["crossnet.bias"] = gk, gb
                     gx0 += gx
+                if g_deep is not None:
+                    gx0 += dnn_backward(g_deep, c["acts"], P, "dnn.", self.n_dnn, grads)
+                g_flat += gx0[:, :W_emb]
+        elif m == "AutoInt":
+            g_lin = g
+            grads["dnn_linear.weight"] = g.T @ c["stack"]
+            gs = g @ P["dnn_linear.weight"]
+            sp, n_att = c["stack_split"], c["n_att"]
+            g_att = gs[:, :sp] if sp is not None else (gs if n_att > 0 else None)
+            g_deep = gs[:, sp:] if sp is not None else (gs if n_att == 0 else None)
+            if g_att is not None:
+                ga = g_att.reshape(E.shape)
+                for l in reversed(range(n_att)):
+                    ga = interacting_backward(ga, c["att_caches"][l], P, "int_layers.%d." % l, kw.get("att_head_num", 2),
+                                              grads, kw.get("att_res", True))
+                g_flat += ga.reshape(B, -1)
+            if g_deep is not None:
+                g_flat += dnn_backward(g_deep, c["acts"], P, "dnn.", self.n_dnn, grads)[:, :W_emb]
+        elif m == "DCNMix":
+            g_lin = g
+            if "stack" in c:
+                grads["dnn_linear.weight"] = g.T @ c["stack"]
+                gs = g @ P["dnn_linear.weight"]
+                sp = c["stack_split"]
+                cross_num = kw.get("cross_num", 2)
+                g_cross = gs[:, :sp] if sp is not None else (gs if cross_num > 0 else None)
+                g_deep = gs[:, sp:] if sp is not None else (gs if cross_num == 0 else None)
+                gx0 = np.zeros((B, W_emb + c["n_dense"]), self.dt)
+                if g_cross is not None:
+                    gx0 += crossnet_mix_backward(g_cross, c["mix_cache"], P, "crossnet.", kw.get("num_experts", 4), grads)
                 if g_deep is not None:
                     gx0 += dnn_backward(g_deep, c["acts"], P, "dnn.", self.n_dnn, grads)
                 g_flat += gx0[:, :W_emb]

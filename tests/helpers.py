@@ -54,7 +54,9 @@ def build_model(spec, device, l2=0.0):
         return cls(dnn, l2_reg_embedding=l2, device=device, **kw)
     if spec["model"] == "AFM":
         return cls(lin, dnn, l2_reg_linear=l2, l2_reg_embedding=l2, l2_reg_att=l2, device=device, **kw)
-    if spec["model"] == "DCN":
+    if spec["model"] == "AutoInt":
+        return cls(lin, dnn, l2_reg_embedding=l2, device=device, **kw)
+    if spec["model"] in ("DCN", "DCNMix"):
         return cls(lin, dnn, l2_reg_linear=l2, l2_reg_embedding=l2, l2_reg_cross=l2, device=device, **kw)
     return cls(lin, dnn, l2_reg_linear=l2, l2_reg_embedding=l2, device=device, **kw)
 
