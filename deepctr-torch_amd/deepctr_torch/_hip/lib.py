@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdctr_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 
@@ -133,6 +133,11 @@ SIGNATURES = {
                                                _I64, _P, _I64, _P, _I32, _P, _P]),
     "dctr_fm_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P]),
     "dctr_fm_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _I64, _I32, _P]),
+    "dctr_interacting_supported": (ctypes.c_int, [_I32, _I32, _I32]),
+    "dctr_interacting_bwd_workspace_floats": (ctypes.c_size_t, [_I32, _I32]),
+    "dctr_interacting_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P]),
+    "dctr_interacting_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P, _I64,
+                                            _P, _P, _P, _P, _P, _P]),
     "dctr_afm_bwd_workspace_floats": (ctypes.c_size_t, [_I32, _I32, _I32]),
     "dctr_afm_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     "dctr_afm_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P,

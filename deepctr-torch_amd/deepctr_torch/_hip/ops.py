@@ -273,6 +273,50 @@ class FMFunction(torch.autograd.Function):
         return gE
 
 
+class InteractFunction(torch.autograd.Function):
+    """InteractingLayer on ``E [B, F, D]`` (csrc/interact.hip): ``(E, Wq, Wk, Wv, Wr | None) -> [B, F, D]``."""
+
+    @staticmethod
+    def forward(ctx, E, Wq, Wk, Wv, Wr, heads, scaling):
+        lib = L.lib()
+        E, lde = _rows3(E, "InteractingLayer input")
+        B, F, D = E.shape
+        ws = [w.detach().float().contiguous() if w is not None else None for w in (Wq, Wk, Wv, Wr)]
+        out = torch.empty((B, F, D), dtype=torch.float32, device=E.device)
+        L.check(lib.dctr_interacting_fwd(_ptr(E), lde, B, F, D, int(heads), int(bool(scaling)), _ptr(ws[0]), _ptr(ws[1]),
+                                         _ptr(ws[2]), _ptr(ws[3]), _ptr(out), F * D, L.stream_handle(E.device)),
+                "dctr_interacting_fwd")
+        ctx.save_for_backward(E, *[w for w in ws if w is not None])
+        ctx.cfg = (int(heads), bool(scaling), ws[3] is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = L.lib()
+        heads, scaling, has_res = ctx.cfg
+        saved = ctx.saved_tensors
+        E, Wq, Wk, Wv = saved[0], saved[1], saved[2], saved[3]
+        Wr = saved[4] if has_res else None
+        E, lde = _rows3(E, "InteractingLayer input")
+        B, F, D = E.shape
+        dev = E.device
+        gout = gout.reshape(B, F * D)
+        if gout.dtype != torch.float32 or gout.stride(1) != 1:
+            gout = gout.float().contiguous()
+        gE = torch.empty((B, F, D), dtype=torch.float32, device=dev)
+        gWq, gWk, gWv = torch.empty_like(Wq), torch.empty_like(Wk), torch.empty_like(Wv)
+        gWr = torch.empty_like(Wr) if has_res else None
+        ws = torch.empty((max(1, lib.dctr_interacting_bwd_workspace_floats(B, D)),), dtype=torch.float32, device=dev)
+        L.check(lib.dctr_interacting_bwd(_ptr(E), lde, B, F, D, heads, int(scaling), _ptr(Wq), _ptr(Wk), _ptr(Wv), _ptr(Wr),
+                                         _ptr(gout), gout.stride(0), _ptr(gE), F * D, _ptr(gWq), _ptr(gWk), _ptr(gWv),
+                                         _ptr(gWr), _ptr(ws), L.stream_handle(dev)), "dctr_interacting_bwd")
+        return gE, gWq, gWk, gWv, gWr, None, None
+
+
+def interacting_supported(F, D, H):
+    return bool(L.lib().dctr_interacting_supported(int(F), int(D), int(H)))
+
+
 class AFMFunction(torch.autograd.Function):
     """AFMLayer on ``E [B, F, D]`` (csrc/afm.hip): ``(E, W [D, A], b [A], h [A, 1], p [D, 1]) -> [B, 1]``."""
 

@@ -91,10 +91,9 @@ class InteractingLayer(nn.Module):
     """Multi-head self-attention over the fields (AutoInt): ``[B, F, D] -> [B, F, D]`` (reference
     interaction.py:328-394; same constructor, same ``W_Query / W_key / W_Value / W_Res [D, D]`` parameters).
 
-    The layer is dense matrix work per sample (four ``[F, D] x [D, D]`` projections, ``H`` score matrices ``[F, F]``):
-    it runs as batched GEMMs + one softmax on PyTorch-ROCm (rocBLAS), with the reference's stack / split / cat
-    reshuffles replaced by views -- a different GPU implementation of the same arithmetic, not a hand-written
-    kernel yet (a one-wave-per-sample LDS kernel like csrc/afm.hip is the obvious next step)."""
+    One kernel forward, one backward (``csrc/interact.hip``): a wave owns a sample, E / Q / K / V / the H score matrices
+    stay in LDS, the backward recomputes the forward and sums the weight gradients in a fixed order.  Shapes outside
+    the kernel (embedding_size > 32, more than 64 fields) run the same arithmetic as batched GEMMs on PyTorch-ROCm."""
 
     def __init__(self, embedding_size, head_num=2, use_res=True, scaling=False, seed=1024, device='cpu'):
         super(InteractingLayer, self).__init__()
@@ -121,6 +120,9 @@ class InteractingLayer(nn.Module):
             raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % (len(inputs.shape)))
         B, F_, D = inputs.shape
         H, A = self.head_num, self.att_embedding_size
+        if inputs.is_cuda and _ops.interacting_supported(F_, D, H):
+            return _ops.InteractFunction.apply(inputs, self.W_Query, self.W_key, self.W_Value,
+                                               self.W_Res if self.use_res else None, H, self.scaling)
         # [B, F, D] -> [B, H, F, A]: head n = columns n*A .. (n+1)*A (torch.split(..., dim=2) of the reference)
         q = torch.matmul(inputs, self.W_Query).view(B, F_, H, A).transpose(1, 2)
         k = torch.matmul(inputs, self.W_key).view(B, F_, H, A).transpose(1, 2)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 10
+#define DCTR_ABI_VERSION 11
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -212,6 +212,23 @@ int dctr_afm_fwd(const float* E, int64_t ld_e, int32_t B, int32_t F, int32_t D, 
 int dctr_afm_bwd(const float* E, int64_t ld_e, int32_t B, int32_t F, int32_t D, int32_t A, const float* W,
                  const float* bias, const float* h, const float* p, const float* gy, float* gE, int64_t ld_ge,
                  float* gW, float* gbias, float* gh, float* gp, float* workspace, dctr_stream_t stream);
+
+/* ---- InteractingLayer of AutoInt (interaction.py:328-394): multi-head self-attention over the fields (csrc/interact.hip)
+ *   Q = E Wq, K = E Wk, V = E Wv;  head n = columns [n*A, (n+1)*A), A = D / H;  P_n = softmax_rows(Q_n K_n^T (/ sqrt(A)
+ *   when scaling));  out = relu([P_0 V_0 | ... | P_{H-1} V_{H-1}] + E Wr)          (Wr = NULL: no residual)
+ *   E [B, F, D] rows at E + b*ld_e;  W* [D, D] row-major (x @ W);  out [B, F*D] rows at out + b*ld_o.
+ * One wave per sample, everything between E and out stays in LDS; the backward recomputes the forward, writes gE and
+ * the four weight gradients (fixed-order sums, no atomics); workspace: dctr_interacting_bwd_workspace_floats(B, D).
+ * dctr_interacting_supported(F, D, H) != 0 iff the shape fits (D <= 32, F <= 64, LDS).                               */
+int dctr_interacting_supported(int32_t F, int32_t D, int32_t H);
+size_t dctr_interacting_bwd_workspace_floats(int32_t B, int32_t D);
+int dctr_interacting_fwd(const float* E, int64_t ld_e, int32_t B, int32_t F, int32_t D, int32_t H, int32_t scaling,
+                         const float* Wq, const float* Wk, const float* Wv, const float* Wr, float* out, int64_t ld_o,
+                         dctr_stream_t stream);
+int dctr_interacting_bwd(const float* E, int64_t ld_e, int32_t B, int32_t F, int32_t D, int32_t H, int32_t scaling,
+                         const float* Wq, const float* Wk, const float* Wv, const float* Wr, const float* gout,
+                         int64_t ld_g, float* gE, int64_t ld_ge, float* gWq, float* gWk, float* gWv, float* gWr,
+                         float* workspace, dctr_stream_t stream);
 
 /* ---- exact lazy regularised / Adam embedding update (csrc/lazy.hip) ------------------------------------------
  * Replaces, in O(batch) per step, what the reference does in O(vocabulary) whenever every row of a table moves at

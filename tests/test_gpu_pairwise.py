@@ -227,3 +227,44 @@ def test_afm_rejects_dense_on_the_deep_side():
     cols = [SparseFeat("a", 5, 4), SparseFeat("b", 6, 4), DenseFeat("d", 1)]
     with pytest.raises(ValueError, match="DenseFeat is not supported"):
         AFM(cols, cols, device=DEV)
+
+
+@pytest.mark.parametrize("B,F,D,H,res,scaling", [(9, 3, 4, 2, True, False), (64, 26, 16, 2, True, False),
+                                                 (33, 7, 8, 4, False, True), (1100, 10, 8, 1, True, True),
+                                                 (5, 64, 32, 8, True, False), (6, 5, 40, 2, True, False)])
+def test_interacting_layer_matches_torch(B, F, D, H, res, scaling):
+    """InteractingLayer (interaction.py:366-394): forward, input gradient and the weight gradients against the
+    reference's own sequence of torch ops in fp64.  The last case (D = 40) is outside the kernel: PyTorch-ROCm path."""
+    from deepctr_torch.layers import InteractingLayer
+    torch.manual_seed(B + F + D)
+    layer = InteractingLayer(D, head_num=H, use_res=res, scaling=scaling, device=DEV)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.normal_(0, 0.3)
+    g = torch.Generator(device=DEV).manual_seed(B)
+    E = (torch.randn(B, F, D, device=DEV, generator=g) * 0.7).requires_grad_(True)
+    R = torch.randn(B, F, D, device=DEV, generator=g)
+    y = layer(E)
+    assert y.shape == (B, F, D)
+    (y * R).sum().backward()
+    names = ["W_Query", "W_key", "W_Value"] + (["W_Res"] if res else [])
+    got = [y.detach(), E.grad] + [getattr(layer, n).grad for n in names]
+    E2 = E.detach().double().requires_grad_(True)
+    Ws = {n: getattr(layer, n).detach().double().requires_grad_(True) for n in names}
+    A = D // H
+    q, k, v = (torch.tensordot(E2, Ws[n], dims=([-1], [0])) for n in names[:3])
+    q, k, v = (torch.stack(torch.split(t, A, dim=2)) for t in (q, k, v))
+    inner = torch.einsum("bnik,bnjk->bnij", q, k)
+    if scaling:
+        inner = inner / A ** 0.5
+    result = torch.matmul(torch.softmax(inner, dim=-1), v)
+    result = torch.squeeze(torch.cat(torch.split(result, 1), dim=-1), dim=0)
+    if res:
+        result = result + torch.tensordot(E2, Ws["W_Res"], dims=([-1], [0]))
+    y2 = torch.relu(result)
+    (y2 * R.double()).sum().backward()
+    want = [y2.detach(), E2.grad] + [Ws[n].grad for n in names]
+    for name, a, r in zip(["y", "gE"] + names, got, want):
+        scale = max(1.0, float(r.abs().max()))
+        err = float((a.double() - r).abs().max())
+        assert err <= 2e-5 * scale, "%s: max|d|=%.3e (scale %.3g)" % (name, err, scale)
