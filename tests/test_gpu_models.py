@@ -98,3 +98,34 @@ def test_training_trajectory_matches_reference(name, opt):
                 d = np.minimum(d, np.abs(got - np.asarray(o64.P[key], np.float64).reshape(got.shape)))
             err = float(d.max()) if d.size else 0.0
             assert err <= TRAJ_TOL, "%s: %.3e" % (key, err)
+
+
+@pytest.mark.parametrize("name", ["dcn_vector", "xdeepfm_criteo", "afm_criteo"])
+def test_fit_replays_graphs_for_autograd_step_models(name, monkeypatch):
+    """fit() also replays a hipGraph of the AUTOGRAD train step (models outside the fused step) when that is
+    replay-safe: same parameters and History as with graphs switched off."""
+    g = load_golden(name)
+    names = []
+    for c in g["spec"]["linear_columns"] + g["spec"]["dnn_columns"]:
+        if c["name"] not in names:
+            names.append(c["name"])
+    n = (g["X"].shape[0] // 16) * 16
+    X = np.concatenate([g["X"][:n]] * 3, axis=0)
+    y = np.concatenate([g["y"][:n]] * 3, axis=0)
+    runs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DCTR_FIT_GRAPH", flag)
+        m = build_model(g["spec"], DEV)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in g["params"].items()})
+        m.compile("adagrad", "binary_crossentropy", metrics=[])
+        fi = m.feature_index
+        x = {nm: X[:, fi[nm][0]] for nm in names}
+        hist = m.fit(x, y, batch_size=16, epochs=2, verbose=0, shuffle=False)
+        used = m._fit_graph is not None and m._fit_graph.get("graph") is not None
+        runs.append(({k: v.clone() for k, v in m.state_dict().items()}, dict(hist.history), used))
+    (a, ha, ua), (b, hb, ub) = runs
+    assert ua and not ub
+    for k in a:
+        err = max_abs(a[k].cpu().numpy(), b[k].cpu().numpy())
+        assert err <= 1e-6 * max(1.0, float(b[k].abs().max())), "%s: %.3e" % (k, err)
+    np.testing.assert_allclose(ha["loss"], hb["loss"], rtol=1e-6)
