@@ -576,6 +576,50 @@ class BilinearFunction(torch.autograd.Function):
         return (None, gE, gV, g_dense) + tuple(gW[i] for i in range(ctx.n_w_in))
 
 
+class BilinearStackedFunction(torch.autograd.Function):
+    """``(x_i W_k^T) * x_j`` for every pair k with the weights given as ONE ``[n_w, D, D]`` tensor (no per-weight
+    parameters to re-seat): the bilinear kernels of csrc/pairwise.hip behind OutterProductLayer's 'mat' kernel."""
+
+    @staticmethod
+    def forward(ctx, meta, E, Wf):
+        lib = L.lib()
+        E, lde = _rows3(E, "pairwise input")
+        B, F, D = E.shape
+        if D > 16:
+            raise NotImplementedError("the gfx950 bilinear kernels support embedding_dim <= 16 (got %d)" % D)
+        Wf = Wf.detach().float().contiguous()
+        P = F * (F - 1) // 2
+        out = torch.empty((B, P * D), dtype=torch.float32, device=E.device)
+        sched = meta.device_tables(E.device)
+        L.check(lib.dctr_bilinear_fwd(_ptr(E), lde, None, 0, _ptr(Wf), _ptr(sched[0]), meta.n_sched, P, F, D, B,
+                                      _ptr(out), P * D, None, 0, 0, P * D, L.stream_handle(E.device)),
+                "dctr_bilinear_fwd")
+        ctx.meta = meta
+        ctx.save_for_backward(E, Wf)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = L.lib()
+        meta = ctx.meta
+        E, Wf = ctx.saved_tensors
+        E, lde = _rows3(E, "pairwise input")
+        B, F, D = E.shape
+        P = F * (F - 1) // 2
+        gout = gout.float()
+        if gout.stride(1) != 1:
+            gout = gout.contiguous()
+        dev = E.device
+        gE = torch.empty((B, F, D), dtype=torch.float32, device=dev)
+        gW = torch.empty((meta.n_w, D, D), dtype=torch.float32, device=dev)
+        ws = torch.empty((max(1, lib.dctr_bilinear_bwd_workspace_floats(B, P, D)),), dtype=torch.float32, device=dev)
+        sched = meta.device_tables(dev)
+        L.check(lib.dctr_bilinear_bwd(_ptr(E), lde, None, 0, _ptr(Wf), _ptr(sched[0]), meta.n_sched, meta.slots,
+                                      _ptr(sched[1]), meta.n_w, P, F, D, B, _ptr(gout), gout.stride(0), _ptr(gE), None,
+                                      _ptr(gW), _ptr(ws), L.stream_handle(dev)), "dctr_bilinear_bwd")
+        return None, gE, gW
+
+
 class BilinearMeta(object):
     """Host-side tables of a BilinearInteraction layer: the tournament schedule and the flat weight slab."""
 

@@ -9,7 +9,7 @@ import torch.nn as nn
 from .._hip import ops as _ops
 from .activation import activation_layer
 
-__all__ = ["FM", "BiInteractionPooling", "AFMLayer", "InteractingLayer", "CrossNetMix", "CIN", "SENETLayer", "BilinearInteraction", "InnerProductLayer", "CrossNet"]
+__all__ = ["FM", "BiInteractionPooling", "AFMLayer", "InteractingLayer", "CrossNetMix", "CIN", "SENETLayer", "BilinearInteraction", "InnerProductLayer", "OutterProductLayer", "CrossNet"]
 
 
 class FM(nn.Module):
@@ -306,6 +306,47 @@ class InnerProductLayer(nn.Module):
     def forward(self, inputs):
         E = inputs if torch.is_tensor(inputs) else torch.cat(list(inputs), dim=1)
         return _ops.InnerProductFunction.apply(E, self.reduce_sum)
+
+
+class OutterProductLayer(nn.Module):
+    """Outer-product layer of PNN: per pair (i < j) the scalar ``p^T K q`` for the kernel types ``mat`` (K = ``kernel[:, k,
+    :]``, a full D x D form), ``vec`` (diagonal) and ``num`` (a scalar) -- list of F ``[B, 1, D]`` tensors (or one
+    ``[B, F, D]`` tensor) ``-> [B, F(F-1)/2]`` (reference interaction.py:580-672; same constructor, same ``kernel``
+    parameter).  'mat' is the bilinear form ``sum_e' (x_i W_k^T)[e'] x_j[e']`` with ``W_k = kernel[:, k, :]``: it runs on
+    the MFMA bilinear kernels of csrc/pairwise.hip followed by a row sum; 'vec' / 'num' scale the element-wise products
+    of csrc/pairwise.hip's inner-product kernel.  (embedding_size > 16 with 'mat': batched GEMMs on PyTorch-ROCm.)"""
+
+    def __init__(self, field_size, embedding_size, kernel_type='mat', seed=1024, device='cpu'):
+        super(OutterProductLayer, self).__init__()
+        self.kernel_type = kernel_type
+        num_inputs = field_size
+        num_pairs = int(num_inputs * (num_inputs - 1) / 2)
+        embed_size = embedding_size
+        if self.kernel_type == 'mat':
+            self.kernel = nn.Parameter(torch.Tensor(embed_size, num_pairs, embed_size))
+        elif self.kernel_type == 'vec':
+            self.kernel = nn.Parameter(torch.Tensor(num_pairs, embed_size))
+        elif self.kernel_type == 'num':
+            self.kernel = nn.Parameter(torch.Tensor(num_pairs, 1))
+        nn.init.xavier_uniform_(self.kernel)
+        self._meta = None
+        self.to(device)
+
+    def forward(self, inputs):
+        E = inputs if torch.is_tensor(inputs) else torch.cat(list(inputs), dim=1)
+        B, F_, D = E.shape
+        P = F_ * (F_ - 1) // 2
+        if self.kernel_type == 'mat':
+            if D <= 16:
+                if self._meta is None or self._meta[0] != F_:
+                    self._meta = (F_, _ops.BilinearMeta(F_, "interaction"))
+                prod = _ops.BilinearStackedFunction.apply(self._meta[1], E, self.kernel.permute(1, 0, 2))
+                return prod.view(B, P, D).sum(dim=-1)
+            idx = torch.triu_indices(F_, F_, 1, device=E.device)
+            pk = torch.einsum("bke,fke->bkf", E[:, idx[0]], self.kernel)
+            return torch.sum(pk * E[:, idx[1]], dim=-1)
+        prod = _ops.InnerProductFunction.apply(E, False)                 # [B, P, D]: p (.) q
+        return torch.sum(prod * self.kernel.unsqueeze(0), dim=-1)
 
 
 class CrossNet(nn.Module):

@@ -1,11 +1,11 @@
 # -*- coding: utf-8 -*-
-"""PNN (reference models/pnn.py:17-109) with the inner-product layer on the gfx950 kernel of csrc/pairwise.hip.
-The outer-product variant (``use_outter``) is outside the hot path of this build."""
+"""PNN (reference models/pnn.py:17-109) with the inner- and outer-product layers on the gfx950 kernels of
+csrc/pairwise.hip."""
 import torch
 import torch.nn as nn
 
 from .basemodel import BaseModel
-from ..layers import DNN, InnerProductLayer
+from ..layers import DNN, InnerProductLayer, OutterProductLayer
 
 
 class PNN(BaseModel):
@@ -19,9 +19,6 @@ class PNN(BaseModel):
                                   init_std=init_std, seed=seed, task=task, device=device, gpus=gpus)
         if kernel_type not in ['mat', 'vec', 'num']:
             raise ValueError("kernel_type must be mat,vec or num")
-        if use_outter:
-            raise NotImplementedError("OutterProductLayer is outside the MI355X hot path of this build "
-                                      "(SURVEY.md section 8(f)); use_inner=True runs on the HIP kernel")
         self.use_inner = use_inner
         self.use_outter = use_outter
         self.kernel_type = kernel_type
@@ -32,6 +29,10 @@ class PNN(BaseModel):
         if self.use_inner:
             product_out_dim += num_pairs
             self.innerproduct = InnerProductLayer(device=device)
+        if self.use_outter:
+            product_out_dim += num_pairs
+            self.outterproduct = OutterProductLayer(num_inputs, self.embedding_size, kernel_type=kernel_type,
+                                                    device=device)
         self.dnn = DNN(product_out_dim + self.compute_input_dim(dnn_feature_columns), dnn_hidden_units,
                        activation=dnn_activation, l2_reg=l2_reg_dnn, dropout_rate=dnn_dropout, use_bn=False,
                        init_std=init_std, device=device)
@@ -46,11 +47,14 @@ class PNN(BaseModel):
         gathered, _, _ = self.fused_inputs(X, want_fm=False)      # [B, F*D | dense]
         B, nf = X.shape[0], len(plan.deep)
         parts = [gathered[:, :plan.emb_width]]
-        if self.use_inner:
+        if self.use_inner or self.use_outter:
             if plan.emb_dim <= 0:
                 raise ValueError("embedding_dim of SparseFeat and VarlenSparseFeat must be same in this model!")
             emb = gathered[:, :plan.emb_width].reshape(B, nf, plan.emb_dim)
+        if self.use_inner:
             parts.append(torch.flatten(self.innerproduct(emb), start_dim=1))
+        if self.use_outter:
+            parts.append(self.outterproduct(emb))
         if plan.dense_cols:
             parts.append(gathered[:, plan.emb_width:])
         dnn_input = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)

@@ -179,6 +179,11 @@ case("dcnmix_deep", "DCNMix", _d, _d, batch=48, steps=True, dnn_hidden_units=(32
 # (DCNMix with dnn_hidden_units=() cannot be built in the reference either: dcnmix.py:56 constructs DNN unconditionally)
 case("dcnmix_wide_experts", "DCNMix", _d, _d, batch=24, dnn_hidden_units=(8,), cross_num=3, low_rank=4, num_experts=2)
 
+case("pnn_outer_mat", "PNN", [], _d, batch=40, steps=True, dnn_hidden_units=(32, 16), use_inner=True, use_outter=True,
+     kernel_type="mat")
+case("pnn_outer_vec", "PNN", [], _d, batch=24, dnn_hidden_units=(16,), use_inner=False, use_outter=True, kernel_type="vec")
+case("pnn_outer_num", "PNN", [], _d, batch=24, dnn_hidden_units=(16,), use_inner=True, use_outter=True, kernel_type="num")
+
 # regularised / Adam trajectories (the reference's DEFAULT kind of training: l2 > 0 on every table, basemodel.py:412-428,
 # and torch.optim.Adam, basemodel.py:447-461): small batches over small vocabularies, so that most rows are NOT touched
 # by a given step and are touched again a few steps later -- what the exact lazy update (csrc/lazy.hip) must replay

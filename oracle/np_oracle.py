@@ -582,9 +582,23 @@ class Oracle(object):
             h, c["acts"] = dnn_forward(np.concatenate([bi, dense_x], axis=1), P, "dnn.", self.n_dnn)
             logit = lin + h @ P["dnn_linear.weight"].T
         elif m == "PNN":
-            ip, c["pairs"] = inner_product_forward(E)
-            c["n_ip"] = ip.shape[1]
-            h, c["acts"] = dnn_forward(np.concatenate([flat, ip, dense_x], axis=1), P, "dnn.", self.n_dnn)
+            prods = []
+            c["n_ip"] = 0
+            if kw.get("use_inner", True):
+                ip, c["pairs"] = inner_product_forward(E)
+                c["n_ip"] = ip.shape[1]
+                prods.append(ip)
+            c["n_op"] = 0
+            if kw.get("use_outter", False):          # OutterProductLayer, interaction.py:616-670
+                ii, jj = np.triu_indices(E.shape[1], 1)
+                p_, q_ = E[:, ii], E[:, jj]
+                K = P["outterproduct.kernel"]
+                kt = kw.get("kernel_type", "mat")
+                op = np.einsum("bke,fke,bkf->bk", p_, K, q_) if kt == "mat" else (p_ * q_ * K[None]).sum(axis=-1)
+                c["op"] = (ii, jj, p_, q_, kt)
+                c["n_op"] = op.shape[1]
+                prods.append(op)
+            h, c["acts"] = dnn_forward(np.concatenate([flat] + prods + [dense_x], axis=1), P, "dnn.", self.n_dnn)
             logit = h @ P["dnn_linear.weight"].T
         else:
             raise ValueError(m)
@@ -717,8 +731,25 @@ class Oracle(object):
         elif m == "PNN":
             gin = dnn_head(g)
             g_flat += gin[:, :W_emb]
-            gip = gin[:, W_emb:W_emb + c["n_ip"]]
-            g_flat += inner_product_backward(E, c["pairs"], gip).reshape(B, -1)
+            if c["n_ip"]:
+                gip = gin[:, W_emb:W_emb + c["n_ip"]]
+                g_flat += inner_product_backward(E, c["pairs"], gip).reshape(B, -1)
+            if c["n_op"]:
+                ii, jj, p_, q_, kt = c["op"]
+                gop = gin[:, W_emb + c["n_ip"]:W_emb + c["n_ip"] + c["n_op"]]
+                K = P["outterproduct.kernel"]
+                if kt == "mat":
+                    grads["outterproduct.kernel"] = np.einsum("bk,bke,bkf->fke", gop, p_, q_)
+                    gp = np.einsum("bk,fke,bkf->bke", gop, K, q_)
+                    gq = np.einsum("bk,bke,fke->bkf", gop, p_, K)
+                else:
+                    gk = (gop[:, :, None] * p_ * q_).sum(axis=0)
+                    grads["outterproduct.kernel"] = gk if kt == "vec" else gk.sum(axis=1, keepdims=True)
+                    gp, gq = gop[:, :, None] * q_ * K[None], gop[:, :, None] * p_ * K[None]
+                gE = np.zeros_like(E)
+                np.add.at(gE, (slice(None), ii), gp)
+                np.add.at(gE, (slice(None), jj), gq)
+                g_flat += gE.reshape(B, -1)
 
         # embedding tables
         g_embs, off = [], 0
