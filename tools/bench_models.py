@@ -29,6 +29,11 @@ spec = {
     "DCN": lambda: M.DCN(cols, cols, dnn_hidden_units=(256, 128), l2_reg_linear=0, l2_reg_embedding=0, device=dev),
     "PNN": lambda: M.PNN(cols, dnn_hidden_units=(256, 128), l2_reg_embedding=0, device=dev),
     "NFM": lambda: M.NFM(cols, cols, dnn_hidden_units=(256, 128), l2_reg_linear=0, l2_reg_embedding=0, device=dev),
+    "WDL": lambda: M.WDL(cols, cols, dnn_hidden_units=(256, 128), l2_reg_linear=0, l2_reg_embedding=0, device=dev),
+    "AutoInt": lambda: M.AutoInt(cols, cols, att_layer_num=3, att_head_num=2, dnn_hidden_units=(256, 128),
+                                 l2_reg_embedding=0, device=dev),
+    "DCNMix": lambda: M.DCNMix(cols, cols, dnn_hidden_units=(256, 128), l2_reg_linear=0, l2_reg_embedding=0,
+                               l2_reg_cross=0, device=dev),
     "AFM": lambda: M.AFM(cols, cols[:26], attention_factor=8, l2_reg_linear=0, l2_reg_embedding=0, l2_reg_att=0,
                          device=dev),
 }
