@@ -298,7 +298,7 @@ size_t lds_bytes(int F, int D, int AP, int P, bool bwd) {
   return n * sizeof(float);
 }
 
-int afm_groups(int B) { return B < 1024 ? B : 1024; }
+int afm_groups(int B) { return B < 4096 ? B : 4096; }   // one wave each: about one round of the chip
 
 template <bool BWD>
 int launch(const AfmArgs& a, int AP, int groups, hipStream_t s) {

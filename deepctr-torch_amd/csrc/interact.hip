@@ -259,7 +259,9 @@ size_t lds_bytes(int F, int D, int H, bool bwd) {
   return n * sizeof(float);
 }
 
-int groups_of(int B, bool bwd) { return B < (bwd ? 1024 : 4096) ? B : (bwd ? 1024 : 4096); }
+// one wave per workgroup, ~13 resident per CU: 4096 workgroups are about one round of the chip; more samples than that
+// are walked grid-stride (the backward's partial weight-gradient rows stay at 16 MB)
+int groups_of(int B, bool) { return B < 4096 ? B : 4096; }
 
 int check(const float* E, int64_t ld_e, int B, int F, int D, int H, const float* Wq, const float* Wk, const float* Wv) {
   if (!E || !Wq || !Wk || !Wv || B < 0 || F <= 0 || D <= 0 || H <= 0 || D % H != 0 ||
