@@ -23,23 +23,15 @@ class AutoInt(BaseModel):
         self.use_dnn = len(dnn_feature_columns) > 0 and len(dnn_hidden_units) > 0
         field_num = len(self.embedding_dict)
         embedding_size = self.embedding_size
-        if len(dnn_hidden_units) and att_layer_num > 0:
-            dnn_linear_in_feature = dnn_hidden_units[-1] + field_num * embedding_size
-        elif len(dnn_hidden_units) > 0:
-            dnn_linear_in_feature = dnn_hidden_units[-1]
-        elif att_layer_num > 0:
-            dnn_linear_in_feature = field_num * embedding_size
-        else:
-            raise NotImplementedError
-        self.dnn_linear = nn.Linear(dnn_linear_in_feature, 1, bias=False).to(device)
+        att_width = field_num * embedding_size if att_layer_num > 0 else 0
+        head_in = att_width + (dnn_hidden_units[-1] if len(dnn_hidden_units) > 0 else 0)   # [attention output | tower output]
         self.dnn_hidden_units = dnn_hidden_units
         self.att_layer_num = att_layer_num
         if self.use_dnn:
-            self.dnn = DNN(self.compute_input_dim(dnn_feature_columns), dnn_hidden_units, activation=dnn_activation,
-                           l2_reg=l2_reg_dnn, dropout_rate=dnn_dropout, use_bn=dnn_use_bn, init_std=init_std,
-                           device=device)
-            self.add_regularization_weight(
-                filter(lambda x: 'weight' in x[0] and 'bn' not in x[0], self.dnn.named_parameters()), l2=l2_reg_dnn)
+            self._make_tower(self.compute_input_dim(dnn_feature_columns), dnn_hidden_units, dnn_activation, l2_reg_dnn,
+                             dnn_dropout, dnn_use_bn, init_std, device, head_in=head_in, l2_head=False)
+        else:
+            self.dnn_linear = nn.Linear(head_in, 1, bias=False).to(device)
         self.int_layers = nn.ModuleList(
             [InteractingLayer(embedding_size, att_head_num, att_res, device=device) for _ in range(att_layer_num)])
         self.to(device)

@@ -234,6 +234,22 @@ class BaseModel(nn.Module):
         dense_value_list = [X[:, self.feature_index[fc.name][0]:self.feature_index[fc.name][1]] for fc in dense_cols]
         return emb_list, dense_value_list
 
+    def _make_tower(self, in_features, hidden_units, activation='relu', l2_reg_dnn=0, dropout=0, use_bn=False,
+                    init_std=0.0001, device='cpu', head_in=None, l2_head=None):
+        """``self.dnn`` (+ ``self.dnn_linear``, the bias-free 1-unit projection every model of the family puts on top of
+        it) with their regularisation groups -- the block each reference model spells out in its constructor (e.g.
+        deepfm.py:55-63, dcn.py:53-70).  ``head_in``: input width of ``dnn_linear`` when it reads more than the tower's
+        last layer (DCN / AutoInt stack other features beside it); ``l2_head``: its L2 strength (default: l2_reg_dnn),
+        ``False`` leaves it unregularised."""
+        from ..layers import DNN
+        self.dnn = DNN(in_features, hidden_units, activation=activation, l2_reg=l2_reg_dnn, dropout_rate=dropout,
+                       use_bn=use_bn, init_std=init_std, device=device)
+        self.dnn_linear = nn.Linear(hidden_units[-1] if head_in is None else head_in, 1, bias=False).to(device)
+        self.add_regularization_weight(
+            [kv for kv in self.dnn.named_parameters() if 'weight' in kv[0] and 'bn' not in kv[0]], l2=l2_reg_dnn)
+        if l2_head is not False:
+            self.add_regularization_weight(self.dnn_linear.weight, l2=l2_reg_dnn if l2_head is None else l2_head)
+
     def compute_input_dim(self, feature_columns, include_sparse=True, include_dense=True, feature_group=False):
         sparse_cols, varlen_cols, dense_cols = split_columns(feature_columns)
         emb_cols = [c for c in feature_columns if isinstance(c, (SparseFeat, VarLenSparseFeat))] \

@@ -3,7 +3,6 @@
 The gather, the tower and the table update are this package's kernels; the cross network's skinny GEMMs run on
 PyTorch-ROCm (layers.CrossNetMix)."""
 import torch
-import torch.nn as nn
 
 from .basemodel import BaseModel
 from ..layers import DNN, CrossNetMix
@@ -22,20 +21,14 @@ class DCNMix(BaseModel):
                                      init_std=init_std, seed=seed, task=task, device=device, gpus=gpus)
         self.dnn_hidden_units = dnn_hidden_units
         self.cross_num = cross_num
-        self.dnn = DNN(self.compute_input_dim(dnn_feature_columns), dnn_hidden_units, activation=dnn_activation,
-                       use_bn=dnn_use_bn, l2_reg=l2_reg_dnn, dropout_rate=dnn_dropout, init_std=init_std, device=device)
-        if len(self.dnn_hidden_units) > 0 and self.cross_num > 0:
-            dnn_linear_in_feature = self.compute_input_dim(dnn_feature_columns) + dnn_hidden_units[-1]
-        elif len(self.dnn_hidden_units) > 0:
-            dnn_linear_in_feature = dnn_hidden_units[-1]
-        elif self.cross_num > 0:
-            dnn_linear_in_feature = self.compute_input_dim(dnn_feature_columns)
-        self.dnn_linear = nn.Linear(dnn_linear_in_feature, 1, bias=False).to(device)
+        width = self.compute_input_dim(dnn_feature_columns)
+        deep, cross = len(dnn_hidden_units) > 0, cross_num > 0
+        # dnn_linear reads [cross output (width) | tower output]: whichever of the two exist
+        head_in = (width if cross else 0) + (dnn_hidden_units[-1] if deep else 0)
+        self._make_tower(width, dnn_hidden_units, dnn_activation, l2_reg_dnn, dnn_dropout, dnn_use_bn, init_std, device,
+                         head_in=head_in, l2_head=l2_reg_linear)
         self.crossnet = CrossNetMix(in_features=self.compute_input_dim(dnn_feature_columns), low_rank=low_rank,
                                     num_experts=num_experts, layer_num=cross_num, device=device)
-        self.add_regularization_weight(
-            filter(lambda x: 'weight' in x[0] and 'bn' not in x[0], self.dnn.named_parameters()), l2=l2_reg_dnn)
-        self.add_regularization_weight(self.dnn_linear.weight, l2=l2_reg_linear)
         for module in [self.crossnet.U_list, self.crossnet.V_list, self.crossnet.C_list]:
             self.add_regularization_weight(module, l2=l2_reg_cross)
         self.to(device)

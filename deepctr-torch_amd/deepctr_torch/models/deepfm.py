@@ -3,8 +3,6 @@
 
 The forward is two device phases instead of the reference's ~200 ATen launches:
 one fused gather (embeddings in DNN-input layout + linear logit + FM term) and the MLP tower."""
-import torch
-import torch.nn as nn
 
 from .basemodel import BaseModel
 from ..layers import DNN, FM
@@ -25,13 +23,8 @@ class DeepFM(BaseModel):
         if use_fm:
             self.fm = FM()
         if self.use_dnn:
-            self.dnn = DNN(self.compute_input_dim(dnn_feature_columns), dnn_hidden_units,
-                           activation=dnn_activation, l2_reg=l2_reg_dnn, dropout_rate=dnn_dropout,
-                           use_bn=dnn_use_bn, init_std=init_std, device=device)
-            self.dnn_linear = nn.Linear(dnn_hidden_units[-1], 1, bias=False).to(device)
-            self.add_regularization_weight(
-                filter(lambda x: 'weight' in x[0] and 'bn' not in x[0], self.dnn.named_parameters()), l2=l2_reg_dnn)
-            self.add_regularization_weight(self.dnn_linear.weight, l2=l2_reg_dnn)
+            self._make_tower(self.compute_input_dim(dnn_feature_columns), dnn_hidden_units, dnn_activation, l2_reg_dnn,
+                             dnn_dropout, dnn_use_bn, init_std, device)
         self.to(device)
 
     def logit_parts(self, X):

@@ -24,10 +24,9 @@ class FiBiNET(BaseModel):
         self.field_size = len(self.embedding_dict)
         self.SE = SENETLayer(self.field_size, reduction_ratio, seed, device)
         self.Bilinear = BilinearInteraction(self.field_size, self.embedding_size, bilinear_type, seed, device)
-        self.dnn = DNN(self.compute_input_dim(dnn_feature_columns), dnn_hidden_units,
-                       activation=dnn_activation, l2_reg=l2_reg_dnn, dropout_rate=dnn_dropout, use_bn=False,
-                       init_std=init_std, device=device)
-        self.dnn_linear = nn.Linear(dnn_hidden_units[-1], 1, bias=False).to(device)
+        self.dnn = DNN(self.compute_input_dim(dnn_feature_columns), dnn_hidden_units, activation=dnn_activation,
+                       l2_reg=l2_reg_dnn, dropout_rate=dnn_dropout, use_bn=False, init_std=init_std, device=device)
+        self.dnn_linear = nn.Linear(dnn_hidden_units[-1], 1, bias=False).to(device)   # (no reg groups: fibinet.py:60-64)
 
     def compute_input_dim(self, feature_columns, include_sparse=True, include_dense=True):
         emb_cols = [c for c in feature_columns if isinstance(c, (SparseFeat, VarLenSparseFeat))] \

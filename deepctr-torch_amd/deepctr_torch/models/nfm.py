@@ -19,13 +19,9 @@ class NFM(BaseModel):
         super(NFM, self).__init__(linear_feature_columns, dnn_feature_columns, l2_reg_linear=l2_reg_linear,
                                   l2_reg_embedding=l2_reg_embedding, init_std=init_std, seed=seed, task=task,
                                   device=device, gpus=gpus)
-        self.dnn = DNN(self.compute_input_dim(dnn_feature_columns, include_sparse=False) + self.embedding_size,
-                       dnn_hidden_units, activation=dnn_activation, l2_reg=l2_reg_dnn, dropout_rate=dnn_dropout,
-                       use_bn=False, init_std=init_std, device=device)
-        self.dnn_linear = nn.Linear(dnn_hidden_units[-1], 1, bias=False).to(device)
-        self.add_regularization_weight(
-            filter(lambda x: 'weight' in x[0] and 'bn' not in x[0], self.dnn.named_parameters()), l2=l2_reg_dnn)
-        self.add_regularization_weight(self.dnn_linear.weight, l2=l2_reg_dnn)
+        # tower input = [bi-interaction vector (embedding_size) | dense features]
+        self._make_tower(self.compute_input_dim(dnn_feature_columns, include_sparse=False) + self.embedding_size,
+                         dnn_hidden_units, dnn_activation, l2_reg_dnn, dnn_dropout, False, init_std, device)
         self.bi_pooling = BiInteractionPooling()
         self.bi_dropout = bi_dropout
         if self.bi_dropout > 0:

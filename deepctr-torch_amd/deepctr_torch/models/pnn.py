@@ -2,10 +2,9 @@
 """PNN (reference models/pnn.py:17-109) with the inner- and outer-product layers on the gfx950 kernels of
 csrc/pairwise.hip."""
 import torch
-import torch.nn as nn
 
 from .basemodel import BaseModel
-from ..layers import DNN, InnerProductLayer, OutterProductLayer
+from ..layers import InnerProductLayer, OutterProductLayer
 
 
 class PNN(BaseModel):
@@ -33,13 +32,8 @@ class PNN(BaseModel):
             product_out_dim += num_pairs
             self.outterproduct = OutterProductLayer(num_inputs, self.embedding_size, kernel_type=kernel_type,
                                                     device=device)
-        self.dnn = DNN(product_out_dim + self.compute_input_dim(dnn_feature_columns), dnn_hidden_units,
-                       activation=dnn_activation, l2_reg=l2_reg_dnn, dropout_rate=dnn_dropout, use_bn=False,
-                       init_std=init_std, device=device)
-        self.dnn_linear = nn.Linear(dnn_hidden_units[-1], 1, bias=False).to(device)
-        self.add_regularization_weight(
-            filter(lambda x: 'weight' in x[0] and 'bn' not in x[0], self.dnn.named_parameters()), l2=l2_reg_dnn)
-        self.add_regularization_weight(self.dnn_linear.weight, l2=l2_reg_dnn)
+        self._make_tower(product_out_dim + self.compute_input_dim(dnn_feature_columns), dnn_hidden_units, dnn_activation,
+                         l2_reg_dnn, dnn_dropout, False, init_std, device)
         self.to(device)
 
     def logit_parts(self, X):
