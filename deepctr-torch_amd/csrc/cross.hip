@@ -23,26 +23,35 @@ __global__ __launch_bounds__(kT) void k_cross_fwd(const float* __restrict__ X, i
   const int lane = threadIdx.x & 63;
   const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
+  // every load is unconditional on a clamped index and masked afterwards (a predicated load compiles to a branch with
+  // its own s_waitcnt vmcnt(0): NR serial round trips per loop otherwise); lanes past W carry zeros
   float x0[NR], xl[NR];
+  int ic[NR];
 #pragma unroll
   for (int q = 0; q < NR; ++q) {
     const int i = q * 64 + lane;
-    x0[q] = i < W ? ldg_f32(X + b * ldx + i) : 0.f;
+    ic[q] = i < W ? i : 0;
+  }
+#pragma unroll
+  for (int q = 0; q < NR; ++q) x0[q] = ldg_f32(X + b * ldx + ic[q]);
+#pragma unroll
+  for (int q = 0; q < NR; ++q) {
+    x0[q] = (q * 64 + lane < W) ? x0[q] : 0.f;
     xl[q] = x0[q];
   }
   for (int l = 0; l < L; ++l) {
+    float kw[NR], kb[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      kw[q] = ldg_f32(Kw + static_cast<int64_t>(l) * W + ic[q]);
+      kb[q] = ldg_f32(Kb + static_cast<int64_t>(l) * W + ic[q]);
+    }
     float part = 0.f;
 #pragma unroll
-    for (int q = 0; q < NR; ++q) {
-      const int i = q * 64 + lane;
-      if (i < W) part += xl[q] * ldg_f32(Kw + static_cast<int64_t>(l) * W + i);
-    }
+    for (int q = 0; q < NR; ++q) part += xl[q] * kw[q];           // xl is 0 past W
     const float s = wave_sum(part);
 #pragma unroll
-    for (int q = 0; q < NR; ++q) {
-      const int i = q * 64 + lane;
-      if (i < W) xl[q] = x0[q] * s + ldg_f32(Kb + static_cast<int64_t>(l) * W + i) + xl[q];
-    }
+    for (int q = 0; q < NR; ++q) xl[q] = (q * 64 + lane < W) ? x0[q] * s + kb[q] + xl[q] : 0.f;
   }
 #pragma unroll
   for (int q = 0; q < NR; ++q) {
@@ -76,29 +85,37 @@ __global__ __launch_bounds__(kT) void k_cross_bwd(const float* __restrict__ X, i
       if (b >= B) break;
       float x0[NR], xl[NR], g[NR];
 #pragma unroll
+      for (int q = 0; q < NR; ++q) {          // unconditional loads on clamped indices, masked below
+        const int i = q * 64 + lane, icq = i < W ? i : 0;
+        x0[q] = ldg_f32(X + b * ldx + icq);
+        g[q] = ldg_f32(gY + b * ldg + icq);
+      }
+#pragma unroll
       for (int q = 0; q < NR; ++q) {
-        const int i = q * 64 + lane;
-        x0[q] = i < W ? ldg_f32(X + b * ldx + i) : 0.f;
+        const bool in = q * 64 + lane < W;
+        x0[q] = in ? x0[q] : 0.f;
+        g[q] = in ? g[q] : 0.f;
         xl[q] = x0[q];
-        g[q] = i < W ? ldg_f32(gY + b * ldg + i) : 0.f;
       }
       for (int k = 0; k < L; ++k) {  // forward again, remembering x_k and s_k
+        float kw[NR], kb[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+          const int i = q * 64 + lane, icq = i < W ? i : 0;
+          kw[q] = ldg_f32(Kw + static_cast<int64_t>(k) * W + icq);
+          kb[q] = ldg_f32(Kb + static_cast<int64_t>(k) * W + icq);
+        }
         float p = 0.f;
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
           const int i = q * 64 + lane;
-          if (i < W) {
-            xs[k * W + i] = xl[q];
-            p += xl[q] * ldg_f32(Kw + static_cast<int64_t>(k) * W + i);
-          }
+          if (i < W) xs[k * W + i] = xl[q];
+          p += xl[q] * kw[q];                    // xl is 0 past W
         }
         const float s = wave_sum(p);
         if (lane == 0) ss[k] = s;
 #pragma unroll
-        for (int q = 0; q < NR; ++q) {
-          const int i = q * 64 + lane;
-          if (i < W) xl[q] = x0[q] * s + ldg_f32(Kb + static_cast<int64_t>(k) * W + i) + xl[q];
-        }
+        for (int q = 0; q < NR; ++q) xl[q] = (q * 64 + lane < W) ? x0[q] * s + kb[q] + xl[q] : 0.f;
       }
       float gx0[NR];
 #pragma unroll
@@ -118,7 +135,7 @@ __global__ __launch_bounds__(kT) void k_cross_bwd(const float* __restrict__ X, i
               gb[q] += g[q];
             }
             gx0[q] += g[q] * s;
-            g[q] += ldg_f32(Kw + static_cast<int64_t>(k) * W + i) * c;
+            g[q] += ldg_f32(Kw + static_cast<int64_t>(k) * W + i) * c;     // (W floats per layer: L1 / L2 resident)
           }
         }
       }
@@ -147,13 +164,35 @@ __global__ __launch_bounds__(kT) void k_cross_bwd(const float* __restrict__ X, i
   }
 }
 
+// gK*[i] = sum_g part[g][i] in workgroup order: a workgroup owns 16 outputs, thread (o, sl) adds the groups sl, sl + 16,
+// ... (eight loads in flight), the 16 slices are added in slice order.  (One thread per output walking the 256 groups
+// one dependent load at a time was the slowest piece of the layer.)
 __global__ __launch_bounds__(kT) void k_cross_reduce(const float* __restrict__ part, int64_t n, int groups,
                                                      float* __restrict__ gKw, float* __restrict__ gKb) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
-  if (i >= 2 * n) return;
+  __shared__ float red[16][17];
+  const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 16 + o;
+  const int64_t ic = i < 2 * n ? i : 0;
   float s = 0.f;
-  for (int g = 0; g < groups; ++g) s += ldg_f32(part + static_cast<int64_t>(g) * 2 * n + i);
-  if (i < n) gKw[i] = s; else gKb[i - n] = s;
+  for (int g0 = sl; g0 < groups; g0 += 16 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int g = g0 + 16 * u;
+      v[u] = ldg_f32(part + static_cast<int64_t>(g < groups ? g : 0) * 2 * n + ic);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (g0 + 16 * u < groups) s += v[u];
+  }
+  red[sl][o] = s;
+  __syncthreads();
+  if (sl == 0 && i < 2 * n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][o];
+    if (i < n) gKw[i] = t; else gKb[i - n] = t;
+  }
 }
 
 int pick_nr(int W) {
@@ -225,7 +264,7 @@ extern "C" int dctr_crossnet_vec_bwd(const float* X, int64_t ld_x, int32_t B, in
     k_cross_bwd<NR><<<dim3(groups), dim3(kT), lds, s>>>(X, ld_x, B, W, L, kernels, bias, gY, ld_g, spw, gX, ld_gx,
                                                        workspace);
   });
-  k_cross_reduce<<<dim3(static_cast<unsigned>((2 * n + kT - 1) / kT)), dim3(kT), 0, s>>>(workspace, n, groups,
+  k_cross_reduce<<<dim3(static_cast<unsigned>((2 * n + 15) / 16)), dim3(kT), 0, s>>>(workspace, n, groups,
                                                                                          g_kernels, g_bias);
   return launch_status();
 }
