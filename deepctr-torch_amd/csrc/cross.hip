@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kT) void k_cross_fwd(const float* __restrict__ X, i
   }
 }
 
-// part: [gridDim.x][2][L][W]  (gw then gb) -- per-workgroup partial parameter gradients
+// part: [gridDim.x * 4][2][L][W]  (gw then gb) -- per-WAVE partial parameter gradients
 template <int NR>
 __global__ __launch_bounds__(kT) void k_cross_bwd(const float* __restrict__ X, int64_t ldx, int B, int W, int L,
                                                   const float* __restrict__ Kw, const float* __restrict__ Kb,
@@ -70,10 +70,8 @@ __global__ __launch_bounds__(kT) void k_cross_bwd(const float* __restrict__ X, i
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* xs = smem + static_cast<size_t>(wv) * L * W;   // [L][W] inputs of every layer (this wave's sample)
   float* ss = smem + static_cast<size_t>(4) * L * W + wv * L;  // [L] the s_l
-  float* mine = part + static_cast<int64_t>(blockIdx.x) * 2 * L * W;
-  // zero this workgroup's slab, then the 4 waves add their register partials one after the other
-  for (int e = threadIdx.x; e < 2 * L * W; e += kT) mine[e] = 0.f;
-  __syncthreads();
+  // every WAVE owns one partial row of the workspace (plain stores, no read-modify-write, no barrier)
+  float* mine = part + (static_cast<int64_t>(blockIdx.x) * 4 + wv) * 2 * L * W;
   for (int l = 0; l < L; ++l) {
     float gw[NR], gb[NR];
 #pragma unroll
@@ -121,6 +119,12 @@ __global__ __launch_bounds__(kT) void k_cross_bwd(const float* __restrict__ X, i
 #pragma unroll
       for (int q = 0; q < NR; ++q) gx0[q] = 0.f;
       for (int k = L - 1; k >= l; --k) {  // reverse; layers below l do not matter for layer l's parameters
+        float kwr[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+          const int i = q * 64 + lane;
+          kwr[q] = ldg_f32(Kw + static_cast<int64_t>(k) * W + (i < W ? i : 0));
+        }
         float p = 0.f;
 #pragma unroll
         for (int q = 0; q < NR; ++q) p += x0[q] * g[q];
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(kT) void k_cross_bwd(const float* __restrict__ X, i
               gb[q] += g[q];
             }
             gx0[q] += g[q] * s;
-            g[q] += ldg_f32(Kw + static_cast<int64_t>(k) * W + i) * c;     // (W floats per layer: L1 / L2 resident)
+            g[q] += kwr[q] * c;
           }
         }
       }
@@ -147,19 +151,13 @@ __global__ __launch_bounds__(kT) void k_cross_bwd(const float* __restrict__ X, i
         }
       }
     }
-    // fixed-order accumulation of the 4 waves into the workgroup slab
-    for (int w = 0; w < 4; ++w) {
-      if (wv == w) {
 #pragma unroll
-        for (int q = 0; q < NR; ++q) {
-          const int i = q * 64 + lane;
-          if (i < W) {
-            mine[static_cast<int64_t>(l) * W + i] += gw[q];
-            mine[static_cast<int64_t>(L + l) * W + i] += gb[q];
-          }
-        }
+    for (int q = 0; q < NR; ++q) {
+      const int i = q * 64 + lane;
+      if (i < W) {
+        stg_f32(mine + static_cast<int64_t>(l) * W + i, gw[q]);
+        stg_f32(mine + static_cast<int64_t>(L + l) * W + i, gb[q]);
       }
-      __syncthreads();
     }
   }
 }
@@ -235,7 +233,7 @@ extern "C" int dctr_crossnet_vec_fwd(const float* X, int64_t ld_x, int32_t B, in
 
 extern "C" size_t dctr_crossnet_vec_bwd_workspace_floats(int32_t B, int32_t W, int32_t L) {
   int spw;
-  return static_cast<size_t>(cross_groups(B > 0 ? B : 1, &spw)) * 2u * L * W;
+  return static_cast<size_t>(cross_groups(B > 0 ? B : 1, &spw)) * 4u * 2u * L * W;   // one row per wave
 }
 
 extern "C" int dctr_crossnet_vec_bwd(const float* X, int64_t ld_x, int32_t B, int32_t W, int32_t L,
@@ -264,7 +262,7 @@ extern "C" int dctr_crossnet_vec_bwd(const float* X, int64_t ld_x, int32_t B, in
     k_cross_bwd<NR><<<dim3(groups), dim3(kT), lds, s>>>(X, ld_x, B, W, L, kernels, bias, gY, ld_g, spw, gX, ld_gx,
                                                        workspace);
   });
-  k_cross_reduce<<<dim3(static_cast<unsigned>((2 * n + 15) / 16)), dim3(kT), 0, s>>>(workspace, n, groups,
+  k_cross_reduce<<<dim3(static_cast<unsigned>((2 * n + 15) / 16)), dim3(kT), 0, s>>>(workspace, n, 4 * groups,
                                                                                          g_kernels, g_bias);
   return launch_status();
 }
