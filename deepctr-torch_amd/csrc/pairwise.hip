@@ -37,9 +37,10 @@ __device__ __forceinline__ int row_stride(int F, int D) {
 // copy the [16, F*D] tile of samples b0.. (b0 < B) into LDS (zeros past B).  Eight UNCONDITIONAL loads per thread are
 // in flight at a time (rows past B are clamped to B-1 and masked afterwards): a predicated load compiles to a
 // branch with its own s_waitcnt vmcnt(0), which made this copy 26 serial memory round trips.
+template <int ROWS = kSB>
 __device__ __forceinline__ void stage_rows(float* dst, int RS, const float* __restrict__ src, int64_t ld, int b0,
                                            int B, int W) {
-  const int n = kSB * W;
+  const int n = ROWS * W;
   for (int e0 = threadIdx.x; e0 < n; e0 += 8 * kT) {
     float v[8];
 #pragma unroll
@@ -114,10 +115,7 @@ __global__ __launch_bounds__(kT) void k_senet_fwd(const float* __restrict__ E, i
   float* a1 = z + kSS * F;      // [kSS][R]
   float* a = a1 + kSS * R;      // [kSS][F]
   const int tid = threadIdx.x, b0 = blockIdx.x * kSS;
-  for (int e = tid; e < kSS * W; e += kT) {
-    const int r = e / W, c = e - r * W;
-    es[e] = (b0 + r < B) ? ldg_f32(E + static_cast<int64_t>(b0 + r) * lde + c) : 0.f;
-  }
+  stage_rows<kSS>(es, W, E, lde, b0, B, W);
   __syncthreads();
   for (int e = tid; e < kSS * F; e += kT) {  // torch.mean(inputs, dim=-1)
     const int r = e / F, f = e - r * F;
@@ -169,12 +167,8 @@ __global__ __launch_bounds__(kT) void k_senet_bwd(const float* __restrict__ gV, 
   float* ga1 = ga + kSS * F;     // [kSS][R]  masked
   float* gz = ga1 + kSS * R;     // [kSS][F]
   const int tid = threadIdx.x, b0 = blockIdx.x * kSS;
-  for (int e = tid; e < kSS * W; e += kT) {
-    const int r = e / W, c = e - r * W;
-    const bool v = b0 + r < B;
-    es[e] = v ? ldg_f32(E + static_cast<int64_t>(b0 + r) * lde + c) : 0.f;
-    gv[e] = v ? ldg_f32(gV + static_cast<int64_t>(b0 + r) * W + c) : 0.f;
-  }
+  stage_rows<kSS>(es, W, E, lde, b0, B, W);
+  stage_rows<kSS>(gv, W, gV, W, b0, B, W);
   __syncthreads();
   for (int e = tid; e < kSS * F; e += kT) {
     const int r = e / F, f = e - r * F;
