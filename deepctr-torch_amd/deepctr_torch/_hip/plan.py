@@ -111,7 +111,8 @@ class LazyState(object):
         self.dirty = False
         self._units_dev = None
         self._key = None
-        self._reg = None
+        self._reg = None          # value for the current weights (dropped by apply())
+        self._last_reg = None     # last value computed (what big models log between two flushes)
         self.opt = L.LazyOpt()
         self.opt.kind = {"sgd": L.LAZY_SGD, "adagrad": L.LAZY_ADAGRAD, "adam": L.LAZY_ADAM}[kind]
         self.opt.lr, self.opt.eps, self.opt.beta1, self.opt.beta2 = self.hyper
@@ -213,24 +214,22 @@ class LazyState(object):
 
     def reg_value(self, device):
         """lambda * sum(w^2) over the lazily regularised tables (the term get_regularization_loss adds to the LOGGED
-        loss): exact at every call for small models, the value of the last flush otherwise."""
+        loss; its gradient is applied by the kernels).  Small models (<= EXACT_REG_ELEMS table elements): flushed and
+        summed at every call, i.e. exact at every step.  Bigger ones: the value of the last flush -- an O(vocabulary)
+        reduction per step is exactly what this mode exists to avoid."""
         if not any(v > 0 for v in self.l2.values()):
             return None
-        if self.n_elems <= self.EXACT_REG_ELEMS:
+        exact = self.n_elems <= self.EXACT_REG_ELEMS
+        if exact:
             self.flush()
-            self._reg = None
-        if self._reg is None:
-            if self.dirty and self.n_elems > self.EXACT_REG_ELEMS:
-                return self._last_reg if getattr(self, "_last_reg", None) is not None else \
-                    torch.zeros((1,), device=device)
+        if self._reg is None and (exact or not self.dirty or self._last_reg is None):
             tot = torch.zeros((1,), device=device)
             for p in self.plan.table_params:
                 lam = self.l2.get(id(p), 0.0)
                 if lam > 0:
                     tot = tot + torch.sum(lam * torch.square(p.detach()))
-            self._reg = tot
-            self._last_reg = tot
-        return self._reg
+            self._reg = self._last_reg = tot
+        return self._reg if self._reg is not None else self._last_reg
 
 
 class EmbeddingPlan(object):
