@@ -204,8 +204,8 @@ class LazyState(object):
         self._ensure(self.step.device)
         self._call(L.lib().dctr_lazy_flush, "dctr_lazy_flush", int(self.plan.max_vocab))
         self.dirty = False
-        if self.optimizer is not None and self.kind == "adam" and self.step.device.type == "cuda" and \
-                not torch.cuda.is_current_stream_capturing():
+        if self.optimizer is not None and self.kind == "adam" and not (
+                self.step.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
             t = float(int(self.step.item()))
             for p in self.plan.table_params:
                 st = self.optimizer.state.get(p)

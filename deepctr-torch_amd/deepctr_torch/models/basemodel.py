@@ -136,8 +136,8 @@ class BaseModel(nn.Module):
         if plan is not None and plan._lazy is not None:
             plan._lazy.flush()
         fused = self.__dict__.get("_fused")
-        if fused and fused.get("slab") is not None and fused["slab"].flat.device.type == "cuda" and \
-                not torch.cuda.is_current_stream_capturing():
+        if fused and fused.get("slab") is not None and not (
+                fused["slab"].flat.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
             fused["slab"].sync_optimizer_state()      # Adam's per-parameter `step` entries
 
     def state_dict(self, *args, **kwargs):

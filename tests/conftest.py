@@ -22,3 +22,18 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture()
+def mock(monkeypatch):
+    """The product's Python stack on CPU tensors over tests/mock_lib.py (a numpy stand-in for libdctr_hip.so): what
+    the host-side plumbing tests run on in this GPU-less container.  Never used by a product path."""
+    import torch
+    from deepctr_torch._hip import lib as L
+    from mock_lib import MockLib
+    m = MockLib()
+    monkeypatch.setattr(L, "lib", lambda: m)
+    monkeypatch.setattr(L, "require_gpu", lambda t, what: None)
+    monkeypatch.setattr(L, "stream_handle", lambda device=None: None)
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))
+    return m

@@ -1,5 +1,6 @@
-"""A numpy stand-in for the tower / head / dense-optimizer entry points of libdctr_hip.so, for CPU tests of the
-Python plumbing above the C-ABI (autograd Functions, DenseSlab, argument marshalling).  Test infrastructure only:
+"""A numpy stand-in for the gather / update / lazy-optimizer / tower / head / dense-optimizer entry points of
+libdctr_hip.so, for CPU tests of the Python plumbing above the C-ABI (autograd Functions, EmbeddingPlan, LazyState,
+DenseSlab, the fused train step, argument marshalling).  Test infrastructure only:
 it decodes the very ctypes arguments the product code passes and computes with the oracle's formulas."""
 import ctypes
 
@@ -17,7 +18,8 @@ def _arr(ptr, shape, ld=None, dtype=np.float32):
         return None
     if len(shape) == 1:
         n = shape[0]
-        return np.ctypeslib.as_array((ctypes.c_float * n).from_address(addr))
+        ct = ctypes.c_int32 if dtype == np.int32 else ctypes.c_float
+        return np.ctypeslib.as_array((ct * n).from_address(addr))
     rows, cols = shape
     ld = cols if ld is None else int(ld)
     flat = np.ctypeslib.as_array((ctypes.c_float * (max(rows - 1, 0) * ld + cols)).from_address(addr))
@@ -133,6 +135,229 @@ class MockLib(object):
             P -= lr * (G / (np.sqrt(S) + eps))
         else:
             P -= lr * G
+        return 0
+
+    # ---- fused gather (include/dctr.h: dctr_embed_fwd), fixed-length fields only ----------------------------
+    @staticmethod
+    def _plan(pref):
+        """dctr_plan_t -> (plan struct, deep fields, wide fields, dense cols, wide-dense cols)."""
+        from deepctr_torch._hip import lib as L
+        c = pref._obj
+        deep = [(L.Field * c.n_deep).from_address(c.deep)[i] for i in range(c.n_deep)] if c.n_deep else []
+        wide = [(L.Field * c.n_wide).from_address(c.wide)[i] for i in range(c.n_wide)] if c.n_wide else []
+        for f in deep + wide:
+            assert f.len == 1, "the numpy stand-in covers fixed-length fields"
+        dcols = list(_arr(c.dense_cols, (c.n_dense,), dtype=np.int32)) if c.n_dense else []
+        wcols = list(_arr(c.wdense_cols, (c.n_wdense,), dtype=np.int32)) if c.n_wdense else []
+        return c, deep, wide, dcols, wcols
+
+    @staticmethod
+    def _rows(X, f, err=None):
+        ids = X[:, f.col].astype(np.int64)
+        bad = (ids < 0) | (ids >= f.vocab)
+        if err is not None and bad.any():
+            err[0] = 1
+        return np.where(bad, 0, ids)
+
+    def dctr_embed_update_supported(self, pref, max_vocab, B):
+        return 1
+
+    def dctr_embed_update_workspace_ints(self, pref, n_units, B):
+        return 0
+
+    def dctr_embed_ids(self, units, n_units, X, ldx, B, ids_t, stream):
+        self.calls.append("embed_ids")
+        U = _arr(units, (n_units * 4,), dtype=np.int32).reshape(n_units, 4)
+        ncol = int(U[:, 2].max()) + 1
+        Xv = _arr(X, (B, ncol), ldx)
+        out = _arr(ids_t, (n_units * B,), dtype=np.int32).reshape(n_units, B)
+        for u in range(n_units):
+            out[u] = Xv[:, U[u, 2]].astype(np.int32)
+        return 0
+
+    def dctr_embed_fwd(self, pref, X, ldx, B, out, ld_out, wide, ld_wide, fm, err, units, n_units, ids_t, fm_s, ld_s,
+                       stream):
+        self.calls.append("embed_fwd")
+        c, deep, widef, dcols, wcols = self._plan(pref)
+        Xv = _arr(X, (B, c.n_xcols), ldx)
+        errv = _arr(err, (1,), dtype=np.int32)
+        S = np.zeros((B, max(c.emb_dim, 1)), np.float32)
+        Q = np.zeros_like(S)
+        if out is not None and _arr(out, (1,)) is not None:
+            O = _arr(out, (B, ld_out), ld_out)
+            O[...] = 0
+            for f in deep:
+                e = _arr(f.table, (f.vocab, f.dim))[self._rows(Xv, f, errv)]
+                O[:, f.out_off:f.out_off + f.dim] = e
+                if c.emb_dim > 0:
+                    S += e
+                    Q += e * e
+            for j, col in enumerate(dcols):
+                O[:, c.dense_off + j] = Xv[:, col]
+        if _arr(wide, (1,)) is not None:
+            w = np.zeros(B, np.float32)
+            for f in widef:
+                w += _arr(f.table, (f.vocab, 1))[self._rows(Xv, f, errv), 0]
+            if wcols:
+                ww = _arr(c.wdense_w, (len(wcols),))
+                for j, col in enumerate(wcols):
+                    w += Xv[:, col] * ww[j]
+            _arr(wide, ((B - 1) * ld_wide + 1,))[::ld_wide] = w
+        if _arr(fm, (1,)) is not None:
+            _arr(fm, (B,))[...] = 0.5 * np.sum(S * S - Q, axis=1)
+        if _arr(fm_s, (1,)) is not None:
+            Sv = _arr(fm_s, (B, ld_s), ld_s)
+            Sv[...] = 0
+            Sv[:, :c.emb_dim] = S[:, :c.emb_dim]
+        if _arr(ids_t, (1,)) is not None:
+            self.dctr_embed_ids(units, n_units, X, ldx, B, ids_t, stream)
+            self.calls.pop()
+        return 0
+
+    # ---- deterministic fused backward + optimizer (dctr_embed_update) ---------------------------------------
+    def dctr_embed_update(self, pref, units, n_units, max_vocab, ids_t, B, g_out, ld_g, out, ld_out, fm_s, ld_s, g_fm,
+                          g_wide, ld_gw, opt, lr, eps, X, ld_x, g_wdense, ws, ws_n, stream):
+        self.calls.append("embed_update:%d" % opt)
+        c, deep, widef, dcols, wcols = self._plan(pref)
+        U = _arr(units, (n_units * 4,), dtype=np.int32).reshape(n_units, 4)
+        ids = _arr(ids_t, (n_units * B,), dtype=np.int32).reshape(n_units, B)
+        gO = _arr(g_out, (B, ld_g), ld_g) if ld_g else None
+        gF = _arr(g_fm, (B,))
+        gW = _arr(g_wide, ((B - 1) * ld_gw + 1,))[::ld_gw] if _arr(g_wide, (1,)) is not None else None
+
+        def scatter(f, rows, G):
+            """sum duplicates in sample order, then one read-modify-write per touched row."""
+            table = _arr(f.table, (f.vocab, f.dim))
+            uniq, inv = np.unique(rows, return_inverse=True)
+            acc = np.zeros((len(uniq), f.dim), np.float32)
+            for b in range(B):
+                acc[inv[b]] += G[b]
+            if opt == 0:
+                table[uniq] -= np.float32(lr) * acc
+            elif opt == 1:
+                st = _arr(f.state, (f.vocab, f.dim))
+                st[uniq] += acc * acc
+                table[uniq] -= np.float32(lr) * (acc / (np.sqrt(st[uniq]) + np.float32(eps)))
+            else:
+                _arr(f.gacc, (f.vocab, f.dim))[uniq] += acc
+
+        for u in range(n_units):
+            di, wi = int(U[u, 0]), int(U[u, 1])
+            if di >= 0:
+                f = deep[di]
+                rows = np.where((ids[u] < 0) | (ids[u] >= f.vocab), 0, ids[u]).astype(np.int64)
+                G = np.zeros((B, f.dim), np.float32)
+                if gO is not None:
+                    G += gO[:, f.out_off:f.out_off + f.dim]
+                if gF is not None:
+                    e = _arr(out, (B, ld_out), ld_out)[:, f.out_off:f.out_off + f.dim]
+                    G += gF[:, None] * (_arr(fm_s, (B, ld_s), ld_s)[:, :f.dim] - e)
+                scatter(f, rows, G)
+            if wi >= 0 and gW is not None:
+                f = widef[wi]
+                rows = np.where((ids[u] < 0) | (ids[u] >= f.vocab), 0, ids[u]).astype(np.int64)
+                scatter(f, rows, gW.reshape(B, 1).astype(np.float32))
+        if _arr(g_wdense, (1,)) is not None and gW is not None and wcols:
+            Xv = _arr(X, (B, c.n_xcols), ld_x)
+            _arr(g_wdense, (len(wcols),))[...] = [np.dot(gW.astype(np.float64), Xv[:, col]) for col in wcols]
+        return 0
+
+    # ---- exact lazy regularised / Adam update (csrc/lazy.hip) -------------------------------------------------
+    @staticmethod
+    def _adam_scalars(o, T):
+        return (np.float32(float(o.lr) / (1.0 - float(o.beta1) ** T)), np.float32(np.sqrt(1.0 - float(o.beta2) ** T)))
+
+    @staticmethod
+    def _opt_step(o, g, w, a, b, ss, bc):
+        """torch.optim's single-tensor step in fp32 on arrays (in place); a / b may be None."""
+        f = np.float32
+        if o.kind == 2:
+            a += (g - a) * (f(1) - f(o.beta1))
+            b *= f(o.beta2)
+            b += (f(1) - f(o.beta2)) * g * g
+            w -= ss * (a / (np.sqrt(b) / bc + f(o.eps)))
+        elif o.kind == 1:
+            a += g * g
+            w -= f(o.lr) * (g / (np.sqrt(a) + f(o.eps)))
+        else:
+            w -= f(o.lr) * g
+
+    def _lazy_pass(self, mode, units, n_units, ids_t, n, step, optref):
+        from deepctr_torch._hip import lib as L
+        o = optref._obj
+        t = int(_arr(step, (1,), dtype=np.int32)[0])
+        target = t + 1 if mode == 1 else t
+        arr = (L.LazyUnit * n_units).from_address(units.value)
+        ids = _arr(ids_t, (n_units * n,), dtype=np.int32).reshape(n_units, n) if mode != 2 else None
+        for u in range(n_units):
+            un = arr[u]
+            stamp = _arr(un.stamp, (un.vocab,), dtype=np.int32)
+            if mode == 2:
+                rows = np.arange(min(n, un.vocab))
+            else:
+                rows = np.unique(np.where((ids[u] < 0) | (ids[u] >= un.vocab), 0, ids[u]).astype(np.int64))
+            rows = rows[stamp[rows] < target]
+            if not len(rows):
+                continue
+            prev = stamp[rows].copy()
+            stamp[rows] = target
+            for tab, s1, s2, gp, dim, lam in ((un.deep, un.deep_s1, un.deep_s2, un.deep_g, un.dim, un.l2_deep),
+                                              (un.wide, un.wide_s1, un.wide_s2, un.wide_g, 1, un.l2_wide)):
+                if not tab:
+                    continue
+                W = _arr(tab, (un.vocab, dim))
+                A = _arr(s1, (un.vocab, dim)) if s1 else None
+                Bv = _arr(s2, (un.vocab, dim)) if s2 else None
+                lam2 = np.float32(2) * np.float32(lam)
+                w = W[rows].copy()
+                a = A[rows].copy() if A is not None else np.zeros_like(w)
+                b = Bv[rows].copy() if Bv is not None else np.zeros_like(w)
+                if o.kind == 2 or lam2 != 0:                    # replay the missed steps prev+1 .. t with g = 2*lambda*w
+                    for T in range(int(prev.min()) + 1, t + 1):
+                        m = prev < T
+                        ss, bc = self._adam_scalars(o, T) if o.kind == 2 else (0, 1)
+                        wm, am, bm = w[m], a[m], b[m]
+                        self._opt_step(o, lam2 * wm, wm, am, bm, ss, bc)
+                        w[m], a[m], b[m] = wm, am, bm
+                if mode == 1:
+                    Gv = _arr(gp, (un.vocab, dim))
+                    g = Gv[rows] + lam2 * w
+                    Gv[rows] = 0
+                    ss, bc = self._adam_scalars(o, t + 1) if o.kind == 2 else (0, 1)
+                    self._opt_step(o, g, w, a, b, ss, bc)
+                W[rows] = w
+                if A is not None:
+                    A[rows] = a
+                if Bv is not None:
+                    Bv[rows] = b
+        return 0
+
+    def dctr_lazy_catchup(self, units, n_units, ids_t, B, step, opt, vec, max_dim, stream):
+        self.calls.append("lazy_catchup")
+        return self._lazy_pass(0, units, n_units, ids_t, B, step, opt)
+
+    def dctr_lazy_apply(self, units, n_units, ids_t, B, step, opt, vec, max_dim, stream):
+        self.calls.append("lazy_apply")
+        return self._lazy_pass(1, units, n_units, ids_t, B, step, opt)
+
+    def dctr_lazy_flush(self, units, n_units, max_vocab, step, opt, vec, max_dim, stream):
+        self.calls.append("lazy_flush")
+        return self._lazy_pass(2, units, n_units, None, max_vocab, step, opt)
+
+    def dctr_lazy_step_inc(self, step, stream):
+        _arr(step, (1,), dtype=np.int32)[0] += 1
+        return 0
+
+    def dctr_dense_opt_reg(self, p, g, s1, s2, lam, n, optref, step, stream):
+        self.calls.append("dense_opt_reg")
+        o = optref._obj
+        T = int(_arr(step, (1,), dtype=np.int32)[0]) + 1
+        P, G = _arr(p, (n,)), _arr(g, (n,))
+        A = _arr(s1, (n,)) if _arr(s1, (1,)) is not None else np.zeros(n, np.float32)
+        Bv = _arr(s2, (n,)) if _arr(s2, (1,)) is not None else np.zeros(n, np.float32)
+        gt = G + (np.float32(2) * _arr(lam, (n,)) * P if _arr(lam, (1,)) is not None else np.float32(0))
+        ss, bc = self._adam_scalars(o, T) if o.kind == 2 else (0, 1)
+        self._opt_step(o, gt, P, A, Bv, ss, bc)
         return 0
 
     def dctr_strerror(self, code):

@@ -1,0 +1,88 @@
+"""CPU: the whole Python stack of a train step (EmbeddingPlan, EmbedFunction, LazyState, DenseSlab, the fused step of
+BaseModel) over the numpy stand-in for the library (tests/mock_lib.py), replaying the REAL reference's 8-step
+trajectories of tests/golden/lazy_*.npz (oracle/make_golden.py): L2 on every table under SGD / Adagrad / Adam, and
+Adam without L2.  What this pins without a GPU: the call protocol (ids -> catch-up -> gather -> update(ACCUM) -> apply ->
+step_inc, flush before any other reader), the ctypes marshalling of dctr_plan_t / dctr_lazy_unit_t, the lambda / state
+wiring per table, and the logged loss.  The kernels' own arithmetic is covered by tests/test_gpu_lazy.py."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_model, load_golden, max_abs
+
+DEV = "cpu"
+TAGS = ("sgd", "adagrad", "adam", "adam0")
+
+
+def _close(tag, got, ref, tol=5e-5):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    scale = max(1.0, float(np.max(np.abs(ref))) if ref.size else 1.0)
+    err = max_abs(got, ref)
+    assert err <= tol * scale, "%s: max|d| = %.3e (scale %.3e)" % (tag, err, scale)
+
+
+def _run(name, tag, predict_at=()):
+    g = load_golden(name)
+    ex = g["extra"]
+    m = build_model(g["spec"], DEV, l2=0.0 if tag == "adam0" else 1e-3)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in g["params"].items()})
+    m.compile("adam" if tag == "adam0" else tag, "binary_crossentropy", metrics=[])
+    m.train()
+    assert m.model_plan().update == ("lazy", "adam" if tag == "adam0" else tag)
+    bce, tot = [], []
+    for i in range(len(ex["lazy_X"])):
+        m.train()
+        loss, total, _ = m._train_step(torch.from_numpy(ex["lazy_X"][i]), torch.from_numpy(ex["lazy_y"][i]))
+        bce.append(float(loss))
+        tot.append(float(total))
+        if i in predict_at:
+            m.eval()
+            with torch.no_grad():
+                m(torch.from_numpy(ex["lazy_X"][0]))
+    return g, m, bce, tot
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_lazy_stack_replays_reference_trajectory(mock, tag):
+    g, m, bce, tot = _run("lazy_deepfm", tag)
+    ex = g["extra"]
+    # one fused step = ids, catch-up, gather, tower step, accumulate, apply, dense optimizer -- in this order
+    first = mock.calls[:mock.calls.index("dense_opt_reg") + 1]
+    assert first == ["embed_ids", "lazy_catchup", "embed_fwd", "mlp_train_step", "embed_update:2", "lazy_apply",
+                     "dense_opt_reg"], first
+    np.testing.assert_allclose(bce, ex["lazy_%s_bce" % tag], rtol=5e-5)
+    np.testing.assert_allclose(tot, ex["lazy_%s_total" % tag], rtol=5e-5)
+    n_flush = mock.calls.count("lazy_flush")
+    sd = m.state_dict()                                   # must flush: every row replayed to the current step
+    assert mock.calls.count("lazy_flush") == n_flush + 1
+    for k, v in ex.items():
+        if k.startswith("lazy_%s/" % tag):
+            _close(k, sd[k[len("lazy_%s/" % tag):]].numpy(), v)
+    m.eval()
+    with torch.no_grad():
+        pred = m(torch.from_numpy(ex["lazy_X"][0]))
+    _close("pred", pred.numpy().reshape(-1, 1), ex["lazy_%s_pred" % tag])
+    p0 = m.embedding_dict[g["spec"]["dnn_columns"][0]["embedding_name"]].weight
+    st = m.optim.state[p0]
+    for key in ("sum", "exp_avg", "exp_avg_sq"):
+        ref = ex.get("lazy_%s_state_%s" % (tag, key))
+        if ref is not None:
+            _close("state." + key, st[key].numpy(), ref)
+    if tag.startswith("adam"):
+        assert float(st["step"]) == len(ex["lazy_X"])
+
+
+def test_flush_between_steps_keeps_the_trajectory(mock):
+    g, m, _, _ = _run("lazy_deepfm", "adam", predict_at=(2, 5))
+    sd = m.state_dict()
+    for k, v in g["extra"].items():
+        if k.startswith("lazy_adam/"):
+            _close(k, sd[k[len("lazy_adam/"):]].numpy(), v)
+
+
+def test_lazy_off_switch_takes_the_dense_path(mock, monkeypatch):
+    monkeypatch.setenv("DCTR_LAZY_UPDATE", "0")
+    g = load_golden("lazy_deepfm")
+    m = build_model(g["spec"], DEV, l2=1e-3)
+    m.compile("adagrad", "binary_crossentropy", metrics=[])
+    assert m.model_plan().update == ("dense",)

@@ -7,18 +7,6 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from mock_lib import MockLib
-
-
-@pytest.fixture()
-def mock(monkeypatch):
-    from deepctr_torch._hip import lib as L
-    m = MockLib()
-    monkeypatch.setattr(L, "lib", lambda: m)
-    monkeypatch.setattr(L, "require_gpu", lambda t, what: None)
-    monkeypatch.setattr(L, "stream_handle", lambda device=None: None)
-    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))
-    return m
 
 
 def _modules(K, hidden, act="relu"):

@@ -1,0 +1,65 @@
+"""CPU: DeepFM / WDL through the real Python stack over the numpy stand-in for the library (tests/mock_lib.py), against
+the reference's golden forward values, per-parameter gradients and 3-step SGD / Adagrad trajectories
+(tests/golden/*.npz).  Pins, without a GPU, what sits between the reference-shaped API and the C-ABI: the plan's field /
+unit tables, buffer strides, the choice of update mode, the dense-gradient route (param.grad) and the in-kernel
+optimizer route.  Fixed-length fields only (the stand-in's scope); the kernels are checked by tests/test_gpu_*.py."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_model, load_golden, max_abs
+
+DEV = "cpu"
+NAMES = ["deepfm_criteo", "deepfm_dense_only", "deepfm_fm_only", "wdl_criteo"]
+
+
+def _loaded(name):
+    g = load_golden(name)
+    m = build_model(g["spec"], DEV)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in g["params"].items()})
+    return g, m
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_forward_matches_reference(mock, name):
+    g, m = _loaded(name)
+    m.eval()
+    with torch.no_grad():
+        y = m(torch.from_numpy(g["X"]))
+    assert max_abs(y.numpy(), g["y_pred"]) <= 2e-5
+    m.model_plan().check_ids()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_dense_gradients_match_reference(mock, name):
+    g, m = _loaded(name)
+    m.train()
+    loss = torch.nn.functional.binary_cross_entropy(m(torch.from_numpy(g["X"])).squeeze(), torch.from_numpy(g["y"]),
+                                                    reduction="sum")
+    m.zero_grad()
+    loss.backward()
+    assert abs(loss.item() - g["loss"]) <= 1e-4 * max(1.0, abs(g["loss"]))
+    for k, p in m.named_parameters():
+        ref = g["grads"][k]
+        got = p.grad.numpy() if p.grad is not None else np.zeros_like(ref)
+        assert max_abs(got, ref) <= 2e-5 * max(1.0, float(np.max(np.abs(ref)))), k
+
+
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
+def test_in_kernel_optimizer_trajectory(mock, name, opt):
+    g, m = _loaded(name)
+    if (opt + "3_loss") not in g["extra"]:
+        pytest.skip("no %s trajectory in this fixture" % opt)
+    m.compile(opt, "binary_crossentropy", metrics=[])
+    m.train()
+    losses = [float(m._train_step(torch.from_numpy(Xb), torch.from_numpy(yb))[0])
+              for Xb, yb in zip(g["extra"]["X_steps"], g["extra"]["y_steps"])]
+    if m.model_plan().table_params:
+        assert m.model_plan().update[0] == opt
+        assert "embed_update:%d" % (0 if opt == "sgd" else 1) in mock.calls
+    np.testing.assert_allclose(losses, g["extra"][opt + "3_loss"], rtol=5e-5)
+    sd = m.state_dict()
+    for k, v in g["extra"].items():
+        if k.startswith(opt + "3/"):
+            assert max_abs(sd[k[len(opt) + 2:]].numpy(), v) <= 1e-4, k
