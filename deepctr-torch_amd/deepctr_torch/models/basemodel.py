@@ -763,8 +763,11 @@ class BaseModel(nn.Module):
             cbs.on_epoch_begin(epoch)
             epoch_logs = {}
             start_time = time.time()
+            # The reference iterates a DataLoader (:213,240): each epoch its iterator first draws a base seed from the
+            # default CPU generator, then (shuffle=True) RandomSampler draws the seed of its permutation.  The same two
+            # draws here: after torch.manual_seed(s) both implementations visit the rows in the same order.
+            torch.empty((), dtype=torch.int64).random_()
             if shuffle:
-                # the permutation torch's RandomSampler would draw (DataLoader(shuffle=True), reference :213)
                 seed = int(torch.empty((), dtype=torch.int64).random_().item())
                 gen = torch.Generator()
                 gen.manual_seed(seed)
@@ -831,6 +834,7 @@ class BaseModel(nn.Module):
         """float64 ``[N, 1]`` predictions, input order preserved (reference basemodel.py:325-352)."""
         self.eval()  # like the reference (:331), predict leaves the model in eval mode
         X_all = self._as_matrix(x)
+        torch.empty((), dtype=torch.int64).random_()     # the base seed the reference's DataLoader iterator draws (:340)
         chunks = []
         with torch.no_grad():
             for lo in range(0, X_all.shape[0], batch_size):

@@ -122,8 +122,8 @@ def mixed_columns(dim=4):
 CASES = []
 
 
-def case(name, model, lin, dnn, batch=64, seed=0, steps=False, lazy=False, **kwargs):
-    CASES.append({"name": name, "batch": batch, "seed": seed, "steps": steps, "lazy": lazy,
+def case(name, model, lin, dnn, batch=64, seed=0, steps=False, lazy=False, fit=False, **kwargs):
+    CASES.append({"name": name, "batch": batch, "seed": seed, "steps": steps, "lazy": lazy, "fit": fit,
                   "spec": {"model": model, "linear_columns": lin, "dnn_columns": dnn, "kwargs": kwargs}})
 
 
@@ -192,6 +192,16 @@ case("lazy_deepfm", "DeepFM", _l, _l, batch=24, lazy=True, dnn_hidden_units=(16,
 _ld = criteo_columns(6, 2, 16, 8)
 case("lazy_dcn", "DCN", _ld, _ld, batch=24, lazy=True, dnn_hidden_units=(16,), cross_num=2)
 LAZY_STEPS, LAZY_L2 = 8, 1e-3
+
+# model.fit() itself (basemodel.py:137-309): History contents and predict() after 3 epochs over 300 rows, batch 64 with
+# a 25 % validation split (225 train rows -> batches 64, 64, 64, 33), metrics binary_crossentropy + auc.  Three runs:
+#   plain     l2 = 0, adagrad, shuffle=False
+#   shuffled  l2 = 0, adagrad, shuffle=True after torch.manual_seed(FIT_SEED): the DataLoader's permutations
+#   default   the reference's default kwargs (l2 = 1e-5 on tables and Linear) with adam, shuffle=True, same seed
+_ft = criteo_columns(8, 3, 20, 8)
+case("fit_deepfm", "DeepFM", _ft, _ft, batch=64, fit=True, dnn_hidden_units=(16, 8))
+FIT_ROWS, FIT_EPOCHS, FIT_SPLIT, FIT_SEED = 300, 3, 0.25, 777
+FIT_RUNS = (("plain", "adagrad", 0.0, False), ("shuffled", "adagrad", 0.0, True), ("default", "adam", 1e-5, True))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -357,6 +367,23 @@ def run_case(ref, case_):
             for key in ("sum", "exp_avg", "exp_avg_sq"):
                 if key in st:
                     out["lazy_%s_state_%s" % (tag, key)] = st[key].detach().numpy().copy()
+    if case_.get("fit"):
+        Xf, yf = synth_inputs(spec, FIT_ROWS, rng)
+        out["fit_X"], out["fit_y"] = Xf, yf
+        names_ = [c["name"] for c in spec["dnn_columns"]]
+        xin = {n: Xf[:, i] for i, n in enumerate(names_)}          # one column per feature (no VarLen here)
+        start = {k: v.clone() for k, v in model.state_dict().items()}
+        for tag, opt_name, l2, shuffle in FIT_RUNS:
+            torch.manual_seed(case_["seed"])
+            m = build_reference_model(ref, spec, l2=l2)
+            m.load_state_dict(start)
+            m.compile(opt_name, "binary_crossentropy", metrics=["binary_crossentropy", "auc"])
+            torch.manual_seed(FIT_SEED)
+            hist = m.fit(xin, yf, batch_size=batch, epochs=FIT_EPOCHS, verbose=2, validation_split=FIT_SPLIT,
+                         shuffle=shuffle)
+            for k, v in hist.history.items():
+                out["fit_%s_hist/%s" % (tag, k)] = np.asarray(v, np.float64)
+            out["fit_%s_pred" % tag] = m.predict(xin, batch_size=50)
     return out
 
 

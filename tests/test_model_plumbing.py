@@ -63,3 +63,29 @@ def test_in_kernel_optimizer_trajectory(mock, name, opt):
     for k, v in g["extra"].items():
         if k.startswith(opt + "3/"):
             assert max_abs(sd[k[len(opt) + 2:]].numpy(), v) <= 1e-4, k
+
+
+FIT_RUNS = (("plain", "adagrad", 0.0, False), ("shuffled", "adagrad", 0.0, True), ("default", "adam", 1e-5, True))
+
+
+@pytest.mark.parametrize("tag,opt,l2,shuffle", FIT_RUNS)
+def test_fit_history_and_predict_match_reference(mock, monkeypatch, tag, opt, l2, shuffle):
+    """model.fit() of the REAL reference (tests/golden/fit_deepfm.npz: 3 epochs, batch 64 with a ragged last batch,
+    validation split, per-batch metrics averaged over steps) -- same History, same predictions; with shuffle=True the
+    same permutations as the reference's DataLoader draws after torch.manual_seed."""
+    monkeypatch.setenv("DCTR_FIT_GRAPH", "0")           # no hipGraphs on CPU tensors
+    g = load_golden("fit_deepfm")
+    ex = g["extra"]
+    m = build_model(g["spec"], DEV, l2=l2)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in g["params"].items()})
+    m.compile(opt, "binary_crossentropy", metrics=["binary_crossentropy", "auc"])
+    x = {c["name"]: ex["fit_X"][:, i] for i, c in enumerate(g["spec"]["dnn_columns"])}
+    torch.manual_seed(777)
+    hist = m.fit(x, ex["fit_y"], batch_size=64, epochs=3, verbose=2, validation_split=0.25, shuffle=shuffle)
+    ref = {k[len("fit_%s_hist/" % tag):]: v for k, v in ex.items() if k.startswith("fit_%s_hist/" % tag)}
+    assert set(hist.history) == set(ref)
+    for k, v in ref.items():
+        np.testing.assert_allclose(hist.history[k], v, rtol=2e-4, err_msg=k)
+    pred = m.predict(x, batch_size=50)
+    assert pred.dtype == np.float64 and pred.shape == ex["fit_%s_pred" % tag].shape
+    assert max_abs(pred, ex["fit_%s_pred" % tag]) <= 5e-5
