@@ -1,0 +1,95 @@
+"""Pin the numpy oracle on the reference's OWN test matrix (tests/models/*_test.py parameter lists as restated in
+tests/test_gpu_reference_matrix.py): for every configuration, build the REAL reference model on torch-CPU, take its
+freshly initialised state_dict, run its eval-mode forward on the same generated inputs and compare with
+``np_oracle.Oracle.forward`` (fp64).  Runs only in the build container (needs /root/reference).  The reference's
+parameters and predictions are stored in ``tests/golden/matrix/reference_matrix.npz`` (with the configurations as json):
+the CPU tests re-check the oracle against them and compare ``state_dict`` keys / shapes, the GPU tests load the
+parameters into the drop-in models and compare the HIP forward with the reference's predictions.
+
+    python oracle/check_matrix.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (HERE, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def configs():
+    """(model, seed, n_sparse, n_dense, kwargs, with_linear, include_length) per case of the matrix."""
+    out = []
+    for use_fm, hidden, ns, nd in [(True, (32,), 3, 3), (False, (32,), 3, 3), (False, (32,), 2, 2), (False, (32,), 1, 1),
+                                   (True, (), 1, 1), (False, (), 2, 2), (True, (32,), 0, 3), (True, (32,), 3, 0),
+                                   (False, (32,), 0, 3), (False, (32,), 3, 0)]:
+        for lin in (True, False):
+            out.append(("DeepFM", 1, ns, nd, dict(use_fm=use_fm, dnn_hidden_units=hidden), lin, False))
+    out.append(("DeepFM", 2, 2, 2, dict(dnn_hidden_units=(32,)), True, True))
+    for hidden, cin, sh, act, ns in [((), (), True, "linear", 1), ((8,), (), True, "linear", 1),
+                                     ((), (8,), True, "linear", 2), ((8,), (8,), False, "relu", 2)]:
+        out.append(("xDeepFM", 3, ns, ns, dict(dnn_hidden_units=hidden, cin_layer_size=cin, cin_split_half=sh,
+                                               cin_activation=act), True, False))
+    for bt in ("each", "interaction", "all"):
+        out.append(("FiBiNET", 4, 3, 3, dict(bilinear_type=bt, dnn_hidden_units=[8, 8]), True, False))
+    for cn, param in [(2, "vector"), (1, "matrix")]:
+        out.append(("DCN", 5, 2, 2, dict(cross_num=cn, cross_parameterization=param, dnn_hidden_units=(32,)), True, False))
+    out.append(("DCNMix", 6, 2, 2, dict(cross_num=1, dnn_hidden_units=(32,)), True, False))
+    for ui, uo, kt, ns in [(True, True, "mat", 2), (True, False, "mat", 2), (False, True, "vec", 3),
+                           (False, True, "num", 3), (False, False, "mat", 1)]:
+        out.append(("PNN", 7, ns, ns, dict(dnn_hidden_units=[32, 32], use_inner=ui, use_outter=uo, kernel_type=kt),
+                    False, False))
+    for ns in (2, 1):
+        out.append(("NFM", 8, ns, ns, dict(dnn_hidden_units=[32, 32]), True, False))
+    out.append(("AFM", 9, 3, 0, dict(use_attention=True), True, False))
+    for al, hidden, ns in [(1, (4,), 2), (2, (4, 4), 2), (1, (), 1), (1, (4,), 1)]:
+        out.append(("AutoInt", 10, ns, ns, dict(att_layer_num=al, dnn_hidden_units=hidden), True, False))
+    return out
+
+
+def main():
+    import torch
+    import make_golden as mg
+    from np_oracle import Oracle
+    sys.path.insert(0, os.path.join(ROOT, "deepctr-torch_amd"))
+    import test_gpu_reference_matrix as tm          # the generator + spec_of the GPU tests use
+    ref = mg.import_reference()
+    worst = 0.0
+    store, meta = {}, []
+    for model, seed, ns, nd, kw, with_lin, inc_len in configs():
+        # (length_name + 'max' crashes in the reference itself on torch >= 1.2: sequence.py:66 subtracts a bool mask)
+        x, y, cols = tm.make_data(seed, ns, nd, include_length=inc_len, seqs=("sum", "mean") if inc_len else
+                                  ("sum", "mean", "max"))
+        spec = tm.spec_of(model, cols if with_lin else [], cols, **kw)
+        torch.manual_seed(0)
+        m = mg.build_reference_model(ref, spec, l2=1e-5)
+        m.eval()
+        X = np.concatenate([np.asarray(x[name], np.float32).reshape(tm.N, -1) for name in m.feature_index], axis=1)
+        with torch.no_grad():
+            want = m(torch.from_numpy(X)).numpy()
+        params = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+        _, got = Oracle(spec, params, dtype=np.float64).forward(X)
+        ok = tm.clean_rows(x, cols)          # rows with an all-padding 'max' field are ~1e9 noise in the reference itself
+        err = float(np.max(np.abs(np.asarray(got).reshape(-1)[ok] - want.reshape(-1)[ok]))) if ok.any() else 0.0
+        worst = max(worst, err)
+        print("%-8s lin=%d %-90s max|d| = %.2e (%d rows)" % (model, with_lin, kw, err, int(ok.sum())))
+        assert err <= 2e-6, (model, kw, err)
+        i = len(meta)
+        meta.append({"model": model, "seed": seed, "n_sparse": ns, "n_dense": nd, "kwargs": kw, "with_linear": with_lin,
+                     "include_length": inc_len, "spec": spec})
+        store["%d/X" % i], store["%d/y_pred" % i], store["%d/clean" % i] = X, want.reshape(-1, 1), ok
+        for k, v in params.items():
+            store["%d/param/%s" % (i, k)] = v
+    out = os.path.join(ROOT, "tests", "golden", "matrix")
+    os.makedirs(out, exist_ok=True)
+    store["configs"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(out, "reference_matrix.npz"), **store)
+    print("oracle == reference on %d configurations of the reference's test matrix (worst %.2e)" % (len(configs()), worst))
+
+
+if __name__ == "__main__":
+    main()

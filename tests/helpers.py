@@ -71,3 +71,20 @@ def load_params(model, params):
 def max_abs(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.max(np.abs(a.reshape(-1) - b.reshape(-1)))) if a.size else 0.0
+
+
+def load_matrix():
+    """tests/golden/matrix/reference_matrix.npz (oracle/check_matrix.py): the reference's freshly initialised parameters
+    and eval-mode predictions on every configuration of its own model tests.  -> list of dicts."""
+    z = np.load(os.path.join(GOLDEN_DIR, "matrix", "reference_matrix.npz"), allow_pickle=False)
+    out = []
+    for i, meta in enumerate(json.loads(str(z["configs"]))):
+        pre = "%d/param/" % i
+        out.append(dict(meta, X=z["%d/X" % i], y_pred=z["%d/y_pred" % i], clean=z["%d/clean" % i],
+                        params={k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}))
+    return out
+
+
+def matrix_id(c):
+    kw = ",".join("%s=%s" % (k, str(v).replace(" ", "")) for k, v in sorted(c["kwargs"].items()))
+    return "%s-%ds%dd-%s%s" % (c["model"], c["n_sparse"], c["n_dense"], kw, "" if c["with_linear"] else "-nolinear")

@@ -1,0 +1,258 @@
+"""GPU: the reference's OWN model tests, restated (tests/models/{DeepFM,xDeepFM,FiBiNET,DCN,DCNMix,PNN,NFM,AFM,AutoInt,
+WDL}_test.py with tests/utils.py:19-66 ``get_test_data`` and :142-171 ``check_model``) -- same parameter matrices, same
+kind of data (1-9 row vocabularies, so vocabulary 1 and id 0 occur; sum / mean / max VarLen columns of random maxlen
+with 0 as padding id; 64 samples), same protocol: compile('adam', 'binary_crossentropy', ['binary_crossentropy',
+'acc']), one epoch of fit with batch 100 > sample count, validation_split 0.5, EarlyStopping + ModelCheckpoint on
+'val_acc', state_dict save / load, whole-model torch.save / torch.load.
+
+The reference's tests assert nothing numeric; here every case ALSO checks the eval-mode forward against the
+numpy oracle on the model's own initial parameters (2e-5), wherever the oracle states the configuration (not PReLU
+towers), and that History / predict have the reference's shape."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import max_abs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+N = 64
+
+
+def make_data(seed, n_sparse, n_dense, emb=4, seqs=("sum", "mean", "max"), include_length=False, min_clean=16):
+    """The reference's generator restated; re-drawn (seed + 1000, ...) until at least ``min_clean`` rows have a well
+    defined forward value (see ``clean_rows``), so that every configuration gets a numeric check."""
+    while True:
+        x, y, cols = _draw(seed, n_sparse, n_dense, emb, seqs, include_length)
+        if int(clean_rows(x, cols).sum()) >= min_clean:
+            return x, y, cols
+        seed += 1000
+
+
+def _draw(seed, n_sparse, n_dense, emb, seqs, include_length):
+    from deepctr_torch.inputs import DenseFeat, SparseFeat, VarLenSparseFeat
+    rng = np.random.default_rng(seed)
+    cols, x = [], {}
+    for i in range(n_sparse):
+        cols.append(SparseFeat("sparse_feature_%d" % i, int(rng.integers(1, 10)), emb, dtype=torch.int32))
+    for i in range(n_dense):
+        cols.append(DenseFeat("dense_feature_%d" % i, 1, dtype=torch.float32))
+    for mode in seqs:
+        ln = "sequence_%s_seq_length" % mode if include_length else None
+        cols.append(VarLenSparseFeat(SparseFeat("sequence_" + mode, vocabulary_size=int(rng.integers(1, 10)),
+                                                embedding_dim=emb), maxlen=int(rng.integers(1, 10)), combiner=mode,
+                                     length_name=ln))
+    for fc in cols:
+        if isinstance(fc, VarLenSparseFeat):
+            x[fc.name] = rng.integers(0, fc.vocabulary_size, (N, fc.maxlen))
+            if fc.length_name:
+                x[fc.length_name] = rng.integers(1, fc.maxlen + 1, N)
+        elif isinstance(fc, SparseFeat):
+            x[fc.name] = rng.integers(0, fc.vocabulary_size, N)
+        else:
+            x[fc.name] = rng.random(N)
+    return x, rng.integers(0, 2, N), cols
+
+
+def clean_rows(x, cols):
+    """Rows whose forward value is well defined.  A 'max' VarLen field whose ids are ALL the padding id 0 pools to
+    ``embedding - 1e9`` in the reference (sequence.py:65-68 subtracts 1e9 from masked positions and takes the max): the
+    logit is then ~1e9 (FM: ~1e18) and its low digits are fp32 rounding noise in the reference itself.  The generator
+    of the reference's tests produces such rows (vocabulary 1, or short sequences of zeros); they must run -- and do,
+    through fit / predict below -- but a numeric comparison is only meaningful on the others."""
+    ok = np.ones(N, bool)
+    for c in cols:
+        if getattr(c, "combiner", None) == "max" and not c.length_name:
+            ok &= (np.asarray(x[c.name]) != 0).any(axis=1)
+    return ok
+
+
+def spec_of(model_name, lin, dnn, **kwargs):
+    def one(c):
+        if hasattr(c, "dimension"):
+            return {"kind": "dense", "name": c.name, "dimension": c.dimension}
+        d = {"kind": "sparse", "name": c.name, "vocab": c.vocabulary_size, "dim": c.embedding_dim,
+             "embedding_name": c.embedding_name}
+        if hasattr(c, "maxlen"):
+            d.update(kind="varlen", maxlen=c.maxlen, combiner=c.combiner, length_name=c.length_name)
+        return d
+    return {"model": model_name, "linear_columns": [one(c) for c in lin], "dnn_columns": [one(c) for c in dnn],
+            "kwargs": kwargs}
+
+
+def check_model(model, x, y, tmp_path, spec=None, cols=()):
+    from deepctr_torch.callbacks import EarlyStopping, ModelCheckpoint
+    X = model._as_matrix([x[name] for name in model.feature_index])
+    ok = clean_rows(x, cols)
+    if spec is not None and ok.any():
+        from np_oracle import Oracle
+        params = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+        model.eval()
+        with torch.no_grad():
+            got = model(X).cpu().numpy()
+        _, want = Oracle(spec, params, dtype=np.float64).forward(X.cpu().numpy())
+        assert max_abs(got[ok], np.asarray(want)[ok]) <= 2e-5
+    ckpt = str(tmp_path / "model.ckpt")
+    model.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy", "acc"])
+    hist = model.fit(x, y, batch_size=100, epochs=1, validation_split=0.5, verbose=2, callbacks=[
+        EarlyStopping(monitor="val_acc", min_delta=0, verbose=1, patience=0, mode="max"),
+        ModelCheckpoint(filepath=ckpt, monitor="val_acc", verbose=1, save_best_only=True, save_weights_only=False,
+                        mode="max", period=1)])
+    assert set(hist.history) == {"loss", "binary_crossentropy", "acc", "val_binary_crossentropy", "val_acc"}
+    assert all(np.isfinite(v).all() for v in hist.history.values())
+    assert os.path.exists(ckpt)
+    w = str(tmp_path / "weights.h5")
+    torch.save(model.state_dict(), w)
+    model.load_state_dict(torch.load(w))
+    before = model.predict(x, batch_size=50)
+    assert before.shape == (N, 1) and before.dtype == np.float64 and np.isfinite(before).all()
+    f = str(tmp_path / "model.h5")
+    torch.save(model, f)
+    again = torch.load(f, weights_only=False)
+    assert max_abs(again.predict(x, batch_size=50), before) == 0.0
+    return model
+
+
+@pytest.mark.parametrize("use_fm,hidden,n_sparse,n_dense", [
+    (True, (32,), 3, 3), (False, (32,), 3, 3), (False, (32,), 2, 2), (False, (32,), 1, 1), (True, (), 1, 1),
+    (False, (), 2, 2), (True, (32,), 0, 3), (True, (32,), 3, 0), (False, (32,), 0, 3), (False, (32,), 3, 0)])
+def test_DeepFM(tmp_path, use_fm, hidden, n_sparse, n_dense):
+    from deepctr_torch.models import DeepFM
+    x, y, cols = make_data(1, n_sparse, n_dense)
+    kw = dict(use_fm=use_fm, dnn_hidden_units=hidden)
+    check_model(DeepFM(cols, cols, dnn_dropout=0.5, device=DEV, **kw), x, y, tmp_path, spec_of("DeepFM", cols, cols, **kw), cols=cols)
+    check_model(DeepFM([], cols, dnn_dropout=0.5, device=DEV, **kw), x, y, tmp_path, spec_of("DeepFM", [], cols, **kw), cols=cols)
+
+
+def test_rows_of_nothing_but_padding_under_max_pooling_run(tmp_path):
+    """Vocabulary 1 under 'max': EVERY row pools to embedding - 1e9 (see ``clean_rows``).  No numeric claim -- the
+    reference's own value is rounding noise -- but fit / predict / save / load must go through, as in the reference."""
+    from deepctr_torch.models import DeepFM
+    x, y, cols = make_data(1, 0, 3, min_clean=0)
+    assert not clean_rows(x, cols).any()
+    check_model(DeepFM(cols, cols, dnn_hidden_units=(32,), dnn_dropout=0.5, device=DEV), x, y, tmp_path, cols=cols)
+
+
+@pytest.mark.parametrize("seqs", [("sum", "mean"), ("sum", "mean", "max")])
+def test_DeepFM_with_sequence_lengths(tmp_path, seqs):
+    """``length_name`` columns (tests/utils.py:58-60).  With 'max' the reference itself raises on current torch
+    (sequence.py:66 subtracts a bool mask); the drop-in computes the masked max the layer intends (oracle)."""
+    from deepctr_torch.models import DeepFM
+    x, y, cols = make_data(2, 2, 2, include_length=True, seqs=seqs)
+    kw = dict(dnn_hidden_units=(32,))
+    check_model(DeepFM(cols, cols, dnn_dropout=0.5, device=DEV, **kw), x, y, tmp_path, spec_of("DeepFM", cols, cols, **kw), cols=cols)
+
+
+@pytest.mark.parametrize("hidden,cin,split_half,act,n_sparse", [
+    ((), (), True, "linear", 1), ((8,), (), True, "linear", 1), ((), (8,), True, "linear", 2),
+    ((8,), (8,), False, "relu", 2)])
+def test_xDeepFM(tmp_path, hidden, cin, split_half, act, n_sparse):
+    from deepctr_torch.models import xDeepFM
+    x, y, cols = make_data(3, n_sparse, n_sparse)
+    kw = dict(dnn_hidden_units=hidden, cin_layer_size=cin, cin_split_half=split_half, cin_activation=act)
+    check_model(xDeepFM(cols, cols, dnn_dropout=0.5, device=DEV, **kw), x, y, tmp_path,
+                spec_of("xDeepFM", cols, cols, **kw), cols=cols)
+
+
+@pytest.mark.parametrize("bilinear_type", ["each", "interaction", "all"])
+def test_FiBiNET(tmp_path, bilinear_type):
+    from deepctr_torch.models import FiBiNET
+    x, y, cols = make_data(4, 3, 3)
+    kw = dict(bilinear_type=bilinear_type, dnn_hidden_units=[8, 8])
+    check_model(FiBiNET(cols, cols, dnn_dropout=0.5, device=DEV, **kw), x, y, tmp_path,
+                spec_of("FiBiNET", cols, cols, **kw), cols=cols)
+
+
+@pytest.mark.parametrize("cross_num,hidden,n_sparse,param", [(2, (32,), 2, "vector"), (1, (32,), 2, "matrix")])
+def test_DCN(tmp_path, cross_num, hidden, n_sparse, param):
+    from deepctr_torch.models import DCN
+    x, y, cols = make_data(5, n_sparse, n_sparse)
+    kw = dict(cross_num=cross_num, cross_parameterization=param, dnn_hidden_units=hidden)
+    check_model(DCN(linear_feature_columns=cols, dnn_feature_columns=cols, dnn_dropout=0.5, device=DEV, **kw), x, y,
+                tmp_path, spec_of("DCN", cols, cols, **kw), cols=cols)
+
+
+@pytest.mark.parametrize("cross_num,hidden,n_sparse", [(0, (32,), 2), (1, (32,), 2)])
+def test_DCNMix(tmp_path, cross_num, hidden, n_sparse):
+    from deepctr_torch.models import DCNMix
+    x, y, cols = make_data(6, n_sparse, n_sparse)
+    kw = dict(cross_num=cross_num, dnn_hidden_units=hidden)
+    check_model(DCNMix(linear_feature_columns=cols, dnn_feature_columns=cols, dnn_dropout=0.5, device=DEV, **kw), x, y,
+                tmp_path, spec_of("DCNMix", cols, cols, **kw) if cross_num else None, cols=cols)
+
+
+@pytest.mark.parametrize("use_inner,use_outter,kernel_type,n_sparse", [
+    (True, True, "mat", 2), (True, False, "mat", 2), (False, True, "vec", 3), (False, True, "num", 3),
+    (False, False, "mat", 1)])
+def test_PNN(tmp_path, use_inner, use_outter, kernel_type, n_sparse):
+    from deepctr_torch.models import PNN
+    x, y, cols = make_data(7, n_sparse, n_sparse)
+    kw = dict(dnn_hidden_units=[32, 32], use_inner=use_inner, use_outter=use_outter, kernel_type=kernel_type)
+    check_model(PNN(cols, dnn_dropout=0.5, device=DEV, **kw), x, y, tmp_path, spec_of("PNN", [], cols, **kw), cols=cols)
+
+
+@pytest.mark.parametrize("n_sparse", [2, 1])
+def test_NFM(tmp_path, n_sparse):
+    from deepctr_torch.models import NFM
+    x, y, cols = make_data(8, n_sparse, n_sparse)
+    kw = dict(dnn_hidden_units=[32, 32])
+    check_model(NFM(cols, cols, dnn_dropout=0.5, device=DEV, **kw), x, y, tmp_path, spec_of("NFM", cols, cols, **kw), cols=cols)
+
+
+def test_AFM(tmp_path):
+    from deepctr_torch.callbacks import EarlyStopping, ModelCheckpoint
+    from deepctr_torch.models import AFM
+    x, y, cols = make_data(9, 3, 0)
+    kw = dict(use_attention=True)
+    model = check_model(AFM(linear_feature_columns=cols, dnn_feature_columns=cols, afm_dropout=0.5, device=DEV, **kw),
+                        x, y, tmp_path, spec_of("AFM", cols, cols, **kw), cols=cols)
+    # the reference's AFM test goes on: two more fits of 3 epochs monitored on val_binary_crossentropy (AFM_test.py:25-38)
+    stop = EarlyStopping(monitor="val_binary_crossentropy", min_delta=0, verbose=1, patience=0, mode="min")
+    for best_only in (True, False):
+        ck = ModelCheckpoint(filepath=str(tmp_path / "m.ckpt"), monitor="val_binary_crossentropy", verbose=1,
+                             save_best_only=best_only, save_weights_only=False, mode="max", period=1)
+        hist = model.fit(x, y, batch_size=64, epochs=3, validation_split=0.5, verbose=2, callbacks=[stop, ck])
+        assert 1 <= len(hist.history["loss"]) <= 3
+
+
+@pytest.mark.parametrize("att_layer_num,hidden,n_sparse", [(1, (4,), 2), (0, (4,), 2), (2, (4, 4), 2), (1, (), 1),
+                                                           (1, (4,), 1)])
+def test_AutoInt(tmp_path, att_layer_num, hidden, n_sparse):
+    from deepctr_torch.models import AutoInt
+    x, y, cols = make_data(10, n_sparse, n_sparse)
+    kw = dict(att_layer_num=att_layer_num, dnn_hidden_units=hidden)
+    check_model(AutoInt(linear_feature_columns=cols, dnn_feature_columns=cols, dnn_dropout=0.5, device=DEV, **kw), x, y,
+                tmp_path, spec_of("AutoInt", cols, cols, **kw) if att_layer_num else None, cols=cols)
+
+
+@pytest.mark.parametrize("n_sparse,n_dense", [(2, 0), (0, 2), (2, 2)])
+def test_WDL(tmp_path, n_sparse, n_dense):
+    from deepctr_torch.models import WDL
+    x, y, cols = make_data(11, n_sparse, n_dense)
+    check_model(WDL(cols, cols, dnn_activation="prelu", dnn_hidden_units=[32, 32], dnn_dropout=0.5, device=DEV), x, y,
+                tmp_path, cols=cols)          # (PReLU tower: not stated by the numpy oracle -- protocol checks only)
+
+
+# ---- the HIP forward against the REFERENCE's stored predictions on the same matrix (oracle/check_matrix.py) ----------
+from helpers import feature_columns, load_matrix, matrix_id  # noqa: E402
+
+
+@pytest.mark.parametrize("c", load_matrix(), ids=matrix_id)
+def test_forward_matches_reference_on_its_test_matrix(c):
+    """The reference's own freshly initialised parameters (state_dict loaded as is) and inputs for every configuration
+    of its model tests: eval-mode predictions of the HIP path == the reference's, 2e-5, on every row with a defined
+    value; the all-padding 'max' rows must still come out finite."""
+    import deepctr_torch.models as M
+    spec = c["spec"]
+    lin, dnn = feature_columns(spec["linear_columns"]), feature_columns(spec["dnn_columns"])
+    cls = getattr(M, c["model"])
+    m = cls(dnn, device=DEV, **c["kwargs"]) if c["model"] == "PNN" else cls(lin, dnn, device=DEV, **c["kwargs"])
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in c["params"].items()})
+    m.eval()
+    with torch.no_grad():
+        got = m(torch.from_numpy(c["X"]).to(DEV)).cpu().numpy()
+    assert np.isfinite(got).all()
+    ok = c["clean"]
+    assert max_abs(got[ok], c["y_pred"][ok]) <= 2e-5

@@ -81,3 +81,32 @@ def test_torch_port_matches_reference():
               for Xb, yb in zip(g["extra"]["X_steps"], g["extra"]["y_steps"])]
     np.testing.assert_allclose(losses, g["extra"]["adagrad3_loss"], rtol=2e-5)
     assert max_abs(port.emb[0].weight.detach().numpy(), g["extra"]["adagrad3/embedding_dict.C1.weight"]) <= 2e-5
+
+
+# ---- the reference's own model-test matrix (tests/golden/matrix, oracle/check_matrix.py) -----------------------------
+from helpers import feature_columns, load_matrix, matrix_id  # noqa: E402
+
+MATRIX = load_matrix()
+
+
+@pytest.mark.parametrize("c", MATRIX, ids=matrix_id)
+def test_oracle_matches_reference_on_its_test_matrix(c):
+    """Every configuration of tests/models/*_test.py of the reference (1-9 row vocabularies, sum / mean / max VarLen
+    columns with padding id 0, no-linear / no-FM / empty-tower / empty-CIN variants ...): oracle == reference forward on
+    the reference's own freshly initialised parameters."""
+    _, y_pred = Oracle(c["spec"], c["params"], dtype=np.float64).forward(c["X"])
+    ok = c["clean"]
+    assert ok.sum() >= 16
+    assert max_abs(np.asarray(y_pred)[ok], c["y_pred"][ok]) <= 2e-6
+
+
+@pytest.mark.parametrize("c", MATRIX, ids=matrix_id)
+def test_state_dict_layout_matches_reference_on_its_test_matrix(c):
+    """Drop-in checkpoints: same keys, same shapes as the reference's ``state_dict()`` for every configuration."""
+    import deepctr_torch.models as M
+    spec = c["spec"]
+    lin, dnn = feature_columns(spec["linear_columns"]), feature_columns(spec["dnn_columns"])
+    cls = getattr(M, c["model"])
+    m = cls(dnn, device="cpu", **c["kwargs"]) if c["model"] == "PNN" else cls(lin, dnn, device="cpu", **c["kwargs"])
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == {k: tuple(v.shape) for k, v in c["params"].items()}
