@@ -71,7 +71,13 @@ def main():
         X = np.concatenate([np.asarray(x[name], np.float32).reshape(tm.N, -1) for name in m.feature_index], axis=1)
         with torch.no_grad():
             want = m(torch.from_numpy(X)).numpy()
-        params = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+        params = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+        okt = torch.from_numpy(tm.clean_rows(x, cols))
+        # gradients of BCE(sum) over the rows with a defined value (dropout is 0 here, so train == eval arithmetic)
+        yt = torch.from_numpy(np.asarray(y, np.float32))
+        m.zero_grad()
+        torch.nn.functional.binary_cross_entropy(m(torch.from_numpy(X)).squeeze(1)[okt], yt[okt], reduction="sum").backward()
+        grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy() for k, p in m.named_parameters()}
         _, got = Oracle(spec, params, dtype=np.float64).forward(X)
         ok = tm.clean_rows(x, cols)          # rows with an all-padding 'max' field are ~1e9 noise in the reference itself
         err = float(np.max(np.abs(np.asarray(got).reshape(-1)[ok] - want.reshape(-1)[ok]))) if ok.any() else 0.0
@@ -82,8 +88,19 @@ def main():
         meta.append({"model": model, "seed": seed, "n_sparse": ns, "n_dense": nd, "kwargs": kw, "with_linear": with_lin,
                      "include_length": inc_len, "spec": spec})
         store["%d/X" % i], store["%d/y_pred" % i], store["%d/clean" % i] = X, want.reshape(-1, 1), ok
+        store["%d/y" % i] = np.asarray(y, np.float32)
         for k, v in params.items():
             store["%d/param/%s" % (i, k)] = v
+        for k, v in grads.items():
+            store["%d/grad/%s" % (i, k)] = v
+        # the oracle's backward on the same rows
+        o = Oracle(spec, params, dtype=np.float64)
+        _, yp = o.forward(X)
+        gl = (np.asarray(yp).reshape(-1, 1) - np.asarray(y, np.float64).reshape(-1, 1)) * ok.reshape(-1, 1)
+        og = o.backward(gl)
+        for k, v in grads.items():
+            e = float(np.max(np.abs(np.asarray(og.get(k, np.zeros_like(v))).reshape(v.shape) - v))) if v.size else 0.0
+            assert e <= 2e-5 * max(1.0, float(np.max(np.abs(v))) if v.size else 1.0), (model, kw, k, e)
     out = os.path.join(ROOT, "tests", "golden", "matrix")
     os.makedirs(out, exist_ok=True)
     store["configs"] = np.array(json.dumps(meta))

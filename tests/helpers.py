@@ -79,9 +79,10 @@ def load_matrix():
     z = np.load(os.path.join(GOLDEN_DIR, "matrix", "reference_matrix.npz"), allow_pickle=False)
     out = []
     for i, meta in enumerate(json.loads(str(z["configs"]))):
-        pre = "%d/param/" % i
-        out.append(dict(meta, X=z["%d/X" % i], y_pred=z["%d/y_pred" % i], clean=z["%d/clean" % i],
-                        params={k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}))
+        pre, gpre = "%d/param/" % i, "%d/grad/" % i
+        out.append(dict(meta, X=z["%d/X" % i], y=z["%d/y" % i], y_pred=z["%d/y_pred" % i], clean=z["%d/clean" % i],
+                        params={k[len(pre):]: z[k] for k in z.files if k.startswith(pre)},
+                        grads={k[len(gpre):]: z[k] for k in z.files if k.startswith(gpre)}))
     return out
 
 

@@ -256,3 +256,26 @@ def test_forward_matches_reference_on_its_test_matrix(c):
     assert np.isfinite(got).all()
     ok = c["clean"]
     assert max_abs(got[ok], c["y_pred"][ok]) <= 2e-5
+
+
+@pytest.mark.parametrize("c", load_matrix(), ids=matrix_id)
+def test_gradients_match_reference_on_its_test_matrix(c):
+    """d BCE(sum over the rows with a defined value) / d every parameter == the reference's autograd, 2e-5 x max|g|:
+    the backward of sum / mean / max pooling with padding, one-row vocabularies, towers of zero layers, ..."""
+    import deepctr_torch.models as M
+    spec = c["spec"]
+    lin, dnn = feature_columns(spec["linear_columns"]), feature_columns(spec["dnn_columns"])
+    cls = getattr(M, c["model"])
+    m = cls(dnn, device=DEV, **c["kwargs"]) if c["model"] == "PNN" else cls(lin, dnn, device=DEV, **c["kwargs"])
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in c["params"].items()})
+    m.train()
+    ok = torch.from_numpy(c["clean"]).to(DEV)
+    y = torch.from_numpy(c["y"]).to(DEV)
+    m.zero_grad()
+    torch.nn.functional.binary_cross_entropy(m(torch.from_numpy(c["X"]).to(DEV)).squeeze(1)[ok], y[ok],
+                                             reduction="sum").backward()
+    m.model_plan().check_ids()
+    for k, p in m.named_parameters():
+        ref = c["grads"][k]
+        got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(ref)
+        assert max_abs(got, ref) <= 2e-5 * max(1.0, float(np.max(np.abs(ref))) if ref.size else 1.0), k

@@ -101,6 +101,18 @@ def test_oracle_matches_reference_on_its_test_matrix(c):
 
 
 @pytest.mark.parametrize("c", MATRIX, ids=matrix_id)
+def test_oracle_backward_matches_reference_on_its_test_matrix(c):
+    """Gradient of BCE(sum) over the rows with a defined value, every parameter (a parameter the model never uses, e.g.
+    the last of FiBiNET's 'each' bilinear weights, has the gradient zero)."""
+    o = Oracle(c["spec"], c["params"], dtype=np.float64)
+    _, y_pred = o.forward(c["X"])
+    g = o.backward((np.asarray(y_pred).reshape(-1, 1) - c["y"].reshape(-1, 1).astype(np.float64)) * c["clean"].reshape(-1, 1))
+    for k, ref in c["grads"].items():
+        got = np.asarray(g.get(k, np.zeros_like(ref))).reshape(ref.shape)
+        assert max_abs(got, ref) <= GRAD_TOL * max(1.0, float(np.max(np.abs(ref))) if ref.size else 1.0), k
+
+
+@pytest.mark.parametrize("c", MATRIX, ids=matrix_id)
 def test_state_dict_layout_matches_reference_on_its_test_matrix(c):
     """Drop-in checkpoints: same keys, same shapes as the reference's ``state_dict()`` for every configuration."""
     import deepctr_torch.models as M
