@@ -56,7 +56,7 @@ def main():
     import make_golden as mg
     from np_oracle import Oracle
     sys.path.insert(0, os.path.join(ROOT, "deepctr-torch_amd"))
-    import test_gpu_reference_matrix as tm          # the generator + spec_of the GPU tests use
+    import matrix_data as tm                        # the generator + spec_of the GPU tests use
     ref = mg.import_reference()
     worst = 0.0
     store, meta = {}, []
@@ -69,8 +69,11 @@ def main():
         m = mg.build_reference_model(ref, spec, l2=1e-5)
         m.eval()
         X = np.concatenate([np.asarray(x[name], np.float32).reshape(tm.N, -1) for name in m.feature_index], axis=1)
+        cap = {}
+        hook = m.out.register_forward_pre_hook(lambda mod, inp: cap.__setitem__("logit", inp[0].detach().clone()))
         with torch.no_grad():
             want = m(torch.from_numpy(X)).numpy()
+        hook.remove()
         params = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
         okt = torch.from_numpy(tm.clean_rows(x, cols))
         # gradients of BCE(sum) over the rows with a defined value (dropout is 0 here, so train == eval arithmetic)
@@ -78,17 +81,20 @@ def main():
         m.zero_grad()
         torch.nn.functional.binary_cross_entropy(m(torch.from_numpy(X)).squeeze(1)[okt], yt[okt], reduction="sum").backward()
         grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy() for k, p in m.named_parameters()}
-        _, got = Oracle(spec, params, dtype=np.float64).forward(X)
+        lg, got = Oracle(spec, params, dtype=np.float64).forward(X)
         ok = tm.clean_rows(x, cols)          # rows with an all-padding 'max' field are ~1e9 noise in the reference itself
         err = float(np.max(np.abs(np.asarray(got).reshape(-1)[ok] - want.reshape(-1)[ok]))) if ok.any() else 0.0
         worst = max(worst, err)
         print("%-8s lin=%d %-90s max|d| = %.2e (%d rows)" % (model, with_lin, kw, err, int(ok.sum())))
         assert err <= 2e-6, (model, kw, err)
+        lerr = float(np.max(np.abs(np.asarray(lg).reshape(-1)[ok] - cap["logit"].numpy().reshape(-1)[ok])))
+        assert lerr <= 1e-5, (model, kw, lerr)
         i = len(meta)
         meta.append({"model": model, "seed": seed, "n_sparse": ns, "n_dense": nd, "kwargs": kw, "with_linear": with_lin,
                      "include_length": inc_len, "spec": spec})
         store["%d/X" % i], store["%d/y_pred" % i], store["%d/clean" % i] = X, want.reshape(-1, 1), ok
         store["%d/y" % i] = np.asarray(y, np.float32)
+        store["%d/logit" % i] = cap["logit"].numpy().reshape(-1, 1)
         for k, v in params.items():
             store["%d/param/%s" % (i, k)] = v
         for k, v in grads.items():

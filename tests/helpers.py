@@ -80,7 +80,7 @@ def load_matrix():
     out = []
     for i, meta in enumerate(json.loads(str(z["configs"]))):
         pre, gpre = "%d/param/" % i, "%d/grad/" % i
-        out.append(dict(meta, X=z["%d/X" % i], y=z["%d/y" % i], y_pred=z["%d/y_pred" % i], clean=z["%d/clean" % i],
+        out.append(dict(meta, X=z["%d/X" % i], y=z["%d/y" % i], y_pred=z["%d/y_pred" % i], logit=z["%d/logit" % i], clean=z["%d/clean" % i],
                         params={k[len(pre):]: z[k] for k in z.files if k.startswith(pre)},
                         grads={k[len(gpre):]: z[k] for k in z.files if k.startswith(gpre)}))
     return out

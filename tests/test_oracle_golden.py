@@ -94,9 +94,10 @@ def test_oracle_matches_reference_on_its_test_matrix(c):
     """Every configuration of tests/models/*_test.py of the reference (1-9 row vocabularies, sum / mean / max VarLen
     columns with padding id 0, no-linear / no-FM / empty-tower / empty-CIN variants ...): oracle == reference forward on
     the reference's own freshly initialised parameters."""
-    _, y_pred = Oracle(c["spec"], c["params"], dtype=np.float64).forward(c["X"])
+    logit, y_pred = Oracle(c["spec"], c["params"], dtype=np.float64).forward(c["X"])
     ok = c["clean"]
     assert ok.sum() >= 16
+    assert max_abs(np.asarray(logit).reshape(-1, 1)[ok], c["logit"][ok]) <= LOGIT_TOL
     assert max_abs(np.asarray(y_pred)[ok], c["y_pred"][ok]) <= 2e-6
 
 
