@@ -7,7 +7,6 @@ gfx950 kernel (``csrc/embed.hip``) reached through :mod:`deepctr_torch._hip`.
 from collections import OrderedDict, defaultdict, namedtuple
 from itertools import chain
 
-import numpy as np
 import torch
 import torch.nn as nn
 

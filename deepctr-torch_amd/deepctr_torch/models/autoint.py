@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 
 from .basemodel import BaseModel
-from ..layers import DNN, InteractingLayer
+from ..layers import InteractingLayer
 
 
 class AutoInt(BaseModel):

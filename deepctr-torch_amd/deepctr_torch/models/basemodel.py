@@ -36,8 +36,7 @@ from .._hip import dense as _dense
 from .._hip import mlp as _mlp
 from .._hip import ops as _ops
 from .._hip.plan import EmbeddingPlan
-from ..inputs import (DenseFeat, SparseFeat, VarLenSparseFeat, build_input_features, create_embedding_matrix,
-                      split_columns)
+from ..inputs import SparseFeat, VarLenSparseFeat, build_input_features, create_embedding_matrix, split_columns
 from ..layers import PredictionLayer
 from ..layers.utils import slice_arrays
 
@@ -251,7 +250,7 @@ class BaseModel(nn.Module):
             self.add_regularization_weight(self.dnn_linear.weight, l2=l2_reg_dnn if l2_head is None else l2_head)
 
     def compute_input_dim(self, feature_columns, include_sparse=True, include_dense=True, feature_group=False):
-        sparse_cols, varlen_cols, dense_cols = split_columns(feature_columns)
+        dense_cols = split_columns(feature_columns)[2]
         emb_cols = [c for c in feature_columns if isinstance(c, (SparseFeat, VarLenSparseFeat))] \
             if len(feature_columns) else []
         dense_dim = sum(c.dimension for c in dense_cols)
@@ -774,7 +773,6 @@ class BaseModel(nn.Module):
                 order = torch.randperm(sample_num, generator=gen).to(self.device)
             else:
                 order = None
-            loss_acc = torch.zeros((), device=self.device, dtype=torch.float64)
             total_acc = torch.zeros((), device=self.device, dtype=torch.float64)
             preds = [] if (verbose > 0 and self.metrics) else None
             bar = tqdm(total=steps_per_epoch, disable=verbose != 1) if tqdm is not None else None
@@ -787,7 +785,6 @@ class BaseModel(nn.Module):
                     else:
                         xb, yb = X_all[lo:hi], y_all[lo:hi]
                     loss, total_loss, y_pred = self._fit_step(xb, yb, batch_size)
-                    loss_acc += loss.double()
                     total_acc += total_loss.double().sum()
                     if preds is not None:
                         preds.append((yb, y_pred.clone()))

@@ -3,7 +3,7 @@
 import torch
 
 from .basemodel import BaseModel
-from ..layers import DNN, CrossNet
+from ..layers import CrossNet
 
 
 class DCN(BaseModel):

@@ -5,7 +5,7 @@ PyTorch-ROCm (layers.CrossNetMix)."""
 import torch
 
 from .basemodel import BaseModel
-from ..layers import DNN, CrossNetMix
+from ..layers import CrossNetMix
 
 
 class DCNMix(BaseModel):

@@ -5,7 +5,7 @@ The forward is two device phases instead of the reference's ~200 ATen launches (
 one fused gather (embeddings in DNN-input layout + linear logit + FM term) and the MLP tower."""
 
 from .basemodel import BaseModel
-from ..layers import DNN, FM
+from ..layers import FM
 
 
 class DeepFM(BaseModel):

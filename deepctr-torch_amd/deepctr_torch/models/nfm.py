@@ -6,7 +6,7 @@ Forward = the fused gather, ONE kernel for BiInteractionPooling + the concatenat
 import torch.nn as nn
 
 from .basemodel import BaseModel
-from ..layers import DNN, BiInteractionPooling
+from ..layers import BiInteractionPooling
 
 
 class NFM(BaseModel):

@@ -3,7 +3,6 @@
 One fused gather (embeddings in DNN-input layout + the wide logit) and the MFMA tower; takes the fused train step."""
 
 from .basemodel import BaseModel
-from ..layers import DNN
 
 
 class WDL(BaseModel):

@@ -4,7 +4,7 @@ One fused gather feeds both towers; each CIN layer is one fp32-MFMA kernel (csrc
 import torch.nn as nn
 
 from .basemodel import BaseModel
-from ..layers import CIN, DNN
+from ..layers import CIN
 
 
 class xDeepFM(BaseModel):

@@ -459,7 +459,6 @@ class ShardedTrainer(object):
         self._segE = _Segment(lambda: self.slab.step(*self.state["mode"]), False)
 
     def _compute(self):
-        from ._hip import mlp as _mlp
         model, st, slab, plan, lay = self.model, self.state, self.slab, self.plan, self.layout
         model._grad_sink = slab
         self._leaves = None
