@@ -200,6 +200,9 @@ LAZY_STEPS, LAZY_L2 = 8, 1e-3
 #   default   the reference's default kwargs (l2 = 1e-5 on tables and Linear) with adam, shuffle=True, same seed
 _ft = criteo_columns(8, 3, 20, 8)
 case("fit_deepfm", "DeepFM", _ft, _ft, batch=64, fit=True, dnn_hidden_units=(16, 8))
+# a model outside the fused train step (autograd + torch.optim around the kernels) and one with an MFMA interaction
+case("fit_dcn", "DCN", _ft, _ft, batch=64, fit=True, dnn_hidden_units=(16,), cross_num=2)
+case("fit_xdeepfm", "xDeepFM", _ft, _ft, batch=64, fit=True, dnn_hidden_units=(16,), cin_layer_size=(8, 6))
 FIT_ROWS, FIT_EPOCHS, FIT_SPLIT, FIT_SEED = 300, 3, 0.25, 777
 FIT_RUNS = (("plain", "adagrad", 0.0, False), ("shuffled", "adagrad", 0.0, True), ("default", "adam", 1e-5, True))
 

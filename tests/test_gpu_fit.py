@@ -3,6 +3,7 @@ over 225 train rows in batches of 64 (a ragged last batch), 25 % validation spli
 (basemodel.py:264-280), evaluate() at every epoch end, predict() afterwards.  Three runs: adagrad without L2 unshuffled;
 the same shuffled after torch.manual_seed (the drop-in draws the DataLoader's permutations); the reference's DEFAULT
 kwargs (l2 = 1e-5, adam) shuffled -- which takes the exact lazy update (csrc/lazy.hip) under hipGraph replays.
+Models: DeepFM (fused train step), DCN (autograd + torch.optim around the kernels), xDeepFM (CIN on MFMA).
 Tolerance: 2e-4 relative on the losses, 5e-3 absolute on AUC (a rank statistic over 33-75 samples: one swapped pair of
 near-equal predictions moves it by ~1e-3)."""
 import numpy as np
@@ -18,9 +19,10 @@ FIT_RUNS = (("plain", "adagrad", 0.0, False), ("shuffled", "adagrad", 0.0, True)
 
 @pytest.mark.parametrize("graphs", ["1", "0"])
 @pytest.mark.parametrize("tag,opt,l2,shuffle", FIT_RUNS)
-def test_fit_history_and_predict_match_reference(monkeypatch, tag, opt, l2, shuffle, graphs):
+@pytest.mark.parametrize("name", ["fit_deepfm", "fit_dcn", "fit_xdeepfm"])
+def test_fit_history_and_predict_match_reference(monkeypatch, name, tag, opt, l2, shuffle, graphs):
     monkeypatch.setenv("DCTR_FIT_GRAPH", graphs)
-    g = load_golden("fit_deepfm")
+    g = load_golden(name)
     ex = g["extra"]
     m = build_model(g["spec"], DEV, l2=l2)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in g["params"].items()})
