@@ -145,8 +145,6 @@ class MockLib(object):
         c = pref._obj
         deep = [(L.Field * c.n_deep).from_address(c.deep)[i] for i in range(c.n_deep)] if c.n_deep else []
         wide = [(L.Field * c.n_wide).from_address(c.wide)[i] for i in range(c.n_wide)] if c.n_wide else []
-        for f in deep + wide:
-            assert f.len == 1, "the numpy stand-in covers fixed-length fields"
         dcols = list(_arr(c.dense_cols, (c.n_dense,), dtype=np.int32)) if c.n_dense else []
         wcols = list(_arr(c.wdense_cols, (c.n_wdense,), dtype=np.int32)) if c.n_wdense else []
         return c, deep, wide, dcols, wcols
@@ -158,6 +156,52 @@ class MockLib(object):
         if err is not None and bad.any():
             err[0] = 1
         return np.where(bad, 0, ids)
+
+    @staticmethod
+    def _seq(X, f, err=None):
+        """ids [B, len] (out-of-range -> 0) and the validity mask [B, len] of a field (inputs.py:146, sequence.py:56-59)."""
+        ids = X[:, f.col:f.col + f.len].astype(np.int64)
+        bad = (ids < 0) | (ids >= f.vocab)
+        if err is not None and bad.any():
+            err[0] = 1
+        ids = np.where(bad, 0, ids)
+        if f.pool == 0:
+            return ids, np.ones_like(ids, dtype=bool)
+        if f.len_col >= 0:
+            return ids, np.arange(f.len)[None, :] < X[:, f.len_col].astype(np.int64)[:, None]
+        return ids, ids != 0
+
+    def _gather(self, X, f, err=None):
+        """pooled embedding [B, dim] of one field (sequence.py:61-77), fp32 like the reference."""
+        table = _arr(f.table, (f.vocab, f.dim))
+        if f.pool == 0:                     # SparseFeat (a VarLen column of maxlen 1 still masks its padding id)
+            return table[self._rows(X, f, err)]
+        ids, mask = self._seq(X, f, err)
+        rows = table[ids]                                          # [B, len, dim]
+        m = mask[:, :, None].astype(np.float32)
+        if f.pool == 3:
+            return (rows - (np.float32(1) - m) * np.float32(1e9)).max(axis=1)
+        tot = (rows * m).sum(axis=1, dtype=np.float32)
+        if f.pool == 2:
+            tot = tot / (mask.sum(axis=1, keepdims=True).astype(np.float32) + np.float32(1e-8))
+        return tot
+
+    def _scatter(self, X, f, G):
+        """(row ids [n], gradient rows [n, dim]) of one field for the pooled gradient G [B, dim]."""
+        if f.pool == 0:
+            return self._rows(X, f), G
+        ids, mask = self._seq(X, f)
+        m = mask[:, :, None].astype(np.float32)
+        if f.pool == 3:
+            rows = _arr(f.table, (f.vocab, f.dim))[ids]
+            arg = (rows - (np.float32(1) - m) * np.float32(1e9)).argmax(axis=1)      # [B, dim]
+            g = np.zeros(rows.shape, np.float32)
+            np.put_along_axis(g, arg[:, None, :], G[:, None, :], axis=1)
+        else:
+            g = G[:, None, :] * m
+            if f.pool == 2:
+                g = g / (mask.sum(axis=1).astype(np.float32)[:, None, None] + np.float32(1e-8))
+        return ids.reshape(-1), g.reshape(-1, f.dim)
 
     def dctr_embed_update_supported(self, pref, max_vocab, B):
         return 1
@@ -187,7 +231,7 @@ class MockLib(object):
             O = _arr(out, (B, ld_out), ld_out)
             O[...] = 0
             for f in deep:
-                e = _arr(f.table, (f.vocab, f.dim))[self._rows(Xv, f, errv)]
+                e = self._gather(Xv, f, errv)
                 O[:, f.out_off:f.out_off + f.dim] = e
                 if c.emb_dim > 0:
                     S += e
@@ -197,7 +241,7 @@ class MockLib(object):
         if _arr(wide, (1,)) is not None:
             w = np.zeros(B, np.float32)
             for f in widef:
-                w += _arr(f.table, (f.vocab, 1))[self._rows(Xv, f, errv), 0]
+                w += self._gather(Xv, f, errv)[:, 0]
             if wcols:
                 ww = _arr(c.wdense_w, (len(wcols),))
                 for j, col in enumerate(wcols):
@@ -212,6 +256,50 @@ class MockLib(object):
         if _arr(ids_t, (1,)) is not None:
             self.dctr_embed_ids(units, n_units, X, ldx, B, ids_t, stream)
             self.calls.pop()
+        return 0
+
+    # ---- general backward (dctr_embed_bwd) + consume pass (dctr_embed_apply): pooled fields, shared tables -----
+    def dctr_embed_bwd(self, pref, X, ldx, B, g_out, ld_g, out, ld_out, g_fm, g_wide, mode, lr, stream):
+        self.calls.append("embed_bwd:%d" % mode)
+        c, deep, widef, dcols, wcols = self._plan(pref)
+        Xv = _arr(X, (B, c.n_xcols), ldx)
+        gO = _arr(g_out, (B, ld_g), ld_g) if ld_g else None
+        gF, gW = _arr(g_fm, (B,)), _arr(g_wide, (B,))
+        O = _arr(out, (B, ld_out), ld_out) if gF is not None else None
+        S = sum(O[:, f.out_off:f.out_off + f.dim] for f in deep) if gF is not None else None
+        work = []
+        for f in deep:
+            G = np.zeros((B, f.dim), np.float32)
+            if gO is not None:
+                G += gO[:, f.out_off:f.out_off + f.dim]
+            if gF is not None:
+                G += gF[:, None] * (S - O[:, f.out_off:f.out_off + f.dim])
+            work.append((f, G))
+        if gW is not None:
+            work += [(f, gW.reshape(B, 1).astype(np.float32)) for f in widef]
+        scat = [(f,) + self._scatter(Xv, f, G) for f, G in work]       # max pooling re-reads the tables: gather first
+        for f, rows, g in scat:
+            dst = _arr(f.gacc if mode == 0 else f.table, (f.vocab, f.dim))
+            np.add.at(dst, rows, g if mode == 0 else -np.float32(lr) * g)
+        return 0
+
+    def dctr_embed_apply(self, pref, X, ldx, B, opt, lr, eps, stream):
+        self.calls.append("embed_apply:%d" % opt)
+        c, deep, widef, dcols, wcols = self._plan(pref)
+        Xv = _arr(X, (B, c.n_xcols), ldx)
+        for f in deep + widef:
+            rows = np.unique(self._seq(Xv, f)[0])
+            gacc, table = _arr(f.gacc, (f.vocab, f.dim)), _arr(f.table, (f.vocab, f.dim))
+            G = gacc[rows].copy()
+            gacc[rows] = 0
+            if opt == 1:
+                st = _arr(f.state, (f.vocab, f.dim))
+                s2 = st[rows] + G * G
+                table[rows] = np.where(G != 0, table[rows] - np.float32(lr) * (G / (np.sqrt(s2) + np.float32(eps))),
+                                       table[rows])
+                st[rows] = s2
+            else:
+                table[rows] -= np.float32(lr) * G
         return 0
 
     # ---- deterministic fused backward + optimizer (dctr_embed_update) ---------------------------------------

@@ -89,3 +89,70 @@ def test_fit_history_and_predict_match_reference(mock, monkeypatch, tag, opt, l2
     pred = m.predict(x, batch_size=50)
     assert pred.dtype == np.float64 and pred.shape == ex["fit_%s_pred" % tag].shape
     assert max_abs(pred, ex["fit_%s_pred" % tag]) <= 5e-5
+
+
+# ---- the reference's own DeepFM test matrix (tests/golden/matrix, oracle/check_matrix.py) on the stand-in --------------
+from helpers import feature_columns, load_matrix, matrix_id  # noqa: E402
+
+DEEPFM_MATRIX = [c for c in load_matrix() if c["model"] == "DeepFM"]
+
+
+def _matrix_model(c):
+    from deepctr_torch.models import DeepFM
+    spec = c["spec"]
+    m = DeepFM(feature_columns(spec["linear_columns"]), feature_columns(spec["dnn_columns"]), device=DEV, **c["kwargs"])
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in c["params"].items()})
+    return m
+
+
+@pytest.mark.parametrize("c", DEEPFM_MATRIX, ids=matrix_id)
+def test_reference_matrix_forward_and_gradients(mock, c):
+    """sum / mean / max VarLen columns (padding id 0 or a length column), one-row vocabularies, no-linear / no-FM /
+    zero-layer-tower variants: the plan's pooled-field descriptors and the general backward route, against the REAL
+    reference's logits (1e-5) and per-parameter gradients."""
+    m = _matrix_model(c)
+    ok = c["clean"]
+    m.eval()
+    cap = {}
+    hook = m.out.register_forward_pre_hook(lambda mod, inp: cap.__setitem__("logit", inp[0].detach()))
+    with torch.no_grad():
+        m(torch.from_numpy(c["X"]))
+    hook.remove()
+    assert max_abs(cap["logit"].numpy().reshape(-1, 1)[ok], c["logit"][ok]) <= 1e-5
+    m.train()
+    okt = torch.from_numpy(ok)
+    m.zero_grad()
+    torch.nn.functional.binary_cross_entropy(m(torch.from_numpy(c["X"])).squeeze(1)[okt], torch.from_numpy(c["y"])[okt],
+                                             reduction="sum").backward()
+    for k, p in m.named_parameters():
+        ref = c["grads"][k]
+        got = p.grad.numpy() if p.grad is not None else np.zeros_like(ref)
+        assert max_abs(got, ref) <= 2e-5 * max(1.0, float(np.max(np.abs(ref))) if ref.size else 1.0), k
+
+
+def test_reference_protocol_runs_on_pooled_fields(mock, monkeypatch, tmp_path):
+    """check_model of the reference's tests (tests/utils.py:142-171) on a VarLen model: adam + default L2 ->
+    the exact dense-gradient route ('dense' update mode), callbacks, state_dict and whole-model save / load."""
+    from deepctr_torch.callbacks import EarlyStopping, ModelCheckpoint
+    from deepctr_torch.models import DeepFM
+    from matrix_data import N, make_data
+    monkeypatch.setenv("DCTR_FIT_GRAPH", "0")
+    x, y, cols = make_data(1, 3, 3)
+    m = DeepFM(cols, cols, dnn_hidden_units=(32,), dnn_dropout=0.5, device=DEV)
+    m.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy", "acc"])
+    assert m.model_plan().update == ("dense",)
+    ckpt = str(tmp_path / "model.ckpt")
+    hist = m.fit(x, y, batch_size=100, epochs=2, validation_split=0.5, verbose=2, callbacks=[
+        EarlyStopping(monitor="val_acc", min_delta=0, verbose=1, patience=1, mode="max"),
+        ModelCheckpoint(filepath=ckpt, monitor="val_acc", verbose=1, save_best_only=True, save_weights_only=False,
+                        mode="max", period=1)])
+    assert set(hist.history) == {"loss", "binary_crossentropy", "acc", "val_binary_crossentropy", "val_acc"}
+    assert "embed_bwd:0" in mock.calls and np.isfinite(hist.history["loss"]).all()
+    w = str(tmp_path / "w.h5")
+    torch.save(m.state_dict(), w)
+    m.load_state_dict(torch.load(w))
+    before = m.predict(x, batch_size=50)
+    f = str(tmp_path / "m.h5")
+    torch.save(m, f)
+    again = torch.load(f, weights_only=False)
+    assert before.shape == (N, 1) and max_abs(again.predict(x, batch_size=50), before) == 0.0
