@@ -1,0 +1,100 @@
+"""tests/golden/api/api_variants.npz: the user-facing call variants of ``compile / fit / evaluate / predict`` executed on
+the REAL reference (torch-CPU) -- what a script written against DeepCTR-Torch may do besides the plain case:
+
+    regress   task='regression', compile('adam', 'mse', ['mse']), reference-default L2, x as a dict
+    listval   x as a LIST in feature_index order, validation_data=(list, y), compile('sgd', ..., ['logloss', 'accuracy'])
+    shared    a VarLen history column sharing the item table (embedding_name), a DenseFeat of dimension 3, 'adagrad', ['auc']
+    rmsprop   compile('rmsprop', ...): an optimizer outside the in-kernel set -> exact dense gradients + torch.optim
+    instance  an optimizer INSTANCE (torch.optim.Adam(lr=0.01, weight_decay=1e-4)) and a loss CALLABLE
+
+Every run: the reference's initial state_dict, its History after 2 unshuffled epochs, evaluate() and predict().
+Runs only in the build container (needs /root/reference):   python oracle/make_api_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402
+
+N, BATCH, EPOCHS = 160, 32, 2
+
+
+def variants():
+    base = mg.criteo_columns(4, 2, 10, 4)
+    shared = [mg.sparse("item", 12, 4), mg.varlen("hist_item", 12, 4, 4, "mean", embedding_name="item"),
+              mg.dense("d3", 3), mg.sparse("user", 7, 4)]
+    return [
+        dict(tag="regress", cols=base, kwargs=dict(task="regression", dnn_hidden_units=(8,)), l2=1e-5, opt="adam",
+             loss="mse", metrics=["mse"], y="real", x="dict", val="split"),
+        dict(tag="listval", cols=base, kwargs=dict(dnn_hidden_units=(8, 4)), l2=1e-5, opt="sgd",
+             loss="binary_crossentropy", metrics=["logloss", "accuracy"], y="binary", x="list", val="data"),
+        dict(tag="shared", cols=shared, kwargs=dict(dnn_hidden_units=(8,)), l2=0.0, opt="adagrad",
+             loss="binary_crossentropy", metrics=["auc"], y="binary", x="dict", val="split"),
+        dict(tag="rmsprop", cols=base, kwargs=dict(dnn_hidden_units=(8,)), l2=1e-5, opt="rmsprop",
+             loss="binary_crossentropy", metrics=["binary_crossentropy"], y="binary", x="dict", val="split"),
+        dict(tag="instance", cols=base, kwargs=dict(dnn_hidden_units=(8,)), l2=0.0, opt="instance",
+             loss="callable", metrics=["acc"], y="binary", x="dict", val="split"),
+    ]
+
+
+def model_input(spec, X, as_list):
+    """dict name -> array (2-D for VarLen / multi-dim dense columns), or the list in feature_index order."""
+    from np_oracle import build_input_features
+    fi = build_input_features(spec["linear_columns"] + spec["dnn_columns"])
+    d = {}
+    for name, (lo, hi) in fi.items():
+        d[name] = X[:, lo] if hi - lo == 1 else X[:, lo:hi]
+    return [d[k] for k in fi] if as_list else d
+
+
+def main():
+    import torch
+    import torch.nn.functional as F
+    ref = mg.import_reference()
+    store, meta = {}, []
+    for v in variants():
+        rng = np.random.default_rng(4242 + sum(map(ord, v["tag"])))
+        spec = {"model": "DeepFM", "linear_columns": v["cols"], "dnn_columns": v["cols"], "kwargs": v["kwargs"]}
+        torch.manual_seed(0)
+        m = mg.build_reference_model(ref, spec, l2=v["l2"])
+        mg.randomise(m, rng)
+        X, y = mg.synth_inputs(spec, N, rng)
+        if v["y"] == "real":
+            y = rng.normal(0.3, 1.0, N).astype(np.float32)
+        Xv, yv = mg.synth_inputs(spec, 48, rng)
+        t = v["tag"]
+        store[t + "/X"], store[t + "/y"], store[t + "/Xv"], store[t + "/yv"] = X, y, Xv, yv
+        for k, p in m.state_dict().items():
+            store[t + "/param/" + k] = p.detach().numpy().copy()
+        opt = torch.optim.Adam(m.parameters(), lr=0.01, weight_decay=1e-4) if v["opt"] == "instance" else v["opt"]
+        loss = F.binary_cross_entropy if v["loss"] == "callable" else v["loss"]
+        m.compile(opt, loss, metrics=v["metrics"])
+        xin = model_input(spec, X, v["x"] == "list")
+        torch.manual_seed(5)
+        if v["val"] == "data":
+            hist = m.fit(xin, y, batch_size=BATCH, epochs=EPOCHS, verbose=2, shuffle=False,
+                         validation_data=(model_input(spec, Xv, True), yv))
+        else:
+            hist = m.fit(xin, y, batch_size=BATCH, epochs=EPOCHS, verbose=2, shuffle=False, validation_split=0.2)
+        for k, val in hist.history.items():
+            store["%s/hist/%s" % (t, k)] = np.asarray(val, np.float64)
+        ev = m.evaluate(model_input(spec, Xv, v["x"] == "list"), yv, batch_size=20)
+        for k, val in ev.items():
+            store["%s/eval/%s" % (t, k)] = np.asarray(val, np.float64)
+        store[t + "/pred"] = m.predict(xin, batch_size=50)
+        for k, p in m.state_dict().items():
+            store[t + "/final/" + k] = p.detach().numpy().copy()
+        meta.append(dict(v, spec=spec))
+        print(t, {k: np.round(val, 4).tolist() for k, val in hist.history.items()}, ev)
+    out = os.path.join(os.path.dirname(HERE), "tests", "golden", "api")
+    os.makedirs(out, exist_ok=True)
+    store["variants"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(out, "api_variants.npz"), **store)
+
+
+if __name__ == "__main__":
+    main()
