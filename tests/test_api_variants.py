@@ -84,3 +84,53 @@ def test_api_variant_on_the_stand_in(mock, monkeypatch, v):
 @pytest.mark.parametrize("v", VARIANTS, ids=lambda v: v["tag"])
 def test_api_variant_on_the_gpu(v):
     _run(v, "cuda:0")
+
+
+# ---- BASELINE.json configs[0]: the reference's Criteo example, end to end (oracle/check_criteo_example.py) -------------
+def _criteo_example(dev):
+    """examples/run_classification_criteo.py from the model definition on (the preprocessing half is checked against
+    the example's pandas / sklearn pipeline by oracle/check_criteo_example.py and tests/test_data_format.py): same
+    DeepFM kwargs, adagrad, 10 shuffled epochs of batch 32 with a 20 % validation split, predict on the held-out rows.
+    40 Adagrad steps drive the training loss from 0.63 to 0.02; the per-epoch losses stay within 5e-4 relative of the
+    reference's (measured on the numpy stand-in: 2e-7), AUC within 5e-3, the test predictions within 2e-4."""
+    from sklearn.metrics import log_loss, roc_auc_score
+    from deepctr_torch.inputs import DenseFeat, SparseFeat, get_feature_names
+    from deepctr_torch.models import DeepFM
+    z = np.load(os.path.join(GOLDEN_DIR, "api", "criteo_example.npz"), allow_pickle=False)
+    names = json.loads(str(z["names"]))
+    sparse, dense = names[:26], names[26:]
+    cols = [SparseFeat(f, vocabulary_size=int(v), embedding_dim=4) for f, v in zip(sparse, z["vocab"])] + \
+           [DenseFeat(f, 1) for f in dense]
+    assert get_feature_names(cols + cols) == names
+    model = DeepFM(linear_feature_columns=cols, dnn_feature_columns=cols, task='binary', l2_reg_embedding=1e-5,
+                   device=dev)
+    model.load_state_dict({k[len("param/"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/")})
+    model.compile("adagrad", "binary_crossentropy", metrics=["binary_crossentropy", "auc"])
+    train = {n: z["train_X"][:, i] for i, n in enumerate(names)}
+    test = {n: z["test_X"][:, i] for i, n in enumerate(names)}
+    torch.manual_seed(2020)
+    hist = model.fit(train, z["train_y"], batch_size=32, epochs=10, verbose=2, validation_split=0.2)
+    ref = {k[len("hist/"):]: z[k] for k in z.files if k.startswith("hist/")}
+    assert set(hist.history) == set(ref)
+    for k, want in ref.items():
+        got = np.asarray(hist.history[k])
+        if "auc" in k:
+            np.testing.assert_allclose(got, want, atol=5e-3, err_msg=k)
+        else:
+            np.testing.assert_allclose(got, want, rtol=5e-4, err_msg=k)
+    pred = model.predict(test, 256)
+    assert max_abs(pred, z["pred"]) <= 2e-4
+    assert abs(log_loss(z["test_y"], pred) - float(z["test_logloss"])) <= 2e-4
+    assert abs(roc_auc_score(z["test_y"], pred) - float(z["test_auc"])) <= 5e-3
+    return model
+
+
+def test_criteo_example_on_the_stand_in(mock, monkeypatch):
+    monkeypatch.setenv("DCTR_FIT_GRAPH", "0")
+    m = _criteo_example("cpu")
+    assert m.model_plan().update == ("lazy", "adagrad")          # the example's L2 terms, applied O(batch)
+
+
+@pytest.mark.gpu
+def test_criteo_example_on_the_gpu():
+    _criteo_example("cuda:0")
