@@ -26,7 +26,7 @@ def _arr(ptr, shape, ld=None, dtype=np.float32):
     return np.lib.stride_tricks.as_strided(flat, shape=(rows, cols), strides=(ld * 4, 4))
 
 
-class MockLib(object):
+class _Core(object):
     def __init__(self):
         self.calls = []
 
@@ -450,3 +450,16 @@ class MockLib(object):
 
     def dctr_strerror(self, code):
         return b"mock error"
+
+
+def _make():
+    from mock_ops import OpsMixin
+
+    class MockLib(OpsMixin, _Core):
+        """every entry point the Python stack calls: gather / update / lazy / tower / head (here) + interaction layers
+        (tests/mock_ops.py)"""
+    return MockLib
+
+
+def MockLib():
+    return _make()()

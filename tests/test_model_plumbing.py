@@ -1,16 +1,17 @@
-"""CPU: DeepFM / WDL through the real Python stack over the numpy stand-in for the library (tests/mock_lib.py), against
-the reference's golden forward values, per-parameter gradients and 3-step SGD / Adagrad trajectories
-(tests/golden/*.npz).  Pins, without a GPU, what sits between the reference-shaped API and the C-ABI: the plan's field /
-unit tables, buffer strides, the choice of update mode, the dense-gradient route (param.grad) and the in-kernel
-optimizer route.  Fixed-length fields only (the stand-in's scope); the kernels are checked by tests/test_gpu_*.py."""
+"""CPU: every model family through the real Python stack over the stand-in for the library (tests/mock_lib.py +
+tests/mock_ops.py), against the reference's golden forward values, per-parameter gradients and 3-step SGD / Adagrad
+trajectories (tests/golden/*.npz), its own model-test matrix (tests/golden/matrix) and its fit() History.  Pins, without
+a GPU, what sits between the reference-shaped API and the C-ABI: the plan's field / unit tables, buffer strides, the
+choice of update mode, the dense-gradient route (param.grad), the in-kernel optimizer route and the marshalling of every
+interaction op.  The kernels themselves are checked by tests/test_gpu_*.py."""
 import numpy as np
 import pytest
 import torch
 
-from helpers import build_model, load_golden, max_abs
+from helpers import build_model, golden_names, load_golden, max_abs
 
 DEV = "cpu"
-NAMES = ["deepfm_criteo", "deepfm_dense_only", "deepfm_fm_only", "wdl_criteo"]
+NAMES = golden_names()
 
 
 def _loaded(name):
@@ -51,13 +52,19 @@ def test_in_kernel_optimizer_trajectory(mock, name, opt):
     g, m = _loaded(name)
     if (opt + "3_loss") not in g["extra"]:
         pytest.skip("no %s trajectory in this fixture" % opt)
+    if opt == "adagrad" and name.startswith("afm"):
+        pytest.skip("AFM under Adagrad is not a reproducible trajectory (sign of ~1e-8 gradients; see test_gpu_models)")
     m.compile(opt, "binary_crossentropy", metrics=[])
     m.train()
     losses = [float(m._train_step(torch.from_numpy(Xb), torch.from_numpy(yb))[0])
               for Xb, yb in zip(g["extra"]["X_steps"], g["extra"]["y_steps"])]
-    if m.model_plan().table_params:
-        assert m.model_plan().update[0] == opt
-        assert "embed_update:%d" % (0 if opt == "sgd" else 1) in mock.calls
+    plan = m.model_plan()
+    if plan.table_params:
+        # ("lazy", opt): DCNMix keeps the reference's quirk of regularising the linear tables with BaseModel's default
+        # 1e-5 whatever l2_reg_linear says (dcnmix.py:52-54 does not forward it) -- the exact lazy form applies
+        assert plan.update[0] in (opt, "sgd2", "lazy")
+        if plan.unit_path and plan.update[0] == opt:
+            assert "embed_update:%d" % (0 if opt == "sgd" else 1) in mock.calls
     np.testing.assert_allclose(losses, g["extra"][opt + "3_loss"], rtol=5e-5)
     sd = m.state_dict()
     for k, v in g["extra"].items():
@@ -91,25 +98,25 @@ def test_fit_history_and_predict_match_reference(mock, monkeypatch, tag, opt, l2
     assert max_abs(pred, ex["fit_%s_pred" % tag]) <= 5e-5
 
 
-# ---- the reference's own DeepFM test matrix (tests/golden/matrix, oracle/check_matrix.py) on the stand-in --------------
+# ---- the reference's own model-test matrix (tests/golden/matrix, oracle/check_matrix.py) on the stand-in ---------------
 from helpers import feature_columns, load_matrix, matrix_id  # noqa: E402
 
-DEEPFM_MATRIX = [c for c in load_matrix() if c["model"] == "DeepFM"]
-
-
 def _matrix_model(c):
-    from deepctr_torch.models import DeepFM
+    import deepctr_torch.models as M
     spec = c["spec"]
-    m = DeepFM(feature_columns(spec["linear_columns"]), feature_columns(spec["dnn_columns"]), device=DEV, **c["kwargs"])
+    lin, dnn = feature_columns(spec["linear_columns"]), feature_columns(spec["dnn_columns"])
+    cls = getattr(M, c["model"])
+    m = cls(dnn, device=DEV, **c["kwargs"]) if c["model"] == "PNN" else cls(lin, dnn, device=DEV, **c["kwargs"])
     m.load_state_dict({k: torch.from_numpy(v) for k, v in c["params"].items()})
     return m
 
 
-@pytest.mark.parametrize("c", DEEPFM_MATRIX, ids=matrix_id)
+@pytest.mark.parametrize("c", load_matrix(), ids=matrix_id)
 def test_reference_matrix_forward_and_gradients(mock, c):
     """sum / mean / max VarLen columns (padding id 0 or a length column), one-row vocabularies, no-linear / no-FM /
-    zero-layer-tower variants: the plan's pooled-field descriptors and the general backward route, against the REAL
-    reference's logits (1e-5) and per-parameter gradients."""
+    zero-layer-tower / empty-CIN / every bilinear and outer-product type ...: the plan's pooled-field descriptors, the
+    general backward route and the argument marshalling of every interaction op (tests/mock_ops.py), for all ten model
+    families, against the REAL reference's logits (1e-5) and per-parameter gradients."""
     m = _matrix_model(c)
     ok = c["clean"]
     m.eval()
