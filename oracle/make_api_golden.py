@@ -6,6 +6,8 @@ the REAL reference (torch-CPU) -- what a script written against DeepCTR-Torch ma
     shared    a VarLen history column sharing the item table (embedding_name), a DenseFeat of dimension 3, 'adagrad', ['auc']
     rmsprop   compile('rmsprop', ...): an optimizer outside the in-kernel set -> exact dense gradients + torch.optim
     instance  an optimizer INSTANCE (torch.optim.Adam(lr=0.01, weight_decay=1e-4)) and a loss CALLABLE
+    split     WDL whose linear and deep sides use DIFFERENT column sets (one column only wide, one only deep, a max-pooled
+              VarLen column on both) and per-column embedding sizes 6 / 3 / 5 / 2
 
 Every run: the reference's initial state_dict, its History after 2 unshuffled epochs, evaluate() and predict().
 Runs only in the build container (needs /root/reference):   python oracle/make_api_golden.py
@@ -27,7 +29,12 @@ def variants():
     base = mg.criteo_columns(4, 2, 10, 4)
     shared = [mg.sparse("item", 12, 4), mg.varlen("hist_item", 12, 4, 4, "mean", embedding_name="item"),
               mg.dense("d3", 3), mg.sparse("user", 7, 4)]
+    split_dnn = [mg.sparse("a", 9, 6), mg.sparse("b", 7, 3), mg.varlen("c", 8, 5, 4, "max"), mg.dense("d2", 2)]
+    split_lin = [mg.sparse("b", 7, 3), mg.dense("e", 1), mg.varlen("c", 8, 5, 4, "max"), mg.sparse("z", 5, 2)]
     return [
+        dict(tag="split", model="WDL", cols=split_dnn, lin_cols=split_lin, kwargs=dict(dnn_hidden_units=(8,)), l2=0.0,
+             opt="adagrad", loss="binary_crossentropy", metrics=["binary_crossentropy"], y="binary", x="dict",
+             val="split", gpu=False),
         dict(tag="regress", cols=base, kwargs=dict(task="regression", dnn_hidden_units=(8,)), l2=1e-5, opt="adam",
              loss="mse", metrics=["mse"], y="real", x="dict", val="split"),
         dict(tag="listval", cols=base, kwargs=dict(dnn_hidden_units=(8, 4)), l2=1e-5, opt="sgd",
@@ -58,7 +65,8 @@ def main():
     store, meta = {}, []
     for v in variants():
         rng = np.random.default_rng(4242 + sum(map(ord, v["tag"])))
-        spec = {"model": "DeepFM", "linear_columns": v["cols"], "dnn_columns": v["cols"], "kwargs": v["kwargs"]}
+        spec = {"model": v.get("model", "DeepFM"), "linear_columns": v.get("lin_cols", v["cols"]),
+                "dnn_columns": v["cols"], "kwargs": v["kwargs"]}
         torch.manual_seed(0)
         m = mg.build_reference_model(ref, spec, l2=v["l2"])
         mg.randomise(m, rng)

@@ -32,10 +32,12 @@ def _model_input(m, X, as_list):
 
 
 def _run(v, dev):
-    from deepctr_torch.models import DeepFM
+    import deepctr_torch.models as M
     d = v["data"]
     cols = feature_columns(v["cols"])
-    m = DeepFM(cols, cols, l2_reg_linear=v["l2"], l2_reg_embedding=v["l2"], device=dev, **v["kwargs"])
+    lin = feature_columns(v["lin_cols"]) if "lin_cols" in v else cols
+    m = getattr(M, v.get("model", "DeepFM"))(lin, cols, l2_reg_linear=v["l2"], l2_reg_embedding=v["l2"], device=dev,
+                                               **v["kwargs"])
     m.load_state_dict({k[len("param/"):]: torch.from_numpy(val) for k, val in d.items() if k.startswith("param/")})
     opt = torch.optim.Adam(m.parameters(), lr=0.01, weight_decay=1e-4) if v["opt"] == "instance" else v["opt"]
     loss = torch.nn.functional.binary_cross_entropy if v["loss"] == "callable" else v["loss"]
@@ -80,8 +82,10 @@ def test_api_variant_on_the_stand_in(mock, monkeypatch, v):
     _run(v, "cpu")
 
 
+# ("split" was added after this round's GPU minutes were spent: it runs on the stand-in only until it has been seen green on
+# an MI355X -- drop the filter then)
 @pytest.mark.gpu
-@pytest.mark.parametrize("v", VARIANTS, ids=lambda v: v["tag"])
+@pytest.mark.parametrize("v", [v for v in VARIANTS if v.get("gpu", True)], ids=lambda v: v["tag"])
 def test_api_variant_on_the_gpu(v):
     _run(v, "cuda:0")
 
