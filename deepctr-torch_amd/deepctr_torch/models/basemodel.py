@@ -274,6 +274,11 @@ class BaseModel(nn.Module):
         else:  # generators / filters must become lists so the model stays picklable
             weight_list = list(weight_list)
         self.regularization_weight.append((weight_list, l1, l2))
+        if self.__dict__.get("optim") is not None:
+            # added after compile(): the reference evaluates its regularisers at every step, so the new term counts from
+            # the next step on -- re-derive which update path is still exact (lazy / in-kernel / fused need L2-only terms)
+            self._fused = None
+            self._apply_update_mode()
 
     def get_regularization_loss(self):
         total = torch.zeros((1,), device=self.device)

@@ -6,6 +6,8 @@ the REAL reference (torch-CPU) -- what a script written against DeepCTR-Torch ma
     shared    a VarLen history column sharing the item table (embedding_name), a DenseFeat of dimension 3, 'adagrad', ['auc']
     rmsprop   compile('rmsprop', ...): an optimizer outside the in-kernel set -> exact dense gradients + torch.optim
     instance  an optimizer INSTANCE (torch.optim.Adam(lr=0.01, weight_decay=1e-4)) and a loss CALLABLE
+    l1        add_regularization_weight(..., l1=1e-3) on the tower weights and on one table after construction (basemodel.py:
+              400-428): the regulariser is no longer L2-only, so neither the lazy nor the fused path may be taken
     split     WDL whose linear and deep sides use DIFFERENT column sets (one column only wide, one only deep, a max-pooled
               VarLen column on both) and per-column embedding sizes 6 / 3 / 5 / 2
 
@@ -32,6 +34,8 @@ def variants():
     split_dnn = [mg.sparse("a", 9, 6), mg.sparse("b", 7, 3), mg.varlen("c", 8, 5, 4, "max"), mg.dense("d2", 2)]
     split_lin = [mg.sparse("b", 7, 3), mg.dense("e", 1), mg.varlen("c", 8, 5, 4, "max"), mg.sparse("z", 5, 2)]
     return [
+        dict(tag="l1", cols=base, kwargs=dict(dnn_hidden_units=(8,)), l2=1e-5, opt="adagrad", loss="binary_crossentropy",
+             metrics=["binary_crossentropy"], y="binary", x="dict", val="split", l1=1e-3, gpu=False),
         dict(tag="split", model="WDL", cols=split_dnn, lin_cols=split_lin, kwargs=dict(dnn_hidden_units=(8,)), l2=0.0,
              opt="adagrad", loss="binary_crossentropy", metrics=["binary_crossentropy"], y="binary", x="dict",
              val="split", gpu=False),
@@ -78,6 +82,9 @@ def main():
         store[t + "/X"], store[t + "/y"], store[t + "/Xv"], store[t + "/yv"] = X, y, Xv, yv
         for k, p in m.state_dict().items():
             store[t + "/param/" + k] = p.detach().numpy().copy()
+        if v.get("l1"):           # user-added L1 terms: on the tower weights and on one embedding table
+            m.add_regularization_weight(filter(lambda kv: "weight" in kv[0], m.dnn.named_parameters()), l1=v["l1"])
+            m.add_regularization_weight(m.embedding_dict["C1"].weight, l1=v["l1"])
         opt = torch.optim.Adam(m.parameters(), lr=0.01, weight_decay=1e-4) if v["opt"] == "instance" else v["opt"]
         loss = F.binary_cross_entropy if v["loss"] == "callable" else v["loss"]
         m.compile(opt, loss, metrics=v["metrics"])

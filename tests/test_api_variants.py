@@ -39,6 +39,9 @@ def _run(v, dev):
     m = getattr(M, v.get("model", "DeepFM"))(lin, cols, l2_reg_linear=v["l2"], l2_reg_embedding=v["l2"], device=dev,
                                                **v["kwargs"])
     m.load_state_dict({k[len("param/"):]: torch.from_numpy(val) for k, val in d.items() if k.startswith("param/")})
+    if v.get("l1"):
+        m.add_regularization_weight(filter(lambda kv: "weight" in kv[0], m.dnn.named_parameters()), l1=v["l1"])
+        m.add_regularization_weight(m.embedding_dict["C1"].weight, l1=v["l1"])
     opt = torch.optim.Adam(m.parameters(), lr=0.01, weight_decay=1e-4) if v["opt"] == "instance" else v["opt"]
     loss = torch.nn.functional.binary_cross_entropy if v["loss"] == "callable" else v["loss"]
     m.compile(opt, loss, metrics=v["metrics"])
@@ -138,3 +141,28 @@ def test_criteo_example_on_the_stand_in(mock, monkeypatch):
 @pytest.mark.gpu
 def test_criteo_example_on_the_gpu():
     _criteo_example("cuda:0")
+
+
+def test_regulariser_added_after_compile_counts(mock, monkeypatch):
+    """The reference evaluates ``regularization_weight`` at every step (basemodel.py:257,412-428), so a term added AFTER
+    compile() takes effect; here the update path chosen at compile time (lazy / in-kernel / fused: L2-only) must be
+    re-derived.  Same fixture as 'l1' -- the reference's result does not depend on the order of the two calls."""
+    monkeypatch.setenv("DCTR_FIT_GRAPH", "0")
+    from deepctr_torch.models import DeepFM
+    v = [v for v in VARIANTS if v["tag"] == "l1"][0]
+    d = v["data"]
+    cols = feature_columns(v["cols"])
+    m = DeepFM(cols, cols, l2_reg_linear=v["l2"], l2_reg_embedding=v["l2"], device="cpu", **v["kwargs"])
+    m.load_state_dict({k[len("param/"):]: torch.from_numpy(val) for k, val in d.items() if k.startswith("param/")})
+    m.compile("adagrad", "binary_crossentropy", metrics=["binary_crossentropy"])
+    assert m.model_plan().update == ("lazy", "adagrad")
+    m.add_regularization_weight(filter(lambda kv: "weight" in kv[0], m.dnn.named_parameters()), l1=v["l1"])
+    m.add_regularization_weight(m.embedding_dict["C1"].weight, l1=v["l1"])
+    assert m.model_plan().update == ("dense",)
+    hist = m.fit(_model_input(m, d["X"], False), d["y"], batch_size=32, epochs=2, verbose=0, shuffle=False,
+                 validation_split=0.2)
+    np.testing.assert_allclose(hist.history["loss"], d["hist/loss"], rtol=2e-4)
+    sd = m.state_dict()
+    for k, val in d.items():
+        if k.startswith("final/"):
+            assert max_abs(sd[k[len("final/"):]].numpy(), val) <= 5e-5, k
