@@ -277,8 +277,7 @@ class BaseModel(nn.Module):
         if self.__dict__.get("optim") is not None:
             # added after compile(): the reference evaluates its regularisers at every step, so the new term counts from
             # the next step on -- re-derive which update path is still exact (lazy / in-kernel / fused need L2-only terms)
-            self._fused = None
-            self._apply_update_mode()
+            self._rederive_update_paths()
 
     def get_regularization_loss(self):
         total = torch.zeros((1,), device=self.device)
@@ -318,6 +317,45 @@ class BaseModel(nn.Module):
         self.optim = self._get_optim(optimizer)
         self.loss_func = self._get_loss_func(loss)
         self.metrics = self._get_metrics(metrics)
+        self._apply_update_mode()
+        self._hyper_sig = self._optim_signature()
+
+    _HYPER_KEYS = ("lr", "eps", "betas", "weight_decay", "momentum", "dampening", "nesterov", "lr_decay", "alpha",
+                   "centered", "amsgrad", "maximize", "initial_accumulator_value")
+
+    def _optim_signature(self):
+        """The optimizer's hyper-parameters as a comparable value.  The O(batch) paths bake lr / eps / betas into
+        kernel arguments (and into captured hipGraphs); the reference reads ``param_groups`` at every step, so a
+        learning-rate schedule stepping ``model.optim`` between epochs must be honoured here too."""
+        opt = self.__dict__.get("optim")
+        if opt is None:
+            return None
+        sig = []
+        for grp in opt.param_groups:
+            row = []
+            for k in self._HYPER_KEYS:
+                v = grp.get(k)
+                if torch.is_tensor(v):
+                    v = float(v) if v.numel() == 1 and not v.is_cuda else id(v)
+                row.append(tuple(v) if isinstance(v, (list, tuple)) else v)
+            sig.append(tuple(row))
+        return tuple(sig)
+
+    def _sync_optimizer_hyper(self):
+        """Re-derive the update paths when the optimizer's hyper-parameters changed since they were last looked at
+        (lazily replayed rows are first flushed with the OLD values: _apply_update_mode)."""
+        sig = self._optim_signature()
+        if sig != self.__dict__.get("_hyper_sig"):
+            self._hyper_sig = sig
+            self._rederive_update_paths()
+
+    def _rederive_update_paths(self):
+        """Something the O(batch) paths were derived from changed (hyper-parameters, the set of regularisers): bring
+        every lazily replayed row and the optimizer's ``step`` entries up to date under the OLD settings, drop the
+        fused-step state and any captured step, choose the paths again."""
+        self._flush_lazy()
+        self._fused = None
+        self._fit_graph = None
         self._apply_update_mode()
 
     def _get_optim(self, optimizer):
@@ -652,6 +690,7 @@ class BaseModel(nn.Module):
         (reference basemodel.py:242-262).  Returns device tensors; nothing is synchronised."""
         # (not tied to self.training: like the reference, fit() keeps training in eval mode after the first validation
         # pass, basemodel.py:215,331; the fused step has no mode-dependent layer -- dropout / BatchNorm rule it out)
+        self._sync_optimizer_hyper()
         if self._aux_is_default():
             st = self._fused_step_state()
             if st is not None:
@@ -695,6 +734,7 @@ class BaseModel(nn.Module):
         shape, 0.63 instead of 1.2 ms for DCN) whenever the step is replay-safe (``_graph_safe_step``); everything
         else -- the ragged last batch, steps that bake host-side values into their launches, CPU-side debugging with
         DCTR_FIT_GRAPH=0 -- runs ``_train_step`` directly.  Same arithmetic either way."""
+        self._sync_optimizer_hyper()                # (drops a captured step whose launches carry the old values)
         g = self._fit_graph
         if xb.shape[0] != batch_size or not xb.is_cuda or os.environ.get("DCTR_FIT_GRAPH", "1") == "0":
             return self._train_step(xb, yb)

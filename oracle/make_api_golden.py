@@ -13,6 +13,7 @@ the REAL reference (torch-CPU) -- what a script written against DeepCTR-Torch ma
 
 Every run: the reference's initial state_dict, its History after 2 unshuffled epochs, evaluate() and predict().
 Runs only in the build container (needs /root/reference):   python oracle/make_api_golden.py
+                                                             python oracle/make_api_golden.py --schedule   (lr_schedule.npz)
 """
 import json
 import os
@@ -111,5 +112,56 @@ def main():
     np.savez_compressed(os.path.join(out, "api_variants.npz"), **store)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--schedule" not in sys.argv:
     main()
+
+
+# ---- learning-rate schedules on model.optim (tests/golden/api/lr_schedule.npz) ------------------------------------------
+SCHED_RUNS = (("adagrad0", "adagrad", 0.0), ("adam", "adam", 1e-5), ("sgd", "sgd", 1e-3), ("adagrad", "adagrad", 1e-3))
+SCHED_STEPS, SCHED_AT, SCHED_GAMMA = 9, (3, 6), 0.5
+
+
+def lr_schedule():
+    """9 reference training steps (basemodel.py:242-262) of DeepFM with ``param_groups[*]['lr'] *= 0.5`` after steps 3
+    and 6 -- what ``torch.optim.lr_scheduler.StepLR(model.optim, 3, 0.5)`` stepped from a callback does.  Small batches
+    over 20-row vocabularies: rows wait several steps between touches, so the lazily replayed rows cross the boundaries."""
+    import torch
+    ref = mg.import_reference()
+    cols = mg.criteo_columns(8, 3, 20, 8)
+    spec = {"model": "DeepFM", "linear_columns": cols, "dnn_columns": cols, "kwargs": {"dnn_hidden_units": (16, 8)}}
+    rng = np.random.default_rng(99)
+    torch.manual_seed(0)
+    m0 = mg.build_reference_model(ref, spec)
+    mg.randomise(m0, rng)
+    start = {k: v.clone() for k, v in m0.state_dict().items()}
+    Xs, ys = zip(*[mg.synth_inputs(spec, 24, rng) for _ in range(SCHED_STEPS)])
+    store = {"spec": np.array(json.dumps(spec)), "X": np.stack(Xs), "y": np.stack(ys)}
+    for k, v in start.items():
+        store["param/" + k] = v.numpy().copy()
+    for tag, opt, l2 in SCHED_RUNS:
+        torch.manual_seed(0)
+        m = mg.build_reference_model(ref, spec, l2=l2)
+        m.load_state_dict(start)
+        m.compile(opt, "binary_crossentropy", metrics=[])
+        m.train()
+        tot = []
+        for i, (Xb, yb) in enumerate(zip(Xs, ys)):
+            if i in SCHED_AT:
+                for grp in m.optim.param_groups:
+                    grp["lr"] *= SCHED_GAMMA
+            yp = m(torch.from_numpy(Xb)).squeeze()
+            m.optim.zero_grad()
+            total = m.loss_func(yp, torch.from_numpy(yb), reduction="sum") + m.get_regularization_loss() + m.aux_loss
+            total.backward()
+            m.optim.step()
+            tot.append(total.item())
+        store[tag + "/total"] = np.asarray(tot, np.float64)
+        for k, v in m.state_dict().items():
+            store["%s/final/%s" % (tag, k)] = v.detach().numpy().copy()
+        print(tag, np.round(tot, 4).tolist())
+    out = os.path.join(os.path.dirname(HERE), "tests", "golden", "api")
+    np.savez_compressed(os.path.join(out, "lr_schedule.npz"), **store)
+
+
+if __name__ == "__main__" and "--schedule" in sys.argv:
+    lr_schedule()

@@ -166,3 +166,42 @@ def test_regulariser_added_after_compile_counts(mock, monkeypatch):
     for k, val in d.items():
         if k.startswith("final/"):
             assert max_abs(sd[k[len("final/"):]].numpy(), val) <= 5e-5, k
+
+
+# ---- learning-rate schedules stepping model.optim (tests/golden/api/lr_schedule.npz) --------------------------------------
+SCHED_RUNS = (("adagrad0", "adagrad", 0.0), ("adam", "adam", 1e-5), ("sgd", "sgd", 1e-3), ("adagrad", "adagrad", 1e-3))
+
+
+def _schedule(tag, opt, l2, dev):
+    """9 steps of the REAL reference with lr halved after steps 3 and 6 (oracle/make_api_golden.py --schedule).  The
+    O(batch) paths carry lr in kernel arguments; lazily replayed rows must be brought up to date with the OLD rate
+    before the new one applies.  Total loss per step and final parameters, 5e-5 relative."""
+    from deepctr_torch.models import DeepFM
+    z = np.load(os.path.join(GOLDEN_DIR, "api", "lr_schedule.npz"), allow_pickle=False)
+    spec = json.loads(str(z["spec"]))
+    cols = feature_columns(spec["dnn_columns"])
+    m = DeepFM(cols, cols, l2_reg_linear=l2, l2_reg_embedding=l2, device=dev, **spec["kwargs"])
+    m.load_state_dict({k[len("param/"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/")})
+    m.compile(opt, "binary_crossentropy", metrics=[])
+    m.train()
+    tot = []
+    for i in range(z["X"].shape[0]):
+        if i in (3, 6):
+            for grp in m.optim.param_groups:
+                grp["lr"] *= 0.5
+        _, total, _ = m._train_step(torch.from_numpy(z["X"][i]).to(dev), torch.from_numpy(z["y"][i]).to(dev))
+        tot.append(float(total))
+    np.testing.assert_allclose(tot, z[tag + "/total"], rtol=5e-5)
+    sd = m.state_dict()
+    pre = tag + "/final/"
+    for k in z.files:
+        if k.startswith(pre):
+            ref = z[k]
+            assert max_abs(sd[k[len(pre):]].cpu().numpy(), ref) <= 5e-5 * max(1.0, float(np.abs(ref).max())), k
+    return m
+
+
+@pytest.mark.parametrize("tag,opt,l2", SCHED_RUNS)
+def test_lr_schedule_on_the_stand_in(mock, tag, opt, l2):
+    m = _schedule(tag, opt, l2, "cpu")
+    assert m.model_plan().update[0] in ("lazy", "adagrad")
