@@ -378,6 +378,11 @@ class EmbeddingPlan(object):
         from zero, later backwards accumulate)."""
         for p in self._params:
             slab = _GACC[p]
+            if not p.requires_grad:
+                # a frozen table (pretrained embeddings): like autograd, hand the optimizer no gradient.  The scatter
+                # still lands in the slab; it is zeroed before it is next used as a gradient.
+                slab._dctr_dirty = True
+                continue
             if p.grad is None:
                 if getattr(slab, "_dctr_dirty", False):
                     slab.zero_()

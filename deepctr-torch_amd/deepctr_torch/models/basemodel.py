@@ -318,7 +318,8 @@ class BaseModel(nn.Module):
         self.loss_func = self._get_loss_func(loss)
         self.metrics = self._get_metrics(metrics)
         self._apply_update_mode()
-        self._hyper_sig = self._optim_signature()
+        self._hyper_sig = self._hyper_raw = None
+        self._sync_optimizer_hyper()          # records the values the paths were derived from
 
     _HYPER_KEYS = ("lr", "eps", "betas", "weight_decay", "momentum", "dampening", "nesterov", "lr_decay", "alpha",
                    "centered", "amsgrad", "maximize", "initial_accumulator_value")
@@ -341,13 +342,35 @@ class BaseModel(nn.Module):
             sig.append(tuple(row))
         return tuple(sig)
 
-    def _sync_optimizer_hyper(self):
-        """Re-derive the update paths when the optimizer's hyper-parameters changed since they were last looked at
-        (lazily replayed rows are first flushed with the OLD values: _apply_update_mode)."""
-        sig = self._optim_signature()
+    def _sync_optimizer_hyper(self, full=True):
+        """Re-derive the update paths when the optimizer's hyper-parameters (or, with ``full``, the set of frozen
+        tables) changed since they were last looked at; lazily replayed rows are first flushed with the OLD values.
+        The common case -- nothing changed -- is one list comparison (~1 us): this runs at every step of fit()."""
+        opt = self.__dict__.get("optim")
+        if opt is None:
+            return
+        raw = [grp.get(k) for grp in opt.param_groups for k in self._HYPER_KEYS]
+        raw.append(id(opt))
+        if full and self._plan is not None:
+            raw.append(tuple(p.requires_grad for p in self._plan.table_params))
+        else:
+            raw.append(None)
+        cached = self.__dict__.get("_hyper_raw")
+        try:
+            same = cached is not None and raw[:-1] == cached[:-1] and (raw[-1] is None or raw[-1] == cached[-1])
+        except Exception:           # tensor-valued hyper-parameters do not compare with ==
+            same = False
+        if same:
+            return
+        if raw[-1] is None and cached is not None:
+            raw[-1] = cached[-1]
+        self._hyper_raw = raw
+        sig = (self._optim_signature(), raw[-1])
         if sig != self.__dict__.get("_hyper_sig"):
+            first = self.__dict__.get("_hyper_sig") is None
             self._hyper_sig = sig
-            self._rederive_update_paths()
+            if not first:
+                self._rederive_update_paths()
 
     def _rederive_update_paths(self):
         """Something the O(batch) paths were derived from changed (hyper-parameters, the set of regularisers): bring
@@ -422,8 +445,8 @@ class BaseModel(nn.Module):
         if opt is None or self._plan is None or os.environ.get("DCTR_SPARSE_UPDATE", "1") == "0":
             return ("dense",), {}
         tables = self._plan.table_params
-        if not tables or self._embedding_reg_active():
-            return ("dense",), {}
+        if not tables or self._embedding_reg_active() or not all(p.requires_grad for p in tables):
+            return ("dense",), {}         # (a frozen table: the in-kernel optimizers would move it)
         group_of = {}
         for grp in opt.param_groups:
             for p in grp["params"]:
@@ -458,7 +481,8 @@ class BaseModel(nn.Module):
                 os.environ.get("DCTR_SPARSE_UPDATE", "1") == "0":
             return None
         tables = plan.table_params
-        if not tables or not plan.unit_path or plan.max_dim > 64 * (4 if plan.vec == 4 else 1):
+        if not tables or not plan.unit_path or plan.max_dim > 64 * (4 if plan.vec == 4 else 1) or \
+                not all(p.requires_grad for p in tables):
             return None
         l2 = {}
         tids = set(id(p) for p in tables)
@@ -734,7 +758,7 @@ class BaseModel(nn.Module):
         shape, 0.63 instead of 1.2 ms for DCN) whenever the step is replay-safe (``_graph_safe_step``); everything
         else -- the ragged last batch, steps that bake host-side values into their launches, CPU-side debugging with
         DCTR_FIT_GRAPH=0 -- runs ``_train_step`` directly.  Same arithmetic either way."""
-        self._sync_optimizer_hyper()                # (drops a captured step whose launches carry the old values)
+        self._sync_optimizer_hyper(full=False)      # (drops a captured step whose launches carry the old values)
         g = self._fit_graph
         if xb.shape[0] != batch_size or not xb.is_cuda or os.environ.get("DCTR_FIT_GRAPH", "1") == "0":
             return self._train_step(xb, yb)
@@ -781,6 +805,7 @@ class BaseModel(nn.Module):
             x, val_x = slice_arrays(x, 0, split_at), slice_arrays(x, split_at)
             y, val_y = slice_arrays(y, 0, split_at), slice_arrays(y, split_at)
 
+        self._sync_optimizer_hyper()
         X_all = self._as_matrix(x)                                   # resident in HBM for the whole fit
         y_all = torch.from_numpy(np.asarray(y)).to(self.device).float()
         if batch_size is None:

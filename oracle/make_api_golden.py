@@ -159,6 +159,28 @@ def lr_schedule():
         for k, v in m.state_dict().items():
             store["%s/final/%s" % (tag, k)] = v.detach().numpy().copy()
         print(tag, np.round(tot, 4).tolist())
+    # frozen tables (pretrained embeddings): requires_grad_(False) on one deep and one wide table before compile();
+    # autograd hands the optimizer no gradient for them, their L2 term still counts in the logged loss
+    for tag, opt, l2 in (("freeze_adagrad", "adagrad", 0.0), ("freeze_adam", "adam", 1e-5)):
+        torch.manual_seed(0)
+        m = mg.build_reference_model(ref, spec, l2=l2)
+        m.load_state_dict(start)
+        m.embedding_dict["C1"].weight.requires_grad_(False)
+        m.linear_model.embedding_dict["C2"].weight.requires_grad_(False)
+        m.compile(opt, "binary_crossentropy", metrics=[])
+        m.train()
+        tot = []
+        for Xb, yb in list(zip(Xs, ys))[:4]:
+            yp = m(torch.from_numpy(Xb)).squeeze()
+            m.optim.zero_grad()
+            total = m.loss_func(yp, torch.from_numpy(yb), reduction="sum") + m.get_regularization_loss() + m.aux_loss
+            total.backward()
+            m.optim.step()
+            tot.append(total.item())
+        store[tag + "/total"] = np.asarray(tot, np.float64)
+        for k, v in m.state_dict().items():
+            store["%s/final/%s" % (tag, k)] = v.detach().numpy().copy()
+        print(tag, np.round(tot, 4).tolist())
     out = os.path.join(os.path.dirname(HERE), "tests", "golden", "api")
     np.savez_compressed(os.path.join(out, "lr_schedule.npz"), **store)
 

@@ -205,3 +205,36 @@ def _schedule(tag, opt, l2, dev):
 def test_lr_schedule_on_the_stand_in(mock, tag, opt, l2):
     m = _schedule(tag, opt, l2, "cpu")
     assert m.model_plan().update[0] in ("lazy", "adagrad")
+
+
+@pytest.mark.parametrize("tag,opt,l2", [("freeze_adagrad", "adagrad", 0.0), ("freeze_adam", "adam", 1e-5)])
+def test_frozen_tables_on_the_stand_in(mock, tag, opt, l2):
+    """requires_grad_(False) on one deep and one wide table (pretrained embeddings): the REAL reference leaves them
+    untouched (autograd yields no gradient, torch.optim skips them) while everything else trains.  The in-kernel / lazy
+    optimizers would move every table, so the exact dense-gradient route must be chosen, without a gradient for the
+    frozen ones.  4 steps: total loss and every final parameter."""
+    from deepctr_torch.models import DeepFM
+    z = np.load(os.path.join(GOLDEN_DIR, "api", "lr_schedule.npz"), allow_pickle=False)
+    spec = json.loads(str(z["spec"]))
+    cols = feature_columns(spec["dnn_columns"])
+    m = DeepFM(cols, cols, l2_reg_linear=l2, l2_reg_embedding=l2, device="cpu", **spec["kwargs"])
+    m.load_state_dict({k[len("param/"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/")})
+    frozen = [m.embedding_dict["C1"].weight, m.linear_model.embedding_dict["C2"].weight]
+    for p in frozen:
+        p.requires_grad_(False)
+    before = [p.detach().clone() for p in frozen]
+    m.compile(opt, "binary_crossentropy", metrics=[])
+    assert m.model_plan().update == ("dense",)
+    m.train()
+    tot = [float(m._train_step(torch.from_numpy(z["X"][i]), torch.from_numpy(z["y"][i]))[1]) for i in range(4)]
+    np.testing.assert_allclose(tot, z[tag + "/total"], rtol=5e-5)
+    assert all(torch.equal(p.detach(), b) for p, b in zip(frozen, before))
+    sd, pre = m.state_dict(), tag + "/final/"
+    for k in z.files:
+        if k.startswith(pre):
+            assert max_abs(sd[k[len(pre):]].numpy(), z[k]) <= 5e-5 * max(1.0, float(np.abs(z[k]).max())), k
+    # thawing them brings the O(batch) path back at the next step
+    for p in frozen:
+        p.requires_grad_(True)
+    m._train_step(torch.from_numpy(z["X"][4]), torch.from_numpy(z["y"][4]))
+    assert m.model_plan().update[0] in ("adagrad", "lazy")
