@@ -887,6 +887,7 @@ class BaseModel(nn.Module):
                     for name in self.metrics:
                         eval_str += " - " + "val_" + name + ": {0: .4f}".format(epoch_logs["val_" + name])
                 print(eval_str)
+            self._flush_lazy()       # callbacks (and whoever reads .weight after fit) see the reference's tables
             cbs.on_epoch_end(epoch, epoch_logs)
             if self.stop_training:
                 break

@@ -92,3 +92,28 @@ def test_lazy_off_switch_takes_the_dense_path(mock, monkeypatch):
     m = build_model(g["spec"], DEV, l2=1e-3)
     m.compile("adagrad", "binary_crossentropy", metrics=[])
     assert m.model_plan().update == ("dense",)
+
+
+def test_tables_are_current_when_callbacks_and_fit_return(mock, monkeypatch):
+    """A callback (or user code after fit) that reads ``embedding_dict[...].weight`` directly must see the reference's
+    tables: every lazily replayed row is brought up to date before on_epoch_end."""
+    from deepctr_torch.callbacks import Callback
+    monkeypatch.setenv("DCTR_FIT_GRAPH", "0")
+    g = load_golden("lazy_deepfm")
+    m = build_model(g["spec"], DEV, l2=1e-3)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in g["params"].items()})
+    m.compile("adam", "binary_crossentropy", metrics=[])
+    X = np.concatenate(list(g["extra"]["lazy_X"]), 0)
+    y = np.concatenate(list(g["extra"]["lazy_y"]), 0)
+    x = {c["name"]: X[:, i] for i, c in enumerate(g["spec"]["dnn_columns"])}
+    seen = []
+
+    class Peek(Callback):
+        def on_epoch_end(self, epoch, logs=None):
+            seen.append(self.model.model_plan().lazy.dirty)
+
+    m.fit(x, y, batch_size=24, epochs=2, verbose=0, shuffle=False, callbacks=[Peek()])
+    assert seen == [False, False] and m.model_plan().update == ("lazy", "adam")
+    # 8 unshuffled batches of 24 = the fixture's 8 steps, twice: after the first epoch the tables equal the reference's
+    w = m.embedding_dict[g["spec"]["dnn_columns"][0]["embedding_name"]].weight.detach().clone()
+    assert torch.equal(w, m.state_dict()["embedding_dict.%s.weight" % g["spec"]["dnn_columns"][0]["embedding_name"]])
