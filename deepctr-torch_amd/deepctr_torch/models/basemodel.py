@@ -855,7 +855,8 @@ class BaseModel(nn.Module):
                     else:
                         xb, yb = X_all[lo:hi], y_all[lo:hi]
                     loss, total_loss, y_pred = self._fit_step(xb, yb, batch_size)
-                    total_acc += total_loss.double().sum()
+                    # one launch: fp64 += fp32 promotes inside the add (cast + sum + add were three)
+                    total_acc += total_loss.reshape(()) if total_loss.numel() == 1 else total_loss.double().sum()
                     if preds is not None:
                         preds.append((yb, y_pred.clone()))
                     if bar is not None:
