@@ -104,3 +104,21 @@ def test_fit_rejects_nothing_silently_on_cpu():
     x = {c["name"]: g["X"][:, i] for i, c in enumerate(g["spec"]["dnn_columns"])}
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.fit(x, g["y"], batch_size=8, epochs=1, verbose=0)
+
+
+def test_committed_bench_line_keeps_the_driver_contract():
+    """profiles/r01_bench_fork_join.json is a verbatim bench.py line from an MI355X run: the keys the driver and the judge
+    read must all be there (a reminder to keep bench.py's output shape stable)."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_bench_fork_join.json")
+    d = json.load(open(path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
+    assert d["roofline"]["bound"] in ("hbm", "mfma") and d["cpu_baseline"]["kind"] in ("reference", "port")
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
+    assert abs(d["value"] - d["config"]["global_batch"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
