@@ -365,7 +365,7 @@ class BaseModel(nn.Module):
         if raw[-1] is None and cached is not None:
             raw[-1] = cached[-1]
         self._hyper_raw = raw
-        sig = (self._optim_signature(), raw[-1])
+        sig = (self._optim_signature(), id(opt), raw[-1])      # (a replaced optimizer object brings its own state)
         if sig != self.__dict__.get("_hyper_sig"):
             first = self.__dict__.get("_hyper_sig") is None
             self._hyper_sig = sig

@@ -238,3 +238,40 @@ def test_frozen_tables_on_the_stand_in(mock, tag, opt, l2):
         p.requires_grad_(True)
     m._train_step(torch.from_numpy(z["X"][4]), torch.from_numpy(z["y"][4]))
     assert m.model_plan().update[0] in ("adagrad", "lazy")
+
+
+def test_replaced_optimizer_object_restarts_its_state(mock):
+    """``model.optim = torch.optim.Adagrad(model.parameters())`` after some steps: a NEW optimizer starts from fresh
+    accumulators; the in-kernel Adagrad must follow the new object's state tensors, not keep the old ones."""
+    from deepctr_torch.models import DeepFM
+    z = np.load(os.path.join(GOLDEN_DIR, "api", "lr_schedule.npz"), allow_pickle=False)
+    spec = json.loads(str(z["spec"]))
+    cols = feature_columns(spec["dnn_columns"])
+
+    def steps(m, lo, hi):
+        for i in range(lo, hi):
+            m._train_step(torch.from_numpy(z["X"][i]), torch.from_numpy(z["y"][i]))
+
+    def fresh():
+        m = DeepFM(cols, cols, l2_reg_linear=0, l2_reg_embedding=0, device="cpu", **spec["kwargs"])
+        m.load_state_dict({k[len("param/"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/")})
+        m.compile("adagrad", "binary_crossentropy", metrics=[])
+        m.train()
+        return m
+    a = fresh()
+    steps(a, 0, 3)
+    a.optim = torch.optim.Adagrad(a.parameters())           # fast paths must notice
+    steps(a, 3, 6)
+    import os as _os
+    _os.environ["DCTR_SPARSE_UPDATE"] = "0"                  # the exact dense-gradient route as the yardstick
+    try:
+        b = fresh()
+        steps(b, 0, 3)
+        b.optim = torch.optim.Adagrad(b.parameters())
+        steps(b, 3, 6)
+    finally:
+        del _os.environ["DCTR_SPARSE_UPDATE"]
+    sa, sb = a.state_dict(), b.state_dict()
+    assert a.model_plan().update[0] == "adagrad" and b.model_plan().update == ("dense",)
+    for k in sa:
+        assert max_abs(sa[k].numpy(), sb[k].numpy()) <= 2e-6, k
