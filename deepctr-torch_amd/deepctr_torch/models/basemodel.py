@@ -351,6 +351,8 @@ class BaseModel(nn.Module):
             return
         raw = [grp.get(k) for grp in opt.param_groups for k in self._HYPER_KEYS]
         raw.append(id(opt))
+        raw.append(id(self.__dict__.get("loss_func")))          # the fused step bakes in BCE
+        raw.append(len(self.regularization_weight))            # (appended to directly, not via add_regularization_weight)
         if full and self._plan is not None:
             raw.append(tuple(p.requires_grad for p in self._plan.table_params))
         else:
@@ -365,7 +367,7 @@ class BaseModel(nn.Module):
         if raw[-1] is None and cached is not None:
             raw[-1] = cached[-1]
         self._hyper_raw = raw
-        sig = (self._optim_signature(), id(opt), raw[-1])      # (a replaced optimizer object brings its own state)
+        sig = (self._optim_signature(), raw[-4], raw[-3], raw[-2], raw[-1])   # (+ optimizer object, loss, #regularisers, frozen tables)
         if sig != self.__dict__.get("_hyper_sig"):
             first = self.__dict__.get("_hyper_sig") is None
             self._hyper_sig = sig
