@@ -906,10 +906,14 @@ class BaseModel(nn.Module):
         self.eval()  # like the reference (:331), predict leaves the model in eval mode
         X_all = self._as_matrix(x)
         torch.empty((), dtype=torch.int64).random_()     # the base seed the reference's DataLoader iterator draws (:340)
+        # In eval mode every sample's prediction is independent of its batch (no batch statistics, no dropout), so the
+        # caller's batch_size -- 256 by default in the reference, i.e. ~4 launches per 256 rows -- only sets a lower
+        # bound on the rows per launch here: identical values, far fewer launches.
+        step = max(int(batch_size), int(os.environ.get("DCTR_PREDICT_ROWS", "8192")))
         chunks = []
         with torch.no_grad():
-            for lo in range(0, X_all.shape[0], batch_size):
-                chunks.append(self(X_all[lo:lo + batch_size]))
+            for lo in range(0, X_all.shape[0], step):
+                chunks.append(self(X_all[lo:lo + step]))
         if self._plan is not None:
             self._plan.check_ids()
         return torch.cat(chunks).cpu().numpy().astype("float64")
