@@ -51,8 +51,8 @@ class AFMLayer(nn.Module):
     projected to one logit -- list of F ``[B, 1, D]`` tensors (or one ``[B, F, D]`` tensor) ``-> [B, 1]`` (reference
     interaction.py:251-325; same constructor, same parameters ``attention_W [D, A]``, ``attention_b [A]``,
     ``projection_h [A, 1]``, ``projection_p [D, 1]``).  One kernel forward, one backward (``csrc/afm.hip``); with an
-    active dropout on the attention output the same math runs as PyTorch-ROCm ops (the mask sits between two fused
-    stages)."""
+    active dropout on the attention output (the mask sits between two fused stages) or a shape outside the kernel
+    (embedding_size > 64, attention_factor > 32, more than 64 fields) the same math runs as PyTorch-ROCm ops."""
 
     def __init__(self, in_features, attention_factor=4, l2_reg_w=0, dropout_rate=0, seed=1024, device='cpu'):
         super(AFMLayer, self).__init__()
@@ -76,7 +76,9 @@ class AFMLayer(nn.Module):
         E = torch.cat(list(inputs), dim=1) if isinstance(inputs, (list, tuple)) else inputs
         if E.dim() != 3:
             raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % E.dim())
-        if self.dropout_rate and self.training:
+        F_, D_ = E.shape[1], E.shape[2]
+        outside = D_ > 64 or self.attention_factor > 32 or F_ > 64       # the kernel's envelope (csrc/afm.hip)
+        if (self.dropout_rate and self.training) or outside:
             F_ = E.shape[1]
             idx = torch.triu_indices(F_, F_, 1, device=E.device)
             bi = E[:, idx[0]] * E[:, idx[1]]
@@ -213,7 +215,15 @@ class CIN(nn.Module):
         final_result = []
         for i, size in enumerate(self.layer_size):
             conv = self.conv1ds[i]
-            curr_out = _ops.CINLayerFunction.apply(hidden, x0, conv.weight.squeeze(-1), conv.bias, fused_relu)
+            if x0.shape[1] <= 32:
+                curr_out = _ops.CINLayerFunction.apply(hidden, x0, conv.weight.squeeze(-1), conv.bias, fused_relu)
+            else:
+                # more fields than the MFMA kernel tiles (csrc/cin.hip: M <= 32), e.g. Criteo with its 13 dense
+                # columns bucketised into fields: the reference's own formulation on PyTorch-ROCm (hipBLASLt)
+                z = (hidden.unsqueeze(2) * x0.unsqueeze(1)).reshape(x0.shape[0], -1, x0.shape[2])
+                curr_out = torch.einsum("oz,bzd->bod", conv.weight.squeeze(-1), z) + conv.bias[None, :, None]
+                if fused_relu:
+                    curr_out = torch.relu(curr_out)
             if not fused_relu and self.activation is not None:
                 curr_out = self.activation(curr_out)
             if self.split_half:
@@ -281,16 +291,33 @@ class BilinearInteraction(nn.Module):
             self._meta = (n_fields, _ops.BilinearMeta(n_fields, self.bilinear_type))
         return self._meta[1]
 
+    def _pairs_torch(self, X):
+        """``[B, F, D] -> [B, P, D]`` as batched GEMMs on PyTorch-ROCm: embedding_size > 16 is outside the MFMA kernel
+        (csrc/pairwise.hip tiles D <= 16)."""
+        F = X.shape[1]
+        idx = torch.triu_indices(F, F, 1, device=X.device)
+        left, right = X[:, idx[0]], X[:, idx[1]]
+        if self.bilinear_type == "all":
+            return torch.matmul(left, self.bilinear.weight.t()) * right
+        W = torch.stack(self._weights())                       # [F | P, D_out, D_in]
+        Wp = W[idx[0]] if self.bilinear_type == "each" else W
+        return torch.einsum("bpd,ped->bpe", left, Wp) * right
+
     def forward(self, inputs):
         if len(inputs.shape) != 3:
             raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % (len(inputs.shape)))
         B, F, D = inputs.shape
+        if D > 16:
+            return self._pairs_torch(inputs)
         out = _ops.BilinearFunction.apply(self.meta(F), inputs, None, None, *self._weights())
         return out.reshape(B, F * (F - 1) // 2, D)
 
     def fused_pair(self, raw, senet, dense=None):
         """FiBiNET's ``cat(Bilinear(senet), Bilinear(raw))`` flattened, followed by the dense features: the DNN input
         of fibinet.py:82-87 produced by one launch that loads every weight tile once for both passes."""
+        if raw.shape[2] > 16:
+            parts = [self._pairs_torch(senet).flatten(1), self._pairs_torch(raw).flatten(1)]
+            return torch.cat(parts + ([dense] if dense is not None else []), dim=1)
         return _ops.BilinearFunction.apply(self.meta(raw.shape[1]), raw, senet, dense, *self._weights())
 
 
@@ -374,8 +401,13 @@ class CrossNet(nn.Module):
     def forward(self, inputs):
         if self.layer_num == 0:
             return inputs
-        if self.parameterization == 'vector':
+        if self.parameterization == 'vector' and inputs.shape[1] <= 2048:
             return _ops.CrossNetVecFunction.apply(inputs, self.kernels, self.bias)
+        if self.parameterization == 'vector':          # wider than the wave-per-sample kernel holds: PyTorch-ROCm ops
+            x_0 = x_l = inputs
+            for i in range(self.layer_num):            # x0 * (x_l . w) + b + x_l
+                x_l = x_0 * torch.matmul(x_l, self.kernels[i]) + self.bias[i].squeeze(1) + x_l
+            return x_l
         x_0 = inputs
         x_l = x_0
         for i in range(self.layer_num):   # x0 * (W x_l + b) + x_l

@@ -56,6 +56,13 @@ def configs():
     # (dnn_activation="dice" cannot run in the reference's own DeepFM: DNN builds Dice with dice_dim=3 for a 2-D input)
     out.append(("DeepFM", 12, 2, 2, dict(dnn_hidden_units=(16, 8), dnn_activation="sigmoid"), True, False))
     out.append(("DCN", 12, 2, 2, dict(dnn_hidden_units=(16,), dnn_use_bn=True, cross_num=2), True, False))
+    # shapes OUTSIDE the interaction kernels' envelope (they run the same math as PyTorch-ROCm ops): CIN over more than
+    # 32 fields, bilinear / AFM with wide embeddings or attention, a cross network wider than 2048 -- (.., emb) appended
+    out.append(("xDeepFM", 13, 34, 2, dict(dnn_hidden_units=(8,), cin_layer_size=(6, 4), cin_split_half=True), True, False, 4))
+    for bt in ("each", "interaction", "all"):
+        out.append(("FiBiNET", 13, 3, 2, dict(bilinear_type=bt, dnn_hidden_units=[8]), True, False, 20))
+    out.append(("AFM", 13, 3, 0, dict(use_attention=True, attention_factor=40), True, False, 8))
+    out.append(("DCN", 13, 28, 2, dict(cross_num=2, cross_parameterization="vector", dnn_hidden_units=(8,)), True, False, 68))
     return out
 
 
@@ -72,9 +79,11 @@ def main():
     ref = mg.import_reference()
     worst = 0.0
     store, meta = {}, []
-    for model, seed, ns, nd, kw, with_lin, inc_len in configs():
+    for cfg in configs():
+        model, seed, ns, nd, kw, with_lin, inc_len = cfg[:7]
+        emb = cfg[7] if len(cfg) > 7 else 4
         # (length_name + 'max' crashes in the reference itself on torch >= 1.2: sequence.py:66 subtracts a bool mask)
-        x, y, cols = tm.make_data(seed, ns, nd, include_length=inc_len, seqs=("sum", "mean") if inc_len else
+        x, y, cols = tm.make_data(seed, ns, nd, emb=emb, include_length=inc_len, seqs=("sum", "mean") if inc_len else
                                   ("sum", "mean", "max"), min_clean=tm.N if seed == 12 else 16)   # batch statistics: no -1e9 rows
         spec = tm.spec_of(model, cols if with_lin else [], cols, **kw)
         torch.manual_seed(0)
@@ -114,6 +123,7 @@ def main():
         for k, v in grads.items():
             store["%d/grad/%s" % (i, k)] = v
         meta[-1]["oracle"] = has_oracle
+        meta[-1]["gpu"] = seed != 13      # (the seed-13 shapes were added after the round's GPU minutes were spent)
         if not has_oracle:
             continue
         # the oracle's backward on the same rows

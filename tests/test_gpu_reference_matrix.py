@@ -178,8 +178,12 @@ def test_WDL(tmp_path, n_sparse, n_dense):
 # ---- the HIP forward against the REFERENCE's stored predictions on the same matrix (oracle/check_matrix.py) ----------
 from helpers import feature_columns, load_matrix, matrix_id  # noqa: E402
 
+# configurations stored after this round's GPU minutes were spent run on the CPU stand-in only (tests/test_model_plumbing.py)
+# until they have been seen green on an MI355X: DCTR_UNVERIFIED_GPU_TESTS=1 includes them
+GPU_MATRIX = [c for c in load_matrix() if c.get("gpu", True) or os.environ.get("DCTR_UNVERIFIED_GPU_TESTS", "0") == "1"]
 
-@pytest.mark.parametrize("c", load_matrix(), ids=matrix_id)
+
+@pytest.mark.parametrize("c", GPU_MATRIX, ids=matrix_id)
 def test_forward_matches_reference_on_its_test_matrix(c):
     """The reference's own freshly initialised parameters (state_dict loaded as is) and inputs for every configuration
     of its model tests: eval-mode logits of the HIP path within 1e-5 of the reference's on every row with a defined
@@ -202,7 +206,7 @@ def test_forward_matches_reference_on_its_test_matrix(c):
     assert max_abs(got[ok], c["y_pred"][ok]) <= 5e-6
 
 
-@pytest.mark.parametrize("c", load_matrix(), ids=matrix_id)
+@pytest.mark.parametrize("c", GPU_MATRIX, ids=matrix_id)
 def test_gradients_match_reference_on_its_test_matrix(c):
     """d BCE(sum over the rows with a defined value) / d every parameter == the reference's autograd, 2e-5 x max|g|:
     the backward of sum / mean / max pooling with padding, one-row vocabularies, towers of zero layers, ..."""
