@@ -254,6 +254,12 @@ class SENETLayer(nn.Module):
     def forward(self, inputs):
         if len(inputs.shape) != 3:
             raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % (len(inputs.shape)))
+        F_, D_ = inputs.shape[1], inputs.shape[2]
+        if 16 * F_ * D_ + 24 * F_ + 8 * self.reduction_size > 16384:
+            # the backward kernel stages 2 x 8 samples x F x D floats in 64 KB of LDS (csrc/pairwise.hip,
+            # dctr_senet_bwd): beyond F*D ~ 1000 (e.g. 39 fields of 32) the reference's formulation on PyTorch-ROCm
+            A = self.excitation(torch.mean(inputs, dim=-1))
+            return torch.mul(inputs, torch.unsqueeze(A, dim=2))
         return _ops.SENETFunction.apply(inputs, self.excitation[0].weight, self.excitation[2].weight)
 
 

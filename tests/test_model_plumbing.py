@@ -163,3 +163,27 @@ def test_reference_protocol_runs_on_pooled_fields(mock, monkeypatch, tmp_path):
     torch.save(m, f)
     again = torch.load(f, weights_only=False)
     assert before.shape == (N, 1) and max_abs(again.predict(x, batch_size=50), before) == 0.0
+
+
+def test_senet_beyond_the_kernel_envelope_matches_oracle(mock):
+    """39 fields of 32 floats: more than dctr_senet_bwd stages in LDS -> the layer runs the reference's formulation as
+    torch ops; values and gradients against the numpy oracle (pinned by the FiBiNET fixtures)."""
+    from deepctr_torch.layers import SENETLayer
+    from np_oracle import senet_backward, senet_forward
+    torch.manual_seed(0)
+    layer = SENETLayer(39, 3, device="cpu")
+    E = torch.randn(6, 39, 32, requires_grad=True)
+    V = layer(E)
+    assert not any(c.startswith("senet") for c in mock.calls)
+    W1, W2 = layer.excitation[0].weight, layer.excitation[2].weight
+    want, cache = senet_forward(E.detach().double().numpy(), W1.detach().double().numpy(), W2.detach().double().numpy())
+    assert max_abs(V.detach().numpy(), want) <= 1e-5
+    gV = torch.randn(V.shape)
+    gE, g1, g2 = torch.autograd.grad(V, [E, W1, W2], gV)
+    oE, o1, o2 = senet_backward(gV.double().numpy(), E.detach().double().numpy(), cache, W1.detach().double().numpy(),
+                                W2.detach().double().numpy())
+    for got, ref in ((gE, oE), (g1, o1), (g2, o2)):
+        assert max_abs(got.numpy(), ref) <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+    small = SENETLayer(5, 2, device="cpu")
+    small(torch.randn(4, 5, 8))
+    assert "senet_fwd" in mock.calls            # inside the envelope the kernel path is taken
