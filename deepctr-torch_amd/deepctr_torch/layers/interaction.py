@@ -297,9 +297,17 @@ class BilinearInteraction(nn.Module):
             self._meta = (n_fields, _ops.BilinearMeta(n_fields, self.bilinear_type))
         return self._meta[1]
 
+    @staticmethod
+    def _kernel_fits(F, D):
+        """The backward-data kernel keeps 4 tiles of 16 samples x (F*D padded) floats in LDS (csrc/pairwise.hip,
+        dctr_bilinear_bwd: <= 158 KB) and the MFMA tiling needs D <= 16: F*D up to ~600, i.e. 37 fields of 16."""
+        rs = F * D
+        rs += (16 - (rs & 31)) & 31
+        return D <= 16 and 4 * 16 * rs * 4 + 4 * 16 * 17 * 4 <= 158 * 1024
+
     def _pairs_torch(self, X):
-        """``[B, F, D] -> [B, P, D]`` as batched GEMMs on PyTorch-ROCm: embedding_size > 16 is outside the MFMA kernel
-        (csrc/pairwise.hip tiles D <= 16)."""
+        """``[B, F, D] -> [B, P, D]`` as batched GEMMs on PyTorch-ROCm, for shapes outside the MFMA kernels
+        (``_kernel_fits``)."""
         F = X.shape[1]
         idx = torch.triu_indices(F, F, 1, device=X.device)
         left, right = X[:, idx[0]], X[:, idx[1]]
@@ -313,7 +321,7 @@ class BilinearInteraction(nn.Module):
         if len(inputs.shape) != 3:
             raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % (len(inputs.shape)))
         B, F, D = inputs.shape
-        if D > 16:
+        if not self._kernel_fits(F, D):
             return self._pairs_torch(inputs)
         out = _ops.BilinearFunction.apply(self.meta(F), inputs, None, None, *self._weights())
         return out.reshape(B, F * (F - 1) // 2, D)
@@ -321,7 +329,7 @@ class BilinearInteraction(nn.Module):
     def fused_pair(self, raw, senet, dense=None):
         """FiBiNET's ``cat(Bilinear(senet), Bilinear(raw))`` flattened, followed by the dense features: the DNN input
         of fibinet.py:82-87 produced by one launch that loads every weight tile once for both passes."""
-        if raw.shape[2] > 16:
+        if not self._kernel_fits(raw.shape[1], raw.shape[2]):
             parts = [self._pairs_torch(senet).flatten(1), self._pairs_torch(raw).flatten(1)]
             return torch.cat(parts + ([dense] if dense is not None else []), dim=1)
         return _ops.BilinearFunction.apply(self.meta(raw.shape[1]), raw, senet, dense, *self._weights())

@@ -187,3 +187,35 @@ def test_senet_beyond_the_kernel_envelope_matches_oracle(mock):
     small = SENETLayer(5, 2, device="cpu")
     small(torch.randn(4, 5, 8))
     assert "senet_fwd" in mock.calls            # inside the envelope the kernel path is taken
+
+
+@pytest.mark.parametrize("btype", ["all", "each", "interaction"])
+def test_bilinear_beyond_the_kernel_envelope_matches_the_kernel_formula(mock, btype):
+    """39 fields of 16: the forward kernel would fit, the backward-data kernel's LDS tiles would not (ENOSUP after the
+    forward) -> the layer must take the torch formulation for the whole op.  Checked against the stand-in of the kernel
+    (tests/mock_ops.py: the formula include/dctr.h documents) on a shape inside the envelope, and for self-consistency of
+    values / gradients beyond it."""
+    from deepctr_torch.layers import BilinearInteraction
+    assert BilinearInteraction._kernel_fits(37, 16) and not BilinearInteraction._kernel_fits(39, 16)
+    assert not BilinearInteraction._kernel_fits(5, 20)
+    torch.manual_seed(0)
+    # same layer, same input: torch formulation vs kernel path (forced) on an in-envelope shape
+    lay = BilinearInteraction(6, 8, btype, device="cpu")
+    E = torch.randn(5, 6, 8, requires_grad=True)
+    out_k = lay(E)
+    assert "bilinear_fwd" in mock.calls
+    out_t = lay._pairs_torch(E)
+    assert max_abs(out_k.detach().numpy(), out_t.detach().numpy()) <= 1e-5
+    g = torch.randn(out_k.shape)
+    ws = [w for w in lay.parameters()]
+    gk = torch.autograd.grad(out_k, [E] + ws, g, allow_unused=True)
+    gt = torch.autograd.grad(out_t, [E] + ws, g, allow_unused=True)
+    for a, b in zip(gk, gt):
+        if a is None or b is None:          # 'each': the last field's weight is never a left factor
+            assert (a is None or float(a.abs().max()) == 0) and (b is None or float(b.abs().max()) == 0)
+        else:
+            assert max_abs(a.numpy(), b.numpy()) <= 2e-5 * max(1.0, float(b.abs().max()))
+    mock.calls.clear()
+    big = BilinearInteraction(39, 16, btype, device="cpu")
+    y = big(torch.randn(3, 39, 16))
+    assert y.shape == (3, 39 * 38 // 2, 16) and not any(c.startswith("bilinear") for c in mock.calls)
