@@ -72,12 +72,27 @@ class AFMLayer(nn.Module):
         self.dropout = nn.Dropout(dropout_rate)
         self.to(device)
 
+    @staticmethod
+    def _kernel_fits(F, D, A):
+        """csrc/afm.hip: D <= 64, A <= 32, F <= 64, and the BACKWARD's per-sample LDS image -- which holds every pair's
+        attention row and gradient row -- within 150 KB (e.g. 55 fields of 16 with attention_factor 8)."""
+        if F < 2:
+            return True           # (the op itself rejects a single field, like the reference's empty torch.cat)
+        if D > 64 or A > 32 or F > 64:
+            return False
+        ap = 4
+        while ap < A:
+            ap <<= 1
+        P = F * (F - 1) // 2
+        n = D * ap + 2 * ap + D + P + F * D + P + D + (D + P * ap + P * D)
+        return 4 * n <= 150 * 1024
+
     def forward(self, inputs):
         E = torch.cat(list(inputs), dim=1) if isinstance(inputs, (list, tuple)) else inputs
         if E.dim() != 3:
             raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % E.dim())
         F_, D_ = E.shape[1], E.shape[2]
-        outside = D_ > 64 or self.attention_factor > 32 or F_ > 64       # the kernel's envelope (csrc/afm.hip)
+        outside = not self._kernel_fits(F_, D_, self.attention_factor)
         if (self.dropout_rate and self.training) or outside:
             F_ = E.shape[1]
             idx = torch.triu_indices(F_, F_, 1, device=E.device)

@@ -219,3 +219,25 @@ def test_bilinear_beyond_the_kernel_envelope_matches_the_kernel_formula(mock, bt
     big = BilinearInteraction(39, 16, btype, device="cpu")
     y = big(torch.randn(3, 39, 16))
     assert y.shape == (3, 39 * 38 // 2, 16) and not any(c.startswith("bilinear") for c in mock.calls)
+
+
+def test_afm_beyond_the_backward_envelope_takes_the_torch_formulation(mock):
+    """56 fields of 16 with attention_factor 8: the forward kernel fits, the backward's LDS image (every pair's attention
+    and gradient rows) does not -> torch formulation for the whole op; equal to the kernel's formula on a small shape."""
+    from deepctr_torch.layers import AFMLayer
+    assert AFMLayer._kernel_fits(39, 16, 8) and not AFMLayer._kernel_fits(56, 16, 8) and not AFMLayer._kernel_fits(30, 64, 32)
+    torch.manual_seed(0)
+    lay = AFMLayer(8, 4, device="cpu")
+    E = torch.randn(5, 6, 8, requires_grad=True)
+    y_k = lay(E)
+    assert "afm_fwd" in mock.calls
+    lay._kernel_fits = staticmethod(lambda F, D, A: False)
+    y_t = lay(E)
+    assert max_abs(y_k.detach().numpy(), y_t.detach().numpy()) <= 1e-5
+    ps = [E] + list(lay.parameters())
+    g = torch.randn(y_k.shape)
+    for a, b in zip(torch.autograd.grad(y_k, ps, g), torch.autograd.grad(y_t, ps, g)):
+        assert max_abs(a.numpy(), b.numpy()) <= 2e-5 * max(1.0, float(b.abs().max()))
+    mock.calls.clear()
+    big = AFMLayer(16, 8, device="cpu")
+    assert big(torch.randn(3, 56, 16)).shape == (3, 1) and "afm_fwd" not in mock.calls
