@@ -430,9 +430,12 @@ class CrossNet(nn.Module):
     def forward(self, inputs):
         if self.layer_num == 0:
             return inputs
-        if self.parameterization == 'vector' and inputs.shape[1] <= 2048:
+        W_ = inputs.shape[1]
+        # csrc/cross.hip: a wave holds a sample of up to 2048 floats; the backward keeps 4 x layers x W floats in LDS
+        fits = W_ <= 2048 and (4 * self.layer_num * W_ + 4 * self.layer_num) * 4 <= 150 * 1024
+        if self.parameterization == 'vector' and fits:
             return _ops.CrossNetVecFunction.apply(inputs, self.kernels, self.bias)
-        if self.parameterization == 'vector':          # wider than the wave-per-sample kernel holds: PyTorch-ROCm ops
+        if self.parameterization == 'vector':          # outside the kernels' envelope: PyTorch-ROCm ops
             x_0 = x_l = inputs
             for i in range(self.layer_num):            # x0 * (x_l . w) + b + x_l
                 x_l = x_0 * torch.matmul(x_l, self.kernels[i]) + self.bias[i].squeeze(1) + x_l

@@ -241,3 +241,25 @@ def test_afm_beyond_the_backward_envelope_takes_the_torch_formulation(mock):
     mock.calls.clear()
     big = AFMLayer(16, 8, device="cpu")
     assert big(torch.randn(3, 56, 16)).shape == (3, 1) and "afm_fwd" not in mock.calls
+
+
+def test_crossnet_beyond_the_backward_envelope_takes_the_torch_formulation(mock):
+    """6 layers over 2000 inputs: the forward kernel fits, the backward's LDS image (4 x layers x W floats) does not."""
+    from deepctr_torch.layers import CrossNet
+    torch.manual_seed(0)
+    small = CrossNet(12, 3, "vector", device="cpu")
+    with torch.no_grad():
+        small.bias.normal_(0, 0.1)
+    x = torch.randn(5, 12, requires_grad=True)
+    y_k = small(x)
+    assert "crossnet_vec_fwd" in mock.calls
+    x_0 = x_l = x
+    for i in range(3):
+        x_l = x_0 * torch.matmul(x_l, small.kernels[i]) + small.bias[i].squeeze(1) + x_l
+    assert max_abs(y_k.detach().numpy(), x_l.detach().numpy()) <= 1e-5
+    mock.calls.clear()
+    big = CrossNet(2000, 6, "vector", device="cpu")
+    assert big(torch.randn(2, 2000)).shape == (2, 2000) and "crossnet_vec_fwd" not in mock.calls
+    ok = CrossNet(429, 6, "vector", device="cpu")          # the Criteo width: inside
+    ok(torch.randn(2, 429))
+    assert "crossnet_vec_fwd" in mock.calls
