@@ -18,6 +18,8 @@ import torch.nn as nn
 from . import lib as L
 from ..layers.activation import Identity
 
+MAX_TOWER_WIDTH = 928
+
 
 def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
@@ -43,7 +45,10 @@ def tower_layers(dnn, dnn_linear=None):
             relu = 0
         else:
             return None
-        if fc.out_features > 2048 or fc.weight.dtype != torch.float32:
+        # csrc/mlp.hip keeps a 16-sample tile of the widest activation (twice) next to the staged input columns in LDS:
+        # 16 * (516 + 2 * (round16(width) + 4)) * 4 bytes <= 150 KB for the fused train step -> width <= 928.  Wider
+        # towers (1024-wide layers are common) stay on PyTorch-ROCm's nn.Linear.
+        if fc.out_features > MAX_TOWER_WIDTH or fc.weight.dtype != torch.float32:
             return None
         layers.append((fc.weight, fc.bias, relu))
     w_out = None

@@ -114,3 +114,20 @@ def test_bce_head_autograd_route(mock):
     for a, b in zip(parts, p2):
         assert torch.allclose(a.grad, b.grad, atol=1e-5)
     assert torch.allclose(bias.grad, b2.grad, atol=1e-4)
+
+
+def test_towers_wider_than_the_kernels_hold_stay_on_torch(mock):
+    """1024-wide layers (a common configuration) exceed what csrc/mlp.hip's 16-sample LDS tile holds: the layer spec must
+    decline them (they run as nn.Linear on PyTorch-ROCm) instead of failing with ENOSUP at the first step."""
+    from deepctr_torch._hip import mlp
+    from deepctr_torch.layers import DNN
+    ok = DNN(40, (928, 64), device="cpu")
+    wide = DNN(40, (1024, 512, 256), device="cpu")
+    lin_ok, lin_wide = torch.nn.Linear(64, 1, bias=False), torch.nn.Linear(256, 1, bias=False)
+    assert mlp.tower_layers(ok, lin_ok) is not None and mlp.tower_layers(wide, lin_wide) is None
+    # the widest accepted layer fits the fused train step's budget: 16 * (516 + 2 * (round16(w) + 4)) * 4 <= 150 KB
+    w = mlp.MAX_TOWER_WIDTH
+    assert 16 * (516 + 2 * ((w + 15) // 16 * 16 + 4)) * 4 <= 150 * 1024 < 16 * (516 + 2 * ((w + 16 + 15) // 16 * 16 + 4)) * 4
+    x = torch.randn(6, 40)
+    y = mlp.tower(wide, lin_wide, x, 40)
+    assert "mlp_fwd" not in mock.calls and torch.allclose(y, lin_wide(wide(x)), atol=1e-6)
