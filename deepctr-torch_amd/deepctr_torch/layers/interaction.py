@@ -350,6 +350,19 @@ class BilinearInteraction(nn.Module):
         return _ops.BilinearFunction.apply(self.meta(raw.shape[1]), raw, senet, dense, *self._weights())
 
 
+def pairwise_products(E, reduce_sum):
+    """``e_i * e_j`` for i < j: ``[B, F, D] -> [B, P, 1 | D]``.  The kernels (csrc/pairwise.hip) keep one sample's fields
+    and -- in the backward -- its P gradient rows in 60 KB of LDS; beyond that (e.g. 45 fields of 16 without the sum)
+    the same products as PyTorch-ROCm ops."""
+    F_, D_ = E.shape[1], E.shape[2]
+    P = F_ * (F_ - 1) // 2
+    if F_ < 2 or (F_ * D_ + P * (1 if reduce_sum else D_) + 2) * 4 <= 60 * 1024:
+        return _ops.InnerProductFunction.apply(E, reduce_sum)
+    idx = torch.triu_indices(F_, F_, 1, device=E.device)
+    prod = E[:, idx[0]] * E[:, idx[1]]
+    return prod.sum(dim=2, keepdim=True) if reduce_sum else prod
+
+
 class InnerProductLayer(nn.Module):
     """Pairwise inner (or element-wise) products of field embeddings (reference interaction.py:537-577):
     list of ``[B, 1, D]`` (or one ``[B, F, D]`` tensor) -> ``[B, F(F-1)/2, 1]`` (``[.., D]`` without reduce_sum)."""
@@ -361,7 +374,7 @@ class InnerProductLayer(nn.Module):
 
     def forward(self, inputs):
         E = inputs if torch.is_tensor(inputs) else torch.cat(list(inputs), dim=1)
-        return _ops.InnerProductFunction.apply(E, self.reduce_sum)
+        return pairwise_products(E, self.reduce_sum)
 
 
 class OutterProductLayer(nn.Module):
@@ -401,7 +414,7 @@ class OutterProductLayer(nn.Module):
             idx = torch.triu_indices(F_, F_, 1, device=E.device)
             pk = torch.einsum("bke,fke->bkf", E[:, idx[0]], self.kernel)
             return torch.sum(pk * E[:, idx[1]], dim=-1)
-        prod = _ops.InnerProductFunction.apply(E, False)                 # [B, P, D]: p (.) q
+        prod = pairwise_products(E, False)                               # [B, P, D]: p (.) q
         return torch.sum(prod * self.kernel.unsqueeze(0), dim=-1)
 
 

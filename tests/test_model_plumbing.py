@@ -263,3 +263,23 @@ def test_crossnet_beyond_the_backward_envelope_takes_the_torch_formulation(mock)
     ok = CrossNet(429, 6, "vector", device="cpu")          # the Criteo width: inside
     ok(torch.randn(2, 429))
     assert "crossnet_vec_fwd" in mock.calls
+
+
+def test_inner_products_beyond_the_backward_envelope(mock):
+    """45 fields of 16 without the sum over d: one sample's P gradient rows no longer fit the backward kernel's LDS."""
+    from deepctr_torch.layers import InnerProductLayer
+    from deepctr_torch.layers.interaction import pairwise_products
+    torch.manual_seed(0)
+    E = torch.randn(4, 6, 8, requires_grad=True)
+    for reduce in (True, False):
+        y_k = pairwise_products(E, reduce)
+        idx = torch.triu_indices(6, 6, 1)
+        y_t = E[:, idx[0]] * E[:, idx[1]]
+        y_t = y_t.sum(dim=2, keepdim=True) if reduce else y_t
+        assert y_k.shape == y_t.shape and max_abs(y_k.detach().numpy(), y_t.detach().numpy()) <= 1e-6
+    assert mock.calls.count("inner_product_fwd") == 2
+    mock.calls.clear()
+    big = torch.randn(2, 45, 16)
+    assert pairwise_products(big, False).shape == (2, 990, 16) and "inner_product_fwd" not in mock.calls
+    assert InnerProductLayer(device="cpu")([t for t in big.split(1, dim=1)]).shape == (2, 990, 1)
+    assert "inner_product_fwd" in mock.calls            # with the sum the backward image is small: kernel
