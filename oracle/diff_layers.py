@@ -82,6 +82,20 @@ run("Interacting_bad_heads", lambda: IT.InteractingLayer(D, 3, device="cpu"))
 run("Interacting_bad_dim", lambda: seeded(IT.InteractingLayer(D, 2, device="cpu"))(x2(5)))
 for t in ("mat", "vec", "num"):
     run("Outter_" + t, lambda t=t: seeded(IT.OutterProductLayer(F, D, t, 1024, "cpu"))(xl()))
+# shapes outside the kernels' envelope (the drop-in switches to torch formulations; values must still be the reference's)
+def big3(F_, D_): return torch.randn(3, F_, D_, generator=torch.Generator().manual_seed(5)) * 0.5
+def bigl(F_, D_): return [t for t in big3(F_, D_).split(1, dim=1)]
+run("CIN_34_fields", lambda: seeded(IT.CIN(34, (6, 4), "relu", True, 1e-5, 1024, "cpu"))(big3(34, 4)))
+for t in ("all", "each", "interaction"):
+    run("Bilinear_D20_" + t, lambda t=t: seeded(IT.BilinearInteraction(4, 20, t, 1024, "cpu"))(big3(4, 20)))
+run("Bilinear_39x16", lambda: seeded(IT.BilinearInteraction(39, 16, "all", 1024, "cpu"))(big3(39, 16)))
+run("SENET_40x32", lambda: seeded(IT.SENETLayer(40, 3, 1024, "cpu"))(big3(40, 32)))
+run("AFM_A40", lambda: seeded(IT.AFMLayer(8, 40, 0.0, 0, 1024, "cpu"))(bigl(5, 8)))
+run("AFM_56_fields", lambda: seeded(IT.AFMLayer(16, 8, 0.0, 0, 1024, "cpu"))(bigl(56, 16)))
+run("CrossNet_2100", lambda: seeded(IT.CrossNet(2100, 2, "vector", device="cpu"))(torch.randn(3, 2100, generator=torch.Generator().manual_seed(6)) * 0.1))
+run("Inner_45_noreduce", lambda: IT.InnerProductLayer(reduce_sum=False, device="cpu")(bigl(45, 16)))
+run("Outter_vec_45", lambda: seeded(IT.OutterProductLayer(45, 16, "vec", 1024, "cpu"))(bigl(45, 16)))
+run("Interacting_D40", lambda: seeded(IT.InteractingLayer(40, 2, True, False, 1024, "cpu"))(big3(5, 40)))
 run("DNN", lambda: seeded(LY.DNN(12, (8, 4), device="cpu"))(x2(12)))
 run("DNN_empty", lambda: LY.DNN(12, (), device="cpu"))
 run("Prediction_binary", lambda: LY.PredictionLayer("binary")(x2(1)))
