@@ -29,7 +29,7 @@ class AutoInt(BaseModel):
         self.att_layer_num = att_layer_num
         if self.use_dnn:
             self._make_tower(self.compute_input_dim(dnn_feature_columns), dnn_hidden_units, dnn_activation, l2_reg_dnn,
-                             dnn_dropout, dnn_use_bn, init_std, device, head_in=head_in, l2_head=False)
+                             dnn_dropout, dnn_use_bn, init_std, device, head_in=head_in, l2_head=False, head_first=True)
         else:
             self.dnn_linear = nn.Linear(head_in, 1, bias=False).to(device)
         self.int_layers = nn.ModuleList(

@@ -234,16 +234,23 @@ class BaseModel(nn.Module):
         return emb_list, dense_value_list
 
     def _make_tower(self, in_features, hidden_units, activation='relu', l2_reg_dnn=0, dropout=0, use_bn=False,
-                    init_std=0.0001, device='cpu', head_in=None, l2_head=None):
+                    init_std=0.0001, device='cpu', head_in=None, l2_head=None, head_first=False):
         """``self.dnn`` (+ ``self.dnn_linear``, the bias-free 1-unit projection every model of the family puts on top of
         it) with their regularisation groups -- the block each reference model spells out in its constructor (e.g.
         deepfm.py:55-63, dcn.py:53-70).  ``head_in``: input width of ``dnn_linear`` when it reads more than the tower's
         last layer (DCN / AutoInt stack other features beside it); ``l2_head``: its L2 strength (default: l2_reg_dnn),
-        ``False`` leaves it unregularised."""
+        ``False`` leaves it unregularised; ``head_first``: construct ``dnn_linear`` before ``dnn`` (autoint.py:63-69) --
+        the order in which the two consume the random generator decides the initial weights a seed produces."""
         from ..layers import DNN
+
+        def head():
+            return nn.Linear(hidden_units[-1] if head_in is None else head_in, 1, bias=False).to(device)
+        if head_first:
+            self.dnn_linear = head()
         self.dnn = DNN(in_features, hidden_units, activation=activation, l2_reg=l2_reg_dnn, dropout_rate=dropout,
                        use_bn=use_bn, init_std=init_std, device=device)
-        self.dnn_linear = nn.Linear(hidden_units[-1] if head_in is None else head_in, 1, bias=False).to(device)
+        if not head_first:
+            self.dnn_linear = head()
         self.add_regularization_weight(
             [kv for kv in self.dnn.named_parameters() if 'weight' in kv[0] and 'bn' not in kv[0]], l2=l2_reg_dnn)
         if l2_head is not False:

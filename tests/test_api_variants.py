@@ -287,3 +287,21 @@ def test_replaced_optimizer_object_restarts_its_state(mock):
 @pytest.mark.parametrize("tag,opt,l2", SCHED_RUNS)
 def test_lr_schedule_on_the_gpu(tag, opt, l2):
     _schedule(tag, opt, l2, "cuda:0")
+
+
+def test_same_seed_same_initial_weights_as_the_reference():
+    """Model construction consumes the torch generator exactly like the reference (same modules, same order, same
+    init functions): DeepFM(..., seed=1024) of the Criteo example starts from the reference's own initial state_dict,
+    bit for bit -- so a user's run is reproducible across the two packages without copying weights."""
+    from deepctr_torch.inputs import DenseFeat, SparseFeat
+    from deepctr_torch.models import DeepFM
+    z = np.load(os.path.join(GOLDEN_DIR, "api", "criteo_example.npz"), allow_pickle=False)
+    names = json.loads(str(z["names"]))
+    cols = [SparseFeat(f, vocabulary_size=int(v), embedding_dim=4) for f, v in zip(names[:26], z["vocab"])] + \
+           [DenseFeat(f, 1) for f in names[26:]]
+    m = DeepFM(linear_feature_columns=cols, dnn_feature_columns=cols, task='binary', l2_reg_embedding=1e-5, device="cpu")
+    sd = m.state_dict()
+    ref = {k[len("param/"):]: z[k] for k in z.files if k.startswith("param/")}
+    assert set(sd) == set(ref)
+    for k, v in ref.items():
+        assert np.array_equal(sd[k].numpy(), v), k

@@ -124,3 +124,8 @@ def test_state_dict_layout_matches_reference_on_its_test_matrix(c):
     m = cls(dnn, device="cpu", **c["kwargs"]) if c["model"] == "PNN" else cls(lin, dnn, device="cpu", **c["kwargs"])
     got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     assert got == {k: tuple(v.shape) for k, v in c["params"].items()}
+    assert list(m.state_dict().keys()) == list(c["params"].keys())          # same registration order
+    # ... and the same VALUES: construction consumes the seeded generator like the reference (same modules, same order,
+    # same init functions), so seed=1024 yields the reference's own initial weights, bit for bit
+    for k, v in c["params"].items():
+        assert np.array_equal(m.state_dict()[k].numpy(), v), k
