@@ -89,6 +89,34 @@ def h_():
     return [round(float(v), 5) for v in hh.history["loss"]] + [list(p.shape), str(p.dtype), round(float(p.sum()), 4)]
 def i_():
     m = mk_model(task="multiclass")
+# ---- every model family FROM SCRATCH: seeded construction, adam with the default L2, two shuffled epochs -------------------
+from deepctr_torch.inputs import VarLenSparseFeat
+import deepctr_torch.models as MM
+fam_cols = [SparseFeat("a", 10, 4), SparseFeat("b", 7, 4), SparseFeat("c", 5, 4), DenseFeat("d", 1), DenseFeat("e", 1),
+            VarLenSparseFeat(SparseFeat("h", 9, 4), 3, "mean")]
+fam_x = dict(x, c=rng.integers(0, 5, N), e=rng.random(N), h=rng.integers(0, 9, (N, 3)))
+FAMILIES = {
+    "DeepFM": dict(dnn_hidden_units=(8, 4)), "xDeepFM": dict(dnn_hidden_units=(8,), cin_layer_size=(6, 4)),
+    "FiBiNET": dict(dnn_hidden_units=(8,)), "DCN": dict(dnn_hidden_units=(8,), cross_num=2),
+    "DCN_matrix": dict(dnn_hidden_units=(8,), cross_num=2, cross_parameterization="matrix"),
+    "DCNMix": dict(dnn_hidden_units=(8,), cross_num=2, low_rank=4, num_experts=2), "PNN": dict(dnn_hidden_units=(8,)),
+    "PNN_outer": dict(dnn_hidden_units=(8,), use_outter=True), "NFM": dict(dnn_hidden_units=(8,)),
+    "AFM": dict(attention_factor=4), "AutoInt": dict(dnn_hidden_units=(8,), att_layer_num=2), "WDL": dict(dnn_hidden_units=(8,)),
+}
+def family(name, kw):
+    def fn():
+        cls = getattr(MM, name.split("_")[0])
+        cols_ = [c for c in fam_cols if not isinstance(c, DenseFeat)] if name == "AFM" else fam_cols
+        m = cls(cols_, device="cpu", **kw) if name.startswith("PNN") else cls(cols_, cols_, device="cpu", **kw)
+        m.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy"])
+        torch.manual_seed(3)
+        h = m.fit({k: v for k, v in fam_x.items() if k in m.feature_index}, y, batch_size=32, epochs=2, verbose=0,
+                  validation_split=0.2)
+        p = m.predict({k: v for k, v in fam_x.items() if k in m.feature_index}, 64)
+        return {"hist": {k: [round(float(v), 5) for v in vs] for k, vs in h.history.items()}, "pred_sum": round(float(p.sum()), 4)}
+    return fn
+for n, kw in FAMILIES.items():
+    run("scratch_" + n, family(n, kw))
 for n, fn in (("metrics", a), ("defaults", b), ("bad_opt", c), ("bad_loss", d), ("unknown_metric", e), ("val3", f), ("val1", gq), ("mae", h_), ("bad_task", i_)):
     run(n, fn)
 print("JSON" + json.dumps(out, sort_keys=True, default=str))
