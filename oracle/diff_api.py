@@ -102,6 +102,9 @@ FAMILIES = {
     "DCNMix": dict(dnn_hidden_units=(8,), cross_num=2, low_rank=4, num_experts=2), "PNN": dict(dnn_hidden_units=(8,)),
     "PNN_outer": dict(dnn_hidden_units=(8,), use_outter=True), "NFM": dict(dnn_hidden_units=(8,)),
     "AFM": dict(attention_factor=4), "AutoInt": dict(dnn_hidden_units=(8,), att_layer_num=2), "WDL": dict(dnn_hidden_units=(8,)),
+    # outside the tower kernels: a 1024-wide layer, BatchNorm, PReLU
+    "DeepFM_wide": dict(dnn_hidden_units=(1024, 8)), "DeepFM_bn": dict(dnn_hidden_units=(8,), dnn_use_bn=True),
+    "WDL_prelu": dict(dnn_hidden_units=(8,), dnn_activation="prelu"),
 }
 def family(name, kw):
     def fn():
