@@ -120,6 +120,19 @@ def family(name, kw):
     return fn
 for n, kw in FAMILIES.items():
     run("scratch_" + n, family(n, kw))
+def pandas_inputs():
+    import pandas as pd
+    df = pd.DataFrame({"a": x["a"], "b": x["b"], "d": x["d"], "label": y})
+    m = mk_model(); m.compile("adagrad", "binary_crossentropy", metrics=["auc"])
+    xin = {n_: df[n_] for n_ in ("a", "b", "d")}                       # pandas Series, as in the examples
+    h = m.fit(xin, df[["label"]].values, batch_size=32, epochs=2, verbose=0, validation_split=0.2, shuffle=False)
+    p1 = m.predict(xin, 40)
+    first = {k: [round(float(v), 5) for v in vs] for k, vs in h.history.items()}
+    h2 = m.fit([df["a"].values, df["b"].values, df["d"].values], df["label"].values, batch_size=50, epochs=1, verbose=0, shuffle=False)
+    ev = m.evaluate(xin, df["label"].values, 30)
+    return [first, round(float(p1.sum()), 4),
+            [round(float(v), 5) for v in h2.history["loss"]], {k: round(float(v), 5) for k, v in ev.items()}]
+run("pandas_inputs", pandas_inputs)
 for n, fn in (("metrics", a), ("defaults", b), ("bad_opt", c), ("bad_loss", d), ("unknown_metric", e), ("val3", f), ("val1", gq), ("mae", h_), ("bad_task", i_)):
     run(n, fn)
 print("JSON" + json.dumps(out, sort_keys=True, default=str))
