@@ -135,6 +135,11 @@ class GraphedTrainStep(object):
         self._ready[s].record(self._side)
         main.wait_event(self._ready[s])
         self.graphs[s].replay()
+        # a replay runs the captured dctr_lazy_apply launches without passing through LazyState.apply(): the host
+        # flag that makes flush() / state_dict() / predict() bring every row up to date must be raised here too
+        lazy = getattr(self.model.model_plan(), "_lazy", None)
+        if lazy is not None:
+            lazy.mark_dirty()
         self._free_ev[s].record(main)
         self._free[s] = self._free_ev[s]
         self._slot, self._j = (s + 1) % self.n_slots, 0

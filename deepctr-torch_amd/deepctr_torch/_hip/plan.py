@@ -194,6 +194,10 @@ class LazyState(object):
         self._call(L.lib().dctr_lazy_apply, "dctr_lazy_apply", ctypes.c_void_p(ids_t.data_ptr()), ids_t.shape[1])
         L.check(L.lib().dctr_lazy_step_inc(ctypes.c_void_p(self.step.data_ptr()), L.stream_handle(ids_t.device)),
                 "dctr_lazy_step_inc")
+        self.mark_dirty()
+
+    def mark_dirty(self):
+        """Train steps ran since the last flush (LazyState.apply, or a hipGraph replay of it): rows lag behind."""
         self.dirty = True
         self._reg = None
 

@@ -782,7 +782,10 @@ class BaseModel(nn.Module):
             from .._hip.graph import GraphedTrainStep
             try:
                 g["graph"] = GraphedTrainStep(self, xb, yb, steps_per_graph=1).capture(xb, yb)
-            except Exception:                      # capture is an optimisation; keep training eagerly
+            except Exception as e:                 # capture is an optimisation; keep training eagerly
+                import warnings
+                warnings.warn("fit(): hipGraph capture of the train step failed (%s: %s); training eagerly"
+                              % (type(e).__name__, e))
                 g["graph"] = None
                 g["warm"] = -10 ** 9
                 torch.cuda.synchronize()

@@ -85,15 +85,8 @@ def test_api_variant_on_the_stand_in(mock, monkeypatch, v):
     _run(v, "cpu")
 
 
-# Cases added after this round's GPU minutes were spent run on the stand-in only until they have been seen green on an
-# MI355X: DCTR_UNVERIFIED_GPU_TESTS=1 runs them (then drop the gate).
-UNVERIFIED = os.environ.get("DCTR_UNVERIFIED_GPU_TESTS", "0") == "1"
-not_yet_on_gpu = pytest.mark.skipif(not UNVERIFIED, reason="added after the round's GPU budget was spent; "
-                                                           "DCTR_UNVERIFIED_GPU_TESTS=1 runs it")
-
-
 @pytest.mark.gpu
-@pytest.mark.parametrize("v", [v for v in VARIANTS if v.get("gpu", True) or UNVERIFIED], ids=lambda v: v["tag"])
+@pytest.mark.parametrize("v", VARIANTS, ids=lambda v: v["tag"])
 def test_api_variant_on_the_gpu(v):
     _run(v, "cuda:0")
 
@@ -283,7 +276,6 @@ def test_replaced_optimizer_object_restarts_its_state(mock):
 
 
 @pytest.mark.gpu
-@not_yet_on_gpu
 @pytest.mark.parametrize("tag,opt,l2", SCHED_RUNS)
 def test_lr_schedule_on_the_gpu(tag, opt, l2):
     _schedule(tag, opt, l2, "cuda:0")
@@ -360,7 +352,6 @@ def test_from_scratch_run_matches_the_reference_on_the_stand_in(mock, monkeypatc
 
 
 @pytest.mark.gpu
-@not_yet_on_gpu
 @pytest.mark.parametrize("name", sorted(SCRATCH))
 def test_from_scratch_run_matches_the_reference_on_the_gpu(name):
     _scratch(name, "cuda:0")

@@ -178,9 +178,7 @@ def test_WDL(tmp_path, n_sparse, n_dense):
 # ---- the HIP forward against the REFERENCE's stored predictions on the same matrix (oracle/check_matrix.py) ----------
 from helpers import feature_columns, load_matrix, matrix_id  # noqa: E402
 
-# configurations stored after this round's GPU minutes were spent run on the CPU stand-in only (tests/test_model_plumbing.py)
-# until they have been seen green on an MI355X: DCTR_UNVERIFIED_GPU_TESTS=1 includes them
-GPU_MATRIX = [c for c in load_matrix() if c.get("gpu", True) or os.environ.get("DCTR_UNVERIFIED_GPU_TESTS", "0") == "1"]
+GPU_MATRIX = load_matrix()
 
 
 @pytest.mark.parametrize("c", GPU_MATRIX, ids=matrix_id)
