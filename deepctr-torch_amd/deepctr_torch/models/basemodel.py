@@ -56,12 +56,20 @@ class Linear(nn.Module):
                                                       device=device)
         # the reference initialises these tables a second time (basemodel.py:55-56); doing the same keeps
         # same-seed initial weights identical to the reference's
+        # (drawn from the CPU generator whatever the device -- see the note on self.weight below)
         for tensor in self.embedding_dict.values():
-            nn.init.normal_(tensor.weight, mean=0, std=init_std)
+            w = torch.empty(tensor.weight.shape, dtype=tensor.weight.dtype)
+            nn.init.normal_(w, mean=0, std=init_std)
+            with torch.no_grad():
+                tensor.weight.copy_(w)
         if len(self.dense_feature_columns) > 0:
-            self.weight = nn.Parameter(
-                torch.Tensor(sum(fc.dimension for fc in self.dense_feature_columns), 1).to(device))
-            torch.nn.init.normal_(self.weight, mean=0, std=init_std)
+            # The reference draws this one on the target device (basemodel.py:58-61): on a GPU that is the CUDA
+            # generator, whose stream no ROCm build can reproduce.  Drawn from the CPU generator instead, the same
+            # seed gives the weights (and every later draw) of the reference constructed on its CPU device, whatever
+            # device this model lives on.
+            w = torch.Tensor(sum(fc.dimension for fc in self.dense_feature_columns), 1)
+            torch.nn.init.normal_(w, mean=0, std=init_std)
+            self.weight = nn.Parameter(w.to(device))
         self._plan = None
 
     def plan(self):
