@@ -123,7 +123,20 @@ def main():
         for k, v in grads.items():
             store["%d/grad/%s" % (i, k)] = v
         meta[-1]["oracle"] = has_oracle
-        meta[-1]["gpu"] = seed != 13      # (the seed-13 shapes were added after the round's GPU minutes were spent)
+        if kw.get("dnn_use_bn"):
+            # Train-mode BatchNorm at initialisation (activations ~1e-4, divided by sqrt(var + 1e-5)) is ill-conditioned:
+            # the SAME reference evaluated in fp64 says how far fp32 round-off alone moves every gradient.  Stored so
+            # (the reference's in-place logit adds keep the wide / final logit in fp32; the tower and its BatchNorm --
+            # where the conditioning problem lives -- run in fp64.)  Stored so
+            # that the GPU test can bound its error by the reference's own fp32 uncertainty instead of skipping.
+            import copy
+            m64 = copy.deepcopy(m).double()
+            m64.train()
+            m64.zero_grad()
+            torch.nn.functional.binary_cross_entropy(m64(torch.from_numpy(X).double()).squeeze(1)[okt].double(), yt[okt].double(),
+                                                     reduction="sum").backward()
+            for k, p in m64.named_parameters():
+                store["%d/grad64/%s" % (i, k)] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
         if not has_oracle:
             continue
         # the oracle's backward on the same rows

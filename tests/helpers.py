@@ -79,10 +79,11 @@ def load_matrix():
     z = np.load(os.path.join(GOLDEN_DIR, "matrix", "reference_matrix.npz"), allow_pickle=False)
     out = []
     for i, meta in enumerate(json.loads(str(z["configs"]))):
-        pre, gpre = "%d/param/" % i, "%d/grad/" % i
+        pre, gpre, g64 = "%d/param/" % i, "%d/grad/" % i, "%d/grad64/" % i
         out.append(dict(meta, X=z["%d/X" % i], y=z["%d/y" % i], y_pred=z["%d/y_pred" % i], logit=z["%d/logit" % i], clean=z["%d/clean" % i],
                         params={k[len(pre):]: z[k] for k in z.files if k.startswith(pre)},
-                        grads={k[len(gpre):]: z[k] for k in z.files if k.startswith(gpre)}))
+                        grads={k[len(gpre):]: z[k] for k in z.files if k.startswith(gpre)},
+                        grads64={k[len(g64):]: z[k] for k in z.files if k.startswith(g64)}))
     return out
 
 

@@ -207,15 +207,12 @@ def test_forward_matches_reference_on_its_test_matrix(c):
 @pytest.mark.parametrize("c", GPU_MATRIX, ids=matrix_id)
 def test_gradients_match_reference_on_its_test_matrix(c):
     """d BCE(sum over the rows with a defined value) / d every parameter == the reference's autograd, 2e-5 x max|g|:
-    the backward of sum / mean / max pooling with padding, one-row vocabularies, towers of zero layers, ..."""
+    the backward of sum / mean / max pooling with padding, one-row vocabularies, towers of zero layers, ...
+    The two train-mode BatchNorm towers are ill-conditioned at initialisation (64 rows of ~1e-4-sized activations divided
+    by sqrt(var + 1e-5)): the reference's OWN fp32 gradients are 3-10 % away from the same reference evaluated with an
+    fp64 tower (stored as grad64 by oracle/check_matrix.py).  There the bound per parameter is 4 x that measured fp32
+    uncertainty, against the fp64 value -- the tightest statement the reference itself supports."""
     import deepctr_torch.models as M
-    if c["kwargs"].get("dnn_use_bn"):
-        # measured on MI355X: 1.7e-4 on a table gradient of scale 7e-3, 5e-5 on a bias gradient whose true value is 0.
-        # BatchNorm over 64 rows of ~1e-4-sized activations (freshly initialised weights) divides by sqrt(var + 1e-5)
-        # and its backward subtracts nearly equal terms: PyTorch-ROCm's and PyTorch-CPU's BatchNorm kernels (neither is
-        # this repo's code) round differently.  The forward (eval mode) is compared above; the host-side wiring of the
-        # BatchNorm tower is compared with the reference on CPU (tests/test_model_plumbing.py, same configurations).
-        pytest.skip("train-mode BatchNorm gradients are ill-conditioned at initialisation (torch kernels, not ours)")
     spec = c["spec"]
     lin, dnn = feature_columns(spec["linear_columns"]), feature_columns(spec["dnn_columns"])
     cls = getattr(M, c["model"])
@@ -231,4 +228,9 @@ def test_gradients_match_reference_on_its_test_matrix(c):
     for k, p in m.named_parameters():
         ref = c["grads"][k]
         got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(ref)
-        assert max_abs(got, ref) <= 2e-5 * max(1.0, float(np.max(np.abs(ref))) if ref.size else 1.0), k
+        tol = 2e-5 * max(1.0, float(np.max(np.abs(ref))) if ref.size else 1.0)
+        if k in c["grads64"]:
+            ref64 = c["grads64"][k]
+            tol = max(tol, 4.0 * max_abs(ref, ref64))
+            ref = ref64
+        assert max_abs(got, ref) <= tol, "%s: %.3e > %.3e" % (k, max_abs(got, ref), tol)
