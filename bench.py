@@ -39,12 +39,15 @@ def parse():
     ap.add_argument("--vocab", type=int, default=1_000_000)
     ap.add_argument("--optimizer", default="adagrad", choices=["adagrad", "sgd"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replays")
-    ap.add_argument("--steps-per-graph", type=int, default=8,
-                    help="train steps captured per hipGraph (the ~15 us launch gap is paid once per graph)")
+    ap.add_argument("--steps-per-graph", type=int, default=0,
+                    help="train steps captured per hipGraph (the ~15 us launch gap is paid once per graph); 0 = the "
+                         "largest divisor of --steps in [8, 32], else 16 plus a tail graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the xDeepFM / FiBiNET legs (BASELINE.json configs 3-4) of the N=1 line")
     ap.add_argument("--force-parallel", action="store_true", help="use the data-parallel trainer even with 1 rank")
     ap.add_argument("--kernel-iters", type=int, default=50, help="event-timed launches per hot-path kernel")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=10)
     return ap.parse_args()
 
 
@@ -142,13 +145,16 @@ def time_hot_kernels(model, X_all, B, iters, opt, ring=16):
 
 def pmc_traffic(kernel, opt, B):
     """HBM bytes per launch of a hand-written kernel from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh:
-    FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB units, corrected with factors calibrated on launches of
-    known byte counts as MI355X_MICROARCH.md prescribes for access patterns other than wide streaming reads).
-    Returns None when no PMC summary for this kernel / launch size is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
+    FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB units).  `bytes` is the RAW counter sum: for random row
+    accesses the raw FETCH_SIZE tallies what the fabric moved (the calibration gather of 64-byte rows reads 1.77x its
+    known bytes: a 64-byte row costs a 128-byte fetch); only wide coalesced streams are under-counted by 2
+    (MI355X_MICROARCH.md), so `fetch_x2_streaming_rule` is the upper bound.  Returns None when no PMC summary for
+    this kernel / launch size is committed."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not paths:
         return None
-    with open(path) as fh:
+    with open(paths[-1]) as fh:
         d = json.load(fh)
     tag = "embed_fwd" if kernel == "embed_fwd" else "embed_update_%s" % opt
     # the PMC driver launches every kernel at B = 4096 and B = 32768: the smaller grid is this bench's launch
@@ -156,10 +162,10 @@ def pmc_traffic(kernel, opt, B):
     if not cands or B != 4096:
         return None
     best = cands[0][1]
-    return {"bytes": best["fetch_bytes_gather_corrected"] + best["write_bytes_corrected"],
-            "fetch_raw": best["fetch_raw_bytes"], "fetch_gather_calibrated": best["fetch_bytes_gather_corrected"],
-            "fetch_x2_streaming_rule": best["fetch_bytes_x2"], "write": best["write_bytes_corrected"],
-            "source": "profiles/r01_pmc_traffic.json"}
+    return {"bytes": best["fetch_raw_bytes"] + best["write_raw_bytes"],
+            "fetch_raw": best["fetch_raw_bytes"], "write_raw": best["write_raw_bytes"],
+            "fetch_x2_streaming_rule": best["fetch_bytes_x2"],
+            "source": "profiles/" + os.path.basename(paths[-1])}
 
 
 def cpu_baseline(args):
@@ -186,8 +192,155 @@ def cpu_baseline(args):
             "ms_per_step": dt / args.cpu_steps * 1e3}
 
 
+class StepRunner(object):
+    """K train steps with NO eager step inside the timed region: whole groups of ``S`` steps replay the main hipGraph,
+    the K mod S leftover steps replay a second, shorter graph captured beforehand (round 1 timed 4 of 20 driver steps
+    eagerly at ~3x the replayed cost)."""
+
+    def __init__(self, model, X, y, B, steps, S, use_graph):
+        self.model, self.X, self.y, self.B = model, X, y, B
+        self.n_batches = X.shape[0] // B
+        self.i = 0
+        self.main = self.tail = None
+        self.S = max(1, min(int(S), steps)) if use_graph else 0
+        self.tail_n = (steps % self.S) if self.S else 0
+        self.use_graph = use_graph
+
+    def batch(self, i):
+        j = i % self.n_batches
+        return self.X[j * self.B:(j + 1) * self.B], self.y[j * self.B:(j + 1) * self.B]
+
+    def eager(self, n):
+        out = None
+        for _ in range(n):
+            out = self.model._train_step(*self.batch(self.i))
+            self.i += 1
+        return out
+
+    def capture(self):
+        from deepctr_torch._hip.graph import GraphedTrainStep
+        xb, yb = self.batch(self.i)
+        # (the synthetic dataset was uploaded and synchronised long before: its slices are complete)
+        self.main = GraphedTrainStep(self.model, xb, yb, steps_per_graph=self.S, inputs_ready=True).capture(xb, yb)
+        if self.tail_n:
+            self.tail = GraphedTrainStep(self.model, xb, yb, steps_per_graph=self.tail_n, double_buffer=False,
+                                         inputs_ready=True).capture(xb, yb)
+
+    def _group(self, g, n):
+        j = self.i % self.n_batches
+        if j + n <= self.n_batches:      # consecutive resident rows: two staging copies for the whole group
+            out = g.step_block(self.X[j * self.B:(j + n) * self.B], self.y[j * self.B:(j + n) * self.B])
+            self.i += n
+            return out
+        out = None
+        for _ in range(n):
+            out = g(*self.batch(self.i))
+            self.i += 1
+        return out
+
+    def run(self, steps):
+        """`steps` train steps; every one of them a graph replay when graphs are on."""
+        if self.main is None:
+            return self.eager(steps)
+        out, done = None, 0
+        while steps - done >= self.S:
+            out = self._group(self.main, self.S)
+            done += self.S
+        if steps - done:
+            assert self.tail is not None and steps - done == self.tail_n, "tail graph does not match the step count"
+            out = self._group(self.tail, self.tail_n)
+        return out
+
+
+def time_steps(model, X, y, B, steps, warmup, S, use_graph):
+    """Warm up (>= `warmup` steps: 3 eager ones, then one replay of every captured graph), time exactly `steps`."""
+    r = StepRunner(model, X, y, B, steps, S, use_graph)
+    n_eager = min(3, max(1, warmup)) if use_graph else warmup
+    r.eager(n_eager)
+    graphed = False
+    if use_graph:
+        try:
+            r.capture()
+            graphed = True
+        except Exception as exc:  # capture is an optimisation: report and continue eagerly
+            print("hipGraph capture failed (%s: %s); running eager" % (type(exc).__name__, exc), file=sys.stderr)
+            r.main = r.tail = None
+            torch.cuda.synchronize()
+    did = n_eager
+    if graphed:
+        while did < warmup or did == n_eager:
+            r.run(r.S + r.tail_n)        # one replay of the main graph (+ one of the tail graph)
+            did += r.S + r.tail_n
+    else:
+        r.eager(max(0, warmup - n_eager))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = r.run(steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    return elapsed, out, graphed, did, r
+
+
+# BASELINE.json configs[2] and configs[3]: same Criteo shape, other interaction layers (SURVEY.md 8(d))
+MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA peak
+OTHER = {
+    "xdeepfm": dict(cls="xDeepFM", kwargs=dict(dnn_hidden_units=(256, 256), cin_layer_size=(128, 128), cin_split_half=True),
+                    flop_per_sample=29.9e6, ref="xdeepfm.py:79-107, interaction.py:207-248",
+                    workload="xDeepFM synthetic Criteo, CIN layers=[128,128] split_half, dnn=(256,256)"),
+    "fibinet": dict(cls="FiBiNET", kwargs=dict(dnn_hidden_units=(128, 128)), flop_per_sample=9.1e6,
+                    ref="fibinet.py:76-102, interaction.py:93-101,140-156",
+                    workload="FiBiNET synthetic Criteo, SENET(reduction 3) + bilinear 'interaction', dnn=(128,128)"),
+}
+
+
+def build_other(name, args, device):
+    from deepctr_torch import models as M
+    from deepctr_torch.inputs import DenseFeat, SparseFeat
+    cols = [SparseFeat("C%d" % (i + 1), args.vocab, DIM) for i in range(F_SPARSE)] + \
+           [DenseFeat("I%d" % (i + 1), 1) for i in range(N_DENSE)]
+    spec = OTHER[name]
+    model = getattr(M, spec["cls"])(cols, cols, l2_reg_linear=0, l2_reg_embedding=0, dnn_dropout=0, seed=1024,
+                                    device=device, **spec["kwargs"])
+    model.compile(args.optimizer, "binary_crossentropy", metrics=[])
+    model.train()
+    return model
+
+
+def other_config(name, args, device, X, y):
+    """One more bench leg at N = 1: the same timed protocol on another model of BASELINE.json; MFMA-bound, so its
+    roofline is algorithmic FLOP / (time x dense fp32 MFMA peak)."""
+    spec = OTHER[name]
+    try:
+        model = build_other(name, args, device)
+        elapsed, out, graphed, did, _ = time_steps(model, X, y, args.batch, args.steps, args.warmup,
+                                                   args.steps_per_graph, not args.no_graph)
+        model.model_plan().check_ids()
+        ms = elapsed / args.steps * 1e3
+        sps = args.batch * args.steps / elapsed
+        tf = sps * spec["flop_per_sample"] / 1e12
+        res = {"workload": spec["workload"] + ", batch=%d, fwd+bwd+%s, l2=0" % (args.batch, args.optimizer),
+               "reference": spec["ref"], "value": sps, "unit": "samples/s", "ms_per_step": ms, "steps": args.steps,
+               "warmup": did, "hip_graph": graphed, "final_loss": float(out[0].item()),
+               "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": tf / MFMA_PEAK_TFLOPS, "flop_per_sample": spec["flop_per_sample"],
+                            "traffic": None}}
+        del model
+        torch.cuda.empty_cache()
+        return res
+    except Exception as exc:  # a failing extra leg must not take the headline down with it
+        torch.cuda.synchronize()
+        return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+
+
+def auto_steps_per_graph(steps):
+    divs = [d for d in range(8, 33) if steps % d == 0]
+    return max(divs) if divs else min(16, steps)
+
+
 def main():
     args = parse()
+    if args.steps_per_graph <= 0:
+        args.steps_per_graph = auto_steps_per_graph(args.steps)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -207,82 +360,49 @@ def main():
     X, y = synth(args, device, rank)
     B = args.batch
     n_batches = X.shape[0] // B
-    parallel = None
-    if dist is not None:
-        # table-sharded embeddings + data-parallel tower (SURVEY.md 8(e) option S): 3 all-to-alls + 1 all-reduce per
-        # step; the compute between the collectives is captured as hipGraph segments after a few eager steps
+
+    if dist is None:
+        elapsed, out, graphed, did_warm, _ = time_steps(model, X, y, B, args.steps, args.warmup, args.steps_per_graph,
+                                                        not args.no_graph)
+        parallel = None
+    else:
+        # table-sharded embeddings + data-parallel tower (SURVEY.md 8(e) option S); the compute between the
+        # collectives is captured as hipGraph segments after a few eager steps
         from deepctr_torch import parallel as par
         parallel = par.ShardedTrainer(model, use_graphs=False)
 
-    def batch(i):
-        j = i % n_batches
-        return X[j * B:(j + 1) * B], y[j * B:(j + 1) * B]
+        def batch(i):
+            j = i % n_batches
+            return X[j * B:(j + 1) * B], y[j * B:(j + 1) * B]
 
-    step_fn = (lambda xb, yb: parallel.train_step(xb, yb)) if parallel else (lambda xb, yb: model._train_step(xb, yb))
-
-    def run(k):
-        """Step on batch k.  The sharded trainer is told the next batch: its ids travel with this step's gradients."""
-        if parallel is not None:
+        def run(k):   # the trainer is told the next batch: its ids travel with this step's gradients
             return parallel.train_step(*batch(k), next_xb=batch(k + 1)[0])
-        return step_fn(*batch(k))
 
-    use_graph = (not args.no_graph) and parallel is None
-    n_eager = min(3, args.warmup) if not args.no_graph else args.warmup
-    i = 0
-    for _ in range(n_eager):
-        run(i)
-        i += 1
-    graphed = None
-    if use_graph:
-        from deepctr_torch._hip.graph import GraphedTrainStep
-        try:
-            # (the synthetic dataset was uploaded and synchronised long before: its slices are complete)
-            graphed = GraphedTrainStep(model, *batch(0), steps_per_graph=args.steps_per_graph,
-                                       inputs_ready=True).capture(*batch(i))
-            step_fn = graphed
-        except Exception as exc:  # capture is an optimisation: report and continue eagerly
-            print("hipGraph capture failed (%s: %s); running eager" % (type(exc).__name__, exc), file=sys.stderr)
-            graphed = None
-            torch.cuda.synchronize()
-    if parallel is not None and not args.no_graph:
-        parallel.use_graphs = True       # segments re-capture on the next step
-        parallel._shape = None
-        graphed = "segments"
-    for _ in range(max(0, args.warmup - n_eager)):
-        run(i)
-        i += 1
-
-    if use_graph and graphed is not None and graphed != "segments":
-        graphed.flush()                  # the timed region starts on a group boundary
-    torch.cuda.synchronize()
-    if dist:
+        i = 0
+        n_eager = min(3, args.warmup) if not args.no_graph else args.warmup
+        for _ in range(n_eager):
+            run(i)
+            i += 1
+        graphed = False
+        if not args.no_graph:
+            parallel.use_graphs = True       # segments re-capture on the next step
+            parallel._shape = None
+            graphed = True
+        for _ in range(max(2 if graphed else 0, args.warmup - n_eager)):
+            run(i)
+            i += 1
+        did_warm = i
+        torch.cuda.synchronize()
         dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    block = 0
-    if use_graph and graphed is not None and graphed != "segments":
-        block = graphed.S if (n_batches % graphed.S == 0 and graphed.S > 1) else 0
-    done = 0
-    while done < args.steps:
-        j = i % n_batches
-        if block and args.steps - done >= block and j + block <= n_batches and graphed._j == 0:
-            # the dataset is resident and the group's batches are consecutive rows: stage them with two copies
-            out = graphed.step_block(X[j * B:(j + block) * B], y[j * B:(j + block) * B])
-            i += block
-            done += block
-        else:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
             out = run(i)
             i += 1
-            done += 1
-    if use_graph and graphed is not None and graphed != "segments":
-        tail = graphed.flush()           # K % steps_per_graph leftover steps run eagerly, inside the timed region
-        out = tail if tail is not None else out
-    torch.cuda.synchronize()
-    if dist:
+        torch.cuda.synchronize()
         dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -308,8 +428,9 @@ def main():
             "config": {"workload": "DeepFM synthetic Criteo (26 sparse x %d vocab, 13 dense, emb_dim=16, batch=%d) "
                                    "fwd+bwd+%s, l2=0, dnn=(256,128)" % (args.vocab, B, args.optimizer),
                        "global_batch": world * B, "parallelism": ("tables sharded x%d + dp%d tower" % (world, world)) if parallel is not None else "single",
-                       "hip_graph": graphed is not None, "steps_per_graph": (args.steps_per_graph if use_graph and graphed is not None else None),
-                       "optimizer": args.optimizer},
+                       "hip_graph": bool(graphed), "steps_per_graph": (min(args.steps_per_graph, args.steps) if graphed and parallel is None else None),
+                       "eager_steps_in_timed_region": 0 if graphed else args.steps,
+                       "warmup_steps_run": did_warm, "optimizer": args.optimizer},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": kern[dom]["gbs"] / HBM_PEAK_GBS,
                          "traffic": (traffic or {}).get("bytes"), "traffic_detail": traffic,
@@ -319,6 +440,10 @@ def main():
                          "whole_step_frac_of_hbm_peak": step_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "final_loss": last_loss,
         }
+        if world == 1 and not args.no_other_configs:
+            del model
+            torch.cuda.empty_cache()
+            result["other_configs"] = {name: other_config(name, args, device, X, y) for name in OTHER}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(result))
