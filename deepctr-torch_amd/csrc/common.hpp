@@ -101,6 +101,10 @@ __device__ __forceinline__ float group_sum(float v) {
 
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 
+// row strides of a field's table / optimizer state (0 in the descriptor = contiguous rows of `dim` floats)
+__device__ __forceinline__ int64_t row_ld(const dctr_field_t& f) { return f.ld > 0 ? f.ld : f.dim; }
+__device__ __forceinline__ int64_t state_ld(const dctr_field_t& f) { return f.ld_state > 0 ? f.ld_state : f.dim; }
+
 inline int hip_status(hipError_t e) { return e == hipSuccess ? DCTR_OK : static_cast<int>(e); }
 
 inline int launch_status() { return hip_status(hipGetLastError()); }

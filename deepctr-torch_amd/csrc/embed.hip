@@ -99,7 +99,7 @@ __device__ __forceinline__ Strip<VEC> pool_field(const dctr_field_t& fd, const f
     const int64_t rid = raw_id(xr, fd.col + t);
     const bool m = by_len ? (static_cast<int64_t>(t) < len_i) : (rid != 0);
     const int64_t id = checked(rid, fd.vocab, bad);
-    Strip<VEC> row = act ? strip_load<VEC>(fd.table + id * fd.dim + e0) : strip_zero<VEC>();
+    Strip<VEC> row = act ? strip_load<VEC>(fd.table + id * row_ld(fd) + e0) : strip_zero<VEC>();
     if (fd.pool == DCTR_POOL_MAX) {
       const float pen = m ? 0.f : 1e9f;
 #pragma unroll
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
                                                         int64_t ldw, float* __restrict__ fm, int32_t* err,
                                                         const int32_t* __restrict__ units, int n_units,
                                                         int32_t* __restrict__ ids_t,
+                                                        uint16_t* __restrict__ parts_t, int n_parts,
                                                         float* __restrict__ fm_s, int64_t lds_) {
   constexpr int SPB = kWave / LPR;
   constexpr int CH = 8;   // row loads in flight per lane and per pass (x4 waves = 32 fields)
@@ -151,11 +152,20 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
   float* orow = out ? out + static_cast<int64_t>(b) * ldo : nullptr;
 
   // side output for dctr_embed_update: the ids of this tile, transposed to [unit][b] (64-byte runs)
+  // (+ parts_t: the partition of dctr_embed_update each entry belongs to, so that its workgroups compare 16-bit tags
+  // instead of dividing every id of the unit again)
   if (ids_t) {
     for (int k = tid; k < n_units * nrows; k += kThreads) {
       const int u = k / nrows, r = k - u * nrows;
-      ids_t[static_cast<int64_t>(u) * B + b0 + r] =
-          static_cast<int32_t>(T.xs[r * P.n_xcols + ldg_i32(units + 4 * u + 2)]);
+      const int32_t id = static_cast<int32_t>(T.xs[r * P.n_xcols + ldg_i32(units + 4 * u + 2)]);
+      ids_t[static_cast<int64_t>(u) * B + b0 + r] = id;
+      if (parts_t) {
+        const int di = ldg_i32(units + 4 * u), wi = ldg_i32(units + 4 * u + 1);
+        const int64_t vocab = (di >= 0) ? T.deep[di].vocab : T.wide[wi].vocab;
+        const uint32_t cid = (static_cast<uint64_t>(static_cast<int64_t>(id)) >= static_cast<uint64_t>(vocab))
+                                 ? 0u : static_cast<uint32_t>(id);
+        parts_t[static_cast<int64_t>(u) * B + b0 + r] = static_cast<uint16_t>(cid % static_cast<uint32_t>(n_parts));
+      }
     }
   }
 
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
     for (int k = 0; k < WCH; ++k) {
       const int f = (k * kNW + wv_id) * LPR + gl;
       const dctr_field_t& fd = T.wide[min(f, nwf - 1)];
-      wval[k] = ldg_f32(fd.table + checked(raw_id(xr, fd.col), fd.vocab, bad));
+      wval[k] = ldg_f32(fd.table + checked(raw_id(xr, fd.col), fd.vocab, bad) * row_ld(fd));
     }
   }
 
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
       const dctr_field_t& fd = T.deep[min(f0 + k * kNW, nfix - 1)];
       const int64_t id = checked(raw_id(xr, fd.col), fd.vocab, bad);
       // lanes past the row width re-read the row's first strip; their value is never used
-      r[k] = strip_load<VEC>(fd.table + id * fd.dim + ((e0 < fd.dim) ? e0 : 0));
+      r[k] = strip_load<VEC>(fd.table + id * row_ld(fd) + ((e0 < fd.dim) ? e0 : 0));
     }
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
     for (int k = 0; k < WCH; ++k) ws += ((k * kNW + wv_id) * LPR + gl < nwf) ? wval[k] : 0.f;
     for (int f = (WCH * kNW + wv_id) * LPR + gl; f < nwf; f += kNW * LPR) {  // > 8*LPR wide fields
       const dctr_field_t& fd = T.wide[f];
-      ws += ldg_f32(fd.table + checked(raw_id(xr, fd.col), fd.vocab, bad));
+      ws += ldg_f32(fd.table + checked(raw_id(xr, fd.col), fd.vocab, bad) * row_ld(fd));
     }
     for (int f = P.n_wide_fixed + wv_id * LPR + gl; f < P.n_wide; f += kNW * LPR) {  // pooled VarLen
       const dctr_field_t& fd = T.wide[f];
@@ -301,6 +311,7 @@ __device__ __forceinline__ void unpool_field(const dctr_field_t& fd, const float
   if (!act) return;
   int bad = 0;  // ids were range-checked (and flagged) by the forward pass
   float* base = SGD ? fd.table : fd.gacc;
+  const int64_t bld = SGD ? row_ld(fd) : fd.dim;   // gacc is contiguous
   const bool by_len = fd.len_col >= 0;
   const int64_t len_i = by_len ? raw_id(xr, fd.len_col) : 0;
   if (fd.pool == DCTR_POOL_MAX) {
@@ -317,7 +328,7 @@ __device__ __forceinline__ void unpool_field(const dctr_field_t& fd, const float
       const int64_t rid = raw_id(xr, fd.col + t);
       const bool m = by_len ? (static_cast<int64_t>(t) < len_i) : (rid != 0);
       const int64_t id = checked(rid, fd.vocab, bad);
-      const Strip<VEC> row = strip_load<VEC>(fd.table + id * fd.dim + e0);
+      const Strip<VEC> row = strip_load<VEC>(fd.table + id * row_ld(fd) + e0);
       const float pen = m ? 0.f : 1e9f;
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
@@ -329,7 +340,7 @@ __device__ __forceinline__ void unpool_field(const dctr_field_t& fd, const float
       }
     }
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) atomic_add_f32(base + bid[i] * fd.dim + e0 + i, scale * gp.v[i]);
+    for (int i = 0; i < VEC; ++i) atomic_add_f32(base + bid[i] * bld + e0 + i, scale * gp.v[i]);
     return;
   }
   float cnt = 0.f;
@@ -346,7 +357,7 @@ __device__ __forceinline__ void unpool_field(const dctr_field_t& fd, const float
     const bool m = by_len ? (static_cast<int64_t>(t) < len_i) : (rid != 0);
     if (!m) continue;
     const int64_t id = checked(rid, fd.vocab, bad);
-    scatter_strip<VEC>(base + id * fd.dim + e0, gs, scale);
+    scatter_strip<VEC>(base + id * bld + e0, gs, scale);
   }
 }
 
@@ -378,7 +389,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_bwd(dctr_plan_t P, const flo
     for (int f = wv_id * LPR + gl; f < P.n_wide_fixed; f += kNW * LPR) {
       const dctr_field_t& fd = T.wide[f];
       const int64_t id = checked(raw_id(xr, fd.col), fd.vocab, bad);
-      atomic_add_f32((SGD ? fd.table : fd.gacc) + id, scale * gw);
+      atomic_add_f32((SGD ? fd.table + id * row_ld(fd) : fd.gacc + id), scale * gw);
     }
     for (int f = P.n_wide_fixed + wv_id * LPR + gl; f < P.n_wide; f += kNW * LPR) {
       const dctr_field_t& fd = T.wide[f];
@@ -436,7 +447,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_bwd(dctr_plan_t P, const flo
         if (f < P.n_deep_fixed) {
           if (act) {
             const int64_t id = checked(raw_id(xr, fd.col), fd.vocab, bad);
-            scatter_strip<VEC>((SGD ? fd.table : fd.gacc) + id * fd.dim + e0, g[k], scale);
+            scatter_strip<VEC>((SGD ? fd.table + id * row_ld(fd) : fd.gacc + id * fd.dim) + e0, g[k], scale);
           }
         } else {
           unpool_field<VEC, SGD>(fd, xr, e0, act, g[k], scale);
@@ -450,15 +461,17 @@ __global__ __launch_bounds__(kThreads) void k_embed_bwd(dctr_plan_t P, const flo
 // pass 2: consume gacc rows of this batch, apply the optimizer, leave gacc zero
 // -------------------------------------------------------------------------------------------------
 template <int OPT>
-__device__ __forceinline__ void apply_elem(const dctr_field_t& fd, int64_t off, float lr, float eps) {
-  const float G = atomic_xchg_f32(fd.gacc + off, 0.f);
+__device__ __forceinline__ void apply_elem(const dctr_field_t& fd, int64_t row, int e, float lr, float eps) {
+  const float G = atomic_xchg_f32(fd.gacc + row * fd.dim + e, 0.f);
   if (G == 0.f) return;  // untouched, already consumed by a duplicate, or a genuinely zero gradient
+  float* w = fd.table + row * row_ld(fd) + e;
   if (OPT == DCTR_OPT_ADAGRAD) {
-    const float s = ldg_f32(fd.state + off) + G * G;
-    stg_f32(fd.state + off, s);
-    stg_f32(fd.table + off, ldg_f32(fd.table + off) - lr * (G / (sqrtf(s) + eps)));
+    float* st = fd.state + row * state_ld(fd) + e;
+    const float s = ldg_f32(st) + G * G;
+    stg_f32(st, s);
+    stg_f32(w, ldg_f32(w) - lr * (G / (sqrtf(s) + eps)));
   } else {
-    stg_f32(fd.table + off, ldg_f32(fd.table + off) - lr * G);
+    stg_f32(w, ldg_f32(w) - lr * G);
   }
 }
 
@@ -482,13 +495,13 @@ __global__ __launch_bounds__(kThreads) void k_embed_apply(dctr_plan_t P, const f
     for (int t = 0; t < fd.len; ++t) {
       const int64_t id = checked(raw_id(xr, fd.col + t), fd.vocab, bad);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) apply_elem<OPT>(fd, id * fd.dim + e0 + i, lr, eps);
+      for (int i = 0; i < VEC; ++i) apply_elem<OPT>(fd, id, e0 + i, lr, eps);
     }
   }
   for (int f = wv_id * LPR + gl; f < P.n_wide; f += kNW * LPR) {
     const dctr_field_t& fd = T.wide[f];
     for (int t = 0; t < fd.len; ++t)
-      apply_elem<OPT>(fd, checked(raw_id(xr, fd.col + t), fd.vocab, bad), lr, eps);
+      apply_elem<OPT>(fd, checked(raw_id(xr, fd.col + t), fd.vocab, bad), 0, lr, eps);
   }
 }
 
@@ -540,13 +553,16 @@ int check_plan(const dctr_plan_t* p, const float* X, int64_t ldx, int32_t B) {
 extern "C" int dctr_embed_fwd(const dctr_plan_t* plan, const float* X, int64_t ldx, int32_t B,
                               float* out, int64_t ld_out, float* wide, int64_t ld_wide, float* fm,
                               int32_t* err, const int32_t* units, int32_t n_units, int32_t* ids_t,
-                              float* fm_s, int64_t ld_s, dctr_stream_t stream) {
+                              uint16_t* parts_t, float* fm_s, int64_t ld_s, dctr_stream_t stream) {
   if (int rc = check_plan(plan, X, ldx, B)) return rc;
   if (wide && ld_wide < 1) return DCTR_EINVAL;
   if (B == 0) return DCTR_OK;
   if (fm && (plan->emb_dim <= 0 || !out)) return DCTR_EINVAL;  // FM needs the deep rows
   if (fm_s && (plan->emb_dim <= 0 || !out || ld_s < plan->emb_dim)) return DCTR_EINVAL;
   if (ids_t && (!units || n_units <= 0)) return DCTR_EINVAL;
+  if (parts_t && !ids_t) return DCTR_EINVAL;
+  const int n_parts = parts_t ? dctr_embed_update_partitions(plan, B) : 0;
+  if (parts_t && (n_parts <= 0 || n_parts > 65535)) return DCTR_ENOSUP;
   if (fm_s && plan->vec > 1 &&
       (ld_s % plan->vec != 0 || reinterpret_cast<uintptr_t>(fm_s) % (4 * plan->vec) != 0))
     return DCTR_EALIGN;
@@ -561,7 +577,7 @@ extern "C" int dctr_embed_fwd(const dctr_plan_t* plan, const float* X, int64_t l
   hipStream_t s = static_cast<hipStream_t>(stream);
   DCTR_DISPATCH(vec, lpr, k_embed_fwd<VEC, LPR><<<grid, block, lds, s>>>(*plan, X, ldx, B, out, ld_out,
                                                                         wide, ld_wide, fm, err, units, n_units,
-                                                                        ids_t, fm_s, ld_s));
+                                                                        ids_t, parts_t, n_parts, fm_s, ld_s));
   return launch_status();
 }
 

@@ -138,20 +138,25 @@ __global__ __launch_bounds__(kT) void k_lazy(const dctr_lazy_unit_t* __restrict_
   const bool deep_on = un.deep != nullptr && e0 < un.dim;
   const bool wide_on = un.wide != nullptr && gl == 0;
   const float lam2d = 2.f * un.l2_deep, lam2w = 2.f * un.l2_wide;
+  // the table and its first state slab may be strided views of one interleaved slab (row strides in the unit);
+  // the second state slab and the gradient slab are contiguous
   const int64_t off = deep_on ? row * un.dim + e0 : 0;
+  const int64_t off_w = deep_on ? row * (un.ld_deep > 0 ? un.ld_deep : un.dim) + e0 : 0;
+  const int64_t off_a = deep_on ? row * (un.ld_deep_s1 > 0 ? un.ld_deep_s1 : un.dim) + e0 : 0;
+  const int64_t row_w = row * (un.ld_wide > 0 ? un.ld_wide : 1), row_a = row * (un.ld_wide_s1 > 0 ? un.ld_wide_s1 : 1);
   float w[VEC], a[VEC], b[VEC], g[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) w[i] = a[i] = b[i] = g[i] = 0.f;
   if (deep_on) {
-    load_vec<VEC>(un.deep + off, w);
-    if (un.deep_s1) load_vec<VEC>(un.deep_s1 + off, a);
+    load_vec<VEC>(un.deep + off_w, w);
+    if (un.deep_s1) load_vec<VEC>(un.deep_s1 + off_a, a);
     if (un.deep_s2) load_vec<VEC>(un.deep_s2 + off, b);
     if (MODE == 1) load_vec<VEC>(un.deep_g + off, g);
   }
   float ww[1] = {0.f}, wa[1] = {0.f}, wb[1] = {0.f}, wg = 0.f;
   if (wide_on) {
-    ww[0] = ldg_f32(un.wide + row);
-    if (un.wide_s1) wa[0] = ldg_f32(un.wide_s1 + row);
+    ww[0] = ldg_f32(un.wide + row_w);
+    if (un.wide_s1) wa[0] = ldg_f32(un.wide_s1 + row_a);
     if (un.wide_s2) wb[0] = ldg_f32(un.wide_s2 + row);
     if (MODE == 1) wg = ldg_f32(un.wide_g + row);
   }
@@ -186,8 +191,8 @@ __global__ __launch_bounds__(kT) void k_lazy(const dctr_lazy_unit_t* __restrict_
 #pragma unroll
       for (int i = 0; i < VEC; ++i) opt_step(o, g[i] + lam2d * w[i], w[i], a[i], b[i], ss1, bc1);
     }
-    store_vec<VEC>(un.deep + off, w);
-    if (un.deep_s1) store_vec<VEC>(un.deep_s1 + off, a);
+    store_vec<VEC>(un.deep + off_w, w);
+    if (un.deep_s1) store_vec<VEC>(un.deep_s1 + off_a, a);
     if (un.deep_s2) store_vec<VEC>(un.deep_s2 + off, b);
   }
   if (wide_on) {
@@ -196,8 +201,8 @@ __global__ __launch_bounds__(kT) void k_lazy(const dctr_lazy_unit_t* __restrict_
       stg_f32(un.wide_g + row, 0.f);
       opt_step(o, wg + lam2w * ww[0], ww[0], wa[0], wb[0], ss1, bc1);
     }
-    stg_f32(un.wide + row, ww[0]);
-    if (un.wide_s1) stg_f32(un.wide_s1 + row, wa[0]);
+    stg_f32(un.wide + row_w, ww[0]);
+    if (un.wide_s1) stg_f32(un.wide_s1 + row_a, wa[0]);
     if (un.wide_s2) stg_f32(un.wide_s2 + row, wb[0]);
   }
 }

@@ -87,12 +87,18 @@ struct HeadArgs {
 
 __device__ __forceinline__ f32x4 ldg_f4(const float* p) { return *(const DCTR_GLOBAL f32x4*)p; }
 
-// diagnostics (tools/mlp_trace.py): 16 wall_clock64 stamps per workgroup, or NULL
+// diagnostics (tools/mlp_trace.py): 16 wall_clock64 stamps per workgroup, or NULL -- only in the DCTR_DIAG build
+// (libdctr_hip_diag.so); the shipped library keeps no mutable global state
+#ifdef DCTR_DIAG
 unsigned long long* g_mlp_trace = nullptr;
 #define MLP_TRACE(T, slot)                                                                   \
   do {                                                                                       \
     if ((T) && threadIdx.x == 0) (T)[blockIdx.x * 16ull + (slot)] = wall_clock64();          \
   } while (0)
+#else
+static unsigned long long* const g_mlp_trace = nullptr;
+#define MLP_TRACE(T, slot) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------------------
 // forward
@@ -115,16 +121,20 @@ __device__ __forceinline__ void fwd_tiles(const float* As, int rs, int kg0, int 
   constexpr int kPD = NT == 1 ? 12 : (NT == 2 ? 8 : (NT == 3 ? 6 : 4));
   constexpr int KS = NT >= 4 ? 1 : (NT >= 2 ? 2 : 4);
   const DCTR_GLOBAL char* wbase = (const DCTR_GLOBAL char*)Ld.W;
+  // first column this lane reads, pulled back inside the row when the (16-wide, zero-padded in LDS) K range is wider
+  // than the weight row itself (K < 12: the lane's A elements are zero there).  Was computed unsigned: for tiny K the
+  // offset wrapped and the last row's loads left the allocation (round 2, tools/uninit_probe.py).
+  const int col0 = (kg0 + 4 * g) < (Ld.ldw - 4) ? (kg0 + 4 * g) : (Ld.ldw - 4);
   uint32_t voff[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     int n = (tile0 + t * kWaves) * 16 + c;
     n = n < Ld.N ? n : Ld.N - 1;
-    voff[t] = (static_cast<uint32_t>(n) * static_cast<uint32_t>(Ld.ldw) + kg0 + 4 * g) * 4u;
+    voff[t] = (static_cast<uint32_t>(n) * static_cast<uint32_t>(Ld.ldw) + static_cast<uint32_t>(col0)) * 4u;
   }
   const float* ap = As + c * rs + 4 * g;
   const int n_it = klen >> 4;
-  const uint32_t omax = static_cast<uint32_t>(Ld.ldw - kg0 - 4 * g - 4) * 4u;  // largest in-row byte offset
+  const uint32_t omax = static_cast<uint32_t>(Ld.ldw - 4 - col0) * 4u;  // largest in-row byte offset (>= 0)
   auto woff = [&](int it) -> uint32_t {
     it = it < n_it ? it : n_it - 1;                       // scalar: `it` is wave-uniform
     const uint32_t o = static_cast<uint32_t>(it) << 6;
@@ -671,7 +681,9 @@ __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
     if (vb) stg_f32(part + A.off_b[l] + mb, tb);
   }
   MLP_TRACE(A.trace, 3);
+#ifdef DCTR_DIAG
   if (A.trace && threadIdx.x == 0) A.trace[blockIdx.x * 16ull + 14] = static_cast<unsigned long long>(l);
+#endif
 }
 
 struct ReduceArgs {
@@ -787,7 +799,9 @@ WgradPlan plan_wgrad(const dctr_mlp_t* m, int32_t B) {
 }  // namespace
 
 // diagnostics: buf holds 3 x 4096 x 16 u64 (forward | backward-data | wgrad workgroups); NULL switches it off
+#ifdef DCTR_DIAG
 extern "C" void dctr_dbg_mlp_trace(unsigned long long* buf) { g_mlp_trace = buf; }
+#endif
 
 extern "C" int dctr_mlp_fwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, float* logit,
                             dctr_stream_t stream) {

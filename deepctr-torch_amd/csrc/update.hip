@@ -46,6 +46,7 @@ struct UpdArgs {
   const dctr_field_t* wide;
   const int32_t* units;  // [n_units][4] = {deep index | -1, wide index | -1, X column, 0}
   const int32_t* ids_t;  // [n_units][B] truncated ids
+  const uint16_t* parts_t;  // [n_units][B] clamp(id) mod P, written next to ids_t by the forward (nullable)
   const float* gout;     // [B, ldg]   d loss / d out (deep slices), nullable
   const float* fm_s;     // [B, lds_]  S[b, :] = sum_f e[b, f, :], needed with gfm
   const float* gfm;      // [B] nullable
@@ -66,15 +67,22 @@ struct UpdArgs {
   // optional pre-bucketed entries (k_bucket): bcnt [n_units * P] (zero at rest), bkeys [n_units * P][kBucket]
   int32_t* bcnt;
   uint32_t* bkeys;
+  int32_t presorted;   // the buckets hold keys already sorted by (id, sample) (dctr_embed_segments)
 };
 
+// Diagnostics (per-workgroup phase stamps, partition override) exist only in the DCTR_DIAG build
+// (`make diag` -> libdctr_hip_diag.so, used by tools/upd_trace.py): the shipped library keeps no mutable
+// global state (include/dctr.h: re-entrant).
+#ifdef DCTR_DIAG
 unsigned long long* g_trace = nullptr;  // host-side: set by dctr_dbg_update_trace
 int g_force_p = -1;
-
 #define DCTR_TRACE(slot)                                                           \
   do {                                                                             \
     if (A.trace && tid == 0) A.trace[blockIdx.x * 8ull + (slot)] = wall_clock64(); \
   } while (0)
+#else
+#define DCTR_TRACE(slot) do { } while (0)
+#endif
 
 // Values that are the same for every lane of the workgroup (descriptor fields fetched through a pointer the
 // compiler cannot prove uniform): pin them to scalar registers, 64-byte descriptors otherwise cost ~30 VGPRs.
@@ -100,7 +108,8 @@ __device__ __forceinline__ dctr_field_t uni_field(const dctr_field_t& f) {
   r.pool = 0;
   r.len_col = -1;
   r.out_off = uni(f.out_off);
-  r.pad_[0] = r.pad_[1] = 0;
+  r.ld = uni(f.ld);
+  r.ld_state = uni(f.ld_state);
   return r;
 }
 
@@ -115,9 +124,10 @@ __device__ __forceinline__ int32_t clamp_id(int32_t id, int64_t vocab) {
 }
 
 // One optimizer step on a strip of a row.  OPT: 0 SGD, 1 Adagrad, 2 accumulate into gacc.
+// off_w / off_s / off_g: float offsets of the strip in the table, the state slab and the (contiguous) gacc slab.
 template <int VEC, int OPT>
-__device__ __forceinline__ void apply_strip(const dctr_field_t& fd, int64_t off, const Strip<VEC>& G,
-                                            const Strip<VEC>& w, const Strip<VEC>& s, float lr,
+__device__ __forceinline__ void apply_strip(const dctr_field_t& fd, int64_t off_w, int64_t off_s, int64_t off_g,
+                                            const Strip<VEC>& G, const Strip<VEC>& w, const Strip<VEC>& s, float lr,
                                             float eps) {
   Strip<VEC> nw, ns;
   if (OPT == DCTR_UPD_ADAGRAD) {  // torch.optim.Adagrad: s += g*g ; p -= lr * g / (sqrt(s) + eps)
@@ -126,16 +136,16 @@ __device__ __forceinline__ void apply_strip(const dctr_field_t& fd, int64_t off,
       ns.v[i] = s.v[i] + G.v[i] * G.v[i];
       nw.v[i] = w.v[i] - lr * (G.v[i] / (sqrtf(ns.v[i]) + eps));
     }
-    strip_store<VEC>(fd.state + off, ns);
-    strip_store<VEC>(fd.table + off, nw);
+    strip_store<VEC>(fd.state + off_s, ns);
+    strip_store<VEC>(fd.table + off_w, nw);
   } else if (OPT == DCTR_UPD_SGD) {  // torch.optim.SGD: p -= lr * g
 #pragma unroll
     for (int i = 0; i < VEC; ++i) nw.v[i] = w.v[i] - lr * G.v[i];
-    strip_store<VEC>(fd.table + off, nw);
+    strip_store<VEC>(fd.table + off_w, nw);
   } else {  // dense-gradient semantics: gacc[row] += g   (w holds the gacc strip)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) nw.v[i] = w.v[i] + G.v[i];
-    strip_store<VEC>(fd.gacc + off, nw);
+    strip_store<VEC>(fd.gacc + off_g, nw);
   }
 }
 
@@ -200,6 +210,9 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
   const bool lane_on = deep_on && (e0 < fd.dim);
   const int goff = deep_on ? fd.out_off + (lane_on ? e0 : 0) : 0;
   const bool fold = (A.gfm != nullptr);
+  // row strides: a table and its Adagrad state may be strided views of one interleaved slab (dctr.h)
+  const int64_t ld_dw = (di >= 0) ? row_ld(fd) : 1, ld_ds = (di >= 0) ? state_ld(fd) : 1;
+  const int64_t ld_ww = (wi >= 0) ? row_ld(fw) : 1, ld_ws = (wi >= 0) ? state_ld(fw) : 1;
 
   // everything an entry contributes: h = g_out + g_fm * S (deep strip), g_fm, g_wide
   auto load_entry = [&](int b, Strip<VEC>& h, float& gf, float& gw) {
@@ -226,18 +239,18 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
     ww = 0.f;
     sw = 0.f;
     if (lane_on) {
-      const int64_t off = row * fd.dim + e0;
-      w = strip_load<VEC>((OPT == DCTR_UPD_ACCUM ? fd.gacc : fd.table) + off);
-      if (OPT == DCTR_UPD_ADAGRAD) s = strip_load<VEC>(fd.state + off);
+      const int64_t off_w = row * ld_dw + e0;
+      w = strip_load<VEC>(OPT == DCTR_UPD_ACCUM ? fd.gacc + row * fd.dim + e0 : fd.table + off_w);
+      if (OPT == DCTR_UPD_ADAGRAD) s = strip_load<VEC>(fd.state + row * ld_ds + e0);
       if (OPT == DCTR_UPD_ACCUM) {
-        if (fold) e = strip_load<VEC>(fd.table + off);
+        if (fold) e = strip_load<VEC>(fd.table + off_w);
       } else {
         e = w;
       }
     }
     if (wide_on && gl == 0) {
-      ww = ldg_f32((OPT == DCTR_UPD_ACCUM ? fw.gacc : fw.table) + row);
-      if (OPT == DCTR_UPD_ADAGRAD) sw = ldg_f32(fw.state + row);
+      ww = ldg_f32(OPT == DCTR_UPD_ACCUM ? fw.gacc + row : fw.table + row * ld_ww);
+      if (OPT == DCTR_UPD_ADAGRAD) sw = ldg_f32(fw.state + row * ld_ws);
     }
   };
   auto apply_row = [&](int64_t row, Strip<VEC> acc, float accf, float accw, const Strip<VEC>& w, const Strip<VEC>& s,
@@ -247,14 +260,14 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc.v[k] -= accf * e.v[k];
       }
-      apply_strip<VEC, OPT>(fd, row * fd.dim + e0, acc, w, s, A.lr, A.eps);
+      apply_strip<VEC, OPT>(fd, row * ld_dw + e0, row * ld_ds + e0, row * fd.dim + e0, acc, w, s, A.lr, A.eps);
     }
     if (wide_on && gl == 0) {
       Strip<1> a1, w1, s1;
       a1.v[0] = accw;
       w1.v[0] = ww;
       s1.v[0] = sw;
-      apply_strip<1, OPT>(fw, row, a1, w1, s1, A.lr, A.eps);
+      apply_strip<1, OPT>(fw, row * ld_ww, row * ld_ws, row, a1, w1, s1, A.lr, A.eps);
     }
   };
 
@@ -303,7 +316,49 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
     }
     // ---- scan: collect the entries of (partition p, id/P mod 2^mbits == mres) ------------------------------------
     // All id loads of a chunk are issued before any is consumed: the scan costs one L2 round trip per chunk.
-    if (!bucketed) {
+    if (!bucketed && A.parts_t) {
+      // The forward stored clamp(id) mod P next to every id: the scan is a 16-bit compare per entry (a workgroup
+      // keeps ~1/P of them), the exact division runs only for the entries kept.  Was: a 64-bit reciprocal multiply
+      // per id, per workgroup -- 5.5 us of quarter-rate integer multiplies at B = 4096 (phase trace, round 1).
+      const uint16_t* pt = A.parts_t + static_cast<int64_t>(u) * B;
+      const uint32_t pp = static_cast<uint32_t>(p);
+      auto keep = [&](int b) {
+        const int32_t id = clamp_id(ldg_i32(ids + b), vocab);
+        const uint32_t idq = div_p(static_cast<uint32_t>(id), A.pmagic, A.pshift);
+        if ((idq & mmask) == static_cast<uint32_t>(mres)) {
+          const int slot = atomicAdd(&n_sh, 1);  // LDS atomic; the order is fixed by the sort below
+          if (slot < kCap) keys[slot] = (idq << A.bbits) | static_cast<uint32_t>(b);
+        }
+      };
+      if ((B & 7) == 0) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const DCTR_GLOBAL u32x4* pv = (const DCTR_GLOBAL u32x4*)pt;
+        const int nvec = B >> 3;
+        for (int c0 = 0; c0 < nvec; c0 += 2 * kThreads) {
+          u32x4 v[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int idx = c0 + q * kThreads + tid;
+            v[q] = pv[idx < nvec ? idx : 0];
+          }
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int idx = c0 + q * kThreads + tid;
+            if (idx < nvec) {
+              const uint32_t d[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                if ((d[j] & 0xFFFFu) == pp) keep(8 * idx + 2 * j);
+                if ((d[j] >> 16) == pp) keep(8 * idx + 2 * j + 1);
+              }
+            }
+          }
+        }
+      } else {
+        for (int b = tid; b < B; b += kThreads)
+          if (static_cast<uint32_t>(*(const DCTR_GLOBAL uint16_t*)(pt + b)) == pp) keep(b);
+      }
+    } else if (!bucketed) {
     auto take = [&](int32_t raw, int b) {
       const int32_t id = clamp_id(raw, vocab);
       const uint32_t idq = div_p(static_cast<uint32_t>(id), A.pmagic, A.pshift);
@@ -343,14 +398,17 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
     const int n = n_sh;
     if (first_pass) {
       DCTR_TRACE(1);
+#ifdef DCTR_DIAG
       if (A.trace && tid == 0) A.trace[blockIdx.x * 8ull + 7] = static_cast<unsigned long long>(n);
+#endif
     }
     if (n == 0) {
       first_pass = false;
       continue;
     }
 
-    if (n <= G) {
+    const bool sorted_in = bucketed && A.presorted;   // (the pre-pass also sorted: straight to the tiles)
+    if (n <= G && !sorted_in) {
       // ---- single tile --------------------------------------------------------------------------------------------
       const bool have = grp < n;
       const uint32_t key = have ? keys[grp] : 0xFFFFFFFFu;
@@ -412,7 +470,9 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
 
     if (n <= kCap) {
       // ---- sort by (id, b), then tiles of G sorted entries with a carry ---------------------------------------------
-      if (n <= kThreads) {
+      if (sorted_in) {
+        // nothing to do
+      } else if (n <= kThreads) {
         // rank sort: keys are unique, so rank = #smaller is a permutation; 2 barriers
         const uint32_t mine = tid < n ? keys[tid] : 0u;
         int rank = 0;
@@ -659,20 +719,120 @@ __global__ __launch_bounds__(kThreads) void k_bucket(UpdArgs A) {
   if (slot < kBucket) A.bkeys[bucket * kBucket + slot] = (idq << A.bbits) | static_cast<uint32_t>(b);
 }
 
-// ---- X -> ids_t (standalone; the forward kernel fuses the same thing) -------------------------------
-__global__ __launch_bounds__(kThreads) void k_embed_ids(const int32_t* __restrict__ units, int n_units,
+// ---- pre-pass: every (unit, partition)'s entries, sorted by (id, sample), parked in the bucket arrays ---------------
+// What a workgroup of k_embed_update otherwise does first -- find its entries among the unit's B, sort them -- depends
+// on the ids alone, which exist as soon as the forward has run: this kernel does it THEN, in the shadow of the tower,
+// and the update kernel (on the step's critical chain once the gradients exist) starts with one coalesced read of its
+// sorted keys: no scan, no sort, no dependent id loads.  FROM_BUCKETS: k_bucket collected the keys (large batches).
+// A partition with more than kBucket entries is left to the update kernel's own scan (the counter says so).
+template <bool FROM_BUCKETS>
+__global__ __launch_bounds__(kThreads) void k_embed_segments(UpdArgs A) {
+  static_assert(kBucket == kThreads, "one thread per bucket slot");
+  __shared__ uint32_t keys[kBucket];
+  __shared__ int n_sh;
+  const int tid = threadIdx.x;
+  const int P = A.P;
+  const int u = static_cast<int>(blockIdx.x) / P, p = static_cast<int>(blockIdx.x) - u * P;
+  if (u >= A.n_units) return;
+  int32_t* cnt = A.bcnt + static_cast<int64_t>(u) * P + p;
+  uint32_t* dst = A.bkeys + (static_cast<int64_t>(u) * P + p) * kBucket;
+  const int B = A.B;
+  int n;
+  if (FROM_BUCKETS) {
+    n = uni(*(const DCTR_GLOBAL int32_t*)cnt);
+    if (n > kBucket || n <= 0) return;
+    if (tid < n) keys[tid] = *(const DCTR_GLOBAL uint32_t*)(dst + tid);
+    __syncthreads();
+  } else {
+    const int32_t* un = A.units + 4 * u;
+    const int di = uni(un[0]), wi = uni(un[1]);
+    const int64_t vocab = uni((di >= 0) ? A.deep[di].vocab : A.wide[wi].vocab);
+    const int32_t* ids = A.ids_t + static_cast<int64_t>(u) * B;
+    const uint16_t* pt = A.parts_t + static_cast<int64_t>(u) * B;
+    const uint32_t pp = static_cast<uint32_t>(p);
+    if (tid == 0) n_sh = 0;
+    __syncthreads();
+    // phase 1: the samples whose partition tag is mine (no dependent loads inside the divergent branches)
+    auto keep = [&](int b) {
+      const int slot = atomicAdd(&n_sh, 1);
+      if (slot < kBucket) keys[slot] = static_cast<uint32_t>(b);
+    };
+    if ((B & 7) == 0) {
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const DCTR_GLOBAL u32x4* pv = (const DCTR_GLOBAL u32x4*)pt;
+      const int nvec = B >> 3;
+      for (int c0 = 0; c0 < nvec; c0 += 2 * kThreads) {
+        u32x4 v[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int idx = c0 + q * kThreads + tid;
+          v[q] = pv[idx < nvec ? idx : 0];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int idx = c0 + q * kThreads + tid;
+          if (idx < nvec) {
+            const uint32_t d[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if ((d[j] & 0xFFFFu) == pp) keep(8 * idx + 2 * j);
+              if ((d[j] >> 16) == pp) keep(8 * idx + 2 * j + 1);
+            }
+          }
+        }
+      }
+    } else {
+      for (int b = tid; b < B; b += kThreads)
+        if (static_cast<uint32_t>(*(const DCTR_GLOBAL uint16_t*)(pt + b)) == pp) keep(b);
+    }
+    __syncthreads();
+    n = n_sh;
+    if (tid == 0) *(DCTR_GLOBAL int32_t*)cnt = n;
+    if (n > kBucket || n == 0) return;
+    // phase 2: one id load per kept entry, all in flight together
+    uint32_t key = 0u;
+    if (tid < n) {
+      const int b = static_cast<int>(keys[tid]);
+      const int32_t id = clamp_id(ldg_i32(ids + b), vocab);
+      key = (div_p(static_cast<uint32_t>(id), A.pmagic, A.pshift) << A.bbits) | static_cast<uint32_t>(b);
+    }
+    __syncthreads();
+    if (tid < n) keys[tid] = key;
+    __syncthreads();
+  }
+  // rank sort: keys are unique, so rank = #smaller is a permutation
+  const uint32_t mine = tid < n ? keys[tid] : 0u;
+  int rank = 0;
+#pragma unroll 8
+  for (int q = 0; q < n; ++q) rank += (keys[q] < mine) ? 1 : 0;
+  if (tid < n) *(DCTR_GLOBAL uint32_t*)(dst + rank) = mine;
+}
+
+// ---- X -> ids_t (+ parts_t) (standalone; the forward kernel fuses the same thing) -------------------
+__global__ __launch_bounds__(kThreads) void k_embed_ids(const dctr_field_t* __restrict__ deep,
+                                                        const dctr_field_t* __restrict__ wide,
+                                                        const int32_t* __restrict__ units, int n_units,
                                                         const float* __restrict__ X, int64_t ldx, int B,
-                                                        int32_t* __restrict__ ids_t) {
+                                                        int32_t* __restrict__ ids_t, uint16_t* __restrict__ parts_t,
+                                                        int n_parts) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
   if (i >= static_cast<int64_t>(n_units) * B) return;
   const int u = static_cast<int>(i / B), b = static_cast<int>(i - static_cast<int64_t>(u) * B);
-  ids_t[i] = static_cast<int32_t>(X[static_cast<int64_t>(b) * ldx + units[4 * u + 2]]);
+  const int32_t id = static_cast<int32_t>(X[static_cast<int64_t>(b) * ldx + units[4 * u + 2]]);
+  ids_t[i] = id;
+  if (parts_t) {
+    const int di = units[4 * u], wi = units[4 * u + 1];
+    const int64_t vocab = (di >= 0) ? deep[di].vocab : wide[wi].vocab;
+    parts_t[i] = static_cast<uint16_t>(static_cast<uint32_t>(clamp_id(id, vocab)) % static_cast<uint32_t>(n_parts));
+  }
 }
 
 // Partitions per unit: ~3/4 of a tile per workgroup (a partition's size is Poisson-like: mean 96 of 128 leaves
 // 3.3 sigma of head room), whatever the batch.  P need not be a power of two.
 int pick_p(int B, int tile) {
+#ifdef DCTR_DIAG
   if (g_force_p > 0) return g_force_p;
+#endif
   int per = tile * 3 / 4;
   if (per < 1) per = 1;
   int P = (B + per - 1) / per;
@@ -685,23 +845,49 @@ int ceil_log2(int64_t x) {
   return l;
 }
 
+// lanes of a workgroup that share one row (a power of two) and the floats each of them moves
+void lane_layout(const dctr_plan_t* plan, int* vec_out, int* lpr_out) {
+  int vec = plan->n_deep > 0 ? plan->vec : 1;
+  if (vec == 4 && plan->emb_dim > 0 && plan->emb_dim % 8 == 0 && plan->emb_dim <= 64) vec = 8;  // two dwordx4 per lane
+  int lpr = 1;
+  const int need = plan->n_deep > 0 ? (plan->max_dim + vec - 1) / vec : 1;
+  while (lpr < need) lpr <<= 1;
+  *vec_out = vec;
+  *lpr_out = lpr;
+}
+
 }  // namespace
 
-extern "C" int dctr_embed_ids(const int32_t* units, int32_t n_units, const float* X, int64_t ldx,
-                              int32_t B, int32_t* ids_t, dctr_stream_t stream) {
+// partitions per unit dctr_embed_update uses for this plan / batch: what the forward's parts_t side output is taken
+// modulo (0 on bad arguments)
+extern "C" int32_t dctr_embed_update_partitions(const dctr_plan_t* plan, int32_t B) {
+  if (!plan || B <= 0) return 0;
+  int vec, lpr;
+  lane_layout(plan, &vec, &lpr);
+  return pick_p(B, kThreads / lpr);
+}
+
+extern "C" int dctr_embed_ids(const dctr_plan_t* plan, const int32_t* units, int32_t n_units, const float* X,
+                              int64_t ldx, int32_t B, int32_t* ids_t, uint16_t* parts_t, dctr_stream_t stream) {
   if (!units || !X || !ids_t || n_units <= 0 || B < 0) return DCTR_EINVAL;
+  if (parts_t && !plan) return DCTR_EINVAL;
   if (B == 0) return DCTR_OK;
+  const int n_parts = parts_t ? dctr_embed_update_partitions(plan, B) : 0;
+  if (parts_t && (n_parts <= 0 || n_parts > 65535)) return DCTR_ENOSUP;
   const int64_t n = static_cast<int64_t>(n_units) * B;
   k_embed_ids<<<dim3(static_cast<unsigned>((n + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                static_cast<hipStream_t>(stream)>>>(units, n_units, X, ldx, B, ids_t);
+                static_cast<hipStream_t>(stream)>>>(plan ? plan->deep : nullptr, plan ? plan->wide : nullptr, units,
+                                                    n_units, X, ldx, B, ids_t, parts_t, n_parts);
   return launch_status();
 }
 
 // diagnostics: per-workgroup phase timestamps (8 x u64 per workgroup, wall_clock64 ticks) and a partition override
+#ifdef DCTR_DIAG
 extern "C" void dctr_dbg_update_trace(unsigned long long* buf, int32_t force_p) {
   g_trace = buf;
   g_force_p = force_p;
 }
+#endif
 
 extern "C" int dctr_embed_update_supported(const dctr_plan_t* plan, int64_t max_vocab, int32_t B) {
   if (!plan || B <= 0) return 0;
@@ -720,21 +906,52 @@ extern "C" int dctr_embed_update_supported(const dctr_plan_t* plan, int64_t max_
 // the kernels leave the counters at zero)
 extern "C" int64_t dctr_embed_update_workspace_ints(const dctr_plan_t* plan, int32_t n_units, int32_t B) {
   if (!plan || n_units <= 0 || B <= 0) return 0;
-  int vec = plan->n_deep > 0 ? plan->vec : 1;
-  if (vec == 4 && plan->emb_dim > 0 && plan->emb_dim % 8 == 0 && plan->emb_dim <= 64) vec = 8;
-  int lpr = 1;
-  const int need = plan->n_deep > 0 ? (plan->max_dim + vec - 1) / vec : 1;
-  while (lpr < need) lpr <<= 1;
+  return static_cast<int64_t>(n_units) * dctr_embed_update_partitions(plan, B) * (1 + kBucket);
+}
+
+extern "C" int dctr_embed_segments(const dctr_plan_t* plan, const int32_t* units, int32_t n_units, int64_t max_vocab,
+                                   const int32_t* ids_t, const uint16_t* parts_t, int32_t B, int32_t* workspace,
+                                   int64_t workspace_ints, dctr_stream_t stream) {
+  if (!plan || !units || !ids_t || !workspace || n_units <= 0 || B < 0) return DCTR_EINVAL;
+  if (B == 0) return DCTR_OK;
+  if (!dctr_embed_update_supported(plan, max_vocab, B)) return DCTR_ENOSUP;
+  int vec, lpr;
+  lane_layout(plan, &vec, &lpr);
   const int P = pick_p(B, kThreads / lpr);
-  return static_cast<int64_t>(n_units) * P * (1 + kBucket);
+  const int64_t nbuckets = static_cast<int64_t>(n_units) * P;
+  if (workspace_ints < nbuckets * (1 + kBucket)) return DCTR_EINVAL;
+  UpdArgs a = {};
+  a.deep = plan->deep; a.wide = plan->wide; a.units = units; a.ids_t = ids_t; a.parts_t = parts_t;
+  a.n_units = n_units; a.B = B; a.P = P;
+  a.bbits = ceil_log2(B < 2 ? 2 : B);
+  a.pshift = 32 + ceil_log2(P);
+  a.pmagic = static_cast<uint64_t>((static_cast<unsigned __int128>(1) << a.pshift) / static_cast<unsigned>(P)) + 1;
+  a.bcnt = workspace;
+  a.bkeys = reinterpret_cast<uint32_t*>(workspace + nbuckets);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(nbuckets)), block(kThreads);
+  // small batches: every workgroup finds its entries by comparing the forward's 16-bit partition tags (B / 8 vector
+  // loads per workgroup).  Large batches (or no tags): one global atomic per entry buckets them first.
+  if (parts_t && P <= 65535 && B < 16384) {
+    k_embed_segments<false><<<grid, block, 0, s>>>(a);
+  } else {
+    const int64_t ne = static_cast<int64_t>(n_units) * B;
+    k_bucket<<<dim3(static_cast<unsigned>((ne + kThreads - 1) / kThreads)), block, 0, s>>>(a);
+    const int st = launch_status();
+    if (st != DCTR_OK) return st;
+    k_embed_segments<true><<<grid, block, 0, s>>>(a);
+  }
+  return launch_status();
 }
 
 extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, int32_t n_units,
-                                 int64_t max_vocab, const int32_t* ids_t, int32_t B, const float* g_out,
+                                 int64_t max_vocab, const int32_t* ids_t, const uint16_t* parts_t, int32_t B,
+                                 const float* g_out,
                                  int64_t ld_g, const float* out, int64_t ld_out, const float* fm_s,
                                  int64_t ld_s, const float* g_fm, const float* g_wide, int64_t ld_gw,
                                  int32_t opt, float lr, float eps, const float* X, int64_t ld_x, float* g_wdense,
-                                 int32_t* workspace, int64_t workspace_ints, dctr_stream_t stream) {
+                                 int32_t* workspace, int64_t workspace_ints, int32_t presorted,
+                                 dctr_stream_t stream) {
   (void)out;
   (void)ld_out;  // kept in the signature: the forward's rows are no longer re-read (FM is folded algebraically)
   if (!plan || !units || !ids_t || n_units <= 0 || B < 0) return DCTR_EINVAL;
@@ -746,28 +963,31 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
   if (opt == DCTR_UPD_ACCUM && !(plan->flags & DCTR_PLAN_HAS_GACC)) return DCTR_EINVAL;
   if (opt == DCTR_UPD_ADAGRAD && !(plan->flags & DCTR_PLAN_HAS_STATE)) return DCTR_EINVAL;
   if (g_fm && (!fm_s || plan->emb_dim <= 0)) return DCTR_EINVAL;
-  int vec = plan->n_deep > 0 ? plan->vec : 1;
-  const int avec = vec;  // alignment granule the caller guarantees
-  if (vec == 4 && plan->emb_dim > 0 && plan->emb_dim % 8 == 0 && plan->emb_dim <= 64) vec = 8;  // two dwordx4 per lane
+  int vec, lpr;
+  lane_layout(plan, &vec, &lpr);
+  const int avec = plan->n_deep > 0 ? plan->vec : 1;  // alignment granule the caller guarantees
   if (avec > 1) {
     if (g_out && (ld_g % avec != 0 || reinterpret_cast<uintptr_t>(g_out) % (4 * avec) != 0)) return DCTR_EALIGN;
     if (g_fm && (ld_s % avec != 0 || reinterpret_cast<uintptr_t>(fm_s) % (4 * avec) != 0)) return DCTR_EALIGN;
   }
   UpdArgs a;
   a.deep = plan->deep; a.wide = plan->wide; a.units = units; a.ids_t = ids_t;
+  a.parts_t = nullptr;
   a.gout = g_out; a.fm_s = fm_s; a.gfm = g_fm; a.gwide = g_wide; a.ldgw = ld_gw;
   a.ldg = ld_g; a.lds_ = ld_s;
   a.n_units = n_units; a.B = B;
   a.bbits = ceil_log2(B < 2 ? 2 : B);
   a.lr = lr; a.eps = eps;
+#ifdef DCTR_DIAG
   a.trace = g_trace;
+#else
+  a.trace = nullptr;
+#endif
   a.X = X; a.ldx = ld_x; a.wdense_cols = plan->wdense_cols; a.n_wdense = plan->n_wdense; a.g_wdense = g_wdense;
 
-  int lpr = 1;
-  const int need = plan->n_deep > 0 ? (plan->max_dim + vec - 1) / vec : 1;
-  while (lpr < need) lpr <<= 1;
   const int P = pick_p(B, kThreads / lpr);
   a.P = P;
+  if (parts_t && P <= 65535) a.parts_t = parts_t;   // (taken modulo the same P: dctr_embed_update_partitions)
   a.pshift = 32 + ceil_log2(P);
   a.pmagic = static_cast<uint64_t>((static_cast<unsigned __int128>(1) << a.pshift) / static_cast<unsigned>(P)) + 1;
   const dim3 grid(static_cast<unsigned>(n_units) * static_cast<unsigned>(P) +
@@ -776,14 +996,20 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   a.bcnt = nullptr;
   a.bkeys = nullptr;
+  a.presorted = 0;
   const int64_t nbuckets = static_cast<int64_t>(n_units) * P;
+  if (presorted && !(workspace && workspace_ints >= nbuckets * (1 + kBucket))) return DCTR_EINVAL;
   if (workspace && workspace_ints >= nbuckets * (1 + kBucket)) {
     a.bcnt = workspace;
     a.bkeys = reinterpret_cast<uint32_t*>(workspace + nbuckets);
-    const int64_t ne = static_cast<int64_t>(n_units) * B;
-    k_bucket<<<dim3(static_cast<unsigned>((ne + kThreads - 1) / kThreads)), block, 0, s>>>(a);
-    const int st = launch_status();
-    if (st != DCTR_OK) return st;
+    if (presorted) {
+      a.presorted = 1;    // dctr_embed_segments filled (and sorted) the buckets on these very ids
+    } else {
+      const int64_t ne = static_cast<int64_t>(n_units) * B;
+      k_bucket<<<dim3(static_cast<unsigned>((ne + kThreads - 1) / kThreads)), block, 0, s>>>(a);
+      const int st = launch_status();
+      if (st != DCTR_OK) return st;
+    }
   }
 
 #define DCTR_UPD_LAUNCH(VEC_, LPR_)                               \

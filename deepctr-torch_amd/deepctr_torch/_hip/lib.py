@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdctr_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 
@@ -20,7 +20,7 @@ class Field(ctypes.Structure):
     _fields_ = [("table", ctypes.c_void_p), ("gacc", ctypes.c_void_p), ("state", ctypes.c_void_p),
                 ("vocab", ctypes.c_int64), ("dim", ctypes.c_int32), ("col", ctypes.c_int32),
                 ("len", ctypes.c_int32), ("pool", ctypes.c_int32), ("len_col", ctypes.c_int32),
-                ("out_off", ctypes.c_int32), ("pad_", ctypes.c_int32 * 2)]
+                ("out_off", ctypes.c_int32), ("ld", ctypes.c_int32), ("ld_state", ctypes.c_int32)]
 
 
 class Plan(ctypes.Structure):
@@ -59,7 +59,9 @@ class LazyUnit(ctypes.Structure):
                 ("deep_g", ctypes.c_void_p), ("wide", ctypes.c_void_p), ("wide_s1", ctypes.c_void_p),
                 ("wide_s2", ctypes.c_void_p), ("wide_g", ctypes.c_void_p), ("stamp", ctypes.c_void_p),
                 ("vocab", ctypes.c_int64), ("dim", ctypes.c_int32), ("col", ctypes.c_int32),
-                ("l2_deep", ctypes.c_float), ("l2_wide", ctypes.c_float)]
+                ("l2_deep", ctypes.c_float), ("l2_wide", ctypes.c_float),
+                ("ld_deep", ctypes.c_int32), ("ld_deep_s1", ctypes.c_int32),
+                ("ld_wide", ctypes.c_int32), ("ld_wide_s1", ctypes.c_int32)]
 
 
 class LazyOpt(ctypes.Structure):
@@ -81,12 +83,13 @@ SIGNATURES = {
     "dctr_sizeof_field": (ctypes.c_size_t, []),
     "dctr_sizeof_plan": (ctypes.c_size_t, []),
     "dctr_embed_fwd": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P, _P, _I32, _P,
-                                      _P, _I64, _P]),
+                                      _P, _P, _I64, _P]),
     "dctr_embed_update_supported": (ctypes.c_int, [ctypes.POINTER(Plan), _I64, _I32]),
-    "dctr_dbg_update_trace": (None, [_P, _I32]),
-    "dctr_embed_ids": (ctypes.c_int, [_P, _I32, _P, _I64, _I32, _P, _P]),
-    "dctr_embed_update": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I32, _I64, _P, _I32, _P, _I64, _P, _I64, _P, _I64,
-                                         _P, _P, _I64, _I32, _F32, _F32, _P, _I64, _P, _P, _I64, _P]),
+    "dctr_embed_update_partitions": (ctypes.c_int32, [ctypes.POINTER(Plan), _I32]),
+    "dctr_embed_ids": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I32, _P, _I64, _I32, _P, _P, _P]),
+    "dctr_embed_update": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I32, _I64, _P, _P, _I32, _P, _I64, _P, _I64, _P, _I64,
+                                         _P, _P, _I64, _I32, _F32, _F32, _P, _I64, _P, _P, _I64, _I32, _P]),
+    "dctr_embed_segments": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I32, _I64, _P, _P, _I32, _P, _I64, _P]),
     "dctr_embed_update_workspace_ints": (ctypes.c_int64, [ctypes.POINTER(Plan), _I32, _I32]),
     "dctr_embed_bwd": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P,
                                       _I32, _F32, _P]),
@@ -117,7 +120,6 @@ SIGNATURES = {
     "dctr_crossnet_vec_bwd_workspace_floats": (ctypes.c_size_t, [_I32, _I32, _I32]),
     "dctr_crossnet_vec_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P]),
     "dctr_sizeof_mlp": (ctypes.c_size_t, []),
-    "dctr_dbg_mlp_trace": (None, [_P]),
     "dctr_mlp_fwd": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _P]),
     "dctr_mlp_bwd_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(Mlp), _I32]),
     "dctr_mlp_bwd": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P]),
@@ -146,8 +148,25 @@ SIGNATURES = {
     "dctr_bi_pooling_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _I64, _P, _I64, _P]),
 }
 
+# entry points that exist only in the diagnostics build (make -C csrc diag -> libdctr_hip_diag.so; include/dctr.h
+# declares them under DCTR_DIAG): tools/upd_trace.py and tools/mlp_trace.py load that library with use_diag_library()
+DIAG_SIGNATURES = {
+    "dctr_dbg_update_trace": (None, [_P, _I32]),
+    "dctr_dbg_mlp_trace": (None, [_P]),
+}
+DIAG_LIB_PATH = os.path.join(_HERE, "libdctr_hip_diag.so")
+
 _lib = None
 _lock = threading.Lock()
+
+
+def use_diag_library():
+    """Profiling tools only: make lib() load the diagnostics build (same ABI + the dctr_dbg_* hooks)."""
+    global LIB_PATH, _lib
+    if not os.path.exists(DIAG_LIB_PATH):
+        raise RuntimeError("%s is not built: make -C deepctr-torch_amd/csrc diag" % DIAG_LIB_PATH)
+    LIB_PATH, _lib = DIAG_LIB_PATH, None
+    SIGNATURES.update(DIAG_SIGNATURES)
 
 
 def available():

@@ -69,18 +69,24 @@ class EmbedFunction(torch.autograd.Function):
             else:
                 lazy.flush()
         # side outputs for the deterministic fused update (only when a backward can follow)
-        ids_t = fm_s = None
+        ids_t = parts_t = fm_s = None
         ld_s = 0
         if for_backward and plan.table_params and plan.update_kernel_ok(B):
             ids_t = torch.empty((len(plan.units), B), dtype=torch.int32, device=X.device)
+            # each entry's partition of the update kernel (a 16-bit tag: its workgroups compare instead of dividing)
+            parts_t = torch.empty((len(plan.units), B), dtype=torch.int16, device=X.device)
             if want_fm:
                 ld_s = (plan.emb_dim + 3) // 4 * 4
                 fm_s = torch.empty((B, ld_s), dtype=torch.float32, device=X.device)
         L.check(lib.dctr_embed_fwd(cplan, _ptr(X), X.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), 1, _ptr(fm),
                                    _ptr(plan.err_flag(X.device)), plan.units_ptr(), len(plan.units), _ptr(ids_t),
-                                   _ptr(fm_s), ld_s, L.stream_handle(X.device)), "dctr_embed_fwd")
+                                   _ptr(parts_t), _ptr(fm_s), ld_s, L.stream_handle(X.device)), "dctr_embed_fwd")
         ctx.plan, ctx.want_fm = plan, want_fm
-        ctx.save_for_backward(X, out if want_fm else None, ids_t, fm_s)
+        # the part of the update that needs only the ids runs now, on a side stream, under the tower
+        ctx.seg_event = None
+        if ids_t is not None and plan.segments_enabled() and getattr(plan, "exchange", None) is None:
+            ctx.seg_event = plan.launch_segments(ids_t, parts_t, B)
+        ctx.save_for_backward(X, out if want_fm else None, ids_t, fm_s, parts_t)
         ctx.set_materialize_grads(False)
         outs = (out if out is not None else X.new_zeros((B, 0)),
                 wide if wide is not None else X.new_zeros((B,)),
@@ -91,7 +97,7 @@ class EmbedFunction(torch.autograd.Function):
     def backward(ctx, g_out, g_wide, g_fm):
         lib = L.lib()
         plan = ctx.plan
-        X, out, ids_t, fm_s = ctx.saved_tensors
+        X, out, ids_t, fm_s, parts_t = ctx.saved_tensors
         B = X.shape[0]
         g_wd = None
         if not plan.has_lookup:
@@ -139,12 +145,12 @@ class EmbedFunction(torch.autograd.Function):
                                           "(DCTR_LAZY_UPDATE=0 selects the exact dense path)")
             lazy._ensure(X.device)
             cplan = plan.bind(X.device)
-            ws, ws_n = plan.update_workspace(B, X.device)
-            L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t), B,
-                                          _ptr(g_out), ld_g, _ptr(out), plan.ld_out, _ptr(fm_s),
+            ws, ws_n, pre = plan.update_workspace_for(ids_t, ctx.seg_event, B)
+            L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t),
+                                          _ptr(parts_t), B, _ptr(g_out), ld_g, _ptr(out), plan.ld_out, _ptr(fm_s),
                                           fm_s.stride(0) if fm_s is not None else 0, _ptr(g_fm), _ptr(g_wide), 1,
                                           L.UPD_ACCUM, 0.0, 0.0, _ptr(X), X.stride(0), _ptr(g_wd), _ptr(ws), ws_n,
-                                          stream), "dctr_embed_update(accumulate)")
+                                          pre, stream), "dctr_embed_update(accumulate)")
             lazy.apply(ids_t)
             return None, None, None, g_w, None, None
 
@@ -161,11 +167,11 @@ class EmbedFunction(torch.autograd.Function):
             else:
                 raise RuntimeError("unknown sparse update mode %r" % (kind,))
             cplan = plan.bind(X.device)
-            ws, ws_n = plan.update_workspace(B, X.device)
-            L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t), B,
-                                          _ptr(g_out), ld_g, _ptr(out), plan.ld_out, _ptr(fm_s),
+            ws, ws_n, pre = plan.update_workspace_for(ids_t, ctx.seg_event, B)
+            L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t),
+                                          _ptr(parts_t), B, _ptr(g_out), ld_g, _ptr(out), plan.ld_out, _ptr(fm_s),
                                           fm_s.stride(0) if fm_s is not None else 0, _ptr(g_fm), _ptr(g_wide), 1,
-                                          opt, lr, eps, _ptr(X), X.stride(0), _ptr(g_wd), _ptr(ws), ws_n, stream),
+                                          opt, lr, eps, _ptr(X), X.stride(0), _ptr(g_wd), _ptr(ws), ws_n, pre, stream),
                     "dctr_embed_update")
             return None, None, None, g_w, None, None
 

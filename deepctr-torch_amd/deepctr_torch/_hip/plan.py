@@ -139,8 +139,8 @@ class LazyState(object):
         plan.ensure_gacc()
         key = [str(device)]
         for p in plan.table_params:
-            key.append((p.data_ptr(), _GACC[p].data_ptr()) + tuple(
-                d[id(p)].data_ptr() if id(p) in d else 0 for d in (self.s1, self.s2)))
+            key.append((p.data_ptr(), _GACC[p].data_ptr(), p.stride(0)) + tuple(
+                (d[id(p)].data_ptr(), d[id(p)].stride(0)) if id(p) in d else 0 for d in (self.s1, self.s2)))
         key = tuple(key)
         if key != self._key:
             arr = (L.LazyUnit * len(plan.units))()
@@ -154,12 +154,18 @@ class LazyState(object):
                     e.deep_s1 = self.s1[id(p)].data_ptr() if id(p) in self.s1 else None
                     e.deep_s2 = self.s2[id(p)].data_ptr() if id(p) in self.s2 else None
                     e.l2_deep = self.l2.get(id(p), 0.0)
+                    e.ld_deep = int(p.stride(0))
+                    e.ld_deep_s1 = int(self.s1[id(p)].stride(0)) if id(p) in self.s1 else 0
+                    if id(p) in self.s2 and not self.s2[id(p)].is_contiguous():
+                        raise RuntimeError("the second optimizer state slab of a table must be contiguous")
                 if fw is not None:
                     p = fw.param
                     e.wide, e.wide_g = p.data_ptr(), _GACC[p].data_ptr()
                     e.wide_s1 = self.s1[id(p)].data_ptr() if id(p) in self.s1 else None
                     e.wide_s2 = self.s2[id(p)].data_ptr() if id(p) in self.s2 else None
                     e.l2_wide = self.l2.get(id(p), 0.0)
+                    e.ld_wide = int(p.stride(0))
+                    e.ld_wide_s1 = int(self.s1[id(p)].stride(0)) if id(p) in self.s1 else 0
                 e.stamp = self.stamps[u].data_ptr()
                 e.vocab = self._unit_vocab(u)
                 e.dim = fd.dim if fd is not None else 1
@@ -183,8 +189,9 @@ class LazyState(object):
         self._ensure(X.device)
         B = X.shape[0]
         ids_t = torch.empty((len(plan.units), B), dtype=torch.int32, device=X.device)
-        L.check(L.lib().dctr_embed_ids(plan.units_ptr(), len(plan.units), ctypes.c_void_p(X.data_ptr()), X.stride(0), B,
-                                       ctypes.c_void_p(ids_t.data_ptr()), L.stream_handle(X.device)), "dctr_embed_ids")
+        L.check(L.lib().dctr_embed_ids(None, plan.units_ptr(), len(plan.units), ctypes.c_void_p(X.data_ptr()),
+                                       X.stride(0), B, ctypes.c_void_p(ids_t.data_ptr()), None,
+                                       L.stream_handle(X.device)), "dctr_embed_ids")
         self._call(L.lib().dctr_lazy_catchup, "dctr_lazy_catchup", ctypes.c_void_p(ids_t.data_ptr()), B)
         return ids_t
 
@@ -319,12 +326,13 @@ class EmbeddingPlan(object):
         self._err = None
         self._wd_idx = None
         self._upd_ws = {}
+        self._seg_stream = None
 
     # models holding a plan stay picklable (tests/utils.py:162-170 of the reference pickle whole models):
     # raw ctypes / device handles are dropped and re-baked lazily
     def __getstate__(self):
         d = dict(self.__dict__)
-        for k in ("_key", "_dev", "cplan", "anchor", "_err", "_wd_idx", "_upd_ws"):
+        for k in ("_key", "_dev", "cplan", "anchor", "_err", "_wd_idx", "_upd_ws", "_seg_stream"):
             d.pop(k, None)
         d["exchange"] = None
         d["sharder"] = None
@@ -425,7 +433,8 @@ class EmbeddingPlan(object):
         key = [str(device)]
         for p in self._params:
             g, s = _GACC.get(p), _STATE.get(p)
-            key.append((p.data_ptr(), g.data_ptr() if g is not None else 0, s.data_ptr() if s is not None else 0))
+            key.append((p.data_ptr(), g.data_ptr() if g is not None else 0, s.data_ptr() if s is not None else 0,
+                        p.stride(0), s.stride(0) if s is not None else 0))
         w = self.wide_dense_weight
         key.append(w.data_ptr() if w is not None else 0)
         return tuple(key)
@@ -439,6 +448,9 @@ class EmbeddingPlan(object):
             arr[i].state = s.data_ptr() if s is not None else None
             arr[i].vocab, arr[i].dim, arr[i].col, arr[i].len = f.vocab, f.dim, f.col, f.len
             arr[i].pool, arr[i].len_col, arr[i].out_off = f.pool, f.len_col, f.out_off
+            # row strides: a table / its state may be strided views of one interleaved slab (_hip/layout.py)
+            arr[i].ld = int(f.param.stride(0))
+            arr[i].ld_state = int(s.stride(0)) if s is not None else 0
         return bytes(arr)
 
     def bind(self, device):
@@ -449,8 +461,16 @@ class EmbeddingPlan(object):
             return ctypes.byref(self.cplan)
         for p in self._params:
             L.require_gpu(p, "embedding table")
-            if not p.is_contiguous() or p.dtype != torch.float32:
-                raise RuntimeError("embedding tables must be contiguous float32")
+            if p.dim() != 2 or p.dtype != torch.float32 or (p.shape[1] > 1 and p.stride(1) != 1) or \
+                    p.stride(0) < p.shape[1]:
+                raise RuntimeError("embedding tables must be float32 [V, D] with unit stride inside a row")
+            if self.vec > 1 and p.shape[1] > 1 and (p.stride(0) % self.vec or p.data_ptr() % (4 * self.vec)):
+                raise RuntimeError("embedding table rows must start on %d-byte boundaries" % (4 * self.vec))
+            st = _STATE.get(p)
+            if st is not None and (st.shape != p.shape or (p.shape[1] > 1 and st.stride(1) != 1) or
+                                   (self.vec > 1 and p.shape[1] > 1 and
+                                    (st.stride(0) % self.vec or st.data_ptr() % (4 * self.vec)))):
+                raise RuntimeError("optimizer state of an embedding table must mirror its shape and alignment")
         if self.wide_dense_weight is not None:
             L.require_gpu(self.wide_dense_weight, "Linear.weight")
 
@@ -496,22 +516,84 @@ class EmbeddingPlan(object):
     def units_ptr(self):
         return ctypes.c_void_p(self._dev["units"].data_ptr())
 
-    def update_workspace(self, B, device):
-        """(int32 tensor | None, n_ints): the optional bucket workspace of ``dctr_embed_update`` -- zero before its
-        first use, left zeroed by the kernels, so one tensor per (batch, device) serves every step.  Used for large
-        batches, where a workgroup's scan over the unit's B ids is the expensive part (DCTR_UPD_BUCKET=1 / 0 forces
-        it on / off)."""
+    def update_workspace(self, B, device, always=False):
+        """(int32 tensor | None, n_ints): the bucket workspace of ``dctr_embed_update`` / ``dctr_embed_segments`` -- zero
+        before its first use, left ready by the kernels, so one tensor per (batch, device) serves every step.  Without
+        the segment pre-pass it only pays for large batches, where a workgroup's scan over the unit's B ids is the
+        expensive part (DCTR_UPD_BUCKET=1 / 0 forces it on / off); ``always``: the pre-pass needs it at any size."""
         import os
         mode = os.environ.get("DCTR_UPD_BUCKET", "auto")
-        if mode == "0" or (mode != "1" and B < 8192):
+        if not always and (mode == "0" or (mode != "1" and B < 8192)):
             return None, 0
         key = (int(B), str(device))
         ws = self._upd_ws.get(key)
         if ws is None:
             n = int(L.lib().dctr_embed_update_workspace_ints(ctypes.byref(self.cplan), len(self.units), int(B)))
             ws = torch.zeros(max(n, 1), dtype=torch.int32, device=device)
-            self._upd_ws = {key: ws}          # one live workspace per plan
+            # One workspace per batch size, kept: a captured hipGraph holds the raw address of the one it was captured
+            # with (fit() alternates between the full-size batch's graph and an eager ragged last batch -- dropping
+            # the first workspace when the second is made left the graph writing into freed memory).  When a run
+            # keeps inventing batch sizes the oldest goes, and the plan version bump makes captured steps re-capture.
+            if len(self._upd_ws) >= 8:
+                self._upd_ws.pop(next(iter(self._upd_ws)))
+                self.version += 1
+            self._upd_ws[key] = ws
         return ws, ws.numel()
+
+    # ---- the segment pre-pass (dctr_embed_segments): what the update needs of the ids, computed right after the
+    # forward on a side stream, in the shadow of the tower ------------------------------------------------------
+    def segments_enabled(self):
+        import os
+        return os.environ.get("DCTR_SEGMENTS", "1") != "0"
+
+    def launch_segments(self, ids_t, parts_t, B):
+        """Enqueue the pre-pass for this forward's ids on the side stream.  Returns the handle the update passes to
+        ``update_workspace_for``.  A workspace still marked by an earlier forward (whose backward never ran -- a
+        forward in train mode that was not followed by a backward) is taken over."""
+        device = ids_t.device
+        ws, ws_n = self.update_workspace(B, device, always=True)
+        dirty = getattr(ws, "_dctr_owner", None) is not None
+
+        def enqueue(stream):
+            if dirty:
+                ws.zero_()          # the abandoned pre-pass left bucket counts behind
+            L.check(L.lib().dctr_embed_segments(ctypes.byref(self.cplan), self.units_ptr(), len(self.units),
+                                                self.max_vocab, ctypes.c_void_p(ids_t.data_ptr()),
+                                                ctypes.c_void_p(parts_t.data_ptr()), int(B),
+                                                ctypes.c_void_p(ws.data_ptr()), ws_n, stream), "dctr_embed_segments")
+
+        if device.type != "cuda":                  # (CPU stand-in: same calls, no streams)
+            enqueue(None)
+            ws._dctr_owner = ids_t.data_ptr()
+            return (True, ws)
+        main = torch.cuda.current_stream(device)
+        side = self._seg_stream
+        if side is None or side.device != device:
+            side = self._seg_stream = torch.cuda.Stream(device=device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            enqueue(L.stream_handle(device))
+            ev = torch.cuda.Event()
+            ev.record(side)
+        ws._dctr_owner = ids_t.data_ptr()
+        return (ev, ws)
+
+    def update_workspace_for(self, ids_t, handle, B):
+        """(workspace | None, n_ints, presorted) for the update of the forward that produced ``ids_t``: its own
+        pre-pass when that ran (after waiting for it); otherwise the plain bucket workspace of large batches -- unless
+        another forward's pre-pass currently owns it, then none (every workgroup scans for itself)."""
+        device = ids_t.device
+        if handle is not None:
+            event, ws = handle
+            if getattr(ws, "_dctr_owner", None) == ids_t.data_ptr():
+                ws._dctr_owner = None
+                if event is not True:
+                    torch.cuda.current_stream(device).wait_event(event)
+                return ws, ws.numel(), 1
+        ws, n = self.update_workspace(B, device)
+        if ws is not None and getattr(ws, "_dctr_owner", None) is not None:
+            return None, 0, 0
+        return ws, n, 0
 
     def update_kernel_ok(self, B):
         """True when the deterministic fused update (dctr_embed_update) can run this plan at batch ``B``."""

@@ -570,6 +570,11 @@ class BaseModel(nn.Module):
         if self._plan._lazy is not None:
             self._plan._lazy.flush()
             self._plan._lazy = None
+        if mode[0] == "adagrad" and self._plan.unit_path:
+            # what the update kernel touches together lives together: a row shares its 128-byte line with its
+            # Adagrad state (weights and optimizer state become strided views; _hip/layout.py)
+            from .._hip.layout import apply_layout
+            state = apply_layout(self._plan, self.optim)
         self._plan.set_state(state)
         if mode[0] == "adagrad" or (mode[0] == "sgd" and self._plan.has_maxpool):
             self._plan.ensure_gacc()   # two-pass updates: allocate the slabs now (outside any graph capture)

@@ -28,6 +28,17 @@ import torch
 import torch.distributed as dist
 
 
+def _broadcast(t, src, group):
+    """dist.broadcast that also serves strided views (tables seated in an interleaved slab, _hip/layout.py):
+    collectives want dense buffers."""
+    if t.is_contiguous():
+        dist.broadcast(t, src, group=group)
+    else:
+        buf = t.contiguous()
+        dist.broadcast(buf, src, group=group)
+        t.copy_(buf)
+
+
 class DenseBucket(object):
     """All dense (non-table) gradients live in ONE flat fp32 buffer; ``param.grad`` are views into it, so the
     all-reduce needs no packing copies and is a single collective (the whole DeepFM tower is 0.57 MB:
@@ -126,9 +137,9 @@ class DataParallelTrainer(object):
         if broadcast_parameters:
             with torch.no_grad():
                 for p in model.parameters():
-                    dist.broadcast(p.data, 0, group=process_group)
+                    _broadcast(p.data, 0, process_group)
                 for b in model.buffers():
-                    dist.broadcast(b.data, 0, group=process_group)
+                    _broadcast(b.data, 0, process_group)
         self._stash = None
         self.plan.exchange = self._defer          # EmbedFunction.backward hands its inputs over instead of updating
 
@@ -180,11 +191,13 @@ class DataParallelTrainer(object):
             if not plan.update_kernel_ok(NB):
                 raise RuntimeError("global batch %d is beyond the deterministic update kernel" % NB)
             ids_t = torch.empty((len(plan.units), NB), dtype=torch.int32, device=X.device)
-            L.check(lib.dctr_embed_ids(plan.units_ptr(), len(plan.units), _ptr(X_all), gathered.stride(0), NB,
-                                       _ptr(ids_t), stream), "dctr_embed_ids")
-            L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t), NB,
+            parts_t = torch.empty((len(plan.units), NB), dtype=torch.int16, device=X.device)
+            L.check(lib.dctr_embed_ids(cplan, plan.units_ptr(), len(plan.units), _ptr(X_all), gathered.stride(0), NB,
+                                       _ptr(ids_t), _ptr(parts_t), stream), "dctr_embed_ids")
+            L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t),
+                                          _ptr(parts_t), NB,
                                           _ptr(G_all) if plan.deep else None, gathered.stride(0), None, 0, None, 0,
-                                          None, _ptr(gw_all) if plan.wide else None, 1, opt, lr, eps, None, 0, None, None, 0, stream),
+                                          None, _ptr(gw_all) if plan.wide else None, 1, opt, lr, eps, None, 0, None, None, 0, 0, stream),
                     "dctr_embed_update(global)")
         work.wait()
         model.optim.step()
@@ -278,12 +291,14 @@ class HipShardOps(object):
             return chunks, None
         cplan = sub.bind(dev)
         ids_t = torch.empty((len(sub.units), NB), dtype=torch.int32, device=dev)
+        parts_t = torch.empty((len(sub.units), NB), dtype=torch.int16, device=dev)
         wide = self._ptr(chunks, lay.wide_col) if lay.has_wide else None
         L.check(L.lib().dctr_embed_fwd(cplan, self._ptr(ids_all), ids_all.stride(0), NB, self._ptr(chunks), lay.ldc,
                                        wide, lay.ldc, None, self._ptr(self.plan.err_flag(dev)), sub.units_ptr(),
-                                       len(sub.units), self._ptr(ids_t), None, 0, L.stream_handle(dev)),
+                                       len(sub.units), self._ptr(ids_t), self._ptr(parts_t), None, 0,
+                                       L.stream_handle(dev)),
                 "dctr_embed_fwd(owned tables, global batch)")
-        return chunks, ids_t
+        return chunks, (ids_t, parts_t)
 
     def assemble_fwd(self, recv, X, want_fm):
         L, lay, plan = self.L, self.lay, self.plan
@@ -335,9 +350,11 @@ class HipShardOps(object):
             raise RuntimeError("global batch %d is beyond the deterministic update kernel" % NB)
         gw = self._ptr(grads_all, lay.wide_col) if lay.has_wide else None
         ws, ws_n = sub.update_workspace(NB, dev)
-        L.check(L.lib().dctr_embed_update(cplan, sub.units_ptr(), len(sub.units), sub.max_vocab, self._ptr(ids_t), NB,
+        ids_t, parts_t = ids_t
+        L.check(L.lib().dctr_embed_update(cplan, sub.units_ptr(), len(sub.units), sub.max_vocab, self._ptr(ids_t),
+                                          self._ptr(parts_t), NB,
                                           self._ptr(grads_all), lay.ldc, None, 0, None, 0, None, gw, lay.ldc, opt, lr,
-                                          eps, None, 0, None, self._ptr(ws), ws_n, L.stream_handle(dev)),
+                                          eps, None, 0, None, self._ptr(ws), ws_n, 0, L.stream_handle(dev)),
                 "dctr_embed_update(owned tables)")
 
 
@@ -399,7 +416,7 @@ class ShardedTrainer(object):
         if broadcast_parameters:
             with torch.no_grad():
                 for p in model.parameters():
-                    dist.broadcast(p.data, 0, group=process_group)
+                    _broadcast(p.data, 0, process_group)
         st = model._fused_step_state()
         if st is not None and (self.plan.update[0] not in ("sgd", "adagrad") or st["slab"].lam is not None):
             st = None        # the lazy regularised / Adam update is single-GPU
@@ -533,7 +550,7 @@ class ShardedTrainer(object):
             for u, (di, wi, col, _) in enumerate(plan.units):
                 owner = u % self.world
                 for f in ([plan.deep[di]] if di >= 0 else []) + ([plan.wide[wi]] if wi >= 0 else []):
-                    dist.broadcast(f.param.data, owner, group=self.group)
-                    s = _STATE.get(f.param)
-                    if s is not None:
-                        dist.broadcast(s, owner, group=self.group)
+                    for t in (f.param.data, _STATE.get(f.param)):
+                        if t is None:
+                            continue
+                        _broadcast(t, owner, self.group)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 11
+#define DCTR_ABI_VERSION 12
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -45,9 +45,9 @@ typedef void* dctr_stream_t; /* hipStream_t */
  * A deep field gathers dim-wide rows (inputs.py:158-180, basemodel.py:368-375); a wide field is the
  * same thing with dim == 1 (Linear's 1-dim tables, basemodel.py:45-46,65-67).                      */
 typedef struct dctr_field {
-  float* table;    /* [vocab, dim] row-major, embedding_dict[embedding_name].weight                 */
-  float* gacc;     /* [vocab, dim] gradient slab, zero at rest (may be NULL when never accumulated)  */
-  float* state;    /* [vocab, dim] optimizer state (Adagrad sum) or NULL                             */
+  float* table;    /* [vocab, dim] rows `ld` floats apart, embedding_dict[embedding_name].weight     */
+  float* gacc;     /* [vocab, dim] contiguous gradient slab, zero at rest (NULL when never accumulated) */
+  float* state;    /* [vocab, dim] rows `ld_state` floats apart: optimizer state (Adagrad sum) or NULL */
   int64_t vocab;   /* rows                                                                           */
   int32_t dim;     /* embedding_dim (1 for wide)                                                     */
   int32_t col;     /* first column of X holding the id(s)        (inputs.py:99-123)                  */
@@ -55,7 +55,9 @@ typedef struct dctr_field {
   int32_t pool;    /* DCTR_POOL_*                                                                    */
   int32_t len_col; /* column of X holding the valid length, or -1: mask = (id != 0) (inputs.py:146)  */
   int32_t out_off; /* float offset of this field's slice inside one output row (deep only)          */
-  int32_t pad_[2];
+  int32_t ld;      /* floats between consecutive rows of `table`; 0 = dim (contiguous).  A table may be a */
+  int32_t ld_state;/* strided view of a slab that interleaves a row with its optimizer state (and the    */
+                   /* wide weight of the same id): what is updated together then shares one 128-byte line */
 } dctr_field_t;
 
 /* The compiled feature-column schema of one model: what build_input_features + create_embedding_matrix
@@ -103,13 +105,14 @@ size_t dctr_sizeof_plan(void);
  *   fm    [B]  0.5 * sum_d ((sum_f e)^2 - sum_f e^2) over ALL deep fields (nullable; needs emb_dim)
  *   err   int32 flag; bit0 is set when an id falls outside [0, vocab) -- such a row reads as row 0
  *         (the reference raises IndexError on CPU; here the flag is polled by the host) (nullable)
- * Two optional side outputs feed dctr_embed_update (both nullable):
+ * Optional side outputs feed dctr_embed_update (all nullable):
  *   ids_t [n_units, B] int32: ids_t[u][b] = (int) X[b, units[u].col]  (units: see dctr_embed_update)
+ *   parts_t [n_units, B] uint16: clamp(ids_t[u][b]) mod dctr_embed_update_partitions(plan, B)  (needs ids_t)
  *   fm_s  [B, ld_s]    S[b, d] = sum_f e[b, f, d], the per-sample field sum FM's backward needs      */
 int dctr_embed_fwd(const dctr_plan_t* plan, const float* X, int64_t ldx, int32_t B, float* out,
                    int64_t ld_out, float* wide, int64_t ld_wide, float* fm, int32_t* err,
-                   const int32_t* units, int32_t n_units, int32_t* ids_t, float* fm_s, int64_t ld_s,
-                   dctr_stream_t stream);
+                   const int32_t* units, int32_t n_units, int32_t* ids_t, uint16_t* parts_t, float* fm_s,
+                   int64_t ld_s, dctr_stream_t stream);
 
 /* ---- backward of the above = embedding_dense_backward + FM backward, as an O(batch) scatter -------
  * Replaces autograd's aten::embedding_dense_backward x(n_deep+n_wide), the pooling backward and
@@ -148,7 +151,8 @@ int dctr_embed_apply(const dctr_plan_t* plan, const float* X, int64_t ldx, int32
  * result is bit-reproducible (needed for replica equality under data parallelism).
  *   units  [n_units][4] int32 (device): {deep field index | -1, wide field index | -1, X column, 0};
  *          a unit is one id column with the deep and/or wide table it feeds
- *   ids_t  [n_units, B] int32 from dctr_embed_fwd / dctr_embed_ids
+ *   ids_t  [n_units, B] int32 from dctr_embed_fwd / dctr_embed_ids;  parts_t [n_units, B] uint16 from the same
+ *          call (nullable: every workgroup then divides every id of its unit itself)
  *   g_out / out / fm_s / g_fm / g_wide as in dctr_embed_bwd (fm_s = side output of dctr_embed_fwd);
  *          g_wide[b] lives at g_wide[b * ld_gw]
  *   opt    DCTR_UPD_SGD      table[row] -= lr * G                          (torch.optim.SGD)
@@ -163,21 +167,40 @@ int dctr_embed_apply(const dctr_plan_t* plan, const float* X, int64_t ldx, int32
 #define DCTR_UPD_ADAGRAD 1
 #define DCTR_UPD_ACCUM 2
 int dctr_embed_update_supported(const dctr_plan_t* plan, int64_t max_vocab, int32_t B);
-/* diagnostics (tools/upd_trace.py): buf != NULL makes every workgroup of dctr_embed_update record 8 u64
- * (wall_clock64 at start / scan / sort / loads issued / loads landed / tile 0 done / end, then its entry count);
- * force_p > 0 overrides the number of partitions per unit.  dctr_dbg_update_trace(NULL, -1) restores normal operation.  */
+/* P = partitions per unit that dctr_embed_update uses for this plan at batch B (0 on bad arguments).  The optional
+ * side output parts_t [n_units, B] uint16 of dctr_embed_fwd / dctr_embed_ids holds clamp(id) mod P (clamp: an id
+ * outside [0, vocab) counts as 0): with it a workgroup's scan over its unit's B entries is a 16-bit compare per
+ * entry instead of an integer division per entry.                                                              */
+int32_t dctr_embed_update_partitions(const dctr_plan_t* plan, int32_t B);
+#ifdef DCTR_DIAG
+/* diagnostics, only in the DCTR_DIAG build (make -C csrc diag -> libdctr_hip_diag.so; tools/upd_trace.py): buf != NULL
+ * makes every workgroup of dctr_embed_update record 8 u64 (wall_clock64 at start / scan / sort / loads issued / loads
+ * landed / tile 0 done / end, then its entry count); force_p > 0 overrides the number of partitions per unit.
+ * dctr_dbg_update_trace(NULL, -1) restores normal operation.  The shipped library has no mutable global state.   */
 void dctr_dbg_update_trace(unsigned long long* buf, int32_t force_p);
-int dctr_embed_ids(const int32_t* units, int32_t n_units, const float* X, int64_t ldx, int32_t B,
-                   int32_t* ids_t, dctr_stream_t stream);
+#endif
+/* plan is only needed (non-NULL) when parts_t is requested */
+int dctr_embed_ids(const dctr_plan_t* plan, const int32_t* units, int32_t n_units, const float* X, int64_t ldx,
+                   int32_t B, int32_t* ids_t, uint16_t* parts_t, dctr_stream_t stream);
 int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, int32_t n_units, int64_t max_vocab,
-                      const int32_t* ids_t, int32_t B, const float* g_out, int64_t ld_g, const float* out,
-                      int64_t ld_out, const float* fm_s, int64_t ld_s, const float* g_fm,
+                      const int32_t* ids_t, const uint16_t* parts_t, int32_t B, const float* g_out, int64_t ld_g,
+                      const float* out, int64_t ld_out, const float* fm_s, int64_t ld_s, const float* g_fm,
                       const float* g_wide, int64_t ld_gw, int32_t opt, float lr, float eps, const float* X,
-                      int64_t ld_x, float* g_wdense, int32_t* workspace, int64_t workspace_ints,
+                      int64_t ld_x, float* g_wdense, int32_t* workspace, int64_t workspace_ints, int32_t presorted,
                       dctr_stream_t stream);
+/* The part of dctr_embed_update that needs nothing but the ids, as its own launch: every (unit, partition)'s entries
+ * found, sorted by (id, sample) and parked in `workspace` (dctr_embed_update_workspace_ints ints; zero before the
+ * first use).  Enqueue it any time after the forward -- on another stream, in the shadow of the tower -- and pass the
+ * same workspace with presorted = 1 to dctr_embed_update: its workgroups then start with one coalesced read of their
+ * keys (no scan, no sort).  Same results, bit for bit.  dctr_embed_update leaves the workspace ready for the next
+ * dctr_embed_segments.                                                                                         */
+int dctr_embed_segments(const dctr_plan_t* plan, const int32_t* units, int32_t n_units, int64_t max_vocab,
+                        const int32_t* ids_t, const uint16_t* parts_t, int32_t B, int32_t* workspace,
+                        int64_t workspace_ints, dctr_stream_t stream);
 /* workspace (nullable): dctr_embed_update_workspace_ints(plan, n_units, B) int32, ZERO before the first use (the
- * kernels leave it ready for the next launch).  With it a pre-pass buckets the (unit, sample) entries by partition,
- * so no workgroup scans a unit's B ids: worth it for large (global) batches; without it every workgroup scans.   */
+ * kernels leave it ready for the next launch).  With it (and presorted = 0) a pre-pass buckets the (unit, sample)
+ * entries by partition, so no workgroup scans a unit's B ids: worth it for large (global) batches; without it every
+ * workgroup scans.  presorted = 1: see dctr_embed_segments.                                                     */
 int64_t dctr_embed_update_workspace_ints(const dctr_plan_t* plan, int32_t n_units, int32_t B);
 
 /* ---- FM on an explicit [B, F, D] tensor (interaction.py:26-34) ------------------------------------
@@ -247,8 +270,8 @@ int dctr_interacting_bwd(const float* E, int64_t ld_e, int32_t B, int32_t F, int
 #define DCTR_LAZY_ADAGRAD 1
 #define DCTR_LAZY_ADAM 2
 typedef struct dctr_lazy_unit {
-  float* deep;    /* [vocab, dim] or NULL */
-  float* deep_s1;
+  float* deep;    /* [vocab, dim] (rows ld_deep floats apart) or NULL */
+  float* deep_s1; /* rows ld_deep_s1 floats apart; deep_s2 / deep_g are contiguous */
   float* deep_s2;
   float* deep_g;
   float* wide;    /* [vocab] or NULL */
@@ -261,6 +284,8 @@ typedef struct dctr_lazy_unit {
   int32_t col;
   float l2_deep;  /* lambda of the L2 term lambda * sum(w^2) on the deep table */
   float l2_wide;
+  int32_t ld_deep, ld_deep_s1; /* row strides in floats, 0 = dim */
+  int32_t ld_wide, ld_wide_s1; /* row strides in floats, 0 = 1   */
 } dctr_lazy_unit_t;
 typedef struct dctr_lazy_opt {
   int32_t kind; /* DCTR_LAZY_* */
@@ -395,9 +420,12 @@ typedef struct dctr_mlp {
   int32_t pad_;
 } dctr_mlp_t;
 size_t dctr_sizeof_mlp(void);
-/* diagnostics (tools/mlp_trace.py): buf = 3 x 4096 x 16 u64 of per-workgroup wall_clock64 stamps (forward |
- * backward-data | wgrad); NULL switches tracing off.  Batches above 65536 samples are not traced correctly.  */
+#ifdef DCTR_DIAG
+/* diagnostics, DCTR_DIAG build only (tools/mlp_trace.py): buf = 3 x 4096 x 16 u64 of per-workgroup wall_clock64
+ * stamps (forward | backward-data | wgrad); NULL switches tracing off.  Batches above 65536 samples are not traced
+ * correctly.  */
 void dctr_dbg_mlp_trace(unsigned long long* buf);
+#endif
 int dctr_mlp_fwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, float* logit, dctr_stream_t stream);
 size_t dctr_mlp_bwd_workspace_floats(const dctr_mlp_t* m, int32_t B);
 int dctr_mlp_bwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g, int64_t ld_g,

@@ -26,6 +26,15 @@ def _arr(ptr, shape, ld=None, dtype=np.float32):
     return np.lib.stride_tricks.as_strided(flat, shape=(rows, cols), strides=(ld * 4, 4))
 
 
+def _tab(f):
+    """the table of a field descriptor, honouring its row stride (dctr_field_t.ld; 0 = contiguous)"""
+    return _arr(f.table, (f.vocab, f.dim), f.ld or f.dim)
+
+
+def _st(f):
+    return _arr(f.state, (f.vocab, f.dim), f.ld_state or f.dim)
+
+
 class _Core(object):
     def __init__(self):
         self.calls = []
@@ -173,7 +182,7 @@ class _Core(object):
 
     def _gather(self, X, f, err=None):
         """pooled embedding [B, dim] of one field (sequence.py:61-77), fp32 like the reference."""
-        table = _arr(f.table, (f.vocab, f.dim))
+        table = _tab(f)
         if f.pool == 0:                     # SparseFeat (a VarLen column of maxlen 1 still masks its padding id)
             return table[self._rows(X, f, err)]
         ids, mask = self._seq(X, f, err)
@@ -193,7 +202,7 @@ class _Core(object):
         ids, mask = self._seq(X, f)
         m = mask[:, :, None].astype(np.float32)
         if f.pool == 3:
-            rows = _arr(f.table, (f.vocab, f.dim))[ids]
+            rows = _tab(f)[ids]
             arg = (rows - (np.float32(1) - m) * np.float32(1e9)).argmax(axis=1)      # [B, dim]
             g = np.zeros(rows.shape, np.float32)
             np.put_along_axis(g, arg[:, None, :], G[:, None, :], axis=1)
@@ -207,9 +216,19 @@ class _Core(object):
         return 1
 
     def dctr_embed_update_workspace_ints(self, pref, n_units, B):
+        return 4
+
+    def dctr_embed_segments(self, pref, units, n_units, max_vocab, ids_t, parts_t, B, ws, ws_n, stream):
+        """(the pre-pass only re-orders work inside the device code: nothing to compute for the stand-in)"""
+        self.calls.append("embed_segments")
         return 0
 
-    def dctr_embed_ids(self, units, n_units, X, ldx, B, ids_t, stream):
+    def dctr_embed_update_partitions(self, pref, B):
+        return max(1, (int(B) + 95) // 96)
+
+    def dctr_embed_ids(self, pref, units, n_units, X, ldx, B, ids_t, parts_t, stream):
+        """(parts_t -- the update kernel's partition tags -- is an optimisation detail of the device code: the
+        stand-in's update does not read it, and leaves it unwritten)"""
         self.calls.append("embed_ids")
         U = _arr(units, (n_units * 4,), dtype=np.int32).reshape(n_units, 4)
         ncol = int(U[:, 2].max()) + 1
@@ -219,8 +238,8 @@ class _Core(object):
             out[u] = Xv[:, U[u, 2]].astype(np.int32)
         return 0
 
-    def dctr_embed_fwd(self, pref, X, ldx, B, out, ld_out, wide, ld_wide, fm, err, units, n_units, ids_t, fm_s, ld_s,
-                       stream):
+    def dctr_embed_fwd(self, pref, X, ldx, B, out, ld_out, wide, ld_wide, fm, err, units, n_units, ids_t, parts_t,
+                       fm_s, ld_s, stream):
         self.calls.append("embed_fwd")
         c, deep, widef, dcols, wcols = self._plan(pref)
         Xv = _arr(X, (B, c.n_xcols), ldx)
@@ -254,7 +273,7 @@ class _Core(object):
             Sv[...] = 0
             Sv[:, :c.emb_dim] = S[:, :c.emb_dim]
         if _arr(ids_t, (1,)) is not None:
-            self.dctr_embed_ids(units, n_units, X, ldx, B, ids_t, stream)
+            self.dctr_embed_ids(pref, units, n_units, X, ldx, B, ids_t, parts_t, stream)
             self.calls.pop()
         return 0
 
@@ -279,7 +298,7 @@ class _Core(object):
             work += [(f, gW.reshape(B, 1).astype(np.float32)) for f in widef]
         scat = [(f,) + self._scatter(Xv, f, G) for f, G in work]       # max pooling re-reads the tables: gather first
         for f, rows, g in scat:
-            dst = _arr(f.gacc if mode == 0 else f.table, (f.vocab, f.dim))
+            dst = _arr(f.gacc, (f.vocab, f.dim)) if mode == 0 else _tab(f)
             np.add.at(dst, rows, g if mode == 0 else -np.float32(lr) * g)
         return 0
 
@@ -289,11 +308,11 @@ class _Core(object):
         Xv = _arr(X, (B, c.n_xcols), ldx)
         for f in deep + widef:
             rows = np.unique(self._seq(Xv, f)[0])
-            gacc, table = _arr(f.gacc, (f.vocab, f.dim)), _arr(f.table, (f.vocab, f.dim))
+            gacc, table = _arr(f.gacc, (f.vocab, f.dim)), _tab(f)
             G = gacc[rows].copy()
             gacc[rows] = 0
             if opt == 1:
-                st = _arr(f.state, (f.vocab, f.dim))
+                st = _st(f)
                 s2 = st[rows] + G * G
                 table[rows] = np.where(G != 0, table[rows] - np.float32(lr) * (G / (np.sqrt(s2) + np.float32(eps))),
                                        table[rows])
@@ -303,8 +322,8 @@ class _Core(object):
         return 0
 
     # ---- deterministic fused backward + optimizer (dctr_embed_update) ---------------------------------------
-    def dctr_embed_update(self, pref, units, n_units, max_vocab, ids_t, B, g_out, ld_g, out, ld_out, fm_s, ld_s, g_fm,
-                          g_wide, ld_gw, opt, lr, eps, X, ld_x, g_wdense, ws, ws_n, stream):
+    def dctr_embed_update(self, pref, units, n_units, max_vocab, ids_t, parts_t, B, g_out, ld_g, out, ld_out, fm_s, ld_s, g_fm,
+                          g_wide, ld_gw, opt, lr, eps, X, ld_x, g_wdense, ws, ws_n, presorted, stream):
         self.calls.append("embed_update:%d" % opt)
         c, deep, widef, dcols, wcols = self._plan(pref)
         U = _arr(units, (n_units * 4,), dtype=np.int32).reshape(n_units, 4)
@@ -315,7 +334,7 @@ class _Core(object):
 
         def scatter(f, rows, G):
             """sum duplicates in sample order, then one read-modify-write per touched row."""
-            table = _arr(f.table, (f.vocab, f.dim))
+            table = _tab(f)
             uniq, inv = np.unique(rows, return_inverse=True)
             acc = np.zeros((len(uniq), f.dim), np.float32)
             for b in range(B):
@@ -323,7 +342,7 @@ class _Core(object):
             if opt == 0:
                 table[uniq] -= np.float32(lr) * acc
             elif opt == 1:
-                st = _arr(f.state, (f.vocab, f.dim))
+                st = _st(f)
                 st[uniq] += acc * acc
                 table[uniq] -= np.float32(lr) * (acc / (np.sqrt(st[uniq]) + np.float32(eps)))
             else:
@@ -389,12 +408,13 @@ class _Core(object):
                 continue
             prev = stamp[rows].copy()
             stamp[rows] = target
-            for tab, s1, s2, gp, dim, lam in ((un.deep, un.deep_s1, un.deep_s2, un.deep_g, un.dim, un.l2_deep),
-                                              (un.wide, un.wide_s1, un.wide_s2, un.wide_g, 1, un.l2_wide)):
+            for tab, s1, s2, gp, dim, lam, ld_w, ld_a in (
+                    (un.deep, un.deep_s1, un.deep_s2, un.deep_g, un.dim, un.l2_deep, un.ld_deep, un.ld_deep_s1),
+                    (un.wide, un.wide_s1, un.wide_s2, un.wide_g, 1, un.l2_wide, un.ld_wide, un.ld_wide_s1)):
                 if not tab:
                     continue
-                W = _arr(tab, (un.vocab, dim))
-                A = _arr(s1, (un.vocab, dim)) if s1 else None
+                W = _arr(tab, (un.vocab, dim), ld_w or dim)
+                A = _arr(s1, (un.vocab, dim), ld_a or dim) if s1 else None
                 Bv = _arr(s2, (un.vocab, dim)) if s2 else None
                 lam2 = np.float32(2) * np.float32(lam)
                 w = W[rows].copy()

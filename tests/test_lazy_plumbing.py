@@ -48,10 +48,11 @@ def test_lazy_stack_replays_reference_trajectory(mock, name, tag):
     g, m, bce, tot = _run(name, tag)
     ex = g["extra"]
     if name == "lazy_deepfm":
-        # one fused step = ids, catch-up, gather, tower step, accumulate, apply, dense optimizer -- in this order
+        # one fused step = ids, catch-up, gather (+ the segment pre-pass of the update, right behind it), tower step,
+        # accumulate, apply, dense optimizer -- in this order
         first = mock.calls[:mock.calls.index("dense_opt_reg") + 1]
-        assert first == ["embed_ids", "lazy_catchup", "embed_fwd", "mlp_train_step", "embed_update:2", "lazy_apply",
-                         "dense_opt_reg"], first
+        assert first == ["embed_ids", "lazy_catchup", "embed_fwd", "embed_segments", "mlp_train_step", "embed_update:2",
+                         "lazy_apply", "dense_opt_reg"], first
     else:
         # DCN is outside the fused step: autograd + torch.optim around the kernels, the tables still lazily
         i0 = mock.calls.index("lazy_apply")
