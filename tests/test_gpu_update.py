@@ -181,3 +181,34 @@ def test_wide_only_and_deep_only_units():
     torch.nn.functional.binary_cross_entropy(torch.sigmoid(logit).squeeze(), y, reduction="sum").backward()
     for k, p in m.named_parameters():
         assert float((p.grad - P[k].grad).abs().max()) <= 2e-5 * max(1.0, float(P[k].grad.abs().max())), k
+
+
+@pytest.mark.parametrize("idmode,B", [("uniform", 4096), ("hot", 4096), ("same", 777), ("hot", 20000)])
+def test_prepass_layouts_and_inkernel_scan_agree_bit_for_bit(monkeypatch, idmode, B):
+    """The same two Adagrad steps three ways -- (a) segment pre-pass (dctr_embed_segments) + interleaved slabs, the
+    default; (b) no pre-pass: every workgroup scans and sorts for itself; (c) the reference's contiguous tensors --
+    must leave bit-identical tables and optimizer state: the layout only moves bytes, the pre-pass only moves work."""
+    vocabs = [1000, 17, 100_000, 3]
+    X = _batch(B, vocabs, 2, idmode, seed=11)
+    results = []
+    for seg, layout in (("1", "interleaved"), ("0", "interleaved"), ("1", "contiguous"), ("1", "block")):
+        monkeypatch.setenv("DCTR_SEGMENTS", seg)
+        monkeypatch.setenv("DCTR_TABLE_LAYOUT", layout)
+        torch.manual_seed(0)
+        m = _model(len(vocabs), vocabs, 16, 2)
+        m.compile("adagrad", "binary_crossentropy")
+        plan = m.model_plan()
+        p0 = plan.table_params[0]
+        assert p0.stride(0) == {"interleaved": 32, "contiguous": 16, "block": 64}[layout]
+        gen = torch.Generator(device=DEV).manual_seed(1)
+        R_out = torch.randn(B, plan.width, device=DEV, generator=gen)
+        for _ in range(2):
+            out, wide, fm = m.fused_inputs(X, want_fm=True)
+            ((out * R_out).sum() + wide.sum() + fm.sum()).backward()
+        torch.cuda.synchronize()
+        plan.check_ids()
+        results.append([p.detach().clone().contiguous() for p in plan.table_params] +
+                       [m.optim.state[p]["sum"].clone().contiguous() for p in plan.table_params])
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            assert torch.equal(a, b)
