@@ -149,10 +149,30 @@ __device__ __forceinline__ void apply_strip(const dctr_field_t& fd, int64_t off_
   }
 }
 
-// (5 workgroups of 4 waves per CU = 1280 resident, more than the ~1100 a launch has: <= 96 VGPRs, no spills;
-// tighter bounds spill 8-40 registers in the Adagrad variant, which shows up as +8 MB of scratch writes per launch)
+// the dense half of Linear (basemodel.py:86-90): g_w[j] = sum_b g_wide[b] * X[b, col_j].  One extra workgroup per
+// dense column, hidden behind the row updates; per-thread partial sums over a strided row set, then a fixed-order
+// tree => deterministic.
+__device__ __forceinline__ void wdense_column(const UpdArgs& A, int j) {
+  __shared__ float red[kThreads / 64];
+  const int tid = threadIdx.x;
+  const int col = ldg_i32(A.wdense_cols + j);
+  float acc = 0.f;
+#pragma unroll 8
+  for (int b = tid; b < A.B; b += kThreads)
+    acc += ldg_f32(A.gwide + static_cast<int64_t>(b) * A.ldgw) * ldg_f32(A.X + static_cast<int64_t>(b) * A.ldx + col);
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kThreads / 64; ++w) t += red[w];
+    stg_f32(A.g_wdense + j, t);
+  }
+}
+
+// One (unit, partition): scan (or take the bucket), sort, segment sums, one read-modify-write per touched row.
 template <int VEC, int LPR, int OPT>
-__global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
+__device__ __forceinline__ void upd_partition(const UpdArgs& A, const int u, const int p) {
   constexpr int G = kThreads / LPR;   // lane groups per workgroup = entries per tile (a power of two)
   constexpr int RW = LPR * VEC;       // floats of one parked gradient row
   __shared__ uint32_t keys[kCap];     // this pass's entries; sorted in place by the tiled path
@@ -166,33 +186,6 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
   const int tid = threadIdx.x;
   const int P = A.P;
   DCTR_TRACE(0);
-
-  if (A.g_wdense && static_cast<int>(blockIdx.x) >= static_cast<int>(gridDim.x) - A.n_wdense) {
-    // the dense half of Linear (basemodel.py:86-90): g_w[j] = sum_b g_wide[b] * X[b, col_j].  One extra
-    // workgroup per dense column, hidden behind the row updates; per-thread partial sums over a strided row set,
-    // then a fixed-order tree => deterministic.  (Kept tiny on purpose: its registers bound the whole kernel.)
-    __shared__ float red[kThreads / 64];
-    const int j = static_cast<int>(blockIdx.x) - (static_cast<int>(gridDim.x) - A.n_wdense);
-    const int col = ldg_i32(A.wdense_cols + j);
-    float acc = 0.f;
-#pragma unroll 8
-    for (int b = tid; b < A.B; b += kThreads)
-      acc += ldg_f32(A.gwide + static_cast<int64_t>(b) * A.ldgw) * ldg_f32(A.X + static_cast<int64_t>(b) * A.ldx + col);
-    acc = wave_sum(acc);
-    if ((tid & 63) == 0) red[tid >> 6] = acc;
-    __syncthreads();
-    if (tid == 0) {
-      float t = 0.f;
-      for (int w = 0; w < kThreads / 64; ++w) t += red[w];
-      stg_f32(A.g_wdense + j, t);
-    }
-    return;
-  }
-
-  // Work item (unit, partition) in plain launch order: consecutive workgroups go to consecutive XCDs, so every
-  // XCD gets the same number of working workgroups.
-  const int u = static_cast<int>(blockIdx.x) / P, p = static_cast<int>(blockIdx.x) - u * P;
-  if (u >= A.n_units) return;
 
   const int32_t* un = A.units + 4 * u;
   const int di = uni(un[0]), wi = uni(un[1]);
@@ -701,6 +694,215 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
   }
 }
 
+// (5 workgroups of 4 waves per CU = 1280 resident, more than the ~1100 a launch has at batch 4096: <= 96 VGPRs, no
+// spills; tighter bounds spill 8-40 registers in the Adagrad variant = +8 MB of scratch writes per launch)
+template <int VEC, int LPR, int OPT>
+__global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
+  if (A.g_wdense && static_cast<int>(blockIdx.x) >= static_cast<int>(gridDim.x) - A.n_wdense) {
+    wdense_column(A, static_cast<int>(blockIdx.x) - (static_cast<int>(gridDim.x) - A.n_wdense));
+    return;
+  }
+  // Work item (unit, partition) in plain launch order: consecutive workgroups go to consecutive XCDs, so every
+  // XCD gets the same number of working workgroups.
+  const int u = static_cast<int>(blockIdx.x) / A.P, p = static_cast<int>(blockIdx.x) - u * A.P;
+  if (u >= A.n_units) return;
+  upd_partition<VEC, LPR, OPT>(A, u, p);
+}
+
+// Behind k_embed_apply_sorted: the partitions the pre-pass could not sort (more than kBucket entries: hot ids) still
+// carry their count.  A workgroup checks kThreads consecutive counters with one coalesced read and runs the general
+// path for the (rare) ones left; the last n_wdense workgroups do the dense half of Linear.
+template <int VEC, int LPR, int OPT>
+__global__ __launch_bounds__(kThreads, 5) void k_embed_update_overflow(UpdArgs A) {
+  const int n_scan = static_cast<int>(gridDim.x) - (A.g_wdense ? A.n_wdense : 0);
+  if (static_cast<int>(blockIdx.x) >= n_scan) {
+    wdense_column(A, static_cast<int>(blockIdx.x) - n_scan);
+    return;
+  }
+  __shared__ int over[kThreads], n_over;
+  const int tid = threadIdx.x;
+  const int64_t nb = static_cast<int64_t>(A.n_units) * A.P;
+  const int64_t bk = static_cast<int64_t>(blockIdx.x) * kThreads + tid;
+  if (tid == 0) n_over = 0;
+  __syncthreads();
+  if (bk < nb && *(const DCTR_GLOBAL int32_t*)(A.bcnt + bk) > kBucket) over[atomicAdd(&n_over, 1)] = static_cast<int>(bk);
+  __syncthreads();
+  const int n = n_over;
+  if (n == 0) return;
+  // (in whatever order the atomics filled the list: partitions own disjoint rows, nothing depends on it)
+  for (int k = 0; k < n; ++k) {
+    const int mine = over[k];
+    const int u = mine / A.P, p = mine - u * A.P;
+    upd_partition<VEC, LPR, OPT>(A, u, p);
+    __syncthreads();
+  }
+}
+
+// ---- the update proper, given the pre-pass's sorted keys ------------------------------------------------------------
+// What is left on the step's critical chain once dctr_embed_segments has run: TWO memory round trips per workgroup --
+// {entry count, sorted keys} (one coalesced read), then {gradient strips, row strips} -- a segmented sum through LDS
+// and one read-modify-write per touched row.  No scan, no sort, no stack: 8 workgroups per CU (the general kernel
+// below: 5), so a saturating launch keeps ~1.6x more rows in flight.  Same tiling, same summation order as the general
+// kernel's tiled path: bit-identical results.  Partitions whose count exceeds kBucket (hot ids) are left alone -- the
+// general kernel, launched right behind, sees their counters and scans them itself (all others read 0 there).
+template <int VEC, int LPR, int OPT>
+__global__ __launch_bounds__(kThreads, 6) void k_embed_apply_sorted(UpdArgs A) {
+  constexpr int G = kThreads / LPR;   // entries per tile
+  constexpr int RW = LPR * VEC;
+  __shared__ uint32_t sid[G];         // id / P of the tile's entries
+  __shared__ __align__(16) float gbuf[G * RW];
+  __shared__ float gfbuf[G], gwbuf[G];
+  __shared__ float carry[RW + 4];
+  __shared__ int carry_id;
+  const int tid = threadIdx.x;
+  const int P = A.P;
+  const int u = static_cast<int>(blockIdx.x) / P, p = static_cast<int>(blockIdx.x) - u * P;
+  if (u >= A.n_units) return;
+  int32_t* cnt = A.bcnt + static_cast<int64_t>(u) * P + p;
+  const uint32_t* src = A.bkeys + (static_cast<int64_t>(u) * P + p) * kBucket;
+  const int grp = tid / LPR, gl = tid % LPR, e0 = gl * VEC;
+  // round trip 1: the count and the first tile's keys leave together (slots past the count hold stale keys of an
+  // earlier step: inside the bucket's own kBucket slots, never used)
+  const int n_raw = *(const DCTR_GLOBAL int32_t*)cnt;
+  uint32_t key = *(const DCTR_GLOBAL uint32_t*)(src + (grp < kBucket ? grp : kBucket - 1));
+  uint32_t knext = *(const DCTR_GLOBAL uint32_t*)(src + (grp + 1 < kBucket ? grp + 1 : kBucket - 1));
+
+  const int32_t* un = A.units + 4 * u;
+  const int di = uni(un[0]), wi = uni(un[1]);
+  dctr_field_t fd = {}, fw = {};
+  if (di >= 0) fd = uni_field(A.deep[di]);
+  if (wi >= 0) fw = uni_field(A.wide[wi]);
+  const uint32_t bmask = (1u << A.bbits) - 1u;
+  const bool deep_on = (di >= 0) && (A.gout || A.gfm);
+  const bool wide_on = (wi >= 0) && A.gwide;
+  const bool lane_on = deep_on && (e0 < fd.dim);
+  const int goff = deep_on ? fd.out_off + (lane_on ? e0 : 0) : 0;
+  const bool fold = (A.gfm != nullptr);
+  const int64_t ld_dw = (di >= 0) ? row_ld(fd) : 1, ld_ds = (di >= 0) ? state_ld(fd) : 1;
+  const int64_t ld_ww = (wi >= 0) ? row_ld(fw) : 1, ld_ws = (wi >= 0) ? state_ld(fw) : 1;
+
+  const int n = uni(n_raw);
+  if (n <= 0 || n > kBucket) return;   // (uniform: every thread read the same counter)
+  __syncthreads();                     // every wave has read the counter ...
+  if (tid == 0) {
+    *(DCTR_GLOBAL int32_t*)cnt = 0;    // ... before it is handed back zeroed for the next pre-pass
+    carry_id = -1;
+  }
+
+  for (int t0 = 0; t0 < n; t0 += G) {
+    const int i = t0 + grp;
+    if (t0 > 0) {
+      key = *(const DCTR_GLOBAL uint32_t*)(src + (i < kBucket ? i : kBucket - 1));
+      knext = *(const DCTR_GLOBAL uint32_t*)(src + (i + 1 < kBucket ? i + 1 : kBucket - 1));
+    }
+    const bool have = i < n;
+    const int b = static_cast<int>(key & bmask);
+    const int idq = static_cast<int>(key >> A.bbits);
+    const int64_t row = static_cast<int64_t>(idq) * P + p;
+    const bool seg_end = have && ((i == n - 1) || (static_cast<int>(knext >> A.bbits) != idq));
+    const bool last_of_tile = have && ((grp == G - 1) || (i == n - 1));
+    // round trip 2: everything this entry contributes, and (segment ends only) the row it lands on
+    Strip<VEC> h = strip_zero<VEC>(), w = strip_zero<VEC>(), s = strip_zero<VEC>(), e = strip_zero<VEC>();
+    float gf = 0.f, gw = 0.f, ww = 0.f, sw = 0.f;
+    if (have) {
+      if (lane_on) {
+        if (A.gout) h = strip_load<VEC>(A.gout + static_cast<int64_t>(b) * A.ldg + goff);
+        if (fold) {
+          const Strip<VEC> S = strip_load<VEC>(A.fm_s + static_cast<int64_t>(b) * A.lds_ + e0);
+          gf = ldg_f32(A.gfm + b);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) h.v[k] += gf * S.v[k];
+        }
+      }
+      if (wide_on && gl == 0) gw = ldg_f32(A.gwide + static_cast<int64_t>(b) * A.ldgw);
+      if (seg_end) {
+        if (lane_on) {
+          const int64_t off_w = row * ld_dw + e0;
+          w = strip_load<VEC>(OPT == DCTR_UPD_ACCUM ? fd.gacc + row * fd.dim + e0 : fd.table + off_w);
+          if (OPT == DCTR_UPD_ADAGRAD) s = strip_load<VEC>(fd.state + row * ld_ds + e0);
+          if (OPT == DCTR_UPD_ACCUM) {
+            if (fold) e = strip_load<VEC>(fd.table + off_w);
+          } else {
+            e = w;
+          }
+        }
+        if (wide_on && gl == 0) {
+          ww = ldg_f32(OPT == DCTR_UPD_ACCUM ? fw.gacc + row : fw.table + row * ld_ww);
+          if (OPT == DCTR_UPD_ADAGRAD) sw = ldg_f32(fw.state + row * ld_ws);
+        }
+      }
+    }
+    if (lane_on) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) gbuf[grp * RW + e0 + k] = h.v[k];
+    }
+    if (gl == 0) {
+      sid[grp] = have ? static_cast<uint32_t>(idq) : 0xFFFFFFFFu;
+      gfbuf[grp] = gf;
+      gwbuf[grp] = gw;
+    }
+    __syncthreads();
+    const bool summer = seg_end || last_of_tile;
+    Strip<VEC> acc = strip_zero<VEC>();
+    float accf = 0.f, accw = 0.f;
+    if (summer) {
+      int jj = grp;  // walk back: fixed order => deterministic (the order of the general kernel's tiled path)
+      while (jj >= 0 && sid[jj] == static_cast<uint32_t>(idq)) {
+        if (lane_on) {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) acc.v[k] += gbuf[jj * RW + e0 + k];
+        }
+        accf += gfbuf[jj];
+        if (gl == 0) accw += gwbuf[jj];
+        --jj;
+      }
+      if (jj < 0 && carry_id == idq) {  // the segment began in an earlier tile
+        if (lane_on) {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) acc.v[k] += carry[e0 + k];
+        }
+        accf += carry[RW];
+        if (gl == 0) accw += carry[RW + 1];
+      }
+      if (seg_end) {
+        if (lane_on) {
+          Strip<VEC> a2 = acc;
+          if (fold) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) a2.v[k] -= accf * e.v[k];
+          }
+          apply_strip<VEC, OPT>(fd, row * ld_dw + e0, row * ld_ds + e0, row * fd.dim + e0, a2, w, s, A.lr, A.eps);
+        }
+        if (wide_on && gl == 0) {
+          Strip<1> a1, w1, s1;
+          a1.v[0] = accw;
+          w1.v[0] = ww;
+          s1.v[0] = sw;
+          apply_strip<1, OPT>(fw, row * ld_ww, row * ld_ws, row, a1, w1, s1, A.lr, A.eps);
+        }
+      }
+    }
+    if (t0 + G >= n) break;   // single tile (the common case): no carry to park
+    __syncthreads();  // every read of gbuf / carry of this tile is done
+    if (last_of_tile) {  // exactly one group: park an open segment's partial, or clear the carry
+      if (!seg_end) {
+        if (lane_on) {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) carry[e0 + k] = acc.v[k];
+        }
+        if (gl == 0) {
+          carry[RW] = accf;
+          carry[RW + 1] = accw;
+          carry_id = idq;
+        }
+      } else if (gl == 0) {
+        carry_id = -1;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- optional pre-pass: bucket the (unit, sample) entries by partition ---------------------------------------------
 // One thread per entry; a bucket's fill order is whatever the atomics give (the update kernel sorts the keys).
 // Pays off when a workgroup's scan over the unit's B ids is the expensive part, i.e. for large (global) batches.
@@ -932,7 +1134,7 @@ extern "C" int dctr_embed_segments(const dctr_plan_t* plan, const int32_t* units
   const dim3 grid(static_cast<unsigned>(nbuckets)), block(kThreads);
   // small batches: every workgroup finds its entries by comparing the forward's 16-bit partition tags (B / 8 vector
   // loads per workgroup).  Large batches (or no tags): one global atomic per entry buckets them first.
-  if (parts_t && P <= 65535 && B < 16384) {
+  if (parts_t && P <= 65535 && B <= 32768) {
     k_embed_segments<false><<<grid, block, 0, s>>>(a);
   } else {
     const int64_t ne = static_cast<int64_t>(n_units) * B;
@@ -1012,15 +1214,35 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
     }
   }
 
-#define DCTR_UPD_LAUNCH(VEC_, LPR_)                               \
-  do {                                                            \
-    if (opt == DCTR_UPD_ADAGRAD) {                                \
-      k_embed_update<VEC_, LPR_, 1><<<grid, block, 0, s>>>(a);    \
-    } else if (opt == DCTR_UPD_SGD) {                             \
-      k_embed_update<VEC_, LPR_, 0><<<grid, block, 0, s>>>(a);    \
-    } else {                                                      \
-      k_embed_update<VEC_, LPR_, 2><<<grid, block, 0, s>>>(a);    \
-    }                                                             \
+  // presorted: the lean kernel does every partition the pre-pass could sort; the general kernel behind it finds their
+  // counters at zero (nothing to do) and takes the overflowing ones (and the dense half of Linear)
+  const dim3 grid_sorted(static_cast<unsigned>(n_units) * static_cast<unsigned>(P));
+  const dim3 grid_over(static_cast<unsigned>((nbuckets + kThreads - 1) / kThreads) +
+                       (g_wdense ? static_cast<unsigned>(plan->n_wdense) : 0u));
+#define DCTR_UPD_LAUNCH(VEC_, LPR_)                                                              \
+  do {                                                                                           \
+    if (opt == DCTR_UPD_ADAGRAD) {                                                               \
+      if (a.presorted) {                                                                         \
+        k_embed_apply_sorted<VEC_, LPR_, 1><<<grid_sorted, block, 0, s>>>(a);                    \
+        k_embed_update_overflow<VEC_, LPR_, 1><<<grid_over, block, 0, s>>>(a);                   \
+      } else {                                                                                   \
+        k_embed_update<VEC_, LPR_, 1><<<grid, block, 0, s>>>(a);                                 \
+      }                                                                                          \
+    } else if (opt == DCTR_UPD_SGD) {                                                            \
+      if (a.presorted) {                                                                         \
+        k_embed_apply_sorted<VEC_, LPR_, 0><<<grid_sorted, block, 0, s>>>(a);                    \
+        k_embed_update_overflow<VEC_, LPR_, 0><<<grid_over, block, 0, s>>>(a);                   \
+      } else {                                                                                   \
+        k_embed_update<VEC_, LPR_, 0><<<grid, block, 0, s>>>(a);                                 \
+      }                                                                                          \
+    } else {                                                                                     \
+      if (a.presorted) {                                                                         \
+        k_embed_apply_sorted<VEC_, LPR_, 2><<<grid_sorted, block, 0, s>>>(a);                    \
+        k_embed_update_overflow<VEC_, LPR_, 2><<<grid_over, block, 0, s>>>(a);                   \
+      } else {                                                                                   \
+        k_embed_update<VEC_, LPR_, 2><<<grid, block, 0, s>>>(a);                                 \
+      }                                                                                          \
+    }                                                                                            \
   } while (0)
 
 #define DCTR_UPD_LPR(VEC_)                      \

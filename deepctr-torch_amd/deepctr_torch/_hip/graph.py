@@ -15,7 +15,27 @@ Two measured facts shape this file (profiles/, MI355X):
     (sharing one memory pool), and the copies of the next group's batches run on a side stream while the current
     graph executes, so they never sit on the critical path.
 """
+import contextlib
+import gc
+
 import torch
+
+
+@contextlib.contextmanager
+def no_gc_during_capture():
+    """A hipGraph capture must not be interrupted by Python's cyclic garbage collector: when it happens to free an
+    older ``torch.cuda.CUDAGraph`` (a dead model's captured step sitting in a reference cycle) -- or anything else
+    whose destructor calls into HIP -- inside the capture, HIP answers ``hipErrorStreamCaptureUnsupported`` from
+    within a destructor and the process aborts (seen on MI355X / ROCm 7.2 as a rare crash of fit()).  Collect
+    first, keep the collector off for the duration."""
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 class GraphedTrainStep(object):
@@ -66,7 +86,7 @@ class GraphedTrainStep(object):
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             outs = []
-            with torch.cuda.graph(g, pool=pool):
+            with no_gc_during_capture(), torch.cuda.graph(g, pool=pool):
                 for j in range(self.S):
                     outs.append(model._train_step(self.x[s][j], self.y[s][j]))
             if pool is None:

@@ -573,10 +573,11 @@ class EmbeddingPlan(object):
         side.wait_stream(main)
         with torch.cuda.stream(side):
             enqueue(L.stream_handle(device))
-            ev = torch.cuda.Event()
-            ev.record(side)
         ws._dctr_owner = ids_t.data_ptr()
-        return (ev, ws)
+        # (the consumer joins with wait_stream, whose events come from torch's pool: a torch.cuda.Event created here
+        # would be destroyed by the garbage collector at some later point -- possibly while a hipGraph capture is
+        # running, which HIP answers with hipErrorStreamCaptureUnsupported from inside a destructor: abort)
+        return (side, ws)
 
     def update_workspace_for(self, ids_t, handle, B):
         """(workspace | None, n_ints, presorted) for the update of the forward that produced ``ids_t``: its own
@@ -588,7 +589,7 @@ class EmbeddingPlan(object):
             if getattr(ws, "_dctr_owner", None) == ids_t.data_ptr():
                 ws._dctr_owner = None
                 if event is not True:
-                    torch.cuda.current_stream(device).wait_event(event)
+                    torch.cuda.current_stream(device).wait_stream(event)      # the side stream: the pre-pass is its last work
                 return ws, ws.numel(), 1
         ws, n = self.update_workspace(B, device)
         if ws is not None and getattr(ws, "_dctr_owner", None) is not None:

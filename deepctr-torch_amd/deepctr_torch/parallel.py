@@ -378,7 +378,8 @@ class _Segment(object):
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             # thread-local capture mode: RCCL's watchdog thread keeps polling events while we capture
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            from ._hip.graph import no_gc_during_capture
+            with no_gc_during_capture(), torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.result = self.fn()
             self.graph = g
         self.graph.replay()

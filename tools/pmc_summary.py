@@ -33,9 +33,16 @@ def load(counter):
 
 def short(name):
     import re
-    m = re.search(r"k_embed_update<\d+, \d+, (\d)>", name)
-    if m:      # last template argument = the optimizer (0 SGD, 1 Adagrad, 2 accumulate)
+    m = re.search(r"k_embed_apply_sorted<\d+, \d+, (\d)>", name)
+    if m:      # the update proper (after the segment pre-pass); last template argument = the optimizer
         return {"0": "embed_update_sgd", "1": "embed_update_adagrad"}.get(m.group(1), "embed_update_accum")
+    if "k_embed_update_overflow" in name:
+        return "embed_update_overflow"
+    if "k_embed_segments" in name:
+        return "embed_segments"
+    m = re.search(r"k_embed_update<\d+, \d+, (\d)>", name)
+    if m:      # the general kernel (no pre-pass); last template argument = the optimizer (0 SGD, 1 Adagrad, 2 accumulate)
+        return {"0": "embed_update_general_sgd", "1": "embed_update_general_adagrad"}.get(m.group(1), "embed_update_general_accum")
     for key, tag in (("k_embed_fwd", "embed_fwd"), ("k_embed_update", "embed_update"),
                      ("CUDAFunctorOnSelf_add", "calib_stream"), ("sum_functor", "calib_reduce"),
                      ("vectorized_gather_kernel", "calib_gather")):
