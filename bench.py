@@ -130,7 +130,7 @@ def time_hot_kernels(model, X_all, B, iters, opt, ring=16):
                                       _ptr(parts_t), B,
                                       _ptr(g_out), plan.ld_out, _ptr(out), plan.ld_out, _ptr(fm_s), DIM, _ptr(g_fm),
                                       _ptr(g_wide), 1, L.UPD_ADAGRAD if opt == "adagrad" else L.UPD_SGD, lr, eps,
-                                      None, 0, None, _ptr(ws), ws_n, 1, s))
+                                      None, 0, None, None, _ptr(ws), ws_n, 1, s))
 
     stages = [("embed_fwd", fwd), ("embed_segments", seg), ("embed_update", upd)]
     for j in range(ring):       # every slot's side outputs exist before any update is timed

@@ -105,6 +105,38 @@ __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 __device__ __forceinline__ int64_t row_ld(const dctr_field_t& f) { return f.ld > 0 ? f.ld : f.dim; }
 __device__ __forceinline__ int64_t state_ld(const dctr_field_t& f) { return f.ld_state > 0 ? f.ld_state : f.dim; }
 
+// dctr_dense_step_t by value for kernels (kind < 0: no step) and the step itself on the element behind a gradient
+struct DenseStepDev {
+  int kind;
+  float lr, eps;
+  const float* grad_base;
+  float* param_base;
+  float* state_base;
+};
+inline DenseStepDev dense_step_dev(const dctr_dense_step_t* s) {
+  DenseStepDev d;
+  d.kind = s ? s->kind : -1;
+  d.lr = s ? s->lr : 0.f;
+  d.eps = s ? s->eps : 0.f;
+  d.grad_base = s ? s->grad_base : nullptr;
+  d.param_base = s ? s->param_base : nullptr;
+  d.state_base = s ? s->state_base : nullptr;
+  return d;
+}
+__device__ __forceinline__ void dense_step_apply(const DenseStepDev& S, const float* gptr, float g) {
+  if (S.kind < 0) return;
+  const int64_t k = gptr - S.grad_base;
+  float w = ldg_f32(S.param_base + k);
+  if (S.kind == DCTR_UPD_ADAGRAD) {   // torch.optim.Adagrad: s += g*g ; p -= lr * g / (sqrt(s) + eps)
+    const float st = ldg_f32(S.state_base + k) + g * g;
+    stg_f32(S.state_base + k, st);
+    w -= S.lr * (g / (sqrtf(st) + S.eps));
+  } else {                            // torch.optim.SGD
+    w -= S.lr * g;
+  }
+  stg_f32(S.param_base + k, w);
+}
+
 inline int hip_status(hipError_t e) { return e == hipSuccess ? DCTR_OK : static_cast<int>(e); }
 
 inline int launch_status() { return hip_status(hipGetLastError()); }

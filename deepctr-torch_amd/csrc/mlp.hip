@@ -699,6 +699,7 @@ struct ReduceArgs {
   int n_head;
   float* loss;                     // [1]
   float* g_bias;                   // [1] nullable
+  DenseStepDev step;               // kind >= 0: also step the parameter behind every gradient element written
 };
 
 __global__ __launch_bounds__(256) void k_mlp_reduce(ReduceArgs A) {
@@ -718,7 +719,11 @@ __global__ __launch_bounds__(256) void k_mlp_reduce(ReduceArgs A) {
     __syncthreads();
     if (threadIdx.x == 0) {
       stg_f32(A.loss, ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]);
-      if (A.g_bias) stg_f32(A.g_bias, ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]);
+      if (A.g_bias) {
+        const float gb = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        stg_f32(A.g_bias, gb);
+        dense_step_apply(A.step, A.g_bias, gb);
+      }
     }
     return;
   }
@@ -731,6 +736,8 @@ __global__ __launch_bounds__(256) void k_mlp_reduce(ReduceArgs A) {
   float acc = 0.f;
   for (int s = 0; s < A.S; ++s) acc += ldg_f32(A.part + static_cast<int64_t>(s) * A.slab + i);
   stg_f32(dst + (i - A.seg_off[sg]), acc);
+  // (row padding of a weight: gradient 0, parameter 0, Adagrad state 0 -- the step leaves all three alone)
+  dense_step_apply(A.step, dst + (i - A.seg_off[sg]), acc);
 }
 
 // ---- host helpers ---------------------------------------------------------------------------------------------
@@ -865,7 +872,7 @@ int bwd_stride(const dctr_mlp_t* m) {
 // weight gradients (split-batch partials) + their fixed-order reduction (+ the head's partials, fused step only)
 int launch_wgrad_reduce(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g,
                         float* workspace, const float* head_loss, const float* head_gbias, int n_head, float* loss,
-                        float* g_bias, hipStream_t s) {
+                        float* g_bias, const dctr_dense_step_t* step, hipStream_t s) {
   const WgradPlan P = plan_wgrad(m, B);
   {
     WgradArgs a;
@@ -901,6 +908,7 @@ int launch_wgrad_reduce(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32
   r.seg_off[ns] = P.slab;
   r.n_seg = ns;
   r.head_loss = head_loss; r.head_gbias = head_gbias; r.n_head = n_head; r.loss = loss; r.g_bias = g_bias;
+  r.step = dense_step_dev(step);
   const unsigned nblk = static_cast<unsigned>((P.slab + 255) / 256) + (head_loss ? 1u : 0u);
   k_mlp_reduce<<<dim3(nblk), dim3(256), 0, s>>>(r);
   return launch_status();
@@ -935,7 +943,7 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, i
     const int st = launch_status();
     if (st != DCTR_OK) return st;
   }
-  return launch_wgrad_reduce(m, x, ld_x, B, g, workspace, nullptr, nullptr, 0, nullptr, nullptr, s);
+  return launch_wgrad_reduce(m, x, ld_x, B, g, workspace, nullptr, nullptr, 0, nullptr, nullptr, nullptr, s);
 }
 
 extern "C" size_t dctr_mlp_train_workspace_floats(const dctr_mlp_t* m, int32_t B) {
@@ -947,7 +955,7 @@ extern "C" size_t dctr_mlp_train_workspace_floats(const dctr_mlp_t* m, int32_t B
 extern "C" int dctr_mlp_train_step(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* part0,
                                    const float* part1, const float* bias, const float* y, float* y_pred, float* loss,
                                    float* g_logit, float* g_bias, float* gx, int64_t ld_gx, float* workspace,
-                                   int32_t defer_wgrad, dctr_stream_t stream) {
+                                   int32_t defer_wgrad, const dctr_dense_step_t* step, dctr_stream_t stream) {
   const int rc = check_mlp(m, B);
   if (rc != DCTR_OK) return rc;
   if (!m->w_out || !y || !y_pred || !loss || !g_logit || !workspace) return DCTR_EINVAL;
@@ -985,11 +993,12 @@ extern "C" int dctr_mlp_train_step(const dctr_mlp_t* m, const float* x, int64_t 
     if (st != DCTR_OK) return st;
   }
   if (defer_wgrad) return DCTR_OK;   // the caller enqueues dctr_mlp_train_wgrad (possibly on another stream)
-  return launch_wgrad_reduce(m, x, ld_x, B, g_logit, workspace, part_loss, part_gb, n_tiles, loss, g_bias, s);
+  return launch_wgrad_reduce(m, x, ld_x, B, g_logit, workspace, part_loss, part_gb, n_tiles, loss, g_bias, step, s);
 }
 
 extern "C" int dctr_mlp_train_wgrad(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g_logit,
-                                    float* workspace, float* loss, float* g_bias, dctr_stream_t stream) {
+                                    float* workspace, float* loss, float* g_bias, const dctr_dense_step_t* step,
+                                    dctr_stream_t stream) {
   const int rc = check_mlp(m, B);
   if (rc != DCTR_OK) return rc;
   if (!m->w_out || !x || !loss || !g_logit || !workspace) return DCTR_EINVAL;
@@ -999,6 +1008,6 @@ extern "C" int dctr_mlp_train_wgrad(const dctr_mlp_t* m, const float* x, int64_t
   const int n_tiles = (B + kTM - 1) / kTM;
   float* part_loss = workspace + static_cast<size_t>(P.slab) * P.S;
   float* part_gb = part_loss + n_tiles;
-  return launch_wgrad_reduce(m, x, ld_x, B, g_logit, workspace, part_loss, part_gb, n_tiles, loss, g_bias,
+  return launch_wgrad_reduce(m, x, ld_x, B, g_logit, workspace, part_loss, part_gb, n_tiles, loss, g_bias, step,
                              static_cast<hipStream_t>(stream));
 }

@@ -63,6 +63,7 @@ struct UpdArgs {
   const int32_t* wdense_cols;
   int32_t n_wdense;
   float* g_wdense;
+  DenseStepDev wd_step;       // kind >= 0: the extra workgroups also step Linear.weight
   unsigned long long* trace;  // diagnostics (tools/upd_trace.py): 8 timestamps per workgroup, or NULL
   // optional pre-bucketed entries (k_bucket): bcnt [n_units * P] (zero at rest), bkeys [n_units * P][kBucket]
   int32_t* bcnt;
@@ -167,6 +168,7 @@ __device__ __forceinline__ void wdense_column(const UpdArgs& A, int j) {
     float t = 0.f;
     for (int w = 0; w < kThreads / 64; ++w) t += red[w];
     stg_f32(A.g_wdense + j, t);
+    dense_step_apply(A.wd_step, A.g_wdense + j, t);
   }
 }
 
@@ -1123,6 +1125,7 @@ extern "C" int dctr_embed_segments(const dctr_plan_t* plan, const int32_t* units
   const int64_t nbuckets = static_cast<int64_t>(n_units) * P;
   if (workspace_ints < nbuckets * (1 + kBucket)) return DCTR_EINVAL;
   UpdArgs a = {};
+  a.wd_step.kind = -1;
   a.deep = plan->deep; a.wide = plan->wide; a.units = units; a.ids_t = ids_t; a.parts_t = parts_t;
   a.n_units = n_units; a.B = B; a.P = P;
   a.bbits = ceil_log2(B < 2 ? 2 : B);
@@ -1152,8 +1155,8 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
                                  int64_t ld_g, const float* out, int64_t ld_out, const float* fm_s,
                                  int64_t ld_s, const float* g_fm, const float* g_wide, int64_t ld_gw,
                                  int32_t opt, float lr, float eps, const float* X, int64_t ld_x, float* g_wdense,
-                                 int32_t* workspace, int64_t workspace_ints, int32_t presorted,
-                                 dctr_stream_t stream) {
+                                 const dctr_dense_step_t* wdense_step, int32_t* workspace, int64_t workspace_ints,
+                                 int32_t presorted, dctr_stream_t stream) {
   (void)out;
   (void)ld_out;  // kept in the signature: the forward's rows are no longer re-read (FM is folded algebraically)
   if (!plan || !units || !ids_t || n_units <= 0 || B < 0) return DCTR_EINVAL;
@@ -1186,6 +1189,7 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
   a.trace = nullptr;
 #endif
   a.X = X; a.ldx = ld_x; a.wdense_cols = plan->wdense_cols; a.n_wdense = plan->n_wdense; a.g_wdense = g_wdense;
+  a.wd_step = dense_step_dev(g_wdense ? wdense_step : nullptr);
 
   const int P = pick_p(B, kThreads / lpr);
   a.P = P;

@@ -58,12 +58,21 @@ class DenseSlab(object):
         self._fork = None
         self._pending = None
         self.deferred = None      # overlap == "defer": the closure that enqueues the weight-gradient kernels
+        # in-kernel optimizer step (single-GPU fused train step): the kernels that finish the dense gradients (the
+        # tower's weight-gradient reduction, the update kernel's Linear.weight workgroups) also step the parameters,
+        # and the embedding update runs on a side stream beside them -- see begin_inline_step()
+        self.inline = None        # DenseStep while a fused train step with in-kernel optimizer is being assembled
+        self.inline_done = False  # the kernels of this step applied it: step() has nothing left to do
+        self.update_stream = None  # the side stream of this step's segment pre-pass (set by ops.EmbedFunction.forward):
+        #                            the tower + head launch makes it wait for itself, the update then runs there
 
     def __getstate__(self):
         d = dict(self.__dict__)
         d["_lay"] = [self._lay[id(p)] for p in self.params]     # id() keys do not survive pickling
         d["_fork"] = d["_pending"] = d["deferred"] = None       # streams / events / closures are per process
         d["overlap"] = False
+        d["inline"] = d["update_stream"] = None
+        d["inline_done"] = False
         return d
 
     # ---- fork / join ------------------------------------------------------------------------------------------------
@@ -77,6 +86,27 @@ class DenseSlab(object):
     # gradients overlap the gradient all-to-all and the embedding update, and joins before the dense all-reduce.  The
     # closure addresses the tensors of the run that created it -- under a hipGraph those are the capture's static
     # buffers, so the closure of the capture stays valid for every replay.
+    def begin_inline_step(self, kind, lr, eps):
+        """The coming train step applies plain SGD / Adagrad to the slab INSIDE the gradient kernels (no
+        ``dctr_dense_opt`` launch, no cross-queue join in front of it).  Returns False (nothing armed) when the slab
+        carries L2 terms or Adam state -- those keep the separate regularised optimizer kernel."""
+        if kind not in ("sgd", "adagrad") or self.lam is not None:
+            return False
+        if kind == "adagrad" and self.state is None:
+            return False
+        st = L.DenseStep()
+        st.kind = L.UPD_ADAGRAD if kind == "adagrad" else L.UPD_SGD
+        st.lr, st.eps = float(lr), float(eps)
+        st.grad_base = self.grad.data_ptr()
+        st.param_base = self.flat.data_ptr()
+        st.state_base = self.state.data_ptr() if kind == "adagrad" else None
+        self.inline, self.inline_done, self.update_stream = st, False, None
+        return True
+
+    def end_inline_step(self):
+        self.inline = None
+        self.update_stream = None
+
     def fork_stream(self, device):
         if not self.overlap or self.overlap == "defer" or torch.device(device).type != "cuda":
             return None
@@ -205,6 +235,9 @@ class DenseSlab(object):
 
     def step(self, kind, lr, eps=0.0, beta1=0.0, beta2=0.0):
         self.join()
+        if self.inline_done:          # the gradient kernels of this step already applied it (begin_inline_step)
+            self.inline_done = False
+            return
         if kind == "adam" or self.lam is not None:
             # Adam, or L2 terms on slab parameters: the regularised kernel of csrc/lazy.hip (one launch + a counter)
             if kind == "adagrad" and self.state is None:

@@ -49,6 +49,12 @@ class Mlp(ctypes.Structure):
                 ("n_layers", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
+class DenseStep(ctypes.Structure):
+    """``dctr_dense_step_t`` (include/dctr.h): an optimizer step applied by the kernel that finishes a gradient."""
+    _fields_ = [("kind", ctypes.c_int32), ("lr", ctypes.c_float), ("eps", ctypes.c_float), ("pad_", ctypes.c_int32),
+                ("grad_base", ctypes.c_void_p), ("param_base", ctypes.c_void_p), ("state_base", ctypes.c_void_p)]
+
+
 PLAN_HAS_GACC, PLAN_HAS_STATE, PLAN_HAS_MAXPOOL = 1, 2, 4
 LAZY_SGD, LAZY_ADAGRAD, LAZY_ADAM = 0, 1, 2
 
@@ -88,7 +94,7 @@ SIGNATURES = {
     "dctr_embed_update_partitions": (ctypes.c_int32, [ctypes.POINTER(Plan), _I32]),
     "dctr_embed_ids": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I32, _P, _I64, _I32, _P, _P, _P]),
     "dctr_embed_update": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I32, _I64, _P, _P, _I32, _P, _I64, _P, _I64, _P, _I64,
-                                         _P, _P, _I64, _I32, _F32, _F32, _P, _I64, _P, _P, _I64, _I32, _P]),
+                                         _P, _P, _I64, _I32, _F32, _F32, _P, _I64, _P, _P, _P, _I64, _I32, _P]),
     "dctr_embed_segments": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I32, _I64, _P, _P, _I32, _P, _I64, _P]),
     "dctr_embed_update_workspace_ints": (ctypes.c_int64, [ctypes.POINTER(Plan), _I32, _I32]),
     "dctr_embed_bwd": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P,
@@ -125,8 +131,9 @@ SIGNATURES = {
     "dctr_mlp_bwd": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P]),
     "dctr_mlp_train_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(Mlp), _I32]),
     "dctr_mlp_train_step": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64,
-                                           _P, _I32, _P]),
-    "dctr_mlp_train_wgrad": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _P, _P, _P, _P]),
+                                           _P, _I32, _P, _P]),
+    "dctr_mlp_train_wgrad": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _P, _P, _P, _P, _P]),
+    "dctr_sizeof_dense_step": (ctypes.c_size_t, []),
     "dctr_bce_head": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P]),
     "dctr_dense_opt": (ctypes.c_int, [_P, _P, _P, _I64, _I32, _F32, _F32, _P]),
     "dctr_shard_assemble_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _I64, _P, _I32, _I32, _P, _P,
@@ -193,7 +200,8 @@ def lib():
             raise RuntimeError("libdctr_hip.so ABI %d != binding ABI %d" % (handle.dctr_abi_version(), ABI_VERSION))
         if handle.dctr_sizeof_field() != ctypes.sizeof(Field) or handle.dctr_sizeof_plan() != ctypes.sizeof(Plan) \
                 or handle.dctr_sizeof_mlp() != ctypes.sizeof(Mlp) \
-                or handle.dctr_sizeof_lazy_unit() != ctypes.sizeof(LazyUnit):
+                or handle.dctr_sizeof_lazy_unit() != ctypes.sizeof(LazyUnit) \
+                or handle.dctr_sizeof_dense_step() != ctypes.sizeof(DenseStep):
             raise RuntimeError("dctr_field_t / dctr_plan_t / dctr_mlp_t layout mismatch between header and binding")
         _lib = handle
     return _lib

@@ -286,26 +286,40 @@ class TowerHeadFunction(torch.autograd.Function):
         # The weight gradients need only what the first launch leaves behind (x, h, dh, g_logit) and nothing but the
         # dense optimizer needs THEM: with a fork stream on the sink they run beside the embedding update (which needs
         # only gx / g_logit) instead of in front of it.  The sink joins the fork before the dense optimizer step.
-        fork = sink.fork_stream(dev) if hasattr(sink, "fork_stream") else None
-        defer = fork is None and getattr(sink, "overlap", False) == "defer" and x.device.type == "cuda"
+        inline = getattr(sink, "inline", None)
+        fork = sink.fork_stream(dev) if (hasattr(sink, "fork_stream") and inline is None) else None
+        defer = fork is None and inline is None and getattr(sink, "overlap", False) == "defer" and x.device.type == "cuda"
         L.check(lib.dctr_mlp_train_step(ctypes.byref(desc), _ptr(x), x.stride(0), B, pp[0], pp[1], _ptr(bias), _ptr(y),
                                         _ptr(y_pred), _ptr(loss), _ptr(g_logit), _ptr(g_bias), _ptr(gx), gx.stride(0),
-                                        _ptr(ws), 1 if (fork is not None or defer) else 0, L.stream_handle(dev)),
-                "dctr_mlp_train_step")
+                                        _ptr(ws), 1 if (fork is not None or defer or inline is not None) else 0, None,
+                                        L.stream_handle(dev)), "dctr_mlp_train_step")
+        if inline is not None:
+            # In-kernel optimizer: the weight gradients and their reduction follow in line on THIS stream and step the
+            # parameters as they finish; the embedding update (which needs only gx / g_logit) is what leaves for the
+            # side stream (ops.EmbedFunction.backward), right behind the event recorded here.  The step's critical
+            # chain -- gather, tower, weight gradients -- then never crosses a queue (a cross-queue dependency costs
+            # 6-10 us on this stack; round 1 paid two per step).
+            upd = getattr(sink, "update_stream", None)
+            if upd is not None:
+                upd.wait_stream(torch.cuda.current_stream(dev))      # the update may start once this launch is done
+            L.check(lib.dctr_mlp_train_wgrad(ctypes.byref(desc), _ptr(x), x.stride(0), B, _ptr(g_logit), _ptr(ws),
+                                             _ptr(loss), _ptr(g_bias), ctypes.byref(inline), L.stream_handle(dev)),
+                    "dctr_mlp_train_wgrad")
+            sink.inline_done = True
         if defer:
             keep = (x, hs, dhs, ws, g_logit, loss, ps, y, wo, gx, desc)
 
             def launch(stream, keep=keep, B=B, g_bias=g_bias):
                 x_, ws_, g_logit_, loss_, desc_ = keep[0], keep[3], keep[4], keep[5], keep[10]
                 L.check(lib.dctr_mlp_train_wgrad(ctypes.byref(desc_), _ptr(x_), x_.stride(0), B, _ptr(g_logit_),
-                                                 _ptr(ws_), _ptr(loss_), _ptr(g_bias),
+                                                 _ptr(ws_), _ptr(loss_), _ptr(g_bias), None,
                                                  ctypes.c_void_p(stream.cuda_stream)), "dctr_mlp_train_wgrad")
             sink.deferred = launch
         if fork is not None:
             side = fork
             side.wait_stream(torch.cuda.current_stream(dev))     # fork point: right behind the tower kernel
             L.check(lib.dctr_mlp_train_wgrad(ctypes.byref(desc), _ptr(x), x.stride(0), B, _ptr(g_logit), _ptr(ws),
-                                             _ptr(loss), _ptr(g_bias), ctypes.c_void_p(side.cuda_stream)),
+                                             _ptr(loss), _ptr(g_bias), None, ctypes.c_void_p(side.cuda_stream)),
                     "dctr_mlp_train_wgrad")
             # everything the forked kernels touch stays allocated until the join (no record_stream bookkeeping)
             sink.forked(side, (x, hs, dhs, ws, g_logit, loss, ps, y, wo))

@@ -12,6 +12,7 @@ scatter executed inside ``EmbedFunction.backward``.  What that scatter does is s
   ``("sgd2", lr)``          two-pass SGD (needed when a max-pooled field re-reads the table).
   ``("adagrad", lr, eps)``  scatter into ``gacc``, then ``dctr_embed_apply`` consumes the touched rows.
 """
+import contextlib
 import ctypes
 
 import torch
@@ -78,13 +79,24 @@ class EmbedFunction(torch.autograd.Function):
             if want_fm:
                 ld_s = (plan.emb_dim + 3) // 4 * 4
                 fm_s = torch.empty((B, ld_s), dtype=torch.float32, device=X.device)
-        L.check(lib.dctr_embed_fwd(cplan, _ptr(X), X.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), 1, _ptr(fm),
-                                   _ptr(plan.err_flag(X.device)), plan.units_ptr(), len(plan.units), _ptr(ids_t),
-                                   _ptr(parts_t), _ptr(fm_s), ld_s, L.stream_handle(X.device)), "dctr_embed_fwd")
-        ctx.plan, ctx.want_fm = plan, want_fm
-        # the part of the update that needs only the ids runs now, on a side stream, under the tower
+        # The part of the update that needs only the ids -- finding and sorting every partition's entries -- runs on a
+        # side stream, under the tower.  In the fused train step with in-kernel optimizer that stream also computes the
+        # ids itself (from X, ahead of the gather) and later runs the update: its chain then waits for the main
+        # stream once (for the tower's gradients) and the main chain -- gather, tower, weight gradients -- for nothing.
+        sink = getattr(plan, "dense_sink", None)
+        segs = ids_t is not None and plan.segments_enabled() and getattr(plan, "exchange", None) is None
+        own_ids = segs and X.is_cuda and sink is not None and getattr(sink, "inline", None) is not None
         ctx.seg_event = None
-        if ids_t is not None and plan.segments_enabled() and getattr(plan, "exchange", None) is None:
+        if own_ids:
+            ctx.seg_event = plan.launch_segments(ids_t, parts_t, B, X=X)
+            if ctx.seg_event[0] is not True:              # (True: the CPU stand-in, no streams)
+                sink.update_stream = ctx.seg_event[0]     # where this step's update will run (see backward)
+        L.check(lib.dctr_embed_fwd(cplan, _ptr(X), X.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), 1, _ptr(fm),
+                                   _ptr(plan.err_flag(X.device)), plan.units_ptr(), len(plan.units),
+                                   None if own_ids else _ptr(ids_t), None if own_ids else _ptr(parts_t), _ptr(fm_s),
+                                   ld_s, L.stream_handle(X.device)), "dctr_embed_fwd")
+        ctx.plan, ctx.want_fm = plan, want_fm
+        if segs and not own_ids:
             ctx.seg_event = plan.launch_segments(ids_t, parts_t, B)
         ctx.save_for_backward(X, out if want_fm else None, ids_t, fm_s, parts_t)
         ctx.set_materialize_grads(False)
@@ -149,7 +161,7 @@ class EmbedFunction(torch.autograd.Function):
             L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t),
                                           _ptr(parts_t), B, _ptr(g_out), ld_g, _ptr(out), plan.ld_out, _ptr(fm_s),
                                           fm_s.stride(0) if fm_s is not None else 0, _ptr(g_fm), _ptr(g_wide), 1,
-                                          L.UPD_ACCUM, 0.0, 0.0, _ptr(X), X.stride(0), _ptr(g_wd), _ptr(ws), ws_n,
+                                          L.UPD_ACCUM, 0.0, 0.0, _ptr(X), X.stride(0), _ptr(g_wd), None, _ptr(ws), ws_n,
                                           pre, stream), "dctr_embed_update(accumulate)")
             lazy.apply(ids_t)
             return None, None, None, g_w, None, None
@@ -167,12 +179,29 @@ class EmbedFunction(torch.autograd.Function):
             else:
                 raise RuntimeError("unknown sparse update mode %r" % (kind,))
             cplan = plan.bind(X.device)
-            ws, ws_n, pre = plan.update_workspace_for(ids_t, ctx.seg_event, B)
-            L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t),
-                                          _ptr(parts_t), B, _ptr(g_out), ld_g, _ptr(out), plan.ld_out, _ptr(fm_s),
-                                          fm_s.stride(0) if fm_s is not None else 0, _ptr(g_fm), _ptr(g_wide), 1,
-                                          opt, lr, eps, _ptr(X), X.stride(0), _ptr(g_wd), _ptr(ws), ws_n, pre, stream),
-                    "dctr_embed_update")
+            sink = getattr(plan, "dense_sink", None)
+            # (armed AND carried out by the tower + head kernel of this step: only then has its event been recorded and
+            # does nobody else step Linear.weight)
+            inline = getattr(sink, "inline", None) if (sink is not None and getattr(sink, "inline_done", False)) else None
+            side = None
+            if inline is not None and X.is_cuda and ctx.seg_event is not None and ctx.seg_event[0] is not True and \
+                    sink.update_stream is ctx.seg_event[0]:
+                # fused train step with in-kernel optimizer: the update leaves the critical chain -- it runs on the
+                # pre-pass's side stream, behind the pre-pass and behind the tower kernel that produced its gradients,
+                # beside the tower's weight-gradient kernels (which stay on the main stream).  DenseSlab.join() brings
+                # the streams together at the end of the step.
+                side = ctx.seg_event[0]      # (already waiting for the tower + head launch: mlp.TowerHeadFunction)
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                ws, ws_n, pre = plan.update_workspace_for(ids_t, ctx.seg_event, B)
+                wd = ctypes.byref(inline) if (inline is not None and g_wd is not None and g_w is None) else None
+                L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t),
+                                              _ptr(parts_t), B, _ptr(g_out), ld_g, _ptr(out), plan.ld_out, _ptr(fm_s),
+                                              fm_s.stride(0) if fm_s is not None else 0, _ptr(g_fm), _ptr(g_wide), 1,
+                                              opt, lr, eps, _ptr(X), X.stride(0), _ptr(g_wd), wd, _ptr(ws), ws_n, pre,
+                                              L.stream_handle(X.device)), "dctr_embed_update")
+            if side is not None:
+                # (everything the side-stream kernels touch stays allocated until the join)
+                sink.forked(side, (X, out, ids_t, parts_t, fm_s, g_out, g_fm, g_wide, g_wd, ws))
             return None, None, None, g_w, None, None
 
         # general path (pooled VarLen fields, shared tables, very large batches): atomic scatter (+ consume pass)

@@ -546,7 +546,7 @@ class EmbeddingPlan(object):
         import os
         return os.environ.get("DCTR_SEGMENTS", "1") != "0"
 
-    def launch_segments(self, ids_t, parts_t, B):
+    def launch_segments(self, ids_t, parts_t, B, X=None):
         """Enqueue the pre-pass for this forward's ids on the side stream.  Returns the handle the update passes to
         ``update_workspace_for``.  A workspace still marked by an earlier forward (whose backward never ran -- a
         forward in train mode that was not followed by a backward) is taken over."""
@@ -557,6 +557,14 @@ class EmbeddingPlan(object):
         def enqueue(stream):
             if dirty:
                 ws.zero_()          # the abandoned pre-pass left bucket counts behind
+            if X is not None:
+                # the ids (and their partition tags) straight from X: the side stream's chain -- ids, pre-pass, and
+                # later the update -- then hangs on nothing the gather kernel produces (one queue crossing less on
+                # the step's critical chain; the gather skips these two side outputs)
+                L.check(L.lib().dctr_embed_ids(ctypes.byref(self.cplan), self.units_ptr(), len(self.units),
+                                               ctypes.c_void_p(X.data_ptr()), X.stride(0), int(B),
+                                               ctypes.c_void_p(ids_t.data_ptr()), ctypes.c_void_p(parts_t.data_ptr()),
+                                               stream), "dctr_embed_ids")
             L.check(L.lib().dctr_embed_segments(ctypes.byref(self.cplan), self.units_ptr(), len(self.units),
                                                 self.max_vocab, ctypes.c_void_p(ids_t.data_ptr()),
                                                 ctypes.c_void_p(parts_t.data_ptr()), int(B),
@@ -588,8 +596,11 @@ class EmbeddingPlan(object):
             event, ws = handle
             if getattr(ws, "_dctr_owner", None) == ids_t.data_ptr():
                 ws._dctr_owner = None
-                if event is not True:
-                    torch.cuda.current_stream(device).wait_stream(event)      # the side stream: the pre-pass is its last work
+                if event is not True and torch.cuda.current_stream(device) != event:
+                    # the side stream: the pre-pass is its last work.  (When the update itself runs on that stream --
+                    # the fused step with in-kernel optimizer -- stream order is all it takes; a stream waiting for
+                    # itself inside a hipGraph capture crashed hipStreamEndCapture.)
+                    torch.cuda.current_stream(device).wait_stream(event)
                 return ws, ws.numel(), 1
         ws, n = self.update_workspace(B, device)
         if ws is not None and getattr(ws, "_dctr_owner", None) is not None:

@@ -709,6 +709,11 @@ class BaseModel(nn.Module):
         plan.dense_sink = slab
         # the tower's weight gradients run on a fork stream beside the embedding update (DCTR_OVERLAP_WGRAD=0: in line)
         slab.overlap = xb.is_cuda and os.environ.get("DCTR_OVERLAP_WGRAD", "1") != "0"
+        # plain SGD / Adagrad: the kernels that finish the dense gradients step the parameters themselves, the
+        # embedding update runs beside them on the pre-pass's stream (DCTR_INLINE_OPT=0: separate optimizer launch)
+        if plan.update[0] in ("sgd", "adagrad") and os.environ.get("DCTR_INLINE_OPT", "1") != "0" and \
+                plan.segments_enabled():
+            slab.begin_inline_step(mode[0], mode[1], mode[2] if len(mode) > 2 else 0.0)
         reg = None
         try:
             loss, y_pred = self.fused_loss(xb, yb, slab)
@@ -724,6 +729,7 @@ class BaseModel(nn.Module):
             self._grad_sink = None
             plan.dense_sink = None
             slab.overlap = False
+            slab.end_inline_step()
             slab.join()
         slab.step(*mode)
         total = loss.detach().reshape(1)

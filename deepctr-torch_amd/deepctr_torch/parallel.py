@@ -197,7 +197,7 @@ class DataParallelTrainer(object):
             L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t),
                                           _ptr(parts_t), NB,
                                           _ptr(G_all) if plan.deep else None, gathered.stride(0), None, 0, None, 0,
-                                          None, _ptr(gw_all) if plan.wide else None, 1, opt, lr, eps, None, 0, None, None, 0, 0, stream),
+                                          None, _ptr(gw_all) if plan.wide else None, 1, opt, lr, eps, None, 0, None, None, None, 0, 0, stream),
                     "dctr_embed_update(global)")
         work.wait()
         model.optim.step()
@@ -354,7 +354,7 @@ class HipShardOps(object):
         L.check(L.lib().dctr_embed_update(cplan, sub.units_ptr(), len(sub.units), sub.max_vocab, self._ptr(ids_t),
                                           self._ptr(parts_t), NB,
                                           self._ptr(grads_all), lay.ldc, None, 0, None, 0, None, gw, lay.ldc, opt, lr,
-                                          eps, None, 0, None, self._ptr(ws), ws_n, 0, L.stream_handle(dev)),
+                                          eps, None, 0, None, None, self._ptr(ws), ws_n, 0, L.stream_handle(dev)),
                 "dctr_embed_update(owned tables)")
 
 

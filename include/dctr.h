@@ -161,11 +161,26 @@ int dctr_embed_apply(const dctr_plan_t* plan, const float* X, int64_t ldx, int32
  *   max_vocab  largest vocab over the plan's fields (sizes the 32-bit sort keys)
  *   g_wdense [plan.n_wdense] (nullable): when given, n_wdense extra workgroups also write the gradient of the dense
  *          half of Linear, g_wdense[j] = sum_b g_wide[b] * X[b, wdense_cols[j]] (basemodel.py:86-90), in a
- *          fixed order; X / ld_x are only read for this.
+ *          fixed order; X / ld_x are only read for this.  wdense_step (nullable): they also step Linear.weight.
  * dctr_embed_update_supported returns 1 when the plan / batch fit (B <= 32768, keys fit 32 bits).    */
 #define DCTR_UPD_SGD 0
 #define DCTR_UPD_ADAGRAD 1
 #define DCTR_UPD_ACCUM 2
+/* One optimizer step on dense parameters, applied by the kernel that finishes their gradient (instead of a separate
+ * dctr_dense_opt launch and the cross-queue join in front of it): the gradient tensor lives at grad_base + k inside
+ * a flat gradient slab, its parameter at param_base + k, its Adagrad state at state_base + k.
+ *   kind  DCTR_UPD_SGD: p -= lr * g        DCTR_UPD_ADAGRAD: s += g*g ; p -= lr * g / (sqrt(s) + eps)
+ * (torch.optim.SGD / Adagrad, basemodel.py:447-461).  Host struct.                                                */
+typedef struct dctr_dense_step {
+  int32_t kind;
+  float lr, eps;
+  int32_t pad_;
+  const float* grad_base;
+  float* param_base;
+  float* state_base; /* NULL for SGD */
+} dctr_dense_step_t;
+size_t dctr_sizeof_dense_step(void);
+
 int dctr_embed_update_supported(const dctr_plan_t* plan, int64_t max_vocab, int32_t B);
 /* P = partitions per unit that dctr_embed_update uses for this plan at batch B (0 on bad arguments).  The optional
  * side output parts_t [n_units, B] uint16 of dctr_embed_fwd / dctr_embed_ids holds clamp(id) mod P (clamp: an id
@@ -186,8 +201,8 @@ int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, int32_t n_u
                       const int32_t* ids_t, const uint16_t* parts_t, int32_t B, const float* g_out, int64_t ld_g,
                       const float* out, int64_t ld_out, const float* fm_s, int64_t ld_s, const float* g_fm,
                       const float* g_wide, int64_t ld_gw, int32_t opt, float lr, float eps, const float* X,
-                      int64_t ld_x, float* g_wdense, int32_t* workspace, int64_t workspace_ints, int32_t presorted,
-                      dctr_stream_t stream);
+                      int64_t ld_x, float* g_wdense, const dctr_dense_step_t* wdense_step, int32_t* workspace,
+                      int64_t workspace_ints, int32_t presorted, dctr_stream_t stream);
 /* The part of dctr_embed_update that needs nothing but the ids, as its own launch: every (unit, partition)'s entries
  * found, sorted by (id, sample) and parked in `workspace` (dctr_embed_update_workspace_ints ints; zero before the
  * first use).  Enqueue it any time after the forward -- on another stream, in the shadow of the tower -- and pass the
@@ -445,9 +460,12 @@ size_t dctr_mlp_train_workspace_floats(const dctr_mlp_t* m, int32_t B);
 int dctr_mlp_train_step(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* part0,
                         const float* part1, const float* bias, const float* y, float* y_pred, float* loss,
                         float* g_logit, float* g_bias, float* gx, int64_t ld_gx, float* workspace,
-                        int32_t defer_wgrad, dctr_stream_t stream);
+                        int32_t defer_wgrad, const dctr_dense_step_t* step, dctr_stream_t stream);
+/* step (nullable, both calls): the reduction that finishes layer[l].gW / gbias, g_w_out and g_bias also applies this
+ * optimizer step to the parameters behind them -- no dctr_dense_opt launch, no join in front of it.               */
 int dctr_mlp_train_wgrad(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g_logit,
-                         float* workspace, float* loss, float* g_bias, dctr_stream_t stream);
+                         float* workspace, float* loss, float* g_bias, const dctr_dense_step_t* step,
+                         dctr_stream_t stream);
 
 /* ---- prediction head + loss (layers/core.py:154-160, basemodel.py:254, F.binary_cross_entropy(reduction='sum'))
  *     z = sum_i part_i[b] + bias ;  y_pred = sigmoid(z) ;  loss = sum_b -(y log p + (1-y) log(1-p))   (logs clamped

@@ -99,11 +99,40 @@ class _Core(object):
     def dctr_mlp_train_workspace_floats(self, mref, B):
         return 16
 
-    def dctr_mlp_train_wgrad(self, mref, x, ld_x, B, g_logit, ws, loss, g_bias, stream):
-        return 0    # the mock's train step has already produced the weight gradients
+    @staticmethod
+    def _dense_step(step, gptr, n):
+        """dctr_dense_step_t applied to the n parameters behind the gradient at gptr (include/dctr.h)"""
+        if step is None or not gptr:
+            return
+        s = step._obj
+        addr = gptr.value if isinstance(gptr, ctypes.c_void_p) else int(gptr)
+        k = addr - s.grad_base
+        g = _arr(addr, (n,))
+        p = _arr(s.param_base + k, (n,))
+        if s.kind == 1:
+            st = _arr(s.state_base + k, (n,))
+            st += g * g
+            p -= np.float32(s.lr) * (g / (np.sqrt(st) + np.float32(s.eps)))
+        else:
+            p -= np.float32(s.lr) * g
+
+    def dctr_mlp_train_wgrad(self, mref, x, ld_x, B, g_logit, ws, loss, g_bias, step, stream):
+        """the mock's train step has already produced the weight gradients; what is left is the in-kernel optimizer"""
+        if step is not None:
+            self.calls.append("mlp_train_wgrad+step")
+            m, layers = self._layers(mref)
+            for e in layers:
+                self._dense_step(step, e.gW, e.N * e.ld_w)
+                if e.bias and e.gbias:
+                    self._dense_step(step, e.gbias, e.N)
+            if m.g_w_out:
+                self._dense_step(step, m.g_w_out, layers[-1].N)
+            if g_bias is not None and getattr(g_bias, "value", g_bias):
+                self._dense_step(step, g_bias, 1)
+        return 0
 
     def dctr_mlp_train_step(self, mref, x, ld_x, B, p0, p1, bias, y, y_pred, loss, g_logit, g_bias, gx, ld_gx, ws,
-                            defer_wgrad, stream):
+                            defer_wgrad, step, stream):
         """forward + head + backward in one call, composed from the pieces above."""
         import torch
         logit = torch.zeros(B)
@@ -323,7 +352,7 @@ class _Core(object):
 
     # ---- deterministic fused backward + optimizer (dctr_embed_update) ---------------------------------------
     def dctr_embed_update(self, pref, units, n_units, max_vocab, ids_t, parts_t, B, g_out, ld_g, out, ld_out, fm_s, ld_s, g_fm,
-                          g_wide, ld_gw, opt, lr, eps, X, ld_x, g_wdense, ws, ws_n, presorted, stream):
+                          g_wide, ld_gw, opt, lr, eps, X, ld_x, g_wdense, wd_step, ws, ws_n, presorted, stream):
         self.calls.append("embed_update:%d" % opt)
         c, deep, widef, dcols, wcols = self._plan(pref)
         U = _arr(units, (n_units * 4,), dtype=np.int32).reshape(n_units, 4)
@@ -367,6 +396,7 @@ class _Core(object):
         if _arr(g_wdense, (1,)) is not None and gW is not None and wcols:
             Xv = _arr(X, (B, c.n_xcols), ld_x)
             _arr(g_wdense, (len(wcols),))[...] = [np.dot(gW.astype(np.float64), Xv[:, col]) for col in wcols]
+            self._dense_step(wd_step, g_wdense, len(wcols))
         return 0
 
     # ---- exact lazy regularised / Adam update (csrc/lazy.hip) -------------------------------------------------
