@@ -207,7 +207,11 @@ __device__ __forceinline__ void fwd_dispatch(int nt, const float* As, int rs, in
   }
 }
 
-// the forward of one 16-sample row tile; `logit_lds` (nullable): [16] LDS floats that receive the projection
+// the forward of one 16-sample row tile; `logit_lds` (nullable): [16] LDS floats that receive the projection.
+// CROSS: the layers are the matrix form of CrossNet (interaction.py:448-451) instead of Linear + activation:
+//     u_l = x_l W_l^T + b_l ;  x_{l+1} = x_0 (.) u_l + x_l          (every layer W x W, x_0 = the staged input tile)
+// u_l is parked in the layer's `dh` buffer (the backward needs it and overwrites it with its own d loss / d u_l).
+template <bool CROSS = false>
 __device__ __forceinline__ void mlp_fwd_body(const MlpArgs& A, float* smem, float* logit_lds) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * kTM;
@@ -276,7 +280,14 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpArgs& A, float* smem, floa
           for (int r = 0; r < 4; ++r) {
             const int row = 4 * g + r;
             float v = acc[t][r];
-            if (Ld.relu) v = v > 0.f ? v : 0.f;
+            if (CROSS) {
+              const float x0v = xs[row * rsx + n];                  // (K0 <= kKC: the whole input tile is staged)
+              const float xlv = (l == 0) ? x0v : in[row * rsh + n];
+              if (Ld.dh && n < Ld.N && b0 + row < A.B) stg_f32(Ld.dh + static_cast<int64_t>(b0 + row) * Ld.ldh + n, v);
+              v = x0v * v + xlv;
+            } else if (Ld.relu) {
+              v = v > 0.f ? v : 0.f;
+            }
             if (n >= Ld.N) v = 0.f;
             outb[row * rsh + n] = v;
             if (Ld.h && n < Ld.N && b0 + row < A.B) stg_f32(Ld.h + static_cast<int64_t>(b0 + row) * Ld.ldh + n, v);
@@ -306,7 +317,12 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpArgs& A, float* smem, floa
 
 __global__ __launch_bounds__(kT) void k_mlp_fwd(MlpArgs A) {
   extern __shared__ __align__(16) float smem[];
-  mlp_fwd_body(A, smem, nullptr);
+  mlp_fwd_body<false>(A, smem, nullptr);
+}
+
+__global__ __launch_bounds__(kT) void k_cross_mat_fwd(MlpArgs A) {
+  extern __shared__ __align__(16) float smem[];
+  mlp_fwd_body<true>(A, smem, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -471,6 +487,153 @@ __global__ __launch_bounds__(kT) void k_mlp_bwd_data(MlpArgs A) {
   mlp_bwd_body(A, smem, nullptr);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// CrossNet, matrix form: backward-data of a 16-sample row tile through all layers
+// ------------------------------------------------------------------------------------------------------------
+// With g = d loss / d x_{l+1}:   a_l = g (.) x_0  (= d loss / d u_l: what the weight-gradient kernel consumes, stored in
+// the layer's `dh`, over the u_l the forward parked there);   d loss / d x_l = g + a_l W_l;   and x_0 collects
+// sum_l g (.) u_l on the side (kept in registers: a thread owns the same elements of the tile in every layer).
+// LDS: x_0 | g (ping) | g (pong) | a_l, [16][rs] floats each.
+__global__ __launch_bounds__(kT) void k_cross_mat_bwd(MlpArgs A) {
+  extern __shared__ __align__(16) float smem[];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int b0 = blockIdx.x * kTM;
+  const int rs = A.rsd;
+  const int W = A.L[0].K;
+  const int Wp = round_up(W, 16);
+  float* x0s = smem;
+  float* gin = x0s + kTM * rs;
+  float* gout = gin + kTM * rs;
+  float* as = gout + kTM * rs;
+  constexpr int kPer = kTM * kKC / kT;      // elements of the tile a thread owns (W <= kKC; unrolled: registers)
+  float side[kPer];
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) side[k] = 0.f;
+  const int n_el = kTM * Wp;
+  for (int e = tid; e < n_el; e += kT) {
+    const int r = e / Wp, n = e - r * Wp;
+    const int64_t b = b0 + r;
+    const bool ok = b < A.B && n < W;
+    x0s[r * rs + n] = ok ? ldg_f32(A.x + b * A.ldx + n) : 0.f;
+    gin[r * rs + n] = ok ? ldg_f32(A.g + b * A.ldg + n) : 0.f;
+  }
+  __syncthreads();
+  for (int l = A.n_layers - 1; l >= 0; --l) {
+    const LayerDev& Ld = A.L[l];
+    // a_l = g (.) x_0 -> LDS (the A operand) and the layer's dh (over u_l, which feeds the side term first)
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int e = tid + k * kT;
+      if (e < n_el) {
+        const int r = e / Wp, n = e - r * Wp;
+        const int64_t b = b0 + r;
+        const float gv = gin[r * rs + n];
+        const float av = gv * x0s[r * rs + n];
+        as[r * rs + n] = av;
+        if (b < A.B && n < W) {
+          float* up = Ld.dh + b * Ld.ldh + n;
+          side[k] += gv * ldg_f32(up);
+          stg_f32(up, av);
+        }
+      }
+    }
+    __syncthreads();
+    // d loss / d x_l = g + a_l W_l : 64-column groups over the waves, reduction over n (rows of W_l)
+    const int ngroups = (W + 63) >> 6;
+    for (int gb = wv; gb < ngroups; gb += kWaves) {
+      const int col0 = 64 * gb + 4 * c;
+      const int colc = col0 < Ld.ldw ? col0 : 0;
+      f32x4 acc[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* ap = as + c * rs + 4 * g;
+      const int n_it = Wp >> 4;
+      const DCTR_GLOBAL char* wbase = (const DCTR_GLOBAL char*)Ld.W;
+      const uint32_t ldw4 = static_cast<uint32_t>(Ld.ldw) * 4u;
+      const uint32_t vlast = static_cast<uint32_t>(Ld.N - 1) * ldw4 + static_cast<uint32_t>(colc) * 4u;
+      uint32_t vrow[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) vrow[j] = static_cast<uint32_t>(4 * g + j) * ldw4 + static_cast<uint32_t>(colc) * 4u;
+      auto wld = [&](int it, f32x4* dst) {
+        it = it < n_it ? it : n_it - 1;
+        const uint32_t so = static_cast<uint32_t>(it) * 16u * ldw4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          uint32_t o = vrow[j] + so;
+          o = o < vlast ? o : vlast;                                  // rows past N re-read row N-1 (A is 0 there)
+          dst[j] = *(const DCTR_GLOBAL f32x4*)(wbase + o);
+        }
+      };
+      constexpr int PD = 5;
+      f32x4 ring[PD][4];
+#pragma unroll
+      for (int d = 0; d < PD - 1; ++d) wld(d, ring[d]);
+      const int n_grp = n_it / PD, rem = n_it - n_grp * PD;
+      f32x4 a_nxt = *reinterpret_cast<const f32x4*>(ap);
+      for (int gi = 0; gi < n_grp; ++gi) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+          const int it = gi * PD + d;
+          wld(it + PD - 1, ring[(d + PD - 1) % PD]);
+          const f32x4 a4 = a_nxt;
+          const int itn = it + 1 < n_it ? it + 1 : it;
+          a_nxt = *reinterpret_cast<const f32x4*>(ap + (itn << 4));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = mfma16(a4[j], ring[d][j][q], acc[q]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < PD - 1; ++d) {
+        if (d < rem) {
+          const int it = n_grp * PD + d;
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + (it << 4));
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = mfma16(a4[j], ring[d][j][q], acc[q]);
+        }
+      }
+      if (col0 < Wp) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * g + r;
+          f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+          const f32x4 gprev = *reinterpret_cast<const f32x4*>(gin + row * rs + col0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = (col0 + q < W) ? v[q] + gprev[q] : 0.f;
+          *reinterpret_cast<f32x4*>(gout + row * rs + col0) = v;
+        }
+      }
+    }
+    __syncthreads();
+    float* t = gin;
+    gin = gout;
+    gout = t;
+  }
+  // d loss / d x_0 = what came down the chain + the side term
+  if (A.gx) {
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int e = tid + k * kT;
+      if (e < n_el) {
+        const int r = e / Wp, n = e - r * Wp;
+        const int64_t b = b0 + r;
+        if (b < A.B && n < A.ldgx) stg_f32(A.gx + b * A.ldgx + n, n < W ? gin[r * rs + n] + side[k] : 0.f);
+      }
+    }
+    // columns [Wp, ldgx) of gx (padding) are written as zeros as well
+    for (int e = tid; e < kTM * 4; e += kT) {
+      const int r = e >> 2, n = Wp + (e & 3);
+      const int64_t b = b0 + r;
+      if (b < A.B && n < A.ldgx) stg_f32(A.gx + b * A.ldgx + n, 0.f);
+    }
+  }
+}
+
 // forward + prediction head + BCE(sum) + backward-data of one row tile in ONE launch (the fused train step): the
 // logits never leave the workgroup, d loss / d logit goes to the backward through LDS, and the head's own launch,
 // the backward's staging round trip and two kernel boundaries disappear.  Per-workgroup partial sums of the loss and
@@ -478,7 +641,7 @@ __global__ __launch_bounds__(kT) void k_mlp_bwd_data(MlpArgs A) {
 __global__ __launch_bounds__(kT) void k_mlp_train(MlpArgs A, HeadArgs Hd) {
   extern __shared__ __align__(16) float smem[];
   __shared__ float zl[kTM], gl[kTM];
-  mlp_fwd_body(A, smem, zl);
+  mlp_fwd_body<false>(A, smem, zl);
   __syncthreads();
   const int tid = threadIdx.x;
   if (tid < 64) {
@@ -1010,4 +1173,91 @@ extern "C" int dctr_mlp_train_wgrad(const dctr_mlp_t* m, const float* x, int64_t
   float* part_gb = part_loss + n_tiles;
   return launch_wgrad_reduce(m, x, ld_x, B, g_logit, workspace, part_loss, part_gb, n_tiles, loss, g_bias, step,
                              static_cast<hipStream_t>(stream));
+}
+
+// ---- CrossNet, matrix parameterisation (interaction.py:448-451) ------------------------------------------------------
+namespace {
+int check_cross(const dctr_mlp_t* m, int32_t B) {
+  const int rc = check_mlp(m, B);
+  if (rc != DCTR_OK) return rc;
+  if (m->w_out) return DCTR_EINVAL;
+  const int W = m->layer[0].K;
+  for (int l = 0; l < m->n_layers; ++l) {
+    const dctr_mlp_layer_t& L = m->layer[l];
+    if (L.K != W || L.N != W || !L.h || !L.dh || L.ld_h < W) return DCTR_EINVAL;
+    if (L.ld_h % 4 != 0 || reinterpret_cast<uintptr_t>(L.h) % 16 != 0 || reinterpret_cast<uintptr_t>(L.dh) % 16 != 0)
+      return DCTR_EALIGN;
+  }
+  return DCTR_OK;
+}
+}  // namespace
+
+extern "C" int dctr_crossnet_mat_supported(int32_t W, int32_t n_layers) {
+  if (W <= 0 || n_layers <= 0 || n_layers > kMaxL) return 0;
+  const int Wp = round_up(W, 16);
+  if (Wp > kKC) return 0;                                              // the forward keeps x_0 as ONE staged chunk
+  const size_t lds_f = static_cast<size_t>(kTM) * ((Wp + 4) + 2 * (Wp + 4)) * 4;
+  const size_t lds_b = static_cast<size_t>(kTM) * 4 * (round_up(W, 64) + 4) * 4;
+  return (lds_f <= 150 * 1024 && lds_b <= 150 * 1024) ? 1 : 0;
+}
+
+extern "C" int dctr_crossnet_mat_fwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B,
+                                     dctr_stream_t stream) {
+  const int rc = check_cross(m, B);
+  if (rc != DCTR_OK) return rc;
+  const int W = m->layer[0].K;
+  if (!x || ld_x < W) return DCTR_EINVAL;
+  if (ld_x % 4 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0) return DCTR_EALIGN;
+  if (!dctr_crossnet_mat_supported(W, m->n_layers)) return DCTR_ENOSUP;
+  if (B == 0) return DCTR_OK;
+  MlpArgs a;
+  fill_layers(m, a.L);
+  a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = nullptr; a.logit = nullptr;
+  a.g = nullptr; a.ldg = 0; a.gx = nullptr; a.ldgx = 0; a.trace = nullptr;
+  const int Wp = round_up(W, 16);
+  a.rsx = Wp + 4;
+  a.rsh = Wp + 4;
+  a.rsd = 0;
+  const size_t lds = static_cast<size_t>(kTM) * (a.rsx + 2 * a.rsh) * 4;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cross_mat_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(lds));
+  k_cross_mat_fwd<<<dim3((B + kTM - 1) / kTM), dim3(kT), lds, static_cast<hipStream_t>(stream)>>>(a);
+  return launch_status();
+}
+
+extern "C" size_t dctr_crossnet_mat_bwd_workspace_floats(const dctr_mlp_t* m, int32_t B) {
+  if (check_mlp(m, B) != DCTR_OK) return 0;
+  const WgradPlan P = plan_wgrad(m, B);
+  return static_cast<size_t>(P.slab) * P.S;
+}
+
+extern "C" int dctr_crossnet_mat_bwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* gY,
+                                     int64_t ld_g, float* gx, int64_t ld_gx, float* workspace, dctr_stream_t stream) {
+  const int rc = check_cross(m, B);
+  if (rc != DCTR_OK) return rc;
+  const int W = m->layer[0].K;
+  if (!x || !gY || !workspace || ld_x < W || ld_g < W) return DCTR_EINVAL;
+  const int rb = check_bwd(m, x, ld_x, B, gx, ld_gx);
+  if (rb != DCTR_OK) return rb;
+  if (!dctr_crossnet_mat_supported(W, m->n_layers)) return DCTR_ENOSUP;
+  if (B == 0) return DCTR_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    MlpArgs a;
+    fill_layers(m, a.L);
+    a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = nullptr; a.logit = nullptr;
+    a.g = gY; a.ldg = ld_g; a.gx = gx; a.ldgx = ld_gx; a.trace = nullptr;
+    a.rsx = 0; a.rsh = 0;
+    a.rsd = round_up(W, 64) + 4;
+    const size_t lds = static_cast<size_t>(kTM) * 4 * a.rsd * 4;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cross_mat_bwd),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    k_cross_mat_bwd<<<dim3((B + kTM - 1) / kTM), dim3(kT), lds, s>>>(a);
+    const int st = launch_status();
+    if (st != DCTR_OK) return st;
+  }
+  // d W_l = a_l^T x_l, d b_l = column sums of a_l: the tower's weight-gradient kernels, as they are
+  return launch_wgrad_reduce(m, x, ld_x, B, nullptr, workspace, nullptr, nullptr, 0, nullptr, nullptr, nullptr, s);
 }

@@ -125,6 +125,10 @@ SIGNATURES = {
     "dctr_crossnet_vec_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _P, _I64, _P]),
     "dctr_crossnet_vec_bwd_workspace_floats": (ctypes.c_size_t, [_I32, _I32, _I32]),
     "dctr_crossnet_vec_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P]),
+    "dctr_crossnet_mat_supported": (ctypes.c_int, [_I32, _I32]),
+    "dctr_crossnet_mat_fwd": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P]),
+    "dctr_crossnet_mat_bwd_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(Mlp), _I32]),
+    "dctr_crossnet_mat_bwd": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P]),
     "dctr_sizeof_mlp": (ctypes.c_size_t, []),
     "dctr_mlp_fwd": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _P]),
     "dctr_mlp_bwd_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(Mlp), _I32]),

@@ -759,3 +759,70 @@ class CrossNetVecFunction(torch.autograd.Function):
                                           gY.stride(0) if B > 1 else W, _ptr(gX), W, _ptr(gk), _ptr(gb), _ptr(ws),
                                           L.stream_handle(X.device)), "dctr_crossnet_vec_bwd")
         return gX, gk.reshape(ctx.kshape), gb.reshape(ctx.bshape)
+
+
+class CrossNetMatFunction(torch.autograd.Function):
+    """CrossNet, matrix parameterisation (reference interaction.py:448-451): ``x_{l+1} = x_0 * (x_l W_l^T + b_l) + x_l``
+    for all layers in ONE forward launch (16 samples per workgroup, x_0 / x_l in LDS, fp32 MFMA) and, for the backward,
+    one data launch + the tower's weight-gradient kernels (csrc/mlp.hip: dctr_crossnet_mat_fwd / _bwd)."""
+
+    @staticmethod
+    def _desc(Wp, ld_w, bias, hs, us, gWs, gbs, W):
+        desc = L.Mlp()
+        desc.n_layers = len(Wp)
+        for l in range(len(Wp)):
+            e = desc.layer[l]
+            e.W, e.bias = Wp[l].data_ptr(), bias[l].data_ptr()
+            e.h, e.dh = hs[l].data_ptr(), us[l].data_ptr()
+            e.gW = gWs[l].data_ptr() if gWs is not None else None
+            e.gbias = gbs[l].data_ptr() if gbs is not None else None
+            e.K = e.N = W
+            e.ld_w, e.ld_h, e.relu = ld_w, hs[l].stride(0), 0
+        desc.w_out = desc.g_w_out = None
+        return desc
+
+    @staticmethod
+    def forward(ctx, X, kernels, bias):
+        lib = L.lib()
+        L.require_gpu(X, "CrossNet input")
+        B, W = X.shape
+        Lyr = kernels.shape[0]
+        ld = (W + 3) // 4 * 4
+        if X.dtype != torch.float32 or X.stride(1) != 1 or X.stride(0) % 4 or X.data_ptr() % 16 or X.stride(0) < W:
+            buf = torch.zeros((B, ld), dtype=torch.float32, device=X.device)
+            buf[:, :W].copy_(X)
+            X = buf
+        # weights with rows padded to a multiple of 4 floats (zeros), one [L, W, ld] block
+        Wpad = torch.zeros((Lyr, W, ld), dtype=torch.float32, device=X.device)
+        Wpad[:, :, :W].copy_(kernels.detach())
+        b2 = bias.detach().reshape(Lyr, W).contiguous()
+        hs = [torch.empty((B, ld), dtype=torch.float32, device=X.device) for _ in range(Lyr)]
+        us = [torch.empty((B, ld), dtype=torch.float32, device=X.device) for _ in range(Lyr)]
+        desc = CrossNetMatFunction._desc([Wpad[l] for l in range(Lyr)], ld, [b2[l] for l in range(Lyr)], hs, us, None,
+                                         None, W)
+        L.check(lib.dctr_crossnet_mat_fwd(ctypes.byref(desc), _ptr(X), X.stride(0), B, L.stream_handle(X.device)),
+                "dctr_crossnet_mat_fwd")
+        ctx.save_for_backward(X, Wpad, b2, *(hs + us))
+        ctx.dims = (B, W, Lyr, ld)
+        ctx.kshape, ctx.bshape = kernels.shape, bias.shape
+        return hs[-1][:, :W]
+
+    @staticmethod
+    def backward(ctx, gY):
+        lib = L.lib()
+        B, W, Lyr, ld = ctx.dims
+        saved = ctx.saved_tensors
+        X, Wpad, b2 = saved[0], saved[1], saved[2]
+        hs, us = list(saved[3:3 + Lyr]), list(saved[3 + Lyr:3 + 2 * Lyr])
+        g = torch.zeros((B, ld), dtype=torch.float32, device=X.device)
+        g[:, :W].copy_(gY)
+        gW = torch.empty((Lyr, W, ld), dtype=torch.float32, device=X.device)
+        gb = torch.empty((Lyr, W), dtype=torch.float32, device=X.device)
+        gX = torch.empty((B, ld), dtype=torch.float32, device=X.device)
+        desc = CrossNetMatFunction._desc([Wpad[l] for l in range(Lyr)], ld, [b2[l] for l in range(Lyr)], hs, us,
+                                         [gW[l] for l in range(Lyr)], [gb[l] for l in range(Lyr)], W)
+        ws = torch.empty((max(1, lib.dctr_crossnet_mat_bwd_workspace_floats(ctypes.byref(desc), B)),),
+                         dtype=torch.float32, device=X.device)
+        L.check(lib.dctr_crossnet_mat_bwd(ctypes.byref(desc), _ptr(X), X.stride(0), B, _ptr(g), ld, _ptr(gX), ld, _ptr(ws),
+                                          L.stream_handle(X.device)), "dctr_crossnet_mat_bwd")
+        return gX[:, :W], gW[:, :, :W].reshape(ctx.kshape), gb.reshape(ctx.bshape)

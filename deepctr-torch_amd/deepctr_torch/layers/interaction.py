@@ -6,6 +6,7 @@ import itertools
 import torch
 import torch.nn as nn
 
+from .._hip import lib as _lib
 from .._hip import ops as _ops
 from .activation import activation_layer
 
@@ -421,7 +422,8 @@ class OutterProductLayer(nn.Module):
 class CrossNet(nn.Module):
     """Cross network of DCN / DCN-M: ``[B, W] -> [B, W]`` (reference interaction.py:397-453; parameters
     ``kernels [L, W, 1 | W]``, ``bias [L, W, 1]``).  The vector form runs all layers in one wave-per-sample kernel
-    (csrc/cross.hip); the matrix form is a ``[B, W] x [W, W]`` GEMM per layer and goes to hipBLASLt."""
+    (csrc/cross.hip); the matrix form runs all layers in one fp32-MFMA launch that keeps x_0 and x_l of a 16-sample
+    tile in LDS (csrc/mlp.hip, ``dctr_crossnet_mat_*``; up to 512 inputs, wider ones go to hipBLASLt)."""
 
     def __init__(self, in_features, layer_num=2, parameterization='vector', seed=1024, device='cpu'):
         super(CrossNet, self).__init__()
@@ -453,7 +455,10 @@ class CrossNet(nn.Module):
             for i in range(self.layer_num):            # x0 * (x_l . w) + b + x_l
                 x_l = x_0 * torch.matmul(x_l, self.kernels[i]) + self.bias[i].squeeze(1) + x_l
             return x_l
-        x_0 = inputs
+        if self.parameterization == 'matrix' and inputs.dim() == 2 and inputs.dtype == torch.float32 and \
+                _lib.lib().dctr_crossnet_mat_supported(int(W_), int(self.layer_num)):
+            return _ops.CrossNetMatFunction.apply(inputs, self.kernels, self.bias)
+        x_0 = inputs                      # wider than the kernels hold in LDS (> 512 inputs): PyTorch-ROCm GEMMs
         x_l = x_0
         for i in range(self.layer_num):   # x0 * (W x_l + b) + x_l
             x_l = x_0 * (torch.addmm(self.bias[i].t(), x_l, self.kernels[i].t())) + x_l

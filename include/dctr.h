@@ -390,13 +390,29 @@ int dctr_inner_product_bwd(const float* E, int64_t ld_e, int32_t B, int32_t F, i
  *   X [B, W] rows at X + b*ld_x;  kernels [L, W] (crossnet.kernels [L, W, 1]);  bias [L, W];  Y [B, W].  W <= 2048.
  * Backward writes gX [B, W], g_kernels [L, W], g_bias [L, W];
  * workspace = dctr_crossnet_vec_bwd_workspace_floats(B, W, L) floats (per-workgroup partials, fixed-order sum).
- * (The matrix parameterisation is a [B, W] x [W, W] GEMM per layer and stays on hipBLASLt.)                    */
+ * (The matrix parameterisation: dctr_crossnet_mat_fwd / _bwd below.)                                             */
 int dctr_crossnet_vec_fwd(const float* X, int64_t ld_x, int32_t B, int32_t W, int32_t L, const float* kernels,
                           const float* bias, float* Y, int64_t ld_y, dctr_stream_t stream);
 size_t dctr_crossnet_vec_bwd_workspace_floats(int32_t B, int32_t W, int32_t L);
 int dctr_crossnet_vec_bwd(const float* X, int64_t ld_x, int32_t B, int32_t W, int32_t L, const float* kernels,
                           const float* bias, const float* gY, int64_t ld_g, float* gX, int64_t ld_gx,
                           float* g_kernels, float* g_bias, float* workspace, dctr_stream_t stream);
+
+/* ---- CrossNet, matrix parameterisation (interaction.py:448-451; csrc/mlp.hip, on the tower's MFMA machinery) ------
+ *     x_{l+1} = x_0 (.) (x_l W_l^T + b_l) + x_l ,  l = 0..L-1          W_l = crossnet.kernels[l]  [W, W]
+ * described as a dctr_mlp_t (declared below) whose layers are all W x W: layer[l].W (rows ld_w floats apart, ld_w % 4
+ * == 0), .bias [W], .h [B, ld_h] receives x_{l+1} (the last one IS the result), .dh [B, ld_h] is scratch shared by
+ * the two calls (the forward parks u_l = x_l W_l^T + b_l there, the backward turns it into d loss / d u_l);  w_out must
+ * be NULL.  A workgroup carries 16 samples through all layers (x_0 and x_l stay in LDS); fp32 MFMA 16x16x4.
+ * The backward takes gY = d loss / d x_L [B, ld_g] and writes gx [B, ld_gx] = d loss / d x_0, layer[l].gW [W, ld_w]
+ * and layer[l].gbias [W] (split-batch partials summed in a fixed order: no atomics);
+ * workspace = dctr_crossnet_mat_bwd_workspace_floats(m, B) floats.  dctr_crossnet_mat_supported: W <= 512 (LDS).   */
+struct dctr_mlp;
+int dctr_crossnet_mat_supported(int32_t W, int32_t n_layers);
+int dctr_crossnet_mat_fwd(const struct dctr_mlp* m, const float* x, int64_t ld_x, int32_t B, dctr_stream_t stream);
+size_t dctr_crossnet_mat_bwd_workspace_floats(const struct dctr_mlp* m, int32_t B);
+int dctr_crossnet_mat_bwd(const struct dctr_mlp* m, const float* x, int64_t ld_x, int32_t B, const float* gY,
+                          int64_t ld_g, float* gx, int64_t ld_gx, float* workspace, dctr_stream_t stream);
 
 /* ---- DNN tower + dnn_linear on fp32 MFMA (csrc/mlp.hip) ---------------------------------------------------
  * DNN.forward (layers/core.py:120-134) with relu (or linear) activations, no BatchNorm, dropout inactive:

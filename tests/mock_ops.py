@@ -280,6 +280,50 @@ class OpsMixin(object):
         _t(g_bias, L, W).copy_(gb)
         return 0
 
+    # ---- CrossNet (matrix): x_{l+1} = x_0 (.) (x_l W_l^T + b_l) + x_l ------------------------------------------------
+    def dctr_crossnet_mat_supported(self, W, n_layers):
+        return 1 if (0 < W <= 512 and 0 < n_layers <= 8) else 0
+
+    @staticmethod
+    def _cross_mat_layers(mref):
+        m = mref._obj
+        return [m.layer[l] for l in range(m.n_layers)]
+
+    def dctr_crossnet_mat_fwd(self, mref, x, ld_x, B, stream):
+        self.calls.append("crossnet_mat_fwd")
+        layers = self._cross_mat_layers(mref)
+        W = layers[0].K
+        x0 = xl = _t(x, B, W, ld_x).double()
+        for e in layers:
+            u = xl @ _t(e.W, W, W, e.ld_w).double().t() + _v(e.bias, W).double()
+            _t(e.dh, B, W, e.ld_h).copy_(u)
+            xl = x0 * u + xl
+            _t(e.h, B, W, e.ld_h).copy_(xl)
+        return 0
+
+    def dctr_crossnet_mat_bwd_workspace_floats(self, mref, B):
+        return 16
+
+    @_with_grad
+    def dctr_crossnet_mat_bwd(self, mref, x, ld_x, B, gY, ld_g, gx, ld_gx, ws, stream):
+        self.calls.append("crossnet_mat_bwd")
+        layers = self._cross_mat_layers(mref)
+        W = layers[0].K
+        x0 = _t(x, B, W, ld_x).double().clone().requires_grad_(True)
+        Ws = [_t(e.W, W, W, e.ld_w).double().clone().requires_grad_(True) for e in layers]
+        bs = [_v(e.bias, W).double().clone().requires_grad_(True) for e in layers]
+        xl = x0
+        for Wl, bl in zip(Ws, bs):
+            xl = x0 * (xl @ Wl.t() + bl) + xl
+        gs = _grads(xl, [x0] + Ws + bs, _t(gY, B, W, ld_g).double())
+        _t(gx, B, W, ld_gx).copy_(gs[0])
+        for l, e in enumerate(layers):
+            full = _t(e.gW, W, e.ld_w, e.ld_w)
+            full.zero_()
+            full[:, :W].copy_(gs[1 + l])
+            _v(e.gbias, W).copy_(gs[1 + len(layers) + l])
+        return 0
+
     # ---- AFMLayer -----------------------------------------------------------------------------------------------------
     @staticmethod
     def _afm(E, W, bias, h, p):
