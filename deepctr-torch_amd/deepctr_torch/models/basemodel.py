@@ -495,7 +495,7 @@ class BaseModel(nn.Module):
         opt = getattr(self, "optim", None)
         plan = self._plan
         if opt is None or plan is None or os.environ.get("DCTR_LAZY_UPDATE", "1") == "0" or \
-                os.environ.get("DCTR_SPARSE_UPDATE", "1") == "0":
+                os.environ.get("DCTR_SPARSE_UPDATE", "1") == "0" or getattr(self, "_no_lazy_update", False):
             return None
         tables = plan.table_params
         if not tables or not plan.unit_path or plan.max_dim > 64 * (4 if plan.vec == 4 else 1) or \

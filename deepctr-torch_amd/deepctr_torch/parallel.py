@@ -125,8 +125,14 @@ class DataParallelTrainer(object):
         self.rank = dist.get_rank(process_group)
         self.plan = model.model_plan()
         if self.plan.update[0] == "lazy":
-            raise NotImplementedError("the lazy regularised / Adam table update is single-GPU; compile with plain "
-                                      "sgd / adagrad and l2_reg_embedding = l2_reg_linear = 0 for multi-GPU training")
+            # The lazy regularised / Adam table update keeps per-row step stamps that are single-GPU.  The replicas
+            # take the EXACT dense-gradient route instead (the reference's own O(vocabulary) update, every replica
+            # applying the same global gradient): correct for any optimizer / regulariser, just not O(batch) --
+            # compile with plain sgd / adagrad and l2_reg_embedding = l2_reg_linear = 0 for the fast multi-GPU path
+            # (DCN keeps BaseModel's default l2_reg_linear, like the reference: dcn.py:49-51).
+            model._no_lazy_update = True
+            model._rederive_update_paths()
+            assert self.plan.update[0] != "lazy"
         if not self.plan.unit_path:
             raise NotImplementedError("data-parallel training needs fixed-length sparse features over distinct "
                                       "tables (the deterministic update kernel); pooled VarLen features are "
@@ -162,9 +168,13 @@ class DataParallelTrainer(object):
             loss = sum([model.loss_func[i](y_pred[:, i], yb[:, i], reduction='sum') for i in range(model.num_tasks)])
         else:
             loss = model.loss_func(y_pred, yb.squeeze(), reduction='sum')
-        total_loss = loss + model.get_regularization_loss() + model.aux_loss
+        # Every rank holds the full dense parameters, so the regularisation / auxiliary terms -- functions of the
+        # parameters, not of the samples -- would enter the SUM all-reduce of the gradients world_size times: each rank
+        # contributes 1 / world of them (round-1 advisor finding).  The value that is logged is the full one.
+        reg = model.get_regularization_loss() + model.aux_loss
+        total_loss = loss + reg
         self._stash = None
-        total_loss.backward()
+        (loss + reg * (1.0 / self.world)).backward()
         work = self.bucket.all_reduce(self.group, async_op=True)      # overlaps with the embedding exchange
 
         st = self._stash
