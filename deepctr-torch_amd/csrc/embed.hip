@@ -543,6 +543,18 @@ int check_plan(const dctr_plan_t* p, const float* X, int64_t ldx, int32_t B) {
     default: { constexpr int VEC = VEC_, LPR = 64; __VA_ARGS__; } break; \
   }
 
+// Dynamic LDS above the 64 KB default needs the kernel's attribute raised first (gfx950: 160 KB per workgroup).  The
+// tile of a plan with very many input columns (hundreds of VarLen positions, thousands of fields) goes up to kMaxTile.
+constexpr size_t kMaxTile = 156 * 1024;
+#define DCTR_LAUNCH(kernel, grid, block, lds, stream, ...)                                                       \
+  do {                                                                                                           \
+    auto kfn_ = kernel;                                                                                          \
+    if ((lds) > 64 * 1024)                                                                                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn_), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                static_cast<int>(lds));                                                          \
+    kfn_<<<grid, block, lds, stream>>>(__VA_ARGS__);                                                             \
+  } while (0)
+
 #define DCTR_DISPATCH(vec, lpr, ...)                              \
   if ((vec) == 4) { DCTR_DISPATCH_LPR(4, lpr, __VA_ARGS__) }      \
   else if ((vec) == 2) { DCTR_DISPATCH_LPR(2, lpr, __VA_ARGS__) } \
@@ -571,13 +583,12 @@ extern "C" int dctr_embed_fwd(const dctr_plan_t* plan, const float* X, int64_t l
     return DCTR_EALIGN;
   const int lpr = lanes_per_row(plan, vec);
   const size_t lds = tile_bytes(plan, lpr, vec);
-  if (lds > 64 * 1024) return DCTR_ENOSUP;
+  if (lds > kMaxTile) return DCTR_ENOSUP;
   const int spb = kWave / lpr;
   const dim3 grid((B + spb - 1) / spb), block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  DCTR_DISPATCH(vec, lpr, k_embed_fwd<VEC, LPR><<<grid, block, lds, s>>>(*plan, X, ldx, B, out, ld_out,
-                                                                        wide, ld_wide, fm, err, units, n_units,
-                                                                        ids_t, parts_t, n_parts, fm_s, ld_s));
+  DCTR_DISPATCH(vec, lpr, DCTR_LAUNCH((k_embed_fwd<VEC, LPR>), grid, block, lds, s, *plan, X, ldx, B, out, ld_out,
+                                      wide, ld_wide, fm, err, units, n_units, ids_t, parts_t, n_parts, fm_s, ld_s));
   return launch_status();
 }
 
@@ -600,16 +611,16 @@ extern "C" int dctr_embed_bwd(const dctr_plan_t* plan, const float* X, int64_t l
   }
   const int lpr = lanes_per_row(plan, vec);
   const size_t lds = tile_bytes(plan, lpr, vec);
-  if (lds > 64 * 1024) return DCTR_ENOSUP;
+  if (lds > kMaxTile) return DCTR_ENOSUP;
   const int spb = kWave / lpr;
   const dim3 grid((B + spb - 1) / spb), block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (mode == DCTR_BWD_SGD) {
-    DCTR_DISPATCH(vec, lpr, k_embed_bwd<VEC, LPR, true><<<grid, block, lds, s>>>(
-                                *plan, X, ldx, B, g_out, ld_g, out, ld_out, g_fm, g_wide, lr));
+    DCTR_DISPATCH(vec, lpr, DCTR_LAUNCH((k_embed_bwd<VEC, LPR, true>), grid, block, lds, s,
+                                        *plan, X, ldx, B, g_out, ld_g, out, ld_out, g_fm, g_wide, lr));
   } else {
-    DCTR_DISPATCH(vec, lpr, k_embed_bwd<VEC, LPR, false><<<grid, block, lds, s>>>(
-                                *plan, X, ldx, B, g_out, ld_g, out, ld_out, g_fm, g_wide, lr));
+    DCTR_DISPATCH(vec, lpr, DCTR_LAUNCH((k_embed_bwd<VEC, LPR, false>), grid, block, lds, s,
+                                        *plan, X, ldx, B, g_out, ld_g, out, ld_out, g_fm, g_wide, lr));
   }
   return launch_status();
 }
@@ -624,16 +635,16 @@ extern "C" int dctr_embed_apply(const dctr_plan_t* plan, const float* X, int64_t
   const int vec = plan->vec;
   const int lpr = lanes_per_row(plan, vec);
   const size_t lds = tile_bytes(plan, lpr, vec);
-  if (lds > 64 * 1024) return DCTR_ENOSUP;
+  if (lds > kMaxTile) return DCTR_ENOSUP;
   const int spb = kWave / lpr;
   const dim3 grid((B + spb - 1) / spb), block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (opt == DCTR_OPT_ADAGRAD) {
-    DCTR_DISPATCH(vec, lpr, k_embed_apply<VEC, LPR, DCTR_OPT_ADAGRAD><<<grid, block, lds, s>>>(
-                                *plan, X, ldx, B, lr, eps));
+    DCTR_DISPATCH(vec, lpr, DCTR_LAUNCH((k_embed_apply<VEC, LPR, DCTR_OPT_ADAGRAD>), grid, block, lds, s,
+                                        *plan, X, ldx, B, lr, eps));
   } else {
-    DCTR_DISPATCH(vec, lpr, k_embed_apply<VEC, LPR, DCTR_OPT_SGD><<<grid, block, lds, s>>>(
-                                *plan, X, ldx, B, lr, eps));
+    DCTR_DISPATCH(vec, lpr, DCTR_LAUNCH((k_embed_apply<VEC, LPR, DCTR_OPT_SGD>), grid, block, lds, s,
+                                        *plan, X, ldx, B, lr, eps));
   }
   return launch_status();
 }

@@ -69,6 +69,7 @@ struct MlpArgs {
   float* gx;         // backward: [B, ldgx] nullable
   int64_t ldgx;
   int rsx, rsh;      // LDS row strides (floats) of the forward
+  int kc;            // columns of the tower input staged in LDS at a time (<= kKC; smaller for wide towers)
   int rsd;           // LDS row stride of the backward-data pass
   unsigned long long* trace;
 };
@@ -220,7 +221,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpArgs& A, float* smem, floa
   float* hb0 = xs + kTM * rsx;    // [16][rsh]  ping
   float* hb1 = hb0 + kTM * rsh;   // [16][rsh]  pong
   const int K0 = A.L[0].K, K0p = round_up(K0, 16);
-  const int kcw = K0p < kKC ? K0p : kKC;
+  const int kcw = K0p < A.kc ? K0p : A.kc;
   MLP_TRACE(A.trace, 0);
 
   const float* in = nullptr;
@@ -925,6 +926,14 @@ void fill_layers(const dctr_mlp_t* m, LayerDev* L) {
   }
 }
 
+// Columns of the tower input staged at a time: as many as leave room for the two activation tiles of the widest layer
+// (1024-wide towers: 256; the chunk only bounds how often the first layer's K loop re-stages).
+int pick_kc(int K0p, int rsh) {
+  int kc = kKC;
+  while (kc > 64 && static_cast<size_t>(kTM) * ((K0p < kc ? K0p : kc) + 4 + 2 * rsh) * 4 > 150 * 1024) kc >>= 1;
+  return kc;
+}
+
 int max_width(const dctr_mlp_t* m) {
   int w = 0;
   for (int l = 0; l < m->n_layers; ++l) w = m->layer[l].N > w ? m->layer[l].N : w;
@@ -990,11 +999,12 @@ extern "C" int dctr_mlp_fwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, i
   a.g = nullptr; a.ldg = 0; a.gx = nullptr; a.ldgx = 0;
   a.trace = g_mlp_trace;
   const int K0p = round_up(m->layer[0].K, 16);
-  a.rsx = (K0p < kKC ? K0p : kKC) + 4;
   a.rsh = round_up(max_width(m), 16) + 4;
+  a.kc = pick_kc(K0p, a.rsh);
+  a.rsx = (K0p < a.kc ? K0p : a.kc) + 4;
   a.rsd = 0;
   const size_t lds = static_cast<size_t>(kTM) * (a.rsx + 2 * a.rsh) * 4;
-  if (lds > 160 * 1024) return DCTR_ENOSUP;
+  if (lds > 150 * 1024) return DCTR_ENOSUP;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
                               static_cast<int>(lds));
@@ -1138,8 +1148,9 @@ extern "C" int dctr_mlp_train_step(const dctr_mlp_t* m, const float* x, int64_t 
     a.g = nullptr; a.ldg = 0; a.gx = gx; a.ldgx = ld_gx;
     a.trace = g_mlp_trace;
     const int K0p = round_up(m->layer[0].K, 16);
-    a.rsx = (K0p < kKC ? K0p : kKC) + 4;
     a.rsh = round_up(max_width(m), 16) + 4;
+    a.kc = pick_kc(K0p, a.rsh);
+    a.rsx = (K0p < a.kc ? K0p : a.kc) + 4;
     a.rsd = bwd_stride(m);
     const size_t lds_f = static_cast<size_t>(kTM) * (a.rsx + 2 * a.rsh) * 4;
     const size_t lds_b = static_cast<size_t>(kTM) * 2 * a.rsd * 4;
@@ -1215,6 +1226,7 @@ extern "C" int dctr_crossnet_mat_fwd(const dctr_mlp_t* m, const float* x, int64_
   a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = nullptr; a.logit = nullptr;
   a.g = nullptr; a.ldg = 0; a.gx = nullptr; a.ldgx = 0; a.trace = nullptr;
   const int Wp = round_up(W, 16);
+  a.kc = kKC;
   a.rsx = Wp + 4;
   a.rsh = Wp + 4;
   a.rsd = 0;

@@ -18,7 +18,7 @@ import torch.nn as nn
 from . import lib as L
 from ..layers.activation import Identity
 
-MAX_TOWER_WIDTH = 928
+MAX_TOWER_WIDTH = 1152
 
 
 def _ptr(t):
@@ -45,9 +45,10 @@ def tower_layers(dnn, dnn_linear=None):
             relu = 0
         else:
             return None
-        # csrc/mlp.hip keeps a 16-sample tile of the widest activation (twice) next to the staged input columns in LDS:
-        # 16 * (516 + 2 * (round16(width) + 4)) * 4 bytes <= 150 KB for the fused train step -> width <= 928.  Wider
-        # towers (1024-wide layers are common) stay on PyTorch-ROCm's nn.Linear.
+        # csrc/mlp.hip keeps a 16-sample tile of the widest activation (twice) next to a chunk of staged input columns
+        # in LDS; the chunk shrinks from 512 to 64 columns as the tower widens (pick_kc), and the backward's two
+        # gradient tiles 16 * 2 * (round64(width) + 4) * 4 bytes <= 150 KB bound the width at 1152 -- 1024-wide towers
+        # run on the kernels.  Wider ones stay on PyTorch-ROCm's nn.Linear.
         if fc.out_features > MAX_TOWER_WIDTH or fc.weight.dtype != torch.float32:
             return None
         layers.append((fc.weight, fc.bias, relu))

@@ -97,13 +97,17 @@ def test_data_parallel_trainer_counts_dense_regularisers_once(tmp_path, kind, mo
     monkeypatch.setattr(L, "require_gpu", lambda t, what: None)
     monkeypatch.setattr(L, "stream_handle", lambda device=None: None)
     monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))
-    torch.set_num_threads(1)
-    m = _model(kind)
-    m.compile("sgd", "binary_crossentropy", metrics=[])
-    m.train()
-    for step in range(3):
-        Xg, yg = _batch(step, world)
-        m._train_step(Xg, yg)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)            # (restored below: later tests compare ill-conditioned fp32 sums bit for bit)
+    try:
+        m = _model(kind)
+        m.compile("sgd", "binary_crossentropy", metrics=[])
+        m.train()
+        for step in range(3):
+            Xg, yg = _batch(step, world)
+            m._train_step(Xg, yg)
+    finally:
+        torch.set_num_threads(threads)
     want = m.state_dict()
     for k, v in want.items():
         err = float((ranks[0][k] - v.detach()).abs().max())

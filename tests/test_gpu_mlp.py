@@ -46,6 +46,8 @@ SHAPES = [  # B, K, hidden, with projection, activation, extra input padding
     (50, 40, (24, 20), False, "relu", 0),         # DCN: the tower output is the last hidden layer
     (33, 18, (10, 7), True, "linear", 2),         # identity activations, ragged widths
     (16, 5, (300,), True, "relu", 3),             # wide single layer: several tile passes per wave
+    (70, 429, (1024, 512, 256), True, "relu", 3), # 1024-wide tower: the input is staged in 256-column chunks
+    (40, 1100, (1152, 64), True, "relu", 0),      # the widest layer the LDS tiles hold, input in 64-column chunks
 ]
 
 

@@ -117,17 +117,20 @@ def test_bce_head_autograd_route(mock):
 
 
 def test_towers_wider_than_the_kernels_hold_stay_on_torch(mock):
-    """1024-wide layers (a common configuration) exceed what csrc/mlp.hip's 16-sample LDS tile holds: the layer spec must
-    decline them (they run as nn.Linear on PyTorch-ROCm) instead of failing with ENOSUP at the first step."""
+    """Layers wider than csrc/mlp.hip's 16-sample LDS tiles hold (1152: the backward's two gradient tiles) must be
+    declined by the layer spec (they run as nn.Linear on PyTorch-ROCm) instead of failing with ENOSUP at the first
+    step; 1024-wide layers -- a common configuration -- are inside."""
     from deepctr_torch._hip import mlp
     from deepctr_torch.layers import DNN
-    ok = DNN(40, (928, 64), device="cpu")
-    wide = DNN(40, (1024, 512, 256), device="cpu")
-    lin_ok, lin_wide = torch.nn.Linear(64, 1, bias=False), torch.nn.Linear(256, 1, bias=False)
+    ok = DNN(40, (1024, 512, 256), device="cpu")
+    wide = DNN(40, (1280, 64), device="cpu")
+    lin_ok, lin_wide = torch.nn.Linear(256, 1, bias=False), torch.nn.Linear(64, 1, bias=False)
     assert mlp.tower_layers(ok, lin_ok) is not None and mlp.tower_layers(wide, lin_wide) is None
-    # the widest accepted layer fits the fused train step's budget: 16 * (516 + 2 * (round16(w) + 4)) * 4 <= 150 KB
+    # the widest accepted layer fits both budgets of the fused train step (150 KB): the forward with the smallest input
+    # chunk (64 columns) and the backward's two [16, round64(w) + 4] gradient tiles
     w = mlp.MAX_TOWER_WIDTH
-    assert 16 * (516 + 2 * ((w + 15) // 16 * 16 + 4)) * 4 <= 150 * 1024 < 16 * (516 + 2 * ((w + 16 + 15) // 16 * 16 + 4)) * 4
+    assert 16 * (68 + 2 * ((w + 15) // 16 * 16 + 4)) * 4 <= 150 * 1024
+    assert 16 * 2 * ((w + 63) // 64 * 64 + 4) * 4 <= 150 * 1024 < 16 * 2 * ((w + 64 + 63) // 64 * 64 + 4) * 4
     x = torch.randn(6, 40)
     y = mlp.tower(wide, lin_wide, x, 40)
     assert "mlp_fwd" not in mock.calls and torch.allclose(y, lin_wide(wide(x)), atol=1e-6)

@@ -134,7 +134,13 @@ def test_reference_matrix_forward_and_gradients(mock, c):
     for k, p in m.named_parameters():
         ref = c["grads"][k]
         got = p.grad.numpy() if p.grad is not None else np.zeros_like(ref)
-        assert max_abs(got, ref) <= 2e-5 * max(1.0, float(np.max(np.abs(ref))) if ref.size else 1.0), k
+        tol = 2e-5 * max(1.0, float(np.max(np.abs(ref))) if ref.size else 1.0)
+        if k in c["grads64"]:
+            # train-mode BatchNorm at initialisation is ill-conditioned (tests/test_gpu_reference_matrix.py): even torch-CPU
+            # against itself differs with the thread count; bounded by the reference's own measured fp32 uncertainty
+            tol = max(tol, 4.0 * max_abs(ref, c["grads64"][k]))
+            ref = c["grads64"][k]
+        assert max_abs(got, ref) <= tol, k
 
 
 def test_reference_protocol_runs_on_pooled_fields(mock, monkeypatch, tmp_path):
