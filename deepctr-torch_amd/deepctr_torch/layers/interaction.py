@@ -231,13 +231,21 @@ class CIN(nn.Module):
         final_result = []
         for i, size in enumerate(self.layer_size):
             conv = self.conv1ds[i]
-            if x0.shape[1] <= 32:
+            M = x0.shape[1]
+            if M <= 32:
                 curr_out = _ops.CINLayerFunction.apply(hidden, x0, conv.weight.squeeze(-1), conv.bias, fused_relu)
             else:
-                # more fields than the MFMA kernel tiles (csrc/cin.hip: M <= 32), e.g. Criteo with its 13 dense
-                # columns bucketised into fields: the reference's own formulation on PyTorch-ROCm (hipBLASLt)
-                z = (hidden.unsqueeze(2) * x0.unsqueeze(1)).reshape(x0.shape[0], -1, x0.shape[2])
-                curr_out = torch.einsum("oz,bzd->bod", conv.weight.squeeze(-1), z) + conv.bias[None, :, None]
+                # More fields than one MFMA tile of csrc/cin.hip (M <= 32), e.g. Criteo with its 13 dense columns
+                # bucketised into fields (39): the sum over the field index m of x_0 splits into groups of <= 32
+                # fields -- one kernel call per group on the group's slice of x_0 (a view) and of the filter, the
+                # pre-activations added, then bias / relu.  Everything stays on the MFMA kernels.
+                W3 = conv.weight.squeeze(-1).view(size, hidden.shape[1], M)
+                curr_out = None
+                for lo in range(0, M, 32):
+                    hi = min(M, lo + 32)
+                    part = _ops.CINLayerFunction.apply(hidden, x0[:, lo:hi], W3[:, :, lo:hi].reshape(size, -1),
+                                                       conv.bias if lo == 0 else None, False)
+                    curr_out = part if curr_out is None else curr_out + part
                 if fused_relu:
                     curr_out = torch.relu(curr_out)
             if not fused_relu and self.activation is not None:
