@@ -635,6 +635,339 @@ __global__ __launch_bounds__(kT) void k_cross_mat_bwd(MlpArgs A) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// CrossNetMix (DCN-Mix): mixture of low-rank experts per cross layer, as three dense layers each (see dctr.h)
+// ------------------------------------------------------------------------------------------------------------
+// one dense layer of a 16-sample tile whose input sits in LDS: bias-initialised accumulators, the forward's MFMA
+// loops, then epi(row, n, value) per output element
+template <typename Epi>
+__device__ __forceinline__ void mix_layer(const LayerDev& Ld, const float* in, int rs, int klen, int wv, int g, int c,
+                                          Epi epi) {
+  const int ntile = (Ld.N + 15) >> 4;
+  for (int tbase = 0; tbase < ntile; tbase += kWaves * kNTMax) {
+    const int tile0 = tbase + wv;
+    int nt = 0;
+#pragma unroll
+    for (int t = 0; t < kNTMax; ++t) nt += (tile0 + t * kWaves < ntile) ? 1 : 0;
+    f32x4 acc[kNTMax];
+#pragma unroll
+    for (int t = 0; t < kNTMax; ++t) {
+      const int n = (tile0 + t * kWaves) * 16 + c;
+      const float bv = (t < nt && n < Ld.N && Ld.bias) ? ldg_f32(Ld.bias + n) : 0.f;
+      acc[t] = f32x4{bv, bv, bv, bv};
+    }
+    fwd_dispatch(nt, in, rs, 0, klen, Ld, tile0, acc, g, c, []() {});
+#pragma unroll
+    for (int t = 0; t < kNTMax; ++t) {
+      if (t < nt) {
+        const int n = (tile0 + t * kWaves) * 16 + c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) epi(4 * g + r, n, acc[t][r]);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kT) void k_cross_mix_fwd(MlpArgs A, int E, int R) {
+  extern __shared__ __align__(16) float smem[];
+  __shared__ float sc[kTM][8];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int b0 = blockIdx.x * kTM;
+  const int W = A.L[0].K, Wp = round_up(W, 16);
+  const int ER = E * R, N1 = ER + E;
+  const int rsw = Wp + 4, rsv = round_up(N1, 16) + 4;
+  float* xs = smem;                 // x_0
+  float* xa = xs + kTM * rsw;       // x_l / x_{l+1}: ping
+  float* xb = xa + kTM * rsw;       //                pong
+  float* v1 = xb + kTM * rsw;       // [v1 | scores]
+  float* v2 = v1 + kTM * rsv;       // s (.) v2
+  for (int e = tid; e < kTM * Wp; e += kT) {
+    const int r = e / Wp, n = e - r * Wp;
+    const int64_t b = b0 + r;
+    xs[r * rsw + n] = (b < A.B && n < W) ? ldg_f32(A.x + b * A.ldx + n) : 0.f;
+  }
+  __syncthreads();
+  const float* xl = xs;
+  float* xn = xa;
+  const int n_cross = A.n_layers / 3;
+  for (int lc = 0; lc < n_cross; ++lc) {
+    const LayerDev& L1 = A.L[3 * lc];
+    const LayerDev& L2 = A.L[3 * lc + 1];
+    const LayerDev& L3 = A.L[3 * lc + 2];
+    // ---- project to the experts' rank spaces (+ the gating scores as E more output columns)
+    mix_layer(L1, xl, rsw, Wp, wv, g, c, [&](int row, int n, float v) {
+      if (n < ER) v = tanhf(v);
+      if (n >= N1) v = 0.f;
+      v1[row * rsv + n] = v;
+      if (n < ER && b0 + row < A.B) stg_f32(L1.h + static_cast<int64_t>(b0 + row) * L1.ldh + n, v);
+    });
+    __syncthreads();
+    if (tid < kTM) {                                     // softmax over the E scores of a sample (torch.softmax, dim=1)
+      float m = -INFINITY;
+      for (int i = 0; i < E; ++i) m = fmaxf(m, v1[tid * rsv + ER + i]);
+      float ex[8], sum = 0.f;
+      for (int i = 0; i < E; ++i) {
+        ex[i] = expf(v1[tid * rsv + ER + i] - m);
+        sum += ex[i];
+      }
+      for (int i = 0; i < E; ++i) {
+        const float si = ex[i] / sum;
+        sc[tid][i] = si;
+        if (b0 + tid < A.B) stg_f32(L1.h + static_cast<int64_t>(b0 + tid) * L1.ldh + ER + i, si);
+      }
+    }
+    __syncthreads();
+    // ---- the experts' r x r maps (one block-diagonal layer); the mixture weights go onto the result
+    mix_layer(L2, v1, rsv, round_up(ER, 16), wv, g, c, [&](int row, int n, float v) {
+      float t = 0.f, ts = 0.f;
+      if (n < ER) {
+        t = tanhf(v);
+        ts = t * sc[row][n / R];
+        if (b0 + row < A.B) {
+          stg_f32(L2.dh + static_cast<int64_t>(b0 + row) * L2.ldh + n, t);     // parked for the backward
+          stg_f32(L2.h + static_cast<int64_t>(b0 + row) * L2.ldh + n, ts);
+        }
+      }
+      v2[row * rsv + n] = ts;
+    });
+    __syncthreads();
+    // ---- back to R^W, bias, cross with x_0, residual
+    mix_layer(L3, v2, rsv, round_up(ER, 16), wv, g, c, [&](int row, int n, float u) {
+      float v = 0.f;
+      if (n < W) {
+        v = xs[row * rsw + n] * u + xl[row * rsw + n];
+        if (b0 + row < A.B) {
+          stg_f32(L3.dh + static_cast<int64_t>(b0 + row) * L3.ldh + n, u);     // parked for the backward
+          stg_f32(L3.h + static_cast<int64_t>(b0 + row) * L3.ldh + n, v);
+        }
+      }
+      xn[row * rsw + n] = v;
+    });
+    __syncthreads();
+    xl = xn;
+    xn = (xn == xa) ? xb : xa;
+  }
+}
+
+// out[row, k] = sum_{n < N} a[row, n] W[n, k] for k in [0, ncols): the backward-data product of one dense layer on a
+// 16-sample tile (a in LDS, zero beyond N); 64-column groups over the waves; epi(row, col0, f32x4) per 4 columns.
+template <typename Epi>
+__device__ __forceinline__ void mix_bwd_product(const float* as, int rs, int Nred, const LayerDev& Ld, int ncols,
+                                                int wv, int g, int c, Epi epi) {
+  const int ngroups = (ncols + 63) >> 6;
+  const int ncp = round_up(ncols, 16);
+  for (int gb = wv; gb < ngroups; gb += kWaves) {
+    const int col0 = 64 * gb + 4 * c;
+    const int colc = col0 < Ld.ldw ? col0 : 0;
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* ap = as + c * rs + 4 * g;
+    const int n_it = Nred >> 4;
+    const DCTR_GLOBAL char* wbase = (const DCTR_GLOBAL char*)Ld.W;
+    const uint32_t ldw4 = static_cast<uint32_t>(Ld.ldw) * 4u;
+    const uint32_t vlast = static_cast<uint32_t>(Ld.N - 1) * ldw4 + static_cast<uint32_t>(colc) * 4u;
+    uint32_t vrow[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vrow[j] = static_cast<uint32_t>(4 * g + j) * ldw4 + static_cast<uint32_t>(colc) * 4u;
+    auto wld = [&](int it, f32x4* dst) {
+      it = it < n_it ? it : n_it - 1;
+      const uint32_t so = static_cast<uint32_t>(it) * 16u * ldw4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t o = vrow[j] + so;
+        o = o < vlast ? o : vlast;                                  // rows past N re-read row N-1 (a is 0 there)
+        dst[j] = *(const DCTR_GLOBAL f32x4*)(wbase + o);
+      }
+    };
+    constexpr int PD = 5;
+    f32x4 ring[PD][4];
+#pragma unroll
+    for (int d = 0; d < PD - 1; ++d) wld(d, ring[d]);
+    const int n_grp = n_it / PD, rem = n_it - n_grp * PD;
+    f32x4 a_nxt = *reinterpret_cast<const f32x4*>(ap);
+    for (int gi = 0; gi < n_grp; ++gi) {
+#pragma unroll
+      for (int d = 0; d < PD; ++d) {
+        const int it = gi * PD + d;
+        wld(it + PD - 1, ring[(d + PD - 1) % PD]);
+        const f32x4 a4 = a_nxt;
+        const int itn = it + 1 < n_it ? it + 1 : it;
+        a_nxt = *reinterpret_cast<const f32x4*>(ap + (itn << 4));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] = mfma16(a4[j], ring[d][j][q], acc[q]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < PD - 1; ++d) {
+      if (d < rem) {
+        const int it = n_grp * PD + d;
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + (it << 4));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] = mfma16(a4[j], ring[d][j][q], acc[q]);
+      }
+    }
+    if (col0 < ncp) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) epi(4 * g + r, col0, f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]});
+    }
+  }
+}
+
+// backward-data of a 16-sample tile through all cross layers.  Per layer, with g = d loss / d x_{l+1}:
+//   a3 = g (.) x_0  (-> dh of layer 3l+2, over the parked u; x_0 collects g (.) u on the side)
+//   p3 = a3 W3;  d s_e = sum_r p3[e, r] v2[e, r];  a2 = p3 (.) s_e (.) (1 - v2^2)  (-> dh of layer 3l+1, over the parked v2)
+//   softmax backward: d score_e = s_e (d s_e - sum_e' s_e' d s_e')
+//   a1 = [ (a2 W2) (.) (1 - v1^2) | d score ]  (-> dh of layer 3l);   d loss / d x_l = g + a1 W1
+__global__ __launch_bounds__(kT) void k_cross_mix_bwd(MlpArgs A, int E, int R) {
+  extern __shared__ __align__(16) float smem[];
+  __shared__ float dsc[kTM][8];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int b0 = blockIdx.x * kTM;
+  const int W = A.L[0].K, Wp = round_up(W, 16);
+  const int ER = E * R, N1 = ER + E;
+  const int ERp = round_up(ER, 16), N1p = round_up(N1, 16);
+  const int rsw = round_up(W, 64) + 4, rsv = round_up(N1, 64) + 4;
+  float* x0s = smem;
+  float* gin = x0s + kTM * rsw;
+  float* gout = gin + kTM * rsw;
+  float* a3 = gout + kTM * rsw;
+  float* p3 = a3 + kTM * rsw;       // [16][rsv]: p3, then a2 in place
+  float* a1 = p3 + kTM * rsv;       // [16][rsv]
+  constexpr int kPer = kTM * kKC / kT;
+  float side[kPer];
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) side[k] = 0.f;
+  const int n_el = kTM * Wp;
+  for (int e = tid; e < n_el; e += kT) {
+    const int r = e / Wp, n = e - r * Wp;
+    const int64_t b = b0 + r;
+    const bool ok = b < A.B && n < W;
+    x0s[r * rsw + n] = ok ? ldg_f32(A.x + b * A.ldx + n) : 0.f;
+    gin[r * rsw + n] = ok ? ldg_f32(A.g + b * A.ldg + n) : 0.f;
+  }
+  for (int e = tid; e < kTM * rsv; e += kT) {
+    p3[e] = 0.f;
+    a1[e] = 0.f;
+  }
+  __syncthreads();
+  const int n_cross = A.n_layers / 3;
+  for (int lc = n_cross - 1; lc >= 0; --lc) {
+    const LayerDev& L1 = A.L[3 * lc];
+    const LayerDev& L2 = A.L[3 * lc + 1];
+    const LayerDev& L3 = A.L[3 * lc + 2];
+    // ---- a3 = g (.) x_0; the side term for x_0
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int e = tid + k * kT;
+      if (e < n_el) {
+        const int r = e / Wp, n = e - r * Wp;
+        const int64_t b = b0 + r;
+        const float gv = gin[r * rsw + n];
+        const float av = gv * x0s[r * rsw + n];
+        a3[r * rsw + n] = av;
+        if (b < A.B && n < W) {
+          float* up = L3.dh + b * L3.ldh + n;
+          side[k] += gv * ldg_f32(up);
+          stg_f32(up, av);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- p3 = a3 W3  ([16, W] x [W, ER])
+    mix_bwd_product(a3, rsw, Wp, L3, ER, wv, g, c, [&](int row, int col0, f32x4 v) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) p3[row * rsv + col0 + q] = (col0 + q < ER) ? v[q] : 0.f;
+    });
+    __syncthreads();
+    // ---- d s_e (a reduction over the expert's R columns), then a2 in place
+    if (tid < kTM * E) {
+      const int row = tid / E, e = tid - row * E;
+      const int64_t b = b0 + row;
+      float acc = 0.f;
+      if (b < A.B)
+        for (int r = 0; r < R; ++r) acc += p3[row * rsv + e * R + r] * ldg_f32(L2.dh + b * L2.ldh + e * R + r);
+      dsc[row][e] = acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < kTM * ERp; e += kT) {
+      const int row = e / ERp, n = e - row * ERp;
+      const int64_t b = b0 + row;
+      float av = 0.f;
+      if (b < A.B && n < ER) {
+        const float t = ldg_f32(L2.dh + b * L2.ldh + n);                     // unscaled v2 (parked by the forward)
+        const float s = ldg_f32(L1.h + b * L1.ldh + ER + n / R);
+        av = p3[row * rsv + n] * s * (1.f - t * t);
+        stg_f32(L2.dh + b * L2.ldh + n, av);
+      }
+      p3[row * rsv + n] = av;
+    }
+    if (tid < kTM) {                                                          // softmax backward
+      const int64_t b = b0 + tid;
+      float dot = 0.f, sv[8];
+      for (int i = 0; i < E; ++i) {
+        sv[i] = b < A.B ? ldg_f32(L1.h + b * L1.ldh + ER + i) : 0.f;
+        dot += sv[i] * dsc[tid][i];
+      }
+      for (int i = 0; i < E; ++i) {
+        const float ds = sv[i] * (dsc[tid][i] - dot);
+        a1[tid * rsv + ER + i] = ds;
+        if (b < A.B) stg_f32(L1.dh + b * L1.ldh + ER + i, ds);
+      }
+    }
+    __syncthreads();
+    // ---- a1[:, :ER] = (a2 W2) (.) (1 - v1^2)
+    mix_bwd_product(p3, rsv, ERp, L2, ER, wv, g, c, [&](int row, int col0, f32x4 v) {
+      const int64_t b = b0 + row;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = col0 + q;
+        float av = 0.f;
+        if (b < A.B && n < ER) {
+          const float t = ldg_f32(L1.h + b * L1.ldh + n);
+          av = v[q] * (1.f - t * t);
+          stg_f32(L1.dh + b * L1.ldh + n, av);
+        }
+        if (n < ER) a1[row * rsv + n] = av;
+      }
+    });
+    __syncthreads();
+    // ---- d loss / d x_l = g + a1 W1  ([16, N1] x [N1, W])
+    mix_bwd_product(a1, rsv, N1p, L1, W, wv, g, c, [&](int row, int col0, f32x4 v) {
+      const f32x4 gprev = *reinterpret_cast<const f32x4*>(gin + row * rsw + col0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = (col0 + q < W) ? v[q] + gprev[q] : 0.f;
+      *reinterpret_cast<f32x4*>(gout + row * rsw + col0) = v;
+    });
+    __syncthreads();
+    float* t = gin;
+    gin = gout;
+    gout = t;
+  }
+  if (A.gx) {
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int e = tid + k * kT;
+      if (e < n_el) {
+        const int r = e / Wp, n = e - r * Wp;
+        const int64_t b = b0 + r;
+        if (b < A.B && n < A.ldgx) stg_f32(A.gx + b * A.ldgx + n, n < W ? gin[r * rsw + n] + side[k] : 0.f);
+      }
+    }
+    for (int e = tid; e < kTM * 4; e += kT) {
+      const int r = e >> 2, n = Wp + (e & 3);
+      const int64_t b = b0 + r;
+      if (b < A.B && n < A.ldgx) stg_f32(A.gx + b * A.ldgx + n, 0.f);
+    }
+  }
+}
+
 // forward + prediction head + BCE(sum) + backward-data of one row tile in ONE launch (the fused train step): the
 // logits never leave the workgroup, d loss / d logit goes to the backward through LDS, and the head's own launch,
 // the backward's staging round trip and two kernel boundaries disappear.  Per-workgroup partial sums of the loss and
@@ -1271,5 +1604,101 @@ extern "C" int dctr_crossnet_mat_bwd(const dctr_mlp_t* m, const float* x, int64_
     if (st != DCTR_OK) return st;
   }
   // d W_l = a_l^T x_l, d b_l = column sums of a_l: the tower's weight-gradient kernels, as they are
+  return launch_wgrad_reduce(m, x, ld_x, B, nullptr, workspace, nullptr, nullptr, 0, nullptr, nullptr, nullptr, s);
+}
+
+// ---- CrossNetMix (interaction.py:499-534) -----------------------------------------------------------------------------
+namespace {
+int check_mix(const dctr_mlp_t* m, int32_t E, int32_t R, int32_t B) {
+  // (not check_mlp: the dense layers of a cross layer do not chain by width -- layer 3l+1 reads the first E*R of
+  // layer 3l's E*R + E outputs)
+  if (!m || B < 0 || m->n_layers <= 0 || m->n_layers > kMaxL) return DCTR_EINVAL;
+  for (int l = 0; l < m->n_layers; ++l) {
+    const dctr_mlp_layer_t& L = m->layer[l];
+    if (!L.W || L.K <= 0 || L.N <= 0 || L.ld_w < L.K) return DCTR_EINVAL;
+    if (L.ld_w % 4 != 0 || reinterpret_cast<uintptr_t>(L.W) % 16 != 0) return DCTR_EALIGN;
+    if (L.N > 2048) return DCTR_ENOSUP;
+  }
+  if (m->w_out || E <= 0 || R <= 0 || m->n_layers % 3 != 0) return DCTR_EINVAL;
+  const int W = m->layer[0].K, ER = E * R;
+  for (int l = 0; l < m->n_layers; ++l) {
+    const dctr_mlp_layer_t& L = m->layer[l];
+    const int k = l % 3;
+    const int wantK = k == 0 ? W : ER, wantN = k == 0 ? ER + E : (k == 1 ? ER : W);
+    if (L.K != wantK || L.N != wantN || !L.h || !L.dh || L.ld_h < L.N) return DCTR_EINVAL;
+    if (L.ld_h % 4 != 0 || reinterpret_cast<uintptr_t>(L.h) % 16 != 0 || reinterpret_cast<uintptr_t>(L.dh) % 16 != 0)
+      return DCTR_EALIGN;
+  }
+  return DCTR_OK;
+}
+size_t mix_lds_fwd(int W, int N1) {
+  return static_cast<size_t>(kTM) * (3 * (round_up(W, 16) + 4) + 2 * (round_up(N1, 16) + 4)) * 4;
+}
+size_t mix_lds_bwd(int W, int N1) {
+  return static_cast<size_t>(kTM) * (4 * (round_up(W, 64) + 4) + 2 * (round_up(N1, 64) + 4)) * 4;
+}
+}  // namespace
+
+extern "C" int dctr_crossnet_mix_supported(int32_t W, int32_t n_cross_layers, int32_t E, int32_t R) {
+  if (W <= 0 || n_cross_layers <= 0 || 3 * n_cross_layers > kMaxL || E <= 0 || E > 8 || R <= 0) return 0;
+  const int N1 = E * R + E;
+  if (round_up(W, 16) > kKC || N1 > 512) return 0;
+  return (mix_lds_fwd(W, N1) <= 150 * 1024 && mix_lds_bwd(W, N1) <= 150 * 1024) ? 1 : 0;
+}
+
+extern "C" int dctr_crossnet_mix_fwd(const dctr_mlp_t* m, int32_t E, int32_t R, const float* x, int64_t ld_x, int32_t B,
+                                     dctr_stream_t stream) {
+  const int rc = check_mix(m, E, R, B);
+  if (rc != DCTR_OK) return rc;
+  const int W = m->layer[0].K;
+  if (!x || ld_x < W) return DCTR_EINVAL;
+  if (!dctr_crossnet_mix_supported(W, m->n_layers / 3, E, R)) return DCTR_ENOSUP;
+  if (B == 0) return DCTR_OK;
+  MlpArgs a;
+  fill_layers(m, a.L);
+  a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = nullptr; a.logit = nullptr;
+  a.g = nullptr; a.ldg = 0; a.gx = nullptr; a.ldgx = 0; a.trace = nullptr;
+  a.kc = kKC; a.rsx = 0; a.rsh = 0; a.rsd = 0;
+  const size_t lds = mix_lds_fwd(W, E * R + E);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cross_mix_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(lds));
+  k_cross_mix_fwd<<<dim3((B + kTM - 1) / kTM), dim3(kT), lds, static_cast<hipStream_t>(stream)>>>(a, E, R);
+  return launch_status();
+}
+
+extern "C" size_t dctr_crossnet_mix_bwd_workspace_floats(const dctr_mlp_t* m, int32_t B) {
+  if (!m || B < 0 || m->n_layers <= 0 || m->n_layers > kMaxL) return 0;
+  const WgradPlan P = plan_wgrad(m, B);
+  return static_cast<size_t>(P.slab) * P.S;
+}
+
+extern "C" int dctr_crossnet_mix_bwd(const dctr_mlp_t* m, int32_t E, int32_t R, const float* x, int64_t ld_x, int32_t B,
+                                     const float* gY, int64_t ld_g, float* gx, int64_t ld_gx, float* workspace,
+                                     dctr_stream_t stream) {
+  const int rc = check_mix(m, E, R, B);
+  if (rc != DCTR_OK) return rc;
+  const int W = m->layer[0].K;
+  if (!x || !gY || !workspace || ld_x < W || ld_g < W) return DCTR_EINVAL;
+  const int rb = check_bwd(m, x, ld_x, B, gx, ld_gx);
+  if (rb != DCTR_OK) return rb;
+  if (!dctr_crossnet_mix_supported(W, m->n_layers / 3, E, R)) return DCTR_ENOSUP;
+  if (B == 0) return DCTR_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    MlpArgs a;
+    fill_layers(m, a.L);
+    a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = nullptr; a.logit = nullptr;
+    a.g = gY; a.ldg = ld_g; a.gx = gx; a.ldgx = ld_gx; a.trace = nullptr;
+    a.kc = kKC; a.rsx = 0; a.rsh = 0; a.rsd = 0;
+    const size_t lds = mix_lds_bwd(W, E * R + E);
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cross_mix_bwd),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    k_cross_mix_bwd<<<dim3((B + kTM - 1) / kTM), dim3(kT), lds, s>>>(a, E, R);
+    const int st = launch_status();
+    if (st != DCTR_OK) return st;
+  }
+  // d W of the three dense layers per cross layer (= packed gV | gG, gC blocks, gU) and d b: the tower's kernels
   return launch_wgrad_reduce(m, x, ld_x, B, nullptr, workspace, nullptr, nullptr, 0, nullptr, nullptr, nullptr, s);
 }

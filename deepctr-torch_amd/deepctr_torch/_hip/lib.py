@@ -33,7 +33,7 @@ class Plan(ctypes.Structure):
                 ("max_dim", ctypes.c_int32), ("vec", ctypes.c_int32), ("flags", ctypes.c_int32)]
 
 
-MLP_MAX_LAYERS = 8
+MLP_MAX_LAYERS = 12
 
 
 class MlpLayer(ctypes.Structure):
@@ -129,6 +129,10 @@ SIGNATURES = {
     "dctr_crossnet_mat_fwd": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P]),
     "dctr_crossnet_mat_bwd_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(Mlp), _I32]),
     "dctr_crossnet_mat_bwd": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P]),
+    "dctr_crossnet_mix_supported": (ctypes.c_int, [_I32, _I32, _I32, _I32]),
+    "dctr_crossnet_mix_fwd": (ctypes.c_int, [ctypes.POINTER(Mlp), _I32, _I32, _P, _I64, _I32, _P]),
+    "dctr_crossnet_mix_bwd_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(Mlp), _I32]),
+    "dctr_crossnet_mix_bwd": (ctypes.c_int, [ctypes.POINTER(Mlp), _I32, _I32, _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P]),
     "dctr_sizeof_mlp": (ctypes.c_size_t, []),
     "dctr_mlp_fwd": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _P]),
     "dctr_mlp_bwd_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(Mlp), _I32]),

@@ -826,3 +826,111 @@ class CrossNetMatFunction(torch.autograd.Function):
         L.check(lib.dctr_crossnet_mat_bwd(ctypes.byref(desc), _ptr(X), X.stride(0), B, _ptr(g), ld, _ptr(gX), ld, _ptr(ws),
                                           L.stream_handle(X.device)), "dctr_crossnet_mat_bwd")
         return gX[:, :W], gW[:, :, :W].reshape(ctx.kshape), gb.reshape(ctx.bshape)
+
+
+class CrossNetMixFunction(torch.autograd.Function):
+    """CrossNetMix of DCN-Mix (reference interaction.py:499-534): per cross layer a mixture of low-rank experts,
+    ``x_{l+1} = x_0 * (sum_e softmax(x_l G^T)_e * tanh(tanh(x_l V_e) C_e^T) U_e^T + b) + x_l``.  All layers in ONE
+    forward launch (csrc/mlp.hip ``dctr_crossnet_mix_fwd``: three dense fp32-MFMA layers per cross layer on a 16-sample
+    tile kept in LDS) and one backward-data launch + the tower's weight-gradient kernels.  The weights travel packed:
+    ``W1 = [V (E*R rows) | G (E rows)] x W``, ``W2 = blockdiag(C_e)``, ``W3[w, e*R + r] = U_e[w, r]``."""
+
+    @staticmethod
+    def _r4(n):
+        return (int(n) + 3) // 4 * 4
+
+    @staticmethod
+    def _pack(U, V, C, G, bias):
+        Lc, E, W, R = U.shape
+        ER = E * R
+        ldW, ldE = CrossNetMixFunction._r4(W), CrossNetMixFunction._r4(ER)
+        dev = U.device
+        W1 = torch.zeros((Lc, ER + E, ldW), dtype=torch.float32, device=dev)
+        W1[:, :ER, :W] = V.permute(0, 1, 3, 2).reshape(Lc, ER, W)       # row e*R + r = V_e[:, r]
+        W1[:, ER:, :W] = G.unsqueeze(0)
+        W2 = torch.zeros((Lc, ER, ldE), dtype=torch.float32, device=dev)
+        for e in range(E):
+            W2[:, e * R:(e + 1) * R, e * R:(e + 1) * R] = C[:, e]         # v2[e, r] = sum_s C[e, r, s] v1[e, s]
+        W3 = torch.zeros((Lc, W, ldE), dtype=torch.float32, device=dev)
+        W3[:, :, :ER] = U.permute(0, 2, 1, 3).reshape(Lc, W, ER)        # W3[w, e*R + r] = U_e[w, r]
+        return W1, W2, W3, bias.reshape(Lc, W).contiguous()
+
+    @staticmethod
+    def _desc(W1, W2, W3, b2, bufs, grads, dims):
+        B, W, Lc, E, R = dims
+        ER = E * R
+        desc = L.Mlp()
+        desc.n_layers = 3 * Lc
+        for lc in range(Lc):
+            for k, (Wt, K, N) in enumerate(((W1[lc], W, ER + E), (W2[lc], ER, ER), (W3[lc], ER, W))):
+                e = desc.layer[3 * lc + k]
+                h, dh = bufs[3 * lc + k]
+                e.W, e.bias = Wt.data_ptr(), (b2[lc].data_ptr() if k == 2 else None)
+                e.h, e.dh = h.data_ptr(), dh.data_ptr()
+                e.K, e.N, e.ld_w, e.ld_h, e.relu = K, N, Wt.stride(0), h.stride(0), 0
+                if grads is not None:
+                    gW, gb = grads[3 * lc + k]
+                    e.gW, e.gbias = gW.data_ptr(), (gb.data_ptr() if gb is not None else None)
+                else:
+                    e.gW = e.gbias = None
+        desc.w_out = desc.g_w_out = None
+        return desc
+
+    @staticmethod
+    def forward(ctx, X, U, V, C, G, bias):
+        lib = L.lib()
+        L.require_gpu(X, "CrossNetMix input")
+        B, W = X.shape
+        Lc, E, _, R = U.shape
+        ER, r4 = E * R, CrossNetMixFunction._r4
+        ld = r4(W)
+        if X.dtype != torch.float32 or X.stride(1) != 1 or X.stride(0) % 4 or X.data_ptr() % 16 or X.stride(0) < W:
+            buf = torch.zeros((B, ld), dtype=torch.float32, device=X.device)
+            buf[:, :W].copy_(X)
+            X = buf
+        W1, W2, W3, b2 = CrossNetMixFunction._pack(U.detach(), V.detach(), C.detach(), G.detach(), bias.detach())
+        bufs = []
+        for lc in range(Lc):
+            for n in (ER + E, ER, W):
+                bufs.append((torch.empty((B, r4(n)), dtype=torch.float32, device=X.device),
+                             torch.empty((B, r4(n)), dtype=torch.float32, device=X.device)))
+        dims = (B, W, Lc, E, R)
+        desc = CrossNetMixFunction._desc(W1, W2, W3, b2, bufs, None, dims)
+        L.check(lib.dctr_crossnet_mix_fwd(ctypes.byref(desc), E, R, _ptr(X), X.stride(0), B, L.stream_handle(X.device)),
+                "dctr_crossnet_mix_fwd")
+        ctx.save_for_backward(X, W1, W2, W3, b2, *[t for pair in bufs for t in pair])
+        ctx.dims = dims
+        ctx.shapes = (U.shape, V.shape, C.shape, G.shape, bias.shape)
+        return bufs[-1][0][:, :W]
+
+    @staticmethod
+    def backward(ctx, gY):
+        lib = L.lib()
+        B, W, Lc, E, R = ctx.dims
+        ER, r4 = E * R, CrossNetMixFunction._r4
+        saved = ctx.saved_tensors
+        X, W1, W2, W3, b2 = saved[:5]
+        flat = saved[5:]
+        bufs = [(flat[2 * i], flat[2 * i + 1]) for i in range(3 * Lc)]
+        dev = X.device
+        ld = r4(W)
+        g = torch.zeros((B, ld), dtype=torch.float32, device=dev)
+        g[:, :W].copy_(gY)
+        gW1, gW2, gW3 = torch.empty_like(W1), torch.empty_like(W2), torch.empty_like(W3)
+        gb = torch.empty((Lc, W), dtype=torch.float32, device=dev)
+        grads = []
+        for lc in range(Lc):
+            grads += [(gW1[lc], None), (gW2[lc], None), (gW3[lc], gb[lc])]
+        gX = torch.empty((B, ld), dtype=torch.float32, device=dev)
+        desc = CrossNetMixFunction._desc(W1, W2, W3, b2, bufs, grads, ctx.dims)
+        ws = torch.empty((max(1, lib.dctr_crossnet_mix_bwd_workspace_floats(ctypes.byref(desc), B)),),
+                         dtype=torch.float32, device=dev)
+        L.check(lib.dctr_crossnet_mix_bwd(ctypes.byref(desc), E, R, _ptr(X), X.stride(0), B, _ptr(g), ld, _ptr(gX), ld,
+                                          _ptr(ws), L.stream_handle(dev)), "dctr_crossnet_mix_bwd")
+        # unpack: V / G from the rows of gW1, the diagonal blocks of gW2, U from gW3
+        gV = gW1[:, :ER, :W].reshape(Lc, E, R, W).permute(0, 1, 3, 2)
+        gG = gW1[:, ER:, :W].sum(0)
+        gC = torch.stack([gW2[:, e * R:(e + 1) * R, e * R:(e + 1) * R] for e in range(E)], dim=1)
+        gU = gW3[:, :, :ER].reshape(Lc, W, E, R).permute(0, 2, 1, 3)
+        sU, sV, sC, sG, sb = ctx.shapes
+        return gX[:, :W], gU.reshape(sU), gV.reshape(sV), gC.reshape(sC), gG.reshape(sG), gb.reshape(sb)

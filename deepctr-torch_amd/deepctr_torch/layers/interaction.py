@@ -159,8 +159,9 @@ class InteractingLayer(nn.Module):
 class CrossNetMix(nn.Module):
     """Cross network of DCN-Mix: a mixture of low-rank experts per layer, ``[B, W] -> [B, W]`` (reference
     interaction.py:456-534; same constructor, same ``U_list / V_list / C_list [L, E, ...]``, ``gating.<e>.weight``,
-    ``bias [L, W, 1]`` parameters).  Skinny GEMMs ([B, W] x [W, r]): batched over the experts on PyTorch-ROCm
-    (hipBLASLt), the reference's per-expert Python loop and stack replaced by one einsum per stage."""
+    ``bias [L, W, 1]`` parameters).  All layers in one fp32-MFMA launch each way (csrc/mlp.hip,
+    ``dctr_crossnet_mix_*``: three dense layers per cross layer on a 16-sample tile in LDS; up to 512 inputs, 4 cross
+    layers, 8 experts); beyond that the batched-einsum formulation on PyTorch-ROCm."""
 
     def __init__(self, in_features, low_rank=32, num_experts=4, layer_num=2, device='cpu'):
         super(CrossNetMix, self).__init__()
@@ -179,9 +180,13 @@ class CrossNetMix(nn.Module):
         self.to(device)
 
     def forward(self, inputs):
-        x_0 = inputs                                                     # [B, W]
-        x_l = x_0
         gate_w = torch.cat([g.weight for g in self.gating], dim=0)       # [E, W]
+        if inputs.dim() == 2 and inputs.dtype == torch.float32 and self.layer_num > 0 and \
+                _lib.lib().dctr_crossnet_mix_supported(int(inputs.shape[1]), int(self.layer_num),
+                                                       int(self.num_experts), int(self.U_list.shape[3])):
+            return _ops.CrossNetMixFunction.apply(inputs, self.U_list, self.V_list, self.C_list, gate_w, self.bias)
+        x_0 = inputs                                                     # [B, W]: beyond the kernels' LDS tiles
+        x_l = x_0
         for i in range(self.layer_num):
             score = torch.softmax(torch.matmul(x_l, gate_w.t()), dim=1)  # [B, E]   G(x_l)
             v_x = torch.tanh(torch.einsum("bw,ewr->ber", x_l, self.V_list[i]))          # project to R^r

@@ -414,6 +414,29 @@ size_t dctr_crossnet_mat_bwd_workspace_floats(const struct dctr_mlp* m, int32_t 
 int dctr_crossnet_mat_bwd(const struct dctr_mlp* m, const float* x, int64_t ld_x, int32_t B, const float* gY,
                           int64_t ld_g, float* gx, int64_t ld_gx, float* workspace, dctr_stream_t stream);
 
+/* ---- CrossNetMix of DCN-Mix (interaction.py:499-534; csrc/mlp.hip) -------------------------------------------------
+ * Per cross layer, with E experts of rank R over W inputs (G = the gating weights [E, W], shared by all layers):
+ *     s = softmax(x_l G^T)                      v1_e = tanh(x_l V_e)                  v2_e = tanh(v1_e C_e^T)
+ *     x_{l+1} = x_0 (.) (sum_e s_e v2_e U_e^T + b) + x_l
+ * described as a dctr_mlp_t of THREE dense layers per cross layer (the caller packs the weights):
+ *   layer 3l   : W1 [E*R + E, W]   rows e*R + r = V_e[:, r], rows E*R + e = G[e];   h = [v1 | s],  dh scratch
+ *   layer 3l+1 : W2 [E*R, E*R]     block-diagonal, block e = C_e;   h = s (.) v2 (what feeds the next product),
+ *                                  dh: the forward parks the unscaled v2 there (the backward needs it)
+ *   layer 3l+2 : W3 [W, E*R]       W3[w, e*R + r] = U_e[w, r];  bias = b;   h = x_{l+1} (the last one IS the result),
+ *                                  dh: the forward parks u = sum_e s_e v2_e U_e^T + b
+ * ld_w % 4 == 0 with zero padding, w_out NULL, n_layers = 3 * cross layers <= DCTR_MLP_MAX_LAYERS.
+ * A workgroup carries 16 samples through all layers (x_0, x_l and the rank-space tiles in LDS; fp32 MFMA 16x16x4).
+ * The backward takes gY = d loss / d x_L and writes gx = d loss / d x_0 and, per dense layer, gW / gbias in the packed
+ * form (the caller unpacks: gV, gG (summed over the cross layers), the diagonal blocks gC, gU, gb).
+ * dctr_crossnet_mix_supported: W <= 512, E*R + E <= 512, E <= 8 (LDS).                                              */
+int dctr_crossnet_mix_supported(int32_t W, int32_t n_cross_layers, int32_t E, int32_t R);
+int dctr_crossnet_mix_fwd(const struct dctr_mlp* m, int32_t E, int32_t R, const float* x, int64_t ld_x, int32_t B,
+                          dctr_stream_t stream);
+size_t dctr_crossnet_mix_bwd_workspace_floats(const struct dctr_mlp* m, int32_t B);
+int dctr_crossnet_mix_bwd(const struct dctr_mlp* m, int32_t E, int32_t R, const float* x, int64_t ld_x, int32_t B,
+                          const float* gY, int64_t ld_g, float* gx, int64_t ld_gx, float* workspace,
+                          dctr_stream_t stream);
+
 /* ---- DNN tower + dnn_linear on fp32 MFMA (csrc/mlp.hip) ---------------------------------------------------
  * DNN.forward (layers/core.py:120-134) with relu (or linear) activations, no BatchNorm, dropout inactive:
  *     h_0 = x ;  h_{l+1} = act(h_l W_l^T + bias_l)            W_l = dnn.linears.<l>.weight [N_l, K_l]
@@ -430,7 +453,7 @@ int dctr_crossnet_mat_bwd(const struct dctr_mlp* m, const float* x, int64_t ld_x
  * Replaces autograd's mm / addmm / threshold_backward / sum chains under basemodel.py:261.  Everything is
  * summed in a fixed order (no atomics): results are bit-reproducible.
  *   workspace  dctr_mlp_bwd_workspace_floats(m, B) floats (split-batch partials of the weight gradients)   */
-#define DCTR_MLP_MAX_LAYERS 8
+#define DCTR_MLP_MAX_LAYERS 12
 typedef struct dctr_mlp_layer {
   const float* W;
   const float* bias; /* [N] nullable                   */

@@ -324,6 +324,77 @@ class OpsMixin(object):
             _v(e.gbias, W).copy_(gs[1 + len(layers) + l])
         return 0
 
+    # ---- CrossNetMix on its packed weights (include/dctr.h): three dense layers per cross layer ------------------------
+    def dctr_crossnet_mix_supported(self, W, n_cross, E, R):
+        return 1 if (0 < W <= 512 and 0 < n_cross <= 4 and 0 < E <= 8 and E * R + E <= 512) else 0
+
+    @staticmethod
+    def _mix_chain(x0, packed, E, R):
+        """packed: [(W1 [ER+E, W], W2 [ER, ER], W3 [W, ER], b [W])] per cross layer -> (x_L, per-layer saved tensors)"""
+        ER = E * R
+        xl, saved = x0, []
+        for W1, W2, W3, b in packed:
+            z = xl @ W1.t()
+            v1, s = torch.tanh(z[:, :ER]), torch.softmax(z[:, ER:], dim=1)
+            t = torch.tanh(v1 @ W2.t())
+            ts = t * s.repeat_interleave(R, dim=1)
+            u = ts @ W3.t() + b
+            xl = x0 * u + xl
+            saved.append((torch.cat([v1, s], 1), t, ts, u, xl))
+        return xl, saved
+
+    def dctr_crossnet_mix_fwd(self, mref, E, R, x, ld_x, B, stream):
+        self.calls.append("crossnet_mix_fwd")
+        m = mref._obj
+        layers = [m.layer[l] for l in range(m.n_layers)]
+        W, ER = layers[0].K, E * R
+        packed = []
+        for lc in range(m.n_layers // 3):
+            e1, e2, e3 = layers[3 * lc:3 * lc + 3]
+            packed.append((_t(e1.W, ER + E, W, e1.ld_w).double(), _t(e2.W, ER, ER, e2.ld_w).double(),
+                           _t(e3.W, W, ER, e3.ld_w).double(), _v(e3.bias, W).double()))
+        _, saved = self._mix_chain(_t(x, B, W, ld_x).double(), packed, E, R)
+        for lc, (h1, t, ts, u, xn) in enumerate(saved):
+            e1, e2, e3 = layers[3 * lc:3 * lc + 3]
+            _t(e1.h, B, ER + E, e1.ld_h).copy_(h1)
+            _t(e2.dh, B, ER, e2.ld_h).copy_(t)
+            _t(e2.h, B, ER, e2.ld_h).copy_(ts)
+            _t(e3.dh, B, W, e3.ld_h).copy_(u)
+            _t(e3.h, B, W, e3.ld_h).copy_(xn)
+        return 0
+
+    def dctr_crossnet_mix_bwd_workspace_floats(self, mref, B):
+        return 16
+
+    @_with_grad
+    def dctr_crossnet_mix_bwd(self, mref, E, R, x, ld_x, B, gY, ld_g, gx, ld_gx, ws, stream):
+        self.calls.append("crossnet_mix_bwd")
+        m = mref._obj
+        layers = [m.layer[l] for l in range(m.n_layers)]
+        W, ER = layers[0].K, E * R
+        x0 = _t(x, B, W, ld_x).double().clone().requires_grad_(True)
+        packed, leaves = [], []
+        for lc in range(m.n_layers // 3):
+            e1, e2, e3 = layers[3 * lc:3 * lc + 3]
+            ws_ = [_t(e1.W, ER + E, W, e1.ld_w).double().clone().requires_grad_(True),
+                   _t(e2.W, ER, ER, e2.ld_w).double().clone().requires_grad_(True),
+                   _t(e3.W, W, ER, e3.ld_w).double().clone().requires_grad_(True),
+                   _v(e3.bias, W).double().clone().requires_grad_(True)]
+            packed.append(tuple(ws_))
+            leaves += ws_
+        out, _ = self._mix_chain(x0, packed, E, R)
+        gs = _grads(out, [x0] + leaves, _t(gY, B, W, ld_g).double())
+        _t(gx, B, W, ld_gx).copy_(gs[0])
+        for lc in range(m.n_layers // 3):
+            e1, e2, e3 = layers[3 * lc:3 * lc + 3]
+            g1, g2, g3, gb = gs[1 + 4 * lc:5 + 4 * lc]
+            for e, gw, rows, cols in ((e1, g1, ER + E, W), (e2, g2, ER, ER), (e3, g3, W, ER)):
+                full = _t(e.gW, rows, e.ld_w, e.ld_w)
+                full.zero_()
+                full[:, :cols].copy_(gw)
+            _v(e3.gbias, W).copy_(gb)
+        return 0
+
     # ---- AFMLayer -----------------------------------------------------------------------------------------------------
     @staticmethod
     def _afm(E, W, bias, h, p):

@@ -276,3 +276,56 @@ def test_interacting_layer_matches_torch(B, F, D, H, res, scaling):
         scale = max(1.0, float(r.abs().max()))
         err = float((a.double() - r).abs().max())
         assert err <= 2e-5 * scale, "%s: max|d|=%.3e (scale %.3g)" % (name, err, scale)
+
+
+@pytest.mark.parametrize("B,W,L,E,R", [(3, 5, 1, 2, 3), (33, 40, 3, 3, 5), (48, 69, 2, 4, 32), (100, 429, 2, 4, 32),
+                                       (1000, 429, 2, 4, 32), (64, 300, 4, 8, 16)])
+def test_crossnet_mix(B, W, L, E, R):
+    """CrossNetMix (interaction.py:499-534) on the kernels (dctr_crossnet_mix_*) against the reference's formulation in
+    fp64: output and every gradient (x, U, V, C, the shared gating weights, bias)."""
+    from deepctr_torch.layers import CrossNetMix
+    torch.manual_seed(W + R)
+    layer = CrossNetMix(W, low_rank=R, num_experts=E, layer_num=L, device=DEV)
+    with torch.no_grad():
+        layer.bias.normal_(0, 0.1)
+        for gt in layer.gating:
+            gt.weight.normal_(0, 0.3)
+    X = (torch.randn(B, W, device=DEV) * 0.5).requires_grad_(True)
+    Rm = torch.randn(B, W, device=DEV)
+    Y = layer(X)
+    node = Y.grad_fn
+    while type(node).__name__ != "CrossNetMixFunctionBackward":
+        assert node.next_functions, "CrossNetMix did not go through dctr_crossnet_mix_fwd"
+        node = node.next_functions[0][0]
+    (Y * Rm).sum().backward()
+    # the reference's formulation (per-expert loop), fp64
+    X2 = X.detach().double().requires_grad_(True)
+    U = layer.U_list.detach().double().requires_grad_(True)
+    V = layer.V_list.detach().double().requires_grad_(True)
+    C = layer.C_list.detach().double().requires_grad_(True)
+    Gs = [gt.weight.detach().double().requires_grad_(True) for gt in layer.gating]
+    Bs = layer.bias.detach().double().requires_grad_(True)
+    x_0 = X2.unsqueeze(2)
+    x_l = x_0
+    for i in range(L):
+        outs, gates = [], []
+        for e in range(E):
+            gates.append(x_l.squeeze(2) @ Gs[e].t())
+            v_x = torch.tanh(torch.matmul(V[i][e].t(), x_l))
+            v_x = torch.tanh(torch.matmul(C[i][e], v_x))
+            uv_x = torch.matmul(U[i][e], v_x)
+            outs.append((x_0 * (uv_x + Bs[i])).squeeze(2))
+        outs = torch.stack(outs, 2)
+        gate = torch.stack(gates, 1)
+        moe = torch.matmul(outs, gate.softmax(1))
+        x_l = moe + x_l
+    ref = x_l.squeeze(2)
+    (ref * Rm.double()).sum().backward()
+    _close(Y.detach(), ref.detach(), "Y", tol=2e-5)
+    _close(X.grad, X2.grad, "gX", tol=5e-5)
+    _close(layer.U_list.grad, U.grad, "gU", tol=5e-5)
+    _close(layer.V_list.grad, V.grad, "gV", tol=5e-5)
+    _close(layer.C_list.grad, C.grad, "gC", tol=5e-5)
+    _close(layer.bias.grad, Bs.grad, "gb", tol=5e-5)
+    for e in range(E):
+        _close(layer.gating[e].weight.grad, Gs[e].grad, "gG%d" % e, tol=5e-5)

@@ -27,6 +27,8 @@ spec = {
                                  l2_reg_linear=0, l2_reg_embedding=0, device=dev),
     "FiBiNET": lambda: M.FiBiNET(cols, cols, dnn_hidden_units=(128, 128), l2_reg_linear=0, l2_reg_embedding=0, device=dev),
     "DCN": lambda: M.DCN(cols, cols, dnn_hidden_units=(256, 128), l2_reg_linear=0, l2_reg_embedding=0, device=dev),
+    "DCN_matrix": lambda: M.DCN(cols, cols, cross_parameterization="matrix", dnn_hidden_units=(256, 128), l2_reg_linear=0,
+                                l2_reg_embedding=0, l2_reg_cross=0, device=dev),
     "PNN": lambda: M.PNN(cols, dnn_hidden_units=(256, 128), l2_reg_embedding=0, device=dev),
     "NFM": lambda: M.NFM(cols, cols, dnn_hidden_units=(256, 128), l2_reg_linear=0, l2_reg_embedding=0, device=dev),
     "WDL": lambda: M.WDL(cols, cols, dnn_hidden_units=(256, 128), l2_reg_linear=0, l2_reg_embedding=0, device=dev),
@@ -38,7 +40,10 @@ spec = {
                          device=dev),
 }
 res = {}
+only = set(sys.argv[1].split(",")) if len(sys.argv) > 1 else None
 for name, make in spec.items():
+    if only is not None and name not in only:
+        continue
     try:
         m = make()
         m.compile("adagrad", "binary_crossentropy", metrics=[])
