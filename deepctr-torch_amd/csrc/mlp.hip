@@ -696,18 +696,20 @@ __global__ __launch_bounds__(kT) void k_cross_mix_fwd(MlpArgs A, int E, int R) {
     const LayerDev& L3 = A.L[3 * lc + 2];
     // ---- project to the experts' rank spaces (+ the gating scores as E more output columns)
     mix_layer(L1, xl, rsw, Wp, wv, g, c, [&](int row, int n, float v) {
-      if (n < ER) v = tanhf(v);
-      if (n >= N1) v = 0.f;
+      // (the scores go to their own array: the next layer reads v1 over round16(E*R) columns and whatever sits
+      // beyond E*R must be zero -- its weight loads are pulled back inside the row there)
+      if (n >= ER && n < N1) sc[row][n - ER] = v;
+      v = (n < ER) ? tanhf(v) : 0.f;
       v1[row * rsv + n] = v;
       if (n < ER && b0 + row < A.B) stg_f32(L1.h + static_cast<int64_t>(b0 + row) * L1.ldh + n, v);
     });
     __syncthreads();
     if (tid < kTM) {                                     // softmax over the E scores of a sample (torch.softmax, dim=1)
       float m = -INFINITY;
-      for (int i = 0; i < E; ++i) m = fmaxf(m, v1[tid * rsv + ER + i]);
+      for (int i = 0; i < E; ++i) m = fmaxf(m, sc[tid][i]);
       float ex[8], sum = 0.f;
       for (int i = 0; i < E; ++i) {
-        ex[i] = expf(v1[tid * rsv + ER + i] - m);
+        ex[i] = expf(sc[tid][i] - m);
         sum += ex[i];
       }
       for (int i = 0; i < E; ++i) {

@@ -278,7 +278,7 @@ def test_interacting_layer_matches_torch(B, F, D, H, res, scaling):
         assert err <= 2e-5 * scale, "%s: max|d|=%.3e (scale %.3g)" % (name, err, scale)
 
 
-@pytest.mark.parametrize("B,W,L,E,R", [(3, 5, 1, 2, 3), (33, 40, 3, 3, 5), (48, 69, 2, 4, 32), (100, 429, 2, 4, 32),
+@pytest.mark.parametrize("B,W,L,E,R", [(3, 5, 1, 2, 3), (33, 40, 3, 3, 5), (48, 69, 2, 3, 8), (48, 69, 2, 4, 32), (100, 429, 2, 4, 32),
                                        (1000, 429, 2, 4, 32), (64, 300, 4, 8, 16)])
 def test_crossnet_mix(B, W, L, E, R):
     """CrossNetMix (interaction.py:499-534) on the kernels (dctr_crossnet_mix_*) against the reference's formulation in
