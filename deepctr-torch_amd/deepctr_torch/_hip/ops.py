@@ -490,6 +490,65 @@ class CINLayerFunction(torch.autograd.Function):
         return gH, gX0, gW, gb, None
 
 
+class CINLayerPooledFunction(torch.autograd.Function):
+    """One CIN layer as xDeepFM consumes it (interaction.py:226-246): the rows of ``A`` that go on as the next layer's
+    hidden state (``n_hidden`` of them; with split_half the first half) come back as a view, the "direct connect"
+    rows come back already summed over the embedding axis -- ``[B, n_direct]`` instead of ``[B, n_direct, D]``.  The
+    reference's split / cat / sum(-1) chain and its autograd (expand, slice, cat, contiguous: ~14 launches per layer)
+    become one reduction forward and one or two copies backward around the same two kernels."""
+
+    @staticmethod
+    def forward(ctx, H, X0, W2d, bias, relu, n_hidden, split):
+        A = cin_layer_forward(H, X0, W2d, bias, relu)
+        O = A.shape[1]
+        ctx.relu, ctx.has_bias, ctx.n_hidden, ctx.split = bool(relu), bias is not None, int(n_hidden), bool(split)
+        ctx.save_for_backward(H, X0, W2d, A if relu else None)
+        direct = A[:, n_hidden:] if split else A
+        pooled = direct.sum(-1)
+        hidden = A[:, :n_hidden] if n_hidden > 0 else A.new_zeros((A.shape[0], 0, A.shape[2]))
+        ctx.O = O
+        return hidden, pooled
+
+    @staticmethod
+    def backward(ctx, g_hidden, g_pooled):
+        lib = L.lib()
+        H, X0, W2d, A = ctx.saved_tensors
+        H, ldh = _rows3(H, "CIN hidden input")
+        X0, ldx = _rows3(X0, "CIN field input")
+        B, h, D = H.shape
+        M, O = X0.shape[1], W2d.shape[0]
+        dev = H.device
+        nh = ctx.n_hidden
+        if ctx.split:
+            gA = torch.empty((B, O, D), dtype=torch.float32, device=dev)
+            if nh > 0:
+                if g_hidden is not None:
+                    gA[:, :nh].copy_(g_hidden)
+                else:
+                    gA[:, :nh].zero_()
+            if g_pooled is not None:
+                gA[:, nh:].copy_(g_pooled.unsqueeze(2).expand(B, O - nh, D))
+            else:
+                gA[:, nh:].zero_()
+        else:           # every row is both hidden state and direct connect
+            if g_hidden is not None and g_pooled is not None:
+                gA = g_hidden + g_pooled.unsqueeze(2)
+            elif g_pooled is not None:
+                gA = g_pooled.unsqueeze(2).expand(B, O, D).contiguous()
+            else:
+                gA = g_hidden.contiguous()
+        W2d = W2d.contiguous()
+        gH = torch.empty((B, h, D), dtype=torch.float32, device=dev)
+        gX0 = torch.empty((B, M, D), dtype=torch.float32, device=dev)
+        gW = torch.empty((O, h * M), dtype=torch.float32, device=dev)
+        gb = torch.empty((O,), dtype=torch.float32, device=dev) if ctx.has_bias else None
+        ws = torch.empty((max(1, lib.dctr_cin_bwd_workspace_floats(B, h, M, D, O)),), dtype=torch.float32, device=dev)
+        L.check(lib.dctr_cin_layer_bwd(_ptr(gA), _ptr(A), O * D, int(ctx.relu), _ptr(H), ldh, _ptr(X0), ldx, _ptr(W2d),
+                                       B, h, M, D, O, _ptr(gH), h * D, _ptr(gX0), M * D, 0, _ptr(gW), _ptr(gb),
+                                       _ptr(ws), L.stream_handle(dev)), "dctr_cin_layer_bwd")
+        return gH, gX0, gW, gb, None, None, None
+
+
 # ---- SENET / Bilinear / InnerProduct (csrc/pairwise.hip) -------------------------------------------------
 class SENETFunction(torch.autograd.Function):
     """V = E * relu(W2 relu(W1 mean_d(E)))  (interaction.py:93-101)."""

@@ -233,6 +233,18 @@ class CIN(nn.Module):
         x0 = inputs
         hidden = x0
         fused_relu = isinstance(self.activation, nn.ReLU)
+        if x0.shape[1] <= 32 and (fused_relu or self.activation is None):
+            # the common case on the kernels' own terms: every layer hands back its hidden rows as a view and its
+            # direct-connect rows already summed over the embedding axis (no split / cat / sum(-1) chain)
+            pooled = []
+            for i, size in enumerate(self.layer_size):
+                conv = self.conv1ds[i]
+                last = i == len(self.layer_size) - 1
+                n_hidden = (0 if last else size // 2) if self.split_half else (0 if last else size)
+                hidden, p = _ops.CINLayerPooledFunction.apply(hidden, x0, conv.weight.squeeze(-1), conv.bias, fused_relu,
+                                                              n_hidden, self.split_half or last)
+                pooled.append(p)
+            return torch.cat(pooled, dim=1)
         final_result = []
         for i, size in enumerate(self.layer_size):
             conv = self.conv1ds[i]
@@ -325,6 +337,19 @@ class BilinearInteraction(nn.Module):
         if self._meta is None or self._meta[0] != n_fields:
             self._meta = (n_fields, _ops.BilinearMeta(n_fields, self.bilinear_type))
         return self._meta[1]
+
+    def stacked_weights(self):
+        """(parameters, their shared ``[n_w, D, D]`` slab) once the kernels have re-seated the per-pair ``nn.Linear``
+        weights as slices of one slab (first forward), else None.  BaseModel steps such a group with ONE optimizer
+        launch instead of handing hundreds of tiny tensors to ``torch.optim``'s foreach kernels."""
+        if self._meta is None or self.bilinear_type == "all":
+            return None
+        slab = self._meta[1]._slab
+        ws = self._weights()
+        if slab is None or slab.shape[0] != len(ws) or ws[0].data_ptr() != slab.data_ptr() or \
+                ws[-1].data_ptr() != slab[-1].data_ptr():
+            return None
+        return ws, slab
 
     @staticmethod
     def _kernel_fits(F, D):

@@ -757,8 +757,64 @@ class BaseModel(nn.Module):
             loss = self.loss_func(y_pred, yb.squeeze(), reduction='sum')
         total_loss = loss + self.get_regularization_loss() + self.aux_loss
         total_loss.backward()
+        self._step_stacked_groups()
         self.optim.step()
         return loss.detach(), total_loss.detach(), y_pred.detach()
+
+    def _step_stacked_groups(self):
+        """Layers that keep many small parameters as slices of one slab (FiBiNET's 2 x 325 bilinear ``nn.Linear``
+        weights, whose gradients the kernels write as one ``[n_w, D, D]`` tensor as well) are stepped with ONE
+        ``dctr_dense_opt`` launch per group here -- ``torch.optim``'s foreach kernels over 655 tensors were 30 launches,
+        161 us per FiBiNET step -- and then hidden from ``optim.step()`` (gradient None: torch skips them).  Only for a
+        plain SGD / Adagrad over the group (the same condition as the fused dense step); the optimizer's ``sum`` state
+        of the group is re-seated once as slices of a state slab, so ``optimizer.state_dict()`` keeps working."""
+        if os.environ.get("DCTR_STACKED_STEP", "1") == "0":
+            return
+        groups = self.__dict__.get("_stacked_cache")
+        if groups is None or groups[0] is not self.optim:
+            found = []
+            for mod in self.modules():
+                fn = getattr(mod, "stacked_weights", None)
+                if fn is not None:
+                    found.append(mod)
+            groups = self._stacked_cache = (self.optim, found, {})
+        _, mods, states = groups
+        if not mods:
+            return
+        import ctypes
+        from .._hip import lib as L
+        for mod in mods:
+            sw = mod.stacked_weights()
+            if sw is None:
+                continue
+            ws, slab = sw
+            g0 = ws[0].grad
+            if g0 is None or not slab.is_cuda:
+                continue
+            mode = self._dense_update_mode(ws)
+            if mode is None or mode[0] not in ("sgd", "adagrad"):
+                continue
+            n, step = slab.numel(), slab[0].numel() * 4
+            gl = ws[-1].grad
+            if gl is None or g0.dtype != torch.float32 or not g0.is_contiguous() or \
+                    gl.data_ptr() != g0.data_ptr() + (len(ws) - 1) * step:
+                continue          # the gradients are not the kernels' single [n_w, D, D] tensor: leave it to torch
+            st = None
+            if mode[0] == "adagrad":
+                st = states.get(id(mod))
+                if st is None or st.shape != slab.shape or st.device != slab.device or \
+                        self.optim.state[ws[0]]["sum"].data_ptr() != st.data_ptr():
+                    st = torch.stack([self.optim.state[w]["sum"] for w in ws]).contiguous()
+                    for i, w in enumerate(ws):
+                        self.optim.state[w]["sum"] = st[i]
+                    states[id(mod)] = st
+            L.check(L.lib().dctr_dense_opt(ctypes.c_void_p(slab.data_ptr()), ctypes.c_void_p(g0.data_ptr()),
+                                           ctypes.c_void_p(st.data_ptr()) if st is not None else None, n,
+                                           L.UPD_ADAGRAD if mode[0] == "adagrad" else L.UPD_SGD, float(mode[1]),
+                                           float(mode[2]) if len(mode) > 2 else 0.0, L.stream_handle(slab.device)),
+                    "dctr_dense_opt(stacked group)")
+            for w in ws:
+                w.grad = None
 
     def _graph_safe_step(self):
         """True when a hipGraph replay of ``_train_step`` does what an eager call does: no host-side value that changes
