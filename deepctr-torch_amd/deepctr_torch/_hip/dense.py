@@ -63,6 +63,7 @@ class DenseSlab(object):
         # and the embedding update runs on a side stream beside them -- see begin_inline_step()
         self.inline = None        # DenseStep while a fused train step with in-kernel optimizer is being assembled
         self.inline_done = False  # the kernels of this step applied it: step() has nothing left to do
+        self.wgrad_side = False   # topology of the in-kernel-optimizer step: True = weight gradients on the fork stream
         self.update_stream = None  # the side stream of this step's segment pre-pass (set by ops.EmbedFunction.forward):
         #                            the tower + head launch makes it wait for itself, the update then runs there
 
@@ -72,6 +73,7 @@ class DenseSlab(object):
         d["_fork"] = d["_pending"] = d["deferred"] = None       # streams / events / closures are per process
         d["overlap"] = False
         d["inline"] = d["update_stream"] = None
+        d["wgrad_side"] = False
         d["inline_done"] = False
         return d
 
@@ -107,8 +109,8 @@ class DenseSlab(object):
         self.inline = None
         self.update_stream = None
 
-    def fork_stream(self, device):
-        if not self.overlap or self.overlap == "defer" or torch.device(device).type != "cuda":
+    def fork_stream(self, device, force=False):
+        if not force and (not self.overlap or self.overlap == "defer" or torch.device(device).type != "cuda"):
             return None
         if self._pending is not None:
             self.join()
@@ -234,10 +236,10 @@ class DenseSlab(object):
         L.check(L.lib().dctr_lazy_step_inc(ptr(self.steps), stream), "dctr_lazy_step_inc")
 
     def step(self, kind, lr, eps=0.0, beta1=0.0, beta2=0.0):
-        self.join()
-        if self.inline_done:          # the gradient kernels of this step already applied it (begin_inline_step)
-            self.inline_done = False
+        if self.inline_done:          # the gradient kernels of this step already applied it (begin_inline_step);
+            self.inline_done = False  # whoever reads the parameters next joins the fork (join())
             return
+        self.join()
         if kind == "adam" or self.lam is not None:
             # Adam, or L2 terms on slab parameters: the regularised kernel of csrc/lazy.hip (one launch + a counter)
             if kind == "adagrad" and self.state is None:

@@ -87,8 +87,12 @@ class GraphedTrainStep(object):
             g = torch.cuda.CUDAGraph()
             outs = []
             with no_gc_during_capture(), torch.cuda.graph(g, pool=pool):
-                for j in range(self.S):
-                    outs.append(model._train_step(self.x[s][j], self.y[s][j]))
+                try:
+                    for j in range(self.S):
+                        model._defer_dense_join = j < self.S - 1      # (see BaseModel._train_step_fused)
+                        outs.append(model._train_step(self.x[s][j], self.y[s][j]))
+                finally:
+                    model._defer_dense_join = False
             if pool is None:
                 pool = g.pool()
             self.graphs.append(g)

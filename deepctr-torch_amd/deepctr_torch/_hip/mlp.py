@@ -288,13 +288,28 @@ class TowerHeadFunction(torch.autograd.Function):
         # dense optimizer needs THEM: with a fork stream on the sink they run beside the embedding update (which needs
         # only gx / g_logit) instead of in front of it.  The sink joins the fork before the dense optimizer step.
         inline = getattr(sink, "inline", None)
+        if inline is not None and hasattr(sink, "join"):
+            sink.join()       # a previous step's forked weight-gradient / optimizer kernels wrote the weights read below
         fork = sink.fork_stream(dev) if (hasattr(sink, "fork_stream") and inline is None) else None
         defer = fork is None and inline is None and getattr(sink, "overlap", False) == "defer" and x.device.type == "cuda"
         L.check(lib.dctr_mlp_train_step(ctypes.byref(desc), _ptr(x), x.stride(0), B, pp[0], pp[1], _ptr(bias), _ptr(y),
                                         _ptr(y_pred), _ptr(loss), _ptr(g_logit), _ptr(g_bias), _ptr(gx), gx.stride(0),
                                         _ptr(ws), 1 if (fork is not None or defer or inline is not None) else 0, None,
                                         L.stream_handle(dev)), "dctr_mlp_train_step")
-        if inline is not None:
+        if inline is not None and getattr(sink, "wgrad_side", False) and x.device.type == "cuda":
+            # Topology "tower_side": the weight gradients + their reduction (which also steps the parameters) go to
+            # the fork stream, the embedding update stays on this one; nothing joins them until the NEXT tower launch
+            # needs the stepped weights (DenseSlab.join() at the top of this function's next call, or at the end of the
+            # step when the caller may read parameters).  Main chain: gather, tower, update, next gather.
+            side = sink.fork_stream(dev, force=True)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            L.check(lib.dctr_mlp_train_wgrad(ctypes.byref(desc), _ptr(x), x.stride(0), B, _ptr(g_logit), _ptr(ws),
+                                             _ptr(loss), _ptr(g_bias), ctypes.byref(inline),
+                                             ctypes.c_void_p(side.cuda_stream)), "dctr_mlp_train_wgrad")
+            sink.forked(side, (x, hs, dhs, ws, g_logit, loss, ps, y, wo))
+            sink.inline_done = True
+            sink.update_stream = None            # (the update runs on this stream: ops.EmbedFunction.backward)
+        elif inline is not None:
             # In-kernel optimizer: the weight gradients and their reduction follow in line on THIS stream and step the
             # parameters as they finish; the embedding update (which needs only gx / g_logit) is what leaves for the
             # side stream (ops.EmbedFunction.backward), right behind the event recorded here.  The step's critical

@@ -714,6 +714,7 @@ class BaseModel(nn.Module):
         if plan.update[0] in ("sgd", "adagrad") and os.environ.get("DCTR_INLINE_OPT", "1") != "0" and \
                 plan.segments_enabled():
             slab.begin_inline_step(mode[0], mode[1], mode[2] if len(mode) > 2 else 0.0)
+            slab.wgrad_side = os.environ.get("DCTR_STEP_TOPOLOGY", "update_side") == "tower_side"
         reg = None
         try:
             loss, y_pred = self.fused_loss(xb, yb, slab)
@@ -730,7 +731,10 @@ class BaseModel(nn.Module):
             plan.dense_sink = None
             slab.overlap = False
             slab.end_inline_step()
-            slab.join()
+            if not (slab.wgrad_side and getattr(self, "_defer_dense_join", False)):
+                # (inside a multi-step hipGraph the captured steps but the last leave the forked weight-gradient /
+                # optimizer kernels unjoined: the next step's tower launch is the first reader of what they write)
+                slab.join()
         slab.step(*mode)
         total = loss.detach().reshape(1)
         if reg is not None:
