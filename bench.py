@@ -38,6 +38,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--vocab", type=int, default=1_000_000)
     ap.add_argument("--optimizer", default="adagrad", choices=["adagrad", "sgd"])
+    ap.add_argument("--ids", default="uniform", choices=["uniform", "zipf"],
+                    help="id distribution of the synthetic batches: uniform over the vocabulary (BASELINE's config: the worst "
+                         "case for caches) or Zipf(1.05) -- a secondary, clearly labelled run (SURVEY 8(d)): hot ids, long "
+                         "duplicate segments in the update")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replays")
     ap.add_argument("--steps-per-graph", type=int, default=0,
                     help="train steps captured per hipGraph (the ~15 us launch gap is paid once per graph); 0 = the "
@@ -66,7 +70,14 @@ def build_model(args, device):
 def synth(args, device, rank):
     gen = torch.Generator().manual_seed(rank)
     n = args.batch * 64
-    ids = torch.randint(0, args.vocab, (n, F_SPARSE), generator=gen)           # uniform: worst case for caches
+    if args.ids == "zipf":
+        # Zipf(alpha = 1.05) over the vocabulary by inverse-CDF sampling of the continuous approximation
+        a = 1.05
+        u = torch.rand((n, F_SPARSE), generator=gen, dtype=torch.float64)
+        vmax = float(args.vocab)
+        ids = (((vmax ** (1 - a) - 1) * u + 1) ** (1 / (1 - a))).floor().clamp_(1, vmax).long() - 1
+    else:
+        ids = torch.randint(0, args.vocab, (n, F_SPARSE), generator=gen)       # uniform: worst case for caches
     X = torch.cat([ids.float(), torch.rand(n, N_DENSE, generator=gen)], dim=1).to(device)
     y = torch.randint(0, 2, (n,), generator=gen).float().to(device)
     return X, y
@@ -439,7 +450,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DeepFM synthetic Criteo (26 sparse x %d vocab, 13 dense, emb_dim=16, batch=%d) "
-                                   "fwd+bwd+%s, l2=0, dnn=(256,128)" % (args.vocab, B, args.optimizer),
+                                   "fwd+bwd+%s, l2=0, dnn=(256,128)%s" % (args.vocab, B, args.optimizer,
+                                                                         "" if args.ids == "uniform" else ", ids ~ Zipf(1.05) [secondary run]"),
                        "global_batch": world * B, "parallelism": ("tables sharded x%d + dp%d tower" % (world, world)) if parallel is not None else "single",
                        "hip_graph": bool(graphed), "steps_per_graph": (min(args.steps_per_graph, args.steps) if graphed and parallel is None else None),
                        "eager_steps_in_timed_region": 0 if graphed else args.steps,

@@ -39,7 +39,8 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kCap = 512;     // sort keys held in LDS
 constexpr int kStack = 40;    // pending (id bits fixed, their value) splits of an overflowing partition
-constexpr int kBucket = 256;  // keys per (unit, partition) bucket of the optional pre-pass (<= kCap)
+constexpr int kBucket = 512;  // keys per (unit, partition) bucket of the pre-pass (<= kCap; 2 per thread of its sort)
+constexpr int kOverPer = 16;  // bucket counters a workgroup of k_embed_update_overflow checks
 
 struct UpdArgs {
   const dctr_field_t* deep;
@@ -173,6 +174,60 @@ __device__ __forceinline__ void wdense_column(const UpdArgs& A, int j) {
 }
 
 // One (unit, partition): scan (or take the bucket), sort, segment sums, one read-modify-write per touched row.
+// ---- where a tile's segments start, without a dependent LDS walk ---------------------------------------------------
+// Every wave publishes which of its groups end a segment (one ballot, before the tile's barrier); a summing group then
+// finds the first entry of its own segment from the flags strictly below it.  The walk over the segment becomes a
+// counted loop whose LDS reads do not depend on each other -- what a hot id (hundreds of entries of one row: Zipf
+// ids) needs; the order of the additions is unchanged.
+template <int LPR>
+__device__ __forceinline__ void publish_tails(unsigned long long* tails, bool tail, int tid) {
+  const unsigned long long m = __ballot(tail && (tid % LPR == 0));
+  if ((tid & 63) == 0) tails[tid >> 6] = m;
+}
+// The walk itself: entries grp, grp-1, ..., j0 of the tile, added in exactly that order (the result must not depend on
+// which path summed it).  Branch-free and in small blocks whose LDS reads are issued together: one LDS latency per
+// block instead of three per entry -- a hot id's segment fills whole tiles, and one group walks each of them alone.
+// (Lanes past the row's width / other than lane 0 of the group sum values nobody reads.)
+template <int VEC>
+__device__ __forceinline__ void seg_walk(const float* gbuf, const float* gfbuf, const float* gwbuf, int RW, int e0,
+                                         int grp, int j0, Strip<VEC>& acc, float& accf, float& accw) {
+  constexpr int NB = VEC >= 8 ? 2 : 4;   // (register budget of the 6-workgroups-per-CU kernel)
+  int jj = grp;
+  for (; jj - (NB - 1) >= j0; jj -= NB) {
+    Strip<VEC> t[NB];
+    float tf[NB], tw[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) t[q].v[k] = gbuf[(jj - q) * RW + e0 + k];
+      tf[q] = gfbuf[jj - q];
+      tw[q] = gwbuf[jj - q];
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc.v[k] += t[q].v[k];
+      accf += tf[q];
+      accw += tw[q];
+    }
+  }
+  for (; jj >= j0; --jj) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc.v[k] += gbuf[jj * RW + e0 + k];
+    accf += gfbuf[jj];
+    accw += gwbuf[jj];
+  }
+}
+
+template <int LPR>
+__device__ __forceinline__ int seg_first(const unsigned long long* tails, int tid) {
+  int wv = tid >> 6;
+  const int lane0 = (tid & 63) / LPR * LPR;
+  unsigned long long m = tails[wv] & ((1ull << lane0) - 1ull);
+  while (m == 0ull && wv > 0) m = tails[--wv];
+  return m ? wv * (64 / LPR) + (63 - __clzll(m)) / LPR + 1 : 0;
+}
+
 template <int VEC, int LPR, int OPT>
 __device__ __forceinline__ void upd_partition(const UpdArgs& A, const int u, const int p) {
   constexpr int G = kThreads / LPR;   // lane groups per workgroup = entries per tile (a power of two)
@@ -185,6 +240,7 @@ __device__ __forceinline__ void upd_partition(const UpdArgs& A, const int u, con
   __shared__ float carry[RW + 4];     // open segment of the tiled path: deep strip | g_fm sum | wide sum
   __shared__ int stack[kStack][2];
   __shared__ int n_sh, mn_sh, mx_sh, carry_id, sp_sh, wcnt[kThreads / 64];
+  __shared__ unsigned long long tails[kThreads / 64];  // per wave: groups of the tile that end a segment
   const int tid = threadIdx.x;
   const int P = A.P;
   DCTR_TRACE(0);
@@ -467,36 +523,27 @@ __device__ __forceinline__ void upd_partition(const UpdArgs& A, const int u, con
       // ---- sort by (id, b), then tiles of G sorted entries with a carry ---------------------------------------------
       if (sorted_in) {
         // nothing to do
-      } else if (n <= kThreads) {
-        // rank sort: keys are unique, so rank = #smaller is a permutation; 2 barriers
-        const uint32_t mine = tid < n ? keys[tid] : 0u;
-        int rank = 0;
-#pragma unroll 8
-        for (int q = 0; q < n; ++q) rank += (keys[q] < mine) ? 1 : 0;
-        __syncthreads();
-        if (tid < n) keys[rank] = mine;
-        __syncthreads();
       } else {
-        int m = 2;
-        while (m < n) m <<= 1;
-        for (int i = n + tid; i < m; i += kThreads) keys[i] = 0xFFFFFFFFu;
-        __syncthreads();
-        for (int k = 2; k <= m; k <<= 1) {
-          for (int st = k >> 1; st > 0; st >>= 1) {
-            for (int i = tid; i < m; i += kThreads) {
-              const int ixs = i ^ st;
-              if (ixs > i) {
-                const uint32_t a = keys[i], b2 = keys[ixs];
-                const bool up = (i & k) == 0;
-                if ((a > b2) == up) {
-                  keys[i] = b2;
-                  keys[ixs] = a;
-                }
-              }
-            }
-            __syncthreads();
-          }
+        // rank sort: keys are unique, so rank = #smaller is a permutation; 2 barriers (kCap / kThreads keys a thread)
+        constexpr int kSl = kCap / kThreads;
+        uint32_t mine[kSl];
+        int rank[kSl];
+#pragma unroll
+        for (int q = 0; q < kSl; ++q) {
+          mine[q] = tid + q * kThreads < n ? keys[tid + q * kThreads] : 0u;
+          rank[q] = 0;
         }
+#pragma unroll 4
+        for (int i = 0; i < n; ++i) {
+          const uint32_t kv = keys[i];
+#pragma unroll
+          for (int q = 0; q < kSl; ++q) rank[q] += (kv < mine[q]) ? 1 : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kSl; ++q)
+          if (tid + q * kThreads < n) keys[rank[q]] = mine[q];
+        __syncthreads();
       }
       for (int t0 = 0; t0 < n; t0 += G) {
         const int i = t0 + grp;
@@ -523,22 +570,15 @@ __device__ __forceinline__ void upd_partition(const UpdArgs& A, const int u, con
           gfbuf[grp] = gf;
           gwbuf[grp] = gw;
         }
+        publish_tails<LPR>(tails, seg_end, tid);
         __syncthreads();
         const bool summer = seg_end || last_of_tile;
         Strip<VEC> acc = strip_zero<VEC>();
         float accf = 0.f, accw = 0.f;
         if (summer) {
-          int jj = grp;  // walk back: fixed order => deterministic
-          while (jj >= 0 && static_cast<int>(keys[t0 + jj] >> A.bbits) == idq) {
-            if (lane_on) {
-#pragma unroll
-              for (int k = 0; k < VEC; ++k) acc.v[k] += gbuf[jj * RW + e0 + k];
-            }
-            accf += gfbuf[jj];
-            if (gl == 0) accw += gwbuf[jj];
-            --jj;
-          }
-          if (jj < 0 && carry_id == idq) {  // the segment began in an earlier tile
+          const int j0 = seg_first<LPR>(tails, tid);
+          seg_walk<VEC>(gbuf, gfbuf, gwbuf, RW, e0, grp, j0, acc, accf, accw);  // fixed order => deterministic
+          if (j0 == 0 && carry_id == idq) {  // the segment began in an earlier tile
             if (lane_on) {
 #pragma unroll
               for (int k = 0; k < VEC; ++k) acc.v[k] += carry[e0 + k];
@@ -712,8 +752,9 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
 }
 
 // Behind k_embed_apply_sorted: the partitions the pre-pass could not sort (more than kBucket entries: hot ids) still
-// carry their count.  A workgroup checks kThreads consecutive counters with one coalesced read and runs the general
-// path for the (rare) ones left; the last n_wdense workgroups do the dense half of Linear.
+// carry their count.  A workgroup checks kOverPer consecutive counters and runs the general path for the (rare) ones
+// left -- few counters per workgroup, so that the overflowing partitions of a skewed batch (one per unit under Zipf
+// ids) are worked on in parallel; the last n_wdense workgroups do the dense half of Linear.
 template <int VEC, int LPR, int OPT>
 __global__ __launch_bounds__(kThreads, 5) void k_embed_update_overflow(UpdArgs A) {
   const int n_scan = static_cast<int>(gridDim.x) - (A.g_wdense ? A.n_wdense : 0);
@@ -721,13 +762,14 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_update_overflow(UpdArgs A
     wdense_column(A, static_cast<int>(blockIdx.x) - n_scan);
     return;
   }
-  __shared__ int over[kThreads], n_over;
+  __shared__ int over[kOverPer], n_over;
   const int tid = threadIdx.x;
   const int64_t nb = static_cast<int64_t>(A.n_units) * A.P;
-  const int64_t bk = static_cast<int64_t>(blockIdx.x) * kThreads + tid;
+  const int64_t bk = static_cast<int64_t>(blockIdx.x) * kOverPer + tid;
   if (tid == 0) n_over = 0;
   __syncthreads();
-  if (bk < nb && *(const DCTR_GLOBAL int32_t*)(A.bcnt + bk) > kBucket) over[atomicAdd(&n_over, 1)] = static_cast<int>(bk);
+  if (tid < kOverPer && bk < nb && *(const DCTR_GLOBAL int32_t*)(A.bcnt + bk) > kBucket)
+    over[atomicAdd(&n_over, 1)] = static_cast<int>(bk);
   __syncthreads();
   const int n = n_over;
   if (n == 0) return;
@@ -751,7 +793,7 @@ template <int VEC, int LPR, int OPT>
 __global__ __launch_bounds__(kThreads, 6) void k_embed_apply_sorted(UpdArgs A) {
   constexpr int G = kThreads / LPR;   // entries per tile
   constexpr int RW = LPR * VEC;
-  __shared__ uint32_t sid[G];         // id / P of the tile's entries
+  __shared__ unsigned long long tails[kThreads / 64];  // per wave: groups of the tile that end a segment
   __shared__ __align__(16) float gbuf[G * RW];
   __shared__ float gfbuf[G], gwbuf[G];
   __shared__ float carry[RW + 4];
@@ -763,6 +805,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_embed_apply_sorted(UpdArgs A) {
   int32_t* cnt = A.bcnt + static_cast<int64_t>(u) * P + p;
   const uint32_t* src = A.bkeys + (static_cast<int64_t>(u) * P + p) * kBucket;
   const int grp = tid / LPR, gl = tid % LPR, e0 = gl * VEC;
+  DCTR_TRACE(0);
   // round trip 1: the count and the first tile's keys leave together (slots past the count hold stale keys of an
   // earlier step: inside the bucket's own kBucket slots, never used)
   const int n_raw = *(const DCTR_GLOBAL int32_t*)cnt;
@@ -785,17 +828,23 @@ __global__ __launch_bounds__(kThreads, 6) void k_embed_apply_sorted(UpdArgs A) {
 
   const int n = uni(n_raw);
   if (n <= 0 || n > kBucket) return;   // (uniform: every thread read the same counter)
+  DCTR_TRACE(1);
+#ifdef DCTR_DIAG
+  if (A.trace && tid == 0) A.trace[blockIdx.x * 8ull + 7] = static_cast<unsigned long long>(n);
+#endif
   __syncthreads();                     // every wave has read the counter ...
   if (tid == 0) {
     *(DCTR_GLOBAL int32_t*)cnt = 0;    // ... before it is handed back zeroed for the next pre-pass
     carry_id = -1;
   }
 
+  uint32_t key_n = 0u, knext_n = 0u;
   for (int t0 = 0; t0 < n; t0 += G) {
     const int i = t0 + grp;
-    if (t0 > 0) {
-      key = *(const DCTR_GLOBAL uint32_t*)(src + (i < kBucket ? i : kBucket - 1));
-      knext = *(const DCTR_GLOBAL uint32_t*)(src + (i + 1 < kBucket ? i + 1 : kBucket - 1));
+    if (t0 + G < n) {  // the next tile's keys leave ahead of this tile's strips: one round trip per tile, not two
+      const int i2 = i + G;
+      key_n = *(const DCTR_GLOBAL uint32_t*)(src + (i2 < kBucket ? i2 : kBucket - 1));
+      knext_n = *(const DCTR_GLOBAL uint32_t*)(src + (i2 + 1 < kBucket ? i2 + 1 : kBucket - 1));
     }
     const bool have = i < n;
     const int b = static_cast<int>(key & bmask);
@@ -839,26 +888,19 @@ __global__ __launch_bounds__(kThreads, 6) void k_embed_apply_sorted(UpdArgs A) {
       for (int k = 0; k < VEC; ++k) gbuf[grp * RW + e0 + k] = h.v[k];
     }
     if (gl == 0) {
-      sid[grp] = have ? static_cast<uint32_t>(idq) : 0xFFFFFFFFu;
       gfbuf[grp] = gf;
       gwbuf[grp] = gw;
     }
+    publish_tails<LPR>(tails, seg_end, tid);
     __syncthreads();
+    if (t0 == 0) DCTR_TRACE(2);
     const bool summer = seg_end || last_of_tile;
     Strip<VEC> acc = strip_zero<VEC>();
     float accf = 0.f, accw = 0.f;
     if (summer) {
-      int jj = grp;  // walk back: fixed order => deterministic (the order of the general kernel's tiled path)
-      while (jj >= 0 && sid[jj] == static_cast<uint32_t>(idq)) {
-        if (lane_on) {
-#pragma unroll
-          for (int k = 0; k < VEC; ++k) acc.v[k] += gbuf[jj * RW + e0 + k];
-        }
-        accf += gfbuf[jj];
-        if (gl == 0) accw += gwbuf[jj];
-        --jj;
-      }
-      if (jj < 0 && carry_id == idq) {  // the segment began in an earlier tile
+      const int j0 = seg_first<LPR>(tails, tid);
+      seg_walk<VEC>(gbuf, gfbuf, gwbuf, RW, e0, grp, j0, acc, accf, accw);  // (the general kernel's order)
+      if (j0 == 0 && carry_id == idq) {  // the segment began in an earlier tile
         if (lane_on) {
 #pragma unroll
           for (int k = 0; k < VEC; ++k) acc.v[k] += carry[e0 + k];
@@ -884,6 +926,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_embed_apply_sorted(UpdArgs A) {
         }
       }
     }
+    if (t0 == 0) DCTR_TRACE(3);
     if (t0 + G >= n) break;   // single tile (the common case): no carry to park
     __syncthreads();  // every read of gbuf / carry of this tile is done
     if (last_of_tile) {  // exactly one group: park an open segment's partial, or clear the carry
@@ -902,7 +945,10 @@ __global__ __launch_bounds__(kThreads, 6) void k_embed_apply_sorted(UpdArgs A) {
       }
     }
     __syncthreads();
+    key = key_n;
+    knext = knext_n;
   }
+  DCTR_TRACE(6);
 }
 
 // ---- optional pre-pass: bucket the (unit, sample) entries by partition ---------------------------------------------
@@ -931,7 +977,8 @@ __global__ __launch_bounds__(kThreads) void k_bucket(UpdArgs A) {
 // A partition with more than kBucket entries is left to the update kernel's own scan (the counter says so).
 template <bool FROM_BUCKETS>
 __global__ __launch_bounds__(kThreads) void k_embed_segments(UpdArgs A) {
-  static_assert(kBucket == kThreads, "one thread per bucket slot");
+  constexpr int kSl = kBucket / kThreads;   // bucket slots per thread
+  static_assert(kBucket % kThreads == 0, "whole slots per thread");
   __shared__ uint32_t keys[kBucket];
   __shared__ int n_sh;
   const int tid = threadIdx.x;
@@ -945,7 +992,9 @@ __global__ __launch_bounds__(kThreads) void k_embed_segments(UpdArgs A) {
   if (FROM_BUCKETS) {
     n = uni(*(const DCTR_GLOBAL int32_t*)cnt);
     if (n > kBucket || n <= 0) return;
-    if (tid < n) keys[tid] = *(const DCTR_GLOBAL uint32_t*)(dst + tid);
+#pragma unroll
+    for (int q = 0; q < kSl; ++q)
+      if (tid + q * kThreads < n) keys[tid + q * kThreads] = *(const DCTR_GLOBAL uint32_t*)(dst + tid + q * kThreads);
     __syncthreads();
   } else {
     const int32_t* un = A.units + 4 * u;
@@ -994,22 +1043,40 @@ __global__ __launch_bounds__(kThreads) void k_embed_segments(UpdArgs A) {
     if (tid == 0) *(DCTR_GLOBAL int32_t*)cnt = n;
     if (n > kBucket || n == 0) return;
     // phase 2: one id load per kept entry, all in flight together
-    uint32_t key = 0u;
-    if (tid < n) {
-      const int b = static_cast<int>(keys[tid]);
-      const int32_t id = clamp_id(ldg_i32(ids + b), vocab);
-      key = (div_p(static_cast<uint32_t>(id), A.pmagic, A.pshift) << A.bbits) | static_cast<uint32_t>(b);
+    uint32_t key[kSl];
+#pragma unroll
+    for (int q = 0; q < kSl; ++q) {
+      key[q] = 0u;
+      if (tid + q * kThreads < n) {
+        const int b = static_cast<int>(keys[tid + q * kThreads]);
+        const int32_t id = clamp_id(ldg_i32(ids + b), vocab);
+        key[q] = (div_p(static_cast<uint32_t>(id), A.pmagic, A.pshift) << A.bbits) | static_cast<uint32_t>(b);
+      }
     }
     __syncthreads();
-    if (tid < n) keys[tid] = key;
+#pragma unroll
+    for (int q = 0; q < kSl; ++q)
+      if (tid + q * kThreads < n) keys[tid + q * kThreads] = key[q];
     __syncthreads();
   }
-  // rank sort: keys are unique, so rank = #smaller is a permutation
-  const uint32_t mine = tid < n ? keys[tid] : 0u;
-  int rank = 0;
-#pragma unroll 8
-  for (int q = 0; q < n; ++q) rank += (keys[q] < mine) ? 1 : 0;
-  if (tid < n) *(DCTR_GLOBAL uint32_t*)(dst + rank) = mine;
+  // rank sort: keys are unique, so rank = #smaller is a permutation (n reads per key: 4 us at 512 keys -- the general
+  // kernel's bitonic sort of the same 512 keys is 45 barrier stages, ~45 us: what made Zipf-distributed ids slow)
+  uint32_t mine[kSl];
+  int rank[kSl];
+#pragma unroll
+  for (int q = 0; q < kSl; ++q) {
+    mine[q] = tid + q * kThreads < n ? keys[tid + q * kThreads] : 0u;
+    rank[q] = 0;
+  }
+#pragma unroll 4
+  for (int i = 0; i < n; ++i) {
+    const uint32_t kv = keys[i];
+#pragma unroll
+    for (int q = 0; q < kSl; ++q) rank[q] += (kv < mine[q]) ? 1 : 0;
+  }
+#pragma unroll
+  for (int q = 0; q < kSl; ++q)
+    if (tid + q * kThreads < n) *(DCTR_GLOBAL uint32_t*)(dst + rank[q]) = mine[q];
 }
 
 // ---- X -> ids_t (+ parts_t) (standalone; the forward kernel fuses the same thing) -------------------
@@ -1221,7 +1288,7 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
   // presorted: the lean kernel does every partition the pre-pass could sort; the general kernel behind it finds their
   // counters at zero (nothing to do) and takes the overflowing ones (and the dense half of Linear)
   const dim3 grid_sorted(static_cast<unsigned>(n_units) * static_cast<unsigned>(P));
-  const dim3 grid_over(static_cast<unsigned>((nbuckets + kThreads - 1) / kThreads) +
+  const dim3 grid_over(static_cast<unsigned>((nbuckets + kOverPer - 1) / kOverPer) +
                        (g_wdense ? static_cast<unsigned>(plan->n_wdense) : 0u));
 #define DCTR_UPD_LAUNCH(VEC_, LPR_)                                                              \
   do {                                                                                           \

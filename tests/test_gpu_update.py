@@ -29,6 +29,9 @@ def _batch(B, vocabs, n_dense, mode, seed):
         elif mode == "hot":          # one id takes ~90 % of the batch: long segments spanning many tiles
             ids = torch.where(torch.rand(B, generator=g) < 0.9, torch.full((B,), min(3, v - 1)),
                               torch.randint(0, v, (B,), generator=g))
+        elif mode == "zipf":         # Zipf(1.05) ranks: a few hot ids of a few hundred samples each, a long tail --
+            r = torch.arange(1, v + 1, dtype=torch.float64)   # partitions of 300-500 entries with multi-tile segments
+            ids = torch.multinomial(r.pow(-1.05), B, replacement=True, generator=g)
         else:                        # "same": every sample hits one row
             ids = torch.full((B,), v - 1)
         cols.append(ids.float())
@@ -67,6 +70,7 @@ CASES = [
     (4096, [100_000, 17, 1_000_000, 3], 16, 13, "uniform"),
     (4096, [100_000, 17], 16, 0, "same"),
     (5000, [1000, 50_000], 12, 1, "hot"),
+    (4096, [100_000, 1000, 40], 16, 1, "zipf"),
 ]
 
 
@@ -183,7 +187,8 @@ def test_wide_only_and_deep_only_units():
         assert float((p.grad - P[k].grad).abs().max()) <= 2e-5 * max(1.0, float(P[k].grad.abs().max())), k
 
 
-@pytest.mark.parametrize("idmode,B", [("uniform", 4096), ("hot", 4096), ("same", 777), ("hot", 20000)])
+@pytest.mark.parametrize("idmode,B", [("uniform", 4096), ("hot", 4096), ("same", 777), ("hot", 20000),
+                                          ("zipf", 4096), ("zipf", 16384)])
 def test_prepass_layouts_and_inkernel_scan_agree_bit_for_bit(monkeypatch, idmode, B):
     """The same two Adagrad steps three ways -- (a) segment pre-pass (dctr_embed_segments) + interleaved slabs, the
     default; (b) no pre-pass: every workgroup scans and sorts for itself; (c) the reference's contiguous tensors --

@@ -1,0 +1,93 @@
+#!/usr/bin/env python
+"""Hot ids and the embedding update: event-timed pre-pass + update of the DeepFM bench shape under uniform and
+Zipf(1.05) ids, and (diagnostics build: make -C deepctr-torch_amd/csrc diag) per-workgroup phase stamps of
+k_embed_apply_sorted, grouped by the number of tiles a workgroup walks -- what a hot partition costs per tile.
+    python tools/zipf_update_probe.py > gpurun_out/zipf_update_probe.json"""
+import ctypes
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "deepctr-torch_amd"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from deepctr_torch._hip import lib as L  # noqa: E402
+
+L.use_diag_library()
+import bench  # noqa: E402
+from deepctr_torch._hip.ops import _ptr  # noqa: E402
+
+B, DIM = 4096, 16
+dev = "cuda:0"
+
+
+def probe(ids_mode):
+    class A:
+        vocab, batch, optimizer, ids = 1_000_000, B, "adagrad", ids_mode
+    model = bench.build_model(A, dev)
+    X, _ = bench.synth(A, dev, 0)
+    res = {"event_timed_us": {n: round(v["avg_us"], 1) for n, v in
+                              bench.time_hot_kernels(model, X, B, 20, "adagrad", ring=8).items()}}
+    lib = L.lib()
+    plan = model.model_plan()
+    cplan = plan.bind(dev)
+    s = L.stream_handle(dev)
+    P = lib.dctr_embed_update_partitions(cplan, B)
+    nu = len(plan.units)
+    ws, ws_n = plan.update_workspace(B, dev, always=True)
+    out = torch.empty(B, plan.ld_out, device=dev)
+    ids_t = torch.empty(nu, B, dtype=torch.int32, device=dev)
+    parts_t = torch.empty(nu, B, dtype=torch.int16, device=dev)
+    fm_s = torch.empty(B, DIM, device=dev)
+    wide, fm = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    g_out = torch.randn(B, plan.ld_out, device=dev) * 1e-3
+    g_fm, g_wide = torch.randn(B, device=dev) * 1e-3, torch.randn(B, device=dev) * 1e-3
+    lr, eps = float(plan.update[1]), float(plan.update[2])
+    nwg = nu * P + 64
+    buf = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
+    rows = []
+    for j in range(4, 8):
+        Xb = X[j * B:(j + 1) * B]
+        L.check(lib.dctr_embed_fwd(cplan, _ptr(Xb), Xb.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), 1, _ptr(fm),
+                                   None, plan.units_ptr(), nu, _ptr(ids_t), _ptr(parts_t), _ptr(fm_s), DIM, s))
+        L.check(lib.dctr_embed_segments(cplan, plan.units_ptr(), nu, plan.max_vocab, _ptr(ids_t), _ptr(parts_t), B,
+                                        _ptr(ws), ws_n, s))
+        buf.zero_()
+        lib.dctr_dbg_update_trace(ctypes.c_void_p(buf.data_ptr()), -1)
+        L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), nu, plan.max_vocab, _ptr(ids_t), _ptr(parts_t), B,
+                                      _ptr(g_out), plan.ld_out, _ptr(out), plan.ld_out, _ptr(fm_s), DIM, _ptr(g_fm),
+                                      _ptr(g_wide), 1, L.UPD_ADAGRAD, lr, eps, None, 0, None, None, _ptr(ws), ws_n, 1,
+                                      s))
+        torch.cuda.synchronize()
+        lib.dctr_dbg_update_trace(None, -1)
+        rows.append(buf.view(nwg, 8).cpu().numpy().astype("int64")[:nu * P])
+    t = np.concatenate(rows[1:])          # (first traced launch: cold instruction cache)
+    tick = 0.01                            # wall_clock64: 100 MHz
+    work = t[t[:, 6] > 0]
+    G = 256 // 4                           # entries per tile at dim 16
+    tiles = (work[:, 7] + G - 1) // G
+    per_launch = []
+    for r in rows[1:]:
+        w = r[r[:, 6] > 0]
+        per_launch.append(float((w[:, 6].max() - r[r[:, 0] > 0][:, 0].min()) * tick))
+    res["P"] = int(P)
+    res["apply_sorted_first_start_to_last_end_us"] = [round(v, 1) for v in per_launch]
+    res["by_tiles"] = {}
+    for k in sorted(set(tiles.tolist())):
+        w = work[tiles == k]
+        res["by_tiles"][int(k)] = {
+            "workgroups": int(len(w)),
+            "entries_mean": float(w[:, 7].mean()),
+            "count_lands_us": float(((w[:, 1] - w[:, 0]) * tick).mean()),
+            "tile0_loads_land_us": float(((w[:, 2] - w[:, 1]) * tick).mean()),
+            "tile0_sum_and_apply_us": float(((w[:, 3] - w[:, 2]) * tick).mean()),
+            "other_tiles_us": float(((w[:, 6] - w[:, 3]) * tick).mean()),
+            "total_us": float(((w[:, 6] - w[:, 0]) * tick).mean()),
+        }
+    return res
+
+
+print(json.dumps({"B": B, "uniform": probe("uniform"), "zipf": probe("zipf")}, indent=1))
