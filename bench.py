@@ -471,10 +471,16 @@ def main():
             result["other_configs"] = {name: other_config(name, args, device, X, y) for name in OTHER}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(result))
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL writes "Librccl path : ..." through C stdio, which (piped)
+        # would otherwise be flushed at exit, behind Python's line
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -1075,6 +1075,11 @@ __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
   // garbage only reaches output rows / columns that are dropped or zeroed at the store); addresses are a uniform
   // base + a per-lane 32-bit offset + a scalar row offset: one v_add per load.  The loads of the next PD-1 groups
   // are in flight while the matrix pipe works on the current one.  A last partial group takes the masked path.
+  // (Measured, round 2 -- tools/micro/mfmabench.hip, tools/mlp_trace.py: the matrix pipe retires one 32x32x2 every
+  // 64 cycles at the 2.13 GHz the chip holds under MFMA load = 30 ns; this loop runs at ~40 ns per MFMA after 3.4 us of
+  // start-up latency.  A variant with adjacent-column 8-byte loads, a 7-deep ring and a prologue ordered so that the
+  // compiler's waits are exact -- it otherwise drains the ring once per round -- ran the loop no faster alone and the
+  // whole train step 2 % slower beside the embedding update: the loop is not latency-bound.)
   constexpr int U = 4, PD = 5;
   const int mac = va ? ma : 0, mbc = vb ? mb : 0, kac = vka ? ka : 0, kbc = vkb ? kb : 0;
   const DCTR_GLOBAL char* dbase = (const DCTR_GLOBAL char*)Ld.dh;

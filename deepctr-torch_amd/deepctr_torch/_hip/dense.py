@@ -64,6 +64,8 @@ class DenseSlab(object):
         self.inline = None        # DenseStep while a fused train step with in-kernel optimizer is being assembled
         self.inline_done = False  # the kernels of this step applied it: step() has nothing left to do
         self.wgrad_side = False   # topology of the in-kernel-optimizer step: True = weight gradients on the fork stream
+        self.gather_side = False  # ... True = gather AND update on the pre-pass's stream (ops.EmbedFunction.forward)
+        self.main_keep = None     # gather_side: tensors the main stream's weight-gradient kernels of the last step read
         self.update_stream = None  # the side stream of this step's segment pre-pass (set by ops.EmbedFunction.forward):
         #                            the tower + head launch makes it wait for itself, the update then runs there
 
@@ -72,8 +74,8 @@ class DenseSlab(object):
         d["_lay"] = [self._lay[id(p)] for p in self.params]     # id() keys do not survive pickling
         d["_fork"] = d["_pending"] = d["deferred"] = None       # streams / events / closures are per process
         d["overlap"] = False
-        d["inline"] = d["update_stream"] = None
-        d["wgrad_side"] = False
+        d["inline"] = d["update_stream"] = d["main_keep"] = None
+        d["wgrad_side"] = d["gather_side"] = False
         d["inline_done"] = False
         return d
 
@@ -118,11 +120,21 @@ class DenseSlab(object):
             self._fork = torch.cuda.Stream(device=device)
         return self._fork
 
+    def side_chain_open(self, side):
+        """True when ``side`` still carries the previous step's un-joined update and is part of the running hipGraph
+        capture: work enqueued on it now is ordered behind that update without waiting for the current stream."""
+        p = self._pending
+        if p is None or side is None or p[0] is not side or not torch.cuda.is_current_stream_capturing():
+            return False
+        with torch.cuda.stream(side):
+            return bool(torch.cuda.is_current_stream_capturing())
+
     def forked(self, stream, keep_alive):
         self._pending = (stream, keep_alive)
 
     def join(self):
         p = self._pending
+        self.main_keep = None
         if p is not None:
             self._pending = None
             torch.cuda.current_stream(self.flat.device).wait_stream(p[0])

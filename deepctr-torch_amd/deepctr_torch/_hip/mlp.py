@@ -288,8 +288,10 @@ class TowerHeadFunction(torch.autograd.Function):
         # dense optimizer needs THEM: with a fork stream on the sink they run beside the embedding update (which needs
         # only gx / g_logit) instead of in front of it.  The sink joins the fork before the dense optimizer step.
         inline = getattr(sink, "inline", None)
-        if inline is not None and hasattr(sink, "join"):
+        if inline is not None and hasattr(sink, "join") and not getattr(sink, "gather_side", False):
             sink.join()       # a previous step's forked weight-gradient / optimizer kernels wrote the weights read below
+        # (gather_side: the fork holds the embedding update and this step's gather -- the tower reads nothing they
+        # write but the gathered rows, for which the gather's own launch made this stream wait)
         fork = sink.fork_stream(dev) if (hasattr(sink, "fork_stream") and inline is None) else None
         defer = fork is None and inline is None and getattr(sink, "overlap", False) == "defer" and x.device.type == "cuda"
         L.check(lib.dctr_mlp_train_step(ctypes.byref(desc), _ptr(x), x.stride(0), B, pp[0], pp[1], _ptr(bias), _ptr(y),
@@ -322,6 +324,11 @@ class TowerHeadFunction(torch.autograd.Function):
                                              _ptr(loss), _ptr(g_bias), ctypes.byref(inline), L.stream_handle(dev)),
                     "dctr_mlp_train_wgrad")
             sink.inline_done = True
+            if getattr(sink, "gather_side", False):
+                # What the weight-gradient kernels above read stays allocated until the NEXT tower launch: the next
+                # step's gather runs on the side stream, ordered behind this launch's first kernel only -- memory the
+                # allocator handed from these tensors to the gather's outputs would be overwritten under the reader.
+                sink.main_keep = (x, hs, dhs, ws, g_logit, loss, ps, y, wo, gx)
         if defer:
             keep = (x, hs, dhs, ws, g_logit, loss, ps, y, wo, gx, desc)
 

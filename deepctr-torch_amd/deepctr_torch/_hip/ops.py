@@ -87,14 +87,31 @@ class EmbedFunction(torch.autograd.Function):
         segs = ids_t is not None and plan.segments_enabled() and getattr(plan, "exchange", None) is None
         own_ids = segs and X.is_cuda and sink is not None and getattr(sink, "inline", None) is not None
         ctx.seg_event = None
-        if own_ids:
-            ctx.seg_event = plan.launch_segments(ids_t, parts_t, B, X=X)
-            if ctx.seg_event[0] is not True:              # (True: the CPU stand-in, no streams)
-                sink.update_stream = ctx.seg_event[0]     # where this step's update will run (see backward)
-        L.check(lib.dctr_embed_fwd(cplan, _ptr(X), X.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), 1, _ptr(fm),
-                                   _ptr(plan.err_flag(X.device)), plan.units_ptr(), len(plan.units),
-                                   None if own_ids else _ptr(ids_t), None if own_ids else _ptr(parts_t), _ptr(fm_s),
-                                   ld_s, L.stream_handle(X.device)), "dctr_embed_fwd")
+        err = plan.err_flag(X.device)
+
+        def gather(stream, with_ids):
+            L.check(lib.dctr_embed_fwd(cplan, _ptr(X), X.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), 1, _ptr(fm),
+                                       _ptr(err), plan.units_ptr(), len(plan.units),
+                                       _ptr(ids_t) if with_ids else None, _ptr(parts_t) if with_ids else None,
+                                       _ptr(fm_s), ld_s, stream), "dctr_embed_fwd")
+
+        if own_ids and getattr(sink, "gather_side", False):
+            # Topology "gather_side": the gather runs on the side stream too, in stream order behind the previous
+            # step's update (the only thing it depends on), so the next step's rows are being fetched while the main
+            # stream still finishes this step's weight gradients; the main stream waits for the gather alone.  Inside
+            # a multi-step capture the side stream does not wait for the main one first (that would be the previous
+            # step's weight-gradient reduction): it does only when it has to -- first step of a capture, eager steps
+            # (whatever produced X ran on the main stream), tables last written elsewhere.
+            ctx.seg_event = plan.launch_segments(ids_t, parts_t, B, before=lambda st: gather(st, True),
+                                                 fork=not sink.side_chain_open(plan._seg_stream))
+            if ctx.seg_event[0] is not True:
+                sink.update_stream = ctx.seg_event[0]
+        else:
+            if own_ids:
+                ctx.seg_event = plan.launch_segments(ids_t, parts_t, B, X=X)
+                if ctx.seg_event[0] is not True:              # (True: the CPU stand-in, no streams)
+                    sink.update_stream = ctx.seg_event[0]     # where this step's update will run (see backward)
+            gather(L.stream_handle(X.device), not own_ids)
         ctx.plan, ctx.want_fm = plan, want_fm
         if segs and not own_ids:
             ctx.seg_event = plan.launch_segments(ids_t, parts_t, B)

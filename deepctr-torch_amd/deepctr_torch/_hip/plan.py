@@ -546,10 +546,14 @@ class EmbeddingPlan(object):
         import os
         return os.environ.get("DCTR_SEGMENTS", "1") != "0"
 
-    def launch_segments(self, ids_t, parts_t, B, X=None):
+    def launch_segments(self, ids_t, parts_t, B, X=None, before=None, fork=True):
         """Enqueue the pre-pass for this forward's ids on the side stream.  Returns the handle the update passes to
         ``update_workspace_for``.  A workspace still marked by an earlier forward (whose backward never ran -- a
-        forward in train mode that was not followed by a backward) is taken over."""
+        forward in train mode that was not followed by a backward) is taken over.
+        ``before(stream_handle)``: work that goes to the side stream ahead of the pre-pass -- the gather itself in the
+        "gather_side" step topology; the calling stream then waits for exactly that work (not for the pre-pass).
+        ``fork=False``: the side stream does not wait for the calling stream first (its own order -- behind the
+        previous step's update -- is all the gather needs)."""
         device = ids_t.device
         ws, ws_n = self.update_workspace(B, device, always=True)
         dirty = getattr(ws, "_dctr_owner", None) is not None
@@ -571,6 +575,8 @@ class EmbeddingPlan(object):
                                                 ctypes.c_void_p(ws.data_ptr()), ws_n, stream), "dctr_embed_segments")
 
         if device.type != "cuda":                  # (CPU stand-in: same calls, no streams)
+            if before is not None:
+                before(None)
             enqueue(None)
             ws._dctr_owner = ids_t.data_ptr()
             return (True, ws)
@@ -578,7 +584,12 @@ class EmbeddingPlan(object):
         side = self._seg_stream
         if side is None or side.device != device:
             side = self._seg_stream = torch.cuda.Stream(device=device)
-        side.wait_stream(main)
+        if fork:
+            side.wait_stream(main)
+        if before is not None:
+            with torch.cuda.stream(side):
+                before(L.stream_handle(device))
+            main.wait_stream(side)          # (an event at the side stream's tail of NOW: the pre-pass comes behind it)
         with torch.cuda.stream(side):
             enqueue(L.stream_handle(device))
         ws._dctr_owner = ids_t.data_ptr()

@@ -714,7 +714,9 @@ class BaseModel(nn.Module):
         if plan.update[0] in ("sgd", "adagrad") and os.environ.get("DCTR_INLINE_OPT", "1") != "0" and \
                 plan.segments_enabled():
             slab.begin_inline_step(mode[0], mode[1], mode[2] if len(mode) > 2 else 0.0)
-            slab.wgrad_side = os.environ.get("DCTR_STEP_TOPOLOGY", "update_side") == "tower_side"
+            topo = os.environ.get("DCTR_STEP_TOPOLOGY", "update_side")
+            slab.wgrad_side = topo == "tower_side"
+            slab.gather_side = topo == "gather_side"
         reg = None
         try:
             loss, y_pred = self.fused_loss(xb, yb, slab)
@@ -731,7 +733,7 @@ class BaseModel(nn.Module):
             plan.dense_sink = None
             slab.overlap = False
             slab.end_inline_step()
-            if not (slab.wgrad_side and getattr(self, "_defer_dense_join", False)):
+            if not ((slab.wgrad_side or slab.gather_side) and getattr(self, "_defer_dense_join", False)):
                 # (inside a multi-step hipGraph the captured steps but the last leave the forked weight-gradient /
                 # optimizer kernels unjoined: the next step's tower launch is the first reader of what they write)
                 slab.join()

@@ -12,6 +12,8 @@ sys.path.insert(0, os.path.join(ROOT, "deepctr-torch_amd"))
 import torch  # noqa: E402
 
 from deepctr_torch._hip import lib as L  # noqa: E402
+
+L.use_diag_library()   # make -C deepctr-torch_amd/csrc diag
 from deepctr_torch._hip import mlp  # noqa: E402
 from deepctr_torch.layers import DNN  # noqa: E402
 
