@@ -9,6 +9,7 @@ extern "C" size_t dctr_sizeof_field(void) { return sizeof(dctr_field_t); }
 extern "C" size_t dctr_sizeof_plan(void) { return sizeof(dctr_plan_t); }
 extern "C" size_t dctr_sizeof_mlp(void) { return sizeof(dctr_mlp_t); }
 extern "C" size_t dctr_sizeof_dense_step(void) { return sizeof(dctr_dense_step_t); }
+extern "C" size_t dctr_sizeof_dense_item(void) { return sizeof(dctr_dense_item_t); }
 
 extern "C" const char* dctr_strerror(int code) {
   switch (code) {

@@ -99,7 +99,102 @@ __global__ __launch_bounds__(256) void k_dense_opt(float* __restrict__ p, const 
   }
 }
 
+// the same step on a LIST of tensors in one launch (torch.optim's foreach walk over an autograd-step model's
+// parameters: 5 launches, 75-80 us per step for xDeepFM / FiBiNET / DCN).  Tensors are cut into chunks of kChunk
+// elements; a block finds its tensor from the chunk prefix sums in the kernel arguments.
+constexpr int kMulti = 48, kChunk = 4096;
+struct MultiArgs {
+  float* p[kMulti];
+  const float* g[kMulti];
+  float* st[kMulti];
+  long long n[kMulti];
+  int blk0[kMulti + 1];
+  int n_items;
+  float lr, eps;
+};
+
+template <int OPT>
+__global__ __launch_bounds__(256) void k_dense_opt_multi(MultiArgs A) {
+  int t = 0;
+  const int blk = blockIdx.x;
+  while (t + 1 < A.n_items && blk >= A.blk0[t + 1]) ++t;
+  float* __restrict__ p = A.p[t];
+  const float* __restrict__ g = A.g[t];
+  float* __restrict__ st = A.st[t];
+  const long long n = A.n[t];
+  const long long base = static_cast<long long>(blk - A.blk0[t]) * kChunk;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
+                         reinterpret_cast<uintptr_t>(st)) & 15u) == 0;
+#pragma unroll
+  for (int r = 0; r < kChunk / 1024; ++r) {
+    const long long i = base + r * 1024 + 4 * threadIdx.x;
+    if (i >= n) break;
+    if (aligned && i + 4 <= n) {
+      f32x4 pv = *(const DCTR_GLOBAL f32x4*)(p + i);
+      const f32x4 gv = *(const DCTR_GLOBAL f32x4*)(g + i);
+      if (OPT == DCTR_UPD_ADAGRAD) {
+        f32x4 sv = *(const DCTR_GLOBAL f32x4*)(st + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          sv[k] = sv[k] + gv[k] * gv[k];
+          pv[k] = pv[k] - A.lr * (gv[k] / (sqrtf(sv[k]) + A.eps));
+        }
+        *(DCTR_GLOBAL f32x4*)(st + i) = sv;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pv[k] = pv[k] - A.lr * gv[k];
+      }
+      *(DCTR_GLOBAL f32x4*)(p + i) = pv;
+    } else {
+      for (long long j = i; j < i + 4 && j < n; ++j) {
+        const float gv = ldg_f32(g + j);
+        float pv = ldg_f32(p + j);
+        if (OPT == DCTR_UPD_ADAGRAD) {
+          const float sv = ldg_f32(st + j) + gv * gv;
+          stg_f32(st + j, sv);
+          pv = pv - A.lr * (gv / (sqrtf(sv) + A.eps));
+        } else {
+          pv = pv - A.lr * gv;
+        }
+        stg_f32(p + j, pv);
+      }
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int dctr_dense_opt_multi(const dctr_dense_item_t* items, int32_t n_items, int32_t opt, float lr, float eps,
+                                    dctr_stream_t stream) {
+  if (n_items < 0 || (n_items > 0 && !items)) return DCTR_EINVAL;
+  if (opt != DCTR_UPD_SGD && opt != DCTR_UPD_ADAGRAD) return DCTR_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  for (int i0 = 0; i0 < n_items;) {
+    MultiArgs a;
+    int k = 0;
+    long long blocks = 0;
+    for (; k < kMulti && i0 + k < n_items; ++k) {
+      const dctr_dense_item_t& it = items[i0 + k];
+      if (it.n < 0 || (it.n > 0 && (!it.p || !it.g || (opt == DCTR_UPD_ADAGRAD && !it.state)))) return DCTR_EINVAL;
+      const long long nb = (it.n + kChunk - 1) / kChunk;
+      if (blocks + nb > 0x7FFFFFF0ll) return DCTR_ENOSUP;
+      a.p[k] = it.p; a.g[k] = it.g; a.st[k] = opt == DCTR_UPD_ADAGRAD ? it.state : it.p; a.n[k] = it.n;
+      a.blk0[k] = static_cast<int>(blocks);
+      blocks += nb;
+    }
+    a.blk0[k] = static_cast<int>(blocks);
+    a.n_items = k; a.lr = lr; a.eps = eps;
+    if (blocks > 0) {
+      const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+      if (opt == DCTR_UPD_ADAGRAD) k_dense_opt_multi<DCTR_UPD_ADAGRAD><<<grid, block, 0, s>>>(a);
+      else k_dense_opt_multi<DCTR_UPD_SGD><<<grid, block, 0, s>>>(a);
+      const int stt = launch_status();
+      if (stt != DCTR_OK) return stt;
+    }
+    i0 += k;
+  }
+  return DCTR_OK;
+}
 
 extern "C" int dctr_bce_head(const float* part0, const float* part1, const float* part2, const float* part3,
                              const float* bias, const float* y, int32_t B, float* y_pred, float* loss,

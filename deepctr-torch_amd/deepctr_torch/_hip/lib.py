@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdctr_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 
@@ -53,6 +53,11 @@ class DenseStep(ctypes.Structure):
     """``dctr_dense_step_t`` (include/dctr.h): an optimizer step applied by the kernel that finishes a gradient."""
     _fields_ = [("kind", ctypes.c_int32), ("lr", ctypes.c_float), ("eps", ctypes.c_float), ("pad_", ctypes.c_int32),
                 ("grad_base", ctypes.c_void_p), ("param_base", ctypes.c_void_p), ("state_base", ctypes.c_void_p)]
+
+
+class DenseItem(ctypes.Structure):
+    """``dctr_dense_item_t`` (include/dctr.h): one tensor of a ``dctr_dense_opt_multi`` list."""
+    _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("state", ctypes.c_void_p), ("n", ctypes.c_int64)]
 
 
 PLAN_HAS_GACC, PLAN_HAS_STATE, PLAN_HAS_MAXPOOL = 1, 2, 4
@@ -144,6 +149,8 @@ SIGNATURES = {
     "dctr_sizeof_dense_step": (ctypes.c_size_t, []),
     "dctr_bce_head": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P]),
     "dctr_dense_opt": (ctypes.c_int, [_P, _P, _P, _I64, _I32, _F32, _F32, _P]),
+    "dctr_sizeof_dense_item": (ctypes.c_size_t, []),
+    "dctr_dense_opt_multi": (ctypes.c_int, [ctypes.POINTER(DenseItem), _I32, _I32, _F32, _F32, _P]),
     "dctr_shard_assemble_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _I64, _P, _I32, _I32, _P, _P,
                                                _I32, _P, _I64, _P, _P, _P, _I64, _P]),
     "dctr_shard_assemble_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _I64, _P, _P, _P, _I64, _P,
@@ -209,7 +216,8 @@ def lib():
         if handle.dctr_sizeof_field() != ctypes.sizeof(Field) or handle.dctr_sizeof_plan() != ctypes.sizeof(Plan) \
                 or handle.dctr_sizeof_mlp() != ctypes.sizeof(Mlp) \
                 or handle.dctr_sizeof_lazy_unit() != ctypes.sizeof(LazyUnit) \
-                or handle.dctr_sizeof_dense_step() != ctypes.sizeof(DenseStep):
+                or handle.dctr_sizeof_dense_step() != ctypes.sizeof(DenseStep) \
+                or handle.dctr_sizeof_dense_item() != ctypes.sizeof(DenseItem):
             raise RuntimeError("dctr_field_t / dctr_plan_t / dctr_mlp_t layout mismatch between header and binding")
         _lib = handle
     return _lib

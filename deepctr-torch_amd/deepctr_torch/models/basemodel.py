@@ -753,19 +753,105 @@ class BaseModel(nn.Module):
             st = self._fused_step_state()
             if st is not None:
                 return self._train_step_fused(st, xb, yb)
-        y_pred = self(xb).squeeze()
-        self.optim.zero_grad()
-        if isinstance(self.loss_func, list):
-            assert len(self.loss_func) == self.num_tasks, \
-                "the length of `loss_func` should be equal with `self.num_tasks`"
-            loss = sum([self.loss_func[i](y_pred[:, i], yb[:, i], reduction='sum') for i in range(self.num_tasks)])
-        else:
+        parts = self.logit_parts(xb) if self._bce_head_ok(xb) else None
+        if parts is not None and not (0 < len(parts) <= 4 and yb.numel() == xb.shape[0] and all(
+                torch.is_tensor(q) and q.numel() == xb.shape[0] for q in parts)):
+            logit = parts[0]                       # (something the fused head does not take: BaseModel.forward's sum)
+            for q in parts[1:]:
+                logit = logit + q
+            y_pred, parts = self.out(logit).squeeze(), None
+            self.optim.zero_grad()
             loss = self.loss_func(y_pred, yb.squeeze(), reduction='sum')
-        total_loss = loss + self.get_regularization_loss() + self.aux_loss
+            total_loss = loss + self.get_regularization_loss() + self.aux_loss
+        elif parts is not None:
+            # binary task, BCE(sum): logit adds, PredictionLayer, loss and their backward as ONE launch
+            # (csrc/head.hip k_bce_head) instead of ~15 elementwise / reduce launches of pure latency
+            loss, y_pred = _mlp.bce_head(parts, self.out.bias if self.out.use_bias else None, yb, unit=True)
+            self.optim.zero_grad()
+            total_loss = loss.reshape(1)
+            if self._has_reg_terms():
+                total_loss = total_loss + self.get_regularization_loss()
+            if not self._aux_is_default():
+                total_loss = total_loss + self.aux_loss
+        else:
+            y_pred = self(xb).squeeze()
+            self.optim.zero_grad()
+            if isinstance(self.loss_func, list):
+                assert len(self.loss_func) == self.num_tasks, \
+                    "the length of `loss_func` should be equal with `self.num_tasks`"
+                loss = sum([self.loss_func[i](y_pred[:, i], yb[:, i], reduction='sum') for i in range(self.num_tasks)])
+            else:
+                loss = self.loss_func(y_pred, yb.squeeze(), reduction='sum')
+            total_loss = loss + self.get_regularization_loss() + self.aux_loss
         total_loss.backward()
         self._step_stacked_groups()
-        self.optim.step()
+        if not self._step_dense_multi():
+            self.optim.step()
         return loss.detach(), total_loss.detach(), y_pred.detach()
+
+    def _bce_head_ok(self, xb):
+        """True when the autograd-route step may take the fused prediction head: the reference's binary task --
+        ``self.out`` a sigmoid PredictionLayer, ``F.binary_cross_entropy`` (basemodel.py:254, 464-477) -- on a model
+        whose ``forward`` is the stock sum of ``logit_parts``."""
+        if not xb.is_cuda or os.environ.get("DCTR_FUSED_HEAD", "1") == "0":
+            return False
+        from ..layers.core import PredictionLayer
+        if self.loss_func is not F.binary_cross_entropy or type(self.out) is not PredictionLayer or \
+                self.out.task != "binary" or getattr(self, "num_tasks", 1) != 1:
+            return False
+        cls = type(self)
+        return cls.forward is BaseModel.forward and cls.logit_parts is not BaseModel.logit_parts
+
+    def _has_reg_terms(self):
+        """False when ``get_regularization_loss()`` is identically zero (no term with a positive strength, no lazily
+        regularised table): the logged total loss is then the loss itself and three launches are saved."""
+        if self._plan is not None and self._plan.update[0] == "lazy":
+            return True
+        return any((l1 > 0 or l2 > 0) and len(weight_list) > 0 for weight_list, l1, l2 in self.regularization_weight)
+
+    def _step_dense_multi(self):
+        """One ``dctr_dense_opt_multi`` launch for every dense parameter autograd left a gradient on, when the compiled
+        optimizer is a plain SGD / Adagrad over them (``_dense_update_mode``): ``torch.optim``'s foreach walk is five
+        launches, 75-80 us per xDeepFM / FiBiNET / DCN step.  Returns True when it stepped EVERY such parameter
+        (``optim.step()`` then has nothing to do and the gradients stay visible like the reference's); parameters it
+        cannot take (non-contiguous, another dtype / device) are left to ``optim.step()`` with the stepped ones hidden."""
+        if os.environ.get("DCTR_MULTI_STEP", "1") == "0":
+            return False
+        todo, rest = [], []
+        for grp in self.optim.param_groups:
+            for p in grp["params"]:
+                g = p.grad
+                if g is None:
+                    continue
+                if p.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32 and p.is_contiguous() and \
+                        g.is_contiguous() and not g.is_sparse and g.device == p.device:
+                    todo.append(p)
+                else:
+                    rest.append(p)
+        if not todo:
+            return False
+        mode = self._dense_update_mode(todo)
+        if mode is None or mode[0] not in ("sgd", "adagrad"):
+            return False
+        import ctypes
+        from .._hip import lib as L
+        if mode[0] == "adagrad":
+            sums = [self.optim.state[p]["sum"] for p in todo]
+            if any(s.dtype != torch.float32 or not s.is_contiguous() or s.device != p.device or s.shape != p.shape
+                   for s, p in zip(sums, todo)):
+                return False
+        items = (L.DenseItem * len(todo))()
+        for i, p in enumerate(todo):
+            items[i].p, items[i].g, items[i].n = p.data_ptr(), p.grad.data_ptr(), p.numel()
+            items[i].state = sums[i].data_ptr() if mode[0] == "adagrad" else None
+        L.check(L.lib().dctr_dense_opt_multi(items, len(todo), L.UPD_ADAGRAD if mode[0] == "adagrad" else L.UPD_SGD,
+                                             float(mode[1]), float(mode[2]) if len(mode) > 2 else 0.0,
+                                             L.stream_handle(todo[0].device)), "dctr_dense_opt_multi")
+        if rest:
+            for p in todo:
+                p.grad = None
+            return False
+        return True
 
     def _step_stacked_groups(self):
         """Layers that keep many small parameters as slices of one slab (FiBiNET's 2 x 325 bilinear ``nn.Linear``

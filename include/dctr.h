@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 12
+#define DCTR_ABI_VERSION 13
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -522,6 +522,19 @@ int dctr_bce_head(const float* part0, const float* part1, const float* part2, co
  * One launch for every dense parameter of the model (the reference's optimizer issues ~8 foreach launches).  */
 int dctr_dense_opt(float* p, const float* g, float* state, int64_t n, int32_t opt, float lr, float eps,
                    dctr_stream_t stream);
+/* The same step on a list of contiguous fp32 tensors -- the parameters of a model whose train step runs through
+ * autograd (xDeepFM's CIN weights, DCN's cross kernels, ...), each with the gradient autograd left in `.grad` and its
+ * Adagrad `sum` -- in one launch per 48 tensors (torch.optim.Adagrad / SGD step, basemodel.py:262: 5 foreach launches).
+ * items: HOST array.  state: ignored for DCTR_UPD_SGD.                                                              */
+typedef struct dctr_dense_item {
+  float* p;
+  const float* g;
+  float* state;
+  int64_t n;
+} dctr_dense_item_t;
+size_t dctr_sizeof_dense_item(void);
+int dctr_dense_opt_multi(const dctr_dense_item_t* items, int32_t n_items, int32_t opt, float lr, float eps,
+                         dctr_stream_t stream);
 
 /* ---- table-sharded multi-GPU exchange: the two "assemble" kernels (csrc/shard.hip, deepctr_torch/parallel.py) ---
  * Rank q of N owns units q, q+N, q+2N, ... (a unit = one id column with its deep and/or wide table).  Owners gather

@@ -175,6 +175,15 @@ class _Core(object):
             P -= lr * G
         return 0
 
+    def dctr_dense_opt_multi(self, items, n_items, opt, lr, eps, stream):
+        for i in range(n_items):
+            it = items[i]
+            if it.n:
+                self.dctr_dense_opt(ctypes.c_void_p(it.p), ctypes.c_void_p(it.g),
+                                    ctypes.c_void_p(it.state) if it.state else None, it.n, opt, lr, eps, stream)
+        self.calls.append("dense_opt_multi")
+        return 0
+
     # ---- fused gather (include/dctr.h: dctr_embed_fwd), fixed-length fields only ----------------------------
     @staticmethod
     def _plan(pref):
