@@ -14,6 +14,8 @@
 // waves of a workgroup never touch the same field inside a round and the per-field gradient tiles in LDS are
 // accumulated with plain read-modify-writes in round order (no float atomics, bit-reproducible).  Parameter
 // gradients (reductions over the batch) go to per-workgroup partial slabs that a second kernel sums in fixed order.
+#include <type_traits>
+
 #include "common.hpp"
 
 using namespace dctr;
@@ -273,6 +275,9 @@ __global__ __launch_bounds__(kT) void k_bilinear_fwd(const float* __restrict__ E
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * kSB;
   const int npass = V ? 2 : 1;
+  int32_t* sch = reinterpret_cast<int32_t*>(xs0 + 2 * kSB * RS);   // [n_sched][4]: the schedule
+  for (int e = tid; e < n_sched; e += kT)
+    *reinterpret_cast<i32x4*>(sch + 4 * e) = *(const DCTR_GLOBAL i32x4*)(sched + 4 * e);
   stage_rows(xs0, RS, V ? V : E, V ? ldv : lde, b0, B, W);
   if (V) stage_rows(xs1, RS, E, lde, b0, B, W);
   if (dense)
@@ -283,38 +288,98 @@ __global__ __launch_bounds__(kT) void k_bilinear_fwd(const float* __restrict__ E
                 ldg_f32(dense + static_cast<int64_t>(b0 + r) * ldd + q));
     }
   __syncthreads();
-  // software pipeline over this wave's pairs: the schedule entry of pair q + 8 and the weight tile of pair q + 4 are in
-  // flight while pair q computes (three dependent L2 round trips per pair otherwise)
-  PairEnt e1 = load_pair(sched, wv, n_sched), e2 = load_pair(sched, wv + 4, n_sched);
-  float w1[4];
-  load_w_raw(Wf, e1, D, g, c, w1);
-  for (int q = wv; q < n_sched; q += 4) {
-    const PairEnt en = e1;
+  // Software pipeline over this wave's pairs.  The schedule sits in LDS (staged above), so a pair's weight address
+  // costs no memory round trip, and the weight tiles of the next kWD pairs are in flight while a pair computes.  What
+  // bound this kernel at 1.35 TB/s (round 1) was not HBM but two latency chains, found in the ISA:
+  //  * `d < D ? xs[..] : 0` compiles to a branch around the ds_read with its own lgkmcnt(0): ~10 dependent LDS round
+  //    trips per pair.  Every LDS operand of a pair -- 4 A values and 4 x_j values per pass, both passes -- is now read
+  //    unconditionally (clamped index, select afterwards) before the first MFMA;
+  //  * loads and stores share one in-order counter on gfx950, and the compiler cannot count stores that sit behind a
+  //    branch: the wait for a weight tile prefetched four pairs earlier became a wait for the PREVIOUS pair's stores
+  //    (one write round trip per pair, ~0.7 us).  Full tiles (D == 16, 16 valid samples) therefore run a branch-free
+  //    body over whole groups of kWD pairs -- every store unconditional, the waits exact -- and only the ragged
+  //    rest takes the predicated body.  (Staging the products through LDS for 2 KB runs per sample was measured
+  //    slower than these direct 64-byte pieces: with one workgroup per CU its store bursts do not overlap compute.)
+  constexpr int kWD = 4;
+  auto entry = [&](int q) {
+    PairEnt e;
+    const int qc = q < n_sched ? q : n_sched - 1;
+    const i32x4 v = *reinterpret_cast<const i32x4*>(sch + 4 * qc);
+    e.i = q < n_sched ? v.x : -1; e.j = v.y; e.wi = v.z; e.k = v.w;
+    return e;
+  };
+  float wring[kWD][4];
+#pragma unroll
+  for (int u = 0; u < kWD; ++u) {
+    load_w_raw(Wf, entry(wv + 4 * u), D, g, c, wring[u]);
+    __builtin_amdgcn_sched_barrier(0);     // ring order: the loop's waits are derived from it
+  }
+  const bool cv = c < D;
+  const int cc = cv ? c : 0;
+  int dcl[4];
+  bool dv[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    dv[s] = 4 * g + s < D;
+    dcl[s] = dv[s] ? 4 * g + s : 0;
+  }
+  auto pair = [&](auto full_tag, int q, float (&wslot)[4]) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const PairEnt en = entry(q);
     float wreg[4];  // B operand: W[e = c][d = 4g + s]
 #pragma unroll
-    for (int s = 0; s < 4; ++s) wreg[s] = (c < D && 4 * g + s < D) ? w1[s] : 0.f;
-    e1 = e2;
-    load_w_raw(Wf, e1, D, g, c, w1);
-    e2 = load_pair(sched, q + 8, n_sched);
-    if (en.i < 0) continue;
-    const int i = en.i, j = en.j, k = en.k;
-    for (int ps = 0; ps < npass; ++ps) {
-      const float* xs = ps ? xs1 : xs0;
-      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < 4; ++s) wreg[s] = (FULL || (cv && dv[s])) ? wslot[s] : 0.f;
+    load_w_raw(Wf, entry(q + 4 * kWD), D, g, c, wslot);
+    const bool live = FULL || en.i >= 0;
+    const int i = live ? en.i : 0, j = live ? en.j : 0, k = en.k;
+    float a[2][4], xj[2][4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int d = 4 * g + s;
-        const float a = d < D ? xs[c * RS + i * D + d] : 0.f;  // A operand: x_i[b = c][d]
-        t = mfma16(a, wreg[s], t);
-      }
+    for (int ps = 0; ps < 2; ++ps) {
+      const float* xs = (ps && npass > 1) ? xs1 : xs0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {  // t[r] = (x_i W^T)[b = 4g + r][e = c]
-        const int b = 4 * g + r;
-        if (c < D && b0 + b < B)
-          stg_f32(out + static_cast<int64_t>(b0 + b) * ldo + (static_cast<int64_t>(ps) * P + k) * D + c,
-                  t[r] * xs[b * RS + j * D + c]);
+      for (int s = 0; s < 4; ++s) a[ps][s] = xs[c * RS + i * D + dcl[s]];          // A operand: x_i[b = c][d]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xj[ps][r] = xs[(4 * g + r) * RS + j * D + cc];   // x_j[b = 4g + r][e = c]
+    }
+    f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      t0 = mfma16((FULL || dv[s]) ? a[0][s] : 0.f, wreg[s], t0);
+      t1 = mfma16((FULL || dv[s]) ? a[1][s] : 0.f, wreg[s], t1);
+    }
+    float* col = out + static_cast<int64_t>(k) * D + c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // t[r] = (x_i W^T)[b = 4g + r][e = c]
+      const int b = 4 * g + r;
+      float* row = col + static_cast<int64_t>(b0 + b) * ldo;
+      if (FULL) {
+        stg_f32(row, t0[r] * xj[0][r]);
+        stg_f32(row + static_cast<int64_t>(P) * D, t1[r] * xj[1][r]);
+      } else if (live && cv && b0 + b < B) {
+        stg_f32(row, t0[r] * xj[0][r]);
+        if (npass > 1) stg_f32(row + static_cast<int64_t>(P) * D, t1[r] * xj[1][r]);
       }
     }
+  };
+  const int mine = (n_sched - wv + 3) / 4;                        // pairs of this wave: q = wv + 4 m
+  const bool fast = (D == 16) && (b0 + kSB <= B) && (npass == 2);
+  const int full_groups = fast ? mine / kWD : 0;
+  int m = 0;
+  auto group = [&]() {
+#pragma unroll
+    for (int u = 0; u < kWD; ++u) {
+      pair(std::true_type{}, wv + 4 * (m + u), wring[u]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    m += kWD;
+  };
+  // (the first group is peeled: the loop is then entered with the same loads and stores outstanding as its back edge
+  // leaves -- the compiler takes the tighter of the two for the waits at the loop head)
+  if (full_groups > 0) group();
+  for (int gi = 1; gi < full_groups; ++gi) group();
+  for (; m < mine + kWD; m += kWD) {      // the ragged rest (and everything of a partial tile)
+#pragma unroll
+    for (int u = 0; u < kWD; ++u) pair(std::false_type{}, wv + 4 * (m + u), wring[u]);
   }
 }
 
@@ -324,7 +389,8 @@ __global__ __launch_bounds__(kT) void k_bilinear_bwd_data(const float* __restric
                                                           const float* __restrict__ Wf,
                                                           const int32_t* __restrict__ sched, int n_sched, int slots,
                                                           int P, int F, int D, int B, const float* __restrict__ gout,
-                                                          int64_t ldg, float* __restrict__ gE, float* __restrict__ gV) {
+                                                          int64_t ldg, float* __restrict__ gE, float* __restrict__ gV,
+                                                          int sch_lds) {
   extern __shared__ __align__(16) float smem[];
   const int RS = row_stride(F, D), W = F * D;
   float* xs0 = smem;
@@ -332,9 +398,14 @@ __global__ __launch_bounds__(kT) void k_bilinear_bwd_data(const float* __restric
   float* gx0 = xs1 + kSB * RS;
   float* gx1 = gx0 + kSB * RS;
   float* tb = gx1 + kSB * RS;  // [4 waves][16][17] layout-change scratch
+  // [n_sched][4]: the schedule (16-byte aligned: RS and 4 * 16 * 17 are multiples of 4 floats)
+  int32_t* sch = reinterpret_cast<int32_t*>(tb + 4 * 16 * 17);
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * kSB;
   const int npass = V ? 2 : 1;
+  if (sch_lds)
+    for (int e = tid; e < n_sched; e += kT)
+      *reinterpret_cast<i32x4*>(sch + 4 * e) = *(const DCTR_GLOBAL i32x4*)(sched + 4 * e);
   stage_rows(xs0, RS, V ? V : E, V ? ldv : lde, b0, B, W);
   if (V) stage_rows(xs1, RS, E, lde, b0, B, W);
   for (int e = tid; e < 2 * kSB * RS; e += kT) gx0[e] = 0.f;
@@ -366,59 +437,111 @@ __global__ __launch_bounds__(kT) void k_bilinear_bwd_data(const float* __restric
       for (int r = 0; r < 4; ++r)
         gp[ps][r] = ldg_f32(gout + grow[r] + (static_cast<int64_t>(ps < npass ? ps : 0) * P + e.k) * D);
   };
-  PairEnt e1 = load_pair(sched, pair_of(0), n_sched), e2 = load_pair(sched, pair_of(1), n_sched);
-  float w1[4], wt1[4], gp1[2][4];
-  load_w_raw(Wf, e1, D, g, c, w1);
-  load_wt_raw(Wf, e1, D, g, c, wt1);
-  load_gp(e1, gp1);
-  for (int it = 0; it < nit; ++it) {
-    const PairEnt en = e1;
-    float wreg[4], wT[4], gpc[2][4];
+  // kPD-deep ring: the weight tiles and the 8 incoming-gradient values of the next kPD pairs are in flight while a pair
+  // computes (round 1 kept ONE pair ahead: every iteration then cost one HBM round trip -- the gradient slab is
+  // streamed, 170 MB at the Criteo shape -- and the kernel ran at 2.2 us per pair).  The schedule sits in LDS, so
+  // the address of a pair kPD iterations ahead costs no memory round trip.
+  constexpr int kPD = 4;    // (8 was measured slower: 207 vs 194 us -- registers, not latency, then bound the wave)
+  auto entry_it = [&](int it) {
+    const int q = pair_of(it);
+    PairEnt e;
+    const int qc = q < n_sched ? q : n_sched - 1;
+    // (the widest field counts leave no LDS for the schedule: it is then read from global memory, L2-resident)
+    const i32x4 v = sch_lds ? *reinterpret_cast<const i32x4*>(sch + 4 * qc) : *(const DCTR_GLOBAL i32x4*)(sched + 4 * qc);
+    e.i = q < n_sched ? v.x : -1; e.j = v.y; e.wi = v.z; e.k = v.w;
+    return e;
+  };
+  float wr[kPD][4], wtr[kPD][4], gpr[kPD][2][4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bool in = c < D && 4 * g + s < D;
-      wreg[s] = in ? w1[s] : 0.f;     // W[e = c][d]
-      wT[s] = in ? wt1[s] : 0.f;      // W[e = d'][d = c]
-    }
+  for (int u = 0; u < kPD; ++u) {
+    const PairEnt e = entry_it(u);
+    load_w_raw(Wf, e, D, g, c, wr[u]);
+    load_wt_raw(Wf, e, D, g, c, wtr[u]);
+    load_gp(e, gpr[u]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const bool cv = c < D;
+  int dcl[4];
+  bool dv[4];
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps)
+  for (int s = 0; s < 4; ++s) {
+    dv[s] = 4 * g + s < D;
+    dcl[s] = dv[s] ? 4 * g + s : 0;
+  }
+  for (int it0 = 0; it0 < nit; it0 += kPD) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) gpc[ps][r] = (c < D && b0 + 4 * g + r < B) ? gp1[ps][r] : 0.f;
-    e1 = e2;
-    load_w_raw(Wf, e1, D, g, c, w1);
-    load_wt_raw(Wf, e1, D, g, c, wt1);
-    load_gp(e1, gp1);
-    e2 = load_pair(sched, pair_of(it + 2), n_sched);
-    if (en.i >= 0) {
-      const int i = en.i, j = en.j;
-      for (int ps = 0; ps < npass; ++ps) {
-        const float* xs = ps ? xs1 : xs0;
-        float* gx = ps ? gx1 : gx0;
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < kPD; ++u) {
+      const int it = it0 + u;
+      if (it < nit) {                       // (uniform over the workgroup: nit is)
+        const PairEnt en = entry_it(it);
+        float wreg[4], wT[4], gpc[2][4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const int d = 4 * g + s;
-          t = mfma16(d < D ? xs[c * RS + i * D + d] : 0.f, wreg[s], t);
+          const bool in = cv && dv[s];
+          wreg[s] = in ? wr[u][s] : 0.f;     // W[e = c][d]
+          wT[s] = in ? wtr[u][s] : 0.f;      // W[e = d'][d = c]
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int b = 4 * g + r;
-          const float gp = ps ? gpc[1][r] : gpc[0][r];
-          if (c < D) gx[b * RS + j * D + c] += gp * t[r];            // gX_j[b][e]
-          mytb[b * 17 + c] = (c < D) ? gp * xs[b * RS + j * D + c] : 0.f;  // g_t[b][e] in C layout
-        }
-        // g_xi[b][d] = sum_e g_t[b][e] W[e][d]: A operand g_t[b = c][e = 4g + s], B operand W[e = 4g + s][d = c]
-        f32x4 u = {0.f, 0.f, 0.f, 0.f};
+        for (int ps = 0; ps < 2; ++ps)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) u = mfma16(mytb[c * 17 + 4 * g + s], wT[s], u);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int b = 4 * g + r;
-          if (c < D) gx[b * RS + i * D + c] += u[r];
+          for (int r = 0; r < 4; ++r) gpc[ps][r] = (cv && b0 + 4 * g + r < B) ? gpr[u][ps][r] : 0.f;
+        {
+          const PairEnt ea = entry_it(it + kPD);
+          load_w_raw(Wf, ea, D, g, c, wr[u]);
+          load_wt_raw(Wf, ea, D, g, c, wtr[u]);
+          load_gp(ea, gpr[u]);
         }
+        const bool live = en.i >= 0;
+        const int i = live ? en.i : 0, j = live ? en.j : 0;
+        // every LDS operand of the pair is read unconditionally before the first MFMA (a predicated ds_read is a
+        // branch with its own lgkmcnt(0))
+        float a[2][4], xj[2][4], gj[2][4];
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const float* xs = (ps && npass > 1) ? xs1 : xs0;
+          const float* gx = (ps && npass > 1) ? gx1 : gx0;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) a[ps][s] = xs[c * RS + i * D + dcl[s]];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            xj[ps][r] = xs[(4 * g + r) * RS + j * D + ccl];
+            gj[ps][r] = gx[(4 * g + r) * RS + j * D + ccl];
+          }
+        }
+        f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          t0 = mfma16(dv[s] ? a[0][s] : 0.f, wreg[s], t0);
+          t1 = mfma16(dv[s] ? a[1][s] : 0.f, wreg[s], t1);
+        }
+        if (live) {
+          for (int ps = 0; ps < npass; ++ps) {
+            float* gx = ps ? gx1 : gx0;
+            const f32x4 t = ps ? t1 : t0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int b = 4 * g + r;
+              const float gp = ps ? gpc[1][r] : gpc[0][r];
+              if (cv) gx[b * RS + j * D + c] = (ps ? gj[1][r] : gj[0][r]) + gp * t[r];   // gX_j[b][e]
+              mytb[b * 17 + c] = cv ? gp * (ps ? xj[1][r] : xj[0][r]) : 0.f;             // g_t[b][e] in C layout
+            }
+            // g_xi[b][d] = sum_e g_t[b][e] W[e][d]: A operand g_t[b = c][e = 4g + s], B operand W[e = 4g + s][d = c]
+            float ga[4], gi[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ga[s] = mytb[c * 17 + 4 * g + s];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gi[r] = gx[(4 * g + r) * RS + i * D + ccl];
+            f32x4 uu = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) uu = mfma16(ga[s], wT[s], uu);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (cv) gx[(4 * g + r) * RS + i * D + c] = gi[r] + uu[r];
+          }
+        }
+        if ((it + 1) % spw == 0) __syncthreads();  // next round touches other (field) columns of gx; rounds are perfect matchings
       }
     }
-    if ((it + 1) % spw == 0) __syncthreads();  // next round touches other (field) columns of gx; rounds are perfect matchings
   }
   for (int e = tid; e < kSB * W; e += kT) {
     const int r = e / W, cc = e - r * W;
@@ -448,18 +571,21 @@ __global__ __launch_bounds__(kT) void k_bilinear_bwd_weight(const float* __restr
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int sg = blockIdx.x;
   const int npass = V ? 2 : 1;
-  // this wave's pairs: q = blockIdx.y*4 + wv, stepping by 4*gridDim.y; at most 8 live accumulators
+  // this wave's pairs: MAXQ CONSECUTIVE schedule entries (the schedule arrives in output order k: the 8 incoming-
+  // gradient pieces of a sample are then 8 * D consecutive floats -- whole 128-byte lines; with entries dealt out
+  // round-robin every line was fetched twice, by different workgroups at different times: 2x the HBM traffic of the
+  // 170 MB slab); at most 8 live accumulators
   constexpr int MAXQ = 8;
   f32x4 acc[MAXQ];
-  const int qstep = 4 * gridDim.y, q0 = blockIdx.y * 4 + wv;
+  const int qstep = 4 * gridDim.y * MAXQ, q0 = (blockIdx.y * 4 + wv) * MAXQ;
   const int ccl = c < D ? c : 0;
-  for (int base = 0; base < n_sched; base += qstep * MAXQ) {
+  for (int base = 0; base < n_sched; base += qstep) {
     // this wave's (at most MAXQ) pairs of the sweep: schedule entries loaded ONCE, not once per tile
     PairEnt ent[MAXQ];
 #pragma unroll
     for (int a = 0; a < MAXQ; ++a) {
       acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-      ent[a] = load_pair(sched, base + q0 + a * qstep, n_sched);
+      ent[a] = load_pair(sched, base + q0 + a, n_sched);
     }
     for (int tl = 0; tl < tiles_per_group; ++tl) {
       const int b0 = (sg * tiles_per_group + tl) * kSB;
@@ -482,21 +608,31 @@ __global__ __launch_bounds__(kT) void k_bilinear_bwd_weight(const float* __restr
       stage_rows(xs0, RS, V ? V : E, V ? ldv : lde, b0, B, W);
       if (V) stage_rows(xs1, RS, E, lde, b0, B, W);
       __syncthreads();
+      // branch-free: every LDS operand is read unconditionally (clamped column / field 0 for an idle entry) and masked
+      // by a select -- `c < D ? xs[..] : 0` compiled to a branch around each ds_read with its own lgkmcnt(0): 128
+      // serial LDS round trips per tile
 #pragma unroll
       for (int a = 0; a < MAXQ; ++a) {
-        if (ent[a].i < 0) continue;
-        const int i = ent[a].i, j = ent[a].j;
+        const bool live = ent[a].i >= 0;
+        const int i = live ? ent[a].i : 0, j = live ? ent[a].j : 0;
+        float xjv[2][4], xiv[2][4];
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
-          if (ps >= npass) break;
-          const float* xs = ps ? xs1 : xs0;
+          const float* xs = (ps && npass > 1) ? xs1 : xs0;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            xjv[ps][s] = xs[(4 * g + s) * RS + j * D + ccl];
+            xiv[ps][s] = xs[(4 * g + s) * RS + i * D + ccl];
+          }
+        }
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const bool on = live && c < D && ps < npass;
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const int b = 4 * g + s;  // reduction index = sample
-            const float gp = (c < D && b0 + b < B) ? gpr[a][ps][s] : 0.f;
-            const float gt = (c < D) ? gp * xs[b * RS + j * D + c] : 0.f;   // A: g_t[b][e = c]
-            const float xi = (c < D) ? xs[b * RS + i * D + c] : 0.f;        // B: x_i[b][d = c]
-            acc[a] = mfma16(gt, xi, acc[a]);
+            const float gp = (on && b0 + b < B) ? gpr[a][ps][s] : 0.f;
+            acc[a] = mfma16(gp * xjv[ps][s], on ? xiv[ps][s] : 0.f, acc[a]);   // A: g_t[b][e = c], B: x_i[b][d = c]
           }
         }
       }
@@ -654,7 +790,7 @@ extern "C" int dctr_bilinear_fwd(const float* E, int64_t ld_e, const float* V, i
   if (!E || !Wf || !sched || !out || B < 0 || F < 2 || D <= 0 || P <= 0 || n_sched <= 0) return DCTR_EINVAL;
   if (D > 16) return DCTR_ENOSUP;
   if (B == 0) return DCTR_OK;
-  const size_t lds = tile_bytes(F, D, 2);
+  const size_t lds = tile_bytes(F, D, 2) + static_cast<size_t>(n_sched) * 16;   // + the schedule
   if (lds > 150 * 1024) return DCTR_ENOSUP;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bilinear_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -678,7 +814,7 @@ extern "C" int dctr_bilinear_bwd(const float* E, int64_t ld_e, const float* V, i
                                  const int32_t* sched, int32_t n_sched, int32_t slots, const int32_t* pair_w,
                                  int32_t n_w, int32_t P, int32_t F, int32_t D, int32_t B, const float* gout,
                                  int64_t ld_g, float* gE, float* gV, float* gW, float* workspace,
-                                 dctr_stream_t stream) {
+                                 const int32_t* sched_k, int32_t n_sched_k, dctr_stream_t stream) {
   if (!E || !Wf || !sched || !pair_w || !gout || !gE || !gW || !workspace || (V && !gV) || B < 0 || F < 2 || D <= 0 ||
       P <= 0 || n_sched <= 0 || slots <= 0 || n_w <= 0)
     return DCTR_EINVAL;
@@ -689,19 +825,23 @@ extern "C" int dctr_bilinear_bwd(const float* E, int64_t ld_e, const float* V, i
     return DCTR_OK;
   }
   {
-    const size_t lds = tile_bytes(F, D, 4) + 4u * 16 * 17 * sizeof(float);
+    size_t lds = tile_bytes(F, D, 4) + 4u * 16 * 17 * sizeof(float);
     if (lds > 158 * 1024) return DCTR_ENOSUP;
+    const int sch_lds = lds + static_cast<size_t>(n_sched) * 16 <= 158 * 1024;
+    if (sch_lds) lds += static_cast<size_t>(n_sched) * 16;
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bilinear_bwd_data),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     k_bilinear_bwd_data<<<dim3((B + kSB - 1) / kSB), dim3(kT), lds, s>>>(E, ld_e, V, ld_v, Wf, sched, n_sched, slots, P,
-                                                                        F, D, B, gout, ld_g, gE, gV);
+                                                                        F, D, B, gout, ld_g, gE, gV, sch_lds);
   }
   {
     const int tiles = (B + kSB - 1) / kSB;
     const int groups = bilinear_groups(B);
     const int tpg = (tiles + groups - 1) / groups;
-    int py = (n_sched + 3) / 4;
+    const int32_t* sw = (sched_k && n_sched_k > 0) ? sched_k : sched;
+    const int nw_s = (sched_k && n_sched_k > 0) ? n_sched_k : n_sched;
+    int py = (nw_s + 31) / 32;      // 4 waves x 8 consecutive pairs per workgroup row
     if (py > 16) py = 16;
     const size_t lds = tile_bytes(F, D, 2);
     if (lds > 64 * 1024)
@@ -709,7 +849,7 @@ extern "C" int dctr_bilinear_bwd(const float* E, int64_t ld_e, const float* V, i
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     // groups whose tiles all fall past B still own a slab: clear the workspace first so they contribute zeros
     (void)hipMemsetAsync(workspace, 0, sizeof(float) * static_cast<size_t>(groups) * P * D * D, s);
-    k_bilinear_bwd_weight<<<dim3(groups, py), dim3(kT), lds, s>>>(E, ld_e, V, ld_v, sched, n_sched, P, F, D, B, gout,
+    k_bilinear_bwd_weight<<<dim3(groups, py), dim3(kT), lds, s>>>(E, ld_e, V, ld_v, sw, nw_s, P, F, D, B, gout,
                                                                  ld_g, tpg, workspace);
     const int64_t total = static_cast<int64_t>(n_w) * D * D;
     k_bilinear_reduce_w<<<dim3(static_cast<unsigned>((total + kT - 1) / kT)), dim3(kT), 0, s>>>(workspace, groups, P,

@@ -361,8 +361,13 @@ int dctr_senet_bwd(const float* gV, const float* E, int64_t ld_e, int32_t B, int
 
 /* BilinearInteraction (interaction.py:140-156): p_k = (x_i W_w^T) (.) x_j for the pairs k = (i, j), i < j.
  *   Wf    [n_w, D, D]  the nn.Linear weights stacked: n_w = 1 ("all"), F ("each", w = i), P ("interaction", w = k)
- *   sched [n_sched][4] int32 (device): {i, j, w, k} in round-robin-tournament order, `slots` entries per round,
- *         i = -1 for an idle slot;  pair_w [P] int32: weight index of pair k
+ *   sched [n_sched][4] int32 (device): {i, j, w, k}.  The FORWARD takes the entries in output order (k ascending, no
+ *         idle entries, n_sched = P): the waves of a workgroup then write neighbouring pieces of a sample's row
+ *         together.  The BACKWARD takes two tables: `sched` in round-robin-tournament order, `slots` entries per round,
+ *         i = -1 for an idle slot (its data kernel lets four waves accumulate into LDS rows without conflicts: a round
+ *         is a perfect matching of the fields), and `sched_k` in output order like the forward's (its weight kernel
+ *         gives every wave 8 consecutive pairs, i.e. whole lines of the incoming gradient; NULL: `sched` is used).
+ *         pair_w [P] int32: weight index of pair k
  *   V     optional second input (FiBiNET's SENET output, fibinet.py:82-83).  With V: out row =
  *         [ V pairs (P*D) | E pairs (P*D) ], else [ E pairs ].  `dense` (nullable): n_dense floats per sample copied
  *         to out[:, dense_off ...) so that `out` IS the reference's DNN input (fibinet.py:86-87).  D <= 16.
@@ -376,7 +381,8 @@ size_t dctr_bilinear_bwd_workspace_floats(int32_t B, int32_t P, int32_t D);
 int dctr_bilinear_bwd(const float* E, int64_t ld_e, const float* V, int64_t ld_v, const float* Wf,
                       const int32_t* sched, int32_t n_sched, int32_t slots, const int32_t* pair_w, int32_t n_w,
                       int32_t P, int32_t F, int32_t D, int32_t B, const float* gout, int64_t ld_g, float* gE,
-                      float* gV, float* gW, float* workspace, dctr_stream_t stream);
+                      float* gV, float* gW, float* workspace, const int32_t* sched_k, int32_t n_sched_k,
+                      dctr_stream_t stream);
 
 /* InnerProductLayer (interaction.py:557-577): out[b, k] = sum_d e_i e_j (reduce != 0) or out[b, k*D + d] = e_i e_j;
  * pair order i < j, i outer.  Backward: gE[b, f, :] = sum_{g != f} gp[b, pair(f, g)] e_g.                    */

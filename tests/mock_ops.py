@@ -188,7 +188,7 @@ class OpsMixin(object):
 
     @_with_grad
     def dctr_bilinear_bwd(self, E, ld_e, V, ld_v, Wf, sched, n_sched, slots, pair_w, n_w, P, F, D, B, gout, ld_g, gE, gV,
-                          gW, ws, stream):
+                          gW, ws, sched_k, n_sched_k, stream):
         self.calls.append("bilinear_bwd")
         pw = torch.from_numpy(_arr(pair_w, (P,), dtype=np.int32).astype(np.int64))
         e = _t(E, B, F * D, ld_e).clone().requires_grad_(True)
