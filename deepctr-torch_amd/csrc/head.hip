@@ -108,6 +108,7 @@ struct MultiArgs {
   const float* g[kMulti];
   float* st[kMulti];
   long long n[kMulti];
+  float c2[kMulti];           // 2 * lambda of the tensor's L2 term (0: none): g += c2 * p before the step
   int blk0[kMulti + 1];
   int n_items;
   float lr, eps;
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(256) void k_dense_opt_multi(MultiArgs A) {
   const float* __restrict__ g = A.g[t];
   float* __restrict__ st = A.st[t];
   const long long n = A.n[t];
+  const float c2 = A.c2[t];
   const long long base = static_cast<long long>(blk - A.blk0[t]) * kChunk;
   const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
                          reinterpret_cast<uintptr_t>(st)) & 15u) == 0;
@@ -131,7 +133,11 @@ __global__ __launch_bounds__(256) void k_dense_opt_multi(MultiArgs A) {
     if (i >= n) break;
     if (aligned && i + 4 <= n) {
       f32x4 pv = *(const DCTR_GLOBAL f32x4*)(p + i);
-      const f32x4 gv = *(const DCTR_GLOBAL f32x4*)(g + i);
+      f32x4 gv = *(const DCTR_GLOBAL f32x4*)(g + i);
+      if (c2 != 0.f) {            // autograd's d/dp of lambda * sum(p^2), added to the gradient: two roundings, no fma
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gv[k] = __fadd_rn(gv[k], __fmul_rn(c2, pv[k]));
+      }
       if (OPT == DCTR_UPD_ADAGRAD) {
         f32x4 sv = *(const DCTR_GLOBAL f32x4*)(st + i);
 #pragma unroll
@@ -147,8 +153,9 @@ __global__ __launch_bounds__(256) void k_dense_opt_multi(MultiArgs A) {
       *(DCTR_GLOBAL f32x4*)(p + i) = pv;
     } else {
       for (long long j = i; j < i + 4 && j < n; ++j) {
-        const float gv = ldg_f32(g + j);
+        float gv = ldg_f32(g + j);
         float pv = ldg_f32(p + j);
+        if (c2 != 0.f) gv = __fadd_rn(gv, __fmul_rn(c2, pv));
         if (OPT == DCTR_UPD_ADAGRAD) {
           const float sv = ldg_f32(st + j) + gv * gv;
           stg_f32(st + j, sv);
@@ -162,7 +169,48 @@ __global__ __launch_bounds__(256) void k_dense_opt_multi(MultiArgs A) {
   }
 }
 
+// sum_i lambda_i * sum(p_i^2) of a tensor list: ONE workgroup, fixed order (thread t sums elements t, t + 1024, ...
+// of every tensor in list order, then a tree): deterministic.  The logged value of the L2 terms that
+// dctr_dense_opt_multi applies as gradients (get_regularization_loss, basemodel.py:412-428).
+__global__ __launch_bounds__(kTH) void k_l2_value_multi(MultiArgs A, float* __restrict__ out) {
+  __shared__ float red[kTH / 64];
+  float acc = 0.f;
+  for (int t = 0; t < A.n_items; ++t) {
+    const float lam = 0.5f * A.c2[t];
+    if (lam == 0.f) continue;
+    const float* __restrict__ p = A.p[t];
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < A.n[t]; i += kTH) {
+      const float v = ldg_f32(p + i);
+      s += v * v;
+    }
+    acc += lam * s;
+  }
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0) stg_f32(out, tot + ldg_f32(out));
+}
+
 }  // namespace
+
+extern "C" int dctr_l2_value_multi(const dctr_dense_item_t* items, int32_t n_items, float* out, dctr_stream_t stream) {
+  if (n_items < 0 || (n_items > 0 && !items) || !out) return DCTR_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  (void)hipMemsetAsync(out, 0, sizeof(float), s);
+  for (int i0 = 0; i0 < n_items; i0 += kMulti) {
+    MultiArgs a;
+    int k = 0;
+    for (; k < kMulti && i0 + k < n_items; ++k) {
+      const dctr_dense_item_t& it = items[i0 + k];
+      if (it.n < 0 || (it.n > 0 && !it.p)) return DCTR_EINVAL;
+      a.p[k] = it.p; a.g[k] = nullptr; a.st[k] = nullptr; a.n[k] = it.n; a.c2[k] = 2.f * it.l2;
+    }
+    a.n_items = k; a.lr = a.eps = 0.f;
+    k_l2_value_multi<<<dim3(1), dim3(kTH), 0, s>>>(a, out);    // (accumulates into out: launches are stream-ordered)
+    const int stt = launch_status();
+    if (stt != DCTR_OK) return stt;
+  }
+  return DCTR_OK;
+}
 
 extern "C" int dctr_dense_opt_multi(const dctr_dense_item_t* items, int32_t n_items, int32_t opt, float lr, float eps,
                                     dctr_stream_t stream) {
@@ -179,6 +227,7 @@ extern "C" int dctr_dense_opt_multi(const dctr_dense_item_t* items, int32_t n_it
       const long long nb = (it.n + kChunk - 1) / kChunk;
       if (blocks + nb > 0x7FFFFFF0ll) return DCTR_ENOSUP;
       a.p[k] = it.p; a.g[k] = it.g; a.st[k] = opt == DCTR_UPD_ADAGRAD ? it.state : it.p; a.n[k] = it.n;
+      a.c2[k] = 2.f * it.l2;
       a.blk0[k] = static_cast<int>(blocks);
       blocks += nb;
     }

@@ -15,6 +15,7 @@ import ctypes
 import torch
 
 from . import lib as L
+from . import streams as _streams
 
 
 def _r4(n):
@@ -117,7 +118,7 @@ class DenseSlab(object):
         if self._pending is not None:
             self.join()
         if self._fork is None:
-            self._fork = torch.cuda.Stream(device=device)
+            self._fork = _streams.side_stream(device, "fork")
         return self._fork
 
     def side_chain_open(self, side):

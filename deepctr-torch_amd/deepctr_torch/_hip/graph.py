@@ -20,6 +20,8 @@ import gc
 
 import torch
 
+from . import streams as _streams
+
 
 @contextlib.contextmanager
 def no_gc_during_capture():
@@ -86,7 +88,8 @@ class GraphedTrainStep(object):
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             outs = []
-            with no_gc_during_capture(), torch.cuda.graph(g, pool=pool):
+            with no_gc_during_capture(), torch.cuda.graph(g, pool=pool,
+                                                          stream=_streams.side_stream(xb.device, "capture")):
                 try:
                     for j in range(self.S):
                         model._defer_dense_join = j < self.S - 1      # (see BaseModel._train_step_fused)
@@ -98,7 +101,7 @@ class GraphedTrainStep(object):
             self.graphs.append(g)
             self.outputs.append(outs)
         self.plan_version = plan.version
-        self._side = torch.cuda.Stream(device=xb.device)
+        self._side = _streams.side_stream(xb.device, "stage")
         self._ready = [torch.cuda.Event() for _ in range(self.n_slots)]
         self._free_ev = [torch.cuda.Event() for _ in range(self.n_slots)]
         self._free = [None] * self.n_slots
@@ -188,7 +191,7 @@ class GraphedTrainStep(object):
 
 def eager_warmup(model, batches):
     """Run the given (x, y) batches eagerly on a side stream, as torch's capture protocol wants."""
-    side = torch.cuda.Stream()
+    side = _streams.side_stream(torch.device("cuda", torch.cuda.current_device()), "warm")
     side.wait_stream(torch.cuda.current_stream())
     outs = None
     with torch.cuda.stream(side):

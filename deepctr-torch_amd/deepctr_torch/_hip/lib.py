@@ -57,7 +57,8 @@ class DenseStep(ctypes.Structure):
 
 class DenseItem(ctypes.Structure):
     """``dctr_dense_item_t`` (include/dctr.h): one tensor of a ``dctr_dense_opt_multi`` list."""
-    _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("state", ctypes.c_void_p), ("n", ctypes.c_int64)]
+    _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("state", ctypes.c_void_p), ("n", ctypes.c_int64),
+                ("l2", ctypes.c_float), ("pad_", ctypes.c_float)]
 
 
 PLAN_HAS_GACC, PLAN_HAS_STATE, PLAN_HAS_MAXPOOL = 1, 2, 4
@@ -151,6 +152,7 @@ SIGNATURES = {
     "dctr_dense_opt": (ctypes.c_int, [_P, _P, _P, _I64, _I32, _F32, _F32, _P]),
     "dctr_sizeof_dense_item": (ctypes.c_size_t, []),
     "dctr_dense_opt_multi": (ctypes.c_int, [ctypes.POINTER(DenseItem), _I32, _I32, _F32, _F32, _P]),
+    "dctr_l2_value_multi": (ctypes.c_int, [ctypes.POINTER(DenseItem), _I32, _P, _P]),
     "dctr_shard_assemble_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _I64, _P, _I32, _I32, _P, _P,
                                                _I32, _P, _I64, _P, _P, _P, _I64, _P]),
     "dctr_shard_assemble_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _I64, _P, _P, _P, _I64, _P,

@@ -16,6 +16,7 @@ import weakref
 import torch
 
 from . import lib as L
+from . import streams as _streams
 from ..inputs import DenseFeat, SparseFeat, VarLenSparseFeat, split_columns
 
 
@@ -583,7 +584,7 @@ class EmbeddingPlan(object):
         main = torch.cuda.current_stream(device)
         side = self._seg_stream
         if side is None or side.device != device:
-            side = self._seg_stream = torch.cuda.Stream(device=device)
+            side = self._seg_stream = _streams.side_stream(device, "seg")
         if fork:
             side.wait_stream(main)
         if before is not None:

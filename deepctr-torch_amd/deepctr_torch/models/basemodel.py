@@ -753,6 +753,8 @@ class BaseModel(nn.Module):
             st = self._fused_step_state()
             if st is not None:
                 return self._train_step_fused(st, xb, yb)
+        l2map = None      # {id(param): (param, lambda)}: L2 terms applied by the optimizer kernel instead of autograd
+        lazy_reg = None
         parts = self.logit_parts(xb) if self._bce_head_ok(xb) else None
         if parts is not None and not (0 < len(parts) <= 4 and yb.numel() == xb.shape[0] and all(
                 torch.is_tensor(q) and q.numel() == xb.shape[0] for q in parts)):
@@ -770,7 +772,12 @@ class BaseModel(nn.Module):
             self.optim.zero_grad()
             total_loss = loss.reshape(1)
             if self._has_reg_terms():
-                total_loss = total_loss + self.get_regularization_loss()
+                l2map = self._fusable_l2()
+                if l2map is None:
+                    total_loss = total_loss + self.get_regularization_loss()
+                elif self._plan is not None and self._plan.update[0] == "lazy":
+                    # the lazily regularised tables' term of the logged loss, on the weights the forward used
+                    lazy_reg = self._plan.lazy.reg_value(self.device)
             if not self._aux_is_default():
                 total_loss = total_loss + self.aux_loss
         else:
@@ -785,9 +792,51 @@ class BaseModel(nn.Module):
             total_loss = loss + self.get_regularization_loss() + self.aux_loss
         total_loss.backward()
         self._step_stacked_groups()
-        if not self._step_dense_multi():
+        done, reg = self._step_dense_multi(l2map)
+        if not done:
             self.optim.step()
-        return loss.detach(), total_loss.detach(), y_pred.detach()
+        total = total_loss.detach()
+        if reg is not None:       # the fused L2 terms (+ the lazily regularised tables') enter the LOGGED loss only
+            total = total + reg
+        if lazy_reg is not None:
+            total = total + lazy_reg
+        return loss.detach(), total, y_pred.detach()
+
+    def _fusable_l2(self):
+        """``{id(p): (p, lambda)}`` when every regularisation term of the model is a plain L2 term on a dense parameter
+        that ``_step_dense_multi`` is certain to step (one term per parameter; fp32, contiguous, on the GPU; the whole
+        optimizer a plain SGD / Adagrad with one lr): the kernel then adds ``2 lambda p`` to the gradient itself -- for
+        DCN's default ``l2_reg_cross`` the autograd route is ~40 launches of pow / mul / sum / add per step.  ``None``
+        when anything else is regularised (L1, a table on the dense-gradient route, a stacked weight group, ...)."""
+        if os.environ.get("DCTR_MULTI_STEP", "1") == "0" or os.environ.get("DCTR_FUSED_L2", "1") == "0":
+            return None
+        every = [p for grp in self.optim.param_groups for p in grp["params"]]
+        mode = self._dense_update_mode(every)
+        if mode is None or mode[0] not in ("sgd", "adagrad"):
+            return None
+        lazy_ids = set()
+        if self._plan is not None and self._plan.update[0] == "lazy":
+            lazy_ids = set(id(p) for p in self._plan.table_params)
+        stacked = set()
+        for mod in self.modules():
+            fn = getattr(mod, "stacked_weights", None)
+            sw = fn() if fn is not None else None
+            if sw is not None:
+                stacked.update(id(w) for w in sw[0])
+        known = set(id(p) for p in every)
+        out = {}
+        for weight_list, l1, l2 in self.regularization_weight:
+            if not (l1 > 0 or l2 > 0):
+                continue
+            for w in weight_list:
+                p = w[1] if isinstance(w, tuple) else w
+                if id(p) in lazy_ids:
+                    continue
+                if l1 > 0 or id(p) in out or id(p) in stacked or id(p) not in known or not p.is_cuda or \
+                        p.dtype != torch.float32 or not p.is_contiguous() or not p.requires_grad:
+                    return None
+                out[id(p)] = (p, float(l2))
+        return out
 
     def _bce_head_ok(self, xb):
         """True when the autograd-route step may take the fused prediction head: the reference's binary task --
@@ -809,18 +858,20 @@ class BaseModel(nn.Module):
             return True
         return any((l1 > 0 or l2 > 0) and len(weight_list) > 0 for weight_list, l1, l2 in self.regularization_weight)
 
-    def _step_dense_multi(self):
+    def _step_dense_multi(self, l2map=None):
         """One ``dctr_dense_opt_multi`` launch for every dense parameter autograd left a gradient on, when the compiled
         optimizer is a plain SGD / Adagrad over them (``_dense_update_mode``): ``torch.optim``'s foreach walk is five
         launches, 75-80 us per xDeepFM / FiBiNET / DCN step.  Returns True when it stepped EVERY such parameter
         (``optim.step()`` then has nothing to do and the gradients stay visible like the reference's); parameters it
         cannot take (non-contiguous, another dtype / device) are left to ``optim.step()`` with the stepped ones hidden."""
         if os.environ.get("DCTR_MULTI_STEP", "1") == "0":
-            return False
+            return False, None
         todo, rest = [], []
         for grp in self.optim.param_groups:
             for p in grp["params"]:
                 g = p.grad
+                if g is None and l2map and id(p) in l2map:
+                    g = p.grad = torch.zeros_like(p)      # (autograd would have left 2 lambda p here)
                 if g is None:
                     continue
                 if p.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32 and p.is_contiguous() and \
@@ -828,30 +879,44 @@ class BaseModel(nn.Module):
                     todo.append(p)
                 else:
                     rest.append(p)
+        if l2map and any(id(p) in l2map for p in rest):
+            raise RuntimeError("an L2-regularised parameter changed its layout during the step")
         if not todo:
-            return False
+            return False, None
         mode = self._dense_update_mode(todo)
         if mode is None or mode[0] not in ("sgd", "adagrad"):
-            return False
+            if l2map:
+                raise RuntimeError("the optimizer changed under a train step with fused L2 terms")
+            return False, None
         import ctypes
         from .._hip import lib as L
         if mode[0] == "adagrad":
             sums = [self.optim.state[p]["sum"] for p in todo]
             if any(s.dtype != torch.float32 or not s.is_contiguous() or s.device != p.device or s.shape != p.shape
                    for s, p in zip(sums, todo)):
-                return False
+                if l2map:
+                    raise RuntimeError("Adagrad state of an L2-regularised parameter is not a plain fp32 tensor")
+                return False, None
         items = (L.DenseItem * len(todo))()
         for i, p in enumerate(todo):
             items[i].p, items[i].g, items[i].n = p.data_ptr(), p.grad.data_ptr(), p.numel()
             items[i].state = sums[i].data_ptr() if mode[0] == "adagrad" else None
+            items[i].l2 = l2map[id(p)][1] if (l2map and id(p) in l2map) else 0.0
+        stream = L.stream_handle(todo[0].device)
+        reg = None
+        if l2map:
+            # value of the fused terms on the weights the forward used (before the step), for the logged loss
+            reg = torch.empty((1,), dtype=torch.float32, device=todo[0].device)
+            L.check(L.lib().dctr_l2_value_multi(items, len(todo), ctypes.c_void_p(reg.data_ptr()), stream),
+                    "dctr_l2_value_multi")
         L.check(L.lib().dctr_dense_opt_multi(items, len(todo), L.UPD_ADAGRAD if mode[0] == "adagrad" else L.UPD_SGD,
-                                             float(mode[1]), float(mode[2]) if len(mode) > 2 else 0.0,
-                                             L.stream_handle(todo[0].device)), "dctr_dense_opt_multi")
+                                             float(mode[1]), float(mode[2]) if len(mode) > 2 else 0.0, stream),
+                "dctr_dense_opt_multi")
         if rest:
             for p in todo:
                 p.grad = None
-            return False
-        return True
+            return False, reg
+        return True, reg
 
     def _step_stacked_groups(self):
         """Layers that keep many small parameters as slices of one slab (FiBiNET's 2 x 325 bilinear ``nn.Linear``

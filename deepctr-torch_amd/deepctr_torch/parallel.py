@@ -395,7 +395,10 @@ class _Segment(object):
             g = torch.cuda.CUDAGraph()
             # thread-local capture mode: RCCL's watchdog thread keeps polling events while we capture
             from ._hip.graph import no_gc_during_capture
-            with no_gc_during_capture(), torch.cuda.graph(g, capture_error_mode="thread_local"):
+            from ._hip import streams as _streams
+            dev = torch.device("cuda", torch.cuda.current_device())
+            with no_gc_during_capture(), torch.cuda.graph(g, capture_error_mode="thread_local",
+                                                          stream=_streams.side_stream(dev, "capture")):
                 self.result = self.fn()
             self.graph = g
         self.graph.replay()
@@ -547,7 +550,8 @@ class ShardedTrainer(object):
         if wgrad is not None:
             main = torch.cuda.current_stream(xb.device)
             if self._side is None:
-                self._side = torch.cuda.Stream(device=xb.device)
+                from ._hip import streams as _streams
+                self._side = _streams.side_stream(xb.device, "shard")
             self._side.wait_stream(main)
             wgrad(self._side)
         dist.all_to_all_single(self._grads_all, send, group=self.group)              # row gradients (+ next ids)

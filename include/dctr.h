@@ -537,10 +537,16 @@ typedef struct dctr_dense_item {
   const float* g;
   float* state;
   int64_t n;
+  float l2;   /* lambda of an L2 term lambda * sum(p^2) on this tensor (basemodel.py:412-428), 0: none.  The step then
+               * uses g + 2*lambda*p -- what autograd adds to .grad for the term (rounded like autograd: product, sum) */
+  float pad_;
 } dctr_dense_item_t;
 size_t dctr_sizeof_dense_item(void);
 int dctr_dense_opt_multi(const dctr_dense_item_t* items, int32_t n_items, int32_t opt, float lr, float eps,
                          dctr_stream_t stream);
+/* out[0] = sum_i l2_i * sum(p_i^2): the value of those terms for the logged loss; one workgroup, fixed summation order.
+ * (g / state of the items are not read.)                                                                            */
+int dctr_l2_value_multi(const dctr_dense_item_t* items, int32_t n_items, float* out, dctr_stream_t stream);
 
 /* ---- table-sharded multi-GPU exchange: the two "assemble" kernels (csrc/shard.hip, deepctr_torch/parallel.py) ---
  * Rank q of N owns units q, q+N, q+2N, ... (a unit = one id column with its deep and/or wide table).  Owners gather

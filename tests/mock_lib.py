@@ -179,9 +179,22 @@ class _Core(object):
         for i in range(n_items):
             it = items[i]
             if it.n:
+                if it.l2:
+                    G = _arr(ctypes.c_void_p(it.g), (it.n,))
+                    G += (np.float32(2.0) * np.float32(it.l2)) * _arr(ctypes.c_void_p(it.p), (it.n,))
                 self.dctr_dense_opt(ctypes.c_void_p(it.p), ctypes.c_void_p(it.g),
                                     ctypes.c_void_p(it.state) if it.state else None, it.n, opt, lr, eps, stream)
         self.calls.append("dense_opt_multi")
+        return 0
+
+    def dctr_l2_value_multi(self, items, n_items, out, stream):
+        tot = 0.0
+        for i in range(n_items):
+            it = items[i]
+            if it.n and it.l2:
+                P = _arr(ctypes.c_void_p(it.p), (it.n,)).astype(np.float64)
+                tot += float(it.l2) * float((P * P).sum())
+        _arr(out, (1,))[0] = tot
         return 0
 
     # ---- fused gather (include/dctr.h: dctr_embed_fwd), fixed-length fields only ----------------------------

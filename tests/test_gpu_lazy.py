@@ -6,6 +6,8 @@ small batches over small vocabularies: most rows are untouched by a step and tou
 reference updates every row at every step (dense gradients, O(vocabulary)); the drop-in replays each row's steps when
 it is next needed (O(batch)) and must land on the same parameters, losses, predictions and optimizer state.
 Tolerance: 2e-5 x max|reference| (fp32 re-association; the recurrences are the same)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -190,3 +192,39 @@ def test_fit_graph_replays_leave_tables_flushed(monkeypatch, name, opt):
         _close(k, a[k].cpu().numpy(), b[k].cpu().numpy(), tol=1e-6)
     np.testing.assert_allclose(ha["loss"], hb["loss"], rtol=1e-6)
     assert max_abs(pa, pb) <= 1e-6
+
+
+def test_side_streams_never_alias_after_many_stream_objects():
+    """torch hands out its 32 pool streams round-robin: a process that has created a few dozen stream objects (a dozen
+    models used to do that) gets the SAME queue again under a new object.  The package's side streams -- pre-pass,
+    weight-gradient fork, batch staging, warm-up, capture -- must stay pairwise distinct and distinct from whatever
+    torch hands out next, or two 'different' streams of one hipGraph capture are one queue (a segmentation fault at the
+    first replay, once 14 earlier tests of this file had run)."""
+    from deepctr_torch._hip import streams
+    junk = [torch.cuda.Stream() for _ in range(45)]           # wrap the pool around
+    got = [streams.side_stream(DEV, r) for r in streams.ROLES]
+    assert len(set(s.stream_id for s in got)) == len(streams.ROLES)
+    assert all(streams.side_stream(DEV, r) is s for r, s in zip(streams.ROLES, got))      # created once
+    # and a graphed fit still replays correctly with the pool wrapped around
+    g = load_golden("lazy_deepfm")
+    Xs, ys = g["extra"]["lazy_X"], g["extra"]["lazy_y"]
+    X, y = np.concatenate(list(Xs), 0), np.concatenate(list(ys), 0)
+    bs = Xs[0].shape[0]
+    names = []
+    for c in g["spec"]["linear_columns"] + g["spec"]["dnn_columns"]:
+        if c["name"] not in names:
+            names.append(c["name"])
+    hists = []
+    for flag in ("1", "0"):
+        os.environ["DCTR_FIT_GRAPH"] = flag
+        try:
+            m = build_model(g["spec"], DEV, l2=1e-3)
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in g["params"].items()})
+            m.compile("adagrad", "binary_crossentropy", metrics=[])
+            fi = m.feature_index
+            hists.append(m.fit({nm: X[:, fi[nm][0]] for nm in names}, y, batch_size=bs, epochs=3, verbose=0,
+                               shuffle=False).history["loss"])
+        finally:
+            os.environ.pop("DCTR_FIT_GRAPH", None)
+    np.testing.assert_allclose(hists[0], hists[1], rtol=1e-6)
+    del junk
