@@ -118,6 +118,8 @@ SIGNATURES = {
     "dctr_cin_bwd_workspace_floats": (ctypes.c_size_t, [_I32, _I32, _I32, _I32, _I32]),
     "dctr_cin_layer_bwd": (ctypes.c_int, [_P, _P, _I64, _I32, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _P, _I64,
                                           _P, _I64, _I32, _P, _P, _P, _P]),
+    "dctr_cin_pool_fwd": (ctypes.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P]),
+    "dctr_cin_pool_bwd": (ctypes.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "dctr_senet_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P, _P]),
     "dctr_senet_bwd_workspace_floats": (ctypes.c_size_t, [_I32, _I32, _I32]),
     "dctr_senet_bwd": (ctypes.c_int, [_P, _P, _I64, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P]),

@@ -520,8 +520,10 @@ class CINLayerPooledFunction(torch.autograd.Function):
         O = A.shape[1]
         ctx.relu, ctx.has_bias, ctx.n_hidden, ctx.split = bool(relu), bias is not None, int(n_hidden), bool(split)
         ctx.save_for_backward(H, X0, W2d, A if relu else None)
-        direct = A[:, n_hidden:] if split else A
-        pooled = direct.sum(-1)
+        nh_pool = n_hidden if split else 0
+        pooled = torch.empty((A.shape[0], O - nh_pool), dtype=torch.float32, device=A.device)
+        L.check(L.lib().dctr_cin_pool_fwd(_ptr(A), A.shape[0], O, A.shape[2], nh_pool, _ptr(pooled),
+                                          L.stream_handle(A.device)), "dctr_cin_pool_fwd")
         hidden = A[:, :n_hidden] if n_hidden > 0 else A.new_zeros((A.shape[0], 0, A.shape[2]))
         ctx.O = O
         return hidden, pooled
@@ -538,15 +540,10 @@ class CINLayerPooledFunction(torch.autograd.Function):
         nh = ctx.n_hidden
         if ctx.split:
             gA = torch.empty((B, O, D), dtype=torch.float32, device=dev)
-            if nh > 0:
-                if g_hidden is not None:
-                    gA[:, :nh].copy_(g_hidden)
-                else:
-                    gA[:, :nh].zero_()
-            if g_pooled is not None:
-                gA[:, nh:].copy_(g_pooled.unsqueeze(2).expand(B, O - nh, D))
-            else:
-                gA[:, nh:].zero_()
+            gh = g_hidden.contiguous() if (nh > 0 and g_hidden is not None) else None
+            gp = g_pooled.contiguous() if g_pooled is not None else None
+            L.check(lib.dctr_cin_pool_bwd(_ptr(gh), _ptr(gp), B, O, D, nh, _ptr(gA), L.stream_handle(dev)),
+                    "dctr_cin_pool_bwd")
         else:           # every row is both hidden state and direct connect
             if g_hidden is not None and g_pooled is not None:
                 gA = g_hidden + g_pooled.unsqueeze(2)

@@ -347,6 +347,15 @@ int dctr_cin_layer_bwd(const float* gA, const float* A, int64_t ld_a, int32_t re
                        int32_t O, float* gH, int64_t ld_gh, float* gX0, int64_t ld_gx, int32_t accumulate_x0,
                        float* gW, float* gbias, float* workspace, dctr_stream_t stream);
 
+/* The layer's "direct connect" rows as xDeepFM consumes them (interaction.py:226-246: split / cat / sum(-1)):
+ *   dctr_cin_pool_fwd: pooled[b, o] = sum_d A[b, n_hidden + o, d]   (A [B, O, D] contiguous, pooled [B, O - n_hidden])
+ *   dctr_cin_pool_bwd: gA[b, o, :] = g_hidden[b, o, :] for o < n_hidden (g_hidden [B, n_hidden, D] contiguous, NULL = 0),
+ *                      g_pooled[b, o - n_hidden] for every d otherwise (NULL = 0)                                    */
+int dctr_cin_pool_fwd(const float* A, int32_t B, int32_t O, int32_t D, int32_t n_hidden, float* pooled,
+                      dctr_stream_t stream);
+int dctr_cin_pool_bwd(const float* g_hidden, const float* g_pooled, int32_t B, int32_t O, int32_t D, int32_t n_hidden,
+                      float* gA, dctr_stream_t stream);
+
 /* ---- SENET / Bilinear / InnerProduct (csrc/pairwise.hip) ----------------------------------------------
  * SENETLayer (interaction.py:93-101): z = mean_d E; a1 = relu(z W1^T); a = relu(a1 W2^T); V = E * a[:, :, None]
  *   E [B, F, D] rows at E + b*ld_e;  W1 [R, F], W2 [F, R] (excitation.0 / .2 weights);  V [B, F*D] contiguous;

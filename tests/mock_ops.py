@@ -253,6 +253,22 @@ class OpsMixin(object):
             _v(gbias, O).copy_(gb)
         return 0
 
+    def dctr_cin_pool_fwd(self, A, B, O, D, n_hidden, pooled, stream):
+        self.calls.append("cin_pool_fwd")
+        a = _t(A, B, O * D).reshape(B, O, D)
+        _t(pooled, B, O - n_hidden).copy_(a[:, n_hidden:].double().sum(-1).float())
+        return 0
+
+    def dctr_cin_pool_bwd(self, g_hidden, g_pooled, B, O, D, n_hidden, gA, stream):
+        self.calls.append("cin_pool_bwd")
+        g = _t(gA, B, O * D).reshape(B, O, D)
+        gh = _t(g_hidden, B, n_hidden * D) if n_hidden else None
+        gp = _t(g_pooled, B, O - n_hidden)
+        if n_hidden:
+            g[:, :n_hidden] = gh.reshape(B, n_hidden, D) if gh is not None else 0.0
+        g[:, n_hidden:] = gp[:, :, None] if gp is not None else 0.0
+        return 0
+
     # ---- CrossNet (vector) --------------------------------------------------------------------------------------------
     @staticmethod
     def _cross(X, K, Bv):
