@@ -639,6 +639,9 @@ class BaseModel(nn.Module):
         GPU kernels for the lookups / interactions / tower)."""
         if os.environ.get("DCTR_FUSED_STEP", "1") == "0":
             return None
+        # a user's forward hooks on the model / its prediction layer see module calls only on the stock route
+        if self._forward_hooks or self._forward_pre_hooks or self.out._forward_hooks or self.out._forward_pre_hooks:
+            return None
         if self._fused is not None and self._fused.get("optim") is getattr(self, "optim", None) and \
                 (self._fused["slab"] is None or self._fused["slab"].intact()):
             return self._fused if self._fused["ok"] else None
@@ -847,6 +850,10 @@ class BaseModel(nn.Module):
         from ..layers.core import PredictionLayer
         if self.loss_func is not F.binary_cross_entropy or type(self.out) is not PredictionLayer or \
                 self.out.task != "binary" or getattr(self, "num_tasks", 1) != 1:
+            return False
+        # (a user's hooks on the model or on its prediction layer must keep firing: they see the module calls only on the
+        # stock route)
+        if self._forward_hooks or self._forward_pre_hooks or self.out._forward_hooks or self.out._forward_pre_hooks:
             return False
         cls = type(self)
         return cls.forward is BaseModel.forward and cls.logit_parts is not BaseModel.logit_parts

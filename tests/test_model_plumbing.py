@@ -289,3 +289,30 @@ def test_inner_products_beyond_the_backward_envelope(mock):
     assert pairwise_products(big, False).shape == (2, 990, 16) and "inner_product_fwd" not in mock.calls
     assert InnerProductLayer(device="cpu")([t for t in big.split(1, dim=1)]).shape == (2, 990, 1)
     assert "inner_product_fwd" in mock.calls            # with the sum the backward image is small: kernel
+
+
+@pytest.mark.parametrize("name", ["deepfm_criteo", "dcn_vector"])
+def test_forward_hooks_keep_firing_in_train_steps(mock, name):
+    """The fast train steps do not call ``model.out`` / ``model.forward`` (fused step: one tower + head + loss kernel;
+    autograd route: one head kernel).  A user's forward hook on either must still fire, as under the reference
+    (basemodel.py:242-254 calls ``model(x)``): with hooks registered the step takes the stock module route, and
+    lands on the same parameters."""
+    g = load_golden(name)
+    finals = []
+    for hooked in (False, True):
+        m = build_model(g["spec"], "cpu")
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in g["params"].items()})
+        m.compile("adagrad", "binary_crossentropy", metrics=[])
+        m.train()
+        seen = []
+        if hooked:
+            m.out.register_forward_pre_hook(lambda mod, inp: seen.append(tuple(inp[0].shape)))
+        mock.calls.clear()
+        for _ in range(2):
+            m._train_step(torch.from_numpy(g["X"]), torch.from_numpy(g["y"]))
+        assert len(seen) == (2 if hooked else 0)
+        fast = any(c in ("mlp_train_step", "bce_head") for c in mock.calls)
+        assert fast != hooked
+        finals.append({k: v.clone() for k, v in m.state_dict().items()})
+    for k in finals[0]:
+        assert max_abs(finals[0][k].numpy(), finals[1][k].numpy()) <= 2e-5 * max(1.0, float(finals[0][k].abs().max())), k
