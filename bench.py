@@ -305,6 +305,7 @@ def time_steps(model, X, y, B, steps, warmup, S, use_graph):
 
 # BASELINE.json configs[2] and configs[3]: same Criteo shape, other interaction layers
 MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA peak
+MFMA_MEASURED_TFLOPS = 133.0
 OTHER = {
     "xdeepfm": dict(cls="xDeepFM", kwargs=dict(dnn_hidden_units=(256, 256), cin_layer_size=(128, 128), cin_split_half=True),
                     flop_per_sample=29.9e6, ref="xdeepfm.py:79-107, interaction.py:207-248",
@@ -345,7 +346,10 @@ def other_config(name, args, device, X, y):
                "warmup": did, "hip_graph": graphed, "final_loss": float(out[0].item()),
                "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": tf / MFMA_PEAK_TFLOPS, "flop_per_sample": spec["flop_per_sample"],
-                            "traffic": None}}
+                            "traffic": None,
+                            # what the fp32 matrix pipe delivers on this chip under load (tools/micro/mfmabench.hip,
+                            # profiles/r02_mfmabench.jsonl: one v_mfma_f32_32x32x2 per 64 cycles at the 2.13 GHz held)
+                            "peak_measured": MFMA_MEASURED_TFLOPS, "frac_of_measured": tf / MFMA_MEASURED_TFLOPS}}
         del model
         torch.cuda.empty_cache()
         return res
