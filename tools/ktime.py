@@ -8,7 +8,7 @@ import bench
 
 
 class A:
-    vocab, batch, optimizer = 1_000_000, 4096, "adagrad"
+    vocab, batch, optimizer, ids = 1_000_000, 4096, "adagrad", "uniform"
 
 
 for opt in sys.argv[1:] or ["adagrad"]:
@@ -17,6 +17,6 @@ for opt in sys.argv[1:] or ["adagrad"]:
     for Bsz in (4096, 32768):
         gen = torch.Generator().manual_seed(0)
         X = torch.cat([torch.randint(0, A.vocab, (Bsz, 26), generator=gen).float(), torch.rand(Bsz, 13, generator=gen)], 1).to("cuda:0")
-        k = bench.time_hot_kernels(model, X, None, 30, opt)
+        k = bench.time_hot_kernels(model, X, Bsz, 30, opt)
         alg = bench.algorithmic_bytes(Bsz, opt)
         print(opt, Bsz, {n: "%.1fus %.0fGB/s" % (v["min_us"], alg[n] / v["min_us"] / 1e3) for n, v in k.items()})

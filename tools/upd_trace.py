@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Where does k_embed_update spend its time?  Runs the DeepFM bench model's update kernel on ROTATING batches (so
+"""Where does k_embed_update (the general update kernel; the pre-sorted path: tools/zipf_update_probe.py) spend its time?  Runs the DeepFM bench model's update kernel on ROTATING batches (so
 table rows come from HBM, not from the 256 MB Infinity Cache like a same-batch timing loop) with per-workgroup
 phase timestamps, and prints phase statistics + event-timed durations for a few partition counts.
     python tools/upd_trace.py [--opt adagrad] > gpurun_out/upd_trace.json"""
@@ -14,6 +14,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "deepctr-torch_amd"))
 import torch  # noqa: E402
 
+from deepctr_torch._hip import lib as _L  # noqa: E402
+
+_L.use_diag_library()   # make -C deepctr-torch_amd/csrc diag
+
 import bench  # noqa: E402
 
 
@@ -22,7 +26,7 @@ def main():
     ap.add_argument("--opt", default="adagrad")
     ap.add_argument("--batch", type=int, default=4096)
     a = ap.parse_args()
-    args = argparse.Namespace(batch=a.batch, vocab=1_000_000, optimizer=a.opt)
+    args = argparse.Namespace(batch=a.batch, vocab=1_000_000, optimizer=a.opt, ids="uniform")
     dev = "cuda:0"
     model = bench.build_model(args, dev)
     X, y = bench.synth(args, dev, 0)
@@ -39,12 +43,14 @@ def main():
     wide, fm = torch.empty(B, device=dev), torch.empty(B, device=dev)
     fm_s = torch.empty(B, 16, device=dev)
     ids = [torch.empty(len(plan.units), B, dtype=torch.int32, device=dev) for _ in range(nb)]
+    parts = [torch.empty(len(plan.units), B, dtype=torch.int16, device=dev) for _ in range(nb)]
     outs = []
-    for j in range(nb):     # forward once per batch to get ids_t / out / fm_s (kept per batch)
+    for j in range(nb):     # forward once per batch to get ids_t / parts_t / out / fm_s (kept per batch)
         o = torch.empty(B, plan.ld_out, device=dev)
         fs = torch.empty(B, 16, device=dev)
         L.check(lib.dctr_embed_fwd(cplan, _ptr(X[j * B:]), X.stride(0), B, _ptr(o), plan.ld_out, _ptr(wide), 1, _ptr(fm),
-                                   None, plan.units_ptr(), len(plan.units), _ptr(ids[j]), _ptr(fs), 16, s))
+                                   None, plan.units_ptr(), len(plan.units), _ptr(ids[j]), _ptr(parts[j]), _ptr(fs), 16,
+                                   s))
         outs.append((o, fs))
     g_out = torch.randn(B, plan.ld_out, device=dev) * 1e-3
     g_fm, g_wide = torch.randn(B, device=dev) * 1e-3, torch.randn(B, device=dev) * 1e-3
@@ -52,17 +58,16 @@ def main():
     eps = float(plan.update[2]) if a.opt == "adagrad" else 0.0
     code = L.UPD_ADAGRAD if a.opt == "adagrad" else L.UPD_SGD
 
-    ws, ws_n = plan.update_workspace(B, dev)
-
-    def upd(j):
+    def upd(j):     # the GENERAL kernel (every workgroup scans and sorts for itself): the one that carries the stamps
         o, fs = outs[j]
-        L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids[j]), B,
-                                      _ptr(g_out), plan.ld_out, _ptr(o), plan.ld_out, _ptr(fs), 16, _ptr(g_fm),
-                                      _ptr(g_wide), 1, code, lr, eps, None, 0, None, _ptr(ws), ws_n, s))
+        L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids[j]),
+                                      _ptr(parts[j]), B, _ptr(g_out), plan.ld_out, _ptr(o), plan.ld_out, _ptr(fs), 16,
+                                      _ptr(g_fm), _ptr(g_wide), 1, code, lr, eps, None, 0, None, None, None, 0, 0, s))
 
     def fwd(j):
         L.check(lib.dctr_embed_fwd(cplan, _ptr(X[j * B:]), X.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), 1, _ptr(fm),
-                                   None, plan.units_ptr(), len(plan.units), _ptr(ids[j]), _ptr(fm_s), 16, s))
+                                   None, plan.units_ptr(), len(plan.units), _ptr(ids[j]), _ptr(parts[j]), _ptr(fm_s), 16,
+                                   s))
 
     def timed(fn, rot, n=48):
         for j in range(4):
