@@ -1206,6 +1206,10 @@ struct ReduceArgs {
   DenseStepDev step;               // kind >= 0: also step the parameter behind every gradient element written
 };
 
+// (Folding this reduction into k_mlp_wgrad -- the last of a tile's S workgroups to arrive sums the partials -- was
+// measured in round 2: correct, and TWICE the step time (0.223 vs 0.113 ms).  The partials must cross XCDs, i.e. every
+// workgroup needs an agent-scope release fence, and on this part that is a write-back of the whole per-XCD L2, issued
+// 296 times beside an embedding update that keeps the L2 full of dirty table lines.  A kernel boundary does it once.)
 __global__ __launch_bounds__(256) void k_mlp_reduce(ReduceArgs A) {
   if (A.head_loss && blockIdx.x == gridDim.x - 1) {   // fixed-order tree over the row tiles' partial sums
     __shared__ float red[2][4];
