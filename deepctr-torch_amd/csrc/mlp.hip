@@ -1294,10 +1294,11 @@ WgradPlan plan_wgrad(const dctr_mlp_t* m, int32_t B) {
   WgradPlan P;
   // Batch slices per output tile.  Measured on the DeepFM tower at batch 4096 (37 tiles; step time in ms): S = 3 0.137,
   // 4 0.123, 5 0.118, 6 0.114, 7 0.116, 8 0.113, 10 0.1115, 12 0.1116, 16 0.115 -- more, shorter workgroups win until the
-  // partial slabs' traffic does (keeping the launch within one wave of 256 workgroups, S = 6, is NOT better).
-  int S = B / 512;
+  // partial slabs' traffic does (keeping the launch within one wave of 256 workgroups, S = 6, is NOT better): ~410 rows per slice.
+  // (re-measured at the end of round 2 with everything else in place: 8 slices 0.1138, 10 0.1124, 12 0.1129, 14 0.1152)
+  int S = (B + 205) / 410;
   if (S < 1) S = 1;
-  if (S > 8) S = 8;
+  if (S > 12) S = 12;
   P.S = S;
   P.bs = round_up((B + S - 1) / S, 8);
   int64_t off = 0;
