@@ -1,0 +1,101 @@
+"""GPU: the multi-tensor optimizer step of the autograd-route train step (csrc/head.hip: dctr_dense_opt_multi,
+dctr_l2_value_multi) against torch.optim on the same tensors, and the CIN pooling kernels (csrc/cin.hip:
+dctr_cin_pool_fwd / _bwd) against the reference's split / sum(-1) formulation (interaction.py:226-246).
+
+The optimizer kernel replaces ``torch.optim.SGD / Adagrad.step()`` (basemodel.py:262) and, for L2 terms, the part of
+``get_regularization_loss()`` (basemodel.py:412-428) that reaches the gradients through autograd: both are elementwise
+fp32 recurrences, so the comparison is (near) bit-level: rtol 2e-7 plus atol 1e-8 -- one ulp of the step term
+lr * g / (sqrt(s) + eps) for parameters of magnitude ~1 (the kernel contracts s + g*g into an fma)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _items(L, params, grads, states, l2s):
+    items = (L.DenseItem * len(params))()
+    for i, p in enumerate(params):
+        items[i].p, items[i].g, items[i].n = p.data_ptr(), grads[i].data_ptr(), p.numel()
+        items[i].state = states[i].data_ptr() if states is not None else None
+        items[i].l2 = l2s[i]
+    return items
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
+@pytest.mark.parametrize("with_l2", [False, True])
+def test_multi_tensor_step_matches_torch_optim(opt, with_l2):
+    from deepctr_torch._hip import lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(3)
+    # odd sizes, a tensor longer than one 4096-element chunk, 60 tensors (two launches of 48), misaligned views
+    shapes = [(1,), (3,), (7, 5), (4097,), (128, 65), (1000,)] + [(17 + i,) for i in range(54)]
+    base = [torch.randn(int(np.prod(s)) + 3, generator=g).to(DEV) for s in shapes]
+    params = [b[1:1 + int(np.prod(s))].view(s) if i % 3 == 0 else b[:int(np.prod(s))].view(s)
+              for i, (b, s) in enumerate(zip(base, shapes))]          # every third one starts 4 bytes off alignment
+    l2s = [(1e-3 if (with_l2 and i % 2 == 0) else 0.0) for i in range(len(params))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in params]
+    lr, eps = 0.01, 1e-10
+    optim = torch.optim.SGD(ref, lr=lr) if opt == "sgd" else torch.optim.Adagrad(ref, lr=lr, eps=eps)
+    states = [torch.zeros_like(p) for p in params] if opt == "adagrad" else None
+    for step in range(3):
+        grads = [torch.randn(p.shape, generator=g).to(DEV) * (10.0 ** (step - 1)) for p in params]
+        # reference: the main gradient plus what autograd adds for lambda * sum(p^2), then the optimizer
+        optim.zero_grad()
+        reg = sum(torch.sum(l * torch.square(r)) for r, l in zip(ref, l2s) if l > 0) if with_l2 else None
+        if reg is not None:
+            reg.backward()
+        for r, gr in zip(ref, grads):
+            r.grad = gr.clone() if r.grad is None else r.grad + gr
+        reg_ref = float(reg.detach()) if reg is not None else 0.0
+        items = _items(L, params, grads, states, l2s)
+        if with_l2:
+            out = torch.empty(1, device=DEV)
+            L.check(lib.dctr_l2_value_multi(items, len(params), ctypes.c_void_p(out.data_ptr()), L.stream_handle(DEV)))
+            assert abs(float(out) - reg_ref) <= 1e-5 * max(1.0, abs(reg_ref))
+        optim.step()
+        L.check(lib.dctr_dense_opt_multi(items, len(params), L.UPD_ADAGRAD if opt == "adagrad" else L.UPD_SGD, lr, eps,
+                                         L.stream_handle(DEV)))
+        torch.cuda.synchronize()
+        for i, (p, r) in enumerate(zip(params, ref)):
+            np.testing.assert_allclose(p.cpu().numpy(), r.detach().cpu().numpy(), rtol=2e-7, atol=1e-8,
+                                       err_msg="tensor %d step %d" % (i, step))
+            if opt == "adagrad":
+                # (s + g*g as one fma here, a product and a sum in torch: up to ~2 ulp)
+                np.testing.assert_allclose(states[i].cpu().numpy(), optim.state[r]["sum"].cpu().numpy(), rtol=5e-7,
+                                           atol=1e-10)
+    for b, s in zip(base, shapes):       # nothing written outside the views
+        assert torch.isfinite(b).all()
+
+
+@pytest.mark.parametrize("B,O,D,nh", [(5, 8, 16, 4), (4096, 128, 16, 64), (33, 7, 5, 0), (2, 6, 16, 6)])
+def test_cin_pool_kernels_match_split_sum(B, O, D, nh):
+    from deepctr_torch._hip import lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(B + O)
+    A = torch.randn(B, O, D, generator=g).to(DEV)
+    if nh < O:
+        pooled = torch.empty(B, O - nh, device=DEV)
+        L.check(lib.dctr_cin_pool_fwd(ctypes.c_void_p(A.data_ptr()), B, O, D, nh, ctypes.c_void_p(pooled.data_ptr()),
+                                      L.stream_handle(DEV)))
+        ref = A[:, nh:].double().sum(-1)
+        assert float((pooled.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    gh = torch.randn(B, nh, D, generator=g).to(DEV) if nh > 0 else None
+    gp = torch.randn(B, O - nh, generator=g).to(DEV) if nh < O else None
+    gA = torch.full((B, O, D), float("nan"), device=DEV)
+    L.check(lib.dctr_cin_pool_bwd(ctypes.c_void_p(gh.data_ptr()) if gh is not None else None,
+                                  ctypes.c_void_p(gp.data_ptr()) if gp is not None else None, B, O, D, nh,
+                                  ctypes.c_void_p(gA.data_ptr()), L.stream_handle(DEV)))
+    want = torch.zeros(B, O, D, device=DEV)
+    if nh > 0:
+        want[:, :nh] = gh
+    if nh < O:
+        want[:, nh:] = gp[:, :, None]
+    assert torch.equal(gA, want)
+    # NULL inputs mean zero
+    gA.fill_(float("nan"))
+    L.check(lib.dctr_cin_pool_bwd(None, None, B, O, D, nh, ctypes.c_void_p(gA.data_ptr()), L.stream_handle(DEV)))
+    assert torch.equal(gA, torch.zeros_like(gA))
