@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--force-parallel", action="store_true", help="use the data-parallel trainer even with 1 rank")
     ap.add_argument("--kernel-iters", type=int, default=50, help="event-timed launches per hot-path kernel")
     ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--diag-trace", default="",
+                    help="development: load libdctr_hip_diag.so and save the tower kernels' per-workgroup phase stamps of "
+                         "the last timed step (as replayed from the hipGraph) to this .npy file (tools/tower_trace.py)")
     return ap.parse_args()
 
 
@@ -382,6 +385,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
+    trace_buf = None
+    if args.diag_trace:
+        import ctypes
+        from deepctr_torch._hip import lib as L
+        L.use_diag_library()
+        trace_buf = torch.zeros(3 * 4096 * 16, dtype=torch.int64, device=device)
+        L.lib().dctr_dbg_mlp_trace(ctypes.c_void_p(trace_buf.data_ptr()))   # before any capture: graphs bake it in
     model = build_model(args, device)
     X, y = synth(args, device, rank)
     B = args.batch
@@ -434,6 +444,9 @@ def main():
         elapsed = float(t.item())
     last_loss = float(out[0].item())
     model.model_plan().check_ids()
+    if trace_buf is not None:
+        import numpy as np
+        np.save(args.diag_trace, trace_buf.view(3, 4096, 16).cpu().numpy())
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3

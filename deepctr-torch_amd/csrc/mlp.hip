@@ -71,6 +71,9 @@ struct MlpArgs {
   int rsx, rsh;      // LDS row strides (floats) of the forward
   int kc;            // columns of the tower input staged in LDS at a time (<= kKC; smaller for wide towers)
   int rsd;           // LDS row stride of the backward-data pass
+  int fast;          // 1: the tower fits the fast bodies (mlp_fwd_fast / mlp_bwd_fast)
+  uint32_t wmask;    // diagnostics: AND mask on the weight byte offsets (0xffffffff normally; DCTR_MLP_WMASK in the diag build
+                     // folds the weight stream onto a few KB that stay in L1 -- timing experiment, wrong results)
   unsigned long long* trace;
 };
 
@@ -87,6 +90,11 @@ struct HeadArgs {
 };
 
 __device__ __forceinline__ f32x4 ldg_f4(const float* p) { return *(const DCTR_GLOBAL f32x4*)p; }
+
+// the fast bodies (defined behind the general ones)
+__device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* smem, float* logit_lds);
+__device__ __forceinline__ void mlp_bwd_fast(const MlpArgs& A, float* smem, const float* g_lds, const float* hb0,
+                                             const float* hb1, int rs_h);
 
 // diagnostics (tools/mlp_trace.py): 16 wall_clock64 stamps per workgroup, or NULL -- only in the DCTR_DIAG build
 // (libdctr_hip_diag.so); the shipped library keeps no mutable global state
@@ -212,8 +220,9 @@ __device__ __forceinline__ void fwd_dispatch(int nt, const float* As, int rs, in
 // CROSS: the layers are the matrix form of CrossNet (interaction.py:448-451) instead of Linear + activation:
 //     u_l = x_l W_l^T + b_l ;  x_{l+1} = x_0 (.) u_l + x_l          (every layer W x W, x_0 = the staged input tile)
 // u_l is parked in the layer's `dh` buffer (the backward needs it and overwrites it with its own d loss / d u_l).
+// Returns the LDS tile [16][rsh] that holds the top layer's output when the body ends.
 template <bool CROSS = false>
-__device__ __forceinline__ void mlp_fwd_body(const MlpArgs& A, float* smem, float* logit_lds) {
+__device__ __forceinline__ const float* mlp_fwd_body(const MlpArgs& A, float* smem, float* logit_lds) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * kTM;
   const int rsx = A.rsx, rsh = A.rsh;
@@ -223,6 +232,13 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpArgs& A, float* smem, floa
   const int K0 = A.L[0].K, K0p = round_up(K0, 16);
   const int kcw = K0p < A.kc ? K0p : A.kc;
   MLP_TRACE(A.trace, 0);
+  // the projection's weights, requested now and used after the last layer (it used to wait for them there)
+  float wo_pre[4] = {0.f, 0.f, 0.f, 0.f};
+  if (A.w_out && (A.logit || logit_lds)) {
+    const int ntop = A.L[A.n_layers - 1].N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wo_pre[i] = ldg_f32(A.w_out + ((lane + 64 * i) < ntop ? (lane + 64 * i) : ntop - 1));
+  }
 
   const float* in = nullptr;
   for (int l = 0; l < A.n_layers; ++l) {
@@ -246,22 +262,39 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpArgs& A, float* smem, floa
           const int klen = (K0p - kc) < kcw ? (K0p - kc) : kcw;
           auto stage = [&]() {
             __syncthreads();  // the previous chunk (or pass) is consumed
-            for (int e = tid; e < kTM * (klen >> 2); e += kT) {
-              const int r = e / (klen >> 2), q = e - r * (klen >> 2);
-              const int k = kc + 4 * q;
-              const int64_t b = b0 + r;
-              f32x4 v = {0.f, 0.f, 0.f, 0.f};
-              if (b < A.B) {
-                const float* src = A.x + b * A.ldx + k;
-                if (k + 3 < K0) {
-                  v = ldg_f4(src);
-                } else {
-                  if (k < K0) v.x = ldg_f32(src);
-                  if (k + 1 < K0) v.y = ldg_f32(src + 1);
-                  if (k + 2 < K0) v.z = ldg_f32(src + 2);
+            // No load here is predicated (a predicated load is a branch around the load with its own vmcnt(0): the
+            // loop used to be one memory round trip per iteration, 4.9 us for the 27 KB tile of the DeepFM tower --
+            // round 3): rows past B re-read row B-1, a dwordx4 that would leave the row is pulled back inside it
+            // (ld_x % 4 == 0), and what lies past K0 or B is zeroed by a select on the way to LDS.
+            const int q4 = klen >> 2, n_e = kTM * q4;
+            const int64_t blast = A.B - 1;
+            for (int e0 = 0; e0 < n_e; e0 += 4 * kT) {
+              f32x4 v[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                int e = e0 + i * kT + tid;
+                e = e < n_e ? e : n_e - 1;
+                const int r = e / q4, q = e - r * q4;
+                const int k = kc + 4 * q;
+                const int64_t b = (b0 + r) < blast ? (b0 + r) : blast;
+                const int64_t kk = k < A.ldx - 4 ? k : A.ldx - 4;
+                v[i] = ldg_f4(A.x + b * A.ldx + kk);
+              }
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const int e = e0 + i * kT + tid;
+                if (e < n_e) {
+                  const int r = e / q4, q = e - r * q4;
+                  const int k = kc + 4 * q;
+                  const bool rv = b0 + r < A.B && k <= A.ldx - 4;
+                  f32x4 w;
+                  w.x = (rv && k < K0) ? v[i].x : 0.f;
+                  w.y = (rv && k + 1 < K0) ? v[i].y : 0.f;
+                  w.z = (rv && k + 2 < K0) ? v[i].z : 0.f;
+                  w.w = (rv && k + 3 < K0) ? v[i].w : 0.f;
+                  *reinterpret_cast<f32x4*>(xs + r * rsx + 4 * q) = w;
                 }
               }
-              *reinterpret_cast<f32x4*>(xs + r * rsx + 4 * q) = v;
             }
             __syncthreads();
             if (kc == 0 && tbase == 0) MLP_TRACE(A.trace, 1);
@@ -305,7 +338,10 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpArgs& A, float* smem, floa
     const LayerDev& Lt = A.L[A.n_layers - 1];
     for (int row = wv; row < kTM; row += kWaves) {
       float s = 0.f;
-      for (int n = lane; n < Lt.N; n += 64) s += in[row * rsh + n] * ldg_f32(A.w_out + n);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (lane + 64 * i < Lt.N) s += in[row * rsh + lane + 64 * i] * wo_pre[i];
+      for (int n = lane + 256; n < Lt.N; n += 64) s += in[row * rsh + n] * ldg_f32(A.w_out + n);
       s = wave_sum(s);
       if (lane == 0) {
         if (A.logit && b0 + row < A.B) stg_f32(A.logit + b0 + row, s);
@@ -314,11 +350,17 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpArgs& A, float* smem, floa
     }
   }
   MLP_TRACE(A.trace, 15);
+  return in;
 }
 
 __global__ __launch_bounds__(kT) void k_mlp_fwd(MlpArgs A) {
   extern __shared__ __align__(16) float smem[];
-  mlp_fwd_body<false>(A, smem, nullptr);
+#ifdef DCTR_FAST_ONLY   // (ISA reading aid: compile the fast body alone)
+  mlp_fwd_fast(A, smem, nullptr);
+#else
+  if (A.fast) mlp_fwd_fast(A, smem, nullptr);
+  else mlp_fwd_body<false>(A, smem, nullptr);
+#endif
 }
 
 __global__ __launch_bounds__(kT) void k_cross_mat_fwd(MlpArgs A) {
@@ -329,9 +371,135 @@ __global__ __launch_bounds__(kT) void k_cross_mat_fwd(MlpArgs A) {
 // ------------------------------------------------------------------------------------------------------------
 // backward, data path: dH_l (gradient w.r.t. the pre-activation of layer l) for every layer, then d/d input
 // ------------------------------------------------------------------------------------------------------------
+// Q consecutive output columns per lane (a group of 16 Q columns per wave pass) of d loss / d input of layer l:
+//     out[16 rows][16 Q cols] = din[16][Np] . W_l[Np][cols]          (reduction over the layer's N outputs)
+// then the epilogue: relu mask of the layer below, into LDS (`dout`) for the next pass and into its `dh`; at l = 0 into gx.
+//  * Q = 4: 64-column groups, dwordx4 weight loads; Q = 2: 32-column groups, dwordx2 -- chosen when the 64-column groups
+//    would leave waves without work (a 256-wide layer has 4 of them for 8 waves: round 3).
+//  * ldw % 4 == 0: a load at col0 < ldw stays inside the row.  Columns past it re-read column 0 and rows past N re-read
+//    row N-1 (the A operand is zero there): no predicated loads in the loop.
+//  * The relu mask of the layer below (its saved output h) is requested BEFORE the weight ring and the MFMA loop and
+//    consumed in the epilogue (it used to be loaded there: one exposed round trip per pass).
+template <int Q>
+__device__ __forceinline__ void bwd_cols(const MlpArgs& A, int l, const float* din, float* dout, int rs, int gb, int b0,
+                                         int g, int c) {
+  typedef float vecq __attribute__((ext_vector_type(Q)));
+  const LayerDev& Ld = A.L[l];
+  const int Np = round_up(Ld.N, 16);      // reduction length
+  const int Kp = round_up(Ld.K, 16);      // output columns kept in LDS for the next (lower) layer
+  const int col0 = 16 * Q * gb + Q * c;
+  const int colc = col0 < Ld.ldw ? col0 : 0;
+  const int lp = l > 0 ? l - 1 : 0;
+  const LayerDev& Lp = A.L[lp];           // (l == 0: only its buffer is borrowed as a valid address)
+  vecq hpre[4];
+  {
+    const int cc = col0 < Lp.ldh - Q ? col0 : Lp.ldh - Q;
+    const int64_t blast = A.B - 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t b = (b0 + 4 * g + r) < blast ? (b0 + 4 * g + r) : blast;
+      hpre[r] = *(const DCTR_GLOBAL vecq*)(Lp.h + b * Lp.ldh + cc);
+    }
+  }
+  f32x4 acc[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* ap = din + c * rs + 4 * g;
+  const int n_it = Np >> 4;
+  // uniform base + 32-bit lane offsets: row n = 16 it + 4 g + j of W starts at byte (n * ldw + colc) * 4
+  const DCTR_GLOBAL char* wbase = (const DCTR_GLOBAL char*)Ld.W;
+  const uint32_t ldw4 = static_cast<uint32_t>(Ld.ldw) * 4u;
+  const uint32_t vlast = static_cast<uint32_t>(Ld.N - 1) * ldw4 + static_cast<uint32_t>(colc) * 4u;
+  uint32_t vrow[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) vrow[j] = static_cast<uint32_t>(4 * g + j) * ldw4 + static_cast<uint32_t>(colc) * 4u;
+  auto wld = [&](int it, vecq* dst) {
+    it = it < n_it ? it : n_it - 1;                               // scalar
+    const uint32_t so = static_cast<uint32_t>(it) * 16u * ldw4;  // scalar
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t o = vrow[j] + so;
+      o = o < vlast ? o : vlast;                                  // rows past N re-read row N-1 (A is 0 there)
+      dst[j] = *(const DCTR_GLOBAL vecq*)(wbase + o);
+    }
+  };
+  constexpr int PD = Q == 4 ? 5 : 8;      // an iteration is 4 Q MFMAs: fewer columns => deeper ring to cover the L2 latency
+  vecq ring[PD][4];
+#pragma unroll
+  for (int d = 0; d < PD - 1; ++d) wld(d, ring[d]);
+  const int n_grp = n_it / PD, rem = n_it - n_grp * PD;
+  f32x4 a_nxt = *reinterpret_cast<const f32x4*>(ap);
+  for (int gi = 0; gi < n_grp; ++gi) {
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+      const int it = gi * PD + d;
+      wld(it + PD - 1, ring[(d + PD - 1) % PD]);
+      const f32x4 a4 = a_nxt;
+      const int itn = it + 1 < n_it ? it + 1 : it;
+      a_nxt = *reinterpret_cast<const f32x4*>(ap + (itn << 4));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[q] = mfma16(a4[j], ring[d][j][q], acc[q]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < PD - 1; ++d) {
+    if (d < rem) {
+      const int it = n_grp * PD + d;
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + (it << 4));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[q] = mfma16(a4[j], ring[d][j][q], acc[q]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * g + r;
+    const int64_t b = b0 + row;
+    vecq v;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) v[q] = acc[q][r];
+    if (l > 0) {
+      if (col0 < Kp) {    // Lp.N == Ld.K
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          float o = v[q];
+          if (Lp.relu && !(hpre[r][q] > 0.f)) o = 0.f;
+          if (col0 + q >= Lp.N || b >= A.B) o = 0.f;
+          v[q] = o;
+        }
+        *reinterpret_cast<vecq*>(dout + row * rs + col0) = v;
+        if (Lp.dh && b < A.B) {
+          if (col0 + Q - 1 < Lp.N) *(DCTR_GLOBAL vecq*)(Lp.dh + b * Lp.ldh + col0) = v;
+          else
+            for (int q = 0; q < Q; ++q)
+              if (col0 + q < Lp.N) stg_f32(Lp.dh + b * Lp.ldh + col0 + q, v[q]);
+        }
+      }
+    } else if (b < A.B) {
+      // columns [K, ldgx) of gx are padding: written as zeros so that no garbage is ever handed on
+      if (col0 + Q - 1 < A.ldgx) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+          if (col0 + q >= Ld.K) v[q] = 0.f;
+        *(DCTR_GLOBAL vecq*)(A.gx + b * A.ldgx + col0) = v;
+      } else {
+        for (int q = 0; q < Q; ++q)
+          if (col0 + q < A.ldgx) stg_f32(A.gx + b * A.ldgx + col0 + q, col0 + q < Ld.K ? v[q] : 0.f);
+      }
+    }
+  }
+}
+
 // the backward-data pass of one row tile; `g_lds` (nullable): [16] LDS floats holding d loss / d logit of the tile's
-// rows (the fused train kernel) instead of A.g
-__device__ __forceinline__ void mlp_bwd_body(const MlpArgs& A, float* smem, const float* g_lds) {
+// rows (the fused train kernel) instead of A.g; `htop` (nullable): the top layer's output tile still in LDS
+// ([16][rs_h], the fused train kernel) instead of its saved copy in global memory
+__device__ __forceinline__ void mlp_bwd_body(const MlpArgs& A, float* smem, const float* g_lds, const float* htop,
+                                             int rs_h) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * kTM;
   const int rs = A.rsd;
@@ -340,20 +508,40 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpArgs& A, float* smem, cons
   const int top = A.n_layers - 1;
   MLP_TRACE(A.trace, 0);
   {
+    // d loss / d pre-activation of the top layer.  Four elements per thread and round trip, every load unconditional
+    // from a clamped address (this loop was one round trip per element: 3.5 us for 16 x 128 -- round 3)
     const LayerDev& Lt = A.L[top];
     const int Np = round_up(Lt.N, 16);
-    for (int e = tid; e < kTM * Np; e += kT) {
-      const int r = e / Np, n = e - r * Np;
-      const int64_t b = b0 + r;
-      float v = 0.f;
-      if (b < A.B && n < Lt.N) {
-        const float gv = A.w_out ? (g_lds ? g_lds[r] : ldg_f32(A.g + b)) * ldg_f32(A.w_out + n)
-                                 : ldg_f32(A.g + b * A.ldg + n);
-        v = gv;
-        if (Lt.relu) v = ldg_f32(Lt.h + b * Lt.ldh + n) > 0.f ? gv : 0.f;
-        if (Lt.dh) stg_f32(Lt.dh + b * Lt.ldh + n, v);
+    const int n_e = kTM * Np;
+    const int64_t blast = A.B - 1;
+    for (int e0 = 0; e0 < n_e; e0 += 4 * kT) {
+      float gv[4], hv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int e = e0 + i * kT + tid;
+        e = e < n_e ? e : n_e - 1;
+        const int r = e / Np, n = e - r * Np;
+        const int nn = n < Lt.N ? n : Lt.N - 1;
+        const int64_t b = (b0 + r) < blast ? (b0 + r) : blast;
+        if (A.w_out) gv[i] = (g_lds ? g_lds[r] : ldg_f32(A.g + b)) * ldg_f32(A.w_out + nn);
+        else gv[i] = ldg_f32(A.g + b * A.ldg + nn);
+        hv[i] = htop ? htop[r * rs_h + nn] : ldg_f32(Lt.h + b * Lt.ldh + nn);
       }
-      d0[r * rs + n] = v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = e0 + i * kT + tid;
+        if (e < n_e) {
+          const int r = e / Np, n = e - r * Np;
+          const int64_t b = b0 + r;
+          float v = 0.f;
+          if (b < A.B && n < Lt.N) {
+            v = gv[i];
+            if (Lt.relu) v = hv[i] > 0.f ? v : 0.f;
+            if (Lt.dh) stg_f32(Lt.dh + b * Lt.ldh + n, v);
+          }
+          d0[r * rs + n] = v;
+        }
+      }
     }
   }
   __syncthreads();
@@ -362,115 +550,13 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpArgs& A, float* smem, cons
   float* dout = d1;
   for (int l = top; l >= 0; --l) {
     const LayerDev& Ld = A.L[l];
-    const int Np = round_up(Ld.N, 16);      // reduction length
-    const int Kp = round_up(Ld.K, 16);      // output columns kept in LDS for the next (lower) layer
-    const int ngroups = (Ld.K + 63) >> 6;
     if (l > 0 || A.gx) {
-      for (int gb = wv; gb < ngroups; gb += kWaves) {
-        const int col0 = 64 * gb + 4 * c;
-        // ldw % 4 == 0: a dwordx4 at col0 < ldw stays inside the row.  Columns past it re-read column 0 and
-        // rows past N re-read row N-1 (the A operand is zero there): no predicated loads in the loop.
-        const int colc = col0 < Ld.ldw ? col0 : 0;
-        f32x4 acc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* ap = din + c * rs + 4 * g;
-        const int n_it = Np >> 4;
-        // uniform base + 32-bit lane offsets: row n = 16 it + 4 g + j of W starts at byte (n * ldw + colc) * 4
-        const DCTR_GLOBAL char* wbase = (const DCTR_GLOBAL char*)Ld.W;
-        const uint32_t ldw4 = static_cast<uint32_t>(Ld.ldw) * 4u;
-        const uint32_t vlast = static_cast<uint32_t>(Ld.N - 1) * ldw4 + static_cast<uint32_t>(colc) * 4u;
-        uint32_t vrow[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) vrow[j] = static_cast<uint32_t>(4 * g + j) * ldw4 + static_cast<uint32_t>(colc) * 4u;
-        auto wld = [&](int it, f32x4* dst) {
-          it = it < n_it ? it : n_it - 1;                               // scalar
-          const uint32_t so = static_cast<uint32_t>(it) * 16u * ldw4;  // scalar
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            uint32_t o = vrow[j] + so;
-            o = o < vlast ? o : vlast;                                  // rows past N re-read row N-1 (A is 0 there)
-            dst[j] = *(const DCTR_GLOBAL f32x4*)(wbase + o);
-          }
-        };
-        constexpr int PD = 5;
-        f32x4 ring[PD][4];
-#pragma unroll
-        for (int d = 0; d < PD - 1; ++d) wld(d, ring[d]);
-        const int n_grp = n_it / PD, rem = n_it - n_grp * PD;
-        f32x4 a_nxt = *reinterpret_cast<const f32x4*>(ap);
-        for (int gi = 0; gi < n_grp; ++gi) {
-#pragma unroll
-          for (int d = 0; d < PD; ++d) {
-            const int it = gi * PD + d;
-            wld(it + PD - 1, ring[(d + PD - 1) % PD]);
-            const f32x4 a4 = a_nxt;
-            const int itn = it + 1 < n_it ? it + 1 : it;
-            a_nxt = *reinterpret_cast<const f32x4*>(ap + (itn << 4));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) acc[q] = mfma16(a4[j], ring[d][j][q], acc[q]);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-#pragma unroll
-        for (int d = 0; d < PD - 1; ++d) {
-          if (d < rem) {
-            const int it = n_grp * PD + d;
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + (it << 4));
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) acc[q] = mfma16(a4[j], ring[d][j][q], acc[q]);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 4 * g + r;
-          const int64_t b = b0 + row;
-          f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-          if (l > 0) {
-            const LayerDev& Lp = A.L[l - 1];  // Lp.N == Ld.K
-            if (col0 < Kp) {
-              f32x4 hv = {1.f, 1.f, 1.f, 1.f};
-              const bool full = b < A.B && col0 + 3 < Lp.N;
-              if (Lp.relu && full) hv = ldg_f4(Lp.h + b * Lp.ldh + col0);
-              else if (Lp.relu && b < A.B) {
-                hv.x = col0 < Lp.N ? ldg_f32(Lp.h + b * Lp.ldh + col0) : 0.f;
-                hv.y = col0 + 1 < Lp.N ? ldg_f32(Lp.h + b * Lp.ldh + col0 + 1) : 0.f;
-                hv.z = col0 + 2 < Lp.N ? ldg_f32(Lp.h + b * Lp.ldh + col0 + 2) : 0.f;
-                hv.w = 0.f;
-              }
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                float o = v[q];
-                if (Lp.relu && !(hv[q] > 0.f)) o = 0.f;
-                if (col0 + q >= Lp.N || b >= A.B) o = 0.f;
-                v[q] = o;
-              }
-              *reinterpret_cast<f32x4*>(dout + row * rs + col0) = v;
-              if (Lp.dh && b < A.B) {
-                if (col0 + 3 < Lp.N) *(DCTR_GLOBAL f32x4*)(Lp.dh + b * Lp.ldh + col0) = v;
-                else
-                  for (int q = 0; q < 4; ++q)
-                    if (col0 + q < Lp.N) stg_f32(Lp.dh + b * Lp.ldh + col0 + q, v[q]);
-              }
-            }
-          } else if (b < A.B) {
-            // columns [K, ldgx) of gx are padding: written as zeros so that no garbage is ever handed on
-            if (col0 + 3 < A.ldgx) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q)
-                if (col0 + q >= Ld.K) v[q] = 0.f;
-              *(DCTR_GLOBAL f32x4*)(A.gx + b * A.ldgx + col0) = v;
-            } else {
-              for (int q = 0; q < 4; ++q)
-                if (col0 + q < A.ldgx) stg_f32(A.gx + b * A.ldgx + col0 + q, col0 + q < Ld.K ? v[q] : 0.f);
-            }
-          }
-        }
+      if (Ld.K <= 32 * kWaves) {
+        const int ngroups = (Ld.K + 31) >> 5;
+        for (int gb = wv; gb < ngroups; gb += kWaves) bwd_cols<2>(A, l, din, dout, rs, gb, b0, g, c);
+      } else {
+        const int ngroups = (Ld.K + 63) >> 6;
+        for (int gb = wv; gb < ngroups; gb += kWaves) bwd_cols<4>(A, l, din, dout, rs, gb, b0, g, c);
       }
     }
     MLP_TRACE(A.trace, 2 + 2 * (top - l));
@@ -483,9 +569,574 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpArgs& A, float* smem, cons
   MLP_TRACE(A.trace, 15);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// fast path (round 3): towers whose layers are at most 512 wide and whose input is one staged chunk -- every
+// BASELINE configuration.  Same arithmetic as the general bodies above (same MFMA order per output element), other
+// schedule: the weight ring of the NEXT phase is requested before the current phase's epilogue and barrier, the tower
+// input before the first weight ring, biases / relu masks / projection weights a phase ahead.  In the general
+// bodies every phase starts with an exposed L2 round trip of every wave (~1-2 us, 6-8 phases per launch).
+// ------------------------------------------------------------------------------------------------------------
+// A 16-row tile [16][rs] in LDS -> rows b0 .. b0 + 15 of a [B, ld] global matrix, N columns (ld % 4 == 0, N <= 512), as
+// dwordx4 stores by all 512 threads: 32 threads cover 512 contiguous bytes of a row.  Called behind the barrier that
+// completes the tile.  (The epilogues used to store their accumulators themselves, one dword per lane and matrix row: 8
+// store instructions per wave that took ~3 us to ISSUE -- measured with a stamp behind them, round 3.)
+__device__ __forceinline__ void tile_store(const float* tile, int rs, float* dst, int64_t ld, int N, int b0, int B) {
+  const int tid = threadIdx.x, r = tid >> 5, q0 = tid & 31;
+  const int n4 = (N + 3) >> 2;
+  if (b0 + r < B) {
+    float* drow = dst + static_cast<int64_t>(b0 + r) * ld;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = q0 + 32 * i;
+      if (q < n4) *(DCTR_GLOBAL f32x4*)(drow + 4 * q) = *reinterpret_cast<const f32x4*>(tile + r * rs + 4 * q);
+    }
+  }
+}
+
+// Forward: a wave always carries TWO weight streams (ring slots 2 d + t) and two accumulator pairs:
+//   * layers of more than 128 outputs: the streams are two 16-column tiles (wv + 16 pass, wv + 8 + 16 pass), up to two
+//     passes (512 outputs);
+//   * layers of at most 128 outputs (one tile per wave): the streams are the two HALVES OF K of that tile, summed at the end.
+// One code path for every layer -- no template dispatch on the tile count.  (With one instantiation per tile count behind a
+// switch, the ring registers were copied at every arm's entry, and a copy of a register that a load is still filling
+// is an s_waitcnt vmcnt(0): every phase drained the loads it was meant to overlap.)
+constexpr int kFPD = 8;                    // ring depth in iterations
+constexpr int kRingSlots = 2 * kFPD;       // dwordx4 weight loads a wave keeps in flight (forward): 14 + the 2 being used
+
+struct FwdPlan {      // one pass of one layer, wave-uniform
+  int col_t1;         // tile index distance of stream 1 (8: column mode, 0: K-split)
+  int k_t1;           // first K iteration of stream 1 (0: column mode, h: K-split)
+  int n_it;           // iterations of the pass (column mode: all of K; K-split: h = ceil(all / 2))
+  int n_all;          // iterations of the whole K range
+};
+__device__ __forceinline__ FwdPlan fwd_plan(const LayerDev& Ld, int klen) {
+  FwdPlan P;
+  const int ntile = (Ld.N + 15) >> 4;
+  P.n_all = klen >> 4;
+  if (ntile > kWaves || (P.n_all & 1)) {
+    // (one tile per wave but an odd K iteration count: stream 1 computes a second copy of column N-1's tile and is
+    // dropped -- towers have even K / 16 in practice)
+    P.col_t1 = kWaves; P.k_t1 = 0; P.n_it = P.n_all;
+  } else {
+    P.col_t1 = 0; P.n_it = P.n_all >> 1; P.k_t1 = P.n_it;
+  }
+  return P;
+}
+
+struct FwdAddr {
+  const DCTR_GLOBAL char* wbase;
+  uint32_t voff[2];
+  uint32_t omax;
+};
+__device__ __forceinline__ FwdAddr fwd_addr(const LayerDev& Ld, const FwdPlan& P, int tile0, int g, int c) {
+  FwdAddr a;
+  a.wbase = (const DCTR_GLOBAL char*)Ld.W;
+  const int col0 = (4 * g) < (Ld.ldw - 4) ? (4 * g) : (Ld.ldw - 4);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int n = (tile0 + t * P.col_t1) * 16 + c;
+    n = n < Ld.N ? n : Ld.N - 1;
+    a.voff[t] = (static_cast<uint32_t>(n) * static_cast<uint32_t>(Ld.ldw) + static_cast<uint32_t>(col0)) * 4u;
+  }
+  a.omax = static_cast<uint32_t>(Ld.ldw - 4 - col0) * 4u;
+  return a;
+}
+// byte offset of K iteration `it` of stream t inside the weight row (clamped into the row: what lies past K meets zeros)
+__device__ __forceinline__ uint32_t fwd_woff(const FwdAddr& a, const FwdPlan& P, int it, int t) {
+  it = it < P.n_it ? it : P.n_it - 1;                       // scalar
+  it += t * P.k_t1;
+  it = it < P.n_all ? it : P.n_all - 1;
+  const uint32_t o = static_cast<uint32_t>(it) << 6;
+  return o < a.omax ? o : a.omax;
+}
+
+__device__ __forceinline__ void fwd_fill(f32x4 (&ring)[kRingSlots], const LayerDev& Ld, int klen, int tile0, int g, int c,
+                                         uint32_t wmask) {
+  const FwdPlan P = fwd_plan(Ld, klen);
+  const FwdAddr a = fwd_addr(Ld, P, tile0, g, c);
+#pragma unroll
+  for (int d = 0; d < kFPD - 1; ++d)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      ring[2 * d + t] = *(const DCTR_GLOBAL f32x4*)(a.wbase + ((a.voff[t] + fwd_woff(a, P, d, t)) & wmask));
+}
+
+// acc[0], acc[1]: the two tiles (column mode) or the tile's sum in acc[0] (K-split; acc[1] unused)
+__device__ __forceinline__ void fwd_run(f32x4 (&ring)[kRingSlots], const float* As, int rs, const LayerDev& Ld, int klen,
+                                        int tile0, int g, int c, f32x4* acc, uint32_t wmask) {
+  constexpr int PD = kFPD;
+  const FwdPlan P = fwd_plan(Ld, klen);
+  const FwdAddr a = fwd_addr(Ld, P, tile0, g, c);
+  const float* ap = As + c * rs + 4 * g;
+  const int n_it = P.n_it;
+  const bool split = P.col_t1 == 0;
+  f32x4 accs[2][2];
+  accs[0][0] = acc[0];
+  accs[1][0] = split ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[1];
+  accs[0][1] = accs[1][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // A fragments: stream 1 reads the same rows of the tile, k_t1 iterations further right (K-split; its range may end one
+  // iteration early: that fragment is zeroed)
+  auto a_of = [&](int it, int t) -> f32x4 {
+    return *reinterpret_cast<const f32x4*>(ap + ((it + t * P.k_t1) << 4));
+  };
+  const int n_grp = n_it / PD, rem = n_it - n_grp * PD;
+  f32x4 a0n = a_of(0, 0), a1n = a_of(0, 1);
+  for (int gi = 0; gi < n_grp; ++gi) {
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+      const int it = gi * PD + d;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        ring[2 * ((d + PD - 1) % PD) + t] =
+            *(const DCTR_GLOBAL f32x4*)(a.wbase + ((a.voff[t] + fwd_woff(a, P, it + PD - 1, t)) & wmask));
+      const f32x4 a0 = a0n, a1 = a1n;
+      const int itn = it + 1 < n_it ? it + 1 : it;
+      a0n = a_of(itn, 0);
+      a1n = a_of(itn, 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        accs[0][j & 1] = mfma16(a0[j], ring[2 * d][j], accs[0][j & 1]);
+        accs[1][j & 1] = mfma16(a1[j], ring[2 * d + 1][j], accs[1][j & 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < PD - 1; ++d) {
+    if (d < rem) {
+      const int it = n_grp * PD + d;
+      const f32x4 a0 = a_of(it, 0), a1 = a_of(it, 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        accs[0][j & 1] = mfma16(a0[j], ring[2 * d][j], accs[0][j & 1]);
+        accs[1][j & 1] = mfma16(a1[j], ring[2 * d + 1][j], accs[1][j & 1]);
+      }
+    }
+  }
+  const f32x4 r0 = accs[0][0] + accs[0][1], r1 = accs[1][0] + accs[1][1];
+  acc[0] = split ? r0 + r1 : r0;
+  acc[1] = r1;
+}
+
+// bias of the wave's (up to two) tiles of a pass: the RAW loads, unconditional from a clamped address (Ld.W stands in for a
+// missing bias vector); fwd_bias_sel() turns them into the values (0 where there is no bias / no tile) at the point of use,
+// so that nothing waits for them earlier
+__device__ __forceinline__ void fwd_bias_ld(const LayerDev& Ld, int tile0, int c, float* raw) {
+  const float* bp = Ld.bias ? Ld.bias : Ld.W;
+  const int col_t1 = fwd_plan(Ld, round_up(Ld.K, 16)).col_t1;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int n = (tile0 + t * col_t1) * 16 + c;
+    raw[t] = ldg_f32(bp + (n < Ld.N ? n : Ld.N - 1));
+  }
+}
+__device__ __forceinline__ void fwd_bias_sel(const LayerDev& Ld, int tile0, int c, const float* raw, float* bv) {
+  const int col_t1 = fwd_plan(Ld, round_up(Ld.K, 16)).col_t1;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int n = (tile0 + t * col_t1) * 16 + c;
+    bv[t] = (n < Ld.N && Ld.bias && (t == 0 || col_t1)) ? raw[t] : 0.f;
+  }
+}
+
+__device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* smem, float* logit_lds) {
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int b0 = blockIdx.x * kTM;
+  const int rsx = A.rsx, rsh = A.rsh;
+  float* xs = smem;               // [16][rsx]  the tower input
+  float* hb0 = xs + kTM * rsx;    // [16][rsh]  ping
+  float* hb1 = hb0 + kTM * rsh;   // [16][rsh]  pong
+  const int K0 = A.L[0].K, K0p = round_up(K0, 16);
+  MLP_TRACE(A.trace, 0);
+  // (loads return in order: what is consumed first is requested first -- input tile, bias, then the weight ring)
+  // the tower input: thread (row tid / 32, dwordx4 columns tid % 32 + 32 i); nothing predicated -- rows past B re-read
+  // row B-1, columns past the row are pulled back inside it, both are zeroed on the way to LDS
+  const int q4 = K0p >> 2;
+  const int xr = tid >> 5, xq = tid & 31;
+  f32x4 xv[4];
+  {
+    const int64_t blast = A.B - 1;
+    const int64_t b = (b0 + xr) < blast ? (b0 + xr) : blast;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = 4 * (xq + 32 * i);
+      const int64_t kk = k < A.ldx - 4 ? k : A.ldx - 4;
+      xv[i] = ldg_f4(A.x + b * A.ldx + kk);
+    }
+  }
+  f32x4 ring[kRingSlots];
+  float braw[2];
+  fwd_bias_ld(A.L[0], wv, c, braw);
+  __builtin_amdgcn_sched_barrier(0);      // (keep the issue order: the compiler otherwise puts the ring in front)
+  fwd_fill(ring, A.L[0], K0p, wv, g, c, A.wmask);
+  int bias_l = 0, bias_tile0 = wv;        // which layer / tile the raw bias values in flight belong to
+  float wo_pre[4] = {0.f, 0.f, 0.f, 0.f};
+  if (A.w_out && (A.logit || logit_lds)) {
+    const int ntop = A.L[A.n_layers - 1].N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wo_pre[i] = ldg_f32(A.w_out + ((lane + 64 * i) < ntop ? (lane + 64 * i) : ntop - 1));
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = xq + 32 * i;
+    if (q < q4) {
+      const int k = 4 * q;
+      const bool rv = b0 + xr < A.B && k <= A.ldx - 4;
+      f32x4 w;
+      w.x = (rv && k < K0) ? xv[i].x : 0.f;
+      w.y = (rv && k + 1 < K0) ? xv[i].y : 0.f;
+      w.z = (rv && k + 2 < K0) ? xv[i].z : 0.f;
+      w.w = (rv && k + 3 < K0) ? xv[i].w : 0.f;
+      *reinterpret_cast<f32x4*>(xs + xr * rsx + k) = w;
+    }
+  }
+  __syncthreads();
+  MLP_TRACE(A.trace, 1);
+  const float* in = xs;
+  int rs_in = rsx;
+  for (int l = 0; l < A.n_layers; ++l) {
+    const LayerDev& Ld = A.L[l];
+    const int ntile = (Ld.N + 15) >> 4;
+    const int klen = round_up(Ld.K, 16);
+    const int col_t1 = fwd_plan(Ld, klen).col_t1;
+    float* outb = (l & 1) ? hb1 : hb0;
+    for (int tile0 = wv; tile0 < ntile || tile0 == wv; tile0 += 2 * kWaves) {     // (every wave runs the first pass)
+      f32x4 acc[2];
+      {
+        float bv[2];
+        fwd_bias_sel(A.L[bias_l], bias_tile0, c, braw, bv);
+        acc[0] = f32x4{bv[0], bv[0], bv[0], bv[0]};
+        acc[1] = f32x4{bv[1], bv[1], bv[1], bv[1]};
+      }
+      fwd_run(ring, in, rs_in, Ld, klen, tile0, g, c, acc, A.wmask);
+      if (tile0 == wv) MLP_TRACE(A.trace, 2 + 3 * l);
+      // the epilogue's stores go first: the memory pipeline is in order, behind a 14 KB burst of weight requests per
+      // wave they waited ~5 us (measured with a stamp between the two: round 3)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int tile = tile0 + t * col_t1;
+        if (tile < ntile && (t == 0 || col_t1)) {
+          const int n = tile * 16 + c;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 4 * g + r;
+            float v = acc[t][r];
+            if (Ld.relu) v = v > 0.f ? v : 0.f;
+            if (n >= Ld.N) v = 0.f;
+            outb[row * rsh + n] = v;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (tile0 == wv && l == 0) MLP_TRACE(A.trace, 9);
+      // what this wave multiplies next -- its tiles of the second pass, or of the next layer -- and the bias that goes
+      // with it: in flight across the barrier
+      if (tile0 + 2 * kWaves < ntile) {
+        bias_l = l; bias_tile0 = tile0 + 2 * kWaves;
+        fwd_bias_ld(Ld, bias_tile0, c, braw);
+        __builtin_amdgcn_sched_barrier(0);
+        fwd_fill(ring, Ld, klen, bias_tile0, g, c, A.wmask);
+      } else if (l + 1 < A.n_layers) {
+        const LayerDev& Ln = A.L[l + 1];
+        bias_l = l + 1; bias_tile0 = wv;
+        fwd_bias_ld(Ln, wv, c, braw);
+        __builtin_amdgcn_sched_barrier(0);
+        fwd_fill(ring, Ln, round_up(Ln.K, 16), wv, g, c, A.wmask);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    MLP_TRACE(A.trace, 3 + 3 * l);
+    __syncthreads();
+    MLP_TRACE(A.trace, 4 + 3 * l);
+    if (Ld.h) tile_store(outb, rsh, Ld.h, Ld.ldh, Ld.N, b0, A.B);   // the saved activation, for the backward kernels
+    in = outb;
+    rs_in = rsh;
+  }
+  if (A.w_out && (A.logit || logit_lds)) {  // dnn_linear: logit[b] = h_last[b, :] . w_out
+    const LayerDev& Lt = A.L[A.n_layers - 1];
+    for (int row = wv; row < kTM; row += kWaves) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (lane + 64 * i < Lt.N) s += in[row * rsh + lane + 64 * i] * wo_pre[i];
+      for (int n = lane + 256; n < Lt.N; n += 64) s += in[row * rsh + n] * ldg_f32(A.w_out + n);
+      s = wave_sum(s);
+      if (lane == 0) {
+        if (A.logit && b0 + row < A.B) stg_f32(A.logit + b0 + row, s);
+        if (logit_lds) logit_lds[row] = s;
+      }
+    }
+  }
+  MLP_TRACE(A.trace, 15);
+  return in;
+}
+
+// ---- backward-data, fast path ---------------------------------------------------------------------------------
+template <int Q>
+struct BwdCfg {
+  static constexpr int PD = Q == 4 ? 6 : 10;   // ring depth in iterations of 4 weight rows x Q columns
+};
+template <int Q>
+struct BwdRing {
+  typedef float vecq __attribute__((ext_vector_type(Q)));
+  vecq r[BwdCfg<Q>::PD][4];
+};
+
+struct BwdAddr {
+  const DCTR_GLOBAL char* wbase;
+  uint32_t vrow[4];
+  uint32_t vlast, ldw4, wmask;
+  int n_it;
+};
+template <int Q>
+__device__ __forceinline__ BwdAddr bwd_addr(const LayerDev& Ld, int gb, int g, int c, uint32_t wmask) {
+  BwdAddr a;
+  a.wmask = wmask;
+  const int col0 = 16 * Q * gb + Q * c;
+  const int colc = col0 < Ld.ldw ? col0 : 0;
+  a.wbase = (const DCTR_GLOBAL char*)Ld.W;
+  a.ldw4 = static_cast<uint32_t>(Ld.ldw) * 4u;
+  a.vlast = static_cast<uint32_t>(Ld.N - 1) * a.ldw4 + static_cast<uint32_t>(colc) * 4u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a.vrow[j] = static_cast<uint32_t>(4 * g + j) * a.ldw4 + static_cast<uint32_t>(colc) * 4u;
+  a.n_it = round_up(Ld.N, 16) >> 4;
+  return a;
+}
+template <int Q>
+__device__ __forceinline__ void bwd_wld(const BwdAddr& a, int it, typename BwdRing<Q>::vecq* dst) {
+  typedef typename BwdRing<Q>::vecq vecq;
+  it = it < a.n_it ? it : a.n_it - 1;                               // scalar
+  const uint32_t so = static_cast<uint32_t>(it) * 16u * a.ldw4;    // scalar
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t o = a.vrow[j] + so;
+    o = o < a.vlast ? o : a.vlast;                                  // rows past N re-read row N-1 (A is 0 there)
+    dst[j] = *(const DCTR_GLOBAL vecq*)(a.wbase + (o & a.wmask));
+  }
+}
+template <int Q>
+__device__ __forceinline__ void bwd_fill(BwdRing<Q>& R, const LayerDev& Ld, int gb, int g, int c, uint32_t wmask) {
+  const BwdAddr a = bwd_addr<Q>(Ld, gb, g, c, wmask);
+#pragma unroll
+  for (int d = 0; d < BwdCfg<Q>::PD - 1; ++d) bwd_wld<Q>(a, d, R.r[d]);
+}
+template <int Q>
+__device__ __forceinline__ void bwd_run(BwdRing<Q>& R, const LayerDev& Ld, const float* din, int rs, int gb, int g, int c,
+                                        f32x4* acc, uint32_t wmask) {
+  constexpr int PD = BwdCfg<Q>::PD;
+  const BwdAddr a = bwd_addr<Q>(Ld, gb, g, c, wmask);
+  const float* ap = din + c * rs + 4 * g;
+  const int n_it = a.n_it;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int n_grp = n_it / PD, rem = n_it - n_grp * PD;
+  f32x4 a_nxt = *reinterpret_cast<const f32x4*>(ap);
+  for (int gi = 0; gi < n_grp; ++gi) {
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+      const int it = gi * PD + d;
+      bwd_wld<Q>(a, it + PD - 1, R.r[(d + PD - 1) % PD]);
+      const f32x4 a4 = a_nxt;
+      const int itn = it + 1 < n_it ? it + 1 : it;
+      a_nxt = *reinterpret_cast<const f32x4*>(ap + (itn << 4));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[q] = mfma16(a4[j], R.r[d][j][q], acc[q]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < PD - 1; ++d) {
+    if (d < rem) {
+      const int it = n_grp * PD + d;
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + (it << 4));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[q] = mfma16(a4[j], R.r[d][j][q], acc[q]);
+    }
+  }
+}
+// relu mask source of the layer below (its saved output), rows 4 g .. 4 g + 3 at the lane's columns: from its tile in LDS
+// when the forward left it there (`hl`, row stride rs_h: the fused train kernel), else from its copy in global memory
+template <int Q>
+__device__ __forceinline__ void bwd_mask(const MlpArgs& A, int l, int gb, int b0, int g, int c, const float* hl, int rs_h,
+                                         typename BwdRing<Q>::vecq* hpre) {
+  typedef typename BwdRing<Q>::vecq vecq;
+  const LayerDev& Lp = A.L[l > 0 ? l - 1 : 0];   // (l == 0: only its buffer is borrowed as a valid address)
+  const int col0 = 16 * Q * gb + Q * c;
+  if (hl) {
+    const int cc = col0 < rs_h - 4 - Q ? col0 : rs_h - 4 - Q;     // (the tile is rs_h - 4 columns wide)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hpre[r] = *reinterpret_cast<const vecq*>(hl + (4 * g + r) * rs_h + cc);
+    return;
+  }
+  const int cc = col0 < Lp.ldh - Q ? col0 : Lp.ldh - Q;
+  const int64_t blast = A.B - 1;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t b = (b0 + 4 * g + r) < blast ? (b0 + 4 * g + r) : blast;
+    hpre[r] = *(const DCTR_GLOBAL vecq*)(Lp.h + b * Lp.ldh + cc);
+  }
+}
+template <int Q>
+__device__ __forceinline__ void bwd_epilogue(const MlpArgs& A, int l, float* dout, int rs, int gb, int b0, int g, int c,
+                                             const f32x4* acc, const typename BwdRing<Q>::vecq* hpre) {
+  typedef typename BwdRing<Q>::vecq vecq;
+  const LayerDev& Ld = A.L[l];
+  const LayerDev& Lp = A.L[l > 0 ? l - 1 : 0];
+  const int Kp = round_up(Ld.K, 16);
+  const int col0 = 16 * Q * gb + Q * c;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * g + r;
+    const int64_t b = b0 + row;
+    vecq v;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) v[q] = acc[q][r];
+    if (l > 0) {
+      if (col0 < Kp) {    // Lp.N == Ld.K
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          float o = v[q];
+          if (Lp.relu && !(hpre[r][q] > 0.f)) o = 0.f;
+          if (col0 + q >= Lp.N || b >= A.B) o = 0.f;
+          v[q] = o;
+        }
+        *reinterpret_cast<vecq*>(dout + row * rs + col0) = v;     // (its copy in Lp.dh: tile_store behind the barrier)
+      }
+    } else if (b < A.B) {
+      if (col0 + Q - 1 < A.ldgx) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+          if (col0 + q >= Ld.K) v[q] = 0.f;
+        *(DCTR_GLOBAL vecq*)(A.gx + b * A.ldgx + col0) = v;
+      } else {
+        for (int q = 0; q < Q; ++q)
+          if (col0 + q < A.ldgx) stg_f32(A.gx + b * A.ldgx + col0 + q, col0 + q < Ld.K ? v[q] : 0.f);
+      }
+    }
+  }
+}
+// ONE column-group width per launch (two ring types alive across the layer loop spilled): Q = 2 (32-column groups) when
+// every layer has at most 256 inputs -- 8 groups keep all 8 waves busy -- else Q = 4 (64-column groups, one pass up to 512)
+template <int Q>
+__device__ __forceinline__ int bwd_groups(const LayerDev& Ld) { return (Ld.K + 16 * Q - 1) / (16 * Q); }
+
+// hb0 / hb1 (nullable, row stride rs_h): the forward's ping / pong activation tiles when they are still in LDS (the fused
+// train kernel with both LDS images): layer j's output then sits in (j & 1 ? hb1 : hb0) for j >= n_layers - 2
+template <int Q>
+__device__ __forceinline__ void mlp_bwd_fast_q(const MlpArgs& A, float* smem, const float* g_lds, const float* hb0,
+                                               const float* hb1, int rs_h) {
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int b0 = blockIdx.x * kTM;
+  const int rs = A.rsd;
+  float* d0 = smem;
+  float* d1 = d0 + kTM * rs;
+  const int top = A.n_layers - 1;
+  auto h_lds = [&](int j) -> const float* {
+    return (hb0 && j >= 0 && j >= top - 1) ? ((j & 1) ? hb1 : hb0) : nullptr;
+  };
+  const float* htop = h_lds(top);
+  MLP_TRACE(A.trace, 0);
+  BwdRing<Q> R;
+  {
+    const LayerDev& Lt = A.L[top];
+    const int Np = round_up(Lt.N, 16);
+    const int n_e = kTM * Np;
+    const int64_t blast = A.B - 1;
+    for (int e0 = 0; e0 < n_e; e0 += 4 * kT) {
+      float gv[4], hv[4], wv4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int e = e0 + i * kT + tid;
+        e = e < n_e ? e : n_e - 1;
+        const int r = e / Np, n = e - r * Np;
+        const int nn = n < Lt.N ? n : Lt.N - 1;
+        const int64_t b = (b0 + r) < blast ? (b0 + r) : blast;
+        if (A.w_out) {
+          gv[i] = g_lds ? g_lds[r] : ldg_f32(A.g + b);
+          wv4[i] = ldg_f32(A.w_out + nn);
+        } else {
+          gv[i] = ldg_f32(A.g + b * A.ldg + nn);
+          wv4[i] = 1.f;
+        }
+        hv[i] = htop ? htop[r * rs_h + nn] : ldg_f32(Lt.h + b * Lt.ldh + nn);
+      }
+      // the top layer's first weights: requested behind the (few) loads of its incoming gradient -- loads return in
+      // order, the ring in front would make the staging wait for all of it
+      if (e0 == 0 && (top > 0 || A.gx) && wv < bwd_groups<Q>(A.L[top])) bwd_fill<Q>(R, A.L[top], wv, g, c, A.wmask);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) gv[i] = A.w_out ? gv[i] * wv4[i] : gv[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = e0 + i * kT + tid;
+        if (e < n_e) {
+          const int r = e / Np, n = e - r * Np;
+          const int64_t b = b0 + r;
+          float v = 0.f;
+          if (b < A.B && n < Lt.N) {
+            v = gv[i];
+            if (Lt.relu) v = hv[i] > 0.f ? v : 0.f;
+          }
+          d0[r * rs + n] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  MLP_TRACE(A.trace, 1);
+  if (A.L[top].dh) tile_store(d0, rs, A.L[top].dh, A.L[top].ldh, A.L[top].N, b0, A.B);
+  float* din = d0;
+  float* dout = d1;
+  for (int l = top; l >= 0; --l) {
+    const LayerDev& Ld = A.L[l];
+    if (l > 0 || A.gx) {
+      const int ngroups = bwd_groups<Q>(Ld);
+      const bool below = l > 0 && (l - 1 > 0 || A.gx);         // a layer below whose weights can be requested early
+      const float* hl = h_lds(l - 1);
+      for (int gb = wv; gb < ngroups; gb += kWaves) {
+        f32x4 acc[Q];
+        typename BwdRing<Q>::vecq msk[4];
+        bwd_mask<Q>(A, l, gb, b0, g, c, hl, rs_h, msk);
+        bwd_run<Q>(R, Ld, din, rs, gb, g, c, acc, A.wmask);
+        bwd_epilogue<Q>(A, l, dout, rs, gb, b0, g, c, acc, msk);
+        __builtin_amdgcn_sched_barrier(0);
+        // what this wave multiplies next, requested behind the epilogue's stores (the memory pipeline is in order: in
+        // front of them the burst delays the stores by microseconds) and in flight across the barrier
+        if (gb + kWaves < ngroups) bwd_fill<Q>(R, Ld, gb + kWaves, g, c, A.wmask);
+        else if (below && wv < bwd_groups<Q>(A.L[l - 1])) bwd_fill<Q>(R, A.L[l - 1], wv, g, c, A.wmask);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // (a wave without a group in this layer still opens the next one)
+      if (wv >= ngroups && below && wv < bwd_groups<Q>(A.L[l - 1])) bwd_fill<Q>(R, A.L[l - 1], wv, g, c, A.wmask);
+    }
+    MLP_TRACE(A.trace, 2 + 2 * (top - l));
+    __syncthreads();
+    MLP_TRACE(A.trace, 3 + 2 * (top - l));
+    // d loss / d pre-activation of the layer below, complete in `dout`: its copy for the weight-gradient kernel
+    if (l > 0 && A.L[l - 1].dh) tile_store(dout, rs, A.L[l - 1].dh, A.L[l - 1].ldh, A.L[l - 1].N, b0, A.B);
+    float* t = din;
+    din = dout;
+    dout = t;
+  }
+  MLP_TRACE(A.trace, 15);
+}
+
+__device__ __forceinline__ void mlp_bwd_fast(const MlpArgs& A, float* smem, const float* g_lds, const float* hb0,
+                                             const float* hb1, int rs_h) {
+  if (A.fast == 2) mlp_bwd_fast_q<2>(A, smem, g_lds, hb0, hb1, rs_h);
+  else mlp_bwd_fast_q<4>(A, smem, g_lds, hb0, hb1, rs_h);
+}
+
 __global__ __launch_bounds__(kT) void k_mlp_bwd_data(MlpArgs A) {
   extern __shared__ __align__(16) float smem[];
-  mlp_bwd_body(A, smem, nullptr);
+  if (A.fast) mlp_bwd_fast(A, smem, nullptr, nullptr, nullptr, 0);
+  else mlp_bwd_body(A, smem, nullptr, nullptr, 0);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -974,23 +1625,29 @@ __global__ __launch_bounds__(kT) void k_cross_mix_bwd(MlpArgs A, int E, int R) {
 // logits never leave the workgroup, d loss / d logit goes to the backward through LDS, and the head's own launch,
 // the backward's staging round trip and two kernel boundaries disappear.  Per-workgroup partial sums of the loss and
 // of d loss / d bias are reduced in fixed order by k_mlp_reduce.
-__global__ __launch_bounds__(kT) void k_mlp_train(MlpArgs A, HeadArgs Hd) {
+__global__ __launch_bounds__(kT) void k_mlp_train(MlpArgs A, HeadArgs Hd, int bwd_off) {
   extern __shared__ __align__(16) float smem[];
   __shared__ float zl[kTM], gl[kTM];
-  mlp_fwd_body<false>(A, smem, zl);
-  __syncthreads();
   const int tid = threadIdx.x;
+  // the head's inputs, requested before the tower runs (they used to cost a round trip between forward and backward);
+  // absent logit parts borrow y's address and are dropped by a select
+  const int64_t hb = static_cast<int64_t>(blockIdx.x) * kTM + (tid & (kTM - 1));
+  const int64_t hbc = hb < A.B ? hb : A.B - 1;
+  const float h_p0 = ldg_f32((Hd.part0 ? Hd.part0 : Hd.y) + hbc), h_p1 = ldg_f32((Hd.part1 ? Hd.part1 : Hd.y) + hbc);
+  const float h_bias = ldg_f32(Hd.bias ? Hd.bias : Hd.y), h_y = ldg_f32(Hd.y + hbc);
+  const float* htop = A.fast ? mlp_fwd_fast(A, smem, zl) : mlp_fwd_body<false>(A, smem, zl);
+  __syncthreads();
   if (tid < 64) {
-    const int64_t b = static_cast<int64_t>(blockIdx.x) * kTM + tid;
+    const int64_t b = hb;
     float li = 0.f, gz = 0.f;
     if (tid < kTM && b < A.B) {
       float z = 0.f;                       // ((linear + fm) + dnn) + bias: the reference's order of additions
-      if (Hd.part0) z += ldg_f32(Hd.part0 + b);
-      if (Hd.part1) z += ldg_f32(Hd.part1 + b);
+      if (Hd.part0) z += h_p0;
+      if (Hd.part1) z += h_p1;
       z += zl[tid];
-      if (Hd.bias) z += ldg_f32(Hd.bias);
+      if (Hd.bias) z += h_bias;
       const float p = 1.f / (1.f + expf(-z));                     // at::sigmoid
-      const float t = ldg_f32(Hd.y + b);
+      const float t = h_y;
       const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);
       li = (t - 1.f) * l1p - t * lp;                              // at::binary_cross_entropy
       const float q = (1.f - p) * p;
@@ -1008,7 +1665,16 @@ __global__ __launch_bounds__(kT) void k_mlp_train(MlpArgs A, HeadArgs Hd) {
   }
   __threadfence_block();   // the saved activations written above are re-read as relu masks below
   __syncthreads();
-  mlp_bwd_body(A, smem, gl);
+  // bwd_off > 0: the backward's two gradient tiles lie BEHIND the forward's LDS image, so the top layer's output tile is
+  // still there and its relu mask needs no global round trip; 0: they alias it (towers too wide for both images)
+#ifdef DCTR_DIAG
+  if (A.trace) A.trace += 16ull * 4096;   // the backward's stamps go to the second region (tools/tower_bench.py)
+#endif
+  if (A.fast) {
+    float* hb0 = smem + kTM * A.rsx;
+    mlp_bwd_fast(A, smem + bwd_off, gl, bwd_off > 0 ? hb0 : nullptr, bwd_off > 0 ? hb0 + kTM * A.rsh : nullptr, A.rsh);
+  }
+  else mlp_bwd_body(A, smem + bwd_off, gl, bwd_off > 0 ? htop : nullptr, A.rsh);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1017,6 +1683,7 @@ __global__ __launch_bounds__(kT) void k_mlp_train(MlpArgs A, HeadArgs Hd) {
 struct WgradArgs {
   LayerDev L[kMaxL];
   int n_layers, B, S, bs;      // S batch splits of bs rows each (bs % 8 == 0)
+  int P, pbs;                  // projection (d w_out) workgroups, pbs rows each; they fill the slabs j, j + P, ... < S
   int blk0[kMaxL + 2];         // first block of layer l; [n_layers] = projection blocks; [n_layers + 1] = end
   int64_t off_w[kMaxL], off_b[kMaxL], off_o, slab;  // float offsets inside one partial slab; slab = its size
   const float* x;
@@ -1027,163 +1694,229 @@ struct WgradArgs {
   unsigned long long* trace;
 };
 
+// One workgroup = one 64x64 tile of one layer's dW over one batch slice; its four waves take the slice's rows in four
+// contiguous quarters (multiples of 8 rows) and are summed through LDS in wave order.
+//  * Lane (p, jl) owns the COLUMN PAIR (2 jl, 2 jl + 1) of the tile in both operands and the row parity p of a
+//    k-step: one global_load_dwordx2 per operand per k-step (two rows x 256 contiguous bytes), i.e. 2 loads per 4
+//    MFMAs.  The four accumulators are the (even | odd n) x (even | odd k) sub-tiles; the LDS park un-permutes them.
+//  * Loads and MFMAs are interleaved one for one (round 3: the previous loop issued 16 dword loads, then 16 MFMAs --
+//    the matrix pipe idled ~340 cycles per group behind the load block's issue time: 40 ns per MFMA against the
+//    pipe's 30).  A load issued between two MFMAs hides under the 64 cycles the first one occupies the pipe.
+//  * The ring keeps PD-1 groups of U k-steps in flight (~1.4 us of MFMA time: an L2 / MALL round trip under load).
+//  * No predicated load anywhere: column pairs past the row are pulled back inside it (they only reach output rows /
+//    columns that are dropped or zeroed at the store), the ragged last rows of a slice are loaded from a clamped
+//    row and masked to zero afterwards.
 __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
   extern __shared__ __align__(16) float wsm[];
-  float* red = wsm;                    // [4 waves][64x64 tile] (64 KB)
+  float* red = wsm;                    // [4 waves][64 n][64 k] (64 KB)
   float* redb = wsm + 4 * 4096;        // [4][64] bias partials
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, p = lane >> 5, jl = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, p = lane >> 5, jl = lane & 31;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int blk = blockIdx.x;
   MLP_TRACE(A.trace, 0);
   int l = 0;
   while (l < A.n_layers && blk >= A.blk0[l + 1]) ++l;
   const int local = blk - A.blk0[l];
   const int s = local % A.S;
-  const int64_t rb0 = static_cast<int64_t>(s) * A.bs;
-  const int64_t rb1 = (rb0 + A.bs < A.B) ? rb0 + A.bs : A.B;
+  const int rb0 = s * A.bs;
+  const int rb1 = (rb0 + A.bs < A.B) ? rb0 + A.bs : A.B;
   float* part = A.part + static_cast<int64_t>(s) * A.slab;
+  // the slice's rows in four quarters (multiples of 8 rows: whole k-step groups), one per wave
+  const int nslice = rb1 > rb0 ? rb1 - rb0 : 0;
+  const int bq = round_up((nslice + 3) / 4, 8);
+  const int wb0 = rb0 + wv * bq;
+  const int wb1 = (wb0 + bq < rb1) ? wb0 + bq : rb1;
+  const int nrow = wb1 > wb0 ? wb1 - wb0 : 0;
 
-  if (l == A.n_layers) {  // d w_out[n] = sum_b g[b] * h_top[b, n]
+  if (l == A.n_layers) {
+    // d w_out[n] = sum_b g[b] * h_top[b, n] over the rows [j * pbs, (j + 1) * pbs) of projection workgroup j.  A half-wave
+    // reads one row as dwordx4 (128 columns per pass), the 8 half-waves take every 8th row, 8 rows in flight per lane;
+    // the 8 partial sums per column are added in a fixed order.  Few, long workgroups on purpose: the launch is sized so
+    // that GEMM tiles + projection workgroups fit the 256 CUs in one round (plan_wgrad).
     const LayerDev& Lt = A.L[A.n_layers - 1];
-    for (int n = tid; n < Lt.N; n += kTW) {
-      float acc = 0.f;
-#pragma unroll 8
-      for (int64_t b = rb0; b < rb1; ++b) acc += ldg_f32(A.g + b) * ldg_f32(Lt.h + b * Lt.ldh + n);
-      stg_f32(part + A.off_o + n, acc);
+    const int j = local;
+    const int pr0 = j * A.pbs, pr1 = (pr0 + A.pbs < A.B) ? pr0 + A.pbs : A.B;
+    const int hw = wv * 2 + p;                       // half-wave 0..7
+    float* redp = wsm;                               // [8][128]
+    for (int n0 = 0; n0 < Lt.N; n0 += 128) {
+      const int n = n0 + 4 * jl;
+      const int nc = n < Lt.ldh - 4 ? n : Lt.ldh - 4;    // ldh % 4 == 0: the dwordx4 stays inside the row
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int b = pr0 + hw; b < pr1; b += 64) {
+        f32x4 hv[8];
+        float gv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int bb = b + 8 * i < pr1 ? b + 8 * i : pr1 - 1;
+          hv[i] = ldg_f4(Lt.h + static_cast<int64_t>(bb) * Lt.ldh + nc);
+          gv[i] = ldg_f32(A.g + bb);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float gq = (b + 8 * i < pr1) ? gv[i] : 0.f;
+          acc += gq * hv[i];
+        }
+      }
+      __syncthreads();
+      *reinterpret_cast<f32x4*>(redp + hw * 128 + 4 * jl) = acc;
+      __syncthreads();
+      if (tid < 128 && n0 + tid < Lt.N) {
+        float t = redp[tid];
+#pragma unroll
+        for (int h = 1; h < 8; ++h) t += redp[h * 128 + tid];
+        for (int sl = j; sl < A.S; sl += A.P) stg_f32(A.part + static_cast<int64_t>(sl) * A.slab + A.off_o + n0 + tid, sl == j ? t : 0.f);
+      }
     }
     return;
   }
 
   const LayerDev& Ld = A.L[l];
   const float* in = (l == 0) ? A.x : A.L[l - 1].h;
-  const int64_t ldi = (l == 0) ? A.ldx : A.L[l - 1].ldh;
+  const int ldi = static_cast<int>((l == 0) ? A.ldx : A.L[l - 1].ldh);
   const int kt = (Ld.K + 63) >> 6;
   const int tile = local / A.S;
   const int m0 = (tile / kt) * 64, k0 = (tile % kt) * 64;
-  // the workgroup's rows are dealt to its four waves in contiguous quarters (even sizes: 2 rows per MFMA)
-  const int bq = round_up(static_cast<int>((rb1 - rb0 + 3) / 4), 2);
-  const int64_t wb0 = rb0 + static_cast<int64_t>(wv) * bq;
-  const int64_t wb1 = (wb0 + bq < rb1) ? wb0 + bq : rb1;
+  const bool want_bias = (k0 == 0);
 
-  const int ma = m0 + jl, mb = m0 + 32 + jl, ka = k0 + jl, kb = k0 + 32 + jl;
-  const bool va = ma < Ld.N, vb = mb < Ld.N, vka = ka < Ld.K, vkb = kb < Ld.K;
-  f32x16 c00, c01, c10, c11;
+  f32x16 c00, c01, c10, c11;   // (n parity, k parity)
 #pragma unroll
   for (int r = 0; r < 16; ++r) c00[r] = c01[r] = c10[r] = c11[r] = 0.f;
-  float sa = 0.f, sb = 0.f;
-  const bool want_bias = (k0 == 0);
-  // Main loop over FULL groups of 2U rows: no predicates, no masks.  Column indices past N / K are clamped (the
-  // garbage only reaches output rows / columns that are dropped or zeroed at the store); addresses are a uniform
-  // base + a per-lane 32-bit offset + a scalar row offset: one v_add per load.  The loads of the next PD-1 groups
-  // are in flight while the matrix pipe works on the current one.  A last partial group takes the masked path.
-  // (Measured, round 2 -- tools/micro/mfmabench.hip, tools/mlp_trace.py: the matrix pipe retires one 32x32x2 every
-  // 64 cycles at the 2.13 GHz the chip holds under MFMA load = 30 ns; this loop runs at ~40 ns per MFMA after 3.4 us of
-  // start-up latency.  A variant with adjacent-column 8-byte loads, a 7-deep ring and a prologue ordered so that the
-  // compiler's waits are exact -- it otherwise drains the ring once per round -- ran the loop no faster alone and the
-  // whole train step 2 % slower beside the embedding update: the loop is not latency-bound.)
-  constexpr int U = 4, PD = 5;
-  const int mac = va ? ma : 0, mbc = vb ? mb : 0, kac = vka ? ka : 0, kbc = vkb ? kb : 0;
+  float sa0 = 0.f, sa1 = 0.f;
+  // column pair of this lane, pulled back inside the row (ldh, ldi are multiples of 4)
+  const int mc = (m0 + 2 * jl) < (Ld.ldh - 2) ? (m0 + 2 * jl) : (Ld.ldh - 2);
+  const int kc = (k0 + 2 * jl) < (ldi - 2) ? (k0 + 2 * jl) : (ldi - 2);
   const DCTR_GLOBAL char* dbase = (const DCTR_GLOBAL char*)Ld.dh;
   const DCTR_GLOBAL char* ibase = (const DCTR_GLOBAL char*)in;
   const uint32_t ldh4 = static_cast<uint32_t>(Ld.ldh) * 4u, ldi4 = static_cast<uint32_t>(ldi) * 4u;
-  const uint32_t va0 = static_cast<uint32_t>(p) * ldh4 + 4u * mac, va1 = static_cast<uint32_t>(p) * ldh4 + 4u * mbc;
-  const uint32_t vx0 = static_cast<uint32_t>(p) * ldi4 + 4u * kac, vx1 = static_cast<uint32_t>(p) * ldi4 + 4u * kbc;
-  const int nrow = static_cast<int>(wb1 > wb0 ? wb1 - wb0 : 0);
-  const int n_full = nrow / (2 * U);                  // full groups
+  const uint32_t va = static_cast<uint32_t>(p) * ldh4 + 4u * static_cast<uint32_t>(mc);
+  const uint32_t vx = static_cast<uint32_t>(p) * ldi4 + 4u * static_cast<uint32_t>(kc);
+  constexpr int U = 4, PD = 4;
+  const int n_full = nrow / (2 * U);                  // full groups of U k-steps (2 rows each)
   const uint32_t row0 = static_cast<uint32_t>(wb0);
-  auto gload = [&](int gidx, float (*v)[4]) {          // group index -> its 2U rows (clamped to the last full group)
+  auto lda = [&](int gidx, int u) -> f32x2 {          // group index -> k-step u's rows (clamped to the last full group)
     gidx = gidx < n_full ? gidx : n_full - 1;          // scalar
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t r = row0 + static_cast<uint32_t>(gidx * 2 * U + 2 * u);   // scalar
-      const uint32_t sd = r * ldh4, si = r * ldi4;                               // scalar
-      v[u][0] = *(const DCTR_GLOBAL float*)(dbase + (va0 + sd));
-      v[u][1] = *(const DCTR_GLOBAL float*)(dbase + (va1 + sd));
-      v[u][2] = *(const DCTR_GLOBAL float*)(ibase + (vx0 + si));
-      v[u][3] = *(const DCTR_GLOBAL float*)(ibase + (vx1 + si));
-    }
+    const uint32_t r = row0 + static_cast<uint32_t>(gidx * 2 * U + 2 * u);
+    return *(const DCTR_GLOBAL f32x2*)(dbase + (va + r * ldh4));
+  };
+  auto ldx = [&](int gidx, int u) -> f32x2 {
+    gidx = gidx < n_full ? gidx : n_full - 1;
+    const uint32_t r = row0 + static_cast<uint32_t>(gidx * 2 * U + 2 * u);
+    return *(const DCTR_GLOBAL f32x2*)(ibase + (vx + r * ldi4));
   };
   if (n_full > 0) {
-    float ring[PD][U][4];
+    f32x2 ra[PD][U], rx[PD][U];
 #pragma unroll
-    for (int d = 0; d < PD - 1; ++d) gload(d, ring[d]);
-    for (int g0 = 0; g0 < n_full; g0 += PD) {
+    for (int d = 0; d < PD - 1; ++d)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        ra[d][u] = lda(d, u);
+        rx[d][u] = ldx(d, u);
+      }
+    // whole rounds of PD groups (no exit inside: the compiler's vmcnt bookkeeping stays exact -- with a break per
+    // group it waited for all but the last 6 loads, i.e. a prefetch distance of 3 k-steps instead of 12), then the
+    // < PD left-over groups, whose operands the last round (or the prologue) has already requested
+    const int n_round = n_full / PD, rem = n_full - n_round * PD;
+    for (int rd = 0; rd < n_round; ++rd) {
 #pragma unroll
       for (int dd = 0; dd < PD; ++dd) {
-        const int gi = g0 + dd;
-        gload(gi + PD - 1, ring[(dd + PD - 1) % PD]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (gi < n_full) {
+        const int gi = rd * PD + dd;
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const float a0 = ring[dd][u][0], a1 = ring[dd][u][1], x0 = ring[dd][u][2], x1 = ring[dd][u][3];
-            c00 = mfma32(a0, x0, c00);
-            c01 = mfma32(a0, x1, c01);
-            c10 = mfma32(a1, x0, c10);
-            c11 = mfma32(a1, x1, c11);
-            sa += a0;
-            sb += a1;
-          }
+        for (int u = 0; u < U; ++u) {
+          const f32x2 a = ra[dd][u], x = rx[dd][u];
+          __builtin_amdgcn_sched_barrier(0);
+          c00 = mfma32(a.x, x.x, c00);
+          // the bias column sums, pinned HERE: written as `sa0 += a.x` the adds are sunk across the scheduling
+          // barriers, `a` outlives the reload of its ring slot, the ring is rotated with v_mov copies at the loop
+          // head -- and those copies wait for every load in flight (the ring drained once per round)
+          asm volatile("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3" : "+v"(sa0), "+v"(sa1) : "v"(a.x), "v"(a.y));
+          __builtin_amdgcn_sched_barrier(0);
+          ra[(dd + PD - 1) % PD][u] = lda(gi + PD - 1, u);
+          __builtin_amdgcn_sched_barrier(0);
+          c01 = mfma32(a.x, x.y, c01);
+          __builtin_amdgcn_sched_barrier(0);
+          rx[(dd + PD - 1) % PD][u] = ldx(gi + PD - 1, u);
+          __builtin_amdgcn_sched_barrier(0);
+          c10 = mfma32(a.y, x.x, c10);
+          c11 = mfma32(a.y, x.y, c11);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < PD - 1; ++d) {
+      if (d < rem) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const f32x2 a = ra[d][u], x = rx[d][u];
+          c00 = mfma32(a.x, x.x, c00);
+          c01 = mfma32(a.x, x.y, c01);
+          c10 = mfma32(a.y, x.x, c10);
+          c11 = mfma32(a.y, x.y, c11);
+          sa0 += a.x;
+          sa1 += a.y;
+        }
       }
     }
   }
-  for (int64_t bb = wb0 + static_cast<int64_t>(n_full) * 2 * U; bb < wb1; bb += 2) {   // ragged tail, masked
-    const int64_t b = bb + p;
-    const bool vr = b < wb1;
-    const int64_t bc = vr ? b : wb0;
-    const float* dr = Ld.dh + bc * Ld.ldh;
-    const float* ir = in + bc * ldi;
-    const float a0 = vr ? ldg_f32(dr + mac) : 0.f, a1 = vr ? ldg_f32(dr + mbc) : 0.f;
-    const float x0 = vr ? ldg_f32(ir + kac) : 0.f, x1 = vr ? ldg_f32(ir + kbc) : 0.f;
-    c00 = mfma32(a0, x0, c00);
-    c01 = mfma32(a0, x1, c01);
-    c10 = mfma32(a1, x0, c10);
-    c11 = mfma32(a1, x1, c11);
-    sa += a0;
-    sb += a1;
-  }
-  MLP_TRACE(A.trace, 1);
-  // combine the four waves in wave order: every wave parks its 64x64 tile, then wave w sums and stores quadrant w
-  {
-    float* dst = red + wv * 4096;
+  if (nrow > 2 * U * n_full) {   // ragged tail (< 8 rows): clamped rows, masked to zero, loaded in one round trip
+    f32x2 ta[U], tx[U];
+    const int t0 = wb0 + 2 * U * n_full;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      dst[(0 * 16 + r) * 64 + lane] = c00[r];
-      dst[(1 * 16 + r) * 64 + lane] = c01[r];
-      dst[(2 * 16 + r) * 64 + lane] = c10[r];
-      dst[(3 * 16 + r) * 64 + lane] = c11[r];
+    for (int u = 0; u < U; ++u) {
+      const int b = t0 + 2 * u + p;
+      const uint32_t bc = static_cast<uint32_t>(b < wb1 ? b : wb0);
+      ta[u] = *(const DCTR_GLOBAL f32x2*)(dbase + (4u * static_cast<uint32_t>(mc) + bc * ldh4));
+      tx[u] = *(const DCTR_GLOBAL f32x2*)(ibase + (4u * static_cast<uint32_t>(kc) + bc * ldi4));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool vr = t0 + 2 * u + p < wb1;
+      const float a0 = vr ? ta[u].x : 0.f, a1 = vr ? ta[u].y : 0.f;   // (the clamped row holds finite data: 0 * x = 0)
+      c00 = mfma32(a0, tx[u].x, c00);
+      c01 = mfma32(a0, tx[u].y, c01);
+      c10 = mfma32(a1, tx[u].x, c10);
+      c11 = mfma32(a1, tx[u].y, c11);
+      sa0 += a0;
+      sa1 += a1;
     }
   }
-  sa += __shfl_xor(sa, 32, kWave);
-  sb += __shfl_xor(sb, 32, kWave);
-  if (want_bias && p == 0) {
-    redb[wv * 64 + jl] = sa;
-    redb[wv * 64 + 32 + jl] = sb;
+  MLP_TRACE(A.trace, 1);
+  // park the wave's tile at its logical coordinates: accumulator (pa, pb), register r, lane (p, jl) is
+  // dW[m0 + 2 acc_row32(r, p) + pa][k0 + 2 jl + pb]
+  {
+    float* dst = red + wv * 4096 + 2 * jl;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = 2 * acc_row32(r, p);
+      *reinterpret_cast<f32x2*>(dst + n * 64) = f32x2{c00[r], c01[r]};
+      *reinterpret_cast<f32x2*>(dst + (n + 1) * 64) = f32x2{c10[r], c11[r]};
+    }
   }
+  sa0 += __shfl_xor(sa0, 32, kWave);
+  sa1 += __shfl_xor(sa1, 32, kWave);
+  if (want_bias && p == 0) *reinterpret_cast<f32x2*>(redb + wv * 64 + 2 * jl) = f32x2{sa0, sa1};
   __syncthreads();
   MLP_TRACE(A.trace, 2);
-  f32x16 q;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int o = (wv * 16 + r) * 64 + lane;
-    q[r] = ((red[o] + red[4096 + o]) + red[2 * 4096 + o]) + red[3 * 4096 + o];
-  }
+  // the four waves' tiles summed in wave order; thread t stores 4 x (4 consecutive k of one row)
   float* pw = part + A.off_w[l];
-  const int rowbase = m0 + 32 * (wv >> 1);
-  const int kq = (wv & 1) ? kb : ka;
-  const bool vkq = (wv & 1) ? vkb : vka;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = rowbase + acc_row32(r, p);
-    if (row < Ld.N && kq < Ld.ldw) stg_f32(pw + static_cast<int64_t>(row) * Ld.ldw + kq, vkq ? q[r] : 0.f);
+  for (int i = 0; i < 4; ++i) {
+    const int e4 = tid + kTW * i;
+    const int n = e4 >> 4, k4 = (e4 & 15) << 2;
+    const float* src = red + n * 64 + k4;
+    const f32x4 q0 = *reinterpret_cast<const f32x4*>(src), q1 = *reinterpret_cast<const f32x4*>(src + 4096),
+                q2 = *reinterpret_cast<const f32x4*>(src + 2 * 4096), q3 = *reinterpret_cast<const f32x4*>(src + 3 * 4096);
+    f32x4 q = ((q0 + q1) + q2) + q3;
+    const int row = m0 + n, col = k0 + k4;
+    if (row < Ld.N && col < Ld.ldw) {   // ldw % 4 == 0: the four columns are inside the row or all outside it
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (col + c >= Ld.K) q[c] = 0.f;
+      *(DCTR_GLOBAL f32x4*)(pw + static_cast<int64_t>(row) * Ld.ldw + col) = q;
+    }
   }
-  if (want_bias && wv == 0 && p == 0) {
-    const float ta = ((redb[jl] + redb[64 + jl]) + redb[128 + jl]) + redb[192 + jl];
-    const float tb = ((redb[32 + jl] + redb[96 + jl]) + redb[160 + jl]) + redb[224 + jl];
-    if (va) stg_f32(part + A.off_b[l] + ma, ta);
-    if (vb) stg_f32(part + A.off_b[l] + mb, tb);
-  }
+  if (want_bias && tid < 64 && m0 + tid < Ld.N)
+    stg_f32(part + A.off_b[l] + m0 + tid, ((redb[tid] + redb[64 + tid]) + redb[128 + tid]) + redb[192 + tid]);
   MLP_TRACE(A.trace, 3);
 #ifdef DCTR_DIAG
   if (A.trace && threadIdx.x == 0) A.trace[blockIdx.x * 16ull + 14] = static_cast<unsigned long long>(l);
@@ -1235,17 +1968,61 @@ __global__ __launch_bounds__(256) void k_mlp_reduce(ReduceArgs A) {
     }
     return;
   }
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  // 4 consecutive floats of the slab per thread (every segment starts at a multiple of 4 floats: a float4 never
+  // straddles two tensors).  The S partials are fetched 8 at a time, all loads of a batch in flight together (round 3:
+  // the loop used to be `acc += load` with a runtime trip count -- S dependent round trips, 5.5 us for 5.7 MB), and
+  // added in slab order.
+  const int64_t i = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 4;
   if (i >= A.seg_off[A.n_seg]) return;
   int sg = 0;
   while (i >= A.seg_off[sg + 1]) ++sg;
   float* dst = A.seg_dst[sg];
-  if (!dst || i - A.seg_off[sg] >= A.seg_len[sg]) return;
-  float acc = 0.f;
-  for (int s = 0; s < A.S; ++s) acc += ldg_f32(A.part + static_cast<int64_t>(s) * A.slab + i);
-  stg_f32(dst + (i - A.seg_off[sg]), acc);
+  const int64_t o = i - A.seg_off[sg];
+  if (!dst || o >= A.seg_len[sg]) return;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; s0 < A.S; s0 += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int sj = s0 + j < A.S ? s0 + j : A.S - 1;
+      v[j] = ldg_f4(A.part + static_cast<int64_t>(sj) * A.slab + i);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (s0 + j < A.S) acc += v[j];
+  }
+  const int nv = (A.seg_len[sg] - o) < 4 ? static_cast<int>(A.seg_len[sg] - o) : 4;
+  float* d = dst + o;
   // (row padding of a weight: gradient 0, parameter 0, Adagrad state 0 -- the step leaves all three alone)
-  dense_step_apply(A.step, dst + (i - A.seg_off[sg]), acc);
+  if (A.step.kind < 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < nv) stg_f32(d + c, acc[c]);
+    return;
+  }
+  // the optimizer step on the elements just finished: parameter and state loads of all four first, then the stores
+  const int64_t k = d - A.step.grad_base;
+  float w[4], st[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int cc = c < nv ? c : 0;
+    w[c] = ldg_f32(A.step.param_base + k + cc);
+    st[c] = A.step.kind == DCTR_UPD_ADAGRAD ? ldg_f32(A.step.state_base + k + cc) : 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c < nv) {
+      const float g = acc[c];
+      stg_f32(d + c, g);
+      if (A.step.kind == DCTR_UPD_ADAGRAD) {   // torch.optim.Adagrad: s += g*g ; p -= lr * g / (sqrt(s) + eps)
+        const float sn = st[c] + g * g;
+        stg_f32(A.step.state_base + k + c, sn);
+        stg_f32(A.step.param_base + k + c, w[c] - A.step.lr * (g / (sqrtf(sn) + A.step.eps)));
+      } else {                                 // torch.optim.SGD
+        stg_f32(A.step.param_base + k + c, w[c] - A.step.lr * g);
+      }
+    }
+  }
 }
 
 // ---- host helpers ---------------------------------------------------------------------------------------------
@@ -1278,6 +2055,26 @@ int pick_kc(int K0p, int rsh) {
   return kc;
 }
 
+// > 0 when the tower fits the fast bodies: one staged input chunk of at most 512 columns, every layer at most 512 wide (one
+// pass of <= 4 output tiles per wave forward, <= 8 column groups backward)
+int tower_fast(const dctr_mlp_t* m, int kc) {
+  const int K0p = round_up(m->layer[0].K, 16);
+  if (K0p > kc || K0p > 512) return 0;
+  int narrow = 1;
+  for (int l = 0; l < m->n_layers; ++l) {
+    if (m->layer[l].N > 512 || m->layer[l].K > 512) return 0;
+    if (m->layer[l].K > 256) narrow = 0;
+  }
+  return narrow ? 2 : 1;     // 2: the backward uses 32-column groups
+}
+
+uint32_t diag_wmask() {
+#ifdef DCTR_DIAG
+  if (const char* e = getenv("DCTR_MLP_WMASK")) return static_cast<uint32_t>(strtoul(e, nullptr, 0));
+#endif
+  return 0xffffffffu;
+}
+
 int max_width(const dctr_mlp_t* m) {
   int w = 0;
   for (int l = 0; l < m->n_layers; ++l) w = m->layer[l].N > w ? m->layer[l].N : w;
@@ -1285,20 +2082,42 @@ int max_width(const dctr_mlp_t* m) {
 }
 
 struct WgradPlan {
-  int S, bs;
+  int S, bs, P, pbs;
   int blk0[kMaxL + 2];
   int64_t off_w[kMaxL], off_b[kMaxL], off_o, slab;
 };
 
 WgradPlan plan_wgrad(const dctr_mlp_t* m, int32_t B) {
   WgradPlan P;
-  // Batch slices per output tile.  Measured on the DeepFM tower at batch 4096 (37 tiles; step time in ms): S = 3 0.137,
-  // 4 0.123, 5 0.118, 6 0.114, 7 0.116, 8 0.113, 10 0.1115, 12 0.1116, 16 0.115 -- more, shorter workgroups win until the
-  // partial slabs' traffic does (keeping the launch within one wave of 256 workgroups, S = 6, is NOT better): ~410 rows per slice.
-  // (re-measured at the end of round 2 with everything else in place: 8 slices 0.1138, 10 0.1124, 12 0.1129, 14 0.1152)
-  int S = (B + 205) / 410;
+  // Batch slices per 64x64 output tile.  The weight-gradient kernel saturates the matrix pipe with ONE wave per SIMD
+  // (32x32x2 issues back to back from a single accumulator chain), so the aim is one 4-wave workgroup per CU, all
+  // resident at once and all of equal length: S ~ 256 CUs / tiles (DeepFM tower: 36 tiles -> 7 slices of ~585 rows,
+  // 252 workgroups).  Fewer slices also mean fewer partial slabs for k_mlp_reduce.  Slices stay >= 64 rows.
+  // (Round 2 ran 10 slices = 360 workgroups, i.e. 104 CUs with two and 152 with one: a 1.4-wave tail.)
+  int tiles = 0;
+  for (int l = 0; l < m->n_layers; ++l) tiles += ((m->layer[l].N + 63) / 64) * ((m->layer[l].K + 63) / 64);
+  // cost model: workgroups spread evenly over 256 CUs, a CU's workgroups run back to back (two co-resident ones share
+  // its matrix pipe, which is the same thing), each costs its rows + ~150 rows' worth of start-up / LDS combine.  One
+  // CU is kept for the projection's workgroup(s): at 7 slices of the DeepFM tower 252 + 7 workgroups was 3 more than the
+  // chip has CUs -- three CUs ran two GEMM workgroups back to back and the launch took twice as long (round 3).
+  int S = 1;
+  {
+    int64_t best = -1;
+    for (int s = 1; s <= 16 && s <= (B >= 64 ? B / 64 : 1); ++s) {
+      const int64_t rounds = (static_cast<int64_t>(tiles) * s + (m->w_out ? 1 : 0) + 255) / 256;
+      const int64_t cost = rounds * ((B + s - 1) / s + 150);
+      if (best < 0 || cost < best) {
+        best = cost;
+        S = s;
+      }
+    }
+  }
+#ifdef DCTR_DIAG
+  if (const char* e = getenv("DCTR_WGRAD_SLICES")) S = atoi(e);   // tools/tower_bench.py sweeps it
+#endif
+  if (S > B / 64) S = B / 64;
+  if (S > 16) S = 16;
   if (S < 1) S = 1;
-  if (S > 12) S = 12;
   P.S = S;
   P.bs = round_up((B + S - 1) / S, 8);
   int64_t off = 0;
@@ -1314,8 +2133,16 @@ WgradPlan plan_wgrad(const dctr_mlp_t* m, int32_t B) {
   }
   P.blk0[m->n_layers] = blk;
   P.off_o = off;
+  P.P = 0;
+  P.pbs = 0;
   if (m->w_out) {
-    blk += S;
+    // projection workgroups: as many as CUs are left in the last round of GEMM workgroups, between 1 and S
+    int spare = 256 - blk % 256;
+    if (blk % 256 == 0) spare = 0;
+    P.P = spare < 1 ? 1 : (spare > S ? S : spare);
+    if (P.P > 4 && B / P.P < 512) P.P = B / 512 > 0 ? (B / 512 < P.P ? B / 512 : P.P) : 1;   // no point in slivers
+    P.pbs = round_up((B + P.P - 1) / P.P, 8);
+    blk += P.P;
     off += round_up(m->layer[m->n_layers - 1].N, 4);
   }
   P.blk0[m->n_layers + 1] = blk;
@@ -1351,6 +2178,7 @@ extern "C" int dctr_mlp_fwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, i
   a.kc = pick_kc(K0p, a.rsh);
   a.rsx = (K0p < a.kc ? K0p : a.kc) + 4;
   a.rsd = 0;
+  a.fast = tower_fast(m, a.kc); a.wmask = diag_wmask();
   const size_t lds = static_cast<size_t>(kTM) * (a.rsx + 2 * a.rsh) * 4;
   if (lds > 150 * 1024) return DCTR_ENOSUP;
   if (lds > 64 * 1024)
@@ -1398,7 +2226,7 @@ int launch_wgrad_reduce(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32
   {
     WgradArgs a;
     fill_layers(m, a.L);
-    a.n_layers = m->n_layers; a.B = B; a.S = P.S; a.bs = P.bs;
+    a.n_layers = m->n_layers; a.B = B; a.S = P.S; a.bs = P.bs; a.P = P.P; a.pbs = P.pbs;
     for (int i = 0; i < kMaxL + 2; ++i) a.blk0[i] = i <= m->n_layers + 1 ? P.blk0[i] : 0;
     for (int l = 0; l < kMaxL; ++l) {
       a.off_w[l] = l < m->n_layers ? P.off_w[l] : 0;
@@ -1430,7 +2258,7 @@ int launch_wgrad_reduce(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32
   r.n_seg = ns;
   r.head_loss = head_loss; r.head_gbias = head_gbias; r.n_head = n_head; r.loss = loss; r.g_bias = g_bias;
   r.step = dense_step_dev(step);
-  const unsigned nblk = static_cast<unsigned>((P.slab + 255) / 256) + (head_loss ? 1u : 0u);
+  const unsigned nblk = static_cast<unsigned>((P.slab / 4 + 255) / 256) + (head_loss ? 1u : 0u);
   k_mlp_reduce<<<dim3(nblk), dim3(256), 0, s>>>(r);
   return launch_status();
 }
@@ -1455,6 +2283,7 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, i
     a.trace = g_mlp_trace ? g_mlp_trace + 16ull * 4096 : nullptr;
     a.rsx = 0; a.rsh = 0;
     a.rsd = bwd_stride(m);
+    a.fast = tower_fast(m, kKC); a.wmask = diag_wmask();
     const size_t lds = static_cast<size_t>(kTM) * 2 * a.rsd * 4;
     if (lds > 160 * 1024) return DCTR_ENOSUP;
     if (lds > 64 * 1024)
@@ -1500,9 +2329,15 @@ extern "C" int dctr_mlp_train_step(const dctr_mlp_t* m, const float* x, int64_t 
     a.kc = pick_kc(K0p, a.rsh);
     a.rsx = (K0p < a.kc ? K0p : a.kc) + 4;
     a.rsd = bwd_stride(m);
+    a.fast = tower_fast(m, a.kc); a.wmask = diag_wmask();
     const size_t lds_f = static_cast<size_t>(kTM) * (a.rsx + 2 * a.rsh) * 4;
     const size_t lds_b = static_cast<size_t>(kTM) * 2 * a.rsd * 4;
-    const size_t lds = lds_f > lds_b ? lds_f : lds_b;
+    size_t lds = lds_f > lds_b ? lds_f : lds_b;
+    int bwd_off = 0;
+    if (lds_f + lds_b <= 150 * 1024) {     // both images fit: the backward keeps the forward's activations in LDS
+      bwd_off = static_cast<int>(lds_f / 4);
+      lds = lds_f + lds_b;
+    }
     if (lds > 150 * 1024) return DCTR_ENOSUP;
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_train), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1510,7 +2345,7 @@ extern "C" int dctr_mlp_train_step(const dctr_mlp_t* m, const float* x, int64_t 
     HeadArgs hd;
     hd.part0 = part0; hd.part1 = part1; hd.bias = bias; hd.y = y; hd.y_pred = y_pred; hd.g_logit = g_logit;
     hd.part_loss = part_loss; hd.part_gbias = part_gb;
-    k_mlp_train<<<dim3(n_tiles), dim3(kT), lds, s>>>(a, hd);
+    k_mlp_train<<<dim3(n_tiles), dim3(kT), lds, s>>>(a, hd, bwd_off);
     const int st = launch_status();
     if (st != DCTR_OK) return st;
   }
@@ -1578,6 +2413,7 @@ extern "C" int dctr_crossnet_mat_fwd(const dctr_mlp_t* m, const float* x, int64_
   a.rsx = Wp + 4;
   a.rsh = Wp + 4;
   a.rsd = 0;
+  a.fast = 0; a.wmask = 0xffffffffu;
   const size_t lds = static_cast<size_t>(kTM) * (a.rsx + 2 * a.rsh) * 4;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cross_mat_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1608,7 +2444,7 @@ extern "C" int dctr_crossnet_mat_bwd(const dctr_mlp_t* m, const float* x, int64_
     fill_layers(m, a.L);
     a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = nullptr; a.logit = nullptr;
     a.g = gY; a.ldg = ld_g; a.gx = gx; a.ldgx = ld_gx; a.trace = nullptr;
-    a.rsx = 0; a.rsh = 0;
+    a.rsx = 0; a.rsh = 0; a.fast = 0; a.wmask = 0xffffffffu;
     a.rsd = round_up(W, 64) + 4;
     const size_t lds = static_cast<size_t>(kTM) * 4 * a.rsd * 4;
     if (lds > 64 * 1024)
@@ -1673,7 +2509,7 @@ extern "C" int dctr_crossnet_mix_fwd(const dctr_mlp_t* m, int32_t E, int32_t R, 
   fill_layers(m, a.L);
   a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = nullptr; a.logit = nullptr;
   a.g = nullptr; a.ldg = 0; a.gx = nullptr; a.ldgx = 0; a.trace = nullptr;
-  a.kc = kKC; a.rsx = 0; a.rsh = 0; a.rsd = 0;
+  a.kc = kKC; a.rsx = 0; a.rsh = 0; a.rsd = 0; a.fast = 0; a.wmask = 0xffffffffu;
   const size_t lds = mix_lds_fwd(W, E * R + E);
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cross_mix_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1705,7 +2541,7 @@ extern "C" int dctr_crossnet_mix_bwd(const dctr_mlp_t* m, int32_t E, int32_t R, 
     fill_layers(m, a.L);
     a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = nullptr; a.logit = nullptr;
     a.g = gY; a.ldg = ld_g; a.gx = gx; a.ldgx = ld_gx; a.trace = nullptr;
-    a.kc = kKC; a.rsx = 0; a.rsh = 0; a.rsd = 0;
+    a.kc = kKC; a.rsx = 0; a.rsh = 0; a.rsd = 0; a.fast = 0; a.wmask = 0xffffffffu;
     const size_t lds = mix_lds_bwd(W, E * R + E);
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cross_mix_bwd),

@@ -40,7 +40,6 @@ constexpr int kThreads = 256;
 constexpr int kCap = 512;     // sort keys held in LDS
 constexpr int kStack = 40;    // pending (id bits fixed, their value) splits of an overflowing partition
 constexpr int kBucket = 512;  // keys per (unit, partition) bucket of the pre-pass (<= kCap; 2 per thread of its sort)
-constexpr int kOverPer = 16;  // bucket counters a workgroup of k_embed_update_overflow checks
 
 struct UpdArgs {
   const dctr_field_t* deep;
@@ -751,46 +750,17 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
   upd_partition<VEC, LPR, OPT>(A, u, p);
 }
 
-// Behind k_embed_apply_sorted: the partitions the pre-pass could not sort (more than kBucket entries: hot ids) still
-// carry their count.  A workgroup checks kOverPer consecutive counters and runs the general path for the (rare) ones
-// left -- few counters per workgroup, so that the overflowing partitions of a skewed batch (one per unit under Zipf
-// ids) are worked on in parallel; the last n_wdense workgroups do the dense half of Linear.
-template <int VEC, int LPR, int OPT>
-__global__ __launch_bounds__(kThreads, 5) void k_embed_update_overflow(UpdArgs A) {
-  const int n_scan = static_cast<int>(gridDim.x) - (A.g_wdense ? A.n_wdense : 0);
-  if (static_cast<int>(blockIdx.x) >= n_scan) {
-    wdense_column(A, static_cast<int>(blockIdx.x) - n_scan);
-    return;
-  }
-  __shared__ int over[kOverPer], n_over;
-  const int tid = threadIdx.x;
-  const int64_t nb = static_cast<int64_t>(A.n_units) * A.P;
-  const int64_t bk = static_cast<int64_t>(blockIdx.x) * kOverPer + tid;
-  if (tid == 0) n_over = 0;
-  __syncthreads();
-  if (tid < kOverPer && bk < nb && *(const DCTR_GLOBAL int32_t*)(A.bcnt + bk) > kBucket)
-    over[atomicAdd(&n_over, 1)] = static_cast<int>(bk);
-  __syncthreads();
-  const int n = n_over;
-  if (n == 0) return;
-  // (in whatever order the atomics filled the list: partitions own disjoint rows, nothing depends on it)
-  for (int k = 0; k < n; ++k) {
-    const int mine = over[k];
-    const int u = mine / A.P, p = mine - u * A.P;
-    upd_partition<VEC, LPR, OPT>(A, u, p);
-    __syncthreads();
-  }
-}
-
 // ---- the update proper, given the pre-pass's sorted keys ------------------------------------------------------------
 // What is left on the step's critical chain once dctr_embed_segments has run: TWO memory round trips per workgroup --
 // {entry count, sorted keys} (one coalesced read), then {gradient strips, row strips} -- a segmented sum through LDS
 // and one read-modify-write per touched row.  No scan, no sort, no stack: 8 workgroups per CU (the general kernel
 // below: 5), so a saturating launch keeps ~1.6x more rows in flight.  Same tiling, same summation order as the general
-// kernel's tiled path: bit-identical results.  Partitions whose count exceeds kBucket (hot ids) are left alone -- the
-// general kernel, launched right behind, sees their counters and scans them itself (all others read 0 there).
+// kernel's tiled path: bit-identical results.  A partition whose count exceeds kBucket (a hot id: the pre-pass could not
+// sort it) takes the general path right here (scan, split by id bits, streaming of a hot id), and the last n_wdense
+// workgroups of the launch do the dense half of Linear.  (Both used to be a second launch, k_embed_update_overflow: 8 us
+// of launch + boundary + counter round trip on the step's critical chain for work that is almost always empty -- round 3.)
 template <int VEC, int LPR, int OPT>
-__global__ __launch_bounds__(kThreads, 6) void k_embed_apply_sorted(UpdArgs A) {
+__global__ __launch_bounds__(kThreads, 5) void k_embed_apply_sorted(UpdArgs A) {
   constexpr int G = kThreads / LPR;   // entries per tile
   constexpr int RW = LPR * VEC;
   __shared__ unsigned long long tails[kThreads / 64];  // per wave: groups of the tile that end a segment
@@ -801,7 +771,11 @@ __global__ __launch_bounds__(kThreads, 6) void k_embed_apply_sorted(UpdArgs A) {
   const int tid = threadIdx.x;
   const int P = A.P;
   const int u = static_cast<int>(blockIdx.x) / P, p = static_cast<int>(blockIdx.x) - u * P;
-  if (u >= A.n_units) return;
+  if (u >= A.n_units) {
+    const int j = static_cast<int>(blockIdx.x) - A.n_units * P;
+    if (A.g_wdense && j < A.n_wdense) wdense_column(A, j);
+    return;
+  }
   int32_t* cnt = A.bcnt + static_cast<int64_t>(u) * P + p;
   const uint32_t* src = A.bkeys + (static_cast<int64_t>(u) * P + p) * kBucket;
   const int grp = tid / LPR, gl = tid % LPR, e0 = gl * VEC;
@@ -827,7 +801,11 @@ __global__ __launch_bounds__(kThreads, 6) void k_embed_apply_sorted(UpdArgs A) {
   const int64_t ld_ww = (wi >= 0) ? row_ld(fw) : 1, ld_ws = (wi >= 0) ? state_ld(fw) : 1;
 
   const int n = uni(n_raw);
-  if (n <= 0 || n > kBucket) return;   // (uniform: every thread read the same counter)
+  if (n <= 0) return;                  // (uniform: every thread read the same counter)
+  if (n > kBucket) {                   // a hot partition: the general path (it takes the counter and re-scans the ids)
+    upd_partition<VEC, LPR, OPT>(A, u, p);
+    return;
+  }
   DCTR_TRACE(1);
 #ifdef DCTR_DIAG
   if (A.trace && tid == 0) A.trace[blockIdx.x * 8ull + 7] = static_cast<unsigned long long>(n);
@@ -853,16 +831,18 @@ __global__ __launch_bounds__(kThreads, 6) void k_embed_apply_sorted(UpdArgs A) {
     const bool seg_end = have && ((i == n - 1) || (static_cast<int>(knext >> A.bbits) != idq));
     const bool last_of_tile = have && ((grp == G - 1) || (i == n - 1));
     // round trip 2: everything this entry contributes, and (segment ends only) the row it lands on
+    // (nothing is USED inside the branches that guard these loads: with `h += gf * S` right behind its loads the compiler
+    // waited for them there, and the row loads below left one round trip later -- three dependent trips per tile where
+    // two were meant; round 3)
     Strip<VEC> h = strip_zero<VEC>(), w = strip_zero<VEC>(), s = strip_zero<VEC>(), e = strip_zero<VEC>();
+    Strip<VEC> S = strip_zero<VEC>();
     float gf = 0.f, gw = 0.f, ww = 0.f, sw = 0.f;
     if (have) {
       if (lane_on) {
         if (A.gout) h = strip_load<VEC>(A.gout + static_cast<int64_t>(b) * A.ldg + goff);
         if (fold) {
-          const Strip<VEC> S = strip_load<VEC>(A.fm_s + static_cast<int64_t>(b) * A.lds_ + e0);
+          S = strip_load<VEC>(A.fm_s + static_cast<int64_t>(b) * A.lds_ + e0);
           gf = ldg_f32(A.gfm + b);
-#pragma unroll
-          for (int k = 0; k < VEC; ++k) h.v[k] += gf * S.v[k];
         }
       }
       if (wide_on && gl == 0) gw = ldg_f32(A.gwide + static_cast<int64_t>(b) * A.ldgw);
@@ -885,7 +865,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_embed_apply_sorted(UpdArgs A) {
     }
     if (lane_on) {
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) gbuf[grp * RW + e0 + k] = h.v[k];
+      for (int k = 0; k < VEC; ++k) gbuf[grp * RW + e0 + k] = h.v[k] + gf * S.v[k];   // (gf = 0, S = 0 without FM)
     }
     if (gl == 0) {
       gfbuf[grp] = gf;
@@ -1285,31 +1265,25 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
     }
   }
 
-  // presorted: the lean kernel does every partition the pre-pass could sort; the general kernel behind it finds their
-  // counters at zero (nothing to do) and takes the overflowing ones (and the dense half of Linear)
-  const dim3 grid_sorted(static_cast<unsigned>(n_units) * static_cast<unsigned>(P));
-  const dim3 grid_over(static_cast<unsigned>((nbuckets + kOverPer - 1) / kOverPer) +
-                       (g_wdense ? static_cast<unsigned>(plan->n_wdense) : 0u));
+  // presorted: one launch -- the lean path for every partition the pre-pass could sort, the general path inside the same
+  // kernel for an overflowing one, the dense half of Linear in the last workgroups (`grid` above already counts them)
 #define DCTR_UPD_LAUNCH(VEC_, LPR_)                                                              \
   do {                                                                                           \
     if (opt == DCTR_UPD_ADAGRAD) {                                                               \
       if (a.presorted) {                                                                         \
-        k_embed_apply_sorted<VEC_, LPR_, 1><<<grid_sorted, block, 0, s>>>(a);                    \
-        k_embed_update_overflow<VEC_, LPR_, 1><<<grid_over, block, 0, s>>>(a);                   \
+        k_embed_apply_sorted<VEC_, LPR_, 1><<<grid, block, 0, s>>>(a);                           \
       } else {                                                                                   \
         k_embed_update<VEC_, LPR_, 1><<<grid, block, 0, s>>>(a);                                 \
       }                                                                                          \
     } else if (opt == DCTR_UPD_SGD) {                                                            \
       if (a.presorted) {                                                                         \
-        k_embed_apply_sorted<VEC_, LPR_, 0><<<grid_sorted, block, 0, s>>>(a);                    \
-        k_embed_update_overflow<VEC_, LPR_, 0><<<grid_over, block, 0, s>>>(a);                   \
+        k_embed_apply_sorted<VEC_, LPR_, 0><<<grid, block, 0, s>>>(a);                           \
       } else {                                                                                   \
         k_embed_update<VEC_, LPR_, 0><<<grid, block, 0, s>>>(a);                                 \
       }                                                                                          \
     } else {                                                                                     \
       if (a.presorted) {                                                                         \
-        k_embed_apply_sorted<VEC_, LPR_, 2><<<grid_sorted, block, 0, s>>>(a);                    \
-        k_embed_update_overflow<VEC_, LPR_, 2><<<grid_over, block, 0, s>>>(a);                   \
+        k_embed_apply_sorted<VEC_, LPR_, 2><<<grid, block, 0, s>>>(a);                           \
       } else {                                                                                   \
         k_embed_update<VEC_, LPR_, 2><<<grid, block, 0, s>>>(a);                                 \
       }                                                                                          \

@@ -59,6 +59,7 @@ class DenseSlab(object):
         self._fork = None
         self._pending = None
         self.deferred = None      # overlap == "defer": the closure that enqueues the weight-gradient kernels
+        self.after_update = None  # topology "tower_side": enqueues the forked weight gradients behind the update's launch
         # in-kernel optimizer step (single-GPU fused train step): the kernels that finish the dense gradients (the
         # tower's weight-gradient reduction, the update kernel's Linear.weight workgroups) also step the parameters,
         # and the embedding update runs on a side stream beside them -- see begin_inline_step()
@@ -73,7 +74,7 @@ class DenseSlab(object):
     def __getstate__(self):
         d = dict(self.__dict__)
         d["_lay"] = [self._lay[id(p)] for p in self.params]     # id() keys do not survive pickling
-        d["_fork"] = d["_pending"] = d["deferred"] = None       # streams / events / closures are per process
+        d["_fork"] = d["_pending"] = d["deferred"] = d["after_update"] = None   # streams / events / closures: per process
         d["overlap"] = False
         d["inline"] = d["update_stream"] = d["main_keep"] = None
         d["wgrad_side"] = d["gather_side"] = False

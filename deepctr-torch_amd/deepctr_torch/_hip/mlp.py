@@ -303,12 +303,24 @@ class TowerHeadFunction(torch.autograd.Function):
             # the fork stream, the embedding update stays on this one; nothing joins them until the NEXT tower launch
             # needs the stepped weights (DenseSlab.join() at the top of this function's next call, or at the end of the
             # step when the caller may read parameters).  Main chain: gather, tower, update, next gather.
+            # The fork is ENQUEUED only after the embedding update has been (ops.EmbedFunction.backward calls
+            # `sink.after_update`): hipGraph keeps a node's FIRST child on the node's own queue and sends later children
+            # to other queues, whatever stream they were captured on -- launched here, ahead of the update, the weight
+            # gradients stayed on the tower's queue and the update (the longer chain since round 3) paid a cross-queue
+            # edge on both ends (~10 us each).
             side = sink.fork_stream(dev, force=True)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            L.check(lib.dctr_mlp_train_wgrad(ctypes.byref(desc), _ptr(x), x.stride(0), B, _ptr(g_logit), _ptr(ws),
-                                             _ptr(loss), _ptr(g_bias), ctypes.byref(inline),
-                                             ctypes.c_void_p(side.cuda_stream)), "dctr_mlp_train_wgrad")
-            sink.forked(side, (x, hs, dhs, ws, g_logit, loss, ps, y, wo))
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))       # fork point: right behind the tower kernel
+            keep = (x, hs, dhs, ws, g_logit, loss, ps, y, wo, desc, inline)
+
+            def launch_fork(side=side, ev=ev, keep=keep, B=B, g_bias=g_bias):
+                x_, ws_, g_logit_, loss_, desc_, inline_ = keep[0], keep[3], keep[4], keep[5], keep[9], keep[10]
+                side.wait_event(ev)
+                L.check(lib.dctr_mlp_train_wgrad(ctypes.byref(desc_), _ptr(x_), x_.stride(0), B, _ptr(g_logit_),
+                                                 _ptr(ws_), _ptr(loss_), _ptr(g_bias), ctypes.byref(inline_),
+                                                 ctypes.c_void_p(side.cuda_stream)), "dctr_mlp_train_wgrad")
+                sink.forked(side, keep)
+            sink.after_update = launch_fork
             sink.inline_done = True
             sink.update_stream = None            # (the update runs on this stream: ops.EmbedFunction.backward)
         elif inline is not None:

@@ -219,6 +219,10 @@ class EmbedFunction(torch.autograd.Function):
             if side is not None:
                 # (everything the side-stream kernels touch stays allocated until the join)
                 sink.forked(side, (X, out, ids_t, parts_t, fm_s, g_out, g_fm, g_wide, g_wd, ws))
+            after = getattr(sink, "after_update", None) if sink is not None else None
+            if after is not None:        # topology "tower_side": the weight gradients fork off behind the update's launch
+                sink.after_update = None
+                after()
             return None, None, None, g_w, None, None
 
         # general path (pooled VarLen fields, shared tables, very large batches): atomic scatter (+ consume pass)

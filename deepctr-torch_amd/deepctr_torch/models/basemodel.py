@@ -735,6 +735,10 @@ class BaseModel(nn.Module):
             self._grad_sink = None
             plan.dense_sink = None
             slab.overlap = False
+            after = getattr(slab, "after_update", None)
+            if after is not None:         # (no embedding update was launched behind the tower: fork now)
+                slab.after_update = None
+                after()
             slab.end_inline_step()
             if not ((slab.wgrad_side or slab.gather_side) and getattr(self, "_defer_dense_join", False)):
                 # (inside a multi-step hipGraph the captured steps but the last leave the forked weight-gradient /

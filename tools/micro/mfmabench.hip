@@ -22,9 +22,11 @@ struct Stamp { unsigned long long core, wall; };
 //         loads consumed LOOK groups later
 template <int MODE, int NACC>
 __global__ __launch_bounds__(256) void k_mfma(const float* __restrict__ src, int ld, int iters, float* sink,
-                                              Stamp* stamps) {
+                                              Stamp* stamps, float base, float slope) {
   const int lane = threadIdx.x & 63;
-  float a = 1.f + lane * 1e-3f, b = 1.f - lane * 1e-3f;
+  // operand values: base = 1, slope = 1e-3 is "live" data; base = slope = 0 multiplies zeros -- the clock the chip holds
+  // under MFMA load depends on the data's switching activity (MI355X_MICROARCH.md, DVFS give-back)
+  float a = base + lane * slope, b = base - lane * slope;
   const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
   float out = 0.f;
   if (MODE == 0) {
@@ -33,9 +35,11 @@ __global__ __launch_bounds__(256) void k_mfma(const float* __restrict__ src, int
     for (int i = 0; i < NACC; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) c[i][r] = 0.f;
-    for (int it = 0; it < iters; it += NACC) {
+    for (int it = 0; it < iters; it += 8 * NACC) {
 #pragma unroll
-      for (int i = 0; i < NACC; ++i) c[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c[i], 0, 0, 0);
+      for (int rep = 0; rep < 8; ++rep)
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) c[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c[i], 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < NACC; ++i) out += c[i][0] + c[i][15];
@@ -45,9 +49,13 @@ __global__ __launch_bounds__(256) void k_mfma(const float* __restrict__ src, int
     for (int i = 0; i < NACC; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) c[i][r] = 0.f;
-    for (int it = 0; it < iters; it += NACC) {
+    // (round 3: unrolled -- the rolled loop carried an s_nop 7 and accumulator moves per 4-8 MFMAs and read 40-48
+    // cycles per 16x16x4 where the pipe issues one every 32)
+    for (int it = 0; it < iters; it += 8 * NACC) {
 #pragma unroll
-      for (int i = 0; i < NACC; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c[i], 0, 0, 0);
+      for (int rep = 0; rep < 8; ++rep)
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c[i], 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < NACC; ++i) out += c[i][0] + c[i][3];
@@ -96,15 +104,16 @@ __global__ __launch_bounds__(256) void k_mfma(const float* __restrict__ src, int
 }
 
 template <int MODE, int NACC>
-void run(const char* name, int blocks, int threads, int iters, const float* src, int ld, float* sink, Stamp* d_st) {
+void run(const char* name, int blocks, int threads, int iters, const float* src, int ld, float* sink, Stamp* d_st,
+         float base = 1.f, float slope = 1e-3f) {
   const int nw = blocks * threads / 64;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  k_mfma<MODE, NACC><<<blocks, threads>>>(src, ld, iters, sink, d_st);
+  k_mfma<MODE, NACC><<<blocks, threads>>>(src, ld, iters, sink, d_st, base, slope);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  k_mfma<MODE, NACC><<<blocks, threads>>>(src, ld, iters, sink, d_st);
+  k_mfma<MODE, NACC><<<blocks, threads>>>(src, ld, iters, sink, d_st, base, slope);
   CK(hipEventRecord(e1));
   CK(hipDeviceSynchronize());
   float ms;
@@ -141,5 +150,10 @@ int main() {
   run<1, 8>("16x16x4 8 acc, 2 waves/SIMD", 512, 256, it, src, ld, sink, st);
   run<2, 4>("32x32x2 4 acc + 2 dwordx2 loads per 4 MFMA (L2-resident), 1 wave/SIMD", 256, 256, 1024, src, ld, sink, st);
   run<2, 4>("32x32x2 4 acc + 2 dwordx2 loads per 4 MFMA (L2-resident), 2 waves/SIMD", 512, 256, 1024, src, ld, sink, st);
+  // the same pipes on all-zero operands: the instruction rate is unchanged, the clock is not
+  run<0, 4>("ZERO operands: 32x32x2 4 acc, 1 wave/SIMD", 256, 256, it, src, ld, sink, st, 0.f, 0.f);
+  run<1, 8>("ZERO operands: 16x16x4 8 acc, 2 waves/SIMD", 512, 256, it, src, ld, sink, st, 0.f, 0.f);
+  // long run (8x the MFMAs): does the clock sag further once the power budget bites?
+  run<0, 4>("32x32x2 4 acc, 1 wave/SIMD, 32768 MFMAs per wave", 256, 256, 8 * it, src, ld, sink, st);
   return 0;
 }
