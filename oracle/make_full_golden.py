@@ -83,7 +83,11 @@ def run(ref, name):
     model = build(ref, name)
     set_params(model, touched)
     start = {k: v.clone() for k, v in model.state_dict().items()}
-    out = {"n_touched": np.array([len(r) for r in touched])}
+    # checksums of what the hash generated HERE: the tests regenerate the same tensors and must find the same sums
+    out = {"n_touched": np.array([len(r) for r in touched]),
+           "check/X": np.array(float(X.astype(np.float64).sum())), "check/y": np.array(float(y.sum())),
+           "check/table_C7": np.array(float(FD.table_rows("embedding_dict.C7.weight", touched[6], FD.DIM).astype(np.float64).sum())),
+           "check/dnn0": np.array(float(FD.dense_param("dnn.linears.0.weight", (8, 429)).astype(np.float64).sum()))}
     cap = {}
     hook = model.out.register_forward_pre_hook(lambda m, inp: cap.__setitem__("logit", inp[0].detach().clone()))
     model.train()
@@ -98,6 +102,23 @@ def run(ref, name):
     out["loss"] = np.array(loss.item(), np.float64)
     collect(out, "grad", model, touched, lambda k, p: p.grad)
     model.zero_grad(set_to_none=True)
+    # the same dense gradients with the reference evaluated in fp64: how far the reference's OWN fp32 gradient is from the
+    # exact one (the CIN biases sum 65 536 terms; two fp32 summation orders differ by ~2e-5 relative there) -- the test
+    # accepts max(2e-5 x max|g|, 2 x that gap)
+    model.double()
+    torch.set_default_dtype(torch.float64)        # (the reference creates a few tensors with the default dtype)
+    try:
+        loss64 = F.binary_cross_entropy(model(xt.double()).squeeze().double(), yt.double(), reduction="sum")
+        loss64.backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    out["loss64"] = np.array(loss64.item(), np.float64)
+    for k, p in model.named_parameters():
+        if "embedding_dict" not in k:
+            store(out, "grad64/" + k, FD.summarise(p.grad.detach().numpy()))
+    model.zero_grad(set_to_none=True)
+    model.float()
+    model.load_state_dict(start)
     for opt_name in ("sgd", "adagrad"):
         model.load_state_dict(start)
         model.compile(opt_name, "binary_crossentropy", metrics=[])

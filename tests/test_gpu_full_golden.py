@@ -1,0 +1,177 @@
+"""GPU parity against the REAL reference at BASELINE.json's full configurations (configs 2-4): 26 sparse x 1M-row
+vocabularies, 13 dense, embedding_dim 16, batch 4096 -- DeepFM (256,128), xDeepFM (CIN [128,128] split_half, dnn (256,256)),
+FiBiNET ('interaction' over all 26 fields, dnn (128,128)).
+
+tests/golden/full_*.npz hold what the reference computed in the build container (oracle/make_full_golden.py): logits,
+predictions, loss, every dense gradient, the gradient of every touched table row, and the parameters after one train step
+under SGD and under Adagrad.  Inputs and parameters are regenerated here from the same integer hash
+(tests/fullsize_data.py).  Bars: logits 1e-5 absolute; gradients 2e-5 x max|gradient of the tensor| (+ the resolution of
+a gradient read back from an SGD step, ulp(w) / lr); updated table rows 2e-5 absolute; updated dense parameters
+2e-5 x max(1, |p|) + lr x the gradient's bar."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fullsize_data as FD
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _golden(name):
+    z = np.load(os.path.join(GOLD, "full_%s.npz" % name), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+_CACHE = {}
+
+
+def _data():
+    if "x" not in _CACHE:
+        X, y = FD.inputs()
+        _CACHE["x"] = (X, y, FD.touched_rows(X))
+    return _CACHE["x"]
+
+
+def _build(name):
+    import deepctr_torch.models as M
+    from deepctr_torch.inputs import DenseFeat, SparseFeat
+    sparse, dense = FD.column_names()
+    cols = [SparseFeat(c, FD.VOCAB, FD.DIM) for c in sparse] + [DenseFeat(c, 1) for c in dense]
+    spec = FD.MODELS[name]
+    m = getattr(M, spec["cls"])(cols, cols, l2_reg_linear=0, l2_reg_embedding=0, dnn_dropout=0, seed=1024, device=DEV,
+                                **spec["kwargs"])
+    X, y, touched = _data()
+    with torch.no_grad():
+        for k, p in m.state_dict().items():
+            if "embedding_dict" in k:
+                f = sparse.index(k.split(".")[-2])
+                rows = touched[f]
+                p[torch.from_numpy(rows).to(DEV)] = torch.from_numpy(FD.table_rows(k, rows, p.shape[1])).to(DEV)
+            else:
+                p.copy_(torch.from_numpy(FD.dense_param(k, tuple(p.shape))))
+    return m
+
+
+def _check_dense(tag, key, got, g, tol_abs):
+    """compare a dense tensor with its stored summary (all values, or strided sample + projections)"""
+    got = np.asarray(got, np.float64)
+    if key + "/all" in g:
+        ref = g[key + "/all"].astype(np.float64)
+        err = float(np.max(np.abs(got - ref))) if ref.size else 0.0
+        assert err <= tol_abs(ref), "%s %s: max|d| = %.3e (bar %.3e)" % (tag, key, err, tol_abs(ref))
+        return
+    flat = got.reshape(-1)
+    ref = g[key + "/sample"].astype(np.float64)
+    err = float(np.max(np.abs(flat[::FD.STRIDE] - ref)))
+    bar = tol_abs(ref)
+    assert err <= bar, "%s %s (sample): max|d| = %.3e (bar %.3e)" % (tag, key, err, bar)
+    for k in range(4):
+        pr = float(np.dot(flat, FD.proj_weights(flat.size, k)))
+        # a sum of n terms each within `bar`, random signs: sqrt(n) x bar is generous for a systematic error to show
+        assert abs(pr - g[key + "/proj"][k]) <= bar * np.sqrt(flat.size) * 0.6 + 1e-9, "%s %s (projection %d)" % (tag, key, k)
+
+
+def _check_rows(tag, key, rows, got_rows, g, tol_abs):
+    """deep-table rows: every 16th touched row in full + projections over all touched rows"""
+    got_rows = np.asarray(got_rows, np.float64)
+    keep = rows % FD.ROW_KEEP == 0
+    assert np.array_equal(rows[keep], g[key + "/rows"])
+    ref = g[key + "/values"].astype(np.float64)
+    bar = tol_abs(ref)
+    err = float(np.max(np.abs(got_rows[keep] - ref)))
+    assert err <= bar, "%s %s (rows): max|d| = %.3e (bar %.3e)" % (tag, key, err, bar)
+    idx = rows[:, None] * got_rows.shape[1] + np.arange(got_rows.shape[1], dtype=np.int64)[None, :]
+    for k in range(4):
+        pr = float(np.sum(got_rows * FD.sym(idx, 9100 + k, FD.SEED_P, 2.0).astype(np.float64)))
+        assert abs(pr - g[key + "/proj"][k]) <= bar * np.sqrt(got_rows.size) * 0.6 + 1e-9, "%s %s (projection %d)" % (tag, key, k)
+
+
+@pytest.mark.parametrize("name", list(FD.MODELS))
+def test_full_size_logits_match_the_reference(name):
+    g = _golden(name)
+    m = _build(name)
+    X, y, _ = _data()
+    cap = {}
+    hook = m.out.register_forward_pre_hook(lambda mod, inp: cap.__setitem__("logit", inp[0].detach()))
+    m.train()
+    with torch.no_grad():
+        y_pred = m(torch.from_numpy(X).to(DEV)).squeeze()
+    hook.remove()
+    torch.cuda.synchronize()
+    m.model_plan().check_ids()
+    logit = cap["logit"].reshape(-1).double().cpu().numpy()
+    err = float(np.max(np.abs(logit - g["logit"].astype(np.float64))))
+    assert err <= 1e-5, "%s: logit max|d| = %.3e" % (name, err)
+    assert float(np.max(np.abs(y_pred.double().cpu().numpy() - g["y_pred"]))) <= 5e-6
+    loss = torch.nn.functional.binary_cross_entropy(y_pred, torch.from_numpy(y).to(DEV), reduction="sum").item()
+    assert abs(loss - float(g["loss"])) <= 2e-5 * float(g["loss"])
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
+@pytest.mark.parametrize("name", list(FD.MODELS))
+def test_full_size_train_step_matches_the_reference(name, opt):
+    """one train step through model._train_step (the fused step for DeepFM, autograd + the fused update kernels for the
+    others) against the reference's step: the loss, every updated dense parameter, every touched row of every table;
+    under SGD the gradients are read back from the step, g = (w0 - w1) / lr, and compared with the reference's autograd
+    gradients as well"""
+    g = _golden(name)
+    m = _build(name)
+    X, y, touched = _data()
+    sparse, _ = FD.column_names()
+    w0 = {k: v.detach().clone() for k, v in m.state_dict().items() if "embedding_dict" not in k}
+    m.compile(opt, "binary_crossentropy", metrics=[])
+    if opt == "adagrad":
+        for grp in m.optim.param_groups:
+            for p in grp["params"]:
+                m.optim.state[p]["sum"].fill_(FD.ADAGRAD_SUM0)
+    m.train()
+    loss, _, _ = m._train_step(torch.from_numpy(X).to(DEV), torch.from_numpy(y).to(DEV))
+    torch.cuda.synchronize()
+    m.model_plan().check_ids()
+    assert abs(loss.item() - float(g[opt + "_loss"])) <= 2e-5 * float(g[opt + "_loss"])
+    sd = m.state_dict()
+    lr = FD.LR_SGD
+    for k, v in sd.items():
+        key = "%s/%s" % (opt, k)
+        if "embedding_dict" in k:
+            f = sparse.index(k.split(".")[-2])
+            rows = touched[f]
+            got = v[torch.from_numpy(rows).to(DEV)].double().cpu().numpy()
+            start = FD.table_rows(k, rows, v.shape[1]).astype(np.float64)
+            if v.shape[1] == 1:
+                ref = g[key + "/all_touched"].astype(np.float64)
+                assert float(np.max(np.abs(got[:, 0] - ref))) <= 2e-5, "%s %s" % (name, key)
+                if opt == "sgd":
+                    gref = g["grad/%s/all_touched" % k].astype(np.float64)
+                    gerr = float(np.max(np.abs((start[:, 0] - got[:, 0]) / lr - gref)))
+                    assert gerr <= 2e-5 * float(np.max(np.abs(gref))) + 1e-6, "%s grad of %s: %.3e" % (name, k, gerr)
+            else:
+                _check_rows(name, key, rows, got, g, lambda ref: 2e-5)
+                if opt == "sgd":
+                    gmax = float(g["grad/%s/absmax" % k])
+                    _check_rows(name, "grad/" + k, rows, (start - got) / lr, g, lambda ref: 2e-5 * gmax + 1e-6)
+        else:
+            got = v.double().cpu().numpy()
+            gk = "grad/" + k
+            gmax = float(g[gk + "/absmax"]) if gk + "/absmax" in g else float(np.max(np.abs(g[gk + "/all"])))
+            # an updated parameter cannot be closer than lr x the gradient's own bar (the CIN biases sum 65 536 terms and
+            # move by ~15: their fp32 sums alone differ by 2e-5 relative between two summation orders)
+            k64 = "grad64/" + k
+            gap = float(np.max(np.abs(g[gk + "/all"].astype(np.float64) - g[k64 + "/all"]))) if gk + "/all" in g else \
+                float(np.max(np.abs(g[gk + "/sample"].astype(np.float64) - g[k64 + "/sample"])))
+            _check_dense(name, key, got, g,
+                         lambda ref: 2e-5 * max(1.0, float(np.max(np.abs(ref)))) + lr * max(2e-5 * gmax, min(2.0 * gap, 1e-4 * gmax)))
+            if opt == "sgd":
+                wabs = max(float(w0[k].abs().max().item()), float(np.abs(got).max()))
+                floor = 2.0 ** (np.floor(np.log2(max(wabs, 1e-30))) - 23) / lr     # ulp(w) / lr
+                # ... or twice the distance of the reference's own fp32 gradient from its fp64 evaluation (stored next to it;
+                # capped at 1e-4 x max|g|: where a ReLU unit flips between fp32 and fp64 that distance is not rounding)
+                k64 = "grad64/" + k
+                gap = float(np.max(np.abs(g[gk + "/all"].astype(np.float64) - g[k64 + "/all"]))) if gk + "/all" in g else \
+                    float(np.max(np.abs(g[gk + "/sample"].astype(np.float64) - g[k64 + "/sample"])))
+                _check_dense(name, gk, (w0[k].double().cpu().numpy() - got) / lr, g,
+                             lambda ref: max(2e-5 * gmax, min(2.0 * gap, 1e-4 * gmax)) + floor)

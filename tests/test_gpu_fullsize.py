@@ -66,7 +66,15 @@ def test_sparse_update_touches_only_batch_rows_and_matches_dense_torch(big, opt)
     dnn_in = torch.cat([E.reshape(BATCH, -1), X[:, F_SPARSE:]], dim=1)
     fm_ref = 0.5 * (E.sum(1).pow(2) - E.pow(2).sum(1)).sum(1, keepdim=True)
     wide_ref = wide.reshape(BATCH, 1) - wbefore[ids[:, f]] + ref_w[ids[:, f]]
-    logit = wide_ref + fm_ref + m.dnn_linear(m.dnn(dnn_in))
+    # the tower restated with plain torch ops on the model's weights (layers/core.py:120-134, deepfm.py:84) -- not the
+    # model's own modules, which run the kernels under test
+    h = dnn_in
+    sd = m.state_dict()
+    for i in range(2):
+        h = torch.relu(torch.nn.functional.linear(h, sd["dnn.linears.%d.weight" % i].detach().clone(),
+                                                  sd["dnn.linears.%d.bias" % i].detach().clone()))
+    tower = torch.nn.functional.linear(h, sd["dnn_linear.weight"].detach().clone())
+    logit = wide_ref + fm_ref + tower
     loss_ref = torch.nn.functional.binary_cross_entropy(m.out(logit).squeeze(), y, reduction="sum")
     g_t, g_w = torch.autograd.grad(loss_ref, [ref_t, ref_w])
     for p in m.parameters():

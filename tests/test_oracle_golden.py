@@ -2,6 +2,8 @@
 
 CPU only.  Forward: logits / predictions / loss; backward: the gradient of EVERY parameter (dense [V, D]
 embedding gradients included); trajectories: 3 reference training steps under SGD and Adagrad."""
+import os
+
 import numpy as np
 import pytest
 
@@ -129,3 +131,22 @@ def test_state_dict_layout_matches_reference_on_its_test_matrix(c):
     # same init functions), so seed=1024 yields the reference's own initial weights, bit for bit
     for k, v in c["params"].items():
         assert np.array_equal(m.state_dict()[k].numpy(), v), k
+
+
+def test_full_size_fixture_inputs_regenerate_bit_for_bit():
+    """tests/golden/full_*.npz (the real reference at 26 x 1M x 16, batch 4096: oracle/make_full_golden.py) store outputs
+    only; inputs and parameters come from tests/fullsize_data.py's integer hash on both sides.  The generator must give here
+    what it gave in the run that produced the fixtures."""
+    import fullsize_data as FD
+    X, y = FD.inputs()
+    touched = FD.touched_rows(X)
+    for name in FD.MODELS:
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_%s.npz" % name))
+        assert float(z["check/X"]) == float(X.astype(np.float64).sum())
+        assert float(z["check/y"]) == float(y.sum())
+        assert float(z["check/table_C7"]) == float(
+            FD.table_rows("embedding_dict.C7.weight", touched[6], FD.DIM).astype(np.float64).sum())
+        assert float(z["check/dnn0"]) == float(FD.dense_param("dnn.linears.0.weight", (8, 429)).astype(np.float64).sum())
+        assert np.array_equal(z["n_touched"], np.array([len(r) for r in touched]))
+        assert z["logit"].shape == (FD.BATCH,) and np.isfinite(z["logit"]).all()
+        assert 1.0 < float(np.abs(z["logit"]).max()) < 10.0          # trained-like scale: the 1e-5 bar means something
