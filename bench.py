@@ -51,6 +51,12 @@ def parse():
                     help="skip the xDeepFM / FiBiNET legs (BASELINE.json configs 3-4) of the N=1 line")
     ap.add_argument("--force-parallel", action="store_true", help="use the data-parallel trainer even with 1 rank")
     ap.add_argument("--kernel-iters", type=int, default=50, help="event-timed launches per hot-path kernel")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed block of --steps steps is run this many times (each bracketed by a synchronize, and a "
+                         "barrier with N > 1); ms_per_step / value are the MEDIAN block, all blocks are listed")
+    ap.add_argument("--warmup-seconds", type=float, default=1.0,
+                    help="besides --warmup steps: keep replaying until this much wall time has passed (clocks, caches and "
+                         "the allocator settle; a 20-step block is 2 ms of GPU time)")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--diag-trace", default="",
                     help="development: load libdctr_hip_diag.so and save the tower kernels' per-workgroup phase stamps of "
@@ -168,53 +174,98 @@ def time_hot_kernels(model, X_all, B, iters, opt, ring=16):
     return res
 
 
+PMC_SOURCES = ("deepctr-torch_amd/csrc/update.hip", "deepctr-torch_amd/csrc/embed.hip", "deepctr-torch_amd/csrc/common.hpp")
+
+
+def kernel_code_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for rel in PMC_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def pmc_traffic(kernel, opt, B):
     """HBM bytes per launch of a hand-written kernel from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh:
-    FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB units).  `bytes` is the RAW counter sum: for random row
-    accesses the raw FETCH_SIZE tallies what the fabric moved (the calibration gather of 64-byte rows reads 1.77x its
-    known bytes: a 64-byte row costs a 128-byte fetch); only wide coalesced streams are under-counted by 2
-    (MI355X_MICROARCH.md), so `fetch_x2_streaming_rule` is the upper bound.  Returns None when no PMC summary for
-    this kernel / launch size is committed."""
+    FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB units; a PMC pass cannot run inside this process).  The
+    summary carries the sha256 of the kernel sources it was taken on (tools/pmc_summary.py): a summary of OTHER code is
+    refused -- `traffic` is then null and `traffic_detail.stale` says why -- instead of silently describing a kernel that
+    no longer exists.  `bytes` = raw counters x the factors calibrated on the kernel's own access pattern (random
+    128-byte lines read-modify-written for the update, 64-byte rows for the gather: tools/micro/rowbench.hip under the same
+    counters); `raw` is the uncorrected sum."""
     import glob
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not paths:
         return None
     with open(paths[-1]) as fh:
         d = json.load(fh)
+    src = "profiles/" + os.path.basename(paths[-1])
+    if d.get("code_hash") != kernel_code_hash():
+        return {"bytes": None, "stale": "%s was measured on other kernel sources (code_hash mismatch): rerun "
+                                         "tools/pmc_traffic.sh" % src, "source": src}
     tag = "embed_fwd" if kernel == "embed_fwd" else "embed_update_%s" % opt
     # the PMC driver launches every kernel at B = 4096 and B = 32768: the smaller grid is this bench's launch
     cands = sorted((int(k.split("@grid")[1]), v) for k, v in d.get("kernels", {}).items() if k.split("@grid")[0] == tag)
     if not cands or B != 4096:
         return None
     best = cands[0][1]
-    return {"bytes": best["fetch_raw_bytes"] + best["write_raw_bytes"],
-            "fetch_raw": best["fetch_raw_bytes"], "write_raw": best["write_raw_bytes"],
-            "fetch_x2_streaming_rule": best["fetch_bytes_x2"],
-            "source": "profiles/" + os.path.basename(paths[-1])}
+    raw = best["fetch_raw_bytes"] + best["write_raw_bytes"]
+    cal = d.get("calibration", {})
+    f128 = (cal.get("calib_rows_128B_rmw_b4096") or {}).get("fetch_factor") or 2.0     # measured: 2.00
+    f64 = (cal.get("calib_rows_64B_read_b4096") or {}).get("fetch_factor") or 1.0      # measured: 1.03
+    # FETCH_SIZE tallies a 128-byte request at 64 bytes (factor 2.00 on random 128-byte lines, read or read-modify-write)
+    # and smaller requests in full (1.03 on random 64-byte rows); WRITE_SIZE needs no correction (1.00).  The update reads
+    # ONE 128-byte line per entry (row + Adagrad state; plain 64-byte rows under SGD), everything else in <= 64-byte
+    # pieces: its fetch is the raw count + 64 bytes per such line.  The gather reads 64-byte rows only.
+    lines128 = F_SPARSE * B if (kernel != "embed_fwd" and opt == "adagrad") else 0
+    fetch = best["fetch_raw_bytes"] * f64 + lines128 * 64 * (f128 - 1.0)
+    return {"bytes": fetch + best["write_raw_bytes"], "raw": raw, "upper_bound_all_fetches_x2": best.get("calibrated_bytes"),
+            "fetch_raw": best["fetch_raw_bytes"], "write_raw": best["write_raw_bytes"], "lines_128B": lines128,
+            "factor_128B": f128, "factor_64B": f64, "code_hash": d.get("code_hash"), "source": src}
 
 
 def cpu_baseline(args):
-    """The reference's dense-gradient algorithm (torch-CPU port) on this box's host cores, bounded sample."""
+    """The reference's dense-gradient algorithm (torch-CPU port, oracle/torch_port.py: the same ATen calls in the same
+    order; 1.1x the real reference's step time on the build container, profiles/r03_reference_cpu_timing.json) on this
+    box's host cores, bounded samples of the bench workload.  SURVEY.md 8(d)'s three variants: (i) the reference's defaults
+    (l2 = 1e-5 on every table and on Linear, Adam), (ii) like for like with the GPU line (l2 = 0, the bench's optimizer)
+    -- this one is `value` --, (iii) forward only."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from torch_port import DeepFMPort, make_optimizer, train_step
-    torch.manual_seed(0)
-    port = DeepFMPort(F_SPARSE, args.vocab, DIM, N_DENSE, hidden=(256, 128))
-    opt = make_optimizer(port, args.optimizer)
     gen = torch.Generator().manual_seed(0)
     X = torch.cat([torch.randint(0, args.vocab, (args.batch, F_SPARSE), generator=gen).float(),
                    torch.rand(args.batch, N_DENSE, generator=gen)], dim=1)
     y = torch.randint(0, 2, (args.batch,), generator=gen).float()
-    train_step(port, opt, X, y)  # warm-up
-    t0 = time.perf_counter()
-    for _ in range(args.cpu_steps):
-        train_step(port, opt, X, y)
-    dt = time.perf_counter() - t0
-    return {"value": args.batch * args.cpu_steps / dt, "unit": "samples/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": "%d train steps (after 1 warm-up) of the same DeepFM/batch=%d/vocab=%d workload, dense [V,D] "
+
+    def timed(fn, n, warm):
+        for _ in range(warm):
+            fn()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        dt = (time.perf_counter() - t0) / n
+        return {"ms_per_step": dt * 1e3, "value": args.batch / dt, "unit": "samples/s", "steps": n, "warmup": warm}
+
+    variants = {}
+    torch.manual_seed(0)
+    port = DeepFMPort(F_SPARSE, args.vocab, DIM, N_DENSE, hidden=(256, 128))
+    opt = make_optimizer(port, args.optimizer)
+    like = timed(lambda: train_step(port, opt, X, y), args.cpu_steps, 2)
+    variants["like_for_like_l2_0_%s" % args.optimizer] = like
+    port.eval()
+    with torch.no_grad():
+        variants["forward_only"] = timed(lambda: port(X), 4 * args.cpu_steps, 3)
+    port.train()
+    del opt
+    adam = make_optimizer(port, "adam")
+    variants["reference_defaults_l2_1e-5_adam"] = timed(lambda: train_step(port, adam, X, y, 1e-5, 1e-5),
+                                                        max(2, args.cpu_steps // 3), 1)
+    return {"value": like["value"], "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d train steps (after 2 warm-up) of the same DeepFM/batch=%d/vocab=%d workload, dense [V,D] "
                       "gradients + dense torch.optim.%s like the reference, l2=0; host has %d logical cpus" % (
                           args.cpu_steps, args.batch, args.vocab, args.optimizer, os.cpu_count() or 0),
-            "ms_per_step": dt / args.cpu_steps * 1e3}
+            "ms_per_step": like["ms_per_step"], "variants": variants}
 
 
 class StepRunner(object):
@@ -277,8 +328,11 @@ class StepRunner(object):
         return out
 
 
-def time_steps(model, X, y, B, steps, warmup, S, use_graph):
-    """Warm up (>= `warmup` steps: 3 eager ones, then one replay of every captured graph), time exactly `steps`."""
+def time_steps(model, X, y, B, steps, warmup, S, use_graph, repeats=1, warmup_seconds=0.0, sync=None):
+    """Warm up (>= `warmup` steps: 3 eager ones, then replays of every captured graph until `warmup_seconds` have passed),
+    then time `repeats` blocks of exactly `steps` steps, each bracketed by `sync()` (default: torch.cuda.synchronize; the
+    multi-GPU caller adds its barrier).  Returns the MEDIAN block's elapsed time first, every block's in `times`."""
+    sync = sync or torch.cuda.synchronize
     r = StepRunner(model, X, y, B, steps, S, use_graph)
     n_eager = min(3, max(1, warmup)) if use_graph else warmup
     r.eager(n_eager)
@@ -292,18 +346,34 @@ def time_steps(model, X, y, B, steps, warmup, S, use_graph):
             r.main = r.tail = None
             torch.cuda.synchronize()
     did = n_eager
+    t_w = time.perf_counter()
     if graphed:
-        while did < warmup or did == n_eager:
+        while did < warmup or did == n_eager or time.perf_counter() - t_w < warmup_seconds:
             r.run(r.S + r.tail_n)        # one replay of the main graph (+ one of the tail graph)
             did += r.S + r.tail_n
+            if warmup_seconds > 0:
+                torch.cuda.synchronize()
     else:
         r.eager(max(0, warmup - n_eager))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out = r.run(steps)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    return elapsed, out, graphed, did, r
+        while time.perf_counter() - t_w < warmup_seconds:
+            r.eager(steps)
+            did += steps
+            torch.cuda.synchronize()
+    times, out = [], None
+    for _ in range(max(1, repeats)):
+        sync()
+        t0 = time.perf_counter()
+        out = r.run(steps)
+        sync()
+        times.append(time.perf_counter() - t0)
+    elapsed = sorted(times)[len(times) // 2]
+    return elapsed, out, graphed, did, r, times
+
+
+def spread(times, steps):
+    ms = sorted(t / steps * 1e3 for t in times)
+    return {"blocks": len(ms), "ms_per_step_median": ms[len(ms) // 2], "ms_per_step_min": ms[0], "ms_per_step_max": ms[-1],
+            "ms_per_step_all": [round(v, 5) for v in (t / steps * 1e3 for t in times)]}
 
 
 # BASELINE.json configs[2] and configs[3]: same Criteo shape, other interaction layers
@@ -338,15 +408,16 @@ def other_config(name, args, device, X, y):
     spec = OTHER[name]
     try:
         model = build_other(name, args, device)
-        elapsed, out, graphed, did, _ = time_steps(model, X, y, args.batch, args.steps, args.warmup,
-                                                   args.steps_per_graph, not args.no_graph)
+        elapsed, out, graphed, did, _, times = time_steps(model, X, y, args.batch, args.steps, args.warmup,
+                                                          args.steps_per_graph, not args.no_graph, args.repeats,
+                                                          args.warmup_seconds)
         model.model_plan().check_ids()
         ms = elapsed / args.steps * 1e3
         sps = args.batch * args.steps / elapsed
         tf = sps * spec["flop_per_sample"] / 1e12
         res = {"workload": spec["workload"] + ", batch=%d, fwd+bwd+%s, l2=0" % (args.batch, args.optimizer),
                "reference": spec["ref"], "value": sps, "unit": "samples/s", "ms_per_step": ms, "steps": args.steps,
-               "warmup": did, "hip_graph": graphed, "final_loss": float(out[0].item()),
+               "warmup": did, "hip_graph": graphed, "final_loss": float(out[0].item()), "timing": spread(times, args.steps),
                "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": tf / MFMA_PEAK_TFLOPS, "flop_per_sample": spec["flop_per_sample"],
                             "traffic": None,
@@ -398,8 +469,9 @@ def main():
     n_batches = X.shape[0] // B
 
     if dist is None:
-        elapsed, out, graphed, did_warm, _ = time_steps(model, X, y, B, args.steps, args.warmup, args.steps_per_graph,
-                                                        not args.no_graph)
+        elapsed, out, graphed, did_warm, _, times = time_steps(model, X, y, B, args.steps, args.warmup,
+                                                               args.steps_per_graph, not args.no_graph, args.repeats,
+                                                               args.warmup_seconds)
         parallel = None
     else:
         # table-sharded embeddings + data-parallel tower (SURVEY.md 8(e) option S); the compute between the
@@ -427,21 +499,31 @@ def main():
         for _ in range(max(2 if graphed else 0, args.warmup - n_eager)):
             run(i)
             i += 1
+        def block():       # exactly --steps steps between barrier + synchronize on both sides; MAX over ranks
+            nonlocal i, out
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out = run(i)
+                i += 1
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        out = None
+        # time-based warm-up: the number of further blocks follows from the first one's MAX-reduced time, so every rank
+        # runs the same number of collectives
+        t_first = block()
+        for _ in range(max(0, int(args.warmup_seconds / max(t_first, 1e-6)))):
+            block()
         did_warm = i
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = run(i)
-            i += 1
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        times = [block() for _ in range(max(1, args.repeats))]
+        elapsed = sorted(times)[len(times) // 2]
     last_loss = float(out[0].item())
     model.model_plan().check_ids()
     if trace_buf is not None:
@@ -481,6 +563,8 @@ def main():
                          "frac_of_hbm_peak": step_alg / (hot_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "whole_step_frac_of_hbm_peak": step_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "final_loss": last_loss,
+            "timing": dict(spread(times, args.steps), warmup_seconds=args.warmup_seconds,
+                           protocol="value / ms_per_step = the median of `blocks` timed blocks of exactly `steps` steps"),
         }
         if world == 1 and not args.no_other_configs:
             del model

@@ -73,11 +73,26 @@ def make_optimizer(model, name):
     raise ValueError(name)
 
 
-def train_step(model, optim, X, y):
-    """basemodel.py:242-262 with l2 = 0."""
+def reg_loss(model, l2_embedding, l2_linear):
+    """basemodel.py:412-428 as DeepFM registers it (basemodel.py:124-127, deepfm.py:55-58): l2_reg_embedding on the deep
+    tables, l2_reg_linear on everything of the linear model; the same ATen calls (square, scalar mul, sum, in-place add)."""
+    total = torch.zeros((1,))
+    if l2_embedding > 0:
+        for e in model.emb:
+            total += torch.sum(l2_embedding * torch.square(e.weight))
+    if l2_linear > 0:
+        for e in model.lin:
+            total += torch.sum(l2_linear * torch.square(e.weight))
+        total += torch.sum(l2_linear * torch.square(model.lin_w))
+    return total
+
+
+def train_step(model, optim, X, y, l2_embedding=0.0, l2_linear=0.0):
+    """basemodel.py:242-262 (the reference adds get_regularization_loss() even when it is identically zero)."""
     y_pred = model(X).squeeze()
     optim.zero_grad()
     loss = F.binary_cross_entropy(y_pred, y.squeeze(), reduction='sum')
-    loss.backward()
+    total = loss + reg_loss(model, l2_embedding, l2_linear)
+    total.backward()
     optim.step()
     return loss

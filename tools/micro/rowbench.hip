@@ -50,6 +50,21 @@ __global__ void k_copy(const float4* __restrict__ a, float4* __restrict__ b, lon
     long G = (long)gridDim.x * blockDim.x;
     for (; i < n; i += G) b[i] = a[i];
 }
+// U dwordx4 loads in flight per lane before the first store (round 3: the one-load-per-iteration copy above reached
+// 4.5 TB/s where MI355X_MICROARCH.md measures 6.3 for a float4 copy -- every ceiling derived from it was ~30 % low)
+template <int U>
+__global__ void k_copy_u(const float4* __restrict__ a, float4* __restrict__ b, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long G = (long)gridDim.x * blockDim.x;
+    for (; i + (U - 1) * G < n; i += U * G) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = a[i + u * G];
+#pragma unroll
+        for (int u = 0; u < U; ++u) b[i + u * G] = v[u];
+    }
+    for (; i < n; i += G) b[i] = a[i];
+}
 
 template <class F> float timeit(F f, int it = 5) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -73,7 +88,15 @@ int main() {
     CK(hipMalloc(&ids_small, NB * 4)); CK(hipMemcpy(ids_small, h.data(), NB * 4, hipMemcpyHostToDevice));
     printf("{\n");
     {   long n4 = V * 4; float us = timeit([&] { k_copy<<<4096, 256>>>(t64, s64, n4); });
-        printf(" \"stream_copy_1.66GB\": {\"us\": %.1f, \"GBs_rd_plus_wr\": %.0f},\n", us, 2.0 * V * 64 / us / 1e3); }
+        printf(" \"stream_copy_1.66GB\": {\"us\": %.1f, \"GBs_rd_plus_wr\": %.0f},\n", us, 2.0 * V * 64 / us / 1e3);
+        const int grids[4] = {2048, 4096, 8192, 16384};
+        for (int gi = 0; gi < 4; ++gi) {
+            const int g = grids[gi];
+            float u4 = timeit([&] { k_copy_u<4><<<g, 256>>>(t64, s64, n4); });
+            float u8 = timeit([&] { k_copy_u<8><<<g, 256>>>(t64, s64, n4); });
+            printf(" \"stream_copy_u4_grid%d\": {\"us\": %.1f, \"GBs_rd_plus_wr\": %.0f},\n", g, u4, 2.0 * V * 64 / u4 / 1e3);
+            printf(" \"stream_copy_u8_grid%d\": {\"us\": %.1f, \"GBs_rd_plus_wr\": %.0f},\n", g, u8, 2.0 * V * 64 / u8 / 1e3);
+        } }
 #define RUN(tag, LPR, UNR, RMW, NARR, A, B2, IDS, NN, bytes_per_row) { \
         int rows_per_wg = 256 / LPR; int grid = (NN + rows_per_wg * UNR - 1) / (rows_per_wg * UNR); if (grid > 256 * 32) grid = 256 * 32; \
         float us = timeit([&] { k_rows<LPR, UNR, RMW, NARR><<<grid, 256>>>(A, B2, IDS, NN, sink); }); \

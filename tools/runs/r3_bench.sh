@@ -1,0 +1,8 @@
+#!/bin/bash
+set -x
+export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r3_bench
+mkdir -p $O
+( timeout 900 python bench.py ) 2> $O/bench.err | grep '^{' > $O/bench.json; echo "bench rc=$?"
+( timeout 600 python bench.py --steps 20 --warmup 5 ) 2> $O/bench_drv.err | grep '^{' > $O/bench_driver_flags.json
