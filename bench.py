@@ -58,6 +58,9 @@ def parse():
                     help="besides --warmup steps: keep replaying until this much wall time has passed (clocks, caches and "
                          "the allocator settle; a 20-step block is 2 ms of GPU time)")
     ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                    help="cpu: the multi-process orchestration only (gloo instead of RCCL) -- there is NO CPU compute path: "
+                         "it runs only where a test has put stand-ins under the C-ABI (tests/test_bench_gloo.py)")
     ap.add_argument("--diag-trace", default="",
                     help="development: load libdctr_hip_diag.so and save the tower kernels' per-workgroup phase stamps of "
                          "the last timed step (as replayed from the hipGraph) to this .npy file (tools/tower_trace.py)")
@@ -447,14 +450,20 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (
             args.gpus, world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    device = "cuda:%d" % local_rank
+    on_gpu = args.device == "cuda"
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+    device = ("cuda:%d" % local_rank) if on_gpu else "cpu"
+    gpu_sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     dist = None
     if world > 1 or args.force_parallel:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        if on_gpu:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     trace_buf = None
     if args.diag_trace:
@@ -492,25 +501,24 @@ def main():
             run(i)
             i += 1
         graphed = False
-        if not args.no_graph:
-            parallel.use_graphs = True       # segments re-capture on the next step
-            parallel._shape = None
+        if not args.no_graph and on_gpu:
+            parallel.set_use_graphs(True)    # the compute segment is captured at the next step
             graphed = True
         for _ in range(max(2 if graphed else 0, args.warmup - n_eager)):
             run(i)
             i += 1
         def block():       # exactly --steps steps between barrier + synchronize on both sides; MAX over ranks
             nonlocal i, out
-            torch.cuda.synchronize()
+            gpu_sync()
             dist.barrier()
-            torch.cuda.synchronize()
+            gpu_sync()
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 out = run(i)
                 i += 1
-            torch.cuda.synchronize()
+            gpu_sync()
             dist.barrier()
-            torch.cuda.synchronize()
+            gpu_sync()
             t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
@@ -533,6 +541,15 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
+        if not on_gpu:      # orchestration run: no kernels to time, no roofline
+            print(json.dumps({"metric": "training samples/sec DeepFM Criteo batch=4096", "value": value, "unit": "samples/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+                              "higher_is_better": True, "scaling": "weak", "data": "synthetic", "device": "cpu (stand-ins)",
+                              "timing": spread(times, args.steps), "final_loss": last_loss}), flush=True)
+            if dist:
+                dist.barrier()
+                dist.destroy_process_group()
+            return
         kern = time_hot_kernels(model, X, B, args.kernel_iters, args.optimizer)
         alg = algorithmic_bytes(B, args.optimizer)
         for k in kern:

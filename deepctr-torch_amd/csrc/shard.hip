@@ -1,6 +1,7 @@
 // shard.hip -- the two "assemble" kernels of table-sharded multi-GPU training (deepctr_torch/parallel.py).
 //
-// Tables are sharded by table across the ranks of one node (rank q owns units q, q+N, q+2N, ...).  Per step
+// Tables are sharded by table across the ranks of one node (an owner / slot map per unit: deepctr_torch/parallel.py
+// ShardLayout.assign balances unit counts and table bytes; without a map rank q owns units q, q+N, q+2N, ...).  Per step
 //   forward   every rank sends the id columns of its B samples to the owners (all-to-all #1), each owner gathers
 //             the rows of ITS tables for all N*B samples with dctr_embed_fwd (csrc/embed.hip) and sends every
 //             rank its B rows back (all-to-all #2);
@@ -27,6 +28,7 @@ struct AsmArgs {
   float* send;           // backward: [N][B][ldc] chunks by owner
   int64_t ldc;
   int32_t N, B, F, D;    // ranks, local batch, deep units (fields), embedding dim
+  const int32_t* owner_slot;   // [F] owner | slot << 16 of every unit, or NULL: owner f % N, slot f / N
   int32_t wide_col;      // column of the wide partial inside a chunk row, -1: no wide tables
   const float* X;        // [B, ldx] the rank's own input matrix (dense columns)
   int64_t ldx;
@@ -49,6 +51,18 @@ struct AsmArgs {
   float* g_wdense;       // [n_wdense] nullable
 };
 
+// unit f -> (owner rank q, slot j of that owner's chunk)
+__device__ __forceinline__ void owner_of(const int32_t* map, int f, int N, int& q, int& j) {
+  if (map) {
+    const int32_t v = ldg_i32(map + f);
+    q = v & 0xFFFF;
+    j = v >> 16;
+  } else {
+    q = f % N;
+    j = f / N;
+  }
+}
+
 // One workgroup = 16 samples; thread (r = tid / 16, c = tid % 16) walks the row of sample r in 16-float steps.
 __global__ __launch_bounds__(kT) void k_assemble_fwd(AsmArgs A) {
   const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
@@ -59,7 +73,8 @@ __global__ __launch_bounds__(kT) void k_assemble_fwd(AsmArgs A) {
   // deep slices: element e = f * D + d of the row comes from owner f % N, slot f / N
   for (int e = c; e < W; e += 16) {
     const int f = e / A.D, d = e - f * A.D;
-    const int q = f % A.N, j = f / A.N;
+    int q, j;
+    owner_of(A.owner_slot, f, A.N, q, j);
     const float v = ldg_f32(A.recv + (static_cast<int64_t>(q) * A.B + bb) * A.ldc + j * A.D + d);
     if (valid) stg_f32(A.out + b * A.ldo + e, v);
   }
@@ -81,7 +96,8 @@ __global__ __launch_bounds__(kT) void k_assemble_fwd(AsmArgs A) {
     for (int d = c; d < A.D; d += 16) {
       float s = 0.f, sq = 0.f;
       for (int f = 0; f < A.F; ++f) {
-        const int q = f % A.N, j = f / A.N;
+        int q, j;
+        owner_of(A.owner_slot, f, A.N, q, j);
         const float v = ldg_f32(A.recv + (static_cast<int64_t>(q) * A.B + bb) * A.ldc + j * A.D + d);
         s += v;
         sq += v * v;
@@ -120,7 +136,8 @@ __global__ __launch_bounds__(kT) void k_assemble_bwd(AsmArgs A) {
   const float gf = A.g_fm ? ldg_f32(A.g_fm + b) : 0.f;
   for (int e = c; e < W; e += 16) {
     const int f = e / A.D, d = e - f * A.D;
-    const int q = f % A.N, j = f / A.N;
+    int q, j;
+    owner_of(A.owner_slot, f, A.N, q, j);
     float g = A.g_out ? ldg_f32(A.g_out + b * A.ldg + e) : 0.f;
     if (A.g_fm) g += gf * (ldg_f32(A.fm_s + b * A.lds_ + d) - ldg_f32(A.out + b * A.ldo + e));
     stg_f32(A.send + (static_cast<int64_t>(q) * A.B + b) * A.ldc + j * A.D + d, g);
@@ -151,7 +168,8 @@ __global__ __launch_bounds__(kT) void k_assemble_fwd_v4(AsmArgs A) {
     for (int k = 0; k < 4; ++k) {
       const int f = f0 + k * FL + fl;
       const int fc = f < A.F ? f : 0;
-      const int q = fc % A.N, j = fc / A.N;
+      int q, j;
+      owner_of(A.owner_slot, fc, A.N, q, j);
       v[k] = *(const DCTR_GLOBAL f32x4*)(A.recv + (static_cast<int64_t>(q) * A.B + bb) * A.ldc + j * D + 4 * d4);
     }
 #pragma unroll
@@ -234,7 +252,8 @@ __global__ __launch_bounds__(kT) void k_assemble_bwd_v4(AsmArgs A) {
     for (int k = 0; k < 4; ++k) {
       const int f = f0 + k * FL + fl;
       if (f < A.F) {
-        const int q = f % A.N, j = f / A.N;
+        int q, j;
+        owner_of(A.owner_slot, f, A.N, q, j);
         f32x4 o = g[k];
         if (A.g_fm) {
 #pragma unroll
@@ -255,7 +274,7 @@ inline bool al16(const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 
 }  // namespace
 
 extern "C" int dctr_shard_assemble_fwd(const float* recv, int64_t ld_chunk, int32_t n_ranks, int32_t B, int32_t F,
-                                       int32_t D, int32_t wide_col, const float* X, int64_t ld_x,
+                                       int32_t D, const int32_t* owner_slot, int32_t wide_col, const float* X, int64_t ld_x,
                                        const int32_t* dense_cols, int32_t n_dense, int32_t dense_off,
                                        const int32_t* wdense_cols, const float* wdense_w, int32_t n_wdense,
                                        float* out, int64_t ld_out, float* wide, float* fm, float* fm_s,
@@ -269,6 +288,7 @@ extern "C" int dctr_shard_assemble_fwd(const float* recv, int64_t ld_chunk, int3
   if (B == 0) return DCTR_OK;
   AsmArgs a = {};
   a.recv = recv; a.ldc = ld_chunk; a.N = n_ranks; a.B = B; a.F = F; a.D = D; a.wide_col = wide_col;
+  a.owner_slot = owner_slot;
   a.X = X; a.ldx = ld_x; a.dense_cols = dense_cols; a.n_dense = n_dense; a.dense_off = dense_off;
   a.wdense_cols = wdense_cols; a.wdense_w = wdense_w; a.n_wdense = n_wdense;
   a.out = out; a.ldo = ld_out; a.wide = wide; a.fm = fm; a.fm_s = fm_s; a.lds_ = ld_s;
@@ -286,7 +306,7 @@ extern "C" int dctr_shard_assemble_fwd(const float* recv, int64_t ld_chunk, int3
 }
 
 extern "C" int dctr_shard_assemble_bwd(float* send, int64_t ld_chunk, int32_t n_ranks, int32_t B, int32_t F, int32_t D,
-                                       int32_t wide_col, const float* g_out, int64_t ld_g, const float* g_wide,
+                                       const int32_t* owner_slot, int32_t wide_col, const float* g_out, int64_t ld_g, const float* g_wide,
                                        const float* g_fm, const float* out, int64_t ld_out, const float* fm_s,
                                        int64_t ld_s, const float* X, int64_t ld_x, const int32_t* wdense_cols,
                                        int32_t n_wdense, float* g_wdense, dctr_stream_t stream) {
@@ -296,6 +316,7 @@ extern "C" int dctr_shard_assemble_bwd(float* send, int64_t ld_chunk, int32_t n_
   if (B == 0) return DCTR_OK;
   AsmArgs a = {};
   a.send = send; a.ldc = ld_chunk; a.N = n_ranks; a.B = B; a.F = F; a.D = D; a.wide_col = wide_col;
+  a.owner_slot = owner_slot;
   a.g_out = g_out; a.ldg = ld_g; a.g_wide = g_wide; a.g_fm = g_fm; a.out = const_cast<float*>(out); a.ldo = ld_out;
   a.fm_s = const_cast<float*>(fm_s); a.lds_ = ld_s; a.X = X; a.ldx = ld_x; a.wdense_cols = wdense_cols;
   a.n_wdense = n_wdense; a.g_wdense = g_wdense;

@@ -575,12 +575,17 @@ class EmbeddingPlan(object):
                                                 ctypes.c_void_p(parts_t.data_ptr()), int(B),
                                                 ctypes.c_void_p(ws.data_ptr()), ws_n, stream), "dctr_embed_segments")
 
+        # Ownership of the workspace is a monotonically increasing token kept in the handle and on the workspace -- not the
+        # address of ids_t: the caching allocator hands a freed address to the next forward, and a stale backward would
+        # then accept another forward's sorted buckets as its own (round-2 advisor finding).
+        _OWNER_TOKEN[0] += 1
+        token = _OWNER_TOKEN[0]
         if device.type != "cuda":                  # (CPU stand-in: same calls, no streams)
             if before is not None:
                 before(None)
             enqueue(None)
-            ws._dctr_owner = ids_t.data_ptr()
-            return (True, ws)
+            ws._dctr_owner = token
+            return (True, ws, token)
         main = torch.cuda.current_stream(device)
         side = self._seg_stream
         if side is None or side.device != device:
@@ -593,11 +598,11 @@ class EmbeddingPlan(object):
             main.wait_stream(side)          # (an event at the side stream's tail of NOW: the pre-pass comes behind it)
         with torch.cuda.stream(side):
             enqueue(L.stream_handle(device))
-        ws._dctr_owner = ids_t.data_ptr()
+        ws._dctr_owner = token
         # (the consumer joins with wait_stream, whose events come from torch's pool: a torch.cuda.Event created here
         # would be destroyed by the garbage collector at some later point -- possibly while a hipGraph capture is
         # running, which HIP answers with hipErrorStreamCaptureUnsupported from inside a destructor: abort)
-        return (side, ws)
+        return (side, ws, token)
 
     def update_workspace_for(self, ids_t, handle, B):
         """(workspace | None, n_ints, presorted) for the update of the forward that produced ``ids_t``: its own
@@ -605,8 +610,8 @@ class EmbeddingPlan(object):
         another forward's pre-pass currently owns it, then none (every workgroup scans for itself)."""
         device = ids_t.device
         if handle is not None:
-            event, ws = handle
-            if getattr(ws, "_dctr_owner", None) == ids_t.data_ptr():
+            event, ws, token = handle
+            if getattr(ws, "_dctr_owner", None) == token:
                 ws._dctr_owner = None
                 if event is not True and torch.cuda.current_stream(device) != event:
                     # the side stream: the pre-pass is its last work.  (When the update itself runs on that stream --
@@ -633,5 +638,7 @@ class EmbeddingPlan(object):
     def has_wide(self):
         return bool(self.wide or (self.wdense_cols and self.wide_dense_weight is not None))
 
+
+_OWNER_TOKEN = [0]       # see EmbeddingPlan.launch_segments
 
 __all__ = ["EmbeddingPlan", "DenseFeat", "SparseFeat", "VarLenSparseFeat"]

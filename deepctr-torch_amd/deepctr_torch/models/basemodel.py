@@ -148,8 +148,20 @@ class BaseModel(nn.Module):
             fused["slab"].sync_optimizer_state()      # Adam's per-parameter `step` entries
 
     def state_dict(self, *args, **kwargs):
+        """The reference's keys / shapes / values.  A table the fused Adagrad update seated in an interleaved slab
+        (_hip/layout.py: row and optimizer state share a 128-byte line) is a strided VIEW; torch.save would serialise the
+        whole underlying storage -- 2-4x the table's bytes, optimizer accumulators included (round-2 advisor finding).
+        The dense parameters of a fused-step model are views of ONE flat slab likewise.  Every entry that is a view of
+        something bigger is handed out as a contiguous copy: a weights-only checkpoint is byte-for-byte the reference's."""
         self._flush_lazy()
-        return super(BaseModel, self).state_dict(*args, **kwargs)
+        sd = super(BaseModel, self).state_dict(*args, **kwargs)
+        if kwargs.get("keep_vars", False):
+            return sd
+        for k, v in list(sd.items()):
+            # a view of something bigger (a table in its slab, a dense parameter in the flat slab of the fused step)
+            if torch.is_tensor(v) and v.untyped_storage().nbytes() > v.numel() * v.element_size():
+                sd[k] = v.detach().clone(memory_format=torch.contiguous_format)
+        return sd
 
     def load_state_dict(self, *args, **kwargs):
         self._flush_lazy()       # every stamp == the step counter: the loaded rows are current by definition
@@ -575,10 +587,27 @@ class BaseModel(nn.Module):
             # Adagrad state (weights and optimizer state become strided views; _hip/layout.py)
             from .._hip.layout import apply_layout
             state = apply_layout(self._plan, self.optim)
+            self._contiguous_optimizer_state_dict()
         self._plan.set_state(state)
         if mode[0] == "adagrad" or (mode[0] == "sgd" and self._plan.has_maxpool):
             self._plan.ensure_gacc()   # two-pass updates: allocate the slabs now (outside any graph capture)
         self._plan.update = mode       # ("dense",) allocates its slabs lazily at the first backward
+
+    def _contiguous_optimizer_state_dict(self):
+        """``optimizer.state_dict()`` hands out the Adagrad accumulators that live in an interleaved slab as contiguous
+        copies too (same reason as ``state_dict``: a saved optimizer must not drag the tables along)."""
+        opt = self.optim
+        if getattr(opt, "_dctr_sd_hook", False) or not hasattr(opt, "register_state_dict_post_hook"):
+            return
+
+        def hook(optimizer, sd):
+            for st in sd.get("state", {}).values():
+                for key, v in list(st.items()):
+                    if torch.is_tensor(v) and v.untyped_storage().nbytes() > v.numel() * v.element_size():
+                        st[key] = v.detach().clone(memory_format=torch.contiguous_format)
+            return sd
+        opt.register_state_dict_post_hook(hook)
+        opt._dctr_sd_hook = True
 
     # ------------------------------------------------------------------------------------------------
     # data plumbing shared by fit / evaluate / predict
@@ -873,8 +902,11 @@ class BaseModel(nn.Module):
         """One ``dctr_dense_opt_multi`` launch for every dense parameter autograd left a gradient on, when the compiled
         optimizer is a plain SGD / Adagrad over them (``_dense_update_mode``): ``torch.optim``'s foreach walk is five
         launches, 75-80 us per xDeepFM / FiBiNET / DCN step.  Returns True when it stepped EVERY such parameter
-        (``optim.step()`` then has nothing to do and the gradients stay visible like the reference's); parameters it
-        cannot take (non-contiguous, another dtype / device) are left to ``optim.step()`` with the stepped ones hidden."""
+        (``optim.step()`` then has nothing to do; ``p.grad`` stays visible like the reference's, EXCEPT that a fused L2
+        term -- ``l2map`` -- is added inside the kernel and not written back: ``p.grad`` then lacks the reference's
+        ``2 lambda p``); parameters it cannot take (non-contiguous, another dtype / device) are left to ``optim.step()``
+        with the stepped ones hidden.  Skipping ``optim.step()`` keeps its bookkeeping honest by hand: Adagrad's per-parameter
+        ``state['step']`` and the ``_step_count`` that learning-rate schedulers check are advanced here."""
         if os.environ.get("DCTR_MULTI_STEP", "1") == "0":
             return False, None
         todo, rest = [], []
@@ -927,6 +959,15 @@ class BaseModel(nn.Module):
             for p in todo:
                 p.grad = None
             return False, reg
+        if mode[0] == "adagrad":
+            for p in todo:
+                st = self.optim.state[p].get("step")
+                if torch.is_tensor(st):
+                    st += 1
+                elif st is not None:
+                    self.optim.state[p]["step"] = st + 1
+        if hasattr(self.optim, "_step_count"):
+            self.optim._step_count += 1       # (what torch.optim.lr_scheduler checks to warn about a skipped step())
         return True, reg
 
     def _step_stacked_groups(self):

@@ -124,6 +124,7 @@ class DataParallelTrainer(object):
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
         self.plan = model.model_plan()
+        self._forced_dense = False
         if self.plan.update[0] == "lazy":
             # The lazy regularised / Adam table update keeps per-row step stamps that are single-GPU.  The replicas
             # take the EXACT dense-gradient route instead (the reference's own O(vocabulary) update, every replica
@@ -132,7 +133,9 @@ class DataParallelTrainer(object):
             # (DCN keeps BaseModel's default l2_reg_linear, like the reference: dcn.py:49-51).
             model._no_lazy_update = True
             model._rederive_update_paths()
-            assert self.plan.update[0] != "lazy"
+            self._forced_dense = True
+            if self.plan.update[0] == "lazy":
+                raise RuntimeError("the model kept the lazy table update although the dense route was requested")
         if not self.plan.unit_path:
             raise NotImplementedError("data-parallel training needs fixed-length sparse features over distinct "
                                       "tables (the deterministic update kernel); pooled VarLen features are "
@@ -151,6 +154,34 @@ class DataParallelTrainer(object):
 
     def close(self):
         self.plan.exchange = None
+        if self._forced_dense:       # hand the model back as it was: single-GPU fit() takes the lazy O(batch) update again
+            self.model._no_lazy_update = False
+            self.model._rederive_update_paths()
+            self._forced_dense = False
+
+    def _regularization_terms(self):
+        """get_regularization_loss() (basemodel.py:412-428 of the reference: sum(l1 |p|) + sum(l2 p^2) per registered
+        weight) split into the terms on bucket parameters and the terms on embedding tables."""
+        model = self.model
+        tables = set(id(p) for p in self.plan.table_params)
+        dense = torch.zeros((1,), device=model.device)
+        tab = torch.zeros((1,), device=model.device)
+        for weight_list, l1, l2 in model.regularization_weight:
+            for w in weight_list:
+                p = w[1] if isinstance(w, tuple) else w
+                term = None
+                if l1 > 0:
+                    term = torch.sum(l1 * torch.abs(p))
+                if l2 > 0:
+                    t2 = torch.sum(l2 * torch.square(p))
+                    term = t2 if term is None else term + t2
+                if term is None:
+                    continue
+                if id(p) in tables:
+                    tab = tab + term
+                else:
+                    dense = dense + term
+        return dense, tab
 
     def _defer(self, **kw):
         if self._stash is not None:
@@ -171,10 +202,14 @@ class DataParallelTrainer(object):
         # Every rank holds the full dense parameters, so the regularisation / auxiliary terms -- functions of the
         # parameters, not of the samples -- would enter the SUM all-reduce of the gradients world_size times: each rank
         # contributes 1 / world of them (round-1 advisor finding).  The value that is logged is the full one.
-        reg = model.get_regularization_loss() + model.aux_loss
+        # ... but ONLY the terms on parameters of the all-reduced dense bucket.  Tables are not in the bucket: a table's
+        # L1 / L2 gradient is applied locally by every replica's own optimizer step (dense-gradient route), unsummed, so
+        # it enters whole (round-2 advisor finding: scaled by 1 / world like the rest it was under-applied world times).
+        reg_dense, reg_tables = self._regularization_terms()
+        reg = reg_dense + reg_tables + model.aux_loss
         total_loss = loss + reg
         self._stash = None
-        (loss + reg * (1.0 / self.world)).backward()
+        (loss + (reg_dense + model.aux_loss) * (1.0 / self.world) + reg_tables).backward()
         work = self.bucket.all_reduce(self.group, async_op=True)      # overlaps with the embedding exchange
 
         st = self._stash
@@ -221,8 +256,9 @@ class DataParallelTrainer(object):
 class ShardLayout(object):
     """Who owns what, and how a chunk row looks.
 
-    Unit ``u`` (one id column with its deep + wide table, ``plan.units``) is owned by rank ``u % N`` and sits in slot
-    ``u // N`` of that owner's chunk.  A chunk row is
+    Unit ``u`` (one id column with its deep + wide table, ``plan.units``) is owned by rank ``owner[u]`` (``assign``:
+    balanced by unit count, then by table bytes) and sits in the slot given by its position among that owner's units.  A
+    chunk row is
         ``[slot 0 | slot 1 | ... | pad to 4 | wide, pad to 4 | n_slots id columns of the NEXT batch | pad to 4]``
     floats; every rank uses ``n_slots = ceil(F / N)`` slots so that all all-to-alls have equal splits (an owner with
     fewer units leaves its last slot unused).  The id columns ride along with the row gradients: the ids the owners
@@ -244,13 +280,50 @@ class ShardLayout(object):
         self.wide_col = (self.n_slots * self.D + 3) // 4 * 4
         self.ids_col = self.wide_col + 4
         self.ldc = (self.ids_col + self.n_slots + 3) // 4 * 4
-        self.owned = [u for u in range(self.F) if u % self.world == self.rank]
+        self.owner = self.assign(plan, self.world)
+        self.owned = [u for u in range(self.F) if self.owner[u] == self.rank]
+        seen = [0] * self.world
+        self.slot = []                 # position of unit u among its owner's units = its slot in that owner's chunk
+        for u in range(self.F):
+            self.slot.append(seen[self.owner[u]])
+            seen[self.owner[u]] += 1
+        self.owner_slot = [self.owner[u] | (self.slot[u] << 16) for u in range(self.F)]   # what the assemble kernels read
         # X columns every destination needs from a sender: [N * n_slots] (unused slots repeat column 0)
         cols = []
         for q in range(self.world):
-            mine = [plan.units[u][2] for u in range(self.F) if u % self.world == q]
+            mine = [plan.units[u][2] for u in range(self.F) if self.owner[u] == q]
             cols += mine + [plan.units[0][2]] * (self.n_slots - len(mine))
         self.id_cols = cols
+
+    @staticmethod
+    def assign(plan, world):
+        """owner[u] for every unit: balanced twice over.  (1) COUNT: every rank owns floor(F / N) or ceil(F / N) units
+        -- each unit brings exactly B entries per step to its owner's gather and update, and ceil(F / N) slots per
+        chunk keep every all-to-all an equal split.  (2) BYTES: within that, units go largest table first to the rank
+        that holds the fewest bytes so far (LPT), so a 10 M-row table does not land beside another one while a rank of
+        ten-row tables idles its HBM (real Criteo vocabularies span 10 .. 10 M rows; the synthetic bench's are equal, for
+        which this reduces to round-robin in unit order).  Deterministic: every rank computes the same map."""
+        F = len(plan.units)
+        lo, extra = F // world, F % world                       # `extra` ranks take one unit more
+
+        def nbytes(u):
+            di, wi = plan.units[u][0], plan.units[u][1]
+            n = 0
+            if di >= 0:
+                n += int(plan.deep[di].param.shape[0]) * int(plan.deep[di].param.shape[1])
+            if wi >= 0:
+                n += int(plan.wide[wi].param.shape[0])
+            return n
+        order = sorted(range(F), key=lambda u: (-nbytes(u), u))
+        load, count, owner = [0] * world, [0] * world, [0] * F
+        for u in order:
+            n_full = sum(1 for q in range(world) if count[q] == lo + 1)
+            cand = [q for q in range(world) if count[q] < lo or (count[q] == lo and n_full < extra)]
+            q = min(cand, key=lambda r: (load[r], count[r], r))
+            owner[u] = q
+            load[q] += nbytes(u)
+            count[q] += 1
+        return owner
 
     def pack_ids(self, X, idx):
         """[N][B][n_slots] float ids: what each owner needs of this rank's B samples (``idx`` = id_cols on X's device)."""
@@ -279,6 +352,12 @@ class HipShardOps(object):
         if self.sub is not None:
             self.sub.share_update_with(plan)
         self._idx = None
+        self._map = None
+
+    def _owner_map(self, dev):
+        if self._map is None or self._map.device != dev:
+            self._map = torch.tensor(self.lay.owner_slot, dtype=torch.int32, device=dev)
+        return self._map
 
     def _ptr(self, t, off=0):
         import ctypes
@@ -327,8 +406,8 @@ class HipShardOps(object):
         fm_s = torch.empty((B, ld_s), dtype=torch.float32, device=dev) if want_fm else None
         w = plan.wide_dense_weight
         L.check(L.lib().dctr_shard_assemble_fwd(
-            self._ptr(recv), lay.ldc, lay.world, B, lay.F, lay.D, lay.wide_col if lay.has_wide else -1, self._ptr(X),
-            X.stride(0), self._ptr(plan._dev["dense"]), len(plan.dense_cols), max(plan.dense_off, 0),
+            self._ptr(recv), lay.ldc, lay.world, B, lay.F, lay.D, self._ptr(self._owner_map(dev)),
+            lay.wide_col if lay.has_wide else -1, self._ptr(X), X.stride(0), self._ptr(plan._dev["dense"]), len(plan.dense_cols), max(plan.dense_off, 0),
             self._ptr(plan._dev["wdense"]), self._ptr(w), len(plan.wdense_cols) if w is not None else 0,
             self._ptr(out), plan.ld_out, self._ptr(wide), self._ptr(fm), self._ptr(fm_s), ld_s,
             L.stream_handle(dev)), "dctr_shard_assemble_fwd")
@@ -340,8 +419,8 @@ class HipShardOps(object):
         send = torch.empty((lay.world * B, lay.ldc), dtype=torch.float32, device=dev)
         w = plan.wide_dense_weight
         L.check(L.lib().dctr_shard_assemble_bwd(
-            self._ptr(send), lay.ldc, lay.world, B, lay.F, lay.D, lay.wide_col if lay.has_wide else -1,
-            self._ptr(g_out), g_out.stride(0) if g_out is not None else 0, self._ptr(g_wide), self._ptr(g_fm),
+            self._ptr(send), lay.ldc, lay.world, B, lay.F, lay.D, self._ptr(self._owner_map(dev)),
+            lay.wide_col if lay.has_wide else -1, self._ptr(g_out), g_out.stride(0) if g_out is not None else 0, self._ptr(g_wide), self._ptr(g_fm),
             self._ptr(out), plan.ld_out, self._ptr(fm_s), fm_s.stride(0) if fm_s is not None else 0, self._ptr(X),
             X.stride(0), self._ptr(plan._dev["wdense"]), len(plan.wdense_cols) if (w is not None and g_wdense is not None) else 0,
             self._ptr(g_wdense), L.stream_handle(dev)), "dctr_shard_assemble_bwd")
@@ -406,7 +485,10 @@ class _Segment(object):
 
 
 class ShardedTrainer(object):
-    """Multi-GPU training of a fused-step model (``BaseModel._fused_step_state``): one process per GPU.
+    """Multi-GPU training with table-sharded embeddings, one process per GPU: models on the fused train step
+    (``BaseModel._fused_step_state``: DeepFM, WDL, NFM) and -- since round 3 -- every other model whose tables take the
+    fused sparse update (xDeepFM, FiBiNET, DCN, PNN, ...: the model's own forward / autograd / optimizer between the same
+    exchange steps).
 
       tables   sharded by table (rank u % N owns unit u: its deep table, wide table and their Adagrad state);
                forward = owner-side gather + rows all-to-all, backward = row-gradient all-to-all (the sparse
@@ -437,15 +519,27 @@ class ShardedTrainer(object):
             with torch.no_grad():
                 for p in model.parameters():
                     _broadcast(p.data, 0, process_group)
-        st = model._fused_step_state()
-        if st is not None and (self.plan.update[0] not in ("sgd", "adagrad") or st["slab"].lam is not None):
-            st = None        # the lazy regularised / Adam update is single-GPU
-        if st is None:
+        if self.plan.update[0] not in ("sgd", "adagrad"):
             raise NotImplementedError(
-                "table-sharded training runs the fused train step: a binary model with a relu DNN tower, "
-                "compile('sgd' | 'adagrad', 'binary_crossentropy'), no L1/L2 regularisers")
+                "table-sharded training needs the fused sparse table update: compile('sgd' | 'adagrad') with "
+                "l2_reg_embedding = l2_reg_linear = 0 (the lazy regularised / Adam update is single-GPU; "
+                "DataParallelTrainer takes any optimizer on replicated tables)")
+        st = model._fused_step_state()
+        if st is not None and st["slab"].lam is not None:
+            st = None
+        # Two routes for everything that is not a table:
+        #   fused     (DeepFM, WDL, NFM: BaseModel._fused_step_state) tower + head + backward as kernels, dense gradients in
+        #             the DenseSlab, one fused dense optimizer launch;
+        #   autograd  (xDeepFM, FiBiNET, DCN, PNN, AFM, AutoInt, ...: round 3) the model's own forward over the assembled
+        #             rows, autograd into ONE flat gradient bucket, the model's own optimizer over the dense parameters.
+        # The exchange -- owners' gather, two all-to-alls, owners' fused update -- is the same for both.
         self.state = st
-        self.slab = st["slab"]
+        self.slab = st["slab"] if st is not None else None
+        self.bucket = None
+        if st is None:
+            tables = set(id(p) for p in self.plan.table_params)
+            self.bucket = DenseBucket([p for p in model.parameters() if id(p) not in tables])
+            self._bucket_view = {id(p): v for p, v in zip(self.bucket.params, self.bucket.views)}
         self.layout = ShardLayout(self.plan, self.world, self.rank)
         self.ops = ops if ops is not None else HipShardOps(model, self.layout)
         self.use_graphs = bool(use_graphs)
@@ -459,6 +553,13 @@ class ShardedTrainer(object):
 
     def close(self):
         self.plan.sharder = None
+
+    def set_use_graphs(self, on):
+        """Switch hipGraph capture of the compute segment on / off; takes effect at the next ``train_step`` (the segments are
+        rebuilt).  Eager steps first, graphs afterwards is the intended order: the first call of a segment uploads
+        descriptors and allocates lazily, neither of which can be captured."""
+        self.use_graphs = bool(on)
+        self._shape = None
 
     # ---- called by _ops.embed (from model.logit_parts) in place of the single-GPU lookup ----------------------------
     def embed(self, X, want_fm, full):
@@ -487,13 +588,51 @@ class ShardedTrainer(object):
         self._ids_view = self._grads_all[:, lay.ids_col:lay.ids_col + lay.n_slots]
         self._announced = None          # identity of the batch whose ids already sit in _ids_view
         self._ids_t = None
-        g = bool(self.use_graphs) and xb.is_cuda
+        g = bool(self.use_graphs) and xb.is_cuda and self.slab is not None    # (the autograd route runs eagerly)
         # Only the multi-kernel segment is worth a graph: a hipGraph launch leaves the GPU idle for ~12 us before its
         # first kernel, a plain launch ~2 us, and the host has slack (it is not the bottleneck of this step).
         self._segB = _Segment(lambda: self.ops.gather(self._ids_view), False)
-        self._segC = _Segment(self._compute, g)
+        self._segC = _Segment(self._compute if self.slab is not None else self._compute_autograd, g)
         self._segD = _Segment(lambda: self.ops.update(self._grads_all, self._ids_t), False)
-        self._segE = _Segment(lambda: self.slab.step(*self.state["mode"]), False)
+        self._segE = _Segment((lambda: self.slab.step(*self.state["mode"])) if self.slab is not None
+                              else self._dense_step_autograd, False)
+
+    def _compute_autograd(self):
+        """The middle segment for a model outside the fused step: its own forward on the assembled rows (``embed`` below
+        is what ``logit_parts`` reaches through ``_ops.embed``), loss (sum) + the regularisers' share, autograd into the
+        flat bucket; the gradients of the assembled rows / wide logit / FM input go back through ``assemble_bwd``."""
+        model, plan, lay = self.model, self.plan, self.layout
+        self._leaves = None
+        y_pred = model(self._x).squeeze()
+        model.optim.zero_grad()
+        self.bucket.attach()
+        if isinstance(model.loss_func, list):
+            loss = sum([model.loss_func[i](y_pred[:, i], self._y[:, i], reduction='sum') for i in range(model.num_tasks)])
+        else:
+            loss = model.loss_func(y_pred, self._y.squeeze(), reduction='sum')
+        # the dense parameters are replicated and their gradients SUM-all-reduced: terms that depend on parameters only
+        # enter 1 / world per rank (tables carry no regulariser here: plan.update is the fused sparse update)
+        reg = model.get_regularization_loss() + model.aux_loss
+        (loss + reg * (1.0 / self.world)).backward()
+        lv = self._leaves
+        if lv is None:
+            raise RuntimeError("the model's forward did not go through the fused lookup")
+        w = plan.wide_dense_weight
+        g_wd = self._bucket_view.get(id(w)) if w is not None else None
+        g_wide = lv["wide"].grad if lv["wide"] is not None else None
+        g_fm = lv["fm"].grad if lv["fm"] is not None else None
+        send = self.ops.assemble_bwd(self._x, lv["out"].grad, g_wide, g_fm, lv["out"].detach(), lv["fm_s"],
+                                     g_wd.reshape(-1) if (g_wd is not None and g_wide is not None) else None)
+        B = self._x.shape[0]
+        send.view(lay.world, B, lay.ldc)[:, :, lay.ids_col:lay.ids_col + lay.n_slots].copy_(self._ids_next)
+        return send, loss.detach(), y_pred.detach()
+
+    def _dense_step_autograd(self):
+        model = self.model
+        model._step_stacked_groups()
+        done, _ = model._step_dense_multi(None)
+        if not done:
+            model.optim.step()
 
     def _compute(self):
         model, st, slab, plan, lay = self.model, self.state, self.slab, self.plan, self.layout
@@ -525,7 +664,7 @@ class ShardedTrainer(object):
         """One optimizer step on the gradient of the loss summed over every rank's batch.  ``next_xb`` (optional):
         the batch of the NEXT call -- its ids are shipped to the owners together with this step's row gradients,
         which saves that step's ids all-to-all.  Every rank must announce (or not) consistently."""
-        if not self.slab.intact():
+        if self.slab is not None and not self.slab.intact():
             raise RuntimeError("a dense parameter was re-allocated; build a new ShardedTrainer")
         if self._shape != (tuple(xb.shape), tuple(yb.shape)):
             self._build(xb, yb)
@@ -546,7 +685,8 @@ class ShardedTrainer(object):
         chunks, self._ids_t = self._segB()
         dist.all_to_all_single(self._recv, chunks, group=self.group)                 # rows -> samples' ranks
         send, loss, y_pred = self._segC()
-        wgrad = self.slab.deferred if xb.device.type == "cuda" else None    # (of the capture, when the segment is a graph replay)
+        # (of the capture, when the segment is a graph replay)
+        wgrad = self.slab.deferred if (self.slab is not None and xb.device.type == "cuda") else None
         if wgrad is not None:
             main = torch.cuda.current_stream(xb.device)
             if self._side is None:
@@ -557,7 +697,8 @@ class ShardedTrainer(object):
         dist.all_to_all_single(self._grads_all, send, group=self.group)              # row gradients (+ next ids)
         if wgrad is not None:
             main.wait_stream(self._side)                                              # the dense gradients are complete
-        work = dist.all_reduce(self.slab.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        flat = self.slab.grad if self.slab is not None else self.bucket.flat
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._segD()                                                                  # overlaps with the all-reduce
         work.wait()
         self._segE()
@@ -569,7 +710,7 @@ class ShardedTrainer(object):
         from ._hip.plan import _STATE
         with torch.no_grad():
             for u, (di, wi, col, _) in enumerate(plan.units):
-                owner = u % self.world
+                owner = self.layout.owner[u]
                 for f in ([plan.deep[di]] if di >= 0 else []) + ([plan.wide[wi]] if wi >= 0 else []):
                     for t in (f.param.data, _STATE.get(f.param)):
                         if t is None:

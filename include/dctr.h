@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 13
+#define DCTR_ABI_VERSION 14
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -567,14 +567,16 @@ int dctr_l2_value_multi(const dctr_dense_item_t* items, int32_t n_items, float* 
  *   partials in rank order + X[:, wdense_cols] . wdense_w), fm [B], fm_s [B, ld_s]  (wide / fm / fm_s nullable).
  * dctr_shard_assemble_bwd: the adjoint; send [N][B][ld_chunk] with G[b, f] = g_out[b, f] + g_fm[b] * (S[b] - e[b, f])
  *   in unit f's slot and g_wide[b] at wide_col; g_wdense [n_wdense] (nullable) = X[:, wdense_cols]^T g_wide.
+ * owner_slot [F] (device, nullable): unit f is owned by rank (owner_slot[f] & 0xffff) and sits in slot
+ *   (owner_slot[f] >> 16) of that owner's chunk; NULL: owner f % N, slot f / N.
  * Deterministic (no atomics).  D <= 64.                                                                          */
 int dctr_shard_assemble_fwd(const float* recv, int64_t ld_chunk, int32_t n_ranks, int32_t B, int32_t F, int32_t D,
-                            int32_t wide_col, const float* X, int64_t ld_x, const int32_t* dense_cols,
+                            const int32_t* owner_slot, int32_t wide_col, const float* X, int64_t ld_x, const int32_t* dense_cols,
                             int32_t n_dense, int32_t dense_off, const int32_t* wdense_cols, const float* wdense_w,
                             int32_t n_wdense, float* out, int64_t ld_out, float* wide, float* fm, float* fm_s,
                             int64_t ld_s, dctr_stream_t stream);
 int dctr_shard_assemble_bwd(float* send, int64_t ld_chunk, int32_t n_ranks, int32_t B, int32_t F, int32_t D,
-                            int32_t wide_col, const float* g_out, int64_t ld_g, const float* g_wide, const float* g_fm,
+                            const int32_t* owner_slot, int32_t wide_col, const float* g_out, int64_t ld_g, const float* g_wide, const float* g_fm,
                             const float* out, int64_t ld_out, const float* fm_s, int64_t ld_s, const float* X,
                             int64_t ld_x, const int32_t* wdense_cols, int32_t n_wdense, float* g_wdense,
                             dctr_stream_t stream);

@@ -135,7 +135,7 @@ def run(ref, name):
         collect(out, opt_name, model, touched, lambda k, p: p)
         model.optim = None
         model.zero_grad(set_to_none=True)
-    path = os.path.join(GOLDEN_DIR, "full_%s.npz" % name)
+    path = os.path.join(GOLDEN_DIR, "full", "%s.npz" % name)
     np.savez_compressed(path, **out)
     print("%-8s logit[min,max]=[%+.3f,%+.3f] loss=%.3f  -> %s (%.1f MB, %.0f s)" % (
         name, out["logit"].min(), out["logit"].max(), float(out["loss"]), os.path.relpath(path),

@@ -5,7 +5,7 @@ Nothing of the 1.7 GB of tables and none of the dense parameters is stored: ever
 (tensor name, flat index) through a 32-bit integer hash, evaluated with numpy integer arithmetic only, so
 ``oracle/make_full_golden.py`` (which runs the REAL reference on them in the build container) and the GPU tests (which
 cannot see the reference) construct bit-identical tensors.  Only the reference's OUTPUTS are committed
-(tests/golden/full_*.npz).  Untouched table rows cannot influence anything and are left at whatever the model
+(tests/golden/full/*.npz).  Untouched table rows cannot influence anything and are left at whatever the model
 constructor drew."""
 import zlib
 

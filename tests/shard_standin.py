@@ -36,7 +36,7 @@ class TorchShardOps(object):
         out = torch.zeros(B, plan.ld_out)
         r = recv.view(lay.world, B, lay.ldc)
         for f in range(lay.F):
-            q, j = f % lay.world, f // lay.world
+            q, j = lay.owner[f], lay.slot[f]
             out[:, f * lay.D:(f + 1) * lay.D] = r[q, :, j * lay.D:(j + 1) * lay.D]
         if plan.dense_cols:
             out[:, plan.dense_off:plan.dense_off + len(plan.dense_cols)] = X[:, plan.dense_cols]
@@ -65,7 +65,7 @@ class TorchShardOps(object):
             E = out[:, :W].view(B, lay.F, lay.D)
             G = G + (g_fm.view(B, 1, 1) * (fm_s[:, :lay.D].unsqueeze(1) - E)).reshape(B, W)
         for f in range(lay.F):
-            q, j = f % lay.world, f // lay.world
+            q, j = lay.owner[f], lay.slot[f]
             send[q, :, j * lay.D:(j + 1) * lay.D] = G[:, f * lay.D:(f + 1) * lay.D]
         if lay.has_wide:
             send[:, :, lay.wide_col] = (g_wide if g_wide is not None else torch.zeros(B)).unsqueeze(0)

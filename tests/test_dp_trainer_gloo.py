@@ -38,6 +38,10 @@ def _model(kind):
     if kind == "dcn":        # reference defaults on the cross network: l2_reg_cross = 1e-5 -> made visible with 1e-2
         return M.DCN(cols, cols, cross_num=2, dnn_hidden_units=(8,), l2_reg_linear=0, l2_reg_embedding=0,
                      l2_reg_cross=1e-2, l2_reg_dnn=1e-2, init_std=0.1, seed=5, device="cpu")
+    if kind == "dcn_table_l2":   # L2 on the TABLES: applied by every replica's own optimizer step, not all-reduced -- it must
+        # enter whole, not 1 / world of it (round-2 advisor finding: embedding_dict.C0.weight was off by 0.5 lr 2 lambda p)
+        return M.DCN(cols, cols, cross_num=2, dnn_hidden_units=(8,), l2_reg_linear=1e-2, l2_reg_embedding=1e-2,
+                     l2_reg_cross=1e-2, l2_reg_dnn=0, init_std=0.1, seed=5, device="cpu")
     return M.xDeepFM(cols, cols, dnn_hidden_units=(8,), cin_layer_size=(6, 4), l2_reg_linear=0, l2_reg_embedding=0,
                      l2_reg_dnn=1e-2, l2_reg_cin=1e-2, init_std=0.1, seed=5, device="cpu")
 
@@ -80,7 +84,7 @@ def _worker(rank, world, port, kind, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["dcn", "xdeepfm"])
+@pytest.mark.parametrize("kind", ["dcn", "xdeepfm", "dcn_table_l2"])
 def test_data_parallel_trainer_counts_dense_regularisers_once(tmp_path, kind, monkeypatch):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)

@@ -2,7 +2,7 @@
 vocabularies, 13 dense, embedding_dim 16, batch 4096 -- DeepFM (256,128), xDeepFM (CIN [128,128] split_half, dnn (256,256)),
 FiBiNET ('interaction' over all 26 fields, dnn (128,128)).
 
-tests/golden/full_*.npz hold what the reference computed in the build container (oracle/make_full_golden.py): logits,
+tests/golden/full/*.npz hold what the reference computed in the build container (oracle/make_full_golden.py): logits,
 predictions, loss, every dense gradient, the gradient of every touched table row, and the parameters after one train step
 under SGD and under Adagrad.  Inputs and parameters are regenerated here from the same integer hash
 (tests/fullsize_data.py).  Bars: logits 1e-5 absolute; gradients 2e-5 x max|gradient of the tensor| (+ the resolution of
@@ -22,7 +22,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _golden(name):
-    z = np.load(os.path.join(GOLD, "full_%s.npz" % name), allow_pickle=False)
+    z = np.load(os.path.join(GOLD, "full", "%s.npz" % name), allow_pickle=False)
     return {k: z[k] for k in z.files}
 
 

@@ -94,7 +94,7 @@ def test_shard_kernels_of_every_rank_match_the_standin(world, opt):
                                  out_g, fms_g, gwd_g).view(world, B, lc.ldc)
         send_c = oc.assemble_bwd(Xc, g_out, g_wide, g_fm, out_c, fms_c, gwd_c).view(world, B, lc.ldc)
         for f in range(lc.F):
-            q, j = f % world, f // world
+            q, j = lc.owner[f], lc.slot[f]
             _close(send_g[q, :, j * lc.D:(j + 1) * lc.D], send_c[q, :, j * lc.D:(j + 1) * lc.D], 2e-6,
                    "row gradient of unit %d" % f)
         if lc.has_wide:

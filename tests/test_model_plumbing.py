@@ -316,3 +316,29 @@ def test_forward_hooks_keep_firing_in_train_steps(mock, name):
         finals.append({k: v.clone() for k, v in m.state_dict().items()})
     for k in finals[0]:
         assert max_abs(finals[0][k].numpy(), finals[1][k].numpy()) <= 2e-5 * max(1.0, float(finals[0][k].abs().max())), k
+
+
+def test_weights_only_checkpoint_is_the_references_size(mock, tmp_path):
+    """After compile('adagrad') a table is a strided view of a slab that interleaves it with its Adagrad state
+    (_hip/layout.py).  state_dict() -- and optimizer.state_dict() -- must still hand out plain contiguous tensors: a saved
+    view drags its whole storage along (2x the table's bytes, accumulators included: round-2 advisor finding)."""
+    import io
+    g, m = _loaded("deepfm_criteo")
+    plain = io.BytesIO()
+    torch.save(m.state_dict(), plain)
+    m.compile("adagrad", "binary_crossentropy", metrics=[])
+    m.train()
+    m._train_step(torch.from_numpy(g["extra"]["X_steps"][0]), torch.from_numpy(g["extra"]["y_steps"][0]))
+    w = m.embedding_dict["C1"].weight
+    assert not w.is_contiguous(), "the test needs the interleaved layout"
+    sd = m.state_dict()
+    assert all(v.is_contiguous() for v in sd.values())
+    assert torch.equal(sd["embedding_dict.C1.weight"], w.detach())
+    after = io.BytesIO()
+    torch.save(sd, after)
+    assert after.getbuffer().nbytes <= plain.getbuffer().nbytes * 1.02
+    osd = m.optim.state_dict()
+    assert all(v.is_contiguous() for st in osd["state"].values() for v in st.values() if torch.is_tensor(v))
+    # and both still load back
+    m.load_state_dict(sd)
+    m.optim.load_state_dict(osd)

@@ -134,14 +134,14 @@ def test_state_dict_layout_matches_reference_on_its_test_matrix(c):
 
 
 def test_full_size_fixture_inputs_regenerate_bit_for_bit():
-    """tests/golden/full_*.npz (the real reference at 26 x 1M x 16, batch 4096: oracle/make_full_golden.py) store outputs
+    """tests/golden/full/*.npz (the real reference at 26 x 1M x 16, batch 4096: oracle/make_full_golden.py) store outputs
     only; inputs and parameters come from tests/fullsize_data.py's integer hash on both sides.  The generator must give here
     what it gave in the run that produced the fixtures."""
     import fullsize_data as FD
     X, y = FD.inputs()
     touched = FD.touched_rows(X)
     for name in FD.MODELS:
-        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_%s.npz" % name))
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full", "%s.npz" % name))
         assert float(z["check/X"]) == float(X.astype(np.float64).sum())
         assert float(z["check/y"]) == float(y.sum())
         assert float(z["check/table_C7"]) == float(
