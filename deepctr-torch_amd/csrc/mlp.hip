@@ -91,10 +91,6 @@ struct HeadArgs {
 
 __device__ __forceinline__ f32x4 ldg_f4(const float* p) { return *(const DCTR_GLOBAL f32x4*)p; }
 
-// the fast bodies (defined behind the general ones)
-__device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* smem, float* logit_lds);
-__device__ __forceinline__ void mlp_bwd_fast(const MlpArgs& A, float* smem, const float* g_lds, const float* hb0,
-                                             const float* hb1, int rs_h);
 
 // diagnostics (tools/mlp_trace.py): 16 wall_clock64 stamps per workgroup, or NULL -- only in the DCTR_DIAG build
 // (libdctr_hip_diag.so); the shipped library keeps no mutable global state
@@ -104,10 +100,51 @@ unsigned long long* g_mlp_trace = nullptr;
   do {                                                                                       \
     if ((T) && threadIdx.x == 0) (T)[blockIdx.x * 16ull + (slot)] = wall_clock64();          \
   } while (0)
+// The fast bodies stamp into LDS (every lane of the wave stores the same 32-bit s_memrealtime value to the slot: no
+// branch, no register pressure; the last wave through a point wins, i.e. the slot holds the slowest wave's time) and the
+// kernel writes the slots out at its very end, so a stamp does not split a software-pipelined region.
+// History (round 3): the diag k_mlp_train used to run 55-65 % slower than the shipped one and its timeline described
+// another kernel.  The cause was one line, `A.trace += ...` before the generic backward: WRITING to the by-value
+// argument struct makes the compiler keep the whole struct in scratch (784 B, every A.x a scratch load, 223 VGPRs).
+// The trace pointer is now passed beside A; both builds have identical register counts and run at the same speed.
+#define FT_DECL                                                                              \
+  __shared__ uint32_t ft_sh_[32];                                                            \
+  uint32_t* ft_ = ft_sh_;                                                                    \
+  if (threadIdx.x < 32) ft_sh_[threadIdx.x] = 0;                                             \
+  __syncthreads()
+#define FT(slot) (ft_[slot] = static_cast<uint32_t>(wall_clock64()))
+#define FT_ARG , uint32_t* ft_
+#define FT_PASS , ft_
+#define FT_DECL_B uint32_t* fb_ = ft_sh_ + 16
+#define FT_PASS_B , fb_
+#define FT_FLUSH_B(T)                                                                                       \
+  do {                                                                                                      \
+    if ((T) && threadIdx.x == 0)                                                                            \
+      for (int i_ = 0; i_ < 16; ++i_) (T)[(4096ull + blockIdx.x) * 16ull + i_] = fb_[i_];                    \
+  } while (0)
+#define FT_FLUSH(T)                                                                                         \
+  do {                                                                                                      \
+    __syncthreads();                                                                                        \
+    if ((T) && threadIdx.x == 0)                                                                            \
+      for (int i_ = 0; i_ < 16; ++i_) (T)[blockIdx.x * 16ull + i_] = ft_[i_];                               \
+  } while (0)
 #else
 static unsigned long long* const g_mlp_trace = nullptr;
 #define MLP_TRACE(T, slot) do { } while (0)
+#define FT_DECL do { } while (0)
+#define FT(slot) do { } while (0)
+#define FT_ARG
+#define FT_PASS
+#define FT_DECL_B do { } while (0)
+#define FT_PASS_B
+#define FT_FLUSH_B(T) do { } while (0)
+#define FT_FLUSH(T) do { } while (0)
 #endif
+
+// the fast bodies (defined behind the general ones)
+__device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* smem, float* logit_lds FT_ARG);
+__device__ __forceinline__ void mlp_bwd_fast(const MlpArgs& A, float* smem, const float* g_lds, const float* hb0,
+                                             const float* hb1, int rs_h FT_ARG);
 
 // ------------------------------------------------------------------------------------------------------------
 // forward
@@ -355,11 +392,16 @@ __device__ __forceinline__ const float* mlp_fwd_body(const MlpArgs& A, float* sm
 
 __global__ __launch_bounds__(kT) void k_mlp_fwd(MlpArgs A) {
   extern __shared__ __align__(16) float smem[];
+  FT_DECL;
 #ifdef DCTR_FAST_ONLY   // (ISA reading aid: compile the fast body alone)
-  mlp_fwd_fast(A, smem, nullptr);
+  mlp_fwd_fast(A, smem, nullptr FT_PASS);
 #else
-  if (A.fast) mlp_fwd_fast(A, smem, nullptr);
-  else mlp_fwd_body<false>(A, smem, nullptr);
+  if (A.fast) {
+    mlp_fwd_fast(A, smem, nullptr FT_PASS);
+    FT_FLUSH(A.trace);
+  } else {
+    mlp_fwd_body<false>(A, smem, nullptr);
+  }
 #endif
 }
 
@@ -499,14 +541,14 @@ __device__ __forceinline__ void bwd_cols(const MlpArgs& A, int l, const float* d
 // rows (the fused train kernel) instead of A.g; `htop` (nullable): the top layer's output tile still in LDS
 // ([16][rs_h], the fused train kernel) instead of its saved copy in global memory
 __device__ __forceinline__ void mlp_bwd_body(const MlpArgs& A, float* smem, const float* g_lds, const float* htop,
-                                             int rs_h) {
+                                             int rs_h, unsigned long long* tr) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * kTM;
   const int rs = A.rsd;
   float* d0 = smem;
   float* d1 = d0 + kTM * rs;
   const int top = A.n_layers - 1;
-  MLP_TRACE(A.trace, 0);
+  MLP_TRACE(tr, 0);
   {
     // d loss / d pre-activation of the top layer.  Four elements per thread and round trip, every load unconditional
     // from a clamped address (this loop was one round trip per element: 3.5 us for 16 x 128 -- round 3)
@@ -545,7 +587,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpArgs& A, float* smem, cons
     }
   }
   __syncthreads();
-  MLP_TRACE(A.trace, 1);
+  MLP_TRACE(tr, 1);
   float* din = d0;
   float* dout = d1;
   for (int l = top; l >= 0; --l) {
@@ -559,14 +601,14 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpArgs& A, float* smem, cons
         for (int gb = wv; gb < ngroups; gb += kWaves) bwd_cols<4>(A, l, din, dout, rs, gb, b0, g, c);
       }
     }
-    MLP_TRACE(A.trace, 2 + 2 * (top - l));
+    MLP_TRACE(tr, 2 + 2 * (top - l));
     __syncthreads();
-    MLP_TRACE(A.trace, 3 + 2 * (top - l));
+    MLP_TRACE(tr, 3 + 2 * (top - l));
     float* t = din;
     din = dout;
     dout = t;
   }
-  MLP_TRACE(A.trace, 15);
+  MLP_TRACE(tr, 15);
 }
 
 
@@ -741,7 +783,7 @@ __device__ __forceinline__ void fwd_bias_sel(const LayerDev& Ld, int tile0, int 
   }
 }
 
-__device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* smem, float* logit_lds) {
+__device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* smem, float* logit_lds FT_ARG) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * kTM;
   const int rsx = A.rsx, rsh = A.rsh;
@@ -749,7 +791,7 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
   float* hb0 = xs + kTM * rsx;    // [16][rsh]  ping
   float* hb1 = hb0 + kTM * rsh;   // [16][rsh]  pong
   const int K0 = A.L[0].K, K0p = round_up(K0, 16);
-  MLP_TRACE(A.trace, 0);
+  FT((0) & 15);
   // (loads return in order: what is consumed first is requested first -- input tile, bias, then the weight ring)
   // the tower input: thread (row tid / 32, dwordx4 columns tid % 32 + 32 i); nothing predicated -- rows past B re-read
   // row B-1, columns past the row are pulled back inside it, both are zeroed on the way to LDS
@@ -793,7 +835,7 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
     }
   }
   __syncthreads();
-  MLP_TRACE(A.trace, 1);
+  FT((1) & 15);
   const float* in = xs;
   int rs_in = rsx;
   for (int l = 0; l < A.n_layers; ++l) {
@@ -811,7 +853,7 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
         acc[1] = f32x4{bv[1], bv[1], bv[1], bv[1]};
       }
       fwd_run(ring, in, rs_in, Ld, klen, tile0, g, c, acc, A.wmask);
-      if (tile0 == wv) MLP_TRACE(A.trace, 2 + 3 * l);
+      if (tile0 == wv) FT((2 + 3 * l) & 15);
       // the epilogue's stores go first: the memory pipeline is in order, behind a 14 KB burst of weight requests per
       // wave they waited ~5 us (measured with a stamp between the two: round 3)
 #pragma unroll
@@ -830,7 +872,7 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (tile0 == wv && l == 0) MLP_TRACE(A.trace, 9);
+      if (l == 0) FT(9);
       // what this wave multiplies next -- its tiles of the second pass, or of the next layer -- and the bias that goes
       // with it: in flight across the barrier
       if (tile0 + 2 * kWaves < ntile) {
@@ -847,9 +889,9 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    MLP_TRACE(A.trace, 3 + 3 * l);
+    FT((3 + 3 * l) & 15);
     __syncthreads();
-    MLP_TRACE(A.trace, 4 + 3 * l);
+    FT((4 + 3 * l) & 15);
     if (Ld.h) tile_store(outb, rsh, Ld.h, Ld.ldh, Ld.N, b0, A.B);   // the saved activation, for the backward kernels
     in = outb;
     rs_in = rsh;
@@ -869,7 +911,7 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
       }
     }
   }
-  MLP_TRACE(A.trace, 15);
+  FT((15) & 15);
   return in;
 }
 
@@ -1031,7 +1073,7 @@ __device__ __forceinline__ int bwd_groups(const LayerDev& Ld) { return (Ld.K + 1
 // train kernel with both LDS images): layer j's output then sits in (j & 1 ? hb1 : hb0) for j >= n_layers - 2
 template <int Q>
 __device__ __forceinline__ void mlp_bwd_fast_q(const MlpArgs& A, float* smem, const float* g_lds, const float* hb0,
-                                               const float* hb1, int rs_h) {
+                                               const float* hb1, int rs_h FT_ARG) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * kTM;
   const int rs = A.rsd;
@@ -1042,7 +1084,7 @@ __device__ __forceinline__ void mlp_bwd_fast_q(const MlpArgs& A, float* smem, co
     return (hb0 && j >= 0 && j >= top - 1) ? ((j & 1) ? hb1 : hb0) : nullptr;
   };
   const float* htop = h_lds(top);
-  MLP_TRACE(A.trace, 0);
+  FT((0) & 15);
   BwdRing<Q> R;
   {
     const LayerDev& Lt = A.L[top];
@@ -1089,7 +1131,7 @@ __device__ __forceinline__ void mlp_bwd_fast_q(const MlpArgs& A, float* smem, co
     }
   }
   __syncthreads();
-  MLP_TRACE(A.trace, 1);
+  FT((1) & 15);
   if (A.L[top].dh) tile_store(d0, rs, A.L[top].dh, A.L[top].ldh, A.L[top].N, b0, A.B);
   float* din = d0;
   float* dout = d1;
@@ -1115,28 +1157,33 @@ __device__ __forceinline__ void mlp_bwd_fast_q(const MlpArgs& A, float* smem, co
       // (a wave without a group in this layer still opens the next one)
       if (wv >= ngroups && below && wv < bwd_groups<Q>(A.L[l - 1])) bwd_fill<Q>(R, A.L[l - 1], wv, g, c, A.wmask);
     }
-    MLP_TRACE(A.trace, 2 + 2 * (top - l));
+    FT((2 + 2 * (top - l)) & 15);
     __syncthreads();
-    MLP_TRACE(A.trace, 3 + 2 * (top - l));
+    FT((3 + 2 * (top - l)) & 15);
     // d loss / d pre-activation of the layer below, complete in `dout`: its copy for the weight-gradient kernel
     if (l > 0 && A.L[l - 1].dh) tile_store(dout, rs, A.L[l - 1].dh, A.L[l - 1].ldh, A.L[l - 1].N, b0, A.B);
     float* t = din;
     din = dout;
     dout = t;
   }
-  MLP_TRACE(A.trace, 15);
+  FT((15) & 15);
 }
 
 __device__ __forceinline__ void mlp_bwd_fast(const MlpArgs& A, float* smem, const float* g_lds, const float* hb0,
-                                             const float* hb1, int rs_h) {
-  if (A.fast == 2) mlp_bwd_fast_q<2>(A, smem, g_lds, hb0, hb1, rs_h);
-  else mlp_bwd_fast_q<4>(A, smem, g_lds, hb0, hb1, rs_h);
+                                             const float* hb1, int rs_h FT_ARG) {
+  if (A.fast == 2) mlp_bwd_fast_q<2>(A, smem, g_lds, hb0, hb1, rs_h FT_PASS);
+  else mlp_bwd_fast_q<4>(A, smem, g_lds, hb0, hb1, rs_h FT_PASS);
 }
 
 __global__ __launch_bounds__(kT) void k_mlp_bwd_data(MlpArgs A) {
   extern __shared__ __align__(16) float smem[];
-  if (A.fast) mlp_bwd_fast(A, smem, nullptr, nullptr, nullptr, 0);
-  else mlp_bwd_body(A, smem, nullptr, nullptr, 0);
+  FT_DECL;
+  if (A.fast) {
+    mlp_bwd_fast(A, smem, nullptr, nullptr, nullptr, 0 FT_PASS);
+    FT_FLUSH(A.trace);
+  } else {
+    mlp_bwd_body(A, smem, nullptr, nullptr, 0, A.trace);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1635,7 +1682,9 @@ __global__ __launch_bounds__(kT) void k_mlp_train(MlpArgs A, HeadArgs Hd, int bw
   const int64_t hbc = hb < A.B ? hb : A.B - 1;
   const float h_p0 = ldg_f32((Hd.part0 ? Hd.part0 : Hd.y) + hbc), h_p1 = ldg_f32((Hd.part1 ? Hd.part1 : Hd.y) + hbc);
   const float h_bias = ldg_f32(Hd.bias ? Hd.bias : Hd.y), h_y = ldg_f32(Hd.y + hbc);
-  const float* htop = A.fast ? mlp_fwd_fast(A, smem, zl) : mlp_fwd_body<false>(A, smem, zl);
+  FT_DECL;
+  FT_DECL_B;
+  const float* htop = A.fast ? mlp_fwd_fast(A, smem, zl FT_PASS) : mlp_fwd_body<false>(A, smem, zl);
   __syncthreads();
   if (tid < 64) {
     const int64_t b = hb;
@@ -1667,14 +1716,17 @@ __global__ __launch_bounds__(kT) void k_mlp_train(MlpArgs A, HeadArgs Hd, int bw
   __syncthreads();
   // bwd_off > 0: the backward's two gradient tiles lie BEHIND the forward's LDS image, so the top layer's output tile is
   // still there and its relu mask needs no global round trip; 0: they alias it (towers too wide for both images)
-#ifdef DCTR_DIAG
-  if (A.trace) A.trace += 16ull * 4096;   // the backward's stamps go to the second region (tools/tower_bench.py)
-#endif
   if (A.fast) {
     float* hb0 = smem + kTM * A.rsx;
-    mlp_bwd_fast(A, smem + bwd_off, gl, bwd_off > 0 ? hb0 : nullptr, bwd_off > 0 ? hb0 + kTM * A.rsh : nullptr, A.rsh);
+    mlp_bwd_fast(A, smem + bwd_off, gl, bwd_off > 0 ? hb0 : nullptr, bwd_off > 0 ? hb0 + kTM * A.rsh : nullptr, A.rsh
+                 FT_PASS_B);
+    FT_FLUSH(A.trace);         // (diag build: the forward's stamps to region 0, the backward's to region 1)
+    FT_FLUSH_B(A.trace);
+  } else {
+    // (diag build: the backward stamps region 1.  Through a local pointer -- writing to A would put the whole argument
+    // struct in scratch)
+    mlp_bwd_body(A, smem + bwd_off, gl, bwd_off > 0 ? htop : nullptr, A.rsh, A.trace ? A.trace + 16ull * 4096 : nullptr);
   }
-  else mlp_bwd_body(A, smem + bwd_off, gl, bwd_off > 0 ? htop : nullptr, A.rsh);
 }
 
 // ------------------------------------------------------------------------------------------------------------

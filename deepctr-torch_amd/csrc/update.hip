@@ -770,12 +770,16 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_apply_sorted(UpdArgs A) {
   __shared__ int carry_id;
   const int tid = threadIdx.x;
   const int P = A.P;
-  const int u = static_cast<int>(blockIdx.x) / P, p = static_cast<int>(blockIdx.x) - u * P;
-  if (u >= A.n_units) {
-    const int j = static_cast<int>(blockIdx.x) - A.n_units * P;
-    if (A.g_wdense && j < A.n_wdense) wdense_column(A, j);
+  // the dense half of Linear goes FIRST in the grid: its workgroups sweep the whole batch (two round trips + a
+  // reduction) and must not queue behind a second round of partition workgroups
+  const int n_lin = A.g_wdense ? A.n_wdense : 0;
+  if (static_cast<int>(blockIdx.x) < n_lin) {
+    wdense_column(A, static_cast<int>(blockIdx.x));
     return;
   }
+  const int wg = static_cast<int>(blockIdx.x) - n_lin;
+  const int u = wg / P, p = wg - u * P;
+  if (u >= A.n_units) return;
   int32_t* cnt = A.bcnt + static_cast<int64_t>(u) * P + p;
   const uint32_t* src = A.bkeys + (static_cast<int64_t>(u) * P + p) * kBucket;
   const int grp = tid / LPR, gl = tid % LPR, e0 = gl * VEC;

@@ -1,0 +1,10 @@
+#!/bin/bash
+export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/r3_models
+mkdir -p $O
+cd /tmp
+for m in xDeepFM FiBiNET; do
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/p_$m -o m -- python $GRAFT_REPO_ROOT/tools/prof_one_model.py $m > $O/$m.log 2>&1
+t=$(find /tmp/p_$m -name "*kernel_trace.csv" | head -1)
+python $GRAFT_REPO_ROOT/tools/step_profile.py $t 1 4 > $O/budget_$m.txt 2>&1
+done
