@@ -736,6 +736,10 @@ __device__ __forceinline__ void fwd_run(f32x4 (&ring)[kRingSlots], const float* 
       const int itn = it + 1 < n_it ? it + 1 : it;
       a0n = a_of(itn, 0);
       a1n = a_of(itn, 1);
+      // (grouped, not interleaved: with the iteration's address arithmetic, loads and LDS reads spread between the MFMAs
+      // by sched_group_barrier the first layer's phase took 8.8 us against 8.5.  Round 3 also tried, without effect on
+      // the kernel's time: warming each XCD's L2 with the weights from the workgroups' first instructions, and
+      // write-through (sc0 sc1) stores of the saved activations / gradients)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

@@ -66,6 +66,8 @@ class DenseSlab(object):
         self.inline = None        # DenseStep while a fused train step with in-kernel optimizer is being assembled
         self.inline_done = False  # the kernels of this step applied it: step() has nothing left to do
         self.wgrad_side = False   # topology of the in-kernel-optimizer step: True = weight gradients on the fork stream
+        self.wgrad_on_seg = False  # ... and that fork stream is the pre-pass's ("tower_seg")
+        self.upd_keep = None      # tower_seg: the operands of the last embedding update (alive until the next one is enqueued)
         self.gather_side = False  # ... True = gather AND update on the pre-pass's stream (ops.EmbedFunction.forward)
         self.main_keep = None     # gather_side: tensors the main stream's weight-gradient kernels of the last step read
         self.update_stream = None  # the side stream of this step's segment pre-pass (set by ops.EmbedFunction.forward):
@@ -76,8 +78,9 @@ class DenseSlab(object):
         d["_lay"] = [self._lay[id(p)] for p in self.params]     # id() keys do not survive pickling
         d["_fork"] = d["_pending"] = d["deferred"] = d["after_update"] = None   # streams / events / closures: per process
         d["overlap"] = False
-        d["inline"] = d["update_stream"] = d["main_keep"] = None
-        d["wgrad_side"] = d["gather_side"] = False
+        d["inline"] = d["update_stream"] = d["main_keep"] = d["upd_keep"] = None
+        d["wgrad_side"] = d["gather_side"] = d["wgrad_on_seg"] = False
+        d["_fork_events"] = None
         d["inline_done"] = False
         return d
 
@@ -131,15 +134,29 @@ class DenseSlab(object):
         with torch.cuda.stream(side):
             return bool(torch.cuda.is_current_stream_capturing())
 
-    def forked(self, stream, keep_alive):
-        self._pending = (stream, keep_alive)
+    def fork_event(self, k):
+        """Two events that live as long as the slab (an event created inside a hipGraph capture and collected during a
+        later one aborts the process: graph.no_gc_during_capture)."""
+        ev = getattr(self, "_fork_events", None)
+        if ev is None:
+            ev = self._fork_events = [torch.cuda.Event(), torch.cuda.Event()]
+        return ev[k]
+
+    def forked(self, stream, keep_alive, done=None):
+        """``done``: an event recorded behind the forked work -- join() then waits for IT instead of the stream's tail
+        (the stream goes on to carry work the joiner must not wait for)."""
+        self._pending = (stream, keep_alive, done)
 
     def join(self):
         p = self._pending
         self.main_keep = None
         if p is not None:
             self._pending = None
-            torch.cuda.current_stream(self.flat.device).wait_stream(p[0])
+            cur = torch.cuda.current_stream(self.flat.device)
+            if len(p) > 2 and p[2] is not None:
+                cur.wait_event(p[2])
+            else:
+                cur.wait_stream(p[0])
         # (the tensors of keep_alive are released only now, on the stream that has just waited for their last reader)
 
     def __setstate__(self, d):

@@ -308,18 +308,31 @@ class TowerHeadFunction(torch.autograd.Function):
             # to other queues, whatever stream they were captured on -- launched here, ahead of the update, the weight
             # gradients stayed on the tower's queue and the update (the longer chain since round 3) paid a cross-queue
             # edge on both ends (~10 us each).
-            side = sink.fork_stream(dev, force=True)
-            ev = torch.cuda.Event()
+            # "tower_seg" (round 3): the fork IS the pre-pass's stream -- two queues in all (main: gather, tower, update;
+            # side: ids, pre-pass, weight gradients + reduction), and the next tower launch waits for an event recorded
+            # right behind the reduction, not for the side stream's tail (by then the next step's pre-pass).
+            # tools/micro/topobench.hip (kernels that only busy-wait their body times) gives this recipe a period 4 us
+            # shorter than "update_side".  The real step is SLOWER (0.107 ms against 0.097, profiles/
+            # r03_step_topologies.json): the update and the weight gradients now start within a microsecond of each other
+            # and k_mlp_wgrad takes 38-40 us beside the update's 1118 workgroups (22 us with the 6 us head start it has
+            # in "update_side"), and that kernel is on this recipe's critical cycle.  Kept as an option, not the default.
+            seg = getattr(sink, "update_stream", None) if getattr(sink, "wgrad_on_seg", False) else None
+            side = seg if seg is not None else sink.fork_stream(dev, force=True)
+            ev = sink.fork_event(0)
             ev.record(torch.cuda.current_stream(dev))       # fork point: right behind the tower kernel
             keep = (x, hs, dhs, ws, g_logit, loss, ps, y, wo, desc, inline)
 
-            def launch_fork(side=side, ev=ev, keep=keep, B=B, g_bias=g_bias):
+            def launch_fork(side=side, ev=ev, keep=keep, B=B, g_bias=g_bias, by_event=seg is not None):
                 x_, ws_, g_logit_, loss_, desc_, inline_ = keep[0], keep[3], keep[4], keep[5], keep[9], keep[10]
                 side.wait_event(ev)
                 L.check(lib.dctr_mlp_train_wgrad(ctypes.byref(desc_), _ptr(x_), x_.stride(0), B, _ptr(g_logit_),
                                                  _ptr(ws_), _ptr(loss_), _ptr(g_bias), ctypes.byref(inline_),
                                                  ctypes.c_void_p(side.cuda_stream)), "dctr_mlp_train_wgrad")
-                sink.forked(side, keep)
+                done = None
+                if by_event:
+                    done = sink.fork_event(1)
+                    done.record(side)
+                sink.forked(side, keep, done)
             sink.after_update = launch_fork
             sink.inline_done = True
             sink.update_stream = None            # (the update runs on this stream: ops.EmbedFunction.backward)

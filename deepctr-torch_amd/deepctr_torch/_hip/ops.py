@@ -107,7 +107,20 @@ class EmbedFunction(torch.autograd.Function):
             if ctx.seg_event[0] is not True:
                 sink.update_stream = ctx.seg_event[0]
         else:
-            if own_ids:
+            if own_ids and getattr(sink, "wgrad_on_seg", False):
+                # Topology "tower_seg": the side stream carries ids, pre-pass and (behind the tower) the weight gradients +
+                # their reduction; the update runs on the MAIN stream.  Inside a multi-step capture the pre-pass does not
+                # wait for the main stream (= for the previous step's update): with that edge hipGraph puts the weight
+                # gradients on the gather's queue and serialises the step (tools/micro/topobench.hip, recipe V1b:
+                # 127 us against 93).  What the edge protected is kept apart instead: the bucket workspace alternates
+                # between two tensors, and the previous update's operands stay allocated until this step's update has
+                # been enqueued (sink.upd_keep), so nothing the side stream writes now can be memory they still read.
+                plan._ws_slot = 1 - getattr(plan, "_ws_slot", 1)
+                ctx.seg_event = plan.launch_segments(ids_t, parts_t, B, X=X, slot=plan._ws_slot,
+                                                     fork=not sink.side_chain_open(plan._seg_stream))
+                if ctx.seg_event[0] is not True:
+                    sink.update_stream = ctx.seg_event[0]
+            elif own_ids:
                 ctx.seg_event = plan.launch_segments(ids_t, parts_t, B, X=X)
                 if ctx.seg_event[0] is not True:              # (True: the CPU stand-in, no streams)
                     sink.update_stream = ctx.seg_event[0]     # where this step's update will run (see backward)
@@ -219,6 +232,8 @@ class EmbedFunction(torch.autograd.Function):
             if side is not None:
                 # (everything the side-stream kernels touch stays allocated until the join)
                 sink.forked(side, (X, out, ids_t, parts_t, fm_s, g_out, g_fm, g_wide, g_wd, ws))
+            elif sink is not None and getattr(sink, "wgrad_on_seg", False):
+                sink.upd_keep = (X, out, ids_t, parts_t, fm_s, g_out, g_fm, g_wide, g_wd, ws)   # (see forward)
             after = getattr(sink, "after_update", None) if sink is not None else None
             if after is not None:        # topology "tower_side": the weight gradients fork off behind the update's launch
                 sink.after_update = None

@@ -517,7 +517,7 @@ class EmbeddingPlan(object):
     def units_ptr(self):
         return ctypes.c_void_p(self._dev["units"].data_ptr())
 
-    def update_workspace(self, B, device, always=False):
+    def update_workspace(self, B, device, always=False, slot=0):
         """(int32 tensor | None, n_ints): the bucket workspace of ``dctr_embed_update`` / ``dctr_embed_segments`` -- zero
         before its first use, left ready by the kernels, so one tensor per (batch, device) serves every step.  Without
         the segment pre-pass it only pays for large batches, where a workgroup's scan over the unit's B ids is the
@@ -526,7 +526,9 @@ class EmbeddingPlan(object):
         mode = os.environ.get("DCTR_UPD_BUCKET", "auto")
         if not always and (mode == "0" or (mode != "1" and B < 8192)):
             return None, 0
-        key = (int(B), str(device))
+        # (slot: the "tower_seg" step topology alternates between two workspaces -- the pre-pass of step n runs on the
+        # side stream while the update of step n-1 may still be reading its own on the main stream)
+        key = (int(B), str(device)) if not slot else (int(B), str(device), int(slot))
         ws = self._upd_ws.get(key)
         if ws is None:
             n = int(L.lib().dctr_embed_update_workspace_ints(ctypes.byref(self.cplan), len(self.units), int(B)))
@@ -547,7 +549,7 @@ class EmbeddingPlan(object):
         import os
         return os.environ.get("DCTR_SEGMENTS", "1") != "0"
 
-    def launch_segments(self, ids_t, parts_t, B, X=None, before=None, fork=True):
+    def launch_segments(self, ids_t, parts_t, B, X=None, before=None, fork=True, slot=0):
         """Enqueue the pre-pass for this forward's ids on the side stream.  Returns the handle the update passes to
         ``update_workspace_for``.  A workspace still marked by an earlier forward (whose backward never ran -- a
         forward in train mode that was not followed by a backward) is taken over.
@@ -556,7 +558,7 @@ class EmbeddingPlan(object):
         ``fork=False``: the side stream does not wait for the calling stream first (its own order -- behind the
         previous step's update -- is all the gather needs)."""
         device = ids_t.device
-        ws, ws_n = self.update_workspace(B, device, always=True)
+        ws, ws_n = self.update_workspace(B, device, always=True, slot=slot)
         dirty = getattr(ws, "_dctr_owner", None) is not None
 
         def enqueue(stream):

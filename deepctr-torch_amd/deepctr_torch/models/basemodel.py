@@ -747,7 +747,8 @@ class BaseModel(nn.Module):
                 plan.segments_enabled():
             slab.begin_inline_step(mode[0], mode[1], mode[2] if len(mode) > 2 else 0.0)
             topo = os.environ.get("DCTR_STEP_TOPOLOGY", "update_side")
-            slab.wgrad_side = topo == "tower_side"
+            slab.wgrad_side = topo in ("tower_side", "tower_seg")
+            slab.wgrad_on_seg = topo == "tower_seg"
             slab.gather_side = topo == "gather_side"
         reg = None
         try:

@@ -27,6 +27,7 @@ ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--slices", default="")
 ap.add_argument("--trace", action="store_true")
 ap.add_argument("--diag", action="store_true")
+ap.add_argument("--flush-mb", type=int, default=0, help="--trace: stream this many MB through the chip before the traced launch")
 ap.add_argument("--nx", type=int, default=8, help="input buffers the launches rotate over")
 args = ap.parse_args()
 if args.trace or args.slices or args.diag:
@@ -209,6 +210,11 @@ if args.slices:
 if args.trace:
     buf = torch.zeros(3 * 4096 * 16, dtype=torch.int64, device=dev)
     lib.dctr_dbg_mlp_trace(ctypes.c_void_p(buf.data_ptr()))
+    if args.flush_mb:
+        junk = torch.empty(args.flush_mb << 18, device=dev)
+        junk2 = torch.empty_like(junk)
+        torch.cuda.synchronize()
+        junk2.copy_(junk)
     launch_train(0, ws)
     launch_wgrad(0, ws, True)
     torch.cuda.synchronize()

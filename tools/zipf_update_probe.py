@@ -74,6 +74,15 @@ def probe(ids_mode):
         w = r[r[:, 6] > 0]
         per_launch.append(float((w[:, 6].max() - r[r[:, 0] > 0][:, 0].min()) * tick))
     res["P"] = int(P)
+    r = rows[-1]
+    live = r[r[:, 0] > 0]
+    t00 = live[:, 0].min()
+    st = (live[:, 0] - t00) * tick
+    done = r[r[:, 6] > 0]
+    en = (done[:, 6] - t00) * tick
+    res["last_launch"] = {"workgroups_started": int(len(live)), "workgroups_with_work": int(len(done)),
+                          "start_us_p10_p50_p90_max": [round(float(np.percentile(st, q)), 2) for q in (10, 50, 90, 100)],
+                          "end_us_p10_p50_p90_max": [round(float(np.percentile(en, q)), 2) for q in (10, 50, 90, 100)]}
     res["apply_sorted_first_start_to_last_end_us"] = [round(v, 1) for v in per_launch]
     res["by_tiles"] = {}
     for k in sorted(set(tiles.tolist())):
@@ -90,4 +99,5 @@ def probe(ids_mode):
     return res
 
 
-print(json.dumps({"B": B, "uniform": probe("uniform"), "zipf": probe("zipf")}, indent=1))
+modes = sys.argv[1:] or ["uniform", "zipf"]
+print(json.dumps(dict({"B": B}, **{m: probe(m) for m in modes}), indent=1))
