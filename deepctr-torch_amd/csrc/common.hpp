@@ -82,6 +82,56 @@ __device__ __forceinline__ void strip_store(float* p, const Strip<VEC>& s) {
   }
 }
 
+// ---- write-through stores + the signal half of dctr_step_wait (include/dctr.h) -----------------------------------------
+// sc0 sc1: the bytes leave this XCD's L2 for memory as they are stored, not at the end-of-kernel write-back; s_waitcnt
+// vmcnt(0) then means they have arrived.  (Inline asm: the compiler's own waitcnt bookkeeping does not see these stores,
+// which only makes its later waits conservative -- memory operations return in order.)
+__device__ __forceinline__ void stg_wt(float* p, float v) {
+  asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void stg_wt(float* p, f32x2 v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void stg_wt(float* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+// plain or write-through, by a wave-uniform flag
+__device__ __forceinline__ void stg_f32(float* p, float v, bool wt) {
+  if (wt) stg_wt(p, v);
+  else *(DCTR_GLOBAL float*)p = v;
+}
+template <int VEC>
+__device__ __forceinline__ void strip_store(float* p, const Strip<VEC>& s, bool wt) {
+  if (!wt) {
+    strip_store<VEC>(p, s);
+  } else if constexpr (VEC == 8) {
+    stg_wt(p, f32x4{s.v[0], s.v[1], s.v[2], s.v[3]});
+    stg_wt(p + 4, f32x4{s.v[4], s.v[5], s.v[6], s.v[7]});
+  } else if constexpr (VEC == 4) {
+    stg_wt(p, f32x4{s.v[0], s.v[1], s.v[2], s.v[3]});
+  } else if constexpr (VEC == 2) {
+    stg_wt(p, f32x2{s.v[0], s.v[1]});
+  } else {
+    stg_wt(p, s.v[0]);
+  }
+}
+// Every thread of the workgroup calls this once, behind its last write-through store: the stores have arrived, the
+// workgroup counts itself done, and the launch's last workgroup advances the signal's generation.  (Relaxed agent-scope
+// atomics: they execute beyond the XCD's L2; a release here would write back the whole L2, ~2-6 us per workgroup.)
+__device__ __forceinline__ void step_signal(int32_t* sync, int signal) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t* gen = sync + 4 * signal;
+    const int32_t n = static_cast<int32_t>(gridDim.x * gridDim.y * gridDim.z);
+    if (__hip_atomic_fetch_add(gen + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n - 1) {
+      __hip_atomic_store(gen + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      gen[3] = static_cast<int32_t>(wall_clock64());     // (when: for tools/step_hops.py)
+      __hip_atomic_fetch_add(gen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // fp32 hardware atomic add without return (global_atomic_add_f32; needs -munsafe-fp-atomics).
 // Tables are ordinary coarse-grained hipMalloc memory owned by PyTorch, where it is valid.
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) {

@@ -26,7 +26,7 @@ constexpr int kNW = 4;  // waves per workgroup
 constexpr int kThreads = kNW * kWave;
 constexpr int kFieldWords = sizeof(dctr_field_t) / 4;
 static_assert(sizeof(dctr_field_t) == 64, "dctr_field_t must be 64 bytes");
-static_assert(sizeof(dctr_plan_t) == 88, "dctr_plan_t layout changed: update the Python binding");
+static_assert(sizeof(dctr_plan_t) == 96, "dctr_plan_t layout changed: update the Python binding");
 
 struct Tile {
   const dctr_field_t* deep;
@@ -121,6 +121,17 @@ __device__ __forceinline__ Strip<VEC> pool_field(const dctr_field_t& fd, const f
   return acc;
 }
 
+// a strip into an LDS row (16-byte aligned when VEC == 4)
+template <int VEC>
+__device__ __forceinline__ void strip_put(float* p, const Strip<VEC>& s) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{s.v[0], s.v[1], s.v[2], s.v[3]};
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) p[i] = s.v[i];
+  }
+}
+
 // -------------------------------------------------------------------------------------------------
 // forward
 // -------------------------------------------------------------------------------------------------
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
                                                         const int32_t* __restrict__ units, int n_units,
                                                         int32_t* __restrict__ ids_t,
                                                         uint16_t* __restrict__ parts_t, int n_parts,
-                                                        float* __restrict__ fm_s, int64_t lds_) {
+                                                        float* __restrict__ fm_s, int64_t lds_, int stage_off) {
   constexpr int SPB = kWave / LPR;
   constexpr int CH = 8;   // row loads in flight per lane and per pass (x4 waves = 32 fields)
   constexpr int WCH = 2;  // wide loads in flight per lane and per pass
@@ -142,6 +153,18 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
   const int grp = lane / LPR, gl = lane % LPR;
   const int b0 = blockIdx.x * SPB;
   const int nrows = min(SPB, B - b0);
+  // P.step_sync: the tower that consumes this launch's outputs runs on another queue behind a dctr_step_wait; they are
+  // signalled complete at the end of the kernel and must have left the chip's caches by then.
+  //  * stage_off != 0: the tile's output rows are assembled in LDS (zero-filled first: the padding columns too) and
+  //    written out as whole rows -- 1 KB per wave-instruction -- with write-through stores.  (Write-through stores of the
+  //    64-byte field slices themselves, 16 rows x 64 bytes per instruction, took the kernel from 12 to 27 us.)
+  //  * otherwise plain stores and an agent-scope release (this XCD's L2 written back) in front of the signal.
+  const bool thru = P.step_sync != nullptr, staged = stage_off != 0;
+  float* lrows = reinterpret_cast<float*>(smem + stage_off);
+  if (staged) {
+    f32x4* z = reinterpret_cast<f32x4*>(lrows);
+    for (int i = tid; i < SPB * static_cast<int>(ldo >> 2); i += kThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const Tile T = stage_tile(P, X, ldx, b0, nrows, SPB, smem);
   const bool valid = grp < nrows;
   const int g = valid ? grp : 0;  // idle groups shadow group 0; their stores are masked
@@ -150,6 +173,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
   const int e0 = gl * VEC;
   int bad = 0;
   float* orow = out ? out + static_cast<int64_t>(b) * ldo : nullptr;
+  float* lrow = lrows + g * ldo;
 
   // side output for dctr_embed_update: the ids of this tile, transposed to [unit][b] (64-byte runs)
   // (+ parts_t: the partition of dctr_embed_update each entry belongs to, so that its workgroups compare 16-bit tags
@@ -202,7 +226,10 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
     for (int k = 0; k < CH; ++k) {
       const dctr_field_t& fd = T.deep[min(f0 + k * kNW, nfix - 1)];
       const bool live = (f0 + k * kNW < nfix) && (e0 < fd.dim);
-      if (live && valid) strip_store<VEC>(orow + fd.out_off + e0, r[k]);
+      if (live && valid) {
+        if (staged) strip_put<VEC>(lrow + fd.out_off + e0, r[k]);
+        else strip_store<VEC>(orow + fd.out_off + e0, r[k]);
+      }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         const float v = live ? r[k].v[i] : 0.f;
@@ -219,7 +246,10 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
       const bool act = e0 < fd.dim;
       const Strip<VEC> p = pool_field<VEC>(fd, xr, e0, act, bad);
       if (act) {
-        if (valid) strip_store<VEC>(orow + fd.out_off + e0, p);
+        if (valid) {
+          if (staged) strip_put<VEC>(lrow + fd.out_off + e0, p);
+          else strip_store<VEC>(orow + fd.out_off + e0, p);
+        }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           S.v[i] += p.v[i];
@@ -228,9 +258,12 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
       }
     }
     // dense block of combined_dnn_input (inputs.py:126-138)
-    if (P.dense_off >= 0 && valid)
-      for (int j = wv_id * LPR + gl; j < P.n_dense; j += kNW * LPR)
-        stg_f32(orow + P.dense_off + j, xr[ldg_i32(P.dense_cols + j)]);
+    if (P.dense_off >= 0 && valid) {
+      for (int j = wv_id * LPR + gl; j < P.n_dense; j += kNW * LPR) {
+        if (staged) lrow[P.dense_off + j] = xr[ldg_i32(P.dense_cols + j)];
+        else stg_f32(orow + P.dense_off + j, xr[ldg_i32(P.dense_cols + j)]);
+      }
+    }
   }
 
   if (wide) {
@@ -277,22 +310,34 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
         Strip<VEC> sv;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) sv.v[i] = st[i];
-        strip_store<VEC>(fm_s + static_cast<int64_t>(b) * lds_ + e0, sv);
+        strip_store<VEC>(fm_s + static_cast<int64_t>(b) * lds_ + e0, sv, staged);
       }
       if (fm) {
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) t += st[i] * st[i] - qt[i];
         t = group_sum<LPR>(t);
-        if (gl == 0 && valid) stg_f32(fm + b, 0.5f * t);
+        if (gl == 0 && valid) stg_f32(fm + b, 0.5f * t, staged);
       }
       if (wide) {
         wt = group_sum<LPR>(wt);
-        if (gl == 0 && valid) stg_f32(wide + static_cast<int64_t>(b) * ldw, wt);
+        if (gl == 0 && valid) stg_f32(wide + static_cast<int64_t>(b) * ldw, wt, staged);
       }
     }
   }
   if (err && bad) atomicOr(err, 1);
+  if (staged) {
+    __syncthreads();
+    const int q4 = static_cast<int>(ldo >> 2);
+    for (int r = wv_id; r < nrows; r += kNW) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(lrows + r * ldo);
+      float* dst = out + static_cast<int64_t>(b0 + r) * ldo;
+      for (int c = lane; c < q4; c += kWave) stg_wt(dst + 4 * c, src[c]);
+    }
+  } else if (thru) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  }
+  if (thru) step_signal(P.step_sync, DCTR_SYNC_GATHER);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -582,13 +627,23 @@ extern "C" int dctr_embed_fwd(const dctr_plan_t* plan, const float* X, int64_t l
   if (out && vec > 1 && (ld_out % vec != 0 || reinterpret_cast<uintptr_t>(out) % (4 * vec) != 0))
     return DCTR_EALIGN;
   const int lpr = lanes_per_row(plan, vec);
-  const size_t lds = tile_bytes(plan, lpr, vec);
+  size_t lds = tile_bytes(plan, lpr, vec);
   if (lds > kMaxTile) return DCTR_ENOSUP;
   const int spb = kWave / lpr;
+  // signalled launches assemble their output rows in LDS when they fit (see the kernel)
+  int stage_off = 0;
+  if (plan->step_sync && out && ld_out % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) {
+    const size_t off = (lds + 15) & ~size_t(15), need = off + static_cast<size_t>(spb) * ld_out * sizeof(float);
+    if (need <= 64 * 1024) {
+      stage_off = static_cast<int>(off);
+      lds = need;
+    }
+  }
   const dim3 grid((B + spb - 1) / spb), block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
   DCTR_DISPATCH(vec, lpr, DCTR_LAUNCH((k_embed_fwd<VEC, LPR>), grid, block, lds, s, *plan, X, ldx, B, out, ld_out,
-                                      wide, ld_wide, fm, err, units, n_units, ids_t, parts_t, n_parts, fm_s, ld_s));
+                                      wide, ld_wide, fm, err, units, n_units, ids_t, parts_t, n_parts, fm_s, ld_s,
+                                      stage_off));
   return launch_status();
 }
 

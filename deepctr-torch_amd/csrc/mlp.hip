@@ -72,6 +72,7 @@ struct MlpArgs {
   int kc;            // columns of the tower input staged in LDS at a time (<= kKC; smaller for wide towers)
   int rsd;           // LDS row stride of the backward-data pass
   int fast;          // 1: the tower fits the fast bodies (mlp_fwd_fast / mlp_bwd_fast)
+  int32_t* sync;     // nullable: k_mlp_train signals DCTR_SYNC_TOWER when gx and g_logit have left the chip (dctr.h)
   uint32_t wmask;    // diagnostics: AND mask on the weight byte offsets (0xffffffff normally; DCTR_MLP_WMASK in the diag build
                      // folds the weight stream onto a few KB that stay in L1 -- timing experiment, wrong results)
   unsigned long long* trace;
@@ -1060,10 +1061,11 @@ __device__ __forceinline__ void bwd_epilogue(const MlpArgs& A, int l, float* dou
 #pragma unroll
         for (int q = 0; q < Q; ++q)
           if (col0 + q >= Ld.K) v[q] = 0.f;
-        *(DCTR_GLOBAL vecq*)(A.gx + b * A.ldgx + col0) = v;
+        if (A.sync) stg_wt(A.gx + b * A.ldgx + col0, v);      // (the update waits for a signal, not for this kernel's end)
+        else *(DCTR_GLOBAL vecq*)(A.gx + b * A.ldgx + col0) = v;
       } else {
         for (int q = 0; q < Q; ++q)
-          if (col0 + q < A.ldgx) stg_f32(A.gx + b * A.ldgx + col0 + q, col0 + q < Ld.K ? v[q] : 0.f);
+          if (col0 + q < A.ldgx) stg_f32(A.gx + b * A.ldgx + col0 + q, col0 + q < Ld.K ? v[q] : 0.f, A.sync != nullptr);
       }
     }
   }
@@ -1706,7 +1708,7 @@ __global__ __launch_bounds__(kT) void k_mlp_train(MlpArgs A, HeadArgs Hd, int bw
       const float q = (1.f - p) * p;
       gz = ((p - t) / fmaxf(q, 1e-12f)) * q;                      // bce backward (grad 1) x sigmoid backward
       stg_f32(Hd.y_pred + b, p);
-      stg_f32(Hd.g_logit + b, gz);
+      stg_f32(Hd.g_logit + b, gz, A.sync != nullptr);
     }
     if (tid < kTM) gl[tid] = gz;
     li = group_sum<16>(li);
@@ -1730,7 +1732,10 @@ __global__ __launch_bounds__(kT) void k_mlp_train(MlpArgs A, HeadArgs Hd, int bw
     // (diag build: the backward stamps region 1.  Through a local pointer -- writing to A would put the whole argument
     // struct in scratch)
     mlp_bwd_body(A, smem + bwd_off, gl, bwd_off > 0 ? htop : nullptr, A.rsh, A.trace ? A.trace + 16ull * 4096 : nullptr);
+    // (the generic body's gx stores are plain: an agent-scope release writes this XCD's dirty lines back first)
+    if (A.sync) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   }
+  if (A.sync) step_signal(A.sync, DCTR_SYNC_TOWER);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1846,7 +1851,7 @@ __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
   const uint32_t ldh4 = static_cast<uint32_t>(Ld.ldh) * 4u, ldi4 = static_cast<uint32_t>(ldi) * 4u;
   const uint32_t va = static_cast<uint32_t>(p) * ldh4 + 4u * static_cast<uint32_t>(mc);
   const uint32_t vx = static_cast<uint32_t>(p) * ldi4 + 4u * static_cast<uint32_t>(kc);
-  constexpr int U = 4, PD = 4;
+  constexpr int U = 4, PD = 3;
   const int n_full = nrow / (2 * U);                  // full groups of U k-steps (2 rows each)
   const uint32_t row0 = static_cast<uint32_t>(wb0);
   auto lda = [&](int gidx, int u) -> f32x2 {          // group index -> k-step u's rows (clamped to the last full group)
@@ -2234,7 +2239,7 @@ extern "C" int dctr_mlp_fwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, i
   a.kc = pick_kc(K0p, a.rsh);
   a.rsx = (K0p < a.kc ? K0p : a.kc) + 4;
   a.rsd = 0;
-  a.fast = tower_fast(m, a.kc); a.wmask = diag_wmask();
+  a.fast = tower_fast(m, a.kc); a.wmask = diag_wmask(); a.sync = nullptr;
   const size_t lds = static_cast<size_t>(kTM) * (a.rsx + 2 * a.rsh) * 4;
   if (lds > 150 * 1024) return DCTR_ENOSUP;
   if (lds > 64 * 1024)
@@ -2339,7 +2344,7 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, i
     a.trace = g_mlp_trace ? g_mlp_trace + 16ull * 4096 : nullptr;
     a.rsx = 0; a.rsh = 0;
     a.rsd = bwd_stride(m);
-    a.fast = tower_fast(m, kKC); a.wmask = diag_wmask();
+    a.fast = tower_fast(m, kKC); a.wmask = diag_wmask(); a.sync = nullptr;
     const size_t lds = static_cast<size_t>(kTM) * 2 * a.rsd * 4;
     if (lds > 160 * 1024) return DCTR_ENOSUP;
     if (lds > 64 * 1024)
@@ -2385,7 +2390,7 @@ extern "C" int dctr_mlp_train_step(const dctr_mlp_t* m, const float* x, int64_t 
     a.kc = pick_kc(K0p, a.rsh);
     a.rsx = (K0p < a.kc ? K0p : a.kc) + 4;
     a.rsd = bwd_stride(m);
-    a.fast = tower_fast(m, a.kc); a.wmask = diag_wmask();
+    a.fast = tower_fast(m, a.kc); a.wmask = diag_wmask(); a.sync = gx ? m->step_sync : nullptr;
     const size_t lds_f = static_cast<size_t>(kTM) * (a.rsx + 2 * a.rsh) * 4;
     const size_t lds_b = static_cast<size_t>(kTM) * 2 * a.rsd * 4;
     size_t lds = lds_f > lds_b ? lds_f : lds_b;
@@ -2469,7 +2474,7 @@ extern "C" int dctr_crossnet_mat_fwd(const dctr_mlp_t* m, const float* x, int64_
   a.rsx = Wp + 4;
   a.rsh = Wp + 4;
   a.rsd = 0;
-  a.fast = 0; a.wmask = 0xffffffffu;
+  a.fast = 0; a.wmask = 0xffffffffu; a.sync = nullptr;
   const size_t lds = static_cast<size_t>(kTM) * (a.rsx + 2 * a.rsh) * 4;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cross_mat_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2500,7 +2505,7 @@ extern "C" int dctr_crossnet_mat_bwd(const dctr_mlp_t* m, const float* x, int64_
     fill_layers(m, a.L);
     a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = nullptr; a.logit = nullptr;
     a.g = gY; a.ldg = ld_g; a.gx = gx; a.ldgx = ld_gx; a.trace = nullptr;
-    a.rsx = 0; a.rsh = 0; a.fast = 0; a.wmask = 0xffffffffu;
+    a.rsx = 0; a.rsh = 0; a.fast = 0; a.wmask = 0xffffffffu; a.sync = nullptr;
     a.rsd = round_up(W, 64) + 4;
     const size_t lds = static_cast<size_t>(kTM) * 4 * a.rsd * 4;
     if (lds > 64 * 1024)
@@ -2565,7 +2570,7 @@ extern "C" int dctr_crossnet_mix_fwd(const dctr_mlp_t* m, int32_t E, int32_t R, 
   fill_layers(m, a.L);
   a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = nullptr; a.logit = nullptr;
   a.g = nullptr; a.ldg = 0; a.gx = nullptr; a.ldgx = 0; a.trace = nullptr;
-  a.kc = kKC; a.rsx = 0; a.rsh = 0; a.rsd = 0; a.fast = 0; a.wmask = 0xffffffffu;
+  a.kc = kKC; a.rsx = 0; a.rsh = 0; a.rsd = 0; a.fast = 0; a.wmask = 0xffffffffu; a.sync = nullptr;
   const size_t lds = mix_lds_fwd(W, E * R + E);
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cross_mix_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2597,7 +2602,7 @@ extern "C" int dctr_crossnet_mix_bwd(const dctr_mlp_t* m, int32_t E, int32_t R, 
     fill_layers(m, a.L);
     a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = nullptr; a.logit = nullptr;
     a.g = gY; a.ldg = ld_g; a.gx = gx; a.ldgx = ld_gx; a.trace = nullptr;
-    a.kc = kKC; a.rsx = 0; a.rsh = 0; a.rsd = 0; a.fast = 0; a.wmask = 0xffffffffu;
+    a.kc = kKC; a.rsx = 0; a.rsh = 0; a.rsd = 0; a.fast = 0; a.wmask = 0xffffffffu; a.sync = nullptr;
     const size_t lds = mix_lds_bwd(W, E * R + E);
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cross_mix_bwd),

@@ -67,6 +67,9 @@ class DenseSlab(object):
         self.inline_done = False  # the kernels of this step applied it: step() has nothing left to do
         self.wgrad_side = False   # topology of the in-kernel-optimizer step: True = weight gradients on the fork stream
         self.wgrad_on_seg = False  # ... and that fork stream is the pre-pass's ("tower_seg")
+        self.flag_sync = False    # topology "flags": gather_side with the two cross-queue edges replaced by dctr_step_wait
+        self.sync_timeout_us = 20000
+        self._sync = None         # the sync block (int32[16], zero at rest between steps' signal / wait pairs)
         self.upd_keep = None      # tower_seg: the operands of the last embedding update (alive until the next one is enqueued)
         self.gather_side = False  # ... True = gather AND update on the pre-pass's stream (ops.EmbedFunction.forward)
         self.main_keep = None     # gather_side: tensors the main stream's weight-gradient kernels of the last step read
@@ -78,7 +81,8 @@ class DenseSlab(object):
         d["_lay"] = [self._lay[id(p)] for p in self.params]     # id() keys do not survive pickling
         d["_fork"] = d["_pending"] = d["deferred"] = d["after_update"] = None   # streams / events / closures: per process
         d["overlap"] = False
-        d["inline"] = d["update_stream"] = d["main_keep"] = d["upd_keep"] = None
+        d["inline"] = d["update_stream"] = d["main_keep"] = d["upd_keep"] = d["_sync"] = None
+        d["flag_sync"] = False
         d["wgrad_side"] = d["gather_side"] = d["wgrad_on_seg"] = False
         d["_fork_events"] = None
         d["inline_done"] = False
@@ -133,6 +137,30 @@ class DenseSlab(object):
             return False
         with torch.cuda.stream(side):
             return bool(torch.cuda.is_current_stream_capturing())
+
+    def sync_block(self, device):
+        """The step's device-side dependency words (include/dctr.h: dctr_step_wait).  Allocated once, outside any
+        hipGraph capture's pool."""
+        if self._sync is None or self._sync.device != torch.device(device):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("the step's sync block must exist before a hipGraph capture begins (run one eager step)")
+            self._sync = torch.zeros(L.SYNC_INTS, dtype=torch.int32, device=device)
+        return self._sync
+
+    def check_sync(self, reset=False):
+        """Raise if a dctr_step_wait ever timed out (synchronises the device).  ``reset``: zero the block -- after an
+        exception interrupted a step between a signal and its wait."""
+        if self._sync is None:
+            return
+        torch.cuda.synchronize(self._sync.device)
+        bad = int(self._sync[L.SYNC_ERR].item())
+        if reset or bad:
+            self._sync.zero_()
+            torch.cuda.synchronize(self._sync.device)
+        if bad:
+            raise RuntimeError("a device-side step dependency timed out (signals %s): kernels of the two queues were not "
+                               "running concurrently (a profiler serialising kernels?) -- results since then are invalid; "
+                               "set DCTR_STEP_TOPOLOGY=update_side" % bin(bad))
 
     def fork_event(self, k):
         """Two events that live as long as the slab (an event created inside a hipGraph capture and collected during a

@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdctr_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 
@@ -30,7 +30,8 @@ class Plan(ctypes.Structure):
                 ("n_deep", ctypes.c_int32), ("n_deep_fixed", ctypes.c_int32), ("n_wide", ctypes.c_int32),
                 ("n_dense", ctypes.c_int32), ("n_wdense", ctypes.c_int32), ("dense_off", ctypes.c_int32),
                 ("emb_dim", ctypes.c_int32), ("n_xcols", ctypes.c_int32), ("n_wide_fixed", ctypes.c_int32),
-                ("max_dim", ctypes.c_int32), ("vec", ctypes.c_int32), ("flags", ctypes.c_int32)]
+                ("max_dim", ctypes.c_int32), ("vec", ctypes.c_int32), ("flags", ctypes.c_int32),
+                ("step_sync", ctypes.c_void_p)]
 
 
 MLP_MAX_LAYERS = 12
@@ -46,7 +47,7 @@ class MlpLayer(ctypes.Structure):
 class Mlp(ctypes.Structure):
     """``dctr_mlp_t`` (include/dctr.h) -- host struct, device pointers."""
     _fields_ = [("layer", MlpLayer * MLP_MAX_LAYERS), ("w_out", ctypes.c_void_p), ("g_w_out", ctypes.c_void_p),
-                ("n_layers", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+                ("n_layers", ctypes.c_int32), ("pad_", ctypes.c_int32), ("step_sync", ctypes.c_void_p)]
 
 
 class DenseStep(ctypes.Structure):
@@ -62,6 +63,7 @@ class DenseItem(ctypes.Structure):
 
 
 PLAN_HAS_GACC, PLAN_HAS_STATE, PLAN_HAS_MAXPOOL = 1, 2, 4
+SYNC_TOWER, SYNC_GATHER, SYNC_ERR, SYNC_INTS = 0, 1, 12, 16
 LAZY_SGD, LAZY_ADAGRAD, LAZY_ADAM = 0, 1, 2
 
 
@@ -150,6 +152,7 @@ SIGNATURES = {
                                            _P, _I32, _P, _P]),
     "dctr_mlp_train_wgrad": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _P, _P, _P, _P, _P]),
     "dctr_sizeof_dense_step": (ctypes.c_size_t, []),
+    "dctr_step_wait": (ctypes.c_int, [_P, _I32, _I32, _P]),
     "dctr_bce_head": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P]),
     "dctr_dense_opt": (ctypes.c_int, [_P, _P, _P, _I64, _I32, _F32, _F32, _P]),
     "dctr_sizeof_dense_item": (ctypes.c_size_t, []),

@@ -283,6 +283,13 @@ class TowerHeadFunction(torch.autograd.Function):
         _fill(desc, meta, Ws, lds, bp, hs, dhs, gWs, gbs, wo, g_wo)
         ws = torch.empty((max(1, lib.dctr_mlp_train_workspace_floats(ctypes.byref(desc), B)),), dtype=torch.float32,
                          device=dev)
+        # topology "flags": the tower + head launch signals gx / g_logit complete in the step's sync block and the
+        # update's stream waits for THAT (dctr_step_wait) instead of an event of this stream
+        sync = None
+        if getattr(sink, "flag_sync", False) and getattr(sink, "inline", None) is not None and \
+                getattr(sink, "update_stream", None) is not None and x.device.type == "cuda":
+            sync = sink.sync_block(dev)
+            desc.step_sync = sync.data_ptr()
         pp = [_ptr(p) for p in ps] + [None] * (2 - len(ps))
         # The weight gradients need only what the first launch leaves behind (x, h, dh, g_logit) and nothing but the
         # dense optimizer needs THEM: with a fork stream on the sink they run beside the embedding update (which needs
@@ -343,7 +350,10 @@ class TowerHeadFunction(torch.autograd.Function):
             # chain -- gather, tower, weight gradients -- then never crosses a queue (a cross-queue dependency costs
             # 6-10 us on this stack; round 1 paid two per step).
             upd = getattr(sink, "update_stream", None)
-            if upd is not None:
+            if upd is not None and sync is not None:
+                L.check(lib.dctr_step_wait(_ptr(sync), L.SYNC_TOWER, sink.sync_timeout_us,
+                                           ctypes.c_void_p(upd.cuda_stream)), "dctr_step_wait(tower)")
+            elif upd is not None:
                 upd.wait_stream(torch.cuda.current_stream(dev))      # the update may start once this launch is done
             L.check(lib.dctr_mlp_train_wgrad(ctypes.byref(desc), _ptr(x), x.stride(0), B, _ptr(g_logit), _ptr(ws),
                                              _ptr(loss), _ptr(g_bias), ctypes.byref(inline), L.stream_handle(dev)),

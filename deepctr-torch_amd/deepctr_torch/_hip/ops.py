@@ -89,11 +89,17 @@ class EmbedFunction(torch.autograd.Function):
         ctx.seg_event = None
         err = plan.err_flag(X.device)
 
-        def gather(stream, with_ids):
-            L.check(lib.dctr_embed_fwd(cplan, _ptr(X), X.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), 1, _ptr(fm),
-                                       _ptr(err), plan.units_ptr(), len(plan.units),
-                                       _ptr(ids_t) if with_ids else None, _ptr(parts_t) if with_ids else None,
-                                       _ptr(fm_s), ld_s, stream), "dctr_embed_fwd")
+        def gather(stream, with_ids, signal=None):
+            # signal: the step's sync block (dense.DenseSlab.sync_block) -- the gather stores its outputs write-through
+            # and signals DCTR_SYNC_GATHER; the tower's stream waits for that with dctr_step_wait, not for an event
+            plan.cplan.step_sync = signal.data_ptr() if signal is not None else None
+            try:
+                L.check(lib.dctr_embed_fwd(cplan, _ptr(X), X.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), 1,
+                                           _ptr(fm), _ptr(err), plan.units_ptr(), len(plan.units),
+                                           _ptr(ids_t) if with_ids else None, _ptr(parts_t) if with_ids else None,
+                                           _ptr(fm_s), ld_s, stream), "dctr_embed_fwd")
+            finally:
+                plan.cplan.step_sync = None
 
         if own_ids and getattr(sink, "gather_side", False):
             # Topology "gather_side": the gather runs on the side stream too, in stream order behind the previous
@@ -102,10 +108,18 @@ class EmbedFunction(torch.autograd.Function):
             # a multi-step capture the side stream does not wait for the main one first (that would be the previous
             # step's weight-gradient reduction): it does only when it has to -- first step of a capture, eager steps
             # (whatever produced X ran on the main stream), tables last written elsewhere.
-            ctx.seg_event = plan.launch_segments(ids_t, parts_t, B, before=lambda st: gather(st, True),
-                                                 fork=not sink.side_chain_open(plan._seg_stream))
+            sync = sink.sync_block(X.device) if getattr(sink, "flag_sync", False) else None
+            ctx.seg_event = plan.launch_segments(ids_t, parts_t, B, before=lambda st: gather(st, True, sync),
+                                                 fork=not sink.side_chain_open(plan._seg_stream),
+                                                 join_before=sync is None)
             if ctx.seg_event[0] is not True:
                 sink.update_stream = ctx.seg_event[0]
+            if sync is not None:
+                # Topology "flags": no graph edge between the two queues inside a step.  A one-wave kernel on THIS
+                # stream waits for the gather's signal (4.6 us from the gather's last workgroup to the tower's first,
+                # against 11-12 us through a cross-queue hipGraph edge: tools/micro/hopbench.hip)
+                L.check(lib.dctr_step_wait(_ptr(sync), L.SYNC_GATHER, sink.sync_timeout_us,
+                                           L.stream_handle(X.device)), "dctr_step_wait(gather)")
         else:
             if own_ids and getattr(sink, "wgrad_on_seg", False):
                 # Topology "tower_seg": the side stream carries ids, pre-pass and (behind the tower) the weight gradients +

@@ -420,6 +420,9 @@ class EmbeddingPlan(object):
         if self._err is not None and int(self._err.item()) != 0:
             self._err.zero_()
             raise IndexError("index out of range in self: a sparse id in X is outside [0, vocabulary_size)")
+        owner = getattr(self, "_sync_owner", None)      # step topology "flags": did a device-side dependency time out?
+        if owner is not None:
+            owner.check_sync()
 
     def dense_matrix(self, X, cols):
         lo, hi = cols[0], cols[-1] + 1
@@ -549,7 +552,7 @@ class EmbeddingPlan(object):
         import os
         return os.environ.get("DCTR_SEGMENTS", "1") != "0"
 
-    def launch_segments(self, ids_t, parts_t, B, X=None, before=None, fork=True, slot=0):
+    def launch_segments(self, ids_t, parts_t, B, X=None, before=None, fork=True, slot=0, join_before=True):
         """Enqueue the pre-pass for this forward's ids on the side stream.  Returns the handle the update passes to
         ``update_workspace_for``.  A workspace still marked by an earlier forward (whose backward never ran -- a
         forward in train mode that was not followed by a backward) is taken over.
@@ -597,7 +600,9 @@ class EmbeddingPlan(object):
         if before is not None:
             with torch.cuda.stream(side):
                 before(L.stream_handle(device))
-            main.wait_stream(side)          # (an event at the side stream's tail of NOW: the pre-pass comes behind it)
+            if join_before:
+                main.wait_stream(side)      # (an event at the side stream's tail of NOW: the pre-pass comes behind it)
+            # (join_before=False: the caller orders the main stream behind `before`'s work itself -- dctr_step_wait)
         with torch.cuda.stream(side):
             enqueue(L.stream_handle(device))
         ws._dctr_owner = token

@@ -749,7 +749,14 @@ class BaseModel(nn.Module):
             topo = os.environ.get("DCTR_STEP_TOPOLOGY", "update_side")
             slab.wgrad_side = topo in ("tower_side", "tower_seg")
             slab.wgrad_on_seg = topo == "tower_seg"
-            slab.gather_side = topo == "gather_side"
+            slab.gather_side = topo in ("gather_side", "flags")
+            # ("flags" needs its sync block to exist before a hipGraph capture begins: a capture without an eager step
+            # in front of it falls back to the event edges of "gather_side")
+            slab.flag_sync = topo == "flags" and xb.is_cuda and \
+                (slab._sync is not None or not torch.cuda.is_current_stream_capturing())
+            if slab.flag_sync:
+                slab.sync_block(xb.device)
+                plan._sync_owner = slab
         reg = None
         try:
             loss, y_pred = self.fused_loss(xb, yb, slab)
@@ -761,6 +768,13 @@ class BaseModel(nn.Module):
                 if rv is not None:
                     reg = rv if reg is None else reg + rv
             loss.backward(gradient=st["one"])       # a resident 1.0: no fill launch per step
+        except BaseException:
+            if slab.flag_sync and not torch.cuda.is_current_stream_capturing():
+                try:                 # a step interrupted between a signal and its wait: start the pairs over
+                    slab.check_sync(reset=True)
+                except RuntimeError:
+                    pass
+            raise
         finally:
             self._grad_sink = None
             plan.dense_sink = None

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 14
+#define DCTR_ABI_VERSION 15
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -82,6 +82,8 @@ typedef struct dctr_plan {
   int32_t vec;                /* 4, 2 or 1: every deep dim, out_off, ld and base pointer is a        */
                               /* multiple of `vec` floats -- lets rows move as dwordx4/x2            */
   int32_t flags;              /* DCTR_PLAN_* : facts about the device arrays the host cannot see     */
+  int32_t* step_sync;         /* nullable: dctr_embed_fwd signals DCTR_SYNC_GATHER in this block when its outputs  */
+                              /* have left the chip's caches (see dctr_step_wait)                                  */
 } dctr_plan_t;
 
 #define DCTR_PLAN_HAS_GACC 1    /* every field has a gacc slab                       */
@@ -487,6 +489,7 @@ typedef struct dctr_mlp {
   float* g_w_out;     /* [N_last] nullable */
   int32_t n_layers;
   int32_t pad_;
+  int32_t* step_sync; /* nullable: dctr_mlp_train_step's first launch signals DCTR_SYNC_TOWER (gx and g_logit complete) */
 } dctr_mlp_t;
 size_t dctr_sizeof_mlp(void);
 #ifdef DCTR_DIAG
@@ -520,6 +523,26 @@ int dctr_mlp_train_step(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32
 int dctr_mlp_train_wgrad(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g_logit,
                          float* workspace, float* loss, float* g_bias, const dctr_dense_step_t* step,
                          dctr_stream_t stream);
+
+/* ---- device-side dependencies between the two queues of a train step ---------------------------------------------
+ * A dependency that crosses hardware queues costs 11-12 us through hipGraph / stream events on this stack, 4.6 us through
+ * a word in memory (tools/micro/hopbench.hip), and the DeepFM step's critical cycle crosses twice (tower -> update,
+ * gather -> tower: 24 of its 99 us).  So the producer kernels can SIGNAL and a one-wave kernel in front of the consumer
+ * WAITS:
+ *   sync block: DCTR_SYNC_INTS int32, zero before first use, one per model.  For each signal s (DCTR_SYNC_TOWER /
+ *     DCTR_SYNC_GATHER): a generation counter the producer's LAST workgroup advances -- after every workgroup has
+ *     stored what the consumer reads with write-through stores and waited for them -- and an epoch counter the waiter
+ *     advances once per call: the n-th wait returns when the n-th signal has been given.
+ *   dctr_step_wait enqueues the waiter (1 workgroup of 64 threads: it cannot keep a producer from being scheduled).  It
+ *     gives up after timeout_us (and raises bit s of the block's error word, DCTR_SYNC_ERR): a kernel stream that is
+ *     serialised by a profiler collecting counters, or a producer that was never launched, costs time, not a hang.
+ * The consumer is launched behind the waiter on the same stream; its own start-of-kernel acquire does the rest.
+ * Signals and waits must pair up one to one (the fused train step does; dctr_step_sync is for nothing else).        */
+#define DCTR_SYNC_TOWER 0
+#define DCTR_SYNC_GATHER 1
+#define DCTR_SYNC_ERR 12     /* index of the error word */
+#define DCTR_SYNC_INTS 16
+int dctr_step_wait(int32_t* sync, int32_t signal, int32_t timeout_us, dctr_stream_t stream);
 
 /* ---- prediction head + loss (layers/core.py:154-160, basemodel.py:254, F.binary_cross_entropy(reduction='sum'))
  *     z = sum_i part_i[b] + bias ;  y_pred = sigmoid(z) ;  loss = sum_b -(y log p + (1-y) log(1-p))   (logs clamped

@@ -1,0 +1,102 @@
+"""The fused train step's capture recipes ("step topologies", DCTR_STEP_TOPOLOGY) run the SAME kernels in the same
+data-dependency order -- they differ in which stream a kernel is enqueued on and in how a dependency between the two
+streams is expressed (stream events / hipGraph edges, or the device-side signal + one-wave waiter of "flags":
+include/dctr.h dctr_step_wait).  So every topology must leave bit-identical parameters behind.  A dependency expressed
+wrongly -- a consumer starting before its producer's stores have landed, a stale cache line -- changes bits.
+
+Small vocabularies on purpose: most rows are touched by consecutive steps, i.e. the gather of step n+1 reads what the
+update of step n wrote a few microseconds earlier."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+F_SPARSE, N_DENSE, DIM, B = 26, 13, 16, 4096
+
+
+def _model(vocab, opt):
+    from deepctr_torch.inputs import DenseFeat, SparseFeat
+    from deepctr_torch.models import DeepFM
+    cols = [SparseFeat("C%d" % (i + 1), vocab, DIM) for i in range(F_SPARSE)] + \
+           [DenseFeat("I%d" % (i + 1), 1) for i in range(N_DENSE)]
+    m = DeepFM(cols, cols, dnn_hidden_units=(256, 128), l2_reg_linear=0, l2_reg_embedding=0, dnn_dropout=0, seed=1024,
+               device=DEV)
+    m.compile(opt, "binary_crossentropy", metrics=[])
+    m.train()
+    return m
+
+
+def _data(vocab, n_batches):
+    gen = torch.Generator().manual_seed(7)
+    n = B * n_batches
+    ids = torch.randint(0, vocab, (n, F_SPARSE), generator=gen)
+    X = torch.cat([ids.float(), torch.rand(n, N_DENSE, generator=gen)], dim=1).to(DEV)
+    y = torch.randint(0, 2, (n,), generator=gen).float().to(DEV)
+    return X, y
+
+
+def _run(topology, vocab, opt, steps, graphed):
+    os.environ["DCTR_STEP_TOPOLOGY"] = topology
+    try:
+        m = _model(vocab, opt)
+        X, y = _data(vocab, 8)
+        bat = lambda i: (X[(i % 8) * B:(i % 8 + 1) * B], y[(i % 8) * B:(i % 8 + 1) * B])
+        losses = []
+        i = 0
+        for _ in range(2):                                  # eager steps first (a capture needs the step's state built)
+            losses.append(m._train_step(*bat(i))[0])
+            i += 1
+        if graphed:
+            from deepctr_torch._hip.graph import GraphedTrainStep
+            S = 4
+            g = GraphedTrainStep(m, *bat(0), steps_per_graph=S, inputs_ready=True).capture(*bat(0))
+            while i < steps:
+                for _ in range(S):
+                    out = g(*bat(i))
+                    i += 1
+                losses.append(out[0].clone())
+            g.flush()
+        else:
+            while i < steps:
+                losses.append(m._train_step(*bat(i))[0])
+                i += 1
+        torch.cuda.synchronize()
+        m.model_plan().check_ids()                          # (also raises when a device-side wait timed out)
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        st = {}
+        for grp in m.optim.param_groups:
+            for p in grp["params"]:
+                for k, v in m.optim.state.get(p, {}).items():
+                    if torch.is_tensor(v) and v.numel() > 1:
+                        st[(id(p), k)] = v.detach().clone()
+        names = {id(p): n for n, p in m.named_parameters()}
+        st = {"%s/%s" % (names.get(pid, "?"), k): v for (pid, k), v in st.items()}
+        return sd, st, torch.stack([l.reshape(()) for l in losses]).cpu()
+    finally:
+        os.environ.pop("DCTR_STEP_TOPOLOGY", None)
+
+
+@pytest.mark.parametrize("graphed", [False, True], ids=["eager", "hipgraph"])
+@pytest.mark.parametrize("opt", ["adagrad", "sgd"])
+@pytest.mark.parametrize("topology", ["flags", "gather_side", "tower_seg"])
+def test_topology_leaves_the_same_bits_as_the_default(topology, opt, graphed):
+    vocab, steps = 3000, 42
+    ref_sd, ref_st, ref_loss = _run("update_side", vocab, opt, steps, graphed)
+    sd, st, loss = _run(topology, vocab, opt, steps, graphed)
+    assert torch.equal(loss, ref_loss), "losses differ: first at step %d" % int((loss != ref_loss).nonzero()[0])
+    for k in ref_sd:
+        assert torch.equal(sd[k], ref_sd[k]), "%s differs under %s" % (k, topology)
+    assert set(st) == set(ref_st)
+    for k in ref_st:
+        assert torch.equal(st[k], ref_st[k]), "optimizer state %s differs under %s" % (k, topology)
+
+
+def test_flags_long_run_on_large_tables():
+    """1M-row tables (the benchmark shape), 200 graph-replayed steps: rows mostly miss every cache"""
+    ref_sd, _, ref_loss = _run("update_side", 1_000_000, "adagrad", 202, True)
+    sd, _, loss = _run("flags", 1_000_000, "adagrad", 202, True)
+    assert torch.equal(loss, ref_loss)
+    for k in ref_sd:
+        assert torch.equal(sd[k], ref_sd[k]), "%s differs" % k
