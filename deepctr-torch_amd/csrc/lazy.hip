@@ -34,7 +34,7 @@ namespace {
 constexpr int kT = 256;
 
 struct OptConst {
-  int kind;   // DCTR_LAZY_SGD / ADAGRAD / ADAM
+  int kind;   // DCTR_LAZY_SGD / ADAGRAD / ADAM / RMSPROP
   float lr, eps, beta1, beta2;
 };
 
@@ -63,6 +63,15 @@ __device__ __forceinline__ void opt_step(const OptConst& o, float g, float& w, f
   } else if (o.kind == DCTR_LAZY_ADAGRAD) {
     a = a + g * g;
     w = w - o.lr * (g / (sqrtf(a) + o.eps));
+  } else if (o.kind == DCTR_LAZY_RMSPROP) {
+    // square_avg.mul_(alpha).addcmul_(g, g, value=1 - alpha); p.addcdiv_(g, square_avg.sqrt().add_(eps), value=-lr)
+    // -- with the roundings of ATen's device kernels (each tensor op rounds; addcmul is a + (v * b) * c and addcdiv is
+    // a + v * (b / c), their last multiply-add contracted): RMSprop divides by sqrt(square_avg) + 1e-8, so a row whose
+    // accumulator is still ~g^2/100 moves by 10 lr whatever |g| is, and an ulp of difference in a sign-deciding value
+    // shows up as 0.1 in the weight.  beta1 carries float(1 - alpha) as torch computes it (in double).
+    const float a1 = __fmul_rn(a, o.beta2);
+    a = __fmaf_rn(__fmul_rn(o.beta1, g), g, a1);
+    w = __fmaf_rn(-o.lr, __fdiv_rn(g, __fadd_rn(__fsqrt_rn(a), o.eps)), w);
   } else {
     w = w - o.lr * g;
   }
@@ -74,7 +83,8 @@ template <int VEC>
 __device__ __forceinline__ void replay(const OptConst& o, float lam2, int from, int to, float (&w)[VEC],
                                        float (&a)[VEC], float (&b)[VEC]) {
   if (from >= to) return;
-  if (o.kind != DCTR_LAZY_ADAM && lam2 == 0.f) return;   // zero gradient: SGD / Adagrad do not move
+  // zero gradient: SGD / Adagrad do not move (RMSprop's square_avg still decays, Adam's moments too)
+  if ((o.kind == DCTR_LAZY_SGD || o.kind == DCTR_LAZY_ADAGRAD) && lam2 == 0.f) return;
   AdamClock ck;
   if (o.kind == DCTR_LAZY_ADAM) ck.start(o, from + 1);
   for (int T = from + 1; T <= to; ++T) {
@@ -236,7 +246,9 @@ __global__ __launch_bounds__(kT) void k_dense_opt_reg(float* __restrict__ p, con
 int check(const dctr_lazy_unit_t* units, int n_units, const int32_t* step, const dctr_lazy_opt_t* opt, int vec,
           int max_dim) {
   if (!units || n_units <= 0 || !step || !opt) return DCTR_EINVAL;
-  if (opt->kind != DCTR_LAZY_SGD && opt->kind != DCTR_LAZY_ADAGRAD && opt->kind != DCTR_LAZY_ADAM) return DCTR_EINVAL;
+  if (opt->kind != DCTR_LAZY_SGD && opt->kind != DCTR_LAZY_ADAGRAD && opt->kind != DCTR_LAZY_ADAM &&
+      opt->kind != DCTR_LAZY_RMSPROP)
+    return DCTR_EINVAL;
   if (vec != 1 && vec != 4) return DCTR_EINVAL;
   if (max_dim < 1 || max_dim > 64 * vec) return DCTR_ENOSUP;
   return DCTR_OK;
@@ -291,9 +303,11 @@ extern "C" int dctr_lazy_flush(const dctr_lazy_unit_t* units, int32_t n_units, i
 extern "C" int dctr_dense_opt_reg(float* p, const float* g, float* s1, float* s2, const float* lam, int64_t n,
                                   const dctr_lazy_opt_t* opt, const int32_t* step, dctr_stream_t stream) {
   if (!p || !g || n < 0 || !opt || !step) return DCTR_EINVAL;
-  if (opt->kind == DCTR_LAZY_ADAGRAD && !s1) return DCTR_EINVAL;
+  if ((opt->kind == DCTR_LAZY_ADAGRAD || opt->kind == DCTR_LAZY_RMSPROP) && !s1) return DCTR_EINVAL;
   if (opt->kind == DCTR_LAZY_ADAM && (!s1 || !s2)) return DCTR_EINVAL;
-  if (opt->kind != DCTR_LAZY_SGD && opt->kind != DCTR_LAZY_ADAGRAD && opt->kind != DCTR_LAZY_ADAM) return DCTR_EINVAL;
+  if (opt->kind != DCTR_LAZY_SGD && opt->kind != DCTR_LAZY_ADAGRAD && opt->kind != DCTR_LAZY_ADAM &&
+      opt->kind != DCTR_LAZY_RMSPROP)
+    return DCTR_EINVAL;
   if (n == 0) return DCTR_OK;
   OptConst o;
   o.kind = opt->kind; o.lr = opt->lr; o.eps = opt->eps; o.beta1 = opt->beta1; o.beta2 = opt->beta2;

@@ -64,7 +64,7 @@ class DenseItem(ctypes.Structure):
 
 PLAN_HAS_GACC, PLAN_HAS_STATE, PLAN_HAS_MAXPOOL = 1, 2, 4
 SYNC_TOWER, SYNC_GATHER, SYNC_ERR, SYNC_INTS = 0, 1, 12, 16
-LAZY_SGD, LAZY_ADAGRAD, LAZY_ADAM = 0, 1, 2
+LAZY_SGD, LAZY_ADAGRAD, LAZY_ADAM, LAZY_RMSPROP = 0, 1, 2, 3
 
 
 class LazyUnit(ctypes.Structure):

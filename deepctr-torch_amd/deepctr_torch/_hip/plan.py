@@ -93,7 +93,7 @@ class LazyState(object):
     """Host side of csrc/lazy.hip: the reference's regularised / Adam table update replayed lazily, exactly.
 
     ``l2`` maps a table parameter to its lambda (0 when unregularised), ``s1`` / ``s2`` to its optimizer state
-    tensors (Adagrad ``sum`` | Adam ``exp_avg``, Adam ``exp_avg_sq``).  Owns the per-unit stamps, the device step
+    tensors (Adagrad ``sum`` | RMSprop ``square_avg`` | Adam ``exp_avg``, Adam ``exp_avg_sq``).  Owns the per-unit stamps, the device step
     counter and the gradient slabs' use; see include/dctr.h for the protocol."""
 
     # tables up to this many elements in total get their logged regularisation term recomputed EXACTLY at every
@@ -115,7 +115,8 @@ class LazyState(object):
         self._reg = None          # value for the current weights (dropped by apply())
         self._last_reg = None     # last value computed (what big models log between two flushes)
         self.opt = L.LazyOpt()
-        self.opt.kind = {"sgd": L.LAZY_SGD, "adagrad": L.LAZY_ADAGRAD, "adam": L.LAZY_ADAM}[kind]
+        self.opt.kind = {"sgd": L.LAZY_SGD, "adagrad": L.LAZY_ADAGRAD, "adam": L.LAZY_ADAM,
+                         "rmsprop": L.LAZY_RMSPROP}[kind]
         self.opt.lr, self.opt.eps, self.opt.beta1, self.opt.beta2 = self.hyper
         self.vec = 4 if plan.vec == 4 else 1
         self.max_dim = max(plan.max_dim, 1)
@@ -216,7 +217,7 @@ class LazyState(object):
         self._ensure(self.step.device)
         self._call(L.lib().dctr_lazy_flush, "dctr_lazy_flush", int(self.plan.max_vocab))
         self.dirty = False
-        if self.optimizer is not None and self.kind == "adam" and not (
+        if self.optimizer is not None and self.kind in ("adam", "rmsprop") and not (
                 self.step.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
             t = float(int(self.step.item()))
             for p in self.plan.table_params:

@@ -84,13 +84,31 @@ class Linear(nn.Module):
 
     def forward(self, X, sparse_feat_refine_weight=None):
         if sparse_feat_refine_weight is not None:
-            raise NotImplementedError("sparse_feat_refine_weight (IFM / DIFM) is outside the MI355X hot path "
-                                      "(SURVEY.md 2.1 #11)")
+            return self._forward_refined(X, sparse_feat_refine_weight)
         plan = self.plan()
         if not plan.has_wide:
             return torch.zeros([X.shape[0], 1], device=X.device)
         _, wide, _ = _ops.embed(plan, X)
         return wide.unsqueeze(1)
+
+
+    def _forward_refined(self, X, refine):
+        """w_{x,i} = m_{x,i} * w_i (IFM / DIFM; reference basemodel.py:80-91).  The per-field first-order weights come
+        out of ONE fused gather as a [B, n] matrix (the tables seen as 1-dim deep fields; VarLen fields pooled), then the
+        reference's own operations in its own order: cat * m_x, sum over the fields, + dense . weight.  Gradients:
+        autograd hands the gather d logit * m_x per field -- the fused table update takes it from there -- and m_x
+        its d logit * w."""
+        cols = list(self.sparse_feature_columns) + list(self.varlen_sparse_feature_columns)
+        linear_logit = torch.zeros([X.shape[0], 1], device=X.device)
+        if cols:
+            embs = _ops.gather_columns(X, self.embedding_dict, self.feature_index, cols)      # each [B, 1, 1]
+            cat = torch.cat(embs, dim=-1) * refine.unsqueeze(1)
+            linear_logit = linear_logit + torch.sum(cat, dim=-1, keepdim=False)
+        if len(self.dense_feature_columns) > 0:
+            dense = torch.cat([X[:, self.feature_index[fc.name][0]:self.feature_index[fc.name][1]]
+                               for fc in self.dense_feature_columns], dim=-1)
+            linear_logit = linear_logit + dense.matmul(self.weight)
+        return linear_logit
 
 
 class BaseModel(nn.Module):
@@ -502,8 +520,8 @@ class BaseModel(nn.Module):
 
     def _lazy_update_mode(self):
         """("lazy", kind) + the LazyState arguments when the tables can take the EXACT lazy form of the reference's
-        dense regularised / Adam update (csrc/lazy.hip): fixed-length fields over distinct tables, a plain SGD /
-        Adagrad / Adam over all tables, L2-only regularisation of the tables.  None otherwise."""
+        dense regularised / Adam / RMSprop update (csrc/lazy.hip): fixed-length fields over distinct tables, a plain SGD /
+        Adagrad / Adam / RMSprop over all tables, L2-only regularisation of the tables.  None otherwise."""
         opt = getattr(self, "optim", None)
         plan = self._plan
         if opt is None or plan is None or os.environ.get("DCTR_LAZY_UPDATE", "1") == "0" or \
@@ -545,6 +563,17 @@ class BaseModel(nn.Module):
                     all("sum" in opt.state.get(p, {}) for p in tables):
                 return dict(kind="adagrad", lr=g0["lr"], eps=g0["eps"], beta1=0.0, beta2=0.0, l2=l2,
                             s1={p: opt.state[p]["sum"] for p in tables}, s2={})
+        if type(opt) is torch.optim.RMSprop:
+            if same("eps") and same("alpha") and all(g.get("momentum", 0) == 0 and not g.get("centered", False) and
+                                                       not g.get("capturable", False) for g in groups):
+                for p in tables:      # torch creates the state at the first step(); the kernels need it now
+                    st = opt.state[p]
+                    if "square_avg" not in st:
+                        st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                        st["square_avg"] = torch.zeros_like(p.data)
+                # (beta1 carries 1 - alpha, rounded from double like the scalar torch hands its kernels)
+                return dict(kind="rmsprop", lr=g0["lr"], eps=g0["eps"], beta1=1 - g0["alpha"], beta2=g0["alpha"], l2=l2,
+                            s1={p: opt.state[p]["square_avg"] for p in tables}, s2={})
         if type(opt) is torch.optim.Adam:
             if same("eps") and same("betas") and all(not g.get("amsgrad", False) and not g.get("capturable", False) and
                                                        not g.get("fused", False) for g in groups):

@@ -286,6 +286,9 @@ int dctr_interacting_bwd(const float* E, int64_t ld_e, int32_t B, int32_t F, int
 #define DCTR_LAZY_SGD 0
 #define DCTR_LAZY_ADAGRAD 1
 #define DCTR_LAZY_ADAM 2
+#define DCTR_LAZY_RMSPROP 3 /* torch.optim.RMSprop (momentum 0, not centered): s1 = square_avg, beta2 = alpha,  */
+                            /* beta1 = 1 - alpha.  A row no sample refers to still has its square_avg decayed at */
+                            /* every step: replayed like Adam's moments                                          */
 typedef struct dctr_lazy_unit {
   float* deep;    /* [vocab, dim] (rows ld_deep floats apart) or NULL */
   float* deep_s1; /* rows ld_deep_s1 floats apart; deep_s2 / deep_g are contiguous */

@@ -208,6 +208,70 @@ def test_reference_shaped_accessors():
         assert max_abs(seqs[c.name].detach().cpu().numpy(), ref) == 0.0
 
 
+def test_linear_with_sparse_feat_refine_weight():
+    """Linear.forward(X, sparse_feat_refine_weight=m_x) (IFM / DIFM; reference basemodel.py:63-92) against a plain torch
+    restatement of the reference's lines: value, d / d m_x, and the table gradients (SGD step read back)."""
+    g, m = _loaded("deepfm_mixed")
+    lm = m.linear_model
+    X = torch.from_numpy(g["X"]).to(DEV)
+    B = X.shape[0]
+    cols = list(lm.sparse_feature_columns) + list(lm.varlen_sparse_feature_columns)
+    gen = torch.Generator().manual_seed(5)
+    mx = (torch.rand(B, len(cols), generator=gen) + 0.5).to(DEV).requires_grad_(True)
+    gy = torch.randn(B, 1, generator=gen).to(DEV)
+
+    # the reference's operations on plain tensors (fp32, same order)
+    tabs = {k: v.weight.detach().clone().requires_grad_(True) for k, v in lm.embedding_dict.items()}
+    mx_ref = mx.detach().clone().requires_grad_(True)
+    parts = []
+    for fc in lm.sparse_feature_columns:
+        lo, hi = lm.feature_index[fc.name]
+        parts.append(tabs[fc.embedding_name][X[:, lo:hi].long()])                     # [B, 1, 1]
+    for fc in lm.varlen_sparse_feature_columns:
+        lo, hi = lm.feature_index[fc.name]
+        ids = X[:, lo:hi].long()
+        e = tabs[fc.embedding_name][ids]                                               # [B, T, 1]
+        if fc.length_name is None:
+            mask = (ids != 0).float().unsqueeze(-1)
+        else:
+            ln = X[:, lm.feature_index[fc.length_name][0]].long()
+            mask = (torch.arange(ids.shape[1], device=DEV)[None, :] < ln[:, None]).float().unsqueeze(-1)
+        if fc.combiner == "max":
+            parts.append(torch.max(e - (1 - mask) * 1e9, dim=1, keepdim=True)[0])
+        else:
+            sm = torch.sum(e * mask, dim=1, keepdim=False)
+            if fc.combiner == "mean":
+                sm = sm / (mask.sum(dim=1) + 1e-8)
+            parts.append(sm.unsqueeze(1))
+    cat = torch.cat(parts, dim=-1) * mx_ref.unsqueeze(1)
+    ref = torch.sum(cat, dim=-1, keepdim=False)
+    dense = [X[:, lm.feature_index[fc.name][0]:lm.feature_index[fc.name][1]] for fc in lm.dense_feature_columns]
+    w_ref = lm.weight.detach().clone().requires_grad_(True) if dense else None
+    if dense:
+        ref = ref + torch.cat(dense, dim=-1).matmul(w_ref)
+    ref.backward(gy)
+
+    m.compile("sgd", "binary_crossentropy", metrics=[])              # tables on the fused SGD update (lr 0.01)
+    before = {k: v.weight.detach().clone() for k, v in lm.embedding_dict.items()}
+    out = lm(X, sparse_feat_refine_weight=mx)
+    assert tuple(out.shape) == (B, 1)
+    assert max_abs(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= 1e-6
+    out.backward(gy)
+    torch.cuda.synchronize()
+    assert max_abs(mx.grad.cpu().numpy(), mx_ref.grad.cpu().numpy()) <= 1e-6
+    if dense:
+        assert max_abs(lm.weight.grad.cpu().numpy(), w_ref.grad.cpu().numpy()) <= 1e-5
+    lr = m.optim.param_groups[0]["lr"]
+    for k, v in lm.embedding_dict.items():
+        if v.weight.grad is not None:        # (tables outside the fused update: autograd's dense gradient)
+            got = v.weight.grad
+        else:
+            got = (before[k] - v.weight.detach()) / lr
+        gref = tabs[k].grad
+        bar = 2e-5 * max(1.0, float(gref.abs().max())) + 2.0 ** -23 * float(before[k].abs().max()) / lr
+        assert max_abs(got.cpu().numpy(), gref.cpu().numpy()) <= bar, k
+
+
 def test_out_of_range_id_is_reported():
     g, m = _loaded("deepfm_fm_only")
     X = torch.from_numpy(g["X"].copy()).to(DEV)

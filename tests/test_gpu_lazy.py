@@ -129,7 +129,7 @@ def test_default_kwargs_fit_runs_lazy():
     assert pred.shape == (X.shape[0], 1) and np.all((pred > 0) & (pred < 1))
 
 
-@pytest.mark.parametrize("opt", ["adam", "adagrad"])
+@pytest.mark.parametrize("opt", ["adam", "adagrad", "rmsprop"])
 def test_lazy_long_gaps_equal_dense_path(opt, monkeypatch):
     """200 steps of batch 8 over 3000-row vocabularies: most rows wait tens to hundreds of steps between two touches
     (the steady state of a big table).  The replayed trajectories must equal the exact dense path's."""
