@@ -438,6 +438,10 @@ class _Core(object):
         elif o.kind == 1:
             a += g * g
             w -= f(o.lr) * (g / (np.sqrt(a) + f(o.eps)))
+        elif o.kind == 3:                       # RMSprop: beta2 = alpha, beta1 = 1 - alpha
+            a *= f(o.beta2)
+            a += (f(o.beta1) * g) * g
+            w -= f(o.lr) * (g / (np.sqrt(a) + f(o.eps)))
         else:
             w -= f(o.lr) * g
 
@@ -472,7 +476,7 @@ class _Core(object):
                 w = W[rows].copy()
                 a = A[rows].copy() if A is not None else np.zeros_like(w)
                 b = Bv[rows].copy() if Bv is not None else np.zeros_like(w)
-                if o.kind == 2 or lam2 != 0:                    # replay the missed steps prev+1 .. t with g = 2*lambda*w
+                if o.kind in (2, 3) or lam2 != 0:               # replay the missed steps prev+1 .. t with g = 2*lambda*w
                     for T in range(int(prev.min()) + 1, t + 1):
                         m = prev < T
                         ss, bc = self._adam_scalars(o, T) if o.kind == 2 else (0, 1)
