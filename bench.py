@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replays")
     ap.add_argument("--steps-per-graph", type=int, default=0,
                     help="train steps captured per hipGraph (the ~15 us launch gap is paid once per graph); 0 = the "
-                         "largest divisor of --steps in [8, 64], else 16 plus a tail graph")
+                         "largest divisor of --steps in [8, 32], else 16 plus a tail graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the xDeepFM / FiBiNET legs (BASELINE.json configs 3-4) of the N=1 line")
@@ -436,7 +436,9 @@ def other_config(name, args, device, X, y):
 
 
 def auto_steps_per_graph(steps):
-    divs = [d for d in range(8, 65) if steps % d == 0]    # (a replay boundary costs ~25 us: tools/micro/topobench.hip)
+    # (a replay boundary costs ~25 us, but 50 steps per graph measured 2.5 % SLOWER per step than 25: every captured step
+    # has its own activation buffers, 40 MB each)
+    divs = [d for d in range(8, 33) if steps % d == 0]
     return max(divs) if divs else min(16, steps)
 
 
