@@ -39,9 +39,50 @@ __device__ __forceinline__ int row_stride(int F, int D) {
 // copy the [16, F*D] tile of samples b0.. (b0 < B) into LDS (zeros past B).  Eight UNCONDITIONAL loads per thread are
 // in flight at a time (rows past B are clamped to B-1 and masked afterwards): a predicated load compiles to a
 // branch with its own s_waitcnt vmcnt(0), which made this copy 26 serial memory round trips.
+// The same copy in dwordx4 pieces, split in its two halves so that a caller can put the loads of several tiles (and
+// whatever else it needs from memory) in flight TOGETHER and pay one round trip: rows_load4 / rows_store4.  Needs
+// rows_vec_ok(); U * kT float4 must cover the tile (U = 8: F*D <= 512 at 16 rows).  (Round 3: the scalar copy below
+// takes ceil(F*D/128) dependent round trips per array -- 4 + 4 per tile at the Criteo shape, ~12 of the ~15 us
+// k_bilinear_bwd_weight spent per 16-sample tile.)
+__device__ __forceinline__ bool rows_vec_ok(int rows, int RS, const float* src, int64_t ld, int W, int U) {
+  return (W & 3) == 0 && (ld & 3) == 0 && (RS & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
+         rows * (W >> 2) <= U * kT;
+}
+template <int U>
+__device__ __forceinline__ void rows_load4(const float* __restrict__ src, int64_t ld, int b0, int B, int rows, int W,
+                                           f32x4 (&v)[U]) {
+  const int w4 = W >> 2, n4 = rows * w4;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int e = threadIdx.x + u * kT;
+    const int ec = e < n4 ? e : 0;
+    const int r = ec / w4, c = ec - r * w4;
+    const int rr = b0 + r < B ? b0 + r : B - 1;
+    v[u] = *(const DCTR_GLOBAL f32x4*)(src + static_cast<int64_t>(rr) * ld + 4 * c);
+  }
+}
+template <int U>
+__device__ __forceinline__ void rows_store4(float* dst, int RS, int b0, int B, int rows, int W, const f32x4 (&v)[U]) {
+  const int w4 = W >> 2, n4 = rows * w4;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int e = threadIdx.x + u * kT;
+    if (e < n4) {
+      const int r = e / w4, c = e - r * w4;
+      *reinterpret_cast<f32x4*>(dst + r * RS + 4 * c) = (b0 + r < B) ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+}
+
 template <int ROWS = kSB>
 __device__ __forceinline__ void stage_rows(float* dst, int RS, const float* __restrict__ src, int64_t ld, int b0,
                                            int B, int W) {
+  if (rows_vec_ok(ROWS, RS, src, ld, W, 8)) {      // (uniform)
+    f32x4 v[8];
+    rows_load4<8>(src, ld, b0, B, ROWS, W, v);
+    rows_store4<8>(dst, RS, b0, B, ROWS, W, v);
+    return;
+  }
   const int n = ROWS * W;
   for (int e0 = threadIdx.x; e0 < n; e0 += 8 * kT) {
     float v[8];
@@ -604,9 +645,21 @@ __global__ __launch_bounds__(kT) void k_bilinear_bwd_weight(const float* __restr
             gpr[a][ps][r] = ldg_f32(gout + static_cast<int64_t>(b < B ? b : B - 1) * ldg +
                                     (static_cast<int64_t>(ps < npass ? ps : 0) * P + ent[a].k) * D + ccl);
           }
-      __syncthreads();
-      stage_rows(xs0, RS, V ? V : E, V ? ldv : lde, b0, B, W);
-      if (V) stage_rows(xs1, RS, E, lde, b0, B, W);
+      const float* src0 = V ? V : E;
+      const int64_t ld0 = V ? ldv : lde;
+      if (rows_vec_ok(kSB, RS, src0, ld0, W, 8) && (!V || rows_vec_ok(kSB, RS, E, lde, W, 8))) {   // (uniform)
+        // both row tiles leave with the gradients above: ONE memory round trip per tile
+        f32x4 r0[8], r1[8];
+        rows_load4<8>(src0, ld0, b0, B, kSB, W, r0);
+        if (V) rows_load4<8>(E, lde, b0, B, kSB, W, r1);
+        __syncthreads();                    // the previous tile's LDS reads are done
+        rows_store4<8>(xs0, RS, b0, B, kSB, W, r0);
+        if (V) rows_store4<8>(xs1, RS, b0, B, kSB, W, r1);
+      } else {
+        __syncthreads();
+        stage_rows(xs0, RS, src0, ld0, b0, B, W);
+        if (V) stage_rows(xs1, RS, E, lde, b0, B, W);
+      }
       __syncthreads();
       // branch-free: every LDS operand is read unconditionally (clamped column / field 0 for an idle entry) and masked
       // by a select -- `c < D ? xs[..] : 0` compiled to a branch around each ds_read with its own lgkmcnt(0): 128
@@ -655,13 +708,40 @@ __global__ __launch_bounds__(kT) void k_bilinear_reduce_w(const float* __restric
                                                           const int32_t* __restrict__ pair_w, int n_w,
                                                           float* __restrict__ gW) {
   const int64_t idx = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
-  if (idx >= static_cast<int64_t>(n_w) * DD) return;
   const int w = static_cast<int>(idx / DD), el = static_cast<int>(idx - static_cast<int64_t>(w) * DD);
+  const bool valid = idx < static_cast<int64_t>(n_w) * DD;
   float s = 0.f;
-  for (int k = 0; k < P; ++k) {
-    if (ldg_i32(pair_w + k) != w) continue;
-    for (int gq = 0; gq < groups; ++gq) s += ldg_f32(part + (static_cast<int64_t>(gq) * P + k) * DD + el);
+  auto add_pair = [&](int k) {
+    // (8 group partials per round trip, added in group order: the serial `s += load` was one trip per group)
+    for (int g0 = 0; g0 < groups; g0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        v[q] = ldg_f32(part + (static_cast<int64_t>(g0 + q < groups ? g0 + q : groups - 1) * P + k) * DD + el);
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (g0 + q < groups) s += v[q];
+    }
+  };
+  if ((DD & 63) == 0) {
+    // a wave shares its weight index: 64 table entries per load, the matching pairs as a ballot mask walked in ascending
+    // order (one dependent load + branch per pair and thread was 325 serial L2 round trips: 26 of this kernel's 31 us)
+    const int lane = threadIdx.x & 63;
+    const int wq = valid ? w : -2;
+    for (int c0 = 0; c0 < P; c0 += 64) {
+      const int pv = ldg_i32(pair_w + (c0 + lane < P ? c0 + lane : P - 1));
+      unsigned long long m = __ballot(c0 + lane < P && pv == __builtin_amdgcn_readfirstlane(wq));
+      while (m) {
+        const int k = c0 + __builtin_ctzll(m);
+        m &= m - 1;
+        if (valid) add_pair(k);
+      }
+    }
+  } else {
+    for (int k = 0; k < P; ++k)
+      if (valid && ldg_i32(pair_w + k) == w) add_pair(k);
   }
+  if (!valid) return;
   gW[idx] = s;
 }
 
@@ -837,12 +917,15 @@ extern "C" int dctr_bilinear_bwd(const float* E, int64_t ld_e, const float* V, i
   }
   {
     const int tiles = (B + kSB - 1) / kSB;
-    const int groups = bilinear_groups(B);
-    const int tpg = (tiles + groups - 1) / groups;
     const int32_t* sw = (sched_k && n_sched_k > 0) ? sched_k : sched;
     const int nw_s = (sched_k && n_sched_k > 0) ? n_sched_k : n_sched;
     int py = (nw_s + 31) / 32;      // 4 waves x 8 consecutive pairs per workgroup row
     if (py > 16) py = 16;
+    // The kernel holds one workgroup per CU (its registers): keep the launch to ONE round of the 256 CUs -- 32 x 11
+    // workgroups at the Criteo shape were a full round plus a 96-workgroup tail, i.e. 16 tile times for the work of 11
+    int groups = bilinear_groups(B);
+    if (groups * py > 256) groups = 256 / py > 0 ? 256 / py : 1;
+    const int tpg = (tiles + groups - 1) / groups;
     const size_t lds = tile_bytes(F, D, 2);
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bilinear_bwd_weight),
