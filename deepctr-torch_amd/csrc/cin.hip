@@ -421,7 +421,24 @@ __global__ __launch_bounds__(kT, 2) void k_cin_wgrad(const float* __restrict__ g
       const int hq = h0 + q4 + 4 * i;
       hv[i] = ldg_f32(hsrc + static_cast<int64_t>(hq < h ? hq : h - 1) * D);
     }
-    {  // gY^T (masked by the saved activation when relu)
+    if (!relu) {  // gY^T as it is (the caller masked it: dctr_cin_pool_bwd with A): 16 rows per round trip, not 8 + 8
+      constexpr int CH = 16;
+      const float* ga = gA + b * lda + d;
+#pragma unroll 1
+      for (int i0 = 0; i0 < OB / 4; i0 += CH) {
+        float g[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int o = q4 + 4 * (i0 + i);
+          g[i] = ldg_f32(ga + static_cast<int64_t>(o < O ? o : O - 1) * D);
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int o = q4 + 4 * (i0 + i);
+          if (i0 + i < OB / 4) gys[cl * kWgP + o] = (cvalid && o < O) ? g[i] : 0.f;
+        }
+      }
+    } else {  // gY^T (masked by the saved activation when relu)
       constexpr int CH = 8;   // 16 loads in flight per thread; 16 rows would spill at OT = 4
       const float* ga = gA + b * lda + d;
       const float* as = relu ? Asv + b * lda + d : ga;
@@ -574,7 +591,8 @@ __global__ __launch_bounds__(256) void k_cin_pool_fwd(const float* __restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_cin_pool_bwd(const float* __restrict__ g_hidden,
-                                                      const float* __restrict__ g_pooled, int64_t n, int O, int D,
+                                                      const float* __restrict__ g_pooled,
+                                                      const float* __restrict__ Asv, int64_t n, int O, int D,
                                                       int n_hidden, float* __restrict__ gA) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;   // one element of gA [B, O, D]
   if (i >= n) return;
@@ -588,7 +606,30 @@ __global__ __launch_bounds__(256) void k_cin_pool_bwd(const float* __restrict__ 
   } else if (g_pooled) {
     v = ldg_f32(g_pooled + b * (O - n_hidden) + (o - n_hidden));
   }
+  if (Asv && !(ldg_f32(Asv + i) > 0.f)) v = 0.f;
   stg_f32(gA + i, v);
+}
+// the same, four elements of a row per thread (D % 4 == 0, 16-byte aligned operands)
+__global__ __launch_bounds__(256) void k_cin_pool_bwd4(const float* __restrict__ g_hidden,
+                                                       const float* __restrict__ g_pooled,
+                                                       const float* __restrict__ Asv, int64_t n4, int O, int D4,
+                                                       int n_hidden, float* __restrict__ gA) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;   // one float4 of gA [B, O, D]
+  if (i >= n4) return;
+  const int64_t row = i / D4;
+  const int d4 = static_cast<int>(i - row * D4);
+  const int64_t b = row / O;
+  const int o = static_cast<int>(row - b * O);
+  // (unconditional loads on valid addresses, selected afterwards)
+  const f32x4 gh = g_hidden ? *(const DCTR_GLOBAL f32x4*)(g_hidden + ((b * n_hidden + (o < n_hidden ? o : 0)) * D4 + d4) * 4)
+                            : f32x4{0.f, 0.f, 0.f, 0.f};
+  const float gp = g_pooled ? ldg_f32(g_pooled + b * (O - n_hidden) + (o >= n_hidden ? o - n_hidden : 0)) : 0.f;
+  f32x4 v = o < n_hidden ? gh : f32x4{gp, gp, gp, gp};
+  if (Asv) {
+    const f32x4 a = *(const DCTR_GLOBAL f32x4*)(Asv + i * 4);
+    v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+  }
+  *(DCTR_GLOBAL f32x4*)(gA + i * 4) = v;
 }
 }  // namespace
 
@@ -602,13 +643,22 @@ extern "C" int dctr_cin_pool_fwd(const float* A, int32_t B, int32_t O, int32_t D
   return launch_status();
 }
 
-extern "C" int dctr_cin_pool_bwd(const float* g_hidden, const float* g_pooled, int32_t B, int32_t O, int32_t D,
-                                 int32_t n_hidden, float* gA, dctr_stream_t stream) {
+extern "C" int dctr_cin_pool_bwd(const float* g_hidden, const float* g_pooled, const float* A_relu, int32_t B,
+                                 int32_t O, int32_t D, int32_t n_hidden, float* gA, dctr_stream_t stream) {
   if (!gA || B < 0 || O <= 0 || D <= 0 || n_hidden < 0 || n_hidden > O) return DCTR_EINVAL;
   const int64_t n = static_cast<int64_t>(B) * O * D;
   if (n == 0) return DCTR_OK;
-  k_cin_pool_bwd<<<dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(
-      g_hidden, g_pooled, n, O, D, n_hidden, gA);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  // (g_hidden needs its row 0 readable when n_hidden == 0: only passed then as NULL)
+  if ((D & 3) == 0 && al16(gA) && al16(g_hidden) && al16(A_relu) && (n_hidden > 0 || !g_hidden)) {
+    const int64_t n4 = n / 4;
+    k_cin_pool_bwd4<<<dim3(static_cast<unsigned>((n4 + 255) / 256)), dim3(256), 0, s>>>(
+        n_hidden > 0 ? g_hidden : nullptr, n_hidden < O ? g_pooled : nullptr, A_relu, n4, O, D / 4, n_hidden, gA);
+  } else {
+    k_cin_pool_bwd<<<dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s>>>(g_hidden, g_pooled, A_relu, n,
+                                                                                     O, D, n_hidden, gA);
+  }
   return launch_status();
 }
 

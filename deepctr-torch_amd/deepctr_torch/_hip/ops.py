@@ -571,12 +571,15 @@ class CINLayerPooledFunction(torch.autograd.Function):
         M, O = X0.shape[1], W2d.shape[0]
         dev = H.device
         nh = ctx.n_hidden
+        relu_in_layer = int(ctx.relu)
         if ctx.split:
             gA = torch.empty((B, O, D), dtype=torch.float32, device=dev)
             gh = g_hidden.contiguous() if (nh > 0 and g_hidden is not None) else None
             gp = g_pooled.contiguous() if g_pooled is not None else None
-            L.check(lib.dctr_cin_pool_bwd(_ptr(gh), _ptr(gp), B, O, D, nh, _ptr(gA), L.stream_handle(dev)),
-                    "dctr_cin_pool_bwd")
+            # (the relu's backward is applied while gA is assembled: the layer kernels then need no mask loads)
+            L.check(lib.dctr_cin_pool_bwd(_ptr(gh), _ptr(gp), _ptr(A) if ctx.relu else None, B, O, D, nh, _ptr(gA),
+                                          L.stream_handle(dev)), "dctr_cin_pool_bwd")
+            relu_in_layer = 0
         else:           # every row is both hidden state and direct connect
             if g_hidden is not None and g_pooled is not None:
                 gA = g_hidden + g_pooled.unsqueeze(2)
@@ -590,7 +593,7 @@ class CINLayerPooledFunction(torch.autograd.Function):
         gW = torch.empty((O, h * M), dtype=torch.float32, device=dev)
         gb = torch.empty((O,), dtype=torch.float32, device=dev) if ctx.has_bias else None
         ws = torch.empty((max(1, lib.dctr_cin_bwd_workspace_floats(B, h, M, D, O)),), dtype=torch.float32, device=dev)
-        L.check(lib.dctr_cin_layer_bwd(_ptr(gA), _ptr(A), O * D, int(ctx.relu), _ptr(H), ldh, _ptr(X0), ldx, _ptr(W2d),
+        L.check(lib.dctr_cin_layer_bwd(_ptr(gA), _ptr(A), O * D, relu_in_layer, _ptr(H), ldh, _ptr(X0), ldx, _ptr(W2d),
                                        B, h, M, D, O, _ptr(gH), h * D, _ptr(gX0), M * D, 0, _ptr(gW), _ptr(gb),
                                        _ptr(ws), L.stream_handle(dev)), "dctr_cin_layer_bwd")
         return gH, gX0, gW, gb, None, None, None

@@ -259,7 +259,7 @@ class OpsMixin(object):
         _t(pooled, B, O - n_hidden).copy_(a[:, n_hidden:].double().sum(-1).float())
         return 0
 
-    def dctr_cin_pool_bwd(self, g_hidden, g_pooled, B, O, D, n_hidden, gA, stream):
+    def dctr_cin_pool_bwd(self, g_hidden, g_pooled, A_relu, B, O, D, n_hidden, gA, stream):
         self.calls.append("cin_pool_bwd")
         g = _t(gA, B, O * D).reshape(B, O, D)
         gh = _t(g_hidden, B, n_hidden * D) if n_hidden else None
@@ -267,6 +267,9 @@ class OpsMixin(object):
         if n_hidden:
             g[:, :n_hidden] = gh.reshape(B, n_hidden, D) if gh is not None else 0.0
         g[:, n_hidden:] = gp[:, :, None] if gp is not None else 0.0
+        a = _t(A_relu, B, O * D)
+        if a is not None:
+            g *= (a.reshape(B, O, D) > 0).to(g.dtype)
         return 0
 
     # ---- CrossNet (vector) --------------------------------------------------------------------------------------------

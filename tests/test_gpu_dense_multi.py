@@ -87,7 +87,7 @@ def test_cin_pool_kernels_match_split_sum(B, O, D, nh):
     gp = torch.randn(B, O - nh, generator=g).to(DEV) if nh < O else None
     gA = torch.full((B, O, D), float("nan"), device=DEV)
     L.check(lib.dctr_cin_pool_bwd(ctypes.c_void_p(gh.data_ptr()) if gh is not None else None,
-                                  ctypes.c_void_p(gp.data_ptr()) if gp is not None else None, B, O, D, nh,
+                                  ctypes.c_void_p(gp.data_ptr()) if gp is not None else None, None, B, O, D, nh,
                                   ctypes.c_void_p(gA.data_ptr()), L.stream_handle(DEV)))
     want = torch.zeros(B, O, D, device=DEV)
     if nh > 0:
@@ -95,7 +95,14 @@ def test_cin_pool_kernels_match_split_sum(B, O, D, nh):
     if nh < O:
         want[:, nh:] = gp[:, :, None]
     assert torch.equal(gA, want)
+    # with the layer's saved relu output: the relu's backward applied on the way (exact zeros, nothing else touched)
+    gA.fill_(float("nan"))
+    L.check(lib.dctr_cin_pool_bwd(ctypes.c_void_p(gh.data_ptr()) if gh is not None else None,
+                                  ctypes.c_void_p(gp.data_ptr()) if gp is not None else None,
+                                  ctypes.c_void_p(A.data_ptr()), B, O, D, nh, ctypes.c_void_p(gA.data_ptr()),
+                                  L.stream_handle(DEV)))
+    assert torch.equal(gA, torch.where(A > 0, want, torch.zeros_like(want)))
     # NULL inputs mean zero
     gA.fill_(float("nan"))
-    L.check(lib.dctr_cin_pool_bwd(None, None, B, O, D, nh, ctypes.c_void_p(gA.data_ptr()), L.stream_handle(DEV)))
+    L.check(lib.dctr_cin_pool_bwd(None, None, None, B, O, D, nh, ctypes.c_void_p(gA.data_ptr()), L.stream_handle(DEV)))
     assert torch.equal(gA, torch.zeros_like(gA))

@@ -3,7 +3,8 @@ export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r3_cin
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_cin.py -x -q 2>&1 | tail -3 > $O/pytest.txt
+timeout 900 python -m pytest tests/test_gpu_cin.py tests/test_gpu_dense_multi.py tests/test_gpu_models.py -x -q -k "cin or xdeepfm or pool" 2>&1 | tail -3 > $O/pytest.txt
+timeout 600 python -m pytest tests/test_gpu_full_golden.py -x -q -k xdeepfm 2>&1 | tail -3 >> $O/pytest.txt
 cd /tmp
 for m in xDeepFM; do
 rm -rf /tmp/p_$m
