@@ -589,11 +589,15 @@ class ShardedTrainer(object):
         self._announced = None          # identity of the batch whose ids already sit in _ids_view
         self._ids_t = None
         g = bool(self.use_graphs) and xb.is_cuda and self.slab is not None    # (the autograd route runs eagerly)
-        # Only the multi-kernel segment is worth a graph: a hipGraph launch leaves the GPU idle for ~12 us before its
-        # first kernel, a plain launch ~2 us, and the host has slack (it is not the bottleneck of this step).
-        self._segB = _Segment(lambda: self.ops.gather(self._ids_view), False)
+        # Only the multi-kernel segment is a graph by default: a hipGraph launch leaves the GPU idle for ~12 us before its
+        # first kernel, a plain launch ~2 us.  DCTR_SHARDED_GRAPH_ALL=1 captures the single-kernel segments too: their host
+        # cost drops from 51 + 49 us to 9 + 7 us (round 3, profiles/r03_shard_host_profile_1rank.txt), and the step time
+        # does not move (0.2305 vs 0.2315 ms): the host then waits that much longer inside the collectives -- the step
+        # is paced by the GPU-side chain of kernels, collectives and stream hand-offs, not by the host.
+        gs = g and os.environ.get("DCTR_SHARDED_GRAPH_ALL", "0") == "1"
+        self._segB = _Segment(lambda: self.ops.gather(self._ids_view), gs)
         self._segC = _Segment(self._compute if self.slab is not None else self._compute_autograd, g)
-        self._segD = _Segment(lambda: self.ops.update(self._grads_all, self._ids_t), False)
+        self._segD = _Segment(lambda: self.ops.update(self._grads_all, self._ids_t), gs)
         self._segE = _Segment((lambda: self.slab.step(*self.state["mode"])) if self.slab is not None
                               else self._dense_step_autograd, False)
 
