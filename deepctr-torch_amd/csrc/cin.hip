@@ -14,6 +14,8 @@
 // tiles x OT row tiles of 32x32 (8 independent accumulators at O=128 -> the matrix pipe issues back to back).
 // Loop over h: the 13 KB weight slice Wt[h] (prepared as [h][M_pad][O_pad] so rows are contiguous) is double
 // buffered in LDS, fetched for h+1 while h computes; one barrier per h.  B=4096 -> 256 workgroups = one per CU.
+#include <cstdlib>
+
 #include "common.hpp"
 
 using namespace dctr;
@@ -42,33 +44,39 @@ __global__ __launch_bounds__(kT) void k_cin_prep_w(const float* __restrict__ W, 
   Wt[idx] = (o < O && mm < M) ? W[static_cast<int64_t>(o) * h * M + hh * M + mm] : 0.f;
 }
 
-template <int OT>
-__global__ __launch_bounds__(kT, 1) void k_cin_fwd(const float* __restrict__ X0, int64_t ldx0,
+// CT column tiles per wave: 2 = four waves per workgroup (one per SIMD, 8 * OT / 2 ... accumulators each), 1 = EIGHT waves
+// (two per SIMD, half the accumulators): the second wave on a SIMD issues its MFMAs while the first waits for its LDS
+// operands at the top of a k-step or at the per-h barrier (round 3: at CT = 2 and OT = 4 the kernel holds 276 registers,
+// i.e. one wave per SIMD, and the matrix pipe idles through every such wait: 70 % of its rate).
+template <int OT, int CT>
+__global__ __launch_bounds__(kT * 2 / CT, 1) void k_cin_fwd(const float* __restrict__ X0, int64_t ldx0,
                                                    const float* __restrict__ H, int64_t ldh, int h, int M,
                                                    int M_pad, int D, int B, const float* __restrict__ Wt,
                                                    int O_pad, int O, const float* __restrict__ bias, int relu,
                                                    float* __restrict__ A, int64_t lda) {
   constexpr int OB = OT * 32;
+  constexpr int NT = kT * 2 / CT;       // threads per workgroup
+  constexpr int WQ = (OT * kT + NT - 1) / NT;   // float4 of a weight slice per thread
   extern __shared__ __align__(16) float smem[];
   float* x0s = smem;                    // [M_pad][256]
   float* ws = x0s + M_pad * kCols;      // [2][M_pad][OB]
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, p = lane >> 5, jl = lane & 31;
   const int64_t c_base = static_cast<int64_t>(blockIdx.x) * kCols;
-  const int o_base = blockIdx.y * 128;
+  const int o_base = blockIdx.y * OB;      // (every y-chunk of a launch has this launch's OT row tiles)
   const int64_t ncol = static_cast<int64_t>(B) * D;
   const int chunk = M_pad * OB;
 
-  int64_t hoff[2];
-  bool cv[2];
+  int64_t hoff[CT];
+  bool cv[CT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int64_t c = c_base + wv * 64 + t * 32 + jl;
+  for (int t = 0; t < CT; ++t) {
+    const int64_t c = c_base + wv * (32 * CT) + t * 32 + jl;
     cv[t] = c < ncol;
     const int64_t b = cv[t] ? c / D : 0;
     const int d = cv[t] ? static_cast<int>(c - b * D) : 0;
     hoff[t] = b * ldh + d;
   }
-  {  // stage X0[b, :, d] of this thread's column
+  if (tid < kCols) {  // stage X0[b, :, d] of this thread's column
     const int64_t c = c_base + tid;
     const bool v = c < ncol;
     const int64_t b = v ? c / D : 0;
@@ -87,12 +95,12 @@ __global__ __launch_bounds__(kT, 1) void k_cin_fwd(const float* __restrict__ X0,
     }
   }
   // weight slice of h = 0
-  f32x4 wreg[OT];
+  f32x4 wreg[WQ];
   auto fetch_w = [&](int hh) {
     const float* src = Wt + static_cast<int64_t>(hh) * M_pad * O_pad + o_base;
 #pragma unroll
-    for (int q = 0; q < OT; ++q) {
-      const int e = q * kT + tid;  // float4 index inside the slice
+    for (int q = 0; q < WQ; ++q) {
+      const int e = q * NT + tid;  // float4 index inside the slice
       const int row = e / (OB / 4), c4 = e - row * (OB / 4);
       wreg[q] = (row < M_pad) ? *(const DCTR_GLOBAL f32x4*)(src + static_cast<int64_t>(row) * O_pad + c4 * 4)
                               : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -101,8 +109,8 @@ __global__ __launch_bounds__(kT, 1) void k_cin_fwd(const float* __restrict__ X0,
   auto park_w = [&](int buf) {
     float* dst = ws + buf * chunk;
 #pragma unroll
-    for (int q = 0; q < OT; ++q) {
-      const int e = q * kT + tid;
+    for (int q = 0; q < WQ; ++q) {
+      const int e = q * NT + tid;
       const int row = e / (OB / 4);
       if (row < M_pad) *reinterpret_cast<f32x4*>(dst + e * 4) = wreg[q];
     }
@@ -110,46 +118,48 @@ __global__ __launch_bounds__(kT, 1) void k_cin_fwd(const float* __restrict__ X0,
   fetch_w(0);
   park_w(0);
   // (columns past the end sit on b = 0, d = 0: their loads are valid, their results are never stored)
-  float hv[2], hnext[2];
+  float hv[CT], hnext[CT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) hv[t] = ldg_f32(H + hoff[t]);
+  for (int t = 0; t < CT; ++t) hv[t] = ldg_f32(H + hoff[t]);
   // hv must have ARRIVED before the loop: if its first use sits inside the loop, the s_waitcnt vmcnt(0) for it is
   // placed there and then also waits, in every iteration, for the prefetch of the next weight slice
-  asm volatile("" : "+v"(hv[0]), "+v"(hv[1]));
+#pragma unroll
+  for (int t = 0; t < CT; ++t) asm volatile("" : "+v"(hv[t]));
   __syncthreads();
 
-  f32x16 acc[OT][2];
+  f32x16 acc[OT][CT];
 #pragma unroll
   for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < CT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ot][t][r] = 0.f;
 
-  const int xoff = wv * 64 + jl;
+  const int xoff = wv * (32 * CT) + jl;
   for (int hh = 0; hh < h; ++hh) {
     const bool more = hh + 1 < h;
     if (more) {
       fetch_w(hh + 1);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) hnext[t] = ldg_f32(H + hoff[t] + static_cast<int64_t>(hh + 1) * D);
+      for (int t = 0; t < CT; ++t) hnext[t] = ldg_f32(H + hoff[t] + static_cast<int64_t>(hh + 1) * D);
     }
     const float* wc = ws + (hh & 1) * chunk;
     for (int s = 0; s < M_pad / 2; ++s) {
       const int mm = 2 * s + p;
-      const float z0 = hv[0] * x0s[mm * kCols + xoff];
-      const float z1 = hv[1] * x0s[mm * kCols + xoff + 32];
+      float z[CT];
+#pragma unroll
+      for (int t = 0; t < CT; ++t) z[t] = hv[t] * x0s[mm * kCols + xoff + 32 * t];
 #pragma unroll
       for (int ot = 0; ot < OT; ++ot) {
         const float a = wc[mm * OB + ot * 32 + jl];
-        acc[ot][0] = mfma32(a, z0, acc[ot][0]);
-        acc[ot][1] = mfma32(a, z1, acc[ot][1]);
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[ot][t] = mfma32(a, z[t], acc[ot][t]);
       }
     }
     if (more) {
       park_w((hh + 1) & 1);
-      hv[0] = hnext[0];
-      hv[1] = hnext[1];
+#pragma unroll
+      for (int t = 0; t < CT; ++t) hv[t] = hnext[t];
     }
     __syncthreads();
   }
@@ -158,11 +168,11 @@ __global__ __launch_bounds__(kT, 1) void k_cin_fwd(const float* __restrict__ X0,
   // every read of x0s): 64 dependent scalar loads in this epilogue would be 64 serial round trips.
   if (tid < OB) x0s[tid] = (bias && o_base + tid < O) ? ldg_f32(bias + o_base + tid) : 0.f;
   __syncthreads();
-  int64_t bcol[2];
-  int dcol[2];
+  int64_t bcol[CT];
+  int dcol[CT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int64_t c = c_base + wv * 64 + t * 32 + jl;
+  for (int t = 0; t < CT; ++t) {
+    const int64_t c = c_base + wv * (32 * CT) + t * 32 + jl;
     bcol[t] = cv[t] ? c / D : 0;
     dcol[t] = cv[t] ? static_cast<int>(c - bcol[t] * D) : 0;
   }
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(kT, 1) void k_cin_fwd(const float* __restrict__ X0,
       if (o < O) {
         const float bo = x0s[ot * 32 + acc_row(r, p)];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < CT; ++t) {
           if (cv[t]) {
             float y = acc[ot][t][r] + bo;
             if (relu) y = y > 0.f ? y : 0.f;
@@ -194,14 +204,17 @@ __global__ __launch_bounds__(kT, 1) void k_cin_fwd(const float* __restrict__ X0,
 // (B operand, reused by every h) live in registers for the whole kernel; the weight slice W[:, h*M .. h*M+M) is
 // double buffered in LDS as [o][32].  The product-rule tails are per-lane FMAs on the accumulator registers.
 // -------------------------------------------------------------------------------------------------------------
-template <int OT>
-__global__ __launch_bounds__(kT, 1) void k_cin_bwd_data(const float* __restrict__ gA, const float* __restrict__ Asv,
+// CT: column tiles per wave (see k_cin_fwd): 2 = four waves, 1 = eight waves of half the registers (at CT = 2, OT = 4 the
+// lane's gY values alone are 128 registers and the kernel holds 356: one wave per SIMD)
+template <int OT, int CT>
+__global__ __launch_bounds__(kT * 2 / CT, 1) void k_cin_bwd_data(const float* __restrict__ gA, const float* __restrict__ Asv,
                                                         int64_t lda, int relu, const float* __restrict__ X0,
                                                         int64_t ldx0, const float* __restrict__ H, int64_t ldh,
                                                         int h, int M, int D, int B, const float* __restrict__ W,
                                                         int O, float* __restrict__ gH, int64_t ldgh, int acc_h,
                                                         float* __restrict__ gX0, int64_t ldgx, int acc_x) {
-  constexpr int OB = OT * 32, NS = OT * 16, NW = OT * 4;  // NW dwords of the weight slice per thread
+  constexpr int NT = kT * 2 / CT;                          // threads per workgroup
+  constexpr int OB = OT * 32, NS = OT * 16, NW = OT * 32 * 32 / NT;  // NW dwords of the weight slice per thread
   extern __shared__ __align__(16) float smem[];
   float* wl = smem;  // [2][OB][32]
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, p = lane >> 5, jl = lane & 31;
@@ -209,22 +222,22 @@ __global__ __launch_bounds__(kT, 1) void k_cin_bwd_data(const float* __restrict_
   const int64_t ncol = static_cast<int64_t>(B) * D;
   const int K = h * M;
 
-  int64_t bb[2];
-  int dd[2];
-  bool cv[2];
+  int64_t bb[CT];
+  int dd[CT];
+  bool cv[CT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int64_t c = c_base + wv * 64 + t * 32 + jl;
+  for (int t = 0; t < CT; ++t) {
+    const int64_t c = c_base + wv * (32 * CT) + t * 32 + jl;
     cv[t] = c < ncol;
     bb[t] = cv[t] ? c / D : 0;
     dd[t] = cv[t] ? static_cast<int>(c - bb[t] * D) : 0;
   }
   // gY of this lane's columns: o = 2*s + p.  Unconditional loads on clamped addresses, masked afterwards (a
   // predicated load is a branch with its own s_waitcnt vmcnt(0): 128 serial round trips in this prologue otherwise).
-  float gy[2][NS];
+  float gy[CT][NS];
   const float* mask_src = relu ? Asv : gA;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < CT; ++t) {
     const int64_t base = bb[t] * lda + dd[t];
 #pragma unroll
     for (int s0 = 0; s0 < NS; s0 += 16) {
@@ -252,9 +265,9 @@ __global__ __launch_bounds__(kT, 1) void k_cin_bwd_data(const float* __restrict_
     }
   }
   // X0 rows matching this lane's accumulator rows
-  float x0r[2][16], gxa[2][16];
+  float x0r[CT][16], gxa[CT][16];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < CT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int mm = acc_row(r, p);
@@ -267,7 +280,7 @@ __global__ __launch_bounds__(kT, 1) void k_cin_bwd_data(const float* __restrict_
   auto fetch_w = [&](int hh) {
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
-      const int e = q * kT + tid;  // = o_local * 32 + m
+      const int e = q * NT + tid;  // = o_local * 32 + m
       const int ol = e >> 5, mm = e & 31;
       wreg[q] = (ol < O && mm < M) ? ldg_f32(W + static_cast<int64_t>(ol) * K + hh * M + mm) : 0.f;
     }
@@ -275,14 +288,15 @@ __global__ __launch_bounds__(kT, 1) void k_cin_bwd_data(const float* __restrict_
   auto park_w = [&](int buf) {
     float* dst = wl + buf * (OB * 32);
 #pragma unroll
-    for (int q = 0; q < NW; ++q) dst[q * kT + tid] = wreg[q];
+    for (int q = 0; q < NW; ++q) dst[q * NT + tid] = wreg[q];
   };
   fetch_w(0);
   park_w(0);
-  float hv[2], hnext[2];
+  float hv[CT], hnext[CT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) hv[t] = ldg_f32(H + bb[t] * ldh + dd[t]);
-  asm volatile("" : "+v"(hv[0]), "+v"(hv[1]));   // arrived before the loop (see k_cin_fwd)
+  for (int t = 0; t < CT; ++t) hv[t] = ldg_f32(H + bb[t] * ldh + dd[t]);
+#pragma unroll
+  for (int t = 0; t < CT; ++t) asm volatile("" : "+v"(hv[t]));   // arrived before the loop (see k_cin_fwd)
   __syncthreads();
 
   for (int hh = 0; hh < h; ++hh) {
@@ -290,22 +304,22 @@ __global__ __launch_bounds__(kT, 1) void k_cin_bwd_data(const float* __restrict_
     if (more) {
       fetch_w(hh + 1);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) hnext[t] = ldg_f32(H + bb[t] * ldh + static_cast<int64_t>(hh + 1) * D + dd[t]);
+      for (int t = 0; t < CT; ++t) hnext[t] = ldg_f32(H + bb[t] * ldh + static_cast<int64_t>(hh + 1) * D + dd[t]);
     }
     const float* wc = wl + (hh & 1) * (OB * 32);
-    f32x16 acc[2];
+    f32x16 acc[CT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < CT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const float a = wc[(2 * s + p) * 32 + jl];
-      acc[0] = mfma32(a, gy[0][s], acc[0]);
-      acc[1] = mfma32(a, gy[1][s], acc[1]);
+#pragma unroll
+      for (int t = 0; t < CT; ++t) acc[t] = mfma32(a, gy[t][s], acc[t]);
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < CT; ++t) {
       float part = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -320,13 +334,13 @@ __global__ __launch_bounds__(kT, 1) void k_cin_bwd_data(const float* __restrict_
     }
     if (more) {
       park_w((hh + 1) & 1);
-      hv[0] = hnext[0];
-      hv[1] = hnext[1];
+#pragma unroll
+      for (int t = 0; t < CT; ++t) hv[t] = hnext[t];
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < CT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int mm = acc_row(r, p);
@@ -690,25 +704,39 @@ extern "C" int dctr_cin_layer_fwd(const float* H, int64_t ld_h, const float* X0,
   k_cin_prep_w<<<dim3(static_cast<unsigned>((total + kT - 1) / kT)), dim3(kT), 0, s>>>(W, O, h, M, M_pad, O_pad,
                                                                                        workspace);
   const int64_t ncol = static_cast<int64_t>(B) * D;
-  const int ychunks = (O_pad + 127) / 128;
+  // outputs per workgroup: 128 (4 row tiles), or 64 -- two workgroups per CU then share the columns' work: twice the
+  // waves per SIMD to hide the per-h barrier and the LDS waits (DCTR_CIN_FWD_CHUNK=64|128; A/B switch)
+  static const int chunk_o = (getenv("DCTR_CIN_FWD_CHUNK") && atoi(getenv("DCTR_CIN_FWD_CHUNK")) == 64) ? 64 : 128;
+  const int ychunks = (O_pad + chunk_o - 1) / chunk_o;
   const dim3 grid(static_cast<unsigned>((ncol + kCols - 1) / kCols), ychunks);
-  // every y-chunk but the last has 4 row tiles; launch the last one separately if it is narrower
-  const int ot_last = (O_pad - (ychunks - 1) * 128) / 32;
+  // every y-chunk but the last has chunk_o / 32 row tiles; launch the last one separately if it is narrower
+  const int ot_last = (O_pad - (ychunks - 1) * chunk_o) / 32;
+  static const bool two_waves = !(getenv("DCTR_CIN_FWD_CT") && getenv("DCTR_CIN_FWD_CT")[0] == '2');   // (A/B switch)
   auto launch = [&](int ot, dim3 g, int ybase) {
     const size_t lds = (static_cast<size_t>(M_pad) * kCols + 2u * M_pad * ot * 32) * sizeof(float);
-    const float* wt = workspace + ybase * 128;
-    const float* bs = bias ? bias + ybase * 128 : nullptr;
-    float* a = A + static_cast<int64_t>(ybase) * 128 * D;
-    const int o_here = O - ybase * 128;
+    const float* wt = workspace + ybase * chunk_o;
+    const float* bs = bias ? bias + ybase * chunk_o : nullptr;
+    float* a = A + static_cast<int64_t>(ybase) * chunk_o * D;
+    const int o_here = O - ybase * chunk_o;
+#define DCTR_CIN_FWD(OT_, CT_)                                                                                       \
+  k_cin_fwd<OT_, CT_><<<g, dim3(kT * 2 / CT_), lds, s>>>(X0, ld_x0, H, ld_h, h, M, M_pad, D, B, wt, O_pad, o_here, bs, \
+                                                         relu, a, ld_a)
+    // wide output tiles (3-4 row tiles = 96-128 accumulator registers per column tile): one column tile per wave, eight
+    // waves; narrow ones: two column tiles per wave, four waves
     switch (ot) {
-      case 1: k_cin_fwd<1><<<g, dim3(kT), lds, s>>>(X0, ld_x0, H, ld_h, h, M, M_pad, D, B, wt, O_pad, o_here, bs, relu, a, ld_a); break;
-      case 2: k_cin_fwd<2><<<g, dim3(kT), lds, s>>>(X0, ld_x0, H, ld_h, h, M, M_pad, D, B, wt, O_pad, o_here, bs, relu, a, ld_a); break;
-      case 3: k_cin_fwd<3><<<g, dim3(kT), lds, s>>>(X0, ld_x0, H, ld_h, h, M, M_pad, D, B, wt, O_pad, o_here, bs, relu, a, ld_a); break;
-      default: k_cin_fwd<4><<<g, dim3(kT), lds, s>>>(X0, ld_x0, H, ld_h, h, M, M_pad, D, B, wt, O_pad, o_here, bs, relu, a, ld_a); break;
+      case 1: DCTR_CIN_FWD(1, 2); break;
+      case 2: if (two_waves && chunk_o == 64) DCTR_CIN_FWD(2, 1); else DCTR_CIN_FWD(2, 2); break;
+      case 3: if (two_waves) DCTR_CIN_FWD(3, 1); else DCTR_CIN_FWD(3, 2); break;
+      default: if (two_waves) DCTR_CIN_FWD(4, 1); else DCTR_CIN_FWD(4, 2); break;
     }
+#undef DCTR_CIN_FWD
   };
-  if (ychunks > 1) launch(4, dim3(grid.x, ychunks - 1), 0);
-  launch(ot_last, dim3(grid.x, 1), ychunks - 1);
+  if (ot_last == chunk_o / 32) {
+    launch(ot_last, dim3(grid.x, ychunks), 0);            // every chunk has the same width: one launch
+  } else {
+    if (ychunks > 1) launch(chunk_o / 32, dim3(grid.x, ychunks - 1), 0);
+    launch(ot_last, dim3(grid.x, 1), ychunks - 1);
+  }
   return launch_status();
 }
 
@@ -749,9 +777,16 @@ extern "C" int dctr_cin_layer_bwd(const float* gA, const float* A, int64_t ld_a,
       const dim3 grid(static_cast<unsigned>((ncol + kCols - 1) / kCols));
       const size_t lds = 2u * ot * 32 * 32 * sizeof(float);
       const int acc_h = ch > 0, acc_x = (ch > 0) || accumulate_x0;
-#define DCTR_CIN_BD(OT_) k_cin_bwd_data<OT_><<<grid, dim3(kT), lds, s>>>(gA_c, A_c, ld_a, relu, X0, ld_x0, H, ld_h, h, M, \
-                                                                       D, B, W_c, o_here, gH, ld_gh, acc_h, gX0, ld_gx, acc_x)
-      switch (ot) { case 1: DCTR_CIN_BD(1); break; case 2: DCTR_CIN_BD(2); break; case 3: DCTR_CIN_BD(3); break; default: DCTR_CIN_BD(4); break; }
+#define DCTR_CIN_BD(OT_, CT_)                                                                                  \
+  k_cin_bwd_data<OT_, CT_><<<grid, dim3(kT * 2 / CT_), lds, s>>>(gA_c, A_c, ld_a, relu, X0, ld_x0, H, ld_h, h, M, D, B, \
+                                                                W_c, o_here, gH, ld_gh, acc_h, gX0, ld_gx, acc_x)
+      static const bool bd_two_waves = !(getenv("DCTR_CIN_BWD_CT") && getenv("DCTR_CIN_BWD_CT")[0] == '2');   // (A/B switch)
+      switch (ot) {
+        case 1: DCTR_CIN_BD(1, 2); break;
+        case 2: DCTR_CIN_BD(2, 2); break;
+        case 3: if (bd_two_waves) DCTR_CIN_BD(3, 1); else DCTR_CIN_BD(3, 2); break;
+        default: if (bd_two_waves) DCTR_CIN_BD(4, 1); else DCTR_CIN_BD(4, 2); break;
+      }
 #undef DCTR_CIN_BD
     }
     // weight side: Q partial [o_here, K] tile sets (+ bias partials) in the workspace, then a fixed-order sum
