@@ -37,6 +37,14 @@ constexpr int kKC = 512;       // columns of the tower input staged in LDS at a 
 constexpr int kNTMax = 4;      // output tiles a wave carries at once (forward)
 constexpr int kTW = 256;       // threads per workgroup (wgrad)
 constexpr int kMaxL = DCTR_MLP_MAX_LAYERS;
+// Padding floats behind every LDS tile row (row strides are a multiple of 16 plus this).  The A operand of
+// v_mfma_f32_16x16x4 is read as one ds_read_b128 per lane -- lane (g = lane / 16, c = lane % 16) takes the 16 bytes at
+// row c, column 4 g of the K block -- and that instruction is served in four FIXED 16-lane groups
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: MI355X_MICROARCH.md, LDS) over 16 slots of 16 bytes.  With a row pitch of
+// s slots the lane's slot is (c s + g) mod 16: for odd s (the +4 padding of rounds 1-3: s = 13 and 1) every group has two
+// lanes on one slot -- SQ_LDS_BANK_CONFLICT was 40 % of the tower's LDS cycles; for s = 2 mod 4 the eight rows of a group
+// that share g land on eight distinct even (g = 0, 2) or odd (g = 1, 3) slots: conflict-free.  s = 2 mod 4 <=> pitch = 8 mod 16.
+constexpr int kPad = 8;
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -92,6 +100,27 @@ struct HeadArgs {
 
 __device__ __forceinline__ f32x4 ldg_f4(const float* p) { return *(const DCTR_GLOBAL f32x4*)p; }
 
+// The embedding lookup as the fused train kernel's input stage (dctr_embed_tower_train_step; round 4): a workgroup gathers
+// the rows of its own 16 samples straight from the tables while it would otherwise wait for the gather kernel's output --
+// what k_embed_fwd (csrc/embed.hip) computes for a plan of fixed-length fields with one embedding_dim, in its order of
+// additions: the [16, K0] tower input tile in LDS (and out to `out`, for the weight gradients), the linear logit and the FM
+// term (kept in LDS for the head), sum_f e (`fm_s`, for FM's backward in the update kernel).
+struct GatherArgs {
+  const dctr_field_t* deep;    // [n_deep] fixed-length fields, dim == D
+  const dctr_field_t* wide;    // [n_wide] fixed-length fields, dim == 1
+  const int32_t* dense_cols;   // [n_dense]
+  const int32_t* wdense_cols;  // [n_wdense]
+  const float* wdense_w;       // [n_wdense] nullable
+  const float* X;              // [B, ldx]
+  int64_t ldx;
+  float* out;                  // [B, ldo] the gathered tower input (combined_dnn_input layout)
+  int64_t ldo;
+  float* fm_s;                 // [B, lds] nullable
+  int64_t lds;
+  int32_t* err;                // nullable
+  int n_deep, n_wide, n_dense, n_wdense, nc, dense_off, D, lpr_shift, want_fm, scratch_off;
+};
+
 
 // diagnostics (tools/mlp_trace.py): 16 wall_clock64 stamps per workgroup, or NULL -- only in the DCTR_DIAG build
 // (libdctr_hip_diag.so); the shipped library keeps no mutable global state
@@ -143,7 +172,9 @@ static unsigned long long* const g_mlp_trace = nullptr;
 #endif
 
 // the fast bodies (defined behind the general ones)
-__device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* smem, float* logit_lds FT_ARG);
+template <bool GATHER>
+__device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* smem, float* logit_lds, const GatherArgs& G,
+                                                     float* p0s, float* p1s FT_ARG);
 __device__ __forceinline__ void mlp_bwd_fast(const MlpArgs& A, float* smem, const float* g_lds, const float* hb0,
                                              const float* hb1, int rs_h FT_ARG);
 
@@ -395,10 +426,10 @@ __global__ __launch_bounds__(kT) void k_mlp_fwd(MlpArgs A) {
   extern __shared__ __align__(16) float smem[];
   FT_DECL;
 #ifdef DCTR_FAST_ONLY   // (ISA reading aid: compile the fast body alone)
-  mlp_fwd_fast(A, smem, nullptr FT_PASS);
+  mlp_fwd_fast<false>(A, smem, nullptr, GatherArgs{}, nullptr, nullptr FT_PASS);
 #else
   if (A.fast) {
-    mlp_fwd_fast(A, smem, nullptr FT_PASS);
+    mlp_fwd_fast<false>(A, smem, nullptr, GatherArgs{}, nullptr, nullptr FT_PASS);
     FT_FLUSH(A.trace);
   } else {
     mlp_fwd_body<false>(A, smem, nullptr);
@@ -788,7 +819,43 @@ __device__ __forceinline__ void fwd_bias_sel(const LayerDev& Ld, int tile0, int 
   }
 }
 
-__device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* smem, float* logit_lds FT_ARG) {
+// LDS scratch of the gather stage (it lies in the backward's image, which nobody touches before the head is done)
+struct GatherLds {
+  const dctr_field_t* deep;   // staged descriptors
+  const dctr_field_t* wide;
+  const float* x;             // [16][nc] the X tile (rows past B repeat row B-1)
+  const int32_t* dcol;        // [n_dense]
+  const int32_t* wcol;        // [n_wdense]
+  const float* ww;            // [n_wdense]
+  float* wv;                  // [16][32] the wide tables' values (0 past n_wide / B)
+  float* st;                  // [16][D] sum_f e
+  float* tm;                  // [16][D] (sum_f e)^2 - sum_f e^2
+};
+__host__ __device__ __forceinline__ int gather_stage_words(int n_deep, int n_wide, int nc, int n_dense, int n_wdense) {
+  return 16 * (n_deep + n_wide) + kTM * nc + n_dense + 2 * n_wdense;
+}
+__host__ __device__ __forceinline__ int gather_lds_words(int n_deep, int n_wide, int nc, int n_dense, int n_wdense, int D) {
+  return round_up(gather_stage_words(n_deep, n_wide, nc, n_dense, n_wdense), 4) + kTM * 32 + 2 * kTM * D;
+}
+__device__ __forceinline__ GatherLds gather_lds(const GatherArgs& G, float* base) {
+  GatherLds S;
+  uint32_t* w = reinterpret_cast<uint32_t*>(base);
+  S.deep = reinterpret_cast<const dctr_field_t*>(w); w += 16 * G.n_deep;
+  S.wide = reinterpret_cast<const dctr_field_t*>(w); w += 16 * G.n_wide;
+  S.x = reinterpret_cast<const float*>(w); w += kTM * G.nc;
+  S.dcol = reinterpret_cast<const int32_t*>(w); w += G.n_dense;
+  S.wcol = reinterpret_cast<const int32_t*>(w); w += G.n_wdense;
+  S.ww = reinterpret_cast<const float*>(w); w += G.n_wdense;
+  w = reinterpret_cast<uint32_t*>(base) + round_up(gather_stage_words(G.n_deep, G.n_wide, G.nc, G.n_dense, G.n_wdense), 4);
+  S.wv = reinterpret_cast<float*>(w); w += kTM * 32;
+  S.st = reinterpret_cast<float*>(w); w += kTM * G.D;
+  S.tm = reinterpret_cast<float*>(w);
+  return S;
+}
+
+template <bool GATHER>
+__device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* smem, float* logit_lds, const GatherArgs& G,
+                                                     float* p0s, float* p1s FT_ARG) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * kTM;
   const int rsx = A.rsx, rsh = A.rsh;
@@ -803,43 +870,146 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
   const int q4 = K0p >> 2;
   const int xr = tid >> 5, xq = tid & 31;
   f32x4 xv[4];
-  {
-    const int64_t blast = A.B - 1;
-    const int64_t b = (b0 + xr) < blast ? (b0 + xr) : blast;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = 4 * (xq + 32 * i);
-      const int64_t kk = k < A.ldx - 4 ? k : A.ldx - 4;
-      xv[i] = ldg_f4(A.x + b * A.ldx + kk);
-    }
-  }
   f32x4 ring[kRingSlots];
   float braw[2];
-  fwd_bias_ld(A.L[0], wv, c, braw);
-  __builtin_amdgcn_sched_barrier(0);      // (keep the issue order: the compiler otherwise puts the ring in front)
-  fwd_fill(ring, A.L[0], K0p, wv, g, c, A.wmask);
-  int bias_l = 0, bias_tile0 = wv;        // which layer / tile the raw bias values in flight belong to
   float wo_pre[4] = {0.f, 0.f, 0.f, 0.f};
-  if (A.w_out && (A.logit || logit_lds)) {
-    const int ntop = A.L[A.n_layers - 1].N;
+  int bias_l = 0, bias_tile0 = wv;        // which layer / tile the raw bias values in flight belong to
+  GatherLds S{};
+  if constexpr (GATHER) {
+    // ---- round trip 1: the field descriptors, the X tile and the dense-column tables -> LDS (<= 4 words per thread, all in
+    // flight together; one concatenated index space, no load behind a branch)
+    S = gather_lds(G, smem + G.scratch_off);
+    uint32_t* stage = reinterpret_cast<uint32_t*>(smem + G.scratch_off);
+    const int e0 = 16 * G.n_deep, e1 = e0 + 16 * G.n_wide, e2 = e1 + kTM * G.nc, e3 = e2 + G.n_dense, e4 = e3 + G.n_wdense,
+              e5 = e4 + G.n_wdense;
+    const int64_t blast = A.B - 1;
+    uint32_t sv[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wo_pre[i] = ldg_f32(A.w_out + ((lane + 64 * i) < ntop ? (lane + 64 * i) : ntop - 1));
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = xq + 32 * i;
-    if (q < q4) {
-      const int k = 4 * q;
-      const bool rv = b0 + xr < A.B && k <= A.ldx - 4;
-      f32x4 w;
-      w.x = (rv && k < K0) ? xv[i].x : 0.f;
-      w.y = (rv && k + 1 < K0) ? xv[i].y : 0.f;
-      w.z = (rv && k + 2 < K0) ? xv[i].z : 0.f;
-      w.w = (rv && k + 3 < K0) ? xv[i].w : 0.f;
-      *reinterpret_cast<f32x4*>(xs + xr * rsx + k) = w;
+    for (int s_ = 0; s_ < 4; ++s_) {
+      int idx = tid + kT * s_;
+      idx = idx < e5 ? idx : e5 - 1;
+      const int j = idx - e1;
+      const int r = j / G.nc, cc = j - r * G.nc;
+      const int64_t b = (b0 + r) < blast ? (b0 + r) : blast;
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(G.deep) + idx;
+      src = idx >= e0 ? reinterpret_cast<const uint32_t*>(G.wide) + (idx - e0) : src;
+      src = idx >= e1 ? reinterpret_cast<const uint32_t*>(G.X + b * G.ldx + cc) : src;
+      src = idx >= e2 ? reinterpret_cast<const uint32_t*>(G.dense_cols) + (idx - e2) : src;
+      src = idx >= e3 ? reinterpret_cast<const uint32_t*>(G.wdense_cols) + (idx - e3) : src;
+      src = idx >= e4 ? reinterpret_cast<const uint32_t*>(G.wdense_w) + (idx - e4) : src;
+      sv[s_] = *(const DCTR_GLOBAL uint32_t*)src;
     }
+    // the tile's columns that no table row fills (dense block, padding up to K0p) start as zeros
+    const int nqd = G.n_deep << G.lpr_shift;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = xq + 32 * i;
+      if (q >= nqd && q < q4) *reinterpret_cast<f32x4*>(xs + xr * rsx + 4 * q) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+      if (tid + kT * s_ < e5) stage[tid + kT * s_] = sv[s_];
+    __syncthreads();
+    FT(10);
+    // ---- round trip 2: every table row of the tile (16 x n_deep x D / 4 dwordx4 pieces + 16 x n_wide floats), then the
+    // bias and the first layer's weight ring behind them
+    const bool rvalid = b0 + xr < A.B;
+    const float* xrow = S.x + xr * G.nc;
+    int bad = 0;
+    const int lmask = (1 << G.lpr_shift) - 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = xq + 32 * i;
+      const int qq = q < nqd ? q : nqd - 1;
+      const dctr_field_t& fd = S.deep[qq >> G.lpr_shift];
+      const int32_t rid = static_cast<int32_t>(xrow[fd.col]);            // Tensor.long(): truncation (basemodel.py:369)
+      const bool oob = static_cast<uint32_t>(rid) >= static_cast<uint32_t>(fd.vocab);
+      bad |= (oob && q < nqd) ? 1 : 0;
+      const int64_t id = oob ? 0 : rid;
+      xv[i] = ldg_f4(fd.table + id * row_ld(fd) + 4 * (qq & lmask));
+    }
+    float wval = 0.f;
+    if (G.n_wide > 0) {
+      const dctr_field_t& fw = S.wide[xq < G.n_wide ? xq : G.n_wide - 1];
+      const int32_t rid = static_cast<int32_t>(xrow[fw.col]);
+      const bool oob = static_cast<uint32_t>(rid) >= static_cast<uint32_t>(fw.vocab);
+      bad |= (oob && xq < G.n_wide) ? 1 : 0;
+      wval = ldg_f32(fw.table + (oob ? 0 : static_cast<int64_t>(rid)) * row_ld(fw));
+    }
+    fwd_bias_ld(A.L[0], wv, c, braw);
+    __builtin_amdgcn_sched_barrier(0);
+    fwd_fill(ring, A.L[0], K0p, wv, g, c, A.wmask);
+    if (A.w_out && (A.logit || logit_lds)) {
+      const int ntop = A.L[A.n_layers - 1].N;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wo_pre[i] = ldg_f32(A.w_out + ((lane + 64 * i) < ntop ? (lane + 64 * i) : ntop - 1));
+    }
+    // the dense block of combined_dnn_input (inputs.py:126-138): scalars of the X tile, LDS to LDS
+    for (int e = tid; e < kTM * G.n_dense; e += kT) {
+      const int r = e / G.n_dense, j = e - r * G.n_dense;
+      xs[r * rsx + G.dense_off + j] = (b0 + r < A.B) ? S.x[r * G.nc + S.dcol[j]] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = xq + 32 * i;
+      if (q < nqd) *reinterpret_cast<f32x4*>(xs + xr * rsx + 4 * q) = rvalid ? xv[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    S.wv[xr * 32 + xq] = (rvalid && xq < G.n_wide) ? wval : 0.f;
+    if (bad && G.err) atomicOr(G.err, 1);
+    __syncthreads();
+    // ---- FM's per-sample sums in k_embed_fwd's order of additions: wave w of that kernel takes fields w, w + 4, ...; its
+    // wave 0 then adds the four partial sums in wave order
+    for (int e = tid; e < kTM * G.D; e += kT) {
+      const int r = e / G.D, d = e - r * G.D;
+      float st = 0.f, qt = 0.f;
+      for (int w = 0; w < 4; ++w) {
+        float sw = 0.f, qw = 0.f;
+        for (int f = w; f < G.n_deep; f += 4) {
+          const float v = xs[r * rsx + f * G.D + d];
+          sw += v;
+          qw = __builtin_fmaf(v, v, qw);
+        }
+        st += sw;
+        qt += qw;
+      }
+      S.st[e] = st;
+      S.tm[e] = __builtin_fmaf(st, st, -qt);
+    }
+  } else {
+    {
+      const int64_t blast = A.B - 1;
+      const int64_t b = (b0 + xr) < blast ? (b0 + xr) : blast;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = 4 * (xq + 32 * i);
+        const int64_t kk = k < A.ldx - 4 ? k : A.ldx - 4;
+        xv[i] = ldg_f4(A.x + b * A.ldx + kk);
+      }
+    }
+    fwd_bias_ld(A.L[0], wv, c, braw);
+    __builtin_amdgcn_sched_barrier(0);      // (keep the issue order: the compiler otherwise puts the ring in front)
+    fwd_fill(ring, A.L[0], K0p, wv, g, c, A.wmask);
+    if (A.w_out && (A.logit || logit_lds)) {
+      const int ntop = A.L[A.n_layers - 1].N;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wo_pre[i] = ldg_f32(A.w_out + ((lane + 64 * i) < ntop ? (lane + 64 * i) : ntop - 1));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = xq + 32 * i;
+      if (q < q4) {
+        const int k = 4 * q;
+        const bool rv = b0 + xr < A.B && k <= A.ldx - 4;
+        f32x4 w;
+        w.x = (rv && k < K0) ? xv[i].x : 0.f;
+        w.y = (rv && k + 1 < K0) ? xv[i].y : 0.f;
+        w.z = (rv && k + 2 < K0) ? xv[i].z : 0.f;
+        w.w = (rv && k + 3 < K0) ? xv[i].w : 0.f;
+        *reinterpret_cast<f32x4*>(xs + xr * rsx + k) = w;
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   FT((1) & 15);
   const float* in = xs;
   int rs_in = rsx;
@@ -898,6 +1068,41 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
     __syncthreads();
     FT((4 + 3 * l) & 15);
     if (Ld.h) tile_store(outb, rsh, Ld.h, Ld.ldh, Ld.N, b0, A.B);   // the saved activation, for the backward kernels
+    if constexpr (GATHER) {
+      if (l == 0) {
+        // the gathered tile (the first layer's input): its copy for the weight-gradient kernel, padding columns as zeros
+        tile_store(xs, rsx, G.out, G.ldo, K0p < static_cast<int>(G.ldo) ? K0p : static_cast<int>(G.ldo), b0, A.B);
+        // the linear logit and the FM term, finished by lpr lanes per sample the way k_embed_fwd's wave 0 does it
+        // (lane gl owns the strip [4 gl, 4 gl + 4) of the row and the wide fields gl, gl + lpr, ... of each "wave" w)
+        const int lpr = 1 << G.lpr_shift;
+        if (tid < kTM * lpr) {
+          const int r = tid >> G.lpr_shift, gl = tid & (lpr - 1);
+          float t = 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) t += S.tm[r * G.D + 4 * gl + i];
+          float wt = 0.f;
+          for (int w = 0; w < 4; ++w) {
+            float pw = 0.f;
+            for (int f = w * lpr + gl; f < G.n_wide; f += 4 * lpr) pw += S.wv[r * 32 + f];
+            if (G.wdense_w)
+              for (int j = w * lpr + gl; j < G.n_wdense; j += 4 * lpr)
+                pw = __builtin_fmaf(S.x[r * G.nc + S.wcol[j]], S.ww[j], pw);
+            wt += pw;
+          }
+          for (int m = lpr >> 1; m >= 1; m >>= 1) {
+            t += __shfl_xor(t, m, kWave);
+            wt += __shfl_xor(wt, m, kWave);
+          }
+          if (gl == 0) {
+            p0s[r] = wt;
+            p1s[r] = 0.5f * t;
+          }
+          if (G.fm_s && b0 + r < A.B)
+            *(DCTR_GLOBAL f32x4*)(G.fm_s + static_cast<int64_t>(b0 + r) * G.lds + 4 * gl) =
+                *reinterpret_cast<const f32x4*>(S.st + r * G.D + 4 * gl);
+        }
+      }
+    }
     in = outb;
     rs_in = rsh;
   }
@@ -1017,7 +1222,7 @@ __device__ __forceinline__ void bwd_mask(const MlpArgs& A, int l, int gb, int b0
   const LayerDev& Lp = A.L[l > 0 ? l - 1 : 0];   // (l == 0: only its buffer is borrowed as a valid address)
   const int col0 = 16 * Q * gb + Q * c;
   if (hl) {
-    const int cc = col0 < rs_h - 4 - Q ? col0 : rs_h - 4 - Q;     // (the tile is rs_h - 4 columns wide)
+    const int cc = col0 < rs_h - kPad - Q ? col0 : rs_h - kPad - Q;     // (the tile is rs_h - kPad columns wide)
 #pragma unroll
     for (int r = 0; r < 4; ++r) hpre[r] = *reinterpret_cast<const vecq*>(hl + (4 * g + r) * rs_h + cc);
     return;
@@ -1678,27 +1883,42 @@ __global__ __launch_bounds__(kT) void k_cross_mix_bwd(MlpArgs A, int E, int R) {
 // logits never leave the workgroup, d loss / d logit goes to the backward through LDS, and the head's own launch,
 // the backward's staging round trip and two kernel boundaries disappear.  Per-workgroup partial sums of the loss and
 // of d loss / d bias are reduced in fixed order by k_mlp_reduce.
-__global__ __launch_bounds__(kT) void k_mlp_train(MlpArgs A, HeadArgs Hd, int bwd_off) {
-  extern __shared__ __align__(16) float smem[];
-  __shared__ float zl[kTM], gl[kTM];
+template <bool GATHER>
+__device__ __forceinline__ void mlp_train_body(const MlpArgs& A, const HeadArgs& Hd, int bwd_off, const GatherArgs& G,
+                                               float* smem) {
+  __shared__ float zl[kTM], gl[kTM], p0s[kTM], p1s[kTM];
   const int tid = threadIdx.x;
   // the head's inputs, requested before the tower runs (they used to cost a round trip between forward and backward);
   // absent logit parts borrow y's address and are dropped by a select
   const int64_t hb = static_cast<int64_t>(blockIdx.x) * kTM + (tid & (kTM - 1));
   const int64_t hbc = hb < A.B ? hb : A.B - 1;
-  const float h_p0 = ldg_f32((Hd.part0 ? Hd.part0 : Hd.y) + hbc), h_p1 = ldg_f32((Hd.part1 ? Hd.part1 : Hd.y) + hbc);
+  float h_p0 = 0.f, h_p1 = 0.f;
+  if constexpr (!GATHER) {
+    h_p0 = ldg_f32((Hd.part0 ? Hd.part0 : Hd.y) + hbc);
+    h_p1 = ldg_f32((Hd.part1 ? Hd.part1 : Hd.y) + hbc);
+  }
   const float h_bias = ldg_f32(Hd.bias ? Hd.bias : Hd.y), h_y = ldg_f32(Hd.y + hbc);
   FT_DECL;
   FT_DECL_B;
-  const float* htop = A.fast ? mlp_fwd_fast(A, smem, zl FT_PASS) : mlp_fwd_body<false>(A, smem, zl);
+  const float* htop = nullptr;
+  if constexpr (GATHER) {
+    htop = mlp_fwd_fast<true>(A, smem, zl, G, p0s, p1s FT_PASS);
+  } else {
+    htop = A.fast ? mlp_fwd_fast<false>(A, smem, zl, G, p0s, p1s FT_PASS) : mlp_fwd_body<false>(A, smem, zl);
+  }
   __syncthreads();
   if (tid < 64) {
     const int64_t b = hb;
     float li = 0.f, gz = 0.f;
     if (tid < kTM && b < A.B) {
       float z = 0.f;                       // ((linear + fm) + dnn) + bias: the reference's order of additions
-      if (Hd.part0) z += h_p0;
-      if (Hd.part1) z += h_p1;
+      if constexpr (GATHER) {
+        z += p0s[tid];
+        if (G.want_fm) z += p1s[tid];
+      } else {
+        if (Hd.part0) z += h_p0;
+        if (Hd.part1) z += h_p1;
+      }
       z += zl[tid];
       if (Hd.bias) z += h_bias;
       const float p = 1.f / (1.f + expf(-z));                     // at::sigmoid
@@ -1722,7 +1942,7 @@ __global__ __launch_bounds__(kT) void k_mlp_train(MlpArgs A, HeadArgs Hd, int bw
   __syncthreads();
   // bwd_off > 0: the backward's two gradient tiles lie BEHIND the forward's LDS image, so the top layer's output tile is
   // still there and its relu mask needs no global round trip; 0: they alias it (towers too wide for both images)
-  if (A.fast) {
+  if (GATHER || A.fast) {
     float* hb0 = smem + kTM * A.rsx;
     mlp_bwd_fast(A, smem + bwd_off, gl, bwd_off > 0 ? hb0 : nullptr, bwd_off > 0 ? hb0 + kTM * A.rsh : nullptr, A.rsh
                  FT_PASS_B);
@@ -1736,6 +1956,18 @@ __global__ __launch_bounds__(kT) void k_mlp_train(MlpArgs A, HeadArgs Hd, int bw
     if (A.sync) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   }
   if (A.sync) step_signal(A.sync, DCTR_SYNC_TOWER);
+}
+
+__global__ __launch_bounds__(kT) void k_mlp_train(MlpArgs A, HeadArgs Hd, int bwd_off) {
+  extern __shared__ __align__(16) float smem[];
+  mlp_train_body<false>(A, Hd, bwd_off, GatherArgs{}, smem);
+}
+
+// the same launch with the embedding lookup as its input stage (GatherArgs): gather + wide + FM + tower + head + BCE +
+// backward-data of a 16-sample tile; fast-path towers only
+__global__ __launch_bounds__(kT) void k_embed_tower_train(MlpArgs A, HeadArgs Hd, int bwd_off, GatherArgs G) {
+  extern __shared__ __align__(16) float smem[];
+  mlp_train_body<true>(A, Hd, bwd_off, G, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2112,7 +2344,7 @@ void fill_layers(const dctr_mlp_t* m, LayerDev* L) {
 // (1024-wide towers: 256; the chunk only bounds how often the first layer's K loop re-stages).
 int pick_kc(int K0p, int rsh) {
   int kc = kKC;
-  while (kc > 64 && static_cast<size_t>(kTM) * ((K0p < kc ? K0p : kc) + 4 + 2 * rsh) * 4 > 150 * 1024) kc >>= 1;
+  while (kc > 64 && static_cast<size_t>(kTM) * ((K0p < kc ? K0p : kc) + kPad + 2 * rsh) * 4 > 150 * 1024) kc >>= 1;
   return kc;
 }
 
@@ -2235,9 +2467,9 @@ extern "C" int dctr_mlp_fwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, i
   a.g = nullptr; a.ldg = 0; a.gx = nullptr; a.ldgx = 0;
   a.trace = g_mlp_trace;
   const int K0p = round_up(m->layer[0].K, 16);
-  a.rsh = round_up(max_width(m), 16) + 4;
+  a.rsh = round_up(max_width(m), 16) + kPad;
   a.kc = pick_kc(K0p, a.rsh);
-  a.rsx = (K0p < a.kc ? K0p : a.kc) + 4;
+  a.rsx = (K0p < a.kc ? K0p : a.kc) + kPad;
   a.rsd = 0;
   a.fast = tower_fast(m, a.kc); a.wmask = diag_wmask(); a.sync = nullptr;
   const size_t lds = static_cast<size_t>(kTM) * (a.rsx + 2 * a.rsh) * 4;
@@ -2276,7 +2508,7 @@ int check_bwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, cons
 int bwd_stride(const dctr_mlp_t* m) {
   int w = max_width(m);
   for (int l = 1; l < m->n_layers; ++l) w = m->layer[l].K > w ? m->layer[l].K : w;
-  return round_up(w, 64) + 4;
+  return round_up(w, 64) + kPad;
 }
 
 // weight gradients (split-batch partials) + their fixed-order reduction (+ the head's partials, fused step only)
@@ -2386,9 +2618,9 @@ extern "C" int dctr_mlp_train_step(const dctr_mlp_t* m, const float* x, int64_t 
     a.g = nullptr; a.ldg = 0; a.gx = gx; a.ldgx = ld_gx;
     a.trace = g_mlp_trace;
     const int K0p = round_up(m->layer[0].K, 16);
-    a.rsh = round_up(max_width(m), 16) + 4;
+    a.rsh = round_up(max_width(m), 16) + kPad;
     a.kc = pick_kc(K0p, a.rsh);
-    a.rsx = (K0p < a.kc ? K0p : a.kc) + 4;
+    a.rsx = (K0p < a.kc ? K0p : a.kc) + kPad;
     a.rsd = bwd_stride(m);
     a.fast = tower_fast(m, a.kc); a.wmask = diag_wmask(); a.sync = gx ? m->step_sync : nullptr;
     const size_t lds_f = static_cast<size_t>(kTM) * (a.rsx + 2 * a.rsh) * 4;
@@ -2412,6 +2644,114 @@ extern "C" int dctr_mlp_train_step(const dctr_mlp_t* m, const float* x, int64_t 
   }
   if (defer_wgrad) return DCTR_OK;   // the caller enqueues dctr_mlp_train_wgrad (possibly on another stream)
   return launch_wgrad_reduce(m, x, ld_x, B, g_logit, workspace, part_loss, part_gb, n_tiles, loss, g_bias, step, s);
+}
+
+namespace {
+// launch geometry shared by dctr_mlp_train_step and dctr_embed_tower_train_step
+struct TrainGeom {
+  MlpArgs a;
+  size_t lds;
+  int bwd_off;
+};
+int train_geom(const dctr_mlp_t* m, int32_t B, TrainGeom* T) {
+  MlpArgs& a = T->a;
+  fill_layers(m, a.L);
+  a.n_layers = m->n_layers; a.B = B; a.w_out = m->w_out; a.logit = nullptr;
+  a.g = nullptr; a.ldg = 0;
+  a.trace = g_mlp_trace;
+  const int K0p = round_up(m->layer[0].K, 16);
+  a.rsh = round_up(max_width(m), 16) + kPad;
+  a.kc = pick_kc(K0p, a.rsh);
+  a.rsx = (K0p < a.kc ? K0p : a.kc) + kPad;
+  a.rsd = bwd_stride(m);
+  a.fast = tower_fast(m, a.kc); a.wmask = diag_wmask();
+  const size_t lds_f = static_cast<size_t>(kTM) * (a.rsx + 2 * a.rsh) * 4;
+  const size_t lds_b = static_cast<size_t>(kTM) * 2 * a.rsd * 4;
+  T->lds = lds_f > lds_b ? lds_f : lds_b;
+  T->bwd_off = 0;
+  if (lds_f + lds_b <= 150 * 1024) {     // both images fit: the backward keeps the forward's activations in LDS
+    T->bwd_off = static_cast<int>(lds_f / 4);
+    T->lds = lds_f + lds_b;
+  }
+  return T->lds > 150 * 1024 ? DCTR_ENOSUP : DCTR_OK;
+}
+
+int lpr_shift_of(int D) {
+  switch (D) {
+    case 4: return 0;
+    case 8: return 1;
+    case 16: return 2;
+    case 32: return 3;
+    case 64: return 4;
+    default: return -1;
+  }
+}
+
+// the plans / towers the fused gather stage takes (everything else keeps dctr_embed_fwd + dctr_mlp_train_step)
+int gather_envelope(const dctr_plan_t* p, const dctr_mlp_t* m, int32_t B, const TrainGeom& T) {
+  if (!p || !p->deep || p->n_deep < 1 || p->n_deep != p->n_deep_fixed || p->n_wide != p->n_wide_fixed) return DCTR_ENOSUP;
+  if (p->n_wide > 32 || p->n_wide < 0 || (p->n_wide && !p->wide)) return DCTR_ENOSUP;
+  if (p->vec != 4 || lpr_shift_of(p->emb_dim) < 0) return DCTR_ENOSUP;
+  const int width = p->n_deep * p->emb_dim;
+  if (p->n_dense < 0 || (p->n_dense > 0 && p->dense_off != width) || (p->n_dense == 0 && p->dense_off >= 0)) return DCTR_ENOSUP;
+  if (m->layer[0].K != width + p->n_dense) return DCTR_ENOSUP;
+  if (!T.a.fast || T.bwd_off <= 0) return DCTR_ENOSUP;
+  const int n_wdense = p->wdense_w ? p->n_wdense : 0;
+  if (gather_stage_words(p->n_deep, p->n_wide, p->n_xcols, p->n_dense, n_wdense) > 4 * kT) return DCTR_ENOSUP;
+  if (gather_lds_words(p->n_deep, p->n_wide, p->n_xcols, p->n_dense, n_wdense, p->emb_dim) > 2 * kTM * T.a.rsd)
+    return DCTR_ENOSUP;
+  (void)B;
+  return DCTR_OK;
+}
+}  // namespace
+
+extern "C" int dctr_embed_tower_train_supported(const dctr_plan_t* plan, const dctr_mlp_t* m, int32_t B) {
+  if (check_mlp(m, B) != DCTR_OK || !m->w_out) return 0;
+  TrainGeom T;
+  if (train_geom(m, B, &T) != DCTR_OK) return 0;
+  return gather_envelope(plan, m, B, T) == DCTR_OK ? 1 : 0;
+}
+
+extern "C" int dctr_embed_tower_train_step(const dctr_plan_t* plan, const float* X, int64_t ldx, const dctr_mlp_t* m,
+                                           int32_t B, int32_t want_fm, const float* bias, const float* y, float* y_pred,
+                                           float* g_logit, float* gx, int64_t ld_gx, float* out, int64_t ld_out,
+                                           float* fm_s, int64_t ld_s, int32_t* err, float* workspace,
+                                           dctr_stream_t stream) {
+  const int rc = check_mlp(m, B);
+  if (rc != DCTR_OK) return rc;
+  if (!plan || !X || !m->w_out || !y || !y_pred || !g_logit || !workspace || !out || !gx) return DCTR_EINVAL;
+  if (ldx < plan->n_xcols || ld_out < m->layer[0].K) return DCTR_EINVAL;
+  if (ld_out % 4 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0) return DCTR_EALIGN;
+  if (want_fm && (!fm_s || ld_s < plan->emb_dim)) return DCTR_EINVAL;
+  if (fm_s && (ld_s % 4 != 0 || reinterpret_cast<uintptr_t>(fm_s) % 16 != 0)) return DCTR_EALIGN;
+  const int rb = check_bwd(m, out, ld_out, B, gx, ld_gx);
+  if (rb != DCTR_OK) return rb;
+  if (B == 0) return DCTR_OK;
+  TrainGeom T;
+  const int rg = train_geom(m, B, &T);
+  if (rg != DCTR_OK) return rg;
+  const int re = gather_envelope(plan, m, B, T);
+  if (re != DCTR_OK) return re;
+  MlpArgs& a = T.a;
+  a.x = out; a.ldx = ld_out; a.gx = gx; a.ldgx = ld_gx; a.sync = nullptr;
+  const WgradPlan P = plan_wgrad(m, B);
+  const int n_tiles = (B + kTM - 1) / kTM;
+  HeadArgs hd;
+  hd.part0 = nullptr; hd.part1 = nullptr; hd.bias = bias; hd.y = y; hd.y_pred = y_pred; hd.g_logit = g_logit;
+  hd.part_loss = workspace + static_cast<size_t>(P.slab) * P.S;
+  hd.part_gbias = hd.part_loss + n_tiles;
+  GatherArgs G;
+  G.deep = plan->deep; G.wide = plan->wide; G.dense_cols = plan->dense_cols; G.wdense_cols = plan->wdense_cols;
+  G.wdense_w = plan->wdense_w; G.X = X; G.ldx = ldx; G.out = out; G.ldo = ld_out; G.fm_s = fm_s; G.lds = ld_s; G.err = err;
+  G.n_deep = plan->n_deep; G.n_wide = plan->n_wide; G.n_dense = plan->n_dense;
+  G.n_wdense = plan->wdense_w ? plan->n_wdense : 0;
+  G.nc = plan->n_xcols; G.dense_off = plan->dense_off; G.D = plan->emb_dim; G.lpr_shift = lpr_shift_of(plan->emb_dim);
+  G.want_fm = want_fm ? 1 : 0; G.scratch_off = T.bwd_off;
+  if (T.lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_embed_tower_train),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(T.lds));
+  k_embed_tower_train<<<dim3(n_tiles), dim3(kT), T.lds, static_cast<hipStream_t>(stream)>>>(a, hd, T.bwd_off, G);
+  return launch_status();
 }
 
 extern "C" int dctr_mlp_train_wgrad(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g_logit,
@@ -2471,8 +2811,8 @@ extern "C" int dctr_crossnet_mat_fwd(const dctr_mlp_t* m, const float* x, int64_
   a.g = nullptr; a.ldg = 0; a.gx = nullptr; a.ldgx = 0; a.trace = nullptr;
   const int Wp = round_up(W, 16);
   a.kc = kKC;
-  a.rsx = Wp + 4;
-  a.rsh = Wp + 4;
+  a.rsx = Wp + kPad;
+  a.rsh = Wp + kPad;
   a.rsd = 0;
   a.fast = 0; a.wmask = 0xffffffffu; a.sync = nullptr;
   const size_t lds = static_cast<size_t>(kTM) * (a.rsx + 2 * a.rsh) * 4;
@@ -2506,7 +2846,7 @@ extern "C" int dctr_crossnet_mat_bwd(const dctr_mlp_t* m, const float* x, int64_
     a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = nullptr; a.logit = nullptr;
     a.g = gY; a.ldg = ld_g; a.gx = gx; a.ldgx = ld_gx; a.trace = nullptr;
     a.rsx = 0; a.rsh = 0; a.fast = 0; a.wmask = 0xffffffffu; a.sync = nullptr;
-    a.rsd = round_up(W, 64) + 4;
+    a.rsd = round_up(W, 64) + kPad;
     const size_t lds = static_cast<size_t>(kTM) * 4 * a.rsd * 4;
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cross_mat_bwd),

@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdctr_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 
@@ -63,7 +63,7 @@ class DenseItem(ctypes.Structure):
 
 
 PLAN_HAS_GACC, PLAN_HAS_STATE, PLAN_HAS_MAXPOOL = 1, 2, 4
-SYNC_TOWER, SYNC_GATHER, SYNC_ERR, SYNC_INTS = 0, 1, 12, 16
+SYNC_TOWER, SYNC_GATHER, SYNC_UPDATE, SYNC_ERR, SYNC_INTS = 0, 1, 2, 12, 32
 LAZY_SGD, LAZY_ADAGRAD, LAZY_ADAM, LAZY_RMSPROP = 0, 1, 2, 3
 
 
@@ -151,8 +151,12 @@ SIGNATURES = {
     "dctr_mlp_train_step": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64,
                                            _P, _I32, _P, _P]),
     "dctr_mlp_train_wgrad": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _P, _P, _P, _P, _P]),
+    "dctr_embed_tower_train_supported": (ctypes.c_int, [ctypes.POINTER(Plan), ctypes.POINTER(Mlp), _I32]),
+    "dctr_embed_tower_train_step": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, ctypes.POINTER(Mlp), _I32, _I32, _P, _P,
+                                                   _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P]),
     "dctr_sizeof_dense_step": (ctypes.c_size_t, []),
     "dctr_step_wait": (ctypes.c_int, [_P, _I32, _I32, _P]),
+    "dctr_step_signal": (ctypes.c_int, [_P, _I32, _P]),
     "dctr_bce_head": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P]),
     "dctr_dense_opt": (ctypes.c_int, [_P, _P, _P, _I64, _I32, _F32, _F32, _P]),
     "dctr_sizeof_dense_item": (ctypes.c_size_t, []),

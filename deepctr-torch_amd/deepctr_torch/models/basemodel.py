@@ -35,6 +35,7 @@ from .. import callbacks as _cb
 from .._hip import dense as _dense
 from .._hip import mlp as _mlp
 from .._hip import ops as _ops
+from .._hip import step as _step
 from .._hip.plan import EmbeddingPlan
 from ..inputs import SparseFeat, VarLenSparseFeat, build_input_features, create_embedding_matrix, split_columns
 from ..layers import PredictionLayer
@@ -766,6 +767,15 @@ class BaseModel(nn.Module):
     def _train_step_fused(self, st, xb, yb):
         slab, mode = st["slab"], st["mode"]
         plan = self.model_plan()
+        # DeepFM / WDL-shaped models: the whole step as five launches enqueued straight through the C ABI, the lookup
+        # inside the tower launch (_hip/step.py) -- no autograd graph, no per-step allocations
+        eng = st.get("engine")
+        if eng is None and getattr(self, "_gather_step", False) and _step.GatherStep.enabled():
+            eng = st["engine"] = _step.GatherStep(self, slab)
+        if eng is not None and _step.GatherStep.enabled() and eng.supports(xb, yb):
+            loss, y_pred = eng.step(xb, yb, mode, defer_join=getattr(self, "_defer_dense_join", False))
+            slab.step(*mode)          # (applied inside the gradient kernels: clears the flag)
+            return loss, loss.reshape(1), y_pred
         self._grad_sink = slab
         plan.dense_sink = slab
         # the tower's weight gradients run on a fork stream beside the embedding update (DCTR_OVERLAP_WGRAD=0: in line)

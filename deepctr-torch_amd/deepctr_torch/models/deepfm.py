@@ -11,6 +11,7 @@ from ..layers import FM
 class DeepFM(BaseModel):
     """Same arguments as the reference (models/deepfm.py:38-43)."""
     _fused_step_ok = True
+    _gather_step = True     # logit_parts() is [linear, (fm), tower] over ONE fused lookup: _hip/step.py applies
 
     def __init__(self, linear_feature_columns, dnn_feature_columns, use_fm=True, dnn_hidden_units=(256, 128),
                  l2_reg_linear=0.00001, l2_reg_embedding=0.00001, l2_reg_dnn=0, init_std=0.0001, seed=1024,

@@ -8,6 +8,7 @@ from .basemodel import BaseModel
 class WDL(BaseModel):
     """Same arguments as the reference (models/wdl.py:36-41)."""
     _fused_step_ok = True
+    _gather_step = True     # logit_parts() is [linear, (fm), tower] over ONE fused lookup: _hip/step.py applies
 
     def __init__(self, linear_feature_columns, dnn_feature_columns, dnn_hidden_units=(256, 128), l2_reg_linear=1e-5,
                  l2_reg_embedding=1e-5, l2_reg_dnn=0, init_std=0.0001, seed=1024, dnn_dropout=0, dnn_activation='relu',

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 16
+#define DCTR_ABI_VERSION 17
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -530,6 +530,26 @@ int dctr_mlp_train_wgrad(const dctr_mlp_t* m, const float* x, int64_t ld_x, int3
                          float* workspace, float* loss, float* g_bias, const dctr_dense_step_t* step,
                          dctr_stream_t stream);
 
+/* ---- the embedding lookup as the fused train launch's input stage (round 4) ------------------------------------------
+ * dctr_embed_fwd + dctr_mlp_train_step(defer_wgrad = 1) as ONE launch for a DeepFM / WDL-shaped model -- logit =
+ * linear(X) [+ FM(embeddings)] + tower(combined_dnn_input) + bias (deepfm.py:67-86, wdl.py): every workgroup gathers the
+ * table rows of its own 16 samples (basemodel.py:354-380), computes the linear logit (basemodel.py:63-92) and the FM
+ * term (interaction.py:26-34) in LDS, and goes on with the tower, the head, BCE(sum) and the backward-data pass.  The
+ * gather kernel, its output's round trip through memory and one kernel boundary leave the step's critical cycle.
+ *   plan   fixed-length fields only, one embedding_dim in {4, 8, 16, 32, 64}, at most 32 wide fields; the tower's input is
+ *          the plan's whole row (layer[0].K == n_deep * emb_dim + n_dense)
+ *   out    [B, ld_out]  written: the gathered row of every sample (what dctr_embed_fwd's `out` holds): the operand of
+ *          dctr_mlp_train_wgrad(m, out, ld_out, ...), which the caller enqueues as after dctr_mlp_train_step(defer_wgrad)
+ *   fm_s   [B, ld_s]    written when non-NULL: sum_f e (FM's backward inside dctr_embed_update); required with want_fm
+ *   y_pred, g_logit, gx, workspace, err: as in dctr_mlp_train_step / dctr_embed_fwd.
+ * Same arithmetic, in the same order, as the two calls it replaces: results are bit-identical to theirs.
+ * dctr_embed_tower_train_supported: 1 when plan + tower fit (else the caller keeps the two-launch path).            */
+int dctr_embed_tower_train_supported(const dctr_plan_t* plan, const dctr_mlp_t* m, int32_t B);
+int dctr_embed_tower_train_step(const dctr_plan_t* plan, const float* X, int64_t ldx, const dctr_mlp_t* m, int32_t B,
+                                int32_t want_fm, const float* bias, const float* y, float* y_pred, float* g_logit,
+                                float* gx, int64_t ld_gx, float* out, int64_t ld_out, float* fm_s, int64_t ld_s,
+                                int32_t* err, float* workspace, dctr_stream_t stream);
+
 /* ---- device-side dependencies between the two queues of a train step ---------------------------------------------
  * A dependency that crosses hardware queues costs 11-12 us through hipGraph / stream events on this stack, 4.6 us through
  * a word in memory (tools/micro/hopbench.hip), and the DeepFM step's critical cycle crosses twice (tower -> update,
@@ -546,9 +566,13 @@ int dctr_mlp_train_wgrad(const dctr_mlp_t* m, const float* x, int64_t ld_x, int3
  * Signals and waits must pair up one to one (the fused train step does; dctr_step_sync is for nothing else).        */
 #define DCTR_SYNC_TOWER 0
 #define DCTR_SYNC_GATHER 1
+#define DCTR_SYNC_UPDATE 2   /* given by dctr_step_signal behind dctr_embed_update (the "fused_flags" step topology) */
 #define DCTR_SYNC_ERR 12     /* index of the error word */
-#define DCTR_SYNC_INTS 16
+#define DCTR_SYNC_INTS 32    /* [4 s, 4 s + 4): signal s' generation / epoch / arrivals / stamp; [16 + 2 s, +2): its waiter's stamps */
 int dctr_step_wait(int32_t* sync, int32_t signal, int32_t timeout_us, dctr_stream_t stream);
+/* The signal as a one-thread launch of its own on the producer's queue, behind the producer (whose end-of-kernel
+ * write-back makes its stores visible first): for a producer that cannot signal from inside its kernel.            */
+int dctr_step_signal(int32_t* sync, int32_t signal, dctr_stream_t stream);
 
 /* ---- prediction head + loss (layers/core.py:154-160, basemodel.py:254, F.binary_cross_entropy(reduction='sum'))
  *     z = sum_i part_i[b] + bias ;  y_pred = sigmoid(z) ;  loss = sum_b -(y log p + (1-y) log(1-p))   (logs clamped

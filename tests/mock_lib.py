@@ -118,6 +118,12 @@ class _Core(object):
 
     def dctr_mlp_train_wgrad(self, mref, x, ld_x, B, g_logit, ws, loss, g_bias, step, stream):
         """the mock's train step has already produced the weight gradients; what is left is the in-kernel optimizer"""
+        hp = getattr(self, "_head_partials", None)
+        if hp is not None:
+            self._head_partials = None
+            _arr(loss, (1,))[0] = hp[0]
+            if g_bias is not None and getattr(g_bias, "value", g_bias):
+                _arr(g_bias, (1,))[0] = hp[1]
         if step is not None:
             self.calls.append("mlp_train_wgrad+step")
             m, layers = self._layers(mref)
@@ -141,6 +147,31 @@ class _Core(object):
         self.dctr_bce_head(p0, p1, lp, None, bias, y, B, y_pred, loss, g_logit, g_bias, stream)
         self.dctr_mlp_bwd(mref, x, ld_x, B, g_logit, 0, gx, ld_gx, ws, stream)
         self.calls = self.calls[:-3] + ["mlp_train_step"]
+        return 0
+
+    def dctr_embed_tower_train_supported(self, pref, mref, B):
+        c = pref._obj
+        return int(c.n_deep >= 1 and c.n_deep == c.n_deep_fixed and c.n_wide == c.n_wide_fixed and c.n_wide <= 32 and
+                   c.vec == 4 and c.emb_dim in (4, 8, 16, 32, 64) and
+                   mref._obj.layer[0].K == c.n_deep * c.emb_dim + c.n_dense)
+
+    def dctr_embed_tower_train_step(self, pref, X, ldx, mref, B, want_fm, bias, y, y_pred, g_logit, gx, ld_gx, out,
+                                    ld_out, fm_s, ld_s, err, ws, stream):
+        """dctr_embed_fwd + dctr_mlp_train_step(defer_wgrad) as one call (include/dctr.h), composed from the two."""
+        import torch
+        wide, fm, loss, gb = torch.zeros(B), torch.zeros(B), torch.zeros(1), torch.zeros(1)
+        P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        self.dctr_embed_fwd(pref, X, ldx, B, out, ld_out, P(wide), 1, P(fm) if want_fm else None, err, None, 0, None,
+                            None, fm_s, ld_s, stream)
+        self.dctr_mlp_train_step(mref, out, ld_out, B, P(wide), P(fm) if want_fm else None, bias, y, y_pred, P(loss),
+                                 g_logit, P(gb), gx, ld_gx, ws, 1, None, stream)
+        # (the device code leaves per-workgroup partial sums of the loss and of d loss / d bias in the workspace and the
+        # weight-gradient call reduces them: the stand-in hands the finished values over the same way)
+        self._head_partials = (float(loss[0]), float(gb[0]))
+        self.calls = self.calls[:-2] + ["embed_tower_train_step"]
+        return 0
+
+    def dctr_step_signal(self, sync, signal, stream):
         return 0
 
     # ---- head ---------------------------------------------------------------------------------------------

@@ -311,7 +311,7 @@ def test_forward_hooks_keep_firing_in_train_steps(mock, name):
         for _ in range(2):
             m._train_step(torch.from_numpy(g["X"]), torch.from_numpy(g["y"]))
         assert len(seen) == (2 if hooked else 0)
-        fast = any(c in ("mlp_train_step", "bce_head") for c in mock.calls)
+        fast = any(c in ("mlp_train_step", "bce_head", "embed_tower_train_step") for c in mock.calls)
         assert fast != hooked
         finals.append({k: v.clone() for k, v in m.state_dict().items()})
     for k in finals[0]:

@@ -42,7 +42,7 @@ for rep in range(60):
 model.model_plan().check_ids()
 r = np.array(rows[5:])
 t_sig, g_sig = r[:, 3], r[:, 7]
-tw0, tw1, gw0, gw1 = r[:, 8], r[:, 9], r[:, 10], r[:, 11]
+tw0, tw1, gw0, gw1 = r[:, 16], r[:, 17], r[:, 18], r[:, 19]
 
 
 def us(a):
