@@ -94,8 +94,61 @@ def main():
     print(json.dumps(out, indent=1))
 
 
+def cli():
+    """bench.py's cpu_baseline leg (kind "reference"): ONE variant of the unmodified reference in this process.
+        python oracle/time_reference.py --reference-root oracle/_ref --batch 4096 --vocab 1000000 --steps 10 \
+            [--optimizer adagrad --l2 0 | --forward-only] --json
+    `--reference-root` is the directory that holds the reference's `deepctr_torch/` package: /root/reference in the build
+    container, the unpacked git-ignored archive of oracle/_ref/ (made by __graft_entry__.build()) on the GPU box."""
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference-root", required=True)
+    ap.add_argument("--batch", type=int, default=B)
+    ap.add_argument("--vocab", type=int, default=V)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--optimizer", default="adagrad")
+    ap.add_argument("--l2", type=float, default=0.0)
+    ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--json", action="store_true")
+    a = ap.parse_args()
+    import torch
+    sys.path.insert(0, HERE)
+    import make_golden as mg
+    mg.REFERENCE = os.path.abspath(a.reference_root)
+    mg.import_reference()
+    from deepctr_torch.inputs import DenseFeat, SparseFeat
+    from deepctr_torch.models import DeepFM
+    gen = torch.Generator().manual_seed(0)
+    X = torch.cat([torch.randint(0, a.vocab, (a.batch, F), generator=gen).float(), torch.rand(a.batch, ND, generator=gen)], 1)
+    y = torch.randint(0, 2, (a.batch,), generator=gen).float()
+    cols = [SparseFeat("C%d" % (i + 1), a.vocab, D) for i in range(F)] + [DenseFeat("I%d" % (i + 1), 1) for i in range(ND)]
+    m = DeepFM(cols, cols, dnn_hidden_units=(256, 128), l2_reg_linear=a.l2, l2_reg_embedding=a.l2, dnn_dropout=0,
+               seed=1024, device="cpu")
+    if a.forward_only:
+        m.eval()
+        with torch.no_grad():
+            r = timed(lambda: m(X), n=a.steps, warm=3)
+    else:
+        m.compile(a.optimizer, "binary_crossentropy", metrics=[])
+        m.train()
+
+        def step():          # basemodel.py:242-262
+            y_pred = m(X).squeeze()
+            m.optim.zero_grad()
+            loss = torch.nn.functional.binary_cross_entropy(y_pred, y, reduction="sum")
+            total = loss + m.get_regularization_loss() + m.aux_loss
+            total.backward()
+            m.optim.step()
+        r = timed(step, n=a.steps, warm=2)
+    r.update(value=a.batch / (r["ms_per_step"] * 1e-3), unit="samples/s", steps=a.steps, threads=torch.get_num_threads(),
+             reference_root=a.reference_root)
+    print(json.dumps(r))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) == 4 and sys.argv[1] == "--one":
+    if "--reference-root" in sys.argv:
+        cli()
+    elif len(sys.argv) == 4 and sys.argv[1] == "--one":
         print(json.dumps(one(sys.argv[2], sys.argv[3])))
     else:
         main()

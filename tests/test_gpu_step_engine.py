@@ -1,0 +1,199 @@
+"""The round-4 train step (deepctr_torch/_hip/step.py: the embedding lookup inside the tower launch,
+dctr_embed_tower_train_step, five launches enqueued straight through the C ABI) against the autograd-assembled fused
+step of rounds 1-3 (dctr_embed_fwd + dctr_mlp_train_step + ...; DCTR_STEP_ENGINE=0).  Same arithmetic in the same order:
+everything observable must be bit-identical -- the kernel's outputs, the losses, every parameter and every optimizer
+state after many steps, eager and graph-replayed.  The older path is itself pinned to the reference's goldens
+(tests/test_gpu_deepfm.py, test_gpu_full_golden.py), and the full-size goldens run through the new one by default.
+
+Small vocabularies on purpose: the gather of step n + 1 reads rows the update of step n wrote microseconds earlier."""
+import ctypes
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cols(vocab, F, D, n_dense):
+    from deepctr_torch.inputs import DenseFeat, SparseFeat
+    return [SparseFeat("C%d" % (i + 1), vocab, D) for i in range(F)] + [DenseFeat("I%d" % (i + 1), 1) for i in range(n_dense)]
+
+
+def _model(kind, vocab, opt, F=26, D=16, n_dense=13, hidden=(256, 128)):
+    from deepctr_torch import models as M
+    cols = _cols(vocab, F, D, n_dense)
+    kw = dict(dnn_hidden_units=hidden, l2_reg_linear=0, l2_reg_embedding=0, dnn_dropout=0, seed=1024, device=DEV)
+    m = M.DeepFM(cols, cols, **kw) if kind == "deepfm" else M.WDL(cols, cols, **kw)
+    m.compile(opt, "binary_crossentropy", metrics=[])
+    m.train()
+    return m
+
+
+def _data(vocab, F, n_dense, B, n_batches, seed=7):
+    gen = torch.Generator().manual_seed(seed)
+    n = B * n_batches
+    ids = torch.randint(0, vocab, (n, F), generator=gen)
+    X = torch.cat([ids.float(), torch.rand(n, n_dense, generator=gen)], dim=1).to(DEV)
+    y = torch.randint(0, 2, (n,), generator=gen).float().to(DEV)
+    return X, y
+
+
+def _run(engine, kind, vocab, opt, steps, graphed, B=4096, F=26, D=16, n_dense=13, hidden=(256, 128), topo=None):
+    os.environ["DCTR_STEP_ENGINE"] = "1" if engine else "0"
+    if topo:
+        os.environ["DCTR_STEP_TOPOLOGY"] = topo
+    try:
+        m = _model(kind, vocab, opt, F, D, n_dense, hidden)
+        X, y = _data(vocab, F, n_dense, B, 8)
+        bat = lambda i: (X[(i % 8) * B:(i % 8 + 1) * B], y[(i % 8) * B:(i % 8 + 1) * B])   # noqa: E731
+        losses, preds = [], []
+        i = 0
+        for _ in range(2):
+            out = m._train_step(*bat(i))
+            losses.append(out[0].clone())
+            preds.append(out[2].clone())
+            i += 1
+        st = m._fused_step_state()
+        assert st is not None
+        used = st.get("engine") is not None and st["engine"].supports(*bat(0))
+        assert used == engine, "engine %s but used=%s" % (engine, used)
+        if graphed:
+            from deepctr_torch._hip.graph import GraphedTrainStep
+            S = 4
+            g = GraphedTrainStep(m, *bat(0), steps_per_graph=S, inputs_ready=True).capture(*bat(0))
+            while i < steps:
+                for _ in range(S):
+                    out = g(*bat(i))
+                    i += 1
+                g.flush()
+                torch.cuda.synchronize()
+                losses.append(out[0].clone())
+                preds.append(out[2].clone())
+        else:
+            while i < steps:
+                out = m._train_step(*bat(i))
+                losses.append(out[0].clone())
+                i += 1
+            preds.append(out[2].clone())
+        torch.cuda.synchronize()
+        m.model_plan().check_ids()
+        if st.get("engine") is not None and st["engine"].sync is not None:
+            assert int(st["engine"].sync[12].item()) == 0, "a device-side wait timed out"
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        ost = {}
+        names = {id(p): n for n, p in m.named_parameters()}
+        for grp in m.optim.param_groups:
+            for p in grp["params"]:
+                for k, v in m.optim.state.get(p, {}).items():
+                    if torch.is_tensor(v) and v.numel() > 1:
+                        ost["%s/%s" % (names.get(id(p), "?"), k)] = v.detach().clone()
+        return sd, ost, torch.stack([l.reshape(()) for l in losses]).cpu(), [p.cpu() for p in preds]
+    finally:
+        os.environ.pop("DCTR_STEP_ENGINE", None)
+        os.environ.pop("DCTR_STEP_TOPOLOGY", None)
+
+
+def _same(a, b, what):
+    ref_sd, ref_st, ref_loss, ref_pred = a
+    sd, st, loss, pred = b
+    assert torch.equal(loss, ref_loss), "%s: losses differ, first at entry %d: %r vs %r" % (
+        what, int((loss != ref_loss).nonzero()[0]), loss[:4].tolist(), ref_loss[:4].tolist())
+    for p, q in zip(pred, ref_pred):
+        assert torch.equal(p, q), "%s: predictions differ (max %.3e)" % (what, float((p - q).abs().max()))
+    for k in ref_sd:
+        assert torch.equal(sd[k], ref_sd[k]), "%s: %s differs (max %.3e)" % (what, k, float((sd[k] - ref_sd[k]).abs().max()))
+    assert set(st) == set(ref_st)
+    for k in ref_st:
+        assert torch.equal(st[k], ref_st[k]), "%s: optimizer state %s differs" % (what, k)
+
+
+@pytest.mark.parametrize("graphed", [False, True], ids=["eager", "hipgraph"])
+@pytest.mark.parametrize("opt", ["adagrad", "sgd"])
+def test_engine_leaves_the_same_bits_as_the_two_launch_step(opt, graphed):
+    _same(_run(False, "deepfm", 3000, opt, 42, graphed), _run(True, "deepfm", 3000, opt, 42, graphed), "deepfm/" + opt)
+
+
+@pytest.mark.parametrize("case", [
+    dict(kind="wdl", D=16),                                   # no FM part
+    dict(kind="deepfm", D=8, F=5, n_dense=3, hidden=(64, 32), B=1000),       # 2 lanes per row, ragged last tile (1000 = 62.5 x 16)
+    dict(kind="deepfm", D=32, F=7, n_dense=0, hidden=(128,), B=512),         # 8 lanes per row, no dense block
+    dict(kind="deepfm", D=4, F=30, n_dense=20, hidden=(128, 64), B=256),     # 1 lane per row, > 16 wide fields per pass
+])
+def test_engine_shapes(case):
+    kw = dict(F=26, D=16, n_dense=13, hidden=(256, 128), B=4096)
+    kw.update(case)
+    kind = kw.pop("kind")
+    _same(_run(False, kind, 500, "adagrad", 10, False, **kw), _run(True, kind, 500, "adagrad", 10, False, **kw), repr(case))
+
+
+@pytest.mark.parametrize("topo", ["serial", "fused_flags"])
+def test_engine_topologies(topo):
+    ref = _run(True, "deepfm", 3000, "adagrad", 42, True)
+    _same(ref, _run(True, "deepfm", 3000, "adagrad", 42, True, topo=topo), topo)
+
+
+def test_engine_long_run_on_large_tables():
+    """1M-row tables (the benchmark shape), 200 graph-replayed steps: rows mostly miss every cache"""
+    _same(_run(False, "deepfm", 1_000_000, "adagrad", 202, True), _run(True, "deepfm", 1_000_000, "adagrad", 202, True),
+          "1M rows")
+
+
+def test_out_of_range_id_is_flagged():
+    m = _model("deepfm", 100, "adagrad")
+    X, y = _data(100, 26, 13, 256, 1)
+    X[5, 3] = 100.0
+    m._train_step(X, y)
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        m.model_plan().check_ids()
+
+
+def test_kernel_outputs_equal_the_two_launches():
+    """dctr_embed_tower_train_step against dctr_embed_fwd + dctr_mlp_train_step(defer_wgrad) on the same inputs: the gathered
+    rows, sum_f e, predictions, d loss / d logit and d loss / d input, bit for bit."""
+    from deepctr_torch._hip import lib as L
+    from deepctr_torch._hip import step as S
+    lib = L.lib()
+    B = 4096
+    m = _model("deepfm", 50_000, "adagrad")
+    X, y = _data(50_000, 26, 13, B, 1)
+    m._train_step(X, y)                      # builds the slab, the plan and the engine's buffers
+    torch.cuda.synchronize()
+    st = m._fused_step_state()
+    eng = st["engine"]
+    b = eng._buffers(B, X.device)
+    plan = m.model_plan()
+    cplan = plan.bind(X.device)
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    s = L.stream_handle(X.device)
+    f32 = dict(dtype=torch.float32, device=DEV)
+    out0, wide0, fm0 = torch.zeros(B, plan.ld_out, **f32), torch.empty(B, **f32), torch.empty(B, **f32)
+    fms0 = torch.empty(B, 16, **f32)
+    L.check(lib.dctr_embed_fwd(cplan, P(X), X.stride(0), B, P(out0), plan.ld_out, P(wide0), 1, P(fm0), None,
+                               plan.units_ptr(), len(plan.units), None, None, P(fms0), 16, s))
+    yp0, gl0, loss0 = torch.empty(B, **f32), torch.empty(B, **f32), torch.empty((), **f32)
+    gx0 = torch.empty(B, plan.ld_out, **f32)
+    L.check(lib.dctr_mlp_train_step(ctypes.byref(b.desc), P(out0), plan.ld_out, B, P(wide0), P(fm0), P(m.out.bias), P(y),
+                                    P(yp0), P(loss0), P(gl0), None, P(gx0), plan.ld_out, P(b.ws), 1, None, s))
+    torch.cuda.synchronize()
+    h0 = [h.clone() for h in b.hs]
+    dh0 = [h.clone() for h in b.dhs]
+    out1, fms1 = torch.zeros(B, plan.ld_out, **f32), torch.empty(B, 16, **f32)
+    yp1, gl1, gx1 = torch.empty(B, **f32), torch.empty(B, **f32), torch.empty(B, plan.ld_out, **f32)
+    L.check(lib.dctr_embed_tower_train_step(cplan, P(X), X.stride(0), ctypes.byref(b.desc), B, 1, P(m.out.bias), P(y),
+                                            P(yp1), P(gl1), P(gx1), plan.ld_out, P(out1), plan.ld_out, P(fms1), 16,
+                                            P(plan.err_flag(X.device)), P(b.ws), s))
+    torch.cuda.synchronize()
+    W = plan.width
+    assert torch.equal(out1[:, :W], out0[:, :W]), "gathered rows"
+    assert float(out1[:, W:].abs().max()) == 0.0, "padding columns of `out` must be written as zeros"
+    assert torch.equal(fms1, fms0), "sum_f e"
+    assert torch.equal(yp1, yp0), "y_pred (max %.3e)" % float((yp1 - yp0).abs().max())
+    assert torch.equal(gl1, gl0), "g_logit"
+    assert torch.equal(gx1[:, :W], gx0[:, :W]), "gx"
+    for a, c in zip(b.hs, h0):
+        assert torch.equal(a, c)
+    for a, c in zip(b.dhs, dh0):
+        assert torch.equal(a, c)

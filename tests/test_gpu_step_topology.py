@@ -39,7 +39,8 @@ def _data(vocab, n_batches):
 
 def _run(topology, vocab, opt, steps, graphed):
     os.environ["DCTR_STEP_TOPOLOGY"] = topology
-    try:
+    os.environ["DCTR_STEP_ENGINE"] = "0"      # these are the recipes of the autograd-assembled step (round 4: _hip/step.py
+    try:                                      # runs DeepFM by default; tests/test_gpu_step_engine.py compares the two)
         m = _model(vocab, opt)
         X, y = _data(vocab, 8)
         bat = lambda i: (X[(i % 8) * B:(i % 8 + 1) * B], y[(i % 8) * B:(i % 8 + 1) * B])
@@ -76,6 +77,7 @@ def _run(topology, vocab, opt, steps, graphed):
         return sd, st, torch.stack([l.reshape(()) for l in losses]).cpu()
     finally:
         os.environ.pop("DCTR_STEP_TOPOLOGY", None)
+        os.environ.pop("DCTR_STEP_ENGINE", None)
 
 
 @pytest.mark.parametrize("graphed", [False, True], ids=["eager", "hipgraph"])

@@ -17,11 +17,12 @@ def short(n):
     return (m.group(1) if m else n)[:28]
 
 
-tr = [i for i, e in enumerate(ev) if "k_mlp_train" in e[2]]
+tr = [i for i, e in enumerate(ev) if "k_mlp_train" in e[2] or "k_embed_tower_train" in e[2]]
+fused = any("k_embed_tower_train" in e[2] for e in ev)      # round 4: the gather runs inside the tower launch
 if len(tr) < n_steps + 3:
     sys.exit("not enough train steps in the trace")
 lo, hi = tr[-(n_steps + 2)], tr[-3]
-while lo > 0 and "k_embed_fwd" not in ev[lo][2]:
+while not fused and lo > 0 and "k_embed_fwd" not in ev[lo][2]:
     lo -= 1
 t0 = ev[lo][0]
 for s, e, n, q, st in ev[lo:hi + 8]:
