@@ -526,6 +526,36 @@ def other_config(name, args, device, X, y):
         return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
 
 
+def fit_api(args, device, X, y, epochs=10):
+    """The public surface (reference basemodel.py:137-309): ``model.fit(x, y, batch_size=4096, epochs=E, verbose=0)`` on the
+    resident 4096 x 64 rows, shuffled epochs; samples/s over E epochs of a second call (the first call warms up: two
+    eager steps, then the capture of the 16-step hipGraph fit() replays on groups of rows)."""
+    import contextlib
+    import io
+    try:
+        model = build_model(args, device)
+        sink = io.StringIO()
+        with contextlib.redirect_stdout(sink):
+            model.fit(X, y, batch_size=args.batch, epochs=2, verbose=0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            hist = model.fit(X, y, batch_size=args.batch, epochs=epochs, verbose=0)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        n = X.shape[0]
+        steps = epochs * ((n - 1) // args.batch + 1)
+        res = {"call": "model.fit(x, y, batch_size=%d, epochs=%d, verbose=0, shuffle=True)" % (args.batch, epochs),
+               "rows": n, "value": epochs * n / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3,
+               "steps": steps, "last_epoch_loss": float(hist.history["loss"][-1]),
+               "steps_per_graph": int(os.environ.get("DCTR_FIT_STEPS_PER_GRAPH", "16"))}
+        del model
+        torch.cuda.empty_cache()
+        return res
+    except Exception as exc:
+        torch.cuda.synchronize()
+        return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+
+
 def auto_steps_per_graph(steps):
     # (a replay boundary costs ~25 us, but 50 steps per graph measured 2.5 % SLOWER per step than 25: every captured step
     # has its own activation buffers, 40 MB each)
@@ -693,6 +723,10 @@ def main():
             del model
             torch.cuda.empty_cache()
             result["other_configs"] = {name: other_config(name, args, device, X, y) for name in OTHER}
+            result["other_configs"]["fit_api"] = fit_api(args, device, X, y)
+            fa = result["other_configs"]["fit_api"]
+            if "value" in fa:
+                fa["vs_step_runner"] = fa["value"] / value
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args)
     if dist:

@@ -144,6 +144,10 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
                                                         int32_t* __restrict__ ids_t,
                                                         uint16_t* __restrict__ parts_t, int n_parts,
                                                         float* __restrict__ fm_s, int64_t lds_, int stage_off) {
+  // No fused multiply-adds in this body: the fused train launch (csrc/mlp.hip, dctr_embed_tower_train_step) computes the
+  // same linear logit / FM term / sum_f e inside the tower kernel and must land on the same bits -- with contraction left
+  // to the compiler the two bodies were contracted differently (round 4: losses equal for 30 steps, then off by one ulp).
+#pragma clang fp contract(off)
   constexpr int SPB = kWave / LPR;
   constexpr int CH = 8;   // row loads in flight per lane and per pass (x4 waves = 32 fields)
   constexpr int WCH = 2;  // wide loads in flight per lane and per pass

@@ -960,6 +960,7 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
     // ---- FM's per-sample sums in k_embed_fwd's order of additions: wave w of that kernel takes fields w, w + 4, ...; its
     // wave 0 then adds the four partial sums in wave order
     for (int e = tid; e < kTM * G.D; e += kT) {
+#pragma clang fp contract(off)      // (k_embed_fwd's roundings: products and sums rounded separately)
       const int r = e / G.D, d = e - r * G.D;
       float st = 0.f, qt = 0.f;
       for (int w = 0; w < 4; ++w) {
@@ -967,13 +968,13 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
         for (int f = w; f < G.n_deep; f += 4) {
           const float v = xs[r * rsx + f * G.D + d];
           sw += v;
-          qw = __builtin_fmaf(v, v, qw);
+          qw += v * v;
         }
         st += sw;
         qt += qw;
       }
       S.st[e] = st;
-      S.tm[e] = __builtin_fmaf(st, st, -qt);
+      S.tm[e] = st * st - qt;
     }
   } else {
     {
@@ -1076,6 +1077,7 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
         // (lane gl owns the strip [4 gl, 4 gl + 4) of the row and the wide fields gl, gl + lpr, ... of each "wave" w)
         const int lpr = 1 << G.lpr_shift;
         if (tid < kTM * lpr) {
+#pragma clang fp contract(off)
           const int r = tid >> G.lpr_shift, gl = tid & (lpr - 1);
           float t = 0.f;
 #pragma unroll
@@ -1086,7 +1088,7 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
             for (int f = w * lpr + gl; f < G.n_wide; f += 4 * lpr) pw += S.wv[r * 32 + f];
             if (G.wdense_w)
               for (int j = w * lpr + gl; j < G.n_wdense; j += 4 * lpr)
-                pw = __builtin_fmaf(S.x[r * G.nc + S.wcol[j]], S.ww[j], pw);
+                pw += S.x[r * G.nc + S.wcol[j]] * S.ww[j];
             wt += pw;
           }
           for (int m = lpr >> 1; m >= 1; m >>= 1) {

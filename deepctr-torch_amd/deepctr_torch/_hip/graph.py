@@ -156,6 +156,41 @@ class GraphedTrainStep(object):
         self._launch()
         return out
 
+    def step_rows(self, X_all, y_all, lo, order=None):
+        """Stage and launch a whole group straight from a device-resident dataset: rows ``[lo, lo + S*B)`` of
+        ``X_all`` / ``y_all``, visited through ``order`` (a device permutation, ``fit(shuffle=True)``) when given -- ONE
+        ``index_select`` per tensor and group into the group's static block, on the staging stream, instead of a pair
+        per step on the training stream.  Returns the list of the group's S step outputs (static tensors: valid once the
+        launch has run and until the same buffer group is reused two launches later)."""
+        if self._j != 0:
+            raise RuntimeError("step_rows() needs an empty group: flush() the staged steps first")
+        s, side = self._slot, self._side
+        n = self.S * self.x[s][0].shape[0]
+        if self._free[s] is not None:
+            side.wait_event(self._free[s])
+        if not self.inputs_ready:
+            side.wait_stream(torch.cuda.current_stream(X_all.device))
+        with torch.cuda.stream(side):
+            xg = self.xg[s].view((n,) + tuple(self.xg[s].shape[2:]))
+            yg = self.yg[s].view((n,) + tuple(self.yg[s].shape[2:]))
+            if order is None:
+                xg.copy_(X_all[lo:lo + n], non_blocking=True)
+                yg.copy_(y_all[lo:lo + n], non_blocking=True)
+            else:
+                idx = order[lo:lo + n]
+                torch.index_select(X_all, 0, idx, out=xg)
+                torch.index_select(y_all, 0, idx, out=yg)
+        outs = self.outputs[s]
+        self._j = self.S
+        self._launch()
+        return outs
+
+    def sync_inputs(self):
+        """With ``inputs_ready``: make the staging stream wait ONCE for what the caller's stream has enqueued so far (a
+        new epoch's permutation), instead of before every group."""
+        if self._side is not None:
+            self._side.wait_stream(torch.cuda.current_stream(self.x[0][0].device))
+
     def _launch(self):
         s = self._slot
         main = torch.cuda.current_stream(self.x[s][0].device)

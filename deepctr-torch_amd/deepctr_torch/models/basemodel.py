@@ -153,6 +153,8 @@ class BaseModel(nn.Module):
         self._flush_lazy()       # the pickled tables are the reference's tables
         d = dict(self.__dict__)
         d["_fit_graph"] = None
+        if d.get("_fused"):       # the step engine holds ctypes descriptors and device buffers: rebuilt on demand
+            d["_fused"] = {k: v for k, v in d["_fused"].items() if k != "engine"}
         return d
 
     def _flush_lazy(self):
@@ -645,6 +647,10 @@ class BaseModel(nn.Module):
     def _as_matrix(self, x):
         """dict / list of per-feature arrays -> one float32 ``[N, sum(widths)]`` matrix on ``self.device``
         (reference basemodel.py:155-156,191-198: np.concatenate in ``feature_index`` order)."""
+        if torch.is_tensor(x) and x.dim() == 2:
+            # (beyond the reference: a dataset that already is one [N, sum(widths)] matrix -- on the device it is used in
+            # place, nothing is concatenated or uploaded again by every fit / predict call)
+            return x.to(self.device).float()
         if isinstance(x, dict):
             x = [x[feature] for feature in self.feature_index]
         x = list(x)
@@ -1099,27 +1105,45 @@ class BaseModel(nn.Module):
             return all(g.get("lr_decay", 0) == 0 for g in opt.param_groups)
         return False
 
-    def _fit_step(self, xb, yb, batch_size):
+    def _fit_group_size(self, n_full, on_gpu):
+        """Train steps per hipGraph inside ``fit()``: a graph launch leaves the GPU idle for ~12 us, a step is 85-100 us,
+        so whole GROUPS of consecutive full-size batches replay as one graph (DCTR_FIT_STEPS_PER_GRAPH, default 16) when
+        an epoch holds enough of them; 1 = one step per graph (small datasets)."""
+        S = int(os.environ.get("DCTR_FIT_STEPS_PER_GRAPH", "16"))
+        if not on_gpu or os.environ.get("DCTR_FIT_GRAPH", "1") == "0" or S <= 1 or n_full < S + 2:
+            return 1
+        return S
+
+    def _fit_graph_ready(self, xb_like, S):
+        g = self._fit_graph
+        if g is None or g.get("graph") is None or g["fused"] is not self._fused:
+            return None
+        gr = g["graph"]
+        return gr if (gr.S == S and gr.valid_for(xb_like)) else None
+
+    def _fit_step(self, xb, yb, batch_size, S=1):
         """One training step of ``fit``: full-size batches replay a hipGraph of the train step (one launch per step
-        instead of 10-100 kernel launches through Python: 150 us instead of 520 us per DeepFM step at the Criteo
-        shape, 0.63 instead of 1.2 ms for DCN) whenever the step is replay-safe (``_graph_safe_step``); everything
-        else -- the ragged last batch, steps that bake host-side values into their launches, CPU-side debugging with
-        DCTR_FIT_GRAPH=0 -- runs ``_train_step`` directly.  Same arithmetic either way."""
+        instead of 10-100 kernel launches through Python) whenever the step is replay-safe (``_graph_safe_step``);
+        everything else -- the ragged last batch, steps that bake host-side values into their launches, CPU-side
+        debugging with DCTR_FIT_GRAPH=0 -- runs ``_train_step`` directly.  Same arithmetic either way.  ``S`` > 1: the
+        captured graph holds S steps and is replayed by ``fit`` itself on whole groups of rows
+        (``GraphedTrainStep.step_rows``); a single step beside the groups (warm-up, tail) runs eagerly."""
         self._sync_optimizer_hyper(full=False)      # (drops a captured step whose launches carry the old values)
         g = self._fit_graph
         if xb.shape[0] != batch_size or not xb.is_cuda or os.environ.get("DCTR_FIT_GRAPH", "1") == "0":
             return self._train_step(xb, yb)
-        if g is not None and g["graph"] is not None and g["graph"].valid_for(xb) and g["fused"] is self._fused:
-            return g["graph"](xb, yb)
-        if g is None or g.get("shape") != tuple(xb.shape) or g["fused"] is not self._fused:
-            g = self._fit_graph = {"shape": tuple(xb.shape), "warm": 0, "graph": None, "fused": self._fused}
+        if g is not None and g["graph"] is not None and g["graph"].valid_for(xb) and g["fused"] is self._fused and \
+                g["graph"].S == S:
+            return g["graph"](xb, yb) if S == 1 else self._train_step(xb, yb)
+        if g is None or g.get("shape") != tuple(xb.shape) or g["fused"] is not self._fused or g.get("S", 1) != S:
+            g = self._fit_graph = {"shape": tuple(xb.shape), "warm": 0, "graph": None, "fused": self._fused, "S": S}
         out = self._train_step(xb, yb)              # eager warm-up steps (also builds the fused-step state)
         g["warm"] += 1
         g["fused"] = self._fused
         if g["warm"] >= 2 and self._graph_safe_step():
             from .._hip.graph import GraphedTrainStep
             try:
-                g["graph"] = GraphedTrainStep(self, xb, yb, steps_per_graph=1).capture(xb, yb)
+                g["graph"] = GraphedTrainStep(self, xb, yb, steps_per_graph=S, inputs_ready=S > 1).capture(xb, yb)
             except Exception as e:                 # capture is an optimisation; keep training eagerly
                 import warnings
                 warnings.warn("fit(): hipGraph capture of the train step failed (%s: %s); training eagerly"
@@ -1157,7 +1181,7 @@ class BaseModel(nn.Module):
 
         self._sync_optimizer_hyper()
         X_all = self._as_matrix(x)                                   # resident in HBM for the whole fit
-        y_all = torch.from_numpy(np.asarray(y)).to(self.device).float()
+        y_all = y.to(self.device).float() if torch.is_tensor(y) else torch.from_numpy(np.asarray(y)).to(self.device).float()
         if batch_size is None:
             batch_size = 256
         self.train()
@@ -1178,42 +1202,85 @@ class BaseModel(nn.Module):
         print("Train on {0} samples, validate on {1} samples, {2} steps per epoch".format(
             sample_num, len(val_y), steps_per_epoch))
         plan = self.model_plan()
-        for epoch in range(initial_epoch, epochs):
-            cbs.on_epoch_begin(epoch)
-            epoch_logs = {}
-            start_time = time.time()
+        n_full = sample_num // batch_size
+        S = self._fit_group_size(n_full, X_all.is_cuda and X_all.device.type == "cuda")
+
+        def draw_order():
             # The reference iterates a DataLoader (:213,240): each epoch its iterator first draws a base seed from the
             # default CPU generator, then (shuffle=True) RandomSampler draws the seed of its permutation.  The same two
             # draws here: after torch.manual_seed(s) both implementations visit the rows in the same order.
             torch.empty((), dtype=torch.int64).random_()
-            if shuffle:
-                seed = int(torch.empty((), dtype=torch.int64).random_().item())
-                gen = torch.Generator()
-                gen.manual_seed(seed)
-                order = torch.randperm(sample_num, generator=gen).to(self.device)
+            if not shuffle:
+                return None
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            gen = torch.Generator()
+            gen.manual_seed(seed)
+            return torch.randperm(sample_num, generator=gen).to(self.device)
+
+        # the NEXT epoch's permutation (1-2 ms of host time per 256 k rows) is drawn while the GPU still runs this epoch's
+        # steps -- only when nothing else can draw from the default generator in between (no validation pass, no user
+        # callbacks), so the sequence of draws stays the reference's
+        lookahead = shuffle and not do_validation and not callbacks and S > 1
+        next_order = None
+        for epoch in range(initial_epoch, epochs):
+            cbs.on_epoch_begin(epoch)
+            epoch_logs = {}
+            start_time = time.time()
+            if next_order is not None:
+                order, next_order = next_order, None
             else:
-                order = None
+                order = draw_order()
             total_acc = torch.zeros((), device=self.device, dtype=torch.float64)
             preds = [] if (verbose > 0 and self.metrics) else None
             bar = tqdm(total=steps_per_epoch, disable=verbose != 1) if tqdm is not None else None
             try:
-                for step in range(steps_per_epoch):
+                step, synced = 0, False
+                while step < steps_per_epoch:
+                    gr = self._fit_graph_ready(X_all[:batch_size], S) if (S > 1 and step + S <= n_full) else None
+                    if gr is not None:
+                        # S consecutive full-size batches: one index_select pair + one graph launch for the group
+                        self._sync_optimizer_hyper(full=False)
+                        gr = self._fit_graph_ready(X_all[:batch_size], S)
+                    if gr is not None:
+                        if not synced:
+                            gr.sync_inputs()            # this epoch's permutation is complete before the first gather
+                            synced = True
+                        lo = step * batch_size
+                        outs = gr.step_rows(X_all, y_all, lo, order)
+                        tl = [o[1] for o in outs]
+                        if all(t.numel() == 1 for t in tl):
+                            total_acc += torch.stack([t.reshape(()) for t in tl]).double().sum()
+                        else:
+                            for t in tl:
+                                total_acc += t.double().sum()
+                        if preds is not None:
+                            for j, o in enumerate(outs):
+                                a, b = lo + j * batch_size, lo + (j + 1) * batch_size
+                                yb = y_all.index_select(0, order[a:b]) if order is not None else y_all[a:b]
+                                preds.append((yb, o[2].clone()))
+                        if bar is not None:
+                            bar.update(S)
+                        step += S
+                        continue
                     lo, hi = step * batch_size, min((step + 1) * batch_size, sample_num)
                     if order is not None:
                         idx = order[lo:hi]
                         xb, yb = X_all.index_select(0, idx), y_all.index_select(0, idx)
                     else:
                         xb, yb = X_all[lo:hi], y_all[lo:hi]
-                    loss, total_loss, y_pred = self._fit_step(xb, yb, batch_size)
+                    loss, total_loss, y_pred = self._fit_step(xb, yb, batch_size, S)
                     # one launch: fp64 += fp32 promotes inside the add (cast + sum + add were three)
                     total_acc += total_loss.reshape(()) if total_loss.numel() == 1 else total_loss.double().sum()
                     if preds is not None:
                         preds.append((yb, y_pred.clone()))
                     if bar is not None:
                         bar.update(1)
+                    step += 1
             finally:
                 if bar is not None:
                     bar.close()
+            if lookahead and epoch + 1 < epochs:
+                next_order = draw_order()
             plan.check_ids()
             epoch_logs["loss"] = float(total_acc.item()) / sample_num
             if preds is not None:
