@@ -93,9 +93,13 @@ class GraphedTrainStep(object):
                 try:
                     for j in range(self.S):
                         model._defer_dense_join = j < self.S - 1      # (see BaseModel._train_step_fused)
+                        # the batch of the NEXT captured step is known (it sits in the group's static block): the step
+                        # engine enqueues its id-only pre-pass right behind this step's embedding update (_hip/step.py)
+                        model._next_batch = self.x[s][j + 1] if j + 1 < self.S else None
                         outs.append(model._train_step(self.x[s][j], self.y[s][j]))
                 finally:
                     model._defer_dense_join = False
+                    model._next_batch = None
             if pool is None:
                 pool = g.pool()
             self.graphs.append(g)

@@ -59,7 +59,8 @@ class GatherStep(object):
         spec = _mlp.tower_layers(model.dnn, model.dnn_linear)
         self.layers, self.w_out = spec
         self.want_fm = bool(getattr(model, "use_fm", False)) and len(model.model_plan().deep) > 0
-        self.sync = None          # topology "fused_flags": the device-side dependency words (include/dctr.h)
+        self._prepassed = None    # token of the batch whose pre-pass the previous step already enqueued
+        self._events, self._ev_i = None, 0
         self.timing = None        # (start, end) events around the update on its queue: bench.py's in-step roofline
 
     # ---- applicability ------------------------------------------------------------------------------------------
@@ -130,10 +131,23 @@ class GatherStep(object):
         return b
 
     # ---- one step -------------------------------------------------------------------------------------------------
-    def step(self, xb, yb, mode, defer_join=False):
+    def _prepass(self, b, cplan, xb, B, stream_handle):
+        """ids + partition tags from X, then every (unit, partition)'s entries found and sorted: all the update needs
+        that is not a gradient."""
+        lib = L.lib()
+        plan = self.model.model_plan()
+        units, n_units = plan.units_ptr(), len(plan.units)
+        L.check(lib.dctr_embed_ids(cplan, units, n_units, _ptr(xb), xb.stride(0), B, _ptr(b.ids_t), _ptr(b.parts_t),
+                                   stream_handle), "dctr_embed_ids")
+        L.check(lib.dctr_embed_segments(cplan, units, n_units, plan.max_vocab, _ptr(b.ids_t), _ptr(b.parts_t), B,
+                                        _ptr(b.upd_ws), b.upd_n, stream_handle), "dctr_embed_segments")
+
+    def step(self, xb, yb, mode, next_xb=None):
         """Enqueue one train step on (xb, yb); returns (loss, y_pred) device tensors.  ``mode``: the dense optimizer's
-        (kind, lr, eps).  ``defer_join``: inside a multi-step hipGraph capture (not its last step) with the "fused_flags"
-        topology the main queue does not wait for the side queue through a graph edge."""
+        (kind, lr, eps).  ``next_xb``: the batch of the step that follows, when the caller knows it (the captured steps of
+        a multi-step hipGraph): its pre-pass is enqueued on the side queue right behind this step's update, so that it
+        runs in the shadow of the queue hop back to the main queue instead of beside the next tower launch (measured:
+        the pre-pass's 1118 workgroups beside the tower cost the tower 4 of its 53 us, profiles/r04_*timeline*)."""
         lib = L.lib()
         model, slab = self.model, self.slab
         plan = model.model_plan()
@@ -163,28 +177,25 @@ class GatherStep(object):
         if getattr(ws_u, "_dctr_owner", None) is not None:      # an abandoned pre-pass of the autograd route left counts
             ws_u.zero_()
             ws_u._dctr_owner = None
+            self._prepassed = None
         units, n_units = plan.units_ptr(), len(plan.units)
         ld = plan.ld_out
         ld_s = b.fm_s.stride(0) if b.fm_s is not None else 0
-        topo = os.environ.get("DCTR_STEP_TOPOLOGY", "update_side")
-        serial = topo == "serial" or not cuda
-        flags = topo == "fused_flags" and cuda
-        if flags and self.sync is None and torch.cuda.is_current_stream_capturing():
-            flags = False        # (a capture without an eager step in front of it: plain graph edges)
-        elif flags:
-            self._sync_block(dev)
+        serial = os.environ.get("DCTR_STEP_TOPOLOGY", "update_side") == "serial" or not cuda
         main = torch.cuda.current_stream(dev) if cuda else None
         side = _streams.side_stream(dev, "seg") if (cuda and not serial) else None
         on_side = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
+        # (did the previous step already enqueue THIS batch's pre-pass?  Only ever inside one hipGraph capture: the token
+        # names the batch's memory, the buffers and the capture)
+        token = (xb.data_ptr(), xb.stride(0), B, id(b), bool(cuda and torch.cuda.is_current_stream_capturing()))
+        have_prepass = self._prepassed is not None and self._prepassed == token and token[4]
+        self._prepassed = None
         try:
-            if side is not None:
-                side.wait_stream(main)       # X is complete; (first step of a capture: the side queue joins the capture)
-            with on_side():
-                sh = L.stream_handle(dev)
-                L.check(lib.dctr_embed_ids(cplan, units, n_units, _ptr(xb), xb.stride(0), B, _ptr(b.ids_t),
-                                           _ptr(b.parts_t), sh), "dctr_embed_ids")
-                L.check(lib.dctr_embed_segments(cplan, units, n_units, plan.max_vocab, _ptr(b.ids_t), _ptr(b.parts_t), B,
-                                                _ptr(ws_u), b.upd_n, sh), "dctr_embed_segments")
+            if not have_prepass:
+                if side is not None:
+                    side.wait_stream(main)   # X is complete; (first step of a capture: the side queue joins the capture)
+                with on_side():
+                    self._prepass(b, cplan, xb, B, L.stream_handle(dev))
             mh = L.stream_handle(dev)
             L.check(lib.dctr_embed_tower_train_step(cplan, _ptr(xb), xb.stride(0), ctypes.byref(b.desc), B,
                                                     1 if self.want_fm else 0, _ptr(bias), _ptr(y), _ptr(y_pred),
@@ -206,23 +217,28 @@ class GatherStep(object):
                                               _ptr(ws_u), b.upd_n, 1, sh), "dctr_embed_update")
                 if self.timing is not None:
                     self.timing[1].record(side if side is not None else main)
-                if flags and defer_join:
-                    L.check(lib.dctr_step_signal(_ptr(self._sync_block(dev)), L.SYNC_UPDATE, sh), "dctr_step_signal")
             if side is not None:
-                if flags and defer_join:
-                    # no graph edge from the side queue back to the main one: a one-wave kernel on the main queue polls
-                    # the word the side queue's signal kernel advances behind the update
-                    L.check(lib.dctr_step_wait(_ptr(self._sync_block(dev)), L.SYNC_UPDATE, 20000, mh), "dctr_step_wait")
-                else:
-                    main.wait_stream(side)
+                # the main queue waits for the UPDATE (an event at the side queue's tail of now); what follows on the side
+                # queue -- the next batch's pre-pass -- is not waited for
+                ev = self._join_event()
+                ev.record(side)
+                nxt = next_xb if (next_xb is not None and torch.cuda.is_current_stream_capturing() and
+                                  tuple(next_xb.shape) == tuple(xb.shape) and next_xb.dtype == xb.dtype and
+                                  next_xb.stride() == xb.stride()) else None
+                if nxt is not None:
+                    with on_side():
+                        self._prepass(b, cplan, nxt, B, L.stream_handle(dev))
+                    self._prepassed = (nxt.data_ptr(), nxt.stride(0), B, id(b), True)
+                main.wait_event(ev)
         finally:
             slab.inline_done = True
             slab.end_inline_step()
         return loss, y_pred
 
-    def _sync_block(self, dev):
-        if self.sync is None or self.sync.device != dev:
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("the step's sync block must exist before a hipGraph capture begins (run one eager step)")
-            self.sync = torch.zeros(L.SYNC_INTS, dtype=torch.int32, device=dev)
-        return self.sync
+    def _join_event(self):
+        """Two events that live as long as the engine, used alternately (an event created inside a hipGraph capture and
+        collected during a later one aborts the process: graph.no_gc_during_capture)."""
+        if self._events is None:
+            self._events = [torch.cuda.Event(), torch.cuda.Event()]
+        self._ev_i = 1 - self._ev_i
+        return self._events[self._ev_i]

@@ -779,7 +779,7 @@ class BaseModel(nn.Module):
         if eng is None and getattr(self, "_gather_step", False) and _step.GatherStep.enabled():
             eng = st["engine"] = _step.GatherStep(self, slab)
         if eng is not None and _step.GatherStep.enabled() and eng.supports(xb, yb):
-            loss, y_pred = eng.step(xb, yb, mode, defer_join=getattr(self, "_defer_dense_join", False))
+            loss, y_pred = eng.step(xb, yb, mode, next_xb=getattr(self, "_next_batch", None))
             slab.step(*mode)          # (applied inside the gradient kernels: clears the flag)
             return loss, loss.reshape(1), y_pred
         self._grad_sink = slab
