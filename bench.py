@@ -528,26 +528,36 @@ def other_config(name, args, device, X, y):
 
 def fit_api(args, device, X, y, epochs=10):
     """The public surface (reference basemodel.py:137-309): ``model.fit(x, y, batch_size=4096, epochs=E, verbose=0)`` on the
-    resident 4096 x 64 rows, shuffled epochs; samples/s over E epochs of a second call (the first call warms up: two
-    eager steps, then the capture of the 16-step hipGraph fit() replays on groups of rows)."""
+    resident 4096 x 64 rows; samples/s over E epochs of a second call (the first call warms up: two eager steps, then the
+    capture of the 16-step hipGraph fit() replays on groups of rows).  `value` is the default call (shuffle=True): every
+    epoch draws the reference's own permutation -- ``torch.randperm(n, generator=...)`` on the HOST, exactly the
+    RandomSampler of the reference's DataLoader (basemodel.py:213), so that both visit the rows in the same order -- which
+    on a 6 ms epoch is most of the wall time; ``shuffle_false`` is the same call without it (the device pipeline alone)."""
     import contextlib
     import io
     try:
         model = build_model(args, device)
         sink = io.StringIO()
-        with contextlib.redirect_stdout(sink):
-            model.fit(X, y, batch_size=args.batch, epochs=2, verbose=0)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            hist = model.fit(X, y, batch_size=args.batch, epochs=epochs, verbose=0)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
         n = X.shape[0]
         steps = epochs * ((n - 1) // args.batch + 1)
-        res = {"call": "model.fit(x, y, batch_size=%d, epochs=%d, verbose=0, shuffle=True)" % (args.batch, epochs),
-               "rows": n, "value": epochs * n / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3,
-               "steps": steps, "last_epoch_loss": float(hist.history["loss"][-1]),
-               "steps_per_graph": int(os.environ.get("DCTR_FIT_STEPS_PER_GRAPH", "16"))}
+        res = {"call": "model.fit(x, y, batch_size=%d, epochs=%d, verbose=0)" % (args.batch, epochs), "rows": n,
+               "steps": steps, "unit": "samples/s", "steps_per_graph": int(os.environ.get("DCTR_FIT_STEPS_PER_GRAPH", "16"))}
+        with contextlib.redirect_stdout(sink):
+            model.fit(X, y, batch_size=args.batch, epochs=2, verbose=0)
+            for tag, shuffle in (("shuffle_true", True), ("shuffle_false", False)):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                hist = model.fit(X, y, batch_size=args.batch, epochs=epochs, verbose=0, shuffle=shuffle)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                res[tag] = {"value": epochs * n / dt, "ms_per_step": dt / steps * 1e3,
+                            "last_epoch_loss": float(hist.history["loss"][-1])}
+        t0 = time.perf_counter()
+        gen = torch.Generator().manual_seed(1)
+        for _ in range(3):
+            torch.randperm(n, generator=gen)
+        res["host_randperm_ms_per_epoch"] = (time.perf_counter() - t0) / 3 * 1e3
+        res["value"], res["ms_per_step"] = res["shuffle_true"]["value"], res["shuffle_true"]["ms_per_step"]
         del model
         torch.cuda.empty_cache()
         return res
@@ -727,6 +737,7 @@ def main():
             fa = result["other_configs"]["fit_api"]
             if "value" in fa:
                 fa["vs_step_runner"] = fa["value"] / value
+                fa["shuffle_false"]["vs_step_runner"] = fa["shuffle_false"]["value"] / value
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args)
     if dist:
