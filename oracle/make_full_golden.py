@@ -33,16 +33,14 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 def build(ref, name):
     import deepctr_torch.inputs as ref_inputs
     import deepctr_torch.models as ref_models
-    sparse, dense = FD.column_names()
-    cols = [ref_inputs.SparseFeat(c, FD.VOCAB, FD.DIM) for c in sparse] + [ref_inputs.DenseFeat(c, 1) for c in dense]
+    cols = FD.feature_columns(ref_inputs, FD.data_of(name))
     spec = FD.MODELS[name]
     return getattr(ref_models, spec["cls"])(cols, cols, l2_reg_linear=0, l2_reg_embedding=0, dnn_dropout=0, seed=1024,
                                             device="cpu", **spec["kwargs"])
 
 
-def set_params(model, touched):
+def set_params(model, touched, sparse):
     import torch
-    sparse, _ = FD.column_names()
     with torch.no_grad():
         for k, p in model.state_dict().items():
             if "embedding_dict" in k:
@@ -58,9 +56,8 @@ def store(out, prefix, d):
         out[prefix + "/" + k] = v
 
 
-def collect(out, tag, model, touched, get):
+def collect(out, tag, model, touched, get, sparse):
     """get(name, param) -> tensor to summarise (the gradient, or the updated parameter)"""
-    sparse, _ = FD.column_names()
     for k, p in model.named_parameters():
         t = get(k, p).detach().numpy()
         if "embedding_dict" in k:
@@ -78,10 +75,12 @@ def run(ref, name):
     import torch
     import torch.nn.functional as F
     t0 = time.time()
-    X, y = FD.inputs()
-    touched = FD.touched_rows(X)
+    data = FD.data_of(name)
+    sparse = FD.table_names(data)
+    X, y = FD.inputs(data)
+    touched = FD.touched_rows(X, data)
     model = build(ref, name)
-    set_params(model, touched)
+    set_params(model, touched, sparse)
     start = {k: v.clone() for k, v in model.state_dict().items()}
     # checksums of what the hash generated HERE: the tests regenerate the same tensors and must find the same sums
     out = {"n_touched": np.array([len(r) for r in touched]),
@@ -100,7 +99,7 @@ def run(ref, name):
     out["logit"] = cap["logit"].numpy().reshape(-1).astype(np.float32)
     out["y_pred"] = y_pred.detach().numpy().astype(np.float32)
     out["loss"] = np.array(loss.item(), np.float64)
-    collect(out, "grad", model, touched, lambda k, p: p.grad)
+    collect(out, "grad", model, touched, lambda k, p: p.grad, sparse)
     model.zero_grad(set_to_none=True)
     # the same dense gradients with the reference evaluated in fp64: how far the reference's OWN fp32 gradient is from the
     # exact one (the CIN biases sum 65 536 terms; two fp32 summation orders differ by ~2e-5 relative there) -- the test
@@ -132,7 +131,7 @@ def run(ref, name):
         total.backward()
         model.optim.step()
         out[opt_name + "_loss"] = np.array(ls.item(), np.float64)
-        collect(out, opt_name, model, touched, lambda k, p: p)
+        collect(out, opt_name, model, touched, lambda k, p: p, sparse)
         model.optim = None
         model.zero_grad(set_to_none=True)
     path = os.path.join(GOLDEN_DIR, "full", "%s.npz" % name)

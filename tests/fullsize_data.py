@@ -19,7 +19,17 @@ MODELS = {
     "deepfm": dict(cls="DeepFM", kwargs=dict(dnn_hidden_units=(256, 128))),
     "xdeepfm": dict(cls="xDeepFM", kwargs=dict(dnn_hidden_units=(256, 256), cin_layer_size=(128, 128), cin_split_half=True)),
     "fibinet": dict(cls="FiBiNET", kwargs=dict(dnn_hidden_units=(128, 128), bilinear_type="interaction")),
+    # round 4 (verdict: no full-size fixture had hot ids or a pooled field): the same DeepFM on ids ~ Zipf(1.05) -- a few
+    # ids fill most of a batch: long duplicate segments in the update, the hot-partition path -- and with one VarLen
+    # history column (maxlen 8, mean-pooled, padding id 0) next to the 26 sparse fields: the general gather / scatter path
+    "deepfm_zipf": dict(cls="DeepFM", kwargs=dict(dnn_hidden_units=(256, 128)), data="zipf"),
+    "deepfm_varlen": dict(cls="DeepFM", kwargs=dict(dnn_hidden_units=(256, 128)), data="varlen"),
 }
+HIST, HIST_LEN, HIST_COMBINER = "H", 8, "mean"
+
+
+def data_of(name):
+    return MODELS[name].get("data", "uniform")
 
 
 def _fmix(x):
@@ -55,16 +65,34 @@ def stream_of(name):
     return zlib.crc32(name.encode()) & 0x7FFFFFFF
 
 
-def inputs():
-    """X [B, 26 + 13] float32 (ids as floats, exact below 2^24; dense in [0, 1)), y [B] float32"""
+def n_xcols(data="uniform"):
+    return F_SPARSE + N_DENSE + (HIST_LEN if data == "varlen" else 0)
+
+
+def inputs(data="uniform"):
+    """X [B, 26 (+ 8) + 13] float32 (ids as floats, exact below 2^24; dense in [0, 1)), y [B] float32.
+    data: "uniform" ids (+ a planted block of duplicates) | "zipf" ids ~ Zipf(1.05) | "varlen": uniform ids + 8 history
+    columns between the sparse and the dense ones."""
     b = np.arange(BATCH, dtype=np.int64)
-    X = np.zeros((BATCH, F_SPARSE + N_DENSE), np.float32)
+    X = np.zeros((BATCH, n_xcols(data)), np.float32)
     for f in range(F_SPARSE):
-        ids = (hash_u32(b, 1000 + f, SEED_X) % np.uint64(VOCAB)).astype(np.int64)
-        ids[1:BATCH // 16] = np.where(np.arange(1, BATCH // 16) % (f + 2) == 0, ids[0], ids[1:BATCH // 16])  # duplicates
+        if data == "zipf":
+            a = 1.05            # inverse CDF of the continuous approximation (bench.py --ids zipf), in fp64
+            u = (hash_u32(b, 1000 + f, SEED_X) >> np.uint64(8)).astype(np.float64) / 16777216.0
+            ids = np.clip(np.floor(((float(VOCAB) ** (1 - a) - 1) * u + 1) ** (1 / (1 - a))), 1, VOCAB).astype(np.int64) - 1
+        else:
+            ids = (hash_u32(b, 1000 + f, SEED_X) % np.uint64(VOCAB)).astype(np.int64)
+            ids[1:BATCH // 16] = np.where(np.arange(1, BATCH // 16) % (f + 2) == 0, ids[0], ids[1:BATCH // 16])  # duplicates
         X[:, f] = ids.astype(np.float32)
+    d0 = F_SPARSE
+    if data == "varlen":
+        length = (hash_u32(b, 4000, SEED_X) % np.uint64(HIST_LEN + 1)).astype(np.int64)       # 0 .. 8 valid positions
+        for t in range(HIST_LEN):
+            ids = 1 + (hash_u32(b, 4100 + t, SEED_X) % np.uint64(VOCAB - 1)).astype(np.int64)
+            X[:, F_SPARSE + t] = np.where(t < length, ids, 0).astype(np.float32)               # 0 = padding (inputs.py:146)
+        d0 += HIST_LEN
     for j in range(N_DENSE):
-        X[:, F_SPARSE + j] = unit(b, 2000 + j, SEED_X)
+        X[:, d0 + j] = unit(b, 2000 + j, SEED_X)
     y = (hash_u32(b, 3000, SEED_X) & np.uint64(1)).astype(np.float32)
     return X, y
 
@@ -93,13 +121,30 @@ def table_rows(name, rows, dim):
     return sym(idx, stream_of(name), SEED_P, param_scale(name, (VOCAB, dim)))
 
 
-def touched_rows(X):
-    """per sparse field: the sorted unique ids of the batch"""
-    return [np.unique(X[:, f].astype(np.int64)) for f in range(F_SPARSE)]
+def touched_rows(X, data="uniform"):
+    """per table (the 26 sparse fields, then the history table): the sorted unique ids of the batch"""
+    t = [np.unique(X[:, f].astype(np.int64)) for f in range(F_SPARSE)]
+    if data == "varlen":
+        t.append(np.unique(X[:, F_SPARSE:F_SPARSE + HIST_LEN].astype(np.int64)))    # (row 0: read, masked, gradient 0)
+    return t
 
 
 def column_names():
     return ["C%d" % (i + 1) for i in range(F_SPARSE)], ["I%d" % (i + 1) for i in range(N_DENSE)]
+
+
+def table_names(data="uniform"):
+    return column_names()[0] + ([HIST] if data == "varlen" else [])
+
+
+def feature_columns(mod, data="uniform"):
+    """the model's feature columns from the SparseFeat / VarLenSparseFeat / DenseFeat of `mod` (the reference's
+    deepctr_torch.inputs or the drop-in's), in X's column order"""
+    sparse, dense = column_names()
+    cols = [mod.SparseFeat(c, VOCAB, DIM) for c in sparse]
+    if data == "varlen":
+        cols.append(mod.VarLenSparseFeat(mod.SparseFeat(HIST, VOCAB, DIM), maxlen=HIST_LEN, combiner=HIST_COMBINER))
+    return cols + [mod.DenseFeat(c, 1) for c in dense]
 
 
 # ---- what of a big tensor is stored / compared -----------------------------------------------------------------------

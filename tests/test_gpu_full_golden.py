@@ -29,22 +29,23 @@ def _golden(name):
 _CACHE = {}
 
 
-def _data():
-    if "x" not in _CACHE:
-        X, y = FD.inputs()
-        _CACHE["x"] = (X, y, FD.touched_rows(X))
-    return _CACHE["x"]
+def _data(name="deepfm"):
+    data = FD.data_of(name)
+    if data not in _CACHE:
+        X, y = FD.inputs(data)
+        _CACHE[data] = (X, y, FD.touched_rows(X, data))
+    return _CACHE[data]
 
 
 def _build(name):
+    import deepctr_torch.inputs as I
     import deepctr_torch.models as M
-    from deepctr_torch.inputs import DenseFeat, SparseFeat
-    sparse, dense = FD.column_names()
-    cols = [SparseFeat(c, FD.VOCAB, FD.DIM) for c in sparse] + [DenseFeat(c, 1) for c in dense]
+    sparse = FD.table_names(FD.data_of(name))
+    cols = FD.feature_columns(I, FD.data_of(name))
     spec = FD.MODELS[name]
     m = getattr(M, spec["cls"])(cols, cols, l2_reg_linear=0, l2_reg_embedding=0, dnn_dropout=0, seed=1024, device=DEV,
                                 **spec["kwargs"])
-    X, y, touched = _data()
+    X, y, touched = _data(name)
     with torch.no_grad():
         for k, p in m.state_dict().items():
             if "embedding_dict" in k:
@@ -56,18 +57,45 @@ def _build(name):
     return m
 
 
+# Achieved error next to its bar for every tensor compared (round-3 verdict: the dense-gradient bar is widened for the
+# tensors the MFMA kernels sum over 65 536 terms -- the margin must be visible): written to
+# gpurun_out/full_golden_errors.json when the module's tests are done (copied to profiles/ per round).
+_ERRS = []
+
+
+def _note(tag, key, err, bar):
+    _ERRS.append({"model": tag, "tensor": key, "max_abs_err": float(err), "bar": float(bar),
+                  "err_over_bar": float(err / bar) if bar > 0 else None})
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_errors():
+    yield
+    import json
+    out = os.path.join(os.path.dirname(GOLD.rstrip(os.sep).rsplit(os.sep, 1)[0]), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        worst = sorted((e for e in _ERRS if e["err_over_bar"] is not None), key=lambda e: -e["err_over_bar"])[:12]
+        with open(os.path.join(out, "full_golden_errors.json"), "w") as fh:
+            json.dump({"n": len(_ERRS), "worst_by_err_over_bar": worst, "all": _ERRS}, fh, indent=1)
+    except OSError:
+        pass
+
+
 def _check_dense(tag, key, got, g, tol_abs):
     """compare a dense tensor with its stored summary (all values, or strided sample + projections)"""
     got = np.asarray(got, np.float64)
     if key + "/all" in g:
         ref = g[key + "/all"].astype(np.float64)
         err = float(np.max(np.abs(got - ref))) if ref.size else 0.0
+        _note(tag, key, err, tol_abs(ref))
         assert err <= tol_abs(ref), "%s %s: max|d| = %.3e (bar %.3e)" % (tag, key, err, tol_abs(ref))
         return
     flat = got.reshape(-1)
     ref = g[key + "/sample"].astype(np.float64)
     err = float(np.max(np.abs(flat[::FD.STRIDE] - ref)))
     bar = tol_abs(ref)
+    _note(tag, key + " (sample)", err, bar)
     assert err <= bar, "%s %s (sample): max|d| = %.3e (bar %.3e)" % (tag, key, err, bar)
     for k in range(4):
         pr = float(np.dot(flat, FD.proj_weights(flat.size, k)))
@@ -83,6 +111,7 @@ def _check_rows(tag, key, rows, got_rows, g, tol_abs):
     ref = g[key + "/values"].astype(np.float64)
     bar = tol_abs(ref)
     err = float(np.max(np.abs(got_rows[keep] - ref)))
+    _note(tag, key + " (rows)", err, bar)
     assert err <= bar, "%s %s (rows): max|d| = %.3e (bar %.3e)" % (tag, key, err, bar)
     idx = rows[:, None] * got_rows.shape[1] + np.arange(got_rows.shape[1], dtype=np.int64)[None, :]
     for k in range(4):
@@ -94,7 +123,7 @@ def _check_rows(tag, key, rows, got_rows, g, tol_abs):
 def test_full_size_logits_match_the_reference(name):
     g = _golden(name)
     m = _build(name)
-    X, y, _ = _data()
+    X, y, _ = _data(name)
     cap = {}
     hook = m.out.register_forward_pre_hook(lambda mod, inp: cap.__setitem__("logit", inp[0].detach()))
     m.train()
@@ -105,6 +134,7 @@ def test_full_size_logits_match_the_reference(name):
     m.model_plan().check_ids()
     logit = cap["logit"].reshape(-1).double().cpu().numpy()
     err = float(np.max(np.abs(logit - g["logit"].astype(np.float64))))
+    _note(name, "logit", err, 1e-5)
     assert err <= 1e-5, "%s: logit max|d| = %.3e" % (name, err)
     assert float(np.max(np.abs(y_pred.double().cpu().numpy() - g["y_pred"]))) <= 5e-6
     loss = torch.nn.functional.binary_cross_entropy(y_pred, torch.from_numpy(y).to(DEV), reduction="sum").item()
@@ -120,8 +150,8 @@ def test_full_size_train_step_matches_the_reference(name, opt):
     gradients as well"""
     g = _golden(name)
     m = _build(name)
-    X, y, touched = _data()
-    sparse, _ = FD.column_names()
+    X, y, touched = _data(name)
+    sparse = FD.table_names(FD.data_of(name))
     w0 = {k: v.detach().clone() for k, v in m.state_dict().items() if "embedding_dict" not in k}
     m.compile(opt, "binary_crossentropy", metrics=[])
     if opt == "adagrad":

@@ -138,9 +138,9 @@ def test_full_size_fixture_inputs_regenerate_bit_for_bit():
     only; inputs and parameters come from tests/fullsize_data.py's integer hash on both sides.  The generator must give here
     what it gave in the run that produced the fixtures."""
     import fullsize_data as FD
-    X, y = FD.inputs()
-    touched = FD.touched_rows(X)
     for name in FD.MODELS:
+        X, y = FD.inputs(FD.data_of(name))
+        touched = FD.touched_rows(X, FD.data_of(name))
         z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full", "%s.npz" % name))
         assert float(z["check/X"]) == float(X.astype(np.float64).sum())
         assert float(z["check/y"]) == float(y.sum())
