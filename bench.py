@@ -526,39 +526,49 @@ def other_config(name, args, device, X, y):
         return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
 
 
-def fit_api(args, device, X, y, epochs=10):
-    """The public surface (reference basemodel.py:137-309): ``model.fit(x, y, batch_size=4096, epochs=E, verbose=0)`` on the
-    resident 4096 x 64 rows; samples/s over E epochs of a second call (the first call warms up: two eager steps, then the
-    capture of the 16-step hipGraph fit() replays on groups of rows).  `value` is the default call (shuffle=True): every
-    epoch draws the reference's own permutation -- ``torch.randperm(n, generator=...)`` on the HOST, exactly the
-    RandomSampler of the reference's DataLoader (basemodel.py:213), so that both visit the rows in the same order -- which
-    on a 6 ms epoch is most of the wall time; ``shuffle_false`` is the same call without it (the device pipeline alone)."""
+def fit_api(args, device, X, y, epochs=5, tile=10):
+    """The public surface (reference basemodel.py:137-309): ``model.fit(x, y, batch_size=4096, epochs=E, verbose=0)`` on a
+    device-resident dataset; samples/s over E epochs of a second call (the first call warms up: two eager steps, then the
+    capture of the 16-step hipGraph fit() replays on groups of rows).  `value` is the DEFAULT call (shuffle=True) on the
+    resident rows tiled `tile` times (640 steps per epoch): every epoch draws the reference's own permutation --
+    ``torch.randperm(n, generator=...)`` on the HOST, exactly the RandomSampler of the reference's DataLoader
+    (basemodel.py:213), so that both visit the rows in the same order; epoch e + 1's permutation is drawn while the GPU still
+    runs epoch e.  ``shuffle_false`` is the same call without it; ``small_epochs`` the 4096 x 64 rows themselves (64-step
+    epochs of ~6 ms of GPU time each, where the per-epoch host work -- the permutation above all -- is most of the wall time)."""
     import contextlib
     import io
     try:
         model = build_model(args, device)
         sink = io.StringIO()
-        n = X.shape[0]
+        Xb, yb = X.repeat(tile, 1), y.repeat(tile)
+        n = Xb.shape[0]
         steps = epochs * ((n - 1) // args.batch + 1)
         res = {"call": "model.fit(x, y, batch_size=%d, epochs=%d, verbose=0)" % (args.batch, epochs), "rows": n,
                "steps": steps, "unit": "samples/s", "steps_per_graph": int(os.environ.get("DCTR_FIT_STEPS_PER_GRAPH", "16"))}
         with contextlib.redirect_stdout(sink):
-            model.fit(X, y, batch_size=args.batch, epochs=2, verbose=0)
+            model.fit(Xb, yb, batch_size=args.batch, epochs=1, verbose=0)
             for tag, shuffle in (("shuffle_true", True), ("shuffle_false", False)):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                hist = model.fit(X, y, batch_size=args.batch, epochs=epochs, verbose=0, shuffle=shuffle)
+                hist = model.fit(Xb, yb, batch_size=args.batch, epochs=epochs, verbose=0, shuffle=shuffle)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
                 res[tag] = {"value": epochs * n / dt, "ms_per_step": dt / steps * 1e3,
                             "last_epoch_loss": float(hist.history["loss"][-1])}
+            n0, e0 = X.shape[0], 10
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.fit(X, y, batch_size=args.batch, epochs=e0, verbose=0)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res["small_epochs"] = {"rows": n0, "epochs": e0, "value": e0 * n0 / dt,
+                                   "ms_per_step": dt / (e0 * ((n0 - 1) // args.batch + 1)) * 1e3}
         t0 = time.perf_counter()
         gen = torch.Generator().manual_seed(1)
-        for _ in range(3):
-            torch.randperm(n, generator=gen)
-        res["host_randperm_ms_per_epoch"] = (time.perf_counter() - t0) / 3 * 1e3
+        torch.randperm(n, generator=gen)
+        res["host_randperm_ms_per_epoch"] = (time.perf_counter() - t0) * 1e3
         res["value"], res["ms_per_step"] = res["shuffle_true"]["value"], res["shuffle_true"]["ms_per_step"]
-        del model
+        del model, Xb, yb
         torch.cuda.empty_cache()
         return res
     except Exception as exc:
