@@ -547,11 +547,13 @@ class ShardedTrainer(object):
         # gains -- 255 vs 234 us per step on MI355X; the multi-rank effect is unmeasured)
         self.overlap_wgrad = os.environ.get("DCTR_SHARDED_OVERLAP_WGRAD", "0") == "1"
         self._side = None
+        self._pre = None          # (chunks, ids) of the announced next batch, gathered at the end of the previous call
         self._shape = None
         self._leaves = None
         self.plan.sharder = self
 
     def close(self):
+        self._join()
         self.plan.sharder = None
 
     def set_use_graphs(self, on):
@@ -667,11 +669,99 @@ class ShardedTrainer(object):
     def train_step(self, xb, yb, next_xb=None):
         """One optimizer step on the gradient of the loss summed over every rank's batch.  ``next_xb`` (optional):
         the batch of the NEXT call -- its ids are shipped to the owners together with this step's row gradients,
-        which saves that step's ids all-to-all.  Every rank must announce (or not) consistently."""
+        which saves that step's ids all-to-all.  Every rank must announce (or not) consistently.
+
+        Queues on a GPU (round 4; profiles/r03_sharded_1rank_timeline.txt showed one queue, every kernel serial, and
+        ~40 % of the step idle between host-issued pieces):
+          main   rows all-to-all -> [assemble, tower + head + backward-data, assemble^T] -> gradient all-to-all -> owners'
+                 update -> owners' gather for the NEXT batch (its ids arrived with the gradients)
+          side   the tower's weight gradients + reduction -> all-reduce of the dense gradient slab -> dense optimizer step
+                 (beside the gradient all-to-all and the update; joined in front of the next tower launch)
+          copy   this call's batch and the announced next batch's ids into the static buffers the captured segment reads
+                 (beside the rows all-to-all)"""
         if self.slab is not None and not self.slab.intact():
             raise RuntimeError("a dense parameter was re-allocated; build a new ShardedTrainer")
         if self._shape != (tuple(xb.shape), tuple(yb.shape)):
             self._build(xb, yb)
+            self._pre = None
+        lay, B = self.layout, xb.shape[0]
+        cuda = xb.device.type == "cuda"
+        queues = cuda and self.slab is not None and os.environ.get("DCTR_SHARDED_QUEUES", "1") != "0"
+        if not queues:
+            return self._train_step_serial(xb, yb, next_xb)
+        from ._hip import streams as _streams
+        main = torch.cuda.current_stream(xb.device)
+        if self._side is None:
+            self._side = _streams.side_stream(xb.device, "shard")
+            self._copy = _streams.side_stream(xb.device, "stage")
+            # (events that live as long as the trainer: one created per step could be collected during a later hipGraph
+            # capture, which HIP answers with an abort -- _hip/graph.py no_gc_during_capture)
+            self._ev = {k: torch.cuda.Event() for k in ("copied", "computed", "dense", "loss")}
+            self._side_busy = False
+        side, cp, ev = self._side, self._copy, self._ev
+        key = (xb.data_ptr(), xb._version)
+        announced = self._announced == key and self._pre is not None
+        # ---- copy queue: what the captured compute segment reads.  (Behind the previous step's compute segment, which read
+        # the same buffers; whatever produced xb / yb / next_xb ran on the caller's stream.)
+        cp.wait_stream(main)
+        with torch.cuda.stream(cp):
+            self._x.copy_(xb, non_blocking=True)
+            self._y.copy_(yb, non_blocking=True)
+            if next_xb is not None and tuple(next_xb.shape) == tuple(xb.shape):
+                self._ids_next.copy_(self.ops.pack_ids(next_xb))
+            ev["copied"].record(cp)
+        if next_xb is not None and tuple(next_xb.shape) == tuple(xb.shape):
+            next_key = (next_xb.data_ptr(), next_xb._version)
+        else:
+            next_key = None
+        # ---- main queue
+        if announced:
+            chunks, self._ids_t = self._pre              # gathered at the end of the previous call
+        else:
+            main.wait_event(ev["copied"])
+            self._ids_tmp.copy_(self.ops.pack_ids(self._x))
+            ids_all = torch.empty_like(self._ids_tmp)
+            dist.all_to_all_single(ids_all, self._ids_tmp, group=self.group)
+            self._ids_view.copy_(ids_all.view(lay.world * B, lay.n_slots))
+            chunks, self._ids_t = self._segB()
+        self._pre = None
+        dist.all_to_all_single(self._recv, chunks, group=self.group)                 # rows -> samples' ranks
+        main.wait_event(ev["copied"])
+        if self._side_busy:
+            main.wait_event(ev["dense"])          # the previous step's dense optimizer step wrote the weights read next
+        self.overlap_wgrad = True
+        send, loss, y_pred = self._segC()
+        ev["computed"].record(main)
+        wgrad = self.slab.deferred
+        # ---- side queue: weight gradients, all-reduce, dense step
+        side.wait_event(ev["computed"])
+        with torch.cuda.stream(side):
+            if wgrad is not None:
+                wgrad(side)
+            ev["loss"].record(side)                   # `loss` (finished by the reduction) is complete here
+            work = dist.all_reduce(self.slab.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work.wait()
+            self._segE()
+            ev["dense"].record(side)
+        self._side_busy = True
+        # ---- main queue goes on: gradient exchange, owners' update, owners' gather for the announced batch
+        dist.all_to_all_single(self._grads_all, send, group=self.group)              # row gradients (+ next ids)
+        self._segD()
+        self._announced = next_key
+        if next_key is not None:
+            self._pre = self._segB()
+        main.wait_event(ev["loss"])                   # what this call returns is complete on the caller's stream
+        return loss, loss.reshape(1), y_pred
+
+    def _join(self):
+        """The caller's stream waits for everything a previous train_step left on the trainer's own queues."""
+        if self._side is not None and getattr(self, "_side_busy", False):
+            torch.cuda.current_stream(self._side.device).wait_event(self._ev["dense"])
+            self._side_busy = False
+
+    def _train_step_serial(self, xb, yb, next_xb=None):
+        """The same step on ONE queue in program order (CPU stand-ins over gloo, the autograd route,
+        DCTR_SHARDED_QUEUES=0)."""
         lay, B = self.layout, xb.shape[0]
         self._x.copy_(xb)
         self._y.copy_(yb)
@@ -712,6 +802,7 @@ class ShardedTrainer(object):
         """Make every rank's copy of every table (and its optimizer state) current: owner -> all."""
         plan = self.plan
         from ._hip.plan import _STATE
+        self._join()
         with torch.no_grad():
             for u, (di, wi, col, _) in enumerate(plan.units):
                 owner = self.layout.owner[u]
