@@ -701,31 +701,40 @@ class ShardedTrainer(object):
         side, cp, ev = self._side, self._copy, self._ev
         key = (xb.data_ptr(), xb._version)
         announced = self._announced == key and self._pre is not None
-        # ---- copy queue: what the captured compute segment reads.  (Behind the previous step's compute segment, which read
-        # the same buffers; whatever produced xb / yb / next_xb ran on the caller's stream.)
-        cp.wait_stream(main)
-        with torch.cuda.stream(cp):
-            self._x.copy_(xb, non_blocking=True)
-            self._y.copy_(yb, non_blocking=True)
-            if next_xb is not None and tuple(next_xb.shape) == tuple(xb.shape):
-                self._ids_next.copy_(self.ops.pack_ids(next_xb))
-            ev["copied"].record(cp)
         if next_xb is not None and tuple(next_xb.shape) == tuple(xb.shape):
             next_key = (next_xb.data_ptr(), next_xb._version)
         else:
             next_key = None
-        # ---- main queue
+
+        def copies():
+            # what the captured compute segment reads.  (Behind the previous step's compute segment, which read the same
+            # buffers; whatever produced xb / yb / next_xb ran on the caller's stream.)
+            cp.wait_stream(main)
+            with torch.cuda.stream(cp):
+                self._x.copy_(xb, non_blocking=True)
+                self._y.copy_(yb, non_blocking=True)
+                if next_key is not None:
+                    self._ids_next.copy_(self.ops.pack_ids(next_xb))
+                ev["copied"].record(cp)
+
+        # The HOST issues every piece of this step and is barely ahead of the GPU: what lies on the step's critical chain
+        # is enqueued first, everything else behind it (round 4: with the side queue's work issued in front of the gradient
+        # all-to-all the main queue idled ~50 us per step waiting for the host).
         if announced:
             chunks, self._ids_t = self._pre              # gathered at the end of the previous call
+            self._pre = None
+            dist.all_to_all_single(self._recv, chunks, group=self.group)             # rows -> samples' ranks
+            copies()
         else:
+            copies()
             main.wait_event(ev["copied"])
             self._ids_tmp.copy_(self.ops.pack_ids(self._x))
             ids_all = torch.empty_like(self._ids_tmp)
             dist.all_to_all_single(ids_all, self._ids_tmp, group=self.group)
             self._ids_view.copy_(ids_all.view(lay.world * B, lay.n_slots))
             chunks, self._ids_t = self._segB()
-        self._pre = None
-        dist.all_to_all_single(self._recv, chunks, group=self.group)                 # rows -> samples' ranks
+            self._pre = None
+            dist.all_to_all_single(self._recv, chunks, group=self.group)             # rows -> samples' ranks
         main.wait_event(ev["copied"])
         if self._side_busy:
             main.wait_event(ev["dense"])          # the previous step's dense optimizer step wrote the weights read next
@@ -733,7 +742,12 @@ class ShardedTrainer(object):
         send, loss, y_pred = self._segC()
         ev["computed"].record(main)
         wgrad = self.slab.deferred
-        # ---- side queue: weight gradients, all-reduce, dense step
+        dist.all_to_all_single(self._grads_all, send, group=self.group)              # row gradients (+ next ids)
+        self._segD()                                                                  # owners' update
+        self._announced = next_key
+        if next_key is not None:
+            self._pre = self._segB()                                                  # owners' gather for the next call
+        # ---- side queue: weight gradients, all-reduce, dense step -- beside the exchange and the update above
         side.wait_event(ev["computed"])
         with torch.cuda.stream(side):
             if wgrad is not None:
@@ -744,12 +758,6 @@ class ShardedTrainer(object):
             self._segE()
             ev["dense"].record(side)
         self._side_busy = True
-        # ---- main queue goes on: gradient exchange, owners' update, owners' gather for the announced batch
-        dist.all_to_all_single(self._grads_all, send, group=self.group)              # row gradients (+ next ids)
-        self._segD()
-        self._announced = next_key
-        if next_key is not None:
-            self._pre = self._segB()
         main.wait_event(ev["loss"])                   # what this call returns is complete on the caller's stream
         return loss, loss.reshape(1), y_pred
 
