@@ -39,7 +39,91 @@ __global__ __launch_bounds__(64) void k_step_signal(int32_t* sync, int signal) {
   __hip_atomic_fetch_add(gen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- direct exchange between the ranks of a table-sharded job (deepctr_torch/parallel.py DirectExchange) -------------
+// Every rank owns receive buffers other ranks' copy engines write into (IPC-mapped device memory) and one arrival word per
+// (exchange, sender).  A step's exchanges are numbered by a counter every rank keeps on its own device and advances in
+// lock-step; a sender POSTS the counter's value into its word on every receiver behind its copies (stream order: the
+// copies have completed), a receiver WAITS until all n words have reached its own counter.  Words only grow: a sender
+// that is a whole exchange ahead cannot be mistaken for the current one, and no word is ever reset.
+__global__ __launch_bounds__(64) void k_exch_post(int32_t* const* __restrict__ peer_words, int n, int my_index,
+                                                  const int32_t* __restrict__ step) {
+  const int r = threadIdx.x;
+  if (r >= n) return;
+  const int32_t v = __hip_atomic_load(step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(peer_words[r] + my_index, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(64) void k_exch_wait(const int32_t* __restrict__ words, int n, const int32_t* __restrict__ step,
+                                                  unsigned long long timeout_ticks, int32_t* err) {
+  const int r = threadIdx.x;
+  const int32_t want = __hip_atomic_load(step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long t0 = wall_clock64();
+  bool ok = r >= n;
+  while (!ok) {
+    const int32_t v = __hip_atomic_load(words + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+    ok = v - want >= 0;
+    if (!ok) {
+      if (wall_clock64() - t0 > timeout_ticks) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  if (!ok && err) __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void k_exch_next(int32_t* step) {
+  if (threadIdx.x == 0) *step = *step + 1;
+}
+
+// dst[i] = sum over the n ranks' slabs, in rank order (every rank computes the same bits): the dense gradients' all-reduce
+// as all-gather by copy engines + this local sum
+__global__ __launch_bounds__(256) void k_sum_ranks(float* __restrict__ dst, const float* __restrict__ src, int n_ranks,
+                                                   int64_t n, int64_t ld) {
+  const int64_t i = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (i + 3 < n) {
+    for (int r = 0; r < n_ranks; ++r) acc += *(const DCTR_GLOBAL f32x4*)(src + r * ld + i);
+    *(DCTR_GLOBAL f32x4*)(dst + i) = acc;
+  } else {
+    for (int64_t k = i; k < n; ++k) {
+      float a = 0.f;
+      for (int r = 0; r < n_ranks; ++r) a += ldg_f32(src + r * ld + k);
+      stg_f32(dst + k, a);
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int dctr_exchange_post(int32_t* const* peer_words, int32_t n, int32_t my_index, const int32_t* step,
+                                  dctr_stream_t stream) {
+  if (!peer_words || !step || n <= 0 || n > 64 || my_index < 0) return DCTR_EINVAL;
+  k_exch_post<<<dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream)>>>(peer_words, n, my_index, step);
+  return launch_status();
+}
+
+extern "C" int dctr_exchange_wait(const int32_t* words, int32_t n, const int32_t* step, int32_t timeout_us, int32_t* err,
+                                  dctr_stream_t stream) {
+  if (!words || !step || n <= 0 || n > 64 || timeout_us <= 0) return DCTR_EINVAL;
+  k_exch_wait<<<dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream)>>>(
+      words, n, step, static_cast<unsigned long long>(timeout_us) * 100ull, err);
+  return launch_status();
+}
+
+extern "C" int dctr_exchange_next(int32_t* step, dctr_stream_t stream) {
+  if (!step) return DCTR_EINVAL;
+  k_exch_next<<<dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream)>>>(step);
+  return launch_status();
+}
+
+extern "C" int dctr_sum_ranks(float* dst, const float* src, int32_t n_ranks, int64_t n, int64_t ld, dctr_stream_t stream) {
+  if (!dst || !src || n_ranks <= 0 || n < 0 || ld < n) return DCTR_EINVAL;
+  if (ld % 4 != 0 || reinterpret_cast<uintptr_t>(dst) % 16 != 0 || reinterpret_cast<uintptr_t>(src) % 16 != 0) return DCTR_EALIGN;
+  if (n == 0) return DCTR_OK;
+  k_sum_ranks<<<dim3(static_cast<unsigned>((n / 4 + 256) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(
+      dst, src, n_ranks, n, ld);
+  return launch_status();
+}
 
 extern "C" int dctr_step_signal(int32_t* sync, int32_t signal, dctr_stream_t stream) {
   if (!sync || signal < 0 || signal > 2) return DCTR_EINVAL;

@@ -574,6 +574,20 @@ int dctr_step_wait(int32_t* sync, int32_t signal, int32_t timeout_us, dctr_strea
  * write-back makes its stores visible first): for a producer that cannot signal from inside its kernel.            */
 int dctr_step_signal(int32_t* sync, int32_t signal, dctr_stream_t stream);
 
+/* ---- direct exchange between the ranks of a table-sharded job (one process per GPU; deepctr_torch/parallel.py) ----------
+ * Replaces the host-issued RCCL all-to-alls / all-reduce of the sharded step (basemodel.py:206-209 is nn.DataParallel in
+ * the reference) by copies into the peers' IPC-mapped receive buffers + a word per (exchange, sender): everything is an
+ * ordinary stream operation, so the WHOLE step -- exchanges included -- is one hipGraph.  `step`: this rank's exchange
+ * counter (device int32); peer_words[r]: rank r's word array for this exchange (device pointers, IPC-mapped), my_index:
+ * this rank's slot in it.  Post behind the copies (same stream); wait in front of the consumer; next advances the counter.
+ * A wait gives up after timeout_us and raises bit 1 of *err.  dctr_sum_ranks: dst[i] = sum_r src[r * ld + i] in rank
+ * order (the dense gradients' all-reduce = all-gather by copy + this sum: every rank lands on the same bits).          */
+int dctr_exchange_post(int32_t* const* peer_words, int32_t n, int32_t my_index, const int32_t* step, dctr_stream_t stream);
+int dctr_exchange_wait(const int32_t* words, int32_t n, const int32_t* step, int32_t timeout_us, int32_t* err,
+                       dctr_stream_t stream);
+int dctr_exchange_next(int32_t* step, dctr_stream_t stream);
+int dctr_sum_ranks(float* dst, const float* src, int32_t n_ranks, int64_t n, int64_t ld, dctr_stream_t stream);
+
 /* ---- prediction head + loss (layers/core.py:154-160, basemodel.py:254, F.binary_cross_entropy(reduction='sum'))
  *     z = sum_i part_i[b] + bias ;  y_pred = sigmoid(z) ;  loss = sum_b -(y log p + (1-y) log(1-p))   (logs clamped
  *     at -100 like ATen) ;  g_logit = d loss / d z as autograd computes it:
