@@ -370,17 +370,18 @@ class HipShardOps(object):
             self._idx = torch.tensor(lay.id_cols, dtype=torch.long, device=X.device)
         return lay.pack_ids(X, self._idx)
 
-    def gather(self, ids_all):
+    def gather(self, ids_all, out=None):
         """ids_all [N*B, n_slots] (any row stride) -> (chunks [N*B, ldc] = rows of MY tables for every global sample,
-        ids_t)."""
+        ids_t).  ``out`` = (chunks, ids_t, parts_t) preallocated (the whole-step graph of the direct exchange: what one
+        replay gathers at its end, the next replay sends at its start)."""
         L, lay, sub = self.L, self.lay, self.sub
         NB, dev = ids_all.shape[0], ids_all.device
-        chunks = torch.empty((NB, lay.ldc), dtype=torch.float32, device=dev)
+        chunks = out[0] if out is not None else torch.empty((NB, lay.ldc), dtype=torch.float32, device=dev)
         if sub is None:
             return chunks, None
         cplan = sub.bind(dev)
-        ids_t = torch.empty((len(sub.units), NB), dtype=torch.int32, device=dev)
-        parts_t = torch.empty((len(sub.units), NB), dtype=torch.int16, device=dev)
+        ids_t = out[1] if out is not None else torch.empty((len(sub.units), NB), dtype=torch.int32, device=dev)
+        parts_t = out[2] if out is not None else torch.empty((len(sub.units), NB), dtype=torch.int16, device=dev)
         wide = self._ptr(chunks, lay.wide_col) if lay.has_wide else None
         L.check(L.lib().dctr_embed_fwd(cplan, self._ptr(ids_all), ids_all.stride(0), NB, self._ptr(chunks), lay.ldc,
                                        wide, lay.ldc, None, self._ptr(self.plan.err_flag(dev)), sub.units_ptr(),
@@ -453,6 +454,120 @@ class HipShardOps(object):
                 "dctr_embed_update(owned tables)")
 
 
+class DirectExchange(object):
+    """The sharded step's three exchanges without a host-issued collective: every rank owns receive buffers that the OTHER
+    ranks' copies write into -- device memory mapped into every process through torch's CUDA IPC -- and one arrival word per
+    (exchange kind, sender) (include/dctr.h, dctr_exchange_post / _wait / _next).
+
+      rows    owner q's chunk for rank r  -> r's ``recv[q]``    (the forward all-to-all)
+      grads   rank r's chunk for owner q  -> q's ``grads[r]``   (the sparse reduce-scatter; carries the next batch's ids)
+      dense   rank r's dense gradient slab -> everybody's ``dense[r]``, then a local sum in rank order (all-reduce as
+              all-gather + sum: N x the bytes of a ring, 0.57 MB x 7 on links that move 50+ GB/s each, and bit-identical
+              sums on every rank by construction)
+
+    One-shot and point-to-point: N - 1 copies per exchange, one per peer, all links busy at once (xGMI is a full mesh of
+    point-to-point links).  Everything is an ordinary stream operation -- copies, a one-wave post kernel, a
+    one-wave wait kernel -- so the WHOLE train step including its exchanges is captured into one hipGraph: the host issues
+    one graph launch per step where the RCCL path issues three collectives and four segments (~0.22 ms of host time per
+    step at one rank, profiles/r04_bench_sharded_1rank_rccl.json: that path is host-paced).
+
+    Buffer reuse needs no extra handshake: owner q can only produce rows for step k + 1 after its update of step k, which
+    needs every rank's gradients of step k, which every rank sends after it has read its rows of step k; words only grow."""
+    KINDS = {"rows": 0, "grads": 1, "dense": 2, "ids": 3}
+
+    def __init__(self, group, world, rank, device, B, ldc, n_slots, n_dense, timeout_us=5000000):
+        from torch.multiprocessing.reductions import reduce_tensor
+        from ._hip import lib as L
+        self.L, self.group, self.world, self.rank = L, group, int(world), int(rank)
+        self.timeout_us = int(timeout_us)
+        dev = torch.device(device)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.ld_dense = (int(n_dense) + 3) // 4 * 4
+        self.recv = torch.zeros((world, B, ldc), **f32)
+        self.grads = torch.zeros((world, B, ldc), **f32)
+        self.dense = torch.zeros((world, self.ld_dense), **f32)
+        self.ids = torch.zeros((world, B, n_slots), **f32)
+        self.words = torch.zeros((len(self.KINDS), 64), dtype=torch.int32, device=dev)
+        self.step = torch.ones((2,), dtype=torch.int32, device=dev)      # [0]: rows / grads / dense, [1]: ids
+        self.err = torch.zeros((1,), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+        mine = [self.recv, self.grads, self.dense, self.ids, self.words]
+        self.peers = [[None] * world for _ in mine]
+        if world == 1:
+            for k, t in enumerate(mine):
+                self.peers[k][0] = t
+        else:
+            handles = [reduce_tensor(t) for t in mine]
+            got = [None] * world
+            dist.all_gather_object(got, [h[1] for h in handles], group=group)
+            for r in range(world):
+                for k, t in enumerate(mine):
+                    self.peers[k][r] = t if r == rank else handles[k][0](*got[r][k])
+            self._keep = got
+        # device tables of the peers' word arrays, one per exchange kind
+        self.word_ptrs = []
+        for kind in range(len(self.KINDS)):
+            self.word_ptrs.append(torch.tensor([self.peers[4][r].data_ptr() + 4 * 64 * kind for r in range(world)],
+                                               dtype=torch.int64, device=dev))
+        if world > 1:
+            dist.barrier(group=group)
+
+    def _ptr(self, t, off=0):
+        import ctypes
+        return ctypes.c_void_p(t.data_ptr() + off)
+
+    def _post_wait(self, kind, counter):
+        L, k = self.L, self.KINDS[kind]
+        s = L.stream_handle(self.words.device)
+        step = self._ptr(self.step, 4 * counter)
+        L.check(L.lib().dctr_exchange_post(self._ptr(self.word_ptrs[k]), self.world, self.rank, step, s),
+                "dctr_exchange_post")
+        L.check(L.lib().dctr_exchange_wait(self._ptr(self.words, 4 * 64 * k), self.world, step, self.timeout_us,
+                                           self._ptr(self.err), s), "dctr_exchange_wait")
+
+    def _scatter(self, which, src):
+        """src [world, ...]: slice r goes to rank r's buffer `which`, into this rank's slot"""
+        for r in range(self.world):
+            self.peers[which][r][self.rank].copy_(src[r], non_blocking=True)
+
+    def send_rows(self, chunks):
+        self._scatter(0, chunks.view(self.recv.shape))
+        self._post_wait("rows", 0)
+        return self.recv.view(-1, self.recv.shape[2])
+
+    def send_grads(self, send):
+        self._scatter(1, send.view(self.grads.shape))
+        self._post_wait("grads", 0)
+        return self.grads.view(-1, self.grads.shape[2])
+
+    def send_ids(self, ids):
+        self._scatter(3, ids)
+        self._post_wait("ids", 1)
+        L = self.L
+        L.check(L.lib().dctr_exchange_next(self._ptr(self.step, 4), L.stream_handle(self.words.device)), "dctr_exchange_next")
+        return self.ids.view(-1, self.ids.shape[2])
+
+    def allreduce_dense(self, flat):
+        n = flat.numel()
+        for r in range(self.world):
+            self.peers[2][r][self.rank][:n].copy_(flat, non_blocking=True)
+        self._post_wait("dense", 0)
+        L = self.L
+        L.check(L.lib().dctr_sum_ranks(self._ptr(flat), self._ptr(self.dense), self.world, n, self.ld_dense,
+                                       L.stream_handle(flat.device)), "dctr_sum_ranks")
+
+    def next(self):
+        L = self.L
+        L.check(L.lib().dctr_exchange_next(self._ptr(self.step), L.stream_handle(self.words.device)), "dctr_exchange_next")
+
+    def check(self):
+        """Raise if a wait ever timed out (synchronises the device)."""
+        if int(self.err.item()) != 0:
+            self.err.zero_()
+            raise RuntimeError("a direct-exchange wait timed out: a peer rank did not reach the same exchange "
+                               "(ranks out of step, or a rank died)")
+
+
 class _Segment(object):
     """A piece of the step between two collectives: run eagerly, or captured once into a hipGraph and replayed
     (collectives stay OUTSIDE the graphs: the host issues 4 graph launches + 3 collectives per step instead of
@@ -509,7 +624,7 @@ class ShardedTrainer(object):
     Only the owner's copy of a table is current during training; ``gather_tables()`` broadcasts the owners' copies
     (and optimizer state) so that ``state_dict()`` is complete on every rank -- call it before saving / predicting."""
 
-    def __init__(self, model, process_group=None, ops=None, broadcast_parameters=True, use_graphs=False):
+    def __init__(self, model, process_group=None, ops=None, broadcast_parameters=True, use_graphs=False, exchange=None):
         if not dist.is_initialized():
             raise RuntimeError("initialise torch.distributed first (backend 'nccl' = RCCL on ROCm)")
         self.model, self.group = model, process_group
@@ -546,6 +661,12 @@ class ShardedTrainer(object):
         # (opt-in: at one rank, where the all-to-alls are short, the extra stream hand-offs cost more than the overlap
         # gains -- 255 vs 234 us per step on MI355X; the multi-rank effect is unmeasured)
         self.overlap_wgrad = os.environ.get("DCTR_SHARDED_OVERLAP_WGRAD", "0") == "1"
+        # "rccl": torch.distributed collectives issued by the host between hipGraph segments; "direct": copies into the
+        # peers' IPC-mapped buffers + arrival words, the whole step one hipGraph (DirectExchange; fused route, GPU only)
+        self.exchange = exchange or os.environ.get("DCTR_SHARDED_EXCHANGE", "rccl")
+        if self.exchange not in ("rccl", "direct"):
+            raise ValueError("exchange must be 'rccl' or 'direct'")
+        self._dx = None
         self._side = None
         self._pre = None          # (chunks, ids) of the announced next batch, gathered at the end of the previous call
         self._shape = None
@@ -554,6 +675,8 @@ class ShardedTrainer(object):
 
     def close(self):
         self._join()
+        if self._dx is not None:
+            self._dx.check()
         self.plan.sharder = None
 
     def set_use_graphs(self, on):
@@ -562,6 +685,8 @@ class ShardedTrainer(object):
         descriptors and allocates lazily, neither of which can be captured."""
         self.use_graphs = bool(on)
         self._shape = None
+        if self._dx is not None:
+            self._direct_seg = _Segment(self._direct_body, bool(on))
 
     # ---- called by _ops.embed (from model.logit_parts) in place of the single-GPU lookup ----------------------------
     def embed(self, X, want_fm, full):
@@ -686,7 +811,9 @@ class ShardedTrainer(object):
             self._pre = None
         lay, B = self.layout, xb.shape[0]
         cuda = xb.device.type == "cuda"
-        queues = cuda and self.slab is not None and os.environ.get("DCTR_SHARDED_QUEUES", "1") != "0"
+        if self.exchange == "direct" and cuda and self.slab is not None:
+            return self._train_step_direct(xb, yb, next_xb)
+        queues = cuda and self.slab is not None and os.environ.get("DCTR_SHARDED_QUEUES", "0") == "1"
         if not queues:
             return self._train_step_serial(xb, yb, next_xb)
         from ._hip import streams as _streams
@@ -759,6 +886,56 @@ class ShardedTrainer(object):
             ev["dense"].record(side)
         self._side_busy = True
         main.wait_event(ev["loss"])                   # what this call returns is complete on the caller's stream
+        return loss, loss.reshape(1), y_pred
+
+    # ---- the whole step as ONE hipGraph over the direct exchange ----------------------------------------------------
+    def _direct_setup(self, xb):
+        lay, B, dev = self.layout, xb.shape[0], xb.device
+        self._dx = DirectExchange(self.group, self.world, self.rank, dev, B, lay.ldc, lay.n_slots, self.slab.grad.numel())
+        sub = self.ops.sub
+        nu = len(sub.units) if sub is not None else 1
+        NB = lay.world * B
+        self._chunks = torch.zeros((NB, lay.ldc), dtype=torch.float32, device=dev)
+        self._ids_buf = torch.zeros((nu, NB), dtype=torch.int32, device=dev)
+        self._parts_buf = torch.zeros((nu, NB), dtype=torch.int16, device=dev)
+        self._direct_seg = _Segment(self._direct_body, bool(self.use_graphs))
+        self._direct_out = None
+
+    def _direct_body(self):
+        """rows exchange -> [assemble, tower + head + backward, weight gradients, assemble^T] -> gradient exchange ->
+        owners' update -> owners' gather for the next batch -> dense exchange + sum + optimizer step: every launch of a
+        step, on one stream, capturable."""
+        dx, lay = self._dx, self.layout
+        self._recv = dx.send_rows(self._chunks)
+        self.overlap_wgrad = False
+        send, loss, y_pred = self._compute()
+        grads_all = dx.send_grads(send)
+        self.ops.update(grads_all, (self._ids_buf, self._parts_buf, None))
+        # (the ids of the announced next batch arrived with the gradients; an un-announced call gathers again itself)
+        self.ops.gather(grads_all[:, lay.ids_col:lay.ids_col + lay.n_slots], out=(self._chunks, self._ids_buf, self._parts_buf))
+        dx.allreduce_dense(self.slab.grad)
+        self.slab.step(*self.state["mode"])
+        dx.next()
+        return loss, y_pred
+
+    def _train_step_direct(self, xb, yb, next_xb=None):
+        lay, B = self.layout, xb.shape[0]
+        if self._dx is None or self._dx.recv.shape[1] != B:
+            self._direct_setup(xb)
+            self._announced = None
+        self._x.copy_(xb)
+        self._y.copy_(yb)
+        key = (xb.data_ptr(), xb._version)
+        if self._announced != key:                       # ids not at their owners yet: the explicit exchange + gather
+            self._ids_tmp.copy_(self.ops.pack_ids(self._x))
+            ids_all = self._dx.send_ids(self._ids_tmp)
+            self.ops.gather(ids_all, out=(self._chunks, self._ids_buf, self._parts_buf))
+        if next_xb is not None and tuple(next_xb.shape) == tuple(xb.shape):
+            self._ids_next.copy_(self.ops.pack_ids(next_xb))
+            self._announced = (next_xb.data_ptr(), next_xb._version)
+        else:
+            self._announced = None
+        loss, y_pred = self._direct_seg()
         return loss, loss.reshape(1), y_pred
 
     def _join(self):

@@ -1,0 +1,108 @@
+"""The direct exchange of the table-sharded step (deepctr_torch.parallel.DirectExchange: copies into the peers' IPC-mapped
+receive buffers + arrival words, no host-issued collective, the whole step one hipGraph) with N > 1 RANKS FOR REAL: N
+processes that share the one GPU of this box -- RCCL refuses two ranks on one device, a hand-written exchange does not.
+Every rank runs the real kernels on its own shard of the tables and its own slice of the global batch; after a few steps
+and ``gather_tables()`` every rank must hold the parameters ONE process reaches on the concatenated batch with the fused
+single-GPU step (itself pinned to the reference: tests/test_gpu_deepfm.py, test_gpu_full_golden.py).
+gloo carries the IPC handshake and the final table broadcast only."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F_, V_, D_, ND_, B_ = 7, 5000, 16, 3, 256
+STEPS = 5
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _batch(step, world):
+    g = torch.Generator().manual_seed(100 + step)
+    ids = torch.randint(0, V_, (world * B_, F_), generator=g).float()
+    X = torch.cat([ids, torch.rand(world * B_, ND_, generator=g)], 1)
+    y = torch.randint(0, 2, (world * B_,), generator=g).float()
+    return X, y
+
+
+def _model(dev):
+    for p in (os.path.join(ROOT, "deepctr-torch_amd"),):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from deepctr_torch.inputs import DenseFeat, SparseFeat
+    from deepctr_torch.models import DeepFM
+    cols = [SparseFeat("C%d" % i, V_, D_) for i in range(F_)] + [DenseFeat("I%d" % i, 1) for i in range(ND_)]
+    return DeepFM(cols, cols, dnn_hidden_units=(64, 32), l2_reg_linear=0, l2_reg_embedding=0, init_std=0.05, seed=7,
+                  device=dev)
+
+
+def _worker(rank, world, port, opt_name, graphs, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        dev = "cuda:0"
+        m = _model(dev)
+        from deepctr_torch.parallel import ShardedTrainer
+        m.compile(opt_name, "binary_crossentropy", metrics=[])
+        m.train()
+        tr = ShardedTrainer(m, exchange="direct", use_graphs=False)
+        batches = [_batch(step, world) for step in range(STEPS)]
+        mine = [(Xg[rank * B_:(rank + 1) * B_].contiguous().to(dev), yg[rank * B_:(rank + 1) * B_].contiguous().to(dev))
+                for Xg, yg in batches]
+        losses = []
+        for step in range(STEPS):
+            if graphs and step == 2:
+                tr.set_use_graphs(True)          # eager steps first, then the captured whole-step graph
+            nxt = mine[step + 1][0] if step + 1 < STEPS and step != 1 else None      # (step 1 -> 2 is NOT announced)
+            losses.append(tr.train_step(mine[step][0], mine[step][1], next_xb=nxt)[0])
+        torch.cuda.synchronize()
+        tr.gather_tables()
+        tr.close()
+        m.model_plan().check_ids()
+        torch.save({"sd": {k: v.detach().cpu().clone() for k, v in m.state_dict().items()},
+                    "loss": torch.stack([l.reshape(()) for l in losses]).cpu()}, os.path.join(out_dir, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graphs", [False, True], ids=["eager", "hipgraph"])
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("opt_name", ["adagrad", "sgd"])
+def test_direct_exchange_ranks_on_one_gpu_equal_the_single_process_step(tmp_path, opt_name, world, graphs):
+    if opt_name == "sgd" and (world == 3 or not graphs):
+        pytest.skip("one SGD case is enough")
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, opt_name, graphs, str(tmp_path)), nprocs=world, join=True)
+    ranks = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
+    for r in range(1, world):
+        for k in ranks[0]["sd"]:
+            assert torch.equal(ranks[0]["sd"][k], ranks[r]["sd"][k]), "replicas differ after gather_tables: %s" % k
+    # the single-process fused step on the concatenated batch
+    dev = "cuda:0"
+    ref = _model(dev)
+    ref.compile(opt_name, "binary_crossentropy", metrics=[])
+    ref.train()
+    ref_loss = []
+    for step in range(STEPS):
+        Xg, yg = _batch(step, world)
+        ref_loss.append(ref._train_step(Xg.to(dev), yg.to(dev))[0].reshape(()))
+    torch.cuda.synchronize()
+    ref_sd = {k: v.detach().cpu() for k, v in ref.state_dict().items()}
+    got_loss = sum(r["loss"] for r in ranks)
+    assert torch.allclose(got_loss, torch.stack(ref_loss).cpu(), rtol=2e-5), (got_loss, ref_loss)
+    for k, v in ref_sd.items():
+        err = float((ranks[0]["sd"][k] - v).abs().max())
+        assert err <= 2e-6 * max(1.0, float(v.abs().max())) + 2e-7, "%s: %.3e" % (k, err)
