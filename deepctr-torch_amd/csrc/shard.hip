@@ -269,6 +269,30 @@ __global__ __launch_bounds__(kT) void k_assemble_bwd_v4(AsmArgs A) {
   }
 }
 
+// One launch in front of a sharded step: this rank's batch into the static buffers the captured step reads, and the NEXT
+// batch's id columns into the id slots of the gradient chunks (the owners need them for step k + 1's gather; they ride in
+// step k's gradient exchange).  Replaces five torch launches (two copies, index_select, a strided copy, an elementwise
+// copy inside the step: ~25 us of kernel boundaries per step).
+__global__ __launch_bounds__(kT) void k_shard_stage(const float* __restrict__ xb, int64_t ld_xb, const float* __restrict__ yb,
+                                                    int B, int ncols, float* __restrict__ x_dst, int64_t ld_xd,
+                                                    float* __restrict__ y_dst, const float* __restrict__ x_next,
+                                                    int64_t ld_xn, const int32_t* __restrict__ id_cols, int N, int n_slots,
+                                                    float* __restrict__ send, int64_t ldc, int ids_col) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+  const int64_t nx = static_cast<int64_t>(B) * ncols;
+  if (t < nx) {
+    const int64_t b = t / ncols, c = t - b * ncols;
+    stg_f32(x_dst + b * ld_xd + c, ldg_f32(xb + b * ld_xb + c));
+  }
+  if (t < B && y_dst) stg_f32(y_dst + t, ldg_f32(yb + t));
+  const int64_t ni = x_next ? static_cast<int64_t>(B) * N * n_slots : 0;
+  if (t < ni) {
+    const int64_t b = t / (N * n_slots), k = t - b * (N * n_slots);
+    const int q = static_cast<int>(k / n_slots), j = static_cast<int>(k - static_cast<int64_t>(q) * n_slots);
+    stg_f32(send + (static_cast<int64_t>(q) * B + b) * ldc + ids_col + j, ldg_f32(x_next + b * ld_xn + ldg_i32(id_cols + k)));
+  }
+}
+
 inline bool al16(const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
 
 }  // namespace
@@ -331,5 +355,22 @@ extern "C" int dctr_shard_assemble_bwd(float* send, int64_t ld_chunk, int32_t n_
   else if (vec && D == 4) k_assemble_bwd_v4<1><<<g8, blk, 0, st>>>(a);
   else if (vec && D == 64) k_assemble_bwd_v4<16><<<g8, blk, 0, st>>>(a);
   else k_assemble_bwd<<<dim3((B + 15) / 16 + extra), blk, 0, st>>>(a);
+  return launch_status();
+}
+
+extern "C" int dctr_shard_stage(const float* xb, int64_t ld_xb, const float* yb, int32_t B, int32_t ncols, float* x_dst,
+                                int64_t ld_xd, float* y_dst, const float* x_next, int64_t ld_xn, const int32_t* id_cols,
+                                int32_t n_ranks, int32_t n_slots, float* send, int64_t ld_chunk, int32_t ids_col,
+                                dctr_stream_t stream) {
+  if (!xb || !x_dst || B < 0 || ncols <= 0 || ld_xb < ncols || ld_xd < ncols) return DCTR_EINVAL;
+  if (y_dst && !yb) return DCTR_EINVAL;
+  if (x_next && (!id_cols || !send || n_ranks <= 0 || n_slots <= 0 || ids_col < 0 || ld_chunk < ids_col + n_slots))
+    return DCTR_EINVAL;
+  if (B == 0) return DCTR_OK;
+  int64_t n = static_cast<int64_t>(B) * ncols;
+  const int64_t ni = x_next ? static_cast<int64_t>(B) * n_ranks * n_slots : 0;
+  if (ni > n) n = ni;
+  k_shard_stage<<<dim3(static_cast<unsigned>((n + kT - 1) / kT)), dim3(kT), 0, static_cast<hipStream_t>(stream)>>>(
+      xb, ld_xb, yb, B, ncols, x_dst, ld_xd, y_dst, x_next, ld_xn, id_cols, n_ranks, n_slots, send, ld_chunk, ids_col);
   return launch_status();
 }

@@ -70,6 +70,30 @@ __global__ __launch_bounds__(64) void k_exch_wait(const int32_t* __restrict__ wo
   if (!ok && err) __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// post + wait (+ the counter's advance behind the step's last exchange) as ONE launch: a kernel boundary costs ~4.7 us in
+// a hipGraph and the direct-exchange step had nine of them for its three exchanges (profiles/r04_sharded_direct_*)
+__global__ __launch_bounds__(64) void k_exch_sync(int32_t* const* __restrict__ peer_words, const int32_t* __restrict__ words,
+                                                  int n, int my_index, int32_t* step, int advance,
+                                                  unsigned long long timeout_ticks, int32_t* err) {
+  const int r = threadIdx.x;
+  const int32_t want = __hip_atomic_load(step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool ok = r >= n;
+  if (r < n) __hip_atomic_store(peer_words[r] + my_index, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned long long t0 = wall_clock64();
+  while (!ok) {
+    const int32_t v = __hip_atomic_load(words + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+    ok = v - want >= 0;
+    if (!ok) {
+      if (wall_clock64() - t0 > timeout_ticks) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  if (!ok && err) __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (every lane has read `want` before any lane gets here: one wave, the loads above are complete)
+  __builtin_amdgcn_wave_barrier();
+  if (advance && r == 0) __hip_atomic_store(step, want + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ void k_exch_next(int32_t* step) {
   if (threadIdx.x == 0) *step = *step + 1;
 }
@@ -77,18 +101,21 @@ __global__ void k_exch_next(int32_t* step) {
 // dst[i] = sum over the n ranks' slabs, in rank order (every rank computes the same bits): the dense gradients' all-reduce
 // as all-gather by copy engines + this local sum
 __global__ __launch_bounds__(256) void k_sum_ranks(float* __restrict__ dst, const float* __restrict__ src, int n_ranks,
-                                                   int64_t n, int64_t ld) {
+                                                   int64_t n, int64_t ld, DenseStepDev S) {
   const int64_t i = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (i + 3 < n) {
     for (int r = 0; r < n_ranks; ++r) acc += *(const DCTR_GLOBAL f32x4*)(src + r * ld + i);
     *(DCTR_GLOBAL f32x4*)(dst + i) = acc;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dense_step_apply(S, dst + i + c, acc[c]);
   } else {
     for (int64_t k = i; k < n; ++k) {
       float a = 0.f;
       for (int r = 0; r < n_ranks; ++r) a += ldg_f32(src + r * ld + k);
       stg_f32(dst + k, a);
+      dense_step_apply(S, dst + k, a);
     }
   }
 }
@@ -116,12 +143,21 @@ extern "C" int dctr_exchange_next(int32_t* step, dctr_stream_t stream) {
   return launch_status();
 }
 
-extern "C" int dctr_sum_ranks(float* dst, const float* src, int32_t n_ranks, int64_t n, int64_t ld, dctr_stream_t stream) {
+extern "C" int dctr_sum_ranks(float* dst, const float* src, int32_t n_ranks, int64_t n, int64_t ld,
+                              const dctr_dense_step_t* step, dctr_stream_t stream) {
   if (!dst || !src || n_ranks <= 0 || n < 0 || ld < n) return DCTR_EINVAL;
   if (ld % 4 != 0 || reinterpret_cast<uintptr_t>(dst) % 16 != 0 || reinterpret_cast<uintptr_t>(src) % 16 != 0) return DCTR_EALIGN;
   if (n == 0) return DCTR_OK;
   k_sum_ranks<<<dim3(static_cast<unsigned>((n / 4 + 256) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(
-      dst, src, n_ranks, n, ld);
+      dst, src, n_ranks, n, ld, dense_step_dev(step));
+  return launch_status();
+}
+
+extern "C" int dctr_exchange_sync(int32_t* const* peer_words, const int32_t* words, int32_t n, int32_t my_index,
+                                  int32_t* step, int32_t advance, int32_t timeout_us, int32_t* err, dctr_stream_t stream) {
+  if (!peer_words || !words || !step || n <= 0 || n > 64 || my_index < 0 || timeout_us <= 0) return DCTR_EINVAL;
+  k_exch_sync<<<dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream)>>>(
+      peer_words, words, n, my_index, step, advance, static_cast<unsigned long long>(timeout_us) * 100ull, err);
   return launch_status();
 }
 

@@ -160,7 +160,10 @@ SIGNATURES = {
     "dctr_exchange_post": (ctypes.c_int, [_P, _I32, _I32, _P, _P]),
     "dctr_exchange_wait": (ctypes.c_int, [_P, _I32, _P, _I32, _P, _P]),
     "dctr_exchange_next": (ctypes.c_int, [_P, _P]),
-    "dctr_sum_ranks": (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P]),
+    "dctr_sum_ranks": (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _P]),
+    "dctr_exchange_sync": (ctypes.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _P, _P]),
+    "dctr_shard_stage": (ctypes.c_int, [_P, _I64, _P, _I32, _I32, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _P, _I64, _I32,
+                                        _P]),
     "dctr_bce_head": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P]),
     "dctr_dense_opt": (ctypes.c_int, [_P, _P, _P, _I64, _I32, _F32, _F32, _P]),
     "dctr_sizeof_dense_item": (ctypes.c_size_t, []),

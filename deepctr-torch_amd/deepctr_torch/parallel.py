@@ -414,10 +414,11 @@ class HipShardOps(object):
             L.stream_handle(dev)), "dctr_shard_assemble_fwd")
         return out, wide, fm, fm_s
 
-    def assemble_bwd(self, X, g_out, g_wide, g_fm, out, fm_s, g_wdense):
+    def assemble_bwd(self, X, g_out, g_wide, g_fm, out, fm_s, g_wdense, send=None):
         L, lay, plan = self.L, self.lay, self.plan
         B, dev = X.shape[0], X.device
-        send = torch.empty((lay.world * B, lay.ldc), dtype=torch.float32, device=dev)
+        if send is None:
+            send = torch.empty((lay.world * B, lay.ldc), dtype=torch.float32, device=dev)
         w = plan.wide_dense_weight
         L.check(L.lib().dctr_shard_assemble_bwd(
             self._ptr(send), lay.ldc, lay.world, B, lay.F, lay.D, self._ptr(self._owner_map(dev)),
@@ -516,14 +517,13 @@ class DirectExchange(object):
         import ctypes
         return ctypes.c_void_p(t.data_ptr() + off)
 
-    def _post_wait(self, kind, counter):
+    def _sync(self, kind, counter, advance):
+        """post this rank's arrival to every peer, wait for every peer's; ``advance``: the counter moves on behind it"""
         L, k = self.L, self.KINDS[kind]
-        s = L.stream_handle(self.words.device)
-        step = self._ptr(self.step, 4 * counter)
-        L.check(L.lib().dctr_exchange_post(self._ptr(self.word_ptrs[k]), self.world, self.rank, step, s),
-                "dctr_exchange_post")
-        L.check(L.lib().dctr_exchange_wait(self._ptr(self.words, 4 * 64 * k), self.world, step, self.timeout_us,
-                                           self._ptr(self.err), s), "dctr_exchange_wait")
+        L.check(L.lib().dctr_exchange_sync(self._ptr(self.word_ptrs[k]), self._ptr(self.words, 4 * 64 * k), self.world,
+                                           self.rank, self._ptr(self.step, 4 * counter), 1 if advance else 0,
+                                           self.timeout_us, self._ptr(self.err), L.stream_handle(self.words.device)),
+                "dctr_exchange_sync")
 
     def _scatter(self, which, src):
         """src [world, ...]: slice r goes to rank r's buffer `which`, into this rank's slot"""
@@ -532,33 +532,31 @@ class DirectExchange(object):
 
     def send_rows(self, chunks):
         self._scatter(0, chunks.view(self.recv.shape))
-        self._post_wait("rows", 0)
+        self._sync("rows", 0, False)
         return self.recv.view(-1, self.recv.shape[2])
 
     def send_grads(self, send):
         self._scatter(1, send.view(self.grads.shape))
-        self._post_wait("grads", 0)
+        self._sync("grads", 0, False)
         return self.grads.view(-1, self.grads.shape[2])
 
     def send_ids(self, ids):
         self._scatter(3, ids)
-        self._post_wait("ids", 1)
-        L = self.L
-        L.check(L.lib().dctr_exchange_next(self._ptr(self.step, 4), L.stream_handle(self.words.device)), "dctr_exchange_next")
+        self._sync("ids", 1, True)
         return self.ids.view(-1, self.ids.shape[2])
 
-    def allreduce_dense(self, flat):
+    def allreduce_dense(self, flat, step=None):
+        """flat <- sum over ranks (rank order); ``step`` (dctr_dense_step_t): the sum kernel also applies the optimizer step.
+        The step's LAST exchange: the counter advances behind it."""
+        import ctypes
         n = flat.numel()
         for r in range(self.world):
             self.peers[2][r][self.rank][:n].copy_(flat, non_blocking=True)
-        self._post_wait("dense", 0)
+        self._sync("dense", 0, True)
         L = self.L
         L.check(L.lib().dctr_sum_ranks(self._ptr(flat), self._ptr(self.dense), self.world, n, self.ld_dense,
-                                       L.stream_handle(flat.device)), "dctr_sum_ranks")
-
-    def next(self):
-        L = self.L
-        L.check(L.lib().dctr_exchange_next(self._ptr(self.step), L.stream_handle(self.words.device)), "dctr_exchange_next")
+                                       ctypes.byref(step) if step is not None else None, L.stream_handle(flat.device)),
+                "dctr_sum_ranks")
 
     def check(self):
         """Raise if a wait ever timed out (synchronises the device)."""
@@ -785,6 +783,12 @@ class ShardedTrainer(object):
         g_wd = slab.grad_of(plan.wide_dense_weight) if plan.wide_dense_weight is not None else None
         g_wide = lv["wide"].grad if lv["wide"] is not None else None
         g_fm = lv["fm"].grad if lv["fm"] is not None else None
+        static = getattr(self, "_send_static", None)
+        if static is not None:
+            # (the direct-exchange step: the staging launch in front of the step has put the next batch's ids in place)
+            send = self.ops.assemble_bwd(self._x, lv["out"].grad, g_wide, g_fm, lv["out"].detach(), lv["fm_s"],
+                                         g_wd if g_wide is not None else None, send=static)
+            return send, loss.detach(), y_pred
         send = self.ops.assemble_bwd(self._x, lv["out"].grad, g_wide, g_fm, lv["out"].detach(), lv["fm_s"],
                                      g_wd if g_wide is not None else None)
         B = self._x.shape[0]
@@ -898,43 +902,78 @@ class ShardedTrainer(object):
         self._chunks = torch.zeros((NB, lay.ldc), dtype=torch.float32, device=dev)
         self._ids_buf = torch.zeros((nu, NB), dtype=torch.int32, device=dev)
         self._parts_buf = torch.zeros((nu, NB), dtype=torch.int16, device=dev)
+        self._send_buf = torch.zeros((NB, lay.ldc), dtype=torch.float32, device=dev)
+        self._id_cols = torch.tensor(lay.id_cols, dtype=torch.int32, device=dev)
         self._direct_seg = _Segment(self._direct_body, bool(self.use_graphs))
-        self._direct_out = None
+        from ._hip import streams as _streams
+        self._side = _streams.side_stream(dev, "shard")
 
     def _direct_body(self):
-        """rows exchange -> [assemble, tower + head + backward, weight gradients, assemble^T] -> gradient exchange ->
-        owners' update -> owners' gather for the next batch -> dense exchange + sum + optimizer step: every launch of a
-        step, on one stream, capturable."""
-        dx, lay = self._dx, self.layout
+        """rows exchange -> [assemble, tower + head + backward-data, assemble^T] -> gradient exchange -> owners' update ->
+        owners' gather for the next batch -> dense exchange + sum + optimizer step; the tower's weight gradients on a second
+        queue beside everything behind the tower.  Every launch of a step, exchanges included, capturable: one hipGraph."""
+        dx, lay, slab = self._dx, self.layout, self.slab
+        main = torch.cuda.current_stream(self._x.device)
+        side = self._side
         self._recv = dx.send_rows(self._chunks)
-        self.overlap_wgrad = False
-        send, loss, y_pred = self._compute()
+        self.overlap_wgrad = True
+        self._send_static = self._send_buf
+        try:
+            send, loss, y_pred = self._compute()
+        finally:
+            self._send_static = None
+        wgrad = slab.deferred
+        if wgrad is not None:
+            side.wait_stream(main)
+            wgrad(side)                              # (loss is finished by its reduction)
         grads_all = dx.send_grads(send)
         self.ops.update(grads_all, (self._ids_buf, self._parts_buf, None))
         # (the ids of the announced next batch arrived with the gradients; an un-announced call gathers again itself)
         self.ops.gather(grads_all[:, lay.ids_col:lay.ids_col + lay.n_slots], out=(self._chunks, self._ids_buf, self._parts_buf))
-        dx.allreduce_dense(self.slab.grad)
-        self.slab.step(*self.state["mode"])
-        dx.next()
+        if wgrad is not None:
+            main.wait_stream(side)
+        mode = self.state["mode"]
+        if slab.begin_inline_step(mode[0], mode[1], mode[2] if len(mode) > 2 else 0.0):
+            try:
+                dx.allreduce_dense(slab.grad, slab.inline)     # the sum kernel steps the parameters
+                slab.inline_done = True
+            finally:
+                slab.end_inline_step()
+            slab.step(*mode)                                   # (clears the flag)
+        else:
+            dx.allreduce_dense(slab.grad)
+            slab.step(*mode)
         return loss, y_pred
 
     def _train_step_direct(self, xb, yb, next_xb=None):
+        import ctypes
+        from ._hip import lib as L
         lay, B = self.layout, xb.shape[0]
         if self._dx is None or self._dx.recv.shape[1] != B:
             self._direct_setup(xb)
             self._announced = None
-        self._x.copy_(xb)
-        self._y.copy_(yb)
+        announce = next_xb is not None and tuple(next_xb.shape) == tuple(xb.shape) and next_xb.stride(1) == 1
+        P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())       # noqa: E731
+        yv = yb.reshape(-1)
+        if xb.dtype == torch.float32 and xb.stride(1) == 1 and yv.dtype == torch.float32 and yv.is_contiguous() and \
+                self._y.is_contiguous() and self._y.numel() == B and (not announce or next_xb.dtype == torch.float32):
+            L.check(L.lib().dctr_shard_stage(P(xb), xb.stride(0), P(yv), B, xb.shape[1], P(self._x), self._x.stride(0),
+                                             P(self._y), P(next_xb) if announce else None,
+                                             next_xb.stride(0) if announce else 0, P(self._id_cols), lay.world, lay.n_slots,
+                                             P(self._send_buf), lay.ldc, lay.ids_col, L.stream_handle(xb.device)),
+                    "dctr_shard_stage")
+        else:
+            self._x.copy_(xb)
+            self._y.copy_(yb)
+            if announce:
+                self._send_buf.view(lay.world, B, lay.ldc)[:, :, lay.ids_col:lay.ids_col + lay.n_slots].copy_(
+                    self.ops.pack_ids(next_xb))
         key = (xb.data_ptr(), xb._version)
         if self._announced != key:                       # ids not at their owners yet: the explicit exchange + gather
             self._ids_tmp.copy_(self.ops.pack_ids(self._x))
             ids_all = self._dx.send_ids(self._ids_tmp)
             self.ops.gather(ids_all, out=(self._chunks, self._ids_buf, self._parts_buf))
-        if next_xb is not None and tuple(next_xb.shape) == tuple(xb.shape):
-            self._ids_next.copy_(self.ops.pack_ids(next_xb))
-            self._announced = (next_xb.data_ptr(), next_xb._version)
-        else:
-            self._announced = None
+        self._announced = (next_xb.data_ptr(), next_xb._version) if announce else None
         loss, y_pred = self._direct_seg()
         return loss, loss.reshape(1), y_pred
 

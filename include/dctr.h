@@ -586,7 +586,18 @@ int dctr_exchange_post(int32_t* const* peer_words, int32_t n, int32_t my_index, 
 int dctr_exchange_wait(const int32_t* words, int32_t n, const int32_t* step, int32_t timeout_us, int32_t* err,
                        dctr_stream_t stream);
 int dctr_exchange_next(int32_t* step, dctr_stream_t stream);
-int dctr_sum_ranks(float* dst, const float* src, int32_t n_ranks, int64_t n, int64_t ld, dctr_stream_t stream);
+int dctr_sum_ranks(float* dst, const float* src, int32_t n_ranks, int64_t n, int64_t ld, const dctr_dense_step_t* step,
+                   dctr_stream_t stream);       /* step (nullable): the optimizer step on the elements it finishes */
+/* post + wait (+ advance != 0: the counter's advance, behind a step's last exchange) as one launch */
+int dctr_exchange_sync(int32_t* const* peer_words, const int32_t* words, int32_t n, int32_t my_index, int32_t* step,
+                       int32_t advance, int32_t timeout_us, int32_t* err, dctr_stream_t stream);
+/* One launch in front of a sharded step: this rank's batch (xb [B, ncols], yb [B]) into the static buffers the captured
+ * step reads, and -- x_next non-NULL -- the next batch's id columns id_cols [n_ranks * n_slots] into columns
+ * [ids_col, ids_col + n_slots) of the gradient chunks send [n_ranks][B][ld_chunk] (they ride in the gradient exchange). */
+int dctr_shard_stage(const float* xb, int64_t ld_xb, const float* yb, int32_t B, int32_t ncols, float* x_dst,
+                     int64_t ld_xd, float* y_dst, const float* x_next, int64_t ld_xn, const int32_t* id_cols,
+                     int32_t n_ranks, int32_t n_slots, float* send, int64_t ld_chunk, int32_t ids_col,
+                     dctr_stream_t stream);
 
 /* ---- prediction head + loss (layers/core.py:154-160, basemodel.py:254, F.binary_cross_entropy(reduction='sum'))
  *     z = sum_i part_i[b] + bias ;  y_pred = sigmoid(z) ;  loss = sum_b -(y log p + (1-y) log(1-p))   (logs clamped

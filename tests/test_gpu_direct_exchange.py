@@ -67,7 +67,7 @@ def _worker(rank, world, port, opt_name, graphs, out_dir):
             if graphs and step == 2:
                 tr.set_use_graphs(True)          # eager steps first, then the captured whole-step graph
             nxt = mine[step + 1][0] if step + 1 < STEPS and step != 1 else None      # (step 1 -> 2 is NOT announced)
-            losses.append(tr.train_step(mine[step][0], mine[step][1], next_xb=nxt)[0])
+            losses.append(tr.train_step(mine[step][0], mine[step][1], next_xb=nxt)[0].clone())   # (a replay's outputs are static)
         torch.cuda.synchronize()
         tr.gather_tables()
         tr.close()

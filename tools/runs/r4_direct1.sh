@@ -2,10 +2,10 @@
 # round 4: the direct exchange -- N processes on one GPU (parity), one rank whole-step graph (timing + timeline)
 export TMPDIR=/tmp
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-O=$GRAFT_REPO_ROOT/gpurun_out/r4_direct1
+O=$GRAFT_REPO_ROOT/gpurun_out/r4_direct2
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_direct_exchange.py -x -q --tb=short 2>&1 | grep -v "amdgpu.ids\|Gloo\|CudaIPC" | tail -30 > $O/pytest.txt
+timeout 900 python -m pytest tests/test_gpu_direct_exchange.py -q --tb=short 2>&1 | grep -v "amdgpu.ids\|Gloo\|CudaIPC" | tail -30 > $O/pytest.txt
 run() {  # tag, env...
   tag=$1; shift
   env MASTER_ADDR=127.0.0.1 MASTER_PORT=29555 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 "$@" timeout 600 python bench.py --gpus 1 --force-parallel --steps 200 --warmup 20 --no-cpu-baseline --no-other-configs --repeats 3 2> $O/bench_$tag.err | grep '^{' > $O/bench_$tag.json
