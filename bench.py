@@ -50,6 +50,13 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the xDeepFM / FiBiNET legs (BASELINE.json configs 3-4) of the N=1 line")
     ap.add_argument("--force-parallel", action="store_true", help="use the data-parallel trainer even with 1 rank")
+    ap.add_argument("--exchange", default=os.environ.get("DCTR_SHARDED_EXCHANGE", "auto"), choices=["auto", "rccl", "direct"],
+                    help="how the table-sharded step exchanges rows / gradients / dense gradients between ranks: 'rccl' = "
+                         "torch.distributed collectives issued by the host between hipGraph segments; 'direct' = copies into "
+                         "the peers' IPC-mapped buffers + arrival words, the whole step one hipGraph (validated with N "
+                         "processes on ONE GPU and at one rank; never run across GPUs: no multi-GPU box was available to the "
+                         "build); 'auto' = direct at one rank, at N > 1 direct only if a two-step self-check succeeds on "
+                         "every rank, else rccl")
     ap.add_argument("--kernel-iters", type=int, default=50, help="event-timed launches per hot-path kernel")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed block of --steps steps is run this many times (each bracketed by a synchronize, and a "
@@ -629,7 +636,32 @@ def main():
         # table-sharded embeddings + data-parallel tower (SURVEY.md 8(e) option S); the compute between the
         # collectives is captured as hipGraph segments after a few eager steps
         from deepctr_torch import parallel as par
-        parallel = par.ShardedTrainer(model, use_graphs=False)
+        exchange = args.exchange
+        if exchange == "auto":
+            exchange = "direct" if (on_gpu and world == 1) else ("direct?" if on_gpu else "rccl")
+        if exchange == "direct?":
+            # N > 1 on GPUs: the direct exchange has only ever run between processes sharing one GPU.  Try it on two
+            # un-timed steps of a throw-away copy of the model; any exception or timed-out wait on ANY rank -> RCCL.
+            ok = 1
+            try:
+                probe_model = build_model(args, device)
+                probe = par.ShardedTrainer(probe_model, use_graphs=False, exchange="direct")
+                for k in range(2):
+                    j = k % n_batches
+                    probe.train_step(X[j * B:(j + 1) * B], y[j * B:(j + 1) * B], next_xb=X[(j + 1) * B:(j + 2) * B])
+                torch.cuda.synchronize()
+                probe._dx.check()
+                probe.close()
+                del probe, probe_model
+                torch.cuda.empty_cache()
+            except Exception as exc:
+                print("direct exchange self-check failed on rank %d (%s: %s): using RCCL" % (rank, type(exc).__name__, exc),
+                      file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], device=device, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            exchange = "direct" if int(flag.item()) == 1 else "rccl"
+        parallel = par.ShardedTrainer(model, use_graphs=False, exchange=exchange)
 
         def batch(i):
             j = i % n_batches
@@ -722,7 +754,7 @@ def main():
             "config": {"workload": "DeepFM synthetic Criteo (26 sparse x %d vocab, 13 dense, emb_dim=16, batch=%d) "
                                    "fwd+bwd+%s, l2=0, dnn=(256,128)%s" % (args.vocab, B, args.optimizer,
                                                                          "" if args.ids == "uniform" else ", ids ~ Zipf(1.05) [secondary run]"),
-                       "global_batch": world * B, "parallelism": ("tables sharded x%d + dp%d tower" % (world, world)) if parallel is not None else "single",
+                       "global_batch": world * B, "parallelism": ("tables sharded x%d + dp%d tower, %s exchange" % (world, world, parallel.exchange)) if parallel is not None else "single",
                        "hip_graph": bool(graphed), "steps_per_graph": (min(args.steps_per_graph, args.steps) if graphed and parallel is None else None),
                        "eager_steps_in_timed_region": 0 if graphed else args.steps,
                        "warmup_steps_run": did_warm, "optimizer": args.optimizer},
