@@ -287,6 +287,15 @@ def embed(plan, X, want_fm=False, full=False):
     sharder = getattr(plan, "sharder", None)
     if sharder is not None:          # table-sharded multi-GPU training (parallel.ShardedTrainer)
         return sharder.embed(X, want_fm, full)
+    owner = getattr(plan, "_owner", None)
+    if owner is not None and getattr(owner, "sharder", None) is not None and torch.is_grad_enabled():
+        # A SECONDARY plan over tables that a ShardedTrainer has sharded (gather_columns / input_from_feature_columns /
+        # Linear.forward next to the model's own fused lookup: IFM / DIFM-style models): this rank's copy of a table it
+        # does not own is stale and the local update below would fork it -- training would diverge silently (round-3
+        # advisor finding).  Only lookups through the model plan go through the exchange.
+        raise NotImplementedError("this lookup reads tables that are sharded across ranks (ShardedTrainer) through a "
+                                  "secondary plan: only the model's own fused lookup is routed through the exchange; "
+                                  "train this model with DataParallelTrainer")
     plan.bind(X.device)
     out, wide, fm = EmbedFunction.apply(plan, X, plan.anchor, plan.wide_dense_weight, bool(want_fm),
                                         torch.is_grad_enabled())

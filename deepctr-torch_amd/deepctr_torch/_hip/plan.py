@@ -129,7 +129,8 @@ class LazyState(object):
         plan = self.plan
         if self.step is None or self.step.device != torch.device(device):
             t0 = 0
-            if self.optimizer is not None and self.kind == "adam":      # resume: Adam's bias correction needs t
+            if self.optimizer is not None and self.kind in ("adam", "rmsprop"):   # resume: Adam's bias correction needs t;
+                # (RMSprop's step only counts, but flush() writes the device counter back into optimizer.state)
                 for p in plan.table_params:
                     st = self.optimizer.state.get(p, {})
                     if "step" in st:

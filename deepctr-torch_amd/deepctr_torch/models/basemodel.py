@@ -169,7 +169,11 @@ class BaseModel(nn.Module):
             fused["slab"].sync_optimizer_state()      # Adam's per-parameter `step` entries
 
     def state_dict(self, *args, **kwargs):
-        """The reference's keys / shapes / values.  A table the fused Adagrad update seated in an interleaved slab
+        """The reference's keys / shapes / values -- as COPIES for every entry that is a view of a larger storage (all
+        interleaved Adagrad tables, all dense parameters of a fused-step model): unlike ``nn.Module.state_dict()`` those
+        entries do not alias the parameters (an in-place edit of one is not seen by the model: use ``load_state_dict``),
+        and a call allocates a transient copy of every such table on the device (``keep_vars=True`` returns the aliasing
+        views).  A table the fused Adagrad update seated in an interleaved slab
         (_hip/layout.py: row and optimizer state share a 128-byte line) is a strided VIEW; torch.save would serialise the
         whole underlying storage -- 2-4x the table's bytes, optimizer accumulators included (round-2 advisor finding).
         The dense parameters of a fused-step model are views of ONE flat slab likewise.  Every entry that is a view of
@@ -1015,10 +1019,8 @@ class BaseModel(nn.Module):
         L.check(L.lib().dctr_dense_opt_multi(items, len(todo), L.UPD_ADAGRAD if mode[0] == "adagrad" else L.UPD_SGD,
                                              float(mode[1]), float(mode[2]) if len(mode) > 2 else 0.0, stream),
                 "dctr_dense_opt_multi")
-        if rest:
-            for p in todo:
-                p.grad = None
-            return False, reg
+        # the bookkeeping torch.optim would have done for the parameters stepped HERE -- also when `rest` goes on to
+        # optim.step() (round-3 advisor: the early return left Adagrad's state['step'] of `todo` behind)
         if mode[0] == "adagrad":
             for p in todo:
                 st = self.optim.state[p].get("step")
@@ -1026,8 +1028,13 @@ class BaseModel(nn.Module):
                     st += 1
                 elif st is not None:
                     self.optim.state[p]["step"] = st + 1
+        if rest:
+            for p in todo:
+                p.grad = None
+            return False, reg
         if hasattr(self.optim, "_step_count"):
-            self.optim._step_count += 1       # (what torch.optim.lr_scheduler checks to warn about a skipped step())
+            self.optim._step_count += 1       # (what older torch.optim.lr_scheduler checks to warn about a skipped step())
+        self.optim._opt_called = True         # (... and what newer ones check)
         return True, reg
 
     def _step_stacked_groups(self):

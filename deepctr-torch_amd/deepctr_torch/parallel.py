@@ -603,7 +603,8 @@ class ShardedTrainer(object):
     fused sparse update (xDeepFM, FiBiNET, DCN, PNN, ...: the model's own forward / autograd / optimizer between the same
     exchange steps).
 
-      tables   sharded by table (rank u % N owns unit u: its deep table, wide table and their Adagrad state);
+      tables   sharded by table (``layout.owner[u]`` owns unit u -- its deep table, wide table and their Adagrad state --
+               balanced by count, then bytes: ShardLayout.assign);
                forward = owner-side gather + rows all-to-all, backward = row-gradient all-to-all (the sparse
                reduce-scatter, which also carries the NEXT batch's ids to the owners) + the owner's deterministic
                fused update.  Each row is updated once, by its owner, from the gradients of ALL N*B samples -- the
@@ -754,6 +755,9 @@ class ShardedTrainer(object):
                                      g_wd.reshape(-1) if (g_wd is not None and g_wide is not None) else None)
         B = self._x.shape[0]
         send.view(lay.world, B, lay.ldc)[:, :, lay.ids_col:lay.ids_col + lay.n_slots].copy_(self._ids_next)
+        # (what the trainer logs as the total: loss + the FULL regularisation / auxiliary terms, like
+        # DataParallelTrainer and the single-GPU step -- not this rank's 1 / world share that entered the backward)
+        self._autograd_total = (loss + reg).detach().reshape(1)
         return send, loss.detach(), y_pred.detach()
 
     def _dense_step_autograd(self):
@@ -1020,7 +1024,8 @@ class ShardedTrainer(object):
         self._segD()                                                                  # overlaps with the all-reduce
         work.wait()
         self._segE()
-        return loss, loss.reshape(1), y_pred
+        total = getattr(self, "_autograd_total", None) if self.slab is None else None
+        return loss, (total if total is not None else loss.reshape(1)), y_pred
 
     def gather_tables(self):
         """Make every rank's copy of every table (and its optimizer state) current: owner -> all."""
