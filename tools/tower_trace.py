@@ -22,6 +22,8 @@ if len(f) and len(b) == len(f):
     t0 = f[:, 0].min()
     res["train"] = {
         "n_wg": int(len(f)), "start_spread": st(f[:, 0] - t0), "fwd_stage_x": st(f[:, 1] - f[:, 0]),
+        # (round 4, k_embed_tower_train: descriptors + X tile landed in LDS = the gather's first round trip)
+        "fwd_gather_round_trip_1": st(f[:, 10] - f[:, 0]) if f[:, 10].max() > 0 else None,
         "fwd_layer0_mfma": st(f[:, 2] - f[:, 1]), "fwd_layer0_epilogue": st(f[:, 3] - f[:, 2]),
         "fwd_layer0_epilogue:stores": st(f[:, 9] - f[:, 2]) if f[:, 9].max() > 0 else None,
         "fwd_layer0_barrier": st(f[:, 4] - f[:, 3]), "fwd_layer1_mfma": st(f[:, 5] - f[:, 4]),
