@@ -176,7 +176,7 @@ template <bool GATHER>
 __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* smem, float* logit_lds, const GatherArgs& G,
                                                      float* p0s, float* p1s FT_ARG);
 __device__ __forceinline__ void mlp_bwd_fast(const MlpArgs& A, float* smem, const float* g_lds, const float* hb0,
-                                             const float* hb1, int rs_h, bool has_wpre, f32x4 wpre FT_ARG);
+                                             const float* hb1, int rs_h FT_ARG);
 
 // ------------------------------------------------------------------------------------------------------------
 // forward
@@ -962,20 +962,13 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
     for (int e = tid; e < kTM * G.D; e += kT) {
 #pragma clang fp contract(off)      // (k_embed_fwd's roundings: products and sums rounded separately)
       const int r = e / G.D, d = e - r * G.D;
-      // every field's element first -- up to 32 LDS reads in flight -- then the adds in k_embed_fwd's order (read and add
-      // in one loop over a run-time field count was one LDS round trip per field: 1.3 us in front of the first layer)
-      float v[32];
-#pragma unroll
-      for (int f = 0; f < 32; ++f) v[f] = xs[r * rsx + (f < G.n_deep ? f : G.n_deep - 1) * G.D + d];
       float st = 0.f, qt = 0.f;
-#pragma unroll
       for (int w = 0; w < 4; ++w) {
         float sw = 0.f, qw = 0.f;
-#pragma unroll
-        for (int f = w; f < 32; f += 4) {
-          const float x = f < G.n_deep ? v[f] : 0.f;
-          sw += x;
-          qw += x * x;
+        for (int f = w; f < G.n_deep; f += 4) {
+          const float v = xs[r * rsx + f * G.D + d];
+          sw += v;
+          qw += v * v;
         }
         st += sw;
         qt += qw;
@@ -1293,7 +1286,7 @@ __device__ __forceinline__ int bwd_groups(const LayerDev& Ld) { return (Ld.K + 1
 // train kernel with both LDS images): layer j's output then sits in (j & 1 ? hb1 : hb0) for j >= n_layers - 2
 template <int Q>
 __device__ __forceinline__ void mlp_bwd_fast_q(const MlpArgs& A, float* smem, const float* g_lds, const float* hb0,
-                                               const float* hb1, int rs_h, bool has_wpre, f32x4 wpre FT_ARG) {
+                                               const float* hb1, int rs_h FT_ARG) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * kTM;
   const int rs = A.rsd;
@@ -1322,9 +1315,7 @@ __device__ __forceinline__ void mlp_bwd_fast_q(const MlpArgs& A, float* smem, co
         const int64_t b = (b0 + r) < blast ? (b0 + r) : blast;
         if (A.w_out) {
           gv[i] = g_lds ? g_lds[r] : ldg_f32(A.g + b);
-          // (wpre: the fused train kernel requested these four values at its very start -- bwd_top_weights() -- instead
-          // of here, where their L2 round trip sat exposed between the head and the first backward pass: ~1 of 2 us)
-          wv4[i] = (has_wpre && e0 == 0) ? wpre[i] : ldg_f32(A.w_out + nn);
+          wv4[i] = ldg_f32(A.w_out + nn);
         } else {
           gv[i] = ldg_f32(A.g + b * A.ldg + nn);
           wv4[i] = 1.f;
@@ -1392,32 +1383,16 @@ __device__ __forceinline__ void mlp_bwd_fast_q(const MlpArgs& A, float* smem, co
 }
 
 __device__ __forceinline__ void mlp_bwd_fast(const MlpArgs& A, float* smem, const float* g_lds, const float* hb0,
-                                             const float* hb1, int rs_h, bool has_wpre, f32x4 wpre FT_ARG) {
-  if (A.fast == 2) mlp_bwd_fast_q<2>(A, smem, g_lds, hb0, hb1, rs_h, has_wpre, wpre FT_PASS);
-  else mlp_bwd_fast_q<4>(A, smem, g_lds, hb0, hb1, rs_h, has_wpre, wpre FT_PASS);
-}
-
-// the dnn_linear weights the backward's top-gradient staging multiplies by (its first four elements per thread, the
-// index arithmetic of mlp_bwd_fast_q's staging loop), requested ahead of time
-__device__ __forceinline__ f32x4 bwd_top_weights(const MlpArgs& A) {
-  f32x4 wpre;
-  const LayerDev& Lt = A.L[A.n_layers - 1];
-  const int Np = round_up(Lt.N, 16), n_e = kTM * Np;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int e = i * kT + static_cast<int>(threadIdx.x);
-    e = e < n_e ? e : n_e - 1;
-    const int n = e - (e / Np) * Np;
-    wpre[i] = ldg_f32(A.w_out + (n < Lt.N ? n : Lt.N - 1));
-  }
-  return wpre;
+                                             const float* hb1, int rs_h FT_ARG) {
+  if (A.fast == 2) mlp_bwd_fast_q<2>(A, smem, g_lds, hb0, hb1, rs_h FT_PASS);
+  else mlp_bwd_fast_q<4>(A, smem, g_lds, hb0, hb1, rs_h FT_PASS);
 }
 
 __global__ __launch_bounds__(kT) void k_mlp_bwd_data(MlpArgs A) {
   extern __shared__ __align__(16) float smem[];
   FT_DECL;
   if (A.fast) {
-    mlp_bwd_fast(A, smem, nullptr, nullptr, nullptr, 0, false, f32x4{0.f, 0.f, 0.f, 0.f} FT_PASS);
+    mlp_bwd_fast(A, smem, nullptr, nullptr, nullptr, 0 FT_PASS);
     FT_FLUSH(A.trace);
   } else {
     mlp_bwd_body(A, smem, nullptr, nullptr, 0, A.trace);
@@ -1925,9 +1900,6 @@ __device__ __forceinline__ void mlp_train_body(const MlpArgs& A, const HeadArgs&
     h_p1 = ldg_f32((Hd.part1 ? Hd.part1 : Hd.y) + hbc);
   }
   const float h_bias = ldg_f32(Hd.bias ? Hd.bias : Hd.y), h_y = ldg_f32(Hd.y + hbc);
-  const bool has_wtop = (GATHER || A.fast) && A.w_out;
-  f32x4 wtop = {0.f, 0.f, 0.f, 0.f};
-  if (has_wtop) wtop = bwd_top_weights(A);
   FT_DECL;
   FT_DECL_B;
   const float* htop = nullptr;
@@ -1974,8 +1946,8 @@ __device__ __forceinline__ void mlp_train_body(const MlpArgs& A, const HeadArgs&
   // still there and its relu mask needs no global round trip; 0: they alias it (towers too wide for both images)
   if (GATHER || A.fast) {
     float* hb0 = smem + kTM * A.rsx;
-    mlp_bwd_fast(A, smem + bwd_off, gl, bwd_off > 0 ? hb0 : nullptr, bwd_off > 0 ? hb0 + kTM * A.rsh : nullptr, A.rsh,
-                 has_wtop, wtop FT_PASS_B);
+    mlp_bwd_fast(A, smem + bwd_off, gl, bwd_off > 0 ? hb0 : nullptr, bwd_off > 0 ? hb0 + kTM * A.rsh : nullptr, A.rsh
+                 FT_PASS_B);
     FT_FLUSH(A.trace);         // (diag build: the forward's stamps to region 0, the backward's to region 1)
     FT_FLUSH_B(A.trace);
   } else {
