@@ -597,6 +597,182 @@ __global__ __launch_bounds__(kT) void k_bilinear_bwd_data(const float* __restric
   }
 }
 
+// The same gradient, re-dealt BY OWNING FIELD (round 4; the default).  The kernel above walks the pairs in tournament
+// rounds and read-modify-writes both fields' gradient rows in LDS: per pair a dependent chain LDS write -> LDS read -> 4
+// dependent MFMAs -> LDS read-modify-write (~2 600 cycles for 512 of MFMA), a barrier per round (25 barriers = 32 of its
+// 194 us), and 120 KB of LDS = one workgroup of one wave per SIMD per CU.  Here a wave OWNS a field f and walks f's F - 1
+// partners in partner order, accumulating gX_f in registers:
+//     f is the pair's j:  acc += gp (.) (x_i W^T)          (one MFMA group, as the forward's)
+//     f is the pair's i:  acc += (gp (.) x_j) W            (layout change of gp (.) x_j through the wave's own LDS scratch)
+// No LDS read-modify-write shared between waves, no barrier after the staging, 70 KB of LDS: two workgroups per CU
+// (blockIdx.y splits the fields in two halves), eight waves per CU.  Every pair is visited twice (by its two owners), so
+// the incoming gradient is read twice -- the second read comes from L2: both owners sit on the same CU within
+// microseconds.  The owner table own[f][slot(partner)] = {partner, side, weight index, pair index} is rebuilt from the
+// tournament schedule by every workgroup (no counters: a partner's slot is its index, so the order of additions is fixed).
+template <int KPD>
+__global__ __launch_bounds__(kT) void k_bilinear_bwd_data_own(const float* __restrict__ E, int64_t lde,
+                                                              const float* __restrict__ V, int64_t ldv,
+                                                              const float* __restrict__ Wf,
+                                                              const int32_t* __restrict__ sched, int n_sched, int P,
+                                                              int F, int D, int B, const float* __restrict__ gout,
+                                                              int64_t ldg, float* __restrict__ gE,
+                                                              float* __restrict__ gV, int nsplit) {
+  extern __shared__ __align__(16) float smem[];
+  const int RS = row_stride(F, D), W = F * D;
+  float* xs0 = smem;
+  float* xs1 = xs0 + kSB * RS;
+  float* tb = xs1 + kSB * RS;   // [4 waves][16][17] layout-change scratch (wave-private)
+  int32_t* own = reinterpret_cast<int32_t*>(tb + 4 * 16 * 17);   // [F][F - 1][4]
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int b0 = blockIdx.x * kSB;
+  const int npass = V ? 2 : 1;
+  const int npar = F - 1;
+  for (int e = tid; e < n_sched; e += kT) {
+    const i32x4 v = *(const DCTR_GLOBAL i32x4*)(sched + 4 * e);
+    if (v.x >= 0) {     // pair (i = v.x < j = v.y): in i's row it sits at slot j - 1, in j's row at slot i
+      *reinterpret_cast<i32x4*>(own + 4 * (v.x * npar + v.y - 1)) = i32x4{v.y, 1, v.z, v.w};
+      *reinterpret_cast<i32x4*>(own + 4 * (v.y * npar + v.x)) = i32x4{v.x, 0, v.z, v.w};
+    }
+  }
+  stage_rows(xs0, RS, V ? V : E, V ? ldv : lde, b0, B, W);
+  if (V) stage_rows(xs1, RS, E, lde, b0, B, W);
+  __syncthreads();
+  float* mytb = tb + wv * (16 * 17);
+  const int owner = static_cast<int>(blockIdx.y) * 4 + wv, stride = 4 * nsplit;
+  const int nf = owner < F ? (F - 1 - owner) / stride + 1 : 0;   // fields owner, owner + stride, ...
+  const int nvis = nf * npar;
+  if (nvis == 0) return;
+  const bool cv = c < D;
+  const int ccl = cv ? c : 0;
+  int dcl[4];
+  bool dv[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    dv[s] = 4 * g + s < D;
+    dcl[s] = dv[s] ? 4 * g + s : 0;
+  }
+  int64_t grow[4];                         // clamped gout row offsets of this lane's 4 samples
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int b = b0 + 4 * g + r;
+    grow[r] = static_cast<int64_t>(b < B ? b : B - 1) * ldg + ccl;
+  }
+  struct Vis { int f, p, side, wi, k; };
+  auto visit = [&](int v) -> Vis {
+    const int vc = v < nvis ? v : nvis - 1;
+    const int fi = vc / npar, t = vc - fi * npar;
+    Vis x;
+    x.f = owner + fi * stride;
+    const i32x4 e = *reinterpret_cast<const i32x4*>(own + 4 * (x.f * npar + t));
+    x.p = e.x; x.side = e.y; x.wi = e.z; x.k = e.w;
+    return x;
+  };
+  float wr[KPD][4], gpr[KPD][2][4];
+  auto issue = [&](const Vis& x, float (&w)[4], float (&gp)[2][4]) {
+    // the pair's weight tile as THIS visit's B operand: W[e = c][d = 4g + s] (f is j) or W[e = 4g + s][d = c] (f is i)
+    const float* base = Wf + static_cast<int64_t>(x.wi) * D * D;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int d = 4 * g + s;
+      const int idx = x.side ? d * D + c : c * D + d;
+      w[s] = ldg_f32(base + ((c < D && d < D) ? idx : 0));
+    }
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        gp[ps][r] = ldg_f32(gout + grow[r] + (static_cast<int64_t>(ps < npass ? ps : 0) * P + x.k) * D);
+  };
+#pragma unroll
+  for (int u = 0; u < KPD; ++u) {
+    issue(visit(u), wr[u], gpr[u]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float acc[2][4];
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[ps][r] = 0.f;
+  // one visit: no memory operation behind a branch (the two sides differ in LDS / MFMA work only), so the waits for the
+  // ring stay exact
+  auto body = [&](int v, float (&wslot)[4], float (&gslot)[2][4]) {
+    const Vis x = visit(v);
+    float wreg[4], gpc[2][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wreg[s] = (cv && dv[s]) ? wslot[s] : 0.f;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gpc[ps][r] = (cv && b0 + 4 * g + r < B) ? gslot[ps][r] : 0.f;
+    issue(visit(v + KPD), wslot, gslot);
+    // every LDS operand read unconditionally before the first MFMA: the partner as A operand (f is j) and in the
+    // accumulator layout (f is i)
+    float xa[2][4], xp[2][4];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const float* xs = (ps && npass > 1) ? xs1 : xs0;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) xa[ps][s] = xs[c * RS + x.p * D + dcl[s]];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xp[ps][r] = xs[(4 * g + r) * RS + x.p * D + ccl];
+    }
+    if (x.side == 0) {          // f = j: acc[b][e] += gp[b][e] * (x_i W^T)[b][e]
+      f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        t0 = mfma16(dv[s] ? xa[0][s] : 0.f, wreg[s], t0);
+        t1 = mfma16(dv[s] ? xa[1][s] : 0.f, wreg[s], t1);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[0][r] += gpc[0][r] * t0[r];
+        acc[1][r] += gpc[1][r] * t1[r];
+      }
+    } else {                    // f = i: acc[b][d] += sum_e (gp (.) x_j)[b][e] W[e][d]
+      for (int ps = 0; ps < npass; ++ps) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mytb[(4 * g + r) * 17 + c] = cv ? gpc[ps][r] * xp[ps][r] : 0.f;   // C layout
+        float ga[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ga[s] = mytb[c * 17 + 4 * g + s];                             // A layout
+        f32x4 uu = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) uu = mfma16(ga[s], wreg[s], uu);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ps][r] += uu[r];
+      }
+    }
+  };
+  auto flush = [&](int f) {     // the field is complete: out it goes
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = b0 + 4 * g + r;
+      if (cv && b < B) {
+        const int64_t o = static_cast<int64_t>(b) * W + f * D + c;
+        if (V) {
+          stg_f32(gV + o, acc[0][r]);
+          stg_f32(gE + o, acc[1][r]);
+        } else {
+          stg_f32(gE + o, acc[0][r]);
+        }
+      }
+      acc[0][r] = acc[1][r] = 0.f;
+    }
+  };
+  // (host: KPD divides F - 1, so a field is a whole number of ring rounds and its stores sit BETWEEN the pipelined loops)
+  const int groups = npar / KPD;
+  for (int fi = 0; fi < nf; ++fi) {
+    for (int gi = 0; gi < groups; ++gi) {
+#pragma unroll
+      for (int u = 0; u < KPD; ++u) {
+        body((fi * groups + gi) * KPD + u, wr[u], gpr[u]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    flush(owner + fi * stride);
+  }
+}
+
 // gradient w.r.t. the weights: gW_k[e][d] = sum_b (gp (.) x_j)[b][e] x_i[b][d], both passes.
 // Workgroup (sample group sg, pair slice): partial[sg][k][e][d]; rows = e, columns = d, reduction = samples.
 __global__ __launch_bounds__(kT) void k_bilinear_bwd_weight(const float* __restrict__ E, int64_t lde,
@@ -904,7 +1080,30 @@ extern "C" int dctr_bilinear_bwd(const float* E, int64_t ld_e, const float* V, i
     (void)hipMemsetAsync(gW, 0, sizeof(float) * n_w * D * D, s);
     return DCTR_OK;
   }
-  {
+  const size_t lds_own = tile_bytes(F, D, 2) + 4u * 16 * 17 * sizeof(float) + static_cast<size_t>(F) * (F - 1) * 16;
+  bool by_owner = lds_own <= 158 * 1024;
+#ifdef DCTR_DIAG
+  if (const char* e = getenv("DCTR_BILINEAR_BWD")) by_owner = by_owner && e[0] != 't';   // "tournament": the round 1-3 kernel
+#endif
+  if (by_owner) {
+    const int nsplit = (2 * lds_own <= 158 * 1024 && F > 4) ? 2 : 1;
+    const dim3 grid((B + kSB - 1) / kSB, nsplit);
+    const int npar = F - 1;      // the ring depth divides the partners per field (25 at the Criteo shape: 5)
+#define DCTR_OWN(K)                                                                                               \
+    do {                                                                                                          \
+      if (lds_own > 64 * 1024)                                                                                    \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bilinear_bwd_data_own<K>),                     \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_own));         \
+      k_bilinear_bwd_data_own<K><<<grid, dim3(kT), lds_own, s>>>(E, ld_e, V, ld_v, Wf, sched, n_sched, P, F, D, B, \
+                                                                 gout, ld_g, gE, gV, nsplit);                     \
+    } while (0)
+    if (npar % 5 == 0) DCTR_OWN(5);
+    else if (npar % 4 == 0) DCTR_OWN(4);
+    else if (npar % 3 == 0) DCTR_OWN(3);
+    else if (npar % 2 == 0) DCTR_OWN(2);
+    else DCTR_OWN(1);
+#undef DCTR_OWN
+  } else {
     size_t lds = tile_bytes(F, D, 4) + 4u * 16 * 17 * sizeof(float);
     if (lds > 158 * 1024) return DCTR_ENOSUP;
     const int sch_lds = lds + static_cast<size_t>(n_sched) * 16 <= 158 * 1024;
