@@ -50,13 +50,15 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the xDeepFM / FiBiNET legs (BASELINE.json configs 3-4) of the N=1 line")
     ap.add_argument("--force-parallel", action="store_true", help="use the data-parallel trainer even with 1 rank")
-    ap.add_argument("--exchange", default=os.environ.get("DCTR_SHARDED_EXCHANGE", "auto"), choices=["auto", "rccl", "direct"],
+    ap.add_argument("--exchange", default=os.environ.get("DCTR_SHARDED_EXCHANGE", "auto"),
+                    choices=["auto", "rccl", "direct", "try-direct"],
                     help="how the table-sharded step exchanges rows / gradients / dense gradients between ranks: 'rccl' = "
                          "torch.distributed collectives issued by the host between hipGraph segments; 'direct' = copies into "
                          "the peers' IPC-mapped buffers + arrival words, the whole step one hipGraph (validated with N "
                          "processes on ONE GPU and at one rank; never run across GPUs: no multi-GPU box was available to the "
-                         "build); 'auto' = direct at one rank, at N > 1 direct only if a two-step self-check succeeds on "
-                         "every rank, else rccl")
+                         "build); 'auto' = direct at one rank, rccl at N > 1 (the path that cannot surprise an unattended "
+                         "scaling run); 'try-direct' = at N > 1 direct if a two-step self-check succeeds on every rank, else "
+                         "rccl")
     ap.add_argument("--kernel-iters", type=int, default=50, help="event-timed launches per hot-path kernel")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed block of --steps steps is run this many times (each bracketed by a synchronize, and a "
@@ -638,6 +640,8 @@ def main():
         from deepctr_torch import parallel as par
         exchange = args.exchange
         if exchange == "auto":
+            exchange = "direct" if (on_gpu and world == 1) else "rccl"
+        elif exchange == "try-direct":
             exchange = "direct" if (on_gpu and world == 1) else ("direct?" if on_gpu else "rccl")
         if exchange == "direct?":
             # N > 1 on GPUs: the direct exchange has only ever run between processes sharing one GPU.  Try it on two
