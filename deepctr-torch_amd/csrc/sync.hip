@@ -122,6 +122,34 @@ __global__ __launch_bounds__(256) void k_sum_ranks(float* __restrict__ dst, cons
 
 }  // namespace
 
+// The exchange's copies and its set-up as plain HIP calls (no torch cross-device logic inside a stream capture):
+// dctr_copy_async = hipMemcpyAsync(device to device) on the caller's stream -- the destination may be memory of another
+// device mapped through IPC; dctr_enable_peer_access(d) lets the CURRENT device's kernels and copies reach device d's
+// memory (hipDeviceEnablePeerAccess; "already enabled" is success; d == current device is a no-op).
+extern "C" int dctr_copy_async(void* dst, const void* src, size_t bytes, dctr_stream_t stream) {
+  if (!dst || !src) return DCTR_EINVAL;
+  if (bytes == 0) return DCTR_OK;
+  return hip_status(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+}
+
+extern "C" int dctr_enable_peer_access(int32_t peer_device) {
+  int cur = -1;
+  hipError_t e = hipGetDevice(&cur);
+  if (e != hipSuccess) return hip_status(e);
+  if (peer_device < 0) return DCTR_EINVAL;
+  if (peer_device == cur) return DCTR_OK;
+  int can = 0;
+  e = hipDeviceCanAccessPeer(&can, cur, peer_device);
+  if (e != hipSuccess) return hip_status(e);
+  if (!can) return DCTR_ENOSUP;
+  e = hipDeviceEnablePeerAccess(peer_device, 0);
+  if (e == hipErrorPeerAccessAlreadyEnabled) {
+    (void)hipGetLastError();
+    return DCTR_OK;
+  }
+  return hip_status(e);
+}
+
 extern "C" int dctr_exchange_post(int32_t* const* peer_words, int32_t n, int32_t my_index, const int32_t* step,
                                   dctr_stream_t stream) {
   if (!peer_words || !step || n <= 0 || n > 64 || my_index < 0) return DCTR_EINVAL;

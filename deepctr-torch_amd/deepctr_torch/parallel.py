@@ -505,6 +505,12 @@ class DirectExchange(object):
                 for k, t in enumerate(mine):
                     self.peers[k][r] = t if r == rank else handles[k][0](*got[r][k])
             self._keep = got
+            # this device's kernels and copies reach every peer's buffers (ranks on ONE device: nothing to enable)
+            with torch.cuda.device(dev):
+                for r in range(world):
+                    pd = self.peers[0][r].device.index
+                    if pd is not None and pd != dev.index:
+                        L.check(L.lib().dctr_enable_peer_access(int(pd)), "dctr_enable_peer_access(%d)" % pd)
         # device tables of the peers' word arrays, one per exchange kind
         self.word_ptrs = []
         for kind in range(len(self.KINDS)):
@@ -525,10 +531,20 @@ class DirectExchange(object):
                                            self.timeout_us, self._ptr(self.err), L.stream_handle(self.words.device)),
                 "dctr_exchange_sync")
 
+    def _copy(self, dst, src):
+        """device-to-device copy on the current stream as ONE hipMemcpyAsync (capturable; no torch cross-device stream
+        logic: the destination may live on a peer GPU)"""
+        if not (dst.is_contiguous() and src.is_contiguous()) or dst.numel() != src.numel() or dst.dtype != src.dtype:
+            dst.copy_(src, non_blocking=True)
+            return
+        L = self.L
+        L.check(L.lib().dctr_copy_async(self._ptr(dst), self._ptr(src), dst.numel() * dst.element_size(),
+                                        L.stream_handle(src.device)), "dctr_copy_async")
+
     def _scatter(self, which, src):
         """src [world, ...]: slice r goes to rank r's buffer `which`, into this rank's slot"""
         for r in range(self.world):
-            self.peers[which][r][self.rank].copy_(src[r], non_blocking=True)
+            self._copy(self.peers[which][r][self.rank], src[r])
 
     def send_rows(self, chunks):
         self._scatter(0, chunks.view(self.recv.shape))
@@ -551,7 +567,7 @@ class DirectExchange(object):
         import ctypes
         n = flat.numel()
         for r in range(self.world):
-            self.peers[2][r][self.rank][:n].copy_(flat, non_blocking=True)
+            self._copy(self.peers[2][r][self.rank][:n], flat)
         self._sync("dense", 0, True)
         L = self.L
         L.check(L.lib().dctr_sum_ranks(self._ptr(flat), self._ptr(self.dense), self.world, n, self.ld_dense,

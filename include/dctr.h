@@ -582,6 +582,11 @@ int dctr_step_signal(int32_t* sync, int32_t signal, dctr_stream_t stream);
  * this rank's slot in it.  Post behind the copies (same stream); wait in front of the consumer; next advances the counter.
  * A wait gives up after timeout_us and raises bit 1 of *err.  dctr_sum_ranks: dst[i] = sum_r src[r * ld + i] in rank
  * order (the dense gradients' all-reduce = all-gather by copy + this sum: every rank lands on the same bits).          */
+/* hipMemcpyAsync(device to device) on the caller's stream (dst may be another device's memory mapped through IPC);
+ * dctr_enable_peer_access(d): the current device may reach device d's memory (no-op for d == current device,
+ * DCTR_ENOSUP when the devices have no peer path).                                                                  */
+int dctr_copy_async(void* dst, const void* src, size_t bytes, dctr_stream_t stream);
+int dctr_enable_peer_access(int32_t peer_device);
 int dctr_exchange_post(int32_t* const* peer_words, int32_t n, int32_t my_index, const int32_t* step, dctr_stream_t stream);
 int dctr_exchange_wait(const int32_t* words, int32_t n, const int32_t* step, int32_t timeout_us, int32_t* err,
                        dctr_stream_t stream);

@@ -2,7 +2,7 @@
 # round 4: the direct exchange -- N processes on one GPU (parity), one rank whole-step graph (timing + timeline)
 export TMPDIR=/tmp
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-O=$GRAFT_REPO_ROOT/gpurun_out/r4_direct2
+O=$GRAFT_REPO_ROOT/gpurun_out/r4_direct3
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 timeout 900 python -m pytest tests/test_gpu_direct_exchange.py -q --tb=short 2>&1 | grep -v "amdgpu.ids\|Gloo\|CudaIPC" | tail -30 > $O/pytest.txt
