@@ -88,6 +88,9 @@ class GraphedTrainStep(object):
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             outs = []
+            eng = (getattr(model, "_fused", None) or {}).get("engine")
+            if eng is not None:
+                eng._prepassed = None        # (a capture that was abandoned half-way must not lend its pre-pass to this one)
             with no_gc_during_capture(), torch.cuda.graph(g, pool=pool,
                                                           stream=_streams.side_stream(xb.device, "capture")):
                 try:
