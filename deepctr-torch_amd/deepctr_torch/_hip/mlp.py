@@ -209,10 +209,21 @@ def tower(dnn, dnn_linear, x, K=None, sink=None):
     """``dnn_linear(dnn(x[:, :K]))`` (or ``dnn(x[:, :K])`` when ``dnn_linear`` is None)."""
     spec = tower_layers(dnn, dnn_linear)
     K = x.shape[1] if K is None else K
-    if spec is None or not x.is_cuda or K > 4096:   # very wide inputs (FiBiNET's 10 k) stay on hipBLASLt for now
+    if spec is not None and x.is_cuda and K > 4096 and len(spec[0]) >= 2:
+        # A very wide FIRST layer (FiBiNET: 10 413 inputs) stays one hipBLASLt GEMM each way; everything behind it -- the
+        # remaining layers, dnn_linear, their backward and weight gradients -- runs on the tower kernels over its output
+        # (round 4: those small layers were 6 hipBLASLt GEMMs of 8-27 us plus ~10 elementwise / reduce launches per step).
+        W0, b0, relu0 = spec[0][0]
+        h0 = torch.nn.functional.linear(x[:, :K] if K != x.shape[1] else x, W0, b0)
+        if relu0:
+            h0 = torch.relu(h0)
+        layers, w_out = spec[0][1:], spec[1]
+        x, K = h0, W0.shape[0]
+    elif spec is None or not x.is_cuda or K > 4096:   # (a single very wide layer, or modules outside the kernels)
         h = dnn(x[:, :K] if K != x.shape[1] else x)
         return dnn_linear(h) if dnn_linear is not None else h
-    layers, w_out = spec
+    else:
+        layers, w_out = spec
     params = []
     for (W, b, _) in layers:
         params += [W, b]
