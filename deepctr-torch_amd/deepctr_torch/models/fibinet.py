@@ -44,7 +44,7 @@ class FiBiNET(BaseModel):
         emb = gathered[:, :plan.emb_width].reshape(B, nf, plan.emb_dim)       # views of the gather's output
         dense = gathered[:, plan.emb_width:] if plan.dense_cols else None
         dnn_input = self.Bilinear.fused_pair(emb, self.SE(emb), dense)
-        dnn_logit = self.dnn_linear(self.dnn(dnn_input))
+        dnn_logit = self.tower_logit(dnn_input)     # wide first layer on hipBLASLt, the rest on csrc/mlp.hip
         if len(self.linear_feature_columns) > 0 and len(self.dnn_feature_columns) > 0:
             return [linear_logit, dnn_logit]
         elif len(self.linear_feature_columns) == 0:
