@@ -26,7 +26,7 @@ constexpr int kNW = 4;  // waves per workgroup
 constexpr int kThreads = kNW * kWave;
 constexpr int kFieldWords = sizeof(dctr_field_t) / 4;
 static_assert(sizeof(dctr_field_t) == 64, "dctr_field_t must be 64 bytes");
-static_assert(sizeof(dctr_plan_t) == 96, "dctr_plan_t layout changed: update the Python binding");
+static_assert(sizeof(dctr_plan_t) == 112, "dctr_plan_t layout changed: update the Python binding");
 
 struct Tile {
   const dctr_field_t* deep;
@@ -176,7 +176,13 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
   const float* xr = T.xs + g * P.n_xcols;
   const int e0 = gl * VEC;
   int bad = 0;
-  float* orow = out ? out + static_cast<int64_t>(b) * ldo : nullptr;
+  // P.out_chunks: output rows go to per-rank buffers (peer memory: the sharded step's push-style rows exchange)
+  const auto row_of = [&](int row) -> float* {
+    if (!P.out_chunks) return out + static_cast<int64_t>(row) * ldo;
+    const int r = row / P.chunk_rows;
+    return reinterpret_cast<float*>(P.out_chunks[r]) + static_cast<int64_t>(row - r * P.chunk_rows) * ldo;
+  };
+  float* orow = out ? row_of(b) : nullptr;
   float* lrow = lrows + g * ldo;
 
   // side output for dctr_embed_update: the ids of this tile, transposed to [unit][b] (64-byte runs)
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
       }
       if (wide) {
         wt = group_sum<LPR>(wt);
-        if (gl == 0 && valid) stg_f32(wide + static_cast<int64_t>(b) * ldw, wt, staged);
+        if (gl == 0 && valid) stg_f32(P.out_chunks ? orow + (wide - out) : wide + static_cast<int64_t>(b) * ldw, wt, staged);
       }
     }
   }
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
     const int q4 = static_cast<int>(ldo >> 2);
     for (int r = wv_id; r < nrows; r += kNW) {
       const f32x4* src = reinterpret_cast<const f32x4*>(lrows + r * ldo);
-      float* dst = out + static_cast<int64_t>(b0 + r) * ldo;
+      float* dst = row_of(b0 + r);
       for (int c = lane; c < q4; c += kWave) stg_wt(dst + 4 * c, src[c]);
     }
   } else if (thru) {
@@ -622,6 +628,8 @@ extern "C" int dctr_embed_fwd(const dctr_plan_t* plan, const float* X, int64_t l
   if (fm_s && (plan->emb_dim <= 0 || !out || ld_s < plan->emb_dim)) return DCTR_EINVAL;
   if (ids_t && (!units || n_units <= 0)) return DCTR_EINVAL;
   if (parts_t && !ids_t) return DCTR_EINVAL;
+  if (plan->out_chunks && (plan->chunk_rows <= 0 || !out || (wide && (ld_wide != ld_out || wide < out || wide - out >= ld_out))))
+    return DCTR_EINVAL;
   const int n_parts = parts_t ? dctr_embed_update_partitions(plan, B) : 0;
   if (parts_t && (n_parts <= 0 || n_parts > 65535)) return DCTR_ENOSUP;
   if (fm_s && plan->vec > 1 &&

@@ -23,9 +23,18 @@ namespace {
 
 constexpr int kT = 256;
 
+// row b of the chunk for owner q: inside the local [N][B][ldc] staging array, or -- push-style exchange -- inside owner q's
+// receive buffer
+__device__ __forceinline__ float* chunk_row(float* send, const uint64_t* chunks, int q, int64_t B, int64_t b, int64_t ldc) {
+  return chunks ? reinterpret_cast<float*>(chunks[q]) + b * ldc : send + (static_cast<int64_t>(q) * B + b) * ldc;
+}
+
 struct AsmArgs {
   const float* recv;     // forward: [N][B][ldc] chunks by owner;   backward: unused
   float* send;           // backward: [N][B][ldc] chunks by owner
+  const uint64_t* send_chunks;   // or: chunk q at (float*)send_chunks[q] ([B][ldc], owner q's receive buffer: peer memory)
+  int32_t carry_col, carry_n;    // send_chunks: columns [carry_col, +carry_n) of every local send row ride along (the next
+                                 // batch's ids, staged there by dctr_shard_stage)
   int64_t ldc;
   int32_t N, B, F, D;    // ranks, local batch, deep units (fields), embedding dim
   const int32_t* owner_slot;   // [F] owner | slot << 16 of every unit, or NULL: owner f % N, slot f / N
@@ -140,11 +149,18 @@ __global__ __launch_bounds__(kT) void k_assemble_bwd(AsmArgs A) {
     owner_of(A.owner_slot, f, A.N, q, j);
     float g = A.g_out ? ldg_f32(A.g_out + b * A.ldg + e) : 0.f;
     if (A.g_fm) g += gf * (ldg_f32(A.fm_s + b * A.lds_ + d) - ldg_f32(A.out + b * A.ldo + e));
-    stg_f32(A.send + (static_cast<int64_t>(q) * A.B + b) * A.ldc + j * A.D + d, g);
+    stg_f32(chunk_row(A.send, A.send_chunks, q, A.B, b, A.ldc) + j * A.D + d, g);
   }
   if (A.wide_col >= 0) {
     const float gw = A.g_wide ? ldg_f32(A.g_wide + b) : 0.f;
-    for (int q = c; q < A.N; q += 16) stg_f32(A.send + (static_cast<int64_t>(q) * A.B + b) * A.ldc + A.wide_col, gw);
+    for (int q = c; q < A.N; q += 16) stg_f32(chunk_row(A.send, A.send_chunks, q, A.B, b, A.ldc) + A.wide_col, gw);
+  }
+  if (A.send_chunks && A.carry_n > 0) {
+    for (int t = c; t < A.N * A.carry_n; t += 16) {
+      const int q = t / A.carry_n, j = t - q * A.carry_n;
+      stg_f32(chunk_row(nullptr, A.send_chunks, q, A.B, b, A.ldc) + A.carry_col + j,
+              ldg_f32(chunk_row(A.send, nullptr, q, A.B, b, A.ldc) + A.carry_col + j));
+    }
   }
 }
 
@@ -259,13 +275,20 @@ __global__ __launch_bounds__(kT) void k_assemble_bwd_v4(AsmArgs A) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) o[c] += gf * (S[c] - e[k][c]);
         }
-        *(DCTR_GLOBAL f32x4*)(A.send + (static_cast<int64_t>(q) * A.B + b) * A.ldc + j * D + 4 * d4) = o;
+        *(DCTR_GLOBAL f32x4*)(chunk_row(A.send, A.send_chunks, q, A.B, b, A.ldc) + j * D + 4 * d4) = o;
       }
     }
   }
   if (A.wide_col >= 0) {
     const float gw = A.g_wide ? ldg_f32(A.g_wide + b) : 0.f;
-    for (int q = l; q < A.N; q += LPS) stg_f32(A.send + (static_cast<int64_t>(q) * A.B + b) * A.ldc + A.wide_col, gw);
+    for (int q = l; q < A.N; q += LPS) stg_f32(chunk_row(A.send, A.send_chunks, q, A.B, b, A.ldc) + A.wide_col, gw);
+  }
+  if (A.send_chunks && A.carry_n > 0) {
+    for (int t = l; t < A.N * A.carry_n; t += LPS) {
+      const int q = t / A.carry_n, j = t - q * A.carry_n;
+      stg_f32(chunk_row(nullptr, A.send_chunks, q, A.B, b, A.ldc) + A.carry_col + j,
+              ldg_f32(chunk_row(A.send, nullptr, q, A.B, b, A.ldc) + A.carry_col + j));
+    }
   }
 }
 
@@ -329,24 +352,27 @@ extern "C" int dctr_shard_assemble_fwd(const float* recv, int64_t ld_chunk, int3
   return launch_status();
 }
 
-extern "C" int dctr_shard_assemble_bwd(float* send, int64_t ld_chunk, int32_t n_ranks, int32_t B, int32_t F, int32_t D,
+extern "C" int dctr_shard_assemble_bwd(float* send, const uint64_t* send_chunks, int32_t carry_col, int32_t carry_n,
+                                       int64_t ld_chunk, int32_t n_ranks, int32_t B, int32_t F, int32_t D,
                                        const int32_t* owner_slot, int32_t wide_col, const float* g_out, int64_t ld_g, const float* g_wide,
                                        const float* g_fm, const float* out, int64_t ld_out, const float* fm_s,
                                        int64_t ld_s, const float* X, int64_t ld_x, const int32_t* wdense_cols,
                                        int32_t n_wdense, float* g_wdense, dctr_stream_t stream) {
-  if (!send || n_ranks <= 0 || B < 0 || F <= 0 || D <= 0) return DCTR_EINVAL;
+  if ((!send && !send_chunks) || n_ranks <= 0 || B < 0 || F <= 0 || D <= 0) return DCTR_EINVAL;
   if (g_fm && (!out || !fm_s)) return DCTR_EINVAL;
+  if (carry_n < 0 || (carry_n > 0 && (!send || !send_chunks || carry_col < 0 || carry_col + carry_n > ld_chunk))) return DCTR_EINVAL;
   if (g_wdense && (!X || !g_wide || !wdense_cols || n_wdense <= 0)) return DCTR_EINVAL;
   if (B == 0) return DCTR_OK;
   AsmArgs a = {};
-  a.send = send; a.ldc = ld_chunk; a.N = n_ranks; a.B = B; a.F = F; a.D = D; a.wide_col = wide_col;
+  a.send = send; a.send_chunks = send_chunks; a.carry_col = carry_col; a.carry_n = carry_n; a.ldc = ld_chunk; a.N = n_ranks; a.B = B; a.F = F; a.D = D; a.wide_col = wide_col;
   a.owner_slot = owner_slot;
   a.g_out = g_out; a.ldg = ld_g; a.g_wide = g_wide; a.g_fm = g_fm; a.out = const_cast<float*>(out); a.ldo = ld_out;
   a.fm_s = const_cast<float*>(fm_s); a.lds_ = ld_s; a.X = X; a.ldx = ld_x; a.wdense_cols = wdense_cols;
   a.n_wdense = n_wdense; a.g_wdense = g_wdense;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned extra = g_wdense ? static_cast<unsigned>(n_wdense) : 0u;
-  const bool vec = D % 4 == 0 && ld_chunk % 4 == 0 && al16(send) && (!g_out || (ld_g % 4 == 0 && al16(g_out))) &&
+  // (send_chunks: the receive buffers are whole allocations, 16-byte aligned by construction -- the caller's contract)
+  const bool vec = D % 4 == 0 && ld_chunk % 4 == 0 && (send_chunks || al16(send)) && (!g_out || (ld_g % 4 == 0 && al16(g_out))) &&
                    (!g_fm || (ld_out % 4 == 0 && al16(out) && ld_s % 4 == 0 && al16(fm_s)));
   const dim3 g8((B + 7) / 8 + extra), blk(kT);
   if (vec && D == 16) k_assemble_bwd_v4<4><<<g8, blk, 0, st>>>(a);

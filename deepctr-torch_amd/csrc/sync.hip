@@ -99,22 +99,26 @@ __global__ void k_exch_next(int32_t* step) {
 }
 
 // dst[i] = sum over the n ranks' slabs, in rank order (every rank computes the same bits): the dense gradients' all-reduce
-// as all-gather by copy engines + this local sum
-__global__ __launch_bounds__(256) void k_sum_ranks(float* __restrict__ dst, const float* __restrict__ src, int n_ranks,
-                                                   int64_t n, int64_t ld, DenseStepDev S) {
+// as all-gather by copy engines + this local sum -- or, tbl != NULL, as a PULL: rank r's slab is read where it lies
+// ((const float*)tbl[r], peer memory) and nothing is copied.  store == 0: the sum is only consumed by the optimizer step
+// (dst then just names the gradients' positions in the slab; it may alias a source that peers are still reading).
+__global__ __launch_bounds__(256) void k_sum_ranks(float* __restrict__ dst, const float* __restrict__ src,
+                                                   const uint64_t* __restrict__ tbl, int n_ranks, int64_t n, int64_t ld,
+                                                   DenseStepDev S, int store) {
   const int64_t i = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 4;
   if (i >= n) return;
+  const auto slab = [&](int r) -> const float* { return tbl ? reinterpret_cast<const float*>(tbl[r]) : src + r * ld; };
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (i + 3 < n) {
-    for (int r = 0; r < n_ranks; ++r) acc += *(const DCTR_GLOBAL f32x4*)(src + r * ld + i);
-    *(DCTR_GLOBAL f32x4*)(dst + i) = acc;
+    for (int r = 0; r < n_ranks; ++r) acc += *(const DCTR_GLOBAL f32x4*)(slab(r) + i);
+    if (store) *(DCTR_GLOBAL f32x4*)(dst + i) = acc;
 #pragma unroll
     for (int c = 0; c < 4; ++c) dense_step_apply(S, dst + i + c, acc[c]);
   } else {
     for (int64_t k = i; k < n; ++k) {
       float a = 0.f;
-      for (int r = 0; r < n_ranks; ++r) a += ldg_f32(src + r * ld + k);
-      stg_f32(dst + k, a);
+      for (int r = 0; r < n_ranks; ++r) a += ldg_f32(slab(r) + k);
+      if (store) stg_f32(dst + k, a);
       dense_step_apply(S, dst + k, a);
     }
   }
@@ -171,13 +175,15 @@ extern "C" int dctr_exchange_next(int32_t* step, dctr_stream_t stream) {
   return launch_status();
 }
 
-extern "C" int dctr_sum_ranks(float* dst, const float* src, int32_t n_ranks, int64_t n, int64_t ld,
-                              const dctr_dense_step_t* step, dctr_stream_t stream) {
-  if (!dst || !src || n_ranks <= 0 || n < 0 || ld < n) return DCTR_EINVAL;
-  if (ld % 4 != 0 || reinterpret_cast<uintptr_t>(dst) % 16 != 0 || reinterpret_cast<uintptr_t>(src) % 16 != 0) return DCTR_EALIGN;
+extern "C" int dctr_sum_ranks(float* dst, const float* src, const uint64_t* src_tbl, int32_t n_ranks, int64_t n, int64_t ld,
+                              const dctr_dense_step_t* step, int32_t store, dctr_stream_t stream) {
+  if (!dst || (!src && !src_tbl) || n_ranks <= 0 || n < 0 || (!src_tbl && ld < n)) return DCTR_EINVAL;
+  if (!store && !step) return DCTR_EINVAL;      // a sum nobody receives
+  if ((!src_tbl && ld % 4 != 0) || reinterpret_cast<uintptr_t>(dst) % 16 != 0 || reinterpret_cast<uintptr_t>(src) % 16 != 0)
+    return DCTR_EALIGN;
   if (n == 0) return DCTR_OK;
   k_sum_ranks<<<dim3(static_cast<unsigned>((n / 4 + 256) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(
-      dst, src, n_ranks, n, ld, dense_step_dev(step));
+      dst, src, src_tbl, n_ranks, n, ld, dense_step_dev(step), store);
   return launch_status();
 }
 

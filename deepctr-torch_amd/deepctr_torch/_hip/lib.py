@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdctr_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 
@@ -31,7 +31,8 @@ class Plan(ctypes.Structure):
                 ("n_dense", ctypes.c_int32), ("n_wdense", ctypes.c_int32), ("dense_off", ctypes.c_int32),
                 ("emb_dim", ctypes.c_int32), ("n_xcols", ctypes.c_int32), ("n_wide_fixed", ctypes.c_int32),
                 ("max_dim", ctypes.c_int32), ("vec", ctypes.c_int32), ("flags", ctypes.c_int32),
-                ("step_sync", ctypes.c_void_p)]
+                ("step_sync", ctypes.c_void_p), ("out_chunks", ctypes.c_void_p), ("chunk_rows", ctypes.c_int32),
+                ("pad_", ctypes.c_int32)]
 
 
 MLP_MAX_LAYERS = 12
@@ -162,7 +163,7 @@ SIGNATURES = {
     "dctr_exchange_post": (ctypes.c_int, [_P, _I32, _I32, _P, _P]),
     "dctr_exchange_wait": (ctypes.c_int, [_P, _I32, _P, _I32, _P, _P]),
     "dctr_exchange_next": (ctypes.c_int, [_P, _P]),
-    "dctr_sum_ranks": (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _P]),
+    "dctr_sum_ranks": (ctypes.c_int, [_P, _P, _P, _I32, _I64, _I64, _P, _I32, _P]),
     "dctr_exchange_sync": (ctypes.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _P, _P]),
     "dctr_shard_stage": (ctypes.c_int, [_P, _I64, _P, _I32, _I32, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _P, _I64, _I32,
                                         _P]),
@@ -173,7 +174,7 @@ SIGNATURES = {
     "dctr_l2_value_multi": (ctypes.c_int, [ctypes.POINTER(DenseItem), _I32, _P, _P]),
     "dctr_shard_assemble_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _I64, _P, _I32, _I32, _P, _P,
                                                _I32, _P, _I64, _P, _P, _P, _I64, _P]),
-    "dctr_shard_assemble_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _I64, _P, _P, _P, _I64, _P,
+    "dctr_shard_assemble_bwd": (ctypes.c_int, [_P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _I64, _P, _P, _P, _I64, _P,
                                                _I64, _P, _I64, _P, _I32, _P, _P]),
     "dctr_fm_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P]),
     "dctr_fm_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _I64, _I32, _P]),

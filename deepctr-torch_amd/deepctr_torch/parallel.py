@@ -370,10 +370,11 @@ class HipShardOps(object):
             self._idx = torch.tensor(lay.id_cols, dtype=torch.long, device=X.device)
         return lay.pack_ids(X, self._idx)
 
-    def gather(self, ids_all, out=None):
+    def gather(self, ids_all, out=None, push=None):
         """ids_all [N*B, n_slots] (any row stride) -> (chunks [N*B, ldc] = rows of MY tables for every global sample,
         ids_t).  ``out`` = (chunks, ids_t, parts_t) preallocated (the whole-step graph of the direct exchange: what one
-        replay gathers at its end, the next replay sends at its start)."""
+        replay gathers at its end, the next replay sends at its start).  ``push`` = (table, B): rank r's B rows are
+        written straight into ``(float*)table[r]`` -- r's receive buffer -- instead of ``chunks`` (dctr_plan_t.out_chunks)."""
         L, lay, sub = self.L, self.lay, self.sub
         NB, dev = ids_all.shape[0], ids_all.device
         chunks = out[0] if out is not None else torch.empty((NB, lay.ldc), dtype=torch.float32, device=dev)
@@ -383,6 +384,8 @@ class HipShardOps(object):
         ids_t = out[1] if out is not None else torch.empty((len(sub.units), NB), dtype=torch.int32, device=dev)
         parts_t = out[2] if out is not None else torch.empty((len(sub.units), NB), dtype=torch.int16, device=dev)
         wide = self._ptr(chunks, lay.wide_col) if lay.has_wide else None
+        sub.cplan.out_chunks = push[0].data_ptr() if push is not None else None
+        sub.cplan.chunk_rows = int(push[1]) if push is not None else 0
         L.check(L.lib().dctr_embed_fwd(cplan, self._ptr(ids_all), ids_all.stride(0), NB, self._ptr(chunks), lay.ldc,
                                        wide, lay.ldc, None, self._ptr(self.plan.err_flag(dev)), sub.units_ptr(),
                                        len(sub.units), self._ptr(ids_t), self._ptr(parts_t), None, 0,
@@ -414,14 +417,16 @@ class HipShardOps(object):
             L.stream_handle(dev)), "dctr_shard_assemble_fwd")
         return out, wide, fm, fm_s
 
-    def assemble_bwd(self, X, g_out, g_wide, g_fm, out, fm_s, g_wdense, send=None):
+    def assemble_bwd(self, X, g_out, g_wide, g_fm, out, fm_s, g_wdense, send=None, push=None):
+        """``push``: device table of the owners' receive buffers -- chunk q is written there, not into ``send``."""
         L, lay, plan = self.L, self.lay, self.plan
         B, dev = X.shape[0], X.device
         if send is None:
             send = torch.empty((lay.world * B, lay.ldc), dtype=torch.float32, device=dev)
         w = plan.wide_dense_weight
         L.check(L.lib().dctr_shard_assemble_bwd(
-            self._ptr(send), lay.ldc, lay.world, B, lay.F, lay.D, self._ptr(self._owner_map(dev)),
+            self._ptr(send), self._ptr(push), lay.ids_col if push is not None else 0, lay.n_slots if push is not None else 0,
+            lay.ldc, lay.world, B, lay.F, lay.D, self._ptr(self._owner_map(dev)),
             lay.wide_col if lay.has_wide else -1, self._ptr(g_out), g_out.stride(0) if g_out is not None else 0, self._ptr(g_wide), self._ptr(g_fm),
             self._ptr(out), plan.ld_out, self._ptr(fm_s), fm_s.stride(0) if fm_s is not None else 0, self._ptr(X),
             X.stride(0), self._ptr(plan._dev["wdense"]), len(plan.wdense_cols) if (w is not None and g_wdense is not None) else 0,
@@ -476,7 +481,11 @@ class DirectExchange(object):
     needs every rank's gradients of step k, which every rank sends after it has read its rows of step k; words only grow."""
     KINDS = {"rows": 0, "grads": 1, "dense": 2, "ids": 3}
 
-    def __init__(self, group, world, rank, device, B, ldc, n_slots, n_dense, timeout_us=5000000):
+    def __init__(self, group, world, rank, device, B, ldc, n_slots, n_dense, timeout_us=5000000, dense_src=None, push=None):
+        """``push`` (default: env DCTR_SHARDED_PUSH != "0"): the producing KERNELS write into the peers' buffers (tables
+        ``row_tbl`` / ``grad_tbl`` of this rank's slots there) and the dense sum reads the peers' gradient slabs
+        (``dense_src``, shared like the receive buffers) where they lie -- no copy nodes at all.  Otherwise every
+        exchange is N copies out of a local staging buffer."""
         from torch.multiprocessing.reductions import reduce_tensor
         from ._hip import lib as L
         self.L, self.group, self.world, self.rank = L, group, int(world), int(rank)
@@ -489,10 +498,15 @@ class DirectExchange(object):
         self.dense = torch.zeros((world, self.ld_dense), **f32)
         self.ids = torch.zeros((world, B, n_slots), **f32)
         self.words = torch.zeros((len(self.KINDS), 64), dtype=torch.int32, device=dev)
-        self.step = torch.ones((2,), dtype=torch.int32, device=dev)      # [0]: rows / grads / dense, [1]: ids
+        # one exchange counter per kind, advanced by that kind's own sync: exchanges of different kinds may sit on
+        # different queues (the dense exchange runs beside the gradient exchange and the owners' update)
+        self.step = torch.ones((len(self.KINDS),), dtype=torch.int32, device=dev)
         self.err = torch.zeros((1,), dtype=torch.int32, device=dev)
         torch.cuda.synchronize(dev)
+        self.push = (os.environ.get("DCTR_SHARDED_PUSH", "1") != "0") if push is None else bool(push)
         mine = [self.recv, self.grads, self.dense, self.ids, self.words]
+        if self.push and dense_src is not None:
+            mine.append(dense_src)
         self.peers = [[None] * world for _ in mine]
         if world == 1:
             for k, t in enumerate(mine):
@@ -516,6 +530,11 @@ class DirectExchange(object):
         for kind in range(len(self.KINDS)):
             self.word_ptrs.append(torch.tensor([self.peers[4][r].data_ptr() + 4 * 64 * kind for r in range(world)],
                                                dtype=torch.int64, device=dev))
+        # push-style: this rank's slot in every peer's receive buffers; pull: every peer's dense gradient slab
+        i64 = dict(dtype=torch.int64, device=dev)
+        self.row_tbl = torch.tensor([self.peers[0][r][rank].data_ptr() for r in range(world)], **i64)
+        self.grad_tbl = torch.tensor([self.peers[1][r][rank].data_ptr() for r in range(world)], **i64)
+        self.dense_tbl = torch.tensor([self.peers[5][r].data_ptr() for r in range(world)], **i64) if len(mine) > 5 else None
         if world > 1:
             dist.barrier(group=group)
 
@@ -523,12 +542,12 @@ class DirectExchange(object):
         import ctypes
         return ctypes.c_void_p(t.data_ptr() + off)
 
-    def _sync(self, kind, counter, advance):
-        """post this rank's arrival to every peer, wait for every peer's; ``advance``: the counter moves on behind it"""
+    def _sync(self, kind):
+        """post this rank's arrival to every peer, wait for every peer's; the kind's counter moves on behind it"""
         L, k = self.L, self.KINDS[kind]
         L.check(L.lib().dctr_exchange_sync(self._ptr(self.word_ptrs[k]), self._ptr(self.words, 4 * 64 * k), self.world,
-                                           self.rank, self._ptr(self.step, 4 * counter), 1 if advance else 0,
-                                           self.timeout_us, self._ptr(self.err), L.stream_handle(self.words.device)),
+                                           self.rank, self._ptr(self.step, 4 * k), 1, self.timeout_us, self._ptr(self.err),
+                                           L.stream_handle(self.words.device)),
                 "dctr_exchange_sync")
 
     def _copy(self, dst, src):
@@ -547,31 +566,40 @@ class DirectExchange(object):
             self._copy(self.peers[which][r][self.rank], src[r])
 
     def send_rows(self, chunks):
-        self._scatter(0, chunks.view(self.recv.shape))
-        self._sync("rows", 0, False)
+        """(push: the gather has written the peers' buffers already -- HipShardOps.gather(push=...))"""
+        if not self.push:
+            self._scatter(0, chunks.view(self.recv.shape))
+        self._sync("rows")
         return self.recv.view(-1, self.recv.shape[2])
 
     def send_grads(self, send):
-        self._scatter(1, send.view(self.grads.shape))
-        self._sync("grads", 0, False)
+        if not self.push:
+            self._scatter(1, send.view(self.grads.shape))
+        self._sync("grads")
         return self.grads.view(-1, self.grads.shape[2])
 
     def send_ids(self, ids):
         self._scatter(3, ids)
-        self._sync("ids", 1, True)
+        self._sync("ids")
         return self.ids.view(-1, self.ids.shape[2])
 
     def allreduce_dense(self, flat, step=None):
-        """flat <- sum over ranks (rank order); ``step`` (dctr_dense_step_t): the sum kernel also applies the optimizer step.
-        The step's LAST exchange: the counter advances behind it."""
+        """flat <- sum over ranks (rank order); ``step`` (dctr_dense_step_t): the sum kernel also applies the optimizer step."""
         import ctypes
         n = flat.numel()
+        L = self.L
+        if self.dense_tbl is not None and step is not None:
+            # pull: the peers' slabs are read where they lie.  Safe against the peers' next step: rank p overwrites its
+            # slab only behind its next rows wait, which needs every rank's next rows post -- issued behind that rank's sum.
+            self._sync("dense")
+            L.check(L.lib().dctr_sum_ranks(self._ptr(flat), None, self._ptr(self.dense_tbl), self.world, n, 0,
+                                           ctypes.byref(step), 0, L.stream_handle(flat.device)), "dctr_sum_ranks(pull)")
+            return
         for r in range(self.world):
             self._copy(self.peers[2][r][self.rank][:n], flat)
-        self._sync("dense", 0, True)
-        L = self.L
-        L.check(L.lib().dctr_sum_ranks(self._ptr(flat), self._ptr(self.dense), self.world, n, self.ld_dense,
-                                       ctypes.byref(step) if step is not None else None, L.stream_handle(flat.device)),
+        self._sync("dense")
+        L.check(L.lib().dctr_sum_ranks(self._ptr(flat), self._ptr(self.dense), None, self.world, n, self.ld_dense,
+                                       ctypes.byref(step) if step is not None else None, 1, L.stream_handle(flat.device)),
                 "dctr_sum_ranks")
 
     def check(self):
@@ -580,6 +608,20 @@ class DirectExchange(object):
             self.err.zero_()
             raise RuntimeError("a direct-exchange wait timed out: a peer rank did not reach the same exchange "
                                "(ranks out of step, or a rank died)")
+
+
+class _GradTap(torch.autograd.Function):
+    """identity whose backward stores the incoming gradient in ``box[key]`` and ends the graph there"""
+
+    @staticmethod
+    def forward(ctx, x, box, key):
+        ctx.box, ctx.key = box, key
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.box[ctx.key] = g
+        return None, None, None
 
 
 class _Segment(object):
@@ -709,9 +751,13 @@ class ShardedTrainer(object):
         if not torch.is_grad_enabled():
             raise RuntimeError("a table-sharded model predicts after trainer.gather_tables(); trainer.close()")
         out, wide, fm, fm_s = self.ops.assemble_fwd(self._recv, X, want_fm)
-        leaves = {"out": out.requires_grad_(), "fm_s": fm_s, "want_fm": bool(want_fm)}
-        leaves["wide"] = wide.requires_grad_() if wide is not None else None
-        leaves["fm"] = fm.requires_grad_() if fm is not None else None
+        leaves = {"out": out, "fm_s": fm_s, "want_fm": bool(want_fm), "wide": wide, "fm": fm, "grads": {}}
+        # the model sees taps of the three tensors: their backward hands the incoming gradient to this trainer as it is
+        # (a leaf's .grad is a CLONE whenever somebody else still holds the gradient -- the tower keeps its gx alive for
+        # the deferred weight gradients: a 7 MB copy node + a graph edge on the step's critical chain)
+        out = _GradTap.apply(out.requires_grad_(), leaves["grads"], "out")
+        wide = _GradTap.apply(wide.requires_grad_(), leaves["grads"], "wide") if wide is not None else None
+        fm = _GradTap.apply(fm.requires_grad_(), leaves["grads"], "fm") if fm is not None else None
         self._leaves = leaves
         B = X.shape[0]
         o = out if (full or not plan.has_lookup) else out[:, :plan.width]
@@ -765,9 +811,8 @@ class ShardedTrainer(object):
             raise RuntimeError("the model's forward did not go through the fused lookup")
         w = plan.wide_dense_weight
         g_wd = self._bucket_view.get(id(w)) if w is not None else None
-        g_wide = lv["wide"].grad if lv["wide"] is not None else None
-        g_fm = lv["fm"].grad if lv["fm"] is not None else None
-        send = self.ops.assemble_bwd(self._x, lv["out"].grad, g_wide, g_fm, lv["out"].detach(), lv["fm_s"],
+        g_out, g_wide, g_fm = self._tapped(lv)
+        send = self.ops.assemble_bwd(self._x, g_out, g_wide, g_fm, lv["out"].detach(), lv["fm_s"],
                                      g_wd.reshape(-1) if (g_wd is not None and g_wide is not None) else None)
         B = self._x.shape[0]
         send.view(lay.world, B, lay.ldc)[:, :, lay.ids_col:lay.ids_col + lay.n_slots].copy_(self._ids_next)
@@ -782,6 +827,19 @@ class ShardedTrainer(object):
         done, _ = model._step_dense_multi(None)
         if not done:
             model.optim.step()
+
+    @staticmethod
+    def _tapped(lv):
+        """(g_out, g_wide, g_fm) as the backward delivered them to the taps of ``embed`` (None: no gradient arrived)"""
+        def pick(key, like):
+            g = lv["grads"].get(key)
+            if g is None or like is None:
+                return None
+            if g.dtype != torch.float32 or (g.dim() == 2 and (g.stride(1) != 1 or g.stride(0) % 4 or g.data_ptr() % 16)) or \
+                    (g.dim() == 1 and g.numel() > 1 and g.stride(0) != 1):
+                g = g.float().contiguous()
+            return g
+        return pick("out", lv["out"]), pick("wide", lv["wide"]), pick("fm", lv["fm"])
 
     def _compute(self):
         model, st, slab, plan, lay = self.model, self.state, self.slab, self.plan, self.layout
@@ -801,15 +859,15 @@ class ShardedTrainer(object):
         if lv is None:
             raise RuntimeError("the model's logit_parts() did not go through the fused lookup")
         g_wd = slab.grad_of(plan.wide_dense_weight) if plan.wide_dense_weight is not None else None
-        g_wide = lv["wide"].grad if lv["wide"] is not None else None
-        g_fm = lv["fm"].grad if lv["fm"] is not None else None
+        g_out, g_wide, g_fm = self._tapped(lv)
         static = getattr(self, "_send_static", None)
         if static is not None:
             # (the direct-exchange step: the staging launch in front of the step has put the next batch's ids in place)
-            send = self.ops.assemble_bwd(self._x, lv["out"].grad, g_wide, g_fm, lv["out"].detach(), lv["fm_s"],
-                                         g_wd if g_wide is not None else None, send=static)
+            send = self.ops.assemble_bwd(self._x, g_out, g_wide, g_fm, lv["out"].detach(), lv["fm_s"],
+                                         g_wd if g_wide is not None else None, send=static,
+                                         push=self._dx.grad_tbl if self._dx.push else None)
             return send, loss.detach(), y_pred
-        send = self.ops.assemble_bwd(self._x, lv["out"].grad, g_wide, g_fm, lv["out"].detach(), lv["fm_s"],
+        send = self.ops.assemble_bwd(self._x, g_out, g_wide, g_fm, lv["out"].detach(), lv["fm_s"],
                                      g_wd if g_wide is not None else None)
         B = self._x.shape[0]
         send.view(lay.world, B, lay.ldc)[:, :, lay.ids_col:lay.ids_col + lay.n_slots].copy_(self._ids_next)
@@ -915,7 +973,8 @@ class ShardedTrainer(object):
     # ---- the whole step as ONE hipGraph over the direct exchange ----------------------------------------------------
     def _direct_setup(self, xb):
         lay, B, dev = self.layout, xb.shape[0], xb.device
-        self._dx = DirectExchange(self.group, self.world, self.rank, dev, B, lay.ldc, lay.n_slots, self.slab.grad.numel())
+        self._dx = DirectExchange(self.group, self.world, self.rank, dev, B, lay.ldc, lay.n_slots, self.slab.grad.numel(),
+                                  dense_src=self.slab.grad)
         sub = self.ops.sub
         nu = len(sub.units) if sub is not None else 1
         NB = lay.world * B
@@ -927,6 +986,9 @@ class ShardedTrainer(object):
         self._direct_seg = _Segment(self._direct_body, bool(self.use_graphs))
         from ._hip import streams as _streams
         self._side = _streams.side_stream(dev, "shard")
+
+    def _push_rows(self):
+        return (self._dx.row_tbl, self._dx.recv.shape[1]) if self._dx.push else None
 
     def _direct_body(self):
         """rows exchange -> [assemble, tower + head + backward-data, assemble^T] -> gradient exchange -> owners' update ->
@@ -943,26 +1005,36 @@ class ShardedTrainer(object):
         finally:
             self._send_static = None
         wgrad = slab.deferred
+        mode = self.state["mode"]
+
+        def dense():
+            if slab.begin_inline_step(mode[0], mode[1], mode[2] if len(mode) > 2 else 0.0):
+                try:
+                    dx.allreduce_dense(slab.grad, slab.inline)     # the sum kernel steps the parameters
+                    slab.inline_done = True
+                finally:
+                    slab.end_inline_step()
+                slab.step(*mode)                                   # (clears the flag)
+            else:
+                dx.allreduce_dense(slab.grad)
+                slab.step(*mode)
+
         if wgrad is not None:
+            # second queue: weight gradients -> dense exchange + sum + optimizer step, beside the gradient exchange, the
+            # owners' update and their gather for the next batch (which touch tables only)
             side.wait_stream(main)
             wgrad(side)                              # (loss is finished by its reduction)
+            with torch.cuda.stream(side):
+                dense()
         grads_all = dx.send_grads(send)
         self.ops.update(grads_all, (self._ids_buf, self._parts_buf, None))
         # (the ids of the announced next batch arrived with the gradients; an un-announced call gathers again itself)
-        self.ops.gather(grads_all[:, lay.ids_col:lay.ids_col + lay.n_slots], out=(self._chunks, self._ids_buf, self._parts_buf))
+        self.ops.gather(grads_all[:, lay.ids_col:lay.ids_col + lay.n_slots], out=(self._chunks, self._ids_buf, self._parts_buf),
+                        push=self._push_rows())
         if wgrad is not None:
             main.wait_stream(side)
-        mode = self.state["mode"]
-        if slab.begin_inline_step(mode[0], mode[1], mode[2] if len(mode) > 2 else 0.0):
-            try:
-                dx.allreduce_dense(slab.grad, slab.inline)     # the sum kernel steps the parameters
-                slab.inline_done = True
-            finally:
-                slab.end_inline_step()
-            slab.step(*mode)                                   # (clears the flag)
         else:
-            dx.allreduce_dense(slab.grad)
-            slab.step(*mode)
+            dense()
         return loss, y_pred
 
     def _train_step_direct(self, xb, yb, next_xb=None):
@@ -992,7 +1064,7 @@ class ShardedTrainer(object):
         if self._announced != key:                       # ids not at their owners yet: the explicit exchange + gather
             self._ids_tmp.copy_(self.ops.pack_ids(self._x))
             ids_all = self._dx.send_ids(self._ids_tmp)
-            self.ops.gather(ids_all, out=(self._chunks, self._ids_buf, self._parts_buf))
+            self.ops.gather(ids_all, out=(self._chunks, self._ids_buf, self._parts_buf), push=self._push_rows())
         self._announced = (next_xb.data_ptr(), next_xb._version) if announce else None
         loss, y_pred = self._direct_seg()
         return loss, loss.reshape(1), y_pred

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 17
+#define DCTR_ABI_VERSION 18
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -84,6 +84,10 @@ typedef struct dctr_plan {
   int32_t flags;              /* DCTR_PLAN_* : facts about the device arrays the host cannot see     */
   int32_t* step_sync;         /* nullable: dctr_embed_fwd signals DCTR_SYNC_GATHER in this block when its outputs  */
                               /* have left the chip's caches (see dctr_step_wait)                                  */
+  const uint64_t* out_chunks; /* nullable, device: dctr_embed_fwd writes output row b (and its wide logit, which must lie   */
+  int32_t chunk_rows;         /* inside the row: wide = out + k, ld_wide = ld_out) to (float*)out_chunks[b / chunk_rows] +  */
+  int32_t pad_;               /* (b % chunk_rows) * ld_out instead of out + b * ld_out: the owner's gather of the sharded   */
+                              /* step pushes every rank's rows straight into that rank's receive buffer (peer memory)      */
 } dctr_plan_t;
 
 #define DCTR_PLAN_HAS_GACC 1    /* every field has a gacc slab                       */
@@ -591,8 +595,11 @@ int dctr_exchange_post(int32_t* const* peer_words, int32_t n, int32_t my_index, 
 int dctr_exchange_wait(const int32_t* words, int32_t n, const int32_t* step, int32_t timeout_us, int32_t* err,
                        dctr_stream_t stream);
 int dctr_exchange_next(int32_t* step, dctr_stream_t stream);
-int dctr_sum_ranks(float* dst, const float* src, int32_t n_ranks, int64_t n, int64_t ld, const dctr_dense_step_t* step,
-                   dctr_stream_t stream);       /* step (nullable): the optimizer step on the elements it finishes */
+int dctr_sum_ranks(float* dst, const float* src, const uint64_t* src_tbl, int32_t n_ranks, int64_t n, int64_t ld,
+                   const dctr_dense_step_t* step, int32_t store, dctr_stream_t stream);
+/* step (nullable): the optimizer step on the elements it finishes.  src_tbl [n_ranks] (device, nullable): rank r's slab
+ * is read where it lies, at (const float*)src_tbl[r] (16-byte aligned, peer memory) -- a pull, no copies; store == 0
+ * (needs step): the sum itself is not written, dst only names the gradients' slab positions and may alias a source.  */
 /* post + wait (+ advance != 0: the counter's advance, behind a step's last exchange) as one launch */
 int dctr_exchange_sync(int32_t* const* peer_words, const int32_t* words, int32_t n, int32_t my_index, int32_t* step,
                        int32_t advance, int32_t timeout_us, int32_t* err, dctr_stream_t stream);
@@ -652,13 +659,16 @@ int dctr_l2_value_multi(const dctr_dense_item_t* items, int32_t n_items, float* 
  *   in unit f's slot and g_wide[b] at wide_col; g_wdense [n_wdense] (nullable) = X[:, wdense_cols]^T g_wide.
  * owner_slot [F] (device, nullable): unit f is owned by rank (owner_slot[f] & 0xffff) and sits in slot
  *   (owner_slot[f] >> 16) of that owner's chunk; NULL: owner f % N, slot f / N.
+ * send_chunks [N] (device, nullable): chunk q is written at (float*)send_chunks[q] ([B][ld_chunk]) instead of
+ *   send + q * B * ld_chunk -- owner q's receive buffer, peer memory: the push-style exchange, no copy node; columns
+ *   [carry_col, carry_col + carry_n) of the LOCAL send rows (dctr_shard_stage's next-batch ids) are copied along.
  * Deterministic (no atomics).  D <= 64.                                                                          */
 int dctr_shard_assemble_fwd(const float* recv, int64_t ld_chunk, int32_t n_ranks, int32_t B, int32_t F, int32_t D,
                             const int32_t* owner_slot, int32_t wide_col, const float* X, int64_t ld_x, const int32_t* dense_cols,
                             int32_t n_dense, int32_t dense_off, const int32_t* wdense_cols, const float* wdense_w,
                             int32_t n_wdense, float* out, int64_t ld_out, float* wide, float* fm, float* fm_s,
                             int64_t ld_s, dctr_stream_t stream);
-int dctr_shard_assemble_bwd(float* send, int64_t ld_chunk, int32_t n_ranks, int32_t B, int32_t F, int32_t D,
+int dctr_shard_assemble_bwd(float* send, const uint64_t* send_chunks, int32_t carry_col, int32_t carry_n, int64_t ld_chunk, int32_t n_ranks, int32_t B, int32_t F, int32_t D,
                             const int32_t* owner_slot, int32_t wide_col, const float* g_out, int64_t ld_g, const float* g_wide, const float* g_fm,
                             const float* out, int64_t ld_out, const float* fm_s, int64_t ld_s, const float* X,
                             int64_t ld_x, const int32_t* wdense_cols, int32_t n_wdense, float* g_wdense,
