@@ -33,15 +33,25 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 __device__ __forceinline__ int acc_row(int r, int p) { return (r & 3) + 8 * (r >> 2) + 4 * p; }
 
 // W [O, h*M] (conv1ds.k.weight squeezed) -> Wt [h][M_pad][O_pad], zero padded
+// sym (layer 1: H IS X0, so Z[(h, m)] = Z[(m, h)]): the two weights of a field pair are folded onto its m > h entry,
+//     Wt[h][m] = W[h][m] + W[m][h] (m > h),  W[h][h] (m == h),  0 (m < h)
+// and the forward walks only m >= h: 351 of the 676 products at 26 fields.
 __global__ __launch_bounds__(kT) void k_cin_prep_w(const float* __restrict__ W, int O, int h, int M, int M_pad,
-                                                   int O_pad, float* __restrict__ Wt) {
+                                                   int O_pad, float* __restrict__ Wt, int sym) {
   const int64_t idx = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
   const int64_t total = static_cast<int64_t>(h) * M_pad * O_pad;
   if (idx >= total) return;
   const int o = static_cast<int>(idx % O_pad);
   const int mm = static_cast<int>((idx / O_pad) % M_pad);
   const int hh = static_cast<int>(idx / (static_cast<int64_t>(O_pad) * M_pad));
-  Wt[idx] = (o < O && mm < M) ? W[static_cast<int64_t>(o) * h * M + hh * M + mm] : 0.f;
+  float w = 0.f;
+  if (o < O && mm < M) {
+    const float* row = W + static_cast<int64_t>(o) * h * M;
+    if (!sym) w = row[hh * M + mm];
+    else if (mm > hh) w = row[hh * M + mm] + row[mm * M + hh];
+    else if (mm == hh) w = row[hh * M + hh];
+  }
+  Wt[idx] = w;
 }
 
 // CT column tiles per wave: 2 = four waves per workgroup (one per SIMD, 8 * OT / 2 ... accumulators each), 1 = EIGHT waves
@@ -53,7 +63,7 @@ __global__ __launch_bounds__(kT * 2 / CT, 1) void k_cin_fwd(const float* __restr
                                                    const float* __restrict__ H, int64_t ldh, int h, int M,
                                                    int M_pad, int D, int B, const float* __restrict__ Wt,
                                                    int O_pad, int O, const float* __restrict__ bias, int relu,
-                                                   float* __restrict__ A, int64_t lda) {
+                                                   float* __restrict__ A, int64_t lda, int sym) {
   constexpr int OB = OT * 32;
   constexpr int NT = kT * 2 / CT;       // threads per workgroup
   constexpr int WQ = (OT * kT + NT - 1) / NT;   // float4 of a weight slice per thread
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(kT * 2 / CT, 1) void k_cin_fwd(const float* __restr
       for (int t = 0; t < CT; ++t) hnext[t] = ldg_f32(H + hoff[t] + static_cast<int64_t>(hh + 1) * D);
     }
     const float* wc = ws + (hh & 1) * chunk;
-    for (int s = 0; s < M_pad / 2; ++s) {
+    for (int s = sym ? (hh >> 1) : 0; s < M_pad / 2; ++s) {   // (sym: the folded weights of m < h are zero)
       const int mm = 2 * s + p;
       float z[CT];
 #pragma unroll
@@ -378,7 +388,7 @@ __global__ __launch_bounds__(kT, 2) void k_cin_wgrad(const float* __restrict__ g
                                                      int64_t lda, int relu, const float* __restrict__ X0,
                                                      int64_t ldx0, const float* __restrict__ H, int64_t ldh, int h,
                                                      int M, int D, int B, int O, int hspan, int PH,
-                                                     float* __restrict__ part, float* __restrict__ bpart) {
+                                                     float* __restrict__ part, float* __restrict__ bpart, int sym) {
   constexpr int OB = OT * 32;
   extern __shared__ __align__(16) float smem[];
   float* gys = smem;                  // [CB][kWgP]
@@ -387,9 +397,11 @@ __global__ __launch_bounds__(kT, 2) void k_cin_wgrad(const float* __restrict__ g
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, p = lane >> 5, jl = lane & 31;
   const int64_t ncol = static_cast<int64_t>(B) * D;
   const int64_t nblk = (ncol + kWgCB - 1) / kWgCB;
-  const int K = h * M;
+  // sym (H IS X0: gW[o, h, m] = gW[o, m, h]): the columns are the M (M + 1) / 2 pairs h <= m, row-major; both factors come
+  // from the staged X0 block, k_cin_wgrad_reduce_sym writes every sum to its two places
+  const int K = sym ? M * (M + 1) / 2 : h * M;
   const int k0 = blockIdx.x * kWgKW;
-  const int h0 = k0 / M;
+  const int h0 = sym ? 0 : k0 / M;
 
   // this lane's column of each of the wave's tiles
   int hk[kWgNT], mk[kWgNT], kk[kWgNT];
@@ -398,10 +410,19 @@ __global__ __launch_bounds__(kT, 2) void k_cin_wgrad(const float* __restrict__ g
     const int k = k0 + (wv * kWgNT + nt) * 32 + jl;
     kk[nt] = k;
     const int kc = k < K ? k : k0;          // out-of-range columns read valid LDS and are never stored
-    const int hq = kc / M;
-    hk[nt] = hq - h0;
-    mk[nt] = kc - hq * M;
+    if (sym) {
+      int hq = 0, rest = kc;                // row hq of the triangle holds M - hq pairs
+      while (rest >= M - hq) { rest -= M - hq; ++hq; }
+      hk[nt] = hq;
+      mk[nt] = hq + rest;
+    } else {
+      const int hq = kc / M;
+      hk[nt] = hq - h0;
+      mk[nt] = kc - hq * M;
+    }
   }
+  const float* hl_base = sym ? x0s : hs;    // where the H factor of a column is staged
+  const int hl_pitch = sym ? kWgPX : PH;
   const bool wave_active = (k0 + wv * kWgNT * 32) < K;
 
   f32x16 acc[OT][kWgNT];
@@ -433,7 +454,7 @@ __global__ __launch_bounds__(kT, 2) void k_cin_wgrad(const float* __restrict__ g
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int hq = h0 + q4 + 4 * i;
-      hv[i] = ldg_f32(hsrc + static_cast<int64_t>(hq < h ? hq : h - 1) * D);
+      hv[i] = sym ? 0.f : ldg_f32(hsrc + static_cast<int64_t>(hq < h ? hq : h - 1) * D);
     }
     if (!relu) {  // gY^T as it is (the caller masked it: dctr_cin_pool_bwd with A): 16 rows per round trip, not 8 + 8
       constexpr int CH = 16;
@@ -489,9 +510,9 @@ __global__ __launch_bounds__(kT, 2) void k_cin_wgrad(const float* __restrict__ g
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int hl = q4 + 4 * i;
-      if (hl < hspan) hs[cl * PH + hl] = (cvalid && h0 + hl < h) ? hv[i] : 0.f;
+      if (!sym && hl < hspan) hs[cl * PH + hl] = (cvalid && h0 + hl < h) ? hv[i] : 0.f;
     }
-    for (int hl = q4 + 16; hl < hspan; hl += 4) {     // only when M is small (hspan > 16)
+    for (int hl = q4 + 16; !sym && hl < hspan; hl += 4) {     // only when M is small (hspan > 16)
       const int hq = h0 + hl < h ? h0 + hl : h - 1;
       const float v = ldg_f32(hsrc + static_cast<int64_t>(hq) * D);
       hs[cl * PH + hl] = (cvalid && h0 + hl < h) ? v : 0.f;
@@ -509,7 +530,7 @@ __global__ __launch_bounds__(kT, 2) void k_cin_wgrad(const float* __restrict__ g
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) a[ot] = gys[cc * kWgP + ot * 32 + jl];
 #pragma unroll
-        for (int nt = 0; nt < kWgNT; ++nt) z[nt] = hs[cc * PH + hk[nt]] * x0s[cc * kWgPX + mk[nt]];
+        for (int nt = 0; nt < kWgNT; ++nt) z[nt] = hl_base[cc * hl_pitch + hk[nt]] * x0s[cc * kWgPX + mk[nt]];
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
@@ -554,14 +575,40 @@ __global__ __launch_bounds__(kT) void k_cin_wgrad_reduce(const float* __restrict
   stg_f32(out + i, (s0 + s1) + (s2 + s3));
 }
 
+// the same sum for the symmetric layer: part[q][o][pair (h <= m)] -> out[o][h * M + m] and out[o][m * M + h]
+__global__ __launch_bounds__(kT) void k_cin_wgrad_reduce_sym(const float* __restrict__ part, int Q, int O, int M,
+                                                             float* __restrict__ out) {
+  const int KP = M * (M + 1) / 2;
+  const int64_t n = static_cast<int64_t>(O) * KP;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+  if (i >= n) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int q = 0;
+  for (; q + 4 <= Q; q += 4) {
+    s0 += ldg_f32(part + (q + 0) * n + i);
+    s1 += ldg_f32(part + (q + 1) * n + i);
+    s2 += ldg_f32(part + (q + 2) * n + i);
+    s3 += ldg_f32(part + (q + 3) * n + i);
+  }
+  for (; q < Q; ++q) s0 += ldg_f32(part + q * n + i);
+  const float v = (s0 + s1) + (s2 + s3);
+  const int o = static_cast<int>(i / KP);
+  int hq = 0, rest = static_cast<int>(i - static_cast<int64_t>(o) * KP);
+  while (rest >= M - hq) { rest -= M - hq; ++hq; }
+  const int mm = hq + rest;
+  float* row = out + static_cast<int64_t>(o) * M * M;
+  stg_f32(row + hq * M + mm, v);
+  if (mm != hq) stg_f32(row + mm * M + hq, v);
+}
+
 // launch geometry of the weight-side kernels (shared by the workspace query and the launcher)
 struct WgradGeom {
   int gx, q, hspan, ph;
   size_t lds;
 };
-inline WgradGeom wgrad_geom(int B, int h, int M, int D) {
+inline WgradGeom wgrad_geom(int B, int h, int M, int D, bool sym = false) {
   WgradGeom g;
-  const int K = h * M;
+  const int K = sym ? M * (M + 1) / 2 : h * M;
   g.gx = (K + kWgKW - 1) / kWgKW;
   const int64_t nblk = (static_cast<int64_t>(B) * D + kWgCB - 1) / kWgCB;
   int64_t q = 512 / g.gx;
@@ -685,7 +732,13 @@ extern "C" size_t dctr_cin_bwd_workspace_floats(int32_t B, int32_t h, int32_t M,
   if (B <= 0 || h <= 0 || M <= 0 || D <= 0 || O <= 0) return 0;
   const WgradGeom g = wgrad_geom(B, h, M, D);
   const size_t o_chunk = O < 128 ? O : 128;
-  return static_cast<size_t>(g.q) * o_chunk * (static_cast<size_t>(h) * M + 1);
+  size_t need = static_cast<size_t>(g.q) * o_chunk * (static_cast<size_t>(h) * M + 1);
+  if (h == M) {   // (the symmetric layer's geometry: fewer columns, more partials)
+    const WgradGeom gs = wgrad_geom(B, h, M, D, true);
+    const size_t ns = static_cast<size_t>(gs.q) * o_chunk * (static_cast<size_t>(M) * (M + 1) / 2 + 1);
+    if (ns > need) need = ns;
+  }
+  return need;
 }
 
 extern "C" int dctr_cin_layer_fwd(const float* H, int64_t ld_h, const float* X0, int64_t ld_x0, const float* W,
@@ -701,8 +754,11 @@ extern "C" int dctr_cin_layer_fwd(const float* H, int64_t ld_h, const float* X0,
   const int M_pad = (M + 1) / 2 * 2, O_pad = (O + 31) / 32 * 32;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t total = static_cast<int64_t>(h) * M_pad * O_pad;
+  // layer 1 of a CIN: the hidden state IS the field matrix -- the outer product is symmetric
+  static const bool sym_ok = !(getenv("DCTR_CIN_SYM") && getenv("DCTR_CIN_SYM")[0] == '0');   // (A/B switch)
+  const int sym = (sym_ok && H == X0 && ld_h == ld_x0 && h == M) ? 1 : 0;
   k_cin_prep_w<<<dim3(static_cast<unsigned>((total + kT - 1) / kT)), dim3(kT), 0, s>>>(W, O, h, M, M_pad, O_pad,
-                                                                                       workspace);
+                                                                                       workspace, sym);
   const int64_t ncol = static_cast<int64_t>(B) * D;
   // outputs per workgroup: 128 (4 row tiles), or 64 -- two workgroups per CU then share the columns' work: twice the
   // waves per SIMD to hide the per-h barrier and the LDS waits (DCTR_CIN_FWD_CHUNK=64|128; A/B switch)
@@ -720,7 +776,7 @@ extern "C" int dctr_cin_layer_fwd(const float* H, int64_t ld_h, const float* X0,
     const int o_here = O - ybase * chunk_o;
 #define DCTR_CIN_FWD(OT_, CT_)                                                                                       \
   k_cin_fwd<OT_, CT_><<<g, dim3(kT * 2 / CT_), lds, s>>>(X0, ld_x0, H, ld_h, h, M, M_pad, D, B, wt, O_pad, o_here, bs, \
-                                                         relu, a, ld_a)
+                                                         relu, a, ld_a, sym)
     // wide output tiles (3-4 row tiles = 96-128 accumulator registers per column tile): one column tile per wave, eight
     // waves; narrow ones: two column tiles per wave, four waves
     switch (ot) {
@@ -761,8 +817,11 @@ extern "C" int dctr_cin_layer_bwd(const float* gA, const float* A, int64_t ld_a,
     }
     return DCTR_OK;
   }
-  const WgradGeom geo = wgrad_geom(B, h, M, D);
+  static const bool sym_ok = !(getenv("DCTR_CIN_SYM") && getenv("DCTR_CIN_SYM")[0] == '0');   // (A/B switch)
+  const bool sym = sym_ok && H == X0 && ld_h == ld_x0 && h == M;      // layer 1: see k_cin_prep_w
+  const WgradGeom geo = wgrad_geom(B, h, M, D, sym);
   if (geo.lds > 160u * 1024u) return DCTR_ENOSUP;
+  const int KW = sym ? M * (M + 1) / 2 : K;     // columns of a partial tile set
   const int64_t ncol = static_cast<int64_t>(B) * D;
   const int chunks = (O + 127) / 128;
   for (int ch = 0; ch < chunks; ++ch) {
@@ -793,20 +852,24 @@ extern "C" int dctr_cin_layer_bwd(const float* gA, const float* A, int64_t ld_a,
     {
       const dim3 grid(geo.gx, geo.q);
       float* part = workspace;
-      float* bpart = gbias ? workspace + static_cast<size_t>(geo.q) * o_here * K : nullptr;
+      float* bpart = gbias ? workspace + static_cast<size_t>(geo.q) * o_here * KW : nullptr;
 #define DCTR_CIN_BW(OT_)                                                                                              \
   do {                                                                                                                \
     if (geo.lds > 64u * 1024u)                                                                                        \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cin_wgrad<OT_>),                                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(geo.lds));               \
     k_cin_wgrad<OT_><<<grid, dim3(kT), geo.lds, s>>>(gA_c, A_c, ld_a, relu, X0, ld_x0, H, ld_h, h, M, D, B, o_here,   \
-                                                     geo.hspan, geo.ph, part, bpart);                                 \
+                                                     geo.hspan, geo.ph, part, bpart, sym ? 1 : 0);                    \
   } while (0)
       switch (ot) { case 1: DCTR_CIN_BW(1); break; case 2: DCTR_CIN_BW(2); break; case 3: DCTR_CIN_BW(3); break; default: DCTR_CIN_BW(4); break; }
 #undef DCTR_CIN_BW
-      const int64_t n = static_cast<int64_t>(o_here) * K;
-      k_cin_wgrad_reduce<<<dim3(static_cast<unsigned>((n + kT - 1) / kT)), dim3(kT), 0, s>>>(
-          part, geo.q, n, gW + static_cast<int64_t>(o0) * K);
+      const int64_t n = static_cast<int64_t>(o_here) * KW;
+      if (sym)
+        k_cin_wgrad_reduce_sym<<<dim3(static_cast<unsigned>((n + kT - 1) / kT)), dim3(kT), 0, s>>>(
+            part, geo.q, o_here, M, gW + static_cast<int64_t>(o0) * K);
+      else
+        k_cin_wgrad_reduce<<<dim3(static_cast<unsigned>((n + kT - 1) / kT)), dim3(kT), 0, s>>>(
+            part, geo.q, n, gW + static_cast<int64_t>(o0) * K);
       if (gbias)
         k_cin_wgrad_reduce<<<dim3(1), dim3(kT), 0, s>>>(bpart, geo.q, o_here, gbias + o0);
     }

@@ -44,6 +44,37 @@ def test_cin_layer_forward_backward(case):
         assert err <= 2e-5 * scale, "%s: max|d|=%.3e (scale %.3g)" % (name, err, scale)
 
 
+SYM_CASES = [  # B, M, D, O, relu, bias     (H IS X0: the first layer of every CIN)
+    (64, 26, 16, 128, True, True), (33, 5, 16, 40, False, True), (17, 31, 8, 200, True, False), (300, 26, 16, 256, True, True),
+    (9, 1, 4, 8, True, True), (40, 2, 5, 32, False, False),
+]
+
+
+@pytest.mark.parametrize("case", SYM_CASES, ids=lambda c: "B%d_M%d_D%d_O%d" % c[:4])
+def test_cin_first_layer_symmetric_products(case):
+    """hidden state == field matrix (interaction.py:216-219 at i = 0): the kernels fold W[o, h, m] + W[o, m, h] and walk
+    only the pairs h <= m forward and in the weight gradient; same bar as the general layer."""
+    from deepctr_torch._hip.ops import CINLayerFunction
+    B, M, D, O, relu, has_bias = case
+    g = torch.Generator(device=DEV).manual_seed(B * 11 + O)
+    X0 = (torch.randn(B, M, D, device=DEV, generator=g) * 0.5).requires_grad_(True)
+    W = (torch.randn(O, M * M, device=DEV, generator=g) * 0.1).requires_grad_(True)
+    b = (torch.randn(O, device=DEV, generator=g) * 0.1).requires_grad_(True) if has_bias else None
+    R = torch.randn(B, O, D, device=DEV, generator=g)
+    A = CINLayerFunction.apply(X0, X0, W, b, relu)
+    (A * R).sum().backward()
+    got = [A.detach(), X0.grad, W.grad] + ([b.grad] if has_bias else [])
+    X2, W2 = (t.detach().double().requires_grad_(True) for t in (X0, W))
+    b2 = b.detach().double().requires_grad_(True) if has_bias else None
+    A2 = _ref(X2, X2, W2, b2, relu)
+    (A2 * R.double()).sum().backward()
+    want = [A2.detach(), X2.grad, W2.grad] + ([b2.grad] if has_bias else [])
+    for name, a, r in zip(["A", "gX0", "gW", "gb"], got, want):
+        scale = max(1.0, float(r.abs().max()))
+        err = float((a.double() - r).abs().max())
+        assert err <= 2e-5 * scale, "%s: max|d|=%.3e (scale %.3g)" % (name, err, scale)
+
+
 def test_cin_layer_on_strided_views():
     """X0 as a view of the gather's [B, ld] output, H as the first half of a previous layer's maps."""
     from deepctr_torch._hip.ops import CINLayerFunction
