@@ -558,21 +558,44 @@ __global__ __launch_bounds__(kT, 2) void k_cin_wgrad(const float* __restrict__ g
   if (bpart && blockIdx.x == 0 && tid < O) stg_f32(bpart + static_cast<int64_t>(blockIdx.y) * O + tid, bsum);
 }
 
-// out[i] = sum_q part[q][i], q ascending (four interleaved chains, combined in a fixed order)
+// out[i] = sum_q part[q][i] in a FIXED order: four neighbouring lanes share an output, lane j of them adds the partials
+// q = j, j + 4, ... ascending, the four sums are combined as (s0 + s1) + (s2 + s3) -- the order of the one-thread-per-output
+// version it replaces, at a quarter of its dependent-load chain (Q = 170-256 partials: 12-21 us -> a few).
+__device__ __forceinline__ float reduce_q4(const float* __restrict__ part, int Q, int64_t n, int64_t i, int j) {
+  float s = 0.f;
+  int q = j;
+  for (; q + 12 < Q; q += 16) {       // four loads in flight per lane
+    const float a = ldg_f32(part + (q + 0) * n + i), b = ldg_f32(part + (q + 4) * n + i);
+    const float c = ldg_f32(part + (q + 8) * n + i), d = ldg_f32(part + (q + 12) * n + i);
+    s += a; s += b; s += c; s += d;
+  }
+  for (; q < Q; q += 4) s += ldg_f32(part + q * n + i);
+  const float s1 = __shfl_xor(s, 1);
+  const float lo = (j & 1) ? s1 + s : s + s1;          // s_even + s_odd on both lanes of a pair
+  const float hi = __shfl_xor(lo, 2);
+  return (j & 2) ? hi + lo : lo + hi;                   // (s0 + s1) + (s2 + s3) on all four
+}
+
 __global__ __launch_bounds__(kT) void k_cin_wgrad_reduce(const float* __restrict__ part, int Q, int64_t n,
                                                          float* __restrict__ out) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+  const int64_t i = t >> 2;
+  const int j = static_cast<int>(t & 3);
+  const float v = reduce_q4(part, Q, n, i < n ? i : n - 1, j);     // (whole quads stay converged for the shuffles)
+  if (i < n && j == 0) stg_f32(out + i, v);
+}
+
+// few outputs, many partials (the bias gradient: n = 128, Q up to 256): one wave per output, lane l adds q = l, l + 64, ...
+// and the 64 sums meet in a butterfly (fixed order)
+__global__ __launch_bounds__(kT) void k_cin_wgrad_reduce_wave(const float* __restrict__ part, int Q, int64_t n,
+                                                              float* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * (kT / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (i >= n) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int q = 0;
-  for (; q + 4 <= Q; q += 4) {
-    s0 += ldg_f32(part + (q + 0) * n + i);
-    s1 += ldg_f32(part + (q + 1) * n + i);
-    s2 += ldg_f32(part + (q + 2) * n + i);
-    s3 += ldg_f32(part + (q + 3) * n + i);
-  }
-  for (; q < Q; ++q) s0 += ldg_f32(part + q * n + i);
-  stg_f32(out + i, (s0 + s1) + (s2 + s3));
+  float s = 0.f;
+  for (int q = lane; q < Q; q += 64) s += ldg_f32(part + q * n + i);
+  s = wave_sum(s);
+  if (lane == 0) stg_f32(out + i, s);
 }
 
 // the same sum for the symmetric layer: part[q][o][pair (h <= m)] -> out[o][h * M + m] and out[o][m * M + h]
@@ -580,18 +603,11 @@ __global__ __launch_bounds__(kT) void k_cin_wgrad_reduce_sym(const float* __rest
                                                              float* __restrict__ out) {
   const int KP = M * (M + 1) / 2;
   const int64_t n = static_cast<int64_t>(O) * KP;
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
-  if (i >= n) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int q = 0;
-  for (; q + 4 <= Q; q += 4) {
-    s0 += ldg_f32(part + (q + 0) * n + i);
-    s1 += ldg_f32(part + (q + 1) * n + i);
-    s2 += ldg_f32(part + (q + 2) * n + i);
-    s3 += ldg_f32(part + (q + 3) * n + i);
-  }
-  for (; q < Q; ++q) s0 += ldg_f32(part + q * n + i);
-  const float v = (s0 + s1) + (s2 + s3);
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+  const int64_t i = t >> 2;
+  const int j = static_cast<int>(t & 3);
+  const float v = reduce_q4(part, Q, n, i < n ? i : n - 1, j);
+  if (i >= n || j != 0) return;
   const int o = static_cast<int>(i / KP);
   int hq = 0, rest = static_cast<int>(i - static_cast<int64_t>(o) * KP);
   while (rest >= M - hq) { rest -= M - hq; ++hq; }
@@ -865,13 +881,13 @@ extern "C" int dctr_cin_layer_bwd(const float* gA, const float* A, int64_t ld_a,
 #undef DCTR_CIN_BW
       const int64_t n = static_cast<int64_t>(o_here) * KW;
       if (sym)
-        k_cin_wgrad_reduce_sym<<<dim3(static_cast<unsigned>((n + kT - 1) / kT)), dim3(kT), 0, s>>>(
+        k_cin_wgrad_reduce_sym<<<dim3(static_cast<unsigned>((4 * n + kT - 1) / kT)), dim3(kT), 0, s>>>(
             part, geo.q, o_here, M, gW + static_cast<int64_t>(o0) * K);
       else
-        k_cin_wgrad_reduce<<<dim3(static_cast<unsigned>((n + kT - 1) / kT)), dim3(kT), 0, s>>>(
+        k_cin_wgrad_reduce<<<dim3(static_cast<unsigned>((4 * n + kT - 1) / kT)), dim3(kT), 0, s>>>(
             part, geo.q, n, gW + static_cast<int64_t>(o0) * K);
       if (gbias)
-        k_cin_wgrad_reduce<<<dim3(1), dim3(kT), 0, s>>>(bpart, geo.q, o_here, gbias + o0);
+        k_cin_wgrad_reduce_wave<<<dim3((o_here + kT / 64 - 1) / (kT / 64)), dim3(kT), 0, s>>>(bpart, geo.q, o_here, gbias + o0);
     }
   }
   return launch_status();
