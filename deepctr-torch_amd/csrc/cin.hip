@@ -362,6 +362,227 @@ __global__ __launch_bounds__(kT * 2 / CT, 1) void k_cin_bwd_data(const float* __
 }
 
 // -------------------------------------------------------------------------------------------------------------
+// backward, data side, FIRST layer (H IS X0).  With gZs[{a, b}] = sum_o (W[o, a, b] + W[o, b, a]) gY[o]  (a != b;
+// W[o, a, a] on the diagonal) the gradient of the shared input is  G[x] = sum_{pairs {a, b}} gZs * (x == a) X0[b] +
+// gZs * (x == b) X0[a]  (a diagonal pair counts twice, as the product rule says): only the M (M + 1) / 2 unordered pairs
+// are needed, not M * M.  They are packed into ceil-half as many 32-row MFMA tiles as k_cin_bwd_data uses, with every
+// accumulator register still tied to a FIXED field, so the tails stay per-lane FMAs on registers:
+//   tile j (j < Hh = ceil(M / 2)):  row i >= j  <->  pair (j, i)                        "main":   G[j] += gZs X0[i],  G[i] += gZs X0[j]
+//   tile j (1 <= j):                row i <  j  <->  pair {Hh + i, Hh - 1 + j} = {a, b} "mirror": G[b] += gZs X0[a],  G[a] += gZs X0[b]
+// (the rows a tile's main pairs leave free hold the triangle of the upper half of the fields; M even needs one more tile,
+// j = Hh, for b = M - 1).  M = 26: 14 tiles instead of 26.  Row i of a lane therefore needs X0[i] and X0[Hh + i] (static
+// registers) and accumulates G[i] and G[Hh + i]; G[j] and G[b] of a tile come out of the same cross-row sums as gH did.
+// Written to gH: the cross-row sums (every field exactly once); to gX0: the per-row accumulators -- the caller adds the
+// two, as it does for the general layer.
+// -------------------------------------------------------------------------------------------------------------
+// the folded weight slices of k_cin_bwd_data_sym: Ws[tile j][o < OB][row i < 32] (zero where a row holds no pair)
+__global__ __launch_bounds__(kT) void k_cin_prep_wsym(const float* __restrict__ W, int O, int M, int OB, int ntiles,
+                                                      float* __restrict__ Ws) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+  if (idx >= static_cast<int64_t>(ntiles) * OB * 32) return;
+  const int i = static_cast<int>(idx & 31), ol = static_cast<int>((idx >> 5) % OB), j = static_cast<int>(idx / (32 * OB));
+  const int Hh = (M + 1) / 2;
+  const bool main = i >= j;
+  const int a = main ? j : Hh + i;
+  const int b = main ? i : Hh - 1 + j;
+  const bool valid = ol < O && (main ? (j < Hh && i < M) : (b < M));     // (mirror rows: a <= b by construction)
+  float w = 0.f;
+  if (valid) {
+    const float* row = W + static_cast<int64_t>(ol) * M * M;
+    w = a == b ? row[a * M + a] : row[a * M + b] + row[b * M + a];
+  }
+  Ws[idx] = w;
+}
+
+template <int OT, int CT>
+__global__ __launch_bounds__(kT * 2 / CT, 1) void k_cin_bwd_data_sym(const float* __restrict__ gA, const float* __restrict__ Asv,
+                                                        int64_t lda, int relu, const float* __restrict__ X0,
+                                                        int64_t ldx0, int M, int D, int B, const float* __restrict__ Ws,
+                                                        int O, float* __restrict__ gH, int64_t ldgh, int acc_h,
+                                                        float* __restrict__ gX0, int64_t ldgx, int acc_x) {
+  constexpr int NT = kT * 2 / CT;
+  constexpr int OB = OT * 32, NS = OT * 16, NW = OT * 32 * 32 / NT;
+  extern __shared__ __align__(16) float smem[];
+  float* wl = smem;  // [2][OB][32]
+  float* xu = smem + 2 * OB * 32;   // [16][kCols]: X0[Hh + i] of the workgroup's columns; at the end the upper-half accumulators
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, p = lane >> 5, jl = lane & 31;
+  const int64_t c_base = static_cast<int64_t>(blockIdx.x) * kCols;
+  const int64_t ncol = static_cast<int64_t>(B) * D;
+  const int Hh = (M + 1) / 2;
+  const int ntiles = (M & 1) ? Hh : Hh + 1;
+
+  int64_t bb[CT];
+  int dd[CT];
+  bool cv[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+    const int64_t c = c_base + wv * (32 * CT) + t * 32 + jl;
+    cv[t] = c < ncol;
+    bb[t] = cv[t] ? c / D : 0;
+    dd[t] = cv[t] ? static_cast<int>(c - bb[t] * D) : 0;
+  }
+  float gy[CT][NS];
+  const float* mask_src = relu ? Asv : gA;
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+    const int64_t base = bb[t] * lda + dd[t];
+#pragma unroll
+    for (int s0 = 0; s0 < NS; s0 += 16) {
+      float a[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int o = 2 * (s0 + i) + p;
+        gy[t][s0 + i] = ldg_f32(gA + base + static_cast<int64_t>(o < O ? o : O - 1) * D);
+      }
+      if (relu) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int o = 2 * (s0 + i) + p;
+          a[i] = ldg_f32(mask_src + base + static_cast<int64_t>(o < O ? o : O - 1) * D);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = 1.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int o = 2 * (s0 + i) + p;
+        gy[t][s0 + i] = (cv[t] && o < O && a[i] > 0.f) ? gy[t][s0 + i] : 0.f;
+      }
+    }
+  }
+  // the two fields of a lane's accumulator row i: i and Hh + i.  Mirror rows are rows i < j <= Hh <= 16: only the
+  // registers r < 8 (rows 0..15) ever hold one
+  constexpr int RU = 8;
+  float x0r[CT][16], gxa[CT][16], gxu[CT][RU];
+  if (tid < kCols) {      // the upper half of the fields, by column, in LDS (two register sets of X0 would spill)
+    const int64_t c = c_base + tid;
+    const bool v = c < ncol;
+    const int64_t b = v ? c / D : 0;
+    const int d = v ? static_cast<int>(c - b * D) : 0;
+    float t16[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t16[i] = ldg_f32(X0 + b * ldx0 + (Hh + i < M ? Hh + i : M - 1) * D + d);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xu[i * kCols + tid] = (v && Hh + i < M) ? t16[i] : 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < CT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int mm = acc_row(r, p);
+      const float v = ldg_f32(X0 + bb[t] * ldx0 + (mm < M ? mm : M - 1) * D + dd[t]);
+      x0r[t][r] = (cv[t] && mm < M) ? v : 0.f;
+      gxa[t][r] = 0.f;
+      if (r < RU) gxu[t][r] = 0.f;
+    }
+
+  float wreg[NW];
+  auto fetch_w = [&](int j) {      // the folded slice of tile j, laid out [o][row] by k_cin_prep_wsym
+    const float* src = Ws + static_cast<int64_t>(j) * (OB * 32);
+#pragma unroll
+    for (int q = 0; q < NW; ++q) wreg[q] = ldg_f32(src + q * NT + tid);
+  };
+  auto park_w = [&](int buf) {
+    float* dst = wl + buf * (OB * 32);
+#pragma unroll
+    for (int q = 0; q < NW; ++q) dst[q * NT + tid] = wreg[q];
+  };
+  // X0[j] of a tile, for this lane's columns (X0[b], b >= Hh, is read from xu)
+  auto tile_fields = [&](int j, float* hj) {
+    const int jc = j < M ? j : M - 1;
+#pragma unroll
+    for (int t = 0; t < CT; ++t) hj[t] = ldg_f32(X0 + bb[t] * ldx0 + static_cast<int64_t>(jc) * D + dd[t]);
+  };
+  fetch_w(0);
+  park_w(0);
+  float hj[CT], hjn[CT];
+  tile_fields(0, hj);
+#pragma unroll
+  for (int t = 0; t < CT; ++t) asm volatile("" : "+v"(hj[t]));   // arrived before the loop (see k_cin_fwd)
+  __syncthreads();
+
+  for (int j = 0; j < ntiles; ++j) {
+    const bool more = j + 1 < ntiles;
+    if (more) {
+      fetch_w(j + 1);
+      tile_fields(j + 1, hjn);
+    }
+    const float* wc = wl + (j & 1) * (OB * 32);
+    f32x16 acc[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float a = wc[(2 * s + p) * 32 + jl];
+#pragma unroll
+      for (int t = 0; t < CT; ++t) acc[t] = mfma32(a, gy[t][s], acc[t]);
+    }
+    const int bfield = Hh - 1 + j;
+    const int brow = (j >= 1 && bfield < M) ? j - 1 : 0;      // row of X0[b] in xu (no mirror pairs: their weights are zero)
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      const int col = wv * (32 * CT) + t * 32 + jl;
+      const float hb = xu[brow * kCols + col];
+      float pm = 0.f, pu = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (r < RU) {
+          const bool main = acc_row(r, p) >= j;
+          const float zm = main ? acc[t][r] : 0.f, zu = main ? 0.f : acc[t][r];
+          pm += zm * x0r[t][r];
+          gxa[t][r] += zm * hj[t];
+          pu += zu * xu[acc_row(r, p) * kCols + col];
+          gxu[t][r] += zu * hb;
+        } else {            // rows 16..31: always a main pair (zero weights when there is none)
+          pm += acc[t][r] * x0r[t][r];
+          gxa[t][r] += acc[t][r] * hj[t];
+        }
+      }
+      pm += __shfl_xor(pm, 32, kWave);
+      pu += __shfl_xor(pu, 32, kWave);
+      if (p == 0 && cv[t]) {
+        if (j < Hh) {
+          float* dst = gH + bb[t] * ldgh + static_cast<int64_t>(j) * D + dd[t];
+          stg_f32(dst, acc_h ? ldg_f32(dst) + pm : pm);
+        }
+        if (j >= 1 && bfield < M) {
+          float* dst = gH + bb[t] * ldgh + static_cast<int64_t>(bfield) * D + dd[t];
+          stg_f32(dst, acc_h ? ldg_f32(dst) + pu : pu);
+        }
+      }
+    }
+    if (more) {
+      park_w((j + 1) & 1);
+#pragma unroll
+      for (int t = 0; t < CT; ++t) hj[t] = hjn[t];
+    }
+    __syncthreads();
+  }
+  // the upper-half accumulators move to the lanes that own those fields' rows (same column: through LDS)
+  float* up = xu;     // [16][kCols] (the loop's last barrier has retired every read of X0's upper half)
+#pragma unroll
+  for (int t = 0; t < CT; ++t)
+#pragma unroll
+    for (int r = 0; r < RU; ++r) up[acc_row(r, p) * kCols + wv * (32 * CT) + t * 32 + jl] = gxu[t][r];
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < CT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int mm = acc_row(r, p);
+      if (cv[t] && mm < M) {
+        float v = gxa[t][r];
+        if (mm >= Hh && mm - Hh < 16) v += up[(mm - Hh) * kCols + wv * (32 * CT) + t * 32 + jl];
+        float* dst = gX0 + bb[t] * ldgx + mm * D + dd[t];
+        stg_f32(dst, acc_x ? ldg_f32(dst) + v : v);
+      }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
 // backward, weight side:  gW[o, k = (h, m)] = sum_c gY[o, c] H[b, h, d] X0[b, m, d]        (c = (b, d))
 // A GEMM with 128 rows (o), K = h*M columns and a reduction over the B*D = 65536 batch columns: 27.9 GFLOP for
 // layer 1 of the Criteo shape.  MFMA roles (v_mfma_f32_32x32x2_f32): rows i = o, columns j = k, reduction = c.
@@ -850,12 +1071,30 @@ extern "C" int dctr_cin_layer_bwd(const float* gA, const float* A, int64_t ld_a,
     // data side: the chunks of o add up in gH / gX0
     {
       const dim3 grid(static_cast<unsigned>((ncol + kCols - 1) / kCols));
-      const size_t lds = 2u * ot * 32 * 32 * sizeof(float);
+      size_t lds = 2u * ot * 32 * 32 * sizeof(float);
+      if (sym) lds += 16u * kCols * sizeof(float);      // X0's upper half by column
       const int acc_h = ch > 0, acc_x = (ch > 0) || accumulate_x0;
 #define DCTR_CIN_BD(OT_, CT_)                                                                                  \
   k_cin_bwd_data<OT_, CT_><<<grid, dim3(kT * 2 / CT_), lds, s>>>(gA_c, A_c, ld_a, relu, X0, ld_x0, H, ld_h, h, M, D, B, \
                                                                 W_c, o_here, gH, ld_gh, acc_h, gX0, ld_gx, acc_x)
       static const bool bd_two_waves = !(getenv("DCTR_CIN_BWD_CT") && getenv("DCTR_CIN_BWD_CT")[0] == '2');   // (A/B switch)
+#define DCTR_CIN_BDS(OT_, CT_)                                                                                      \
+  k_cin_bwd_data_sym<OT_, CT_><<<grid, dim3(kT * 2 / CT_), lds, s>>>(gA_c, A_c, ld_a, relu, X0, ld_x0, M, D, B, workspace, \
+                                                                    o_here, gH, ld_gh, acc_h, gX0, ld_gx, acc_x)
+      static const bool sym_data = !(getenv("DCTR_CIN_SYM_DATA") && getenv("DCTR_CIN_SYM_DATA")[0] == '0');   // (A/B switch)
+      if (sym && sym_data) {
+        const int ntiles = (M & 1) ? (M + 1) / 2 : (M + 1) / 2 + 1;
+        const int64_t nws = static_cast<int64_t>(ntiles) * ot * 32 * 32;
+        // (the workspace is free until the weight side, behind this launch on the stream, writes its partials)
+        k_cin_prep_wsym<<<dim3(static_cast<unsigned>((nws + kT - 1) / kT)), dim3(kT), 0, s>>>(W_c, o_here, M, ot * 32, ntiles,
+                                                                                              workspace);
+        switch (ot) {
+          case 1: DCTR_CIN_BDS(1, 2); break;
+          case 2: DCTR_CIN_BDS(2, 2); break;
+          case 3: if (bd_two_waves) DCTR_CIN_BDS(3, 1); else DCTR_CIN_BDS(3, 2); break;
+          default: if (bd_two_waves) DCTR_CIN_BDS(4, 1); else DCTR_CIN_BDS(4, 2); break;
+        }
+      } else
       switch (ot) {
         case 1: DCTR_CIN_BD(1, 2); break;
         case 2: DCTR_CIN_BD(2, 2); break;
@@ -863,6 +1102,7 @@ extern "C" int dctr_cin_layer_bwd(const float* gA, const float* A, int64_t ld_a,
         default: if (bd_two_waves) DCTR_CIN_BD(4, 1); else DCTR_CIN_BD(4, 2); break;
       }
 #undef DCTR_CIN_BD
+#undef DCTR_CIN_BDS
     }
     // weight side: Q partial [o_here, K] tile sets (+ bias partials) in the workspace, then a fixed-order sum
     {
