@@ -12,6 +12,8 @@ Gradients take one of two routes:
 """
 import ctypes
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -205,6 +207,70 @@ class TowerFunction(torch.autograd.Function):
         return (gx, None) + tuple(rets)
 
 
+class _TunedGemm(object):
+    """PyTorch-ROCm's TunableOp (the search over hipBLASLt / rocBLAS solutions) around the plain library GEMMs of a very
+    wide layer's BACKWARD: the library's default picks for [4096 x 128] x [128 x 10 413] and [128 x 4096] x [4096 x 10 413]
+    run at 70-83 TFLOP/s, the tuned ones at ~105 (profiles/r04_fibinet_tunableop.txt).  Scoped: the process-wide switches are restored on exit; nothing is
+    written to the working directory (the picks go to a file in the temp directory unless the user named one); inside a hipGraph capture only cached picks are used
+    (a search launches and times kernels)."""
+    named = False
+
+    def __enter__(self):
+        t = torch.cuda.tunable
+        self.prev = (t.is_enabled(), t.tuning_is_enabled())
+        if os.environ.get("DCTR_TUNABLE_GEMM", "1") == "0":
+            return self
+        if not self.prev[0] and not os.environ.get("PYTORCH_TUNABLEOP_FILENAME") and not _TunedGemm.named:
+            # (this torch appends every pick to the results file as it is found: keep it out of the working directory)
+            import tempfile
+            t.set_filename(os.path.join(tempfile.gettempdir(), "dctr_tunableop_%d.csv" % os.getuid()), True)
+            _TunedGemm.named = True
+        t.enable(True)
+        t.tuning_enable(not torch.cuda.is_current_stream_capturing())
+        return self
+
+    def __exit__(self, *exc):
+        t = torch.cuda.tunable
+        t.tuning_enable(self.prev[1])
+        t.enable(self.prev[0])
+        return False
+
+
+class WideLinearFunction(torch.autograd.Function):
+    """act(x[:, :K] W^T + b) for a layer too wide for the tower kernels (K > 4096): three library GEMMs (forward, input
+    gradient, weight gradient), the two backward ones under ``_TunedGemm``; the relu mask and the bias gradient without
+    autograd's extra nodes."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, relu):
+        # (the forward keeps the library's default pick: the faster ones TunableOp finds for K = 10 413 accumulate in longer
+        # chains -- rms error 1.1e-6 against 0.8e-6 -- and the full-size gradient fixtures then sit at 0.6-1.3 of their bars
+        # instead of 0.5; tools/probes/tuned_gemm_error.py.  The two backward GEMMs lose nothing: K = 128 and K = B.)
+        h = torch.addmm(b, x, W.t()) if b is not None else torch.mm(x, W.t())
+        if relu:
+            h = torch.relu_(h)
+        ctx.relu, ctx.has_bias = bool(relu), b is not None
+        ctx.save_for_backward(x, W, h if relu else None)
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W, h = ctx.saved_tensors
+        if ctx.relu:
+            g = g * (h > 0)
+        elif not g.is_contiguous():
+            g = g.contiguous()
+        gx = gW = gb = None
+        with _TunedGemm():
+            if ctx.needs_input_grad[0]:
+                gx = torch.mm(g, W)
+            if ctx.needs_input_grad[1]:
+                gW = torch.mm(g.t(), x)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(0)
+        return gx, gW, gb, None
+
+
 def tower(dnn, dnn_linear, x, K=None, sink=None):
     """``dnn_linear(dnn(x[:, :K]))`` (or ``dnn(x[:, :K])`` when ``dnn_linear`` is None)."""
     spec = tower_layers(dnn, dnn_linear)
@@ -214,9 +280,7 @@ def tower(dnn, dnn_linear, x, K=None, sink=None):
         # remaining layers, dnn_linear, their backward and weight gradients -- runs on the tower kernels over its output
         # (round 4: those small layers were 6 hipBLASLt GEMMs of 8-27 us plus ~10 elementwise / reduce launches per step).
         W0, b0, relu0 = spec[0][0]
-        h0 = torch.nn.functional.linear(x[:, :K] if K != x.shape[1] else x, W0, b0)
-        if relu0:
-            h0 = torch.relu(h0)
+        h0 = WideLinearFunction.apply(x[:, :K] if K != x.shape[1] else x, W0, b0, bool(relu0))
         layers, w_out = spec[0][1:], spec[1]
         x, K = h0, W0.shape[0]
     elif spec is None or not x.is_cuda or K > 4096:   # (a single very wide layer, or modules outside the kernels)

@@ -1,14 +1,14 @@
 #!/bin/bash
 # round 4: FiBiNET's bilinear backward re-dealt by owning field -- parity, kernel budget, step time
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r4_fib3
+O=$GRAFT_REPO_ROOT/gpurun_out/r4_fib6
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 (timeout 900 python -m pytest tests/test_gpu_pairwise.py tests/test_gpu_full_golden.py -q --tb=short -k "bilinear or fibinet or Bilinear or FiBiNET" 2>&1 | tail -12) > $O/pytest.log
 (timeout 900 python -m pytest tests/test_gpu_models.py tests/test_gpu_reference_matrix.py -q --tb=short -k "fibinet or FiBiNET" 2>&1 | tail -6) >> $O/pytest.log
 cd /tmp; rm -rf /tmp/prof_f
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_f -o fib -- python $GRAFT_REPO_ROOT/tools/prof_one_model.py FiBiNET > $O/prof.log 2>&1
-t=$(find /tmp/prof_f -name "*kernel_trace.csv" | head -1); python $GRAFT_REPO_ROOT/tools/step_profile.py $t 1 4 > $O/fibinet_step_kernel_budget.txt 2>&1
+t=$(find /tmp/prof_f -name "*kernel_trace.csv" | head -1); python $GRAFT_REPO_ROOT/tools/step_profile.py $t 0 3 > $O/fibinet_step_kernel_budget.txt 2>&1
 cd $GRAFT_REPO_ROOT
 timeout 600 python - > $O/fibinet_bench.json 2> $O/fibinet_bench.err <<'PY'
 import sys, json
