@@ -6,6 +6,7 @@ import torch.nn as nn
 
 from .basemodel import BaseModel
 from ..inputs import DenseFeat, SparseFeat, VarLenSparseFeat
+from .._hip import ops as _ops
 from ..layers import DNN, BilinearInteraction, SENETLayer
 
 
@@ -39,10 +40,8 @@ class FiBiNET(BaseModel):
 
     def logit_parts(self, X):
         plan = self.model_plan()
-        gathered, linear_logit, _ = self.fused_inputs(X, want_fm=False)
-        B, nf = X.shape[0], len(plan.deep)
-        emb = gathered[:, :plan.emb_width].reshape(B, nf, plan.emb_dim)       # views of the gather's output
-        dense = gathered[:, plan.emb_width:] if plan.dense_cols else None
+        gathered, linear_logit, _ = self.fused_inputs(X, want_fm=False, full=True)
+        emb, dense = _ops.split_gathered(gathered, plan)                      # views of the gather's output
         dnn_input = self.Bilinear.fused_pair(emb, self.SE(emb), dense)
         dnn_logit = self.tower_logit(dnn_input)     # wide first layer on hipBLASLt, the rest on csrc/mlp.hip
         if len(self.linear_feature_columns) > 0 and len(self.dnn_feature_columns) > 0:
