@@ -246,6 +246,8 @@ class WideLinearFunction(torch.autograd.Function):
         # (the forward keeps the library's default pick: the faster ones TunableOp finds for K = 10 413 accumulate in longer
         # chains -- rms error 1.1e-6 against 0.8e-6 -- and the full-size gradient fixtures then sit at 0.6-1.3 of their bars
         # instead of 0.5; tools/probes/tuned_gemm_error.py.  The two backward GEMMs lose nothing: K = 128 and K = B.)
+        # (relu in the GEMM's epilogue -- torch._addmm_activation -- and the bias gradient as a matrix-vector product were
+        # measured: 0.848 against 0.833 ms per FiBiNET step, the library then picks a slower solution)
         h = torch.addmm(b, x, W.t()) if b is not None else torch.mm(x, W.t())
         if relu:
             h = torch.relu_(h)
