@@ -375,6 +375,189 @@ __global__ __launch_bounds__(kT * 2 / CT, 1) void k_cin_bwd_data(const float* __
 // Written to gH: the cross-row sums (every field exactly once); to gX0: the per-row accumulators -- the caller adds the
 // two, as it does for the general layer.
 // -------------------------------------------------------------------------------------------------------------
+// -------------------------------------------------------------------------------------------------------------
+// backward, data side, rows FLATTENED over (h, m): k_cin_bwd_data gives every h its own 32-row MFMA tile and leaves
+// 32 - M rows of it empty (M = 26: 19 % of the matrix work of the layer's biggest kernel).  Here row i of tile T is the
+// pair kf = 32 T + i = (h, m) = divmod(kf, M): K / 32 tiles instead of h (52 instead of 64 at h = 64, M = 26).  The price is
+// that an accumulator row is no longer one field.  M is a template parameter and the tile loop is unrolled over the
+// period after which the row -> (h, m) pattern repeats (TPER = M / gcd(32, M) tiles = 32 / gcd(32, M) values of h; 13
+// tiles / 16 h at M = 26), so that every register index below is a compile-time constant: the lane keeps X0[b, :, d] and
+// the gX0 accumulators of ALL M fields in registers (26 + 26) and the two candidates of a row -- its fields differ by 4
+// between the lane halves -- are chosen with a select.  Per accumulator row: ~7 VALU operations instead of 2.
+// -------------------------------------------------------------------------------------------------------------
+constexpr int cin_gcd(int a, int b) { return b == 0 ? a : cin_gcd(b, a % b); }
+
+template <int OT, int M>
+__global__ __launch_bounds__(kT * 2, 1) void k_cin_bwd_data_flat(const float* __restrict__ gA, const float* __restrict__ Asv,
+                                                        int64_t lda, int relu, const float* __restrict__ X0,
+                                                        int64_t ldx0, const float* __restrict__ H, int64_t ldh,
+                                                        int h, int D, int B, const float* __restrict__ W,
+                                                        int O, float* __restrict__ gH, int64_t ldgh, int acc_h,
+                                                        float* __restrict__ gX0, int64_t ldgx, int acc_x) {
+  constexpr int NT = kT * 2;                               // eight waves, one column tile each
+  constexpr int OB = OT * 32, NS = OT * 16, NW = OT * 32 * 32 / NT;
+  constexpr int G = cin_gcd(32, M), TPER = M / G, HPER = 32 / G;
+  extern __shared__ __align__(16) float smem[];
+  float* wl = smem;  // [2][OB][32]
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, p = lane >> 5, jl = lane & 31;
+  const int64_t c_base = static_cast<int64_t>(blockIdx.x) * kCols;
+  const int64_t ncol = static_cast<int64_t>(B) * D;
+  const int K = h * M;
+  const int ntiles = (K + 31) / 32;
+
+  const int64_t c = c_base + wv * 32 + jl;
+  const bool cv = c < ncol;
+  const int64_t bb = cv ? c / D : 0;
+  const int dd = cv ? static_cast<int>(c - bb * D) : 0;
+  float gy[NS];
+  {
+    const float* mask_src = relu ? Asv : gA;
+    const int64_t base = bb * lda + dd;
+#pragma unroll
+    for (int s0 = 0; s0 < NS; s0 += 16) {
+      float a[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int o = 2 * (s0 + i) + p;
+        gy[s0 + i] = ldg_f32(gA + base + static_cast<int64_t>(o < O ? o : O - 1) * D);
+      }
+      if (relu) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int o = 2 * (s0 + i) + p;
+          a[i] = ldg_f32(mask_src + base + static_cast<int64_t>(o < O ? o : O - 1) * D);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = 1.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int o = 2 * (s0 + i) + p;
+        gy[s0 + i] = (cv && o < O && a[i] > 0.f) ? gy[s0 + i] : 0.f;
+      }
+    }
+  }
+  float x0r[M], gxa[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const float v = ldg_f32(X0 + bb * ldx0 + m * D + dd);
+    x0r[m] = cv ? v : 0.f;
+    gxa[m] = 0.f;
+  }
+  const float pm0 = p ? 0.f : 1.f, pm1 = p ? 1.f : 0.f;   // which of a row's two candidate fields this lane half holds
+
+  float wreg[NW];
+  auto fetch_w = [&](int T) {       // W[o][32 T + i]: 128-byte runs
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const int e = q * NT + tid;  // = o_local * 32 + row
+      const int ol = e >> 5, kf = 32 * T + (e & 31);
+      const float v = ldg_f32(W + static_cast<int64_t>(ol < O ? ol : O - 1) * K + (kf < K ? kf : K - 1));
+      wreg[q] = (ol < O && kf < K) ? v : 0.f;
+    }
+  };
+  auto park_w = [&](int buf) {
+    float* dst = wl + buf * (OB * 32);
+#pragma unroll
+    for (int q = 0; q < NW; ++q) dst[q * NT + tid] = wreg[q];
+  };
+  // H[b, hA .. hA + 2, d] of a tile (hA = the field of its first row; 32 rows touch at most three fields for M >= 16)
+  static_assert(M >= 16 && M <= 32, "a tile of 32 rows must not span more than three fields");
+  auto tile_h = [&](int T, float& ha, float& hb, float& hc) {
+    const int hA = (32 * T) / M;
+    const int h0c = hA < h ? hA : h - 1, h1c = hA + 1 < h ? hA + 1 : h - 1, h2c = hA + 2 < h ? hA + 2 : h - 1;
+    ha = ldg_f32(H + bb * ldh + static_cast<int64_t>(h0c) * D + dd);
+    hb = ldg_f32(H + bb * ldh + static_cast<int64_t>(h1c) * D + dd);
+    hc = ldg_f32(H + bb * ldh + static_cast<int64_t>(h2c) * D + dd);
+  };
+  fetch_w(0);
+  park_w(0);
+  float hvA, hvB, hvC, hnA = 0.f, hnB = 0.f, hnC = 0.f;
+  tile_h(0, hvA, hvB, hvC);
+  asm volatile("" : "+v"(hvA));   // arrived before the loop (see k_cin_fwd)
+  asm volatile("" : "+v"(hvB));
+  asm volatile("" : "+v"(hvC));
+  __syncthreads();
+
+  float part[HPER + 1];
+#pragma unroll
+  for (int i = 0; i <= HPER; ++i) part[i] = 0.f;
+
+  for (int Tb = 0; Tb < ntiles; Tb += TPER) {
+    const int hbase = (Tb / TPER) * HPER;      // field of the period's first row
+#pragma unroll
+    for (int tm = 0; tm < TPER; ++tm) {
+      const int T = Tb + tm;
+      if (T < ntiles) {                        // (uniform)
+        const bool more = T + 1 < ntiles;
+        if (more) {
+          fetch_w(T + 1);
+          tile_h(T + 1, hnA, hnB, hnC);
+        }
+        const float* wc = wl + (T & 1) * (OB * 32);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc = mfma32(wc[(2 * s + p) * 32 + jl], gy[s], acc);
+        // tails: everything below indexes registers with constants (tm, r are unrolled)
+        const int hA = (32 * tm) / M;          // relative to hbase
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i0 = (r & 3) + 8 * (r >> 2);            // the row of lane half 0; half 1 holds row i0 + 4
+          const int k0 = 32 * tm + i0, k1 = k0 + 4;
+          const int h0 = k0 / M, m0 = k0 % M, h1 = k1 / M, m1 = k1 % M;
+          const float z = acc[r];
+          const float xs = p ? x0r[m1] : x0r[m0];
+          const float hs0 = h0 == hA ? hvA : (h0 == hA + 1 ? hvB : hvC), hs1 = h1 == hA ? hvA : (h1 == hA + 1 ? hvB : hvC);
+          const float hs = (h0 == h1) ? hs0 : (p ? hs1 : hs0);
+          const float zh = z * hs, zx = z * xs;
+          gxa[m0] = fmaf(zh, pm0, gxa[m0]);
+          gxa[m1] = fmaf(zh, pm1, gxa[m1]);
+          if (h0 == h1) {
+            part[h0] += zx;
+          } else {
+            part[h0] = fmaf(zx, pm0, part[h0]);
+            part[h1] = fmaf(zx, pm1, part[h1]);
+          }
+        }
+        // fields whose last row lies in this tile are complete
+#pragma unroll
+        for (int hr = 0; hr < HPER; ++hr) {
+          if (((hr + 1) * M - 1) / 32 == tm) {
+            float v = part[hr];
+            v += __shfl_xor(v, 32, kWave);
+            part[hr] = 0.f;
+            const int hq = hbase + hr;
+            if (p == 0 && cv && hq < h) {
+              float* dst = gH + bb * ldgh + static_cast<int64_t>(hq) * D + dd;
+              stg_f32(dst, acc_h ? ldg_f32(dst) + v : v);
+            }
+          }
+        }
+        if (more) {
+          park_w((T + 1) & 1);
+          hvA = hnA;
+          hvB = hnB;
+          hvC = hnC;
+        }
+        __syncthreads();
+      }
+    }
+  }
+  // both lane halves hold partial sums of every field of their column
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    float v = gxa[m];
+    v += __shfl_xor(v, 32, kWave);
+    if (cv && (m & 1) == p) {
+      float* dst = gX0 + bb * ldgx + m * D + dd;
+      stg_f32(dst, acc_x ? ldg_f32(dst) + v : v);
+    }
+  }
+}
+
 // the folded weight slices of k_cin_bwd_data_sym: Ws[tile j][o < OB][row i < 32] (zero where a row holds no pair)
 __global__ __launch_bounds__(kT) void k_cin_prep_wsym(const float* __restrict__ W, int O, int M, int OB, int ntiles,
                                                       float* __restrict__ Ws) {
@@ -1082,6 +1265,16 @@ extern "C" int dctr_cin_layer_bwd(const float* gA, const float* A, int64_t ld_a,
   k_cin_bwd_data_sym<OT_, CT_><<<grid, dim3(kT * 2 / CT_), lds, s>>>(gA_c, A_c, ld_a, relu, X0, ld_x0, M, D, B, workspace, \
                                                                     o_here, gH, ld_gh, acc_h, gX0, ld_gx, acc_x)
       static const bool sym_data = !(getenv("DCTR_CIN_SYM_DATA") && getenv("DCTR_CIN_SYM_DATA")[0] == '0');   // (A/B switch)
+      static const bool flat_ok = !(getenv("DCTR_CIN_FLAT") && getenv("DCTR_CIN_FLAT")[0] == '0');   // (A/B switch)
+      if (!(sym && sym_data) && flat_ok && M == 26 && ot >= 3) {
+        // the padded rows of the per-field tiles cost more than the flattened rows' bookkeeping (298 -> .. us at h = 64)
+        if (ot == 3)
+          k_cin_bwd_data_flat<3, 26><<<grid, dim3(kT * 2), lds, s>>>(gA_c, A_c, ld_a, relu, X0, ld_x0, H, ld_h, h, D, B, W_c,
+                                                                    o_here, gH, ld_gh, acc_h, gX0, ld_gx, acc_x);
+        else
+          k_cin_bwd_data_flat<4, 26><<<grid, dim3(kT * 2), lds, s>>>(gA_c, A_c, ld_a, relu, X0, ld_x0, H, ld_h, h, D, B, W_c,
+                                                                    o_here, gH, ld_gh, acc_h, gX0, ld_gx, acc_x);
+      } else
       if (sym && sym_data) {
         const int ntiles = (M & 1) ? (M + 1) / 2 : (M + 1) / 2 + 1;
         const int64_t nws = static_cast<int64_t>(ntiles) * ot * 32 * 32;

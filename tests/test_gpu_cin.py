@@ -17,6 +17,9 @@ CASES = [  # B, h, M, D, O, relu, bias
     (5, 3, 3, 4, 8, True, True), (33, 7, 5, 16, 40, False, True), (64, 26, 26, 16, 128, True, True),
     (100, 64, 26, 16, 128, True, True), (17, 6, 4, 8, 200, True, False), (40, 2, 31, 5, 32, True, True),
     (257, 5, 7, 3, 33, False, False), (16, 26, 26, 16, 256, True, True),
+    # 26 fields, wide outputs: the backward with rows flattened over (h, m) (k_cin_bwd_data_flat; 3, 13 + 2 and 1 tile periods,
+    # a last tile past K, output chunks of 96 / 128 / 128 + 72)
+    (100, 64, 26, 16, 128, True, True), (37, 3, 26, 8, 96, False, True), (50, 17, 26, 16, 200, True, False), (64, 1, 26, 4, 128, True, True),
 ]
 
 

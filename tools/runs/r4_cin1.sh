@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4: symmetric first CIN layer -- parity + xDeepFM step time (sym on / off) + kernel budget
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r4_cin3
+O=$GRAFT_REPO_ROOT/gpurun_out/r4_cin5
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 (timeout 900 python -m pytest tests/test_gpu_cin.py -q --tb=short 2>&1 | tail -8) > $O/pytest.log
