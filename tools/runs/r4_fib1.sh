@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4: FiBiNET's bilinear backward re-dealt by owning field -- parity, kernel budget, step time
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r4_fib7
+O=$GRAFT_REPO_ROOT/gpurun_out/r4_fib8
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 (timeout 900 python -m pytest tests/test_gpu_pairwise.py tests/test_gpu_full_golden.py -q --tb=short -k "bilinear or fibinet or Bilinear or FiBiNET" 2>&1 | tail -12) > $O/pytest.log
