@@ -40,6 +40,10 @@ constexpr int kThreads = 256;
 constexpr int kCap = 512;     // sort keys held in LDS
 constexpr int kStack = 40;    // pending (id bits fixed, their value) splits of an overflowing partition
 constexpr int kBucket = 512;  // keys per (unit, partition) bucket of the pre-pass (<= kCap; 2 per thread of its sort)
+constexpr int kChunk = 4096;  // most samples of a unit one workgroup of the two-level pre-pass re-orders in LDS
+constexpr int kFineMax = 16;  // most consecutive partitions per coarse bin (one workgroup of the second level sorts them all)
+constexpr int kSortT = 256;   // threads of a second-level workgroup
+constexpr int kBinsMax = 4096;   // coarse bins per unit (B <= 2^20: P <= 10923, 2731 bins)
 
 struct UpdArgs {
   const dctr_field_t* deep;
@@ -69,6 +73,13 @@ struct UpdArgs {
   int32_t* bcnt;
   uint32_t* bkeys;
   int32_t presorted;   // the buckets hold keys already sorted by (id, sample) (dctr_embed_segments)
+  // two-level pre-pass of large batches (k_prepass_bin / k_prepass_sort): every chunk of kChunk samples of a unit
+  // re-ordered by coarse bin (`fine` consecutive partitions), with the chunk's bin offsets
+  uint32_t* stage_keys;   // [n_units][n_chunks * chunk]
+  uint16_t* stage_tags;   // [n_units][n_chunks * chunk] partition of the entry
+  int32_t* stage_offs;    // [n_units][n_chunks][n_bins + 1]
+  int32_t n_chunks, n_bins, chunk;   // chunk: samples per level-1 workgroup (a power of two <= kChunk)
+  int32_t fine;                      // partitions per coarse bin (<= kFineMax)
 };
 
 // Diagnostics (per-workgroup phase stamps, partition override) exist only in the DCTR_DIAG build
@@ -1063,6 +1074,209 @@ __global__ __launch_bounds__(kThreads) void k_embed_segments(UpdArgs A) {
     if (tid + q * kThreads < n) *(DCTR_GLOBAL uint32_t*)(dst + rank[q]) = mine[q];
 }
 
+// ---- two-level pre-pass of LARGE batches (global batches of the sharded trainer, saturating launches) -----------------
+// What k_embed_segments computes -- every (unit, partition)'s keys sorted by (id, sample) in its bucket, the count beside it
+// -- for batches where "every workgroup scans the unit's B tags" (B / 96 workgroups x B tags per unit: quadratic) or "one
+// global atomic + one scattered 4-byte store per entry" (k_bucket; 540 us at B = 262 144) is the expensive part:
+//   level 1  k_prepass_bin   workgroup (unit, chunk of <= kChunk samples): LDS counting sort of the chunk's entries by COARSE
+//                            BIN (`fine` consecutive partitions): keys + 16-bit partition tags written back in bin order,
+//                            coalesced, with the chunk's bin offsets.  No global atomics, no capacity: exact for any ids.
+//   level 2  k_prepass_sort  workgroup (unit, coarse bin): collects the bin's run of every chunk (B / n_bins entries on
+//                            average) into `fine` LDS buckets, rank-sorts each bucket (keys are unique), writes the
+//                            sorted keys and the counts.  A partition with more than kBucket entries only gets its count
+//                            (the update kernel's general path takes it, as after k_embed_segments).
+// The result does not depend on the order the LDS atomics hand out slots: the rank sort fixes it.
+__global__ __launch_bounds__(kThreads) void k_prepass_bin(UpdArgs A) {
+  // dynamic LDS, sized by the launch (prepass_bin_lds): keys [chunk] | cnt [n_bins + 1] (counts, then exclusive starts) |
+  // cur [n_bins] | tags [chunk] -- 30 KB at B = 262 144 (five workgroups per CU) instead of 56 KB for the largest shapes
+  extern __shared__ __align__(16) uint32_t pp_lds[];
+  __shared__ int wsum[kThreads / 64];
+  const int tid = threadIdx.x;
+  uint32_t* keys = pp_lds;
+  int* cnt = reinterpret_cast<int*>(keys + A.chunk);
+  int* cur = cnt + (A.n_bins + 1);
+  uint16_t* tags = reinterpret_cast<uint16_t*>(cur + A.n_bins);
+  const int u = static_cast<int>(blockIdx.x) / A.n_chunks, ck = static_cast<int>(blockIdx.x) - u * A.n_chunks;
+  const int32_t* un = A.units + 4 * u;
+  const int di = uni(un[0]), wi = uni(un[1]);
+  const int64_t vocab = uni((di >= 0) ? A.deep[di].vocab : A.wide[wi].vocab);
+  const int B = A.B, NB = A.n_bins;
+  const int chunk = A.chunk;
+  const uint32_t fine = static_cast<uint32_t>(A.fine);
+  const int b0 = ck * chunk;
+  const int n = (B - b0) < chunk ? (B - b0) : chunk;
+  const int32_t* ids = A.ids_t + static_cast<int64_t>(u) * B + b0;
+  for (int i = tid; i < NB; i += kThreads) {
+    cnt[i] = 0;
+    cur[i] = 0;
+  }
+  __syncthreads();
+  // pass A: bin sizes (the ids stay in L2 for pass B; 16 registers of keys per thread would cost more than re-reading)
+#pragma unroll 4
+  for (int e = tid; e < chunk; e += kThreads) {
+    if (e < n) {
+      const int32_t id = clamp_id(ldg_i32(ids + e), vocab);
+      const uint32_t idq = div_p(static_cast<uint32_t>(id), A.pmagic, A.pshift);
+      const uint32_t p = static_cast<uint32_t>(id) - idq * static_cast<uint32_t>(A.P);
+      atomicAdd(&cnt[p / fine], 1);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the NB counts (NB <= kBinsMax: kSc per thread, wave scan, four wave totals)
+  {
+    constexpr int kSc = kBinsMax / kThreads;
+    int v[kSc], t = 0;
+#pragma unroll
+    for (int j = 0; j < kSc; ++j) {
+      const int i = kSc * tid + j;
+      v[j] = i < NB ? cnt[i] : 0;
+      t += v[j];
+    }
+    int incl = t;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off, 64);
+      if ((tid & 63) >= off) incl += o;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+    int run = base + incl - t;
+#pragma unroll
+    for (int j = 0; j < kSc; ++j) {
+      const int i = kSc * tid + j;
+      if (i < NB) cnt[i] = run;
+      run += v[j];
+    }
+    if (tid == kThreads - 1) cnt[NB] = run;     // (= n; bins past kSc * kThreads do not exist: NB <= kBinsMax)
+  }
+  __syncthreads();
+  // pass B: scatter (key, tag) to its bin's run
+#pragma unroll 4
+  for (int e = tid; e < chunk; e += kThreads) {
+    if (e < n) {
+      const int32_t id = clamp_id(ldg_i32(ids + e), vocab);
+      const uint32_t idq = div_p(static_cast<uint32_t>(id), A.pmagic, A.pshift);
+      const uint32_t p = static_cast<uint32_t>(id) - idq * static_cast<uint32_t>(A.P);
+      const int c = static_cast<int>(p / fine);
+      const int pos = cnt[c] + atomicAdd(&cur[c], 1);
+      keys[pos] = (idq << A.bbits) | static_cast<uint32_t>(b0 + e);
+      tags[pos] = static_cast<uint16_t>(p);
+    }
+  }
+  __syncthreads();
+  const int64_t so = (static_cast<int64_t>(u) * A.n_chunks + ck) * chunk;
+  for (int e = tid; e < n; e += kThreads) {
+    *(DCTR_GLOBAL uint32_t*)(A.stage_keys + so + e) = keys[e];
+    *(DCTR_GLOBAL uint16_t*)(A.stage_tags + so + e) = tags[e];
+  }
+  int32_t* offs = A.stage_offs + (static_cast<int64_t>(u) * A.n_chunks + ck) * (NB + 1);
+  for (int i = tid; i <= NB; i += kThreads) *(DCTR_GLOBAL int32_t*)(offs + i) = cnt[i];
+}
+
+__global__ __launch_bounds__(kSortT) void k_prepass_sort(UpdArgs A) {
+  extern __shared__ __align__(16) uint32_t bk_lds[];      // [fine][kBucket]
+  __shared__ int cnt[kFineMax], n_f[kFineMax], start[kFineMax + 1];
+  const int fine = A.fine;
+  const int tid = threadIdx.x;
+  const int NB = A.n_bins, P = A.P;
+  const int u = static_cast<int>(blockIdx.x) / NB, c = static_cast<int>(blockIdx.x) - u * NB;
+  if (tid < fine) cnt[tid] = 0;
+  __syncthreads();
+  // eight lanes per chunk walk the bin's run of that chunk -- TWO chunks per lane group at a time, their offsets requested
+  // together and their entries requested together: the walk is two dependent round trips per pass (offsets, entries), and at
+  // B = 262 144 (64 chunks, ~6 entries per run) a workgroup is nothing but those round trips
+  const int sub = tid & 7;
+  const uint32_t p0 = static_cast<uint32_t>(c) * static_cast<uint32_t>(fine);
+  constexpr int kGroups = kSortT / 8;
+#ifdef DCTR_DIAG
+  const int dbg = A.presorted;     // timing experiments of tools/prepass_bench.py (wrong results): 1 no stores, 2 no sort, 4 no walk
+#else
+  constexpr int dbg = 0;
+#endif
+  for (int ck0 = tid >> 3; ck0 < ((dbg & 4) ? 0 : A.n_chunks); ck0 += 2 * kGroups) {
+    int s0[2], s1[2];
+    const uint32_t* kk[2];
+    const uint16_t* tt[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ck = ck0 + h * kGroups;
+      const int ckc = ck < A.n_chunks ? ck : ck0;
+      const int64_t row = static_cast<int64_t>(u) * A.n_chunks + ckc;
+      const int32_t* offs = A.stage_offs + row * (NB + 1) + c;
+      s0[h] = ldg_i32(offs);
+      s1[h] = ldg_i32(offs + 1);
+      kk[h] = A.stage_keys + row * A.chunk;
+      tt[h] = A.stage_tags + row * A.chunk;
+    }
+    if (ck0 + kGroups >= A.n_chunks) s1[1] = s0[1];     // (no second chunk: an empty run)
+    // four entries per lane and chunk in flight (a hot id's run is hundreds of entries long: one dependent round trip per
+    // entry made the hot bin's workgroup the launch's tail)
+    const int len0 = s1[0] - s0[0], len1 = s1[1] - s0[1];
+    const int len = len0 > len1 ? len0 : len1;
+    for (int i = sub; i < len; i += 32) {
+      uint32_t key[2][4];
+      uint32_t tg[2][4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int lh = h ? len1 : len0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int ii = i + 8 * q;
+          ii = ii < lh ? ii : (lh > 0 ? lh - 1 : 0);
+          ii += s0[h];
+          ii = lh > 0 ? ii : 0;                          // (an empty run: any staged entry, masked below)
+          key[h][q] = *(const DCTR_GLOBAL uint32_t*)(kk[h] + ii);
+          tg[h][q] = *(const DCTR_GLOBAL uint16_t*)(tt[h] + ii);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int lh = h ? len1 : len0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (i + 8 * q < lh) {
+            const int f = static_cast<int>(tg[h][q] - p0);
+            const int slot = atomicAdd(&cnt[f], 1);
+            if (slot < kBucket) bk_lds[f * kBucket + slot] = key[h][q];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // counts out; prefix of the sortable partitions' sizes for the flattened rank sort (in LDS: indexed per entry)
+  if (tid == 0) {
+    int run = 0;
+    for (int f = 0; f < fine; ++f) {
+      const int nf = cnt[f];
+      start[f] = run;
+      n_f[f] = (nf <= kBucket && static_cast<int>(p0) + f < P) ? nf : 0;
+      run += n_f[f];
+    }
+    start[fine] = run;
+  }
+  if (tid < fine && static_cast<int>(p0) + tid < P)
+    *(DCTR_GLOBAL int32_t*)(A.bcnt + static_cast<int64_t>(u) * P + p0 + tid) = cnt[tid];
+  __syncthreads();
+  const int total = start[fine];
+  for (int e = tid; e < total; e += kSortT) {
+    int f = 0;
+    for (int g = 1; g < fine; ++g) f += (e >= start[g]) ? 1 : 0;
+    const int nf = n_f[f];
+    const uint32_t* src = bk_lds + f * kBucket;
+    const uint32_t mine = src[e - start[f]];
+    // (one broadcast LDS read per key: ~45 of the kernel's ~80 us at B = 262 144; dwordx4 reads with masked compares
+    // measured slower, 137 against 112 us for both levels)
+    int rank = 0;
+#pragma unroll 4
+    for (int i = 0; i < ((dbg & 2) ? 1 : nf); ++i) rank += (src[i] < mine) ? 1 : 0;
+    if (!(dbg & 1) || rank == 12345678)
+      *(DCTR_GLOBAL uint32_t*)(A.bkeys + (static_cast<int64_t>(u) * P + p0 + f) * kBucket + rank) = mine;
+  }
+}
+
 // ---- X -> ids_t (+ parts_t) (standalone; the forward kernel fuses the same thing) -------------------
 __global__ __launch_bounds__(kThreads) void k_embed_ids(const dctr_field_t* __restrict__ deep,
                                                         const dctr_field_t* __restrict__ wide,
@@ -1159,9 +1373,69 @@ extern "C" int dctr_embed_update_supported(const dctr_plan_t* plan, int64_t max_
 
 // ints of the optional bucket workspace of dctr_embed_update for this plan / batch (must be zero before its first use;
 // the kernels leave the counters at zero)
+// Staging of the two-level pre-pass behind the bucket arrays: keys [n_units][n_chunks * chunk] u32, tags (u16, two per
+// int), chunk offsets [n_units][n_chunks][n_bins + 1].  Used from kTwoLevelMin samples: below it a workgroup's scan over
+// the unit's B partition tags is as cheap (uniform ids: 17.6 against 24 us at B = 8192) or cheaper (Zipf ids: 39 against
+// 26 us -- four partitions of several hundred entries rank-sorted by ONE workgroup); profiles/r04_prepass_two_level.jsonl.
+constexpr int kTwoLevelMin = 16384;
+struct StageLayout {
+  int n_chunks, n_bins, chunk, fine;
+  int64_t keys_off, tags_off, offs_off, total;   // int32 offsets inside the workspace
+};
+StageLayout stage_layout(int32_t n_units, int32_t B, int P) {
+  StageLayout L;
+  // samples per level-1 workgroup: as large as LDS allows once the launch has ~1000 workgroups, never below 512
+  L.chunk = kChunk;
+  while (L.chunk > 512 && static_cast<int64_t>(n_units) * B / L.chunk < 1024) L.chunk >>= 1;
+  L.n_chunks = (B + L.chunk - 1) / L.chunk;
+  // partitions per coarse bin: the second level reads a (chunk, bin) run of chunk * fine / P ~ 96 * fine * chunk / B entries
+  // per three lines it touches (keys, tags, offsets) and is bound by that request rate at large batches (B = 262 144,
+  // fine 4: 192 lines per 380 entries, 80 us); more partitions per workgroup make the runs longer -- and the rank sort
+  // of a skewed bin more serial, hence only as many as the batch needs
+  L.fine = 4;      // (measured at B = 262 144: 4 -> 110, 16 -> 126 us for both levels; profiles/r04_prepass_two_level.jsonl)
+  L.n_bins = (P + L.fine - 1) / L.fine;
+  const int64_t ne = static_cast<int64_t>(n_units) * L.n_chunks * L.chunk;
+  L.keys_off = static_cast<int64_t>(n_units) * P * (1 + kBucket);
+  L.tags_off = L.keys_off + ne;
+  L.offs_off = L.tags_off + (ne + 1) / 2;
+  L.total = L.offs_off + static_cast<int64_t>(n_units) * L.n_chunks * (L.n_bins + 1);
+  return L;
+}
+
+// the two launches of the two-level pre-pass on `a` (units, ids, P, magic, bcnt / bkeys set by the caller)
+int launch_two_level(UpdArgs a, const StageLayout& SL, int32_t* workspace, hipStream_t s) {
+  a.stage_keys = reinterpret_cast<uint32_t*>(workspace + SL.keys_off);
+  a.stage_tags = reinterpret_cast<uint16_t*>(workspace + SL.tags_off);
+  a.stage_offs = workspace + SL.offs_off;
+  a.n_chunks = SL.n_chunks;
+  a.n_bins = SL.n_bins;
+  a.chunk = SL.chunk;
+  a.fine = SL.fine;
+  a.presorted = 0;
+#ifdef DCTR_DIAG
+  if (const char* e = getenv("DCTR_PREPASS_DBG")) a.presorted = atoi(e);
+#endif
+  const size_t lds1 = static_cast<size_t>(SL.chunk) * 6 + static_cast<size_t>(2 * SL.n_bins + 1) * 4;
+  k_prepass_bin<<<dim3(static_cast<unsigned>(a.n_units) * SL.n_chunks), dim3(kThreads), lds1, s>>>(a);
+  const int st = launch_status();
+  if (st != DCTR_OK) return st;
+  k_prepass_sort<<<dim3(static_cast<unsigned>(a.n_units) * SL.n_bins), dim3(kSortT),
+                   static_cast<size_t>(SL.fine) * kBucket * 4, s>>>(a);
+  return launch_status();
+}
+bool two_level_applies(const StageLayout& SL, int32_t B, int P, int64_t workspace_ints) {
+  int two_level_min = kTwoLevelMin;
+#ifdef DCTR_DIAG
+  if (const char* e = getenv("DCTR_PREPASS_TWO_LEVEL_MIN")) two_level_min = atoi(e);   // tools/prepass_bench.py sweeps it
+#endif
+  return B >= kTwoLevelMin && B >= two_level_min && SL.n_bins <= kBinsMax && P <= 65535 && workspace_ints >= SL.total;
+}
+
 extern "C" int64_t dctr_embed_update_workspace_ints(const dctr_plan_t* plan, int32_t n_units, int32_t B) {
   if (!plan || n_units <= 0 || B <= 0) return 0;
-  return static_cast<int64_t>(n_units) * dctr_embed_update_partitions(plan, B) * (1 + kBucket);
+  const int P = dctr_embed_update_partitions(plan, B);
+  if (B >= kTwoLevelMin && stage_layout(n_units, B, P).n_bins <= kBinsMax) return stage_layout(n_units, B, P).total;
+  return static_cast<int64_t>(n_units) * P * (1 + kBucket);
 }
 
 extern "C" int dctr_embed_segments(const dctr_plan_t* plan, const int32_t* units, int32_t n_units, int64_t max_vocab,
@@ -1187,8 +1461,12 @@ extern "C" int dctr_embed_segments(const dctr_plan_t* plan, const int32_t* units
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(nbuckets)), block(kThreads);
   // small batches: every workgroup finds its entries by comparing the forward's 16-bit partition tags (B / 8 vector
-  // loads per workgroup).  Large batches (or no tags): one global atomic per entry buckets them first.
-  if (parts_t && P <= 65535 && B <= 32768) {
+  // loads per workgroup).  Large batches: the two-level pre-pass (chunks re-ordered by coarse bin, then one workgroup
+  // per bin), when the caller's workspace has room for its staging; else (or without tags): one global atomic per entry.
+  const StageLayout SL = stage_layout(n_units, B, P);
+  if (two_level_applies(SL, B, P, workspace_ints)) {
+    return launch_two_level(a, SL, workspace, s);
+  } else if (parts_t && P <= 65535 && B <= 32768) {
     k_embed_segments<false><<<grid, block, 0, s>>>(a);
   } else {
     const int64_t ne = static_cast<int64_t>(n_units) * B;
@@ -1259,8 +1537,15 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
   if (workspace && workspace_ints >= nbuckets * (1 + kBucket)) {
     a.bcnt = workspace;
     a.bkeys = reinterpret_cast<uint32_t*>(workspace + nbuckets);
+    const StageLayout SL = stage_layout(n_units, B, P);
     if (presorted) {
       a.presorted = 1;    // dctr_embed_segments filled (and sorted) the buckets on these very ids
+    } else if (two_level_applies(SL, B, P, workspace_ints)) {
+      // a large batch without a pre-pass (the owners' update of the table-sharded step): the two-level pre-pass here, in
+      // line, then the lean pre-sorted kernel -- instead of one global atomic per entry and every workgroup's own sort
+      const int st = launch_two_level(a, SL, workspace, s);
+      if (st != DCTR_OK) return st;
+      a.presorted = 1;
     } else {
       const int64_t ne = static_cast<int64_t>(n_units) * B;
       k_bucket<<<dim3(static_cast<unsigned>((ne + kThreads - 1) / kThreads)), block, 0, s>>>(a);

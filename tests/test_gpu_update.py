@@ -188,17 +188,24 @@ def test_wide_only_and_deep_only_units():
 
 
 @pytest.mark.parametrize("idmode,B", [("uniform", 4096), ("hot", 4096), ("same", 777), ("hot", 20000),
-                                          ("zipf", 4096), ("zipf", 16384)])
+                                          ("zipf", 4096), ("zipf", 16384),
+                                          # (the two-level pre-pass of large batches: k_prepass_bin + k_prepass_sort)
+                                          ("uniform", 70000), ("zipf", 40000), ("same", 9000)])
 def test_prepass_layouts_and_inkernel_scan_agree_bit_for_bit(monkeypatch, idmode, B):
-    """The same two Adagrad steps three ways -- (a) segment pre-pass (dctr_embed_segments) + interleaved slabs, the
-    default; (b) no pre-pass: every workgroup scans and sorts for itself; (c) the reference's contiguous tensors --
+    """The same two Adagrad steps five ways -- (a) segment pre-pass (dctr_embed_segments) + interleaved slabs, the
+    default; (b) no separate pre-pass (large batches: the update buckets / pre-sorts in line); (c) the reference's
+    contiguous tensors; (d) the block layout; (e) no workspace: every workgroup scans and sorts for itself --
     must leave bit-identical tables and optimizer state: the layout only moves bytes, the pre-pass only moves work."""
     vocabs = [1000, 17, 100_000, 3]
     X = _batch(B, vocabs, 2, idmode, seed=11)
     results = []
-    for seg, layout in (("1", "interleaved"), ("0", "interleaved"), ("1", "contiguous"), ("1", "block")):
+    # (bucket "0": no workspace at all -- every workgroup of the general kernel scans the unit's ids and sorts for itself;
+    # from B = 16 384 the other variants all pass through the two-level pre-pass, this one never does)
+    for seg, layout, bucket in (("1", "interleaved", "auto"), ("0", "interleaved", "auto"), ("1", "contiguous", "auto"),
+                                ("1", "block", "auto"), ("0", "interleaved", "0")):
         monkeypatch.setenv("DCTR_SEGMENTS", seg)
         monkeypatch.setenv("DCTR_TABLE_LAYOUT", layout)
+        monkeypatch.setenv("DCTR_UPD_BUCKET", bucket)
         torch.manual_seed(0)
         m = _model(len(vocabs), vocabs, 16, 2)
         m.compile("adagrad", "binary_crossentropy")
