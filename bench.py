@@ -634,6 +634,7 @@ def main():
                                                                args.steps_per_graph, not args.no_graph, args.repeats,
                                                                args.warmup_seconds)
         parallel = None
+        S_blk = 0
     else:
         # table-sharded embeddings + data-parallel tower (SURVEY.md 8(e) option S); the compute between the
         # collectives is captured as hipGraph segments after a few eager steps
@@ -674,6 +675,25 @@ def main():
         def run(k):   # the trainer is told the next batch: its ids travel with this step's gradients
             return parallel.train_step(*batch(k), next_xb=batch(k + 1)[0])
 
+        # direct exchange: S consecutive steps per hipGraph (ShardedTrainer.train_block), like the single-GPU runner; the
+        # blocks are runs of S consecutive resident batches (a run that would wrap starts over at row 0)
+        S_blk = min(args.steps_per_graph, args.steps, n_batches // 2) if (exchange == "direct" and on_gpu and
+                                                                          not args.no_graph and
+                                                                          os.environ.get("DCTR_SHARDED_BLOCK", "1") != "0") else 0
+        if S_blk < 2 or args.steps % S_blk != 0:
+            S_blk = 0
+        blk_pos = [0]
+
+        def block_at(j):
+            return X[j * B:(j + S_blk) * B].view(S_blk, B, X.shape[1]), y[j * B:(j + S_blk) * B].view(S_blk, B)
+
+        def run_block():
+            j = blk_pos[0]
+            jn = j + S_blk if j + 2 * S_blk <= n_batches else 0
+            xs, ys = block_at(j)
+            blk_pos[0] = jn
+            return parallel.train_block(xs, ys, next_first=X[jn * B:(jn + 1) * B])
+
         i = 0
         n_eager = min(3, args.warmup) if not args.no_graph else args.warmup
         for _ in range(n_eager):
@@ -683,18 +703,29 @@ def main():
         if not args.no_graph and on_gpu:
             parallel.set_use_graphs(True)    # the compute segment is captured at the next step
             graphed = True
-        for _ in range(max(2 if graphed else 0, args.warmup - n_eager)):
-            run(i)
-            i += 1
+        if S_blk and graphed:
+            for _ in range(3):      # eager block, capture, one replay
+                run_block()
+                i += S_blk
+        else:
+            S_blk = 0
+            for _ in range(max(2 if graphed else 0, args.warmup - n_eager)):
+                run(i)
+                i += 1
         def block():       # exactly --steps steps between barrier + synchronize on both sides; MAX over ranks
             nonlocal i, out
             gpu_sync()
             dist.barrier()
             gpu_sync()
             t0 = time.perf_counter()
-            for _ in range(args.steps):
-                out = run(i)
-                i += 1
+            if S_blk:
+                for _ in range(args.steps // S_blk):
+                    out = run_block()
+                    i += S_blk
+            else:
+                for _ in range(args.steps):
+                    out = run(i)
+                    i += 1
             gpu_sync()
             dist.barrier()
             gpu_sync()
@@ -759,7 +790,7 @@ def main():
                                    "fwd+bwd+%s, l2=0, dnn=(256,128)%s" % (args.vocab, B, args.optimizer,
                                                                          "" if args.ids == "uniform" else ", ids ~ Zipf(1.05) [secondary run]"),
                        "global_batch": world * B, "parallelism": ("tables sharded x%d + dp%d tower, %s exchange" % (world, world, parallel.exchange)) if parallel is not None else "single",
-                       "hip_graph": bool(graphed), "steps_per_graph": (min(args.steps_per_graph, args.steps) if graphed and parallel is None else None),
+                       "hip_graph": bool(graphed), "steps_per_graph": (min(args.steps_per_graph, args.steps) if graphed and parallel is None else (S_blk or None) if graphed else None),
                        "eager_steps_in_timed_region": 0 if graphed else args.steps,
                        "warmup_steps_run": did_warm, "optimizer": args.optimizer},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS,

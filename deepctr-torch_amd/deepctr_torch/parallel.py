@@ -997,6 +997,16 @@ class ShardedTrainer(object):
         dx, lay, slab = self._dx, self.layout, self.slab
         main = torch.cuda.current_stream(self._x.device)
         side = self._side
+        # the id-only half of the owners' update (every partition's entries found and sorted: dctr_embed_segments) on the
+        # pre-pass queue, beside the rows exchange, the assembly and the tower: the ids of this batch have been sitting in
+        # _ids_buf since the previous step's gather.  The update then runs its lean pre-sorted kernel.  OPT-IN
+        # (DCTR_SHARDED_SEGMENTS=1): measured at one rank the step is SLOWER with it, 0.158 against 0.144 ms -- the third
+        # queue inside the captured step costs more in cross-queue edges than the update kernel saves
+        # (gpurun r4_s2_6, profiles/r04_bench_sharded_1rank_block.json).
+        seg = None
+        sub = self.ops.sub
+        if sub is not None and os.environ.get("DCTR_SHARDED_SEGMENTS", "0") == "1" and sub.segments_enabled():
+            seg = sub.launch_segments(self._ids_buf, self._parts_buf, self._ids_buf.shape[1])
         self._recv = dx.send_rows(self._chunks)
         self.overlap_wgrad = True
         self._send_static = self._send_buf
@@ -1027,7 +1037,7 @@ class ShardedTrainer(object):
             with torch.cuda.stream(side):
                 dense()
         grads_all = dx.send_grads(send)
-        self.ops.update(grads_all, (self._ids_buf, self._parts_buf, None))
+        self.ops.update(grads_all, (self._ids_buf, self._parts_buf, seg))
         # (the ids of the announced next batch arrived with the gradients; an un-announced call gathers again itself)
         self.ops.gather(grads_all[:, lay.ids_col:lay.ids_col + lay.n_slots], out=(self._chunks, self._ids_buf, self._parts_buf),
                         push=self._push_rows())
@@ -1037,14 +1047,13 @@ class ShardedTrainer(object):
             dense()
         return loss, y_pred
 
-    def _train_step_direct(self, xb, yb, next_xb=None):
+    def _stage(self, xb, yb, next_xb):
+        """One launch in front of a direct-exchange step: the batch into the static buffers the step reads, the announced
+        next batch's id columns into the gradient chunks (dctr_shard_stage); plain copies for other dtypes / strides."""
         import ctypes
         from ._hip import lib as L
         lay, B = self.layout, xb.shape[0]
-        if self._dx is None or self._dx.recv.shape[1] != B:
-            self._direct_setup(xb)
-            self._announced = None
-        announce = next_xb is not None and tuple(next_xb.shape) == tuple(xb.shape) and next_xb.stride(1) == 1
+        announce = next_xb is not None
         P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())       # noqa: E731
         yv = yb.reshape(-1)
         if xb.dtype == torch.float32 and xb.stride(1) == 1 and yv.dtype == torch.float32 and yv.is_contiguous() and \
@@ -1060,6 +1069,74 @@ class ShardedTrainer(object):
             if announce:
                 self._send_buf.view(lay.world, B, lay.ldc)[:, :, lay.ids_col:lay.ids_col + lay.n_slots].copy_(
                     self.ops.pack_ids(next_xb))
+
+    # ---- S consecutive steps of the direct exchange as ONE hipGraph ---------------------------------------------------
+    def train_block(self, x_block, y_block, next_first=None):
+        """``x_block [S, B, C]`` / ``y_block [S, B]``: S consecutive train steps, equal to S ``train_step`` calls that each
+        announce their successor.  With the direct exchange on a GPU the S steps -- staging, exchanges, tower, owners'
+        update and gather, dense sum -- are ONE hipGraph replay on static block buffers (a step-per-graph replay leaves
+        the GPU idle ~20 us between two launches: profiles/r04_sharded_1rank_direct_push_timeline.txt).
+        ``next_first [B, C]``: the first batch of the NEXT call (its ids travel with the last step's gradients); every
+        rank must announce (or not) consistently.  Returns the last step's ``(loss, total, y_pred)``."""
+        S, B = int(x_block.shape[0]), int(x_block.shape[1])
+        if not (self.exchange == "direct" and x_block.is_cuda and self.slab is not None):
+            out = None
+            for j in range(S):
+                nxt = x_block[j + 1] if j + 1 < S else next_first
+                out = self.train_step(x_block[j], y_block[j], next_xb=nxt)
+            return out
+        if not self.slab.intact():
+            raise RuntimeError("a dense parameter was re-allocated; build a new ShardedTrainer")
+        xb0, yb0 = x_block[0], y_block[0]
+        if self._shape != (tuple(xb0.shape), tuple(yb0.shape)):
+            self._build(xb0, yb0)
+            self._pre = None
+        if self._dx is None or self._dx.recv.shape[1] != B:
+            self._direct_setup(xb0)
+            self._announced = None
+        blk = getattr(self, "_blk", None)
+        if blk is None or tuple(blk["x"].shape) != tuple(x_block.shape) or blk["x"].dtype != x_block.dtype or \
+                blk["dx"] is not self._dx:
+            blk = self._blk = {"x": torch.empty_like(x_block, memory_format=torch.contiguous_format),
+                               "y": torch.empty((S,) + tuple(yb0.shape), dtype=y_block.dtype, device=y_block.device),
+                               "nf": torch.empty_like(xb0, memory_format=torch.contiguous_format), "seg": {},
+                               "dx": self._dx}
+        blk["x"].copy_(x_block)
+        blk["y"].copy_(y_block.reshape(blk["y"].shape))
+        announce = next_first is not None and tuple(next_first.shape) == tuple(xb0.shape)
+        if announce:
+            blk["nf"].copy_(next_first)
+        key = (x_block.data_ptr(), x_block._version)
+        if self._announced != key:                       # ids not at their owners yet: the explicit exchange + gather
+            self._ids_tmp.copy_(self.ops.pack_ids(blk["x"][0]))
+            ids_all = self._dx.send_ids(self._ids_tmp)
+            self.ops.gather(ids_all, out=(self._chunks, self._ids_buf, self._parts_buf), push=self._push_rows())
+        self._announced = (next_first.data_ptr(), next_first._version) if announce else None
+        seg = blk["seg"].get((announce, bool(self.use_graphs)))
+        if seg is None:
+            def steps(blk=blk, announce=announce, S=S):
+                out = None
+                for j in range(S):
+                    nxt = blk["x"][j + 1] if j + 1 < S else (blk["nf"] if announce else None)
+                    self._stage(blk["x"][j], blk["y"][j], nxt)
+                    out = self._direct_body()
+                return out
+            seg = blk["seg"][(announce, bool(self.use_graphs))] = _Segment(steps, bool(self.use_graphs))
+            # (the first call of a _Segment runs eagerly -- descriptor uploads, lazy buffers; the single-step segment has
+            # normally done that already)
+            seg.primed = getattr(self, "_direct_seg", None) is not None and self._direct_seg.primed
+        loss, y_pred = seg()
+        return loss, loss.reshape(1), y_pred
+
+    def _train_step_direct(self, xb, yb, next_xb=None):
+        import ctypes
+        from ._hip import lib as L
+        lay, B = self.layout, xb.shape[0]
+        if self._dx is None or self._dx.recv.shape[1] != B:
+            self._direct_setup(xb)
+            self._announced = None
+        announce = next_xb is not None and tuple(next_xb.shape) == tuple(xb.shape) and next_xb.stride(1) == 1
+        self._stage(xb, yb, next_xb if announce else None)
         key = (xb.data_ptr(), xb._version)
         if self._announced != key:                       # ids not at their owners yet: the explicit exchange + gather
             self._ids_tmp.copy_(self.ops.pack_ids(self._x))

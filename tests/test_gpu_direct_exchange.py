@@ -106,3 +106,71 @@ def test_direct_exchange_ranks_on_one_gpu_equal_the_single_process_step(tmp_path
     for k, v in ref_sd.items():
         err = float((ranks[0]["sd"][k] - v).abs().max())
         assert err <= 2e-6 * max(1.0, float(v.abs().max())) + 2e-7, "%s: %.3e" % (k, err)
+
+
+# ---- S steps per hipGraph: ShardedTrainer.train_block ------------------------------------------------------------------
+BLK_S, BLK_N = 2, 3            # three blocks of two steps behind two single steps: eager block, captured block, replay
+
+
+def _worker_block(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        dev = "cuda:0"
+        m = _model(dev)
+        from deepctr_torch.parallel import ShardedTrainer
+        m.compile("adagrad", "binary_crossentropy", metrics=[])
+        m.train()
+        tr = ShardedTrainer(m, exchange="direct", use_graphs=False)
+        n = 2 + BLK_S * BLK_N
+        batches = [_batch(step, world) for step in range(n)]
+        Xr = torch.stack([Xg[rank * B_:(rank + 1) * B_] for Xg, _ in batches]).to(dev)      # [n, B, C] resident
+        yr = torch.stack([yg[rank * B_:(rank + 1) * B_] for _, yg in batches]).to(dev)
+        losses = []
+        for step in range(2):
+            losses.append(tr.train_step(Xr[step], yr[step], next_xb=Xr[step + 1])[0].clone())
+        tr.set_use_graphs(True)
+        for b in range(BLK_N):
+            lo = 2 + b * BLK_S
+            nxt = Xr[lo + BLK_S] if lo + BLK_S < n else None
+            losses.append(tr.train_block(Xr[lo:lo + BLK_S], yr[lo:lo + BLK_S], next_first=nxt)[0].clone())
+        torch.cuda.synchronize()
+        tr._dx.check()
+        tr.gather_tables()
+        tr.close()
+        m.model_plan().check_ids()
+        torch.save({"sd": {k: v.detach().cpu().clone() for k, v in m.state_dict().items()},
+                    "loss": torch.stack([l.reshape(()) for l in losses]).cpu()}, os.path.join(out_dir, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_train_block_equals_the_single_process_steps(tmp_path):
+    """Two ranks sharing the GPU, the steps behind the second one as blocks of BLK_S steps per hipGraph (first block eager,
+    second captured and replayed, third a pure replay): parameters and the blocks' last losses equal the single-process
+    fused step on the concatenated batches."""
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker_block, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    ranks = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
+    for k in ranks[0]["sd"]:
+        assert torch.equal(ranks[0]["sd"][k], ranks[1]["sd"][k]), "replicas differ after gather_tables: %s" % k
+    dev = "cuda:0"
+    ref = _model(dev)
+    ref.compile("adagrad", "binary_crossentropy", metrics=[])
+    ref.train()
+    n = 2 + BLK_S * BLK_N
+    ref_loss = []
+    for step in range(n):
+        Xg, yg = _batch(step, world)
+        ref_loss.append(ref._train_step(Xg.to(dev), yg.to(dev))[0].reshape(()))
+    torch.cuda.synchronize()
+    want = torch.stack([ref_loss[0], ref_loss[1]] + [ref_loss[2 + (b + 1) * BLK_S - 1] for b in range(BLK_N)]).cpu()
+    got = sum(r["loss"] for r in ranks)
+    assert torch.allclose(got, want, rtol=2e-5), (got, want)
+    for k, v in ref.state_dict().items():
+        v = v.detach().cpu()
+        err = float((ranks[0]["sd"][k] - v).abs().max())
+        assert err <= 2e-6 * max(1.0, float(v.abs().max())) + 2e-7, "%s: %.3e" % (k, err)
