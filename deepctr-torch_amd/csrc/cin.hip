@@ -1157,6 +1157,13 @@ extern "C" size_t dctr_cin_bwd_workspace_floats(int32_t B, int32_t h, int32_t M,
     const WgradGeom gs = wgrad_geom(B, h, M, D, true);
     const size_t ns = static_cast<size_t>(gs.q) * o_chunk * (static_cast<size_t>(M) * (M + 1) / 2 + 1);
     if (ns > need) need = ns;
+    // k_cin_prep_wsym stages the folded weight slices of k_cin_bwd_data_sym in the same workspace: [tiles][ot * 32][32].
+    // (Small shapes -- 5 fields, 8 feature maps, 64 samples: 3072 floats against 832 of partials -- used to write past
+    // the end of the buffer: zeros over whatever the allocator had placed behind it, found as an order-dependent
+    // failure of tests/test_gpu_reference_matrix.py in the second session of round 4.)
+    const size_t ntiles = (M & 1) ? (M + 1) / 2 : (M + 1) / 2 + 1;
+    const size_t nw = ntiles * ((o_chunk + 31) / 32) * 32 * 32;
+    if (nw > need) need = nw;
   }
   return need;
 }

@@ -190,6 +190,70 @@ __global__ __launch_bounds__(kTH) void k_l2_value_multi(MultiArgs A, float* __re
   if (threadIdx.x == 0) stg_f32(out, tot + ldg_f32(out));
 }
 
+
+// ---- autograd glue of the models that run through torch.autograd (xDeepFM, FiBiNET, DCN, PNN, ...) as single launches ----
+
+// out[b, 0:W) = a[b, :] (+ c[b, :]),  out[b, W:W+nd) = d[b, :],  out[b, W+nd:ldo) = 0 : the gradient of the gather's output
+// [B, ld] from the gradients of its two views (the field block as [B, F*D], the dense block) -- as slices that is two
+// copies and a fill (three launches, 17 us at the Criteo shape), plus an add when two consumers share the field block.
+// W % 4 == 0, ldo % 4 == 0, rows 16-byte aligned: the field block moves as dwordx4.
+__global__ __launch_bounds__(256) void k_rows_join(const float* __restrict__ a, int64_t lda, const float* __restrict__ c,
+                                                   int64_t ldc, int W, const float* __restrict__ d, int64_t ldd, int nd,
+                                                   float* __restrict__ out, int64_t ldo, int B) {
+  const int q4 = static_cast<int>(ldo >> 2), w4 = W >> 2;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= static_cast<int64_t>(B) * q4) return;
+  const int b = static_cast<int>(i / q4), q = static_cast<int>(i - static_cast<int64_t>(b) * q4);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (q < w4) {
+    if (a) v = *(const DCTR_GLOBAL f32x4*)(a + b * lda + 4 * q);
+    if (c) v += *(const DCTR_GLOBAL f32x4*)(c + b * ldc + 4 * q);
+  } else if (d) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int col = 4 * q + k - W;
+      if (col < nd) v[k] = ldg_f32(d + b * ldd + col);
+    }
+  }
+  *(DCTR_GLOBAL f32x4*)(out + b * ldo + 4 * q) = v;
+}
+
+// relu's backward on g [B, N] (mask h > 0, like aten::threshold_backward) fused with the bias gradient's column sums:
+// workgroup w takes the rows [w * kRows, ...), thread n the columns n, n + 256, ...; partial sums part[w][N] are added by
+// k_colsum_finish in workgroup order (deterministic).  Replaces threshold_backward + sum(0) (a 2-stage ATen reduction).
+constexpr int kColRows = 32;
+__global__ __launch_bounds__(256) void k_relu_bwd_colsum(const float* __restrict__ g, int64_t ldg, const float* __restrict__ h,
+                                                         int64_t ldh, int B, int N, float* __restrict__ go, int64_t ldo,
+                                                         float* __restrict__ part) {
+  const int r0 = blockIdx.x * kColRows;
+  const int r1 = (r0 + kColRows < B) ? r0 + kColRows : B;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int b = r0; b < r1; ++b) {
+      const float gv = ldg_f32(g + b * ldg + n);
+      const float v = (h == nullptr || ldg_f32(h + b * ldh + n) > 0.f) ? gv : 0.f;
+      if (go) stg_f32(go + b * ldo + n, v);
+      s += v;
+    }
+    stg_f32(part + static_cast<int64_t>(blockIdx.x) * N + n, s);
+  }
+}
+__global__ __launch_bounds__(256) void k_colsum_finish(const float* __restrict__ part, int groups, int N,
+                                                       float* __restrict__ out) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int g0 = 0; g0 < groups; g0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = ldg_f32(part + static_cast<int64_t>(g0 + k < groups ? g0 + k : groups - 1) * N + n);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (g0 + k < groups) s += v[k];
+  }
+  stg_f32(out + n, s);
+}
 }  // namespace
 
 extern "C" int dctr_l2_value_multi(const dctr_dense_item_t* items, int32_t n_items, float* out, dctr_stream_t stream) {
@@ -270,5 +334,36 @@ extern "C" int dctr_dense_opt(float* p, const float* g, float* state, int64_t n,
     k_dense_opt<DCTR_UPD_ADAGRAD><<<grid, block, 0, s>>>(p, g, state, n4, n, lr, eps);
   else
     k_dense_opt<DCTR_UPD_SGD><<<grid, block, 0, s>>>(p, g, state, n4, n, lr, eps);
+  return launch_status();
+}
+
+extern "C" int dctr_rows_join(const float* a, int64_t ld_a, const float* c, int64_t ld_c, int32_t W, const float* d,
+                              int64_t ld_d, int32_t n_d, float* out, int64_t ld_out, int32_t B, dctr_stream_t stream) {
+  if (!out || B < 0 || W < 0 || n_d < 0 || ld_out < W + n_d || (n_d > 0 && !d)) return DCTR_EINVAL;
+  if (B == 0) return DCTR_OK;
+  if (W % 4 != 0 || ld_out % 4 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0) return DCTR_EALIGN;
+  if (a && (ld_a % 4 != 0 || reinterpret_cast<uintptr_t>(a) % 16 != 0 || ld_a < W)) return DCTR_EALIGN;
+  if (c && (ld_c % 4 != 0 || reinterpret_cast<uintptr_t>(c) % 16 != 0 || ld_c < W)) return DCTR_EALIGN;
+  const int64_t n = static_cast<int64_t>(B) * (ld_out / 4);
+  k_rows_join<<<dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(
+      a, ld_a, c, ld_c, W, d, ld_d, n_d, out, ld_out, B);
+  return launch_status();
+}
+
+extern "C" size_t dctr_relu_bwd_bias_workspace_floats(int32_t B, int32_t N) {
+  if (B <= 0 || N <= 0) return 0;
+  return static_cast<size_t>((B + kColRows - 1) / kColRows) * N;
+}
+
+extern "C" int dctr_relu_bwd_bias(const float* g, int64_t ld_g, const float* h, int64_t ld_h, int32_t B, int32_t N,
+                                  float* g_out, int64_t ld_o, float* g_bias, float* workspace, dctr_stream_t stream) {
+  if (!g || !g_bias || !workspace || B <= 0 || N <= 0 || ld_g < N || (h && ld_h < N) || (g_out && ld_o < N))
+    return DCTR_EINVAL;
+  const int groups = (B + kColRows - 1) / kColRows;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  k_relu_bwd_colsum<<<dim3(groups), dim3(256), 0, s>>>(g, ld_g, h, ld_h, B, N, g_out, ld_o, workspace);
+  const int st = launch_status();
+  if (st != DCTR_OK) return st;
+  k_colsum_finish<<<dim3((N + 255) / 256), dim3(256), 0, s>>>(workspace, groups, N, g_bias);
   return launch_status();
 }

@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdctr_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 
@@ -169,6 +169,9 @@ SIGNATURES = {
                                         _P]),
     "dctr_bce_head": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P]),
     "dctr_dense_opt": (ctypes.c_int, [_P, _P, _P, _I64, _I32, _F32, _F32, _P]),
+    "dctr_rows_join": (ctypes.c_int, [_P, _I64, _P, _I64, _I32, _P, _I64, _I32, _P, _I64, _I32, _P]),
+    "dctr_relu_bwd_bias_workspace_floats": (ctypes.c_size_t, [_I32, _I32]),
+    "dctr_relu_bwd_bias": (ctypes.c_int, [_P, _I64, _P, _I64, _I32, _I32, _P, _I64, _P, _P, _P]),
     "dctr_sizeof_dense_item": (ctypes.c_size_t, []),
     "dctr_dense_opt_multi": (ctypes.c_int, [ctypes.POINTER(DenseItem), _I32, _I32, _F32, _F32, _P]),
     "dctr_l2_value_multi": (ctypes.c_int, [ctypes.POINTER(DenseItem), _I32, _P, _P]),

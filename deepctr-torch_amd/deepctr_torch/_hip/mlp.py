@@ -258,17 +258,34 @@ class WideLinearFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, W, h = ctx.saved_tensors
-        if ctx.relu:
+        gb = None
+        if g.is_cuda and g.dtype == torch.float32 and ctx.has_bias and ctx.needs_input_grad[2] and g.dim() == 2 and \
+                g.stride(1) == 1 and os.environ.get("DCTR_GLUE_KERNELS", "1") != "0":
+            # relu's backward and the bias gradient's column sums in one pass (csrc/head.hip k_relu_bwd_colsum + the
+            # fixed-order finish) instead of threshold_backward + a two-stage ATen sum(0)
+            lib = L.lib()
+            B, N = g.shape
+            go = torch.empty((B, N), dtype=torch.float32, device=g.device) if ctx.relu else None
+            gb = torch.empty((N,), dtype=torch.float32, device=g.device)
+            ws = torch.empty((max(1, lib.dctr_relu_bwd_bias_workspace_floats(B, N)),), dtype=torch.float32, device=g.device)
+            L.check(lib.dctr_relu_bwd_bias(_ptr(g), g.stride(0), _ptr(h) if ctx.relu else None,
+                                           h.stride(0) if ctx.relu else 0, B, N, _ptr(go), N, _ptr(gb), _ptr(ws),
+                                           L.stream_handle(g.device)), "dctr_relu_bwd_bias")
+            if ctx.relu:
+                g = go
+            elif not g.is_contiguous():
+                g = g.contiguous()
+        elif ctx.relu:
             g = torch.ops.aten.threshold_backward(g, h, 0)     # (relu's own backward: one launch)
         elif not g.is_contiguous():
             g = g.contiguous()
-        gx = gW = gb = None
+        gx = gW = None
         with _TunedGemm():
             if ctx.needs_input_grad[0]:
                 gx = torch.mm(g, W)
             if ctx.needs_input_grad[1]:
                 gW = torch.mm(g.t(), x)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if gb is None and ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g.sum(0)
         return gx, gW, gb, None
 

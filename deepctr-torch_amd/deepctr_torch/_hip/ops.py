@@ -14,6 +14,7 @@ scatter executed inside ``EmbedFunction.backward``.  What that scatter does is s
 """
 import contextlib
 import ctypes
+import os
 
 import torch
 
@@ -323,6 +324,19 @@ class SplitGatheredFunction(torch.autograd.Function):
         B, ld, W, nd = ctx.dims
         ref = g_emb if g_emb is not None else g_dense
         g = torch.empty((B, ld), dtype=ref.dtype, device=ref.device)
+        if ref.is_cuda and ref.dtype == torch.float32 and W % 4 == 0 and ld % 4 == 0 and \
+                os.environ.get("DCTR_GLUE_KERNELS", "1") != "0":
+            # one launch (csrc/head.hip k_rows_join) instead of two copies and a fill
+            ge = g_emb.reshape(B, W) if g_emb is not None else None
+            if ge is not None and (ge.stride(1) != 1 or ge.stride(0) % 4 or ge.data_ptr() % 16):
+                ge = ge.contiguous()
+            gd = g_dense if (g_dense is not None and nd > 0) else None
+            if gd is not None and (gd.stride(1) != 1 or gd.dtype != torch.float32):
+                gd = gd.float().contiguous()
+            L.check(L.lib().dctr_rows_join(_ptr(ge), ge.stride(0) if ge is not None else 0, None, 0, W, _ptr(gd),
+                                           gd.stride(0) if gd is not None else 0, nd if gd is not None else 0, _ptr(g), ld,
+                                           B, L.stream_handle(ref.device)), "dctr_rows_join")
+            return g, None, None, None, None
         if g_emb is not None:
             g[:, :W].copy_(g_emb.reshape(B, W))
         else:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 18
+#define DCTR_ABI_VERSION 19
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -620,6 +620,19 @@ int dctr_shard_stage(const float* xb, int64_t ld_xb, const float* yb, int32_t B,
 int dctr_bce_head(const float* part0, const float* part1, const float* part2, const float* part3, const float* bias,
                   const float* y, int32_t B, float* y_pred, float* loss, float* g_logit, float* g_bias,
                   dctr_stream_t stream);
+
+/* ---- autograd glue as single launches (models on torch.autograd: xDeepFM, FiBiNET, DCN, PNN, ...) ------------------------
+ * dctr_rows_join: out[b, 0:W) = a[b, :] (+ c[b, :]), out[b, W:W+n_d) = d[b, :], out[b, W+n_d:ld_out) = 0 -- the gradient of
+ * the gather's output [B, ld_out] from the gradients of its two views (replaces the slice backward's copies + fill, and
+ * autograd's add when c is given; a, c, d nullable).  W, ld_* multiples of 4, 16-byte aligned rows.
+ * dctr_relu_bwd_bias: g_out = g * (h > 0) (aten::threshold_backward; h NULL: g_out = g; g_out NULL: not written) and
+ * g_bias[n] = sum_b g_out[b, n] in a fixed order (replaces threshold_backward + sum(0) behind a wide nn.Linear,
+ * layers/core.py:120-134).  workspace: dctr_relu_bwd_bias_workspace_floats(B, N) floats.                             */
+int dctr_rows_join(const float* a, int64_t ld_a, const float* c, int64_t ld_c, int32_t W, const float* d, int64_t ld_d,
+                   int32_t n_d, float* out, int64_t ld_out, int32_t B, dctr_stream_t stream);
+size_t dctr_relu_bwd_bias_workspace_floats(int32_t B, int32_t N);
+int dctr_relu_bwd_bias(const float* g, int64_t ld_g, const float* h, int64_t ld_h, int32_t B, int32_t N, float* g_out,
+                       int64_t ld_o, float* g_bias, float* workspace, dctr_stream_t stream);
 
 /* ---- dense optimizer over one flat parameter slab (torch.optim.SGD / Adagrad, basemodel.py:447-461) --------
  *   DCTR_UPD_SGD      p -= lr * g

@@ -76,3 +76,16 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "np_oracle" not in text and "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_cin_backward_workspace_covers_the_symmetric_layers_weight_staging():
+    """dctr_cin_layer_bwd stages the folded weight slices of the symmetric first layer ([tiles][ot * 32][32] floats,
+    k_cin_prep_wsym) in the caller's workspace before the partial sums go there: at small shapes that staging is the
+    larger of the two (round 4: 5 fields, 8 feature maps, 64 samples wrote 3072 floats into 832).  Host-side arithmetic
+    only -- callable without a GPU."""
+    from deepctr_torch._hip import lib as L
+    lib = L.lib()
+    for (B, M, D, O) in [(64, 5, 4, 8), (16, 2, 4, 1), (1, 3, 8, 200), (4096, 26, 16, 128), (7, 32, 16, 33)]:
+        ntiles = (M + 1) // 2 if M & 1 else (M + 1) // 2 + 1
+        ot = (min(O, 128) + 31) // 32
+        assert lib.dctr_cin_bwd_workspace_floats(B, M, M, D, O) >= ntiles * ot * 32 * 32, (B, M, D, O)

@@ -233,4 +233,5 @@ def test_gradients_match_reference_on_its_test_matrix(c):
             ref64 = c["grads64"][k]
             tol = max(tol, 4.0 * max_abs(ref, ref64))
             ref = ref64
-        assert max_abs(got, ref) <= tol, "%s: %.3e > %.3e" % (k, max_abs(got, ref), tol)
+        assert max_abs(got, ref) <= tol, "%s: %.3e > %.3e (grad is None: %s, requires_grad: %s, sparse update: %s)" % (
+            k, max_abs(got, ref), tol, p.grad is None, p.requires_grad, m.model_plan().update[0])
