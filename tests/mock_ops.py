@@ -110,6 +110,31 @@ class OpsMixin(object):
         _t(gE, B, F * D, ld_ge).copy_(g)
         return 0
 
+    # ---- autograd glue (csrc/head.hip: dctr_rows_join, dctr_relu_bwd_bias) ---------------------------------------------
+    def dctr_rows_join(self, a, ld_a, c, ld_c, W, d, ld_d, n_d, out, ld_out, B, stream):
+        self.calls.append("rows_join")
+        o = _t(out, B, ld_out)
+        o.zero_()
+        if a:
+            o[:, :W] += _t(a, B, W, ld_a)
+        if c:
+            o[:, :W] += _t(c, B, W, ld_c)
+        if d and n_d > 0:
+            o[:, W:W + n_d] = _t(d, B, n_d, ld_d)
+        return 0
+
+    def dctr_relu_bwd_bias_workspace_floats(self, B, N):
+        return 16
+
+    def dctr_relu_bwd_bias(self, g, ld_g, h, ld_h, B, N, g_out, ld_o, g_bias, ws, stream):
+        self.calls.append("relu_bwd_bias")
+        gv = _t(g, B, N, ld_g)
+        v = gv * (_t(h, B, N, ld_h) > 0) if h else gv
+        if g_out:
+            _t(g_out, B, N, ld_o).copy_(v)
+        _v(g_bias, N).copy_(v.sum(0))
+        return 0
+
     # ---- SENET ------------------------------------------------------------------------------------------------------
     @staticmethod
     def _senet(E, W1, W2):
