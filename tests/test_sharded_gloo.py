@@ -70,17 +70,20 @@ def _worker(rank, world, port, opt_name, out_dir):
             with torch.no_grad():
                 for p in m.parameters():
                     p.add_(0.01)
-        m.compile(opt_name, "binary_crossentropy", metrics=[])
+        m.compile(opt_name.split("+")[0], "binary_crossentropy", metrics=[])
         m.train()
         lay = ShardLayout(m.model_plan(), world, rank)
         tr = ShardedTrainer(m, ops=TorchShardOps(m, lay))
         assert tr.layout.n_slots == (F_ + world - 1) // world
         batches = [_batch(step, world) for step in range(4)]
         mine = [(Xg[rank * B_:(rank + 1) * B_].contiguous(), yg[rank * B_:(rank + 1) * B_].contiguous()) for Xg, yg in batches]
-        for step in range(4):
+        use_block = opt_name.endswith("+block")
+        for step in range(2 if use_block else 4):
             # steps 0 -> 1 and 2 -> 3 announce the next batch (ids ride in the gradient all-to-all); step 2 does not
             nxt = mine[step + 1][0] if step in (0, 2) else None
             tr.train_step(mine[step][0], mine[step][1], next_xb=nxt)
+        if use_block:     # steps 2 and 3 as ONE train_block call (without the direct exchange: the same two train_steps)
+            tr.train_block(torch.stack([mine[2][0], mine[3][0]]), torch.stack([mine[2][1], mine[3][1]]), next_first=None)
         tr.gather_tables()
         tr.close()
         torch.save({k: v.detach().clone() for k, v in m.state_dict().items()}, os.path.join(out_dir, "rank%d.pt" % rank))
@@ -91,8 +94,10 @@ def _worker(rank, world, port, opt_name, out_dir):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("opt_name", ["sgd", "adagrad"])
+@pytest.mark.parametrize("opt_name", ["sgd", "adagrad", "adagrad+block"])
 def test_sharded_training_equals_single_process_on_the_global_batch(tmp_path, opt_name, world):
+    if opt_name.endswith("+block") and world == 3:
+        pytest.skip("one train_block case is enough")
     port = _free_port()
     mp.spawn(_worker, args=(world, port, opt_name, str(tmp_path)), nprocs=world, join=True)
     ranks = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
@@ -107,7 +112,7 @@ def test_sharded_training_equals_single_process_on_the_global_batch(tmp_path, op
     init = torch.load(os.path.join(str(tmp_path), "init.pt"))
     ref = DeepFMPort(F_, V_, D_, ND_, hidden=(16, 8))
     ref.load_reference_state({k: v.numpy() for k, v in init.items()}, ["C%d" % i for i in range(F_)])
-    opt = (torch.optim.SGD(ref.parameters(), lr=0.01) if opt_name == "sgd" else torch.optim.Adagrad(ref.parameters()))
+    opt = (torch.optim.SGD(ref.parameters(), lr=0.01) if opt_name == "sgd" else torch.optim.Adagrad(ref.parameters()))   # ("adagrad+block": Adagrad)
     for step in range(4):
         Xg, yg = _batch(step, world)
         train_step(ref, opt, Xg, yg)
