@@ -39,10 +39,11 @@ class A:
     vocab, batch, optimizer = 1_000_000, 4096, "adagrad"
 
 
-for opt in ("adagrad", "sgd"):
+# (PMC_OPTS / PMC_BATCHES restrict the sweep: the bench line needs adagrad at 4096 only)
+for opt in os.environ.get("PMC_OPTS", "adagrad,sgd").split(","):
     A.optimizer = opt
     model = bench.build_model(A, dev)
-    for Bsz in (4096, 32768):
+    for Bsz in [int(b) for b in os.environ.get("PMC_BATCHES", "4096,32768").split(",")]:
         gen = torch.Generator().manual_seed(0)
         X = torch.cat([torch.randint(0, A.vocab, (8 * Bsz, 26), generator=gen).float(),
                        torch.rand(8 * Bsz, 13, generator=gen)], 1).to(dev)
