@@ -168,7 +168,7 @@ int dctr_embed_apply(const dctr_plan_t* plan, const float* X, int64_t ldx, int32
  *   g_wdense [plan.n_wdense] (nullable): when given, n_wdense extra workgroups also write the gradient of the dense
  *          half of Linear, g_wdense[j] = sum_b g_wide[b] * X[b, wdense_cols[j]] (basemodel.py:86-90), in a
  *          fixed order; X / ld_x are only read for this.  wdense_step (nullable): they also step Linear.weight.
- * dctr_embed_update_supported returns 1 when the plan / batch fit (B <= 32768, keys fit 32 bits).    */
+ * dctr_embed_update_supported returns 1 when the plan / batch fit (B <= 2^20, keys fit 32 bits).    */
 #define DCTR_UPD_SGD 0
 #define DCTR_UPD_ADAGRAD 1
 #define DCTR_UPD_ACCUM 2
