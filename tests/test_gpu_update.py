@@ -224,3 +224,45 @@ def test_prepass_layouts_and_inkernel_scan_agree_bit_for_bit(monkeypatch, idmode
     for other in results[1:]:
         for a, b in zip(results[0], other):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("idmode,B", [("uniform", 4096), ("zipf", 20000), ("hot", 40000)])
+def test_prepass_buckets_equal_the_numpy_statement(idmode, B):
+    """dctr_embed_ids + dctr_embed_segments against oracle/prepass_oracle.segments_direct: every (unit, partition)'s count and
+    its sorted keys, for the tag-scan path (B < 16 384) and the two-level path (k_prepass_bin + k_prepass_sort) alike."""
+    import ctypes
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    from prepass_oracle import segments_direct
+    from deepctr_torch._hip import lib as L
+    vocabs = [1000, 17, 100_000]
+    X = _batch(B, vocabs, 1, idmode, seed=23)
+    m = _model(len(vocabs), vocabs, 16, 1)
+    m.compile("adagrad", "binary_crossentropy")
+    plan = m.model_plan()
+    dev = torch.device(DEV)
+    cplan = plan.bind(dev)
+    lib = L.lib()
+    nu = len(plan.units)
+    P = int(lib.dctr_embed_update_partitions(cplan, B))
+    n_ws = int(lib.dctr_embed_update_workspace_ints(cplan, nu, B))
+    ws = torch.zeros(n_ws, dtype=torch.int32, device=dev)
+    ids_t = torch.empty(nu, B, dtype=torch.int32, device=dev)
+    parts_t = torch.empty(nu, B, dtype=torch.int16, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())      # noqa: E731
+    s = L.stream_handle(dev)
+    L.check(lib.dctr_embed_ids(cplan, plan.units_ptr(), nu, p(X), X.stride(0), B, p(ids_t), p(parts_t), s), "ids")
+    L.check(lib.dctr_embed_segments(cplan, plan.units_ptr(), nu, plan.max_vocab, p(ids_t), p(parts_t), B, p(ws), n_ws, s),
+            "segments")
+    torch.cuda.synchronize()
+    cnt = ws[:nu * P].cpu().numpy().reshape(nu, P)
+    keys = ws[nu * P:nu * P * 513].cpu().numpy().view(np.uint32).reshape(nu, P, 512)
+    Xc = X.cpu().numpy()
+    for u, (di, wi, col, _) in enumerate(plan.units):
+        vocab = plan.deep[di].vocab if di >= 0 else plan.wide[wi].vocab
+        c0, k0 = segments_direct(Xc[:, col].astype(np.int64), vocab, P)
+        assert np.array_equal(cnt[u], c0), u
+        for q in range(P):
+            if c0[q] <= 512:
+                assert np.array_equal(keys[u, q, :c0[q]], k0[q]), (u, q)
