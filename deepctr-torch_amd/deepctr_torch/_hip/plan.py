@@ -535,6 +535,8 @@ class EmbeddingPlan(object):
         # side stream while the update of step n-1 may still be reading its own on the main stream)
         key = (int(B), str(device)) if not slot else (int(B), str(device), int(slot))
         ws = self._upd_ws.get(key)
+        if ws is not None:
+            self._upd_ws[key] = self._upd_ws.pop(key)      # (least recently used goes first)
         if ws is None:
             n = int(L.lib().dctr_embed_update_workspace_ints(ctypes.byref(self.cplan), len(self.units), int(B)))
             ws = torch.zeros(max(n, 1), dtype=torch.int32, device=device)

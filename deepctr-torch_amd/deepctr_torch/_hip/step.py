@@ -46,7 +46,7 @@ def _r4(n):
 class _Buffers(object):
     """Everything one batch size needs, allocated once: activations, gradients, workspaces, the tower descriptor."""
     __slots__ = ("B", "out", "gx", "fm_s", "g_logit", "hs", "dhs", "ws", "ids_t", "parts_t", "desc", "upd_ws", "upd_n",
-                 "keep")
+                 "keep", "pinned")
 
 
 class GatherStep(object):
@@ -89,6 +89,7 @@ class GatherStep(object):
         key = (int(B), str(dev), plan.version)
         hit = self._bufs.get(key)
         if hit is not None:
+            self._bufs[key] = self._bufs.pop(key)      # (most recently used last)
             return hit if hit is not False else None
         lib = L.lib()
         b = _Buffers()
@@ -125,8 +126,17 @@ class GatherStep(object):
         b.parts_t = torch.empty((len(plan.units), B), dtype=torch.int16, device=dev)
         b.upd_ws, b.upd_n = plan.update_workspace(B, dev, always=True)
         b.keep = (Ws, gWs, gbs, g_wo)
+        b.pinned = False
+        # Least recently used goes first -- but never a set a hipGraph was captured on: the graph holds raw addresses of
+        # out / gx / hs / ws / ids_t / the update workspace and nothing else keeps them alive (a fit() over shards of many
+        # ragged tail sizes used to push the full-batch set out from under its still-replaying graph: round-4 advisor
+        # finding).  Pinned sets of an older plan version are dead (their graphs re-capture) and may go.
         if len(self._bufs) >= 8:
-            self._bufs.pop(next(iter(self._bufs)))
+            for k in list(self._bufs):
+                v = self._bufs[k]
+                if v is False or not v.pinned or k[2] != plan.version:
+                    self._bufs.pop(k)
+                    break
         self._bufs[key] = b
         return b
 
@@ -155,6 +165,8 @@ class GatherStep(object):
         cuda = dev.type == "cuda"
         B = xb.shape[0]
         b = self._buffers(B, dev)
+        if cuda and torch.cuda.is_current_stream_capturing():
+            b.pinned = True           # a graph now holds this set's addresses: exempt from eviction
         cplan = plan.bind(dev)
         y = yb.reshape(-1)
         if y.dtype != torch.float32 or not y.is_contiguous():

@@ -654,6 +654,9 @@ class BaseModel(nn.Module):
         if torch.is_tensor(x) and x.dim() == 2:
             # (beyond the reference: a dataset that already is one [N, sum(widths)] matrix -- on the device it is used in
             # place, nothing is concatenated or uploaded again by every fit / predict call)
+            need = max([hi for (_, hi) in self.feature_index.values()] + [0])
+            if x.shape[1] < need:
+                raise ValueError("the input matrix has %d columns, the feature columns need %d" % (x.shape[1], need))
             return x.to(self.device).float()
         if isinstance(x, dict):
             x = [x[feature] for feature in self.feature_index]
@@ -1181,9 +1184,14 @@ class BaseModel(nn.Module):
                 val_x = [val_x[feature] for feature in self.feature_index]
         elif validation_split and 0. < validation_split < 1.:
             do_validation = True
-            n0 = x[0].shape[0] if hasattr(x[0], 'shape') else len(x[0])
-            split_at = int(n0 * (1. - validation_split))
-            x, val_x = slice_arrays(x, 0, split_at), slice_arrays(x, split_at)
+            if torch.is_tensor(x) and x.dim() == 2:
+                # a resident [N, sum(widths)] matrix (see _as_matrix): split its ROWS (x[0] is a row here, not a feature)
+                split_at = int(x.shape[0] * (1. - validation_split))
+                x, val_x = x[:split_at], x[split_at:]
+            else:
+                n0 = x[0].shape[0] if hasattr(x[0], 'shape') else len(x[0])
+                split_at = int(n0 * (1. - validation_split))
+                x, val_x = slice_arrays(x, 0, split_at), slice_arrays(x, split_at)
             y, val_y = slice_arrays(y, 0, split_at), slice_arrays(y, split_at)
 
         self._sync_optimizer_hyper()

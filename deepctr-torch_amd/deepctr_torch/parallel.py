@@ -768,6 +768,11 @@ class ShardedTrainer(object):
         lay, dev, B = self.layout, xb.device, xb.shape[0]
         self._shape = (tuple(xb.shape), tuple(yb.shape))
         self._x, self._y = torch.empty_like(xb), torch.empty_like(yb)
+        # captured direct-exchange segments hold the raw addresses of the staging tensors just replaced (same B, another
+        # y shape: round-4 advisor finding) -- they are rebuilt with the new ones
+        if getattr(self, "_dx", None) is not None:
+            self._direct_seg = _Segment(self._direct_body, bool(self.use_graphs))
+        self._blk = None
         self._ids_next = torch.zeros((lay.world, B, lay.n_slots), dtype=torch.float32, device=dev)
         self._ids_tmp = torch.empty((lay.world, B, lay.n_slots), dtype=torch.float32, device=dev)
         self._recv = torch.empty((lay.world * B, lay.ldc), dtype=torch.float32, device=dev)
