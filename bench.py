@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the xDeepFM / FiBiNET legs (BASELINE.json configs 3-4) of the N=1 line")
     ap.add_argument("--force-parallel", action="store_true", help="use the data-parallel trainer even with 1 rank")
+    ap.add_argument("--no-saturating", action="store_true", help="skip the saturating-launch leg (B_eff 262 144)")
     ap.add_argument("--exchange", default=os.environ.get("DCTR_SHARDED_EXCHANGE", "auto"),
                     choices=["auto", "rccl", "direct", "try-direct"],
                     help="how the table-sharded step exchanges rows / gradients / dense gradients between ranks: 'rccl' = "
@@ -198,17 +199,23 @@ def time_update_in_step(model, X, y, B, n=80):
         return None
     nb = X.shape[0] // B
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    evt = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     try:
         for i in range(n):
             eng.timing = evs[i]
+            eng.timing_tower = evt[i]
             j = i % nb
             model._train_step(X[j * B:(j + 1) * B], y[j * B:(j + 1) * B])
     finally:
         eng.timing = None
+        eng.timing_tower = None
     torch.cuda.synchronize()
     ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs[n // 4:])      # us; the first quarter warms up
+    tt = sorted(a.elapsed_time(b) * 1e3 for a, b in evt[n // 4:])
     return {"avg_us": sum(ts) / len(ts), "median_us": ts[len(ts) // 2], "min_us": ts[0], "launches": len(ts),
-            "how": "HIP events on the update's queue around dctr_embed_update in eager two-queue train steps"}
+            "how": "HIP events on the update's queue around dctr_embed_update in eager two-queue train steps",
+            "tower": {"avg_us": sum(tt) / len(tt), "median_us": tt[len(tt) // 2], "min_us": tt[0], "launches": len(tt),
+                      "how": "HIP events on the main queue around dctr_embed_tower_train_step in the same eager steps"}}
 
 
 def saturating_launch(args, model, device, B_sat=262144):
@@ -301,27 +308,44 @@ def reference_cpu_baseline(args):
     ref_root = tempfile.mkdtemp(prefix="dctr_ref_")
     with tarfile.open(arc) as tf:
         tf.extractall(ref_root)
+    def run(extra, steps, threads):
+        cmd = [sys.executable, os.path.join(ROOT, "oracle", "time_reference.py"), "--reference-root", ref_root,
+               "--batch", str(args.batch), "--vocab", str(args.vocab), "--steps", str(steps), "--threads", str(threads),
+               "--json"] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+    # Thread sweep (round-4 verdict: torch's default of one thread per logical cpu OVERSUBSCRIBES this workload -- 128
+    # threads: 1 646 samples/s; the survey's 8 threads: 4 781): the like-for-like variant at 8 ... ncpu threads, 3 timed
+    # steps each; the best count then runs every variant with the full step count.  `value` is the BEST the host gives.
+    ncpu = os.cpu_count() or 1
+    like_extra = ["--optimizer", args.optimizer, "--l2", "0"]
+    sweep = {}
+    try:
+        for th in [t for t in (8, 16, 32, 64, 128) if t <= ncpu] or [ncpu]:
+            sweep[th] = run(like_extra, 3, th)["value"]
+        best = max(sweep, key=sweep.get)
+    except Exception as exc:
+        print("reference cpu_baseline thread sweep failed: %s" % exc, file=sys.stderr)
+        return None
     variants = {}
-    for tag, extra, steps in (("like_for_like_l2_0_%s" % args.optimizer, ["--optimizer", args.optimizer, "--l2", "0"],
-                               args.cpu_steps),
+    for tag, extra, steps in (("like_for_like_l2_0_%s" % args.optimizer, like_extra, args.cpu_steps),
                               ("forward_only", ["--forward-only"], 4 * args.cpu_steps),
                               ("reference_defaults_l2_1e-5_adam", ["--optimizer", "adam", "--l2", "1e-5"],
                                max(2, args.cpu_steps // 3))):
-        cmd = [sys.executable, os.path.join(ROOT, "oracle", "time_reference.py"), "--reference-root", ref_root,
-               "--batch", str(args.batch), "--vocab", str(args.vocab), "--steps", str(steps), "--json"] + extra
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-            line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-            variants[tag] = json.loads(line)
+            variants[tag] = run(extra, steps, best)
         except Exception as exc:
             print("reference cpu_baseline leg %s failed: %s" % (tag, exc), file=sys.stderr)
             return None
     like = variants["like_for_like_l2_0_%s" % args.optimizer]
-    return {"value": like["value"], "unit": "samples/s", "cores": like.get("threads", torch.get_num_threads()),
+    return {"value": like["value"], "unit": "samples/s", "cores": like.get("threads", best), "threads": best,
+            "thread_sweep_samples_per_s": {str(k): v for k, v in sorted(sweep.items())},
             "kind": "reference",
             "sample": "%d train steps (after 2 warm-up) of the UNMODIFIED reference (unpacked from oracle/_ref/, timed as "
-                      "basemodel.py:242-262) on the same DeepFM/batch=%d/vocab=%d workload, %s, l2=0; host has %d logical "
-                      "cpus" % (like["steps"], args.batch, args.vocab, args.optimizer, os.cpu_count() or 0),
+                      "basemodel.py:242-262) on the same DeepFM/batch=%d/vocab=%d workload, %s, l2=0, at the best thread "
+                      "count of a sweep (%d of %d logical cpus)" % (like["steps"], args.batch, args.vocab, args.optimizer,
+                                                                     best, ncpu),
             "ms_per_step": like["ms_per_step"], "variants": variants}
 
 
@@ -505,6 +529,77 @@ def build_other(name, args, device):
     return model
 
 
+def deepfm_leg(tag, args, device, X, y):
+    """DeepFM legs beside the headline, same timed protocol (hipGraph replays, median block):
+      default_kwargs  the reference's DEFAULT kwargs -- l2_reg_embedding = l2_reg_linear = 1e-5 (deepfm.py:41) and
+                      compile('adam') (the reference's tests/utils.py:157) -- on the exact lazy update (csrc/lazy.hip)
+      deepfm_varlen   the headline's 26 + 13 columns plus ONE pooled history (VarLenSparseFeat, maxlen 8, mean, ids != 0 mask,
+                      its own 1M-row table on the deep and the wide side): the north_star's "EmbeddingBag backward"
+    """
+    from deepctr_torch.inputs import DenseFeat, SparseFeat, VarLenSparseFeat
+    from deepctr_torch.models import DeepFM
+    try:
+        cols = [SparseFeat("C%d" % (i + 1), args.vocab, DIM) for i in range(F_SPARSE)]
+        Xl, opt, l2 = X, args.optimizer, 0.0
+        if tag == "default_kwargs":
+            opt, l2 = "adam", 1e-5
+            workload = "DeepFM synthetic Criteo, the reference's default kwargs: l2_reg_embedding = l2_reg_linear = 1e-5, adam"
+        else:
+            T = 8
+            cols = cols + [VarLenSparseFeat(SparseFeat("hist", args.vocab, DIM), maxlen=T, combiner="mean")]
+            gen = torch.Generator().manual_seed(77)
+            n = X.shape[0]
+            hist = torch.randint(1, args.vocab, (n, T), generator=gen)
+            length = torch.randint(1, T + 1, (n, 1), generator=gen)
+            hist = hist * (torch.arange(T).unsqueeze(0) < length)            # padded with id 0 (the mask, inputs.py:146)
+            # column order of build_input_features (inputs.py:99-123): sparse, dense, then the VarLen positions
+            Xl = torch.cat([X, hist.float().to(X.device)], dim=1).contiguous()
+            workload = "DeepFM synthetic Criteo + one pooled history (VarLenSparseFeat maxlen 8, mean, mean length 4.5)"
+        cols = cols[:F_SPARSE] + [DenseFeat("I%d" % (i + 1), 1) for i in range(N_DENSE)] + cols[F_SPARSE:]
+        model = DeepFM(cols, cols, dnn_hidden_units=(256, 128), l2_reg_linear=l2, l2_reg_embedding=l2, dnn_dropout=0,
+                       seed=1024, device=device)
+        model.compile(opt, "binary_crossentropy", metrics=[])
+        model.train()
+        elapsed, out, graphed, did, _, times = time_steps(model, Xl, y, args.batch, args.steps, args.warmup,
+                                                          args.steps_per_graph, not args.no_graph, args.repeats,
+                                                          args.warmup_seconds)
+        model.model_plan().check_ids()
+        st = model._fused_step_state()
+        plan = model.model_plan()
+        res = {"workload": workload + ", batch=%d, fwd+bwd+%s" % (args.batch, opt), "value": args.batch * args.steps / elapsed,
+               "unit": "samples/s", "ms_per_step": elapsed / args.steps * 1e3, "steps": args.steps, "warmup": did,
+               "hip_graph": graphed, "final_loss": float(out[0].item()), "timing": spread(times, args.steps),
+               "update_mode": plan.update[0], "unit_path": bool(plan.unit_path),
+               "step_engine": bool(st is not None and st.get("engine") is not None)}
+        del model, Xl
+        torch.cuda.empty_cache()
+        return res
+    except Exception as exc:
+        torch.cuda.synchronize()
+        return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+
+
+def sharded_1rank(args):
+    """The table-sharded step (ShardedTrainer, direct exchange, S steps per hipGraph) at ONE rank, as a child process of
+    this very script (`--force-parallel`): every exchange executes (posts and waits on this rank's own arrival words), so the
+    line prices the sharded step's launches and boundaries while no multi-GPU node times the real thing."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-parallel", "--exchange", "direct",
+           "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-other-configs", "--no-cpu-baseline",
+           "--batch", str(args.batch), "--vocab", str(args.vocab), "--optimizer", args.optimizer, "--kernel-iters", "2",
+           "--no-saturating"]
+    env = dict(os.environ, MASTER_PORT=str(29600 + os.getpid() % 300), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        return {"workload": d["config"]["workload"], "parallelism": d["config"]["parallelism"], "value": d["value"],
+                "unit": "samples/s", "ms_per_step": d["ms_per_step"], "steps": d["steps"], "timing": d["timing"],
+                "exchange": d["config"].get("exchange"), "steps_per_graph": d["config"].get("steps_per_graph"),
+                "final_loss": d["final_loss"]}
+    except Exception as exc:
+        return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+
+
 def other_config(name, args, device, X, y):
     """One more bench leg at N = 1: the same timed protocol on another model of BASELINE.json; MFMA-bound, so its
     roofline is algorithmic FLOP / (time x dense fp32 MFMA peak)."""
@@ -640,6 +735,7 @@ def main():
         # collectives is captured as hipGraph segments after a few eager steps
         from deepctr_torch import parallel as par
         exchange = args.exchange
+        exch_info = {"requested": args.exchange, "self_check": None}
         if exchange == "auto":
             exchange = "direct" if (on_gpu and world == 1) else "rccl"
         elif exchange == "try-direct":
@@ -666,6 +762,12 @@ def main():
             flag = torch.tensor([ok], device=device, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             exchange = "direct" if int(flag.item()) == 1 else "rccl"
+            exch_info["self_check"] = "passed on every rank" if exchange == "direct" else "failed on at least one rank"
+            exch_info["self_check_this_rank"] = bool(ok)
+        exch_info["ran"] = exchange
+        if rank == 0:     # which exchange the timed steps use, said BEFORE they run (stderr: stdout carries the JSON line)
+            print("bench: sharded step over the %s exchange (requested %s; direct-exchange self-check: %s)" % (
+                exchange, args.exchange, exch_info["self_check"] or "not run"), file=sys.stderr, flush=True)
         parallel = par.ShardedTrainer(model, use_graphs=False, exchange=exchange)
 
         def batch(i):
@@ -779,9 +881,29 @@ def main():
         traffic = pmc_traffic(dom, args.optimizer, B)
         dom_us = in_step["avg_us"] if in_step else kern[dom]["avg_us"]
         dom_gbs = alg[dom] / (dom_us * 1e-6) / 1e9
-        sat = saturating_launch(args, model, device) if (world == 1 and args.vocab >= 100000) else None
+        sat = saturating_launch(args, model, device) if (world == 1 and args.vocab >= 100000 and
+                                                         not args.no_saturating) else None
         hot_us = sum(v["avg_us"] for v in kern.values())
         step_alg = sum(alg[k] for k in kern)
+        # SURVEY.md 8(d)'s own per-sample figures: the whole train step (rows + ids + labels + dense parameters; Adagrad
+        # adds the state's read + write) and the update proper (row + state, read + write) -- next to the per-kernel count
+        # above, which also charges the re-read of the [B, ld] gradient strips, fm_s and the sorted keys
+        rows_b = F_SPARSE * DIM * 4 + F_SPARSE * 4                                   # 1768 B: one deep + one wide row per field
+        step_8d = (2 * rows_b + (F_SPARSE + N_DENSE) * 4 + 8 + 279) + (2 * rows_b if args.optimizer == "adagrad" else 0)
+        upd_8d = (4 if args.optimizer == "adagrad" else 2) * rows_b
+        # the tower launch (gather + tower forward + head + backward-data) is the step's LONGEST kernel and MFMA-bound:
+        # forward + backward-data = 2 x 2 x (429 x 256 + 256 x 128 + 128) flop per sample
+        k0 = F_SPARSE * DIM + N_DENSE
+        tower_flop = 2 * 2 * (k0 * 256 + 256 * 128 + 128) * B
+        tower = (in_step or {}).get("tower")
+        dominant = None
+        if tower:
+            tf = tower_flop / (tower["avg_us"] * 1e-6) / 1e12
+            dominant = {"kernel": "embed_tower_train", "bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS, "avg_us": tower["avg_us"],
+                        "flop_per_launch": tower_flop, "timed": "in step", "detail": tower,
+                        "note": "the step's longest launch (gather of the tile's rows + tower forward + head + BCE + "
+                                "backward-data); the HBM-bound kernel the roofline object describes is the second longest"}
         result = {
             "metric": "training samples/sec DeepFM Criteo batch=4096", "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -792,16 +914,24 @@ def main():
                        "global_batch": world * B, "parallelism": ("tables sharded x%d + dp%d tower, %s exchange" % (world, world, parallel.exchange)) if parallel is not None else "single",
                        "hip_graph": bool(graphed), "steps_per_graph": (min(args.steps_per_graph, args.steps) if graphed and parallel is None else (S_blk or None) if graphed else None),
                        "eager_steps_in_timed_region": 0 if graphed else args.steps,
-                       "warmup_steps_run": did_warm, "optimizer": args.optimizer},
+                       "warmup_steps_run": did_warm, "optimizer": args.optimizer,
+                       "exchange": exch_info if parallel is not None else None},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": dom_gbs / HBM_PEAK_GBS,
                          "traffic": (traffic or {}).get("bytes"), "traffic_detail": traffic,
                          "alg_bytes_per_launch": alg[dom], "avg_us": dom_us,
+                         "alg_bytes_per_sample": alg[dom] / B,
+                         "alg_bytes_per_sample_8d": upd_8d if dom == "embed_update" else None,
+                         "frac_8d": (upd_8d * B / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if dom == "embed_update" else None,
+                         "dominant": dominant,
+                         "whole_step_frac_8d": value / world * step_8d / 1e9 / HBM_PEAK_GBS,
+                         "whole_step_bytes_per_sample_8d": step_8d,
                          "timed": "in step" if in_step else "stand-alone", "in_step": in_step,
                          "standalone_avg_us": kern[dom]["avg_us"], "standalone_frac": kern[dom]["gbs"] / HBM_PEAK_GBS},
             "hot_path": {"kernels": kern, "sum_us": hot_us, "saturating": sat,
                          "frac_of_hbm_peak": step_alg / (hot_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                         "whole_step_frac_of_hbm_peak": step_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "whole_step_frac_of_hbm_peak_kernel_bytes": step_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "whole_step_frac_8d": value / world * step_8d / 1e9 / HBM_PEAK_GBS},
             "final_loss": last_loss,
             "timing": dict(spread(times, args.steps), warmup_seconds=args.warmup_seconds,
                            protocol="value / ms_per_step = the median of `blocks` timed blocks of exactly `steps` steps"),
@@ -810,7 +940,13 @@ def main():
             del model
             torch.cuda.empty_cache()
             result["other_configs"] = {name: other_config(name, args, device, X, y) for name in OTHER}
+            for tag in ("deepfm_varlen", "default_kwargs"):
+                result["other_configs"][tag] = deepfm_leg(tag, args, device, X, y)
+                if "ms_per_step" in result["other_configs"][tag]:
+                    result["other_configs"][tag]["ms_per_step_vs_headline"] = result["other_configs"][tag]["ms_per_step"] / ms
             result["other_configs"]["fit_api"] = fit_api(args, device, X, y)
+            if parallel is None:
+                result["other_configs"]["sharded_1rank"] = sharded_1rank(args)
             fa = result["other_configs"]["fit_api"]
             if "value" in fa:
                 fa["vs_step_runner"] = fa["value"] / value

@@ -7,6 +7,9 @@ extern "C" int dctr_abi_version(void) { return DCTR_ABI_VERSION; }
 
 extern "C" size_t dctr_sizeof_field(void) { return sizeof(dctr_field_t); }
 extern "C" size_t dctr_sizeof_plan(void) { return sizeof(dctr_plan_t); }
+extern "C" size_t dctr_sizeof_uslot(void) { return sizeof(dctr_uslot_t); }
+extern "C" size_t dctr_sizeof_vunit(void) { return sizeof(dctr_vunit_t); }
+extern "C" size_t dctr_sizeof_plan_ext(void) { return sizeof(dctr_plan_ext_t); }
 extern "C" size_t dctr_sizeof_mlp(void) { return sizeof(dctr_mlp_t); }
 extern "C" size_t dctr_sizeof_dense_step(void) { return sizeof(dctr_dense_step_t); }
 extern "C" size_t dctr_sizeof_dense_item(void) { return sizeof(dctr_dense_item_t); }

@@ -26,7 +26,7 @@ constexpr int kNW = 4;  // waves per workgroup
 constexpr int kThreads = kNW * kWave;
 constexpr int kFieldWords = sizeof(dctr_field_t) / 4;
 static_assert(sizeof(dctr_field_t) == 64, "dctr_field_t must be 64 bytes");
-static_assert(sizeof(dctr_plan_t) == 112, "dctr_plan_t layout changed: update the Python binding");
+static_assert(sizeof(dctr_plan_t) == 120, "dctr_plan_t layout changed: update the Python binding");
 
 struct Tile {
   const dctr_field_t* deep;
@@ -86,14 +86,20 @@ __device__ __forceinline__ int64_t checked(int64_t id, int64_t vocab, int& bad) 
 //   mask mode   (len_col < 0): m_t = (id_t != 0); length = sum_t m_t
 //   length mode (len_col >= 0): m_t = (t < length)
 //   sum : sum_t m_t e_t        mean: that / (length + 1e-8)        max: max_t (e_t - (1 - m_t) * 1e9)
+//   am (nullable; max pooling): this sample's arg-max bytes of the field at e0 -- the position of the FIRST maximum per
+//   element (torch.max's backward routes the gradient there), the side output dctr_embed_update reads
 template <int VEC>
 __device__ __forceinline__ Strip<VEC> pool_field(const dctr_field_t& fd, const float* xr, int e0,
-                                                 bool act, int& bad) {
+                                                 bool act, int& bad, uint8_t* am = nullptr) {
   const bool by_len = fd.len_col >= 0;
   const int64_t len_i = by_len ? raw_id(xr, fd.len_col) : 0;
   Strip<VEC> acc;
+  int arg[VEC];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) acc.v[i] = (fd.pool == DCTR_POOL_MAX) ? -INFINITY : 0.f;
+  for (int i = 0; i < VEC; ++i) {
+    acc.v[i] = (fd.pool == DCTR_POOL_MAX) ? -INFINITY : 0.f;
+    arg[i] = 0;
+  }
   float cnt = 0.f;
   for (int t = 0; t < fd.len; ++t) {
     const int64_t rid = raw_id(xr, fd.col + t);
@@ -105,6 +111,7 @@ __device__ __forceinline__ Strip<VEC> pool_field(const dctr_field_t& fd, const f
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         const float v = row.v[i] - pen;
+        arg[i] = (v > acc.v[i]) ? t : arg[i];
         acc.v[i] = (v > acc.v[i]) ? v : acc.v[i];
       }
     } else if (m) {
@@ -117,6 +124,10 @@ __device__ __forceinline__ Strip<VEC> pool_field(const dctr_field_t& fd, const f
     const float den = (by_len ? static_cast<float>(len_i) : cnt) + 1e-8f;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc.v[i] = acc.v[i] / den;
+  }
+  if (am && act && fd.pool == DCTR_POOL_MAX) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) *(DCTR_GLOBAL uint8_t*)(am + i) = static_cast<uint8_t>(arg[i]);
   }
   return acc;
 }
@@ -143,7 +154,10 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
                                                         const int32_t* __restrict__ units, int n_units,
                                                         int32_t* __restrict__ ids_t,
                                                         uint16_t* __restrict__ parts_t, int n_parts,
-                                                        float* __restrict__ fm_s, int64_t lds_, int stage_off) {
+                                                        float* __restrict__ fm_s, int64_t lds_, int stage_off,
+                                                        uint8_t* __restrict__ amax, int64_t ld_am,
+                                                        const int32_t* __restrict__ am_deep_off,
+                                                        const int32_t* __restrict__ am_wide_off) {
   // No fused multiply-adds in this body: the fused train launch (csrc/mlp.hip, dctr_embed_tower_train_step) computes the
   // same linear logit / FM term / sum_f e inside the tower kernel and must land on the same bits -- with contraction left
   // to the compiler the two bodies were contracted differently (round 4: losses equal for 30 steps, then off by one ulp).
@@ -254,7 +268,12 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
     for (int f = P.n_deep_fixed + wv_id; f < P.n_deep; f += kNW) {
       const dctr_field_t& fd = T.deep[f];
       const bool act = e0 < fd.dim;
-      const Strip<VEC> p = pool_field<VEC>(fd, xr, e0, act, bad);
+      uint8_t* am = nullptr;
+      if (amax && valid && fd.pool == DCTR_POOL_MAX) {
+        const int off = ldg_i32(am_deep_off + f);
+        if (off >= 0) am = amax + static_cast<int64_t>(b) * ld_am + off + e0;
+      }
+      const Strip<VEC> p = pool_field<VEC>(fd, xr, e0, act, bad, am);
       if (act) {
         if (valid) {
           if (staged) strip_put<VEC>(lrow + fd.out_off + e0, p);
@@ -285,7 +304,12 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
     }
     for (int f = P.n_wide_fixed + wv_id * LPR + gl; f < P.n_wide; f += kNW * LPR) {  // pooled VarLen
       const dctr_field_t& fd = T.wide[f];
-      ws += pool_field<1>(fd, xr, 0, true, bad).v[0];
+      uint8_t* am = nullptr;
+      if (amax && valid && fd.pool == DCTR_POOL_MAX) {
+        const int off = ldg_i32(am_wide_off + f);
+        if (off >= 0) am = amax + static_cast<int64_t>(b) * ld_am + off;
+      }
+      ws += pool_field<1>(fd, xr, 0, true, bad, am).v[0];
     }
     if (P.wdense_w)
       for (int j = wv_id * LPR + gl; j < P.n_wdense; j += kNW * LPR)
@@ -653,9 +677,15 @@ extern "C" int dctr_embed_fwd(const dctr_plan_t* plan, const float* X, int64_t l
   }
   const dim3 grid((B + spb - 1) / spb), block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // general update units (dctr_plan_ext_t): the ids / tags side outputs come from dctr_embed_ids (a unit spans several X
+  // columns); what the forward contributes is the arg-max side output of max-pooled fields
+  const dctr_plan_ext_t* x = plan->ext;
+  if (x && ids_t) return DCTR_EINVAL;
+  if (x && x->amax && (x->ld_amax <= 0 || !x->am_deep_off || !x->am_wide_off)) return DCTR_EINVAL;
   DCTR_DISPATCH(vec, lpr, DCTR_LAUNCH((k_embed_fwd<VEC, LPR>), grid, block, lds, s, *plan, X, ldx, B, out, ld_out,
                                       wide, ld_wide, fm, err, units, n_units, ids_t, parts_t, n_parts, fm_s, ld_s,
-                                      stage_off));
+                                      stage_off, x ? x->amax : nullptr, x ? x->ld_amax : 0,
+                                      x ? x->am_deep_off : nullptr, x ? x->am_wide_off : nullptr));
   return launch_status();
 }
 

@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdctr_hip.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 
@@ -32,7 +32,33 @@ class Plan(ctypes.Structure):
                 ("emb_dim", ctypes.c_int32), ("n_xcols", ctypes.c_int32), ("n_wide_fixed", ctypes.c_int32),
                 ("max_dim", ctypes.c_int32), ("vec", ctypes.c_int32), ("flags", ctypes.c_int32),
                 ("step_sync", ctypes.c_void_p), ("out_chunks", ctypes.c_void_p), ("chunk_rows", ctypes.c_int32),
-                ("pad_", ctypes.c_int32)]
+                ("pad_", ctypes.c_int32), ("ext", ctypes.c_void_p)]
+
+
+class USlot(ctypes.Structure):
+    """``dctr_uslot_t`` (include/dctr.h): one X column feeding one general update unit -- 48 bytes."""
+    _fields_ = [("col", ctypes.c_int32), ("goff", ctypes.c_int32), ("wide", ctypes.c_int32), ("pool", ctypes.c_int32),
+                ("t", ctypes.c_int32), ("len", ctypes.c_int32), ("len_col", ctypes.c_int32), ("den", ctypes.c_int32),
+                ("am_deep", ctypes.c_int32), ("am_wide", ctypes.c_int32), ("vu0", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
+class VUnit(ctypes.Structure):
+    """``dctr_vunit_t``: (unit, group of P partitions) -- 40 bytes."""
+    _fields_ = [("di", ctypes.c_int32), ("wi", ctypes.c_int32), ("c0", ctypes.c_int32), ("n_slots", ctypes.c_int32),
+                ("k", ctypes.c_int32), ("j", ctypes.c_int32), ("kshift", ctypes.c_int32), ("pad_", ctypes.c_int32),
+                ("kmagic", ctypes.c_uint64)]
+
+
+class PlanExt(ctypes.Structure):
+    """``dctr_plan_ext_t``: general update units of a plan (pooled VarLen fields, shared tables) + per-step side buffers."""
+    _fields_ = [("slots", ctypes.c_void_p), ("vunits", ctypes.c_void_p), ("am_deep_off", ctypes.c_void_p),
+                ("am_wide_off", ctypes.c_void_p), ("h_vunits", ctypes.c_void_p), ("h_vocab", ctypes.c_void_p),
+                ("den_t", ctypes.c_void_p), ("amax", ctypes.c_void_p),
+                ("n_vcols", ctypes.c_int32), ("n_vunits", ctypes.c_int32), ("n_units", ctypes.c_int32),
+                ("max_unit_slots", ctypes.c_int32), ("n_den", ctypes.c_int32), ("ld_amax", ctypes.c_int32)]
+
+
+MAX_UNIT_SLOTS = 128
 
 
 MLP_MAX_LAYERS = 12
@@ -97,6 +123,9 @@ SIGNATURES = {
     "dctr_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "dctr_sizeof_field": (ctypes.c_size_t, []),
     "dctr_sizeof_plan": (ctypes.c_size_t, []),
+    "dctr_sizeof_uslot": (ctypes.c_size_t, []),
+    "dctr_sizeof_vunit": (ctypes.c_size_t, []),
+    "dctr_sizeof_plan_ext": (ctypes.c_size_t, []),
     "dctr_embed_fwd": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P, _P, _I32, _P,
                                       _P, _P, _I64, _P]),
     "dctr_embed_update_supported": (ctypes.c_int, [ctypes.POINTER(Plan), _I64, _I32]),
@@ -239,6 +268,9 @@ def lib():
             raise RuntimeError("libdctr_hip.so ABI %d != binding ABI %d" % (handle.dctr_abi_version(), ABI_VERSION))
         if handle.dctr_sizeof_field() != ctypes.sizeof(Field) or handle.dctr_sizeof_plan() != ctypes.sizeof(Plan) \
                 or handle.dctr_sizeof_mlp() != ctypes.sizeof(Mlp) \
+                or handle.dctr_sizeof_uslot() != ctypes.sizeof(USlot) \
+                or handle.dctr_sizeof_vunit() != ctypes.sizeof(VUnit) \
+                or handle.dctr_sizeof_plan_ext() != ctypes.sizeof(PlanExt) \
                 or handle.dctr_sizeof_lazy_unit() != ctypes.sizeof(LazyUnit) \
                 or handle.dctr_sizeof_dense_step() != ctypes.sizeof(DenseStep) \
                 or handle.dctr_sizeof_dense_item() != ctypes.sizeof(DenseItem):

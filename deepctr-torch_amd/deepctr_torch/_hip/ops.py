@@ -71,15 +71,19 @@ class EmbedFunction(torch.autograd.Function):
             else:
                 lazy.flush()
         # side outputs for the deterministic fused update (only when a backward can follow)
-        ids_t = parts_t = fm_s = None
+        ids_t = parts_t = fm_s = den_t = amax = None
         ld_s = 0
         if for_backward and plan.table_params and plan.update_kernel_ok(B):
-            ids_t = torch.empty((len(plan.units), B), dtype=torch.int32, device=X.device)
+            ids_t = torch.empty((plan.n_vcols, B), dtype=torch.int32, device=X.device)
             # each entry's partition of the update kernel (a 16-bit tag: its workgroups compare instead of dividing)
-            parts_t = torch.empty((len(plan.units), B), dtype=torch.int16, device=X.device)
+            parts_t = torch.empty((plan.n_vcols, B), dtype=torch.int16, device=X.device)
             if want_fm:
                 ld_s = (plan.emb_dim + 3) // 4 * 4
                 fm_s = torch.empty((B, ld_s), dtype=torch.float32, device=X.device)
+            # general units (pooled VarLen fields, shared tables): mean pooling's divisors (written with the ids) and
+            # max pooling's arg-max positions (written by the gather) are this step's side buffers
+            den_t, amax = plan.step_buffers(B, X.device)
+        plan.point_step_buffers(den_t, amax)
         # The part of the update that needs only the ids -- finding and sorting every partition's entries -- runs on a
         # side stream, under the tower.  In the fused train step with in-kernel optimizer that stream also computes the
         # ids itself (from X, ahead of the gather) and later runs the update: its chain then waits for the main
@@ -94,13 +98,17 @@ class EmbedFunction(torch.autograd.Function):
             # signal: the step's sync block (dense.DenseSlab.sync_block) -- the gather stores its outputs write-through
             # and signals DCTR_SYNC_GATHER; the tower's stream waits for that with dctr_step_wait, not for an event
             plan.cplan.step_sync = signal.data_ptr() if signal is not None else None
+            fused_ids = with_ids and plan.gen is None      # (a general unit spans several X columns: dctr_embed_ids)
             try:
                 L.check(lib.dctr_embed_fwd(cplan, _ptr(X), X.stride(0), B, _ptr(out), plan.ld_out, _ptr(wide), 1,
-                                           _ptr(fm), _ptr(err), plan.units_ptr(), len(plan.units),
-                                           _ptr(ids_t) if with_ids else None, _ptr(parts_t) if with_ids else None,
+                                           _ptr(fm), _ptr(err), plan.units_ptr(), plan.n_grid_units,
+                                           _ptr(ids_t) if fused_ids else None, _ptr(parts_t) if fused_ids else None,
                                            _ptr(fm_s), ld_s, stream), "dctr_embed_fwd")
             finally:
                 plan.cplan.step_sync = None
+            if with_ids and not fused_ids and ids_t is not None:
+                L.check(lib.dctr_embed_ids(cplan, plan.units_ptr(), plan.n_grid_units, _ptr(X), X.stride(0), B,
+                                           _ptr(ids_t), _ptr(parts_t), stream), "dctr_embed_ids")
 
         if own_ids and getattr(sink, "gather_side", False):
             # Topology "gather_side": the gather runs on the side stream too, in stream order behind the previous
@@ -143,7 +151,7 @@ class EmbedFunction(torch.autograd.Function):
         ctx.plan, ctx.want_fm = plan, want_fm
         if segs and not own_ids:
             ctx.seg_event = plan.launch_segments(ids_t, parts_t, B)
-        ctx.save_for_backward(X, out if want_fm else None, ids_t, fm_s, parts_t)
+        ctx.save_for_backward(X, out if (want_fm or plan.gen is not None) else None, ids_t, fm_s, parts_t, den_t, amax)
         ctx.set_materialize_grads(False)
         outs = (out if out is not None else X.new_zeros((B, 0)),
                 wide if wide is not None else X.new_zeros((B,)),
@@ -154,8 +162,9 @@ class EmbedFunction(torch.autograd.Function):
     def backward(ctx, g_out, g_wide, g_fm):
         lib = L.lib()
         plan = ctx.plan
-        X, out, ids_t, fm_s, parts_t = ctx.saved_tensors
+        X, out, ids_t, fm_s, parts_t, den_t, amax = ctx.saved_tensors
         B = X.shape[0]
+        plan.point_step_buffers(den_t, amax)
         g_wd = None
         if not plan.has_lookup:
             g_out = None
@@ -203,7 +212,7 @@ class EmbedFunction(torch.autograd.Function):
             lazy._ensure(X.device)
             cplan = plan.bind(X.device)
             ws, ws_n, pre = plan.update_workspace_for(ids_t, ctx.seg_event, B)
-            L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t),
+            L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), plan.n_grid_units, plan.max_vocab, _ptr(ids_t),
                                           _ptr(parts_t), B, _ptr(g_out), ld_g, _ptr(out), plan.ld_out, _ptr(fm_s),
                                           fm_s.stride(0) if fm_s is not None else 0, _ptr(g_fm), _ptr(g_wide), 1,
                                           L.UPD_ACCUM, 0.0, 0.0, _ptr(X), X.stride(0), _ptr(g_wd), None, _ptr(ws), ws_n,
@@ -239,16 +248,16 @@ class EmbedFunction(torch.autograd.Function):
             with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
                 ws, ws_n, pre = plan.update_workspace_for(ids_t, ctx.seg_event, B)
                 wd = ctypes.byref(inline) if (inline is not None and g_wd is not None and g_w is None) else None
-                L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t),
+                L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), plan.n_grid_units, plan.max_vocab, _ptr(ids_t),
                                               _ptr(parts_t), B, _ptr(g_out), ld_g, _ptr(out), plan.ld_out, _ptr(fm_s),
                                               fm_s.stride(0) if fm_s is not None else 0, _ptr(g_fm), _ptr(g_wide), 1,
                                               opt, lr, eps, _ptr(X), X.stride(0), _ptr(g_wd), wd, _ptr(ws), ws_n, pre,
                                               L.stream_handle(X.device)), "dctr_embed_update")
             if side is not None:
                 # (everything the side-stream kernels touch stays allocated until the join)
-                sink.forked(side, (X, out, ids_t, parts_t, fm_s, g_out, g_fm, g_wide, g_wd, ws))
+                sink.forked(side, (X, out, ids_t, parts_t, fm_s, g_out, g_fm, g_wide, g_wd, ws, den_t, amax))
             elif sink is not None and getattr(sink, "wgrad_on_seg", False):
-                sink.upd_keep = (X, out, ids_t, parts_t, fm_s, g_out, g_fm, g_wide, g_wd, ws)   # (see forward)
+                sink.upd_keep = (X, out, ids_t, parts_t, fm_s, g_out, g_fm, g_wide, g_wd, ws, den_t, amax)   # (see forward)
             after = getattr(sink, "after_update", None) if sink is not None else None
             if after is not None:        # topology "tower_side": the weight gradients fork off behind the update's launch
                 sink.after_update = None

@@ -280,23 +280,30 @@ class EmbeddingPlan(object):
         self.width = emb_width + len(self.dense_cols)      # logical row width (combined_dnn_input)
         self.ld_out = max(4, (self.width + 3) // 4 * 4)     # padded leading dimension of `out`
 
-        # units of the deterministic update kernel (csrc/update.hip): one id column of X with the deep and / or
-        # wide table it feeds.  Usable when every field is fixed-length and no table is shared.
-        self.units = []
-        used_wide = set()
-        for i, f in enumerate(self.deep):
-            j = next((k for k, w in enumerate(self.wide) if k not in used_wide and w.col == f.col and
-                      w.vocab == f.vocab and w.len == 1), -1)
-            if j >= 0:
-                used_wide.add(j)
-            self.units.append((i, j, f.col, 0))
-        for k, w in enumerate(self.wide):
-            if k not in used_wide:
-                self.units.append((-1, k, w.col, 0))
+        # units of the deterministic update kernel (csrc/update_kernels.hpp).  SIMPLE plans (every field fixed-length, no
+        # table shared): a unit is one id column of X with the deep and / or wide table it feeds -- the layout the kernels
+        # have always run, also what the lazy update, the sharded trainers and the two-level pre-pass assume.  Otherwise
+        # (pooled VarLen fields, tables shared through embedding_name): GENERAL units, see _build_general_units.
         all_fields = self.deep + self.wide
         self.max_vocab = max([f.vocab for f in all_fields] + [1])
-        self.unit_path = (len(all_fields) > 0 and all(f.len == 1 and f.pool == 0 for f in all_fields) and
-                          len(set(id(f.param) for f in all_fields)) == len(all_fields))
+        self.simple_units = (len(all_fields) > 0 and all(f.len == 1 and f.pool == 0 for f in all_fields) and
+                             len(set(id(f.param) for f in all_fields)) == len(all_fields))
+        self.units = []
+        self.gen = None          # host image of dctr_plan_ext_t (general units), None for simple plans
+        if self.simple_units or not all_fields:
+            used_wide = set()
+            for i, f in enumerate(self.deep):
+                j = next((k for k, w in enumerate(self.wide) if k not in used_wide and w.col == f.col and
+                          w.vocab == f.vocab and w.len == 1), -1)
+                if j >= 0:
+                    used_wide.add(j)
+                self.units.append((i, j, f.col, 0))
+            for k, w in enumerate(self.wide):
+                if k not in used_wide:
+                    self.units.append((-1, k, w.col, 0))
+            self.unit_path = self.simple_units
+        else:
+            self.unit_path = self._build_general_units()
 
         self._params = []  # unique table parameters, first-use order
         seen = set()
@@ -313,6 +320,114 @@ class EmbeddingPlan(object):
         self._lazy = None      # LazyState when the tables take the exact lazy regularised / Adam update
         self._reset_device_image()
 
+    # ---- general update units (include/dctr.h: dctr_plan_ext_t) -----------------------------------------------------
+    def _build_general_units(self):
+        """A unit = (deep table | none, wide table | none) + every X column that feeds it: the positions of a pooled
+        VarLenSparseFeat (inputs.py:141-155) and every column that shares the table through ``embedding_name``
+        (inputs.py:158-180).  A deep group (all deep fields over one table) pairs with a wide group when their columns
+        match one to one -- same X column, pooling, length source -- as they do when ``linear_feature_columns`` and
+        ``dnn_feature_columns`` name the same features; otherwise each side is a unit of its own.  Returns False when the
+        kernels' envelope does not hold it (then the atomic two-pass path of csrc/embed.hip runs)."""
+        def groups(fields):
+            g = {}
+            for i, f in enumerate(fields):
+                g.setdefault(id(f.param), []).append(i)
+            return list(g.values())
+
+        def sigs(fields, idxs):
+            return [((f.col + t, f.pool, f.len, f.len_col, t), i) for i in idxs for f in (fields[i],) for t in range(f.len)]
+
+        dgroups, wgroups = groups(self.deep), groups(self.wide)
+        wsig = [sigs(self.wide, g) for g in wgroups]
+        used = set()
+        units = []          # (deep slots [(sig, di)], wide slots aligned with them | None)
+        for g in dgroups:
+            ds = sigs(self.deep, g)
+            vocab = self.deep[g[0]].vocab
+            hit = None
+            for k, ws in enumerate(wsig):
+                if k in used or self.wide[wgroups[k][0]].vocab != vocab or len(ws) != len(ds):
+                    continue
+                if sorted(x[0] for x in ws) == sorted(x[0] for x in ds) and len(set(x[0] for x in ds)) == len(ds):
+                    hit = k
+                    break
+            if hit is None:
+                units.append((ds, None))
+            else:
+                used.add(hit)
+                by_sig = dict((x[0], x[1]) for x in wsig[hit])
+                units.append((ds, [(x[0], by_sig[x[0]]) for x in ds]))
+        for k, ws in enumerate(wsig):
+            if k not in used:
+                units.append((None, ws))
+
+        am_deep, am_wide, ld_am = [-1] * len(self.deep), [-1] * len(self.wide), 0
+        for i, f in enumerate(self.deep):
+            if f.pool == 3:
+                am_deep[i], ld_am = ld_am, ld_am + f.dim
+        for i, f in enumerate(self.wide):
+            if f.pool == 3:
+                am_wide[i], ld_am = ld_am, ld_am + 1
+        ld_am = (ld_am + 15) // 16 * 16
+        slots, vunits, vocabs, den_rows = [], [], [], {}
+        self.units = []
+        for ds, ws in units:
+            ref = ds if ds is not None else ws
+            ns = len(ref)
+            if ns > L.MAX_UNIT_SLOTS:
+                return False
+            c0, vu0 = len(slots), len(vunits)
+            di = ds[0][1] if ds is not None else -1
+            wi = ws[0][1] if ws is not None else -1
+            for n, (sig, _) in enumerate(ref):
+                col, pool, length, len_col, t = sig
+                if pool == 3 and length > 255:
+                    return False
+                fdi = ds[n][1] if ds is not None else -1
+                fwi = ws[n][1] if ws is not None else -1
+                den = -1
+                if pool == 2:
+                    den = den_rows.setdefault((col - t, length, len_col), len(den_rows))
+                slots.append(dict(col=col, goff=self.deep[fdi].out_off if fdi >= 0 else -1, wide=1 if fwi >= 0 else 0,
+                                  pool=pool, t=t, len=length, len_col=len_col, den=den,
+                                  am_deep=am_deep[fdi] if fdi >= 0 else -1, am_wide=am_wide[fwi] if fwi >= 0 else -1,
+                                  vu0=vu0))
+            k = ns                      # groups of P partitions: a partition then holds ~96 entries whatever the slots
+            kshift = 32 + max(0, (k - 1).bit_length())
+            for j in range(k):
+                vunits.append(dict(di=di, wi=wi, c0=c0, n_slots=ns, k=k, j=j, kshift=kshift,
+                                   kmagic=((1 << kshift) // k + 1) & 0xFFFFFFFFFFFFFFFF))
+                vocabs.append(self.deep[di].vocab if di >= 0 else self.wide[wi].vocab)
+            self.units.append((di, wi, ref[0][0][0], 0))
+        self.gen = dict(slots=slots, vunits=vunits, vocabs=vocabs, am_deep=am_deep, am_wide=am_wide, ld_amax=ld_am,
+                        n_den=len(den_rows), max_unit_slots=max(len(d if d is not None else w) for d, w in units))
+        return True
+
+    @property
+    def n_vcols(self):
+        """Rows of ids_t / parts_t: one per X column feeding a unit (= len(units) for simple plans)."""
+        return len(self.gen["slots"]) if self.gen is not None else len(self.units)
+
+    @property
+    def n_grid_units(self):
+        """What the update entry points take as ``n_units``: the vunits of a general plan, else the units."""
+        return len(self.gen["vunits"]) if self.gen is not None else len(self.units)
+
+    def step_buffers(self, B, device):
+        """(den_t [n_den, B] | None, amax [B, ld_amax] u8 | None): per-step side buffers of a general plan."""
+        if self.gen is None:
+            return None, None
+        den = torch.empty((self.gen["n_den"], B), dtype=torch.float32, device=device) if self.gen["n_den"] else None
+        am = torch.empty((B, self.gen["ld_amax"]), dtype=torch.uint8, device=device) if self.gen["ld_amax"] else None
+        return den, am
+
+    def point_step_buffers(self, den_t, amax):
+        """Aim the ext block at this step's side buffers (read at enqueue time, like dctr_plan_t.step_sync)."""
+        self._step_bufs = (den_t, amax)         # (bind() re-creates the ext block when a table pointer moved)
+        if self.gen is not None and self.cext is not None:
+            self.cext.den_t = den_t.data_ptr() if den_t is not None else None
+            self.cext.amax = amax.data_ptr() if amax is not None else None
+
     @property
     def lazy(self):
         return self._owner.lazy if self._owner is not None else self._lazy
@@ -325,6 +440,9 @@ class EmbeddingPlan(object):
         self._key = None
         self._dev = {}
         self.cplan = L.Plan()
+        self.cext = None
+        self._host_ext = None
+        self._step_bufs = (None, None)
         self.anchor = None
         self._err = None
         self._wd_idx = None
@@ -335,7 +453,7 @@ class EmbeddingPlan(object):
     # raw ctypes / device handles are dropped and re-baked lazily
     def __getstate__(self):
         d = dict(self.__dict__)
-        for k in ("_key", "_dev", "cplan", "anchor", "_err", "_wd_idx", "_upd_ws", "_seg_stream"):
+        for k in ("_key", "_dev", "cplan", "cext", "_host_ext", "_step_bufs", "anchor", "_err", "_wd_idx", "_upd_ws", "_seg_stream"):
             d.pop(k, None)
         d["exchange"] = None
         d["sharder"] = None
@@ -511,6 +629,32 @@ class EmbeddingPlan(object):
         if self.has_maxpool:
             flags |= L.PLAN_HAS_MAXPOOL
         c.flags = flags
+        c.ext = None
+        if self.gen is not None:
+            g = self.gen
+            sl = (L.USlot * len(g["slots"]))()
+            for i, d in enumerate(g["slots"]):
+                for k_, v in d.items():
+                    setattr(sl[i], k_, v)
+            vu = (L.VUnit * len(g["vunits"]))()
+            for i, d in enumerate(g["vunits"]):
+                for k_, v in d.items():
+                    setattr(vu[i], k_, v)
+            hv = (ctypes.c_int64 * len(g["vocabs"]))(*g["vocabs"])
+            self._dev["slots"] = up(bytes(sl), torch.uint8)
+            self._dev["vunits"] = up(bytes(vu), torch.uint8)
+            self._dev["am_deep"] = up(np.asarray(g["am_deep"] or [-1], dtype=np.int32).tobytes(), torch.int32)
+            self._dev["am_wide"] = up(np.asarray(g["am_wide"] or [-1], dtype=np.int32).tobytes(), torch.int32)
+            x = L.PlanExt()
+            x.slots, x.vunits = self._dev["slots"].data_ptr(), self._dev["vunits"].data_ptr()
+            x.am_deep_off, x.am_wide_off = self._dev["am_deep"].data_ptr(), self._dev["am_wide"].data_ptr()
+            x.h_vunits, x.h_vocab = ctypes.addressof(vu), ctypes.addressof(hv)
+            x.den_t = x.amax = None
+            x.n_vcols, x.n_vunits, x.n_units = len(g["slots"]), len(g["vunits"]), len(self.units)
+            x.max_unit_slots, x.n_den, x.ld_amax = g["max_unit_slots"], g["n_den"], g["ld_amax"]
+            self.cext, self._host_ext = x, (vu, hv)
+            c.ext = ctypes.addressof(x)
+            self.point_step_buffers(*getattr(self, "_step_bufs", (None, None)))
         self._key = key
         self.version += 1
         if self.anchor is None or self.anchor.device != device:
@@ -538,7 +682,7 @@ class EmbeddingPlan(object):
         if ws is not None:
             self._upd_ws[key] = self._upd_ws.pop(key)      # (least recently used goes first)
         if ws is None:
-            n = int(L.lib().dctr_embed_update_workspace_ints(ctypes.byref(self.cplan), len(self.units), int(B)))
+            n = int(L.lib().dctr_embed_update_workspace_ints(ctypes.byref(self.cplan), self.n_grid_units, int(B)))
             ws = torch.zeros(max(n, 1), dtype=torch.int32, device=device)
             # One workspace per batch size, kept: a captured hipGraph holds the raw address of the one it was captured
             # with (fit() alternates between the full-size batch's graph and an eager ragged last batch -- dropping
@@ -575,11 +719,11 @@ class EmbeddingPlan(object):
                 # the ids (and their partition tags) straight from X: the side stream's chain -- ids, pre-pass, and
                 # later the update -- then hangs on nothing the gather kernel produces (one queue crossing less on
                 # the step's critical chain; the gather skips these two side outputs)
-                L.check(L.lib().dctr_embed_ids(ctypes.byref(self.cplan), self.units_ptr(), len(self.units),
+                L.check(L.lib().dctr_embed_ids(ctypes.byref(self.cplan), self.units_ptr(), self.n_grid_units,
                                                ctypes.c_void_p(X.data_ptr()), X.stride(0), int(B),
                                                ctypes.c_void_p(ids_t.data_ptr()), ctypes.c_void_p(parts_t.data_ptr()),
                                                stream), "dctr_embed_ids")
-            L.check(L.lib().dctr_embed_segments(ctypes.byref(self.cplan), self.units_ptr(), len(self.units),
+            L.check(L.lib().dctr_embed_segments(ctypes.byref(self.cplan), self.units_ptr(), self.n_grid_units,
                                                 self.max_vocab, ctypes.c_void_p(ids_t.data_ptr()),
                                                 ctypes.c_void_p(parts_t.data_ptr()), int(B),
                                                 ctypes.c_void_p(ws.data_ptr()), ws_n, stream), "dctr_embed_segments")

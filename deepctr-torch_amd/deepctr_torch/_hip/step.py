@@ -62,6 +62,7 @@ class GatherStep(object):
         self._prepassed = None    # token of the batch whose pre-pass the previous step already enqueued
         self._events, self._ev_i = None, 0
         self.timing = None        # (start, end) events around the update on its queue: bench.py's in-step roofline
+        self.timing_tower = None  # (start, end) events around the gather + tower launch on the main queue
 
     # ---- applicability ------------------------------------------------------------------------------------------
     @staticmethod
@@ -209,10 +210,14 @@ class GatherStep(object):
                 with on_side():
                     self._prepass(b, cplan, xb, B, L.stream_handle(dev))
             mh = L.stream_handle(dev)
+            if self.timing_tower is not None:
+                self.timing_tower[0].record(main)
             L.check(lib.dctr_embed_tower_train_step(cplan, _ptr(xb), xb.stride(0), ctypes.byref(b.desc), B,
                                                     1 if self.want_fm else 0, _ptr(bias), _ptr(y), _ptr(y_pred),
                                                     _ptr(b.g_logit), _ptr(b.gx), ld, _ptr(b.out), ld, _ptr(b.fm_s), ld_s,
                                                     _ptr(err), _ptr(b.ws), mh), "dctr_embed_tower_train_step")
+            if self.timing_tower is not None:
+                self.timing_tower[1].record(main)
             if side is not None:
                 side.wait_stream(main)       # the update may start once the first launch is done
             L.check(lib.dctr_mlp_train_wgrad(ctypes.byref(b.desc), _ptr(b.out), ld, B, _ptr(b.g_logit), _ptr(b.ws),

@@ -535,7 +535,7 @@ class BaseModel(nn.Module):
                 os.environ.get("DCTR_SPARSE_UPDATE", "1") == "0" or getattr(self, "_no_lazy_update", False):
             return None
         tables = plan.table_params
-        if not tables or not plan.unit_path or plan.max_dim > 64 * (4 if plan.vec == 4 else 1) or \
+        if not tables or not plan.simple_units or plan.max_dim > 64 * (4 if plan.vec == 4 else 1) or \
                 not all(p.requires_grad for p in tables):
             return None
         l2 = {}

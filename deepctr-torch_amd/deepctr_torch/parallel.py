@@ -136,7 +136,7 @@ class DataParallelTrainer(object):
             self._forced_dense = True
             if self.plan.update[0] == "lazy":
                 raise RuntimeError("the model kept the lazy table update although the dense route was requested")
-        if not self.plan.unit_path:
+        if not self.plan.simple_units:
             raise NotImplementedError("data-parallel training needs fixed-length sparse features over distinct "
                                       "tables (the deterministic update kernel); pooled VarLen features are "
                                       "single-GPU for now")
@@ -265,7 +265,7 @@ class ShardLayout(object):
     need for step k+1 travel in step k's gradient all-to-all, which removes one collective per step."""
 
     def __init__(self, plan, world, rank):
-        if not plan.unit_path or plan.emb_dim <= 0 or not plan.deep:
+        if not plan.simple_units or plan.emb_dim <= 0 or not plan.deep:
             raise NotImplementedError("table-sharded training needs fixed-length sparse features over distinct "
                                       "tables that share one embedding_dim (pooled VarLen features: single GPU)")
         if any(di < 0 for (di, wi, col, _) in plan.units):

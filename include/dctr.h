@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 19
+#define DCTR_ABI_VERSION 20
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -60,6 +60,65 @@ typedef struct dctr_field {
                    /* wide weight of the same id): what is updated together then shares one 128-byte line */
 } dctr_field_t;
 
+/* ---- general update units (round 5): pooled VarLen fields and shared tables on the deterministic update ------
+ * The reference pools a VarLenSparseFeat with SequencePoolingLayer (inputs.py:141-155, sequence.py:49-77) and lets
+ * several feature columns share one nn.Embedding through `embedding_name` (inputs.py:158-180); autograd then sends
+ * every (sample, position) of every such column to embedding_dense_backward of the ONE table.  Here a UNIT is a
+ * (deep table | none, wide table | none) pair with every X column that feeds it -- its SLOTS (virtual columns):
+ *   ids_t / parts_t are [n_vcols, B]; a unit's slots are consecutive virtual columns [c0, c0 + n_slots), so its entries
+ *   are the contiguous run ids_t[c0 * B ... (c0 + n_slots) * B) and an entry is named by v = slot_local * B + b;
+ *   a slot whose position is masked out for a sample (sum / mean pooling: id == 0, or t >= length) carries the tag
+ *   0xFFFF in parts_t and is no entry; a max-pooled slot is always an entry, its gradient is masked per element by
+ *   the forward's arg-max side output;
+ *   a unit of n_slots slots is split over k = n_slots groups of P partitions (rows {id : id mod (k P) == j P + p} belong
+ *   to workgroup (vunit (unit, j), p)), so a partition holds ~96 entries whatever the number of slots.
+ * A plan without `ext` is the simple case the kernels have always run: unit u = one X column (units[u]) over its own
+ * tables, n_vcols = n_vunits = n_units.                                                                              */
+typedef struct dctr_uslot {
+  int32_t col;      /* X column of the id                                                                            */
+  int32_t goff;     /* float offset of the deep field's slice in `out` / `g_out` rows; -1: no deep side              */
+  int32_t wide;     /* 1: the entry carries the wide gradient too                                                    */
+  int32_t pool;     /* DCTR_POOL_* of the field(s) of this slot                                                      */
+  int32_t t;        /* position inside a pooled field (0 otherwise)                                                  */
+  int32_t len;      /* positions of the field                                                                        */
+  int32_t len_col;  /* X column of the valid length, -1: mask = (id != 0)                                            */
+  int32_t den;      /* row of den_t holding mean pooling's divisor count + 1e-8 (sequence.py:72-74); -1              */
+  int32_t am_deep;  /* byte offset in an amax row of the deep field's per-element arg-max positions (max pooling); -1 */
+  int32_t am_wide;  /* the same for the wide field (one byte); -1                                                    */
+  int32_t vu0;      /* first vunit of the slot's unit                                                                */
+  int32_t pad_;
+} dctr_uslot_t;
+
+typedef struct dctr_vunit {
+  int32_t di, wi;        /* field whose descriptor supplies the unit's deep / wide table; -1: none                   */
+  int32_t c0, n_slots;   /* the unit's virtual columns                                                               */
+  int32_t k, j;          /* the unit has k * P partitions; this vunit's workgroups own [j P, (j + 1) P)              */
+  int32_t kshift, pad_;  /* q / k == (q * kmagic) >> kshift for 0 <= q < 2^31 (kshift = 32 + ceil_log2 k)            */
+  uint64_t kmagic;
+} dctr_vunit_t;
+
+/* host struct; `slots`, `vunits`, `am_deep_off`, `am_wide_off`, `den_t`, `amax` are DEVICE pointers, `h_*` host arrays.
+ * den_t / amax are PER-STEP buffers the caller points at before each call (like dctr_plan_t.step_sync):
+ *   den_t [n_den, B] float  written by dctr_embed_ids, read by dctr_embed_update
+ *   amax  [B, ld_amax] u8   written by dctr_embed_fwd (arg-max position per element of every max-pooled field, first
+ *                           maximum wins like torch.max), read by dctr_embed_update                                  */
+typedef struct dctr_plan_ext {
+  const dctr_uslot_t* slots;    /* [n_vcols]                                                                         */
+  const dctr_vunit_t* vunits;   /* [n_vunits]                                                                        */
+  const int32_t* am_deep_off;   /* [n_deep] byte offset in an amax row, -1: not max-pooled                           */
+  const int32_t* am_wide_off;   /* [n_wide]                                                                          */
+  const dctr_vunit_t* h_vunits; /* host copy of vunits                                                               */
+  const int64_t* h_vocab;       /* [n_vunits] rows of the vunit's tables                                             */
+  float* den_t;
+  uint8_t* amax;
+  int32_t n_vcols, n_vunits, n_units, max_unit_slots;
+  int32_t n_den, ld_amax;
+} dctr_plan_ext_t;
+#define DCTR_MAX_UNIT_SLOTS 128
+size_t dctr_sizeof_uslot(void);
+size_t dctr_sizeof_vunit(void);
+size_t dctr_sizeof_plan_ext(void);
+
 /* The compiled feature-column schema of one model: what build_input_features + create_embedding_matrix
  * + Linear.__init__ establish in the reference (inputs.py:99-180, basemodel.py:34-61).
  * The struct itself lives in HOST memory; the arrays it points to live on the device.              */
@@ -88,6 +147,7 @@ typedef struct dctr_plan {
   int32_t chunk_rows;         /* inside the row: wide = out + k, ld_wide = ld_out) to (float*)out_chunks[b / chunk_rows] +  */
   int32_t pad_;               /* (b % chunk_rows) * ld_out instead of out + b * ld_out: the owner's gather of the sharded   */
                               /* step pushes every rank's rows straight into that rank's receive buffer (peer memory)      */
+  const dctr_plan_ext_t* ext; /* nullable (host): general update units -- pooled VarLen fields, shared tables (above)     */
 } dctr_plan_t;
 
 #define DCTR_PLAN_HAS_GACC 1    /* every field has a gacc slab                       */

@@ -110,8 +110,11 @@ def cli():
     ap.add_argument("--l2", type=float, default=0.0)
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--json", action="store_true")
+    ap.add_argument("--threads", type=int, default=0, help="torch.set_num_threads (0: torch's default = every logical cpu)")
     a = ap.parse_args()
     import torch
+    if a.threads > 0:
+        torch.set_num_threads(a.threads)
     sys.path.insert(0, HERE)
     import make_golden as mg
     mg.REFERENCE = os.path.abspath(a.reference_root)

@@ -18,7 +18,7 @@ def _arr(ptr, shape, ld=None, dtype=np.float32):
         return None
     if len(shape) == 1:
         n = shape[0]
-        ct = ctypes.c_int32 if dtype == np.int32 else ctypes.c_float
+        ct = {np.int32: ctypes.c_int32, np.uint16: ctypes.c_uint16, np.uint8: ctypes.c_uint8}.get(dtype, ctypes.c_float)
         return np.ctypeslib.as_array((ct * n).from_address(addr))
     rows, cols = shape
     ld = cols if ld is None else int(ld)
@@ -241,6 +241,16 @@ class _Core(object):
         return c, deep, wide, dcols, wcols
 
     @staticmethod
+    def _ext(pref):
+        """dctr_plan_ext_t of a general plan -> (ext struct, slots, vunits), else None."""
+        from deepctr_torch._hip import lib as L
+        c = pref._obj if pref is not None else None
+        if c is None or not c.ext:
+            return None
+        x = L.PlanExt.from_address(c.ext)
+        return x, (L.USlot * x.n_vcols).from_address(x.slots), (L.VUnit * x.n_vunits).from_address(x.vunits)
+
+    @staticmethod
     def _rows(X, f, err=None):
         ids = X[:, f.col].astype(np.int64)
         bad = (ids < 0) | (ids >= f.vocab)
@@ -312,6 +322,31 @@ class _Core(object):
         """(parts_t -- the update kernel's partition tags -- is an optimisation detail of the device code: the
         stand-in's update does not read it, and leaves it unwritten)"""
         self.calls.append("embed_ids")
+        ext = self._ext(pref)
+        if ext is not None:
+            # general units: ids_t / parts_t are [n_vcols, B]; a masked-out position carries the tag 0xFFFF (every other
+            # tag is 0 here: the stand-in's update does not partition); mean pooling's divisors go to ext.den_t
+            x, slots, _ = ext
+            c = pref._obj
+            Xv = _arr(X, (B, c.n_xcols), ldx)
+            out = _arr(ids_t, (x.n_vcols * B,), dtype=np.int32).reshape(x.n_vcols, B)
+            tags = _arr(parts_t, (x.n_vcols * B,), dtype=np.uint16)
+            tags = tags.reshape(x.n_vcols, B) if tags is not None else None
+            den = _arr(ctypes.c_void_p(x.den_t), (x.n_den * B,)).reshape(x.n_den, B) if (x.n_den and x.den_t) else None
+            for ci in range(x.n_vcols):
+                sl = slots[ci]
+                rid = Xv[:, sl.col].astype(np.int32)
+                out[ci] = rid
+                valid = np.ones(B, bool)
+                if sl.pool in (1, 2):
+                    valid = (sl.t < Xv[:, sl.len_col].astype(np.int32)) if sl.len_col >= 0 else (rid != 0)
+                if tags is not None:
+                    tags[ci] = np.where(valid, 0, 0xFFFF).astype(np.uint16)
+                if den is not None and sl.den >= 0 and sl.t == 0:
+                    cnt = Xv[:, sl.len_col].astype(np.int32).astype(np.float32) if sl.len_col >= 0 else \
+                        (Xv[:, sl.col:sl.col + sl.len].astype(np.int32) != 0).sum(axis=1).astype(np.float32)
+                    den[sl.den] = cnt + np.float32(1e-8)
+            return 0
         U = _arr(units, (n_units * 4,), dtype=np.int32).reshape(n_units, 4)
         ncol = int(U[:, 2].max()) + 1
         Xv = _arr(X, (B, ncol), ldx)
@@ -357,6 +392,19 @@ class _Core(object):
         if _arr(ids_t, (1,)) is not None:
             self.dctr_embed_ids(pref, units, n_units, X, ldx, B, ids_t, parts_t, stream)
             self.calls.pop()
+        ext = self._ext(pref)
+        if ext is not None and ext[0].amax and ext[0].ld_amax:
+            x = ext[0]
+            A = _arr(ctypes.c_void_p(x.amax), (B * x.ld_amax,), dtype=np.uint8).reshape(B, x.ld_amax)
+            offd = _arr(ctypes.c_void_p(x.am_deep_off), (max(1, c.n_deep),), dtype=np.int32)
+            offw = _arr(ctypes.c_void_p(x.am_wide_off), (max(1, c.n_wide),), dtype=np.int32)
+            for fs, offs in ((deep, offd), (widef, offw)):
+                for i, f in enumerate(fs):
+                    if f.pool == 3 and offs[i] >= 0:
+                        ids, mask = self._seq(Xv, f)
+                        m = mask[:, :, None].astype(np.float32)
+                        arg = (_tab(f)[ids] - (np.float32(1) - m) * np.float32(1e9)).argmax(axis=1)      # first maximum
+                        A[:, offs[i]:offs[i] + f.dim] = arg.astype(np.uint8)
         return 0
 
     # ---- general backward (dctr_embed_bwd) + consume pass (dctr_embed_apply): pooled fields, shared tables -----
@@ -408,11 +456,19 @@ class _Core(object):
                           g_wide, ld_gw, opt, lr, eps, X, ld_x, g_wdense, wd_step, ws, ws_n, presorted, stream):
         self.calls.append("embed_update:%d" % opt)
         c, deep, widef, dcols, wcols = self._plan(pref)
-        U = _arr(units, (n_units * 4,), dtype=np.int32).reshape(n_units, 4)
-        ids = _arr(ids_t, (n_units * B,), dtype=np.int32).reshape(n_units, B)
         gO = _arr(g_out, (B, ld_g), ld_g) if ld_g else None
         gF = _arr(g_fm, (B,))
         gW = _arr(g_wide, ((B - 1) * ld_gw + 1,))[::ld_gw] if _arr(g_wide, (1,)) is not None else None
+        ext = self._ext(pref)
+        if ext is not None:
+            self._update_general(ext, c, deep, widef, ids_t, parts_t, B, gO, gF, gW, out, ld_out, fm_s, ld_s, opt, lr, eps)
+            if _arr(g_wdense, (1,)) is not None and gW is not None and wcols:
+                Xv = _arr(X, (B, c.n_xcols), ld_x)
+                _arr(g_wdense, (len(wcols),))[...] = [np.dot(gW.astype(np.float64), Xv[:, col]) for col in wcols]
+                self._dense_step(wd_step, g_wdense, len(wcols))
+            return 0
+        U = _arr(units, (n_units * 4,), dtype=np.int32).reshape(n_units, 4)
+        ids = _arr(ids_t, (n_units * B,), dtype=np.int32).reshape(n_units, B)
 
         def scatter(f, rows, G):
             """sum duplicates in sample order, then one read-modify-write per touched row."""
@@ -451,6 +507,92 @@ class _Core(object):
             _arr(g_wdense, (len(wcols),))[...] = [np.dot(gW.astype(np.float64), Xv[:, col]) for col in wcols]
             self._dense_step(wd_step, g_wdense, len(wcols))
         return 0
+
+    def _update_general(self, ext, c, deep, widef, ids_t, parts_t, B, gO, gF, gW, out, ld_out, fm_s, ld_s, opt, lr, eps):
+        """dctr_embed_update on GENERAL units (include/dctr.h, dctr_plan_ext_t): every valid (slot, sample) entry of a unit
+        contributes its field's gradient slice times the pooling weight; duplicates of a row are summed in (id, slot, sample)
+        order, each touched row is read-modify-written once."""
+        x, slots, vunits = ext
+        ids = _arr(ids_t, (x.n_vcols * B,), dtype=np.int32).reshape(x.n_vcols, B)
+        tags = _arr(parts_t, (x.n_vcols * B,), dtype=np.uint16).reshape(x.n_vcols, B)
+        O = _arr(out, (B, ld_out), ld_out) if gF is not None else None
+        S = _arr(fm_s, (B, ld_s), ld_s) if gF is not None else None
+        den = _arr(ctypes.c_void_p(x.den_t), (x.n_den * B,)).reshape(x.n_den, B) if (x.n_den and x.den_t) else None
+        am = _arr(ctypes.c_void_p(x.amax), (B * x.ld_amax,), dtype=np.uint8).reshape(B, x.ld_amax) if (x.ld_amax and x.amax) \
+            else None
+
+        def apply(f, rows, G, fold_e=None):
+            table = _tab(f)
+            order = np.lexsort((np.arange(len(rows)), rows))
+            rows, G = rows[order], G[order]
+            uniq, start = np.unique(rows, return_index=True)
+            acc = np.zeros((len(uniq), f.dim), np.float32)
+            ends = list(start[1:]) + [len(rows)]
+            for i, (a, b) in enumerate(zip(start, ends)):
+                for r in range(b - 1, a - 1, -1):           # (the kernels walk a segment backwards)
+                    acc[i] += G[r]
+            if fold_e is not None:
+                gfs = fold_e[order]
+                for i, (a, b) in enumerate(zip(start, ends)):
+                    tot = np.float32(0)
+                    for r in range(b - 1, a - 1, -1):
+                        tot += gfs[r]
+                    acc[i] -= tot * table[uniq[i]]
+            if opt == 0:
+                table[uniq] -= np.float32(lr) * acc
+            elif opt == 1:
+                st = _st(f)
+                st[uniq] += acc * acc
+                table[uniq] -= np.float32(lr) * (acc / (np.sqrt(st[uniq]) + np.float32(eps)))
+            else:
+                _arr(f.gacc, (f.vocab, f.dim))[uniq] += acc
+
+        work = []
+        for vu in vunits:
+            if vu.j != 0:
+                continue
+            fd = deep[vu.di] if vu.di >= 0 else None
+            fw = widef[vu.wi] if vu.wi >= 0 else None
+            vocab = (fd or fw).vocab
+            rows_all, Gd_all, Gf_all, Gw_all = [], [], [], []
+            for ci in range(vu.c0, vu.c0 + vu.n_slots):
+                sl = slots[ci]
+                valid = tags[ci] != 0xFFFF
+                rid = ids[ci].astype(np.int64)
+                rows = np.where((rid < 0) | (rid >= vocab), 0, rid)
+                Gd = np.zeros((B, fd.dim if fd is not None else 1), np.float32)
+                gfe = np.zeros(B, np.float32)
+                if fd is not None and sl.goff >= 0 and (gO is not None or gF is not None):
+                    D = fd.dim
+                    if gO is not None:
+                        Gd += gO[:, sl.goff:sl.goff + D]
+                    if gF is not None:
+                        if sl.pool == 0:
+                            Gd += gF[:, None] * S[:, :D]
+                            gfe = gF.astype(np.float32).copy()
+                        else:
+                            Gd += gF[:, None] * (S[:, :D] - O[:, sl.goff:sl.goff + D])
+                    if sl.pool == 2:
+                        Gd = Gd / den[sl.den][:, None]
+                    elif sl.pool == 3:
+                        Gd = np.where(am[:, sl.am_deep:sl.am_deep + D] == sl.t, Gd, np.float32(0))
+                Gw = np.zeros((B, 1), np.float32)
+                if fw is not None and sl.wide and gW is not None:
+                    Gw = gW.reshape(B, 1).astype(np.float32)
+                    if sl.pool == 2:
+                        Gw = Gw / den[sl.den][:, None]
+                    elif sl.pool == 3:
+                        Gw = np.where(am[:, sl.am_wide:sl.am_wide + 1] == sl.t, Gw, np.float32(0))
+                rows_all.append(rows[valid]); Gd_all.append(Gd[valid]); Gf_all.append(gfe[valid]); Gw_all.append(Gw[valid])
+            rows = np.concatenate(rows_all)
+            if not len(rows):
+                continue
+            work.append((fd, fw, rows, np.concatenate(Gd_all), np.concatenate(Gf_all), np.concatenate(Gw_all)))
+        for fd, fw, rows, Gd, Gf, Gw in work:
+            if fd is not None and (gO is not None or gF is not None):
+                apply(fd, rows, Gd, Gf if gF is not None else None)
+            if fw is not None and gW is not None:
+                apply(fw, rows, Gw)
 
     # ---- exact lazy regularised / Adam update (csrc/lazy.hip) -------------------------------------------------
     @staticmethod
