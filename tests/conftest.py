@@ -17,7 +17,7 @@ def pytest_configure(config):
 # kernel-level parity first, then the layers / models / fit() that sit on those kernels: with `-x` one late failure in a
 # model test must not hide the kernels' own tests (round-1 verdict).  Files not listed keep their alphabetical place
 # after these.
-GPU_ORDER = ["test_gpu_update.py", "test_gpu_pairwise.py", "test_gpu_cin.py", "test_gpu_mlp.py", "test_gpu_dense_multi.py", "test_gpu_shard_kernels.py",
+GPU_ORDER = ["test_gpu_update.py", "test_gpu_update_general.py", "test_gpu_pairwise.py", "test_gpu_cin.py", "test_gpu_mlp.py", "test_gpu_dense_multi.py", "test_gpu_shard_kernels.py",
              "test_gpu_deepfm.py",
              "test_gpu_fullsize.py", "test_gpu_lazy.py", "test_gpu_parallel.py", "test_gpu_checkpoint.py",
              "test_gpu_models.py", "test_gpu_fit.py", "test_gpu_reference_matrix.py", "test_api_variants.py"]

@@ -1,0 +1,235 @@
+"""GPU: the deterministic sorted update on GENERAL units (round 5) -- pooled VarLenSparseFeat fields (sum / mean / max, mask and
+length mode: inputs.py:141-155, sequence.py:49-77) and tables shared through ``embedding_name`` (inputs.py:158-180) -- against
+the numpy oracle (oracle/np_oracle.py, fp64; pinned to the reference by tests/test_oracle_golden.py) at sizes the small golden
+fixtures do not reach: batch 4096, 16-float rows, 100 000-row tables, histories of 8 and 50 positions, hot ids whose
+partitions overflow the pre-pass buckets.  Also: bit-reproducibility, pre-pass / in-kernel-scan agreement, and that no
+float-atomic entry point (dctr_embed_bwd / dctr_embed_apply) is reachable from a pooled or shared-table model."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_model, load_golden, max_abs
+from np_oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _sp(name, vocab, dim, emb=None):
+    return {"kind": "sparse", "name": name, "vocab": vocab, "dim": dim, "embedding_name": emb or name}
+
+
+def _vl(name, vocab, dim, maxlen, combiner, length_name=None, emb=None):
+    return {"kind": "varlen", "name": name, "vocab": vocab, "dim": dim, "maxlen": maxlen, "combiner": combiner,
+            "length_name": length_name, "embedding_name": emb or name}
+
+
+def _spec(dim, big, hist_len):
+    """user, item, item2 (shares item's table), a sum history over the item table, a mean history with a length column,
+    a max history, two dense columns."""
+    V = 100_000 if big else 37
+    cols = [_sp("user", V, dim), _sp("item", V // 2 + 3, dim), _sp("item2", V // 2 + 3, dim, emb="item"),
+            {"kind": "dense", "name": "price", "dimension": 2},
+            _vl("hist", V // 2 + 3, dim, hist_len, "sum", emb="item"),
+            _vl("tags", 1000 if big else 11, dim, 5, "mean", length_name="tags_len"),
+            _vl("kw", 300 if big else 9, dim, 3, "max"),
+            _vl("mhist", 5000 if big else 13, dim, 4, "mean")]
+    return {"model": "DeepFM", "linear_columns": cols, "dnn_columns": cols,
+            "kwargs": {"dnn_hidden_units": [16, 8], "dnn_dropout": 0, "init_std": 0.05, "seed": 7}}
+
+
+def _data(spec, B, mode, seed):
+    """X in build_input_features order (inputs.py:99-123): columns as listed, a VarLen's positions then -- appended by the first
+    VarLen that names it -- its length column."""
+    g = np.random.RandomState(seed)
+    parts = []
+    for c in spec["dnn_columns"]:
+        V = c.get("vocab", 0)
+
+        def ids(shape):
+            if mode == "hot":       # one id takes ~85 % of the entries: partitions overflow the pre-pass buckets
+                return np.where(g.rand(*shape) < 0.85, min(5, V - 1), g.randint(1, V, shape))
+            return g.randint(1, V, shape)
+        if c["kind"] == "sparse":
+            parts.append(ids((B, 1)).astype(np.float32))
+        elif c["kind"] == "dense":
+            parts.append(g.rand(B, c["dimension"]).astype(np.float32))
+        else:
+            T = c["maxlen"]
+            seq = ids((B, T))
+            # (0: an empty history -- except under 'max', where it pools to embedding - 1e9 and the reference's own value
+            # is rounding noise: tests/matrix_data.py clean_rows)
+            n = g.randint(1 if c["combiner"] == "max" else 0, T + 1, (B, 1))
+            seq = np.where(np.arange(T)[None, :] < n, seq, 0)   # padded with id 0
+            parts.append(seq.astype(np.float32))
+            if c["length_name"] is not None:
+                parts.append(n.astype(np.float32))
+    X = np.concatenate(parts, axis=1)
+    y = g.randint(0, 2, B).astype(np.float32)
+    return X, y
+
+
+def _fresh(spec, seed=3):
+    torch.manual_seed(seed)
+    m = build_model(spec, DEV)
+    params = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+    return m, params
+
+
+CASES = [(64, 4, False, 4, "uniform"), (777, 6, False, 4, "uniform"), (300, 5, False, 3, "hot"),
+         (4096, 16, True, 8, "uniform"), (4096, 16, True, 8, "hot"), (2048, 16, True, 50, "uniform"),
+         (4096, 8, True, 8, "hot")]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "B%d_D%d_T%d_%s" % (c[0], c[1], c[3], c[4]))
+@pytest.mark.parametrize("opt", ["dense", "sgd", "adagrad"])
+def test_general_units_match_the_oracle(case, opt):
+    B, dim, big, T, mode = case
+    spec = _spec(dim, big, T)
+    m, params = _fresh(spec)
+    plan = m.model_plan()
+    assert not plan.simple_units and plan.unit_path and plan.gen is not None
+    X, y = _data(spec, B, mode, seed=B + T)
+    Xd, yd = torch.from_numpy(X).to(DEV), torch.from_numpy(y).to(DEV)
+    o = Oracle(spec, params, dtype=np.float64)
+    if opt == "dense":
+        m.train()
+        loss = torch.nn.functional.binary_cross_entropy(m(Xd).squeeze(), yd, reduction="sum")
+        m.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        plan.check_ids()
+        _, y_pred = o.forward(X)
+        grads = o.backward(y_pred - y.reshape(-1, 1))
+        for k, p in m.named_parameters():
+            ref = np.asarray(grads[k]).reshape(p.shape)
+            scale = max(1.0, float(np.max(np.abs(ref))))
+            err = max_abs(p.grad.cpu().numpy(), ref)
+            assert err <= 2e-5 * scale, "%s: max|d|=%.3e scale %.3g" % (k, err, scale)
+        return
+    lr = 0.01
+    m.compile(opt, "binary_crossentropy", metrics=[])
+    assert plan.update[0] == opt
+    m.train()
+    st = None
+    for step in range(2):
+        loss, _, _ = m._train_step(Xd, yd)
+        lo, st = o.train_step(X, y, optimizer=opt, lr=lr, eps=1e-10, state=st)
+        assert abs(loss.item() - lo) <= 2e-5 * max(1.0, abs(lo))
+    torch.cuda.synchronize()
+    plan.check_ids()
+    sd = m.state_dict()
+    for k, v in o.P.items():
+        err = max_abs(sd[k].cpu().numpy(), v)
+        # Adagrad's first steps are lr * sign(g): an element whose gradient cancels to ~1e-9 in fp32 lands on either side
+        # (the reference's own fp32 run does the same, tests/test_gpu_models.py) -- bounded by 2 lr there
+        bar = 2e-5 * max(1.0, float(np.max(np.abs(v)))) if opt == "sgd" else 2e-5 + 0.0
+        if opt == "adagrad":
+            d = np.abs(sd[k].cpu().numpy().astype(np.float64) - np.asarray(v, np.float64).reshape(sd[k].shape))
+            frac_bad = float((d > 2e-5).mean())
+            assert frac_bad <= 2e-4 and float(d.max()) <= 2.5 * lr, "%s: %.3e (%.2e of elements off)" % (k, d.max(), frac_bad)
+        else:
+            assert err <= bar, "%s: %.3e" % (k, err)
+
+
+def test_general_update_is_bit_reproducible():
+    """Same inputs -> bit-identical tables and optimizer state, run to run (no atomics, fixed summation order): the property
+    tests/test_gpu_update.py::test_update_kernel_is_bit_reproducible checks for fixed-length fields, for a pooled model."""
+    spec = _spec(16, True, 8)
+    X, y = _data(spec, 4096, "hot", seed=5)
+    Xd, yd = torch.from_numpy(X).to(DEV), torch.from_numpy(y).to(DEV)
+    results = []
+    for rep in range(3):
+        m, _ = _fresh(spec)
+        m.compile("adagrad", "binary_crossentropy", metrics=[])
+        m.train()
+        for _ in range(3):
+            m._train_step(Xd, yd)
+        torch.cuda.synchronize()
+        plan = m.model_plan()
+        results.append([p.detach().clone().contiguous() for p in plan.table_params] +
+                       [m.optim.state[p]["sum"].clone().contiguous() for p in plan.table_params])
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("mode,B", [("uniform", 4096), ("hot", 4096), ("hot", 20000)])
+def test_general_prepass_and_inkernel_scan_agree_bit_for_bit(monkeypatch, mode, B):
+    """Pre-pass on the side stream (tag scan; one atomic per entry from 65 536 entries per unit), no separate pre-pass
+    (the update buckets in line), no workspace at all (every workgroup scans and sorts for itself): identical bits."""
+    spec = _spec(16, True, 8)
+    X, y = _data(spec, B, mode, seed=11)
+    Xd, yd = torch.from_numpy(X).to(DEV), torch.from_numpy(y).to(DEV)
+    results = []
+    for seg, bucket in (("1", "auto"), ("0", "auto"), ("0", "1"), ("0", "0")):
+        monkeypatch.setenv("DCTR_SEGMENTS", seg)
+        monkeypatch.setenv("DCTR_UPD_BUCKET", bucket)
+        m, _ = _fresh(spec)
+        m.compile("adagrad", "binary_crossentropy", metrics=[])
+        m.train()
+        for _ in range(2):
+            m._train_step(Xd, yd)
+        torch.cuda.synchronize()
+        m.model_plan().check_ids()
+        plan = m.model_plan()
+        results.append([p.detach().clone().contiguous() for p in plan.table_params] +
+                       [m.optim.state[p]["sum"].clone().contiguous() for p in plan.table_params])
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            assert torch.equal(a, b)
+
+
+def _forbid_atomics(monkeypatch):
+    from deepctr_torch._hip import lib as L
+
+    def boom(*a, **k):
+        raise AssertionError("the float-atomic scatter was reached")
+    lib = L.lib()
+    monkeypatch.setattr(lib, "dctr_embed_bwd", boom, raising=False)
+    monkeypatch.setattr(lib, "dctr_embed_apply", boom, raising=False)
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adagrad", "adam"])
+def test_no_atomic_scatter_reachable_from_the_mixed_golden(monkeypatch, opt):
+    """tests/golden/deepfm_mixed (sum / mean / max pooling, a history sharing the item table, a length column) trains through
+    the sorted update in every update mode: 'sgd' / 'adagrad' in kernel, 'adam' through the dense-gradient (accumulate) mode."""
+    _forbid_atomics(monkeypatch)
+    g = load_golden("deepfm_mixed")
+    m = build_model(g["spec"], DEV)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in g["params"].items()})
+    m.compile(opt, "binary_crossentropy", metrics=[])
+    m.train()
+    assert m.model_plan().unit_path
+    losses = [m._train_step(torch.from_numpy(Xb).to(DEV), torch.from_numpy(yb).to(DEV))[0].item()
+              for Xb, yb in zip(g["extra"]["X_steps"], g["extra"]["y_steps"])]
+    torch.cuda.synchronize()
+    if opt != "adam":
+        np.testing.assert_allclose(losses, g["extra"][opt + "3_loss"], rtol=2e-5)
+
+
+@pytest.mark.parametrize("model,kw", [("DeepFM", dict(dnn_hidden_units=(32,))), ("xDeepFM", dict(dnn_hidden_units=(16,), cin_layer_size=(8, 8))),
+                                      ("FiBiNET", dict(dnn_hidden_units=(16,))), ("DCN", dict(dnn_hidden_units=(16,))),
+                                      ("PNN", dict(dnn_hidden_units=(16,))), ("WDL", dict(dnn_hidden_units=(16,))),
+                                      ("NFM", dict(dnn_hidden_units=(16,))), ("AutoInt", dict(dnn_hidden_units=(16,)))])
+@pytest.mark.parametrize("with_len", [False, True])
+def test_reference_test_data_takes_the_unit_path(monkeypatch, model, kw, with_len):
+    """The data of the reference's own model tests (tests/utils.py:19-66 restated in tests/matrix_data.py: sum / mean / max VarLen
+    columns over 1-9 row vocabularies, id 0 as padding): plan.unit_path, a train-mode forward + backward and an Adagrad fit
+    through the sorted update, the atomic entry points never called."""
+    _forbid_atomics(monkeypatch)
+    import deepctr_torch.models as M
+    from matrix_data import make_data
+    seqs = ("sum", "mean") if with_len else ("sum", "mean", "max")
+    x, y, cols = make_data(1, 3, 2, include_length=with_len, seqs=seqs)
+    m = M.PNN(cols, device=DEV, **kw) if model == "PNN" else getattr(M, model)(cols, cols, device=DEV, **kw)
+    plan = m.model_plan()
+    assert plan.unit_path and plan.gen is not None and not plan.simple_units
+    X = m._as_matrix([x[name] for name in m.feature_index])
+    yd = torch.from_numpy(np.asarray(y, np.float32)).to(DEV)
+    m.train()
+    torch.nn.functional.binary_cross_entropy(m(X).squeeze(1), yd, reduction="sum").backward()
+    torch.cuda.synchronize()
+    m.compile("adagrad", "binary_crossentropy", metrics=[])
+    hist = m.fit(x, y, batch_size=32, epochs=2, verbose=0)
+    assert np.isfinite(hist.history["loss"]).all()
