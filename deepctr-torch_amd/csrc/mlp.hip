@@ -119,6 +119,11 @@ struct GatherArgs {
   int64_t lds;
   int32_t* err;                // nullable
   int n_deep, n_wide, n_dense, n_wdense, nc, dense_off, D, lpr_shift, want_fm, scratch_off;
+  // pooled VarLen fields (sum / mean; round 5): deep fields [n_deep_fixed, n_deep) and wide fields [n_wide_fixed, n_wide) are
+  // pooled over their positions; gsd / gsw list those positions in field order, entry = (field << 16) | position
+  int n_deep_fixed, n_wide_fixed, n_gsd, n_gsw;
+  const int32_t* gsd;
+  const int32_t* gsw;
 };
 
 
@@ -827,15 +832,22 @@ struct GatherLds {
   const int32_t* dcol;        // [n_dense]
   const int32_t* wcol;        // [n_wdense]
   const float* ww;            // [n_wdense]
+  const int32_t* gsd;         // [n_gsd] pooled deep positions
+  const int32_t* gsw;         // [n_gsw] pooled wide positions
   float* wv;                  // [16][32] the wide tables' values (0 past n_wide / B)
   float* st;                  // [16][D] sum_f e
   float* tm;                  // [16][D] (sum_f e)^2 - sum_f e^2
+  float* pb;                  // [16][n_gsd][D] the rows of the pooled deep fields' positions (0 where masked out)
+  float* pw;                  // [16][n_gsw] the pooled wide fields' values per position
 };
-__host__ __device__ __forceinline__ int gather_stage_words(int n_deep, int n_wide, int nc, int n_dense, int n_wdense) {
-  return 16 * (n_deep + n_wide) + kTM * nc + n_dense + 2 * n_wdense;
+__host__ __device__ __forceinline__ int gather_stage_words(int n_deep, int n_wide, int nc, int n_dense, int n_wdense,
+                                                           int n_gsd = 0, int n_gsw = 0) {
+  return 16 * (n_deep + n_wide) + kTM * nc + n_dense + 2 * n_wdense + n_gsd + n_gsw;
 }
-__host__ __device__ __forceinline__ int gather_lds_words(int n_deep, int n_wide, int nc, int n_dense, int n_wdense, int D) {
-  return round_up(gather_stage_words(n_deep, n_wide, nc, n_dense, n_wdense), 4) + kTM * 32 + 2 * kTM * D;
+__host__ __device__ __forceinline__ int gather_lds_words(int n_deep, int n_wide, int nc, int n_dense, int n_wdense, int D,
+                                                         int n_gsd = 0, int n_gsw = 0) {
+  return round_up(gather_stage_words(n_deep, n_wide, nc, n_dense, n_wdense, n_gsd, n_gsw), 4) + kTM * 32 + 2 * kTM * D +
+         kTM * n_gsd * D + round_up(kTM * n_gsw, 4);
 }
 __device__ __forceinline__ GatherLds gather_lds(const GatherArgs& G, float* base) {
   GatherLds S;
@@ -846,10 +858,15 @@ __device__ __forceinline__ GatherLds gather_lds(const GatherArgs& G, float* base
   S.dcol = reinterpret_cast<const int32_t*>(w); w += G.n_dense;
   S.wcol = reinterpret_cast<const int32_t*>(w); w += G.n_wdense;
   S.ww = reinterpret_cast<const float*>(w); w += G.n_wdense;
-  w = reinterpret_cast<uint32_t*>(base) + round_up(gather_stage_words(G.n_deep, G.n_wide, G.nc, G.n_dense, G.n_wdense), 4);
+  S.gsd = reinterpret_cast<const int32_t*>(w); w += G.n_gsd;
+  S.gsw = reinterpret_cast<const int32_t*>(w); w += G.n_gsw;
+  w = reinterpret_cast<uint32_t*>(base) +
+      round_up(gather_stage_words(G.n_deep, G.n_wide, G.nc, G.n_dense, G.n_wdense, G.n_gsd, G.n_gsw), 4);
   S.wv = reinterpret_cast<float*>(w); w += kTM * 32;
   S.st = reinterpret_cast<float*>(w); w += kTM * G.D;
-  S.tm = reinterpret_cast<float*>(w);
+  S.tm = reinterpret_cast<float*>(w); w += kTM * G.D;
+  S.pb = reinterpret_cast<float*>(w); w += kTM * G.n_gsd * G.D;
+  S.pw = reinterpret_cast<float*>(w);
   return S;
 }
 
@@ -881,7 +898,7 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
     S = gather_lds(G, smem + G.scratch_off);
     uint32_t* stage = reinterpret_cast<uint32_t*>(smem + G.scratch_off);
     const int e0 = 16 * G.n_deep, e1 = e0 + 16 * G.n_wide, e2 = e1 + kTM * G.nc, e3 = e2 + G.n_dense, e4 = e3 + G.n_wdense,
-              e5 = e4 + G.n_wdense;
+              e4b = e4 + G.n_wdense, e4c = e4b + G.n_gsd, e5 = e4c + G.n_gsw;
     const int64_t blast = A.B - 1;
     uint32_t sv[4];
 #pragma unroll
@@ -897,10 +914,13 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
       src = idx >= e2 ? reinterpret_cast<const uint32_t*>(G.dense_cols) + (idx - e2) : src;
       src = idx >= e3 ? reinterpret_cast<const uint32_t*>(G.wdense_cols) + (idx - e3) : src;
       src = idx >= e4 ? reinterpret_cast<const uint32_t*>(G.wdense_w) + (idx - e4) : src;
+      src = idx >= e4b ? reinterpret_cast<const uint32_t*>(G.gsd) + (idx - e4b) : src;
+      src = idx >= e4c ? reinterpret_cast<const uint32_t*>(G.gsw) + (idx - e4c) : src;
       sv[s_] = *(const DCTR_GLOBAL uint32_t*)src;
     }
     // the tile's columns that no table row fills (dense block, padding up to K0p) start as zeros
-    const int nqd = G.n_deep << G.lpr_shift;
+    const int nqd = G.n_deep << G.lpr_shift;          // quads of the row that table rows fill ...
+    const int nqf = G.n_deep_fixed << G.lpr_shift;    // ... of which the fixed-length fields' (one row each)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = xq + 32 * i;
@@ -920,21 +940,61 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = xq + 32 * i;
-      const int qq = q < nqd ? q : nqd - 1;
+      const int qq = q < nqf ? q : nqf - 1;
       const dctr_field_t& fd = S.deep[qq >> G.lpr_shift];
       const int32_t rid = static_cast<int32_t>(xrow[fd.col]);            // Tensor.long(): truncation (basemodel.py:369)
       const bool oob = static_cast<uint32_t>(rid) >= static_cast<uint32_t>(fd.vocab);
-      bad |= (oob && q < nqd) ? 1 : 0;
+      bad |= (oob && q < nqf) ? 1 : 0;
       const int64_t id = oob ? 0 : rid;
       xv[i] = ldg_f4(fd.table + id * row_ld(fd) + 4 * (qq & lmask));
     }
     float wval = 0.f;
-    if (G.n_wide > 0) {
-      const dctr_field_t& fw = S.wide[xq < G.n_wide ? xq : G.n_wide - 1];
+    if (G.n_wide_fixed > 0) {
+      const dctr_field_t& fw = S.wide[xq < G.n_wide_fixed ? xq : G.n_wide_fixed - 1];
       const int32_t rid = static_cast<int32_t>(xrow[fw.col]);
       const bool oob = static_cast<uint32_t>(rid) >= static_cast<uint32_t>(fw.vocab);
-      bad |= (oob && xq < G.n_wide) ? 1 : 0;
+      bad |= (oob && xq < G.n_wide_fixed) ? 1 : 0;
       wval = ldg_f32(fw.table + (oob ? 0 : static_cast<int64_t>(rid)) * row_ld(fw));
+    }
+    // pooled VarLen fields (inputs.py:141-155, sequence.py:49-77): every position's row, up to four 16-byte pieces and one
+    // wide value per thread, in flight with the rows above; a masked-out position (id == 0, or t >= length) parks zeros
+    f32x4 pv[4];
+    int pdst[4];
+    float pwv = 0.f;
+    int pwdst = -1;
+    if (G.n_gsd > 0) {
+      const int per_row = G.n_gsd << G.lpr_shift, ni = kTM * per_row;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int w_ = tid + kT * i;
+        const int wc = w_ < ni ? w_ : ni - 1;
+        const int r = wc / per_row, rem = wc - r * per_row;
+        const int sl_ = rem >> G.lpr_shift, piece = rem & lmask;
+        const int ft = S.gsd[sl_];
+        const dctr_field_t& fd = S.deep[ft >> 16];
+        const int t = ft & 0xFFFF;
+        const float* xr_ = S.x + r * G.nc;
+        const int32_t rid = static_cast<int32_t>(xr_[fd.col + t]);
+        const bool m = fd.len_col >= 0 ? (t < static_cast<int32_t>(xr_[fd.len_col])) : (rid != 0);
+        const bool oob = static_cast<uint32_t>(rid) >= static_cast<uint32_t>(fd.vocab);
+        const bool live = w_ < ni && b0 + r < A.B;
+        bad |= (oob && live) ? 1 : 0;
+        pv[i] = ldg_f4(fd.table + (oob ? 0 : static_cast<int64_t>(rid)) * row_ld(fd) + 4 * piece);
+        pdst[i] = w_ < ni ? ((r * G.n_gsd + sl_) * G.D + 4 * piece) | ((m && live) ? 0 : (1 << 30)) : -1;
+      }
+    }
+    if (G.n_gsw > 0 && tid < kTM * G.n_gsw) {
+      const int r = tid / G.n_gsw, sl_ = tid - r * G.n_gsw;
+      const int ft = S.gsw[sl_];
+      const dctr_field_t& fw = S.wide[ft >> 16];
+      const int t = ft & 0xFFFF;
+      const float* xr_ = S.x + r * G.nc;
+      const int32_t rid = static_cast<int32_t>(xr_[fw.col + t]);
+      const bool m = fw.len_col >= 0 ? (t < static_cast<int32_t>(xr_[fw.len_col])) : (rid != 0);
+      const bool oob = static_cast<uint32_t>(rid) >= static_cast<uint32_t>(fw.vocab);
+      bad |= (oob && b0 + r < A.B) ? 1 : 0;
+      pwv = ldg_f32(fw.table + (oob ? 0 : static_cast<int64_t>(rid)) * row_ld(fw));
+      pwdst = tid | ((m && b0 + r < A.B) ? 0 : (1 << 30));
     }
     fwd_bias_ld(A.L[0], wv, c, braw);
     __builtin_amdgcn_sched_barrier(0);
@@ -952,11 +1012,56 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = xq + 32 * i;
-      if (q < nqd) *reinterpret_cast<f32x4*>(xs + xr * rsx + 4 * q) = rvalid ? xv[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (q < nqf) *reinterpret_cast<f32x4*>(xs + xr * rsx + 4 * q) = rvalid ? xv[i] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    S.wv[xr * 32 + xq] = (rvalid && xq < G.n_wide) ? wval : 0.f;
+    S.wv[xr * 32 + xq] = (rvalid && xq < G.n_wide_fixed) ? wval : 0.f;
+    if (G.n_gsd > 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (pdst[i] >= 0)
+          *reinterpret_cast<f32x4*>(S.pb + (pdst[i] & ~(1 << 30))) = (pdst[i] >> 30) ? f32x4{0.f, 0.f, 0.f, 0.f} : pv[i];
+    }
+    if (pwdst >= 0) S.pw[pwdst & ~(1 << 30)] = (pwdst >> 30) ? 0.f : pwv;
     if (bad && G.err) atomicOr(G.err, 1);
     __syncthreads();
+    if (G.n_deep > G.n_deep_fixed || G.n_wide > G.n_wide_fixed) {
+      // ---- the pooling itself, in pool_field's order (csrc/embed.hip): positions added one after the other, a masked-out
+      // position adds nothing; mean divides by (count | length) + 1e-8 (sequence.py:72-74)
+#pragma clang fp contract(off)
+      const int lpr = 1 << G.lpr_shift;
+      const int npd = G.n_deep - G.n_deep_fixed, npw = G.n_wide - G.n_wide_fixed;
+      for (int e = tid; e < kTM * (npd * lpr + npw); e += kT) {
+        const int r = e / (npd * lpr + npw), rem = e - r * (npd * lpr + npw);
+        const bool deep_item = rem < npd * lpr;
+        const int fi = deep_item ? G.n_deep_fixed + (rem >> G.lpr_shift) : G.n_wide_fixed + (rem - npd * lpr);
+        const int piece = deep_item ? (rem & lmask) : 0;
+        const dctr_field_t& fd = deep_item ? S.deep[fi] : S.wide[fi];
+        int base = 0;     // the field's first position in the flattened list
+        for (int g2 = deep_item ? G.n_deep_fixed : G.n_wide_fixed; g2 < fi; ++g2) base += (deep_item ? S.deep[g2] : S.wide[g2]).len;
+        const float* xr_ = S.x + r * G.nc;
+        const bool by_len = fd.len_col >= 0;
+        float den = 1.f;
+        if (fd.pool == DCTR_POOL_MEAN) {
+          float cnt = 0.f;
+          if (by_len) cnt = static_cast<float>(static_cast<int32_t>(xr_[fd.len_col]));
+          else
+            for (int t = 0; t < fd.len; ++t) cnt += (static_cast<int32_t>(xr_[fd.col + t]) != 0) ? 1.f : 0.f;
+          den = cnt + 1e-8f;
+        }
+        if (deep_item) {
+          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int t = 0; t < fd.len; ++t) acc += *reinterpret_cast<const f32x4*>(S.pb + (r * G.n_gsd + base + t) * G.D + 4 * piece);
+          if (fd.pool == DCTR_POOL_MEAN) acc = f32x4{acc.x / den, acc.y / den, acc.z / den, acc.w / den};
+          *reinterpret_cast<f32x4*>(xs + r * rsx + fi * G.D + 4 * piece) = (b0 + r < A.B) ? acc : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+          float acc = 0.f;
+          for (int t = 0; t < fd.len; ++t) acc += S.pw[r * G.n_gsw + base + t];
+          if (fd.pool == DCTR_POOL_MEAN) acc = acc / den;
+          S.wv[r * 32 + fi] = (b0 + r < A.B) ? acc : 0.f;
+        }
+      }
+      __syncthreads();
+    }
     // ---- FM's per-sample sums in k_embed_fwd's order of additions: wave w of that kernel takes fields w, w + 4, ...; its
     // wave 0 then adds the four partial sums in wave order
     for (int e = tid; e < kTM * G.D; e += kT) {
@@ -965,7 +1070,12 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
       float st = 0.f, qt = 0.f;
       for (int w = 0; w < 4; ++w) {
         float sw = 0.f, qw = 0.f;
-        for (int f = w; f < G.n_deep; f += 4) {
+        for (int f = w; f < G.n_deep_fixed; f += 4) {
+          const float v = xs[r * rsx + f * G.D + d];
+          sw += v;
+          qw += v * v;
+        }
+        for (int f = G.n_deep_fixed + w; f < G.n_deep; f += 4) {     // (k_embed_fwd: the wave's pooled fields follow)
           const float v = xs[r * rsx + f * G.D + d];
           sw += v;
           qw += v * v;
@@ -1085,7 +1195,8 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
           float wt = 0.f;
           for (int w = 0; w < 4; ++w) {
             float pw = 0.f;
-            for (int f = w * lpr + gl; f < G.n_wide; f += 4 * lpr) pw += S.wv[r * 32 + f];
+            for (int f = w * lpr + gl; f < G.n_wide_fixed; f += 4 * lpr) pw += S.wv[r * 32 + f];
+            for (int f = G.n_wide_fixed + w * lpr + gl; f < G.n_wide; f += 4 * lpr) pw += S.wv[r * 32 + f];   // pooled
             if (G.wdense_w)
               for (int j = w * lpr + gl; j < G.n_wdense; j += 4 * lpr)
                 pw += S.x[r * G.nc + S.wcol[j]] * S.ww[j];
@@ -2691,7 +2802,16 @@ int lpr_shift_of(int D) {
 
 // the plans / towers the fused gather stage takes (everything else keeps dctr_embed_fwd + dctr_mlp_train_step)
 int gather_envelope(const dctr_plan_t* p, const dctr_mlp_t* m, int32_t B, const TrainGeom& T) {
-  if (!p || !p->deep || p->n_deep < 1 || p->n_deep != p->n_deep_fixed || p->n_wide != p->n_wide_fixed) return DCTR_ENOSUP;
+  if (!p || !p->deep || p->n_deep < 1 || p->n_deep_fixed < 1) return DCTR_ENOSUP;
+  // pooled VarLen fields: sum / mean only (max pooling's arg-max side output comes from dctr_embed_fwd), their positions
+  // listed in the ext block, at most four 16-byte pieces and one wide value per thread of the 16-sample tile
+  const bool pooled = p->n_deep != p->n_deep_fixed || p->n_wide != p->n_wide_fixed;
+  const int n_gsd = (pooled && p->ext) ? p->ext->n_gslot_deep : 0, n_gsw = (pooled && p->ext) ? p->ext->n_gslot_wide : 0;
+  if (pooled) {
+    if (!p->ext || (p->flags & DCTR_PLAN_HAS_MAXPOOL) || !p->ext->gslot_deep || !p->ext->gslot_wide) return DCTR_ENOSUP;
+    if ((p->n_deep != p->n_deep_fixed) != (n_gsd > 0) || (p->n_wide != p->n_wide_fixed) != (n_gsw > 0)) return DCTR_ENOSUP;
+    if (p->emb_dim <= 0 || kTM * n_gsd * (p->emb_dim / 4) > 4 * kT || kTM * n_gsw > kT) return DCTR_ENOSUP;
+  }
   if (p->n_wide > 32 || p->n_wide < 0 || (p->n_wide && !p->wide)) return DCTR_ENOSUP;
   if (p->vec != 4 || lpr_shift_of(p->emb_dim) < 0) return DCTR_ENOSUP;
   const int width = p->n_deep * p->emb_dim;
@@ -2699,8 +2819,8 @@ int gather_envelope(const dctr_plan_t* p, const dctr_mlp_t* m, int32_t B, const 
   if (m->layer[0].K != width + p->n_dense) return DCTR_ENOSUP;
   if (!T.a.fast || T.bwd_off <= 0) return DCTR_ENOSUP;
   const int n_wdense = p->wdense_w ? p->n_wdense : 0;
-  if (gather_stage_words(p->n_deep, p->n_wide, p->n_xcols, p->n_dense, n_wdense) > 4 * kT) return DCTR_ENOSUP;
-  if (gather_lds_words(p->n_deep, p->n_wide, p->n_xcols, p->n_dense, n_wdense, p->emb_dim) > 2 * kTM * T.a.rsd)
+  if (gather_stage_words(p->n_deep, p->n_wide, p->n_xcols, p->n_dense, n_wdense, n_gsd, n_gsw) > 4 * kT) return DCTR_ENOSUP;
+  if (gather_lds_words(p->n_deep, p->n_wide, p->n_xcols, p->n_dense, n_wdense, p->emb_dim, n_gsd, n_gsw) > 2 * kTM * T.a.rsd)
     return DCTR_ENOSUP;
   (void)B;
   return DCTR_OK;
@@ -2749,6 +2869,10 @@ extern "C" int dctr_embed_tower_train_step(const dctr_plan_t* plan, const float*
   G.n_wdense = plan->wdense_w ? plan->n_wdense : 0;
   G.nc = plan->n_xcols; G.dense_off = plan->dense_off; G.D = plan->emb_dim; G.lpr_shift = lpr_shift_of(plan->emb_dim);
   G.want_fm = want_fm ? 1 : 0; G.scratch_off = T.bwd_off;
+  G.n_deep_fixed = plan->n_deep_fixed; G.n_wide_fixed = plan->n_wide_fixed;
+  const bool pooled = plan->n_deep != plan->n_deep_fixed || plan->n_wide != plan->n_wide_fixed;
+  G.n_gsd = pooled ? plan->ext->n_gslot_deep : 0; G.n_gsw = pooled ? plan->ext->n_gslot_wide : 0;
+  G.gsd = pooled ? plan->ext->gslot_deep : nullptr; G.gsw = pooled ? plan->ext->gslot_wide : nullptr;
   if (T.lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_embed_tower_train),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(T.lds));

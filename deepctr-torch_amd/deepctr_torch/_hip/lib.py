@@ -55,7 +55,9 @@ class PlanExt(ctypes.Structure):
                 ("am_wide_off", ctypes.c_void_p), ("h_vunits", ctypes.c_void_p), ("h_vocab", ctypes.c_void_p),
                 ("den_t", ctypes.c_void_p), ("amax", ctypes.c_void_p),
                 ("n_vcols", ctypes.c_int32), ("n_vunits", ctypes.c_int32), ("n_units", ctypes.c_int32),
-                ("max_unit_slots", ctypes.c_int32), ("n_den", ctypes.c_int32), ("ld_amax", ctypes.c_int32)]
+                ("max_unit_slots", ctypes.c_int32), ("n_den", ctypes.c_int32), ("ld_amax", ctypes.c_int32),
+                ("gslot_deep", ctypes.c_void_p), ("gslot_wide", ctypes.c_void_p),
+                ("n_gslot_deep", ctypes.c_int32), ("n_gslot_wide", ctypes.c_int32)]
 
 
 MAX_UNIT_SLOTS = 128

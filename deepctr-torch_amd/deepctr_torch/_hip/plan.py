@@ -652,6 +652,12 @@ class EmbeddingPlan(object):
             x.den_t = x.amax = None
             x.n_vcols, x.n_vunits, x.n_units = len(g["slots"]), len(g["vunits"]), len(self.units)
             x.max_unit_slots, x.n_den, x.ld_amax = g["max_unit_slots"], g["n_den"], g["ld_amax"]
+            gsd = [(i << 16) | t for i, f in enumerate(self.deep) if f.pool != 0 for t in range(f.len)]
+            gsw = [(i << 16) | t for i, f in enumerate(self.wide) if f.pool != 0 for t in range(f.len)]
+            self._dev["gslot_deep"] = up(np.asarray(gsd or [0], dtype=np.int32).tobytes(), torch.int32)
+            self._dev["gslot_wide"] = up(np.asarray(gsw or [0], dtype=np.int32).tobytes(), torch.int32)
+            x.gslot_deep, x.gslot_wide = self._dev["gslot_deep"].data_ptr(), self._dev["gslot_wide"].data_ptr()
+            x.n_gslot_deep, x.n_gslot_wide = len(gsd), len(gsw)
             self.cext, self._host_ext = x, (vu, hv)
             c.ext = ctypes.addressof(x)
             self.point_step_buffers(*getattr(self, "_step_bufs", (None, None)))

