@@ -51,6 +51,9 @@ def parse():
                     help="skip the xDeepFM / FiBiNET legs (BASELINE.json configs 3-4) of the N=1 line")
     ap.add_argument("--force-parallel", action="store_true", help="use the data-parallel trainer even with 1 rank")
     ap.add_argument("--no-saturating", action="store_true", help="skip the saturating-launch leg (B_eff 262 144)")
+    ap.add_argument("--legs", default="all",
+                    help="comma-separated subset of the N = 1 line's other_configs to run (xdeepfm, fibinet, deepfm_varlen, "
+                         "default_kwargs, fit_api, sharded_1rank); 'all' by default")
     ap.add_argument("--exchange", default=os.environ.get("DCTR_SHARDED_EXCHANGE", "auto"),
                     choices=["auto", "rccl", "direct", "try-direct"],
                     help="how the table-sharded step exchanges rows / gradients / dense gradients between ranks: 'rccl' = "
@@ -570,7 +573,7 @@ def deepfm_leg(tag, args, device, X, y):
                "unit": "samples/s", "ms_per_step": elapsed / args.steps * 1e3, "steps": args.steps, "warmup": did,
                "hip_graph": graphed, "final_loss": float(out[0].item()), "timing": spread(times, args.steps),
                "update_mode": plan.update[0], "unit_path": bool(plan.unit_path),
-               "step_engine": bool(st is not None and st.get("engine") is not None)}
+               "step_engine": bool(st is not None and st.get("engine") is not None and st["engine"].steps_run > 0)}
         del model, Xl
         torch.cuda.empty_cache()
         return res
@@ -939,15 +942,19 @@ def main():
         if world == 1 and not args.no_other_configs:
             del model
             torch.cuda.empty_cache()
-            result["other_configs"] = {name: other_config(name, args, device, X, y) for name in OTHER}
+            want = (lambda t: True) if args.legs == "all" else (lambda t: t in args.legs.split(","))
+            result["other_configs"] = {name: other_config(name, args, device, X, y) for name in OTHER if want(name)}
             for tag in ("deepfm_varlen", "default_kwargs"):
+                if not want(tag):
+                    continue
                 result["other_configs"][tag] = deepfm_leg(tag, args, device, X, y)
                 if "ms_per_step" in result["other_configs"][tag]:
                     result["other_configs"][tag]["ms_per_step_vs_headline"] = result["other_configs"][tag]["ms_per_step"] / ms
-            result["other_configs"]["fit_api"] = fit_api(args, device, X, y)
-            if parallel is None:
+            if want("fit_api"):
+                result["other_configs"]["fit_api"] = fit_api(args, device, X, y)
+            if parallel is None and want("sharded_1rank"):
                 result["other_configs"]["sharded_1rank"] = sharded_1rank(args)
-            fa = result["other_configs"]["fit_api"]
+            fa = result["other_configs"].get("fit_api", {})
             if "value" in fa:
                 fa["vs_step_runner"] = fa["value"] / value
                 fa["shuffle_false"]["vs_step_runner"] = fa["shuffle_false"]["value"] / value

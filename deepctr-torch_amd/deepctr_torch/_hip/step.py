@@ -63,6 +63,7 @@ class GatherStep(object):
         self._events, self._ev_i = None, 0
         self.timing = None        # (start, end) events around the update on its queue: bench.py's in-step roofline
         self.timing_tower = None  # (start, end) events around the gather + tower launch on the main queue
+        self.steps_run = 0        # steps this engine enqueued (eager or captured): who asks whether it really ran
 
     # ---- applicability ------------------------------------------------------------------------------------------
     @staticmethod
@@ -170,6 +171,7 @@ class GatherStep(object):
         cuda = dev.type == "cuda"
         B = xb.shape[0]
         b = self._buffers(B, dev)
+        self.steps_run += 1
         if cuda and torch.cuda.is_current_stream_capturing():
             b.pinned = True           # a graph now holds this set's addresses: exempt from eviction
         cplan = plan.bind(dev)

@@ -16,14 +16,21 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _cols(vocab, F, D, n_dense):
-    from deepctr_torch.inputs import DenseFeat, SparseFeat
-    return [SparseFeat("C%d" % (i + 1), vocab, D) for i in range(F)] + [DenseFeat("I%d" % (i + 1), 1) for i in range(n_dense)]
+# pooled = (maxlen of a mean history over its own table [ids != 0 mask], maxlen of a sum history that shares C1's table and
+# has a length column): the general update units of round 5 -- pooled VarLen fields, a shared table -- inside the engine
+def _cols(vocab, F, D, n_dense, pooled=None):
+    from deepctr_torch.inputs import DenseFeat, SparseFeat, VarLenSparseFeat
+    cols = [SparseFeat("C%d" % (i + 1), vocab, D) for i in range(F)] + [DenseFeat("I%d" % (i + 1), 1) for i in range(n_dense)]
+    if pooled:
+        cols.append(VarLenSparseFeat(SparseFeat("hist", vocab, D), maxlen=pooled[0], combiner="mean"))
+        cols.append(VarLenSparseFeat(SparseFeat("seq", vocab, D, embedding_name="C1"), maxlen=pooled[1], combiner="sum",
+                                     length_name="seq_len"))
+    return cols
 
 
-def _model(kind, vocab, opt, F=26, D=16, n_dense=13, hidden=(256, 128)):
+def _model(kind, vocab, opt, F=26, D=16, n_dense=13, hidden=(256, 128), pooled=None):
     from deepctr_torch import models as M
-    cols = _cols(vocab, F, D, n_dense)
+    cols = _cols(vocab, F, D, n_dense, pooled)
     kw = dict(dnn_hidden_units=hidden, l2_reg_linear=0, l2_reg_embedding=0, dnn_dropout=0, seed=1024, device=DEV)
     m = M.DeepFM(cols, cols, **kw) if kind == "deepfm" else M.WDL(cols, cols, **kw)
     m.compile(opt, "binary_crossentropy", metrics=[])
@@ -31,22 +38,31 @@ def _model(kind, vocab, opt, F=26, D=16, n_dense=13, hidden=(256, 128)):
     return m
 
 
-def _data(vocab, F, n_dense, B, n_batches, seed=7):
+def _data(vocab, F, n_dense, B, n_batches, seed=7, pooled=None):
     gen = torch.Generator().manual_seed(seed)
     n = B * n_batches
     ids = torch.randint(0, vocab, (n, F), generator=gen)
-    X = torch.cat([ids.float(), torch.rand(n, n_dense, generator=gen)], dim=1).to(DEV)
+    X = torch.cat([ids.float(), torch.rand(n, n_dense, generator=gen)], dim=1)
+    if pooled:
+        T0, T1 = pooled
+        h = torch.randint(1, vocab, (n, T0), generator=gen)
+        h = h * (torch.arange(T0)[None, :] < torch.randint(0, T0 + 1, (n, 1), generator=gen))     # 0-padded, some empty
+        sq = torch.randint(0, vocab, (n, T1), generator=gen)
+        ln = torch.randint(0, T1 + 1, (n, 1), generator=gen)
+        X = torch.cat([X, h.float(), sq.float(), ln.float()], dim=1)      # (inputs.py:99-123: positions, then the length)
+    X = X.to(DEV)
     y = torch.randint(0, 2, (n,), generator=gen).float().to(DEV)
     return X, y
 
 
-def _run(engine, kind, vocab, opt, steps, graphed, B=4096, F=26, D=16, n_dense=13, hidden=(256, 128), topo=None):
+def _run(engine, kind, vocab, opt, steps, graphed, B=4096, F=26, D=16, n_dense=13, hidden=(256, 128), topo=None,
+         pooled=None):
     os.environ["DCTR_STEP_ENGINE"] = "1" if engine else "0"
     if topo:
         os.environ["DCTR_STEP_TOPOLOGY"] = topo
     try:
-        m = _model(kind, vocab, opt, F, D, n_dense, hidden)
-        X, y = _data(vocab, F, n_dense, B, 8)
+        m = _model(kind, vocab, opt, F, D, n_dense, hidden, pooled)
+        X, y = _data(vocab, F, n_dense, B, 8, pooled=pooled)
         bat = lambda i: (X[(i % 8) * B:(i % 8 + 1) * B], y[(i % 8) * B:(i % 8 + 1) * B])   # noqa: E731
         losses, preds = [], []
         i = 0
@@ -118,12 +134,23 @@ def test_engine_leaves_the_same_bits_as_the_two_launch_step(opt, graphed):
     dict(kind="deepfm", D=8, F=5, n_dense=3, hidden=(64, 32), B=1000),       # 2 lanes per row, ragged last tile (1000 = 62.5 x 16)
     dict(kind="deepfm", D=32, F=7, n_dense=0, hidden=(128,), B=512),         # 8 lanes per row, no dense block
     dict(kind="deepfm", D=4, F=30, n_dense=20, hidden=(128, 64), B=256),     # 1 lane per row, > 16 wide fields per pass
+    # pooled VarLen fields + a shared table inside the fused gather (general update units)
+    dict(kind="deepfm", pooled=(8, 5)),
+    dict(kind="wdl", D=8, F=5, n_dense=3, hidden=(64, 32), B=1000, pooled=(3, 2)),
+    dict(kind="deepfm", D=32, F=4, n_dense=0, hidden=(128,), B=512, pooled=(6, 4)),
 ])
 def test_engine_shapes(case):
     kw = dict(F=26, D=16, n_dense=13, hidden=(256, 128), B=4096)
     kw.update(case)
     kind = kw.pop("kind")
     _same(_run(False, kind, 500, "adagrad", 10, False, **kw), _run(True, kind, 500, "adagrad", 10, False, **kw), repr(case))
+
+
+def test_engine_runs_pooled_fields_graph_replayed():
+    """26 + 13 Criteo columns + a mean history + a sum history over C1's table: 42 graph-replayed steps, bit for bit the
+    two-launch step (whose pooled lookup and sorted update are pinned to the reference's goldens)."""
+    _same(_run(False, "deepfm", 3000, "adagrad", 42, True, pooled=(8, 5)),
+          _run(True, "deepfm", 3000, "adagrad", 42, True, pooled=(8, 5)), "deepfm + pooled")
 
 
 @pytest.mark.parametrize("topo", ["serial"])

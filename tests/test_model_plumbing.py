@@ -345,3 +345,57 @@ def test_weights_only_checkpoint_is_the_references_size(mock, tmp_path):
     # and both still load back
     m.load_state_dict(sd)
     m.optim.load_state_dict(osd)
+
+
+def test_step_engine_takes_pooled_sum_and_mean_fields(mock, monkeypatch):
+    """Round 5: a DeepFM with a mean history (ids != 0 mask) and a sum history over a SHARED table (length column) runs on the
+    step engine (deepctr_torch/_hip/step.py: general update units, per-step den_t buffer, n_vcols-row id arrays) and lands where
+    the autograd-assembled step lands; a max-pooled column keeps the two-launch step (its arg-max comes from dctr_embed_fwd)."""
+    from deepctr_torch.inputs import DenseFeat, SparseFeat, VarLenSparseFeat
+    from deepctr_torch.models import DeepFM
+
+    def cols(with_max):
+        c = [SparseFeat("a", 30, 8), SparseFeat("b", 20, 8), DenseFeat("x", 2),
+             VarLenSparseFeat(SparseFeat("hist", 25, 8), maxlen=4, combiner="mean"),
+             VarLenSparseFeat(SparseFeat("seq", 30, 8, embedding_name="a"), maxlen=3, combiner="sum", length_name="seq_len")]
+        if with_max:
+            c.append(VarLenSparseFeat(SparseFeat("kw", 9, 8), maxlen=2, combiner="max"))
+        return c
+
+    rng = np.random.RandomState(0)
+    B = 48
+
+    def data(with_max):
+        h = rng.randint(1, 25, (B, 4)) * (np.arange(4)[None, :] < rng.randint(0, 5, (B, 1)))
+        parts = [rng.randint(0, 30, (B, 1)), rng.randint(0, 20, (B, 1)), rng.rand(B, 2), h, rng.randint(0, 30, (B, 3)),
+                 rng.randint(0, 4, (B, 1))]
+        if with_max:
+            parts.append(rng.randint(1, 9, (B, 2)))
+        return torch.from_numpy(np.concatenate(parts, axis=1).astype(np.float32)), \
+            torch.from_numpy(rng.randint(0, 2, B).astype(np.float32))
+
+    def run(engine, with_max, X, y):
+        monkeypatch.setenv("DCTR_STEP_ENGINE", "1" if engine else "0")
+        torch.manual_seed(0)
+        c = cols(with_max)
+        m = DeepFM(c, c, dnn_hidden_units=(16, 8), l2_reg_linear=0, l2_reg_embedding=0, dnn_dropout=0, device=DEV)
+        m.compile("adagrad", "binary_crossentropy", metrics=[])
+        m.train()
+        mock.calls.clear()
+        losses = [float(m._train_step(X, y)[0]) for _ in range(3)]
+        st = m._fused_step_state()
+        used = st is not None and st.get("engine") is not None and st["engine"].steps_run > 0
+        return m, losses, used, list(mock.calls)
+
+    X, y = data(False)
+    m1, l1, used1, calls1 = run(True, False, X, y)
+    m0, l0, used0, calls0 = run(False, False, X, y)
+    assert used1 and not used0 and "embed_tower_train_step" in calls1 and "embed_tower_train_step" not in calls0
+    assert not m1.model_plan().simple_units and m1.model_plan().gen is not None
+    assert not any(c.startswith("embed_bwd") for c in calls1 + calls0)
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m0.state_dict().items()):
+        assert max_abs(a.numpy(), b.numpy()) <= 1e-6, k
+    Xm, ym = data(True)
+    _, lm, usedm, callsm = run(True, True, Xm, ym)
+    assert not usedm and "embed_update:1" in callsm and np.isfinite(lm).all()
