@@ -1,0 +1,224 @@
+"""``model.fit()`` under ``torchrun`` (WORLD_SIZE > 1): one process per GPU, the minibatch sharded over the ranks.
+
+Reference: ``basemodel.py:206-209`` -- with ``gpus`` the reference wraps the model in ``nn.DataParallel`` and sets
+``batch_size *= len(gpus)``: the caller's ``batch_size`` is PER GPU, a step trains on ``batch_size x n_gpus`` samples, the
+loss is a sum over that global batch (``:254``), metrics are computed on the gathered predictions (``:264-269``).  Here the
+same contract, one process per GPU (``torch.distributed``: RCCL on GPUs, gloo on CPU stand-ins):
+
+  * every rank holds the whole dataset and draws the reference's epoch permutation (the same draws from the default
+    generator; rank 0's permutation is broadcast so that a rank seeded differently cannot fork the run);
+  * step k trains on rows ``order[k G : (k + 1) G]`` of the permutation, ``G = batch_size x world``; rank r contributes the
+    slice ``[r b, (r + 1) b)`` of them; the step itself is ``parallel.ShardedTrainer.train_step`` (tables sharded over the
+    ranks, tower data-parallel): one optimizer step on the gradient of the global batch -- the single-process step on G
+    samples;
+  * a ragged last batch (fewer than G rows) does not split evenly: the owners' tables are made current everywhere
+    (``gather_tables``) and EVERY rank runs the single-process step on the whole ragged batch -- identical inputs and
+    deterministic kernels leave identical replicas, owners included;
+  * ``History``: the epoch loss is the all-reduced sum over every sample / sample count; every metric is evaluated per
+    GLOBAL batch on the all-gathered (label, prediction) pairs, as ``DataParallel`` hands them to the reference;
+  * validation, callbacks and whatever reads ``model.embedding_dict`` after an epoch see complete tables
+    (``gather_tables`` at the end of every epoch that needs it).
+
+Models / optimizers outside ``ShardedTrainer``'s envelope (pooled or shared tables, Adam, L2 on the tables) raise
+``NotImplementedError`` naming the reason -- never a silent single-GPU run."""
+import os
+import time
+
+import numpy as np
+import torch
+
+
+def context():
+    """(world, rank) when this process is one of several training ranks, else None."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        w = dist.get_world_size()
+        return (w, dist.get_rank()) if w > 1 else None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("DCTR_FIT_DISTRIBUTED", "1") != "0":
+        return (int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0")))
+    return None
+
+
+def _ensure_group(device):
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        cuda = torch.device(device).type == "cuda"
+        kw = dict(device_id=torch.device(device)) if cuda else {}
+        dist.init_process_group("nccl" if cuda else "gloo", rank=int(os.environ.get("RANK", "0")),
+                                world_size=int(os.environ["WORLD_SIZE"]), **kw)
+    return dist
+
+
+def trainer_for(model):
+    """The model's ShardedTrainer (built once per compile(): it holds exchange buffers and captured segments)."""
+    from . import parallel as par
+    tr = getattr(model, "_dist_trainer", None)
+    plan = model.model_plan()
+    if tr is not None and tr.model is model and getattr(tr, "_optim", None) is getattr(model, "optim", None) and \
+            tr.plan is plan and plan.sharder in (None, tr):
+        plan.sharder = tr          # (the previous fit() left every rank's tables current and detached the trainer)
+        tr._announced = None
+        tr._pre = None
+        return tr
+    if not plan.simple_units:
+        raise NotImplementedError("fit() under torchrun shards the embedding tables over the ranks (ShardedTrainer): that "
+                                  "needs fixed-length sparse features over distinct tables; this model has pooled VarLen "
+                                  "features or shared tables -- train it on one GPU or with parallel.DataParallelTrainer")
+    ops = None
+    factory = getattr(model, "_shard_ops_factory", None)      # (tests: stand-ins for the device kernels)
+    if factory is not None:
+        ops = factory(model, par.ShardLayout(plan, *context()))
+    tr = par.ShardedTrainer(model, ops=ops, exchange=os.environ.get("DCTR_SHARDED_EXCHANGE", "rccl"))
+    tr._optim = getattr(model, "optim", None)
+    model._dist_trainer = tr
+    return tr
+
+
+class _Unsharded(object):
+    """``with _Unsharded(trainer):`` -- lookups go through the local tables (current after ``gather_tables``)."""
+
+    def __init__(self, tr):
+        self.tr = tr
+
+    def __enter__(self):
+        self.tr._join()
+        self.tr.plan.sharder = None
+        return self
+
+    def __exit__(self, *exc):
+        self.tr.plan.sharder = self.tr
+        self.tr._announced = None      # whatever was announced to the owners is stale now
+        self.tr._pre = None
+        return False
+
+
+def fit(model, X_all, y_all, batch_size, epochs, verbose, initial_epoch, do_validation, val_x, val_y, shuffle, callbacks):
+    from . import callbacks as _cb
+    dist = _ensure_group(model.device)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = X_all.device
+    tr = trainer_for(model)
+    b, G = int(batch_size), int(batch_size) * world
+    sample_num = X_all.shape[0]
+    n_full, n_tail = sample_num // G, sample_num % G
+    steps_per_epoch = n_full + (1 if n_tail else 0)
+    model.train()
+    if rank == 0:
+        print("%s -- %d ranks, batch %d per rank (%d global), tables sharded over the ranks (%s exchange)" % (
+            model.device, world, b, G, tr.exchange))
+        print("Train on {0} samples, validate on {1} samples, {2} steps per epoch".format(
+            sample_num, len(val_y), steps_per_epoch))
+    cbs = _cb.CallbackList((callbacks or []) + [model.history])
+    cbs.set_model(model)
+    cbs.on_train_begin()
+    cbs.set_model(model)
+    model.stop_training = False
+    plan = model.model_plan()
+
+    def draw_order():
+        # the reference's two draws per epoch (see BaseModel.fit); rank 0's permutation wins
+        torch.empty((), dtype=torch.int64).random_()
+        if not shuffle:
+            return None
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        gen = torch.Generator()
+        gen.manual_seed(seed)
+        order = torch.randperm(sample_num, generator=gen).to(dev)
+        dist.broadcast(order, 0)
+        return order
+
+    def rows(lo, hi):
+        if order is not None:
+            idx = order[lo:hi]
+            return X_all.index_select(0, idx), y_all.index_select(0, idx)
+        return X_all[lo:hi].contiguous(), y_all[lo:hi].contiguous()
+
+    graphs_on = False
+    for epoch in range(initial_epoch, epochs):
+        cbs.on_epoch_begin(epoch)
+        epoch_logs = {}
+        start_time = time.time()
+        order = draw_order()
+        acc_sharded = torch.zeros((), device=dev, dtype=torch.float64)    # this rank's share of the full batches
+        acc_tail = torch.zeros((), device=dev, dtype=torch.float64)       # the ragged batch (the same on every rank)
+        preds = [] if (verbose > 0 and model.metrics) else None
+        current = False                 # every rank's tables current?
+        nxt = rows(rank * b, (rank + 1) * b) if n_full else None
+        for step in range(n_full):
+            xb, yb = nxt
+            lo = (step + 1) * G + rank * b
+            nxt = rows(lo, lo + b) if step + 1 < n_full else None
+            if not graphs_on and step >= 2 and dev.type == "cuda" and os.environ.get("DCTR_FIT_GRAPH", "1") != "0":
+                tr.set_use_graphs(True)     # (two eager steps first: descriptors are uploaded, buffers allocated)
+                graphs_on = True
+            loss, total_loss, y_pred = tr.train_step(xb, yb, next_xb=nxt[0] if nxt is not None else None)
+            acc_sharded += total_loss.detach().double().sum()
+            if preds is not None:
+                preds.append((yb, y_pred.detach().reshape(-1).clone(), True))
+        if n_tail:
+            tr.gather_tables()
+            with _Unsharded(tr):
+                xb, yb = rows(n_full * G, sample_num)
+                loss, total_loss, y_pred = model._train_step(xb, yb)
+            acc_tail += total_loss.detach().double().sum()
+            current = True
+            if preds is not None:
+                preds.append((yb, y_pred.detach().reshape(-1).clone(), False))
+        dist.all_reduce(acc_sharded)
+        plan.check_ids()
+        epoch_logs["loss"] = float((acc_sharded + acc_tail).item()) / sample_num
+        if preds is not None:
+            # the reference's metric of every (global) batch, averaged over steps (basemodel.py:264-269,280)
+            per_batch = {name: [] for name in model.metrics}
+            for yb, yp, sharded in preds:
+                if sharded:
+                    both = torch.stack([yb.reshape(-1).float(), yp.float()])
+                    parts = [torch.empty_like(both) for _ in range(world)]
+                    dist.all_gather(parts, both)
+                    both = torch.cat(parts, dim=1)
+                    yt, ypn = both[0].cpu().numpy(), both[1].cpu().numpy().astype("float64")
+                else:
+                    yt, ypn = yb.cpu().numpy(), yp.cpu().numpy().astype("float64")
+                for name, fun in model.metrics.items():
+                    per_batch[name].append(fun(yt, ypn))
+            for name, vals in per_batch.items():
+                epoch_logs[name] = np.sum(vals) / steps_per_epoch
+        last = epoch + 1 >= epochs
+        if (do_validation or callbacks or last) and not current:
+            tr.gather_tables()
+            current = True
+        if do_validation:
+            with _Unsharded(tr):
+                for name, result in model.evaluate(val_x, val_y, batch_size).items():
+                    epoch_logs["val_" + name] = result
+            model.train()
+        if verbose > 0 and rank == 0:
+            epoch_time = int(time.time() - start_time)
+            print('Epoch {0}/{1}'.format(epoch + 1, epochs))
+            eval_str = "{0}s - loss: {1: .4f}".format(epoch_time, epoch_logs["loss"])
+            for name in model.metrics:
+                eval_str += " - " + name + ": {0: .4f}".format(epoch_logs[name])
+            if do_validation:
+                for name in model.metrics:
+                    eval_str += " - " + "val_" + name + ": {0: .4f}".format(epoch_logs["val_" + name])
+            print(eval_str)
+        if callbacks:
+            with _Unsharded(tr):
+                cbs.on_epoch_end(epoch, epoch_logs)
+        else:
+            cbs.on_epoch_end(epoch, epoch_logs)
+        stop = torch.tensor([1 if model.stop_training else 0], device=dev)
+        dist.all_reduce(stop, op=dist.ReduceOp.MAX)       # (EarlyStopping must stop every rank: the steps are collective)
+        if int(stop.item()):
+            model.stop_training = True
+            if not current:
+                tr.gather_tables()
+            break
+    # leave the model usable on its own (predict / evaluate / state_dict read complete local tables); the trainer is kept
+    # for the next fit() call and re-attached there
+    tr._join()
+    tr.plan.sharder = None
+    cbs.on_train_end()
+    return model.history

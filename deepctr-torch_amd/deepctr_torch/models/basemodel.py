@@ -421,9 +421,14 @@ class BaseModel(nn.Module):
         self._hyper_raw = raw
         sig = (self._optim_signature(), raw[-4], raw[-3], raw[-2], raw[-1])   # (+ optimizer object, loss, #regularisers, frozen tables)
         if sig != self.__dict__.get("_hyper_sig"):
-            first = self.__dict__.get("_hyper_sig") is None
+            prev = self.__dict__.get("_hyper_sig")
+            first = prev is None
+            # (recorded before the plan existed -- compile() ahead of the first lookup: the frozen-table entry was None then.
+            # Nothing was derived from it; filling it in is no change.  Re-deriving here dropped the fused-step state, and
+            # with it the dense slab a ShardedTrainer had already adopted: fit() under torchrun)
+            filled_in = (not first) and prev[-1] is None and sig[:-1] == prev[:-1]
             self._hyper_sig = sig
-            if not first:
+            if not first and not filled_in:
                 self._rederive_update_paths()
 
     def _rederive_update_paths(self):
@@ -1200,9 +1205,16 @@ class BaseModel(nn.Module):
         if batch_size is None:
             batch_size = 256
         self.train()
+        from .. import distributed_fit as _dfit
+        if _dfit.context() is not None:
+            # one process per GPU (torchrun): the minibatch is sharded over the ranks, batch_size is per GPU like the
+            # reference's `batch_size *= len(gpus)` under nn.DataParallel (basemodel.py:206-209)
+            return _dfit.fit(self, X_all, y_all, batch_size, epochs, verbose, initial_epoch, do_validation, val_x, val_y,
+                             shuffle, callbacks)
         if self.gpus:
             print('parallel running on these gpus:', self.gpus,
-                  '-- nn.DataParallel is not used; launch one process per GPU (see deepctr_torch.parallel)')
+                  '-- nn.DataParallel is not used; launch one process per GPU with torchrun: fit() then shards the '
+                  'minibatch over the ranks (deepctr_torch/distributed_fit.py)')
         else:
             print(self.device)
         sample_num = X_all.shape[0]

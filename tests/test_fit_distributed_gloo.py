@@ -1,0 +1,110 @@
+"""CPU, gloo, world 2: ``model.fit()`` under one process per rank (deepctr_torch/distributed_fit.py; reference:
+basemodel.py:206-209, ``batch_size *= len(gpus)`` under nn.DataParallel) against ONE process running the same ``fit()`` with
+``batch_size x world``: same History (loss and metrics of every epoch), same final parameters on every rank.  106 rows,
+12 per rank: four sharded steps of 24 and a ragged batch of 10 per epoch (taken by every rank on gathered tables); shuffled
+epochs (rank 1 seeds its generator differently: rank 0's permutation is broadcast), a validation split, a metric.
+The REAL trainer / model / fit loop run in every process; the device kernels are stood in for by tests/mock_lib.py and
+tests/shard_standin.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F_, V_, D_, ND_, B_, N_ = 5, 30, 8, 3, 12, 133
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _setup_paths():
+    for p in (os.path.join(ROOT, "deepctr-torch_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _data():
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(0, V_, (N_, F_), generator=g).float()
+    X = torch.cat([ids, torch.rand(N_, ND_, generator=g)], 1).numpy()
+    y = torch.randint(0, 2, (N_,), generator=g).float().numpy()
+    names = ["C%d" % i for i in range(F_)] + ["I%d" % i for i in range(ND_)]
+    return {n: X[:, i] for i, n in enumerate(names)}, y
+
+
+def _model():
+    from deepctr_torch.inputs import DenseFeat, SparseFeat
+    from deepctr_torch.models import DeepFM
+    cols = [SparseFeat("C%d" % i, V_, D_) for i in range(F_)] + [DenseFeat("I%d" % i, 1) for i in range(ND_)]
+    m = DeepFM(cols, cols, dnn_hidden_units=(16, 8), l2_reg_linear=0, l2_reg_embedding=0, init_std=0.1, seed=7, device="cpu")
+    m.compile("adagrad", "binary_crossentropy", metrics=["binary_crossentropy"])
+    return m
+
+
+def _patch_for_cpu():
+    from deepctr_torch._hip import lib as L
+    from mock_lib import MockLib
+    m = MockLib()
+    L.lib = lambda: m
+    L.require_gpu = lambda t, what: None
+    L.stream_handle = lambda device=None: None
+    torch.Tensor.is_cuda = property(lambda self: True)
+
+
+def _fit(m, batch, shuffle):
+    x, y = _data()
+    torch.manual_seed(123)
+    hist = m.fit(x, y, batch_size=batch, epochs=2, verbose=2, shuffle=shuffle, validation_split=0.2)
+    return {k: [float(v) for v in vals] for k, vals in hist.history.items()}
+
+
+def _worker(rank, world, port, shuffle, out_dir):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank))
+    os.environ["DCTR_FIT_GRAPH"] = "0"
+    torch.set_num_threads(1)
+    _patch_for_cpu()
+    import torch.distributed as dist
+    from shard_standin import TorchShardOps
+    m = _model()
+    m._shard_ops_factory = lambda model, lay: TorchShardOps(model, lay)
+    if rank != 0:
+        torch.manual_seed(999)       # (overwritten by _fit's seed; the broadcast permutation is what keeps ranks together)
+    hist = _fit(m, B_, shuffle)      # fit() initialises the process group itself from the torchrun environment
+    pred = m.predict(_data()[0], batch_size=50)
+    torch.save({"hist": hist, "pred": pred, "sd": {k: v.detach().clone() for k, v in m.state_dict().items()}},
+               os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_fit_under_two_ranks_equals_fit_on_the_global_batch(tmp_path, mock, shuffle):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), shuffle, str(tmp_path)), nprocs=world, join=True)
+    ranks = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(world)]
+    os.environ["DCTR_FIT_GRAPH"] = "0"
+    try:
+        ref_model = _model()
+        ref_hist = _fit(ref_model, B_ * world, shuffle)
+    finally:
+        os.environ.pop("DCTR_FIT_GRAPH", None)
+    ref_pred = ref_model.predict(_data()[0], batch_size=50)
+    for r in range(world):
+        assert set(ranks[r]["hist"]) == set(ref_hist) == {"loss", "binary_crossentropy", "val_binary_crossentropy"}
+        for k, want in ref_hist.items():
+            np.testing.assert_allclose(ranks[r]["hist"][k], want, rtol=2e-5, err_msg="rank %d %s" % (r, k))
+        assert float(np.abs(ranks[r]["pred"] - ref_pred).max()) <= 2e-5
+        for k, v in ref_model.state_dict().items():
+            err = float((ranks[r]["sd"][k] - v).abs().max())
+            assert err <= 2e-5 * max(1.0, float(v.abs().max())), "rank %d %s: %.3e" % (r, k, err)
+    for k in ranks[0]["sd"]:
+        assert torch.equal(ranks[0]["sd"][k], ranks[1]["sd"][k]), "replicas differ: %s" % k

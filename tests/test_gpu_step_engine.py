@@ -137,7 +137,8 @@ def test_engine_leaves_the_same_bits_as_the_two_launch_step(opt, graphed):
     # pooled VarLen fields + a shared table inside the fused gather (general update units)
     dict(kind="deepfm", pooled=(8, 5)),
     dict(kind="wdl", D=8, F=5, n_dense=3, hidden=(64, 32), B=1000, pooled=(3, 2)),
-    dict(kind="deepfm", D=32, F=4, n_dense=0, hidden=(128,), B=512, pooled=(6, 4)),
+    dict(kind="deepfm", D=32, F=4, n_dense=0, hidden=(256, 128), B=512, pooled=(6, 4)),   # (the positions' rows are staged in
+    # the backward's LDS image: a narrow tower leaves no room and keeps the two-launch step)
 ])
 def test_engine_shapes(case):
     kw = dict(F=26, D=16, n_dense=13, hidden=(256, 128), B=4096)
