@@ -240,6 +240,50 @@ def saturating_launch(args, model, device, B_sat=262144):
     out["gather_frac_of_hbm_peak"] = out["kernels"]["embed_fwd"]["frac_of_hbm_peak"]
     out["update_path_frac_of_hbm_peak"] = path_b / (path_us * 1e-6) / 1e9 / HBM_PEAK_GBS
     out["update_path_us"] = path_us
+    # the predict path (round 5): a model that was never compiled seats deep row + wide weight of an id in one 128-byte line
+    # (_hip/layout.py apply_infer_layout); the same gather kernel without the update's side outputs, on that layout and on
+    # the training layout
+    try:
+        from deepctr_torch._hip import lib as L
+        from deepctr_torch._hip.layout import apply_infer_layout
+        from deepctr_torch._hip.ops import _ptr
+        from deepctr_torch.inputs import DenseFeat, SparseFeat
+        from deepctr_torch.models import DeepFM
+        cols = [SparseFeat("C%d" % (i + 1), args.vocab, DIM) for i in range(F_SPARSE)] + \
+               [DenseFeat("I%d" % (i + 1), 1) for i in range(N_DENSE)]
+        pm = DeepFM(cols, cols, dnn_hidden_units=(256, 128), l2_reg_linear=0, l2_reg_embedding=0, dnn_dropout=0, seed=1024,
+                    device=device)
+        pplan = pm.model_plan()
+        seated = apply_infer_layout(pplan)
+        lib = L.lib()
+        ld = (F_SPARSE * DIM + N_DENSE + 3) // 4 * 4
+        fwd_b = B_sat * ((F_SPARSE + N_DENSE) * 4 + F_SPARSE * DIM * 4 + F_SPARSE * 4 + ld * 4 + 8)
+        res = {}
+        for tag, plan_ in (("predict_layout", pplan), ("training_layout", model.model_plan())):
+            cp = plan_.bind(Xs.device)
+            o = torch.empty(B_sat, plan_.ld_out, device=Xs.device)
+            w_, f_ = torch.empty(B_sat, device=Xs.device), torch.empty(B_sat, device=Xs.device)
+            s_ = L.stream_handle(Xs.device)
+            evs = []
+            for it in range(8):
+                Xb = Xs[(it % 2) * B_sat:(it % 2 + 1) * B_sat]
+                a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                L.check(lib.dctr_embed_fwd(cp, _ptr(Xb), Xb.stride(0), B_sat, _ptr(o), plan_.ld_out, _ptr(w_), 1, _ptr(f_), None,
+                                           plan_.units_ptr(), plan_.n_grid_units, None, None, None, 0, s_))
+                b_.record()
+                evs.append((a, b_))
+            torch.cuda.synchronize()
+            ts = sorted(a.elapsed_time(b_) * 1e3 for a, b_ in evs[2:])
+            us = sum(ts) / len(ts)
+            res[tag] = {"avg_us": us, "min_us": ts[0], "alg_bytes": fwd_b, "gbs": fwd_b / (us * 1e-6) / 1e9,
+                        "frac_of_hbm_peak": fwd_b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            del o, w_, f_
+        res["units_seated"] = seated
+        out["embed_fwd_forward_only"] = res
+        del pm
+    except Exception as exc:
+        out["embed_fwd_forward_only"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     del Xs
     torch.cuda.empty_cache()
     return out

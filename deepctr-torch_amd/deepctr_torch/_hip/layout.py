@@ -10,6 +10,9 @@ for ONE 128-byte line holding both.  So whatever the update kernel touches toget
   "block"        one slab per unit [V, 64]: row r = [ e_r (16) | w_r | wide sum_r | pad 14 | Adagrad sum_r (16) | pad 16 ]
                  -- the gather reads e_r and w_r from ONE line (26 instead of 52 random requests per sample)
   "contiguous"   the reference's layout: every tensor on its own
+  "infer"        (apply_infer_layout, models that only ever predict) one slab per unit [V, 32]: row r = [ e_r (D <= 28) | w_r |
+                 pad ] -- ONE 128-byte line per (sample, field) for the gather instead of two (the deep row's line and the wide
+                 weight's line): profiles/r02_kernel_sweep_layouts.json, 302 against 391 us at B_eff 262 144
 
 ``nn.Embedding.weight`` and ``optimizer.state[p]['sum']`` become strided VIEWS of the slabs: ``state_dict`` keys,
 shapes and values, ``optimizer.state_dict()``, ``load_state_dict`` and every torch op on them keep working; the
@@ -87,3 +90,33 @@ def apply_layout(plan, optimizer, state_key="sum", layout=None):
             optimizer.state[p][state_key] = sv
             out[p] = sv
     return out
+
+
+def apply_infer_layout(plan):
+    """Forward-only seating (round 5): a model that was never compiled for training -- ``predict()`` / ``evaluate()`` on
+    loaded weights -- pays two random 128-byte lines per (sample, field) in the reference's layout, the deep row's and the
+    wide weight's.  Every unit with a deep table of D <= 28 floats (a multiple of 4) and a wide table over the same ids is
+    re-seated in ONE ``[V, 32]`` slab, row r = ``[ e_r | w_r | pad ]``; ``weight`` tensors become strided views (``state_dict``
+    keys, shapes and values unchanged).  Idempotent; ``compile()`` re-seats again for the optimizer it gets (apply_layout).
+    Returns the number of units re-seated by this call."""
+    if os.environ.get("DCTR_PREDICT_LAYOUT", "1") == "0":
+        return 0
+    n = 0
+    for di, wi, _, _ in plan.units:
+        if di < 0 or wi < 0:
+            continue
+        pd, pw = plan.deep[di].param, plan.wide[wi].param
+        D = int(pd.shape[1])
+        if D > 28 or D % 4 or int(pw.shape[1]) != 1 or pd.shape[0] != pw.shape[0] or pd.device != pw.device:
+            continue
+        ed, ew = _SLAB.get(pd), _SLAB.get(pw)
+        if _is_view_of(pd, ed) and _is_view_of(pw, ew) and ed[0] is ew[0] and ed[0].shape[1] == 32:
+            continue
+        if any(_is_view_of(p, e) for p, e in ((pd, ed), (pw, ew))):
+            continue        # seated for training (interleaved / block): not a forward-only model, leave it
+        slab = torch.zeros((int(pd.shape[0]), 32), dtype=torch.float32, device=pd.device)
+        with torch.no_grad():
+            _seat(pd, slab, 0, None, None)
+            _seat(pw, slab, D, None, None)
+        n += 1
+    return n

@@ -1347,6 +1347,11 @@ class BaseModel(nn.Module):
         """float64 ``[N, 1]`` predictions, input order preserved (reference basemodel.py:325-352)."""
         self.eval()  # like the reference (:331), predict leaves the model in eval mode
         X_all = self._as_matrix(x)
+        if self.__dict__.get("optim") is None and X_all.is_cuda and self.model_plan() is not None:
+            # never compiled for training (weights loaded, then predict / evaluate): the forward-only table layout -- deep
+            # row and wide weight of an id in one 128-byte line (_hip/layout.py)
+            from .._hip.layout import apply_infer_layout
+            apply_infer_layout(self._plan)
         torch.empty((), dtype=torch.int64).random_()     # the base seed the reference's DataLoader iterator draws (:340)
         # In eval mode every sample's prediction is independent of its batch (no batch statistics, no dropout), so the
         # caller's batch_size -- 256 by default in the reference, i.e. ~4 launches per 256 rows -- only sets a lower

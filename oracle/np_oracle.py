@@ -147,14 +147,35 @@ def dnn_forward(x, P, prefix, n_layers):
     return x, acts
 
 
+def relu_bias_backward(g, h):
+    """What autograd does behind ``relu(x W^T + b)`` (core.py:120-134): aten::threshold_backward -- the gradient passes where
+    the activation is positive -- and the bias gradient, the sum over the batch.  ``h`` None: no activation."""
+    gz = g * (h > 0) if h is not None else g
+    return gz, gz.sum(axis=0)
+
+
 def dnn_backward(g, acts, P, prefix, n_layers, grads):
     for i in reversed(range(n_layers)):
         W = P[prefix + "linears.%d.weight" % i]
-        g = g * (acts[i + 1] > 0)
+        g, gb = relu_bias_backward(g, acts[i + 1])
         grads[prefix + "linears.%d.weight" % i] = g.T @ acts[i]
-        grads[prefix + "linears.%d.bias" % i] = g.sum(axis=0)
+        grads[prefix + "linears.%d.bias" % i] = gb
         g = g @ W
     return g
+
+
+def optimizer_step(kind, p, g, state, lr, eps=1e-10, l2=0.0):
+    """One step of the reference's optimizers on one tensor (basemodel.py:447-461: torch.optim.SGD(lr) / Adagrad(lr), default
+    arguments), with an optional L2 term lambda * sum(p^2) of get_regularization_loss (basemodel.py:412-428) entering through
+    its gradient 2 lambda p.  Returns (new p, new state); ``state`` is Adagrad's ``sum`` (None for SGD)."""
+    if l2:
+        g = g + 2.0 * l2 * p
+    if kind == "sgd":
+        return p - lr * g, state
+    if kind == "adagrad":
+        s = (state if state is not None else np.zeros_like(p)) + g * g
+        return p - lr * g / (np.sqrt(s) + eps), s
+    raise ValueError(kind)
 
 
 def inner_product_forward(E):
@@ -212,16 +233,37 @@ def crossnet_backward(g, xs, kernels, bias, param):
     return g + gx0, gk, gb
 
 
+def cin_layer_forward(H, X0, W, b, relu=True):
+    """One CIN layer (interaction.py:216-229): Z = einsum('bhd,bmd->bhmd', H, X0) flattened over (h, m), the 1x1 Conv1d
+    W [O, h m] (+ bias), the activation.  H [B, h, D], X0 [B, m, D] -> (A [B, O, D], (Z, Y))."""
+    B, _, D = X0.shape
+    Z = (H[:, :, None, :] * X0[:, None, :, :]).reshape(B, H.shape[1] * X0.shape[1], D)
+    Y = np.einsum("ok,bkd->bod", W, Z)
+    if b is not None:
+        Y = Y + b[None, :, None]
+    return (np.maximum(Y, 0) if relu else Y), (Z, Y)
+
+
+def cin_layer_backward(gA, H, X0, W, cache, relu=True):
+    """Gradients of one CIN layer: (gH, gX0 through the products only, gW [O, h m], gb [O])."""
+    Z, Y = cache
+    B, F, D = X0.shape
+    gY = gA * (Y > 0) if relu else gA
+    gW = np.einsum("bod,bkd->ok", gY, Z)
+    gb = gY.sum(axis=(0, 2))
+    gZ = np.einsum("ok,bod->bkd", W, gY).reshape(B, H.shape[1], F, D)
+    gH = (gZ * X0[:, None, :, :]).sum(axis=2)
+    gX0 = (gZ * H[:, :, None, :]).sum(axis=1)
+    return gH, gX0, gW, gb
+
+
 def cin_forward(X0, P, prefix, layer_size, split_half, activation="relu"):
     """interaction.py:207-248.  X0 [B, F, D] -> [B, featuremap_num]."""
-    B, F, D = X0.shape
     hidden, finals, cache = [X0], [], []
     for i, size in enumerate(layer_size):
         H = hidden[-1]
-        Z = (H[:, :, None, :] * X0[:, None, :, :]).reshape(B, H.shape[1] * F, D)   # einsum bhd,bmd->bhmd
         W, b = P[prefix + "conv1ds.%d.weight" % i][:, :, 0], P[prefix + "conv1ds.%d.bias" % i]
-        Y = np.einsum("ok,bkd->bod", W, Z) + b[None, :, None]
-        A = np.maximum(Y, 0) if activation == "relu" else Y
+        A, (Z, Y) = cin_layer_forward(H, X0, W, b, activation == "relu")
         if split_half and i != len(layer_size) - 1:
             nxt, direct = A[:, :size // 2], A[:, size // 2:]
         elif split_half:
@@ -244,7 +286,6 @@ def cin_backward(gp, X0, cache, P, prefix, layer_size, split_half, grads, activa
     gX0 = np.zeros_like(X0)
     g_next = None
     for i in reversed(range(len(layer_size))):
-        size = layer_size[i]
         H, Z, Y = cache[i]
         gdir = np.repeat(gp[:, offs[i]:offs[i + 1], None], D, axis=2)
         if split_half and i != len(layer_size) - 1:
@@ -253,13 +294,11 @@ def cin_backward(gp, X0, cache, P, prefix, layer_size, split_half, grads, activa
             gA = gdir
         else:
             gA = gdir + (g_next if g_next is not None else 0)
-        gY = gA * (Y > 0) if activation == "relu" else gA
         W = P[prefix + "conv1ds.%d.weight" % i][:, :, 0]
-        grads[prefix + "conv1ds.%d.weight" % i] = np.einsum("bod,bkd->ok", gY, Z)[:, :, None]
-        grads[prefix + "conv1ds.%d.bias" % i] = gY.sum(axis=(0, 2))
-        gZ = np.einsum("ok,bod->bkd", W, gY).reshape(B, H.shape[1], F, D)
-        gH = (gZ * X0[:, None, :, :]).sum(axis=2)
-        gX0 += (gZ * H[:, :, None, :]).sum(axis=1)
+        gH, gX0_i, gW, gb = cin_layer_backward(gA, H, X0, W, (Z, Y), activation == "relu")
+        grads[prefix + "conv1ds.%d.weight" % i] = gW[:, :, None]
+        grads[prefix + "conv1ds.%d.bias" % i] = gb
+        gX0 += gX0_i
         if i == 0:
             gX0 += gH
         else:
@@ -774,12 +813,7 @@ class Oracle(object):
         state = {} if state is None else state
         for k, g in grads.items():
             g = np.asarray(g, dtype=self.dt).reshape(self.P[k].shape)
-            if optimizer == "sgd":
-                self.P[k] = self.P[k] - self.dt.type(lr) * g
-            elif optimizer == "adagrad":
-                s = state.get(k, np.zeros_like(self.P[k])) + g * g
+            self.P[k], s = optimizer_step(optimizer, self.P[k], g, state.get(k), self.dt.type(lr), self.dt.type(eps))
+            if s is not None:
                 state[k] = s
-                self.P[k] = self.P[k] - self.dt.type(lr) * g / (np.sqrt(s) + self.dt.type(eps))
-            else:
-                raise ValueError(optimizer)
         return loss, state

@@ -1,16 +1,35 @@
-"""GPU: the fp32-MFMA CIN layer kernels (csrc/cin.hip) against a plain PyTorch fp32/fp64 reference of the same op
-(the reference's einsum + 1x1 conv, interaction.py:216-229), forward and all four gradients."""
+"""GPU: the fp32-MFMA CIN layer kernels (csrc/cin.hip) against the numpy oracle's statement of one CIN layer in fp64
+(oracle/np_oracle.py cin_layer_forward / cin_layer_backward: the reference's einsum + 1x1 conv, interaction.py:216-229 -- the
+functions np_oracle.cin_forward / cin_backward are made of, which tests/test_oracle_golden.py pins to the reference's xDeepFM
+goldens), forward values at 1e-5 x scale and all four gradients at 2e-5 x scale."""
+import numpy as np
 import pytest
 import torch
+
+from np_oracle import cin_backward, cin_forward, cin_layer_backward, cin_layer_forward
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _ref(H, X0, W, b, relu):
-    Z = (H[:, :, None, :] * X0[:, None, :, :]).reshape(H.shape[0], -1, H.shape[2])
-    Y = torch.einsum("ok,bkd->bod", W, Z) + (b[None, :, None] if b is not None else 0)
-    return torch.relu(Y) if relu else Y
+def _n(t):
+    return None if t is None else t.detach().double().cpu().numpy()
+
+
+def _oracle_layer(H, X0, W, b, relu, R, same=False):
+    """(A, gH, gX0, gW, gb) of  sum(A * R)  in fp64 by the oracle; ``same``: H is X0 (both gradients land on X0)."""
+    Hn, Xn, Wn, bn = _n(H), _n(X0), _n(W), _n(b)
+    A, cache = cin_layer_forward(Hn, Xn, Wn, bn, relu)
+    gH, gX0, gW, gb = cin_layer_backward(_n(R), Hn, Xn, Wn, cache, relu)
+    if same:
+        gX0 = gX0 + gH
+    return A, gH, gX0, gW, gb
+
+
+def _check(name, got, want, tol):
+    scale = max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(got.detach().double().cpu().numpy() - want).max())
+    assert err <= tol * scale, "%s: max|d|=%.3e (scale %.3g)" % (name, err, scale)
 
 
 CASES = [  # B, h, M, D, O, relu, bias
@@ -35,16 +54,10 @@ def test_cin_layer_forward_backward(case):
     R = torch.randn(B, O, D, device=DEV, generator=g)
     A = CINLayerFunction.apply(H, X0, W, b, relu)
     (A * R).sum().backward()
-    got = [A.detach(), H.grad, X0.grad, W.grad] + ([b.grad] if has_bias else [])
-    H2, X2, W2 = (t.detach().double().requires_grad_(True) for t in (H, X0, W))
-    b2 = b.detach().double().requires_grad_(True) if has_bias else None
-    A2 = _ref(H2, X2, W2, b2, relu)
-    (A2 * R.double()).sum().backward()
-    want = [A2.detach(), H2.grad, X2.grad, W2.grad] + ([b2.grad] if has_bias else [])
-    for name, a, r in zip(["A", "gH", "gX0", "gW", "gb"], got, want):
-        scale = max(1.0, float(r.abs().max()))
-        err = float((a.double() - r).abs().max())
-        assert err <= 2e-5 * scale, "%s: max|d|=%.3e (scale %.3g)" % (name, err, scale)
+    A2, gH, gX0, gW, gb = _oracle_layer(H, X0, W, b, relu, R)
+    _check("A", A, A2, 1e-5)
+    for name, a, r in (("gH", H.grad, gH), ("gX0", X0.grad, gX0), ("gW", W.grad, gW)) + ((("gb", b.grad, gb),) if has_bias else ()):
+        _check(name, a, r, 2e-5)
 
 
 SYM_CASES = [  # B, M, D, O, relu, bias     (H IS X0: the first layer of every CIN)
@@ -66,16 +79,10 @@ def test_cin_first_layer_symmetric_products(case):
     R = torch.randn(B, O, D, device=DEV, generator=g)
     A = CINLayerFunction.apply(X0, X0, W, b, relu)
     (A * R).sum().backward()
-    got = [A.detach(), X0.grad, W.grad] + ([b.grad] if has_bias else [])
-    X2, W2 = (t.detach().double().requires_grad_(True) for t in (X0, W))
-    b2 = b.detach().double().requires_grad_(True) if has_bias else None
-    A2 = _ref(X2, X2, W2, b2, relu)
-    (A2 * R.double()).sum().backward()
-    want = [A2.detach(), X2.grad, W2.grad] + ([b2.grad] if has_bias else [])
-    for name, a, r in zip(["A", "gX0", "gW", "gb"], got, want):
-        scale = max(1.0, float(r.abs().max()))
-        err = float((a.double() - r).abs().max())
-        assert err <= 2e-5 * scale, "%s: max|d|=%.3e (scale %.3g)" % (name, err, scale)
+    A2, _, gX0, gW, gb = _oracle_layer(X0, X0, W, b, relu, R, same=True)
+    _check("A", A, A2, 1e-5)
+    for name, a, r in (("gX0", X0.grad, gX0), ("gW", W.grad, gW)) + ((("gb", b.grad, gb),) if has_bias else ()):
+        _check(name, a, r, 2e-5)
 
 
 def test_cin_layer_on_strided_views():
@@ -88,8 +95,31 @@ def test_cin_layer_on_strided_views():
     H = prev[:, :64]
     W = torch.randn(128, 64 * 26, device=DEV) * 0.05
     A = CINLayerFunction.apply(H, X0, W, None, True)
-    R = _ref(H.double(), X0.double(), W.double(), None, True)
-    assert float((A.double() - R).abs().max()) <= 2e-5 * max(1.0, float(R.abs().max()))
+    _check("A", A, cin_layer_forward(_n(H), _n(X0), _n(W), None, True)[0], 1e-5)
+
+
+@pytest.mark.parametrize("F,D,layers,split_half,B", [(26, 16, (128, 128), True, 96), (26, 16, (64, 32, 16), False, 40),
+                                                     (7, 8, (10, 6), True, 33), (5, 4, (8,), True, 9), (31, 5, (12, 12), False, 17)])
+def test_cin_module_matches_the_oracle_stack(F, D, layers, split_half, B):
+    """The CIN module (layers/interaction.py: symmetric first layer, split_half hand-over, the pooling kernels) against
+    np_oracle.cin_forward / cin_backward (interaction.py:207-248) in fp64: output and every gradient."""
+    from deepctr_torch.layers import CIN
+    torch.manual_seed(F * 7 + D)
+    cin = CIN(F, layers, split_half=split_half, device=DEV)
+    for p_ in cin.parameters():
+        torch.nn.init.normal_(p_, 0, 0.1)
+    X0 = (torch.randn(B, F, D, device=DEV) * 0.5).requires_grad_(True)
+    R = torch.randn(B, sum(s // 2 if (split_half and i != len(layers) - 1) else s for i, s in enumerate(layers)), device=DEV)
+    y = cin(X0)
+    (y * R).sum().backward()
+    P = {"cin." + k: _n(v) for k, v in cin.state_dict().items()}
+    y2, cache = cin_forward(_n(X0), P, "cin.", layers, split_half)
+    grads = {}
+    gX0 = cin_backward(_n(R), _n(X0), cache, P, "cin.", layers, split_half, grads)
+    _check("y", y, y2, 1e-5)
+    _check("gX0", X0.grad, gX0, 2e-5)
+    for k, p_ in cin.named_parameters():
+        _check(k, p_.grad, grads["cin." + k].reshape(tuple(p_.shape)), 2e-5)
 
 
 def test_cin_module_shapes_and_errors():

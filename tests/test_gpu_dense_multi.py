@@ -12,6 +12,8 @@ import numpy as np
 import pytest
 import torch
 
+from np_oracle import optimizer_step
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
@@ -52,6 +54,8 @@ def test_multi_tensor_step_matches_torch_optim(opt, with_l2):
             r.grad = gr.clone() if r.grad is None else r.grad + gr
         reg_ref = float(reg.detach()) if reg is not None else 0.0
         items = _items(L, params, grads, states, l2s)
+        before = [(p.double().cpu().numpy().copy(), states[i].double().cpu().numpy().copy() if states is not None else None)
+                  for i, p in enumerate(params)]
         if with_l2:
             out = torch.empty(1, device=DEV)
             L.check(lib.dctr_l2_value_multi(items, len(params), ctypes.c_void_p(out.data_ptr()), L.stream_handle(DEV)))
@@ -63,6 +67,12 @@ def test_multi_tensor_step_matches_torch_optim(opt, with_l2):
         for i, (p, r) in enumerate(zip(params, ref)):
             np.testing.assert_allclose(p.cpu().numpy(), r.detach().cpu().numpy(), rtol=2e-7, atol=1e-8,
                                        err_msg="tensor %d step %d" % (i, step))
+            # ... and against the oracle's statement of the same step in fp64 (np_oracle.optimizer_step: what
+            # Oracle.train_step applies, pinned to the reference's 3-step goldens), the L2 term entering as 2 lambda p
+            pw, sw = optimizer_step(opt, before[i][0], grads[i].double().cpu().numpy(), before[i][1], lr, eps, l2=l2s[i])
+            np.testing.assert_allclose(p.double().cpu().numpy(), pw, rtol=2e-6, atol=2e-7, err_msg="oracle, tensor %d step %d" % (i, step))
+            if opt == "adagrad":
+                np.testing.assert_allclose(states[i].double().cpu().numpy(), sw, rtol=2e-6, atol=1e-9)
             if opt == "adagrad":
                 # (s + g*g as one fma here, a product and a sum in torch: up to ~2 ulp)
                 np.testing.assert_allclose(states[i].cpu().numpy(), optim.state[r]["sum"].cpu().numpy(), rtol=5e-7,

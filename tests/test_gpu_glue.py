@@ -49,7 +49,12 @@ def test_relu_bwd_bias(B, N, relu):
     want = torch.ops.aten.threshold_backward(gr, h, 0) if relu else gr
     if relu:
         assert torch.equal(go, want)
-    ref = want.double().sum(0)
+    # the oracle's statement of the same two autograd nodes (np_oracle.relu_bias_backward: what dnn_backward is made of)
+    from np_oracle import relu_bias_backward
+    gz64, gb64 = relu_bias_backward(gr.double().cpu().numpy(), h.double().cpu().numpy() if relu else None)
+    if relu:
+        assert float((go.double().cpu() - torch.from_numpy(gz64)).abs().max()) == 0.0
+    ref = torch.from_numpy(gb64).to(DEV)
     assert float((gb.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
     gb2 = torch.empty(N, device=DEV)
     L.check(lib.dctr_relu_bwd_bias(_p(gr), gr.stride(0), _p(h), N if relu else 0, B, N, _p(go), N, _p(gb2), _p(ws),

@@ -1,19 +1,30 @@
-"""GPU: SENET / Bilinear / InnerProduct / CrossNet kernels (csrc/pairwise.hip, cross.hip) against plain PyTorch
-references of the same ops (what the reference's layers compute, interaction.py:93-101,140-156,438-453,557-577),
-values and every gradient, in fp64."""
+"""GPU: SENET / Bilinear / InnerProduct / CrossNet kernels (csrc/pairwise.hip, cross.hip) against the numpy oracle in fp64
+(oracle/np_oracle.py senet_* / bilinear_* / inner_product_* / crossnet_*: what the reference's layers compute,
+interaction.py:93-101,140-156,438-453,557-577 -- pinned to the reference's FiBiNET / PNN / DCN goldens by
+tests/test_oracle_golden.py): values at 1e-5 x scale, every gradient at 2e-5 x scale.  (BiInteraction / AFM / Interacting /
+CrossNetMix further down keep a torch fp64 expression beside their model-level goldens.)"""
 import itertools
 
+import numpy as np
 import pytest
 import torch
 
+import np_oracle as O
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+
+
+def _n(t):
+    return t.detach().double().cpu().numpy()
 
 
 def _close(a, r, what, tol=2e-5):
     if r is None:                      # torch leaves the gradient of an unused parameter undefined; we return zeros
         assert a is None or float(a.abs().max()) == 0.0, what
         return
+    if isinstance(r, np.ndarray):      # an oracle value
+        r = torch.from_numpy(np.ascontiguousarray(r)).to(a.device).reshape(a.shape)
     scale = max(1.0, float(r.abs().max())) if r.numel() else 1.0
     err = float((a.double() - r).abs().max()) if r.numel() else 0.0
     assert err <= tol * scale, "%s: max|d|=%.3e (scale %.3g)" % (what, err, scale)
@@ -30,15 +41,13 @@ def test_senet(B, F, D, ratio):
     R = torch.randn(B, F, D, device=DEV)
     V = layer(E)
     (V * R).sum().backward()
-    E2 = E.detach().double().requires_grad_(True)
-    W1, W2 = (layer.excitation[i].weight.detach().double().requires_grad_(True) for i in (0, 2))
-    A = torch.relu(torch.relu(E2.mean(-1) @ W1.t()) @ W2.t())
-    V2 = E2 * A.unsqueeze(2)
-    (V2 * R.double()).sum().backward()
-    _close(V.detach(), V2.detach(), "V")
-    _close(E.grad, E2.grad, "gE")
-    _close(layer.excitation[0].weight.grad, W1.grad, "gW1")
-    _close(layer.excitation[2].weight.grad, W2.grad, "gW2")
+    W1, W2 = _n(layer.excitation[0].weight), _n(layer.excitation[2].weight)
+    V2, cache = O.senet_forward(_n(E), W1, W2)
+    gE, gW1, gW2 = O.senet_backward(_n(R), _n(E), cache, W1, W2)
+    _close(V.detach(), V2, "V", tol=1e-5)
+    _close(E.grad, gE, "gE")
+    _close(layer.excitation[0].weight.grad, gW1, "gW1")
+    _close(layer.excitation[2].weight.grad, gW2, "gW2")
 
 
 def _bilinear_ref(X, Ws, btype):
@@ -64,15 +73,14 @@ def test_bilinear_single_input(B, F, D, btype):
     out = layer(X)
     assert out.shape == (B, P, D)
     (out * R).sum().backward()
-    params = list(layer.parameters())
-    X2 = X.detach().double().requires_grad_(True)
-    Ws = [p.detach().double().requires_grad_(True) for p in params]
-    ref = _bilinear_ref(X2, Ws, btype)
-    (ref * R.double()).sum().backward()
-    _close(out.detach(), ref.detach(), "out")
-    _close(X.grad, X2.grad, "gX")
-    for k, (p, w) in enumerate(zip(params, Ws)):
-        _close(p.grad, w.grad, "gW%d" % k)
+    Pn = {"bl." + k: _n(v) for k, v in layer.state_dict().items()}
+    ref = O.bilinear_forward(_n(X), Pn, "bl.", btype)
+    grads = {}
+    gX = O.bilinear_backward(_n(R), _n(X), Pn, "bl.", btype, grads)
+    _close(out.detach(), ref, "out", tol=1e-5)
+    _close(X.grad, gX, "gX")
+    for k, p in layer.named_parameters():
+        _close(p.grad, grads.get("bl." + k), "g" + k)      # ('each': the last field's matrix is never a left factor)
 
 
 @pytest.mark.parametrize("btype", ["interaction", "each", "all"])
@@ -130,11 +138,14 @@ def test_inner_product(B, F, D, reduce_sum):
     assert out.shape == (B, P, 1 if reduce_sum else D)
     R = torch.randn_like(out)
     (out * R).sum().backward()
+    if reduce_sum:          # the oracle's statement (interaction.py:557-577, reduce_sum=True: PNN's use)
+        ref, pairs = O.inner_product_forward(_n(E))
+        _close(out.detach(), ref[:, :, None], "out", tol=1e-5)
+        _close(E.grad, O.inner_product_backward(_n(E), pairs, _n(R)[:, :, 0]), "gE")
+        return
     E2 = E.detach().double().requires_grad_(True)
     row, col = zip(*itertools.combinations(range(F), 2))
     ref = E2[:, list(row)] * E2[:, list(col)]
-    if reduce_sum:
-        ref = ref.sum(2, keepdim=True)
     (ref * R.double()).sum().backward()
     _close(out.detach(), ref.detach(), "out")
     _close(E.grad, E2.grad, "gE")
@@ -161,21 +172,13 @@ def test_crossnet(B, W, L, param):
                 assert node.next_functions, "the matrix form did not go through dctr_crossnet_mat_fwd"
                 node = node.next_functions[0][0]
     (Y * R).sum().backward()
-    X2 = X.detach().double().requires_grad_(True)
-    K, Bs = layer.kernels.detach().double().requires_grad_(True), layer.bias.detach().double().requires_grad_(True)
-    x0 = X2.unsqueeze(2)
-    xl = x0
-    for i in range(L):
-        if param == "vector":
-            xl = torch.matmul(x0, torch.tensordot(xl, K[i], dims=([1], [0]))) + Bs[i] + xl
-        else:
-            xl = x0 * (torch.matmul(K[i], xl) + Bs[i]) + xl
-    ref = xl.squeeze(2)
-    (ref * R.double()).sum().backward()
-    _close(Y.detach(), ref.detach(), "Y")
-    _close(X.grad, X2.grad, "gX")
-    _close(layer.kernels.grad, K.grad, "gK", tol=5e-5)
-    _close(layer.bias.grad, Bs.grad, "gb")
+    K, Bs = _n(layer.kernels), _n(layer.bias)
+    ref, xs = O.crossnet_forward(_n(X), K, Bs, param)
+    gX, gK, gB = O.crossnet_backward(_n(R), xs, K, Bs, param)
+    _close(Y.detach(), ref, "Y", tol=1e-5)
+    _close(X.grad, gX, "gX")
+    _close(layer.kernels.grad, gK, "gK", tol=5e-5)
+    _close(layer.bias.grad, gB, "gb")
 
 
 @pytest.mark.parametrize("B,F,D", [(7, 3, 4), (64, 26, 16), (33, 5, 7)])

@@ -102,3 +102,39 @@ def test_flags_long_run_on_large_tables():
     assert torch.equal(loss, ref_loss)
     for k in ref_sd:
         assert torch.equal(sd[k], ref_sd[k]), "%s differs" % k
+
+
+@pytest.mark.parametrize("opt", ["adagrad", "sgd"])
+def test_default_topology_follows_the_oracle_trajectory(opt):
+    """What the bit-comparisons above are anchored to: six steps of the default topology against the numpy oracle's fp64 train
+    step (oracle/np_oracle.py Oracle.train_step: the reference's dense update, pinned to its 3-step goldens) on a small
+    vocabulary -- every parameter within 2e-5 (Adagrad: 2e-4 of the elements may sit on the other side of a sign of a ~1e-9
+    gradient, as in tests/test_gpu_models.py)."""
+    import numpy as np
+    from np_oracle import Oracle
+    vocab, Bs, steps = 500, 512, 6
+    os.environ["DCTR_STEP_ENGINE"] = "0"
+    try:
+        m = _model(vocab, opt)
+        X, y = _data(vocab, 1)
+        spec = {"model": "DeepFM", "kwargs": {"dnn_hidden_units": [256, 128]},
+                "linear_columns": None, "dnn_columns": None}
+        cols = [{"kind": "sparse", "name": "C%d" % (i + 1), "vocab": vocab, "dim": DIM, "embedding_name": "C%d" % (i + 1)}
+                for i in range(F_SPARSE)] + [{"kind": "dense", "name": "I%d" % (i + 1), "dimension": 1} for i in range(N_DENSE)]
+        spec["linear_columns"] = spec["dnn_columns"] = cols
+        o = Oracle(spec, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, dtype=np.float64)
+        st = None
+        for i in range(steps):
+            xb, yb = X[i * Bs:(i + 1) * Bs], y[i * Bs:(i + 1) * Bs]
+            loss = m._train_step(xb, yb)[0]
+            lo, st = o.train_step(xb.cpu().numpy(), yb.cpu().numpy(), optimizer=opt, lr=0.01, eps=1e-10, state=st)
+            assert abs(float(loss) - lo) <= 2e-5 * max(1.0, abs(lo))
+        sd = m.state_dict()
+        for k, v in o.P.items():
+            d = np.abs(sd[k].double().cpu().numpy() - np.asarray(v).reshape(tuple(sd[k].shape)))
+            if opt == "sgd":
+                assert float(d.max()) <= 2e-5 * max(1.0, float(np.abs(v).max())), k
+            else:
+                assert float((d > 2e-5).mean()) <= 2e-4 and float(d.max()) <= 0.2, "%s: %.3e" % (k, d.max())
+    finally:
+        os.environ.pop("DCTR_STEP_ENGINE", None)
