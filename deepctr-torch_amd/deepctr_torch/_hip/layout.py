@@ -84,7 +84,10 @@ def apply_layout(plan, optimizer, state_key="sum", layout=None):
                 continue
             D = int(p.shape[1])
             ent = _SLAB.get(p)
-            slab = ent[0] if (_is_view_of(p, ent) and ent[0].shape[1] == 2 * D) else \
+            # (the slab a parameter already lives in is reused only if it is THIS layout's: same width AND the state column
+            # recorded for it -- a forward-only [V, 32] slab of a D = 16 table has the width of the interleaved one but
+            # keeps the wide weight where the Adagrad state would go)
+            slab = ent[0] if (_is_view_of(p, ent) and ent[0].shape[1] == 2 * D and ent[2] == D) else \
                 torch.empty((int(p.shape[0]), 2 * D), dtype=torch.float32, device=p.device)
             sv = _seat(p, slab, 0, states[id(p)], D)
             optimizer.state[p][state_key] = sv
