@@ -18,7 +18,9 @@ import sys
 from collections import OrderedDict, defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ("deepctr-torch_amd/csrc/update.hip", "deepctr-torch_amd/csrc/embed.hip", "deepctr-torch_amd/csrc/common.hpp")
+KERNEL_SOURCES = ("deepctr-torch_amd/csrc/update.hip", "deepctr-torch_amd/csrc/update_kernels.hpp",
+                  "deepctr-torch_amd/csrc/update_launch.inc", "deepctr-torch_amd/csrc/embed.hip",
+                  "deepctr-torch_amd/csrc/common.hpp")
 
 
 def code_hash():
@@ -47,7 +49,7 @@ def load(counter):
 
 def short(name):
     import re
-    m = re.search(r"k_embed_apply_sorted<\d+, \d+, (\d)>", name)
+    m = re.search(r"k_embed_apply_sorted<\d+, \d+, (\d)(?:, (?:false|true))?>", name)
     if m:      # the update proper (after the segment pre-pass); last template argument = the optimizer
         return {"0": "embed_update_sgd", "1": "embed_update_adagrad"}.get(m.group(1), "embed_update_accum")
     m = re.search(r"k_rows<(\d+), (\d+), (true|false), (\d+)>", name)
@@ -56,7 +58,7 @@ def short(name):
                                        "_x2arrays" if m.group(4) == "2" else "")
     if "k_embed_segments" in name:
         return "embed_segments"
-    m = re.search(r"k_embed_update<\d+, \d+, (\d)>", name)
+    m = re.search(r"k_embed_update<\d+, \d+, (\d)(?:, (?:false|true))?>", name)
     if m:      # the general kernel (no pre-pass); last template argument = the optimizer (0 SGD, 1 Adagrad, 2 accumulate)
         return {"0": "embed_update_general_sgd", "1": "embed_update_general_adagrad"}.get(m.group(1), "embed_update_general_accum")
     for key, tag in (("k_embed_fwd", "embed_fwd"), ("k_embed_update", "embed_update"),
