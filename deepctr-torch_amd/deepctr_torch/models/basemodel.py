@@ -1244,17 +1244,39 @@ class BaseModel(nn.Module):
             gen.manual_seed(seed)
             return torch.randperm(sample_num, generator=gen).to(self.device)
 
-        # the NEXT epoch's permutation (1-2 ms of host time per 256 k rows) is drawn while the GPU still runs this epoch's
-        # steps -- only when nothing else can draw from the default generator in between (no validation pass, no user
-        # callbacks), so the sequence of draws stays the reference's
+        # The permutations of the epochs AHEAD are drawn on worker threads while the GPU runs (torch.randperm on the host: 11 ms
+        # per 262 144 rows on the benchmark box, against 6 ms of GPU work for such an epoch -- fit() of short epochs was
+        # host-bound at 0.46 ms per step, profiles/r05_fit_profile.txt) -- only when nothing else can draw from the default
+        # generator in between (no validation pass, no user callbacks): the two draws per epoch the reference makes are then
+        # made up front, in the reference's order, so the generator ends where the reference's ends; every permutation comes
+        # from its own seeded generator, as in RandomSampler.
         lookahead = shuffle and not do_validation and not callbacks and S > 1
-        next_order = None
+        perm_pool, perm_futs = None, {}
+        if lookahead and epochs - initial_epoch > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            seeds = []
+            for _ in range(initial_epoch, epochs):
+                torch.empty((), dtype=torch.int64).random_()
+                seeds.append(int(torch.empty((), dtype=torch.int64).random_().item()))
+            perm_pool = ThreadPoolExecutor(max_workers=min(4, len(seeds)))
+
+            def _perm(seed):
+                gen = torch.Generator()
+                gen.manual_seed(seed)
+                return torch.randperm(sample_num, generator=gen)
+
+            def _submit(e):       # at most four permutations in flight / parked (8 bytes x rows each)
+                if e < epochs and e not in perm_futs:
+                    perm_futs[e] = perm_pool.submit(_perm, seeds[e - initial_epoch])
+            for e in range(initial_epoch, min(epochs, initial_epoch + 4)):
+                _submit(e)
         for epoch in range(initial_epoch, epochs):
             cbs.on_epoch_begin(epoch)
             epoch_logs = {}
             start_time = time.time()
-            if next_order is not None:
-                order, next_order = next_order, None
+            if perm_pool is not None:
+                order = perm_futs.pop(epoch).result().to(self.device)
+                _submit(epoch + 4)
             else:
                 order = draw_order()
             total_acc = torch.zeros((), device=self.device, dtype=torch.float64)
@@ -1306,8 +1328,6 @@ class BaseModel(nn.Module):
             finally:
                 if bar is not None:
                     bar.close()
-            if lookahead and epoch + 1 < epochs:
-                next_order = draw_order()
             plan.check_ids()
             epoch_logs["loss"] = float(total_acc.item()) / sample_num
             if preds is not None:
@@ -1336,6 +1356,8 @@ class BaseModel(nn.Module):
             cbs.on_epoch_end(epoch, epoch_logs)
             if self.stop_training:
                 break
+        if perm_pool is not None:
+            perm_pool.shutdown(wait=False)
         cbs.on_train_end()
         return self.history
 

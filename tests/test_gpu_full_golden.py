@@ -189,12 +189,11 @@ def test_full_size_train_step_matches_the_reference(name, opt):
         else:
             # Dense parameters are judged against the reference's FP64 gradient (stored as grad64/ next to its fp32 one): the
             # gradient itself under plain SGD, (w0 - w) / lr, and the updated parameter against the oracle's optimizer step
-            # (np_oracle.optimizer_step, what Oracle.train_step applies) on that fp64 gradient -- ONE relative bar, 5e-5 of
-            # the gradient's largest element (+ one ulp of the parameter over lr: the subtraction w0 - w rounds there).
-            # Why not 2e-5: these gradients are sums over 4 096 samples that CANCEL -- for FiBiNET's 325 bilinear matrices
-            # sum |term| is 100-250 x max |g| -- and fp32 accumulation then sits at ~2-4e-5 of max |g| in any summation order
-            # (measured: 4.3e-5 on Bilinear.bilinear.59.weight, the worst of ~400 tensors, 2e-5-3.9e-5 on a dozen more of those
-            # matrices, everything else inside 2e-5: profiles/r05_full_golden_errors.json).
+            # (np_oracle.optimizer_step, what Oracle.train_step applies) on that fp64 gradient -- ONE relative bar, 2e-5 of
+            # the gradient's largest element, plus the resolution of the measurement: a gradient read back from an SGD step is
+            # quantised to ulp(w) / lr (w = fl(w0 - fl(lr g)): half an ulp from rounding w, up to one more from the product) --
+            # 1.5 ulp(w) / lr.  (FiBiNET's bilinear matrices have max |g| ~ 3e-3 at |w| ~ 0.5: there the floor IS the bar;
+            # measured 1.1 ulp on Bilinear.bilinear.59.weight.)
             # (Rounds 3-4 compared with the reference's fp32 gradient and widened the bar by the reference's own
             # fp32-vs-fp64 gap, up to 1e-4: these kernels sit closer to the fp64 value than the reference's fp32 run does.)
             got = v.double().cpu().numpy()
@@ -209,7 +208,7 @@ def test_full_size_train_step_matches_the_reference(name, opt):
             ref64, _ = optimizer_step(opt, w0k, g64, s0, lr if opt == "sgd" else FD.LR_ADAGRAD, 1e-10)
             sens = 1.0 if opt == "sgd" else 1.0 / np.sqrt(FD.ADAGRAD_SUM0)      # d step / d g
             lr_eff = lr if opt == "sgd" else FD.LR_ADAGRAD
-            bar = 2e-5 * max(1.0, float(np.max(np.abs(ref64)))) + lr_eff * sens * 5e-5 * gmax
+            bar = 2e-5 * max(1.0, float(np.max(np.abs(ref64)))) + lr_eff * sens * 2e-5 * gmax
             err = float(np.max(np.abs(pick(got) - ref64)))
             _note(name, key + " (vs fp64 step)", err, bar)
             assert err <= bar, "%s %s: max|d| = %.3e (bar %.3e)" % (name, key, err, bar)
@@ -217,6 +216,6 @@ def test_full_size_train_step_matches_the_reference(name, opt):
                 wabs = max(float(w0[k].abs().max().item()), float(np.abs(got).max()))
                 floor = 2.0 ** (np.floor(np.log2(max(wabs, 1e-30))) - 23) / lr     # ulp(w) / lr
                 gerr = float(np.max(np.abs((w0k - pick(got)) / lr - g64)))
-                gbar = 5e-5 * gmax + floor
+                gbar = 2e-5 * gmax + 1.5 * floor
                 _note(name, k64, gerr, gbar)
                 assert gerr <= gbar, "%s %s: max|d| = %.3e (bar %.3e, err / bar %.2f)" % (name, k64, gerr, gbar, gerr / gbar)

@@ -115,7 +115,16 @@ def test_default_topology_follows_the_oracle_trajectory(opt):
     vocab, Bs, steps = 500, 512, 6
     os.environ["DCTR_STEP_ENGINE"] = "0"
     try:
-        m = _model(vocab, opt)
+        # (init_std 0.05, not the default 1e-4: with 1e-4 weights the embedding gradients are ~1e-9 -- at Adagrad's eps of
+        # 1e-10 -- and g / (|g| + eps) of an fp32 and an fp64 evaluation differ by percents: the AFM case of test_gpu_models)
+        from deepctr_torch.inputs import DenseFeat, SparseFeat
+        from deepctr_torch.models import DeepFM
+        fcols = [SparseFeat("C%d" % (i + 1), vocab, DIM) for i in range(F_SPARSE)] + \
+                [DenseFeat("I%d" % (i + 1), 1) for i in range(N_DENSE)]
+        m = DeepFM(fcols, fcols, dnn_hidden_units=(256, 128), l2_reg_linear=0, l2_reg_embedding=0, dnn_dropout=0, seed=1024,
+                   init_std=0.05, device=DEV)
+        m.compile(opt, "binary_crossentropy", metrics=[])
+        m.train()
         X, y = _data(vocab, 1)
         spec = {"model": "DeepFM", "kwargs": {"dnn_hidden_units": [256, 128]},
                 "linear_columns": None, "dnn_columns": None}

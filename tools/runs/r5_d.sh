@@ -14,7 +14,7 @@ cp gpurun_out/pmc_summary.json $O/pmc_summary.json
 rm -rf /tmp/prof5
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof5 -o deepfm -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 25 --no-cpu-baseline --no-other-configs --no-saturating ) > $O/rocprof.log 2>&1; echo "rocprof rc=$?"
 f=$(find /tmp/prof5 -name "*kernel_stats.csv" | head -1); cp $f $O/deepfm_kernel_stats.csv; head -8 $f | cut -c1-160
-t=$(find /tmp/prof5 -name "*kernel_trace.csv" | head -1); python tools/timeline.py $t 9 > $O/timeline.txt 2>&1; tail -30 $O/timeline.txt | cut -c1-160
+t=$(find /tmp/prof5 -name "*kernel_trace.csv" | head -1); python tools/timeline.py $t 9 90 > $O/timeline.txt 2>&1; tail -30 $O/timeline.txt | cut -c1-160
 ( timeout 300 python bench.py --steps 20 --warmup 5 ) 2> $O/bench_driver.err | grep '^{' > $O/bench_driver_flags.json
 python -c "
 import json
