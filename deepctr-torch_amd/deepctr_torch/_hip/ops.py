@@ -196,7 +196,7 @@ class EmbedFunction(torch.autograd.Function):
 
         if getattr(plan, "exchange", None) is not None:
             # data-parallel: the trainer all-gathers the row gradients and applies the global update
-            plan.exchange(X=X, g_out=g_out, out=out, fm_s=fm_s, g_fm=g_fm, g_wide=g_wide)
+            plan.exchange(X=X, g_out=g_out, out=out, fm_s=fm_s, g_fm=g_fm, g_wide=g_wide, amax=amax)
             return None, None, None, g_w, None, None
 
         update = plan.update

@@ -19,8 +19,10 @@ same contract, one process per GPU (``torch.distributed``: RCCL on GPUs, gloo on
   * validation, callbacks and whatever reads ``model.embedding_dict`` after an epoch see complete tables
     (``gather_tables`` at the end of every epoch that needs it).
 
-Models / optimizers outside ``ShardedTrainer``'s envelope (pooled or shared tables, Adam, L2 on the tables) raise
-``NotImplementedError`` naming the reason -- never a silent single-GPU run."""
+Models / optimizers outside ``ShardedTrainer``'s envelope (pooled VarLen features, tables shared through embedding_name, Adam /
+RMSprop, L2 on the tables, the reference's default kwargs) train through ``parallel.DataParallelTrainer`` instead: tables
+replicated, every rank applies the same global update from the all-gathered row gradients -- the single-process step on the
+global batch as well, O(vocabulary) only where the optimizer itself is.  Never a silent single-GPU run."""
 import os
 import time
 
@@ -51,46 +53,106 @@ def _ensure_group(device):
     return dist
 
 
+class _Sharded(object):
+    """ShardedTrainer behind the few calls the epoch loop makes."""
+    kind = "tables sharded over the ranks"
+
+    def __init__(self, tr):
+        self.tr = tr
+        self.exchange = tr.exchange
+
+    def train_step(self, xb, yb, next_xb=None):
+        return self.tr.train_step(xb, yb, next_xb=next_xb)
+
+    def set_use_graphs(self, on):
+        self.tr.set_use_graphs(on)
+
+    def gather_tables(self):
+        self.tr.gather_tables()
+
+    def detach(self):
+        self.tr._join()
+        self.tr.plan.sharder = None
+
+    def attach(self):
+        self.tr.plan.sharder = self.tr
+        self.tr._announced = None      # whatever was announced to the owners is stale now
+        self.tr._pre = None
+
+
+class _Replicated(object):
+    """DataParallelTrainer (replicated tables, any model / optimizer) behind the same calls: every replica's tables are
+    always current, nothing to gather, nothing to announce."""
+    kind = "tables replicated"
+    exchange = "all-gather of row gradients"
+
+    def __init__(self, tr):
+        self.tr = tr
+
+    def train_step(self, xb, yb, next_xb=None):
+        return self.tr.train_step(xb, yb)
+
+    def set_use_graphs(self, on):
+        pass
+
+    def gather_tables(self):
+        pass
+
+    def detach(self):
+        # (a ragged batch taken by every rank on its own runs the autograd route + torch.optim like the trainer's steps do:
+        # one owner of the dense optimizer state -- Adam's step counters -- whichever step runs)
+        self.tr.plan.exchange = None
+        self._env = os.environ.get("DCTR_FUSED_STEP")
+        os.environ["DCTR_FUSED_STEP"] = "0"
+
+    def attach(self):
+        self.tr.plan.exchange = self.tr._defer
+        if getattr(self, "_env", None) is None:
+            os.environ.pop("DCTR_FUSED_STEP", None)
+        else:
+            os.environ["DCTR_FUSED_STEP"] = self._env
+
+
 def trainer_for(model):
-    """The model's ShardedTrainer (built once per compile(): it holds exchange buffers and captured segments)."""
+    """The model's trainer (built once per compile(): it holds exchange buffers and captured segments): ShardedTrainer where
+    its envelope holds the model, DataParallelTrainer otherwise."""
     from . import parallel as par
-    tr = getattr(model, "_dist_trainer", None)
+    ad = getattr(model, "_dist_trainer", None)
     plan = model.model_plan()
-    if tr is not None and tr.model is model and getattr(tr, "_optim", None) is getattr(model, "optim", None) and \
-            tr.plan is plan and plan.sharder in (None, tr):
-        plan.sharder = tr          # (the previous fit() left every rank's tables current and detached the trainer)
-        tr._announced = None
-        tr._pre = None
-        return tr
-    if not plan.simple_units:
-        raise NotImplementedError("fit() under torchrun shards the embedding tables over the ranks (ShardedTrainer): that "
-                                  "needs fixed-length sparse features over distinct tables; this model has pooled VarLen "
-                                  "features or shared tables -- train it on one GPU or with parallel.DataParallelTrainer")
-    ops = None
-    factory = getattr(model, "_shard_ops_factory", None)      # (tests: stand-ins for the device kernels)
-    if factory is not None:
-        ops = factory(model, par.ShardLayout(plan, *context()))
-    tr = par.ShardedTrainer(model, ops=ops, exchange=os.environ.get("DCTR_SHARDED_EXCHANGE", "rccl"))
-    tr._optim = getattr(model, "optim", None)
-    model._dist_trainer = tr
-    return tr
+    if ad is not None and ad.tr.model is model and getattr(ad, "_optim", None) is getattr(model, "optim", None) and \
+            ad.tr.plan is plan:
+        ad.attach()                # (the previous fit() left every rank's tables current and detached the trainer)
+        return ad
+    ad = None
+    if plan.simple_units and plan.update[0] in ("sgd", "adagrad") and os.environ.get("DCTR_FIT_TRAINER", "auto") != "replicated":
+        try:
+            ops = None
+            factory = getattr(model, "_shard_ops_factory", None)      # (tests: stand-ins for the device kernels)
+            if factory is not None:
+                ops = factory(model, par.ShardLayout(plan, *context()))
+            ad = _Sharded(par.ShardedTrainer(model, ops=ops, exchange=os.environ.get("DCTR_SHARDED_EXCHANGE", "rccl")))
+        except NotImplementedError:
+            plan.sharder = None
+            ad = None
+    if ad is None:
+        ad = _Replicated(par.DataParallelTrainer(model))
+    ad._optim = getattr(model, "optim", None)
+    model._dist_trainer = ad
+    return ad
 
 
 class _Unsharded(object):
-    """``with _Unsharded(trainer):`` -- lookups go through the local tables (current after ``gather_tables``)."""
+    """``with _Unsharded(trainer):`` -- lookups and updates go through the local tables (current after ``gather_tables``)."""
 
     def __init__(self, tr):
         self.tr = tr
 
     def __enter__(self):
-        self.tr._join()
-        self.tr.plan.sharder = None
+        self.tr.detach()
         return self
 
     def __exit__(self, *exc):
-        self.tr.plan.sharder = self.tr
-        self.tr._announced = None      # whatever was announced to the owners is stale now
-        self.tr._pre = None
+        self.tr.attach()
         return False
 
 
@@ -106,8 +168,7 @@ def fit(model, X_all, y_all, batch_size, epochs, verbose, initial_epoch, do_vali
     steps_per_epoch = n_full + (1 if n_tail else 0)
     model.train()
     if rank == 0:
-        print("%s -- %d ranks, batch %d per rank (%d global), tables sharded over the ranks (%s exchange)" % (
-            model.device, world, b, G, tr.exchange))
+        print("%s -- %d ranks, batch %d per rank (%d global), %s (%s)" % (model.device, world, b, G, tr.kind, tr.exchange))
         print("Train on {0} samples, validate on {1} samples, {2} steps per epoch".format(
             sample_num, len(val_y), steps_per_epoch))
     cbs = _cb.CallbackList((callbacks or []) + [model.history])
@@ -218,7 +279,6 @@ def fit(model, X_all, y_all, batch_size, epochs, verbose, initial_epoch, do_vali
             break
     # leave the model usable on its own (predict / evaluate / state_dict read complete local tables); the trainer is kept
     # for the next fit() call and re-attached there
-    tr._join()
-    tr.plan.sharder = None
+    tr.detach()
     cbs.on_train_end()
     return model.history

@@ -136,10 +136,9 @@ class DataParallelTrainer(object):
             self._forced_dense = True
             if self.plan.update[0] == "lazy":
                 raise RuntimeError("the model kept the lazy table update although the dense route was requested")
-        if not self.plan.simple_units:
-            raise NotImplementedError("data-parallel training needs fixed-length sparse features over distinct "
-                                      "tables (the deterministic update kernel); pooled VarLen features are "
-                                      "single-GPU for now")
+        if not self.plan.unit_path:
+            raise NotImplementedError("data-parallel training needs the deterministic update kernel; this model's "
+                                      "feature columns are outside its envelope (a table fed by more than 128 columns)")
         tables = set(id(p) for p in self.plan.table_params)
         self.bucket = DenseBucket([p for p in model.parameters() if id(p) not in tables])
         self.payload = SparsePayload(self.plan.emb_width, self.plan.n_xcols)
@@ -218,7 +217,8 @@ class DataParallelTrainer(object):
             X = st["X"]
             G = fold_fm(st["g_out"], plan.emb_width, st["out"], st["fm_s"], st["g_fm"], plan.emb_dim) \
                 if plan.deep else None
-            gathered = self.payload.gather(self.payload.pack(X, G, st["g_wide"]), self.group)
+            with torch.no_grad():      # (plain data movement; a pooled field's folded gradient can arrive attached to a graph)
+                gathered = self.payload.gather(self.payload.pack(X, G, st["g_wide"]).detach(), self.group)
             X_all, G_all, gw_all = self.payload.views(gathered)
             NB = gathered.shape[0]
             lib = L.lib()
@@ -235,11 +235,18 @@ class DataParallelTrainer(object):
             cplan = plan.bind(X.device)
             if not plan.update_kernel_ok(NB):
                 raise RuntimeError("global batch %d is beyond the deterministic update kernel" % NB)
-            ids_t = torch.empty((len(plan.units), NB), dtype=torch.int32, device=X.device)
-            parts_t = torch.empty((len(plan.units), NB), dtype=torch.int16, device=X.device)
-            L.check(lib.dctr_embed_ids(cplan, plan.units_ptr(), len(plan.units), _ptr(X_all), gathered.stride(0), NB,
+            ids_t = torch.empty((plan.n_vcols, NB), dtype=torch.int32, device=X.device)
+            parts_t = torch.empty((plan.n_vcols, NB), dtype=torch.int16, device=X.device)
+            # general units (pooled VarLen fields, shared tables; round 5): mean pooling's divisors are recomputed from the
+            # gathered X with the ids; max pooling's arg-max positions (a side output of every rank's own gather) are
+            # all-gathered like the gradients.  FM's backward is already folded into G on the POOLED values (fold_fm).
+            den_t, amax_all = plan.step_buffers(NB, X.device)
+            if amax_all is not None:
+                dist.all_gather_into_tensor(amax_all, st["amax"].contiguous(), group=self.group)
+            plan.point_step_buffers(den_t, amax_all)
+            L.check(lib.dctr_embed_ids(cplan, plan.units_ptr(), plan.n_grid_units, _ptr(X_all), gathered.stride(0), NB,
                                        _ptr(ids_t), _ptr(parts_t), stream), "dctr_embed_ids")
-            L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), len(plan.units), plan.max_vocab, _ptr(ids_t),
+            L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), plan.n_grid_units, plan.max_vocab, _ptr(ids_t),
                                           _ptr(parts_t), NB,
                                           _ptr(G_all) if plan.deep else None, gathered.stride(0), None, 0, None, 0,
                                           None, _ptr(gw_all) if plan.wide else None, 1, opt, lr, eps, None, 0, None, None, None, 0, 0, stream),
@@ -1131,7 +1138,18 @@ class ShardedTrainer(object):
             # normally done that already)
             seg.primed = getattr(self, "_direct_seg", None) is not None and self._direct_seg.primed
         loss, y_pred = seg()
+        self._direct_watchdog(S)
         return loss, loss.reshape(1), y_pred
+
+    def _direct_watchdog(self, n_steps):
+        """A direct-exchange wait that timed out only raises a bit on the device and the step goes on with incomplete
+        peer buffers: poll it every few hundred steps (one device sync), not only in close() -- a dead or desynchronised
+        rank must not train silently wrong for the rest of the run (round-4 advisor finding)."""
+        self._dx_steps = getattr(self, "_dx_steps", 0) + int(n_steps)
+        if self._dx_steps >= int(os.environ.get("DCTR_DIRECT_CHECK_EVERY", "512")):
+            self._dx_steps = 0
+            if not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+                self._dx.check()
 
     def _train_step_direct(self, xb, yb, next_xb=None):
         import ctypes
@@ -1149,6 +1167,7 @@ class ShardedTrainer(object):
             self.ops.gather(ids_all, out=(self._chunks, self._ids_buf, self._parts_buf), push=self._push_rows())
         self._announced = (next_xb.data_ptr(), next_xb._version) if announce else None
         loss, y_pred = self._direct_seg()
+        self._direct_watchdog(1)
         return loss, loss.reshape(1), y_pred
 
     def _join(self):

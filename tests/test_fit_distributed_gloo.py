@@ -32,19 +32,30 @@ def _setup_paths():
             sys.path.insert(0, p)
 
 
-def _data():
+def _data(kind="sharded"):
     g = torch.Generator().manual_seed(11)
     ids = torch.randint(0, V_, (N_, F_), generator=g).float()
     X = torch.cat([ids, torch.rand(N_, ND_, generator=g)], 1).numpy()
     y = torch.randint(0, 2, (N_,), generator=g).float().numpy()
     names = ["C%d" % i for i in range(F_)] + ["I%d" % i for i in range(ND_)]
-    return {n: X[:, i] for i, n in enumerate(names)}, y
+    x = {n: X[:, i] for i, n in enumerate(names)}
+    if kind == "replicated":
+        h = torch.randint(1, V_, (N_, 3), generator=g) * (torch.arange(3)[None, :] < torch.randint(0, 4, (N_, 1), generator=g))
+        x["hist"] = h.numpy()
+    return x, y
 
 
-def _model():
-    from deepctr_torch.inputs import DenseFeat, SparseFeat
+def _model(kind="sharded"):
+    """'sharded': fixed-length fields, Adagrad, no L2 -> ShardedTrainer.  'replicated': a pooled history over C0's table, the
+    reference's default L2 and adam -> outside that envelope -> DataParallelTrainer (replicated tables)."""
+    from deepctr_torch.inputs import DenseFeat, SparseFeat, VarLenSparseFeat
     from deepctr_torch.models import DeepFM
     cols = [SparseFeat("C%d" % i, V_, D_) for i in range(F_)] + [DenseFeat("I%d" % i, 1) for i in range(ND_)]
+    if kind == "replicated":
+        cols.append(VarLenSparseFeat(SparseFeat("hist", V_, D_, embedding_name="C0"), maxlen=3, combiner="mean"))
+        m = DeepFM(cols, cols, dnn_hidden_units=(16, 8), init_std=0.1, seed=7, device="cpu")
+        m.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy"])
+        return m
     m = DeepFM(cols, cols, dnn_hidden_units=(16, 8), l2_reg_linear=0, l2_reg_embedding=0, init_std=0.1, seed=7, device="cpu")
     m.compile("adagrad", "binary_crossentropy", metrics=["binary_crossentropy"])
     return m
@@ -60,14 +71,14 @@ def _patch_for_cpu():
     torch.Tensor.is_cuda = property(lambda self: True)
 
 
-def _fit(m, batch, shuffle):
-    x, y = _data()
+def _fit(m, batch, shuffle, kind="sharded"):
+    x, y = _data(kind)
     torch.manual_seed(123)
     hist = m.fit(x, y, batch_size=batch, epochs=2, verbose=2, shuffle=shuffle, validation_split=0.2)
     return {k: [float(v) for v in vals] for k, vals in hist.history.items()}
 
 
-def _worker(rank, world, port, shuffle, out_dir):
+def _worker(rank, world, port, shuffle, out_dir, kind="sharded"):
     _setup_paths()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank))
     os.environ["DCTR_FIT_GRAPH"] = "0"
@@ -75,12 +86,13 @@ def _worker(rank, world, port, shuffle, out_dir):
     _patch_for_cpu()
     import torch.distributed as dist
     from shard_standin import TorchShardOps
-    m = _model()
+    m = _model(kind)
     m._shard_ops_factory = lambda model, lay: TorchShardOps(model, lay)
     if rank != 0:
         torch.manual_seed(999)       # (overwritten by _fit's seed; the broadcast permutation is what keeps ranks together)
-    hist = _fit(m, B_, shuffle)      # fit() initialises the process group itself from the torchrun environment
-    pred = m.predict(_data()[0], batch_size=50)
+    hist = _fit(m, B_, shuffle, kind)      # fit() initialises the process group itself from the torchrun environment
+    assert type(m._dist_trainer).__name__ == ("_Sharded" if kind == "sharded" else "_Replicated")
+    pred = m.predict(_data(kind)[0], batch_size=50)
     torch.save({"hist": hist, "pred": pred, "sd": {k: v.detach().clone() for k, v in m.state_dict().items()}},
                os.path.join(out_dir, "rank%d.pt" % rank))
     dist.destroy_process_group()
@@ -106,5 +118,30 @@ def test_fit_under_two_ranks_equals_fit_on_the_global_batch(tmp_path, mock, shuf
         for k, v in ref_model.state_dict().items():
             err = float((ranks[r]["sd"][k] - v).abs().max())
             assert err <= 2e-5 * max(1.0, float(v.abs().max())), "rank %d %s: %.3e" % (r, k, err)
+    for k in ranks[0]["sd"]:
+        assert torch.equal(ranks[0]["sd"][k], ranks[1]["sd"][k]), "replicas differ: %s" % k
+
+
+def test_fit_under_two_ranks_outside_the_sharded_envelope_uses_replicated_tables(tmp_path, mock):
+    """A pooled history over a SHARED table, the reference's default L2, adam: ShardedTrainer's envelope does not hold it, fit()
+    under torchrun trains it through DataParallelTrainer (replicated tables; the sorted update on general units over the
+    all-gathered row gradients) -- same History / predictions / parameters as one process on the global batch."""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), True, str(tmp_path), "replicated"), nprocs=world, join=True)
+    ranks = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(world)]
+    os.environ["DCTR_FIT_GRAPH"] = "0"
+    try:
+        ref_model = _model("replicated")
+        ref_hist = _fit(ref_model, B_ * world, True, "replicated")
+    finally:
+        os.environ.pop("DCTR_FIT_GRAPH", None)
+    ref_pred = ref_model.predict(_data("replicated")[0], batch_size=50)
+    for r in range(world):
+        for k, want in ref_hist.items():
+            np.testing.assert_allclose(ranks[r]["hist"][k], want, rtol=5e-5, err_msg="rank %d %s" % (r, k))
+        assert float(np.abs(ranks[r]["pred"] - ref_pred).max()) <= 5e-5
+        for k, v in ref_model.state_dict().items():
+            err = float((ranks[r]["sd"][k] - v).abs().max())
+            assert err <= 5e-5 * max(1.0, float(v.abs().max())), "rank %d %s: %.3e" % (r, k, err)
     for k in ranks[0]["sd"]:
         assert torch.equal(ranks[0]["sd"][k], ranks[1]["sd"][k]), "replicas differ: %s" % k
