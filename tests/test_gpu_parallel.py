@@ -100,3 +100,36 @@ def test_sharded_trainer_one_rank_matches_single_gpu_and_reference(one_rank_grou
     with torch.no_grad():
         y = models[1](torch.from_numpy(g["X"]).to(DEV))
     assert y.shape[0] == g["X"].shape[0]
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
+def test_trainer_runs_pooled_and_shared_tables(one_rank_group, opt):
+    """DataParallelTrainer on general update units (round 5): tests/golden/deepfm_mixed -- sum / mean / max pooled VarLen
+    fields, a history sharing the item table, a length column -- through gather -> all-gather of row gradients and arg-max
+    positions -> the global sorted update, against the reference's 3-step trajectory and the single-GPU step."""
+    from deepctr_torch.parallel import DataParallelTrainer
+    g = load_golden("deepfm_mixed")
+    models = []
+    for use_trainer in (False, True):
+        m = build_model(g["spec"], DEV)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in g["params"].items()})
+        m.compile(opt, "binary_crossentropy", metrics=[])
+        m.train()
+        assert m.model_plan().gen is not None
+        tr = DataParallelTrainer(m) if use_trainer else None
+        losses = []
+        for Xb, yb in zip(g["extra"]["X_steps"], g["extra"]["y_steps"]):
+            xb, yb = torch.from_numpy(Xb).to(DEV), torch.from_numpy(yb).to(DEV)
+            losses.append((tr.train_step(xb, yb) if tr else m._train_step(xb, yb))[0].item())
+        if tr:
+            tr.close()
+        torch.cuda.synchronize()
+        m.model_plan().check_ids()
+        np.testing.assert_allclose(losses, g["extra"][opt + "3_loss"], rtol=2e-5)
+        models.append(m)
+    a, b = models[0].state_dict(), models[1].state_dict()
+    for k in a:
+        assert max_abs(a[k].cpu().numpy(), b[k].cpu().numpy()) <= 2e-6, k
+    for k, v in g["extra"].items():
+        if k.startswith(opt + "3/"):
+            assert max_abs(b[k[len(opt) + 2:]].cpu().numpy(), v) <= 2e-5, k
