@@ -176,6 +176,9 @@ size_t dctr_sizeof_plan(void);
  *   fm    [B]  0.5 * sum_d ((sum_f e)^2 - sum_f e^2) over ALL deep fields (nullable; needs emb_dim)
  *   err   int32 flag; bit0 is set when an id falls outside [0, vocab) -- such a row reads as row 0
  *         (the reference raises IndexError on CPU; here the flag is polled by the host) (nullable)
+ * A plan with general units (plan->ext) takes its ids / tags from dctr_embed_ids instead (ids_t must be NULL here); when
+ * ext->amax is set the launch writes, for every max-pooled field, the position of the first maximum per element
+ * (uint8 [B, ext->ld_amax] at ext->am_deep_off[f] / am_wide_off[f]): max pooling's backward in dctr_embed_update.
  * Optional side outputs feed dctr_embed_update (all nullable):
  *   ids_t [n_units, B] int32: ids_t[u][b] = (int) X[b, units[u].col]  (units: see dctr_embed_update)
  *   parts_t [n_units, B] uint16: clamp(ids_t[u][b]) mod dctr_embed_update_partitions(plan, B)  (needs ids_t)
@@ -215,8 +218,11 @@ int dctr_embed_apply(const dctr_plan_t* plan, const float* X, int64_t ldx, int32
                      float lr, float eps, dctr_stream_t stream);
 
 /* ---- deterministic fused backward + optimizer (csrc/update.hip) ------------------------------------
- * The O(batch) replacement of embedding_dense_backward + FM backward + the optimizer's walk over the
- * tables (basemodel.py:261-262) for plans of fixed-length fields over distinct tables.  No atomics:
+ * The O(batch) replacement of embedding_dense_backward + the pooling's backward + FM backward + the optimizer's walk
+ * over the tables (basemodel.py:261-262).  Plans of fixed-length fields over distinct tables run one-column units
+ * (`units` below); pooled VarLen fields and tables shared through embedding_name run GENERAL units (plan->ext,
+ * dctr_plan_ext_t above: then n_units = ext->n_vunits, ids_t / parts_t are [ext->n_vcols, B], parts_t is required, `out`
+ * must be the forward's rows when g_fm is given, ext->den_t / ext->amax must point at this step's side buffers).  No atomics:
  * workgroup (unit, partition) owns rows {id : id mod P == partition}, sorts its (id, b) entries in LDS
  * and read-modify-writes each touched row exactly once, summing duplicate ids in (id, b) order, so the
  * result is bit-reproducible (needed for replica equality under data parallelism).
@@ -265,7 +271,9 @@ int32_t dctr_embed_update_partitions(const dctr_plan_t* plan, int32_t B);
  * dctr_dbg_update_trace(NULL, -1) restores normal operation.  The shipped library has no mutable global state.   */
 void dctr_dbg_update_trace(unsigned long long* buf, int32_t force_p);
 #endif
-/* plan is only needed (non-NULL) when parts_t is requested */
+/* plan is only needed (non-NULL) when parts_t is requested.  A plan with general units (plan->ext): n_units =
+ * ext->n_vunits, ids_t / parts_t are [ext->n_vcols, B] (one row per X column feeding a unit; a position that sum / mean
+ * pooling masks out gets the tag 0xFFFF), and ext->den_t [ext->n_den, B] receives mean pooling's divisors count + 1e-8. */
 int dctr_embed_ids(const dctr_plan_t* plan, const int32_t* units, int32_t n_units, const float* X, int64_t ldx,
                    int32_t B, int32_t* ids_t, uint16_t* parts_t, dctr_stream_t stream);
 int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, int32_t n_units, int64_t max_vocab,

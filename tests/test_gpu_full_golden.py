@@ -187,35 +187,46 @@ def test_full_size_train_step_matches_the_reference(name, opt):
                     gmax = float(g["grad/%s/absmax" % k])
                     _check_rows(name, "grad/" + k, rows, (start - got) / lr, g, lambda ref: 2e-5 * gmax + 1e-6)
         else:
-            # Dense parameters are judged against the reference's FP64 gradient (stored as grad64/ next to its fp32 one): the
-            # gradient itself under plain SGD, (w0 - w) / lr, and the updated parameter against the oracle's optimizer step
-            # (np_oracle.optimizer_step, what Oracle.train_step applies) on that fp64 gradient -- ONE relative bar, 2e-5 of
-            # the gradient's largest element, plus the resolution of the measurement: a gradient read back from an SGD step is
-            # quantised to ulp(w) / lr (w = fl(w0 - fl(lr g)): half an ulp from rounding w, up to one more from the product) --
-            # 1.5 ulp(w) / lr.  (FiBiNET's bilinear matrices have max |g| ~ 3e-3 at |w| ~ 0.5: there the floor IS the bar;
-            # measured 1.1 ulp on Bilinear.bilinear.59.weight.)
-            # (Rounds 3-4 compared with the reference's fp32 gradient and widened the bar by the reference's own
-            # fp32-vs-fp64 gap, up to 1e-4: these kernels sit closer to the fp64 value than the reference's fp32 run does.)
+            # Dense parameters: every element must agree with the reference's fp32 result OR with its fp64 evaluation (both are
+            # stored: grad/ and grad64/) within ONE relative bar, 2e-5 of the gradient's largest element.  Two references
+            # because the tower is piecewise linear: where a first-layer pre-activation lies within ~1e-7 of zero, an fp32 and
+            # an fp64 forward take different branches of the ReLU and that sample's whole contribution to a weight row
+            # (~4e-4 of max |g| on FiBiNET's 10 413-wide layer) moves -- the reference's own two runs differ by that much; an
+            # element on either branch is right.  The updated parameter is compared the same way: the reference's fp32
+            # parameter, or the oracle's optimizer step (np_oracle.optimizer_step) on the fp64 gradient.  The gradient read
+            # back from an SGD step, (w0 - w) / lr, is quantised to ulp(w) / lr (half an ulp from rounding w, up to one more
+            # from the product): 1.5 ulp(w) / lr is the resolution of that measurement, added to its bar (FiBiNET's
+            # bilinear matrices: max |g| ~ 3e-3 at |w| ~ 0.5 -- there the floor IS the bar; measured 1.1 ulp).
+            # (Rounds 3-4 widened the bar itself by the reference's fp32-vs-fp64 gap, up to 1e-4.)
             got = v.double().cpu().numpy()
             gk, k64 = "grad/" + k, "grad64/" + k
             full = k64 + "/all" in g
-            g64 = np.asarray(g[k64 + ("/all" if full else "/sample")], np.float64)
+            sfx = "/all" if full else "/sample"
+            g64, g32 = np.asarray(g[k64 + sfx], np.float64), np.asarray(g[gk + sfx], np.float64)
             gmax = float(g[gk + "/absmax"]) if gk + "/absmax" in g else float(np.max(np.abs(g64)))
             pick = (lambda a: np.asarray(a, np.float64).reshape(g64.shape)) if full else \
                 (lambda a: np.asarray(a, np.float64).reshape(-1)[::FD.STRIDE])
             w0k = pick(w0[k].double().cpu().numpy())
-            s0 = np.full_like(w0k, FD.ADAGRAD_SUM0) if opt == "adagrad" else None
-            ref64, _ = optimizer_step(opt, w0k, g64, s0, lr if opt == "sgd" else FD.LR_ADAGRAD, 1e-10)
-            sens = 1.0 if opt == "sgd" else 1.0 / np.sqrt(FD.ADAGRAD_SUM0)      # d step / d g
             lr_eff = lr if opt == "sgd" else FD.LR_ADAGRAD
+            s0 = np.full_like(w0k, FD.ADAGRAD_SUM0) if opt == "adagrad" else None
+            ref64, _ = optimizer_step(opt, w0k, g64, s0, lr_eff, 1e-10)
+            ref32 = np.asarray(g[key + sfx], np.float64).reshape(ref64.shape)
+            sens = 1.0 if opt == "sgd" else 1.0 / np.sqrt(FD.ADAGRAD_SUM0)      # d step / d g
             bar = 2e-5 * max(1.0, float(np.max(np.abs(ref64)))) + lr_eff * sens * 2e-5 * gmax
-            err = float(np.max(np.abs(pick(got) - ref64)))
-            _note(name, key + " (vs fp64 step)", err, bar)
+            gotk = pick(got)
+            err = float(np.max(np.minimum(np.abs(gotk - ref32), np.abs(gotk - ref64))))
+            _note(name, key + " (fp32 | fp64 step)", err, bar)
             assert err <= bar, "%s %s: max|d| = %.3e (bar %.3e)" % (name, key, err, bar)
+            if not full:      # the elements between the samples: four random projections of the whole tensor (fp32 reference)
+                flat = got.reshape(-1)
+                for q in range(4):
+                    pr = float(np.dot(flat, FD.proj_weights(flat.size, q)))
+                    assert abs(pr - g[key + "/proj"][q]) <= bar * np.sqrt(flat.size) * 0.6 + 1e-9, "%s %s (projection %d)" % (name, key, q)
             if opt == "sgd":
                 wabs = max(float(w0[k].abs().max().item()), float(np.abs(got).max()))
                 floor = 2.0 ** (np.floor(np.log2(max(wabs, 1e-30))) - 23) / lr     # ulp(w) / lr
-                gerr = float(np.max(np.abs((w0k - pick(got)) / lr - g64)))
+                gotg = (w0k - gotk) / lr
+                gerr = float(np.max(np.minimum(np.abs(gotg - g32.reshape(gotg.shape)), np.abs(gotg - g64))))
                 gbar = 2e-5 * gmax + 1.5 * floor
-                _note(name, k64, gerr, gbar)
-                assert gerr <= gbar, "%s %s: max|d| = %.3e (bar %.3e, err / bar %.2f)" % (name, k64, gerr, gbar, gerr / gbar)
+                _note(name, gk + " (fp32 | fp64)", gerr, gbar)
+                assert gerr <= gbar, "%s %s: max|d| = %.3e (bar %.3e, err / bar %.2f)" % (name, gk, gerr, gbar, gerr / gbar)
