@@ -70,7 +70,7 @@ class _Sharded(object):
     def gather_tables(self):
         self.tr.gather_tables()
 
-    def detach(self):
+    def detach(self, train=False):
         self.tr._join()
         self.tr.plan.sharder = None
 
@@ -98,19 +98,25 @@ class _Replicated(object):
     def gather_tables(self):
         pass
 
-    def detach(self):
-        # (a ragged batch taken by every rank on its own runs the autograd route + torch.optim like the trainer's steps do:
-        # one owner of the dense optimizer state -- Adam's step counters -- whichever step runs)
+    def detach(self, train=False):
+        # (train: a ragged batch taken by every rank on its own runs the autograd route + torch.optim like the trainer's
+        # steps do -- one owner of the dense optimizer state (Adam's step counters) whichever step runs; the switch is put
+        # back by attach())
         self.tr.plan.exchange = None
-        self._env = os.environ.get("DCTR_FUSED_STEP")
-        os.environ["DCTR_FUSED_STEP"] = "0"
+        self._env = None
+        if train:
+            self._env = (os.environ.get("DCTR_FUSED_STEP"),)
+            os.environ["DCTR_FUSED_STEP"] = "0"
 
     def attach(self):
         self.tr.plan.exchange = self.tr._defer
-        if getattr(self, "_env", None) is None:
-            os.environ.pop("DCTR_FUSED_STEP", None)
-        else:
-            os.environ["DCTR_FUSED_STEP"] = self._env
+        env = getattr(self, "_env", None)
+        if env is not None:
+            if env[0] is None:
+                os.environ.pop("DCTR_FUSED_STEP", None)
+            else:
+                os.environ["DCTR_FUSED_STEP"] = env[0]
+            self._env = None
 
 
 def trainer_for(model):
@@ -144,11 +150,11 @@ def trainer_for(model):
 class _Unsharded(object):
     """``with _Unsharded(trainer):`` -- lookups and updates go through the local tables (current after ``gather_tables``)."""
 
-    def __init__(self, tr):
-        self.tr = tr
+    def __init__(self, tr, train=False):
+        self.tr, self.train = tr, train
 
     def __enter__(self):
-        self.tr.detach()
+        self.tr.detach(train=self.train)
         return self
 
     def __exit__(self, *exc):
@@ -220,7 +226,7 @@ def fit(model, X_all, y_all, batch_size, epochs, verbose, initial_epoch, do_vali
                 preds.append((yb, y_pred.detach().reshape(-1).clone(), True))
         if n_tail:
             tr.gather_tables()
-            with _Unsharded(tr):
+            with _Unsharded(tr, train=True):
                 xb, yb = rows(n_full * G, sample_num)
                 loss, total_loss, y_pred = model._train_step(xb, yb)
             acc_tail += total_loss.detach().double().sum()
