@@ -210,14 +210,22 @@ def test_full_size_train_step_matches_the_reference(name, opt):
             lr_eff = lr if opt == "sgd" else FD.LR_ADAGRAD
             s0 = np.full_like(w0k, FD.ADAGRAD_SUM0) if opt == "adagrad" else None
             ref64, _ = optimizer_step(opt, w0k, g64, s0, lr_eff, 1e-10)
-            ref32 = np.asarray(g[key + sfx], np.float64).reshape(ref64.shape)
+            # (the fixture may hold the updated parameter sampled where it holds the gradient in full, or the other way round)
+            if key + sfx in g:
+                ref32 = np.asarray(g[key + sfx], np.float64).reshape(ref64.shape)
+            elif full:         # gradient in full, parameter sampled: compare on the samples
+                ref32 = np.asarray(g[key + "/sample"], np.float64)
+                ref64 = ref64.reshape(-1)[::FD.STRIDE]
+                pick = lambda a: np.asarray(a, np.float64).reshape(-1)[::FD.STRIDE]      # noqa: E731
+            else:              # gradient sampled, parameter in full
+                ref32 = np.asarray(g[key + "/all"], np.float64).reshape(-1)[::FD.STRIDE]
             sens = 1.0 if opt == "sgd" else 1.0 / np.sqrt(FD.ADAGRAD_SUM0)      # d step / d g
             bar = 2e-5 * max(1.0, float(np.max(np.abs(ref64)))) + lr_eff * sens * 2e-5 * gmax
             gotk = pick(got)
             err = float(np.max(np.minimum(np.abs(gotk - ref32), np.abs(gotk - ref64))))
             _note(name, key + " (fp32 | fp64 step)", err, bar)
             assert err <= bar, "%s %s: max|d| = %.3e (bar %.3e)" % (name, key, err, bar)
-            if not full:      # the elements between the samples: four random projections of the whole tensor (fp32 reference)
+            if key + "/proj" in g:      # the elements between the samples: four random projections of the whole tensor (fp32 reference)
                 flat = got.reshape(-1)
                 for q in range(4):
                     pr = float(np.dot(flat, FD.proj_weights(flat.size, q)))
@@ -225,8 +233,9 @@ def test_full_size_train_step_matches_the_reference(name, opt):
             if opt == "sgd":
                 wabs = max(float(w0[k].abs().max().item()), float(np.abs(got).max()))
                 floor = 2.0 ** (np.floor(np.log2(max(wabs, 1e-30))) - 23) / lr     # ulp(w) / lr
-                gotg = (w0k - gotk) / lr
-                gerr = float(np.max(np.minimum(np.abs(gotg - g32.reshape(gotg.shape)), np.abs(gotg - g64))))
+                gotg = (pick(w0[k].double().cpu().numpy()) - gotk) / lr
+                g32s, g64s = (g32.reshape(-1)[::FD.STRIDE], g64.reshape(-1)[::FD.STRIDE]) if gotg.shape != g64.shape else (g32, g64)
+                gerr = float(np.max(np.minimum(np.abs(gotg - g32s.reshape(gotg.shape)), np.abs(gotg - g64s.reshape(gotg.shape)))))
                 gbar = 2e-5 * gmax + 1.5 * floor
                 _note(name, gk + " (fp32 | fp64)", gerr, gbar)
                 assert gerr <= gbar, "%s %s: max|d| = %.3e (bar %.3e, err / bar %.2f)" % (name, gk, gerr, gbar, gerr / gbar)
