@@ -399,3 +399,38 @@ def test_step_engine_takes_pooled_sum_and_mean_fields(mock, monkeypatch):
     Xm, ym = data(True)
     _, lm, usedm, callsm = run(True, True, Xm, ym)
     assert not usedm and "embed_update:1" in callsm and np.isfinite(lm).all()
+
+
+def test_forward_only_layout_round_trip_on_the_stand_in(mock):
+    """_hip/layout.py apply_infer_layout (round 5): predict() on a never-compiled model seats deep row + wide weight of an id
+    in one [V, 32] slab; values, state_dict and a later compile('adagrad') (re-seating into the interleaved slabs -- which must
+    NOT adopt the forward-only slab of the same width: the Adagrad state would land on the wide weights) are unaffected."""
+    g = load_golden("deepfm_criteo")
+    m = build_model(g["spec"], DEV)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in g["params"].items()})
+    X = g["X"]
+    x = {name: (X[:, lo] if hi - lo == 1 else X[:, lo:hi]) for name, (lo, hi) in m.feature_index.items()}
+    pred = m.predict(x, batch_size=64)
+    plan = m.model_plan()
+    n = 0
+    for di, wi, _, _ in plan.units:
+        if di >= 0 and wi >= 0 and plan.deep[di].dim % 4 == 0 and plan.deep[di].dim <= 28:
+            pd, pw = plan.deep[di].param, plan.wide[wi].param
+            assert pd.stride(0) == 32 and pw.stride(0) == 32 and pw.data_ptr() == pd.data_ptr() + 4 * plan.deep[di].dim
+            n += 1
+    assert n > 0
+    assert max_abs(pred.reshape(-1), g["y_pred"].reshape(-1)) <= 1e-5
+    sd = m.state_dict()
+    for k, v in g["params"].items():
+        assert sd[k].is_contiguous() and max_abs(sd[k].numpy(), v) == 0.0, k
+    m.compile("adagrad", "binary_crossentropy", metrics=[])
+    for di, wi, _, _ in plan.units:
+        if wi >= 0:
+            assert plan.wide[wi].param.stride(0) == 2           # [V, 2]: weight | Adagrad sum
+    sd2 = m.state_dict()
+    for k, v in g["params"].items():
+        assert max_abs(sd2[k].numpy(), v) == 0.0, "%s changed while re-seating" % k
+    m.train()
+    losses = [float(m._train_step(torch.from_numpy(Xb), torch.from_numpy(yb))[0])
+              for Xb, yb in zip(g["extra"]["X_steps"], g["extra"]["y_steps"])]
+    np.testing.assert_allclose(losses, g["extra"]["adagrad3_loss"], rtol=5e-5)
