@@ -124,6 +124,12 @@ struct GatherArgs {
   int n_deep_fixed, n_wide_fixed, n_gsd, n_gsw;
   const int32_t* gsd;
   const int32_t* gsw;
+  // max pooling: the position of the first maximum per element goes to amax [B, ld_am] (what dctr_embed_fwd writes: the
+  // update routes the gradient there); byte offsets per field from the plan's ext block (-1: not max-pooled)
+  uint8_t* amax;
+  int64_t ld_am;
+  const int32_t* am_deep_off;
+  const int32_t* am_wide_off;
 };
 
 
@@ -980,7 +986,10 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
         const bool live = w_ < ni && b0 + r < A.B;
         bad |= (oob && live) ? 1 : 0;
         pv[i] = ldg_f4(fd.table + (oob ? 0 : static_cast<int64_t>(rid)) * row_ld(fd) + 4 * piece);
-        pdst[i] = w_ < ni ? ((r * G.n_gsd + sl_) * G.D + 4 * piece) | ((m && live) ? 0 : (1 << 30)) : -1;
+        // (max pooling looks at every position -- a masked-out one as row - 1e9, sequence.py:65-68 -- so its rows are parked
+        // as they are; sum / mean park zeros for a masked-out position)
+        const bool keep = live && (m || fd.pool == DCTR_POOL_MAX);
+        pdst[i] = w_ < ni ? ((r * G.n_gsd + sl_) * G.D + 4 * piece) | (keep ? 0 : (1 << 30)) : -1;
       }
     }
     if (G.n_gsw > 0 && tid < kTM * G.n_gsw) {
@@ -994,7 +1003,7 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
       const bool oob = static_cast<uint32_t>(rid) >= static_cast<uint32_t>(fw.vocab);
       bad |= (oob && b0 + r < A.B) ? 1 : 0;
       pwv = ldg_f32(fw.table + (oob ? 0 : static_cast<int64_t>(rid)) * row_ld(fw));
-      pwdst = tid | ((m && b0 + r < A.B) ? 0 : (1 << 30));
+      pwdst = tid | (((m || fw.pool == DCTR_POOL_MAX) && b0 + r < A.B) ? 0 : (1 << 30));
     }
     fwd_bias_ld(A.L[0], wv, c, braw);
     __builtin_amdgcn_sched_barrier(0);
@@ -1048,7 +1057,41 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
             for (int t = 0; t < fd.len; ++t) cnt += (static_cast<int32_t>(xr_[fd.col + t]) != 0) ? 1.f : 0.f;
           den = cnt + 1e-8f;
         }
-        if (deep_item) {
+        if (fd.pool == DCTR_POOL_MAX) {
+          // max_t (e_t - (1 - m_t) 1e9), the FIRST maximum's position per element (pool_field in csrc/embed.hip: strict >)
+          const int32_t len_i = by_len ? static_cast<int32_t>(xr_[fd.len_col]) : 0;
+          const int nel = deep_item ? 4 : 1;
+          float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+          int arg[4] = {0, 0, 0, 0};
+          for (int t = 0; t < fd.len; ++t) {
+            const bool m = by_len ? (t < len_i) : (static_cast<int32_t>(xr_[fd.col + t]) != 0);
+            const float pen = m ? 0.f : 1e9f;
+            float vals[4] = {0.f, 0.f, 0.f, 0.f};
+            if (deep_item) {
+              const f32x4 row = *reinterpret_cast<const f32x4*>(S.pb + (r * G.n_gsd + base + t) * G.D + 4 * piece);
+              vals[0] = row.x; vals[1] = row.y; vals[2] = row.z; vals[3] = row.w;
+            } else {
+              vals[0] = S.pw[r * G.n_gsw + base + t];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float v = vals[i] - pen;
+              arg[i] = (v > best[i]) ? t : arg[i];
+              best[i] = (v > best[i]) ? v : best[i];
+            }
+          }
+          const bool rv = b0 + r < A.B;
+          if (deep_item) *reinterpret_cast<f32x4*>(xs + r * rsx + fi * G.D + 4 * piece) =
+              rv ? f32x4{best[0], best[1], best[2], best[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+          else S.wv[r * 32 + fi] = rv ? best[0] : 0.f;
+          if (G.amax && rv) {
+            const int off = ldg_i32((deep_item ? G.am_deep_off : G.am_wide_off) + fi);
+            if (off >= 0) {
+              uint8_t* dst = G.amax + static_cast<int64_t>(b0 + r) * G.ld_am + off + (deep_item ? 4 * piece : 0);
+              for (int i = 0; i < nel; ++i) *(DCTR_GLOBAL uint8_t*)(dst + i) = static_cast<uint8_t>(arg[i]);
+            }
+          }
+        } else if (deep_item) {
           f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
           for (int t = 0; t < fd.len; ++t) acc += *reinterpret_cast<const f32x4*>(S.pb + (r * G.n_gsd + base + t) * G.D + 4 * piece);
           if (fd.pool == DCTR_POOL_MEAN) acc = f32x4{acc.x / den, acc.y / den, acc.z / den, acc.w / den};
@@ -2803,12 +2846,13 @@ int lpr_shift_of(int D) {
 // the plans / towers the fused gather stage takes (everything else keeps dctr_embed_fwd + dctr_mlp_train_step)
 int gather_envelope(const dctr_plan_t* p, const dctr_mlp_t* m, int32_t B, const TrainGeom& T) {
   if (!p || !p->deep || p->n_deep < 1 || p->n_deep_fixed < 1) return DCTR_ENOSUP;
-  // pooled VarLen fields: sum / mean only (max pooling's arg-max side output comes from dctr_embed_fwd), their positions
-  // listed in the ext block, at most four 16-byte pieces and one wide value per thread of the 16-sample tile
+  // pooled VarLen fields (sum / mean / max): their positions listed in the ext block, at most four 16-byte pieces and one
+  // wide value per thread of the 16-sample tile
   const bool pooled = p->n_deep != p->n_deep_fixed || p->n_wide != p->n_wide_fixed;
   const int n_gsd = (pooled && p->ext) ? p->ext->n_gslot_deep : 0, n_gsw = (pooled && p->ext) ? p->ext->n_gslot_wide : 0;
   if (pooled) {
-    if (!p->ext || (p->flags & DCTR_PLAN_HAS_MAXPOOL) || !p->ext->gslot_deep || !p->ext->gslot_wide) return DCTR_ENOSUP;
+    if (!p->ext || !p->ext->gslot_deep || !p->ext->gslot_wide) return DCTR_ENOSUP;
+    if ((p->flags & DCTR_PLAN_HAS_MAXPOOL) && (p->ext->ld_amax <= 0 || !p->ext->am_deep_off || !p->ext->am_wide_off)) return DCTR_ENOSUP;
     if ((p->n_deep != p->n_deep_fixed) != (n_gsd > 0) || (p->n_wide != p->n_wide_fixed) != (n_gsw > 0)) return DCTR_ENOSUP;
     if (p->emb_dim <= 0 || kTM * n_gsd * (p->emb_dim / 4) > 4 * kT || kTM * n_gsw > kT) return DCTR_ENOSUP;
   }
@@ -2873,6 +2917,10 @@ extern "C" int dctr_embed_tower_train_step(const dctr_plan_t* plan, const float*
   const bool pooled = plan->n_deep != plan->n_deep_fixed || plan->n_wide != plan->n_wide_fixed;
   G.n_gsd = pooled ? plan->ext->n_gslot_deep : 0; G.n_gsw = pooled ? plan->ext->n_gslot_wide : 0;
   G.gsd = pooled ? plan->ext->gslot_deep : nullptr; G.gsw = pooled ? plan->ext->gslot_wide : nullptr;
+  const bool maxp = pooled && (plan->flags & DCTR_PLAN_HAS_MAXPOOL);
+  if (maxp && !plan->ext->amax) return DCTR_EINVAL;       // (the caller points ext->amax at this step's arg-max buffer)
+  G.amax = maxp ? plan->ext->amax : nullptr; G.ld_am = maxp ? plan->ext->ld_amax : 0;
+  G.am_deep_off = maxp ? plan->ext->am_deep_off : nullptr; G.am_wide_off = maxp ? plan->ext->am_wide_off : nullptr;
   if (T.lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_embed_tower_train),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(T.lds));

@@ -46,7 +46,7 @@ def _r4(n):
 class _Buffers(object):
     """Everything one batch size needs, allocated once: activations, gradients, workspaces, the tower descriptor."""
     __slots__ = ("B", "out", "gx", "fm_s", "g_logit", "hs", "dhs", "ws", "ids_t", "parts_t", "desc", "upd_ws", "upd_n",
-                 "keep", "pinned", "den_t")
+                 "keep", "pinned", "den_t", "amax")
 
 
 class GatherStep(object):
@@ -126,9 +126,9 @@ class GatherStep(object):
         b.ws = torch.empty((max(1, lib.dctr_mlp_train_workspace_floats(ctypes.byref(b.desc), int(B))),), **f32)
         b.ids_t = torch.empty((plan.n_vcols, B), dtype=torch.int32, device=dev)
         b.parts_t = torch.empty((plan.n_vcols, B), dtype=torch.int16, device=dev)
-        # (general units -- pooled sum / mean fields, shared tables: mean pooling's divisors, written with the ids; a
-        # max-pooled field's arg-max comes from dctr_embed_fwd, such plans keep the two-launch step)
-        b.den_t = plan.step_buffers(B, dev)[0]
+        # (general units -- pooled fields, shared tables: mean pooling's divisors, written with the ids, and max pooling's
+        # arg-max positions, written by the tower launch's gather stage)
+        b.den_t, b.amax = plan.step_buffers(B, dev)
         b.upd_ws, b.upd_n = plan.update_workspace(B, dev, always=True)
         b.keep = (Ws, gWs, gbs, g_wo)
         b.pinned = False
@@ -152,7 +152,7 @@ class GatherStep(object):
         lib = L.lib()
         plan = self.model.model_plan()
         units, n_units = plan.units_ptr(), plan.n_grid_units
-        plan.point_step_buffers(b.den_t, None)
+        plan.point_step_buffers(b.den_t, b.amax)
         L.check(lib.dctr_embed_ids(cplan, units, n_units, _ptr(xb), xb.stride(0), B, _ptr(b.ids_t), _ptr(b.parts_t),
                                    stream_handle), "dctr_embed_ids")
         L.check(lib.dctr_embed_segments(cplan, units, n_units, plan.max_vocab, _ptr(b.ids_t), _ptr(b.parts_t), B,
@@ -198,7 +198,7 @@ class GatherStep(object):
             ws_u._dctr_owner = None
             self._prepassed = None
         units, n_units = plan.units_ptr(), plan.n_grid_units
-        plan.point_step_buffers(b.den_t, None)
+        plan.point_step_buffers(b.den_t, b.amax)
         ld = plan.ld_out
         ld_s = b.fm_s.stride(0) if b.fm_s is not None else 0
         serial = os.environ.get("DCTR_STEP_TOPOLOGY", "update_side") == "serial" or not cuda

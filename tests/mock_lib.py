@@ -152,7 +152,7 @@ class _Core(object):
     def dctr_embed_tower_train_supported(self, pref, mref, B):
         c = pref._obj
         pooled = c.n_deep != c.n_deep_fixed or c.n_wide != c.n_wide_fixed
-        if pooled and (not c.ext or (c.flags & 4)):          # (pooled fields: sum / mean over an ext block; no max pooling)
+        if pooled and not c.ext:          # (pooled fields: their positions are listed in the ext block)
             return 0
         return int(c.n_deep >= 1 and c.n_deep_fixed >= 1 and c.n_wide <= 32 and
                    c.vec == 4 and c.emb_dim in (4, 8, 16, 32, 64) and

@@ -25,6 +25,8 @@ def _cols(vocab, F, D, n_dense, pooled=None):
         cols.append(VarLenSparseFeat(SparseFeat("hist", vocab, D), maxlen=pooled[0], combiner="mean"))
         cols.append(VarLenSparseFeat(SparseFeat("seq", vocab, D, embedding_name="C1"), maxlen=pooled[1], combiner="sum",
                                      length_name="seq_len"))
+        if len(pooled) > 2:      # a max-pooled history (ids != 0 mask; at least one position valid: tests/matrix_data.py clean_rows)
+            cols.append(VarLenSparseFeat(SparseFeat("kw", vocab, D), maxlen=pooled[2], combiner="max"))
     return cols
 
 
@@ -50,6 +52,11 @@ def _data(vocab, F, n_dense, B, n_batches, seed=7, pooled=None):
         sq = torch.randint(0, vocab, (n, T1), generator=gen)
         ln = torch.randint(0, T1 + 1, (n, 1), generator=gen)
         X = torch.cat([X, h.float(), sq.float(), ln.float()], dim=1)      # (inputs.py:99-123: positions, then the length)
+        if len(pooled) > 2:
+            T2 = pooled[2]
+            kw = torch.randint(1, vocab, (n, T2), generator=gen)
+            kw = kw * (torch.arange(T2)[None, :] < torch.randint(1, T2 + 1, (n, 1), generator=gen))
+            X = torch.cat([X, kw.float()], dim=1)
     X = X.to(DEV)
     y = torch.randint(0, 2, (n,), generator=gen).float().to(DEV)
     return X, y
@@ -136,6 +143,8 @@ def test_engine_leaves_the_same_bits_as_the_two_launch_step(opt, graphed):
     dict(kind="deepfm", D=4, F=30, n_dense=20, hidden=(128, 64), B=256),     # 1 lane per row, > 16 wide fields per pass
     # pooled VarLen fields + a shared table inside the fused gather (general update units)
     dict(kind="deepfm", pooled=(8, 5)),
+    dict(kind="deepfm", pooled=(4, 3, 5)),                                   # + a max-pooled history: arg-max from the tower launch
+    dict(kind="wdl", D=8, F=6, n_dense=2, hidden=(128, 64), B=777, pooled=(3, 2, 4)),
     dict(kind="wdl", D=8, F=5, n_dense=3, hidden=(64, 32), B=1000, pooled=(3, 2)),
     dict(kind="deepfm", D=32, F=4, n_dense=0, hidden=(256, 128), B=512, pooled=(6, 4)),   # (the positions' rows are staged in
     # the backward's LDS image: a narrow tower leaves no room and keeps the two-launch step)

@@ -349,8 +349,8 @@ def test_weights_only_checkpoint_is_the_references_size(mock, tmp_path):
 
 def test_step_engine_takes_pooled_sum_and_mean_fields(mock, monkeypatch):
     """Round 5: a DeepFM with a mean history (ids != 0 mask) and a sum history over a SHARED table (length column) runs on the
-    step engine (deepctr_torch/_hip/step.py: general update units, per-step den_t buffer, n_vcols-row id arrays) and lands where
-    the autograd-assembled step lands; a max-pooled column keeps the two-launch step (its arg-max comes from dctr_embed_fwd)."""
+    step engine (deepctr_torch/_hip/step.py: general update units, per-step den_t / amax buffers, n_vcols-row id arrays) and
+    lands where the autograd-assembled step lands; so does one with a max-pooled column."""
     from deepctr_torch.inputs import DenseFeat, SparseFeat, VarLenSparseFeat
     from deepctr_torch.models import DeepFM
 
@@ -396,9 +396,14 @@ def test_step_engine_takes_pooled_sum_and_mean_fields(mock, monkeypatch):
     np.testing.assert_allclose(l1, l0, rtol=1e-6)
     for (k, a), (_, b) in zip(m1.state_dict().items(), m0.state_dict().items()):
         assert max_abs(a.numpy(), b.numpy()) <= 1e-6, k
+    # a max-pooled column too: its arg-max positions are a side output of the tower launch's gather stage
     Xm, ym = data(True)
-    _, lm, usedm, callsm = run(True, True, Xm, ym)
-    assert not usedm and "embed_update:1" in callsm and np.isfinite(lm).all()
+    mm1, lm1, usedm1, callsm1 = run(True, True, Xm, ym)
+    mm0, lm0, usedm0, _ = run(False, True, Xm, ym)
+    assert usedm1 and not usedm0 and "embed_update:1" in callsm1 and "embed_tower_train_step" in callsm1
+    np.testing.assert_allclose(lm1, lm0, rtol=1e-6)
+    for (k, a), (_, b) in zip(mm1.state_dict().items(), mm0.state_dict().items()):
+        assert max_abs(a.numpy(), b.numpy()) <= 1e-6, k
 
 
 def test_forward_only_layout_round_trip_on_the_stand_in(mock):
