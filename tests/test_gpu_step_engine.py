@@ -46,7 +46,7 @@ def _data(vocab, F, n_dense, B, n_batches, seed=7, pooled=None):
     ids = torch.randint(0, vocab, (n, F), generator=gen)
     X = torch.cat([ids.float(), torch.rand(n, n_dense, generator=gen)], dim=1)
     if pooled:
-        T0, T1 = pooled
+        T0, T1 = pooled[0], pooled[1]
         h = torch.randint(1, vocab, (n, T0), generator=gen)
         h = h * (torch.arange(T0)[None, :] < torch.randint(0, T0 + 1, (n, 1), generator=gen))     # 0-padded, some empty
         sq = torch.randint(0, vocab, (n, T1), generator=gen)
