@@ -1047,18 +1047,23 @@ inline WgradGeom wgrad_geom(int B, int h, int M, int D, bool sym = false) {
 }  // namespace
 
 // ---- the "direct connect" rows of a layer, as xDeepFM consumes them (interaction.py:226-246) ------------------------
-// pooled[b, o] = sum_d A[b, n_hidden + o, d]  (d ascending), and its adjoint together with the hidden rows' gradient:
-// gA[b, o, :] = g_hidden[b, o, :] (o < n_hidden), g_pooled[b, o - n_hidden] broadcast over d (else).  One launch each
-// (torch: a strided reduction at 0.8 TB/s forward; slice-copy + expand-copy backward).
+// pooled[b, o] = sum_d A[b, pool_from + o, d]  (d ascending; rows of `pooled` ld_p apart: a layer's block of the CIN's
+// [B, featuremap_num] output), and its adjoint together with the hidden rows' gradient:
+//   gA[b, o, :] = (o < n_hidden ? g_hidden[b, o, :] : 0) + (o >= pool_from ? gp(b, o - pool_from) : 0)
+//   gp(b, j)    = g_pooled[b * ld_gp + j]               (w_head == NULL)
+//               = g_pooled[b * ld_gp] * w_head[j]       (the 1-unit projection xDeepFM puts on the CIN, xdeepfm.py:72:
+//                                                        g_pooled is then the logit's gradient, one float per sample)
+// One launch each (torch: a strided reduction at 0.8 TB/s forward; slice-copy + expand-copy (+ an outer-product GEMM)
+// backward).
 namespace {
 __global__ __launch_bounds__(256) void k_cin_pool_fwd(const float* __restrict__ A, int64_t n_out, int O, int D,
-                                                      int n_hidden, float* __restrict__ pooled) {
+                                                      int pool_from, float* __restrict__ pooled, int64_t ld_p) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= n_out) return;
-  const int nd = O - n_hidden;
+  const int nd = O - pool_from;
   const int64_t b = i / nd;
   const int o = static_cast<int>(i - b * nd);
-  const float* src = A + (b * O + n_hidden + o) * D;
+  const float* src = A + (b * O + pool_from + o) * D;
   float s = 0.f;
   if ((D & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
     for (int d = 0; d < D; d += 4) {
@@ -1068,13 +1073,19 @@ __global__ __launch_bounds__(256) void k_cin_pool_fwd(const float* __restrict__ 
   } else {
     for (int d = 0; d < D; ++d) s += ldg_f32(src + d);
   }
-  stg_f32(pooled + i, s);
+  stg_f32(pooled + b * ld_p + o, s);
+}
+
+__device__ __forceinline__ float pool_grad(const float* __restrict__ g_pooled, int64_t ld_gp,
+                                           const float* __restrict__ w_head, int64_t b, int j) {
+  return w_head ? ldg_f32(g_pooled + b * ld_gp) * ldg_f32(w_head + j) : ldg_f32(g_pooled + b * ld_gp + j);
 }
 
 __global__ __launch_bounds__(256) void k_cin_pool_bwd(const float* __restrict__ g_hidden,
-                                                      const float* __restrict__ g_pooled,
+                                                      const float* __restrict__ g_pooled, int64_t ld_gp,
+                                                      const float* __restrict__ w_head,
                                                       const float* __restrict__ Asv, int64_t n, int O, int D,
-                                                      int n_hidden, float* __restrict__ gA) {
+                                                      int n_hidden, int pool_from, float* __restrict__ gA) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;   // one element of gA [B, O, D]
   if (i >= n) return;
   const int64_t row = i / D;                 // b * O + o
@@ -1082,19 +1093,17 @@ __global__ __launch_bounds__(256) void k_cin_pool_bwd(const float* __restrict__ 
   const int64_t b = row / O;
   const int o = static_cast<int>(row - b * O);
   float v = 0.f;
-  if (o < n_hidden) {
-    if (g_hidden) v = ldg_f32(g_hidden + (b * n_hidden + o) * D + d);
-  } else if (g_pooled) {
-    v = ldg_f32(g_pooled + b * (O - n_hidden) + (o - n_hidden));
-  }
+  if (o < n_hidden && g_hidden) v = ldg_f32(g_hidden + (b * n_hidden + o) * D + d);
+  if (o >= pool_from && g_pooled) v += pool_grad(g_pooled, ld_gp, w_head, b, o - pool_from);
   if (Asv && !(ldg_f32(Asv + i) > 0.f)) v = 0.f;
   stg_f32(gA + i, v);
 }
 // the same, four elements of a row per thread (D % 4 == 0, 16-byte aligned operands)
 __global__ __launch_bounds__(256) void k_cin_pool_bwd4(const float* __restrict__ g_hidden,
-                                                       const float* __restrict__ g_pooled,
+                                                       const float* __restrict__ g_pooled, int64_t ld_gp,
+                                                       const float* __restrict__ w_head,
                                                        const float* __restrict__ Asv, int64_t n4, int O, int D4,
-                                                       int n_hidden, float* __restrict__ gA) {
+                                                       int n_hidden, int pool_from, float* __restrict__ gA) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;   // one float4 of gA [B, O, D]
   if (i >= n4) return;
   const int64_t row = i / D4;
@@ -1104,8 +1113,9 @@ __global__ __launch_bounds__(256) void k_cin_pool_bwd4(const float* __restrict__
   // (unconditional loads on valid addresses, selected afterwards)
   const f32x4 gh = g_hidden ? *(const DCTR_GLOBAL f32x4*)(g_hidden + ((b * n_hidden + (o < n_hidden ? o : 0)) * D4 + d4) * 4)
                             : f32x4{0.f, 0.f, 0.f, 0.f};
-  const float gp = g_pooled ? ldg_f32(g_pooled + b * (O - n_hidden) + (o >= n_hidden ? o - n_hidden : 0)) : 0.f;
-  f32x4 v = o < n_hidden ? gh : f32x4{gp, gp, gp, gp};
+  const float gp = g_pooled ? pool_grad(g_pooled, ld_gp, w_head, b, o >= pool_from ? o - pool_from : 0) : 0.f;
+  f32x4 v = o < n_hidden ? gh : f32x4{0.f, 0.f, 0.f, 0.f};
+  if (o >= pool_from) { v.x += gp; v.y += gp; v.z += gp; v.w += gp; }
   if (Asv) {
     const f32x4 a = *(const DCTR_GLOBAL f32x4*)(Asv + i * 4);
     v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
@@ -1114,31 +1124,37 @@ __global__ __launch_bounds__(256) void k_cin_pool_bwd4(const float* __restrict__
 }
 }  // namespace
 
-extern "C" int dctr_cin_pool_fwd(const float* A, int32_t B, int32_t O, int32_t D, int32_t n_hidden, float* pooled,
-                                 dctr_stream_t stream) {
-  if (!A || !pooled || B < 0 || O <= 0 || D <= 0 || n_hidden < 0 || n_hidden >= O) return DCTR_EINVAL;
-  const int64_t n = static_cast<int64_t>(B) * (O - n_hidden);
+extern "C" int dctr_cin_pool_fwd(const float* A, int32_t B, int32_t O, int32_t D, int32_t pool_from, float* pooled,
+                                 int64_t ld_pooled, dctr_stream_t stream) {
+  if (!A || !pooled || B < 0 || O <= 0 || D <= 0 || pool_from < 0 || pool_from >= O || ld_pooled < O - pool_from)
+    return DCTR_EINVAL;
+  const int64_t n = static_cast<int64_t>(B) * (O - pool_from);
   if (n == 0) return DCTR_OK;
   k_cin_pool_fwd<<<dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(
-      A, n, O, D, n_hidden, pooled);
+      A, n, O, D, pool_from, pooled, ld_pooled);
   return launch_status();
 }
 
-extern "C" int dctr_cin_pool_bwd(const float* g_hidden, const float* g_pooled, const float* A_relu, int32_t B,
-                                 int32_t O, int32_t D, int32_t n_hidden, float* gA, dctr_stream_t stream) {
-  if (!gA || B < 0 || O <= 0 || D <= 0 || n_hidden < 0 || n_hidden > O) return DCTR_EINVAL;
+extern "C" int dctr_cin_pool_bwd(const float* g_hidden, const float* g_pooled, int64_t ld_gp, const float* w_head,
+                                 const float* A_relu, int32_t B, int32_t O, int32_t D, int32_t n_hidden,
+                                 int32_t pool_from, float* gA, dctr_stream_t stream) {
+  if (!gA || B < 0 || O <= 0 || D <= 0 || n_hidden < 0 || n_hidden > O || pool_from < 0 || pool_from > O)
+    return DCTR_EINVAL;
+  if (g_pooled && pool_from < O && ld_gp < (w_head ? 1 : O - pool_from)) return DCTR_EINVAL;
+  if (w_head && !g_pooled) return DCTR_EINVAL;
   const int64_t n = static_cast<int64_t>(B) * O * D;
   if (n == 0) return DCTR_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  const float* gp = pool_from < O ? g_pooled : nullptr;
   // (g_hidden needs its row 0 readable when n_hidden == 0: only passed then as NULL)
   if ((D & 3) == 0 && al16(gA) && al16(g_hidden) && al16(A_relu) && (n_hidden > 0 || !g_hidden)) {
     const int64_t n4 = n / 4;
     k_cin_pool_bwd4<<<dim3(static_cast<unsigned>((n4 + 255) / 256)), dim3(256), 0, s>>>(
-        n_hidden > 0 ? g_hidden : nullptr, n_hidden < O ? g_pooled : nullptr, A_relu, n4, O, D / 4, n_hidden, gA);
+        n_hidden > 0 ? g_hidden : nullptr, gp, ld_gp, w_head, A_relu, n4, O, D / 4, n_hidden, pool_from, gA);
   } else {
-    k_cin_pool_bwd<<<dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s>>>(g_hidden, g_pooled, A_relu, n,
-                                                                                     O, D, n_hidden, gA);
+    k_cin_pool_bwd<<<dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s>>>(
+        n_hidden > 0 ? g_hidden : nullptr, gp, ld_gp, w_head, A_relu, n, O, D, n_hidden, pool_from, gA);
   }
   return launch_status();
 }

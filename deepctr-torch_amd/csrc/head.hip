@@ -218,6 +218,20 @@ __global__ __launch_bounds__(256) void k_rows_join(const float* __restrict__ a, 
   *(DCTR_GLOBAL f32x4*)(out + b * ldo + 4 * q) = v;
 }
 
+// out[b] = sum_j x[b, j] w[j]: a bias-free 1-unit Linear over narrow rows (xDeepFM's cin_linear, xdeepfm.py:72 / :97 -- 192
+// columns at the Criteo shape, where the library GEMM is 12 us of launch + tile set-up for 0.8 MFLOP).  One wave per row,
+// lanes stride the columns, a fixed butterfly adds the 64 partials: the same bits on every run.
+__global__ __launch_bounds__(256) void k_rows_dot(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                                                  int B, int N, float* __restrict__ out) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  const float* row = x + static_cast<int64_t>(b) * ldx;
+  float s = 0.f;
+  for (int j = lane; j < N; j += 64) s += ldg_f32(row + j) * ldg_f32(w + j);
+  s = wave_sum(s);
+  if (lane == 0) stg_f32(out + b, s);
+}
+
 // relu's backward on g [B, N] (mask h > 0, like aten::threshold_backward) fused with the bias gradient's column sums:
 // workgroup w takes the rows [w * kRows, ...), thread n the columns n, n + 256, ...; partial sums part[w][N] are added by
 // k_colsum_finish in workgroup order (deterministic).  Replaces threshold_backward + sum(0) (a 2-stage ATen reduction).
@@ -347,6 +361,14 @@ extern "C" int dctr_rows_join(const float* a, int64_t ld_a, const float* c, int6
   const int64_t n = static_cast<int64_t>(B) * (ld_out / 4);
   k_rows_join<<<dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(
       a, ld_a, c, ld_c, W, d, ld_d, n_d, out, ld_out, B);
+  return launch_status();
+}
+
+extern "C" int dctr_rows_dot(const float* x, int64_t ld_x, const float* w, int32_t B, int32_t N, float* out,
+                             dctr_stream_t stream) {
+  if (!x || !w || !out || B < 0 || N <= 0 || ld_x < N) return DCTR_EINVAL;
+  if (B == 0) return DCTR_OK;
+  k_rows_dot<<<dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(x, ld_x, w, B, N, out);
   return launch_status();
 }
 

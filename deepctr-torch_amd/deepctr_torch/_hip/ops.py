@@ -611,66 +611,143 @@ class CINLayerFunction(torch.autograd.Function):
         return gH, gX0, gW, gb, None
 
 
-class CINLayerPooledFunction(torch.autograd.Function):
-    """One CIN layer as xDeepFM consumes it (interaction.py:226-246): the rows of ``A`` that go on as the next layer's
-    hidden state (``n_hidden`` of them; with split_half the first half) come back as a view, the "direct connect"
-    rows come back already summed over the embedding axis -- ``[B, n_direct]`` instead of ``[B, n_direct, D]``.  The
-    reference's split / cat / sum(-1) chain and its autograd (expand, slice, cat, contiguous: ~14 launches per layer)
-    become one reduction forward and one or two copies backward around the same two kernels."""
+class CINStackFunction(torch.autograd.Function):
+    """The whole CIN (interaction.py:207-248) as ONE autograd node, optionally with the bias-free 1-unit projection
+    xDeepFM puts on its output (xdeepfm.py:72, :97):
+
+        x        [B, F, D] field matrix, or the gather's [B, >= F*D] row matrix whose first F*D columns are the fields
+                 (xDeepFM: the gradient comes back in that shape -- no view backward (fill + slice copy) behind the CIN)
+        wb       W_1, b_1, W_2, b_2, ...: the conv1ds' ``[O, h*F, 1]`` weights and ``[O]`` biases (None = no bias)
+        w_head   None -> returns the CIN output ``[B, featuremap_num]``; ``[1, featuremap_num]`` -> returns
+                 ``[B, 1]`` = output @ w_head.T
+
+    Every layer's pooling kernel writes its block of the ``[B, featuremap_num]`` output in place (no torch.cat) and the
+    backward reads the blocks' gradients in place (no slice copies); the layers' field-matrix gradients accumulate in one
+    buffer inside the kernels (no adds); with ``w_head`` the projection's backward towards the layers is folded into the
+    gradient-assembly kernel (dctr_cin_pool_bwd) and its forward is one wave-per-row dot product (dctr_rows_dot).
+    Per layer: dctr_cin_layer_fwd + dctr_cin_pool_fwd forward, dctr_cin_pool_bwd + dctr_cin_layer_bwd backward."""
 
     @staticmethod
-    def forward(ctx, H, X0, W2d, bias, relu, n_hidden, split):
-        A = cin_layer_forward(H, X0, W2d, bias, relu)
-        O = A.shape[1]
-        ctx.relu, ctx.has_bias, ctx.n_hidden, ctx.split = bool(relu), bias is not None, int(n_hidden), bool(split)
-        ctx.save_for_backward(H, X0, W2d, A if relu else None)
-        nh_pool = n_hidden if split else 0
-        pooled = torch.empty((A.shape[0], O - nh_pool), dtype=torch.float32, device=A.device)
-        L.check(L.lib().dctr_cin_pool_fwd(_ptr(A), A.shape[0], O, A.shape[2], nh_pool, _ptr(pooled),
-                                          L.stream_handle(A.device)), "dctr_cin_pool_fwd")
-        hidden = A[:, :n_hidden] if n_hidden > 0 else A.new_zeros((A.shape[0], 0, A.shape[2]))
-        ctx.O = O
-        return hidden, pooled
-
-    @staticmethod
-    def backward(ctx, g_hidden, g_pooled):
+    def forward(ctx, x, F, D, relu, split_half, w_head, *wb):
         lib = L.lib()
-        H, X0, W2d, A = ctx.saved_tensors
-        H, ldh = _rows3(H, "CIN hidden input")
-        X0, ldx = _rows3(X0, "CIN field input")
-        B, h, D = H.shape
-        M, O = X0.shape[1], W2d.shape[0]
-        dev = H.device
-        nh = ctx.n_hidden
-        relu_in_layer = int(ctx.relu)
-        if ctx.split:
+        if x.dim() == 2:
+            if x.shape[1] < F * D or x.stride(1) != 1 or x.dtype != torch.float32:
+                raise ValueError("CIN: the row matrix must hold F*D contiguous float32 columns")
+            X0 = x[:, :F * D].unflatten(1, (F, D))
+        else:
+            X0 = x
+        B = X0.shape[0]
+        dev = x.device
+        n = len(wb) // 2
+        sizes = [wb[2 * i].shape[0] for i in range(n)]
+        geo = []                          # per layer: (O, n_hidden, pool_from, offset of its block)
+        off = 0
+        for i, O in enumerate(sizes):
+            last = i == n - 1
+            nh = 0 if last else (O // 2 if split_half else O)
+            pf = nh if split_half else 0
+            geo.append((O, nh, pf, off))
+            off += O - pf
+        fm = off
+        feat = torch.empty((B, fm), dtype=torch.float32, device=dev)
+        As = []
+        hidden = X0
+        for i in range(n):
+            O, nh, pf, o0 = geo[i]
+            bias = wb[2 * i + 1]
+            A = cin_layer_forward(hidden, X0, wb[2 * i].reshape(O, -1), bias, relu)
+            if B > 0:
+                L.check(lib.dctr_cin_pool_fwd(_ptr(A), B, O, D, pf, ctypes.c_void_p(feat.data_ptr() + 4 * o0), fm,
+                                              L.stream_handle(dev)), "dctr_cin_pool_fwd")
+            As.append(A)
+            hidden = A[:, :nh] if nh > 0 else None
+        ctx.geo, ctx.relu, ctx.F, ctx.D, ctx.fm = geo, bool(relu), int(F), int(D), fm
+        ctx.flat = x.dim() == 2
+        ctx.x_cols = x.shape[1] if ctx.flat else 0
+        ctx.has_head = w_head is not None
+        ctx.has_bias = [wb[2 * i + 1] is not None for i in range(n)]
+        ctx.w_shapes = [tuple(wb[2 * i].shape) for i in range(n)]
+        ctx.save_for_backward(x, w_head, feat if ctx.has_head else None, *(list(wb[0::2]) + As))
+        if not ctx.has_head:
+            return feat
+        if w_head.numel() != fm:
+            raise ValueError("CIN head: %d weights for %d feature maps" % (w_head.numel(), fm))
+        logit = torch.empty((B, 1), dtype=torch.float32, device=dev)
+        wh = w_head.detach().contiguous()
+        L.check(lib.dctr_rows_dot(_ptr(feat), fm, _ptr(wh), B, fm, _ptr(logit), L.stream_handle(dev)), "dctr_rows_dot")
+        return logit
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.lib()
+        sv = ctx.saved_tensors
+        x, w_head, feat = sv[0], sv[1], sv[2]
+        n = len(ctx.geo)
+        Ws, As = sv[3:3 + n], sv[3 + n:3 + 2 * n]
+        F, D, fm = ctx.F, ctx.D, ctx.fm
+        dev = x.device
+        B = x.shape[0]
+        st = L.stream_handle(dev)
+        g = g.contiguous().float()
+        if ctx.flat:
+            X0 = x[:, :F * D].unflatten(1, (F, D))
+            gx = torch.empty((B, ctx.x_cols), dtype=torch.float32, device=dev)
+            if ctx.x_cols > F * D:
+                gx[:, F * D:].zero_()          # (the dense columns behind the fields: not the CIN's inputs)
+            ld_gx = ctx.x_cols
+        else:
+            X0 = x
+            gx = torch.empty((B, F, D), dtype=torch.float32, device=dev)
+            ld_gx = F * D
+        X0r, ldx = _rows3(X0, "CIN field input")
+        g_wh = None
+        if ctx.has_head:
+            g_wh = torch.mm(g.reshape(1, B), feat).reshape(w_head.shape)
+            wh = w_head.detach().contiguous().reshape(-1)
+        rets = [None] * (2 * n)
+        g_hidden = None
+        first_gh = None
+        for i in range(n - 1, -1, -1):
+            O, nh, pf, o0 = ctx.geo[i]
+            A = As[i]
+            H = X0 if i == 0 else As[i - 1][:, :ctx.geo[i - 1][1]]
+            Hr, ldh = (X0r, ldx) if i == 0 else _rows3(H, "CIN hidden input")
+            h = Hr.shape[1]
             gA = torch.empty((B, O, D), dtype=torch.float32, device=dev)
-            gh = g_hidden.contiguous() if (nh > 0 and g_hidden is not None) else None
-            gp = g_pooled.contiguous() if g_pooled is not None else None
-            # (the relu's backward is applied while gA is assembled: the layer kernels then need no mask loads)
-            L.check(lib.dctr_cin_pool_bwd(_ptr(gh), _ptr(gp), _ptr(A) if ctx.relu else None, B, O, D, nh, _ptr(gA),
-                                          L.stream_handle(dev)), "dctr_cin_pool_bwd")
-            relu_in_layer = 0
-        else:           # every row is both hidden state and direct connect
-            if g_hidden is not None and g_pooled is not None:
-                gA = g_hidden + g_pooled.unsqueeze(2)
-            elif g_pooled is not None:
-                gA = g_pooled.unsqueeze(2).expand(B, O, D).contiguous()
+            if ctx.has_head:
+                gp, ld_gp, whp = _ptr(g), 1, ctypes.c_void_p(wh.data_ptr() + 4 * o0)
             else:
-                gA = g_hidden.contiguous()
-        W2d = W2d.contiguous()
-        gH = torch.empty((B, h, D), dtype=torch.float32, device=dev)
-        gX0 = torch.empty((B, M, D), dtype=torch.float32, device=dev)
-        gW = torch.empty((O, h * M), dtype=torch.float32, device=dev)
-        gb = torch.empty((O,), dtype=torch.float32, device=dev) if ctx.has_bias else None
-        ws = torch.empty((max(1, lib.dctr_cin_bwd_workspace_floats(B, h, M, D, O)),), dtype=torch.float32, device=dev)
-        L.check(lib.dctr_cin_layer_bwd(_ptr(gA), _ptr(A), O * D, relu_in_layer, _ptr(H), ldh, _ptr(X0), ldx, _ptr(W2d),
-                                       B, h, M, D, O, _ptr(gH), h * D, _ptr(gX0), M * D, 0, _ptr(gW), _ptr(gb),
-                                       _ptr(ws), L.stream_handle(dev)), "dctr_cin_layer_bwd")
-        return gH, gX0, gW, gb, None, None, None
+                gp, ld_gp, whp = ctypes.c_void_p(g.data_ptr() + 4 * o0), fm, None
+            if B > 0:
+                # (the relu's backward is applied while gA is assembled: the layer kernels then need no mask loads)
+                L.check(lib.dctr_cin_pool_bwd(_ptr(g_hidden) if nh > 0 else None, gp, ld_gp, whp,
+                                              _ptr(A) if ctx.relu else None, B, O, D, nh, pf, _ptr(gA), st),
+                        "dctr_cin_pool_bwd")
+            W2d = Ws[i].detach().reshape(O, -1)
+            W2d = W2d if W2d.is_contiguous() else W2d.contiguous()
+            # the hidden rows' gradient: the previous layer's g_hidden; layer 1's hidden state IS the field matrix -- its
+            # two gradients meet in gx (the symmetric kernel writes them from different threads: a scratch + one add)
+            gH = torch.empty((B, h, D), dtype=torch.float32, device=dev)
+            gW = torch.empty((O, W2d.shape[1]), dtype=torch.float32, device=dev)
+            gb = torch.empty((O,), dtype=torch.float32, device=dev) if ctx.has_bias[i] else None
+            ws = torch.empty((max(1, lib.dctr_cin_bwd_workspace_floats(B, h, F, D, O)),), dtype=torch.float32, device=dev)
+            L.check(lib.dctr_cin_layer_bwd(_ptr(gA), _ptr(A), O * D, 0, _ptr(Hr), ldh, _ptr(X0r), ldx, _ptr(W2d),
+                                           B, h, F, D, O, _ptr(gH), h * D, _ptr(gx), ld_gx, int(i != n - 1), _ptr(gW),
+                                           _ptr(gb), _ptr(ws), st), "dctr_cin_layer_bwd")
+            rets[2 * i] = gW.reshape(ctx.w_shapes[i])
+            rets[2 * i + 1] = gb
+            if i == 0:
+                first_gh = gH
+            else:
+                g_hidden = gH
+        if B > 0:
+            if ctx.flat:
+                gx[:, :F * D].add_(first_gh.reshape(B, F * D))
+            else:
+                gx.add_(first_gh)
+        return (gx, None, None, None, None, g_wh) + tuple(rets)
 
 
-# ---- SENET / Bilinear / InnerProduct (csrc/pairwise.hip) -------------------------------------------------
 class SENETFunction(torch.autograd.Function):
     """V = E * relu(W2 relu(W1 mean_d(E)))  (interaction.py:93-101)."""
 

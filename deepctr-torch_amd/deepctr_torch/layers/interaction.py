@@ -8,7 +8,7 @@ import torch.nn as nn
 
 from .._hip import lib as _lib
 from .._hip import ops as _ops
-from .activation import activation_layer
+from .activation import Identity, activation_layer
 
 __all__ = ["FM", "BiInteractionPooling", "AFMLayer", "InteractingLayer", "CrossNetMix", "CIN", "SENETLayer", "BilinearInteraction", "InnerProductLayer", "OutterProductLayer", "CrossNet"]
 
@@ -227,24 +227,30 @@ class CIN(nn.Module):
                 self.field_nums.append(size)
         self.to(device)
 
+    def _stack_ok(self, n_fields):
+        """The common case on the kernels' own terms (csrc/cin.hip: at most 32 fields, relu or no activation)."""
+        plain = self.activation is None or type(self.activation) in (nn.ReLU, Identity, nn.Identity)
+        return n_fields <= 32 and plain and not (self.activation is not None and (
+            self.activation._forward_hooks or self.activation._forward_pre_hooks))
+
+    def _stack(self, x, F, D, w_head):
+        """The whole stack as one autograd node (_hip/ops.py CINStackFunction): ``x`` the ``[B, F, D]`` field matrix or a
+        ``[B, >= F*D]`` row matrix that starts with it; ``w_head``: None, or the ``[1, featuremap_num]`` weight of the
+        bias-free projection a model puts on the output (xDeepFM's cin_linear) -- the result is then ``[B, 1]``."""
+        wb = []
+        for conv in self.conv1ds:
+            wb += [conv.weight, conv.bias]
+        return _ops.CINStackFunction.apply(x, F, D, isinstance(self.activation, nn.ReLU), bool(self.split_half), w_head,
+                                           *wb)
+
     def forward(self, inputs):
         if len(inputs.shape) != 3:
             raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % (len(inputs.shape)))
         x0 = inputs
         hidden = x0
         fused_relu = isinstance(self.activation, nn.ReLU)
-        if x0.shape[1] <= 32 and (fused_relu or self.activation is None):
-            # the common case on the kernels' own terms: every layer hands back its hidden rows as a view and its
-            # direct-connect rows already summed over the embedding axis (no split / cat / sum(-1) chain)
-            pooled = []
-            for i, size in enumerate(self.layer_size):
-                conv = self.conv1ds[i]
-                last = i == len(self.layer_size) - 1
-                n_hidden = (0 if last else size // 2) if self.split_half else (0 if last else size)
-                hidden, p = _ops.CINLayerPooledFunction.apply(hidden, x0, conv.weight.squeeze(-1), conv.bias, fused_relu,
-                                                              n_hidden, self.split_half or last)
-                pooled.append(p)
-            return torch.cat(pooled, dim=1)
+        if self._stack_ok(x0.shape[1]):
+            return self._stack(x0, x0.shape[1], x0.shape[2], None)
         final_result = []
         for i, size in enumerate(self.layer_size):
             conv = self.conv1ds[i]

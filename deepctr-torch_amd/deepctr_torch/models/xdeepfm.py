@@ -45,8 +45,16 @@ class xDeepFM(BaseModel):
             if plan.emb_dim <= 0:
                 raise ValueError("embedding_dim of SparseFeat and VarlenSparseFeat must be same in this model!")
             B, nf = X.shape[0], len(plan.deep)
-            cin_input = dnn_input[:, :plan.emb_width].reshape(B, nf, plan.emb_dim)   # view of the gather's output
-            parts.append(self.cin_linear(self.cin(cin_input)))
+            hooked = any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks
+                         for m in (self.cin, self.cin_linear))
+            if not hooked and self.cin._stack_ok(nf) and type(self.cin_linear) is nn.Linear:
+                # CIN + cin_linear as one autograd node on the gather's row matrix itself: the gradient comes back in
+                # that shape, the projection is a wave-per-row dot product forward and folded into the layers'
+                # gradient assembly backward (_hip/ops.py CINStackFunction)
+                parts.append(self.cin._stack(dnn_input, nf, plan.emb_dim, self.cin_linear.weight))
+            else:
+                cin_input = dnn_input[:, :plan.emb_width].reshape(B, nf, plan.emb_dim)   # view of the gather's output
+                parts.append(self.cin_linear(self.cin(cin_input)))
         if self.use_dnn:
             parts.append(self.tower_logit(dnn_input, plan.width))
         return parts

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 20
+#define DCTR_ABI_VERSION 21
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -430,16 +430,26 @@ int dctr_cin_layer_bwd(const float* gA, const float* A, int64_t ld_a, int32_t re
                        float* gW, float* gbias, float* workspace, dctr_stream_t stream);
 
 /* The layer's "direct connect" rows as xDeepFM consumes them (interaction.py:226-246: split / cat / sum(-1)):
- *   dctr_cin_pool_fwd: pooled[b, o] = sum_d A[b, n_hidden + o, d]   (A [B, O, D] contiguous, pooled [B, O - n_hidden])
- *   dctr_cin_pool_bwd: gA[b, o, :] = g_hidden[b, o, :] for o < n_hidden (g_hidden [B, n_hidden, D] contiguous, NULL = 0),
- *                      g_pooled[b, o - n_hidden] for every d otherwise (NULL = 0);
+ *   dctr_cin_pool_fwd: pooled[b * ld_pooled + o] = sum_d A[b, pool_from + o, d]   (A [B, O, D] contiguous; `pooled` may be
+ *                      the layer's block of the CIN's [B, featuremap_num] output: no torch.cat behind the layers)
+ *   dctr_cin_pool_bwd: gA[b, o, :] = (o < n_hidden ? g_hidden[b, o, :] : 0) + (o >= pool_from ? gp(b, o - pool_from) : 0)
+ *                      g_hidden [B, n_hidden, D] contiguous (NULL = 0); gp(b, j) = g_pooled[b * ld_gp + j] (NULL = 0), or,
+ *                      with w_head: g_pooled[b * ld_gp] * w_head[j] -- the backward of the bias-free 1-unit Linear xDeepFM
+ *                      puts on the CIN output (xdeepfm.py:72, :97) folded in: g_pooled is then the logit's gradient.
+ *                      split_half: pool_from == n_hidden (disjoint row sets); otherwise pool_from = 0 and every row below
+ *                      n_hidden receives both terms (interaction.py:240-242).
  *                      A_relu (nullable, [B, O, D]): the layer's saved relu output -- gA is zeroed where it is not > 0, i.e.
  *                      the relu's backward is applied HERE and dctr_cin_layer_bwd is then called with relu = 0 (its two
  *                      kernels stage 16 gradient rows per memory round trip instead of 8 + 8 mask rows)               */
-int dctr_cin_pool_fwd(const float* A, int32_t B, int32_t O, int32_t D, int32_t n_hidden, float* pooled,
-                      dctr_stream_t stream);
-int dctr_cin_pool_bwd(const float* g_hidden, const float* g_pooled, const float* A_relu, int32_t B, int32_t O, int32_t D,
-                      int32_t n_hidden, float* gA, dctr_stream_t stream);
+int dctr_cin_pool_fwd(const float* A, int32_t B, int32_t O, int32_t D, int32_t pool_from, float* pooled,
+                      int64_t ld_pooled, dctr_stream_t stream);
+int dctr_cin_pool_bwd(const float* g_hidden, const float* g_pooled, int64_t ld_gp, const float* w_head,
+                      const float* A_relu, int32_t B, int32_t O, int32_t D, int32_t n_hidden, int32_t pool_from,
+                      float* gA, dctr_stream_t stream);
+
+/* out[b] = sum_j x[b * ld_x + j] * w[j]   (csrc/head.hip): nn.Linear(N, 1, bias=False) over narrow rows -- xDeepFM's
+ * cin_linear (xdeepfm.py:72, :97).  One wave per row, fixed summation order.                                          */
+int dctr_rows_dot(const float* x, int64_t ld_x, const float* w, int32_t B, int32_t N, float* out, dctr_stream_t stream);
 
 /* ---- SENET / Bilinear / InnerProduct (csrc/pairwise.hip) ----------------------------------------------
  * SENETLayer (interaction.py:93-101): z = mean_d E; a1 = relu(z W1^T); a = relu(a1 W2^T); V = E * a[:, :, None]

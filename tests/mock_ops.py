@@ -278,23 +278,34 @@ class OpsMixin(object):
             _v(gbias, O).copy_(gb)
         return 0
 
-    def dctr_cin_pool_fwd(self, A, B, O, D, n_hidden, pooled, stream):
+    def dctr_cin_pool_fwd(self, A, B, O, D, pool_from, pooled, ld_pooled, stream):
         self.calls.append("cin_pool_fwd")
         a = _t(A, B, O * D).reshape(B, O, D)
-        _t(pooled, B, O - n_hidden).copy_(a[:, n_hidden:].double().sum(-1).float())
+        _t(pooled, B, O - pool_from, ld_pooled).copy_(a[:, pool_from:].double().sum(-1).float())
         return 0
 
-    def dctr_cin_pool_bwd(self, g_hidden, g_pooled, A_relu, B, O, D, n_hidden, gA, stream):
+    def dctr_cin_pool_bwd(self, g_hidden, g_pooled, ld_gp, w_head, A_relu, B, O, D, n_hidden, pool_from, gA, stream):
+        """include/dctr.h: gA[b, o, :] = (o < n_hidden ? g_hidden[b, o, :] : 0) + (o >= pool_from ? gp(b, o - pool_from) : 0),
+        gp = g_pooled[b, j], or g_pooled[b] * w_head[j] when the projection's backward is folded in; relu mask last."""
         self.calls.append("cin_pool_bwd")
         g = _t(gA, B, O * D).reshape(B, O, D)
+        g.zero_()
         gh = _t(g_hidden, B, n_hidden * D) if n_hidden else None
-        gp = _t(g_pooled, B, O - n_hidden)
-        if n_hidden:
-            g[:, :n_hidden] = gh.reshape(B, n_hidden, D) if gh is not None else 0.0
-        g[:, n_hidden:] = gp[:, :, None] if gp is not None else 0.0
+        if gh is not None:
+            g[:, :n_hidden] += gh.reshape(B, n_hidden, D)
+        nd = O - pool_from
+        if nd > 0 and _arr(g_pooled, (1,)) is not None:
+            w = _v(w_head, nd)
+            gp = _t(g_pooled, B, 1, ld_gp) * w[None, :] if w is not None else _t(g_pooled, B, nd, ld_gp)
+            g[:, pool_from:] += gp[:, :, None]
         a = _t(A_relu, B, O * D)
         if a is not None:
             g *= (a.reshape(B, O, D) > 0).to(g.dtype)
+        return 0
+
+    def dctr_rows_dot(self, x, ld_x, w, B, N, out, stream):
+        self.calls.append("rows_dot")
+        _v(out, B).copy_((_t(x, B, N, ld_x).double() @ _v(w, N).double()).float())
         return 0
 
     # ---- CrossNet (vector) --------------------------------------------------------------------------------------------

@@ -122,6 +122,65 @@ def test_cin_module_matches_the_oracle_stack(F, D, layers, split_half, B):
         _check(k, p_.grad, grads["cin." + k].reshape(tuple(p_.shape)), 2e-5)
 
 
+@pytest.mark.parametrize("F,D,layers,split_half,B,extra,relu", [
+    (26, 16, (128, 128), True, 96, 13, True), (26, 16, (64, 32, 16), False, 40, 0, True), (7, 8, (10, 6), True, 33, 5, False),
+    (5, 4, (8,), True, 9, 3, True), (31, 5, (12, 12), False, 17, 1, True), (26, 16, (128, 128), True, 1, 13, True)])
+def test_cin_stack_with_projection_on_the_row_matrix(F, D, layers, split_half, B, extra, relu):
+    """CIN + xDeepFM's bias-free 1-unit projection (xdeepfm.py:72, :97) as one autograd node on the gather's own
+    [B, F*D + dense] row matrix (a view with a longer leading dimension, like the gather's padded output): the logit, the
+    gradient in the row matrix's shape (zeros behind the fields), the layers' and the projection's weight gradients --
+    against np_oracle.cin_forward / cin_backward and the projection written out in fp64."""
+    from deepctr_torch.layers import CIN
+    torch.manual_seed(F * 5 + D + B)
+    cin = CIN(F, layers, activation="relu" if relu else "linear", split_half=split_half, device=DEV)
+    for p_ in cin.parameters():
+        torch.nn.init.normal_(p_, 0, 0.1)
+    fm = sum(s // 2 if (split_half and i != len(layers) - 1) else s for i, s in enumerate(layers))
+    w_head = (torch.randn(1, fm, device=DEV) * 0.3).requires_grad_(True)
+    store = torch.randn(B, F * D + extra + 3, device=DEV) * 0.5
+    x = store[:, :F * D + extra].detach().requires_grad_(True)      # (a non-contiguous leaf: stride F*D + extra + 3)
+    assert x.stride(0) == F * D + extra + 3
+    R = torch.randn(B, 1, device=DEV)
+    y = cin._stack(x, F, D, w_head)
+    assert y.shape == (B, 1)
+    (y * R).sum().backward()
+    P = {"cin." + k: _n(v) for k, v in cin.state_dict().items()}
+    X0 = _n(x)[:, :F * D].reshape(B, F, D)
+    act = "relu" if relu else "linear"
+    out, cache = cin_forward(X0, P, "cin.", layers, split_half, activation=act)
+    wn = _n(w_head)
+    _check("logit", y, out @ wn.T, 1e-5)
+    grads = {}
+    g_feat = _n(R) @ wn
+    gX0 = cin_backward(g_feat, X0, cache, P, "cin.", layers, split_half, grads, activation=act)
+    want_gx = np.concatenate([gX0.reshape(B, F * D), np.zeros((B, extra))], axis=1)
+    assert x.grad.shape == x.shape
+    _check("gx", x.grad, want_gx, 2e-5)
+    _check("g_w_head", w_head.grad, _n(R).T @ out, 2e-5)
+    for k, p_ in cin.named_parameters():
+        _check(k, p_.grad, grads["cin." + k].reshape(tuple(p_.shape)), 2e-5)
+
+
+def test_xdeepfm_takes_the_stack_and_hooks_take_the_modules():
+    """xDeepFM routes CIN + cin_linear through the one-node stack; a forward hook on either module sends the step
+    through the modules again (so the hook fires) with the same logit."""
+    from deepctr_torch.inputs import DenseFeat, SparseFeat
+    from deepctr_torch.models import xDeepFM
+    cols = [SparseFeat("c%d" % i, 20 + i, 4) for i in range(5)] + [DenseFeat("d", 2)]
+    torch.manual_seed(2)
+    m = xDeepFM(cols, cols, dnn_hidden_units=(16,), cin_layer_size=(8, 6), init_std=0.1, device=DEV)
+    g = np.random.RandomState(0)
+    X = torch.from_numpy(np.concatenate([g.randint(0, 20, (33, 5)), g.rand(33, 2)], axis=1).astype(np.float32)).to(DEV)
+    m.eval()
+    y0 = m(X)
+    seen = []
+    h = m.cin_linear.register_forward_hook(lambda mod, i, o: seen.append(o.shape))
+    y1 = m(X)
+    h.remove()
+    assert seen == [(33, 1)]
+    assert float((y0 - y1).detach().abs().max()) <= 1e-6
+
+
 def test_cin_module_shapes_and_errors():
     from deepctr_torch.layers import CIN
     cin = CIN(5, (8, 6), device=DEV)

@@ -85,20 +85,21 @@ def test_multi_tensor_step_matches_torch_optim(opt, with_l2):
 def test_cin_pool_kernels_match_split_sum(B, O, D, nh):
     from deepctr_torch._hip import lib as L
     lib = L.lib()
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
     g = torch.Generator().manual_seed(B + O)
     A = torch.randn(B, O, D, generator=g).to(DEV)
     if nh < O:
-        pooled = torch.empty(B, O - nh, device=DEV)
-        L.check(lib.dctr_cin_pool_fwd(ctypes.c_void_p(A.data_ptr()), B, O, D, nh, ctypes.c_void_p(pooled.data_ptr()),
-                                      L.stream_handle(DEV)))
+        # the layer's block of a wider [B, ld] output: only its O - nh columns are written
+        ld = O - nh + 5
+        store = torch.full((B, ld), float("nan"), device=DEV)
+        L.check(lib.dctr_cin_pool_fwd(P(A), B, O, D, nh, ctypes.c_void_p(store.data_ptr() + 8), ld, L.stream_handle(DEV)))
         ref = A[:, nh:].double().sum(-1)
-        assert float((pooled.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+        assert float((store[:, 2:2 + O - nh].double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+        assert torch.isnan(store[:, :2]).all() and torch.isnan(store[:, 2 + O - nh:]).all()
     gh = torch.randn(B, nh, D, generator=g).to(DEV) if nh > 0 else None
     gp = torch.randn(B, O - nh, generator=g).to(DEV) if nh < O else None
     gA = torch.full((B, O, D), float("nan"), device=DEV)
-    L.check(lib.dctr_cin_pool_bwd(ctypes.c_void_p(gh.data_ptr()) if gh is not None else None,
-                                  ctypes.c_void_p(gp.data_ptr()) if gp is not None else None, None, B, O, D, nh,
-                                  ctypes.c_void_p(gA.data_ptr()), L.stream_handle(DEV)))
+    L.check(lib.dctr_cin_pool_bwd(P(gh), P(gp), O - nh, None, None, B, O, D, nh, nh, P(gA), L.stream_handle(DEV)))
     want = torch.zeros(B, O, D, device=DEV)
     if nh > 0:
         want[:, :nh] = gh
@@ -107,12 +108,49 @@ def test_cin_pool_kernels_match_split_sum(B, O, D, nh):
     assert torch.equal(gA, want)
     # with the layer's saved relu output: the relu's backward applied on the way (exact zeros, nothing else touched)
     gA.fill_(float("nan"))
-    L.check(lib.dctr_cin_pool_bwd(ctypes.c_void_p(gh.data_ptr()) if gh is not None else None,
-                                  ctypes.c_void_p(gp.data_ptr()) if gp is not None else None,
-                                  ctypes.c_void_p(A.data_ptr()), B, O, D, nh, ctypes.c_void_p(gA.data_ptr()),
-                                  L.stream_handle(DEV)))
+    L.check(lib.dctr_cin_pool_bwd(P(gh), P(gp), O - nh, None, P(A), B, O, D, nh, nh, P(gA), L.stream_handle(DEV)))
     assert torch.equal(gA, torch.where(A > 0, want, torch.zeros_like(want)))
     # NULL inputs mean zero
     gA.fill_(float("nan"))
-    L.check(lib.dctr_cin_pool_bwd(None, None, None, B, O, D, nh, ctypes.c_void_p(gA.data_ptr()), L.stream_handle(DEV)))
+    L.check(lib.dctr_cin_pool_bwd(None, None, 0, None, None, B, O, D, nh, nh, P(gA), L.stream_handle(DEV)))
     assert torch.equal(gA, torch.zeros_like(gA))
+    # without split_half every hidden row is a direct-connect row too (interaction.py:240-242): pool_from = 0, both terms
+    gp_all = torch.randn(B, O + 3, generator=g).to(DEV)              # (rows O + 3 apart: a block of a wider gradient)
+    gA.fill_(float("nan"))
+    L.check(lib.dctr_cin_pool_bwd(P(gh), P(gp_all), O + 3, None, None, B, O, D, nh, 0, P(gA), L.stream_handle(DEV)))
+    want = gp_all[:, :O, None].expand(B, O, D).clone()
+    if nh > 0:
+        want[:, :nh] = gh + want[:, :nh]      # (the kernel's order: hidden term first)
+    assert torch.equal(gA, want)
+    # the 1-unit projection's backward folded in (xdeepfm.py:72): gp(b, j) = g_logit[b] * w_head[j], one product in fp32
+    if nh < O:
+        g_logit = torch.randn(B, generator=g).to(DEV)
+        w_head = torch.randn(O - nh, generator=g).to(DEV)
+        gA.fill_(float("nan"))
+        L.check(lib.dctr_cin_pool_bwd(P(gh), P(g_logit), 1, P(w_head), P(A), B, O, D, nh, nh, P(gA), L.stream_handle(DEV)))
+        want = torch.zeros(B, O, D, device=DEV)
+        if nh > 0:
+            want[:, :nh] = gh
+        want[:, nh:] = (g_logit[:, None] * w_head[None, :])[:, :, None]
+        assert torch.equal(gA, torch.where(A > 0, want, torch.zeros_like(want)))
+
+
+@pytest.mark.parametrize("B,N,ld", [(1, 1, 1), (5, 192, 192), (4096, 192, 200), (33, 70, 71), (257, 1000, 1000)])
+def test_rows_dot_matches_fp64(B, N, ld):
+    """dctr_rows_dot: out[b] = sum_j x[b, j] w[j] (nn.Linear(N, 1, bias=False), xdeepfm.py:72) -- against fp64, and
+    bit-identical run to run (fixed summation order)."""
+    from deepctr_torch._hip import lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(B + N)
+    x = torch.randn(B, ld, generator=g).to(DEV)
+    w = torch.randn(N, generator=g).to(DEV)
+    outs = []
+    for _ in range(2):
+        out = torch.full((B,), float("nan"), device=DEV)
+        L.check(lib.dctr_rows_dot(ctypes.c_void_p(x.data_ptr()), ld, ctypes.c_void_p(w.data_ptr()), B, N,
+                                  ctypes.c_void_p(out.data_ptr()), L.stream_handle(DEV)))
+        outs.append(out)
+    ref = x[:, :N].double() @ w.double()
+    scale = float((x[:, :N].double().abs() @ w.double().abs()).max())
+    assert float((outs[0].double() - ref).abs().max()) <= 1e-6 * max(1.0, scale)
+    assert torch.equal(outs[0], outs[1])

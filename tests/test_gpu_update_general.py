@@ -240,3 +240,38 @@ def test_reference_test_data_takes_the_unit_path(monkeypatch, model, kw, with_le
     m.compile("adagrad", "binary_crossentropy", metrics=[])
     hist = m.fit(x, y, batch_size=32, epochs=2, verbose=0)
     assert np.isfinite(hist.history["loss"]).all()
+
+
+@pytest.mark.parametrize("opt", ["dense", "adagrad"])
+def test_past_the_envelope_the_atomic_fallback_still_matches_the_oracle(opt):
+    """A history of 130 positions is more X columns than one update unit stages (128): plan.unit_path is False and the
+    float-atomic two-pass kernels (dctr_embed_bwd + dctr_embed_apply) run -- the only shape that still reaches them.  Same
+    oracle, same bars (their sums are order-dependent in the last bits, not in the fifth digit)."""
+    cols = [_sp("user", 50, 8), _vl("long_hist", 40, 8, 130, "mean"), {"kind": "dense", "name": "price", "dimension": 1}]
+    spec = {"model": "DeepFM", "linear_columns": cols, "dnn_columns": cols,
+            "kwargs": {"dnn_hidden_units": [16], "dnn_dropout": 0, "init_std": 0.05, "seed": 7}}
+    m, params = _fresh(spec)
+    plan = m.model_plan()
+    assert not plan.unit_path and plan.gen is None
+    X, y = _data(spec, 96, "uniform", seed=3)
+    Xd, yd = torch.from_numpy(X).to(DEV), torch.from_numpy(y).to(DEV)
+    o = Oracle(spec, params, dtype=np.float64)
+    if opt == "dense":
+        m.train()
+        torch.nn.functional.binary_cross_entropy(m(Xd).squeeze(), yd, reduction="sum").backward()
+        torch.cuda.synchronize()
+        _, y_pred = o.forward(X)
+        grads = o.backward(y_pred - y.reshape(-1, 1))
+        for k, p in m.named_parameters():
+            ref = np.asarray(grads[k]).reshape(p.shape)
+            assert max_abs(p.grad.cpu().numpy(), ref) <= 2e-5 * max(1.0, float(np.max(np.abs(ref)))), k
+        return
+    m.compile("adagrad", "binary_crossentropy", metrics=[])
+    m.train()
+    loss, _, _ = m._train_step(Xd, yd)
+    lo, _ = o.train_step(X, y, optimizer="adagrad", lr=0.01, eps=1e-10, state=None)
+    assert abs(loss.item() - lo) <= 2e-5 * max(1.0, abs(lo))
+    sd = m.state_dict()
+    for k, v in o.P.items():      # (Adagrad's first step is lr * sign(g): same bar as test_general_units_match_the_oracle)
+        d = np.abs(sd[k].cpu().numpy().astype(np.float64) - np.asarray(v, np.float64).reshape(sd[k].shape))
+        assert float((d > 2e-5).mean()) <= 2e-4 and float(d.max()) <= 0.025, "%s: %.3e" % (k, d.max())

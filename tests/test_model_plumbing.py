@@ -174,6 +174,45 @@ def test_reference_protocol_runs_on_pooled_fields(mock, monkeypatch, tmp_path):
     assert before.shape == (N, 1) and max_abs(again.predict(x, batch_size=50), before) == 0.0
 
 
+def test_history_longer_than_a_unit_stages_takes_the_two_pass_route(mock):
+    """130 positions > DCTR_MAX_UNIT_SLOTS: the plan declines the unit path and the host routes the backward through
+    dctr_embed_bwd (+ dctr_embed_apply under an in-kernel optimizer) -- gradients against autograd on the same formulas."""
+    from deepctr_torch._hip.lib import MAX_UNIT_SLOTS
+    from deepctr_torch.inputs import DenseFeat, SparseFeat, VarLenSparseFeat
+    from deepctr_torch.models import DeepFM
+    T = MAX_UNIT_SLOTS + 2
+    cols = [SparseFeat("user", 50, 8), VarLenSparseFeat(SparseFeat("long_hist", 40, 8), maxlen=T, combiner="mean"),
+            DenseFeat("price", 1)]
+    torch.manual_seed(0)
+    m = DeepFM(cols, cols, dnn_hidden_units=(16,), init_std=0.05, device=DEV)
+    plan = m.model_plan()
+    assert not plan.unit_path and plan.gen is None
+    g = np.random.RandomState(1)
+    B = 48
+    n = g.randint(0, T + 1, (B, 1))
+    seq = np.where(np.arange(T)[None, :] < n, g.randint(1, 40, (B, T)), 0)
+    X = torch.from_numpy(np.concatenate([g.randint(0, 50, (B, 1)), seq, g.rand(B, 1)], axis=1).astype(np.float32))
+    m.train()
+    m(X).sum().backward()
+    assert any(c.startswith("embed_bwd") for c in mock.calls) and not any(c.startswith("embed_update") for c in mock.calls)
+    E = m.embedding_dict["long_hist"].weight
+    got = E.grad.clone()
+    # autograd over torch ops on the same parameters
+    m.zero_grad()
+    ids = X[:, 1:1 + T].long()
+    mask = (ids != 0).float().unsqueeze(-1)
+    pooled = (E[ids] * mask).sum(1) / (mask.sum(1) + 1e-8)
+    Eu = m.embedding_dict["user"].weight[X[:, 0].long()]
+    Wl = m.linear_model.embedding_dict
+    wide = Wl["user"].weight[X[:, 0].long()] + ((Wl["long_hist"].weight[ids] * mask).sum(1) / (mask.sum(1) + 1e-8)) \
+        + X[:, -1:] @ m.linear_model.weight
+    s1 = Eu + pooled
+    fm = 0.5 * (s1 * s1 - (Eu * Eu + pooled * pooled)).sum(1, keepdim=True)
+    deep = m.dnn_linear(m.dnn(torch.cat([Eu, pooled, X[:, -1:]], dim=1)))
+    torch.sigmoid(wide + fm + deep + m.out.bias).sum().backward()
+    assert max_abs(got.numpy(), E.grad.numpy()) <= 2e-5 * max(1.0, float(E.grad.abs().max()))
+
+
 def test_senet_beyond_the_kernel_envelope_matches_oracle(mock):
     """39 fields of 32 floats: more than dctr_senet_bwd stages in LDS -> the layer runs the reference's formulation as
     torch ops; values and gradients against the numpy oracle (pinned by the FiBiNET fixtures)."""

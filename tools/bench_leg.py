@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""One DeepFM leg of bench.py's other_configs on its own (for rocprofv3: the process then holds that leg's kernels only).
+"""One leg of bench.py's other_configs (a DeepFM variant, or xdeepfm / fibinet) on its own (for rocprofv3: the process then holds that leg's kernels only).
     python tools/bench_leg.py deepfm_varlen [--steps 100]"""
 import json
 import os
@@ -17,4 +17,7 @@ if args.steps_per_graph <= 0:
 import torch  # noqa: E402
 torch.cuda.set_device(0)
 X, y = bench.synth(args, "cuda:0", 0)
-print(json.dumps(bench.deepfm_leg(leg, args, "cuda:0", X, y)))
+if leg in bench.OTHER:
+    print(json.dumps(bench.other_config(leg, args, "cuda:0", X, y)))
+else:
+    print(json.dumps(bench.deepfm_leg(leg, args, "cuda:0", X, y)))
