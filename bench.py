@@ -620,6 +620,34 @@ def deepfm_leg(tag, args, device, X, y):
                "hip_graph": graphed, "final_loss": float(out[0].item()), "timing": spread(times, args.steps),
                "update_mode": plan.update[0], "unit_path": bool(plan.unit_path),
                "step_engine": bool(st is not None and st.get("engine") is not None and st["engine"].steps_run > 0)}
+        if tag == "default_kwargs" and plan.update[0] == "lazy":
+            # The lazy update replays, for every row, the optimizer steps the row slept through (an L2 term / Adam's moments
+            # move every row at every step: basemodel.py:412-428): per step it owes one optimizer step for EVERY row of every
+            # table, paid when a batch draws the row, by the per-step sweep of one K-th of the rows, or by the next flush.
+            # The shared synthetic set is 64 batches in a cycle (74 % of the rows are never drawn); the second measurement
+            # draws 1024 distinct batches, where every row comes back after V / B = 244 steps on average.  With the sweep
+            # (K = 32) both pay the whole debt inside the timed region; without it (DCTR_LAZY_SWEEP_K=0) the first left 74 %
+            # of it to a flush that the timed region never ran (0.29-0.30 ms) and the second stalled on its longest
+            # sleepers (1.2-1.5 ms).
+            res["rows_repeat_every_steps"] = int(X.shape[0] // args.batch)
+            try:
+                nb = 1024
+                gen = torch.Generator(device=device).manual_seed(99)
+                Xs = torch.cat([torch.randint(0, args.vocab, (nb * args.batch, F_SPARSE), generator=gen, device=device).float(),
+                                torch.rand((nb * args.batch, N_DENSE), generator=gen, device=device)], dim=1)
+                ys = torch.randint(0, 2, (nb * args.batch,), generator=gen, device=device).float()
+                el2, _, g2, did2, _, t2 = time_steps(model, Xs, ys, args.batch, args.steps, max(args.warmup, nb + 64),
+                                                     args.steps_per_graph, not args.no_graph, args.repeats, 0.0)
+                res["sweep_k"] = int(getattr(plan.lazy, "sweep_k", 0))
+                res["steady_state"] = {"distinct_batches": nb, "mean_steps_between_draws": round(args.vocab / args.batch, 1),
+                                       "ms_per_step": el2 / args.steps * 1e3, "value": args.batch * args.steps / el2,
+                                       "unit": "samples/s", "warmup": did2, "hip_graph": g2,
+                                       "timing": spread(t2, args.steps),
+                                       "note": "uniform ids over fresh batches: every row is drawn again and again"}
+                del Xs, ys
+            except Exception as exc:
+                torch.cuda.synchronize()
+                res["steady_state"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
         del model, Xl
         torch.cuda.empty_cache()
         return res

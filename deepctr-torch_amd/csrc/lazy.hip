@@ -32,10 +32,20 @@ using namespace dctr;
 namespace {
 
 constexpr int kT = 256;
+#ifdef DCTR_LAZY_IEEE_REPLAY
+constexpr bool kFastReplay = false;   // (A/B build: the replay loop on IEEE division / square root)
+#else
+constexpr bool kFastReplay = true;
+#endif
 
 struct OptConst {
   int kind;   // DCTR_LAZY_SGD / ADAGRAD / ADAM / RMSPROP
   float lr, eps, beta1, beta2;
+  // Adam's step-dependent scalars by step number (dctr_lazy_opt_t: adam_ss[T - 1], adam_bc[T - 1]; constant from the last
+  // entry on), or NULL: computed in the kernel (AdamClock)
+  const float* adam_ss;
+  const float* adam_bc;
+  int n_ss, n_bc;
 };
 
 // step-dependent scalars of Adam for step number T (1-based), maintained incrementally in double
@@ -52,17 +62,68 @@ struct AdamClock {
   __device__ __forceinline__ float bc2_sqrt() const { return static_cast<float>(sqrt(1.0 - p2)); }
 };
 
-// one optimizer step on one element.  a = Adagrad sum | Adam exp_avg, b = Adam exp_avg_sq.
+// Adam's scalars of step T from the host's tables.  At the Criteo shape a row sleeps V / B ~ 244 steps between two batches
+// that touch it and its catch-up replays every one of them: with the scalars computed in the loop (two double
+// multiplies, a double division and a double square root per step and lane) that arithmetic was ~40 % of k_lazy's
+// 282 us; they depend on T alone, so the host tabulates them once -- with the same pow / division / sqrt in double that
+// torch.optim.Adam performs per step on the host (adam.py: bias_correction = 1 - beta ** step).
+__device__ __forceinline__ void adam_tab(const OptConst& o, int T, float& ss, float& bc) {
+  ss = ldg_f32(o.adam_ss + ((T < o.n_ss ? T : o.n_ss) - 1));
+  bc = ldg_f32(o.adam_bc + ((T < o.n_bc ? T : o.n_bc) - 1));
+}
+__device__ __forceinline__ void adam_scalars(const OptConst& o, int T, float& ss, float& bc) {
+  if (o.adam_ss) {
+    adam_tab(o, T, ss, bc);
+  } else {
+    AdamClock ck;
+    ck.start(o, T);
+    ss = ck.step_size();
+    bc = ck.bc2_sqrt();
+  }
+}
+
+// Division and square root of the REPLAY loop.  A row that slept k steps replays k optimizer steps whose only gradient is
+// the L2 term; at the Criteo shape (k ~ V / B = 244) that loop is the whole cost of the default-kwargs step, and two IEEE
+// divisions + one IEEE square root were ~30 of its ~50 instructions per element (v_div_scale x 2, v_rcp, five fmas,
+// v_div_fmas, v_div_fixup each: the range scaling and special-case fix-ups of a general division).  Here: hardware
+// reciprocal / reciprocal square root (1 ulp) and ONE Newton correction through the exact residual (fma), i.e. the core of
+// the IEEE sequence without its scaling and fix-ups -- the operands of this loop are ordinary normal numbers (denominators
+// >= eps, moments of magnitude (lambda w)^2).  Result within 1 ulp of the correctly rounded one, the same on every run.
+// The step that carries a DATA gradient (apply) and the dense slab keep the IEEE operations.
+__device__ __forceinline__ float div_nr(float a, float d, float rd) {   // rd = rcp(d)
+  const float q = a * rd;
+  return fmaf(fmaf(-q, d, a), rd, q);
+}
+__device__ __forceinline__ float sqrt_nr(float x) {
+  const float r = __builtin_amdgcn_rsqf(x);
+  const float s = x * r;
+  const float t = fmaf(fmaf(-s, s, x), 0.5f * r, s);
+  return x > 0.f ? t : 0.f;        // (rsq(0) = inf; a moment is never negative)
+}
+
+// one optimizer step on one element.  a = Adagrad sum | Adam exp_avg, b = Adam exp_avg_sq.  FAST: the replay loop's
+// division / square root (above); rbc = rcp(bc2s), computed once per step by the caller.
+template <bool FAST = false>
 __device__ __forceinline__ void opt_step(const OptConst& o, float g, float& w, float& a, float& b, float step_size,
-                                         float bc2s) {
+                                         float bc2s, float rbc = 0.f) {
   if (o.kind == DCTR_LAZY_ADAM) {
     a = a + (g - a) * (1.f - o.beta1);
     b = b * o.beta2 + (1.f - o.beta2) * g * g;
-    const float denom = sqrtf(b) / bc2s + o.eps;
-    w = w - step_size * (a / denom);
+    if (FAST) {
+      const float denom = div_nr(sqrt_nr(b), bc2s, rbc) + o.eps;
+      w = w - step_size * div_nr(a, denom, __builtin_amdgcn_rcpf(denom));
+    } else {
+      const float denom = sqrtf(b) / bc2s + o.eps;
+      w = w - step_size * (a / denom);
+    }
   } else if (o.kind == DCTR_LAZY_ADAGRAD) {
     a = a + g * g;
-    w = w - o.lr * (g / (sqrtf(a) + o.eps));
+    if (FAST) {
+      const float denom = sqrt_nr(a) + o.eps;
+      w = w - o.lr * div_nr(g, denom, __builtin_amdgcn_rcpf(denom));
+    } else {
+      w = w - o.lr * (g / (sqrtf(a) + o.eps));
+    }
   } else if (o.kind == DCTR_LAZY_RMSPROP) {
     // square_avg.mul_(alpha).addcmul_(g, g, value=1 - alpha); p.addcdiv_(g, square_avg.sqrt().add_(eps), value=-lr)
     // -- with the roundings of ATen's device kernels (each tensor op rounds; addcmul is a + (v * b) * c and addcdiv is
@@ -77,14 +138,54 @@ __device__ __forceinline__ void opt_step(const OptConst& o, float g, float& w, f
   }
 }
 
-// Replay the steps from+1 .. to of an UNTOUCHED element (g = 2*lambda*w) -- the reference's dense update of a row
-// no sample of those batches referred to.
-template <int VEC>
-__device__ __forceinline__ void replay(const OptConst& o, float lam2, int from, int to, float (&w)[VEC],
-                                       float (&a)[VEC], float (&b)[VEC]) {
+// Replay the steps from+1 .. to of an UNTOUCHED row (g = 2*lambda*w) -- the reference's dense update of a row no sample
+// of those batches referred to: the lane's strip of the deep row and, on the lane that holds it, the wide weight, in ONE
+// walk over the steps (the wide weight used to take a second walk by a quarter of the lanes while the others waited).
+// Adam with the host's tables, the WHOLE WAVE in step: every lane walks T = from_min + 1 .. to (from_min = the earliest
+// stamp among the wave's rows) and sits out the steps its own row has already seen.  All lanes then read the SAME table
+// entry per trip -- one cache line per load instruction.  Walking each row from its own stamp (the loop below) made the 16
+// lane groups of a wave read 16 different lines per trip, twice: with rows that slept differently long (any real batch)
+// the CU's L1 spent three times the loop's arithmetic on tag lookups (1 670 cycles per trip against 577 when every row had
+// slept the same 64 steps).  Must be called by all 64 lanes (rows that need nothing: from = to).
+template <int VEC, bool FAST>
+__device__ __forceinline__ void replay_in_step(const OptConst& o, float lam2d, float lam2w, bool deep_on, bool wide_on,
+                                               int from, int to, float (&w)[VEC], float (&a)[VEC], float (&b)[VEC],
+                                               float& ww, float& wa, float& wb) {
+  int from_min = from;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int other = __shfl_xor(from_min, off, kWave);
+    from_min = other < from_min ? other : from_min;
+  }
+  from_min = __builtin_amdgcn_readfirstlane(from_min);
+  if (from_min >= to) return;
+  float ss, bc;
+  adam_tab(o, from_min + 1, ss, bc);
+  for (int T = from_min + 1; T <= to; ++T) {
+    float ssn, bcn;
+    adam_tab(o, T + 1, ssn, bcn);       // (the next step's pair is in flight while this step computes; clamped: valid)
+    if (T > from) {
+      const float rbc = __builtin_amdgcn_rcpf(bc);
+      if (deep_on) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) opt_step<FAST>(o, lam2d * w[i], w[i], a[i], b[i], ss, bc, rbc);
+      }
+      if (wide_on) opt_step<FAST>(o, lam2w * ww, ww, wa, wb, ss, bc, rbc);
+    }
+    ss = ssn;
+    bc = bcn;
+  }
+}
+
+template <int VEC, bool FAST>
+__device__ __forceinline__ void replay(const OptConst& o, float lam2d, float lam2w, bool deep_on, bool wide_on, int from,
+                                       int to, float (&w)[VEC], float (&a)[VEC], float (&b)[VEC], float& ww, float& wa,
+                                       float& wb) {
   if (from >= to) return;
   // zero gradient: SGD / Adagrad do not move (RMSprop's square_avg still decays, Adam's moments too)
-  if ((o.kind == DCTR_LAZY_SGD || o.kind == DCTR_LAZY_ADAGRAD) && lam2 == 0.f) return;
+  const bool still = o.kind == DCTR_LAZY_SGD || o.kind == DCTR_LAZY_ADAGRAD;
+  const bool do_d = deep_on && !(still && lam2d == 0.f), do_w = wide_on && !(still && lam2w == 0.f);
+  if (!do_d && !do_w) return;
   AdamClock ck;
   if (o.kind == DCTR_LAZY_ADAM) ck.start(o, from + 1);
   for (int T = from + 1; T <= to; ++T) {
@@ -94,8 +195,12 @@ __device__ __forceinline__ void replay(const OptConst& o, float lam2, int from, 
       bc = ck.bc2_sqrt();
       ck.next();
     }
+    const float rbc = __builtin_amdgcn_rcpf(bc);
+    if (do_d) {
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) opt_step(o, lam2 * w[i], w[i], a[i], b[i], ss, bc);
+      for (int i = 0; i < VEC; ++i) opt_step<FAST>(o, lam2d * w[i], w[i], a[i], b[i], ss, bc, rbc);
+    }
+    if (do_w) opt_step<FAST>(o, lam2w * ww, ww, wa, wb, ss, bc, rbc);
   }
 }
 
@@ -119,34 +224,55 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
   strip_store<VEC>(p, s);
 }
 
-// The three passes share one body: MODE 0 catch-up (batch ids), 1 apply (batch ids), 2 flush (all rows).
+// The passes share one body: MODE 0 catch-up (batch ids), 1 apply (batch ids), 2 flush (all rows), 3 sweep (the
+// (t mod K)-th of K windows of every table's rows: see dctr_lazy_sweep).
 // A lane group of `lpr` lanes (a power of two <= 64) owns one (unit, entry); lane gl handles the deep strip
 // [gl*VEC, gl*VEC + VEC) and, when gl == 0, the wide element.
 template <int VEC, int MODE>
 __global__ __launch_bounds__(kT) void k_lazy(const dctr_lazy_unit_t* __restrict__ units, int n_units,
                                              const int32_t* __restrict__ ids_t, int64_t n_entries, int lpr_shift,
-                                             const int32_t* __restrict__ step_ptr, OptConst o) {
+                                             const int32_t* __restrict__ step_ptr, OptConst o,
+                                             const int32_t* __restrict__ order, int sweep_k, int part) {
   const int lpr = 1 << lpr_shift;
   const int64_t grp = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> lpr_shift;
   const int gl = threadIdx.x & (lpr - 1);
   const int u = blockIdx.y;
-  if (u >= n_units || grp >= n_entries) return;
+  if (u >= n_units) return;
+  // (lane groups past the end stay in the wave: the replay walks the steps with all 64 lanes, replay_in_step)
+  bool dead = grp >= n_entries;
   const dctr_lazy_unit_t un = units[u];
   const int t = *(const DCTR_GLOBAL int32_t*)step_ptr;
-  int64_t row;
+  int64_t row = 0;
   if (MODE == 2) {
     row = grp;
-    if (row >= un.vocab) return;
-  } else {
-    const int32_t id = ldg_i32(ids_t + static_cast<int64_t>(u) * n_entries + grp);
+    if (row >= un.vocab) {
+      dead = true;
+      row = 0;
+    }
+  } else if (MODE == 3) {
+    const int64_t wlen = (un.vocab + sweep_k - 1) / sweep_k;      // this table's window
+    row = static_cast<int64_t>(t % sweep_k) * wlen + grp;
+    if (grp >= wlen || row >= un.vocab) {
+      dead = true;
+      row = 0;
+    }
+  } else if (!dead) {
+    // (catch-up: entries dealt by gap, k_lazy_order -- a wave's rows then sleep about equally long)
+    const int64_t ent = (MODE == 0 && order) ? ldg_i32(order + static_cast<int64_t>(u) * n_entries + grp) : grp;
+    const int32_t id = ldg_i32(ids_t + static_cast<int64_t>(u) * n_entries + ent);
     row = (static_cast<uint64_t>(static_cast<int64_t>(id)) >= static_cast<uint64_t>(un.vocab)) ? 0 : id;
   }
   // The row's strips are loaded BEFORE the claim is known (a row has one claimant per launch except for duplicate ids,
   // whose losers simply drop what they loaded): the claim's atomic round trip and the row's HBM round trip overlap
   // instead of following each other.  A winner's early loads are valid: nobody else writes its row in this launch.
   const int e0 = gl * VEC;
-  const bool deep_on = un.deep != nullptr && e0 < un.dim;
-  const bool wide_on = un.wide != nullptr && gl == 0;
+  // part (sweep / flush, whose rows have no second claimant): 0 = the whole row; 1 = the wide weight only, one LANE per row
+  // and the stamp left alone; 2 = the deep row only, then the stamp.  Pass 1 in front of pass 2 replays the wide weights of
+  // 64 rows per wavefront trip instead of 16 (a quarter of the lanes carried them while the others waited: 27 of a trip's
+  // 96 instructions).
+  const bool deep_on = !dead && un.deep != nullptr && e0 < un.dim && part != 1;
+  const bool wide_on = !dead && un.wide != nullptr && gl == 0 && part != 2;
+  if (part == 1 && un.wide == nullptr) return;
   const float lam2d = 2.f * un.l2_deep, lam2w = 2.f * un.l2_wide;
   // the table and its first state slab may be strided views of one interleaved slab (row strides in the unit);
   // the second state slab and the gradient slab are contiguous
@@ -172,27 +298,28 @@ __global__ __launch_bounds__(kT) void k_lazy(const dctr_lazy_unit_t* __restrict_
   }
   // claim the row: the winner is the only group that touches it in this launch
   const int target = (MODE == 1) ? t + 1 : t;
-  int prev = 0;
-  if (gl == 0) {
-    if (MODE == 2) {
+  int prev = target;
+  if (gl == 0 && !dead) {
+    if (MODE >= 2) {
       prev = un.stamp[row];
-      if (prev < target) un.stamp[row] = target;
+      if (prev < target && part != 1) un.stamp[row] = target;
     } else {
       prev = atomicMax(un.stamp + row, target);
     }
   }
   prev = __shfl(prev, (threadIdx.x & 63) & ~(lpr - 1), kWave);
-  if (prev >= target) return;
-
-  float ss1 = 0.f, bc1 = 1.f;        // Adam scalars of step t + 1 (apply)
-  if (MODE == 1 && o.kind == DCTR_LAZY_ADAM) {
-    AdamClock ck;
-    ck.start(o, t + 1);
-    ss1 = ck.step_size();
-    bc1 = ck.bc2_sqrt();
+  const bool live = prev < target;
+  if (MODE != 1 && o.kind == DCTR_LAZY_ADAM && o.adam_ss) {
+    replay_in_step<VEC, kFastReplay>(o, lam2d, lam2w, deep_on && live, wide_on && live, live ? prev : t, t, w, a, b, ww[0],
+                                     wa[0], wb[0]);
+    if (!live) return;
+  } else {
+    if (!live) return;
+    replay<VEC, kFastReplay>(o, lam2d, lam2w, deep_on, wide_on, prev, t, w, a, b, ww[0], wa[0], wb[0]);   // (apply after a catch-up: prev == t)
   }
+  float ss1 = 0.f, bc1 = 1.f;        // Adam scalars of step t + 1 (apply)
+  if (MODE == 1 && o.kind == DCTR_LAZY_ADAM) adam_scalars(o, t + 1, ss1, bc1);
   if (deep_on) {
-    replay<VEC>(o, lam2d, prev, t, w, a, b);          // (apply after a catch-up: prev == t, nothing to replay)
     if (MODE == 1) {
       float z[VEC];
 #pragma unroll
@@ -206,7 +333,6 @@ __global__ __launch_bounds__(kT) void k_lazy(const dctr_lazy_unit_t* __restrict_
     if (un.deep_s2) store_vec<VEC>(un.deep_s2 + off, b);
   }
   if (wide_on) {
-    replay<1>(o, lam2w, prev, t, ww, wa, wb);
     if (MODE == 1) {
       stg_f32(un.wide_g + row, 0.f);
       opt_step(o, wg + lam2w * ww[0], ww[0], wa[0], wb[0], ss1, bc1);
@@ -215,6 +341,71 @@ __global__ __launch_bounds__(kT) void k_lazy(const dctr_lazy_unit_t* __restrict_
     if (un.wide_s1) stg_f32(un.wide_s1 + row_a, wa[0]);
     if (un.wide_s2) stg_f32(un.wide_s2 + row, wb[0]);
   }
+}
+
+// ---- catch-up: the batch's entries ordered by how long their rows slept -----------------------------------------------
+// k_lazy gives every lane group one row and walks its missed steps: a wave runs until the LONGEST gap among its 16 rows
+// is done.  The gaps of a big table's rows are geometric (mean V / B = 244 steps at the Criteo shape) and the expected
+// maximum of 16 of them is 3.4 x their mean -- 70 % of the lanes' cycles went to waiting (measured: 0.29 ms per step while
+// every row came back after exactly 64 steps, the bench's 64-batch cycle; 1.45 ms on fresh batches).  One workgroup per
+// unit deals the entries into 256 buckets of gap (width = mean gap / 32: eight means end to end, everything longer in
+// the last one), longest first: order[u][k] = the k-th entry to process.  Rows of one wave then differ by a bucket's
+// width.  Counting sort through LDS; the order inside a bucket depends on the atomics' arrival but no result does (every
+// row is replayed by itself).
+constexpr int kOrderT = 1024;
+__global__ __launch_bounds__(kOrderT) void k_lazy_order(const dctr_lazy_unit_t* __restrict__ units,
+                                                        const int32_t* __restrict__ ids_t, int n_entries,
+                                                        const int32_t* __restrict__ step_ptr, int32_t* __restrict__ order) {
+  __shared__ int hist[256];
+  __shared__ unsigned long long total;
+  __shared__ int red[kOrderT / 64];
+  const int u = blockIdx.x;
+  const dctr_lazy_unit_t un = units[u];
+  const int t = *(const DCTR_GLOBAL int32_t*)step_ptr;
+  const int32_t* ids = ids_t + static_cast<int64_t>(u) * n_entries;
+  int32_t* out = order + static_cast<int64_t>(u) * n_entries;
+  auto gap_of = [&](int i) {
+    const int32_t id = ldg_i32(ids + i);
+    const int64_t row = (static_cast<uint64_t>(static_cast<int64_t>(id)) >= static_cast<uint64_t>(un.vocab)) ? 0 : id;
+    const int g = t - ldg_i32(un.stamp + row);
+    return g > 0 ? g : 0;
+  };
+  if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+  if (threadIdx.x == 0) total = 0ull;
+  __syncthreads();
+  // mean gap -> bucket width
+  unsigned long long mine = 0ull;
+  for (int i = threadIdx.x; i < n_entries; i += kOrderT) mine += static_cast<unsigned long long>(gap_of(i));
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, kWave);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&total, mine);
+  __syncthreads();
+  const int mean = static_cast<int>(total / static_cast<unsigned long long>(n_entries));
+  const int width = mean / 32 > 0 ? mean / 32 : 1;
+  auto bucket_of = [&](int g) {          // bucket 0 = the longest gaps
+    const int b = g / width;
+    return 255 - (b < 255 ? b : 255);
+  };
+  for (int i = threadIdx.x; i < n_entries; i += kOrderT) atomicAdd(&hist[bucket_of(gap_of(i))], 1);
+  __syncthreads();
+  // exclusive scan of the 256 counts (wave 0..3 each scan 64, then add the waves' totals)
+  if (threadIdx.x < 256) {
+    const int c = hist[threadIdx.x];
+    int x = c;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int y = __shfl_up(x, off, kWave);
+      if ((threadIdx.x & 63) >= off) x += y;
+    }
+    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = x;
+    hist[threadIdx.x] = x - c;           // exclusive within the wave
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    int base = 0;
+    for (int w = 0; w < (threadIdx.x >> 6); ++w) base += red[w];
+    hist[threadIdx.x] += base;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_entries; i += kOrderT) out[atomicAdd(&hist[bucket_of(gap_of(i))], 1)] = i;
 }
 
 __global__ void k_lazy_inc(int32_t* step) { *step += 1; }
@@ -228,12 +419,7 @@ __global__ __launch_bounds__(kT) void k_dense_opt_reg(float* __restrict__ p, con
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
   if (i >= n) return;
   float ss = 0.f, bc = 1.f;
-  if (o.kind == DCTR_LAZY_ADAM) {
-    AdamClock ck;
-    ck.start(o, *(const DCTR_GLOBAL int32_t*)step_ptr + 1);
-    ss = ck.step_size();
-    bc = ck.bc2_sqrt();
-  }
+  if (o.kind == DCTR_LAZY_ADAM) adam_scalars(o, *(const DCTR_GLOBAL int32_t*)step_ptr + 1, ss, bc);
   float w = ldg_f32(p + i);
   float a = s1 ? ldg_f32(s1 + i) : 0.f, b = s2 ? ldg_f32(s2 + i) : 0.f;
   const float gt = ldg_f32(g + i) + (lam ? 2.f * ldg_f32(lam + i) * w : 0.f);
@@ -241,6 +427,17 @@ __global__ __launch_bounds__(kT) void k_dense_opt_reg(float* __restrict__ p, con
   stg_f32(p + i, w);
   if (s1) stg_f32(s1 + i, a);
   if (s2) stg_f32(s2 + i, b);
+}
+
+OptConst opt_const(const dctr_lazy_opt_t* opt) {
+  OptConst o;
+  o.kind = opt->kind; o.lr = opt->lr; o.eps = opt->eps; o.beta1 = opt->beta1; o.beta2 = opt->beta2;
+  const bool tab = opt->kind == DCTR_LAZY_ADAM && opt->adam_ss && opt->adam_bc && opt->n_ss > 0 && opt->n_bc > 0;
+  o.adam_ss = tab ? opt->adam_ss : nullptr;
+  o.adam_bc = tab ? opt->adam_bc : nullptr;
+  o.n_ss = tab ? opt->n_ss : 0;
+  o.n_bc = tab ? opt->n_bc : 0;
+  return o;
 }
 
 int check(const dctr_lazy_unit_t* units, int n_units, const int32_t* step, const dctr_lazy_opt_t* opt, int vec,
@@ -256,7 +453,7 @@ int check(const dctr_lazy_unit_t* units, int n_units, const int32_t* step, const
 
 template <int MODE>
 int launch(const dctr_lazy_unit_t* units, int n_units, const int32_t* ids_t, int64_t n_entries, const int32_t* step,
-           const dctr_lazy_opt_t* opt, int vec, int max_dim, hipStream_t s) {
+           const dctr_lazy_opt_t* opt, int vec, int max_dim, hipStream_t s, int32_t* order = nullptr, int sweep_k = 0) {
   const int rc = check(units, n_units, step, opt, vec, max_dim);
   if (rc != DCTR_OK) return rc;
   if (n_entries <= 0) return DCTR_OK;
@@ -265,26 +462,46 @@ int launch(const dctr_lazy_unit_t* units, int n_units, const int32_t* ids_t, int
     lpr <<= 1;
     ++shift;
   }
-  OptConst o;
-  o.kind = opt->kind; o.lr = opt->lr; o.eps = opt->eps; o.beta1 = opt->beta1; o.beta2 = opt->beta2;
+  const OptConst o = opt_const(opt);
   const int64_t threads = n_entries << shift;
   const dim3 grid(static_cast<unsigned>((threads + kT - 1) / kT), static_cast<unsigned>(n_units));
+  static const bool ordered = !(getenv("DCTR_LAZY_ORDER") && getenv("DCTR_LAZY_ORDER")[0] == '0');   // (A/B switch)
+  // zero-gradient steps of SGD / Adagrad without an L2 term move nothing: no replay to balance
+  const bool replays = !((o.kind == DCTR_LAZY_SGD || o.kind == DCTR_LAZY_ADAGRAD) && !opt->any_l2);
+  if (MODE == 0 && order && ordered && replays && n_entries >= 64 && n_entries <= (1 << 18)) {
+    k_lazy_order<<<dim3(static_cast<unsigned>(n_units)), dim3(kOrderT), 0, s>>>(units, ids_t, static_cast<int>(n_entries),
+                                                                                step, order);
+  } else {
+    order = nullptr;
+  }
+  static const bool split = !(getenv("DCTR_LAZY_SPLIT_WIDE") && getenv("DCTR_LAZY_SPLIT_WIDE")[0] == '0');   // (A/B switch)
+  int part = 0;
+  if (MODE >= 2 && split && shift > 0) {
+    // the wide weights first, one lane per row (the stamps are written by the second pass)
+    const dim3 gw(static_cast<unsigned>((n_entries + kT - 1) / kT), static_cast<unsigned>(n_units));
+    if (vec == 4)
+      k_lazy<4, MODE><<<gw, dim3(kT), 0, s>>>(units, n_units, ids_t, n_entries, 0, step, o, order, sweep_k, 1);
+    else
+      k_lazy<1, MODE><<<gw, dim3(kT), 0, s>>>(units, n_units, ids_t, n_entries, 0, step, o, order, sweep_k, 1);
+    part = 2;
+  }
   if (vec == 4)
-    k_lazy<4, MODE><<<grid, dim3(kT), 0, s>>>(units, n_units, ids_t, n_entries, shift, step, o);
+    k_lazy<4, MODE><<<grid, dim3(kT), 0, s>>>(units, n_units, ids_t, n_entries, shift, step, o, order, sweep_k, part);
   else
-    k_lazy<1, MODE><<<grid, dim3(kT), 0, s>>>(units, n_units, ids_t, n_entries, shift, step, o);
+    k_lazy<1, MODE><<<grid, dim3(kT), 0, s>>>(units, n_units, ids_t, n_entries, shift, step, o, order, sweep_k, part);
   return launch_status();
 }
 
 }  // namespace
 
 extern "C" size_t dctr_sizeof_lazy_unit(void) { return sizeof(dctr_lazy_unit_t); }
+extern "C" size_t dctr_sizeof_lazy_opt(void) { return sizeof(dctr_lazy_opt_t); }
 
 extern "C" int dctr_lazy_catchup(const dctr_lazy_unit_t* units, int32_t n_units, const int32_t* ids_t, int32_t B,
                                  const int32_t* step, const dctr_lazy_opt_t* opt, int32_t vec, int32_t max_dim,
-                                 dctr_stream_t stream) {
+                                 int32_t* order_ws, dctr_stream_t stream) {
   if (B < 0 || (B > 0 && !ids_t)) return DCTR_EINVAL;
-  return launch<0>(units, n_units, ids_t, B, step, opt, vec, max_dim, static_cast<hipStream_t>(stream));
+  return launch<0>(units, n_units, ids_t, B, step, opt, vec, max_dim, static_cast<hipStream_t>(stream), order_ws);
 }
 
 extern "C" int dctr_lazy_apply(const dctr_lazy_unit_t* units, int32_t n_units, const int32_t* ids_t, int32_t B,
@@ -300,6 +517,14 @@ extern "C" int dctr_lazy_flush(const dctr_lazy_unit_t* units, int32_t n_units, i
   return launch<2>(units, n_units, nullptr, max_vocab, step, opt, vec, max_dim, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int dctr_lazy_sweep(const dctr_lazy_unit_t* units, int32_t n_units, int64_t max_vocab, int32_t K,
+                               const int32_t* step, const dctr_lazy_opt_t* opt, int32_t vec, int32_t max_dim,
+                               dctr_stream_t stream) {
+  if (max_vocab < 0 || K <= 0) return DCTR_EINVAL;
+  const int64_t wlen = (max_vocab + K - 1) / K;
+  return launch<3>(units, n_units, nullptr, wlen, step, opt, vec, max_dim, static_cast<hipStream_t>(stream), nullptr, K);
+}
+
 extern "C" int dctr_dense_opt_reg(float* p, const float* g, float* s1, float* s2, const float* lam, int64_t n,
                                   const dctr_lazy_opt_t* opt, const int32_t* step, dctr_stream_t stream) {
   if (!p || !g || n < 0 || !opt || !step) return DCTR_EINVAL;
@@ -309,8 +534,7 @@ extern "C" int dctr_dense_opt_reg(float* p, const float* g, float* s1, float* s2
       opt->kind != DCTR_LAZY_RMSPROP)
     return DCTR_EINVAL;
   if (n == 0) return DCTR_OK;
-  OptConst o;
-  o.kind = opt->kind; o.lr = opt->lr; o.eps = opt->eps; o.beta1 = opt->beta1; o.beta2 = opt->beta2;
+  const OptConst o = opt_const(opt);
   k_dense_opt_reg<<<dim3(static_cast<unsigned>((n + kT - 1) / kT)), dim3(kT), 0, static_cast<hipStream_t>(stream)>>>(
       p, g, s1, s2, lam, n, step, o);
   return launch_status();

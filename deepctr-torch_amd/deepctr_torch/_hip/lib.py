@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdctr_hip.so")
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 
@@ -110,7 +110,9 @@ class LazyUnit(ctypes.Structure):
 class LazyOpt(ctypes.Structure):
     """dctr_lazy_opt_t"""
     _fields_ = [("kind", ctypes.c_int32), ("lr", ctypes.c_float), ("eps", ctypes.c_float),
-                ("beta1", ctypes.c_float), ("beta2", ctypes.c_float)]
+                ("beta1", ctypes.c_float), ("beta2", ctypes.c_float),
+                ("n_ss", ctypes.c_int32), ("n_bc", ctypes.c_int32), ("any_l2", ctypes.c_int32),
+                ("adam_ss", ctypes.c_void_p), ("adam_bc", ctypes.c_void_p)]
 POOL_CODE = {None: 0, "sum": 1, "mean": 2, "max": 3}
 BWD_ACCUM, BWD_SGD = 0, 1
 OPT_SGD, OPT_ADAGRAD = 0, 1
@@ -141,7 +143,9 @@ SIGNATURES = {
                                       _I32, _F32, _P]),
     "dctr_embed_apply": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _I32, _F32, _F32, _P]),
     "dctr_sizeof_lazy_unit": (ctypes.c_size_t, []),
-    "dctr_lazy_catchup": (ctypes.c_int, [_P, _I32, _P, _I32, _P, _P, _I32, _I32, _P]),
+    "dctr_sizeof_lazy_opt": (ctypes.c_size_t, []),
+    "dctr_lazy_sweep": (ctypes.c_int, [_P, _I32, _I64, _I32, _P, _P, _I32, _I32, _P]),
+    "dctr_lazy_catchup": (ctypes.c_int, [_P, _I32, _P, _I32, _P, _P, _I32, _I32, _P, _P]),
     "dctr_lazy_apply": (ctypes.c_int, [_P, _I32, _P, _I32, _P, _P, _I32, _I32, _P]),
     "dctr_lazy_flush": (ctypes.c_int, [_P, _I32, _I64, _P, _P, _I32, _I32, _P]),
     "dctr_lazy_step_inc": (ctypes.c_int, [_P, _P]),
@@ -275,6 +279,7 @@ def lib():
                 or handle.dctr_sizeof_vunit() != ctypes.sizeof(VUnit) \
                 or handle.dctr_sizeof_plan_ext() != ctypes.sizeof(PlanExt) \
                 or handle.dctr_sizeof_lazy_unit() != ctypes.sizeof(LazyUnit) \
+                or handle.dctr_sizeof_lazy_opt() != ctypes.sizeof(LazyOpt) \
                 or handle.dctr_sizeof_dense_step() != ctypes.sizeof(DenseStep) \
                 or handle.dctr_sizeof_dense_item() != ctypes.sizeof(DenseItem):
             raise RuntimeError("dctr_field_t / dctr_plan_t / dctr_mlp_t layout mismatch between header and binding")

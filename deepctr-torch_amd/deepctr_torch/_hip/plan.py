@@ -11,6 +11,7 @@ weight, so ``state_dict`` keys stay the reference's); next to a table may sit tw
 re-zeroes exactly the rows it consumed, so no O(V) memset ever runs) and ``state`` (Adagrad sum).
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -118,12 +119,61 @@ class LazyState(object):
         self.opt.kind = {"sgd": L.LAZY_SGD, "adagrad": L.LAZY_ADAGRAD, "adam": L.LAZY_ADAM,
                          "rmsprop": L.LAZY_RMSPROP}[kind]
         self.opt.lr, self.opt.eps, self.opt.beta1, self.opt.beta2 = self.hyper
+        self.opt.any_l2 = int(any(v > 0 for v in self.l2.values()))
+        # rows move between two touches (an L2 term, or moments that keep decaying): there are steps to replay
+        self.replays = bool(self.opt.any_l2) or kind in ("adam", "rmsprop")
+        # every train step also brings one K-th of every table to the current step (dctr_lazy_sweep): no row sleeps longer
+        # than K steps (0: off -- rows pay their whole history when they are next drawn or at the next flush)
+        self.sweep_k = int(os.environ.get("DCTR_LAZY_SWEEP_K", "32"))
         self.vec = 4 if plan.vec == 4 else 1
         self.max_dim = max(plan.max_dim, 1)
         self.n_elems = sum(p.numel() for p in plan.table_params)
+        self._adam_tab = None     # (ss, bc) device tables of Adam's step-dependent scalars (include/dctr.h dctr_lazy_opt_t)
 
     def signature(self):
         return (self.kind, self.hyper, tuple(sorted(self.l2.items())))
+
+    ADAM_TABLE_MAX = 1 << 22
+
+    @staticmethod
+    def adam_tables(lr, beta1, beta2, limit=1 << 22):
+        """(step_size[T - 1], sqrt(bias_correction2)[T - 1]) for T = 1 .. n as float32 arrays, computed like torch.optim.Adam
+        computes them per step on the host (adam.py: ``1 - beta ** step`` in double, ``lr / bias_correction1``,
+        ``sqrt(bias_correction2)``), each up to the first step whose bias correction is exactly 1 in double (the value
+        from there on); None when a table would exceed ``limit`` entries (a beta within 1e-5 of 1)."""
+        import math
+        import numpy as np
+        out = []
+        for beta in (float(beta1), float(beta2)):
+            if not 0.0 <= beta < 1.0:
+                return None
+            n = 1 if beta == 0.0 else int(math.ceil(math.log(2.0 ** -54) / math.log(beta))) + 2
+            if n > limit:
+                return None
+            corr = 1.0 - np.power(np.float64(beta), np.arange(1, n + 1, dtype=np.float64))
+            if corr[-1] != 1.0:
+                return None
+            out.append(corr)
+        ss = (np.float64(lr) / out[0]).astype(np.float32)
+        bc = np.sqrt(out[1]).astype(np.float32)
+        return ss, bc
+
+    def _ensure_adam_tables(self, device):
+        if self.kind != "adam" or os.environ.get("DCTR_LAZY_ADAM_TABLES", "1") == "0":
+            return
+        if self._adam_tab is None or self._adam_tab[0].device != torch.device(device):
+            # (from the hyper-parameters as the optimizer holds them, in double -- the in-kernel fallback starts from their
+            # float32 roundings: beta2 = 0.999 is 1.3e-8 off there, 4e-6 of the step size after a thousand steps)
+            lr, _, b1, b2 = self.hyper
+            tabs = self.adam_tables(lr, b1, b2, self.ADAM_TABLE_MAX)
+            if tabs is None:
+                self._adam_tab = ()
+            else:
+                self._adam_tab = tuple(torch.from_numpy(t).to(device) for t in tabs)
+        if self._adam_tab:
+            ss, bc = self._adam_tab
+            self.opt.adam_ss, self.opt.n_ss = ss.data_ptr(), ss.numel()
+            self.opt.adam_bc, self.opt.n_bc = bc.data_ptr(), bc.numel()
 
     def _ensure(self, device):
         plan = self.plan
@@ -139,6 +189,7 @@ class LazyState(object):
             self.stamps = [torch.full((int(self._unit_vocab(u)),), t0, dtype=torch.int32, device=device)
                            for u in range(len(plan.units))]
             self._key = None
+        self._ensure_adam_tables(device)
         plan.ensure_gacc()
         key = [str(device)]
         for p in plan.table_params:
@@ -180,11 +231,12 @@ class LazyState(object):
         di, wi, _, _ = self.plan.units[u]
         return self.plan.deep[di].vocab if di >= 0 else self.plan.wide[wi].vocab
 
-    def _call(self, fn, name, *mid):
+    def _call(self, fn, name, *mid, **kw):
         dev = self.step.device
+        tail = kw.get("tail", ())
         L.check(fn(ctypes.c_void_p(self._units_dev.data_ptr()), len(self.plan.units), *mid,
                    ctypes.c_void_p(self.step.data_ptr()), ctypes.byref(self.opt), self.vec, self.max_dim,
-                   L.stream_handle(dev)), name)
+                   *(tuple(tail) + (L.stream_handle(dev),))), name)
 
     def catchup(self, X):
         """Before the gather of a train step: bring the batch's rows to the current step.  Returns ids_t."""
@@ -195,7 +247,14 @@ class LazyState(object):
         L.check(L.lib().dctr_embed_ids(None, plan.units_ptr(), len(plan.units), ctypes.c_void_p(X.data_ptr()),
                                        X.stride(0), B, ctypes.c_void_p(ids_t.data_ptr()), None,
                                        L.stream_handle(X.device)), "dctr_embed_ids")
-        self._call(L.lib().dctr_lazy_catchup, "dctr_lazy_catchup", ctypes.c_void_p(ids_t.data_ptr()), B)
+        if self.sweep_k > 0 and self.replays:
+            self._call(L.lib().dctr_lazy_sweep, "dctr_lazy_sweep", int(plan.max_vocab), self.sweep_k)
+        # without the sweep rows sleep geometrically long: scratch for the entries' order by gap (rows that slept equally
+        # long are then replayed side by side); with it no gap exceeds K and the ordering pass costs more than it saves
+        order = torch.empty((len(plan.units), B), dtype=torch.int32, device=X.device) \
+            if (self.sweep_k <= 0 and self.replays) else None
+        self._call(L.lib().dctr_lazy_catchup, "dctr_lazy_catchup", ctypes.c_void_p(ids_t.data_ptr()), B,
+                   tail=(ctypes.c_void_p(order.data_ptr()) if order is not None else None,))
         return ids_t
 
     def apply(self, ids_t):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 21
+#define DCTR_ABI_VERSION 22
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -387,15 +387,38 @@ typedef struct dctr_lazy_unit {
 typedef struct dctr_lazy_opt {
   int32_t kind; /* DCTR_LAZY_* */
   float lr, eps, beta1, beta2;
+  /* Adam only, optional (NULL: the kernels compute the scalars themselves, in double, per step and lane): DEVICE tables of
+   * the step-dependent scalars torch.optim.Adam computes on the host (adam.py: bias_correction = 1 - beta ** step),
+   *   adam_ss[T - 1] = (float)(lr / (1 - beta1^T))     adam_bc[T - 1] = (float)sqrt(1 - beta2^T)      T = 1 .. n
+   * each long enough that its last entry is the limit (1 - beta^T == 1 in double: 349 / 36 708 steps at the default
+   * betas): steps past the end read the last entry.  A row that slept k steps replays k optimizer steps in its catch-up:
+   * the tables take two double multiplies, a division and a square root per replayed step and lane out of that loop.   */
+  int32_t n_ss, n_bc;
+  int32_t any_l2; /* some unit carries an L2 term (SGD / Adagrad rows then move between two touches: the catch-up has steps
+                     to replay and orders its entries by gap) */
+  const float* adam_ss;
+  const float* adam_bc;
 } dctr_lazy_opt_t;
 size_t dctr_sizeof_lazy_unit(void);
+size_t dctr_sizeof_lazy_opt(void);
+/* order_ws (nullable): n_units * B ints of scratch -- with it the catch-up first deals every unit's entries by the number of
+ * steps their rows slept (one launch, a counting sort per unit), so that the rows one wavefront replays side by side need
+ * about the same number of steps: geometric gaps otherwise leave a wave waiting for its longest row (3.4 x the mean of 16). */
 int dctr_lazy_catchup(const dctr_lazy_unit_t* units, int32_t n_units, const int32_t* ids_t, int32_t B,
                       const int32_t* step, const dctr_lazy_opt_t* opt, int32_t vec, int32_t max_dim,
-                      dctr_stream_t stream);
+                      int32_t* order_ws, dctr_stream_t stream);
 int dctr_lazy_apply(const dctr_lazy_unit_t* units, int32_t n_units, const int32_t* ids_t, int32_t B,
                     const int32_t* step, const dctr_lazy_opt_t* opt, int32_t vec, int32_t max_dim,
                     dctr_stream_t stream);
 int dctr_lazy_flush(const dctr_lazy_unit_t* units, int32_t n_units, int64_t max_vocab, const int32_t* step,
+                    const dctr_lazy_opt_t* opt, int32_t vec, int32_t max_dim, dctr_stream_t stream);
+/* dctr_lazy_sweep: bring the (*step mod K)-th of K windows of every table's rows ([w * ceil(vocab / K), ...)) to the current
+ * step -- the flush of one K-th of the rows, called once per train step in front of the catch-up.  No row then sleeps
+ * longer than K steps: a row's replay is a sequential loop over its missed steps, so without the sweep a rarely drawn id
+ * stalls the step it finally appears in for its whole history (one lane group, gap x ~0.5 us), and a flush after N steps
+ * pays N steps for every row nobody drew.  The arithmetic is the same and each (row, step) is still applied exactly once,
+ * in order: results are unchanged.  The window follows the device-side step counter: replayable from a hipGraph.           */
+int dctr_lazy_sweep(const dctr_lazy_unit_t* units, int32_t n_units, int64_t max_vocab, int32_t K, const int32_t* step,
                     const dctr_lazy_opt_t* opt, int32_t vec, int32_t max_dim, dctr_stream_t stream);
 int dctr_lazy_step_inc(int32_t* step, dctr_stream_t stream);
 /* The same optimizer step (number *step + 1) over a flat dense slab with an optional per-element lambda

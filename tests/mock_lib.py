@@ -600,6 +600,10 @@ class _Core(object):
     # ---- exact lazy regularised / Adam update (csrc/lazy.hip) -------------------------------------------------
     @staticmethod
     def _adam_scalars(o, T):
+        if o.adam_ss and o.adam_bc:       # the host's tables (dctr_lazy_opt_t): entry T - 1, the last entry past the end
+            ss = _arr(ctypes.c_void_p(o.adam_ss), (o.n_ss,))
+            bc = _arr(ctypes.c_void_p(o.adam_bc), (o.n_bc,))
+            return ss[min(T, o.n_ss) - 1], bc[min(T, o.n_bc) - 1]
         return (np.float32(float(o.lr) / (1.0 - float(o.beta1) ** T)), np.float32(np.sqrt(1.0 - float(o.beta2) ** T)))
 
     @staticmethod
@@ -621,7 +625,7 @@ class _Core(object):
         else:
             w -= f(o.lr) * g
 
-    def _lazy_pass(self, mode, units, n_units, ids_t, n, step, optref):
+    def _lazy_pass(self, mode, units, n_units, ids_t, n, step, optref, sweep_k=0):
         from deepctr_torch._hip import lib as L
         o = optref._obj
         t = int(_arr(step, (1,), dtype=np.int32)[0])
@@ -631,7 +635,10 @@ class _Core(object):
         for u in range(n_units):
             un = arr[u]
             stamp = _arr(un.stamp, (un.vocab,), dtype=np.int32)
-            if mode == 2:
+            if mode == 2 and sweep_k > 0:       # dctr_lazy_sweep: the (t mod K)-th of K windows of this table's rows
+                wlen = (un.vocab + sweep_k - 1) // sweep_k
+                rows = np.arange((t % sweep_k) * wlen, min((t % sweep_k + 1) * wlen, un.vocab))
+            elif mode == 2:
                 rows = np.arange(min(n, un.vocab))
             else:
                 rows = np.unique(np.where((ids[u] < 0) | (ids[u] >= un.vocab), 0, ids[u]).astype(np.int64))
@@ -672,7 +679,7 @@ class _Core(object):
                     Bv[rows] = b
         return 0
 
-    def dctr_lazy_catchup(self, units, n_units, ids_t, B, step, opt, vec, max_dim, stream):
+    def dctr_lazy_catchup(self, units, n_units, ids_t, B, step, opt, vec, max_dim, order_ws, stream):
         self.calls.append("lazy_catchup")
         return self._lazy_pass(0, units, n_units, ids_t, B, step, opt)
 
@@ -683,6 +690,10 @@ class _Core(object):
     def dctr_lazy_flush(self, units, n_units, max_vocab, step, opt, vec, max_dim, stream):
         self.calls.append("lazy_flush")
         return self._lazy_pass(2, units, n_units, None, max_vocab, step, opt)
+
+    def dctr_lazy_sweep(self, units, n_units, max_vocab, K, step, opt, vec, max_dim, stream):
+        self.calls.append("lazy_sweep")
+        return self._lazy_pass(2, units, n_units, None, max_vocab, step, opt, sweep_k=int(K))
 
     def dctr_lazy_step_inc(self, step, stream):
         _arr(step, (1,), dtype=np.int32)[0] += 1

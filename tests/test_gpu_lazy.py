@@ -162,6 +162,46 @@ def test_lazy_long_gaps_equal_dense_path(opt, monkeypatch):
         _close(k, finals[0][k].cpu().numpy(), finals[1][k].cpu().numpy(), tol=tol)
 
 
+@pytest.mark.parametrize("opt,sweep_k", [("adam", "256"), ("adam", "7"), ("adam", "0"), ("adagrad", "7"), ("sgd", "5")])
+def test_ordered_catchup_and_sweep_equal_dense_path(opt, sweep_k, monkeypatch):
+    """Batches of 256 over 20 000-row vocabularies (mean gap ~80 steps): large enough that the catch-up deals its entries by
+    gap (k_lazy_order, B >= 64) and that the whole wave walks the steps together (replay_in_step); the per-step sweep with
+    the default K, with a K the run wraps around many times, and without.  Every (row, step) must be applied exactly once,
+    in order, whoever applies it -- sweep, catch-up or the final flush: the exact dense path's parameters."""
+    from deepctr_torch.inputs import DenseFeat, SparseFeat
+    from deepctr_torch.models import DeepFM
+    gen = torch.Generator().manual_seed(5)
+    V, B, steps = 20000, 256, 60
+    cols = [SparseFeat("a", V, 16), SparseFeat("b", V // 3, 16), SparseFeat("c", 50, 16), DenseFeat("d", 2)]
+    X = torch.cat([torch.randint(0, V, (steps * B, 1), generator=gen).float(),
+                   torch.randint(0, V // 3, (steps * B, 1), generator=gen).float(),
+                   torch.randint(0, 50, (steps * B, 1), generator=gen).float(), torch.rand(steps * B, 2, generator=gen)], 1)
+    y = torch.randint(0, 2, (steps * B,), generator=gen).float()
+    X, y = X.to(DEV), y.to(DEV)
+    finals = []
+    for lazy in ("1", "0"):
+        monkeypatch.setenv("DCTR_LAZY_UPDATE", lazy)
+        monkeypatch.setenv("DCTR_LAZY_SWEEP_K", sweep_k)
+        m = DeepFM(cols, cols, dnn_hidden_units=(16,), l2_reg_embedding=1e-3, l2_reg_linear=1e-3, init_std=0.1, seed=7,
+                   device=DEV)
+        m.compile(opt, "binary_crossentropy", metrics=[])
+        m.train()
+        assert m.model_plan().update[0] == ("lazy" if lazy == "1" else "dense")
+        for i in range(steps):
+            m._train_step(X[i * B:(i + 1) * B], y[i * B:(i + 1) * B])
+            if lazy == "1" and i == steps // 2:
+                m.state_dict()                      # a flush in the middle: the sweep goes on from wherever the counter is
+        if lazy == "1":
+            lz = m.model_plan().lazy
+            assert lz.sweep_k == int(sweep_k)
+            if int(sweep_k) > 0 and int(sweep_k) <= steps:      # every window came by: no row is more than K steps behind
+                t = int(lz.step.item())
+                assert all(int((t - st).max().item()) <= int(sweep_k) for st in lz.stamps)
+        finals.append({k: v.clone() for k, v in m.state_dict().items()})
+    for k in finals[0]:
+        _close(k, finals[0][k].cpu().numpy(), finals[1][k].cpu().numpy(), tol=1e-4)
+
+
 @pytest.mark.parametrize("name,opt", [("lazy_deepfm", "adam"), ("lazy_deepfm", "adagrad"), ("lazy_dcn", "adagrad")])
 def test_fit_graph_replays_leave_tables_flushed(monkeypatch, name, opt):
     """Every batch full-size (sample_num % batch_size == 0) over 3 epochs: after the first epoch all train steps are
