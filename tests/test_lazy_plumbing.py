@@ -119,3 +119,41 @@ def test_tables_are_current_when_callbacks_and_fit_return(mock, monkeypatch):
     # 8 unshuffled batches of 24 = the fixture's 8 steps, twice: after the first epoch the tables equal the reference's
     w = m.embedding_dict[g["spec"]["dnn_columns"][0]["embedding_name"]].weight.detach().clone()
     assert torch.equal(w, m.state_dict()["embedding_dict.%s.weight" % g["spec"]["dnn_columns"][0]["embedding_name"]])
+
+
+def test_adam_tables_are_torchs_own_scalars():
+    """LazyState.adam_tables: entry T - 1 = what torch.optim.Adam computes on the host at step T (adam.py: bias_correction =
+    1 - beta ** step in double; step_size = lr / bias_correction1; sqrt(bias_correction2)), rounded to float32 once; the
+    last entries are the limits (lr and 1) so that steps past the end may read them; a beta too close to 1 gets no table."""
+    import math
+    from deepctr_torch._hip.plan import LazyState
+    lr, b1, b2 = 1e-3, 0.9, 0.999
+    ss, bc = LazyState.adam_tables(lr, b1, b2)
+    assert ss.dtype == np.float32 and bc.dtype == np.float32
+    for T in (1, 2, 3, 10, 100, 349, 1000, 20000, len(bc)):
+        if T <= len(ss):
+            assert ss[T - 1] == np.float32(lr / (1.0 - b1 ** T)), T
+        assert bc[T - 1] == np.float32(math.sqrt(1.0 - b2 ** T)), T
+    assert 1.0 - b1 ** len(ss) == 1.0 and ss[-1] == np.float32(lr)
+    assert 1.0 - b2 ** len(bc) == 1.0 and bc[-1] == np.float32(1.0)
+    assert 340 < len(ss) < 400 and 36000 < len(bc) < 40000
+    assert LazyState.adam_tables(lr, 0.0, 0.999)[0].tolist() == [np.float32(lr)]
+    assert LazyState.adam_tables(lr, 0.9, 0.9999999) is None          # 370 M entries: computed in the kernel instead
+    assert LazyState.adam_tables(lr, 0.9, 1.0) is None
+
+
+@pytest.mark.parametrize("sweep_k", ["0", "3", "32"])
+def test_sweep_changes_who_pays_not_what(mock, monkeypatch, sweep_k):
+    """The per-step sweep (dctr_lazy_sweep: one K-th of every table brought to the current step in front of the catch-up)
+    only moves work between the sweep, the catch-up and the flush: the same reference trajectory with K = 3 (the windows
+    come by many times), the default and without."""
+    monkeypatch.setenv("DCTR_LAZY_SWEEP_K", sweep_k)
+    g, m, bce, tot = _run("lazy_deepfm", "adam")
+    ex = g["extra"]
+    assert ("lazy_sweep" in mock.calls) == (sweep_k != "0")
+    np.testing.assert_allclose(bce, ex["lazy_adam_bce"], rtol=5e-5)
+    sd = m.state_dict()
+    for k, v in ex.items():
+        if k.startswith("lazy_adam/"):
+            ref = np.asarray(v)
+            assert max_abs(sd[k[len("lazy_adam/"):]].numpy(), ref) <= 2e-5 * max(1.0, float(np.abs(ref).max())), k
