@@ -1,4 +1,4 @@
-// lazy.hip -- the reference's REGULARISED / ADAM embedding update in O(batch), exactly (gfx950).
+// lazy.hip -- the reference's REGULARISED / ADAM embedding update without its O(vocabulary) memory traffic (gfx950).
 //
 // With l2_reg_embedding / l2_reg_linear > 0 (the reference's defaults, basemodel.py:100-102,412-428) or with
 // torch.optim.Adam (the examples' optimizer, basemodel.py:447-461) EVERY row of every table moves at every step:
@@ -6,18 +6,24 @@
 // gradient is zero.  The reference pays O(vocabulary) for that (442 M parameters at the Criteo shape: 7 ms / step
 // even on this GPU).  But a row's trajectory between two batches that touch it depends on nothing but the row
 // itself:   g_t = 2*lambda*w_t ;  (w, state)_{t+1} = opt_step(w_t, state_t, g_t, t+1)
-// so it can be replayed LAZILY, bit-for-bit the same recurrence, the next time the row is needed:
+// so it can be replayed LAZILY -- the same recurrence, step by step, in fp32 -- the next time the row is needed:
 //   stamp[row] = number of optimizer steps already applied to the row;  *step = steps completed so far (t)
 //   k_lazy_catchup  (before the gather of a train step, on the batch's ids): the lane group that wins
 //                   atomicMax(stamp[row], t) replays the missed steps stamp..t-1 with g = 2*lambda*w -> the gather
-//                   reads exactly the reference's w_t;
+//                   reads the reference's w_t;
 //   dctr_embed_update(OPT_ACCUM) (csrc/update.hip, deterministic, no atomics): gacc[row] = sum of the batch's data
 //                   gradients of the row;
 //   k_lazy_apply    (after the backward): the group that wins atomicMax(stamp[row], t+1) applies step t+1 with
 //                   g = gacc[row] + 2*lambda*w and zeroes gacc[row];
-//   k_lazy_flush    (before anything else reads the tables: predict / evaluate / state_dict): replays every row to t.
-// Cost per step: O(batch * mean gap) optimizer steps (gap = V / B ~ 244 at the Criteo shape: ~0.1 ms of VALU work)
-// instead of O(V) memory traffic.  Deterministic: whichever duplicate wins a row computes the same thing.
+//   k_lazy_flush    (before anything else reads the tables: predict / evaluate / state_dict): replays every row to t;
+//   dctr_lazy_sweep (round 5; in front of every catch-up): the flush of the (t mod K)-th of K windows of rows -- no row
+//                   sleeps longer than K steps (a replay is a sequential chain: a batch's longest sleeper used to set the
+//                   launch's time, and rows nobody drew left their whole history to the next flush).
+// The arithmetic owed stays what the reference does -- one optimizer step per row per step, ~0.3 ms of VALU work at the
+// Criteo shape -- but not its 10.6 GB of row traffic.  Deterministic: whichever duplicate wins a row computes the same
+// thing, and each (row, step) is applied exactly once, in order, whoever applies it.  The replayed (zero-data-gradient)
+// steps divide by reciprocal + one Newton correction (div_nr / sqrt_nr below: within 1 ulp of the IEEE operations the
+// reference's device kernels use); the step that carries a data gradient uses the IEEE operations.
 //
 // Optimizer arithmetic = torch.optim's (single-tensor formulas, fp32; the step-dependent scalars in double like
 // torch computes them on the host):

@@ -91,7 +91,7 @@ def _fields_for(columns, tables, feature_index, unpooled):
 
 
 class LazyState(object):
-    """Host side of csrc/lazy.hip: the reference's regularised / Adam table update replayed lazily, exactly.
+    """Host side of csrc/lazy.hip: the reference's regularised / Adam table update replayed lazily, step by step.
 
     ``l2`` maps a table parameter to its lambda (0 when unregularised), ``s1`` / ``s2`` to its optimizer state
     tensors (Adagrad ``sum`` | RMSprop ``square_avg`` | Adam ``exp_avg``, Adam ``exp_avg_sq``).  Owns the per-unit stamps, the device step

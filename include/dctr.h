@@ -347,15 +347,15 @@ int dctr_interacting_bwd(const float* E, int64_t ld_e, int32_t B, int32_t F, int
                          int64_t ld_g, float* gE, int64_t ld_ge, float* gWq, float* gWk, float* gWv, float* gWr,
                          float* workspace, dctr_stream_t stream);
 
-/* ---- exact lazy regularised / Adam embedding update (csrc/lazy.hip) ------------------------------------------
- * Replaces, in O(batch) per step, what the reference does in O(vocabulary) whenever every row of a table moves at
+/* ---- lazy regularised / Adam embedding update (csrc/lazy.hip) -------------------------------------------------
+ * Replaces, without the O(vocabulary) memory traffic, what the reference does whenever every row of a table moves at
  * every step: the dense L2 gradient 2*lambda*w of get_regularization_loss (basemodel.py:412-428; l2_reg_embedding /
  * l2_reg_linear default to 1e-5) and torch.optim.Adam's moment-driven updates of untouched rows
  * (basemodel.py:447-461).  A row's trajectory between two batches that touch it depends on the row alone, so it is
  * replayed -- the same recurrence, step by step -- when the row is next needed.  One "unit" = one id column of X with
  * the deep and / or wide table it feeds (as in dctr_embed_update); `stamp[row]` = optimizer steps already applied
  * to the row, `*step` (device) = steps completed so far.  Per train step the caller enqueues
- *   dctr_embed_ids -> dctr_lazy_catchup -> dctr_embed_fwd -> ... -> dctr_embed_update(DCTR_UPD_ACCUM)
+ *   dctr_embed_ids -> [dctr_lazy_sweep ->] dctr_lazy_catchup -> dctr_embed_fwd -> ... -> dctr_embed_update(DCTR_UPD_ACCUM)
  *   -> dctr_lazy_apply -> dctr_lazy_step_inc,
  * and dctr_lazy_flush before anything else reads the tables (predict / evaluate / state_dict).
  *   *_s1  Adagrad `sum` | Adam `exp_avg`     *_s2  Adam `exp_avg_sq`     *_g  gradient slab, zero at rest
