@@ -77,6 +77,11 @@ __device__ __forceinline__ void adam_tab(const OptConst& o, int T, float& ss, fl
   ss = ldg_f32(o.adam_ss + ((T < o.n_ss ? T : o.n_ss) - 1));
   bc = ldg_f32(o.adam_bc + ((T < o.n_bc ? T : o.n_bc) - 1));
 }
+// the same for a wave-uniform T: plain loads the compiler can issue on the scalar unit (no per-lane address arithmetic)
+__device__ __forceinline__ void adam_tab_uniform(const OptConst& o, int T, float& ss, float& bc) {
+  ss = o.adam_ss[(T < o.n_ss ? T : o.n_ss) - 1];
+  bc = o.adam_bc[(T < o.n_bc ? T : o.n_bc) - 1];
+}
 __device__ __forceinline__ void adam_scalars(const OptConst& o, int T, float& ss, float& bc) {
   if (o.adam_ss) {
     adam_tab(o, T, ss, bc);
@@ -101,10 +106,11 @@ __device__ __forceinline__ float div_nr(float a, float d, float rd) {   // rd = 
   return fmaf(fmaf(-q, d, a), rd, q);
 }
 __device__ __forceinline__ float sqrt_nr(float x) {
-  const float r = __builtin_amdgcn_rsqf(x);
+  // (a moment is never negative; rsq of the clamped value keeps x = 0 at exactly 0 -- 0 * finite -- without a select.  A
+  // moment below the smallest normal number comes out smaller than its root: it is added to eps = 1e-8 either way)
+  const float r = __builtin_amdgcn_rsqf(fmaxf(x, 1.17549435e-38f));
   const float s = x * r;
-  const float t = fmaf(fmaf(-s, s, x), 0.5f * r, s);
-  return x > 0.f ? t : 0.f;        // (rsq(0) = inf; a moment is never negative)
+  return fmaf(fmaf(-s, s, x), 0.5f * r, s);
 }
 
 // one optimizer step on one element.  a = Adagrad sum | Adam exp_avg, b = Adam exp_avg_sq.  FAST: the replay loop's
@@ -166,10 +172,10 @@ __device__ __forceinline__ void replay_in_step(const OptConst& o, float lam2d, f
   from_min = __builtin_amdgcn_readfirstlane(from_min);
   if (from_min >= to) return;
   float ss, bc;
-  adam_tab(o, from_min + 1, ss, bc);
+  adam_tab_uniform(o, from_min + 1, ss, bc);
   for (int T = from_min + 1; T <= to; ++T) {
     float ssn, bcn;
-    adam_tab(o, T + 1, ssn, bcn);       // (the next step's pair is in flight while this step computes; clamped: valid)
+    adam_tab_uniform(o, T + 1, ssn, bcn);       // (the next step's pair is in flight while this step computes; clamped: valid)
     if (T > from) {
       const float rbc = __builtin_amdgcn_rcpf(bc);
       if (deep_on) {
