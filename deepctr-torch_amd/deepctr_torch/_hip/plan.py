@@ -125,6 +125,7 @@ class LazyState(object):
         # every train step also brings one K-th of every table to the current step (dctr_lazy_sweep): no row sleeps longer
         # than K steps (0: off -- rows pay their whole history when they are next drawn or at the next flush)
         self.sweep_k = int(os.environ.get("DCTR_LAZY_SWEEP_K", "32"))
+        self._sweep_side = None   # the side stream a sweep was forked on and not yet joined (see _fork_sweep)
         self.vec = 4 if plan.vec == 4 else 1
         self.max_dim = max(plan.max_dim, 1)
         self.n_elems = sum(p.numel() for p in plan.table_params)
@@ -247,20 +248,43 @@ class LazyState(object):
         L.check(L.lib().dctr_embed_ids(None, plan.units_ptr(), len(plan.units), ctypes.c_void_p(X.data_ptr()),
                                        X.stride(0), B, ctypes.c_void_p(ids_t.data_ptr()), None,
                                        L.stream_handle(X.device)), "dctr_embed_ids")
-        if self.sweep_k > 0 and self.replays:
-            self._call(L.lib().dctr_lazy_sweep, "dctr_lazy_sweep", int(plan.max_vocab), self.sweep_k)
+        self._join_sweep()
         # without the sweep rows sleep geometrically long: scratch for the entries' order by gap (rows that slept equally
         # long are then replayed side by side); with it no gap exceeds K and the ordering pass costs more than it saves
         order = torch.empty((len(plan.units), B), dtype=torch.int32, device=X.device) \
             if (self.sweep_k <= 0 and self.replays) else None
         self._call(L.lib().dctr_lazy_catchup, "dctr_lazy_catchup", ctypes.c_void_p(ids_t.data_ptr()), B,
                    tail=(ctypes.c_void_p(order.data_ptr()) if order is not None else None,))
+        if self.sweep_k > 0 and self.replays:
+            self._fork_sweep(X.device)
         return ids_t
+
+    def _fork_sweep(self, device):
+        """The sweep of this step's window, BESIDE the rest of the step: it starts behind the catch-up (the batch's rows then
+        carry the current stamp, and the sweep leaves rows at the current stamp alone), runs on its own stream while the
+        gather, the tower, the update and the data-gradient step run on the caller's, and is joined before the step counter
+        moves (apply) -- nothing in between writes a row the sweep writes: those passes touch the batch's rows only.
+        DCTR_LAZY_SWEEP_ASYNC=0 (and CPU stand-in runs): in line."""
+        dev = torch.device(device)
+        if dev.type != "cuda" or os.environ.get("DCTR_LAZY_SWEEP_ASYNC", "1") == "0":
+            self._call(L.lib().dctr_lazy_sweep, "dctr_lazy_sweep", int(self.plan.max_vocab), self.sweep_k)
+            return
+        side = _streams.side_stream(dev, "sweep")
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self._call(L.lib().dctr_lazy_sweep, "dctr_lazy_sweep", int(self.plan.max_vocab), self.sweep_k)
+        self._sweep_side = side
+
+    def _join_sweep(self):
+        side, self._sweep_side = self._sweep_side, None
+        if side is not None:
+            torch.cuda.current_stream(side.device).wait_stream(side)
 
     def apply(self, ids_t):
         """After dctr_embed_update(ACCUM): step t+1 on the batch's rows, then t += 1."""
         self._ensure(ids_t.device)
         self._call(L.lib().dctr_lazy_apply, "dctr_lazy_apply", ctypes.c_void_p(ids_t.data_ptr()), ids_t.shape[1])
+        self._join_sweep()          # (the sweep reads the step counter: it must be done before the counter moves)
         L.check(L.lib().dctr_lazy_step_inc(ctypes.c_void_p(self.step.data_ptr()), L.stream_handle(ids_t.device)),
                 "dctr_lazy_step_inc")
         self.mark_dirty()
@@ -272,6 +296,7 @@ class LazyState(object):
 
     def flush(self, device=None):
         """Bring EVERY row to the current step (before predict / evaluate / state_dict read the tables)."""
+        self._join_sweep()
         if not self.dirty or self.step is None:
             return
         self._ensure(self.step.device)

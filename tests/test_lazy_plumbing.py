@@ -48,15 +48,15 @@ def test_lazy_stack_replays_reference_trajectory(mock, name, tag):
     g, m, bce, tot = _run(name, tag)
     ex = g["extra"]
     if name == "lazy_deepfm":
-        # one fused step = ids, the sweep of one K-th of the rows, catch-up, gather (+ the segment pre-pass of the update,
+        # one fused step = ids, catch-up, the sweep of one K-th of the rows (beside the rest of the step on the GPU), gather (+ the segment pre-pass of the update,
         # right behind it), tower step, accumulate, apply, dense optimizer -- in this order
         first = mock.calls[:mock.calls.index("dense_opt_reg") + 1]
-        assert first == ["embed_ids", "lazy_sweep", "lazy_catchup", "embed_fwd", "embed_segments", "mlp_train_step",
+        assert first == ["embed_ids", "lazy_catchup", "lazy_sweep", "embed_fwd", "embed_segments", "mlp_train_step",
                          "embed_update:2", "lazy_apply", "dense_opt_reg"], first
     else:
         # DCN is outside the fused step: autograd + torch.optim around the kernels, the tables still lazily
         i0 = mock.calls.index("lazy_apply")
-        assert mock.calls[:4] == ["embed_ids", "lazy_sweep", "lazy_catchup", "embed_fwd"] and \
+        assert mock.calls[:4] == ["embed_ids", "lazy_catchup", "lazy_sweep", "embed_fwd"] and \
             "embed_update:2" in mock.calls[:i0]
     np.testing.assert_allclose(bce, ex["lazy_%s_bce" % tag], rtol=5e-5)
     np.testing.assert_allclose(tot, ex["lazy_%s_total" % tag], rtol=5e-5)
