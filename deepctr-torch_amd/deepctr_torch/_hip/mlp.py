@@ -13,6 +13,7 @@ Gradients take one of two routes:
 import ctypes
 
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -212,10 +213,19 @@ class _TunedGemm(object):
     wide layer's BACKWARD: the library's default picks for [4096 x 128] x [128 x 10 413] and [128 x 4096] x [4096 x 10 413]
     run at 70-83 TFLOP/s, the tuned ones at ~105 (profiles/r04_fibinet_tunableop.txt).  Scoped: the process-wide switches are restored on exit; nothing is
     written to the working directory (the picks go to a file in the temp directory unless the user named one); inside a hipGraph capture only cached picks are used
-    (a search launches and times kernels)."""
+    (a search launches and times kernels).
+
+    What it costs (round-4 advisor): the switches are PROCESS-wide -- a GEMM another thread issues while this block is open is
+    tuned too, and two threads opening it would restore each other's state, hence the lock held for the block's duration --
+    and the search is timing-based: two runs may settle on different solutions for the two backward GEMMs, i.e. different
+    summation orders in the last bits of FiBiNET-sized layers' gradients (every other kernel of this package has a fixed
+    order).  ``DCTR_TUNABLE_GEMM=0`` keeps the library's default picks: run-to-run identical bits, ~5 % slower FiBiNET
+    steps; ``PYTORCH_TUNABLEOP_FILENAME`` pins the picks of an earlier run."""
     named = False
+    _lock = threading.RLock()
 
     def __enter__(self):
+        _TunedGemm._lock.acquire()
         t = torch.cuda.tunable
         self.prev = (t.is_enabled(), t.tuning_is_enabled())
         if os.environ.get("DCTR_TUNABLE_GEMM", "1") == "0":
@@ -230,9 +240,12 @@ class _TunedGemm(object):
         return self
 
     def __exit__(self, *exc):
-        t = torch.cuda.tunable
-        t.tuning_enable(self.prev[1])
-        t.enable(self.prev[0])
+        try:
+            t = torch.cuda.tunable
+            t.tuning_enable(self.prev[1])
+            t.enable(self.prev[0])
+        finally:
+            _TunedGemm._lock.release()
         return False
 
 
