@@ -173,16 +173,38 @@ inline DenseStepDev dense_step_dev(const dctr_dense_step_t* s) {
   d.state_base = s ? s->state_base : nullptr;
   return d;
 }
+// The dense optimizers' arithmetic, ONE definition for every kernel that steps a dense parameter (k_mlp_reduce, the reduction
+// folded into k_mlp_wgrad, k_sum_ranks, the update kernel's Linear.weight role, ...): products and sums rounded separately, in
+// the order of the reference's formulas (torch.optim.Adagrad: s += g * g; p -= lr * g / (sqrt(s) + eps); SGD: p -= lr * g).
+// Contraction is switched off on purpose: left to the compiler, `w - lr * q` became v_fma in one copy of this code and
+// v_mul + v_sub in the next (even between the four elements of one thread: round 6, ISA of k_mlp_reduce), so two kernels
+// that must agree bit for bit -- the engine's folded reduction and the separate launch -- did not.
+__device__ __forceinline__ float adagrad_sum(float st, float g) {
+#pragma clang fp contract(off)
+  const float gg = g * g;
+  return st + gg;
+}
+__device__ __forceinline__ float adagrad_param(float w, float g, float sn, float lr, float eps) {
+#pragma clang fp contract(off)
+  const float q = g / (sqrtf(sn) + eps);
+  const float d = lr * q;
+  return w - d;
+}
+__device__ __forceinline__ float sgd_param(float w, float g, float lr) {
+#pragma clang fp contract(off)
+  const float d = lr * g;
+  return w - d;
+}
 __device__ __forceinline__ void dense_step_apply(const DenseStepDev& S, const float* gptr, float g) {
   if (S.kind < 0) return;
   const int64_t k = gptr - S.grad_base;
   float w = ldg_f32(S.param_base + k);
   if (S.kind == DCTR_UPD_ADAGRAD) {   // torch.optim.Adagrad: s += g*g ; p -= lr * g / (sqrt(s) + eps)
-    const float st = ldg_f32(S.state_base + k) + g * g;
+    const float st = adagrad_sum(ldg_f32(S.state_base + k), g);
     stg_f32(S.state_base + k, st);
-    w -= S.lr * (g / (sqrtf(st) + S.eps));
+    w = adagrad_param(w, g, st, S.lr, S.eps);
   } else {                            // torch.optim.SGD
-    w -= S.lr * g;
+    w = sgd_param(w, g, S.lr);
   }
   stg_f32(S.param_base + k, w);
 }

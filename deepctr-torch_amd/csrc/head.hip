@@ -73,13 +73,13 @@ __global__ __launch_bounds__(256) void k_dense_opt(float* __restrict__ p, const 
       f32x4 sv = *(const DCTR_GLOBAL f32x4*)(st + 4 * i);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        sv[k] = sv[k] + gv[k] * gv[k];
-        pv[k] = pv[k] - lr * (gv[k] / (sqrtf(sv[k]) + eps));
+        sv[k] = adagrad_sum(sv[k], gv[k]);      // (common.hpp: the one definition of the dense optimizers' arithmetic)
+        pv[k] = adagrad_param(pv[k], gv[k], sv[k], lr, eps);
       }
       *(DCTR_GLOBAL f32x4*)(st + 4 * i) = sv;
     } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) pv[k] = pv[k] - lr * gv[k];
+      for (int k = 0; k < 4; ++k) pv[k] = sgd_param(pv[k], gv[k], lr);
     }
     *(DCTR_GLOBAL f32x4*)(p + 4 * i) = pv;
   } else {
@@ -88,11 +88,11 @@ __global__ __launch_bounds__(256) void k_dense_opt(float* __restrict__ p, const 
       const float gv = ldg_f32(g + j);
       float pv = ldg_f32(p + j);
       if (OPT == DCTR_UPD_ADAGRAD) {
-        const float sv = ldg_f32(st + j) + gv * gv;
+        const float sv = adagrad_sum(ldg_f32(st + j), gv);
         stg_f32(st + j, sv);
-        pv = pv - lr * (gv / (sqrtf(sv) + eps));
+        pv = adagrad_param(pv, gv, sv, lr, eps);
       } else {
-        pv = pv - lr * gv;
+        pv = sgd_param(pv, gv, lr);
       }
       stg_f32(p + j, pv);
     }
@@ -142,13 +142,13 @@ __global__ __launch_bounds__(256) void k_dense_opt_multi(MultiArgs A) {
         f32x4 sv = *(const DCTR_GLOBAL f32x4*)(st + i);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          sv[k] = sv[k] + gv[k] * gv[k];
-          pv[k] = pv[k] - A.lr * (gv[k] / (sqrtf(sv[k]) + A.eps));
+          sv[k] = adagrad_sum(sv[k], gv[k]);
+          pv[k] = adagrad_param(pv[k], gv[k], sv[k], A.lr, A.eps);
         }
         *(DCTR_GLOBAL f32x4*)(st + i) = sv;
       } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pv[k] = pv[k] - A.lr * gv[k];
+        for (int k = 0; k < 4; ++k) pv[k] = sgd_param(pv[k], gv[k], A.lr);
       }
       *(DCTR_GLOBAL f32x4*)(p + i) = pv;
     } else {
@@ -157,11 +157,11 @@ __global__ __launch_bounds__(256) void k_dense_opt_multi(MultiArgs A) {
         float pv = ldg_f32(p + j);
         if (c2 != 0.f) gv = __fadd_rn(gv, __fmul_rn(c2, pv));
         if (OPT == DCTR_UPD_ADAGRAD) {
-          const float sv = ldg_f32(st + j) + gv * gv;
+          const float sv = adagrad_sum(ldg_f32(st + j), gv);
           stg_f32(st + j, sv);
-          pv = pv - A.lr * (gv / (sqrtf(sv) + A.eps));
+          pv = adagrad_param(pv, gv, sv, A.lr, A.eps);
         } else {
-          pv = pv - A.lr * gv;
+          pv = sgd_param(pv, gv, A.lr);
         }
         stg_f32(p + j, pv);
       }

@@ -81,6 +81,8 @@ struct MlpArgs {
   int rsd;           // LDS row stride of the backward-data pass
   int fast;          // 1: the tower fits the fast bodies (mlp_fwd_fast / mlp_bwd_fast)
   int32_t* sync;     // nullable: k_mlp_train signals DCTR_SYNC_TOWER when gx and g_logit have left the chip (dctr.h)
+  int wt;            // != 0: what the weight-gradient launch reads (h, dh, the gathered rows, g_logit, the head's partials) is
+                     // stored write-through (fast bodies only): that launch waits for DCTR_SYNC_T_GEN, not for this one's end
   uint32_t wmask;    // diagnostics: AND mask on the weight byte offsets (0xffffffff normally; DCTR_MLP_WMASK in the diag build
                      // folds the weight stream onto a few KB that stay in L1 -- timing experiment, wrong results)
   unsigned long long* trace;
@@ -130,6 +132,11 @@ struct GatherArgs {
   int64_t ld_am;
   const int32_t* am_deep_off;
   const int32_t* am_wide_off;
+  // round 6 (dctr_embed_tower_train_step_sync): the launch may START before the previous step's weight-gradient launch has
+  // stepped the dense parameters -- it gathers its rows first and waits here, in the kernel, until sync[DCTR_SYNC_W_GEN] has
+  // reached sync[DCTR_SYNC_T_GEN] (towers finished so far = weight steps that must have happened); NULL: no wait
+  int32_t* wsync;
+  unsigned long long wtimeout;   // s_memrealtime ticks (100 MHz)
 };
 
 
@@ -185,7 +192,7 @@ static unsigned long long* const g_mlp_trace = nullptr;
 // the fast bodies (defined behind the general ones)
 template <bool GATHER>
 __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* smem, float* logit_lds, const GatherArgs& G,
-                                                     float* p0s, float* p1s FT_ARG);
+                                                     float* p0s, float* p1s, const float* bias_p, float& h_bias FT_ARG);
 __device__ __forceinline__ void mlp_bwd_fast(const MlpArgs& A, float* smem, const float* g_lds, const float* hb0,
                                              const float* hb1, int rs_h FT_ARG);
 
@@ -437,10 +444,12 @@ __global__ __launch_bounds__(kT) void k_mlp_fwd(MlpArgs A) {
   extern __shared__ __align__(16) float smem[];
   FT_DECL;
 #ifdef DCTR_FAST_ONLY   // (ISA reading aid: compile the fast body alone)
-  mlp_fwd_fast<false>(A, smem, nullptr, GatherArgs{}, nullptr, nullptr FT_PASS);
+  float nb_ = 0.f;
+  mlp_fwd_fast<false>(A, smem, nullptr, GatherArgs{}, nullptr, nullptr, nullptr, nb_ FT_PASS);
 #else
   if (A.fast) {
-    mlp_fwd_fast<false>(A, smem, nullptr, GatherArgs{}, nullptr, nullptr FT_PASS);
+    float nb_ = 0.f;
+    mlp_fwd_fast<false>(A, smem, nullptr, GatherArgs{}, nullptr, nullptr, nullptr, nb_ FT_PASS);
     FT_FLUSH(A.trace);
   } else {
     mlp_fwd_body<false>(A, smem, nullptr);
@@ -666,7 +675,10 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpArgs& A, float* smem, cons
 // dwordx4 stores by all 512 threads: 32 threads cover 512 contiguous bytes of a row.  Called behind the barrier that
 // completes the tile.  (The epilogues used to store their accumulators themselves, one dword per lane and matrix row: 8
 // store instructions per wave that took ~3 us to ISSUE -- measured with a stamp behind them, round 3.)
-__device__ __forceinline__ void tile_store(const float* tile, int rs, float* dst, int64_t ld, int N, int b0, int B) {
+// (wt: write-through stores -- the reader is a kernel on ANOTHER queue that waits for a word in memory, not for this launch's
+// end: dctr_mlp_train_wgrad_sync behind dctr_embed_tower_train_step_sync)
+__device__ __forceinline__ void tile_store(const float* tile, int rs, float* dst, int64_t ld, int N, int b0, int B,
+                                           bool wt = false) {
   const int tid = threadIdx.x, r = tid >> 5, q0 = tid & 31;
   const int n4 = (N + 3) >> 2;
   if (b0 + r < B) {
@@ -674,7 +686,11 @@ __device__ __forceinline__ void tile_store(const float* tile, int rs, float* dst
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = q0 + 32 * i;
-      if (q < n4) *(DCTR_GLOBAL f32x4*)(drow + 4 * q) = *reinterpret_cast<const f32x4*>(tile + r * rs + 4 * q);
+      if (q < n4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * rs + 4 * q);
+        if (wt) stg_wt(drow + 4 * q, v);
+        else *(DCTR_GLOBAL f32x4*)(drow + 4 * q) = v;
+      }
     }
   }
 }
@@ -878,7 +894,7 @@ __device__ __forceinline__ GatherLds gather_lds(const GatherArgs& G, float* base
 
 template <bool GATHER>
 __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* smem, float* logit_lds, const GatherArgs& G,
-                                                     float* p0s, float* p1s FT_ARG) {
+                                                     float* p0s, float* p1s, const float* bias_p, float& h_bias FT_ARG) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * kTM;
   const int rsx = A.rsx, rsh = A.rsh;
@@ -1005,13 +1021,17 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
       pwv = ldg_f32(fw.table + (oob ? 0 : static_cast<int64_t>(rid)) * row_ld(fw));
       pwdst = tid | (((m || fw.pool == DCTR_POOL_MAX) && b0 + r < A.B) ? 0 : (1 << 30));
     }
-    fwd_bias_ld(A.L[0], wv, c, braw);
-    __builtin_amdgcn_sched_barrier(0);
-    fwd_fill(ring, A.L[0], K0p, wv, g, c, A.wmask);
-    if (A.w_out && (A.logit || logit_lds)) {
-      const int ntop = A.L[A.n_layers - 1].N;
+    // (G.wsync: the dense parameters may still be under the previous step's optimizer step -- nothing of them is requested
+    // before the wait below)
+    if (!G.wsync) {
+      fwd_bias_ld(A.L[0], wv, c, braw);
+      __builtin_amdgcn_sched_barrier(0);
+      fwd_fill(ring, A.L[0], K0p, wv, g, c, A.wmask);
+      if (A.w_out && (A.logit || logit_lds)) {
+        const int ntop = A.L[A.n_layers - 1].N;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wo_pre[i] = ldg_f32(A.w_out + ((lane + 64 * i) < ntop ? (lane + 64 * i) : ntop - 1));
+        for (int i = 0; i < 4; ++i) wo_pre[i] = ldg_f32(A.w_out + ((lane + 64 * i) < ntop ? (lane + 64 * i) : ntop - 1));
+      }
     }
     // the dense block of combined_dnn_input (inputs.py:126-138): scalars of the X tile, LDS to LDS
     for (int e = tid; e < kTM * G.n_dense; e += kT) {
@@ -1032,7 +1052,39 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
     }
     if (pwdst >= 0) S.pw[pwdst & ~(1 << 30)] = (pwdst >> 30) ? 0.f : pwv;
     if (bad && G.err) atomicOr(G.err, 1);
-    __syncthreads();
+    if (G.wsync) {
+      // ---- the rows are here; now the weights must be: ONE wave polls the generation word (relaxed, past the L1), everybody
+      // meets at the barrier, then the bias, the first weight ring and the projection are requested -- what the launch does
+      // right behind its row loads when it has nothing to wait for.  No acquire fence: this launch has not read a dense
+      // parameter yet (its start invalidated the L1), the reducers never leave one in an L1 (sc1 loads, write-through
+      // stores), and lines of ordinary device memory are never stale in an L2 (memory probes).  A wait that runs out raises
+      // bit 2 of the plan's error word and goes on: wrong numbers and a raised flag, not a hang.
+      if (wv == 0) {
+        const int32_t want = __hip_atomic_load(G.wsync + DCTR_SYNC_T_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = wall_clock64();
+        for (;;) {
+          const int32_t have = __hip_atomic_load(G.wsync + DCTR_SYNC_W_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (have - want >= 0) break;
+          if (wall_clock64() - t0 > G.wtimeout) {
+            if (lane == 0 && G.err) atomicOr(G.err, 4);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      __syncthreads();
+      h_bias = ldg_f32(bias_p);
+      fwd_bias_ld(A.L[0], wv, c, braw);
+      __builtin_amdgcn_sched_barrier(0);
+      fwd_fill(ring, A.L[0], K0p, wv, g, c, A.wmask);
+      if (A.w_out && (A.logit || logit_lds)) {
+        const int ntop = A.L[A.n_layers - 1].N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wo_pre[i] = ldg_f32(A.w_out + ((lane + 64 * i) < ntop ? (lane + 64 * i) : ntop - 1));
+      }
+    } else {
+      __syncthreads();
+    }
     if (G.n_deep > G.n_deep_fixed || G.n_wide > G.n_wide_fixed) {
       // ---- the pooling itself, in pool_field's order (csrc/embed.hip): positions added one after the other, a masked-out
       // position adds nothing; mean divides by (count | length) + 1e-8 (sequence.py:72-74)
@@ -1221,11 +1273,11 @@ __device__ __forceinline__ const float* mlp_fwd_fast(const MlpArgs& A, float* sm
     FT((3 + 3 * l) & 15);
     __syncthreads();
     FT((4 + 3 * l) & 15);
-    if (Ld.h) tile_store(outb, rsh, Ld.h, Ld.ldh, Ld.N, b0, A.B);   // the saved activation, for the backward kernels
+    if (Ld.h) tile_store(outb, rsh, Ld.h, Ld.ldh, Ld.N, b0, A.B, A.wt != 0);   // the saved activation, for the backward kernels
     if constexpr (GATHER) {
       if (l == 0) {
         // the gathered tile (the first layer's input): its copy for the weight-gradient kernel, padding columns as zeros
-        tile_store(xs, rsx, G.out, G.ldo, K0p < static_cast<int>(G.ldo) ? K0p : static_cast<int>(G.ldo), b0, A.B);
+        tile_store(xs, rsx, G.out, G.ldo, K0p < static_cast<int>(G.ldo) ? K0p : static_cast<int>(G.ldo), b0, A.B, A.wt != 0);
         // the linear logit and the FM term, finished by lpr lanes per sample the way k_embed_fwd's wave 0 does it
         // (lane gl owns the strip [4 gl, 4 gl + 4) of the row and the wide fields gl, gl + lpr, ... of each "wave" w)
         const int lpr = 1 << G.lpr_shift;
@@ -1499,7 +1551,7 @@ __device__ __forceinline__ void mlp_bwd_fast_q(const MlpArgs& A, float* smem, co
   }
   __syncthreads();
   FT((1) & 15);
-  if (A.L[top].dh) tile_store(d0, rs, A.L[top].dh, A.L[top].ldh, A.L[top].N, b0, A.B);
+  if (A.L[top].dh) tile_store(d0, rs, A.L[top].dh, A.L[top].ldh, A.L[top].N, b0, A.B, A.wt != 0);
   float* din = d0;
   float* dout = d1;
   for (int l = top; l >= 0; --l) {
@@ -1528,7 +1580,7 @@ __device__ __forceinline__ void mlp_bwd_fast_q(const MlpArgs& A, float* smem, co
     __syncthreads();
     FT((3 + 2 * (top - l)) & 15);
     // d loss / d pre-activation of the layer below, complete in `dout`: its copy for the weight-gradient kernel
-    if (l > 0 && A.L[l - 1].dh) tile_store(dout, rs, A.L[l - 1].dh, A.L[l - 1].ldh, A.L[l - 1].N, b0, A.B);
+    if (l > 0 && A.L[l - 1].dh) tile_store(dout, rs, A.L[l - 1].dh, A.L[l - 1].ldh, A.L[l - 1].N, b0, A.B, A.wt != 0);
     float* t = din;
     din = dout;
     dout = t;
@@ -2053,14 +2105,20 @@ __device__ __forceinline__ void mlp_train_body(const MlpArgs& A, const HeadArgs&
     h_p0 = ldg_f32((Hd.part0 ? Hd.part0 : Hd.y) + hbc);
     h_p1 = ldg_f32((Hd.part1 ? Hd.part1 : Hd.y) + hbc);
   }
-  const float h_bias = ldg_f32(Hd.bias ? Hd.bias : Hd.y), h_y = ldg_f32(Hd.y + hbc);
+  // (out.bias is a dense parameter: with G.wsync it is requested behind the wait for the weights, inside mlp_fwd_fast)
+  const float* bias_p = Hd.bias ? Hd.bias : Hd.y;
+  float h_bias = 0.f;
+  bool early_bias = true;
+  if constexpr (GATHER) early_bias = G.wsync == nullptr;
+  if (early_bias) h_bias = ldg_f32(bias_p);
+  const float h_y = ldg_f32(Hd.y + hbc);
   FT_DECL;
   FT_DECL_B;
   const float* htop = nullptr;
   if constexpr (GATHER) {
-    htop = mlp_fwd_fast<true>(A, smem, zl, G, p0s, p1s FT_PASS);
+    htop = mlp_fwd_fast<true>(A, smem, zl, G, p0s, p1s, bias_p, h_bias FT_PASS);
   } else {
-    htop = A.fast ? mlp_fwd_fast<false>(A, smem, zl, G, p0s, p1s FT_PASS) : mlp_fwd_body<false>(A, smem, zl);
+    htop = A.fast ? mlp_fwd_fast<false>(A, smem, zl, G, p0s, p1s, bias_p, h_bias FT_PASS) : mlp_fwd_body<false>(A, smem, zl);
   }
   __syncthreads();
   if (tid < 64) {
@@ -2084,14 +2142,14 @@ __device__ __forceinline__ void mlp_train_body(const MlpArgs& A, const HeadArgs&
       const float q = (1.f - p) * p;
       gz = ((p - t) / fmaxf(q, 1e-12f)) * q;                      // bce backward (grad 1) x sigmoid backward
       stg_f32(Hd.y_pred + b, p);
-      stg_f32(Hd.g_logit + b, gz, A.sync != nullptr);
+      stg_f32(Hd.g_logit + b, gz, A.sync != nullptr || A.wt != 0);
     }
     if (tid < kTM) gl[tid] = gz;
     li = group_sum<16>(li);
     float gs = group_sum<16>(gz);
     if (tid == 0) {
-      stg_f32(Hd.part_loss + blockIdx.x, li);
-      stg_f32(Hd.part_gbias + blockIdx.x, gs);
+      stg_f32(Hd.part_loss + blockIdx.x, li, A.wt != 0);
+      stg_f32(Hd.part_gbias + blockIdx.x, gs, A.wt != 0);
     }
   }
   __threadfence_block();   // the saved activations written above are re-read as relu masks below
@@ -2112,6 +2170,22 @@ __device__ __forceinline__ void mlp_train_body(const MlpArgs& A, const HeadArgs&
     if (A.sync) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   }
   if (A.sync) step_signal(A.sync, DCTR_SYNC_TOWER);
+  if constexpr (GATHER) {
+    // one more tower launch done: the launch's last workgroup advances sync[DCTR_SYNC_T_GEN].  Two readers: the NEXT tower
+    // launch on this queue (it waits until as many weight steps have happened) and -- when A.wt -- the weight-gradient launch
+    // of THIS step, spinning on another queue: everything it reads was stored write-through and is drained here.
+    if (G.wsync) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (this wave's write-through stores have arrived)
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int32_t n = static_cast<int32_t>(gridDim.x);
+        if (__hip_atomic_fetch_add(G.wsync + DCTR_SYNC_T_ARR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n - 1) {
+          __hip_atomic_store(G.wsync + DCTR_SYNC_T_ARR, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(G.wsync + DCTR_SYNC_T_GEN, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(kT) void k_mlp_train(MlpArgs A, HeadArgs Hd, int bwd_off) {
@@ -2141,7 +2215,101 @@ struct WgradArgs {
   const float* g;  // [B] when w_out
   float* part;     // [S][slab]
   unsigned long long* trace;
+  // ---- the reduction folded into this launch (dctr_mlp_train_wgrad_sync, round 6); cnt == NULL: off (k_mlp_reduce follows).
+  // A tile's S workgroups store their partials WRITE-THROUGH, drain them and take a ticket of the tile's counter; the one that
+  // draws the last ticket sums the S slabs in slab order (k_mlp_reduce's arithmetic, element for element), stores the gradient
+  // and steps the parameter behind it.  The projection's P workgroups do the same for d w_out and -- in the same last
+  // arriver -- the head's partial sums (loss, d bias).  Every reducer stores the parameters write-through, drains, and counts
+  // itself done; the launch's last reducer advances sync[DCTR_SYNC_W_GEN]: a tower launch that waits for it
+  // (dctr_embed_tower_train_step_sync) may then read every dense parameter.
+  int32_t* cnt;        // [n_red] arrivals per reducer (zero at rest)
+  int32_t* sync;       // the model's sync block (include/dctr.h)
+  int wait_tower;      // != 0: the launch may start before this step's tower launch has finished (another queue, no graph
+                       // edge): every workgroup first waits until sync[DCTR_SYNC_T_GEN] > sync[DCTR_SYNC_W_GEN]
+  unsigned long long wtimeout;
+  int32_t* err;        // nullable: bit 3 (8) when that wait ran out
+  int n_red;           // GEMM tiles (+ 1 with a projection)
+  float* gW[kMaxL];    // gradient tensors the sums go to
+  float* gb[kMaxL];    // nullable
+  float* g_wo;
+  const float* head_loss;   // [n_head] nullable (fused train step)
+  const float* head_gbias;
+  int n_head;
+  float* loss;
+  float* g_bias;
+  DenseStepDev step;
 };
+
+// optimizer step on four consecutive elements whose gradients `acc` were just finished: k_mlp_reduce's arithmetic, expression
+// for expression (the two paths must agree bit for bit: tests/test_gpu_step_engine.py)
+__device__ __forceinline__ void fold_step4(const DenseStepDev& S, float* d, const f32x4 acc, const f32x4 w, const f32x4 st) {
+  stg_wt(d, acc);
+  if (S.kind < 0) return;
+  const int64_t k = d - S.grad_base;
+  f32x4 wn, sn4;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float g = acc[c];
+    if (S.kind == DCTR_UPD_ADAGRAD) {
+      const float sn = adagrad_sum(st[c], g);
+      sn4[c] = sn;
+      wn[c] = adagrad_param(w[c], g, sn, S.lr, S.eps);
+    } else {
+      sn4[c] = 0.f;
+      wn[c] = sgd_param(w[c], g, S.lr);
+    }
+  }
+  if (S.kind == DCTR_UPD_ADAGRAD) stg_wt(S.state_base + k, sn4);
+  stg_wt(S.param_base + k, wn);
+}
+__device__ __forceinline__ void fold_step1(const DenseStepDev& S, float* d, const float g) {
+  stg_wt(d, g);
+  if (S.kind < 0) return;
+  const int64_t k = d - S.grad_base;
+  const float w = __hip_atomic_load(S.param_base + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (sc1: past the L1)
+  if (S.kind == DCTR_UPD_ADAGRAD) {
+    const float sn = adagrad_sum(__hip_atomic_load(S.state_base + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), g);
+    stg_wt(S.state_base + k, sn);
+    stg_wt(S.param_base + k, adagrad_param(w, g, sn, S.lr, S.eps));
+  } else {
+    stg_wt(S.param_base + k, sgd_param(w, g, S.lr));
+  }
+}
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// a 16-byte load that bypasses this CU's L1 (sc1): the partial slabs were stored write-through by other workgroups
+__device__ __forceinline__ f32x4 ld_slab4(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16));
+}
+__device__ __forceinline__ float ld_slab1(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 16));
+}
+// every thread of the workgroup, behind its last write-through store: the stores have arrived; thread 0 takes a ticket of
+// `cnt` (relaxed, agent scope: the atomic executes beyond the XCD's L2) -> true in the workgroup that drew the last of `n`
+// (which hands the counter back zeroed).  `flag`: one LDS word.
+__device__ __forceinline__ bool fold_arrive(int32_t* cnt, int n, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == n - 1) ? 1 : 0;
+    if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = last;
+  }
+  __syncthreads();
+  return *flag != 0;
+}
+// a reducer is done (its parameter stores drained): the launch's last one advances the weights' generation
+__device__ __forceinline__ void fold_done(int32_t* sync, int n_red) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = __hip_atomic_fetch_add(sync + DCTR_SYNC_W_ARR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == n_red - 1) {
+      __hip_atomic_store(sync + DCTR_SYNC_W_ARR, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(sync + DCTR_SYNC_W_GEN, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
 
 // One workgroup = one 64x64 tile of one layer's dW over one batch slice; its four waves take the slice's rows in four
 // contiguous quarters (multiples of 8 rows) and are summed through LDS in wave order.
@@ -2163,6 +2331,24 @@ __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int blk = blockIdx.x;
   MLP_TRACE(A.trace, 0);
+  if (A.cnt && A.wait_tower) {
+    // one wave polls (relaxed, past the L1); the tower stored everything this launch reads write-through and drained it in
+    // front of its arrival, this CU's L1 holds none of those lines (nothing was read yet): plain loads from here on
+    if (wv == 0) {
+      const int32_t want = __hip_atomic_load(A.sync + DCTR_SYNC_W_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+      const unsigned long long t0 = wall_clock64();
+      for (;;) {
+        const int32_t have = __hip_atomic_load(A.sync + DCTR_SYNC_T_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (have - want >= 0) break;
+        if (wall_clock64() - t0 > A.wtimeout) {
+          if (lane == 0 && A.err) atomicOr(A.err, 8);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    __syncthreads();
+  }
   int l = 0;
   while (l < A.n_layers && blk >= A.blk0[l + 1]) ++l;
   const int local = blk - A.blk0[l];
@@ -2213,9 +2399,53 @@ __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
         float t = redp[tid];
 #pragma unroll
         for (int h = 1; h < 8; ++h) t += redp[h * 128 + tid];
-        for (int sl = j; sl < A.S; sl += A.P) stg_f32(A.part + static_cast<int64_t>(sl) * A.slab + A.off_o + n0 + tid, sl == j ? t : 0.f);
+        for (int sl = j; sl < A.S; sl += A.P)
+          stg_f32(A.part + static_cast<int64_t>(sl) * A.slab + A.off_o + n0 + tid, sl == j ? t : 0.f, A.cnt != nullptr);
       }
     }
+    if (!A.cnt) return;
+    // ---- folded reduction: the last of the P projection workgroups sums d w_out over the S slabs and finishes the head
+    int* flag = reinterpret_cast<int*>(wsm + 4 * 4096 + 256);
+    if (!fold_arrive(A.cnt + (A.n_red - 1), A.P, flag)) return;
+    {
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(A.part, 0, static_cast<int>(A.S * A.slab * 4), 0x00020000);
+      for (int n = tid; n < Lt.N; n += kTW) {
+        float acc = 0.f;
+        for (int s0 = 0; s0 < A.S; s0 += 8) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int sj = s0 + q < A.S ? s0 + q : A.S - 1;
+            v[q] = ld_slab1(rs, static_cast<uint32_t>((static_cast<int64_t>(sj) * A.slab + A.off_o + n) * 4));
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (s0 + q < A.S) acc += v[q];
+        }
+        if (A.g_wo) fold_step1(A.step, A.g_wo + n, acc);
+      }
+      if (A.head_loss) {   // k_mlp_reduce's head workgroup: fixed-order tree over the row tiles' partial sums
+        __syncthreads();
+        float* hred = wsm;     // [2][4]
+        float l = 0.f, gsum = 0.f;
+        for (int k = tid; k < A.n_head; k += 256) {
+          l += ldg_f32(A.head_loss + k);
+          gsum += ldg_f32(A.head_gbias + k);
+        }
+        l = wave_sum(l);
+        gsum = wave_sum(gsum);
+        if ((tid & 63) == 0) {
+          hred[tid >> 6] = l;
+          hred[4 + (tid >> 6)] = gsum;
+        }
+        __syncthreads();
+        if (tid == 0) {
+          stg_f32(A.loss, ((hred[0] + hred[1]) + hred[2]) + hred[3]);
+          if (A.g_bias) fold_step1(A.step, A.g_bias, ((hred[4] + hred[5]) + hred[6]) + hred[7]);
+        }
+      }
+    }
+    fold_done(A.sync, A.n_red);
     return;
   }
 
@@ -2361,12 +2591,73 @@ __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         if (col + c >= Ld.K) q[c] = 0.f;
-      *(DCTR_GLOBAL f32x4*)(pw + static_cast<int64_t>(row) * Ld.ldw + col) = q;
+      if (A.cnt) stg_wt(pw + static_cast<int64_t>(row) * Ld.ldw + col, q);
+      else *(DCTR_GLOBAL f32x4*)(pw + static_cast<int64_t>(row) * Ld.ldw + col) = q;
     }
   }
   if (want_bias && tid < 64 && m0 + tid < Ld.N)
-    stg_f32(part + A.off_b[l] + m0 + tid, ((redb[tid] + redb[64 + tid]) + redb[128 + tid]) + redb[192 + tid]);
+    stg_f32(part + A.off_b[l] + m0 + tid, ((redb[tid] + redb[64 + tid]) + redb[128 + tid]) + redb[192 + tid], A.cnt != nullptr);
   MLP_TRACE(A.trace, 3);
+  if (A.cnt) {
+    // ---- folded reduction: the tile's last workgroup to arrive sums its S slabs (slab order) and steps the parameters
+    int* flag = reinterpret_cast<int*>(wsm + 4 * 4096 + 256);
+    if (!fold_arrive(A.cnt + (A.blk0[l] / A.S + tile), A.S, flag)) return;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(A.part, 0, static_cast<int>(A.S * A.slab * 4), 0x00020000);
+    const uint32_t slab4 = static_cast<uint32_t>(A.slab) * 4u;
+    const auto rs_p = __builtin_amdgcn_make_buffer_rsrc(A.step.param_base ? A.step.param_base : A.part, 0, 0x7FFFFFF0, 0x00020000);
+    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc(A.step.state_base ? A.step.state_base : A.part, 0, 0x7FFFFFF0, 0x00020000);
+    float* gWl = A.gW[l];
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih) {      // two rounds of two element quads: (S + 2) x 2 loads in flight per thread
+      f32x4 acc[2], w4[2], st4[2];
+      bool ok[2];
+      float* dptr[2];
+      f32x4 v[2][8];
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int e4 = tid + kTW * (2 * ih + ii);
+        const int n = e4 >> 4, k4 = (e4 & 15) << 2;
+        const int row = m0 + n, col = k0 + k4;
+        ok[ii] = row < Ld.N && col < Ld.ldw;
+        const int64_t o = ok[ii] ? static_cast<int64_t>(row) * Ld.ldw + col : 0;
+        dptr[ii] = gWl + o;
+        const uint32_t b0_ = static_cast<uint32_t>(A.off_w[l] + o) * 4u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[ii][q] = ld_slab4(rs, b0_ + static_cast<uint32_t>(q < A.S ? q : A.S - 1) * slab4);
+        // (sc1 loads: a parameter line must never sit in this CU's L1 -- a tower workgroup that waits for this launch's
+        // signal may run on the same CU and read the line right after it was stepped)
+        const uint32_t kb = static_cast<uint32_t>(dptr[ii] - A.step.grad_base) * 4u;
+        w4[ii] = A.step.kind >= 0 ? ld_slab4(rs_p, kb) : f32x4{0.f, 0.f, 0.f, 0.f};
+        st4[ii] = A.step.kind == DCTR_UPD_ADAGRAD ? ld_slab4(rs_s, kb) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        acc[ii] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (q < A.S) acc[ii] += v[ii][q];
+        for (int s0 = 8; s0 < A.S; s0 += 8) {    // (more than 8 slices: never at the BASELINE shapes)
+          const uint32_t b0_ = static_cast<uint32_t>(A.off_w[l] + (dptr[ii] - gWl)) * 4u;
+          for (int q = 0; q < 8 && s0 + q < A.S; ++q) acc[ii] += ld_slab4(rs, b0_ + static_cast<uint32_t>(s0 + q) * slab4);
+        }
+        if (ok[ii] && gWl) fold_step4(A.step, dptr[ii], acc[ii], w4[ii], st4[ii]);
+      }
+    }
+    if (want_bias && tid < 64 && m0 + tid < Ld.N && A.gb[l]) {
+      const uint32_t b0_ = static_cast<uint32_t>(A.off_b[l] + m0 + tid) * 4u;
+      float acc = 0.f;
+      for (int s0 = 0; s0 < A.S; s0 += 8) {
+        float vb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) vb[q] = ld_slab1(rs, b0_ + static_cast<uint32_t>(s0 + q < A.S ? s0 + q : A.S - 1) * slab4);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (s0 + q < A.S) acc += vb[q];
+      }
+      fold_step1(A.step, A.gb[l] + m0 + tid, acc);
+    }
+    fold_done(A.sync, A.n_red);
+  }
 #ifdef DCTR_DIAG
   if (A.trace && threadIdx.x == 0) A.trace[blockIdx.x * 16ull + 14] = static_cast<unsigned long long>(l);
 #endif
@@ -2464,11 +2755,11 @@ __global__ __launch_bounds__(256) void k_mlp_reduce(ReduceArgs A) {
       const float g = acc[c];
       stg_f32(d + c, g);
       if (A.step.kind == DCTR_UPD_ADAGRAD) {   // torch.optim.Adagrad: s += g*g ; p -= lr * g / (sqrt(s) + eps)
-        const float sn = st[c] + g * g;
+        const float sn = adagrad_sum(st[c], g);
         stg_f32(A.step.state_base + k + c, sn);
-        stg_f32(A.step.param_base + k + c, w[c] - A.step.lr * (g / (sqrtf(sn) + A.step.eps)));
+        stg_f32(A.step.param_base + k + c, adagrad_param(w[c], g, sn, A.step.lr, A.step.eps));
       } else {                                 // torch.optim.SGD
-        stg_f32(A.step.param_base + k + c, w[c] - A.step.lr * g);
+        stg_f32(A.step.param_base + k + c, sgd_param(w[c], g, A.step.lr));
       }
     }
   }
@@ -2627,7 +2918,7 @@ extern "C" int dctr_mlp_fwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, i
   a.kc = pick_kc(K0p, a.rsh);
   a.rsx = (K0p < a.kc ? K0p : a.kc) + kPad;
   a.rsd = 0;
-  a.fast = tower_fast(m, a.kc); a.wmask = diag_wmask(); a.sync = nullptr;
+  a.fast = tower_fast(m, a.kc); a.wmask = diag_wmask(); a.sync = nullptr; a.wt = 0;
   const size_t lds = static_cast<size_t>(kTM) * (a.rsx + 2 * a.rsh) * 4;
   if (lds > 150 * 1024) return DCTR_ENOSUP;
   if (lds > 64 * 1024)
@@ -2668,10 +2959,14 @@ int bwd_stride(const dctr_mlp_t* m) {
 }
 
 // weight gradients (split-batch partials) + their fixed-order reduction (+ the head's partials, fused step only)
+// (sync + cnt: ONE launch -- the reduction and the optimizer step folded into k_mlp_wgrad's last arrivers, the weights'
+// generation advanced at the end: dctr_mlp_train_wgrad_sync)
 int launch_wgrad_reduce(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g,
                         float* workspace, const float* head_loss, const float* head_gbias, int n_head, float* loss,
-                        float* g_bias, const dctr_dense_step_t* step, hipStream_t s) {
+                        float* g_bias, const dctr_dense_step_t* step, hipStream_t s, int32_t* sync = nullptr,
+                        int32_t* cnt = nullptr, int wait_tower = 0, int32_t timeout_us = 0, int32_t* err = nullptr) {
   const WgradPlan P = plan_wgrad(m, B);
+  if (cnt && static_cast<int64_t>(P.S) * P.slab * 4 >= (int64_t(1) << 31)) return DCTR_ENOSUP;
   {
     WgradArgs a;
     fill_layers(m, a.L);
@@ -2683,12 +2978,22 @@ int launch_wgrad_reduce(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32
     }
     a.off_o = P.off_o; a.slab = P.slab; a.x = x; a.ldx = ld_x; a.w_out = m->w_out; a.g = g; a.part = workspace;
     a.trace = g_mlp_trace ? g_mlp_trace + 16ull * 8192 : nullptr;
-    constexpr int kWgLds = (4 * 4096 + 256) * 4;
+    a.cnt = cnt; a.sync = sync;
+    a.wait_tower = wait_tower; a.wtimeout = static_cast<unsigned long long>(timeout_us > 0 ? timeout_us : 0) * 100ull; a.err = err;
+    a.n_red = P.blk0[m->n_layers] / P.S + (m->w_out ? 1 : 0);
+    for (int l = 0; l < kMaxL; ++l) {
+      a.gW[l] = l < m->n_layers ? m->layer[l].gW : nullptr;
+      a.gb[l] = (l < m->n_layers && m->layer[l].bias) ? m->layer[l].gbias : nullptr;
+    }
+    a.g_wo = m->w_out ? m->g_w_out : nullptr;
+    a.head_loss = head_loss; a.head_gbias = head_gbias; a.n_head = n_head; a.loss = loss; a.g_bias = g_bias;
+    a.step = dense_step_dev(step);
+    constexpr int kWgLds = (4 * 4096 + 256 + 16) * 4;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize,
                               kWgLds);
     k_mlp_wgrad<<<dim3(P.blk0[m->n_layers + 1]), dim3(kTW), kWgLds, s>>>(a);
     const int st = launch_status();
-    if (st != DCTR_OK) return st;
+    if (st != DCTR_OK || cnt) return st;
   }
   ReduceArgs r;
   r.S = P.S; r.slab = P.slab; r.part = workspace;
@@ -2732,7 +3037,7 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_t* m, const float* x, int64_t ld_x, i
     a.trace = g_mlp_trace ? g_mlp_trace + 16ull * 4096 : nullptr;
     a.rsx = 0; a.rsh = 0;
     a.rsd = bwd_stride(m);
-    a.fast = tower_fast(m, kKC); a.wmask = diag_wmask(); a.sync = nullptr;
+    a.fast = tower_fast(m, kKC); a.wmask = diag_wmask(); a.sync = nullptr; a.wt = 0;
     const size_t lds = static_cast<size_t>(kTM) * 2 * a.rsd * 4;
     if (lds > 160 * 1024) return DCTR_ENOSUP;
     if (lds > 64 * 1024)
@@ -2778,7 +3083,7 @@ extern "C" int dctr_mlp_train_step(const dctr_mlp_t* m, const float* x, int64_t 
     a.kc = pick_kc(K0p, a.rsh);
     a.rsx = (K0p < a.kc ? K0p : a.kc) + kPad;
     a.rsd = bwd_stride(m);
-    a.fast = tower_fast(m, a.kc); a.wmask = diag_wmask(); a.sync = gx ? m->step_sync : nullptr;
+    a.fast = tower_fast(m, a.kc); a.wmask = diag_wmask(); a.sync = gx ? m->step_sync : nullptr; a.wt = 0;
     const size_t lds_f = static_cast<size_t>(kTM) * (a.rsx + 2 * a.rsh) * 4;
     const size_t lds_b = static_cast<size_t>(kTM) * 2 * a.rsd * 4;
     size_t lds = lds_f > lds_b ? lds_f : lds_b;
@@ -2820,7 +3125,7 @@ int train_geom(const dctr_mlp_t* m, int32_t B, TrainGeom* T) {
   a.kc = pick_kc(K0p, a.rsh);
   a.rsx = (K0p < a.kc ? K0p : a.kc) + kPad;
   a.rsd = bwd_stride(m);
-  a.fast = tower_fast(m, a.kc); a.wmask = diag_wmask();
+  a.fast = tower_fast(m, a.kc); a.wmask = diag_wmask(); a.wt = 0;
   const size_t lds_f = static_cast<size_t>(kTM) * (a.rsx + 2 * a.rsh) * 4;
   const size_t lds_b = static_cast<size_t>(kTM) * 2 * a.rsd * 4;
   T->lds = lds_f > lds_b ? lds_f : lds_b;
@@ -2878,11 +3183,39 @@ extern "C" int dctr_embed_tower_train_supported(const dctr_plan_t* plan, const d
   return gather_envelope(plan, m, B, T) == DCTR_OK ? 1 : 0;
 }
 
+namespace {
+int embed_tower_train_step(const dctr_plan_t* plan, const float* X, int64_t ldx, const dctr_mlp_t* m,
+                           int32_t B, int32_t want_fm, const float* bias, const float* y, float* y_pred,
+                           float* g_logit, float* gx, int64_t ld_gx, float* out, int64_t ld_out,
+                           float* fm_s, int64_t ld_s, int32_t* err, float* workspace, int32_t* wsync, int32_t timeout_us,
+                           dctr_stream_t stream);
+}  // namespace
+
 extern "C" int dctr_embed_tower_train_step(const dctr_plan_t* plan, const float* X, int64_t ldx, const dctr_mlp_t* m,
                                            int32_t B, int32_t want_fm, const float* bias, const float* y, float* y_pred,
                                            float* g_logit, float* gx, int64_t ld_gx, float* out, int64_t ld_out,
                                            float* fm_s, int64_t ld_s, int32_t* err, float* workspace,
                                            dctr_stream_t stream) {
+  return embed_tower_train_step(plan, X, ldx, m, B, want_fm, bias, y, y_pred, g_logit, gx, ld_gx, out, ld_out, fm_s, ld_s, err,
+                                workspace, nullptr, 0, stream);
+}
+
+extern "C" int dctr_embed_tower_train_step_sync(const dctr_plan_t* plan, const float* X, int64_t ldx, const dctr_mlp_t* m,
+                                                int32_t B, int32_t want_fm, const float* bias, const float* y, float* y_pred,
+                                                float* g_logit, float* gx, int64_t ld_gx, float* out, int64_t ld_out,
+                                                float* fm_s, int64_t ld_s, int32_t* err, float* workspace, int32_t* sync,
+                                                int32_t timeout_us, dctr_stream_t stream) {
+  if (!sync || timeout_us <= 0 || B <= 0) return DCTR_EINVAL;      // (B == 0 would not advance the tower generation)
+  return embed_tower_train_step(plan, X, ldx, m, B, want_fm, bias, y, y_pred, g_logit, gx, ld_gx, out, ld_out, fm_s, ld_s, err,
+                                workspace, sync, timeout_us, stream);
+}
+
+namespace {
+int embed_tower_train_step(const dctr_plan_t* plan, const float* X, int64_t ldx, const dctr_mlp_t* m,
+                           int32_t B, int32_t want_fm, const float* bias, const float* y, float* y_pred,
+                           float* g_logit, float* gx, int64_t ld_gx, float* out, int64_t ld_out,
+                           float* fm_s, int64_t ld_s, int32_t* err, float* workspace, int32_t* wsync, int32_t timeout_us,
+                           dctr_stream_t stream) {
   const int rc = check_mlp(m, B);
   if (rc != DCTR_OK) return rc;
   if (!plan || !X || !m->w_out || !y || !y_pred || !g_logit || !workspace || !out || !gx) return DCTR_EINVAL;
@@ -2899,7 +3232,7 @@ extern "C" int dctr_embed_tower_train_step(const dctr_plan_t* plan, const float*
   const int re = gather_envelope(plan, m, B, T);
   if (re != DCTR_OK) return re;
   MlpArgs& a = T.a;
-  a.x = out; a.ldx = ld_out; a.gx = gx; a.ldgx = ld_gx; a.sync = nullptr;
+  a.x = out; a.ldx = ld_out; a.gx = gx; a.ldgx = ld_gx; a.sync = nullptr; a.wt = wsync ? 1 : 0;
   const WgradPlan P = plan_wgrad(m, B);
   const int n_tiles = (B + kTM - 1) / kTM;
   HeadArgs hd;
@@ -2921,12 +3254,14 @@ extern "C" int dctr_embed_tower_train_step(const dctr_plan_t* plan, const float*
   if (maxp && !plan->ext->amax) return DCTR_EINVAL;       // (the caller points ext->amax at this step's arg-max buffer)
   G.amax = maxp ? plan->ext->amax : nullptr; G.ld_am = maxp ? plan->ext->ld_amax : 0;
   G.am_deep_off = maxp ? plan->ext->am_deep_off : nullptr; G.am_wide_off = maxp ? plan->ext->am_wide_off : nullptr;
+  G.wsync = wsync; G.wtimeout = static_cast<unsigned long long>(timeout_us > 0 ? timeout_us : 0) * 100ull;
   if (T.lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_embed_tower_train),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(T.lds));
   k_embed_tower_train<<<dim3(n_tiles), dim3(kT), T.lds, static_cast<hipStream_t>(stream)>>>(a, hd, T.bwd_off, G);
   return launch_status();
 }
+}  // namespace
 
 extern "C" int dctr_mlp_train_wgrad(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g_logit,
                                     float* workspace, float* loss, float* g_bias, const dctr_dense_step_t* step,
@@ -2942,6 +3277,35 @@ extern "C" int dctr_mlp_train_wgrad(const dctr_mlp_t* m, const float* x, int64_t
   float* part_gb = part_loss + n_tiles;
   return launch_wgrad_reduce(m, x, ld_x, B, g_logit, workspace, part_loss, part_gb, n_tiles, loss, g_bias, step,
                              static_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t dctr_mlp_train_wgrad_counters(const dctr_mlp_t* m, int32_t B) {
+  if (check_mlp(m, B) != DCTR_OK) return 0;
+  const WgradPlan P = plan_wgrad(m, B);
+  return static_cast<size_t>(P.blk0[m->n_layers] / P.S + 1);
+}
+
+extern "C" int dctr_mlp_train_wgrad_sync(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g_logit,
+                                         float* workspace, float* loss, float* g_bias, const dctr_dense_step_t* step,
+                                         int32_t* sync, int32_t* counters, int32_t wait_tower, int32_t timeout_us,
+                                         int32_t* err, dctr_stream_t stream) {
+  const int rc = check_mlp(m, B);
+  if (rc != DCTR_OK) return rc;
+  if (!m->w_out || !x || !loss || !g_logit || !workspace || !sync || !counters) return DCTR_EINVAL;
+  if (wait_tower && timeout_us <= 0) return DCTR_EINVAL;
+  if (ld_x % 4 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0) return DCTR_EALIGN;
+  for (int l = 0; l < m->n_layers; ++l)
+    if (!m->layer[l].gW || reinterpret_cast<uintptr_t>(m->layer[l].gW) % 16 != 0) return DCTR_EALIGN;
+  if (step && (reinterpret_cast<uintptr_t>(step->param_base) % 16 != 0 || reinterpret_cast<uintptr_t>(step->grad_base) % 16 != 0 ||
+               reinterpret_cast<uintptr_t>(step->state_base) % 16 != 0))
+    return DCTR_EALIGN;
+  if (B == 0) return DCTR_EINVAL;       // (the generation must advance once per call)
+  const WgradPlan P = plan_wgrad(m, B);
+  const int n_tiles = (B + kTM - 1) / kTM;
+  float* part_loss = workspace + static_cast<size_t>(P.slab) * P.S;
+  float* part_gb = part_loss + n_tiles;
+  return launch_wgrad_reduce(m, x, ld_x, B, g_logit, workspace, part_loss, part_gb, n_tiles, loss, g_bias, step,
+                             static_cast<hipStream_t>(stream), sync, counters, wait_tower ? 1 : 0, timeout_us, err);
 }
 
 // ---- CrossNet, matrix parameterisation (interaction.py:448-451) ------------------------------------------------------
@@ -2988,7 +3352,7 @@ extern "C" int dctr_crossnet_mat_fwd(const dctr_mlp_t* m, const float* x, int64_
   a.rsx = Wp + kPad;
   a.rsh = Wp + kPad;
   a.rsd = 0;
-  a.fast = 0; a.wmask = 0xffffffffu; a.sync = nullptr;
+  a.fast = 0; a.wmask = 0xffffffffu; a.sync = nullptr; a.wt = 0;
   const size_t lds = static_cast<size_t>(kTM) * (a.rsx + 2 * a.rsh) * 4;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cross_mat_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -3019,7 +3383,7 @@ extern "C" int dctr_crossnet_mat_bwd(const dctr_mlp_t* m, const float* x, int64_
     fill_layers(m, a.L);
     a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = nullptr; a.logit = nullptr;
     a.g = gY; a.ldg = ld_g; a.gx = gx; a.ldgx = ld_gx; a.trace = nullptr;
-    a.rsx = 0; a.rsh = 0; a.fast = 0; a.wmask = 0xffffffffu; a.sync = nullptr;
+    a.rsx = 0; a.rsh = 0; a.fast = 0; a.wmask = 0xffffffffu; a.sync = nullptr; a.wt = 0;
     a.rsd = round_up(W, 64) + kPad;
     const size_t lds = static_cast<size_t>(kTM) * 4 * a.rsd * 4;
     if (lds > 64 * 1024)
@@ -3084,7 +3448,7 @@ extern "C" int dctr_crossnet_mix_fwd(const dctr_mlp_t* m, int32_t E, int32_t R, 
   fill_layers(m, a.L);
   a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = nullptr; a.logit = nullptr;
   a.g = nullptr; a.ldg = 0; a.gx = nullptr; a.ldgx = 0; a.trace = nullptr;
-  a.kc = kKC; a.rsx = 0; a.rsh = 0; a.rsd = 0; a.fast = 0; a.wmask = 0xffffffffu; a.sync = nullptr;
+  a.kc = kKC; a.rsx = 0; a.rsh = 0; a.rsd = 0; a.fast = 0; a.wmask = 0xffffffffu; a.sync = nullptr; a.wt = 0;
   const size_t lds = mix_lds_fwd(W, E * R + E);
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cross_mix_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -3116,7 +3480,7 @@ extern "C" int dctr_crossnet_mix_bwd(const dctr_mlp_t* m, int32_t E, int32_t R, 
     fill_layers(m, a.L);
     a.n_layers = m->n_layers; a.B = B; a.x = x; a.ldx = ld_x; a.w_out = nullptr; a.logit = nullptr;
     a.g = gY; a.ldg = ld_g; a.gx = gx; a.ldgx = ld_gx; a.trace = nullptr;
-    a.kc = kKC; a.rsx = 0; a.rsh = 0; a.rsd = 0; a.fast = 0; a.wmask = 0xffffffffu; a.sync = nullptr;
+    a.kc = kKC; a.rsx = 0; a.rsh = 0; a.rsd = 0; a.fast = 0; a.wmask = 0xffffffffu; a.sync = nullptr; a.wt = 0;
     const size_t lds = mix_lds_bwd(W, E * R + E);
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cross_mix_bwd),

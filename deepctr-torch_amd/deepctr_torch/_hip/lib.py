@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdctr_hip.so")
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 
@@ -191,6 +191,11 @@ SIGNATURES = {
     "dctr_embed_tower_train_supported": (ctypes.c_int, [ctypes.POINTER(Plan), ctypes.POINTER(Mlp), _I32]),
     "dctr_embed_tower_train_step": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, ctypes.POINTER(Mlp), _I32, _I32, _P, _P,
                                                    _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P]),
+    "dctr_mlp_train_wgrad_counters": (ctypes.c_size_t, [ctypes.POINTER(Mlp), _I32]),
+    "dctr_mlp_train_wgrad_sync": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _I32,
+                                                 _P, _P]),
+    "dctr_embed_tower_train_step_sync": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, ctypes.POINTER(Mlp), _I32, _I32, _P,
+                                                        _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _I32, _P]),
     "dctr_sizeof_dense_step": (ctypes.c_size_t, []),
     "dctr_step_wait": (ctypes.c_int, [_P, _I32, _I32, _P]),
     "dctr_step_signal": (ctypes.c_int, [_P, _I32, _P]),

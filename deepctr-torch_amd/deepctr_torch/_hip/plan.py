@@ -621,9 +621,21 @@ class EmbeddingPlan(object):
 
     def check_ids(self):
         """Poll the out-of-range flag (one device sync).  The reference raises IndexError at once on CPU."""
-        if self._err is not None and int(self._err.item()) != 0:
-            self._err.zero_()
-            raise IndexError("index out of range in self: a sparse id in X is outside [0, vocabulary_size)")
+        if self._err is not None:
+            bits = int(self._err.item())
+            if bits != 0:
+                self._err.zero_()
+                import os
+                if (bits & 12) and os.environ.get("DCTR_DBG_IGNORE_WAIT") == "1":       # (timing experiments only)
+                    import sys
+                    print("dctr: an in-kernel wait timed out (bits %d) -- ignored (DCTR_DBG_IGNORE_WAIT)" % bits, file=sys.stderr)
+                    return
+                if bits & 12:   # (dctr_embed_tower_train_step_sync / dctr_mlp_train_wgrad_sync: an in-kernel wait ran out)
+                    raise RuntimeError("a train step's tower launch gave up waiting for the previous step's dense optimizer "
+                                       "step (DCTR_SYNC_W_GEN): the two queues of the step fell out of step -- results "
+                                       "since the last check are not to be trusted (DCTR_STEP_TOPOLOGY=update_side avoids "
+                                       "the in-kernel wait)")
+                raise IndexError("index out of range in self: a sparse id in X is outside [0, vocabulary_size)")
         owner = getattr(self, "_sync_owner", None)      # step topology "flags": did a device-side dependency time out?
         if owner is not None:
             owner.check_sync()

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 22
+#define DCTR_ABI_VERSION 23
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -660,6 +660,33 @@ int dctr_embed_tower_train_step(const dctr_plan_t* plan, const float* X, int64_t
                                 float* gx, int64_t ld_gx, float* out, int64_t ld_out, float* fm_s, int64_t ld_s,
                                 int32_t* err, float* workspace, dctr_stream_t stream);
 
+/* The same two launches for a step whose critical cycle is tower -> embedding update -> next tower on ONE queue, with the
+ * weight gradients on a second queue (round 6; reference: the optimizer step of basemodel.py:262 must precede the next
+ * forward of basemodel.py:246 -- here that order is kept by a word in memory, see DCTR_SYNC_W_GEN below):
+ *   dctr_mlp_train_wgrad_sync        dctr_mlp_train_wgrad as ONE launch: a tile's last workgroup to arrive sums the tile's
+ *                                    partial slabs in slab order and steps the parameters (the arithmetic of the separate
+ *                                    reduction launch, bit for bit), then the launch advances sync[DCTR_SYNC_W_GEN].
+ *                                    counters: dctr_mlp_train_wgrad_counters(m, B) int32, zero before the first call.
+ *                                    wait_tower != 0: the call may be enqueued on a queue that is NOT ordered behind this
+ *                                    step's tower launch -- every workgroup then waits in the kernel until
+ *                                    sync[DCTR_SYNC_T_GEN] > sync[DCTR_SYNC_W_GEN] (the _sync tower launch stores what this
+ *                                    one reads write-through and drains it in front of its arrival); a wait longer than
+ *                                    timeout_us raises bit 3 (8) of *err and goes on.
+ *   dctr_embed_tower_train_step_sync dctr_embed_tower_train_step that requests no dense parameter (tower weights, biases,
+ *                                    the projection, `bias`) before sync[DCTR_SYNC_W_GEN] has caught up with the number of
+ *                                    tower launches finished on this block; a wait that exceeds timeout_us raises bit 2 (4)
+ *                                    of *err and goes on.  Results: those of the plain calls, bit for bit.                */
+size_t dctr_mlp_train_wgrad_counters(const dctr_mlp_t* m, int32_t B);
+int dctr_mlp_train_wgrad_sync(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g_logit,
+                              float* workspace, float* loss, float* g_bias, const dctr_dense_step_t* step, int32_t* sync,
+                              int32_t* counters, int32_t wait_tower, int32_t timeout_us, int32_t* err,
+                              dctr_stream_t stream);
+int dctr_embed_tower_train_step_sync(const dctr_plan_t* plan, const float* X, int64_t ldx, const dctr_mlp_t* m, int32_t B,
+                                     int32_t want_fm, const float* bias, const float* y, float* y_pred, float* g_logit,
+                                     float* gx, int64_t ld_gx, float* out, int64_t ld_out, float* fm_s, int64_t ld_s,
+                                     int32_t* err, float* workspace, int32_t* sync, int32_t timeout_us,
+                                     dctr_stream_t stream);
+
 /* ---- device-side dependencies between the two queues of a train step ---------------------------------------------
  * A dependency that crosses hardware queues costs 11-12 us through hipGraph / stream events on this stack, 4.6 us through
  * a word in memory (tools/micro/hopbench.hip), and the DeepFM step's critical cycle crosses twice (tower -> update,
@@ -679,6 +706,18 @@ int dctr_embed_tower_train_step(const dctr_plan_t* plan, const float* X, int64_t
 #define DCTR_SYNC_UPDATE 2   /* given by dctr_step_signal behind dctr_embed_update (the "fused_flags" step topology) */
 #define DCTR_SYNC_ERR 12     /* index of the error word */
 #define DCTR_SYNC_INTS 32    /* [4 s, 4 s + 4): signal s' generation / epoch / arrivals / stamp; [16 + 2 s, +2): its waiter's stamps */
+/* Round 6 -- the weights' hand-over INSIDE the waiting kernel (no waiter launch, no graph edge): words of the same block.
+ *   W_GEN  weight steps finished: advanced by the last reducer of dctr_mlp_train_wgrad_sync, after every dense parameter
+ *          it steps has been stored write-through and waited for;
+ *   T_GEN  tower launches finished: advanced by the last workgroup of dctr_embed_tower_train_step_sync.
+ * A tower launch may start while the previous step's weight-gradient launch still runs on another queue: it stages its X
+ * tile and gathers its table rows (which only need the embedding update, ordered in front of it on its own queue), then
+ * waits until W_GEN >= T_GEN (as read at its start) before it requests the first dense parameter.  The two calls must
+ * alternate strictly (tower, weight gradients, tower, ...) on one sync block; the block is zero before the first call.  */
+#define DCTR_SYNC_W_GEN 24
+#define DCTR_SYNC_W_ARR 25
+#define DCTR_SYNC_T_GEN 26
+#define DCTR_SYNC_T_ARR 27
 int dctr_step_wait(int32_t* sync, int32_t signal, int32_t timeout_us, dctr_stream_t stream);
 /* The signal as a one-thread launch of its own on the producer's queue, behind the producer (whose end-of-kernel
  * write-back makes its stores visible first): for a producer that cannot signal from inside its kernel.            */

@@ -289,6 +289,9 @@ def build_reference_model(ref, spec, l2=0.0):
     return cls(lin, dnn, l2_reg_linear=l2, l2_reg_embedding=l2, device="cpu", **kw)
 
 
+ADAGRAD_SUM0 = 0.05
+
+
 def run_case(ref, case_):
     import torch
     import torch.nn.functional as F
@@ -321,9 +324,16 @@ def run_case(ref, case_):
         Xs, ys = zip(*[synth_inputs(spec, batch, rng) for _ in range(3)])
         out["X_steps"], out["y_steps"] = np.stack(Xs), np.stack(ys)
         start = {k: v.clone() for k, v in model.state_dict().items()}
-        for opt_name in ("sgd", "adagrad"):
+        # "adagradp": Adagrad with every accumulator preset to ADAGRAD_SUM0 -- from zero accumulators the first steps are
+        # lr * sign(g), so an element whose gradient cancels to ~1e-8 is rounding noise in ANY implementation (AFM's
+        # attention path); with a preset accumulator the step is lr * g / sqrt(s0 + g^2), smooth in g
+        for opt_name in ("sgd", "adagrad", "adagradp"):
             model.load_state_dict(start)
-            model.compile(opt_name, "binary_crossentropy", metrics=[])
+            model.compile("adagrad" if opt_name == "adagradp" else opt_name, "binary_crossentropy", metrics=[])
+            if opt_name == "adagradp":
+                for grp in model.optim.param_groups:
+                    for p in grp["params"]:
+                        model.optim.state[p]["sum"].fill_(ADAGRAD_SUM0)
             losses = []
             for Xb, yb in zip(Xs, ys):  # the reference's own step, basemodel.py:242-262
                 yp = model(torch.from_numpy(Xb)).squeeze()

@@ -99,6 +99,9 @@ class _Core(object):
     def dctr_mlp_train_workspace_floats(self, mref, B):
         return 16
 
+    def dctr_mlp_train_wgrad_counters(self, mref, B):
+        return 4
+
     @staticmethod
     def _dense_step(step, gptr, n):
         """dctr_dense_step_t applied to the n parameters behind the gradient at gptr (include/dctr.h)"""

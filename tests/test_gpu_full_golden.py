@@ -65,9 +65,26 @@ def _build(name):
 _ERRS = []
 
 
-def _note(tag, key, err, bar):
-    _ERRS.append({"model": tag, "tensor": key, "max_abs_err": float(err), "bar": float(bar),
-                  "err_over_bar": float(err / bar) if bar > 0 else None})
+def _note(tag, key, err, bar, n_split=None, n_used64=None, n=None):
+    e = {"model": tag, "tensor": key, "max_abs_err": float(err), "bar": float(bar),
+         "err_over_bar": float(err / bar) if bar > 0 else None}
+    if n_split is not None:
+        e.update(n_elements=int(n), n_reference_fp32_fp64_split=int(n_split), n_needed_the_fp64_side=int(n_used64))
+    _ERRS.append(e)
+
+
+def _either(got, ref32, ref64, bar):
+    """The fp32-or-fp64 rule for dense tensors, bounded (round 6): an element may take the reference's fp64 value instead of
+    its fp32 one ONLY where the fixture's own two evaluations are split by more than half the bar -- the elements of a weight
+    row that a ReLU branch flip moved (see the comment at the call site).  Everywhere else the reference's fp32 value alone
+    decides, so a kernel error cannot hide between the two.  Returns (max error under that rule, number of split elements,
+    number of elements that needed the fp64 side); the counts go to full_golden_errors.json."""
+    got, ref32, ref64 = (np.asarray(a, np.float64).reshape(-1) for a in (got, ref32, ref64))
+    d32, d64 = np.abs(got - ref32), np.abs(got - ref64)
+    split = np.abs(ref32 - ref64) > 0.5 * bar
+    d = np.where(split, np.minimum(d32, d64), d32)
+    used64 = split & (d32 > bar) & (d64 <= bar)
+    return (float(d.max()) if d.size else 0.0), int(split.sum()), int(used64.sum())
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -222,8 +239,8 @@ def test_full_size_train_step_matches_the_reference(name, opt):
             sens = 1.0 if opt == "sgd" else 1.0 / np.sqrt(FD.ADAGRAD_SUM0)      # d step / d g
             bar = 2e-5 * max(1.0, float(np.max(np.abs(ref64)))) + lr_eff * sens * 2e-5 * gmax
             gotk = pick(got)
-            err = float(np.max(np.minimum(np.abs(gotk - ref32), np.abs(gotk - ref64))))
-            _note(name, key + " (fp32 | fp64 step)", err, bar)
+            err, n_split, n_used64 = _either(gotk, ref32, ref64, bar)
+            _note(name, key + " (fp32 | fp64 step)", err, bar, n_split, n_used64, gotk.size)
             assert err <= bar, "%s %s: max|d| = %.3e (bar %.3e)" % (name, key, err, bar)
             if key + "/proj" in g:      # the elements between the samples: four random projections of the whole tensor (fp32 reference)
                 flat = got.reshape(-1)
@@ -235,7 +252,7 @@ def test_full_size_train_step_matches_the_reference(name, opt):
                 floor = 2.0 ** (np.floor(np.log2(max(wabs, 1e-30))) - 23) / lr     # ulp(w) / lr
                 gotg = (pick(w0[k].double().cpu().numpy()) - gotk) / lr
                 g32s, g64s = (g32.reshape(-1)[::FD.STRIDE], g64.reshape(-1)[::FD.STRIDE]) if gotg.shape != g64.shape else (g32, g64)
-                gerr = float(np.max(np.minimum(np.abs(gotg - g32s.reshape(gotg.shape)), np.abs(gotg - g64s.reshape(gotg.shape)))))
                 gbar = 2e-5 * gmax + 1.5 * floor
-                _note(name, gk + " (fp32 | fp64)", gerr, gbar)
+                gerr, n_split, n_used64 = _either(gotg, g32s.reshape(gotg.shape), g64s.reshape(gotg.shape), gbar)
+                _note(name, gk + " (fp32 | fp64)", gerr, gbar, n_split, n_used64, gotg.size)
                 assert gerr <= gbar, "%s %s: max|d| = %.3e (bar %.3e, err / bar %.2f)" % (name, gk, gerr, gbar, gerr / gbar)

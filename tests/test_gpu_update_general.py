@@ -13,6 +13,7 @@ from np_oracle import Oracle
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+ADAGRAD_SUM0 = 0.05
 
 
 def _sp(name, vocab, dim, emb=None):
@@ -112,6 +113,14 @@ def test_general_units_match_the_oracle(case, opt):
     assert plan.update[0] == opt
     m.train()
     st = None
+    if opt == "adagrad":
+        # every accumulator preset (like tests/fullsize_data.ADAGRAD_SUM0): from zero the first step is lr * sign(g) and an
+        # element whose gradient cancels to ~1e-9 has no defined answer; from s0 the step is smooth in g and EVERY element
+        # is held to the bar (rounds 5's "2e-4 of the elements may be off by 2.5 lr" clause is gone)
+        for grp in m.optim.param_groups:
+            for p in grp["params"]:
+                m.optim.state[p]["sum"].fill_(ADAGRAD_SUM0)
+        st = {k: np.full(np.shape(v), ADAGRAD_SUM0, np.float64) for k, v in o.P.items()}
     # (hot ids under plain SGD: ~3 500 gradients land on one row, lr 0.01 x that sum throws the model into another regime
     # and the second step compares chaos with chaos -- one step there)
     for step in range(1 if (mode == "hot" and opt == "sgd") else 2):
@@ -123,15 +132,7 @@ def test_general_units_match_the_oracle(case, opt):
     sd = m.state_dict()
     for k, v in o.P.items():
         err = max_abs(sd[k].cpu().numpy(), v)
-        # Adagrad's first steps are lr * sign(g): an element whose gradient cancels to ~1e-9 in fp32 lands on either side
-        # (the reference's own fp32 run does the same, tests/test_gpu_models.py) -- bounded by 2 lr there
-        bar = 2e-5 * max(1.0, float(np.max(np.abs(v)))) if opt == "sgd" else 2e-5 + 0.0
-        if opt == "adagrad":
-            d = np.abs(sd[k].cpu().numpy().astype(np.float64) - np.asarray(v, np.float64).reshape(sd[k].shape))
-            frac_bad = float((d > 2e-5).mean())
-            assert frac_bad <= 2e-4 and float(d.max()) <= 2.5 * lr, "%s: %.3e (%.2e of elements off)" % (k, d.max(), frac_bad)
-        else:
-            assert err <= bar, "%s: %.3e" % (k, err)
+        assert err <= 2e-5 * max(1.0, float(np.max(np.abs(v)))), "%s: %.3e" % (k, err)
 
 
 def test_general_update_is_bit_reproducible():
@@ -267,11 +268,15 @@ def test_past_the_envelope_the_atomic_fallback_still_matches_the_oracle(opt):
             assert max_abs(p.grad.cpu().numpy(), ref) <= 2e-5 * max(1.0, float(np.max(np.abs(ref)))), k
         return
     m.compile("adagrad", "binary_crossentropy", metrics=[])
+    for grp in m.optim.param_groups:      # preset accumulators: every element has a defined answer (see above)
+        for p in grp["params"]:
+            m.optim.state[p]["sum"].fill_(ADAGRAD_SUM0)
     m.train()
     loss, _, _ = m._train_step(Xd, yd)
-    lo, _ = o.train_step(X, y, optimizer="adagrad", lr=0.01, eps=1e-10, state=None)
+    st = {k: np.full(np.shape(v), ADAGRAD_SUM0, np.float64) for k, v in o.P.items()}
+    lo, _ = o.train_step(X, y, optimizer="adagrad", lr=0.01, eps=1e-10, state=st)
     assert abs(loss.item() - lo) <= 2e-5 * max(1.0, abs(lo))
     sd = m.state_dict()
-    for k, v in o.P.items():      # (Adagrad's first step is lr * sign(g): same bar as test_general_units_match_the_oracle)
-        d = np.abs(sd[k].cpu().numpy().astype(np.float64) - np.asarray(v, np.float64).reshape(sd[k].shape))
-        assert float((d > 2e-5).mean()) <= 2e-4 and float(d.max()) <= 0.025, "%s: %.3e" % (k, d.max())
+    for k, v in o.P.items():
+        err = max_abs(sd[k].cpu().numpy(), v)
+        assert err <= 2e-5 * max(1.0, float(np.max(np.abs(v)))), "%s: %.3e" % (k, err)

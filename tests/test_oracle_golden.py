@@ -85,6 +85,28 @@ def test_torch_port_matches_reference():
     assert max_abs(port.emb[0].weight.detach().numpy(), g["extra"]["adagrad3/embedding_dict.C1.weight"]) <= 2e-5
 
 
+STEP_FIXTURES = [n for n in golden_names() if "adagradp3_loss" in np.load(
+    os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", n + ".npz")).files]
+
+
+@pytest.mark.parametrize("name", STEP_FIXTURES)
+def test_oracle_adagrad_trajectory_from_preset_accumulators(name):
+    """``adagradp3``: three reference Adagrad steps with every accumulator preset to 0.05 (oracle/make_golden.py) -- the step is
+    then smooth in the gradient (no lr * sign(g) first step), so the fp64 oracle must land on the reference's fp32
+    parameters on EVERY element, AFM's attention path included."""
+    g = load_golden(name)
+    o = Oracle(g["spec"], g["params"], dtype=np.float64)
+    st = {k: np.full(np.shape(v), 0.05, np.float64) for k, v in o.P.items()}
+    losses = []
+    for Xb, yb in zip(g["extra"]["X_steps"], g["extra"]["y_steps"]):
+        lo, st = o.train_step(Xb, yb, optimizer="adagrad", lr=0.01, eps=1e-10, state=st)
+        losses.append(lo)
+    np.testing.assert_allclose(losses, g["extra"]["adagradp3_loss"], rtol=2e-5)
+    for k, v in g["extra"].items():
+        if k.startswith("adagradp3/"):
+            assert max_abs(o.P[k[10:]], v) <= 2e-5, k
+
+
 # ---- the reference's own model-test matrix (tests/golden/matrix, oracle/check_matrix.py) -----------------------------
 from helpers import feature_columns, load_matrix, matrix_id  # noqa: E402
 
