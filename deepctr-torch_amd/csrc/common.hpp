@@ -190,11 +190,9 @@ __device__ __forceinline__ float adagrad_param(float w, float g, float sn, float
   const float d = lr * q;
   return w - d;
 }
-__device__ __forceinline__ float sgd_param(float w, float g, float lr) {
-#pragma clang fp contract(off)
-  const float d = lr * g;
-  return w - d;
-}
+// (SGD: ONE rounding, p + (-lr) * g fused -- what `p.add_(g, alpha=-lr)` of torch.optim.SGD computes on the GPU and, through
+// Vectorized::fmadd, on the reference's CPU; tests/test_gpu_dense_multi.py holds this to 2e-7 of torch.optim)
+__device__ __forceinline__ float sgd_param(float w, float g, float lr) { return __builtin_fmaf(-lr, g, w); }
 __device__ __forceinline__ void dense_step_apply(const DenseStepDev& S, const float* gptr, float g) {
   if (S.kind < 0) return;
   const int64_t k = gptr - S.grad_base;

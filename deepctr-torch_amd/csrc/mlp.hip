@@ -2171,11 +2171,9 @@ __device__ __forceinline__ void mlp_train_body(const MlpArgs& A, const HeadArgs&
   }
   if (A.sync) step_signal(A.sync, DCTR_SYNC_TOWER);
   if constexpr (GATHER) {
-    // one more tower launch done: the launch's last workgroup advances sync[DCTR_SYNC_T_GEN].  Two readers: the NEXT tower
-    // launch on this queue (it waits until as many weight steps have happened) and -- when A.wt -- the weight-gradient launch
-    // of THIS step, spinning on another queue: everything it reads was stored write-through and is drained here.
+    // one more tower launch done (the next one waits until as many weight steps have happened): the launch's last workgroup
+    // advances sync[DCTR_SYNC_T_GEN].  Plain ordering suffices -- the reader is a LATER launch on this queue.
     if (G.wsync) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (this wave's write-through stores have arrived)
       __syncthreads();
       if (threadIdx.x == 0) {
         const int32_t n = static_cast<int32_t>(gridDim.x);
@@ -2224,10 +2222,6 @@ struct WgradArgs {
   // (dctr_embed_tower_train_step_sync) may then read every dense parameter.
   int32_t* cnt;        // [n_red] arrivals per reducer (zero at rest)
   int32_t* sync;       // the model's sync block (include/dctr.h)
-  int wait_tower;      // != 0: the launch may start before this step's tower launch has finished (another queue, no graph
-                       // edge): every workgroup first waits until sync[DCTR_SYNC_T_GEN] > sync[DCTR_SYNC_W_GEN]
-  unsigned long long wtimeout;
-  int32_t* err;        // nullable: bit 3 (8) when that wait ran out
   int n_red;           // GEMM tiles (+ 1 with a projection)
   float* gW[kMaxL];    // gradient tensors the sums go to
   float* gb[kMaxL];    // nullable
@@ -2331,24 +2325,6 @@ __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int blk = blockIdx.x;
   MLP_TRACE(A.trace, 0);
-  if (A.cnt && A.wait_tower) {
-    // one wave polls (relaxed, past the L1); the tower stored everything this launch reads write-through and drained it in
-    // front of its arrival, this CU's L1 holds none of those lines (nothing was read yet): plain loads from here on
-    if (wv == 0) {
-      const int32_t want = __hip_atomic_load(A.sync + DCTR_SYNC_W_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-      const unsigned long long t0 = wall_clock64();
-      for (;;) {
-        const int32_t have = __hip_atomic_load(A.sync + DCTR_SYNC_T_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (have - want >= 0) break;
-        if (wall_clock64() - t0 > A.wtimeout) {
-          if (lane == 0 && A.err) atomicOr(A.err, 8);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(8);
-      }
-    }
-    __syncthreads();
-  }
   int l = 0;
   while (l < A.n_layers && blk >= A.blk0[l + 1]) ++l;
   const int local = blk - A.blk0[l];
@@ -2964,7 +2940,7 @@ int bwd_stride(const dctr_mlp_t* m) {
 int launch_wgrad_reduce(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g,
                         float* workspace, const float* head_loss, const float* head_gbias, int n_head, float* loss,
                         float* g_bias, const dctr_dense_step_t* step, hipStream_t s, int32_t* sync = nullptr,
-                        int32_t* cnt = nullptr, int wait_tower = 0, int32_t timeout_us = 0, int32_t* err = nullptr) {
+                        int32_t* cnt = nullptr) {
   const WgradPlan P = plan_wgrad(m, B);
   if (cnt && static_cast<int64_t>(P.S) * P.slab * 4 >= (int64_t(1) << 31)) return DCTR_ENOSUP;
   {
@@ -2979,7 +2955,6 @@ int launch_wgrad_reduce(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32
     a.off_o = P.off_o; a.slab = P.slab; a.x = x; a.ldx = ld_x; a.w_out = m->w_out; a.g = g; a.part = workspace;
     a.trace = g_mlp_trace ? g_mlp_trace + 16ull * 8192 : nullptr;
     a.cnt = cnt; a.sync = sync;
-    a.wait_tower = wait_tower; a.wtimeout = static_cast<unsigned long long>(timeout_us > 0 ? timeout_us : 0) * 100ull; a.err = err;
     a.n_red = P.blk0[m->n_layers] / P.S + (m->w_out ? 1 : 0);
     for (int l = 0; l < kMaxL; ++l) {
       a.gW[l] = l < m->n_layers ? m->layer[l].gW : nullptr;
@@ -3232,7 +3207,7 @@ int embed_tower_train_step(const dctr_plan_t* plan, const float* X, int64_t ldx,
   const int re = gather_envelope(plan, m, B, T);
   if (re != DCTR_OK) return re;
   MlpArgs& a = T.a;
-  a.x = out; a.ldx = ld_out; a.gx = gx; a.ldgx = ld_gx; a.sync = nullptr; a.wt = wsync ? 1 : 0;
+  a.x = out; a.ldx = ld_out; a.gx = gx; a.ldgx = ld_gx; a.sync = nullptr; a.wt = 0;
   const WgradPlan P = plan_wgrad(m, B);
   const int n_tiles = (B + kTM - 1) / kTM;
   HeadArgs hd;
@@ -3287,12 +3262,10 @@ extern "C" size_t dctr_mlp_train_wgrad_counters(const dctr_mlp_t* m, int32_t B) 
 
 extern "C" int dctr_mlp_train_wgrad_sync(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g_logit,
                                          float* workspace, float* loss, float* g_bias, const dctr_dense_step_t* step,
-                                         int32_t* sync, int32_t* counters, int32_t wait_tower, int32_t timeout_us,
-                                         int32_t* err, dctr_stream_t stream) {
+                                         int32_t* sync, int32_t* counters, dctr_stream_t stream) {
   const int rc = check_mlp(m, B);
   if (rc != DCTR_OK) return rc;
   if (!m->w_out || !x || !loss || !g_logit || !workspace || !sync || !counters) return DCTR_EINVAL;
-  if (wait_tower && timeout_us <= 0) return DCTR_EINVAL;
   if (ld_x % 4 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0) return DCTR_EALIGN;
   for (int l = 0; l < m->n_layers; ++l)
     if (!m->layer[l].gW || reinterpret_cast<uintptr_t>(m->layer[l].gW) % 16 != 0) return DCTR_EALIGN;
@@ -3305,7 +3278,7 @@ extern "C" int dctr_mlp_train_wgrad_sync(const dctr_mlp_t* m, const float* x, in
   float* part_loss = workspace + static_cast<size_t>(P.slab) * P.S;
   float* part_gb = part_loss + n_tiles;
   return launch_wgrad_reduce(m, x, ld_x, B, g_logit, workspace, part_loss, part_gb, n_tiles, loss, g_bias, step,
-                             static_cast<hipStream_t>(stream), sync, counters, wait_tower ? 1 : 0, timeout_us, err);
+                             static_cast<hipStream_t>(stream), sync, counters);
 }
 
 // ---- CrossNet, matrix parameterisation (interaction.py:448-451) ------------------------------------------------------

@@ -65,7 +65,7 @@ class GraphedTrainStep(object):
                    for _ in range(self.n_slots)]
         self.x = [[self.xg[s][j] for j in range(self.S)] for s in range(self.n_slots)]
         self.y = [[self.yg[s][j] for j in range(self.S)] for s in range(self.n_slots)]
-        self.graphs, self.outputs, self.chains = [], [], []
+        self.graphs, self.outputs = [], []
         self.plan_version = None
         self._slot, self._j = 0, 0
         self._side = self._ready = self._free = self._free_ev = None
@@ -75,54 +75,24 @@ class GraphedTrainStep(object):
         return self.graphs[0] if self.graphs else None
 
     def capture(self, xb, yb):
-        """Capture ``steps_per_graph`` steps per buffer group on (xb, yb).  Capture does not execute.
-
-        Round 6: a model on the step engine (_hip/step.py) whose two queues make progress independently is captured as
-        THREE linear graphs per group -- the main chain (tower, update per step), the side chain (weight gradients, the
-        pre-pass two steps ahead) and a one-launch prologue (the first batch's pre-pass) -- which _launch() replays on two
-        streams.  The chains meet through words in memory only (include/dctr.h DCTR_SYNC_W_GEN / T_GEN): inside a hipGraph
-        every cross-queue edge costs the queue it touches 6-12 us, and the single-capture step has two of them on its critical
-        cycle (profiles/r06_step_edges.txt)."""
+        """Capture ``steps_per_graph`` steps per buffer group on (xb, yb).  Capture does not execute."""
         model = self.model
         plan = model.model_plan()
         plan.bind(xb.device)
         pool = None
-        self.graphs, self.outputs, self.chains = [], [], []
-        eng = (getattr(model, "_fused", None) or {}).get("engine")
-        chained = eng is not None and eng.chains_ok(xb, yb)
-        cap_stream = _streams.side_stream(xb.device, "capture")
+        self.graphs, self.outputs = [], []
         for s in range(self.n_slots):
             for j in range(self.S):
                 self.x[s][j].copy_(xb)
                 self.y[s][j].copy_(yb)
             torch.cuda.synchronize()
-            if eng is not None:
-                eng._prepassed = None        # (a capture that was abandoned half-way must not lend its pre-pass to this one)
-            if chained:
-                got = {}
-                try:
-                    for chain in ("pro", "main", "side"):
-                        g = torch.cuda.CUDAGraph()
-                        outs = []
-                        with no_gc_during_capture(), torch.cuda.graph(g, pool=pool, stream=cap_stream):
-                            for j in range(self.S):
-                                eng.chain = chain
-                                eng.chain_ctx = {"j": j, "S": self.S,
-                                                 "x1": self.x[s][j + 1] if j + 1 < self.S else None,
-                                                 "x2": self.x[s][j + 2] if j + 2 < self.S else None}
-                                outs.append(model._train_step(self.x[s][j], self.y[s][j]))
-                        if pool is None:
-                            pool = g.pool()
-                        got[chain] = (g, outs)
-                finally:
-                    eng.chain, eng.chain_ctx = None, None
-                self.graphs.append(got["main"][0])
-                self.chains.append((got["pro"][0], got["side"][0]))
-                self.outputs.append(got["main"][1])
-                continue
             g = torch.cuda.CUDAGraph()
             outs = []
-            with no_gc_during_capture(), torch.cuda.graph(g, pool=pool, stream=cap_stream):
+            eng = (getattr(model, "_fused", None) or {}).get("engine")
+            if eng is not None:
+                eng._prepassed = None        # (a capture that was abandoned half-way must not lend its pre-pass to this one)
+            with no_gc_during_capture(), torch.cuda.graph(g, pool=pool,
+                                                          stream=_streams.side_stream(xb.device, "capture")):
                 try:
                     for j in range(self.S):
                         model._defer_dense_join = j < self.S - 1      # (see BaseModel._train_step_fused)
@@ -136,7 +106,6 @@ class GraphedTrainStep(object):
             if pool is None:
                 pool = g.pool()
             self.graphs.append(g)
-            self.chains.append(None)
             self.outputs.append(outs)
         self.plan_version = plan.version
         self._side = _streams.side_stream(xb.device, "stage")
@@ -144,9 +113,6 @@ class GraphedTrainStep(object):
         self._free_ev = [torch.cuda.Event() for _ in range(self.n_slots)]
         self._free = [None] * self.n_slots
         self._slot, self._j = 0, 0
-        if chained:
-            self._chain_side = _streams.side_stream(xb.device, "seg")
-            self._ev_pro, self._ev_side = torch.cuda.Event(), torch.cuda.Event()
         return self
 
     def valid_for(self, xb):
@@ -237,24 +203,7 @@ class GraphedTrainStep(object):
         main = torch.cuda.current_stream(self.x[s][0].device)
         self._ready[s].record(self._side)
         main.wait_event(self._ready[s])
-        if self.chains[s] is not None:
-            # two chains on two queues: the prologue (first batch's pre-pass) on the side queue, behind everything the caller's
-            # queue holds (the previous group's main chain, whatever else touched the tables); the main chain behind the
-            # prologue; the side chain beside it; the caller's queue ends up behind both
-            side = self._chain_side
-            g_pro, g_side = self.chains[s]
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                g_pro.replay()
-                self._ev_pro.record(side)
-            main.wait_event(self._ev_pro)
-            self.graphs[s].replay()
-            with torch.cuda.stream(side):
-                g_side.replay()
-                self._ev_side.record(side)
-            main.wait_event(self._ev_side)
-        else:
-            self.graphs[s].replay()
+        self.graphs[s].replay()
         # a replay runs the captured dctr_lazy_apply launches without passing through LazyState.apply(): the host
         # flag that makes flush() / state_dict() / predict() bring every row up to date must be raised here too
         lazy = getattr(self.model.model_plan(), "_lazy", None)

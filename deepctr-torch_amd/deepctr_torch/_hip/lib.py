@@ -192,8 +192,7 @@ SIGNATURES = {
     "dctr_embed_tower_train_step": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, ctypes.POINTER(Mlp), _I32, _I32, _P, _P,
                                                    _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P]),
     "dctr_mlp_train_wgrad_counters": (ctypes.c_size_t, [ctypes.POINTER(Mlp), _I32]),
-    "dctr_mlp_train_wgrad_sync": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _I32,
-                                                 _P, _P]),
+    "dctr_mlp_train_wgrad_sync": (ctypes.c_int, [ctypes.POINTER(Mlp), _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dctr_embed_tower_train_step_sync": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, ctypes.POINTER(Mlp), _I32, _I32, _P,
                                                         _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _I32, _P]),
     "dctr_sizeof_dense_step": (ctypes.c_size_t, []),

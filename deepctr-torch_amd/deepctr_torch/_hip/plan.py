@@ -630,7 +630,7 @@ class EmbeddingPlan(object):
                     import sys
                     print("dctr: an in-kernel wait timed out (bits %d) -- ignored (DCTR_DBG_IGNORE_WAIT)" % bits, file=sys.stderr)
                     return
-                if bits & 12:   # (dctr_embed_tower_train_step_sync / dctr_mlp_train_wgrad_sync: an in-kernel wait ran out)
+                if bits & 12:   # (dctr_embed_tower_train_step_sync: its wait for the weights' generation ran out)
                     raise RuntimeError("a train step's tower launch gave up waiting for the previous step's dense optimizer "
                                        "step (DCTR_SYNC_W_GEN): the two queues of the step fell out of step -- results "
                                        "since the last check are not to be trusted (DCTR_STEP_TOPOLOGY=update_side avoids "

@@ -24,19 +24,17 @@ captured step.
 The arithmetic is the two-launch path's, in its order: parameters after any number of steps are bit-identical
 (tests/test_gpu_step_engine.py).
 
-Round 6, the default topology (``DCTR_STEP_TOPOLOGY=weights_flag``; ``update_side`` is the round-4 one above):
+Round 6, an OPT-IN topology (``DCTR_STEP_TOPOLOGY=weights_flag``; bit-identical, measured slower than the default:
+``GatherStep.topology``):
 
-    main queue :  tower(k) -> dctr_embed_update(k) -> tower(k+1) ...            the critical cycle, ONE queue
+    main queue :  tower(k) -> dctr_embed_update(k) -> tower(k+1) ...
     side queue :  [after tower(k)] dctr_mlp_train_wgrad_sync(k) -> [after update(k)] pre-pass of batch k+1
 
-Both of the old cycle's cross-queue edges (tower -> update, update -> next tower: ~12 us each in a hipGraph) are gone from
-it.  What tower(k+1) needs from the side queue -- the dense parameters stepped by the weight-gradient launch of step k -- it
-waits for INSIDE the kernel, after it has staged its X tile and gathered its table rows (the 11 us it spends before it
-touches a weight): a word in memory the weight-gradient launch advances when its last reducer has stored the parameters
-(include/dctr.h, DCTR_SYNC_W_GEN).  The reduction launch is folded into the weight-gradient launch (a tile's last arriver
-sums the partial slabs in slab order: the same bits).  Because tower(k+1) now runs beside the weight gradients of step k,
-which read step k's activations, the activation buffers exist twice and alternate.  The only cross-queue graph edges left
-(tower -> weight gradients, pre-pass -> update) have 20-50 us of slack.
+What tower(k+1) needs from the side queue -- the dense parameters stepped by the weight-gradient launch of step k -- it waits
+for INSIDE the kernel, after it has staged its X tile and gathered its table rows: a word in memory the weight-gradient launch
+advances when its last reducer has stored the parameters (include/dctr.h, DCTR_SYNC_W_GEN).  The reduction is folded into the
+weight-gradient launch (a tile's last arriver sums the partial slabs in slab order: the same bits).  tower(k+1) then runs
+beside the weight gradients of step k, which read step k's activations: the activation buffers exist twice and alternate.
 """
 import contextlib
 import ctypes
@@ -62,7 +60,7 @@ class _Buffers(object):
     ``alt``: a second set of what the tower launch writes and the weight-gradient launch reads (out, gx, fm_s, g_logit,
     hs, dhs, ws, desc) -- the weights_flag topology alternates between the two; everything else is shared."""
     __slots__ = ("B", "out", "gx", "fm_s", "g_logit", "hs", "dhs", "ws", "ids_t", "parts_t", "desc", "upd_ws", "upd_n",
-                 "keep", "pinned", "den_t", "amax", "alt", "cnt", "psets")
+                 "keep", "pinned", "den_t", "amax", "alt", "cnt")
 
 
 class GatherStep(object):
@@ -83,8 +81,6 @@ class GatherStep(object):
         self._sync = None         # the weights_flag topology's sync block (include/dctr.h DCTR_SYNC_W_GEN / T_GEN)
         self._parity = 0          # which activation set the next step writes
         self._pool, self._pool_i = None, 0
-        self.chain, self.chain_ctx = None, None    # set by _hip/graph.py while it captures one chain of a group of steps
-        self._probed, self._outs = {}, {}
 
     # ---- applicability ------------------------------------------------------------------------------------------
     @staticmethod
@@ -164,7 +160,6 @@ class GatherStep(object):
         a.fm_s = torch.empty_like(b.fm_s) if b.fm_s is not None else None
         a.g_logit, a.ws = torch.empty_like(b.g_logit), torch.empty_like(b.ws)
         b.alt = a
-        b.psets = None
         b.cnt = torch.zeros((max(1, lib.dctr_mlp_train_wgrad_counters(ctypes.byref(b.desc), int(B))),), dtype=torch.int32,
                             device=dev)
         # Least recently used goes first -- but never a set a hipGraph was captured on: the graph holds raw addresses of
@@ -199,9 +194,7 @@ class GatherStep(object):
         a multi-step hipGraph): its pre-pass is enqueued on the side queue right behind this step's update, so that it
         runs in the shadow of the queue hop back to the main queue instead of beside the next tower launch (measured:
         the pre-pass's 1118 workgroups beside the tower cost the tower 4 of its 53 us, profiles/r04_*timeline*)."""
-        if self.chain is not None:
-            return self._step_chain(xb, yb, mode)
-        if xb.device.type == "cuda" and self.topology() == "weights_flag_edges":
+        if xb.device.type == "cuda" and self.topology() == "weights_flag":
             return self._step_flag(xb, yb, mode, next_xb)
         lib = L.lib()
         model, slab = self.model, self.slab
@@ -301,162 +294,14 @@ class GatherStep(object):
     # ---- round 6: tower -> update -> tower on one queue, the weights handed over through a word in memory --------------
     @staticmethod
     def topology():
-        """weights_flag (default): groups of steps captured by _hip/graph.py run as TWO chains on two queues that meet only
-        through words in memory (_step_chain); eager steps and anything else take the round-4 two-queue step (update_side).
-        weights_flag_edges: the same hand-over inside ONE capture, ordered by graph edges (an experiment: every cross-queue
-        edge costs the queue it touches 6-12 us -- profiles/r06_step_edges.txt -- so this is slower than update_side)."""
-        t = os.environ.get("DCTR_STEP_TOPOLOGY", "weights_flag")
-        return t if t in ("weights_flag", "weights_flag_edges", "update_side", "serial") else "weights_flag"
-
-    # ---- two chains, no graph edge between them ---------------------------------------------------------------------
-    def chains_ok(self, xb, yb, main=None):
-        """May groups of steps on this batch shape run as two separately captured chains (see _step_chain)?  Needs the two
-        queues to make progress independently: probed once per pair of streams with a wait on one and its signal on the
-        other, in both directions (two streams that share a hardware queue would leave every in-kernel wait to its
-        time-out)."""
-        if xb.device.type != "cuda" or self.topology() != "weights_flag" or not self.supports(xb, yb):
-            return False
-        dev = xb.device
-        main = main or torch.cuda.current_stream(dev)
-        side = _streams.side_stream(dev, "seg")
-        key = (main.cuda_stream, side.cuda_stream)
-        hit = self._probed.get(key)
-        if hit is None:
-            hit = self._probed[key] = self._probe(main, side, dev)
-        return hit
-
-    def _probe(self, main, side, dev):
-        if torch.cuda.is_current_stream_capturing():
-            return False
-        lib = L.lib()
-        blk = torch.zeros((L.SYNC_INTS,), dtype=torch.int32, device=dev)
-        torch.cuda.synchronize(dev)
-        ok = True
-        for waiter, signaller, sig in ((main, side, 0), (side, main, 1)):
-            with torch.cuda.stream(waiter):
-                L.check(lib.dctr_step_wait(_ptr(blk), sig, 20000, L.stream_handle(dev)), "dctr_step_wait")
-            with torch.cuda.stream(signaller):
-                L.check(lib.dctr_step_signal(_ptr(blk), sig, L.stream_handle(dev)), "dctr_step_signal")
-            torch.cuda.synchronize(dev)
-            if int(blk[L.SYNC_ERR].item()) != 0:
-                ok = False
-                break
-        return ok
-
-    def chain_outputs(self, xb):
-        """(loss, y_pred) of the step on this static batch: ONE pair per batch address, shared by the captures of the two
-        chains (the tower launch writes y_pred in one graph, the weight-gradient launch the loss in the other)."""
-        key = (xb.data_ptr(), int(xb.shape[0]))
-        o = self._outs.get(key)
-        if o is None:
-            dev = xb.device
-            o = self._outs[key] = (torch.zeros((), dtype=torch.float32, device=dev),
-                                   torch.zeros((xb.shape[0],), dtype=torch.float32, device=dev))
-        return o
-
-    def _prepass_set(self, b, k, dev):
-        """the k-th of three (ids_t, parts_t, den_t, update workspace) sets: the pre-pass runs two steps ahead of its update"""
-        sets = getattr(b, "psets", None)
-        if sets is None:
-            plan = self.model.model_plan()
-            sets = [(b.ids_t, b.parts_t, b.den_t, b.upd_ws, b.upd_n)]
-            for slot in (1, 2):
-                ws, n = plan.update_workspace(b.B, dev, always=True, slot=10 + slot)
-                den = torch.empty_like(b.den_t) if b.den_t is not None else None
-                sets.append((torch.empty_like(b.ids_t), torch.empty_like(b.parts_t), den, ws, n))
-            b.psets = sets
-        return sets[k % 3]
-
-    def _step_chain(self, xb, yb, mode):
-        """One step's share of ONE chain (self.chain: "main" | "side" | "pro"), enqueued on the CURRENT stream -- called
-        while _hip/graph.py captures the chain into its own linear hipGraph.  self.chain_ctx = {j, S, x1, x2}: the step's
-        index in the group and the static batches of the next two steps (None past the group's end).
-
-            main : tower(j) [waits in its kernel for the weights of step j-1] ; update(j)
-            pro  : pre-pass(0)                                 (j == 0 only; replayed in front of the two others)
-            side : [j == 0: pre-pass(1)] ; weight gradients(j) [wait in their kernel for tower(j)] ; pre-pass(j+2)
-
-        Why update(j) may rely on pre-pass(j) without waiting for anything: it follows tower(j) on its queue; tower(j) has
-        waited for the weights of step j-1; the weight-gradient launch of step j-1 is BEHIND pre-pass(j) on the side queue
-        (j = 0: the prologue graph is replayed, and waited for by an event, in front of the main chain).  Buffers: activations
-        alternate between two sets (the weight gradients of step j read while tower(j+1) writes), the pre-pass's outputs
-        between three (written two steps ahead of their update)."""
-        lib = L.lib()
-        model, slab = self.model, self.slab
-        plan = model.model_plan()
-        dev, B = xb.device, xb.shape[0]
-        b = self._buffers(B, dev)
-        ctx = self.chain_ctx
-        j = int(ctx["j"])
-        chain = self.chain
-        if torch.cuda.is_current_stream_capturing():
-            b.pinned = True
-        a = b if (j & 1) == 0 else b.alt
-        cplan = plan.bind(dev)
-        y = yb.reshape(-1)
-        if chain == "main" and (y.dtype != torch.float32 or not y.is_contiguous()):
-            y = y.float().contiguous()       # (only the tower launch reads the labels)
-        loss, y_pred = self.chain_outputs(xb)
-        kind = plan.update[0]
-        opt = L.UPD_ADAGRAD if kind == "adagrad" else L.UPD_SGD
-        lr = float(plan.update[1])
-        eps = float(plan.update[2]) if kind == "adagrad" else 0.0
-        if not slab.begin_inline_step(mode[0], mode[1], mode[2] if len(mode) > 2 else 0.0):
-            raise RuntimeError("the gather step needs a plain SGD / Adagrad dense optimizer")
-        try:
-            inline = slab.inline
-            bias = model.out.bias
-            g_bias = slab.grad_of(bias)
-            lw = plan.wide_dense_weight
-            g_wd = slab.grad_of(lw) if lw is not None else None
-            err = plan.err_flag(dev)
-            if self._sync is None or self._sync.device != dev:
-                self._sync = torch.zeros((L.SYNC_INTS,), dtype=torch.int32, device=dev)
-            units, n_units = plan.units_ptr(), plan.n_grid_units
-            ld = plan.ld_out
-            ld_s = a.fm_s.stride(0) if a.fm_s is not None else 0
-            sh = L.stream_handle(dev)
-            timeout_us = int(os.environ.get("DCTR_STEP_WAIT_US", "200000"))
-
-            def prepass(x, k):
-                ids_t, parts_t, den_t, ws_u, n_u = self._prepass_set(b, k, dev)
-                plan.point_step_buffers(den_t, b.amax)
-                L.check(lib.dctr_embed_ids(cplan, units, n_units, _ptr(x), x.stride(0), B, _ptr(ids_t), _ptr(parts_t), sh),
-                        "dctr_embed_ids")
-                L.check(lib.dctr_embed_segments(cplan, units, n_units, plan.max_vocab, _ptr(ids_t), _ptr(parts_t), B,
-                                                _ptr(ws_u), n_u, sh), "dctr_embed_segments")
-
-            if chain == "pro":
-                if j == 0:
-                    prepass(xb, 0)
-            elif chain == "main":
-                self.steps_run += 1
-                ids_t, parts_t, den_t, ws_u, n_u = self._prepass_set(b, j, dev)
-                plan.point_step_buffers(den_t, b.amax)
-                L.check(lib.dctr_embed_tower_train_step_sync(
-                    cplan, _ptr(xb), xb.stride(0), ctypes.byref(a.desc), B, 1 if self.want_fm else 0, _ptr(bias), _ptr(y),
-                    _ptr(y_pred), _ptr(a.g_logit), _ptr(a.gx), ld, _ptr(a.out), ld, _ptr(a.fm_s), ld_s, _ptr(err), _ptr(a.ws),
-                    _ptr(self._sync), timeout_us, sh), "dctr_embed_tower_train_step_sync")
-                L.check(lib.dctr_embed_update(cplan, units, n_units, plan.max_vocab, _ptr(ids_t), _ptr(parts_t), B,
-                                              _ptr(a.gx), ld, _ptr(a.out), ld, _ptr(a.fm_s), ld_s,
-                                              _ptr(a.g_logit) if self.want_fm else None,
-                                              _ptr(a.g_logit) if plan.has_wide else None, 1, opt, lr, eps, _ptr(xb),
-                                              xb.stride(0), _ptr(g_wd), ctypes.byref(inline) if g_wd is not None else None,
-                                              _ptr(ws_u), n_u, 1, sh), "dctr_embed_update")
-            elif chain == "side":
-                if j == 0 and ctx.get("x1") is not None:
-                    prepass(ctx["x1"], 1)
-                L.check(lib.dctr_mlp_train_wgrad_sync(ctypes.byref(a.desc), _ptr(a.out), ld, B, _ptr(a.g_logit), _ptr(a.ws),
-                                                      _ptr(loss), _ptr(g_bias), ctypes.byref(inline), _ptr(self._sync),
-                                                      _ptr(b.cnt), 1, timeout_us, _ptr(err), sh), "dctr_mlp_train_wgrad_sync")
-                if ctx.get("x2") is not None:
-                    prepass(ctx["x2"], j + 2)
-            else:
-                raise ValueError(chain)
-        finally:
-            slab.inline_done = True
-            slab.end_inline_step()
-        return loss, y_pred
+        """update_side (default): the round-4 two-queue step.  weights_flag (round 6, opt-in): tower -> update on ONE queue,
+        the dense parameters handed to the next tower launch through a word in memory (_step_flag) -- bit-identical
+        (tests/test_gpu_step_engine.py) and measured SLOWER, 0.107 against 0.090 ms per step: every cross-queue edge of a
+        hipGraph costs the queues it touches 6-12 us, and this arrangement still has three of them per step on the main queue
+        (profiles/r06_step_edges.txt; DESIGN.md section 3 has the whole account, including the edge-free two-graph variant
+        that was built, measured at 0.104 ms and removed)."""
+        t = os.environ.get("DCTR_STEP_TOPOLOGY", "update_side")
+        return t if t in ("weights_flag", "update_side", "serial") else "update_side"
 
     def _event(self):
         """events that live as long as the engine, handed out round-robin (see _join_event)"""
@@ -540,8 +385,7 @@ class GatherStep(object):
             with torch.cuda.stream(side):
                 L.check(lib.dctr_mlp_train_wgrad_sync(ctypes.byref(a.desc), _ptr(a.out), ld, B, _ptr(a.g_logit), _ptr(a.ws),
                                                       _ptr(loss), _ptr(g_bias), ctypes.byref(inline), _ptr(self._sync),
-                                                      _ptr(b.cnt), 0, 0, None, L.stream_handle(dev)),
-                        "dctr_mlp_train_wgrad_sync")
+                                                      _ptr(b.cnt), L.stream_handle(dev)), "dctr_mlp_train_wgrad_sync")
             # main queue: the update, right behind the tower (its pre-pass finished long ago: an edge with slack)
             if not (dbg & 2):
                 main.wait_event(ev_pre)

@@ -667,11 +667,6 @@ int dctr_embed_tower_train_step(const dctr_plan_t* plan, const float* X, int64_t
  *                                    partial slabs in slab order and steps the parameters (the arithmetic of the separate
  *                                    reduction launch, bit for bit), then the launch advances sync[DCTR_SYNC_W_GEN].
  *                                    counters: dctr_mlp_train_wgrad_counters(m, B) int32, zero before the first call.
- *                                    wait_tower != 0: the call may be enqueued on a queue that is NOT ordered behind this
- *                                    step's tower launch -- every workgroup then waits in the kernel until
- *                                    sync[DCTR_SYNC_T_GEN] > sync[DCTR_SYNC_W_GEN] (the _sync tower launch stores what this
- *                                    one reads write-through and drains it in front of its arrival); a wait longer than
- *                                    timeout_us raises bit 3 (8) of *err and goes on.
  *   dctr_embed_tower_train_step_sync dctr_embed_tower_train_step that requests no dense parameter (tower weights, biases,
  *                                    the projection, `bias`) before sync[DCTR_SYNC_W_GEN] has caught up with the number of
  *                                    tower launches finished on this block; a wait that exceeds timeout_us raises bit 2 (4)
@@ -679,8 +674,7 @@ int dctr_embed_tower_train_step(const dctr_plan_t* plan, const float* X, int64_t
 size_t dctr_mlp_train_wgrad_counters(const dctr_mlp_t* m, int32_t B);
 int dctr_mlp_train_wgrad_sync(const dctr_mlp_t* m, const float* x, int64_t ld_x, int32_t B, const float* g_logit,
                               float* workspace, float* loss, float* g_bias, const dctr_dense_step_t* step, int32_t* sync,
-                              int32_t* counters, int32_t wait_tower, int32_t timeout_us, int32_t* err,
-                              dctr_stream_t stream);
+                              int32_t* counters, dctr_stream_t stream);
 int dctr_embed_tower_train_step_sync(const dctr_plan_t* plan, const float* X, int64_t ldx, const dctr_mlp_t* m, int32_t B,
                                      int32_t want_fm, const float* bias, const float* y, float* y_pred, float* g_logit,
                                      float* gx, int64_t ld_gx, float* out, int64_t ld_out, float* fm_s, int64_t ld_s,

@@ -163,10 +163,17 @@ def test_engine_runs_pooled_fields_graph_replayed():
           _run(True, "deepfm", 3000, "adagrad", 42, True, pooled=(8, 5)), "deepfm + pooled")
 
 
-@pytest.mark.parametrize("topo", ["serial"])
+@pytest.mark.parametrize("topo", ["serial", "weights_flag"])
 def test_engine_topologies(topo):
+    """Every way of enqueueing the step leaves the default's bits.  Round 6: ``weights_flag`` (tower -> update on one queue,
+    the dense parameters handed to the next tower launch through DCTR_SYNC_W_GEN, the reduction folded into the
+    weight-gradient launch: _hip/step.py) -- opt-in, slower than the default, kept exact."""
     ref = _run(True, "deepfm", 3000, "adagrad", 42, True)
     _same(ref, _run(True, "deepfm", 3000, "adagrad", 42, True, topo=topo), topo)
+    if topo == "weights_flag":
+        _same(_run(True, "deepfm", 3000, "sgd", 22, True, pooled=(4, 3, 5)),
+              _run(True, "deepfm", 3000, "sgd", 22, True, topo=topo, pooled=(4, 3, 5)), topo + " + pooled")
+        _same(_run(True, "wdl", 3000, "sgd", 6, False), _run(True, "wdl", 3000, "sgd", 6, False, topo=topo), topo + " eager")
 
 
 def test_engine_long_run_on_large_tables():
