@@ -60,9 +60,10 @@ def parse():
                          "torch.distributed collectives issued by the host between hipGraph segments; 'direct' = copies into "
                          "the peers' IPC-mapped buffers + arrival words, the whole step one hipGraph (validated with N "
                          "processes on ONE GPU and at one rank; never run across GPUs: no multi-GPU box was available to the "
-                         "build); 'auto' = direct at one rank, rccl at N > 1 (the path that cannot surprise an unattended "
-                         "scaling run); 'try-direct' = at N > 1 direct if a two-step self-check succeeds on every rank, else "
-                         "rccl")
+                         "build); 'auto' (= 'try-direct') = direct at one rank; at N > 1 direct when the exchange's "
+                         "self-test (bytes pushed into / pulled out of every peer's buffers by kernels, three rounds, "
+                         "compared element by element) passes on EVERY rank, else rccl -- the JSON line and stderr say "
+                         "which ran")
     ap.add_argument("--kernel-iters", type=int, default=50, help="event-timed launches per hot-path kernel")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed block of --steps steps is run this many times (each bracketed by a synchronize, and a "
@@ -811,40 +812,14 @@ def main():
         # table-sharded embeddings + data-parallel tower (SURVEY.md 8(e) option S); the compute between the
         # collectives is captured as hipGraph segments after a few eager steps
         from deepctr_torch import parallel as par
-        exchange = args.exchange
-        exch_info = {"requested": args.exchange, "self_check": None}
-        if exchange == "auto":
-            exchange = "direct" if (on_gpu and world == 1) else "rccl"
-        elif exchange == "try-direct":
-            exchange = "direct" if (on_gpu and world == 1) else ("direct?" if on_gpu else "rccl")
-        if exchange == "direct?":
-            # N > 1 on GPUs: the direct exchange has only ever run between processes sharing one GPU.  Try it on two
-            # un-timed steps of a throw-away copy of the model; any exception or timed-out wait on ANY rank -> RCCL.
-            ok = 1
-            try:
-                probe_model = build_model(args, device)
-                probe = par.ShardedTrainer(probe_model, use_graphs=False, exchange="direct")
-                for k in range(2):
-                    j = k % n_batches
-                    probe.train_step(X[j * B:(j + 1) * B], y[j * B:(j + 1) * B], next_xb=X[(j + 1) * B:(j + 2) * B])
-                torch.cuda.synchronize()
-                probe._dx.check()
-                probe.close()
-                del probe, probe_model
-                torch.cuda.empty_cache()
-            except Exception as exc:
-                print("direct exchange self-check failed on rank %d (%s: %s): using RCCL" % (rank, type(exc).__name__, exc),
-                      file=sys.stderr)
-                ok = 0
-            flag = torch.tensor([ok], device=device, dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            exchange = "direct" if int(flag.item()) == 1 else "rccl"
-            exch_info["self_check"] = "passed on every rank" if exchange == "direct" else "failed on at least one rank"
-            exch_info["self_check_this_rank"] = bool(ok)
-        exch_info["ran"] = exchange
+        # --exchange auto (the default) / try-direct: the direct exchange wherever it can be trusted -- one rank always; N > 1
+        # after parallel.DirectExchange.self_test has passed on EVERY rank (a model-free check of the bytes kernels push into /
+        # pull out of the peers' IPC-mapped buffers, three rounds over the same addresses) -- RCCL otherwise
+        exchange, note = par.resolve_exchange(args.exchange, device) if on_gpu else ("rccl", "no GPU")
+        exch_info = {"requested": args.exchange, "ran": exchange, "self_check": note}
         if rank == 0:     # which exchange the timed steps use, said BEFORE they run (stderr: stdout carries the JSON line)
-            print("bench: sharded step over the %s exchange (requested %s; direct-exchange self-check: %s)" % (
-                exchange, args.exchange, exch_info["self_check"] or "not run"), file=sys.stderr, flush=True)
+            print("bench: sharded step over the %s exchange (requested %s; %s)" % (exchange, args.exchange, note),
+                  file=sys.stderr, flush=True)
         parallel = par.ShardedTrainer(model, use_graphs=False, exchange=exchange)
 
         def batch(i):

@@ -16,7 +16,8 @@
 //   k_lazy_apply    (after the backward): the group that wins atomicMax(stamp[row], t+1) applies step t+1 with
 //                   g = gacc[row] + 2*lambda*w and zeroes gacc[row];
 //   k_lazy_flush    (before anything else reads the tables: predict / evaluate / state_dict): replays every row to t;
-//   dctr_lazy_sweep (round 5; in front of every catch-up): the flush of the (t mod K)-th of K windows of rows -- no row
+//   dctr_lazy_sweep (round 5; once per step BEHIND the catch-up, finished before the step counter moves -- never beside a
+//   catch-up, the stamps are not atomic: include/dctr.h): the flush of the (t mod K)-th of K windows of rows -- no row
 //                   sleeps longer than K steps (a replay is a sequential chain: a batch's longest sleeper used to set the
 //                   launch's time, and rows nobody drew left their whole history to the next flush).
 // The arithmetic owed stays what the reference does -- one optimizer step per row per step, ~0.3 ms of VALU work at the

@@ -219,8 +219,9 @@ class _TunedGemm(object):
     tuned too, and two threads opening it would restore each other's state, hence the lock held for the block's duration --
     and the search is timing-based: two runs may settle on different solutions for the two backward GEMMs, i.e. different
     summation orders in the last bits of FiBiNET-sized layers' gradients (every other kernel of this package has a fixed
-    order).  ``DCTR_TUNABLE_GEMM=0`` keeps the library's default picks: run-to-run identical bits, ~5 % slower FiBiNET
-    steps; ``PYTORCH_TUNABLEOP_FILENAME`` pins the picks of an earlier run."""
+    order).  Hence OFF by default since round 6 (the library's default picks: run-to-run identical bits, like every other
+    kernel of this package; under torchrun every rank then also picks alike -- round-5 advisor finding); ``DCTR_TUNABLE_GEMM=1``
+    switches the search on (~5 % faster FiBiNET steps), ``PYTORCH_TUNABLEOP_FILENAME`` pins the picks of an earlier run."""
     named = False
     _lock = threading.RLock()
 
@@ -228,7 +229,7 @@ class _TunedGemm(object):
         _TunedGemm._lock.acquire()
         t = torch.cuda.tunable
         self.prev = (t.is_enabled(), t.tuning_is_enabled())
-        if os.environ.get("DCTR_TUNABLE_GEMM", "1") == "0":
+        if os.environ.get("DCTR_TUNABLE_GEMM", "0") != "1":
             return self
         if not self.prev[0] and not os.environ.get("PYTORCH_TUNABLEOP_FILENAME") and not _TunedGemm.named:
             # (this torch appends every pick to the results file as it is found: keep it out of the working directory)

@@ -64,6 +64,19 @@ class _Sharded(object):
     def train_step(self, xb, yb, next_xb=None):
         return self.tr.train_step(xb, yb, next_xb=next_xb)
 
+    def train_block(self, x_block, y_block, next_first=None):
+        """S consecutive steps as one hipGraph over the direct exchange (ShardedTrainer.train_block) -> this rank's data loss
+        summed over the S steps (fp64 device scalar)"""
+        self.tr.train_block(x_block, y_block, next_first=next_first)
+        return self.tr.last_block_loss
+
+    def blocks(self, dev):
+        """steps per hipGraph for full groups of batches, 0: step by step"""
+        if self.tr.exchange != "direct" or dev.type != "cuda" or self.tr.slab is None or \
+                os.environ.get("DCTR_FIT_GRAPH", "1") == "0":
+            return 0
+        return max(0, int(os.environ.get("DCTR_FIT_STEPS_PER_GRAPH", "16")))
+
     def set_use_graphs(self, on):
         self.tr.set_use_graphs(on)
 
@@ -91,6 +104,9 @@ class _Replicated(object):
 
     def train_step(self, xb, yb, next_xb=None):
         return self.tr.train_step(xb, yb)
+
+    def blocks(self, dev):
+        return 0
 
     def set_use_graphs(self, on):
         pass
@@ -125,8 +141,8 @@ def trainer_for(model):
     from . import parallel as par
     ad = getattr(model, "_dist_trainer", None)
     plan = model.model_plan()
-    if ad is not None and ad.tr.model is model and getattr(ad, "_optim", None) is getattr(model, "optim", None) and \
-            ad.tr.plan is plan:
+    if ad is not None and not getattr(ad, "_closed", False) and ad.tr.model is model and \
+            getattr(ad, "_optim", None) is getattr(model, "optim", None) and ad.tr.plan is plan:
         ad.attach()                # (the previous fit() left every rank's tables current and detached the trainer)
         return ad
     ad = None
@@ -136,7 +152,9 @@ def trainer_for(model):
             factory = getattr(model, "_shard_ops_factory", None)      # (tests: stand-ins for the device kernels)
             if factory is not None:
                 ops = factory(model, par.ShardLayout(plan, *context()))
-            ad = _Sharded(par.ShardedTrainer(model, ops=ops, exchange=os.environ.get("DCTR_SHARDED_EXCHANGE", "rccl")))
+            # 'auto': the direct exchange (whole steps, exchanges included, as hipGraphs of S steps) wherever its
+            # self-test passes on every rank, RCCL otherwise -- parallel.resolve_exchange says which and why
+            ad = _Sharded(par.ShardedTrainer(model, ops=ops, exchange=os.environ.get("DCTR_SHARDED_EXCHANGE", "auto")))
         except NotImplementedError:
             plan.sharder = None
             ad = None
@@ -174,9 +192,16 @@ def fit(model, X_all, y_all, batch_size, epochs, verbose, initial_epoch, do_vali
     steps_per_epoch = n_full + (1 if n_tail else 0)
     model.train()
     if rank == 0:
-        print("%s -- %d ranks, batch %d per rank (%d global), %s (%s)" % (model.device, world, b, G, tr.kind, tr.exchange))
+        note = getattr(getattr(tr, "tr", None), "exchange_note", "")
+        print("%s -- %d ranks, batch %d per rank (%d global), %s (%s exchange%s)" % (
+            model.device, world, b, G, tr.kind, tr.exchange, ": " + note if note else ""))
         print("Train on {0} samples, validate on {1} samples, {2} steps per epoch".format(
             sample_num, len(val_y), steps_per_epoch))
+    # every rank runs the callbacks (EarlyStopping must see the logs everywhere: its decision is all-reduced below), but a
+    # callback that WRITES -- ModelCheckpoint -- does so on rank 0 only: the ranks hold the same gathered parameters, and
+    # several processes pickling into one path at once can leave a truncated file (round-5 advisor finding)
+    if callbacks and rank != 0:
+        callbacks = [c for c in callbacks if not isinstance(c, _cb.ModelCheckpoint)]
     cbs = _cb.CallbackList((callbacks or []) + [model.history])
     cbs.set_model(model)
     cbs.on_train_begin()
@@ -203,27 +228,59 @@ def fit(model, X_all, y_all, batch_size, epochs, verbose, initial_epoch, do_vali
         return X_all[lo:hi].contiguous(), y_all[lo:hi].contiguous()
 
     graphs_on = False
+    S_blk = tr.blocks(dev)
+    if S_blk < 2:
+        S_blk = 0
+    blk_rows = None
+    if S_blk:
+        # row positions of S consecutive steps' slices of THIS rank inside the epoch order: step j of a block takes
+        # order[(k + j) G + r b : ... + b] -- one index_select per block instead of one per step
+        blk_rows = (torch.arange(S_blk, device=dev)[:, None] * G + rank * b + torch.arange(b, device=dev)[None, :]).reshape(-1)
+
+    def block_rows(step):
+        pos = blk_rows + step * G
+        idx = order.index_select(0, pos) if order is not None else pos
+        return (X_all.index_select(0, idx).view(S_blk, b, X_all.shape[1]), y_all.index_select(0, idx).view((S_blk, b) + tuple(y_all.shape[1:])))
+
     for epoch in range(initial_epoch, epochs):
         cbs.on_epoch_begin(epoch)
         epoch_logs = {}
         start_time = time.time()
         order = draw_order()
-        acc_sharded = torch.zeros((), device=dev, dtype=torch.float64)    # this rank's share of the full batches
+        # this rank's share of the full batches: the DATA loss (all-reduced below) and, apart, what each step adds that does
+        # not depend on the samples -- regularisation and auxiliary terms, which every rank computes in full on identical
+        # dense replicas: they enter the epoch's loss ONCE per step, not once per rank (round-5 advisor finding)
+        acc_sharded = torch.zeros((), device=dev, dtype=torch.float64)
+        acc_terms = torch.zeros((), device=dev, dtype=torch.float64)
         acc_tail = torch.zeros((), device=dev, dtype=torch.float64)       # the ragged batch (the same on every rank)
         preds = [] if (verbose > 0 and model.metrics) else None
         current = False                 # every rank's tables current?
         nxt = rows(rank * b, (rank + 1) * b) if n_full else None
-        for step in range(n_full):
-            xb, yb = nxt
-            lo = (step + 1) * G + rank * b
-            nxt = rows(lo, lo + b) if step + 1 < n_full else None
+        step = 0
+        while step < n_full:
+            model._sync_optimizer_hyper(full=False)      # (a callback may have moved lr: the single-process loop looks too)
             if not graphs_on and step >= 2 and dev.type == "cuda" and os.environ.get("DCTR_FIT_GRAPH", "1") != "0":
                 tr.set_use_graphs(True)     # (two eager steps first: descriptors are uploaded, buffers allocated)
                 graphs_on = True
+            if S_blk and graphs_on and preds is None and step + S_blk <= n_full:
+                # S steps as ONE hipGraph, exchanges included (ShardedTrainer.train_block over the direct exchange)
+                xs, ys = block_rows(step)
+                lo = (step + S_blk) * G + rank * b
+                nf = rows(lo, lo + b) if step + S_blk < n_full else None
+                acc_sharded += tr.train_block(xs, ys, next_first=nf[0] if nf is not None else None)
+                step += S_blk
+                nxt = nf
+                continue
+            xb, yb = nxt if nxt is not None else rows(step * G + rank * b, step * G + (rank + 1) * b)
+            lo = (step + 1) * G + rank * b
+            nxt = rows(lo, lo + b) if step + 1 < n_full else None
             loss, total_loss, y_pred = tr.train_step(xb, yb, next_xb=nxt[0] if nxt is not None else None)
-            acc_sharded += total_loss.detach().double().sum()
+            data = loss.detach().double().sum()
+            acc_sharded += data
+            acc_terms += total_loss.detach().double().sum() - data
             if preds is not None:
                 preds.append((yb, y_pred.detach().reshape(-1).clone(), True))
+            step += 1
         if n_tail:
             tr.gather_tables()
             with _Unsharded(tr, train=True):
@@ -235,7 +292,7 @@ def fit(model, X_all, y_all, batch_size, epochs, verbose, initial_epoch, do_vali
                 preds.append((yb, y_pred.detach().reshape(-1).clone(), False))
         dist.all_reduce(acc_sharded)
         plan.check_ids()
-        epoch_logs["loss"] = float((acc_sharded + acc_tail).item()) / sample_num
+        epoch_logs["loss"] = float((acc_sharded + acc_terms + acc_tail).item()) / sample_num
         if preds is not None:
             # the reference's metric of every (global) batch, averaged over steps (basemodel.py:264-269,280)
             per_batch = {name: [] for name in model.metrics}
@@ -274,6 +331,7 @@ def fit(model, X_all, y_all, batch_size, epochs, verbose, initial_epoch, do_vali
         if callbacks:
             with _Unsharded(tr):
                 cbs.on_epoch_end(epoch, epoch_logs)
+            dist.barrier()         # (rank 0 may have written a checkpoint: nobody runs ahead of it)
         else:
             cbs.on_epoch_end(epoch, epoch_logs)
         stop = torch.tensor([1 if model.stop_training else 0], device=dev)
@@ -286,5 +344,10 @@ def fit(model, X_all, y_all, batch_size, epochs, verbose, initial_epoch, do_vali
     # leave the model usable on its own (predict / evaluate / state_dict read complete local tables); the trainer is kept
     # for the next fit() call and re-attached there
     tr.detach()
+    if isinstance(tr, _Replicated):
+        # hand the model back as it was: a later single-process fit() takes the lazy O(batch) update again (the trainer
+        # forced the dense route); the next distributed fit() builds a new trainer
+        tr.tr.close()
+        tr._closed = True
     cbs.on_train_end()
     return model.history

@@ -609,12 +609,97 @@ class DirectExchange(object):
                                        ctypes.byref(step) if step is not None else None, 1, L.stream_handle(flat.device)),
                 "dctr_sum_ranks")
 
+    def self_test(self, rounds=3):
+        """Does the direct exchange move the right BYTES between these ranks?  Model-free, a few hundred microseconds:
+        ``rounds`` times (the same addresses, different values -- a stale line in anybody's cache would show) every rank
+        (1) stores a pattern that names (round, sender, receiver, element) into its slot of every peer's ``recv`` buffer with
+        a KERNEL running on its own device (dctr_sum_ranks over one source: the way the owners' gather and the gradient
+        assembly push), (2) passes the rows exchange, (3) compares what arrived from every sender with what that sender must
+        have written, (4) pulls every peer's ``dense`` slab through the pointer table (the way the dense sum reads them) and
+        compares the sum, (5) passes the gradient exchange so that nobody overwrites a buffer somebody still checks.
+        Returns the number of wrong elements seen by THIS rank (+ 1 when a wait timed out); the caller reduces over ranks.
+        bench.py / distributed_fit use it before they trust the exchange on more than one GPU: it has only ever been
+        exercised between processes that share one device (tests/test_gpu_direct_exchange.py)."""
+        import ctypes
+        L = self.L
+        dev = self.recv.device
+        n = int(self.recv.shape[1] * self.recv.shape[2])
+        nd = int(self.ld_dense)
+        idx = torch.arange(n, dtype=torch.float32, device=dev) * (1.0 / 1024.0)
+        idd = torch.arange(nd, dtype=torch.float32, device=dev) * (1.0 / 1024.0)
+        bad = torch.zeros((), dtype=torch.int64, device=dev)
+        stage = torch.empty((self.world, n), dtype=torch.float32, device=dev)
+        pulled = torch.empty((nd,), dtype=torch.float32, device=dev)
+        tbl = torch.tensor([self.peers[2][r][r].data_ptr() for r in range(self.world)], dtype=torch.int64, device=dev)
+        stream = L.stream_handle(dev)
+        for it in range(int(rounds)):
+            for q in range(self.world):
+                stage[q] = idx + float(1000 * it + 10 * self.rank + q)
+            self.dense[self.rank, :nd] = idd + float(100 * it + self.rank)        # my own slab, read by everybody in (4)
+            for q in range(self.world):
+                dst = self.peers[0][q][self.rank]
+                L.check(L.lib().dctr_sum_ranks(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(stage[q].data_ptr()), None,
+                                               1, n, n, None, 1, stream), "dctr_sum_ranks(push)")
+            self._sync("rows")
+            for r in range(self.world):
+                want = idx + float(1000 * it + 10 * r + self.rank)
+                bad += (self.recv[r].reshape(-1) != want).sum()
+            L.check(L.lib().dctr_sum_ranks(ctypes.c_void_p(pulled.data_ptr()), None, ctypes.c_void_p(tbl.data_ptr()),
+                                           self.world, nd, 0, None, 1, stream), "dctr_sum_ranks(pull)")
+            want = torch.zeros_like(pulled)
+            for r in range(self.world):           # (rank order, like the kernel: the same float sums)
+                want = want + (idd + float(100 * it + r))
+            bad += (pulled != want).sum()
+            self._sync("grads")
+        torch.cuda.synchronize(dev)
+        n_bad = int(bad.item())
+        if int(self.err.item()) != 0:
+            self.err.zero_()
+            n_bad += 1
+        return n_bad
+
     def check(self):
         """Raise if a wait ever timed out (synchronises the device)."""
         if int(self.err.item()) != 0:
             self.err.zero_()
             raise RuntimeError("a direct-exchange wait timed out: a peer rank did not reach the same exchange "
                                "(ranks out of step, or a rank died)")
+
+
+def resolve_exchange(requested, device, group=None, verbose=True):
+    """'rccl' | 'direct' | 'auto' | 'try-direct'  ->  ('rccl' | 'direct', what happened).
+
+    'auto' (the default of ``fit()`` under torchrun and of ``bench.py``): the direct exchange wherever it can be TRUSTED -- one
+    rank always; several ranks after ``DirectExchange.self_test`` has passed on every one of them (a model-free check of the
+    bytes that kernels push into / pull out of the peers' IPC-mapped buffers, the arrival words and the time-outs); RCCL
+    otherwise (CPU stand-ins, a failed or throwing self-test on ANY rank).  Collective: every rank must call it."""
+    dev = torch.device(device)
+    world = dist.get_world_size(group)
+    if requested in ("rccl", "direct"):
+        return requested, "as requested"
+    if requested not in ("auto", "try-direct"):
+        raise ValueError("exchange must be 'rccl', 'direct', 'auto' or 'try-direct'")
+    if dev.type != "cuda":
+        return "rccl", "no GPU: torch.distributed collectives"
+    if world == 1:
+        return "direct", "one rank"
+    ok, why = 1, ""
+    try:
+        dx = DirectExchange(group, world, dist.get_rank(group), dev, 64, 32, 4, 1024,
+                            dense_src=torch.zeros(1024, dtype=torch.float32, device=dev), timeout_us=2000000)
+        n_bad = dx.self_test()
+        if n_bad:
+            ok, why = 0, "%d wrong elements / timed-out waits" % n_bad
+        del dx
+    except Exception as exc:          # (IPC mapping refused, peer access missing, a launch error ...)
+        ok, why = 0, "%s: %s" % (type(exc).__name__, str(exc)[:200])
+    flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    passed = int(flag.item()) == 1
+    if not ok and verbose:
+        import sys
+        print("direct exchange self-test failed on rank %d (%s)" % (dist.get_rank(group), why), file=sys.stderr, flush=True)
+    return ("direct", "self-test passed on every rank") if passed else ("rccl", "self-test failed on at least one rank")
 
 
 class _GradTap(torch.autograd.Function):
@@ -728,8 +813,15 @@ class ShardedTrainer(object):
         # "rccl": torch.distributed collectives issued by the host between hipGraph segments; "direct": copies into the
         # peers' IPC-mapped buffers + arrival words, the whole step one hipGraph (DirectExchange; fused route, GPU only)
         self.exchange = exchange or os.environ.get("DCTR_SHARDED_EXCHANGE", "rccl")
+        self.exchange_note = "as requested"
+        if self.exchange in ("auto", "try-direct"):
+            # (the direct exchange drives the fused route only; the autograd route keeps the host-issued collectives)
+            if st is None:
+                self.exchange, self.exchange_note = "rccl", "autograd route"
+            else:
+                self.exchange, self.exchange_note = resolve_exchange(self.exchange, model.device, process_group)
         if self.exchange not in ("rccl", "direct"):
-            raise ValueError("exchange must be 'rccl' or 'direct'")
+            raise ValueError("exchange must be 'rccl', 'direct', 'auto' or 'try-direct'")
         self._dx = None
         self._side = None
         self._pre = None          # (chunks, ids) of the announced next batch, gathered at the end of the previous call
@@ -1092,10 +1184,13 @@ class ShardedTrainer(object):
         rank must announce (or not) consistently.  Returns the last step's ``(loss, total, y_pred)``."""
         S, B = int(x_block.shape[0]), int(x_block.shape[1])
         if not (self.exchange == "direct" and x_block.is_cuda and self.slab is not None):
-            out = None
+            out, acc = None, None
             for j in range(S):
                 nxt = x_block[j + 1] if j + 1 < S else next_first
                 out = self.train_step(x_block[j], y_block[j], next_xb=nxt)
+                t = out[0].detach().double().sum()
+                acc = t if acc is None else acc + t
+            self.last_block_loss = acc
             return out
         if not self.slab.intact():
             raise RuntimeError("a dense parameter was re-allocated; build a new ShardedTrainer")
@@ -1127,17 +1222,21 @@ class ShardedTrainer(object):
         seg = blk["seg"].get((announce, bool(self.use_graphs)))
         if seg is None:
             def steps(blk=blk, announce=announce, S=S):
-                out = None
+                out, losses = None, []
                 for j in range(S):
                     nxt = blk["x"][j + 1] if j + 1 < S else (blk["nf"] if announce else None)
                     self._stage(blk["x"][j], blk["y"][j], nxt)
                     out = self._direct_body()
+                    losses.append(out[0].reshape(()))
+                # (fit() logs the loss of EVERY step: the block's sum, in fp64, as part of the same graph)
+                blk["loss_sum"] = torch.stack(losses).double().sum()
                 return out
             seg = blk["seg"][(announce, bool(self.use_graphs))] = _Segment(steps, bool(self.use_graphs))
             # (the first call of a _Segment runs eagerly -- descriptor uploads, lazy buffers; the single-step segment has
             # normally done that already)
             seg.primed = getattr(self, "_direct_seg", None) is not None and self._direct_seg.primed
         loss, y_pred = seg()
+        self.last_block_loss = blk.get("loss_sum")       # fp64 scalar: this rank's data loss summed over the block's S steps
         self._direct_watchdog(S)
         return loss, loss.reshape(1), y_pred
 

@@ -355,9 +355,14 @@ int dctr_interacting_bwd(const float* E, int64_t ld_e, int32_t B, int32_t F, int
  * replayed -- the same recurrence, step by step -- when the row is next needed.  One "unit" = one id column of X with
  * the deep and / or wide table it feeds (as in dctr_embed_update); `stamp[row]` = optimizer steps already applied
  * to the row, `*step` (device) = steps completed so far.  Per train step the caller enqueues
- *   dctr_embed_ids -> [dctr_lazy_sweep ->] dctr_lazy_catchup -> dctr_embed_fwd -> ... -> dctr_embed_update(DCTR_UPD_ACCUM)
+ *   dctr_embed_ids -> dctr_lazy_catchup -> dctr_embed_fwd -> ... -> dctr_embed_update(DCTR_UPD_ACCUM)
  *   -> dctr_lazy_apply -> dctr_lazy_step_inc,
  * and dctr_lazy_flush before anything else reads the tables (predict / evaluate / state_dict).
+ * dctr_lazy_sweep (optional, once per step) goes BEHIND the catch-up -- never beside it: sweep and catch-up read and write
+ * the stamps non-atomically and skip a row only when its stamp is already current, so a sweep that overlaps a catch-up
+ * replays rows twice -- and must have finished before dctr_lazy_step_inc (it reads the step counter).  Between the two it
+ * may run on a stream of its own beside the gather, the tower, the update and dctr_lazy_apply: they touch the batch's
+ * rows, which the catch-up has stamped current and the sweep therefore skips.                                       */
  *   *_s1  Adagrad `sum` | Adam `exp_avg`     *_s2  Adam `exp_avg_sq`     *_g  gradient slab, zero at rest
  *   vec   1 or 4: every deep dim and base pointer is a multiple of `vec` floats;  max_dim <= 64*vec                */
 #define DCTR_LAZY_SGD 0

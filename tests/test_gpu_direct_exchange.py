@@ -174,3 +174,42 @@ def test_train_block_equals_the_single_process_steps(tmp_path):
         v = v.detach().cpu()
         err = float((ranks[0]["sd"][k] - v).abs().max())
         assert err <= 2e-6 * max(1.0, float(v.abs().max())) + 2e-7, "%s: %.3e" % (k, err)
+
+
+# ---- the exchange's self-test (what fit() under torchrun and bench.py run before they trust it at N > 1) -------------------
+def _worker_selftest(rank, world, port, sabotage, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        for p in (os.path.join(ROOT, "deepctr-torch_amd"),):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        from deepctr_torch import parallel as par
+        if sabotage and rank == 1:
+            # one rank sees wrong bytes (here: it compares against a pattern nobody wrote): EVERY rank must fall back
+            real = par.DirectExchange.self_test
+            par.DirectExchange.self_test = lambda self, rounds=3: real(self, rounds) + 7
+        got = par.resolve_exchange("auto", "cuda:0", verbose=False)
+        dx = par.DirectExchange(None, world, rank, torch.device("cuda:0"), 32, 16, 2, 64,
+                                dense_src=torch.zeros(64, device="cuda:0"))
+        n_bad = dx.self_test(rounds=4)
+        torch.save({"got": got, "n_bad": n_bad}, os.path.join(out_dir, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sabotage", [False, True], ids=["clean", "one_rank_fails"])
+def test_exchange_self_test_and_resolution(tmp_path, sabotage):
+    """parallel.resolve_exchange('auto') with three ranks on the GPU: the direct exchange when DirectExchange.self_test sees
+    every byte right on every rank, RCCL on EVERY rank as soon as one rank reports a mismatch; the self-test itself (kernel
+    pushes into the peers' buffers, pulls through the pointer table, four rounds over the same addresses) counts zero wrong
+    elements."""
+    world = 3
+    port = _free_port()
+    mp.spawn(_worker_selftest, args=(world, port, sabotage, str(tmp_path)), nprocs=world, join=True)
+    ranks = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
+    for r in ranks:
+        assert r["got"][0] == ("rccl" if sabotage else "direct"), r["got"]
+        assert r["n_bad"] == (7 if (sabotage and r is ranks[1]) else 0)
