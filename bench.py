@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--no-saturating", action="store_true", help="skip the saturating-launch leg (B_eff 262 144)")
     ap.add_argument("--legs", default="all",
                     help="comma-separated subset of the N = 1 line's other_configs to run (xdeepfm, fibinet, deepfm_varlen, "
-                         "default_kwargs, fit_api, sharded_1rank); 'all' by default")
+                         "default_kwargs, fit_api, sharded_1rank, fit_api_sharded_1rank); 'all' by default")
     ap.add_argument("--exchange", default=os.environ.get("DCTR_SHARDED_EXCHANGE", "auto"),
                     choices=["auto", "rccl", "direct", "try-direct"],
                     help="how the table-sharded step exchanges rows / gradients / dense gradients between ranks: 'rccl' = "
@@ -678,6 +678,47 @@ def sharded_1rank(args):
         return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
 
 
+def fit_api_sharded_1rank(args):
+    """``model.fit()`` through the table-sharded trainer at ONE rank (child process, DCTR_FIT_FORCE_TRAINER=1): the public call a
+    torchrun user makes, with the exchange resolved by parallel.resolve_exchange ('auto') and full groups of steps replayed as
+    one hipGraph each (distributed_fit.py) -- next to `sharded_1rank`, the trainer driven directly."""
+    import subprocess
+    code = (
+        "import sys, os, json, time, io, contextlib\n"
+        "sys.path.insert(0, os.path.join(%r, 'deepctr-torch_amd'))\n"
+        "sys.argv = ['bench.py', '--batch', '%d', '--vocab', '%d', '--optimizer', '%s']\n"
+        "import torch\n"
+        "import importlib.util\n"
+        "spec = importlib.util.spec_from_file_location('bench', %r); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+        "args = b.parse()\n"
+        "torch.cuda.set_device(0)\n"
+        "model = b.build_model(args, 'cuda:0')\n"
+        "X, y = b.synth(args, 'cuda:0', 0)\n"
+        "X, y = X.repeat(4, 1), y.repeat(4)\n"
+        "sink = io.StringIO()\n"
+        "with contextlib.redirect_stdout(sink):\n"
+        "    model.fit(X, y, batch_size=args.batch, epochs=1, verbose=0, shuffle=False)\n"
+        "    torch.cuda.synchronize(); t0 = time.perf_counter()\n"
+        "    h = model.fit(X, y, batch_size=args.batch, epochs=3, verbose=0, shuffle=False)\n"
+        "    torch.cuda.synchronize(); dt = time.perf_counter() - t0\n"
+        "n = X.shape[0]; steps = 3 * (n // args.batch)\n"
+        "tr = model._dist_trainer\n"
+        "print(json.dumps({'value': 3 * n / dt, 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'trainer': type(tr).__name__,\n"
+        "                  'exchange': tr.exchange, 'exchange_note': getattr(tr.tr, 'exchange_note', None),\n"
+        "                  'steps_per_graph': tr.blocks(X.device), 'last_epoch_loss': float(h.history['loss'][-1])}))\n"
+    ) % (os.path.dirname(os.path.abspath(__file__)), args.batch, args.vocab, args.optimizer, os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29300 + os.getpid() % 300), WORLD_SIZE="1", RANK="0",
+               LOCAL_RANK="0", DCTR_FIT_FORCE_TRAINER="1")
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        d.update(call="model.fit(x, y, batch_size=%d, epochs=3, shuffle=False) under DCTR_FIT_FORCE_TRAINER=1, WORLD_SIZE=1" % args.batch,
+                 unit="samples/s")
+        return d
+    except Exception as exc:
+        return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300]), "stderr": (r.stderr[-400:] if "r" in dir() else None)}
+
+
 def other_config(name, args, device, X, y):
     """One more bench leg at N = 1: the same timed protocol on another model of BASELINE.json; MFMA-bound, so its
     roofline is algorithmic FLOP / (time x dense fp32 MFMA peak)."""
@@ -1003,6 +1044,11 @@ def main():
                 result["other_configs"]["fit_api"] = fit_api(args, device, X, y)
             if parallel is None and want("sharded_1rank"):
                 result["other_configs"]["sharded_1rank"] = sharded_1rank(args)
+            if parallel is None and want("fit_api_sharded_1rank"):
+                leg = result["other_configs"]["fit_api_sharded_1rank"] = fit_api_sharded_1rank(args)
+                s1 = result["other_configs"].get("sharded_1rank", {})
+                if "ms_per_step" in leg and "ms_per_step" in s1:
+                    leg["ms_per_step_vs_sharded_1rank"] = leg["ms_per_step"] / s1["ms_per_step"]
             fa = result["other_configs"].get("fit_api", {})
             if "value" in fa:
                 fa["vs_step_runner"] = fa["value"] / value

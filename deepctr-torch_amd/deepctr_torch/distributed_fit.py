@@ -31,11 +31,17 @@ import torch
 
 
 def context():
-    """(world, rank) when this process is one of several training ranks, else None."""
+    """(world, rank) when this process is one of several training ranks, else None.  ``DCTR_FIT_FORCE_TRAINER=1``: also for a
+    world of ONE rank -- fit() then runs through the sharded trainer and its exchange with nobody to exchange with (what
+    bench.py's ``fit_api_sharded_1rank`` leg and the one-GPU tests time and check)."""
     import torch.distributed as dist
+    force = os.environ.get("DCTR_FIT_FORCE_TRAINER") == "1"
     if dist.is_available() and dist.is_initialized():
         w = dist.get_world_size()
-        return (w, dist.get_rank()) if w > 1 else None
+        return (w, dist.get_rank()) if (w > 1 or force) else None
+    if force and os.environ.get("DCTR_FIT_DISTRIBUTED", "1") != "0":
+        os.environ.setdefault("WORLD_SIZE", "1")
+        return (int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0")))
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("DCTR_FIT_DISTRIBUTED", "1") != "0":
         return (int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0")))
     return None
@@ -256,17 +262,24 @@ def fit(model, X_all, y_all, batch_size, epochs, verbose, initial_epoch, do_vali
         preds = [] if (verbose > 0 and model.metrics) else None
         current = False                 # every rank's tables current?
         nxt = rows(rank * b, (rank + 1) * b) if n_full else None
-        step = 0
+        step, blk_next = 0, None
         while step < n_full:
             model._sync_optimizer_hyper(full=False)      # (a callback may have moved lr: the single-process loop looks too)
             if not graphs_on and step >= 2 and dev.type == "cuda" and os.environ.get("DCTR_FIT_GRAPH", "1") != "0":
                 tr.set_use_graphs(True)     # (two eager steps first: descriptors are uploaded, buffers allocated)
                 graphs_on = True
             if S_blk and graphs_on and preds is None and step + S_blk <= n_full:
-                # S steps as ONE hipGraph, exchanges included (ShardedTrainer.train_block over the direct exchange)
-                xs, ys = block_rows(step)
-                lo = (step + S_blk) * G + rank * b
-                nf = rows(lo, lo + b) if step + S_blk < n_full else None
+                # S steps as ONE hipGraph, exchanges included (ShardedTrainer.train_block over the direct exchange).  What
+                # follows is announced with the last step's gradients -- the NEXT block's own first batch when another full
+                # block follows (the trainer recognises an announced batch by its storage), else the next single batch
+                xs, ys = blk_next if blk_next is not None else block_rows(step)
+                blk_next, nf = None, None
+                if step + 2 * S_blk <= n_full:
+                    blk_next = block_rows(step + S_blk)
+                    nf = (blk_next[0][0], blk_next[1][0])
+                elif step + S_blk < n_full:
+                    lo = (step + S_blk) * G + rank * b
+                    nf = rows(lo, lo + b)
                 acc_sharded += tr.train_block(xs, ys, next_first=nf[0] if nf is not None else None)
                 step += S_blk
                 nxt = nf

@@ -1221,7 +1221,10 @@ class ShardedTrainer(object):
         self._announced = (next_first.data_ptr(), next_first._version) if announce else None
         seg = blk["seg"].get((announce, bool(self.use_graphs)))
         if seg is None:
-            def steps(blk=blk, announce=announce, S=S):
+            sums = blk.setdefault("sums", {})
+            skey = (announce, bool(self.use_graphs))
+
+            def steps(blk=blk, announce=announce, S=S, sums=sums, skey=skey):
                 out, losses = None, []
                 for j in range(S):
                     nxt = blk["x"][j + 1] if j + 1 < S else (blk["nf"] if announce else None)
@@ -1229,14 +1232,16 @@ class ShardedTrainer(object):
                     out = self._direct_body()
                     losses.append(out[0].reshape(()))
                 # (fit() logs the loss of EVERY step: the block's sum, in fp64, as part of the same graph)
-                blk["loss_sum"] = torch.stack(losses).double().sum()
+                # (one tensor per captured variant: a replay refreshes the tensor of ITS capture)
+                sums[skey] = torch.stack(losses).double().sum()
                 return out
             seg = blk["seg"][(announce, bool(self.use_graphs))] = _Segment(steps, bool(self.use_graphs))
             # (the first call of a _Segment runs eagerly -- descriptor uploads, lazy buffers; the single-step segment has
             # normally done that already)
             seg.primed = getattr(self, "_direct_seg", None) is not None and self._direct_seg.primed
         loss, y_pred = seg()
-        self.last_block_loss = blk.get("loss_sum")       # fp64 scalar: this rank's data loss summed over the block's S steps
+        # fp64 scalar: this rank's data loss summed over the block's S steps
+        self.last_block_loss = blk.get("sums", {}).get((announce, bool(self.use_graphs)))
         self._direct_watchdog(S)
         return loss, loss.reshape(1), y_pred
 

@@ -213,3 +213,65 @@ def test_exchange_self_test_and_resolution(tmp_path, sabotage):
     for r in ranks:
         assert r["got"][0] == ("rccl" if sabotage else "direct"), r["got"]
         assert r["n_bad"] == (7 if (sabotage and r is ranks[1]) else 0)
+
+
+# ---- fit() itself through the direct exchange: groups of steps as one hipGraph each ----------------------------------------
+FIT_B, FIT_N, FIT_S = 64, 64 * 2 * 11 + 37, 3     # per-rank batch; 11 global batches of 128 and a ragged tail of 37 rows
+
+
+def _fit_data():
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, V_, (FIT_N, F_), generator=g).float()
+    X = torch.cat([ids, torch.rand(FIT_N, ND_, generator=g)], 1)
+    y = torch.randint(0, 2, (FIT_N,), generator=g).float()
+    return X, y
+
+
+def _worker_fit(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", DCTR_FIT_STEPS_PER_GRAPH=str(FIT_S))
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # (RCCL refuses two ranks on one device)
+    try:
+        torch.cuda.set_device(0)
+        m = _model("cuda:0")
+        m.compile("adagrad", "binary_crossentropy", metrics=[])
+        X, y = _fit_data()
+        torch.manual_seed(77)
+        hist = m.fit(X.to("cuda:0"), y.to("cuda:0"), batch_size=FIT_B, epochs=2, verbose=0, shuffle=True)
+        tr = m._dist_trainer
+        torch.save({"sd": {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, "loss": list(hist.history["loss"]),
+                    "trainer": type(tr).__name__, "exchange": tr.exchange, "note": tr.tr.exchange_note,
+                    "blocks": tr.blocks(torch.device("cuda:0")), "had_block": getattr(tr.tr, "last_block_loss", None) is not None},
+                   os.path.join(out_dir, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fit_through_the_direct_exchange_equals_single_process_fit(tmp_path):
+    """``model.fit()`` with two ranks on the GPU: the exchange resolves to 'direct' through its self-test, the epoch runs two
+    eager steps, then blocks of three steps per hipGraph (ShardedTrainer.train_block), the left-over full batches one by one
+    and the ragged tail on gathered tables -- History and parameters of ONE process fitting the global batch size."""
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker_fit, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    ranks = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
+    for r in ranks:
+        assert r["trainer"] == "_Sharded" and r["exchange"] == "direct" and "self-test passed" in r["note"], r
+        assert r["blocks"] == FIT_S and r["had_block"]
+    ref = _model("cuda:0")
+    ref.compile("adagrad", "binary_crossentropy", metrics=[])
+    X, y = _fit_data()
+    torch.manual_seed(77)
+    os.environ["DCTR_FIT_DISTRIBUTED"] = "0"
+    try:
+        hist = ref.fit(X.to("cuda:0"), y.to("cuda:0"), batch_size=FIT_B * world, epochs=2, verbose=0, shuffle=True)
+    finally:
+        os.environ.pop("DCTR_FIT_DISTRIBUTED", None)
+    import numpy as np
+    for r in ranks:
+        np.testing.assert_allclose(r["loss"], hist.history["loss"], rtol=2e-5)
+    for k, v in ref.state_dict().items():
+        v = v.detach().cpu()
+        err = float((ranks[0]["sd"][k] - v).abs().max())
+        assert err <= 2e-6 * max(1.0, float(v.abs().max())) + 2e-7, "%s: %.3e" % (k, err)
+        assert torch.equal(ranks[0]["sd"][k], ranks[1]["sd"][k]), "replicas differ: %s" % k
