@@ -58,6 +58,11 @@ struct AsmArgs {
   const float* g_wide;   // [B] nullable
   const float* g_fm;     // [B] nullable
   float* g_wdense;       // [n_wdense] nullable
+  // round 6: the carried columns come straight from the NEXT batch's X (dctr_shard_assemble_bwd_next) -- carried value (q, j)
+  // of sample b = x_next[b, carry_cols[q * carry_n + j]] -- instead of from the local send rows dctr_shard_stage filled
+  const float* x_next;
+  int64_t ldxn;
+  const int32_t* carry_cols;
 };
 
 // unit f -> (owner rank q, slot j of that owner's chunk)
@@ -159,7 +164,8 @@ __global__ __launch_bounds__(kT) void k_assemble_bwd(AsmArgs A) {
     for (int t = c; t < A.N * A.carry_n; t += 16) {
       const int q = t / A.carry_n, j = t - q * A.carry_n;
       stg_f32(chunk_row(nullptr, A.send_chunks, q, A.B, b, A.ldc) + A.carry_col + j,
-              ldg_f32(chunk_row(A.send, nullptr, q, A.B, b, A.ldc) + A.carry_col + j));
+              A.x_next ? ldg_f32(A.x_next + b * A.ldxn + ldg_i32(A.carry_cols + t))
+                       : ldg_f32(chunk_row(A.send, nullptr, q, A.B, b, A.ldc) + A.carry_col + j));
     }
   }
 }
@@ -287,7 +293,8 @@ __global__ __launch_bounds__(kT) void k_assemble_bwd_v4(AsmArgs A) {
     for (int t = l; t < A.N * A.carry_n; t += LPS) {
       const int q = t / A.carry_n, j = t - q * A.carry_n;
       stg_f32(chunk_row(nullptr, A.send_chunks, q, A.B, b, A.ldc) + A.carry_col + j,
-              ldg_f32(chunk_row(A.send, nullptr, q, A.B, b, A.ldc) + A.carry_col + j));
+              A.x_next ? ldg_f32(A.x_next + b * A.ldxn + ldg_i32(A.carry_cols + t))
+                       : ldg_f32(chunk_row(A.send, nullptr, q, A.B, b, A.ldc) + A.carry_col + j));
     }
   }
 }
@@ -358,9 +365,23 @@ extern "C" int dctr_shard_assemble_bwd(float* send, const uint64_t* send_chunks,
                                        const float* g_fm, const float* out, int64_t ld_out, const float* fm_s,
                                        int64_t ld_s, const float* X, int64_t ld_x, const int32_t* wdense_cols,
                                        int32_t n_wdense, float* g_wdense, dctr_stream_t stream) {
+  return dctr_shard_assemble_bwd_next(send, send_chunks, carry_col, carry_n, ld_chunk, n_ranks, B, F, D, owner_slot, wide_col, g_out,
+                                      ld_g, g_wide, g_fm, out, ld_out, fm_s, ld_s, X, ld_x, wdense_cols, n_wdense, g_wdense,
+                                      nullptr, 0, nullptr, stream);
+}
+
+extern "C" int dctr_shard_assemble_bwd_next(float* send, const uint64_t* send_chunks, int32_t carry_col, int32_t carry_n,
+                                            int64_t ld_chunk, int32_t n_ranks, int32_t B, int32_t F, int32_t D,
+                                            const int32_t* owner_slot, int32_t wide_col, const float* g_out, int64_t ld_g,
+                                            const float* g_wide, const float* g_fm, const float* out, int64_t ld_out,
+                                            const float* fm_s, int64_t ld_s, const float* X, int64_t ld_x,
+                                            const int32_t* wdense_cols, int32_t n_wdense, float* g_wdense,
+                                            const float* x_next, int64_t ld_xn, const int32_t* carry_cols,
+                                            dctr_stream_t stream) {
   if ((!send && !send_chunks) || n_ranks <= 0 || B < 0 || F <= 0 || D <= 0) return DCTR_EINVAL;
   if (g_fm && (!out || !fm_s)) return DCTR_EINVAL;
-  if (carry_n < 0 || (carry_n > 0 && (!send || !send_chunks || carry_col < 0 || carry_col + carry_n > ld_chunk))) return DCTR_EINVAL;
+  if (x_next && (!carry_cols || !send_chunks || carry_n <= 0 || ld_xn <= 0)) return DCTR_EINVAL;
+  if (carry_n < 0 || (carry_n > 0 && ((!send && !x_next) || !send_chunks || carry_col < 0 || carry_col + carry_n > ld_chunk))) return DCTR_EINVAL;
   if (g_wdense && (!X || !g_wide || !wdense_cols || n_wdense <= 0)) return DCTR_EINVAL;
   if (B == 0) return DCTR_OK;
   AsmArgs a = {};
@@ -369,6 +390,7 @@ extern "C" int dctr_shard_assemble_bwd(float* send, const uint64_t* send_chunks,
   a.g_out = g_out; a.ldg = ld_g; a.g_wide = g_wide; a.g_fm = g_fm; a.out = const_cast<float*>(out); a.ldo = ld_out;
   a.fm_s = const_cast<float*>(fm_s); a.lds_ = ld_s; a.X = X; a.ldx = ld_x; a.wdense_cols = wdense_cols;
   a.n_wdense = n_wdense; a.g_wdense = g_wdense;
+  a.x_next = x_next; a.ldxn = ld_xn; a.carry_cols = carry_cols;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned extra = g_wdense ? static_cast<unsigned>(n_wdense) : 0u;
   // (send_chunks: the receive buffers are whole allocations, 16-byte aligned by construction -- the caller's contract)

@@ -219,6 +219,8 @@ SIGNATURES = {
                                                _I32, _P, _I64, _P, _P, _P, _I64, _P]),
     "dctr_shard_assemble_bwd": (ctypes.c_int, [_P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _I64, _P, _P, _P, _I64, _P,
                                                _I64, _P, _I64, _P, _I32, _P, _P]),
+    "dctr_shard_assemble_bwd_next": (ctypes.c_int, [_P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _I64, _P, _P, _P, _I64,
+                                                    _P, _I64, _P, _I64, _P, _I32, _P, _P, _I64, _P, _P]),
     "dctr_fm_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P]),
     "dctr_fm_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _I64, _I32, _P]),
     "dctr_interacting_supported": (ctypes.c_int, [_I32, _I32, _I32]),

@@ -360,6 +360,7 @@ class HipShardOps(object):
             self.sub.share_update_with(plan)
         self._idx = None
         self._map = None
+        self._idc = None
 
     def _owner_map(self, dev):
         if self._map is None or self._map.device != dev:
@@ -424,20 +425,28 @@ class HipShardOps(object):
             L.stream_handle(dev)), "dctr_shard_assemble_fwd")
         return out, wide, fm, fm_s
 
-    def assemble_bwd(self, X, g_out, g_wide, g_fm, out, fm_s, g_wdense, send=None, push=None):
-        """``push``: device table of the owners' receive buffers -- chunk q is written there, not into ``send``."""
+    def assemble_bwd(self, X, g_out, g_wide, g_fm, out, fm_s, g_wdense, send=None, push=None, next_x=None, carry=True):
+        """``push``: device table of the owners' receive buffers -- chunk q is written there, not into ``send``.
+        ``next_x`` (push only): the NEXT batch's input matrix -- its id columns ride along straight from there
+        (dctr_shard_assemble_bwd_next; otherwise from the local send rows dctr_shard_stage filled); ``carry=False``: nothing
+        rides along (the next batch is not announced)."""
         L, lay, plan = self.L, self.lay, self.plan
         B, dev = X.shape[0], X.device
         if send is None:
             send = torch.empty((lay.world * B, lay.ldc), dtype=torch.float32, device=dev)
         w = plan.wide_dense_weight
-        L.check(L.lib().dctr_shard_assemble_bwd(
-            self._ptr(send), self._ptr(push), lay.ids_col if push is not None else 0, lay.n_slots if push is not None else 0,
+        carry_n = lay.n_slots if (push is not None and carry) else 0
+        if next_x is not None and (self._idc is None or self._idc.device != dev):
+            self._idc = torch.tensor(lay.id_cols, dtype=torch.int32, device=dev)
+        L.check(L.lib().dctr_shard_assemble_bwd_next(
+            self._ptr(send), self._ptr(push), lay.ids_col if push is not None else 0, carry_n,
             lay.ldc, lay.world, B, lay.F, lay.D, self._ptr(self._owner_map(dev)),
             lay.wide_col if lay.has_wide else -1, self._ptr(g_out), g_out.stride(0) if g_out is not None else 0, self._ptr(g_wide), self._ptr(g_fm),
             self._ptr(out), plan.ld_out, self._ptr(fm_s), fm_s.stride(0) if fm_s is not None else 0, self._ptr(X),
             X.stride(0), self._ptr(plan._dev["wdense"]), len(plan.wdense_cols) if (w is not None and g_wdense is not None) else 0,
-            self._ptr(g_wdense), L.stream_handle(dev)), "dctr_shard_assemble_bwd")
+            self._ptr(g_wdense), self._ptr(next_x) if (next_x is not None and carry_n) else None,
+            next_x.stride(0) if (next_x is not None and carry_n) else 0,
+            self._ptr(self._idc) if (next_x is not None and carry_n) else None, L.stream_handle(dev)), "dctr_shard_assemble_bwd")
         return send
 
     def update(self, grads_all, ids_t):
@@ -867,6 +876,12 @@ class ShardedTrainer(object):
         lay, dev, B = self.layout, xb.device, xb.shape[0]
         self._shape = (tuple(xb.shape), tuple(yb.shape))
         self._x, self._y = torch.empty_like(xb), torch.empty_like(yb)
+        eng = getattr(self, "_eng", None)
+        if eng is not None:       # (the engine compute segment reads the staged batch out of its own [B, C + 1] buffer)
+            if eng["xfull"].shape[0] == B and eng["xfull"].shape[1] == xb.shape[1] + 1 and eng["xfull"].device == xb.device:
+                self._x = eng["xfull"][:, :xb.shape[1]]
+            else:
+                self._eng = None
         # captured direct-exchange segments hold the raw addresses of the staging tensors just replaced (same B, another
         # y shape: round-4 advisor finding) -- they are rebuilt with the new ones
         if getattr(self, "_dx", None) is not None:
@@ -1090,12 +1105,129 @@ class ShardedTrainer(object):
         self._direct_seg = _Segment(self._direct_body, bool(self.use_graphs))
         from ._hip import streams as _streams
         self._side = _streams.side_stream(dev, "shard")
+        self._eng = self._engine_setup(B, dev)
+
+    # ---- the compute segment as C-ABI calls: the tower launch reads its rows straight from the exchange buffer --------------
+    def _engine_setup(self, B, dev):
+        """Round 6.  The compute segment used to run through the model's autograd Functions: ``dctr_shard_assemble_fwd``
+        copied the rows out of the receive buffer into the tower's input (+ the linear logit and the FM term), the tower launch
+        read that copy, autograd delivered the three gradients to taps.  For a model whose logit is ``linear [+ FM] + tower``
+        (``_gather_step``: DeepFM, WDL) the fused gather + tower launch of the single-GPU step engine
+        (``dctr_embed_tower_train_step``, csrc/mlp.hip) does all of that itself when it is handed a plan whose TABLES ARE THE
+        RECEIVE BUFFER: "table" of field f = the slot of f's owner in ``recv`` (rows ``ldc`` floats apart, one row per sample),
+        "id" = the sample's own index (an extra column of the staged batch), the wide "tables" = the owners' summed wide
+        values.  One launch and 7 us less per step (profiles/r06_sharded_1rank_timeline*.txt), no autograd graph, same
+        arithmetic in the same order (tests/test_gpu_direct_exchange.py compare with the single-process step).
+        -> dict of what the segment needs, or None (autograd route)."""
+        import ctypes
+        model, plan, lay, slab = self.model, self.plan, self.layout, self.slab
+        if not getattr(model, "_gather_step", False) or not self._dx.push or self.ops.__class__ is not HipShardOps or \
+                os.environ.get("DCTR_SHARDED_ENGINE", "1") == "0" or not plan.simple_units:
+            return None
+        from ._hip import lib as L
+        from ._hip.plan import EmbeddingPlan
+        from ._hip.step import GatherStep
+        from .inputs import DenseFeat, SparseFeat
+        eng = GatherStep(model, slab)
+        b = eng._buffers(B, dev)
+        if b is None:
+            return None
+        C = int(plan.n_xcols)
+        recv = self._dx.recv                        # [world, B, ldc]: rank q's rows of MY samples arrive in recv[q]
+
+        class _Tbl(object):
+            def __init__(self, w):
+                self.weight = w
+        fi, deep_cols, wide_cols, deep_t, wide_t = {}, [], [], {}, {}
+        for i in range(lay.F):
+            q, sl = lay.owner[i], lay.slot[i]
+            name = "recv_slot_%d" % i
+            deep_cols.append(SparseFeat(name, B, lay.D))
+            deep_t[name] = _Tbl(recv[q][:, sl * lay.D:(sl + 1) * lay.D])
+            fi[name] = (C, C + 1)
+        if lay.has_wide:
+            for q in sorted(set(lay.owner)):
+                name = "recv_wide_%d" % q
+                wide_cols.append(SparseFeat(name, B, 1))
+                wide_t[name] = _Tbl(recv[q][:, lay.wide_col:lay.wide_col + 1])
+                fi[name] = (C, C + 1)
+        for fc in model.dnn_feature_columns:
+            if isinstance(fc, DenseFeat):
+                deep_cols.append(fc)
+                fi[fc.name] = model.feature_index[fc.name]
+        for fc in model._linear_feature_columns:
+            if isinstance(fc, DenseFeat):
+                wide_cols.append(fc)
+                fi[fc.name] = model.feature_index[fc.name]
+        pseudo = EmbeddingPlan(fi, deep_columns=deep_cols, deep_tables=deep_t, wide_columns=wide_cols,
+                               wide_tables=wide_t if wide_t else None, wide_dense_weight=plan.wide_dense_weight)
+        if pseudo.width != plan.width or pseudo.ld_out != plan.ld_out or (pseudo.wide_dense_weight is None) != \
+                (plan.wide_dense_weight is None):
+            return None
+        cp = pseudo.bind(dev)
+        if L.lib().dctr_embed_tower_train_supported(cp, ctypes.byref(b.desc), int(B)) != 1:
+            return None
+        # the staged batch with one more column: the sample's own index, the "id" of every pseudo field
+        xfull = torch.zeros((B, C + 1), dtype=torch.float32, device=dev)
+        xfull[:, C] = torch.arange(B, dtype=torch.float32, device=dev)
+        self._x = xfull[:, :C]
+        return {"eng": eng, "b": b, "pseudo": pseudo, "xfull": xfull, "want_fm": eng.want_fm}
+
+    def _compute_engine(self, xf=None, y=None, next_x=None, carry=True):
+        """[rows in recv] -> fused gather + tower + head + BCE + backward-data (ONE launch) -> gradient assembly into the
+        owners' buffers; the tower's weight gradients are left to the caller (``slab.deferred``), like TowerHeadFunction does.
+        ``xf`` [B, C + 1] / ``y``: the batch in place (a step of a captured block: nothing was staged), its last column the
+        sample index; default: the staged copy.  ``next_x``: the announced next batch, read in place by the gradient
+        assembly."""
+        import ctypes
+        from ._hip import lib as L
+        E = self._eng
+        model, plan, slab, lay = self.model, self.plan, self.slab, self.layout
+        b, pseudo = E["b"], E["pseudo"]
+        xf = E["xfull"] if xf is None else xf
+        dev = xf.device
+        B = xf.shape[0]
+        lib = L.lib()
+        P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())       # noqa: E731
+        cp = pseudo.bind(dev)
+        y = (self._y if y is None else y).reshape(-1)
+        if getattr(self, "_pending_join", False):
+            # the previous step's weight gradients / dense sum / optimizer step (second queue) were left unjoined: the tower
+            # launch below is the first reader of what they write -- joined HERE, behind the rows exchange, not at the end of
+            # that step (the cross-queue edge then has the staging / exchange launches to hide behind)
+            torch.cuda.current_stream(dev).wait_stream(self._side)
+            self._pending_join = False
+        y_pred = torch.empty((B,), dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        ld = plan.ld_out
+        ld_s = b.fm_s.stride(0) if b.fm_s is not None else 0
+        bias = model.out.bias
+        sh = L.stream_handle(dev)
+        L.check(lib.dctr_embed_tower_train_step(cp, P(xf), xf.stride(0), ctypes.byref(b.desc), B, 1 if E["want_fm"] else 0,
+                                                P(bias), P(y), P(y_pred), P(b.g_logit), P(b.gx), ld, P(b.out), ld, P(b.fm_s),
+                                                ld_s, P(plan.err_flag(dev)), P(b.ws), sh), "dctr_embed_tower_train_step(recv)")
+        g_bias = slab.grad_of(bias)
+
+        def wgrad(stream):
+            with torch.cuda.stream(stream):
+                L.check(lib.dctr_mlp_train_wgrad(ctypes.byref(b.desc), P(b.out), ld, B, P(b.g_logit), P(b.ws), P(loss),
+                                                 P(g_bias), None, L.stream_handle(dev)), "dctr_mlp_train_wgrad")
+        slab.deferred = wgrad
+        g_wd = slab.grad_of(plan.wide_dense_weight) if plan.wide_dense_weight is not None else None
+        send = self.ops.assemble_bwd(xf[:, :plan.n_xcols], b.gx, b.g_logit if plan.has_wide else None,
+                                     b.g_logit if E["want_fm"] else None, b.out, b.fm_s,
+                                     g_wd if plan.has_wide else None, send=self._send_static,
+                                     push=self._dx.grad_tbl if self._dx.push else None, next_x=next_x, carry=carry)
+        return send, loss, y_pred
 
     def _push_rows(self):
         return (self._dx.row_tbl, self._dx.recv.shape[1]) if self._dx.push else None
 
-    def _direct_body(self):
-        """rows exchange -> [assemble, tower + head + backward-data, assemble^T] -> gradient exchange -> owners' update ->
+    def _direct_body(self, inplace=None, defer_join=False):
+        """(``inplace`` = (xf [B, C + 1], y, next_x | None, announce): a step of a captured block on the engine compute
+        segment -- the batch is read where it lies, nothing was staged; ``defer_join``: the second queue is joined in front of
+        the NEXT step's tower launch instead of at the end of this step.)
+        rows exchange -> [assemble, tower + head + backward-data, assemble^T] -> gradient exchange -> owners' update ->
         owners' gather for the next batch -> dense exchange + sum + optimizer step; the tower's weight gradients on a second
         queue beside everything behind the tower.  Every launch of a step, exchanges included, capturable: one hipGraph."""
         dx, lay, slab = self._dx, self.layout, self.slab
@@ -1115,7 +1247,10 @@ class ShardedTrainer(object):
         self.overlap_wgrad = True
         self._send_static = self._send_buf
         try:
-            send, loss, y_pred = self._compute()
+            if inplace is not None:
+                send, loss, y_pred = self._compute_engine(inplace[0], inplace[1], inplace[2], carry=inplace[3])
+            else:
+                send, loss, y_pred = self._compute_engine() if getattr(self, "_eng", None) is not None else self._compute()
         finally:
             self._send_static = None
         wgrad = slab.deferred
@@ -1146,7 +1281,10 @@ class ShardedTrainer(object):
         self.ops.gather(grads_all[:, lay.ids_col:lay.ids_col + lay.n_slots], out=(self._chunks, self._ids_buf, self._parts_buf),
                         push=self._push_rows())
         if wgrad is not None:
-            main.wait_stream(side)
+            if defer_join and getattr(self, "_eng", None) is not None:
+                self._pending_join = True
+            else:
+                main.wait_stream(side)
         else:
             dense()
         return loss, y_pred
@@ -1202,12 +1340,19 @@ class ShardedTrainer(object):
             self._direct_setup(xb0)
             self._announced = None
         blk = getattr(self, "_blk", None)
+        C = int(x_block.shape[2])
+        inplace = getattr(self, "_eng", None) is not None and x_block.dtype == torch.float32 and \
+            y_block.dtype == torch.float32 and yb0.numel() == B and os.environ.get("DCTR_SHARDED_INPLACE", "1") != "0"
         if blk is None or tuple(blk["x"].shape) != tuple(x_block.shape) or blk["x"].dtype != x_block.dtype or \
-                blk["dx"] is not self._dx:
-            blk = self._blk = {"x": torch.empty_like(x_block, memory_format=torch.contiguous_format),
+                blk["dx"] is not self._dx or blk["inplace"] != inplace:
+            # (engine compute segment: the block keeps one more column per row, the sample's own index -- the "id" the
+            # tower launch looks its rows up with in the receive buffer -- and the steps read their batch where it lies)
+            xfull = torch.zeros((S, B, C + 1), dtype=x_block.dtype, device=x_block.device)
+            xfull[:, :, C] = torch.arange(B, dtype=torch.float32, device=x_block.device)[None, :]
+            nffull = torch.zeros((B, C + 1), dtype=x_block.dtype, device=x_block.device)
+            blk = self._blk = {"xfull": xfull, "x": xfull[:, :, :C],
                                "y": torch.empty((S,) + tuple(yb0.shape), dtype=y_block.dtype, device=y_block.device),
-                               "nf": torch.empty_like(xb0, memory_format=torch.contiguous_format), "seg": {},
-                               "dx": self._dx}
+                               "nf": nffull[:, :C], "seg": {}, "dx": self._dx, "inplace": inplace}
         blk["x"].copy_(x_block)
         blk["y"].copy_(y_block.reshape(blk["y"].shape))
         announce = next_first is not None and tuple(next_first.shape) == tuple(xb0.shape)
@@ -1228,8 +1373,12 @@ class ShardedTrainer(object):
                 out, losses = None, []
                 for j in range(S):
                     nxt = blk["x"][j + 1] if j + 1 < S else (blk["nf"] if announce else None)
-                    self._stage(blk["x"][j], blk["y"][j], nxt)
-                    out = self._direct_body()
+                    if blk["inplace"]:
+                        out = self._direct_body(inplace=(blk["xfull"][j], blk["y"][j], nxt, nxt is not None),
+                                                defer_join=j + 1 < S)
+                    else:
+                        self._stage(blk["x"][j], blk["y"][j], nxt)
+                        out = self._direct_body()
                     losses.append(out[0].reshape(()))
                 # (fit() logs the loss of EVERY step: the block's sum, in fp64, as part of the same graph)
                 # (one tensor per captured variant: a replay refreshes the tensor of ITS capture)

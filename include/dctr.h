@@ -362,7 +362,7 @@ int dctr_interacting_bwd(const float* E, int64_t ld_e, int32_t B, int32_t F, int
  * the stamps non-atomically and skip a row only when its stamp is already current, so a sweep that overlaps a catch-up
  * replays rows twice -- and must have finished before dctr_lazy_step_inc (it reads the step counter).  Between the two it
  * may run on a stream of its own beside the gather, the tower, the update and dctr_lazy_apply: they touch the batch's
- * rows, which the catch-up has stamped current and the sweep therefore skips.                                       */
+ * rows, which the catch-up has stamped current and the sweep therefore skips.
  *   *_s1  Adagrad `sum` | Adam `exp_avg`     *_s2  Adam `exp_avg_sq`     *_g  gradient slab, zero at rest
  *   vec   1 or 4: every deep dim and base pointer is a multiple of `vec` floats;  max_dim <= 64*vec                */
 #define DCTR_LAZY_SGD 0
@@ -830,6 +830,15 @@ int dctr_shard_assemble_bwd(float* send, const uint64_t* send_chunks, int32_t ca
                             const float* out, int64_t ld_out, const float* fm_s, int64_t ld_s, const float* X,
                             int64_t ld_x, const int32_t* wdense_cols, int32_t n_wdense, float* g_wdense,
                             dctr_stream_t stream);
+/* The same with the carried columns taken straight from the NEXT batch's input matrix (round 6: the staging launch in front
+ * of every step of a captured group is gone): carried value (q, j) of sample b = x_next[b, carry_cols[q * carry_n + j]]
+ * (carry_cols [n_ranks * carry_n], device); x_next == NULL: dctr_shard_assemble_bwd.                                    */
+int dctr_shard_assemble_bwd_next(float* send, const uint64_t* send_chunks, int32_t carry_col, int32_t carry_n, int64_t ld_chunk,
+                                 int32_t n_ranks, int32_t B, int32_t F, int32_t D, const int32_t* owner_slot, int32_t wide_col,
+                                 const float* g_out, int64_t ld_g, const float* g_wide, const float* g_fm, const float* out,
+                                 int64_t ld_out, const float* fm_s, int64_t ld_s, const float* X, int64_t ld_x,
+                                 const int32_t* wdense_cols, int32_t n_wdense, float* g_wdense, const float* x_next,
+                                 int64_t ld_xn, const int32_t* carry_cols, dctr_stream_t stream);
 
 #ifdef __cplusplus
 }
