@@ -27,7 +27,22 @@ t0 = ev[lo][0]
 for s, e, n, q in ev[lo - 6:hi + 2]:
     print("%8.1f -> %8.1f (%5.1f us) q=%s %s" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, q, short(n)))
 st = [ev[i][0] for i in tw]
+big = [k for k in range(1, len(st)) if st[k] - st[k - 1] > 250e3]
+if big:
+    k = big[-1]
+    print("---- a block boundary (between two hipGraph launches):")
+    for s, e, n, q in ev[tw[k - 1]:tw[k] + 3]:
+        print("%8.1f -> %8.1f (%5.1f us) q=%s %s" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, q, short(n)))
 print("step periods (us):", [round((b - a) / 1e3) for a, b in zip(st, st[1:])][-45:])
 PY
 cat $O/timeline.txt | head -90
 rm -rf $O/trace
+for st in 100 200; do
+timeout 300 python bench.py --gpus 1 --force-parallel --exchange direct --steps $st --warmup 5 --no-other-configs --no-cpu-baseline --no-saturating --kernel-iters 2 > $O/bench_$st.json 2> $O/bench_$st.err
+python - <<PY
+import json
+try:
+    d=json.loads([l for l in open("$O/bench_$st.json") if l.startswith("{")][-1]); print("sharded_1rank steps=$st S=", d["config"]["steps_per_graph"], round(d["ms_per_step"],5), d["timing"]["ms_per_step_all"])
+except Exception as e: print("failed", e)
+PY
+done
