@@ -9,10 +9,12 @@ A "step" = forward + BCE(sum) + backward (fused sparse embedding update) + dense
 one batch of 4096 synthetic Criteo-shaped samples (26 sparse x 1M-row vocab, 13 dense, emb_dim 16) whose
 dataset (4096 x 64 rows) is already resident in HBM.  Prints ONE JSON line (rank 0).  Besides the
 contract's keys it carries
-  roofline     achieved GB/s of the dominant hand-written kernel = ALGORITHMIC bytes per launch (DESIGN.md
-               section 4) / its average duration measured here with HIP events on the launch stream
-  cpu_baseline the reference's algorithm restated in torch-CPU (oracle/torch_port.py), timed on this box's
-               host cores on a bounded sample (rank 0, N=1 only)
+  roofline     the embedding update (the step's HBM-bound kernel): ALGORITHMIC bytes per launch / its
+               duration INSIDE the step (HIP events on its queue); scalar keys beside it name the step's longest launch
+               (dominant_kernel / _bound / _avg_us / _frac, timed inside hipGraph replays through dctr_stamp) and the clock
+               and power the box held (sclk_mhz, power_w)
+  cpu_baseline the UNMODIFIED reference (unpacked from oracle/_ref/, kind "reference"), timed on this box's host cores at
+               the best thread count of a sweep, on a bounded sample (rank 0, N=1 only)
 """
 import argparse
 import json
@@ -220,6 +222,78 @@ def time_update_in_step(model, X, y, B, n=80):
             "how": "HIP events on the update's queue around dctr_embed_update in eager two-queue train steps",
             "tower": {"avg_us": sum(tt) / len(tt), "median_us": tt[len(tt) // 2], "min_us": tt[0], "launches": len(tt),
                       "how": "HIP events on the main queue around dctr_embed_tower_train_step in the same eager steps"}}
+
+
+def time_kernels_in_graph(model, X, y, B, S=20, replays=6):
+    """The step's two long launches timed INSIDE hipGraph replays (round-5 verdict: eager-step HIP events put the tower launch
+    at 57 us where the graph-replayed launch takes 49.5): a group of S steps is captured with one-thread dctr_stamp launches
+    around the tower launch (main queue) and around the embedding update (its queue) that write the device's 100 MHz wall
+    clock; the durations are differences of those stamps, averaged over every step of `replays` replays.  A stamp launch
+    costs the queue ~1-2 us, which the figures include (rocprofv3's own kernel durations under profiles/ are the cross-check).
+    None when the model does not run on the step engine."""
+    st = model._fused_step_state()
+    eng = st.get("engine") if st else None
+    if eng is None:
+        return None
+    from deepctr_torch._hip.graph import GraphedTrainStep
+    nb = X.shape[0] // B
+    S = min(S, nb)
+    stamps = torch.zeros((S, 5), dtype=torch.int64, device=X.device)
+    try:
+        eng.stamps, eng.stamp_i = stamps, 0
+        g = GraphedTrainStep(model, X[:B], y[:B], steps_per_graph=S, double_buffer=False, inputs_ready=True).capture(X[:B], y[:B])
+    finally:
+        eng.stamps = None
+    tower, upd, per, cost = [], [], [], []
+    for r in range(replays):
+        g.step_block(X[:S * B], y[:S * B])
+        torch.cuda.synchronize()
+        v = stamps.cpu().numpy().astype("float64") / 100.0          # us
+        if r == 0:
+            continue                                                  # (first replay: cold)
+        tower += list(v[:, 1] - v[:, 0])
+        upd += list(v[:, 3] - v[:, 2])
+        per += list(v[1:, 0] - v[:-1, 0])
+        cost += list(v[:, 0] - v[:, 4])
+    del g
+    mean = lambda a: float(sum(a) / len(a)) if a else None          # noqa: E731
+    c = mean(cost) or 0.0
+    return {"tower_us": mean(tower) - c, "update_us": mean(upd) - c, "stamp_launch_us": c, "tower_us_raw": mean(tower),
+            "update_us_raw": mean(upd), "step_period_us": mean(per), "steps": len(tower),
+            "how": "dctr_stamp launches (device wall clock, 10 ns ticks) around the launch inside %d-step hipGraph replays: "
+                   "the time the launch holds its queue (its end-of-kernel write-back included, which rocprofv3's kernel "
+                   "duration leaves out), less what one stamp launch costs (two stamps back to back); the stamps lengthen "
+                   "the step itself by ~8 %%" % S}
+
+
+def gpu_clock_power(busy):
+    """(sclk MHz, power W) read from rocm-smi while `busy()` keeps the GPU replaying train steps -- so that a number measured
+    on a box that clocks lower can be told from a slower kernel (round-5 verdict: 11-16 % box-to-box spread on the MFMA-bound
+    legs).  None where rocm-smi does not answer."""
+    import re
+    import subprocess
+    try:
+        busy()
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=20).stdout
+        busy()
+        torch.cuda.synchronize()
+        d = json.loads(out[out.index("{"):])
+        card = d[sorted(d)[0]]
+        sclk = power = None
+        for k, v in card.items():
+            kl = k.lower()
+            if sclk is None and "sclk" in kl:
+                m = re.search(r"(\d+)\s*mhz", str(v).lower())
+                if m:
+                    sclk = float(m.group(1))
+            if power is None and "power" in kl and "(w)" in kl:
+                try:
+                    power = float(v)
+                except (TypeError, ValueError):
+                    pass
+        return {"sclk_mhz": sclk, "power_w": power}
+    except Exception as exc:
+        return {"sclk_mhz": None, "power_w": None, "error": "%s: %s" % (type(exc).__name__, str(exc)[:120])}
 
 
 def saturating_launch(args, model, device, B_sat=262144):
@@ -971,6 +1045,9 @@ def main():
             kern["embed_fwd"]["in_step"] = False
             dom = "embed_update"
         in_step = time_update_in_step(model, X, y, B) if (engine_on and dom == "embed_update") else None
+        in_graph = time_kernels_in_graph(model, X, y, B) if engine_on else None
+        clk = gpu_clock_power(lambda: time_steps(model, X, y, B, 200, 1, args.steps_per_graph, not args.no_graph)[0]) \
+            if (world == 1 and on_gpu) else {}
         traffic = pmc_traffic(dom, args.optimizer, B)
         dom_us = in_step["avg_us"] if in_step else kern[dom]["avg_us"]
         dom_gbs = alg[dom] / (dom_us * 1e-6) / 1e9
@@ -1017,6 +1094,19 @@ def main():
                          "alg_bytes_per_sample_8d": upd_8d if dom == "embed_update" else None,
                          "frac_8d": (upd_8d * B / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if dom == "embed_update" else None,
                          "dominant": dominant,
+                         # scalar keys (a record that flattens nested objects keeps them): the step's LONGEST launch, timed
+                         # inside hipGraph replays (dctr_stamp launches around it: time_kernels_in_graph), the update the
+                         # same way, and the clock / power the box held while replaying train steps
+                         "dominant_kernel": "embed_tower_train" if in_graph else None,
+                         "dominant_bound": "mfma" if in_graph else None,
+                         "dominant_avg_us": (in_graph or {}).get("tower_us"),
+                         "dominant_frac": (tower_flop / (in_graph["tower_us"] * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS)
+                         if (in_graph and in_graph.get("tower_us")) else None,
+                         "update_avg_us_in_graph": (in_graph or {}).get("update_us"),
+                         "update_frac_in_graph": (alg["embed_update"] / (in_graph["update_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS)
+                         if (in_graph and in_graph.get("update_us")) else None,
+                         "in_graph": in_graph,
+                         "sclk_mhz": clk.get("sclk_mhz"), "power_w": clk.get("power_w"),
                          "whole_step_frac_8d": value / world * step_8d / 1e9 / HBM_PEAK_GBS,
                          "whole_step_bytes_per_sample_8d": step_8d,
                          "timed": "in step" if in_step else "stand-alone", "in_step": in_step,

@@ -94,6 +94,12 @@ __global__ __launch_bounds__(64) void k_exch_sync(int32_t* const* __restrict__ p
   if (advance && r == 0) __hip_atomic_store(step, want + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// *dst = the device's 100 MHz wall clock now: a one-thread launch between two kernels of a queue dates the boundary (bench.py's
+// graph-replayed kernel durations: HIP events cannot be read back out of a hipGraph replay)
+__global__ __launch_bounds__(64) void k_stamp(unsigned long long* dst) {
+  if (threadIdx.x == 0) *dst = wall_clock64();
+}
+
 __global__ void k_exch_next(int32_t* step) {
   if (threadIdx.x == 0) *step = *step + 1;
 }
@@ -192,6 +198,12 @@ extern "C" int dctr_exchange_sync(int32_t* const* peer_words, const int32_t* wor
   if (!peer_words || !words || !step || n <= 0 || n > 64 || my_index < 0 || timeout_us <= 0) return DCTR_EINVAL;
   k_exch_sync<<<dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream)>>>(
       peer_words, words, n, my_index, step, advance, static_cast<unsigned long long>(timeout_us) * 100ull, err);
+  return launch_status();
+}
+
+extern "C" int dctr_stamp(uint64_t* dst, dctr_stream_t stream) {
+  if (!dst) return DCTR_EINVAL;
+  k_stamp<<<dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream)>>>(reinterpret_cast<unsigned long long*>(dst));
   return launch_status();
 }
 

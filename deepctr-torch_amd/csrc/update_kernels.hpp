@@ -1,9 +1,9 @@
 // update.hip -- deterministic, atomic-free embedding backward with the optimizer fused in (gfx950).
 //
 // Replaces autograd's aten::embedding_dense_backward x (n_deep + n_wide) + FM's backward + the dense
-// optimizer walk over every table (basemodel.py:261-262, interaction.py:26-34) for plans made of
-// fixed-length fields over distinct tables -- the Criteo shape.  (Plans with pooled VarLen fields or
-// shared tables keep the atomic two-pass kernels of embed.hip.)
+// optimizer walk over every table (basemodel.py:261-262, interaction.py:26-34): fixed-length fields over distinct
+// tables (the Criteo shape) and -- since round 5, GEN = true below -- pooled VarLen fields and tables shared through
+// embedding_name.  (The atomic two-pass kernels of embed.hip only take a unit of more than 128 X columns.)
 //
 // Why not atomics: measured on MI355X at B=4096 (profiles/r01_*), the scatter (1.7 M dword atomics)
 // took 36 us and the xchg-consume pass 59 us -- 9 % of the HBM roofline -- and float atomics make

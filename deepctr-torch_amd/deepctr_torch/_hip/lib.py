@@ -198,6 +198,7 @@ SIGNATURES = {
     "dctr_sizeof_dense_step": (ctypes.c_size_t, []),
     "dctr_step_wait": (ctypes.c_int, [_P, _I32, _I32, _P]),
     "dctr_step_signal": (ctypes.c_int, [_P, _I32, _P]),
+    "dctr_stamp": (ctypes.c_int, [_P, _P]),
     "dctr_copy_async": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P]),
     "dctr_enable_peer_access": (ctypes.c_int, [_I32]),
     "dctr_exchange_post": (ctypes.c_int, [_P, _I32, _I32, _P, _P]),

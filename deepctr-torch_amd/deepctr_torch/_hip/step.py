@@ -77,6 +77,9 @@ class GatherStep(object):
         self._events, self._ev_i = None, 0
         self.timing = None        # (start, end) events around the update on its queue: bench.py's in-step roofline
         self.timing_tower = None  # (start, end) events around the gather + tower launch on the main queue
+        self.stamps = None        # int64 [n, 4 | 5] device tensor: bench.py's graph-replayed kernel durations -- step k dates the
+        self.stamp_i = 0          # boundaries around its tower launch (columns 0, 1) and its update (2, 3): dctr_stamp;
+                                  # column 4: one more stamp right in front of column 0's (the cost of a stamp launch)
         self.steps_run = 0        # steps this engine enqueued (eager or captured): who asks whether it really ran
         self._sync = None         # the weights_flag topology's sync block (include/dctr.h DCTR_SYNC_W_GEN / T_GEN)
         self._parity = 0          # which activation set the next step writes
@@ -251,12 +254,23 @@ class GatherStep(object):
             mh = L.stream_handle(dev)
             if self.timing_tower is not None:
                 self.timing_tower[0].record(main)
+            stamp = None
+            if self.stamps is not None and cuda:
+                row = self.stamp_i % self.stamps.shape[0]
+                self.stamp_i += 1
+                ncol = int(self.stamps.shape[1])
+                stamp = [ctypes.c_void_p(self.stamps.data_ptr() + 8 * (ncol * row + c)) for c in range(ncol)]
+                if ncol > 4:     # (two stamps back to back: what one stamp launch itself costs the queue)
+                    L.check(lib.dctr_stamp(stamp[4], mh), "dctr_stamp")
+                L.check(lib.dctr_stamp(stamp[0], mh), "dctr_stamp")
             L.check(lib.dctr_embed_tower_train_step(cplan, _ptr(xb), xb.stride(0), ctypes.byref(b.desc), B,
                                                     1 if self.want_fm else 0, _ptr(bias), _ptr(y), _ptr(y_pred),
                                                     _ptr(b.g_logit), _ptr(b.gx), ld, _ptr(b.out), ld, _ptr(b.fm_s), ld_s,
                                                     _ptr(err), _ptr(b.ws), mh), "dctr_embed_tower_train_step")
             if self.timing_tower is not None:
                 self.timing_tower[1].record(main)
+            if stamp is not None:            # (in front of the fork: the edge's cost on this queue is not the launch's)
+                L.check(lib.dctr_stamp(stamp[1], mh), "dctr_stamp")
             if side is not None:
                 side.wait_stream(main)       # the update may start once the first launch is done
             L.check(lib.dctr_mlp_train_wgrad(ctypes.byref(b.desc), _ptr(b.out), ld, B, _ptr(b.g_logit), _ptr(b.ws),
@@ -265,12 +279,16 @@ class GatherStep(object):
                 sh = L.stream_handle(dev)
                 if self.timing is not None:
                     self.timing[0].record(side if side is not None else main)
+                if stamp is not None:
+                    L.check(lib.dctr_stamp(stamp[2], sh), "dctr_stamp")
                 L.check(lib.dctr_embed_update(cplan, units, n_units, plan.max_vocab, _ptr(b.ids_t), _ptr(b.parts_t), B,
                                               _ptr(b.gx), ld, _ptr(b.out), ld, _ptr(b.fm_s), ld_s,
                                               _ptr(b.g_logit) if self.want_fm else None,
                                               _ptr(b.g_logit) if plan.has_wide else None, 1, opt, lr, eps, _ptr(xb),
                                               xb.stride(0), _ptr(g_wd), ctypes.byref(inline) if g_wd is not None else None,
                                               _ptr(ws_u), b.upd_n, 1, sh), "dctr_embed_update")
+                if stamp is not None:
+                    L.check(lib.dctr_stamp(stamp[3], sh), "dctr_stamp")
                 if self.timing is not None:
                     self.timing[1].record(side if side is not None else main)
             if side is not None:

@@ -721,6 +721,10 @@ int dctr_step_wait(int32_t* sync, int32_t signal, int32_t timeout_us, dctr_strea
 /* The signal as a one-thread launch of its own on the producer's queue, behind the producer (whose end-of-kernel
  * write-back makes its stores visible first): for a producer that cannot signal from inside its kernel.            */
 int dctr_step_signal(int32_t* sync, int32_t signal, dctr_stream_t stream);
+/* *dst (device) = the 100 MHz device wall clock at the moment a one-thread launch runs on `stream`: put between two kernels
+ * of a queue it dates their boundary -- the only way to time a kernel INSIDE a hipGraph replay (bench.py: the graph-replayed
+ * duration of the step's dominant kernels).                                                                           */
+int dctr_stamp(uint64_t* dst, dctr_stream_t stream);
 
 /* ---- direct exchange between the ranks of a table-sharded job (one process per GPU; deepctr_torch/parallel.py) ----------
  * Replaces the host-issued RCCL all-to-alls / all-reduce of the sharded step (basemodel.py:206-209 is nn.DataParallel in

@@ -177,6 +177,9 @@ class _Core(object):
         self.calls = self.calls[:-2] + ["embed_tower_train_step"]
         return 0
 
+    def dctr_stamp(self, dst, stream):
+        return 0
+
     def dctr_step_signal(self, sync, signal, stream):
         return 0
 
