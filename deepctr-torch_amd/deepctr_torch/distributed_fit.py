@@ -19,8 +19,9 @@ same contract, one process per GPU (``torch.distributed``: RCCL on GPUs, gloo on
   * validation, callbacks and whatever reads ``model.embedding_dict`` after an epoch see complete tables
     (``gather_tables`` at the end of every epoch that needs it).
 
-Models / optimizers outside ``ShardedTrainer``'s envelope (pooled VarLen features, tables shared through embedding_name, Adam /
-RMSprop, L2 on the tables, the reference's default kwargs) train through ``parallel.DataParallelTrainer`` instead: tables
+Pooled VarLen features and tables shared through ``embedding_name`` are sharded too (round 6: the owner of a table group pools
+its positions locally and ships one row per field).  Models / optimizers outside ``ShardedTrainer``'s envelope (Adam / RMSprop,
+L2 on the tables -- the reference's default kwargs --, unequal embedding_dims) train through ``parallel.DataParallelTrainer`` instead: tables
 replicated, every rank applies the same global update from the all-gathered row gradients -- the single-process step on the
 global batch as well, O(vocabulary) only where the optimizer itself is.  Never a silent single-GPU run."""
 import os
@@ -152,10 +153,11 @@ def trainer_for(model):
         ad.attach()                # (the previous fit() left every rank's tables current and detached the trainer)
         return ad
     ad = None
-    if plan.simple_units and plan.update[0] in ("sgd", "adagrad") and os.environ.get("DCTR_FIT_TRAINER", "auto") != "replicated":
+    factory = getattr(model, "_shard_ops_factory", None)      # (tests: stand-ins for the device kernels, simple plans only)
+    if (plan.simple_units or factory is None) and plan.unit_path and plan.update[0] in ("sgd", "adagrad") and \
+            os.environ.get("DCTR_FIT_TRAINER", "auto") != "replicated":
         try:
             ops = None
-            factory = getattr(model, "_shard_ops_factory", None)      # (tests: stand-ins for the device kernels)
             if factory is not None:
                 ops = factory(model, par.ShardLayout(plan, *context()))
             # 'auto': the direct exchange (whole steps, exchanges included, as hipGraphs of S steps) wherever its

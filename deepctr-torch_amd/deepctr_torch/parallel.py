@@ -263,79 +263,137 @@ class DataParallelTrainer(object):
 class ShardLayout(object):
     """Who owns what, and how a chunk row looks.
 
-    Unit ``u`` (one id column with its deep + wide table, ``plan.units``) is owned by rank ``owner[u]`` (``assign``:
-    balanced by unit count, then by table bytes) and sits in the slot given by its position among that owner's units.  A
+    The unit of ownership is a TABLE GROUP: one deep table with every feature column that feeds it -- a fixed-length
+    SparseFeat, the positions of a pooled VarLenSparseFeat (inputs.py:141-155), columns that share the table through
+    ``embedding_name`` (inputs.py:158-180) -- plus the wide tables of the same features.  Group g is owned by rank
+    ``group_owner[g]`` (``assign``: balanced by slot count, then by table bytes).  Every deep FIELD f of the model (a row of
+    ``plan.deep``: what ``combined_dnn_input`` concatenates) has a slot in its owner's chunk: the owner looks the field up --
+    pooling a VarLen field's positions locally -- and ships ONE row of D floats per sample, whatever the field's length.  A
     chunk row is
-        ``[slot 0 | slot 1 | ... | pad to 4 | wide, pad to 4 | n_slots id columns of the NEXT batch | pad to 4]``
-    floats; every rank uses ``n_slots = ceil(F / N)`` slots so that all all-to-alls have equal splits (an owner with
-    fewer units leaves its last slot unused).  The id columns ride along with the row gradients: the ids the owners
-    need for step k+1 travel in step k's gradient all-to-all, which removes one collective per step."""
+        ``[slot 0 | slot 1 | ... | pad to 4 | wide, pad to 4 | n_ids id columns of the NEXT batch | pad to 4]``
+    floats; every rank uses ``n_slots`` = the largest number of fields any rank owns and ``n_ids`` = the largest number of X
+    columns any owner needs (every position of its pooled fields, their length columns), so that all exchanges have equal
+    splits.  The id columns ride along with the row gradients: the ids the owners need for step k+1 travel in step k's
+    gradient exchange.  Simple plans (fixed-length fields over distinct tables, the Criteo shape): one field per group, one
+    id column per slot -- the layout of rounds 3-5, unchanged.  (Round 6: general groups; reference for what a group is:
+    inputs.py:158-180.)"""
 
     def __init__(self, plan, world, rank):
-        if not plan.simple_units or plan.emb_dim <= 0 or not plan.deep:
-            raise NotImplementedError("table-sharded training needs fixed-length sparse features over distinct "
-                                      "tables that share one embedding_dim (pooled VarLen features: single GPU)")
-        if any(di < 0 for (di, wi, col, _) in plan.units):
-            raise NotImplementedError("every linear sparse feature must also be a DNN feature for the sharded path")
-        has_wide = [wi >= 0 for (di, wi, col, _) in plan.units]
-        if any(has_wide) and not all(has_wide):
-            raise NotImplementedError("linear sparse features must cover all or none of the DNN sparse features")
+        if plan.emb_dim <= 0 or not plan.deep:
+            raise NotImplementedError("table-sharded training needs sparse features that share one embedding_dim")
+        if not plan.unit_path:
+            raise NotImplementedError("a table fed by more than 128 columns is beyond the deterministic update kernel")
         self.world, self.rank = int(world), int(rank)
-        self.F, self.D = len(plan.units), int(plan.emb_dim)
-        self.has_wide = bool(has_wide and has_wide[0])
-        self.n_slots = (self.F + self.world - 1) // self.world
+        self.F, self.D = len(plan.deep), int(plan.emb_dim)
+        # ---- groups: deep fields by table; the wide fields of the same features join their group
+        by_table, groups = {}, []
+        for i, f in enumerate(plan.deep):
+            g = by_table.get(id(f.param))
+            if g is None:
+                g = by_table[id(f.param)] = len(groups)
+                groups.append({"deep": [], "wide": [], "names": []})
+            groups[g]["deep"].append(i)
+            groups[g]["names"].append(f.name)
+        name_group = {}
+        for g, grp in enumerate(groups):
+            for n in grp["names"]:
+                name_group[n] = g
+        wide_tables = {}
+        for k, w in enumerate(plan.wide):
+            g = name_group.get(w.name)
+            if g is None:
+                raise NotImplementedError("every linear sparse feature must also be a DNN feature for the sharded path")
+            other = wide_tables.setdefault(id(w.param), g)
+            if other != g:
+                raise NotImplementedError("a linear table shared across the DNN's table groups cannot be sharded by table")
+            groups[g]["wide"].append(k)
+        n_wide_names = len(set(w.name for w in plan.wide))
+        if plan.wide and n_wide_names != len(set(f.name for f in plan.deep)):
+            raise NotImplementedError("linear sparse features must cover all or none of the DNN sparse features")
+        self.has_wide = bool(plan.wide)
+        self.groups = groups
+        self.simple = bool(plan.simple_units)
+        self.group_owner = self.assign(plan, groups, self.world)
+        self.owner = [0] * self.F                      # per deep field
+        for g, grp in enumerate(groups):
+            for i in grp["deep"]:
+                self.owner[i] = self.group_owner[g]
+        # slot of a field = its position in its owner's SUB-PLAN (_hip/plan.py _fields_for: fixed-length fields first, then
+        # the pooled ones, each in the model's order)
+        self.slot = [0] * self.F
+        self.fields_of = []                            # per rank: its deep fields in slot order
+        for q in range(self.world):
+            mine = [i for i in range(self.F) if self.owner[i] == q]
+            mine = [i for i in mine if plan.deep[i].len == 1 and plan.deep[i].pool == 0] + \
+                   [i for i in mine if not (plan.deep[i].len == 1 and plan.deep[i].pool == 0)]
+            for s_, i in enumerate(mine):
+                self.slot[i] = s_
+            self.fields_of.append(mine)
+        self.owned = list(self.fields_of[self.rank])
+        self.n_slots = max(1, max(len(m) for m in self.fields_of))
+        self.owner_slot = [self.owner[i] | (self.slot[i] << 16) for i in range(self.F)]   # what the assemble kernels read
+        # X columns every destination needs from a sender: every position of the owner's fields (deep or wide) and their
+        # length columns, each once, in slot order; [N * n_ids] (unused entries repeat column 0)
+        self.cols_of, self.local_index = [], []
+        for q in range(self.world):
+            cols, fi_local = [], {}
+            fields = [plan.deep[i] for i in self.fields_of[q]]
+            names = set(f.name for f in fields)
+            fields += [w for w in plan.wide if w.name in names]
+            for f in fields:
+                if f.name not in fi_local:
+                    fi_local[f.name] = (len(cols), len(cols) + f.len)
+                    cols += list(range(f.col, f.col + f.len))
+                if f.len_col >= 0:
+                    key = ("len", f.len_col)
+                    if key not in fi_local:
+                        fi_local[key] = (len(cols), len(cols) + 1)
+                        cols.append(f.len_col)
+            self.cols_of.append(cols)
+            self.local_index.append(fi_local)
+        self.n_ids = max(1, max(len(c) for c in self.cols_of))
         self.wide_col = (self.n_slots * self.D + 3) // 4 * 4
         self.ids_col = self.wide_col + 4
-        self.ldc = (self.ids_col + self.n_slots + 3) // 4 * 4
-        self.owner = self.assign(plan, self.world)
-        self.owned = [u for u in range(self.F) if self.owner[u] == self.rank]
-        seen = [0] * self.world
-        self.slot = []                 # position of unit u among its owner's units = its slot in that owner's chunk
-        for u in range(self.F):
-            self.slot.append(seen[self.owner[u]])
-            seen[self.owner[u]] += 1
-        self.owner_slot = [self.owner[u] | (self.slot[u] << 16) for u in range(self.F)]   # what the assemble kernels read
-        # X columns every destination needs from a sender: [N * n_slots] (unused slots repeat column 0)
+        self.ldc = (self.ids_col + self.n_ids + 3) // 4 * 4
+        first = plan.deep[0].col
         cols = []
         for q in range(self.world):
-            mine = [plan.units[u][2] for u in range(self.F) if self.owner[u] == q]
-            cols += mine + [plan.units[0][2]] * (self.n_slots - len(mine))
+            cols += self.cols_of[q] + [first] * (self.n_ids - len(self.cols_of[q]))
         self.id_cols = cols
 
     @staticmethod
-    def assign(plan, world):
-        """owner[u] for every unit: balanced twice over.  (1) COUNT: every rank owns floor(F / N) or ceil(F / N) units
-        -- each unit brings exactly B entries per step to its owner's gather and update, and ceil(F / N) slots per
-        chunk keep every all-to-all an equal split.  (2) BYTES: within that, units go largest table first to the rank
-        that holds the fewest bytes so far (LPT), so a 10 M-row table does not land beside another one while a rank of
-        ten-row tables idles its HBM (real Criteo vocabularies span 10 .. 10 M rows; the synthetic bench's are equal, for
-        which this reduces to round-robin in unit order).  Deterministic: every rank computes the same map."""
-        F = len(plan.units)
-        lo, extra = F // world, F % world                       # `extra` ranks take one unit more
-
-        def nbytes(u):
-            di, wi = plan.units[u][0], plan.units[u][1]
-            n = 0
-            if di >= 0:
-                n += int(plan.deep[di].param.shape[0]) * int(plan.deep[di].param.shape[1])
-            if wi >= 0:
-                n += int(plan.wide[wi].param.shape[0])
+    def assign(plan, groups, world):
+        """owner of every table group: balanced twice over.  (1) SLOTS: a group brings one slot per deep field to its
+        owner's chunk and B entries per X column to its gather and update; groups go, largest first, to the rank with the
+        fewest slots so far -- for one-field groups (the Criteo shape) every rank then owns floor(F / N) or ceil(F / N)
+        fields.  (2) BYTES: ties go to the rank that holds the fewest table bytes (LPT), so a 10 M-row table does not land
+        beside another one while a rank of ten-row tables idles its HBM.  Deterministic: every rank computes the same map."""
+        def nbytes(grp):
+            p = plan.deep[grp["deep"][0]].param
+            n = int(p.shape[0]) * int(p.shape[1])
+            seen = set()
+            for k in grp["wide"]:
+                w = plan.wide[k].param
+                if id(w) not in seen:
+                    seen.add(id(w))
+                    n += int(w.shape[0])
             return n
-        order = sorted(range(F), key=lambda u: (-nbytes(u), u))
-        load, count, owner = [0] * world, [0] * world, [0] * F
-        for u in order:
-            n_full = sum(1 for q in range(world) if count[q] == lo + 1)
-            cand = [q for q in range(world) if count[q] < lo or (count[q] == lo and n_full < extra)]
-            q = min(cand, key=lambda r: (load[r], count[r], r))
-            owner[u] = q
-            load[q] += nbytes(u)
-            count[q] += 1
+
+        def slots(grp):
+            return len(grp["deep"])
+        order = sorted(range(len(groups)), key=lambda g: (-slots(groups[g]), -nbytes(groups[g]), g))
+        load, count, owner = [0] * world, [0] * world, [0] * len(groups)
+        for g in order:
+            q = min(range(world), key=lambda r: (count[r], load[r], r))
+            owner[g] = q
+            load[q] += nbytes(groups[g])
+            count[q] += slots(groups[g])
         return owner
 
     def pack_ids(self, X, idx):
-        """[N][B][n_slots] float ids: what each owner needs of this rank's B samples (``idx`` = id_cols on X's device)."""
+        """[N][B][n_ids] float ids: what each owner needs of this rank's B samples (``idx`` = id_cols on X's device)."""
         B = X.shape[0]
-        return X.index_select(1, idx).view(B, self.world, self.n_slots).permute(1, 0, 2)
+        return X.index_select(1, idx).view(B, self.world, self.n_ids).permute(1, 0, 2)
 
 
 class HipShardOps(object):
@@ -344,23 +402,40 @@ class HipShardOps(object):
     def __init__(self, model, layout):
         from ._hip import lib as L
         from ._hip.plan import EmbeddingPlan
-        from .inputs import SparseFeat
+        from .inputs import SparseFeat, VarLenSparseFeat
         self.L, self.lay = L, layout
         plan = model.model_plan()
         self.plan = plan
-        deep_cols = [c for c in model.dnn_feature_columns if isinstance(c, SparseFeat) and not hasattr(c, "maxlen")]
-        by_name = {c.name: c for c in model._linear_feature_columns if isinstance(c, SparseFeat)}
-        mine = [deep_cols[u] for u in layout.owned]
-        fi = {c.name: (j, j + 1) for j, c in enumerate(mine)}
-        wide_cols = [by_name[c.name] for c in mine] if layout.has_wide else []
+        # the owner's SUB-PLAN: its deep fields in slot order (fixed-length first, then pooled -- the order EmbeddingPlan
+        # itself gives them), the wide columns of the same features, over a compact id matrix [N * B, n_ids] whose columns
+        # are layout.cols_of[rank]
+        by_name = {}
+        for c in model.dnn_feature_columns:
+            if isinstance(c, (SparseFeat, VarLenSparseFeat)):
+                by_name.setdefault(c.name, c)
+        lin_by_name = {c.name: c for c in model._linear_feature_columns if isinstance(c, (SparseFeat, VarLenSparseFeat))}
+        mine = [by_name[plan.deep[i].name] for i in layout.owned]
+        fi_local = layout.local_index[layout.rank]
+        fi = {}
+        for c in mine:
+            fi[c.name] = fi_local[c.name]
+            ln = getattr(c, "length_name", None)
+            if ln is not None:
+                fi[ln] = fi_local[("len", model.feature_index[ln][0])]
+        wide_cols = [lin_by_name[c.name] for c in mine if c.name in lin_by_name] if layout.has_wide else []
         self.sub = EmbeddingPlan(fi, deep_columns=mine, deep_tables=model.embedding_dict, wide_columns=wide_cols,
                                  wide_tables=model.linear_model.embedding_dict if wide_cols else None,
                                  wide_dense_weight=None, with_dense=False) if mine else None
         if self.sub is not None:
             self.sub.share_update_with(plan)
+            got = [f.name for f in self.sub.deep]
+            want = [plan.deep[i].name for i in layout.owned]
+            if got != want:
+                raise RuntimeError("the owner's sub-plan orders its fields %r, the layout expects %r" % (got, want))
         self._idx = None
         self._map = None
         self._idc = None
+        self._side_bufs = {}        # general sub-plans: (den_t, amax) per global batch size, shared by gather and update
 
     def _owner_map(self, dev):
         if self._map is None or self._map.device != dev:
@@ -389,16 +464,25 @@ class HipShardOps(object):
         if sub is None:
             return chunks, None
         cplan = sub.bind(dev)
-        ids_t = out[1] if out is not None else torch.empty((len(sub.units), NB), dtype=torch.int32, device=dev)
-        parts_t = out[2] if out is not None else torch.empty((len(sub.units), NB), dtype=torch.int16, device=dev)
+        ids_t = out[1] if out is not None else torch.empty((sub.n_vcols, NB), dtype=torch.int32, device=dev)
+        parts_t = out[2] if out is not None else torch.empty((sub.n_vcols, NB), dtype=torch.int16, device=dev)
         wide = self._ptr(chunks, lay.wide_col) if lay.has_wide else None
         sub.cplan.out_chunks = push[0].data_ptr() if push is not None else None
         sub.cplan.chunk_rows = int(push[1]) if push is not None else 0
+        general = sub.gen is not None
+        if general:
+            # pooled / shared-table fields: the owner pools its positions locally (one row of D floats per field leaves);
+            # mean pooling's divisors (written with the ids) and max pooling's arg-max positions (written by the gather) stay
+            # here for the update of the same batch
+            sub.point_step_buffers(*self._general_bufs(NB, dev))
         L.check(L.lib().dctr_embed_fwd(cplan, self._ptr(ids_all), ids_all.stride(0), NB, self._ptr(chunks), lay.ldc,
                                        wide, lay.ldc, None, self._ptr(self.plan.err_flag(dev)), sub.units_ptr(),
-                                       len(sub.units), self._ptr(ids_t), self._ptr(parts_t), None, 0,
-                                       L.stream_handle(dev)),
+                                       sub.n_grid_units, None if general else self._ptr(ids_t),
+                                       None if general else self._ptr(parts_t), None, 0, L.stream_handle(dev)),
                 "dctr_embed_fwd(owned tables, global batch)")
+        if general:
+            L.check(L.lib().dctr_embed_ids(cplan, sub.units_ptr(), sub.n_grid_units, self._ptr(ids_all), ids_all.stride(0), NB,
+                                           self._ptr(ids_t), self._ptr(parts_t), L.stream_handle(dev)), "dctr_embed_ids")
         # the id-only half of the owners' update (find + sort every partition's entries) starts now, on a side stream,
         # under the row all-to-all and the tower (EmbeddingPlan.launch_segments)
         # (opt-in: measured at one rank the step is host-paced -- the side-stream hand-offs of the pre-pass cost more
@@ -406,6 +490,13 @@ class HipShardOps(object):
         handle = sub.launch_segments(ids_t, parts_t, NB) if (os.environ.get("DCTR_SHARDED_SEGMENTS", "0") == "1" and
                                                              dev.type == "cuda") else None
         return chunks, (ids_t, parts_t, handle)
+
+    def _general_bufs(self, NB, dev):
+        key = (int(NB), str(dev))
+        b = self._side_bufs.get(key)
+        if b is None:
+            b = self._side_bufs[key] = self.sub.step_buffers(NB, dev)
+        return b
 
     def assemble_fwd(self, recv, X, want_fm):
         L, lay, plan = self.L, self.lay, self.plan
@@ -435,7 +526,7 @@ class HipShardOps(object):
         if send is None:
             send = torch.empty((lay.world * B, lay.ldc), dtype=torch.float32, device=dev)
         w = plan.wide_dense_weight
-        carry_n = lay.n_slots if (push is not None and carry) else 0
+        carry_n = lay.n_ids if (push is not None and carry) else 0
         if next_x is not None and (self._idc is None or self._idc.device != dev):
             self._idc = torch.tensor(lay.id_cols, dtype=torch.int32, device=dev)
         L.check(L.lib().dctr_shard_assemble_bwd_next(
@@ -469,7 +560,9 @@ class HipShardOps(object):
         gw = self._ptr(grads_all, lay.wide_col) if lay.has_wide else None
         ids_t, parts_t, handle = ids_t
         ws, ws_n, pre = sub.update_workspace_for(ids_t, handle, NB)
-        L.check(L.lib().dctr_embed_update(cplan, sub.units_ptr(), len(sub.units), sub.max_vocab, self._ptr(ids_t),
+        if sub.gen is not None:
+            sub.point_step_buffers(*self._general_bufs(NB, dev))     # (what this batch's gather left: divisors, arg-max)
+        L.check(L.lib().dctr_embed_update(cplan, sub.units_ptr(), sub.n_grid_units, sub.max_vocab, self._ptr(ids_t),
                                           self._ptr(parts_t), NB,
                                           self._ptr(grads_all), lay.ldc, None, 0, None, 0, None, gw, lay.ldc, opt, lr,
                                           eps, None, 0, None, None, self._ptr(ws), ws_n, pre, L.stream_handle(dev)),
@@ -762,8 +855,9 @@ class ShardedTrainer(object):
     fused sparse update (xDeepFM, FiBiNET, DCN, PNN, ...: the model's own forward / autograd / optimizer between the same
     exchange steps).
 
-      tables   sharded by table (``layout.owner[u]`` owns unit u -- its deep table, wide table and their Adagrad state --
-               balanced by count, then bytes: ShardLayout.assign);
+      tables   sharded by table GROUP (a deep table with every feature column that feeds it -- fixed-length, pooled VarLen,
+               shared through embedding_name -- and the same features' wide tables; ``layout.group_owner[g]`` owns group g and
+               its Adagrad state; balanced by slots, then bytes: ShardLayout.assign);
                forward = owner-side gather + rows all-to-all, backward = row-gradient all-to-all (the sparse
                reduce-scatter, which also carries the NEXT batch's ids to the owners) + the owner's deterministic
                fused update.  Each row is updated once, by its owner, from the gradients of ALL N*B samples -- the
@@ -887,12 +981,12 @@ class ShardedTrainer(object):
         if getattr(self, "_dx", None) is not None:
             self._direct_seg = _Segment(self._direct_body, bool(self.use_graphs))
         self._blk = None
-        self._ids_next = torch.zeros((lay.world, B, lay.n_slots), dtype=torch.float32, device=dev)
-        self._ids_tmp = torch.empty((lay.world, B, lay.n_slots), dtype=torch.float32, device=dev)
+        self._ids_next = torch.zeros((lay.world, B, lay.n_ids), dtype=torch.float32, device=dev)
+        self._ids_tmp = torch.empty((lay.world, B, lay.n_ids), dtype=torch.float32, device=dev)
         self._recv = torch.empty((lay.world * B, lay.ldc), dtype=torch.float32, device=dev)
         # what arrives in the gradient all-to-all: row gradients of step k AND the ids of step k+1
         self._grads_all = torch.zeros((lay.world * B, lay.ldc), dtype=torch.float32, device=dev)
-        self._ids_view = self._grads_all[:, lay.ids_col:lay.ids_col + lay.n_slots]
+        self._ids_view = self._grads_all[:, lay.ids_col:lay.ids_col + lay.n_ids]
         self._announced = None          # identity of the batch whose ids already sit in _ids_view
         self._ids_t = None
         g = bool(self.use_graphs) and xb.is_cuda and self.slab is not None    # (the autograd route runs eagerly)
@@ -934,7 +1028,7 @@ class ShardedTrainer(object):
         send = self.ops.assemble_bwd(self._x, g_out, g_wide, g_fm, lv["out"].detach(), lv["fm_s"],
                                      g_wd.reshape(-1) if (g_wd is not None and g_wide is not None) else None)
         B = self._x.shape[0]
-        send.view(lay.world, B, lay.ldc)[:, :, lay.ids_col:lay.ids_col + lay.n_slots].copy_(self._ids_next)
+        send.view(lay.world, B, lay.ldc)[:, :, lay.ids_col:lay.ids_col + lay.n_ids].copy_(self._ids_next)
         # (what the trainer logs as the total: loss + the FULL regularisation / auxiliary terms, like
         # DataParallelTrainer and the single-GPU step -- not this rank's 1 / world share that entered the backward)
         self._autograd_total = (loss + reg).detach().reshape(1)
@@ -989,7 +1083,7 @@ class ShardedTrainer(object):
         send = self.ops.assemble_bwd(self._x, g_out, g_wide, g_fm, lv["out"].detach(), lv["fm_s"],
                                      g_wd if g_wide is not None else None)
         B = self._x.shape[0]
-        send.view(lay.world, B, lay.ldc)[:, :, lay.ids_col:lay.ids_col + lay.n_slots].copy_(self._ids_next)
+        send.view(lay.world, B, lay.ldc)[:, :, lay.ids_col:lay.ids_col + lay.n_ids].copy_(self._ids_next)
         return send, loss.detach(), y_pred
 
     def train_step(self, xb, yb, next_xb=None):
@@ -1059,7 +1153,7 @@ class ShardedTrainer(object):
             self._ids_tmp.copy_(self.ops.pack_ids(self._x))
             ids_all = torch.empty_like(self._ids_tmp)
             dist.all_to_all_single(ids_all, self._ids_tmp, group=self.group)
-            self._ids_view.copy_(ids_all.view(lay.world * B, lay.n_slots))
+            self._ids_view.copy_(ids_all.view(lay.world * B, lay.n_ids))
             chunks, self._ids_t = self._segB()
             self._pre = None
             dist.all_to_all_single(self._recv, chunks, group=self.group)             # rows -> samples' ranks
@@ -1092,10 +1186,10 @@ class ShardedTrainer(object):
     # ---- the whole step as ONE hipGraph over the direct exchange ----------------------------------------------------
     def _direct_setup(self, xb):
         lay, B, dev = self.layout, xb.shape[0], xb.device
-        self._dx = DirectExchange(self.group, self.world, self.rank, dev, B, lay.ldc, lay.n_slots, self.slab.grad.numel(),
+        self._dx = DirectExchange(self.group, self.world, self.rank, dev, B, lay.ldc, lay.n_ids, self.slab.grad.numel(),
                                   dense_src=self.slab.grad)
         sub = self.ops.sub
-        nu = len(sub.units) if sub is not None else 1
+        nu = sub.n_vcols if sub is not None else 1      # (one row of ids per X column feeding a unit)
         NB = lay.world * B
         self._chunks = torch.zeros((NB, lay.ldc), dtype=torch.float32, device=dev)
         self._ids_buf = torch.zeros((nu, NB), dtype=torch.int32, device=dev)
@@ -1278,7 +1372,7 @@ class ShardedTrainer(object):
         grads_all = dx.send_grads(send)
         self.ops.update(grads_all, (self._ids_buf, self._parts_buf, seg))
         # (the ids of the announced next batch arrived with the gradients; an un-announced call gathers again itself)
-        self.ops.gather(grads_all[:, lay.ids_col:lay.ids_col + lay.n_slots], out=(self._chunks, self._ids_buf, self._parts_buf),
+        self.ops.gather(grads_all[:, lay.ids_col:lay.ids_col + lay.n_ids], out=(self._chunks, self._ids_buf, self._parts_buf),
                         push=self._push_rows())
         if wgrad is not None:
             if defer_join and getattr(self, "_eng", None) is not None:
@@ -1302,14 +1396,14 @@ class ShardedTrainer(object):
                 self._y.is_contiguous() and self._y.numel() == B and (not announce or next_xb.dtype == torch.float32):
             L.check(L.lib().dctr_shard_stage(P(xb), xb.stride(0), P(yv), B, xb.shape[1], P(self._x), self._x.stride(0),
                                              P(self._y), P(next_xb) if announce else None,
-                                             next_xb.stride(0) if announce else 0, P(self._id_cols), lay.world, lay.n_slots,
+                                             next_xb.stride(0) if announce else 0, P(self._id_cols), lay.world, lay.n_ids,
                                              P(self._send_buf), lay.ldc, lay.ids_col, L.stream_handle(xb.device)),
                     "dctr_shard_stage")
         else:
             self._x.copy_(xb)
             self._y.copy_(yb)
             if announce:
-                self._send_buf.view(lay.world, B, lay.ldc)[:, :, lay.ids_col:lay.ids_col + lay.n_slots].copy_(
+                self._send_buf.view(lay.world, B, lay.ldc)[:, :, lay.ids_col:lay.ids_col + lay.n_ids].copy_(
                     self.ops.pack_ids(next_xb))
 
     # ---- S consecutive steps of the direct exchange as ONE hipGraph ---------------------------------------------------
@@ -1440,7 +1534,7 @@ class ShardedTrainer(object):
             self._ids_tmp.copy_(self.ops.pack_ids(self._x))
             ids_all = torch.empty_like(self._ids_tmp)
             dist.all_to_all_single(ids_all, self._ids_tmp, group=self.group)
-            self._ids_view.copy_(ids_all.view(lay.world * B, lay.n_slots))
+            self._ids_view.copy_(ids_all.view(lay.world * B, lay.n_ids))
         if next_xb is not None and tuple(next_xb.shape) == tuple(xb.shape):
             self._ids_next.copy_(self.ops.pack_ids(next_xb))
             self._announced = (next_xb.data_ptr(), next_xb._version)
@@ -1475,10 +1569,15 @@ class ShardedTrainer(object):
         from ._hip.plan import _STATE
         self._join()
         with torch.no_grad():
-            for u, (di, wi, col, _) in enumerate(plan.units):
-                owner = self.layout.owner[u]
-                for f in ([plan.deep[di]] if di >= 0 else []) + ([plan.wide[wi]] if wi >= 0 else []):
-                    for t in (f.param.data, _STATE.get(f.param)):
+            for g, grp in enumerate(self.layout.groups):
+                owner = self.layout.group_owner[g]
+                params, seen = [], set()
+                for f in [plan.deep[i] for i in grp["deep"]] + [plan.wide[k] for k in grp["wide"]]:
+                    if id(f.param) not in seen:
+                        seen.add(id(f.param))
+                        params.append(f.param)
+                for p_ in params:
+                    for t in (p_.data, _STATE.get(p_)):
                         if t is None:
                             continue
                         _broadcast(t, owner, self.group)

@@ -275,3 +275,105 @@ def test_fit_through_the_direct_exchange_equals_single_process_fit(tmp_path):
         err = float((ranks[0]["sd"][k] - v).abs().max())
         assert err <= 2e-6 * max(1.0, float(v.abs().max())) + 2e-7, "%s: %.3e" % (k, err)
         assert torch.equal(ranks[0]["sd"][k], ranks[1]["sd"][k]), "replicas differ: %s" % k
+
+
+# ---- general table groups: pooled VarLen fields and tables shared through embedding_name, sharded (round 6) ----------------
+def _pooled_cols():
+    for p in (os.path.join(ROOT, "deepctr-torch_amd"),):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from deepctr_torch.inputs import DenseFeat, SparseFeat, VarLenSparseFeat
+    cols = [SparseFeat("C%d" % i, V_, D_) for i in range(4)]
+    cols.append(SparseFeat("C4", V_, D_, embedding_name="C0"))                       # shares C0's table
+    cols += [DenseFeat("I%d" % i, 1) for i in range(2)]
+    cols.append(VarLenSparseFeat(SparseFeat("hist", V_, D_, embedding_name="C1"), maxlen=4, combiner="mean"))   # over C1's table
+    cols.append(VarLenSparseFeat(SparseFeat("tags", 300, D_), maxlen=3, combiner="sum"))
+    cols.append(VarLenSparseFeat(SparseFeat("kw", 200, D_), maxlen=5, combiner="max", length_name="kw_len"))
+    return cols
+
+
+def _pooled_model(dev):
+    from deepctr_torch.models import DeepFM
+    cols = _pooled_cols()
+    return DeepFM(cols, cols, dnn_hidden_units=(64, 32), l2_reg_linear=0, l2_reg_embedding=0, init_std=0.05, seed=7, device=dev)
+
+
+def _pooled_batch(step, world):
+    g = torch.Generator().manual_seed(300 + step)
+    n = world * B_
+    ids = torch.randint(0, V_, (n, 5), generator=g).float()
+    dense = torch.rand(n, 2, generator=g)
+    hist = torch.randint(1, V_, (n, 4), generator=g) * (torch.arange(4)[None, :] < torch.randint(0, 5, (n, 1), generator=g))
+    tags = torch.randint(1, 300, (n, 3), generator=g) * (torch.arange(3)[None, :] < torch.randint(0, 4, (n, 1), generator=g))
+    kw = torch.randint(0, 200, (n, 5), generator=g)
+    kw_len = torch.randint(1, 6, (n, 1), generator=g)
+    # (inputs.py:99-123: columns in feature order; a VarLen's positions, then -- behind the first VarLen that names it -- its
+    # length column)
+    X = torch.cat([ids, dense, hist.float(), tags.float(), kw.float(), kw_len.float()], 1)
+    y = torch.randint(0, 2, (n,), generator=g).float()
+    return X, y
+
+
+def _worker_pooled(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        dev = "cuda:0"
+        m = _pooled_model(dev)
+        from deepctr_torch.parallel import ShardedTrainer
+        m.compile("adagrad", "binary_crossentropy", metrics=[])
+        m.train()
+        tr = ShardedTrainer(m, exchange="direct", use_graphs=False)
+        lay = tr.layout
+        assert not lay.simple and lay.n_ids > lay.n_slots
+        batches = [_pooled_batch(step, world) for step in range(STEPS)]
+        mine = [(Xg[rank * B_:(rank + 1) * B_].contiguous().to(dev), yg[rank * B_:(rank + 1) * B_].contiguous().to(dev))
+                for Xg, yg in batches]
+        losses = []
+        for step in range(STEPS):
+            if step == 2:
+                tr.set_use_graphs(True)
+            nxt = mine[step + 1][0] if step + 1 < STEPS else None
+            losses.append(tr.train_step(mine[step][0], mine[step][1], next_xb=nxt)[0].clone())
+        torch.cuda.synchronize()
+        tr.gather_tables()
+        tr.close()
+        m.model_plan().check_ids()
+        torch.save({"sd": {k: v.detach().cpu().clone() for k, v in m.state_dict().items()},
+                    "loss": torch.stack([l.reshape(()) for l in losses]).cpu(),
+                    "owners": list(lay.group_owner), "n_slots": lay.n_slots, "n_ids": lay.n_ids},
+                   os.path.join(out_dir, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pooled_and_shared_tables_are_sharded_too(tmp_path, world):
+    """DeepFM with a table shared through embedding_name, a mean history over another field's table, a sum-pooled and a
+    max-pooled VarLen field (length column): ShardedTrainer owns table GROUPS, the owner pools locally and ships one row per
+    field, the owner's update is the deterministic general one -- parameters and losses of the single-process step on the
+    concatenated batch (whose pooled lookup / update are pinned to the reference: tests/test_gpu_update_general.py)."""
+    port = _free_port()
+    mp.spawn(_worker_pooled, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    ranks = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
+    assert len(set(ranks[0]["owners"])) == min(world, len(ranks[0]["owners"]))       # every rank owns a group
+    for r in range(1, world):
+        for k in ranks[0]["sd"]:
+            assert torch.equal(ranks[0]["sd"][k], ranks[r]["sd"][k]), "replicas differ after gather_tables: %s" % k
+    dev = "cuda:0"
+    ref = _pooled_model(dev)
+    ref.compile("adagrad", "binary_crossentropy", metrics=[])
+    ref.train()
+    ref_loss = []
+    for step in range(STEPS):
+        Xg, yg = _pooled_batch(step, world)
+        ref_loss.append(ref._train_step(Xg.to(dev), yg.to(dev))[0].reshape(()))
+    torch.cuda.synchronize()
+    got_loss = sum(r["loss"] for r in ranks)
+    assert torch.allclose(got_loss, torch.stack(ref_loss).cpu(), rtol=2e-5), (got_loss, ref_loss)
+    for k, v in ref.state_dict().items():
+        v = v.detach().cpu()
+        err = float((ranks[0]["sd"][k] - v).abs().max())
+        assert err <= 2e-6 * max(1.0, float(v.abs().max())) + 2e-7, "%s: %.3e" % (k, err)
