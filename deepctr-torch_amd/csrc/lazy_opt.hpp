@@ -1,0 +1,134 @@
+// lazy_opt.hpp -- the optimizer arithmetic of the lazily replayed table update (csrc/lazy.hip), shared with the sorted
+// embedding update (csrc/update_kernels.hpp, DCTR_UPD_LAZY: round 6 -- the step that carries the batch's data gradient runs
+// inside the update kernel instead of a gradient slab + a second pass).  See lazy.hip for the protocol.
+#pragma once
+#include "common.hpp"
+
+namespace dctr_lazy {
+using namespace dctr;
+
+#ifdef DCTR_LAZY_IEEE_REPLAY
+constexpr bool kFastReplay = false;   // (A/B build: the replay loop on IEEE division / square root)
+#else
+constexpr bool kFastReplay = true;
+#endif
+
+struct OptConst {
+  int kind;   // DCTR_LAZY_SGD / ADAGRAD / ADAM / RMSPROP
+  float lr, eps, beta1, beta2;
+  // Adam's step-dependent scalars by step number (dctr_lazy_opt_t: adam_ss[T - 1], adam_bc[T - 1]; constant from the last
+  // entry on), or NULL: computed in the kernel (AdamClock)
+  const float* adam_ss;
+  const float* adam_bc;
+  int n_ss, n_bc;
+};
+
+// step-dependent scalars of Adam for step number T (1-based), maintained incrementally in double
+struct AdamClock {
+  double p1, p2;      // beta1^T, beta2^T
+  double b1, b2, lr;
+  __device__ __forceinline__ void start(const OptConst& o, int T) {
+    b1 = o.beta1; b2 = o.beta2; lr = o.lr;
+    p1 = pow(b1, static_cast<double>(T));
+    p2 = pow(b2, static_cast<double>(T));
+  }
+  __device__ __forceinline__ void next() { p1 *= b1; p2 *= b2; }
+  __device__ __forceinline__ float step_size() const { return static_cast<float>(lr / (1.0 - p1)); }
+  __device__ __forceinline__ float bc2_sqrt() const { return static_cast<float>(sqrt(1.0 - p2)); }
+};
+
+// Adam's scalars of step T from the host's tables.  At the Criteo shape a row sleeps V / B ~ 244 steps between two batches
+// that touch it and its catch-up replays every one of them: with the scalars computed in the loop (two double
+// multiplies, a double division and a double square root per step and lane) that arithmetic was ~40 % of k_lazy's
+// 282 us; they depend on T alone, so the host tabulates them once -- with the same pow / division / sqrt in double that
+// torch.optim.Adam performs per step on the host (adam.py: bias_correction = 1 - beta ** step).
+__device__ __forceinline__ void adam_tab(const OptConst& o, int T, float& ss, float& bc) {
+  ss = ldg_f32(o.adam_ss + ((T < o.n_ss ? T : o.n_ss) - 1));
+  bc = ldg_f32(o.adam_bc + ((T < o.n_bc ? T : o.n_bc) - 1));
+}
+// the same for a wave-uniform T: plain loads the compiler can issue on the scalar unit (no per-lane address arithmetic)
+__device__ __forceinline__ void adam_tab_uniform(const OptConst& o, int T, float& ss, float& bc) {
+  ss = o.adam_ss[(T < o.n_ss ? T : o.n_ss) - 1];
+  bc = o.adam_bc[(T < o.n_bc ? T : o.n_bc) - 1];
+}
+__device__ __forceinline__ void adam_scalars(const OptConst& o, int T, float& ss, float& bc) {
+  if (o.adam_ss) {
+    adam_tab(o, T, ss, bc);
+  } else {
+    AdamClock ck;
+    ck.start(o, T);
+    ss = ck.step_size();
+    bc = ck.bc2_sqrt();
+  }
+}
+
+// Division and square root of the REPLAY loop.  A row that slept k steps replays k optimizer steps whose only gradient is
+// the L2 term; at the Criteo shape (k ~ V / B = 244) that loop is the whole cost of the default-kwargs step, and two IEEE
+// divisions + one IEEE square root were ~30 of its ~50 instructions per element (v_div_scale x 2, v_rcp, five fmas,
+// v_div_fmas, v_div_fixup each: the range scaling and special-case fix-ups of a general division).  Here: hardware
+// reciprocal / reciprocal square root (1 ulp) and ONE Newton correction through the exact residual (fma), i.e. the core of
+// the IEEE sequence without its scaling and fix-ups -- the operands of this loop are ordinary normal numbers (denominators
+// >= eps, moments of magnitude (lambda w)^2).  Result within 1 ulp of the correctly rounded one, the same on every run.
+// The step that carries a DATA gradient (apply) and the dense slab keep the IEEE operations.
+__device__ __forceinline__ float div_nr(float a, float d, float rd) {   // rd = rcp(d)
+  const float q = a * rd;
+  return fmaf(fmaf(-q, d, a), rd, q);
+}
+__device__ __forceinline__ float sqrt_nr(float x) {
+  // (a moment is never negative; rsq of the clamped value keeps x = 0 at exactly 0 -- 0 * finite -- without a select.  A
+  // moment below the smallest normal number comes out smaller than its root: it is added to eps = 1e-8 either way)
+  const float r = __builtin_amdgcn_rsqf(fmaxf(x, 1.17549435e-38f));
+  const float s = x * r;
+  return fmaf(fmaf(-s, s, x), 0.5f * r, s);
+}
+
+// one optimizer step on one element.  a = Adagrad sum | Adam exp_avg, b = Adam exp_avg_sq.  FAST: the replay loop's
+// division / square root (above); rbc = rcp(bc2s), computed once per step by the caller.
+template <bool FAST = false>
+__device__ __forceinline__ void opt_step(const OptConst& o, float g, float& w, float& a, float& b, float step_size,
+                                         float bc2s, float rbc = 0.f) {
+  if (o.kind == DCTR_LAZY_ADAM) {
+    a = a + (g - a) * (1.f - o.beta1);
+    b = b * o.beta2 + (1.f - o.beta2) * g * g;
+    if (FAST) {
+      const float denom = div_nr(sqrt_nr(b), bc2s, rbc) + o.eps;
+      w = w - step_size * div_nr(a, denom, __builtin_amdgcn_rcpf(denom));
+    } else {
+      const float denom = sqrtf(b) / bc2s + o.eps;
+      w = w - step_size * (a / denom);
+    }
+  } else if (o.kind == DCTR_LAZY_ADAGRAD) {
+    a = a + g * g;
+    if (FAST) {
+      const float denom = sqrt_nr(a) + o.eps;
+      w = w - o.lr * div_nr(g, denom, __builtin_amdgcn_rcpf(denom));
+    } else {
+      w = w - o.lr * (g / (sqrtf(a) + o.eps));
+    }
+  } else if (o.kind == DCTR_LAZY_RMSPROP) {
+    // square_avg.mul_(alpha).addcmul_(g, g, value=1 - alpha); p.addcdiv_(g, square_avg.sqrt().add_(eps), value=-lr)
+    // -- with the roundings of ATen's device kernels (each tensor op rounds; addcmul is a + (v * b) * c and addcdiv is
+    // a + v * (b / c), their last multiply-add contracted): RMSprop divides by sqrt(square_avg) + 1e-8, so a row whose
+    // accumulator is still ~g^2/100 moves by 10 lr whatever |g| is, and an ulp of difference in a sign-deciding value
+    // shows up as 0.1 in the weight.  beta1 carries float(1 - alpha) as torch computes it (in double).
+    const float a1 = __fmul_rn(a, o.beta2);
+    a = __fmaf_rn(__fmul_rn(o.beta1, g), g, a1);
+    w = __fmaf_rn(-o.lr, __fdiv_rn(g, __fadd_rn(__fsqrt_rn(a), o.eps)), w);
+  } else {
+    w = w - o.lr * g;
+  }
+}
+
+
+inline OptConst opt_const(const dctr_lazy_opt_t* opt) {
+  OptConst o;
+  o.kind = opt->kind; o.lr = opt->lr; o.eps = opt->eps; o.beta1 = opt->beta1; o.beta2 = opt->beta2;
+  const bool tab = opt->kind == DCTR_LAZY_ADAM && opt->adam_ss && opt->adam_bc && opt->n_ss > 0 && opt->n_bc > 0;
+  o.adam_ss = tab ? opt->adam_ss : nullptr;
+  o.adam_bc = tab ? opt->adam_bc : nullptr;
+  o.n_ss = tab ? opt->n_ss : 0;
+  o.n_bc = tab ? opt->n_bc : 0;
+  return o;
+}
+
+}  // namespace dctr_lazy

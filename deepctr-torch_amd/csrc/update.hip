@@ -680,6 +680,18 @@ extern "C" int dctr_embed_segments(const dctr_plan_t* plan, const int32_t* units
   return launch_status();
 }
 
+namespace {
+int embed_update_impl(const dctr_plan_t* plan, const int32_t* units, int32_t n_units,
+                      int64_t max_vocab, const int32_t* ids_t, const uint16_t* parts_t, int32_t B,
+                      const float* g_out,
+                      int64_t ld_g, const float* out, int64_t ld_out, const float* fm_s,
+                      int64_t ld_s, const float* g_fm, const float* g_wide, int64_t ld_gw,
+                      int32_t opt, float lr, float eps, const float* X, int64_t ld_x, float* g_wdense,
+                      const dctr_dense_step_t* wdense_step, int32_t* workspace, int64_t workspace_ints,
+                      int32_t presorted, dctr_stream_t stream, const dctr_lazy_unit_t* lz, const int32_t* lz_step,
+                      const dctr_lazy_opt_t* lz_opt);
+}  // namespace
+
 extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, int32_t n_units,
                                  int64_t max_vocab, const int32_t* ids_t, const uint16_t* parts_t, int32_t B,
                                  const float* g_out,
@@ -688,6 +700,36 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
                                  int32_t opt, float lr, float eps, const float* X, int64_t ld_x, float* g_wdense,
                                  const dctr_dense_step_t* wdense_step, int32_t* workspace, int64_t workspace_ints,
                                  int32_t presorted, dctr_stream_t stream) {
+  if (opt == DCTR_UPD_LAZY) return DCTR_EINVAL;       // (dctr_embed_update_lazy)
+  return embed_update_impl(plan, units, n_units, max_vocab, ids_t, parts_t, B, g_out, ld_g, out, ld_out, fm_s, ld_s, g_fm,
+                           g_wide, ld_gw, opt, lr, eps, X, ld_x, g_wdense, wdense_step, workspace, workspace_ints, presorted,
+                           stream, nullptr, nullptr, nullptr);
+}
+
+extern "C" int dctr_embed_update_lazy(const dctr_plan_t* plan, const int32_t* units, int32_t n_units, int64_t max_vocab,
+                                      const int32_t* ids_t, const uint16_t* parts_t, int32_t B, const float* g_out,
+                                      int64_t ld_g, const float* out, int64_t ld_out, const float* fm_s, int64_t ld_s,
+                                      const float* g_fm, const float* g_wide, int64_t ld_gw, const float* X, int64_t ld_x,
+                                      float* g_wdense, int32_t* workspace, int64_t workspace_ints,
+                                      const dctr_lazy_unit_t* lazy_units, const int32_t* step, const dctr_lazy_opt_t* lazy_opt,
+                                      dctr_stream_t stream) {
+  if (!lazy_units || !step || !lazy_opt) return DCTR_EINVAL;
+  if (plan && plan->ext) return DCTR_ENOSUP;            // (simple units only, like csrc/lazy.hip)
+  return embed_update_impl(plan, units, n_units, max_vocab, ids_t, parts_t, B, g_out, ld_g, out, ld_out, fm_s, ld_s, g_fm,
+                           g_wide, ld_gw, DCTR_UPD_LAZY, 0.f, 0.f, X, ld_x, g_wdense, nullptr, workspace, workspace_ints, 1,
+                           stream, lazy_units, step, lazy_opt);
+}
+
+namespace {
+int embed_update_impl(const dctr_plan_t* plan, const int32_t* units, int32_t n_units,
+                      int64_t max_vocab, const int32_t* ids_t, const uint16_t* parts_t, int32_t B,
+                      const float* g_out,
+                      int64_t ld_g, const float* out, int64_t ld_out, const float* fm_s,
+                      int64_t ld_s, const float* g_fm, const float* g_wide, int64_t ld_gw,
+                      int32_t opt, float lr, float eps, const float* X, int64_t ld_x, float* g_wdense,
+                      const dctr_dense_step_t* wdense_step, int32_t* workspace, int64_t workspace_ints,
+                      int32_t presorted, dctr_stream_t stream, const dctr_lazy_unit_t* lz, const int32_t* lz_step,
+                      const dctr_lazy_opt_t* lz_opt) {
   // (out / ld_out: the forward's rows.  Fixed-length fields never re-read them -- FM is folded algebraically at the row --
   // a POOLED field's FM backward needs its pooled value, which is no table row: general units read it there)
   if (!plan || !units || !ids_t || n_units <= 0 || B < 0) return DCTR_EINVAL;
@@ -702,7 +744,13 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
   if (g_wide && ld_gw < 1) return DCTR_EINVAL;
   if (g_wdense && (!X || !g_wide || plan->n_wdense <= 0 || !plan->wdense_cols)) return DCTR_EINVAL;
   if (B == 0) return DCTR_OK;
-  if (opt != DCTR_UPD_SGD && opt != DCTR_UPD_ADAGRAD && opt != DCTR_UPD_ACCUM) return DCTR_EINVAL;
+  if (opt != DCTR_UPD_SGD && opt != DCTR_UPD_ADAGRAD && opt != DCTR_UPD_ACCUM && opt != DCTR_UPD_LAZY) return DCTR_EINVAL;
+  if (opt == DCTR_UPD_LAZY) {
+    if (!lz || !lz_step || !lz_opt || gen || !presorted) return DCTR_EINVAL;
+    if (lz_opt->kind != DCTR_LAZY_SGD && lz_opt->kind != DCTR_LAZY_ADAGRAD && lz_opt->kind != DCTR_LAZY_ADAM &&
+        lz_opt->kind != DCTR_LAZY_RMSPROP)
+      return DCTR_EINVAL;
+  }
   if (!dctr_embed_update_supported(plan, max_vocab, B)) return DCTR_ENOSUP;
   if (opt == DCTR_UPD_ACCUM && !(plan->flags & DCTR_PLAN_HAS_GACC)) return DCTR_EINVAL;
   if (opt == DCTR_UPD_ADAGRAD && !(plan->flags & DCTR_PLAN_HAS_STATE)) return DCTR_EINVAL;
@@ -728,6 +776,8 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
 #endif
   a.X = X; a.ldx = ld_x; a.wdense_cols = plan->wdense_cols; a.n_wdense = plan->n_wdense; a.g_wdense = g_wdense;
   a.wd_step = dense_step_dev(g_wdense ? wdense_step : nullptr);
+  a.lz = lz; a.lz_step = lz_step;
+  if (lz_opt) a.lzo = dctr_lazy::opt_const(lz_opt);
 
   const int P = pick_p(B, kThreads / lpr);
   fill_partition_args(a, B, P);
@@ -775,3 +825,4 @@ extern "C" int dctr_embed_update(const dctr_plan_t* plan, const int32_t* units, 
 #undef DCTR_UPD_GEN
   return launch_status();
 }
+}  // namespace

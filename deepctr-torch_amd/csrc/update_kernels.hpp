@@ -42,6 +42,7 @@
 // update_gen.hip (GEN = true instantiations): two translation units that compile in parallel.
 #pragma once
 #include "common.hpp"
+#include "lazy_opt.hpp"
 
 using namespace dctr;
 
@@ -102,6 +103,12 @@ struct UpdArgs {
   int64_t ld_am;
   uint64_t bmagic;                   // v / B == (v * bmagic) >> bshift
   int32_t bshift;
+  // DCTR_UPD_LAZY (round 6; simple units only): the lazily regularised / Adam tables' step that carries the batch's data
+  // gradient -- g = G + 2 lambda w, one step of csrc/lazy.hip's optimizer on (w, s1, s2), stamp = t + 1 -- at the row, where
+  // the sorted update has the gradient's sum in registers (it used to go through a gradient slab and a second pass)
+  const dctr_lazy_unit_t* lz;        // [n_units] device
+  dctr_lazy::OptConst lzo;
+  const int32_t* lz_step;            // device: optimizer steps completed so far
 };
 
 constexpr int kMaxSlots = DCTR_MAX_UNIT_SLOTS;   // slots of one unit (their descriptors are staged in LDS)
@@ -147,6 +154,49 @@ __device__ __forceinline__ dctr_field_t uni_field(const dctr_field_t& f) {
   r.ld = uni(f.ld);
   r.ld_state = uni(f.ld_state);
   return r;
+}
+
+// a unit's lazily updated tables, wave-uniform (DCTR_UPD_LAZY)
+struct LazyCtx {
+  float* deep; float* s1; float* s2; float* wide; float* ws1; float* ws2; int32_t* stamp;
+  int64_t ld_d, ld_s1, ld_w, ld_ws1;
+  int dim;
+  float lam2d, lam2w, ss1, bc1;
+  int t;
+};
+__device__ __forceinline__ LazyCtx lazy_ctx(const UpdArgs& A, int u) {
+  LazyCtx Z;
+  const dctr_lazy_unit_t* un = A.lz + u;
+  Z.deep = uni(un->deep); Z.s1 = uni(un->deep_s1); Z.s2 = uni(un->deep_s2);
+  Z.wide = uni(un->wide); Z.ws1 = uni(un->wide_s1); Z.ws2 = uni(un->wide_s2);
+  Z.stamp = uni(un->stamp);
+  Z.dim = uni(un->dim);
+  const int ldd = uni(un->ld_deep), lds1 = uni(un->ld_deep_s1), ldw = uni(un->ld_wide), ldws = uni(un->ld_wide_s1);
+  Z.ld_d = ldd > 0 ? ldd : Z.dim;
+  Z.ld_s1 = lds1 > 0 ? lds1 : Z.dim;
+  Z.ld_w = ldw > 0 ? ldw : 1;
+  Z.ld_ws1 = ldws > 0 ? ldws : 1;
+  Z.lam2d = 2.f * __builtin_bit_cast(float, uni(__builtin_bit_cast(int32_t, un->l2_deep)));
+  Z.lam2w = 2.f * __builtin_bit_cast(float, uni(__builtin_bit_cast(int32_t, un->l2_wide)));
+  Z.t = uni(*(const DCTR_GLOBAL int32_t*)A.lz_step);
+  Z.ss1 = 0.f;
+  Z.bc1 = 1.f;
+  if (A.lzo.kind == DCTR_LAZY_ADAM) dctr_lazy::adam_scalars(A.lzo, Z.t + 1, Z.ss1, Z.bc1);
+  return Z;
+}
+// the step on one strip: G = the batch's gradient sum for the row; w / a / b = the row's strips of the table and the
+// optimizer's two state slabs (zeros where a slab is absent).  lazy.hip k_lazy<., 1>'s arithmetic (opt_step, IEEE division).
+template <int VEC>
+__device__ __forceinline__ void lazy_apply_strip(const UpdArgs& A, const LazyCtx& Z, float lam2, float* pw, float* pa,
+                                                 float* pb, const Strip<VEC>& G, const Strip<VEC>& w, const Strip<VEC>& a,
+                                                 const Strip<VEC>& b) {
+  Strip<VEC> nw = w, na = a, nb = b;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i)
+    dctr_lazy::opt_step(A.lzo, G.v[i] + lam2 * w.v[i], nw.v[i], na.v[i], nb.v[i], Z.ss1, Z.bc1);
+  strip_store<VEC>(pw, nw);
+  if (pa) strip_store<VEC>(pa, na);
+  if (pb) strip_store<VEC>(pb, nb);
 }
 
 // id / P and id % P for a runtime P through a host-computed reciprocal (exact for 0 <= id < 2^31)
@@ -472,12 +522,26 @@ __device__ __forceinline__ void upd_partition(const UpdArgs& A, const int u, con
   };
   // the strips of a row this lane may update: w (table, or gacc in accumulate mode), s (Adagrad state), e (the
   // table strip FM's fold needs; = w unless accumulating)
+  LazyCtx Z = {};
+  if constexpr (OPT == DCTR_UPD_LAZY) Z = lazy_ctx(A, u);
   auto load_row = [&](int64_t row, Strip<VEC>& w, Strip<VEC>& s, Strip<VEC>& e, float& ww, float& sw) {
     w = strip_zero<VEC>();
     s = strip_zero<VEC>();
     e = strip_zero<VEC>();
     ww = 0.f;
     sw = 0.f;
+    if constexpr (OPT == DCTR_UPD_LAZY) {      // (s carries the first state slab; the second is fetched at the step)
+      if (lane_on) {
+        w = strip_load<VEC>(Z.deep + row * Z.ld_d + e0);
+        if (Z.s1) s = strip_load<VEC>(Z.s1 + row * Z.ld_s1 + e0);
+        e = w;
+      }
+      if (wide_on && gl == 0) {
+        ww = ldg_f32(Z.wide + row * Z.ld_w);
+        if (Z.ws1) sw = ldg_f32(Z.ws1 + row * Z.ld_ws1);
+      }
+      return;
+    }
     if (lane_on) {
       const int64_t off_w = row * ld_dw + e0;
       w = strip_load<VEC>(OPT == DCTR_UPD_ACCUM ? fd.gacc + row * fd.dim + e0 : fd.table + off_w);
@@ -495,6 +559,28 @@ __device__ __forceinline__ void upd_partition(const UpdArgs& A, const int u, con
   };
   auto apply_row = [&](int64_t row, Strip<VEC> acc, float accf, float accw, const Strip<VEC>& w, const Strip<VEC>& s,
                        const Strip<VEC>& e, float ww, float sw) {
+    if constexpr (OPT == DCTR_UPD_LAZY) {
+      if (lane_on) {
+        if (fold) {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) acc.v[k] -= accf * e.v[k];
+        }
+        const Strip<VEC> b2 = Z.s2 ? strip_load<VEC>(Z.s2 + row * Z.dim + e0) : strip_zero<VEC>();
+        lazy_apply_strip<VEC>(A, Z, Z.lam2d, Z.deep + row * Z.ld_d + e0, Z.s1 ? Z.s1 + row * Z.ld_s1 + e0 : nullptr,
+                              Z.s2 ? Z.s2 + row * Z.dim + e0 : nullptr, acc, w, s, b2);
+      }
+      if (wide_on && gl == 0) {
+        Strip<1> a1, w1, s1, b1;
+        a1.v[0] = accw;
+        w1.v[0] = ww;
+        s1.v[0] = sw;
+        b1.v[0] = Z.ws2 ? ldg_f32(Z.ws2 + row) : 0.f;
+        lazy_apply_strip<1>(A, Z, Z.lam2w, Z.wide + row * Z.ld_w, Z.ws1 ? Z.ws1 + row * Z.ld_ws1 : nullptr,
+                            Z.ws2 ? Z.ws2 + row : nullptr, a1, w1, s1, b1);
+      }
+      if (gl == 0) *(DCTR_GLOBAL int32_t*)(Z.stamp + row) = Z.t + 1;     // the row has seen step t + 1
+      return;
+    }
     if (lane_on) {
       if (fold) {
 #pragma unroll
@@ -1013,6 +1099,8 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_apply_sorted(UpdArgs A) {
     upd_partition<VEC, LPR, OPT, GEN>(A, u, p, sl);
     return;
   }
+  LazyCtx Z = {};
+  if constexpr (OPT == DCTR_UPD_LAZY) Z = lazy_ctx(A, u);
   DCTR_TRACE(1);
 #ifdef DCTR_DIAG
   if (A.trace && tid == 0) A.trace[blockIdx.x * 8ull + 7] = static_cast<unsigned long long>(n);
@@ -1043,7 +1131,8 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_apply_sorted(UpdArgs A) {
     // two were meant; round 3)
     Strip<VEC> h = strip_zero<VEC>(), w = strip_zero<VEC>(), s = strip_zero<VEC>(), e = strip_zero<VEC>();
     Strip<VEC> S = strip_zero<VEC>();
-    float gf = 0.f, gw = 0.f, ww = 0.f, sw = 0.f;
+    Strip<VEC> s2 = strip_zero<VEC>();      // (DCTR_UPD_LAZY: the second state slab's strip)
+    float gf = 0.f, gw = 0.f, ww = 0.f, sw = 0.f, sw2 = 0.f;
     if (have) {
       if constexpr (GEN) {
         // (h comes back complete -- pooled value, pooling weight and g_fm S applied; S stays 0 for the sum below)
@@ -1059,6 +1148,19 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_apply_sorted(UpdArgs A) {
       if (wide_on && gl == 0) gw = ldg_f32(A.gwide + static_cast<int64_t>(b) * A.ldgw);
       }
       if (seg_end) {
+        if constexpr (OPT == DCTR_UPD_LAZY) {
+          if (lane_on) {
+            w = strip_load<VEC>(Z.deep + row * Z.ld_d + e0);
+            if (Z.s1) s = strip_load<VEC>(Z.s1 + row * Z.ld_s1 + e0);
+            if (Z.s2) s2 = strip_load<VEC>(Z.s2 + row * Z.dim + e0);
+            e = w;
+          }
+          if (wide_on && gl == 0) {
+            ww = ldg_f32(Z.wide + row * Z.ld_w);
+            if (Z.ws1) sw = ldg_f32(Z.ws1 + row * Z.ld_ws1);
+            if (Z.ws2) sw2 = ldg_f32(Z.ws2 + row);
+          }
+        } else {
         if (lane_on) {
           const int64_t off_w = row * ld_dw + e0;
           w = strip_load<VEC>(OPT == DCTR_UPD_ACCUM ? fd.gacc + row * fd.dim + e0 : fd.table + off_w);
@@ -1072,6 +1174,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_apply_sorted(UpdArgs A) {
         if (wide_on && gl == 0) {
           ww = ldg_f32(OPT == DCTR_UPD_ACCUM ? fw.gacc + row : fw.table + row * ld_ww);
           if (OPT == DCTR_UPD_ADAGRAD) sw = ldg_f32(fw.state + row * ld_ws);
+        }
         }
       }
     }
@@ -1101,6 +1204,27 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_apply_sorted(UpdArgs A) {
         if (gl == 0) accw += carry[RW + 1];
       }
       if (seg_end) {
+        if constexpr (OPT == DCTR_UPD_LAZY) {
+          if (lane_on) {
+            Strip<VEC> a2 = acc;
+            if (fold) {
+#pragma unroll
+              for (int k = 0; k < VEC; ++k) a2.v[k] -= accf * e.v[k];
+            }
+            lazy_apply_strip<VEC>(A, Z, Z.lam2d, Z.deep + row * Z.ld_d + e0, Z.s1 ? Z.s1 + row * Z.ld_s1 + e0 : nullptr,
+                                  Z.s2 ? Z.s2 + row * Z.dim + e0 : nullptr, a2, w, s, s2);
+          }
+          if (wide_on && gl == 0) {
+            Strip<1> a1, w1, s1, b1;
+            a1.v[0] = accw;
+            w1.v[0] = ww;
+            s1.v[0] = sw;
+            b1.v[0] = sw2;
+            lazy_apply_strip<1>(A, Z, Z.lam2w, Z.wide + row * Z.ld_w, Z.ws1 ? Z.ws1 + row * Z.ld_ws1 : nullptr,
+                                Z.ws2 ? Z.ws2 + row : nullptr, a1, w1, s1, b1);
+          }
+          if (gl == 0) *(DCTR_GLOBAL int32_t*)(Z.stamp + row) = Z.t + 1;   // the row has seen step t + 1
+        } else {
         if (lane_on) {
           Strip<VEC> a2 = acc;
           if (fold) {
@@ -1115,6 +1239,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_apply_sorted(UpdArgs A) {
           w1.v[0] = ww;
           s1.v[0] = sw;
           apply_strip<1, OPT>(fw, row * ld_ww, row * ld_ws, row, a1, w1, s1, A.lr, A.eps);
+        }
         }
       }
     }

@@ -116,7 +116,8 @@ class LazyOpt(ctypes.Structure):
 POOL_CODE = {None: 0, "sum": 1, "mean": 2, "max": 3}
 BWD_ACCUM, BWD_SGD = 0, 1
 OPT_SGD, OPT_ADAGRAD = 0, 1
-UPD_SGD, UPD_ADAGRAD, UPD_ACCUM = 0, 1, 2
+UPD_SGD, UPD_ADAGRAD, UPD_ACCUM, UPD_LAZY = 0, 1, 2, 3
+EINVAL, ENOSUP = -1, -2          # (include/dctr.h DCTR_EINVAL / DCTR_ENOSUP)
 
 _I32, _I64, _F32, _P = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -137,6 +138,8 @@ SIGNATURES = {
     "dctr_embed_ids": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I32, _P, _I64, _I32, _P, _P, _P]),
     "dctr_embed_update": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I32, _I64, _P, _P, _I32, _P, _I64, _P, _I64, _P, _I64,
                                          _P, _P, _I64, _I32, _F32, _F32, _P, _I64, _P, _P, _P, _I64, _I32, _P]),
+    "dctr_embed_update_lazy": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I32, _I64, _P, _P, _I32, _P, _I64, _P, _I64, _P, _I64,
+                                              _P, _P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _P]),
     "dctr_embed_segments": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I32, _I64, _P, _P, _I32, _P, _I64, _P]),
     "dctr_embed_update_workspace_ints": (ctypes.c_int64, [ctypes.POINTER(Plan), _I32, _I32]),
     "dctr_embed_bwd": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _I64, _I32, _P, _I64, _P, _I64, _P, _P,

@@ -212,6 +212,11 @@ class EmbedFunction(torch.autograd.Function):
             lazy._ensure(X.device)
             cplan = plan.bind(X.device)
             ws, ws_n, pre = plan.update_workspace_for(ids_t, ctx.seg_event, B)
+            # round 6: with pre-sorted entries the regularised / Adam step runs at the row, inside the sorted update (no
+            # gradient slab, no second pass over the batch's rows: csrc/update_kernels.hpp DCTR_UPD_LAZY)
+            if pre and lazy.update_fused(plan, cplan, ids_t, parts_t, B, g_out, ld_g, out, fm_s, g_fm, g_wide, X, g_wd, ws,
+                                         ws_n):
+                return None, None, None, g_w, None, None
             L.check(lib.dctr_embed_update(cplan, plan.units_ptr(), plan.n_grid_units, plan.max_vocab, _ptr(ids_t),
                                           _ptr(parts_t), B, _ptr(g_out), ld_g, _ptr(out), plan.ld_out, _ptr(fm_s),
                                           fm_s.stride(0) if fm_s is not None else 0, _ptr(g_fm), _ptr(g_wide), 1,

@@ -289,6 +289,27 @@ class LazyState(object):
                 "dctr_lazy_step_inc")
         self.mark_dirty()
 
+    def update_fused(self, plan, cplan, ids_t, parts_t, B, g_out, ld_g, out, fm_s, g_fm, g_wide, X, g_wd, ws, ws_n):
+        """The data-gradient step INSIDE the sorted update (dctr_embed_update_lazy, round 6): what dctr_embed_update(ACCUM) +
+        apply() did in two passes over the batch's rows through a gradient slab.  Needs pre-sorted entries (the segment
+        pre-pass ran on these ids).  False: not taken (the caller runs the two passes)."""
+        if os.environ.get("DCTR_LAZY_FUSED_APPLY", "1") == "0":
+            return False
+        P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())       # noqa: E731
+        rc = L.lib().dctr_embed_update_lazy(
+            cplan, plan.units_ptr(), plan.n_grid_units, plan.max_vocab, P(ids_t), P(parts_t), B, P(g_out), ld_g, P(out),
+            plan.ld_out, P(fm_s), fm_s.stride(0) if fm_s is not None else 0, P(g_fm), P(g_wide), 1, P(X), X.stride(0), P(g_wd),
+            P(ws), ws_n, ctypes.c_void_p(self._units_dev.data_ptr()), ctypes.c_void_p(self.step.data_ptr()),
+            ctypes.byref(self.opt), L.stream_handle(X.device))
+        if rc == L.ENOSUP:
+            return False
+        L.check(rc, "dctr_embed_update_lazy")
+        self._join_sweep()          # (the sweep reads the step counter: it must be done before the counter moves)
+        L.check(L.lib().dctr_lazy_step_inc(ctypes.c_void_p(self.step.data_ptr()), L.stream_handle(X.device)),
+                "dctr_lazy_step_inc")
+        self.mark_dirty()
+        return True
+
     def mark_dirty(self):
         """Train steps ran since the last flush (LazyState.apply, or a hipGraph replay of it): rows lag behind."""
         self.dirty = True

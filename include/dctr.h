@@ -243,6 +243,7 @@ int dctr_embed_apply(const dctr_plan_t* plan, const float* X, int64_t ldx, int32
 #define DCTR_UPD_SGD 0
 #define DCTR_UPD_ADAGRAD 1
 #define DCTR_UPD_ACCUM 2
+#define DCTR_UPD_LAZY 3   /* dctr_embed_update_lazy only: the lazily regularised / Adam step at the row (see below) */
 /* One optimizer step on dense parameters, applied by the kernel that finishes their gradient (instead of a separate
  * dctr_dense_opt launch and the cross-queue join in front of it): the gradient tensor lives at grad_base + k inside
  * a flat gradient slab, its parameter at param_base + k, its Adagrad state at state_base + k.
@@ -405,6 +406,18 @@ typedef struct dctr_lazy_opt {
   const float* adam_bc;
 } dctr_lazy_opt_t;
 size_t dctr_sizeof_lazy_unit(void);
+/* Round 6 -- the step that carries the batch's DATA gradient, inside the sorted update: dctr_embed_update's gradient sums
+ * (same arguments, same order of additions) meet g = G + 2 lambda w and ONE optimizer step of `lazy_opt` on (w, s1, s2) at the
+ * row, which is stamped t + 1 (*step = t is read, not advanced: dctr_lazy_step_inc follows as before).  Replaces
+ * dctr_embed_update(DCTR_UPD_ACCUM) + dctr_lazy_apply -- no gradient slab, no second pass over the batch's rows.  Needs what
+ * csrc/lazy.hip needs (simple units, the batch's rows caught up to t by dctr_lazy_catchup) and pre-sorted entries
+ * (dctr_embed_segments on the same ids: `workspace`); DCTR_ENOSUP otherwise -- the caller keeps the two-pass route.       */
+int dctr_embed_update_lazy(const dctr_plan_t* plan, const int32_t* units, int32_t n_units, int64_t max_vocab,
+                           const int32_t* ids_t, const uint16_t* parts_t, int32_t B, const float* g_out, int64_t ld_g,
+                           const float* out, int64_t ld_out, const float* fm_s, int64_t ld_s, const float* g_fm,
+                           const float* g_wide, int64_t ld_gw, const float* X, int64_t ld_x, float* g_wdense,
+                           int32_t* workspace, int64_t workspace_ints, const struct dctr_lazy_unit* lazy_units,
+                           const int32_t* step, const struct dctr_lazy_opt* lazy_opt, dctr_stream_t stream);
 size_t dctr_sizeof_lazy_opt(void);
 /* order_ws (nullable): n_units * B ints of scratch -- with it the catch-up first deals every unit's entries by the number of
  * steps their rows slept (one launch, a counting sort per unit), so that the rows one wavefront replays side by side need

@@ -461,6 +461,9 @@ class _Core(object):
         return 0
 
     # ---- deterministic fused backward + optimizer (dctr_embed_update) ---------------------------------------
+    def dctr_embed_update_lazy(self, *a):
+        return -2          # (DCTR_ENOSUP: the stand-in keeps the two-pass route)
+
     def dctr_embed_update(self, pref, units, n_units, max_vocab, ids_t, parts_t, B, g_out, ld_g, out, ld_out, fm_s, ld_s, g_fm,
                           g_wide, ld_gw, opt, lr, eps, X, ld_x, g_wdense, wd_step, ws, ws_n, presorted, stream):
         self.calls.append("embed_update:%d" % opt)
