@@ -366,7 +366,7 @@ def saturating_launch(args, model, device, B_sat=262144):
 
 PMC_SOURCES = ("deepctr-torch_amd/csrc/update.hip", "deepctr-torch_amd/csrc/update_kernels.hpp",
                "deepctr-torch_amd/csrc/update_launch.inc", "deepctr-torch_amd/csrc/embed.hip",
-               "deepctr-torch_amd/csrc/common.hpp")
+               "deepctr-torch_amd/csrc/common.hpp", "deepctr-torch_amd/csrc/lazy_opt.hpp")
 
 
 def kernel_code_hash():

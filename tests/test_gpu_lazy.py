@@ -272,3 +272,58 @@ def test_side_streams_never_alias_after_many_stream_objects():
             os.environ.pop("DCTR_FIT_GRAPH", None)
     np.testing.assert_allclose(hists[0], hists[1], rtol=1e-6)
     del junk
+
+
+@pytest.mark.parametrize("opt", ["adam", "adagrad", "sgd"])
+@pytest.mark.parametrize("ids", ["uniform", "hot"])
+def test_step_inside_the_sorted_update_equals_the_two_pass_route(monkeypatch, opt, ids):
+    """Round 6: the data-gradient step of the lazily regularised / Adam tables runs at the row inside the sorted update
+    (dctr_embed_update_lazy, csrc/update_kernels.hpp DCTR_UPD_LAZY) instead of dctr_embed_update(ACCUM) + dctr_lazy_apply.
+    Same sums in the same order, the same optimizer arithmetic (csrc/lazy_opt.hpp): after 6 steps at batch 4096 the
+    tables, both optimizer moments and the losses of the two routes agree to a few ulps -- also with a HOT id (85 % of a
+    column's entries: the partition overflows the pre-pass's bucket and takes the update kernel's general path)."""
+    from deepctr_torch.inputs import DenseFeat, SparseFeat
+    from deepctr_torch.models import DeepFM
+    B, V, F, D = 4096, 20000, 6, 16
+    gen = torch.Generator().manual_seed(3)
+    X_ids = torch.randint(0, V, (8 * B, F), generator=gen)
+    if ids == "hot":
+        hot = torch.rand(8 * B, F, generator=gen) < 0.85
+        X_ids = torch.where(hot, torch.full_like(X_ids, 7), X_ids)
+    X = torch.cat([X_ids.float(), torch.rand(8 * B, 3, generator=gen)], 1).to(DEV)
+    y = torch.randint(0, 2, (8 * B,), generator=gen).float().to(DEV)
+    runs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("DCTR_LAZY_FUSED_APPLY", fused)
+        cols = [SparseFeat("C%d" % i, V, D) for i in range(F)] + [DenseFeat("I%d" % i, 1) for i in range(3)]
+        m = DeepFM(cols, cols, dnn_hidden_units=(64, 32), l2_reg_linear=1e-4, l2_reg_embedding=1e-4, init_std=0.05, seed=5,
+                   device=DEV)
+        m.compile(opt, "binary_crossentropy", metrics=[])
+        m.train()
+        assert m.model_plan().update[0] == "lazy"
+        calls = []
+        if fused == "1":
+            from deepctr_torch._hip import lib as L
+            real = L.lib().dctr_embed_update_lazy
+            monkeypatch.setattr(L.lib(), "dctr_embed_update_lazy", lambda *a: (calls.append(1), real(*a))[1], raising=False)
+        losses = [m._train_step(X[i * B:(i + 1) * B], y[i * B:(i + 1) * B])[0].item() for i in range(6)]
+        if fused == "1":
+            assert len(calls) == 6, "the fused route was not taken"
+            monkeypatch.undo()
+        torch.cuda.synchronize()
+        m.model_plan().check_ids()
+        sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}      # (flushes every row to the current step)
+        st = {}
+        for k, p in m.named_parameters():
+            for key, v in m.optim.state.get(p, {}).items():
+                if torch.is_tensor(v) and v.numel() > 1:
+                    st[k + "/" + key] = v.detach().cpu().clone()
+        runs.append((losses, sd, st))
+    (la, sa, ta), (lb, sb, tb) = runs
+    np.testing.assert_allclose(la, lb, rtol=1e-6)
+    for k in sb:
+        err = float((sa[k] - sb[k]).abs().max())
+        assert err <= 1e-6 * max(1.0, float(sb[k].abs().max())), "%s: %.3e" % (k, err)
+    for k in tb:
+        err = float((ta[k] - tb[k]).abs().max())
+        assert err <= 1e-6 * max(1.0, float(tb[k].abs().max())) + 1e-12, "%s: %.3e" % (k, err)

@@ -20,7 +20,7 @@ from collections import OrderedDict, defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_SOURCES = ("deepctr-torch_amd/csrc/update.hip", "deepctr-torch_amd/csrc/update_kernels.hpp",
                   "deepctr-torch_amd/csrc/update_launch.inc", "deepctr-torch_amd/csrc/embed.hip",
-                  "deepctr-torch_amd/csrc/common.hpp")
+                  "deepctr-torch_amd/csrc/common.hpp", "deepctr-torch_amd/csrc/lazy_opt.hpp")
 
 
 def code_hash():
