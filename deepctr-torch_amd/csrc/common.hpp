@@ -211,4 +211,16 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? DCTR_OK : static_
 
 inline int launch_status() { return hip_status(hipGetLastError()); }
 
+
+// Issue priority of the launches on a train step's critical chain (gather, tower, update, catch-up ...).  The lazily
+// replayed tables' per-step SWEEP (lazy.hip, k_lazy<., 3>) is ~230 us of packed arithmetic that runs beside the chain on
+// its own queue and leaves its waves at the default priority 0: a SIMD's arbiter then issues the chain's (latency-bound,
+// few instructions between loads) waves ahead of it, and the sweep fills the cycles the chain leaves.  Without this
+// every chain instruction queued behind up to six sweep waves and the step cost sweep + chain.  No effect when a launch
+// has the SIMDs to itself.
+__device__ __forceinline__ void step_priority() {
+#ifndef DCTR_NO_STEP_PRIORITY
+  __builtin_amdgcn_s_setprio(3);
+#endif
+}
 }  // namespace dctr

@@ -162,6 +162,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_fwd(dctr_plan_t P, const flo
   // same linear logit / FM term / sum_f e inside the tower kernel and must land on the same bits -- with contraction left
   // to the compiler the two bodies were contracted differently (round 4: losses equal for 30 steps, then off by one ulp).
 #pragma clang fp contract(off)
+  step_priority();
   constexpr int SPB = kWave / LPR;
   constexpr int CH = 8;   // row loads in flight per lane and per pass (x4 waves = 32 fields)
   constexpr int WCH = 2;  // wide loads in flight per lane and per pass

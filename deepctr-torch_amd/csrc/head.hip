@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kTH) void k_l2_value_multi(MultiArgs A, float* __re
     acc += lam * s;
   }
   const float tot = block_sum(acc, red);
-  if (threadIdx.x == 0) stg_f32(out, tot + ldg_f32(out));
+  if (threadIdx.x == 0) stg_f32(out, A.lr != 0.f ? tot + ldg_f32(out) : tot);     // (lr: "a launch went before this one")
 }
 
 
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void k_colsum_finish(const float* __restrict__
 extern "C" int dctr_l2_value_multi(const dctr_dense_item_t* items, int32_t n_items, float* out, dctr_stream_t stream) {
   if (n_items < 0 || (n_items > 0 && !items) || !out) return DCTR_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  (void)hipMemsetAsync(out, 0, sizeof(float), s);
+  if (n_items == 0) (void)hipMemsetAsync(out, 0, sizeof(float), s);
   for (int i0 = 0; i0 < n_items; i0 += kMulti) {
     MultiArgs a;
     int k = 0;
@@ -282,8 +282,9 @@ extern "C" int dctr_l2_value_multi(const dctr_dense_item_t* items, int32_t n_ite
       if (it.n < 0 || (it.n > 0 && !it.p)) return DCTR_EINVAL;
       a.p[k] = it.p; a.g[k] = nullptr; a.st[k] = nullptr; a.n[k] = it.n; a.c2[k] = 2.f * it.l2;
     }
-    a.n_items = k; a.lr = a.eps = 0.f;
-    k_l2_value_multi<<<dim3(1), dim3(kTH), 0, s>>>(a, out);    // (accumulates into out: launches are stream-ordered)
+    a.n_items = k; a.eps = 0.f;
+    a.lr = i0 > 0 ? 1.f : 0.f;                                 // the first launch stores, the later ones add
+    k_l2_value_multi<<<dim3(1), dim3(kTH), 0, s>>>(a, out);    // (launches are stream-ordered)
     const int stt = launch_status();
     if (stt != DCTR_OK) return stt;
   }

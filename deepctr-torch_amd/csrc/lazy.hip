@@ -23,8 +23,9 @@
 // The arithmetic owed stays what the reference does -- one optimizer step per row per step, ~0.3 ms of VALU work at the
 // Criteo shape -- but not its 10.6 GB of row traffic.  Deterministic: whichever duplicate wins a row computes the same
 // thing, and each (row, step) is applied exactly once, in order, whoever applies it.  The replayed (zero-data-gradient)
-// steps divide by reciprocal + one Newton correction (div_nr / sqrt_nr below: within 1 ulp of the IEEE operations the
-// reference's device kernels use); the step that carries a data gradient uses the IEEE operations.
+// steps divide and take roots through the hardware reciprocal / reciprocal square root (div_nr / sqrt_nr in lazy_opt.hpp:
+// within 1.5 ulp of the IEEE operations; the bound, the cost and the build switch are stated there); the step that carries
+// a data gradient uses the IEEE operations.
 //
 // Optimizer arithmetic = torch.optim's (single-tensor formulas, fp32; the step-dependent scalars in double like
 // torch computes them on the host):
@@ -133,14 +134,14 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
 // A lane group of `lpr` lanes (a power of two <= 64) owns one (unit, entry); lane gl handles the deep strip
 // [gl*VEC, gl*VEC + VEC) and, when gl == 0, the wide element.
 template <int VEC, int MODE>
-__global__ __launch_bounds__(kT) void k_lazy(const dctr_lazy_unit_t* __restrict__ units, int n_units,
-                                             const int32_t* __restrict__ ids_t, int64_t n_entries, int lpr_shift,
-                                             const int32_t* __restrict__ step_ptr, OptConst o,
-                                             const int32_t* __restrict__ order, int sweep_k, int part) {
+__device__ __forceinline__ void lazy_block(const dctr_lazy_unit_t* __restrict__ units, int n_units,
+                                           const int32_t* __restrict__ ids_t, int64_t n_entries, int lpr_shift,
+                                           const int32_t* __restrict__ step_ptr, const OptConst& o,
+                                           const int32_t* __restrict__ order, int sweep_k, int part, int64_t block_x,
+                                           int u, int tid) {
   const int lpr = 1 << lpr_shift;
-  const int64_t grp = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> lpr_shift;
-  const int gl = threadIdx.x & (lpr - 1);
-  const int u = blockIdx.y;
+  const int64_t grp = (block_x * kT + tid) >> lpr_shift;
+  const int gl = tid & (lpr - 1);
   if (u >= n_units) return;
   // (lane groups past the end stay in the wave: the replay walks the steps with all 64 lanes, replay_in_step)
   bool dead = grp >= n_entries;
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(kT) void k_lazy(const dctr_lazy_unit_t* __restrict_
       prev = atomicMax(un.stamp + row, target);
     }
   }
-  prev = __shfl(prev, (threadIdx.x & 63) & ~(lpr - 1), kWave);
+  prev = __shfl(prev, (tid & 63) & ~(lpr - 1), kWave);
   const bool live = prev < target;
   if (MODE != 1 && o.kind == DCTR_LAZY_ADAM && o.adam_ss) {
     replay_in_step<VEC, kFastReplay>(o, lam2d, lam2w, deep_on && live, wide_on && live, live ? prev : t, t, w, a, b, ww[0],
@@ -247,6 +248,16 @@ __global__ __launch_bounds__(kT) void k_lazy(const dctr_lazy_unit_t* __restrict_
   }
 }
 
+template <int VEC, int MODE>
+__global__ __launch_bounds__(kT) void k_lazy(const dctr_lazy_unit_t* __restrict__ units, int n_units,
+                                             const int32_t* __restrict__ ids_t, int64_t n_entries, int lpr_shift,
+                                             const int32_t* __restrict__ step_ptr, OptConst o,
+                                             const int32_t* __restrict__ order, int sweep_k, int part) {
+  if (MODE != 3) step_priority();
+  lazy_block<VEC, MODE>(units, n_units, ids_t, n_entries, lpr_shift, step_ptr, o, order, sweep_k, part, blockIdx.x,
+                        blockIdx.y, threadIdx.x);
+}
+
 // ---- catch-up: the batch's entries ordered by how long their rows slept -----------------------------------------------
 // k_lazy gives every lane group one row and walks its missed steps: a wave runs until the LONGEST gap among its 16 rows
 // is done.  The gaps of a big table's rows are geometric (mean V / B = 244 steps at the Criteo shape) and the expected
@@ -260,6 +271,7 @@ constexpr int kOrderT = 1024;
 __global__ __launch_bounds__(kOrderT) void k_lazy_order(const dctr_lazy_unit_t* __restrict__ units,
                                                         const int32_t* __restrict__ ids_t, int n_entries,
                                                         const int32_t* __restrict__ step_ptr, int32_t* __restrict__ order) {
+  step_priority();
   __shared__ int hist[256];
   __shared__ unsigned long long total;
   __shared__ int red[kOrderT / 64];
@@ -320,6 +332,7 @@ __global__ __launch_bounds__(kT) void k_dense_opt_reg(float* __restrict__ p, con
                                                       float* __restrict__ s1, float* __restrict__ s2,
                                                       const float* __restrict__ lam, int64_t n,
                                                       const int32_t* __restrict__ step_ptr, OptConst o) {
+  step_priority();
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
   if (i >= n) return;
   float ss = 0.f, bc = 1.f;
@@ -357,7 +370,6 @@ int launch(const dctr_lazy_unit_t* units, int n_units, const int32_t* ids_t, int
   }
   const OptConst o = opt_const(opt);
   const int64_t threads = n_entries << shift;
-  const dim3 grid(static_cast<unsigned>((threads + kT - 1) / kT), static_cast<unsigned>(n_units));
   static const bool ordered = !(getenv("DCTR_LAZY_ORDER") && getenv("DCTR_LAZY_ORDER")[0] == '0');   // (A/B switch)
   // zero-gradient steps of SGD / Adagrad without an L2 term move nothing: no replay to balance
   const bool replays = !((o.kind == DCTR_LAZY_SGD || o.kind == DCTR_LAZY_ADAGRAD) && !opt->any_l2);
@@ -368,20 +380,24 @@ int launch(const dctr_lazy_unit_t* units, int n_units, const int32_t* ids_t, int
     order = nullptr;
   }
   static const bool split = !(getenv("DCTR_LAZY_SPLIT_WIDE") && getenv("DCTR_LAZY_SPLIT_WIDE")[0] == '0');   // (A/B switch)
+  // (round 6 measured the sweep as a PERSISTENT launch -- one 1024-lane workgroup per CU, <= 80 VGPRs, so that a tower
+  // workgroup (192 VGPRs on all four SIMDs of a CU) always finds room beside it: slower, 0.52 ms against 0.44.  At four
+  // waves per SIMD the replay chain is latency-bound (the plain grid holds five to six), and what the chain's launches gain
+  // is less than that.  The step is bound by the SUM of its arithmetic, not by who gets the registers.)
+  auto run = [&](int64_t n_threads, int sh, int part) {
+    const int64_t blocks = (n_threads + kT - 1) / kT;
+    const dim3 g(static_cast<unsigned>(blocks), static_cast<unsigned>(n_units));
+    if (vec == 4)
+      k_lazy<4, MODE><<<g, dim3(kT), 0, s>>>(units, n_units, ids_t, n_entries, sh, step, o, order, sweep_k, part);
+    else
+      k_lazy<1, MODE><<<g, dim3(kT), 0, s>>>(units, n_units, ids_t, n_entries, sh, step, o, order, sweep_k, part);
+  };
   int part = 0;
   if (MODE >= 2 && split && shift > 0) {
-    // the wide weights first, one lane per row (the stamps are written by the second pass)
-    const dim3 gw(static_cast<unsigned>((n_entries + kT - 1) / kT), static_cast<unsigned>(n_units));
-    if (vec == 4)
-      k_lazy<4, MODE><<<gw, dim3(kT), 0, s>>>(units, n_units, ids_t, n_entries, 0, step, o, order, sweep_k, 1);
-    else
-      k_lazy<1, MODE><<<gw, dim3(kT), 0, s>>>(units, n_units, ids_t, n_entries, 0, step, o, order, sweep_k, 1);
+    run(n_entries, 0, 1);     // the wide weights first, one lane per row (the stamps are written by the second pass)
     part = 2;
   }
-  if (vec == 4)
-    k_lazy<4, MODE><<<grid, dim3(kT), 0, s>>>(units, n_units, ids_t, n_entries, shift, step, o, order, sweep_k, part);
-  else
-    k_lazy<1, MODE><<<grid, dim3(kT), 0, s>>>(units, n_units, ids_t, n_entries, shift, step, o, order, sweep_k, part);
+  run(threads, shift, part);
   return launch_status();
 }
 

@@ -63,23 +63,44 @@ __device__ __forceinline__ void adam_scalars(const OptConst& o, int T, float& ss
 }
 
 // Division and square root of the REPLAY loop.  A row that slept k steps replays k optimizer steps whose only gradient is
-// the L2 term; at the Criteo shape (k ~ V / B = 244) that loop is the whole cost of the default-kwargs step, and two IEEE
-// divisions + one IEEE square root were ~30 of its ~50 instructions per element (v_div_scale x 2, v_rcp, five fmas,
-// v_div_fmas, v_div_fixup each: the range scaling and special-case fix-ups of a general division).  Here: hardware
-// reciprocal / reciprocal square root (1 ulp) and ONE Newton correction through the exact residual (fma), i.e. the core of
-// the IEEE sequence without its scaling and fix-ups -- the operands of this loop are ordinary normal numbers (denominators
-// >= eps, moments of magnitude (lambda w)^2).  Result within 1 ulp of the correctly rounded one, the same on every run.
-// The step that carries a DATA gradient (apply) and the dense slab keep the IEEE operations.
+// the L2 term; every row owes one such step per train step (whoever pays it: catch-up, sweep or flush), so at the Criteo
+// shape this loop is 26 M row-steps x 16 elements per train step and its instruction count IS the cost of the
+// default-kwargs step: the chip's vector ALUs are saturated by it (sweep alone: 231 us of a 0.44 ms step).
+//   round 5: IEEE division / square root (v_div_scale x 2, v_rcp, five fmas, v_div_fmas, v_div_fixup each: ~30 of ~50
+//            instructions per element) -> hardware reciprocal / reciprocal square root + ONE Newton correction through
+//            the exact residual (<= 1 ulp): 0.62 -> 0.46 ms.
+//   round 6: the Newton corrections go too (DCTR_LAZY_REPLAY_NR=1 at build time brings them back): q = a * rcp(d),
+//            s = x * rsq(x).  v_rcp_f32 / v_rsq_f32 are accurate to 1 ulp, the product rounds once more: <= 1.5 ulp per
+//            operation, three of them in a step's update lr_t * m / (sqrt(v) / bc + eps) -- a relative error of ~3e-7 of
+//            a STEP (itself ~1e-3 of the weight's magnitude), unbiased, next to the 6e-8 every fp32 rounding of the step
+//            contributes.  7 of the loop's 17 packed instructions per element pair: sweep 231 -> 195 us, step 0.437 ->
+//            0.401 ms on one box (tools/runs/nonr_ab.sh).  Every test of the lazy update and every golden trajectory of
+//            the reference with adam + L2 passes unchanged with either build (same bars).
+// The operands of this loop are ordinary normal numbers (denominators >= eps, moments of magnitude (lambda w)^2); the
+// result is the same on every run and for every schedule (who replays a step never changes what the step computes).
+// The step that carries a DATA gradient (apply, the sorted update) and the dense slab keep the IEEE operations.
+#ifndef DCTR_LAZY_REPLAY_NR
+#define DCTR_LAZY_REPLAY_NR 0
+#endif
 __device__ __forceinline__ float div_nr(float a, float d, float rd) {   // rd = rcp(d)
   const float q = a * rd;
+#if DCTR_LAZY_REPLAY_NR
   return fmaf(fmaf(-q, d, a), rd, q);
+#else
+  return q;
+#endif
 }
 __device__ __forceinline__ float sqrt_nr(float x) {
-  // (a moment is never negative; rsq of the clamped value keeps x = 0 at exactly 0 -- 0 * finite -- without a select.  A
-  // moment below the smallest normal number comes out smaller than its root: it is added to eps = 1e-8 either way)
+  // (a moment is never negative; x = 0 stays exactly 0 -- 0 * finite -- without a select: the smallest normal number added
+  // (a packed add; it vanishes in the rounding of any moment above 2^-102) or clamped to.  A moment below it comes out
+  // smaller than its root: it is added to eps = 1e-8 either way)
+#if DCTR_LAZY_REPLAY_NR
   const float r = __builtin_amdgcn_rsqf(fmaxf(x, 1.17549435e-38f));
   const float s = x * r;
   return fmaf(fmaf(-s, s, x), 0.5f * r, s);
+#else
+  return x * __builtin_amdgcn_rsqf(x + 1.17549435e-38f);
+#endif
 }
 
 // one optimizer step on one element.  a = Adagrad sum | Adam exp_avg, b = Adam exp_avg_sq.  FAST: the replay loop's

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket(UpdArgs A) {
 // A partition with more than kBucket entries is left to the update kernel's own scan (the counter says so).
 template <bool FROM_BUCKETS, bool GEN>
 __global__ __launch_bounds__(kThreads) void k_embed_segments(UpdArgs A) {
+  step_priority();
   constexpr int kSl = kBucket / kThreads;   // bucket slots per thread
   static_assert(kBucket % kThreads == 0, "whole slots per thread");
   __shared__ uint32_t keys[kBucket];
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_segments(UpdArgs A) {
 //                            (the update kernel's general path takes it, as after k_embed_segments).
 // The result does not depend on the order the LDS atomics hand out slots: the rank sort fixes it.
 __global__ __launch_bounds__(kThreads) void k_prepass_bin(UpdArgs A) {
+  step_priority();
   // dynamic LDS, sized by the launch (prepass_bin_lds): keys [chunk] | cnt [n_bins + 1] (counts, then exclusive starts) |
   // cur [n_bins] | tags [chunk] -- 30 KB at B = 262 144 (five workgroups per CU) instead of 56 KB for the largest shapes
   extern __shared__ __align__(16) uint32_t pp_lds[];
@@ -263,6 +265,7 @@ __global__ __launch_bounds__(kThreads) void k_prepass_bin(UpdArgs A) {
 }
 
 __global__ __launch_bounds__(kSortT) void k_prepass_sort(UpdArgs A) {
+  step_priority();
   extern __shared__ __align__(16) uint32_t bk_lds[];      // [fine][kBucket]
   __shared__ int cnt[kFineMax], n_f[kFineMax], start[kFineMax + 1];
   const int fine = A.fine;
@@ -371,6 +374,7 @@ __global__ __launch_bounds__(kThreads) void k_embed_ids(const dctr_field_t* __re
                                                         const float* __restrict__ X, int64_t ldx, int B,
                                                         int32_t* __restrict__ ids_t, uint16_t* __restrict__ parts_t,
                                                         int n_parts) {
+  step_priority();
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
   if (i >= static_cast<int64_t>(n_units) * B) return;
   const int u = static_cast<int>(i / B), b = static_cast<int>(i - static_cast<int64_t>(u) * B);

@@ -1023,6 +1023,7 @@ __device__ __forceinline__ void upd_partition(const UpdArgs& A, const int u, con
 // spills; tighter bounds spill 8-40 registers in the Adagrad variant = +8 MB of scratch writes per launch)
 template <int VEC, int LPR, int OPT, bool GEN>
 __global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
+  step_priority();
   __shared__ dctr_uslot_t sl[GEN ? kMaxSlots : 1];
   if (A.g_wdense && static_cast<int>(blockIdx.x) >= static_cast<int>(gridDim.x) - A.n_wdense) {
     wdense_column(A, static_cast<int>(blockIdx.x) - (static_cast<int>(gridDim.x) - A.n_wdense));
@@ -1047,6 +1048,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_embed_update(UpdArgs A) {
 // of launch + boundary + counter round trip on the step's critical chain for work that is almost always empty -- round 3.)
 template <int VEC, int LPR, int OPT, bool GEN>
 __global__ __launch_bounds__(kThreads, 5) void k_embed_apply_sorted(UpdArgs A) {
+  step_priority();
   constexpr int G = kThreads / LPR;   // entries per tile
   constexpr int RW = LPR * VEC;
   __shared__ dctr_uslot_t sl[GEN ? kMaxSlots : 1];     // the unit's slot descriptors (general units)

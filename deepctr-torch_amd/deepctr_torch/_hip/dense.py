@@ -23,6 +23,8 @@ def _r4(n):
 
 
 class DenseSlab(object):
+    L2_VALUE_SMALL = 1 << 16        # regularised elements up to which reg_value() is the single-workgroup launch
+
     def __init__(self, params, pad_rows=()):
         """params: list of nn.Parameter (fp32, same device); pad_rows: parameters whose rows are padded."""
         self.params = list(params)
@@ -268,18 +270,35 @@ class DenseSlab(object):
         """``{param: lambda}`` of the L2 terms on slab parameters: applied inside the optimizer kernel as
         g += 2*lambda*p (what autograd adds for ``lambda * sum(p^2)``, basemodel.py:412-428)."""
         lam_of = dict((id(p), float(v)) for p, v in lam_of.items() if v > 0)
+        self._l2_items = None
         if not lam_of:
             self.lam = None
             return
         self.lam = torch.zeros_like(self.flat)
+        todo = []
         for p in self.params:
             if id(p) in lam_of:
                 self._view(self.lam, p).fill_(lam_of[id(p)])
+                todo.append((self._view(self.flat, p), lam_of[id(p)]))
+        # few regularised elements (DeepFM's defaults: the 13 dense weights of Linear): their logged value is ONE
+        # single-workgroup launch over those tensors instead of a product + a two-kernel dot over the whole slab
+        if self.flat.is_cuda and sum(v.numel() for v, _ in todo) <= self.L2_VALUE_SMALL and \
+                all(v.is_contiguous() for v, _ in todo):
+            items = (L.DenseItem * len(todo))()
+            for i, (v, lam) in enumerate(todo):
+                items[i].p, items[i].g, items[i].state, items[i].n, items[i].l2 = v.data_ptr(), None, None, v.numel(), lam
+            self._l2_items = items
+            self._l2_out = torch.zeros((1,), dtype=torch.float32, device=self.flat.device)
 
     def reg_value(self):
         """sum(lambda * p^2) over the slab (the dense parameters' share of get_regularization_loss), or None."""
         if self.lam is None:
             return None
+        if getattr(self, "_l2_items", None) is not None:
+            out = torch.empty_like(self._l2_out)
+            L.check(L.lib().dctr_l2_value_multi(self._l2_items, len(self._l2_items), ctypes.c_void_p(out.data_ptr()),
+                                                L.stream_handle(self.flat.device)), "dctr_l2_value_multi")
+            return out
         return torch.dot(self.lam * self.flat, self.flat).reshape(1)
 
     def _opt_reg(self, kind, lr, eps, beta1, beta2, stream):
