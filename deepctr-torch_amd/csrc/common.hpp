@@ -218,9 +218,15 @@ inline int launch_status() { return hip_status(hipGetLastError()); }
 // few instructions between loads) waves ahead of it, and the sweep fills the cycles the chain leaves.  Without this
 // every chain instruction queued behind up to six sweep waves and the step cost sweep + chain.  No effect when a launch
 // has the SIMDs to itself.
+// (the tower's weight gradients at a LOWER level than the embedding update they run beside: the update gets 1.7 us
+// shorter, 21.6 -> 19.9, and the step 1.6 us longer, 0.0898 -> 0.0914 ms -- the two chains are balanced: tools/runs/lib_ab.sh)
+#ifndef DCTR_WGRAD_PRIORITY
+#define DCTR_WGRAD_PRIORITY 3
+#endif
+template <int LEVEL = 3>
 __device__ __forceinline__ void step_priority() {
 #ifndef DCTR_NO_STEP_PRIORITY
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(LEVEL);
 #endif
 }
 }  // namespace dctr

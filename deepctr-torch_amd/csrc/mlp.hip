@@ -2320,7 +2320,7 @@ __device__ __forceinline__ void fold_done(int32_t* sync, int n_red) {
 //    columns that are dropped or zeroed at the store), the ragged last rows of a slice are loaded from a clamped
 //    row and masked to zero afterwards.
 __global__ __launch_bounds__(kTW, 2) void k_mlp_wgrad(WgradArgs A) {
-  step_priority();
+  step_priority<DCTR_WGRAD_PRIORITY>();
   extern __shared__ __align__(16) float wsm[];
   float* red = wsm;                    // [4 waves][64 n][64 k] (64 KB)
   float* redb = wsm + 4 * 4096;        // [4][64] bias partials
@@ -2663,7 +2663,7 @@ struct ReduceArgs {
 // workgroup needs an agent-scope release fence, and on this part that is a write-back of the whole per-XCD L2, issued
 // 296 times beside an embedding update that keeps the L2 full of dirty table lines.  A kernel boundary does it once.)
 __global__ __launch_bounds__(256) void k_mlp_reduce(ReduceArgs A) {
-  step_priority();
+  step_priority<DCTR_WGRAD_PRIORITY>();
   if (A.head_loss && blockIdx.x == gridDim.x - 1) {   // fixed-order tree over the row tiles' partial sums
     __shared__ float red[2][4];
     float l = 0.f, gsum = 0.f;

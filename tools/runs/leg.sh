@@ -26,4 +26,18 @@ for r in rows[:28]:
     print("%-62s calls %6s avg %8.1f us  %5.1f %%" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
 PY
 head -30 $O/kernels.txt
+# the same launches split by grid size (k_lazy<., 3> runs twice per step: wide pass, deep pass)
+t=$(find $O/trace -name "*kernel_trace.csv" | head -1)
+python - "$t" > $O/kernels_by_grid.txt <<'PY'
+import csv, re, sys, collections
+acc = collections.defaultdict(lambda: [0, 0.0])
+for r in csv.DictReader(open(sys.argv[1])):
+    m = re.search(r"(k_\w+(<[^>]*>)?)", r["Kernel_Name"])
+    if not m: continue
+    k = (m.group(1)[:50], r.get("Grid_Size") or r.get("Grid_Size_X"), r.get("Workgroup_Size") or r.get("Workgroup_Size_X"))
+    a = acc[k]; a[0] += 1; a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+for k, (n, t) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:24]:
+    print("%-52s grid %10s wg %5s calls %6d avg %8.1f us" % (k[0], k[1], k[2], n, t / n))
+PY
+head -12 $O/kernels_by_grid.txt
 rm -rf $O/trace
