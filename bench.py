@@ -963,24 +963,59 @@ def main():
             blk_pos[0] = jn
             return parallel.train_block(xs, ys, next_first=X[jn * B:(jn + 1) * B])
 
-        i = 0
-        n_eager = min(3, args.warmup) if not args.no_graph else args.warmup
-        for _ in range(n_eager):
-            run(i)
-            i += 1
-        graphed = False
-        if not args.no_graph and on_gpu:
-            parallel.set_use_graphs(True)    # the compute segment is captured at the next step
-            graphed = True
-        if S_blk and graphed:
-            for _ in range(3):      # eager block, capture, one replay
-                run_block()
-                i += S_blk
-        else:
-            S_blk = 0
-            for _ in range(max(2 if graphed else 0, args.warmup - n_eager)):
+        def warm():
+            nonlocal S_blk
+            i = 0
+            n_eager = min(3, args.warmup) if not args.no_graph else args.warmup
+            for _ in range(n_eager):
                 run(i)
                 i += 1
+            graphed = False
+            if not args.no_graph and on_gpu:
+                parallel.set_use_graphs(True)    # the compute segment is captured at the next step
+                graphed = True
+            if S_blk and graphed:
+                for _ in range(3):      # eager block, capture, one replay
+                    run_block()
+                    i += S_blk
+            else:
+                S_blk = 0
+                for _ in range(max(2 if graphed else 0, args.warmup - n_eager)):
+                    run(i)
+                    i += 1
+            return i, graphed
+
+        # The direct exchange has passed its byte-level self-test at this point, but at N > 1 the first real steps are the first
+        # time the whole captured step crosses physical links: run the warm-up under a health check (a wait that timed out
+        # raises a bit on the device; nothing in a direct-exchange step is a host collective, so every rank gets here) and let
+        # ALL ranks fall back to RCCL together if any of them saw one.
+        failed = 0
+        try:
+            i, graphed = warm()
+            if exchange == "direct" and world > 1 and parallel._dx is not None:
+                parallel._dx.check()
+        except RuntimeError as exc:
+            if not (exchange == "direct" and world > 1):
+                raise
+            failed = 1
+            print("bench: rank %d: direct exchange failed in the warm-up steps (%s)" % (rank, exc), file=sys.stderr, flush=True)
+        if exchange == "direct" and world > 1:
+            flag = torch.tensor([failed], device=device, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                exchange = "rccl"
+                exch_info["ran"], exch_info["fell_back"] = "rccl", "a direct-exchange wait timed out during the warm-up steps"
+                if rank == 0:
+                    print("bench: falling back to the RCCL exchange on every rank", file=sys.stderr, flush=True)
+                try:
+                    parallel.close()
+                except Exception:
+                    pass
+                model = build_model(args, device)
+                parallel = par.ShardedTrainer(model, use_graphs=False, exchange="rccl")
+                S_blk = 0
+                blk_pos[0] = 0
+                i, graphed = warm()
         def block():       # exactly --steps steps between barrier + synchronize on both sides; MAX over ranks
             nonlocal i, out
             gpu_sync()
