@@ -771,7 +771,7 @@ def fit_api_sharded_1rank(args):
         "X, y = X.repeat(4, 1), y.repeat(4)\n"
         "sink = io.StringIO()\n"
         "with contextlib.redirect_stdout(sink):\n"
-        "    model.fit(X, y, batch_size=args.batch, epochs=1, verbose=0, shuffle=False)\n"
+        "    model.fit(X, y, batch_size=args.batch, epochs=2, verbose=0, shuffle=False)\n"    # (every block variant captured)
         "    torch.cuda.synchronize(); t0 = time.perf_counter()\n"
         "    h = model.fit(X, y, batch_size=args.batch, epochs=3, verbose=0, shuffle=False)\n"
         "    torch.cuda.synchronize(); dt = time.perf_counter() - t0\n"

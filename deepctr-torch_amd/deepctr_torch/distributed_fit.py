@@ -87,6 +87,10 @@ class _Sharded(object):
     def set_use_graphs(self, on):
         self.tr.set_use_graphs(on)
 
+    def graphs_on(self):
+        """an earlier fit() call left the trainer replaying captured segments: this call starts on them"""
+        return bool(self.tr.use_graphs)
+
     def gather_tables(self):
         self.tr.gather_tables()
 
@@ -117,6 +121,9 @@ class _Replicated(object):
 
     def set_use_graphs(self, on):
         pass
+
+    def graphs_on(self):
+        return False
 
     def gather_tables(self):
         pass
@@ -235,7 +242,7 @@ def fit(model, X_all, y_all, batch_size, epochs, verbose, initial_epoch, do_vali
             return X_all.index_select(0, idx), y_all.index_select(0, idx)
         return X_all[lo:hi].contiguous(), y_all[lo:hi].contiguous()
 
-    graphs_on = False
+    graphs_on = tr.graphs_on()
     S_blk = tr.blocks(dev)
     if S_blk < 2:
         S_blk = 0

@@ -942,6 +942,8 @@ class ShardedTrainer(object):
         """Switch hipGraph capture of the compute segment on / off; takes effect at the next ``train_step`` (the segments are
         rebuilt).  Eager steps first, graphs afterwards is the intended order: the first call of a segment uploads
         descriptors and allocates lazily, neither of which can be captured."""
+        if bool(on) == bool(self.use_graphs):
+            return        # (fit() asks at the start of every call: captured segments and blocks of an earlier call stay valid)
         self.use_graphs = bool(on)
         self._shape = None
         if self._dx is not None:

@@ -29,6 +29,7 @@ rm -rf $OUT/prof
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o deepfm -- python $OUT/../bench.py --steps 96 --warmup 16 --no-cpu-baseline ) > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?"
 f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); head -8 $f | cut -c1-140
 t=$(find $OUT/prof -name "*kernel_trace.csv" | head -1); python tools/timeline.py $t 9 > $OUT/timeline.txt; tail -1 $OUT/timeline.txt
+cp $f $OUT/deepfm_kernel_stats.csv; rm -rf $OUT/prof       # (gpurun copies back at most 64 MiB: the raw trace is not kept)
 ( timeout 600 python tools/bench_models.py ) > $OUT/models.json 2> $OUT/models.err; echo "models rc=$?"
 python -c "
 import json
