@@ -253,6 +253,19 @@ __global__ __launch_bounds__(256) void k_relu_bwd_colsum(const float* __restrict
     stg_f32(part + static_cast<int64_t>(blockIdx.x) * N + n, s);
   }
 }
+// part[w][n] = sum over the rows b of group w of  wt[b] * x[b, n]   (the weight gradient of a bias-free 1-unit projection
+// over narrow rows: g_w = g^T X, xDeepFM's cin_linear -- a [1, B] x [B, N] library GEMM before); finished by k_colsum_finish
+__global__ __launch_bounds__(256) void k_rows_wsum(const float* __restrict__ x, int64_t ldx, const float* __restrict__ wt,
+                                                   int B, int N, float* __restrict__ part) {
+  const int r0 = blockIdx.x * kColRows;
+  const int r1 = (r0 + kColRows < B) ? r0 + kColRows : B;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int b = r0; b < r1; ++b) s = fmaf(ldg_f32(wt + b), ldg_f32(x + b * ldx + n), s);
+    stg_f32(part + static_cast<int64_t>(blockIdx.x) * N + n, s);
+  }
+}
 __global__ __launch_bounds__(256) void k_colsum_finish(const float* __restrict__ part, int groups, int N,
                                                        float* __restrict__ out) {
   const int n = blockIdx.x * 256 + threadIdx.x;
@@ -370,6 +383,18 @@ extern "C" int dctr_rows_dot(const float* x, int64_t ld_x, const float* w, int32
   if (!x || !w || !out || B < 0 || N <= 0 || ld_x < N) return DCTR_EINVAL;
   if (B == 0) return DCTR_OK;
   k_rows_dot<<<dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(x, ld_x, w, B, N, out);
+  return launch_status();
+}
+
+extern "C" int dctr_rows_tdot(const float* x, int64_t ld_x, const float* w, int32_t B, int32_t N, float* out,
+                              float* workspace, dctr_stream_t stream) {
+  if (!x || !w || !out || !workspace || B <= 0 || N <= 0 || ld_x < N) return DCTR_EINVAL;
+  const int groups = (B + kColRows - 1) / kColRows;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  k_rows_wsum<<<dim3(groups), dim3(256), 0, s>>>(x, ld_x, w, B, N, workspace);
+  const int st = launch_status();
+  if (st != DCTR_OK) return st;
+  k_colsum_finish<<<dim3((N + 255) / 256), dim3(256), 0, s>>>(workspace, groups, N, out);
   return launch_status();
 }
 

@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdctr_hip.so")
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 
@@ -162,6 +162,7 @@ SIGNATURES = {
     "dctr_cin_pool_fwd": (ctypes.c_int, [_P, _I32, _I32, _I32, _I32, _P, _I64, _P]),
     "dctr_cin_pool_bwd": (ctypes.c_int, [_P, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "dctr_rows_dot": (ctypes.c_int, [_P, _I64, _P, _I32, _I32, _P, _P]),
+    "dctr_rows_tdot": (ctypes.c_int, [_P, _I64, _P, _I32, _I32, _P, _P, _P]),
     "dctr_senet_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P, _P]),
     "dctr_senet_bwd_workspace_floats": (ctypes.c_size_t, [_I32, _I32, _I32]),
     "dctr_senet_bwd": (ctypes.c_int, [_P, _P, _I64, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P]),

@@ -694,11 +694,14 @@ class CINStackFunction(torch.autograd.Function):
         B = x.shape[0]
         st = L.stream_handle(dev)
         g = g.contiguous().float()
+        ctx_join = False
         if ctx.flat:
             X0 = x[:, :F * D].unflatten(1, (F, D))
             gx = torch.empty((B, ctx.x_cols), dtype=torch.float32, device=dev)
-            if ctx.x_cols > F * D:
-                gx[:, F * D:].zero_()          # (the dense columns behind the fields: not the CIN's inputs)
+            # (the dense columns behind the fields are not the CIN's inputs: zeroed by the joining launch at the end, or here)
+            ctx_join = B > 0 and (F * D) % 4 == 0 and ctx.x_cols % 4 == 0 and os.environ.get("DCTR_GLUE_KERNELS", "1") != "0"
+            if ctx.x_cols > F * D and not ctx_join:
+                gx[:, F * D:].zero_()
             ld_gx = ctx.x_cols
         else:
             X0 = x
@@ -707,7 +710,15 @@ class CINStackFunction(torch.autograd.Function):
         X0r, ldx = _rows3(X0, "CIN field input")
         g_wh = None
         if ctx.has_head:
-            g_wh = torch.mm(g.reshape(1, B), feat).reshape(w_head.shape)
+            if B > 0 and os.environ.get("DCTR_GLUE_KERNELS", "1") != "0":
+                # g_w = g^T feat as fixed-order column sums (csrc/head.hip k_rows_wsum) instead of a [1, B] x [B, fm] GEMM
+                g_wh = torch.empty((fm,), dtype=torch.float32, device=dev)
+                ws = torch.empty((max(1, lib.dctr_relu_bwd_bias_workspace_floats(B, fm)),), dtype=torch.float32, device=dev)
+                L.check(lib.dctr_rows_tdot(_ptr(feat), feat.stride(0), _ptr(g), B, fm, _ptr(g_wh), _ptr(ws), st),
+                        "dctr_rows_tdot")
+                g_wh = g_wh.reshape(w_head.shape)
+            else:
+                g_wh = torch.mm(g.reshape(1, B), feat).reshape(w_head.shape)
             wh = w_head.detach().contiguous().reshape(-1)
         rets = [None] * (2 * n)
         g_hidden = None
@@ -746,7 +757,12 @@ class CINStackFunction(torch.autograd.Function):
             else:
                 g_hidden = gH
         if B > 0:
-            if ctx.flat:
+            if ctx.flat and ctx_join:
+                # gx[:, :F D] += first_gh and gx[:, F D:] = 0 in one launch (in place: every lane reads and writes its own words)
+                fg = first_gh.reshape(B, F * D)
+                L.check(lib.dctr_rows_join(_ptr(gx), ld_gx, _ptr(fg), fg.stride(0), F * D, None, 0, 0, _ptr(gx), ld_gx, B, st),
+                        "dctr_rows_join")
+            elif ctx.flat:
                 gx[:, :F * D].add_(first_gh.reshape(B, F * D))
             else:
                 gx.add_(first_gh)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 23
+#define DCTR_ABI_VERSION 24
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -491,6 +491,11 @@ int dctr_cin_pool_bwd(const float* g_hidden, const float* g_pooled, int64_t ld_g
 /* out[b] = sum_j x[b * ld_x + j] * w[j]   (csrc/head.hip): nn.Linear(N, 1, bias=False) over narrow rows -- xDeepFM's
  * cin_linear (xdeepfm.py:72, :97).  One wave per row, fixed summation order.                                          */
 int dctr_rows_dot(const float* x, int64_t ld_x, const float* w, int32_t B, int32_t N, float* out, dctr_stream_t stream);
+/* out[j] = sum_b w[b] * x[b * ld_x + j]   (ABI 24): the weight gradient of that projection, g_w = g^T X -- torch.mm of a
+ * [1, B] row with the [B, N] feature maps before (a 16 us library GEMM at B = 4096, N = 192).  Rows in groups of 32, the
+ * groups' sums added in group order: deterministic.  workspace: dctr_relu_bwd_bias_workspace_floats(B, N) floats.   */
+int dctr_rows_tdot(const float* x, int64_t ld_x, const float* w, int32_t B, int32_t N, float* out, float* workspace,
+                   dctr_stream_t stream);
 
 /* ---- SENET / Bilinear / InnerProduct (csrc/pairwise.hip) ----------------------------------------------
  * SENETLayer (interaction.py:93-101): z = mean_d E; a1 = relu(z W1^T); a = relu(a1 W2^T); V = E * a[:, :, None]
@@ -785,7 +790,8 @@ int dctr_bce_head(const float* part0, const float* part1, const float* part2, co
 /* ---- autograd glue as single launches (models on torch.autograd: xDeepFM, FiBiNET, DCN, PNN, ...) ------------------------
  * dctr_rows_join: out[b, 0:W) = a[b, :] (+ c[b, :]), out[b, W:W+n_d) = d[b, :], out[b, W+n_d:ld_out) = 0 -- the gradient of
  * the gather's output [B, ld_out] from the gradients of its two views (replaces the slice backward's copies + fill, and
- * autograd's add when c is given; a, c, d nullable).  W, ld_* multiples of 4, 16-byte aligned rows.
+ * autograd's add when c is given; a, c, d nullable).  W, ld_* multiples of 4, 16-byte aligned rows.  out may BE a (same
+ * leading dimension): every lane reads the words it writes -- "a[:, :W] += c, a[:, W:] = 0" in one launch.
  * dctr_relu_bwd_bias: g_out = g * (h > 0) (aten::threshold_backward; h NULL: g_out = g; g_out NULL: not written) and
  * g_bias[n] = sum_b g_out[b, n] in a fixed order (replaces threshold_backward + sum(0) behind a wide nn.Linear,
  * layers/core.py:120-134).  workspace: dctr_relu_bwd_bias_workspace_floats(B, N) floats.                             */

@@ -114,13 +114,14 @@ class OpsMixin(object):
     def dctr_rows_join(self, a, ld_a, c, ld_c, W, d, ld_d, n_d, out, ld_out, B, stream):
         self.calls.append("rows_join")
         o = _t(out, B, ld_out)
-        o.zero_()
+        res = torch.zeros_like(o)          # (out may be a itself: every word is read before it is written, like the kernel)
         if a:
-            o[:, :W] += _t(a, B, W, ld_a)
+            res[:, :W] += _t(a, B, W, ld_a)
         if c:
-            o[:, :W] += _t(c, B, W, ld_c)
+            res[:, :W] += _t(c, B, W, ld_c)
         if d and n_d > 0:
-            o[:, W:W + n_d] = _t(d, B, n_d, ld_d)
+            res[:, W:W + n_d] = _t(d, B, n_d, ld_d)
+        o.copy_(res)
         return 0
 
     def dctr_relu_bwd_bias_workspace_floats(self, B, N):
@@ -306,6 +307,11 @@ class OpsMixin(object):
     def dctr_rows_dot(self, x, ld_x, w, B, N, out, stream):
         self.calls.append("rows_dot")
         _v(out, B).copy_((_t(x, B, N, ld_x).double() @ _v(w, N).double()).float())
+        return 0
+
+    def dctr_rows_tdot(self, x, ld_x, w, B, N, out, ws, stream):
+        self.calls.append("rows_tdot")
+        _v(out, N).copy_(torch.mm(_v(w, B).reshape(1, B), _t(x, B, N, ld_x)).reshape(-1))    # (the reference's own fp32 product)
         return 0
 
     # ---- CrossNet (vector) --------------------------------------------------------------------------------------------

@@ -136,6 +136,30 @@ def test_cin_pool_kernels_match_split_sum(B, O, D, nh):
 
 
 @pytest.mark.parametrize("B,N,ld", [(1, 1, 1), (5, 192, 192), (4096, 192, 200), (33, 70, 71), (257, 1000, 1000)])
+def test_rows_tdot_matches_fp64(B, N, ld):
+    """dctr_rows_tdot: out[j] = sum_b w[b] x[b, j] (the weight gradient of xDeepFM's cin_linear, xdeepfm.py:72: g^T X) --
+    against fp64 and torch.mm's own result, bit-identical run to run (fixed summation order)."""
+    from deepctr_torch._hip import lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(7 * B + N)
+    x = torch.randn(B, ld, generator=g).to(DEV)
+    w = torch.randn(B, generator=g).to(DEV)
+    ws = torch.empty((max(1, lib.dctr_relu_bwd_bias_workspace_floats(B, N)),), device=DEV)
+    outs = []
+    for _ in range(2):
+        out = torch.full((N,), float("nan"), device=DEV)
+        ws.fill_(float("nan"))
+        L.check(lib.dctr_rows_tdot(ctypes.c_void_p(x.data_ptr()), ld, ctypes.c_void_p(w.data_ptr()), B, N,
+                                   ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()), L.stream_handle(DEV)))
+        outs.append(out)
+    ref = w.double() @ x[:, :N].double()
+    scale = float((w.double().abs() @ x[:, :N].double().abs()).max())
+    assert float((outs[0].double() - ref).abs().max()) <= 1e-6 * max(1.0, scale)
+    assert float((outs[0] - torch.mm(w.reshape(1, B), x[:, :N]).reshape(-1)).abs().max()) <= 2e-6 * max(1.0, scale)
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("B,N,ld", [(1, 1, 1), (5, 192, 192), (4096, 192, 200), (33, 70, 71), (257, 1000, 1000)])
 def test_rows_dot_matches_fp64(B, N, ld):
     """dctr_rows_dot: out[b] = sum_j x[b, j] w[j] (nn.Linear(N, 1, bias=False), xdeepfm.py:72) -- against fp64, and
     bit-identical run to run (fixed summation order)."""
