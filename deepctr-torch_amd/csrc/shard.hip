@@ -237,9 +237,12 @@ __global__ __launch_bounds__(kT) void k_assemble_bwd_v4(AsmArgs A) {
   constexpr int LPS = 32, FL = LPS / D4, SPB = kT / LPS;
   const int tid = threadIdx.x;
   const int nblk = (A.B + SPB - 1) / SPB;
-  if (static_cast<int>(blockIdx.x) >= nblk) {   // d loss / d Linear.weight, one workgroup per dense column
+  const int n_col = static_cast<int>(gridDim.x) - nblk;
+  // d loss / d Linear.weight, one workgroup per dense column -- the FIRST workgroups of the grid: each walks all B samples
+  // (two dependent rounds of strided loads + a reduction, ~6 us) and used to start last, as the launch's tail
+  if (static_cast<int>(blockIdx.x) < n_col) {
     __shared__ float red[kT / 64];
-    const int j = static_cast<int>(blockIdx.x) - nblk;
+    const int j = static_cast<int>(blockIdx.x);
     const int col = ldg_i32(A.wdense_cols + j);
     float acc = 0.f;
 #pragma unroll 8
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(kT) void k_assemble_bwd_v4(AsmArgs A) {
     return;
   }
   const int sl = tid / LPS, l = tid % LPS, d4 = l % D4, fl = l / D4;
-  const int64_t b = static_cast<int64_t>(blockIdx.x) * SPB + sl;
+  const int64_t b = static_cast<int64_t>(static_cast<int>(blockIdx.x) - n_col) * SPB + sl;
   if (b >= A.B) return;
   const int D = 4 * D4;
   const float gf = A.g_fm ? ldg_f32(A.g_fm + b) : 0.f;
