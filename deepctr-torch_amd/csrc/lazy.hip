@@ -72,8 +72,18 @@ __device__ __forceinline__ void replay_in_step(const OptConst& o, float lam2d, f
     if (T > from) {
       const float rbc = __builtin_amdgcn_rcpf(bc);
       if (deep_on) {
+        if (FAST && !DCTR_LAZY_REPLAY_NR && VEC % 2 == 0) {
+          // (this loop is Adam with the host's tables by construction: packed pairs, lazy_opt.hpp adam_replay_step)
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) opt_step<FAST>(o, lam2d * w[i], w[i], a[i], b[i], ss, bc, rbc);
+          for (int i = 0; i < VEC; i += 2) {
+            f32x2 w2 = {w[i], w[i + 1]}, a2 = {a[i], a[i + 1]}, b2 = {b[i], b[i + 1]};
+            adam_replay_step<f32x2>(1.f - o.beta1, 1.f - o.beta2, o.beta2, o.eps, w2 * lam2d, ss, rbc, w2, a2, b2);
+            w[i] = w2.x; w[i + 1] = w2.y; a[i] = a2.x; a[i + 1] = a2.y; b[i] = b2.x; b[i + 1] = b2.y;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) opt_step<FAST>(o, lam2d * w[i], w[i], a[i], b[i], ss, bc, rbc);
+        }
       }
       if (wide_on) opt_step<FAST>(o, lam2w * ww, ww, wa, wb, ss, bc, rbc);
     }

