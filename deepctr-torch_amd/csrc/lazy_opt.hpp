@@ -109,10 +109,10 @@ __device__ __forceinline__ float sqrt_nr(float x) {
 // the same order with every fused multiply-add written out and contraction off, so that whoever replays a (row, step) --
 // catch-up, sweep, flush; one lane or a packed pair -- computes the same bits (the compiler contracts `a * b + c` in one
 // kernel and not in the next: round-6 finding on the dense optimizer, common.hpp).  11 vector instructions + 2
-// transcendentals per element; packed: per PAIR.  Left to the compiler the loop's third that sits between the reciprocal
+// transcendentals per element (9 + 2 with the hardware square root instead of v * rsq(v + tiny)); packed: per PAIR.  Left to the compiler the loop's third that sits between the reciprocal
 // square roots and the reciprocals (`+ tiny`, `x * rsq`, `fma(.., rbc, eps)`, the quotient) stayed unpacked: 15 packed + 18
 // plain instructions per trip of four elements, now 22 packed.
-//   g = lam2 w ;  m += (g - m)(1 - beta1) ;  v = v beta2 + ((1 - beta2) g) g ;  s = v rsq(v + tiny) ;
+//   g = lam2 w ;  m += (g - m)(1 - beta1) ;  v = v beta2 + ((1 - beta2) g) g ;  s = sqrt(v) (the 1-ulp instruction) ;
 //   den = s / bc + eps  (as fma(s, 1 / bc, eps)) ;  w -= ss (m rcp(den))
 template <typename T>
 __device__ __forceinline__ T rsq_t(T x);
@@ -120,6 +120,12 @@ template <>
 __device__ __forceinline__ float rsq_t<float>(float x) { return __builtin_amdgcn_rsqf(x); }
 template <>
 __device__ __forceinline__ f32x2 rsq_t<f32x2>(f32x2 x) { return f32x2{__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)}; }
+template <typename T>
+__device__ __forceinline__ T sqrt_t(T x);
+template <>
+__device__ __forceinline__ float sqrt_t<float>(float x) { return __builtin_amdgcn_sqrtf(x); }
+template <>
+__device__ __forceinline__ f32x2 sqrt_t<f32x2>(f32x2 x) { return f32x2{__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)}; }
 template <typename T>
 __device__ __forceinline__ T rcp_t(T x);
 template <>
@@ -135,7 +141,7 @@ __device__ __forceinline__ void adam_replay_step(float c1, float c2, float beta2
 #pragma clang fp contract(off)
   m = fma_t(g - m, T(c1), m);
   v = fma_t(g * c2, g, v * beta2);
-  const T s = v * rsq_t<T>(v + 1.17549435e-38f);
+  const T s = sqrt_t<T>(v);        // (v_sqrt_f32: 1 ulp, exact 0 at 0 -- no clamp and no multiply as with v * rsq(v + tiny))
   const T den = fma_t(s, T(rbc), T(eps));
   const T q = m * rcp_t<T>(den);
   w = fma_t(T(-ss), q, w);
