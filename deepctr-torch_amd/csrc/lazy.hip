@@ -66,11 +66,16 @@ __device__ __forceinline__ void replay_in_step(const OptConst& o, float lam2d, f
   if (from_min >= to) return;
   float ss, bc;
   adam_tab_uniform(o, from_min + 1, ss, bc);
+  // (the divisor's reciprocal from the host's third table when there is one: a v_rcp_f32 per trip is 16 of the loop's
+  // ~250 issue cycles)
+  const bool tab_r = o.adam_rbc != nullptr;
+  float rb = tab_r ? o.adam_rbc[(from_min + 1 < o.n_bc ? from_min + 1 : o.n_bc) - 1] : 0.f;
   for (int T = from_min + 1; T <= to; ++T) {
     float ssn, bcn;
     adam_tab_uniform(o, T + 1, ssn, bcn);       // (the next step's pair is in flight while this step computes; clamped: valid)
+    const float rbn = tab_r ? o.adam_rbc[(T + 1 < o.n_bc ? T + 1 : o.n_bc) - 1] : 0.f;
     if (T > from) {
-      const float rbc = __builtin_amdgcn_rcpf(bc);
+      const float rbc = tab_r ? rb : __builtin_amdgcn_rcpf(bc);
       if (deep_on) {
         if (FAST && !DCTR_LAZY_REPLAY_NR && VEC % 2 == 0) {
           // (this loop is Adam with the host's tables by construction: packed pairs, lazy_opt.hpp adam_replay_step)
@@ -89,6 +94,7 @@ __device__ __forceinline__ void replay_in_step(const OptConst& o, float lam2d, f
     }
     ss = ssn;
     bc = bcn;
+    rb = rbn;
   }
 }
 

@@ -20,6 +20,7 @@ struct OptConst {
   // entry on), or NULL: computed in the kernel (AdamClock)
   const float* adam_ss;
   const float* adam_bc;
+  const float* adam_rbc;   // 1 / adam_bc (n_bc entries) or NULL
   int n_ss, n_bc;
 };
 
@@ -193,6 +194,7 @@ inline OptConst opt_const(const dctr_lazy_opt_t* opt) {
   const bool tab = opt->kind == DCTR_LAZY_ADAM && opt->adam_ss && opt->adam_bc && opt->n_ss > 0 && opt->n_bc > 0;
   o.adam_ss = tab ? opt->adam_ss : nullptr;
   o.adam_bc = tab ? opt->adam_bc : nullptr;
+  o.adam_rbc = tab ? opt->adam_rbc : nullptr;
   o.n_ss = tab ? opt->n_ss : 0;
   o.n_bc = tab ? opt->n_bc : 0;
   return o;

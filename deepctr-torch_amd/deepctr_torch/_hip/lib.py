@@ -112,7 +112,7 @@ class LazyOpt(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("lr", ctypes.c_float), ("eps", ctypes.c_float),
                 ("beta1", ctypes.c_float), ("beta2", ctypes.c_float),
                 ("n_ss", ctypes.c_int32), ("n_bc", ctypes.c_int32), ("any_l2", ctypes.c_int32),
-                ("adam_ss", ctypes.c_void_p), ("adam_bc", ctypes.c_void_p)]
+                ("adam_ss", ctypes.c_void_p), ("adam_bc", ctypes.c_void_p), ("adam_rbc", ctypes.c_void_p)]
 POOL_CODE = {None: 0, "sum": 1, "mean": 2, "max": 3}
 BWD_ACCUM, BWD_SGD = 0, 1
 OPT_SGD, OPT_ADAGRAD = 0, 1

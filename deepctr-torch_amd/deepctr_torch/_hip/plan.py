@@ -157,7 +157,8 @@ class LazyState(object):
             out.append(corr)
         ss = (np.float64(lr) / out[0]).astype(np.float32)
         bc = np.sqrt(out[1]).astype(np.float32)
-        return ss, bc
+        rbc = (1.0 / np.sqrt(out[1])).astype(np.float32)       # (the replay loop's divisor as a factor: dctr_lazy_opt_t.adam_rbc)
+        return ss, bc, rbc
 
     def _ensure_adam_tables(self, device):
         if self.kind != "adam" or os.environ.get("DCTR_LAZY_ADAM_TABLES", "1") == "0":
@@ -172,9 +173,10 @@ class LazyState(object):
             else:
                 self._adam_tab = tuple(torch.from_numpy(t).to(device) for t in tabs)
         if self._adam_tab:
-            ss, bc = self._adam_tab
+            ss, bc, rbc = self._adam_tab
             self.opt.adam_ss, self.opt.n_ss = ss.data_ptr(), ss.numel()
             self.opt.adam_bc, self.opt.n_bc = bc.data_ptr(), bc.numel()
+            self.opt.adam_rbc = rbc.data_ptr()
 
     def _ensure(self, device):
         plan = self.plan

@@ -404,6 +404,9 @@ typedef struct dctr_lazy_opt {
                      to replay and orders its entries by gap) */
   const float* adam_ss;
   const float* adam_bc;
+  const float* adam_rbc; /* optional (ABI 24), n_bc entries: (float)(1 / sqrt(1 - beta2^T)) -- the replay loop divides by
+                            adam_bc[T - 1] through this reciprocal; NULL: it takes the hardware reciprocal of adam_bc itself,
+                            one quarter-rate instruction per replayed step and wavefront */
 } dctr_lazy_opt_t;
 size_t dctr_sizeof_lazy_unit(void);
 /* Round 6 -- the step that carries the batch's DATA gradient, inside the sorted update: dctr_embed_update's gradient sums

@@ -128,7 +128,8 @@ def test_adam_tables_are_torchs_own_scalars():
     import math
     from deepctr_torch._hip.plan import LazyState
     lr, b1, b2 = 1e-3, 0.9, 0.999
-    ss, bc = LazyState.adam_tables(lr, b1, b2)
+    ss, bc, rbc = LazyState.adam_tables(lr, b1, b2)
+    np.testing.assert_allclose(rbc.astype(np.float64) * bc.astype(np.float64), 1.0, rtol=2e-7)
     assert ss.dtype == np.float32 and bc.dtype == np.float32
     for T in (1, 2, 3, 10, 100, 349, 1000, 20000, len(bc)):
         if T <= len(ss):
