@@ -250,6 +250,22 @@ class _TunedGemm(object):
         return False
 
 
+_PADDED_W = {}
+
+
+def _padded_weight(W, ld):
+    """[N, ld] copy of ``W [N, K]`` with zero columns behind K, in a buffer kept per (weight storage, ld): the pad is written
+    once, the K columns at every call (the weight moves every step)."""
+    key = (W.data_ptr(), int(ld), tuple(W.shape), str(W.device))
+    buf = _PADDED_W.get(key)
+    if buf is None:
+        if len(_PADDED_W) > 8:
+            _PADDED_W.clear()
+        buf = _PADDED_W[key] = torch.zeros((W.shape[0], int(ld)), dtype=W.dtype, device=W.device)
+    buf[:, :W.shape[1]].copy_(W.detach())
+    return buf
+
+
 class WideLinearFunction(torch.autograd.Function):
     """act(x[:, :K] W^T + b) for a layer too wide for the tower kernels (K > 4096): three library GEMMs (forward, input
     gradient, weight gradient), the two backward ones under ``_TunedGemm``; the relu mask and the bias gradient without
@@ -296,7 +312,14 @@ class WideLinearFunction(torch.autograd.Function):
         gx = gW = None
         with _TunedGemm():
             if ctx.needs_input_grad[0]:
-                gx = torch.mm(g, W)
+                if x.stride(0) != x.shape[1]:
+                    # the input came with padded rows (ops.slab_ld: rows on 128-byte lines): its gradient goes back with the
+                    # same row stride -- the kernels that consume it read 64-byte pieces per (sample, pair)
+                    # (through a zero-padded copy of W: with `out=` a strided view the library picked a 24 us slower GEMM)
+                    Wp = _padded_weight(W, x.stride(0))
+                    gx = torch.mm(g, Wp)[:, :W.shape[1]]
+                else:
+                    gx = torch.mm(g, W)
             if ctx.needs_input_grad[1]:
                 gW = torch.mm(g.t(), x)
         if gb is None and ctx.has_bias and ctx.needs_input_grad[2]:

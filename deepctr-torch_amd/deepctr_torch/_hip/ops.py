@@ -830,6 +830,13 @@ def tournament_schedule(F, bilinear_type):
     return rows, n // 2, pair_w, n_w
 
 
+def slab_ld(width):
+    """Row stride (floats) of a wide [B, width] slab whose rows should start on 128-byte lines (DCTR_SLAB_ALIGN=0: dense)."""
+    if os.environ.get("DCTR_SLAB_ALIGN", "1") == "0" or width < 1024:
+        return int(width)
+    return (int(width) + 31) // 32 * 32
+
+
 class BilinearFunction(torch.autograd.Function):
     """(x_i W^T) * x_j for every pair, on E and optionally on a second input V with the same weights; the result is
     written in the DNN-input layout ``[V pairs | E pairs | dense]`` (fibinet.py:82-87)."""
@@ -851,10 +858,15 @@ class BilinearFunction(torch.autograd.Function):
         if dense is not None and (dense.stride(1) != 1 or dense.dtype != torch.float32):
             dense = dense.float().contiguous()
         width = npass * P * D + n_dense
-        out = torch.empty((B, width), dtype=torch.float32, device=E.device)
+        # rows of the product slab start on a 128-byte line (round 6): a pair's D floats per sample are one 64-byte piece, and
+        # with rows of 10 413 floats (41 652 bytes) every piece straddled two lines -- twice the memory requests in this
+        # kernel's stores and in the backward kernels' reads of the gradient slab (mlp.WideLinearFunction returns it with the
+        # same row stride).  The GEMMs behind take the view with its leading dimension.
+        ld_out = slab_ld(width)
+        out = torch.empty((B, ld_out), dtype=torch.float32, device=E.device)[:, :width]
         sched = meta.device_tables(E.device)
         L.check(lib.dctr_bilinear_fwd(_ptr(E), lde, _ptr(V), ldv, _ptr(Wf), _ptr(sched[2]), sched[2].shape[0], P, F, D, B,
-                                      _ptr(out), width, _ptr(dense), dense.stride(0) if dense is not None else 0,
+                                      _ptr(out), ld_out, _ptr(dense), dense.stride(0) if dense is not None else 0,
                                       n_dense, npass * P * D, L.stream_handle(E.device)), "dctr_bilinear_fwd")
         ctx.meta, ctx.n_w_in = meta, len(weights)
         ctx.has_v, ctx.has_dense = V is not None, dense is not None
