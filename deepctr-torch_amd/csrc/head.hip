@@ -232,54 +232,68 @@ __global__ __launch_bounds__(256) void k_rows_dot(const float* __restrict__ x, i
   if (lane == 0) stg_f32(out + b, s);
 }
 
-// relu's backward on g [B, N] (mask h > 0, like aten::threshold_backward) fused with the bias gradient's column sums:
-// workgroup w takes the rows [w * kRows, ...), thread n the columns n, n + 256, ...; partial sums part[w][N] are added by
-// k_colsum_finish in workgroup order (deterministic).  Replaces threshold_backward + sum(0) (a 2-stage ATen reduction).
-constexpr int kColRows = 32;
-__global__ __launch_bounds__(256) void k_relu_bwd_colsum(const float* __restrict__ g, int64_t ldg, const float* __restrict__ h,
-                                                         int64_t ldh, int B, int N, float* __restrict__ go, int64_t ldo,
-                                                         float* __restrict__ part) {
+// relu's backward on g [B, N] (mask h > 0, like aten::threshold_backward) fused with the bias gradient's column sums.
+// Workgroup w takes kColRows rows; its 256 lanes are 4 row slices x 64 columns: lane (ty, tx) adds the rows ty, ty + 4, ...
+// of the group for the columns tx, tx + 64, ... (every load of a lane independent of the others: one memory round trip per
+// column tile -- the one-lane-per-column version walked 32 rows in four dependent rounds with half its lanes idle at
+// N = 128: 16.6 us for 6 MB), the four slices meet in LDS in slice order, and k_colsum_finish adds the groups' sums in a
+// fixed order.  Deterministic.  Replaces threshold_backward + sum(0) (a 2-stage ATen reduction).
+constexpr int kColRows = 16;
+template <bool WSUM>
+__global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ g, int64_t ldg, const float* __restrict__ h,
+                                                     int64_t ldh, const float* __restrict__ wt, int B, int N,
+                                                     float* __restrict__ go, int64_t ldo, float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int r0 = blockIdx.x * kColRows;
-  const int r1 = (r0 + kColRows < B) ? r0 + kColRows : B;
-  for (int n = threadIdx.x; n < N; n += 256) {
+  for (int n0 = 0; n0 < N; n0 += 64) {
+    const int n = n0 + tx;
     float s = 0.f;
-#pragma unroll 8
-    for (int b = r0; b < r1; ++b) {
-      const float gv = ldg_f32(g + b * ldg + n);
-      const float v = (h == nullptr || ldg_f32(h + b * ldh + n) > 0.f) ? gv : 0.f;
-      if (go) stg_f32(go + b * ldo + n, v);
-      s += v;
+    if (n < N) {
+#pragma unroll
+      for (int k = 0; k < kColRows / 4; ++k) {
+        const int b = r0 + ty + 4 * k;
+        if (b < B) {
+          const float gv = ldg_f32(g + b * ldg + n);
+          if (WSUM) {     // part[w][n] = sum_b wt[b] * x[b, n]  (g is x here)
+            s = fmaf(ldg_f32(wt + b), gv, s);
+          } else {
+            const float v = (h == nullptr || ldg_f32(h + b * ldh + n) > 0.f) ? gv : 0.f;
+            if (go) stg_f32(go + b * ldo + n, v);
+            s += v;
+          }
+        }
+      }
     }
-    stg_f32(part + static_cast<int64_t>(blockIdx.x) * N + n, s);
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && n < N)
+      stg_f32(part + static_cast<int64_t>(blockIdx.x) * N + n, ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx]);
+    __syncthreads();
   }
 }
-// part[w][n] = sum over the rows b of group w of  wt[b] * x[b, n]   (the weight gradient of a bias-free 1-unit projection
-// over narrow rows: g_w = g^T X, xDeepFM's cin_linear -- a [1, B] x [B, N] library GEMM before); finished by k_colsum_finish
-__global__ __launch_bounds__(256) void k_rows_wsum(const float* __restrict__ x, int64_t ldx, const float* __restrict__ wt,
-                                                   int B, int N, float* __restrict__ part) {
-  const int r0 = blockIdx.x * kColRows;
-  const int r1 = (r0 + kColRows < B) ? r0 + kColRows : B;
-  for (int n = threadIdx.x; n < N; n += 256) {
-    float s = 0.f;
-#pragma unroll 8
-    for (int b = r0; b < r1; ++b) s = fmaf(ldg_f32(wt + b), ldg_f32(x + b * ldx + n), s);
-    stg_f32(part + static_cast<int64_t>(blockIdx.x) * N + n, s);
-  }
-}
+// out[n] = sum_w part[w][n]: sixteen neighbouring lanes share a column, lane j adds the groups j, j + 16, ... ascending and
+// the sixteen sums meet in a butterfly (xor 8, 4, 2, 1): a fixed order, a sixteenth of the one-lane-per-column chain.
 __global__ __launch_bounds__(256) void k_colsum_finish(const float* __restrict__ part, int groups, int N,
                                                        float* __restrict__ out) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int n = t >> 4, j = t & 15;
+  const int nc = n < N ? n : N - 1;          // (whole 16-lane groups stay converged for the shuffles)
   float s = 0.f;
-  for (int g0 = 0; g0 < groups; g0 += 8) {
-    float v[8];
+  for (int w = j; w < groups; w += 64) {     // four loads in flight per lane
+    float v[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = ldg_f32(part + static_cast<int64_t>(g0 + k < groups ? g0 + k : groups - 1) * N + n);
+    for (int k = 0; k < 4; ++k) v[k] = ldg_f32(part + static_cast<int64_t>(w + 16 * k < groups ? w + 16 * k : groups - 1) * N + nc);
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (g0 + k < groups) s += v[k];
+    for (int k = 0; k < 4; ++k)
+      if (w + 16 * k < groups) s += v[k];
   }
-  stg_f32(out + n, s);
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) {
+    const float o = __shfl_xor(s, off, 64);
+    s = (j & off) ? o + s : s + o;           // lower lane's sum first on both sides: the same bits on all sixteen lanes
+  }
+  if (n < N && j == 0) stg_f32(out + n, s);
 }
 }  // namespace
 
@@ -391,10 +405,10 @@ extern "C" int dctr_rows_tdot(const float* x, int64_t ld_x, const float* w, int3
   if (!x || !w || !out || !workspace || B <= 0 || N <= 0 || ld_x < N) return DCTR_EINVAL;
   const int groups = (B + kColRows - 1) / kColRows;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  k_rows_wsum<<<dim3(groups), dim3(256), 0, s>>>(x, ld_x, w, B, N, workspace);
+  k_colsum_part<true><<<dim3(groups), dim3(256), 0, s>>>(x, ld_x, nullptr, 0, w, B, N, nullptr, 0, workspace);
   const int st = launch_status();
   if (st != DCTR_OK) return st;
-  k_colsum_finish<<<dim3((N + 255) / 256), dim3(256), 0, s>>>(workspace, groups, N, out);
+  k_colsum_finish<<<dim3((16 * N + 255) / 256), dim3(256), 0, s>>>(workspace, groups, N, out);
   return launch_status();
 }
 
@@ -409,9 +423,9 @@ extern "C" int dctr_relu_bwd_bias(const float* g, int64_t ld_g, const float* h, 
     return DCTR_EINVAL;
   const int groups = (B + kColRows - 1) / kColRows;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  k_relu_bwd_colsum<<<dim3(groups), dim3(256), 0, s>>>(g, ld_g, h, ld_h, B, N, g_out, ld_o, workspace);
+  k_colsum_part<false><<<dim3(groups), dim3(256), 0, s>>>(g, ld_g, h, ld_h, nullptr, B, N, g_out, ld_o, workspace);
   const int st = launch_status();
   if (st != DCTR_OK) return st;
-  k_colsum_finish<<<dim3((N + 255) / 256), dim3(256), 0, s>>>(workspace, groups, N, g_bias);
+  k_colsum_finish<<<dim3((16 * N + 255) / 256), dim3(256), 0, s>>>(workspace, groups, N, g_bias);
   return launch_status();
 }

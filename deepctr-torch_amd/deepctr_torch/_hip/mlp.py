@@ -291,7 +291,7 @@ class WideLinearFunction(torch.autograd.Function):
         gb = None
         if g.is_cuda and g.dtype == torch.float32 and ctx.has_bias and ctx.needs_input_grad[2] and g.dim() == 2 and \
                 g.stride(1) == 1 and os.environ.get("DCTR_GLUE_KERNELS", "1") != "0":
-            # relu's backward and the bias gradient's column sums in one pass (csrc/head.hip k_relu_bwd_colsum + the
+            # relu's backward and the bias gradient's column sums in one pass (csrc/head.hip k_colsum_part + the
             # fixed-order finish) instead of threshold_backward + a two-stage ATen sum(0)
             lib = L.lib()
             B, N = g.shape

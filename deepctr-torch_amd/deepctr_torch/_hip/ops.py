@@ -711,7 +711,7 @@ class CINStackFunction(torch.autograd.Function):
         g_wh = None
         if ctx.has_head:
             if B > 0 and os.environ.get("DCTR_GLUE_KERNELS", "1") != "0":
-                # g_w = g^T feat as fixed-order column sums (csrc/head.hip k_rows_wsum) instead of a [1, B] x [B, fm] GEMM
+                # g_w = g^T feat as fixed-order column sums (csrc/head.hip k_colsum_part) instead of a [1, B] x [B, fm] GEMM
                 g_wh = torch.empty((fm,), dtype=torch.float32, device=dev)
                 ws = torch.empty((max(1, lib.dctr_relu_bwd_bias_workspace_floats(B, fm)),), dtype=torch.float32, device=dev)
                 L.check(lib.dctr_rows_tdot(_ptr(feat), feat.stride(0), _ptr(g), B, fm, _ptr(g_wh), _ptr(ws), st),
