@@ -157,7 +157,13 @@ __global__ __launch_bounds__(kT) void k_senet_fwd(const float* __restrict__ E, i
   float* z = es + kSS * W;      // [kSS][F]
   float* a1 = z + kSS * F;      // [kSS][R]
   float* a = a1 + kSS * R;      // [kSS][F]
+  float* w1s = a + kSS * F;     // [R][F]   both weight matrices once per workgroup: the two small products below walked
+  float* w2s = w1s + R * F;     // [F][R]   them through 26 / 8 dependent global loads per output
   const int tid = threadIdx.x, b0 = blockIdx.x * kSS;
+  for (int e = tid; e < R * F; e += kT) {
+    w1s[e] = ldg_f32(W1 + e);
+    w2s[e] = ldg_f32(W2 + e);
+  }
   stage_rows<kSS>(es, W, E, lde, b0, B, W);
   __syncthreads();
   for (int e = tid; e < kSS * F; e += kT) {  // torch.mean(inputs, dim=-1)
@@ -170,14 +176,14 @@ __global__ __launch_bounds__(kT) void k_senet_fwd(const float* __restrict__ E, i
   for (int e = tid; e < kSS * R; e += kT) {  // relu(Linear(F -> R, no bias))
     const int r = e / R, q = e - r * R;
     float s = 0.f;
-    for (int f = 0; f < F; ++f) s += z[r * F + f] * ldg_f32(W1 + q * F + f);
+    for (int f = 0; f < F; ++f) s += z[r * F + f] * w1s[q * F + f];
     a1[e] = s > 0.f ? s : 0.f;
   }
   __syncthreads();
   for (int e = tid; e < kSS * F; e += kT) {  // relu(Linear(R -> F, no bias))
     const int r = e / F, f = e - r * F;
     float s = 0.f;
-    for (int q = 0; q < R; ++q) s += a1[r * R + q] * ldg_f32(W2 + f * R + q);
+    for (int q = 0; q < R; ++q) s += a1[r * R + q] * w2s[f * R + q];
     a[e] = s > 0.f ? s : 0.f;
   }
   __syncthreads();
@@ -209,7 +215,13 @@ __global__ __launch_bounds__(kT) void k_senet_bwd(const float* __restrict__ gV, 
   float* ga = z + kSS * F;       // [kSS][F]  masked
   float* ga1 = ga + kSS * F;     // [kSS][R]  masked
   float* gz = ga1 + kSS * R;     // [kSS][F]
+  float* w1s = gz + kSS * F;     // [R][F]  (as in the forward)
+  float* w2s = w1s + R * F;      // [F][R]
   const int tid = threadIdx.x, b0 = blockIdx.x * kSS;
+  for (int e = tid; e < R * F; e += kT) {
+    w1s[e] = ldg_f32(W1 + e);
+    w2s[e] = ldg_f32(W2 + e);
+  }
   stage_rows<kSS>(es, W, E, lde, b0, B, W);
   stage_rows<kSS>(gv, W, gV, W, b0, B, W);
   __syncthreads();
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(kT) void k_senet_bwd(const float* __restrict__ gV, 
   for (int e = tid; e < kSS * R; e += kT) {
     const int r = e / R, q = e - r * R;
     float s = 0.f;
-    for (int f = 0; f < F; ++f) s += ga[r * F + f] * ldg_f32(W2 + f * R + q);
+    for (int f = 0; f < F; ++f) s += ga[r * F + f] * w2s[f * R + q];
     const float a1v = (b0 + r < B) ? ldg_f32(a1_in + static_cast<int64_t>(b0) * R + e) : 0.f;
     ga1[e] = a1v > 0.f ? s : 0.f;
   }
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(kT) void k_senet_bwd(const float* __restrict__ gV, 
   for (int e = tid; e < kSS * F; e += kT) {
     const int r = e / F, f = e - r * F;
     float s = 0.f;
-    for (int q = 0; q < R; ++q) s += ga1[r * R + q] * ldg_f32(W1 + q * F + f);
+    for (int q = 0; q < R; ++q) s += ga1[r * R + q] * w1s[q * F + f];
     gz[e] = s / static_cast<float>(D);
   }
   __syncthreads();
@@ -270,7 +282,8 @@ __global__ __launch_bounds__(kT) void k_senet_bwd(const float* __restrict__ gV, 
 // the groups sl, sl + 16, ... (eight loads in flight), the 16 slices are then added in slice order.  (One thread per
 // output walking all 512 groups one dependent load at a time took 117 us for 208 outputs.)
 __global__ __launch_bounds__(kT) void k_reduce_partials(const float* __restrict__ part, int64_t stride,
-                                                        int64_t count, int groups, float* __restrict__ out) {
+                                                        int64_t count, int groups, float* __restrict__ out,
+                                                        int64_t split, float* __restrict__ out2) {
   __shared__ float red[16][17];
   const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 16 + o;
@@ -293,7 +306,8 @@ __global__ __launch_bounds__(kT) void k_reduce_partials(const float* __restrict_
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][o];
-    out[i] = t;
+    if (i < split) out[i] = t;        // (two result tensors behind one partial layout: SENET's gW1 | gW2)
+    else out2[i - split] = t;
   }
 }
 
@@ -1005,7 +1019,8 @@ extern "C" int dctr_senet_fwd(const float* E, int64_t ld_e, int32_t B, int32_t F
   if (!E || !W1 || !W2 || !V || !a || !a1 || B < 0 || F <= 0 || D <= 0 || R <= 0 || ld_e < static_cast<int64_t>(F) * D)
     return DCTR_EINVAL;
   if (B == 0) return DCTR_OK;
-  const size_t lds = (static_cast<size_t>(kSS) * F * D + 2u * kSS * F + static_cast<size_t>(kSS) * R) * sizeof(float);
+  const size_t lds = (static_cast<size_t>(kSS) * F * D + 2u * kSS * F + static_cast<size_t>(kSS) * R + 2u * R * F) *
+                     sizeof(float);
   if (lds > 64 * 1024) return DCTR_ENOSUP;
   k_senet_fwd<<<dim3((B + kSS - 1) / kSS), dim3(kT), lds, static_cast<hipStream_t>(stream)>>>(E, ld_e, B, F, D, W1, W2,
                                                                                             R, V, a, a1);
@@ -1028,14 +1043,13 @@ extern "C" int dctr_senet_bwd(const float* gV, const float* E, int64_t ld_e, int
     return DCTR_OK;
   }
   const int groups = (B + kSS - 1) / kSS;
-  const size_t lds = (2u * kSS * F * D + 3u * kSS * F + static_cast<size_t>(kSS) * R) * sizeof(float);
+  const size_t lds = (2u * kSS * F * D + 3u * kSS * F + static_cast<size_t>(kSS) * R + 2u * R * F) * sizeof(float);
   if (lds > 64 * 1024) return DCTR_ENOSUP;
   k_senet_bwd<<<dim3(groups), dim3(kT), lds, s>>>(gV, E, ld_e, B, F, D, W1, W2, R, a, a1, gE, workspace);
   // workspace[g] = [gW1 (R*F) | gW2 (F*R)]
   const int64_t n = 2LL * R * F, half = static_cast<int64_t>(R) * F;
-  const dim3 rg(static_cast<unsigned>((half + 15) / 16));
-  k_reduce_partials<<<rg, dim3(kT), 0, s>>>(workspace, n, half, groups, gW1);
-  k_reduce_partials<<<rg, dim3(kT), 0, s>>>(workspace + half, n, half, groups, gW2);
+  const dim3 rg(static_cast<unsigned>((n + 15) / 16));
+  k_reduce_partials<<<rg, dim3(kT), 0, s>>>(workspace, n, n, groups, gW1, half, gW2);     // (one launch for both)
   return launch_status();
 }
 
