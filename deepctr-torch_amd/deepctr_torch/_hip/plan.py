@@ -241,8 +241,9 @@ class LazyState(object):
                    ctypes.c_void_p(self.step.data_ptr()), ctypes.byref(self.opt), self.vec, self.max_dim,
                    *(tuple(tail) + (L.stream_handle(dev),))), name)
 
-    def catchup(self, X):
-        """Before the gather of a train step: bring the batch's rows to the current step.  Returns ids_t."""
+    def catchup(self, X, sweep=True):
+        """Before the gather of a train step: bring the batch's rows to the current step.  Returns ids_t.  ``sweep=False``: a
+        second catch-up of the same step (the data-parallel trainer's global batch): the step's window is swept already."""
         plan = self.plan
         self._ensure(X.device)
         B = X.shape[0]
@@ -257,7 +258,7 @@ class LazyState(object):
             if (self.sweep_k <= 0 and self.replays) else None
         self._call(L.lib().dctr_lazy_catchup, "dctr_lazy_catchup", ctypes.c_void_p(ids_t.data_ptr()), B,
                    tail=(ctypes.c_void_p(order.data_ptr()) if order is not None else None,))
-        if self.sweep_k > 0 and self.replays:
+        if sweep and self.sweep_k > 0 and self.replays:
             self._fork_sweep(X.device)
         return ids_t
 

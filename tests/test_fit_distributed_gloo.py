@@ -59,6 +59,13 @@ def _model(kind="sharded"):
         m = DeepFM(cols, cols, dnn_hidden_units=(16, 8), init_std=0.1, seed=7, device="cpu", **kw)
         m.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy"])
         return m
+    if kind == "lazy":
+        # the reference's DEFAULT kwargs in kind -- L2 on every table (made visible: 0.02), adam -- on fixed-length fields: the
+        # lazy regularised / Adam table update, which the data-parallel trainer now keeps (round 6)
+        m = DeepFM(cols, cols, dnn_hidden_units=(16, 8), l2_reg_linear=0.02, l2_reg_embedding=0.02, init_std=0.1, seed=7,
+                   device="cpu")
+        m.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy"])
+        return m
     kw = dict(l2_reg_dnn=0.2) if kind == "sharded_l2dnn" else {}      # (sharded tables, dense L2: the trainer's autograd route)
     m = DeepFM(cols, cols, dnn_hidden_units=(16, 8), l2_reg_linear=0, l2_reg_embedding=0, init_std=0.1, seed=7, device="cpu", **kw)
     m.compile("adagrad", "binary_crossentropy", metrics=["binary_crossentropy"])
@@ -96,8 +103,9 @@ def _worker(rank, world, port, shuffle, out_dir, kind="sharded"):
         torch.manual_seed(999)       # (overwritten by _fit's seed; the broadcast permutation is what keeps ranks together)
     hist = _fit(m, B_, shuffle, kind)      # fit() initialises the process group itself from the torchrun environment
     assert type(m._dist_trainer).__name__ == ("_Sharded" if kind.startswith("sharded") else "_Replicated")
+    took_lazy = bool(getattr(m._dist_trainer.tr, "_lazy", False))
     pred = m.predict(_data(kind)[0], batch_size=50)
-    torch.save({"hist": hist, "pred": pred, "sd": {k: v.detach().clone() for k, v in m.state_dict().items()}},
+    torch.save({"hist": hist, "pred": pred, "lazy": took_lazy, "sd": {k: v.detach().clone() for k, v in m.state_dict().items()}},
                os.path.join(out_dir, "rank%d.pt" % rank))
     dist.destroy_process_group()
 
@@ -170,3 +178,32 @@ def test_history_counts_regularisation_once_per_step_not_once_per_rank(tmp_path,
     for r in range(world):
         for k, want in ref_hist.items():
             np.testing.assert_allclose(ranks[r]["hist"][k], want, rtol=1e-4, err_msg="rank %d %s" % (r, k))
+
+
+def test_default_kwargs_in_kind_stay_on_the_lazy_update_under_two_ranks(tmp_path, mock):
+    """L2 on every table + adam (the reference's default kwargs, deepfm.py:41 / tests/utils.py:157) under torchrun: replicated
+    tables, and -- round 6 -- the LAZY regularised / Adam update on every replica instead of the O(vocabulary) dense route:
+    each replica catches up its own batch's rows before its gather and the other ranks' rows before the global data-gradient
+    step; same History / predictions / parameters as one process on the global batch, replicas bit-identical."""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), True, str(tmp_path), "lazy"), nprocs=world, join=True)
+    ranks = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(world)]
+    os.environ["DCTR_FIT_GRAPH"] = "0"
+    try:
+        ref_model = _model("lazy")
+        assert ref_model.model_plan().update[0] == "lazy"
+        ref_hist = _fit(ref_model, B_ * world, True, "lazy")
+    finally:
+        os.environ.pop("DCTR_FIT_GRAPH", None)
+    ref_pred = ref_model.predict(_data("lazy")[0], batch_size=50)
+    assert ref_hist["loss"][0] > 1.005 * ref_hist["binary_crossentropy"][0]      # (the regulariser is visible)
+    for r in range(world):
+        assert ranks[r]["lazy"], "rank %d fell back to the dense route" % r
+        for k, want in ref_hist.items():
+            np.testing.assert_allclose(ranks[r]["hist"][k], want, rtol=5e-5, err_msg="rank %d %s" % (r, k))
+        assert float(np.abs(ranks[r]["pred"] - ref_pred).max()) <= 5e-5
+        for k, v in ref_model.state_dict().items():
+            err = float((ranks[r]["sd"][k] - v).abs().max())
+            assert err <= 5e-5 * max(1.0, float(v.abs().max())), "rank %d %s: %.3e" % (r, k, err)
+    for k in ranks[0]["sd"]:
+        assert torch.equal(ranks[0]["sd"][k], ranks[1]["sd"][k]), "replicas differ: %s" % k

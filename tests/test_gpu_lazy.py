@@ -330,3 +330,52 @@ def test_step_inside_the_sorted_update_equals_the_two_pass_route(monkeypatch, op
     for k in tb:
         err = float((ta[k] - tb[k]).abs().max())
         assert err <= bar * max(1.0, float(tb[k].abs().max())) + 1e-12, "%s: %.3e" % (k, err)
+
+
+def test_data_parallel_trainer_keeps_the_lazy_update(monkeypatch):
+    """Round 6: the reference's default kwargs (L2 on the tables, adam) under the replicated-tables trainer stay on the lazy
+    update -- a replica catches up its own batch's rows before its gather and the global batch's rows before the data-gradient
+    step.  One rank (RCCL at world size 1) against the single-process train step on the same batches: same losses, tables and
+    moments to a few ulps (the trainer's step goes through torch.optim for the dense parameters, the single-process one through
+    the fused dense step: 2e-5 there)."""
+    import socket
+    import torch.distributed as dist
+    from deepctr_torch import parallel as par
+    from deepctr_torch.inputs import DenseFeat, SparseFeat
+    from deepctr_torch.models import DeepFM
+    B, V, F, D = 2048, 5000, 6, 16
+    gen = torch.Generator().manual_seed(9)
+    X = torch.cat([torch.randint(0, V, (6 * B, F), generator=gen).float(), torch.rand(6 * B, 3, generator=gen)], 1).to(DEV)
+    y = torch.randint(0, 2, (6 * B,), generator=gen).float().to(DEV)
+
+    def build():
+        cols = [SparseFeat("C%d" % i, V, D) for i in range(F)] + [DenseFeat("I%d" % i, 1) for i in range(3)]
+        m = DeepFM(cols, cols, dnn_hidden_units=(64, 32), l2_reg_linear=1e-4, l2_reg_embedding=1e-4, init_std=0.05, seed=5, device=DEV)
+        m.compile("adam", "binary_crossentropy", metrics=[])
+        m.train()
+        assert m.model_plan().update[0] == "lazy"
+        return m
+
+    ref = build()
+    monkeypatch.setenv("DCTR_FUSED_STEP", "0")        # (the trainer's own route for the dense parameters: autograd + torch.optim)
+    ref_losses = [float(ref._train_step(X[i * B:(i + 1) * B], y[i * B:(i + 1) * B])[0].item()) for i in range(6)]
+    monkeypatch.delenv("DCTR_FUSED_STEP")
+    ref_sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        m = build()
+        tr = par.DataParallelTrainer(m)
+        assert tr._lazy and m.model_plan().update[0] == "lazy"
+        losses = [float(tr.train_step(X[i * B:(i + 1) * B], y[i * B:(i + 1) * B])[0].item()) for i in range(6)]
+        tr.close()
+        torch.cuda.synchronize()
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    finally:
+        dist.destroy_process_group()
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
+    for k, v in ref_sd.items():
+        err = float((sd[k] - v).abs().max())
+        assert err <= 2e-5 * max(1.0, float(v.abs().max())), "%s: %.3e" % (k, err)
