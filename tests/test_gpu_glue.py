@@ -88,3 +88,38 @@ def test_wide_linear_and_split_functions_match_plain_autograd(monkeypatch):
         assert torch.equal(a, c)
     assert float((got["1"][2] - got["0"][2]).abs().max()) <= 1e-5 * float(got["0"][2].abs().max())
     assert torch.equal(got["1"][3], got["0"][3])
+
+
+def test_stamp_writes_an_increasing_device_clock_also_inside_a_graph():
+    """dctr_stamp (csrc/sync.hip; what bench.py times launches with INSIDE hipGraph replays): a one-lane kernel that stores
+    the device's real-time counter.  Stamps of one stream are ordered; the distance of two stamps around a launch covers the
+    launch; replaying the captured sequence refreshes them."""
+    import ctypes
+    from deepctr_torch._hip import lib as L
+    lib = L.lib()
+    st = torch.zeros(4, dtype=torch.int64, device=DEV)
+    x = torch.randn(1 << 22, device=DEV)
+
+    def seq():
+        h = L.stream_handle(DEV)
+        L.check(lib.dctr_stamp(ctypes.c_void_p(st.data_ptr()), h), "dctr_stamp")
+        L.check(lib.dctr_stamp(ctypes.c_void_p(st.data_ptr() + 8), h), "dctr_stamp")
+        x.mul_(1.0001)
+        L.check(lib.dctr_stamp(ctypes.c_void_p(st.data_ptr() + 16), h), "dctr_stamp")
+
+    seq()
+    torch.cuda.synchronize()
+    a = st.cpu().tolist()
+    assert 0 < a[0] <= a[1] < a[2], a
+    assert a[2] - a[1] > a[1] - a[0] >= 0          # (an 16 MB elementwise launch sits between the last two)
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        seq()
+        with torch.cuda.graph(g, stream=s):
+            seq()
+    g.replay()
+    torch.cuda.synchronize()
+    b = st.cpu().tolist()
+    assert b[0] > a[2] and b[0] <= b[1] < b[2], (a, b)

@@ -332,17 +332,22 @@ def test_step_inside_the_sorted_update_equals_the_two_pass_route(monkeypatch, op
         assert err <= bar * max(1.0, float(tb[k].abs().max())) + 1e-12, "%s: %.3e" % (k, err)
 
 
-def test_data_parallel_trainer_keeps_the_lazy_update(monkeypatch):
-    """Round 6: the reference's default kwargs (L2 on the tables, adam) under the replicated-tables trainer stay on the lazy
-    update -- a replica catches up its own batch's rows before its gather and the global batch's rows before the data-gradient
-    step.  One rank (RCCL at world size 1) against the single-process train step on the same batches: same losses, tables and
-    moments to a few ulps (the trainer's step goes through torch.optim for the dense parameters, the single-process one through
-    the fused dense step: 2e-5 there)."""
-    import socket
+def _dp_lazy_worker(rank, port):
+    """(child process: RCCL is initialised and torn down here, not in the pytest process -- a hipGraph replay in a process that
+    had a process group destroyed earlier segfaulted inside the runtime)"""
+    import os
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(ROOT, "deepctr-torch_amd"),):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import numpy as np
+    import torch
     import torch.distributed as dist
     from deepctr_torch import parallel as par
     from deepctr_torch.inputs import DenseFeat, SparseFeat
     from deepctr_torch.models import DeepFM
+    DEV = "cuda:0"
     B, V, F, D = 2048, 5000, 6, 16
     gen = torch.Generator().manual_seed(9)
     X = torch.cat([torch.randint(0, V, (6 * B, F), generator=gen).float(), torch.rand(6 * B, 3, generator=gen)], 1).to(DEV)
@@ -357,13 +362,11 @@ def test_data_parallel_trainer_keeps_the_lazy_update(monkeypatch):
         return m
 
     ref = build()
-    monkeypatch.setenv("DCTR_FUSED_STEP", "0")        # (the trainer's own route for the dense parameters: autograd + torch.optim)
+    os.environ["DCTR_FUSED_STEP"] = "0"       # (the trainer's own route for the dense parameters: autograd + torch.optim)
     ref_losses = [float(ref._train_step(X[i * B:(i + 1) * B], y[i * B:(i + 1) * B])[0].item()) for i in range(6)]
-    monkeypatch.delenv("DCTR_FUSED_STEP")
+    os.environ.pop("DCTR_FUSED_STEP")
     ref_sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
-    monkeypatch.setenv("MASTER_PORT", str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         m = build()
@@ -379,3 +382,15 @@ def test_data_parallel_trainer_keeps_the_lazy_update(monkeypatch):
     for k, v in ref_sd.items():
         err = float((sd[k] - v).abs().max())
         assert err <= 2e-5 * max(1.0, float(v.abs().max())), "%s: %.3e" % (k, err)
+
+
+def test_data_parallel_trainer_keeps_the_lazy_update():
+    """Round 6: the reference's default kwargs (L2 on the tables, adam) under the replicated-tables trainer stay on the lazy
+    update -- a replica catches up its own batch's rows before its gather and the global batch's rows before the data-gradient
+    step.  One rank (RCCL at world size 1, in a child process) against the single-process train step on the same batches: same
+    losses, tables and moments (the trainer's step goes through torch.optim for the dense parameters like the reference step it
+    is compared with: 2e-5)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_dp_lazy_worker, args=(port,), nprocs=1, join=True)
