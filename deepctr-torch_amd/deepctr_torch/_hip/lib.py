@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdctr_hip.so")
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 
@@ -171,6 +171,9 @@ SIGNATURES = {
     "dctr_bilinear_bwd_workspace_floats": (ctypes.c_size_t, [_I32, _I32, _I32]),
     "dctr_bilinear_bwd": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P,
                                          _I64, _P, _P, _P, _P, _P, _I32, _P]),
+    "dctr_bilinear_wide_bwd_workspace_floats": (ctypes.c_size_t, [_I32, _I32]),
+    "dctr_bilinear_wide_bwd": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _I64,
+                                              _P, _I64, _I32, _P, _P, _P, _P, _P]),
     "dctr_inner_product_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P]),
     "dctr_inner_product_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P, _I64, _P]),
     "dctr_crossnet_vec_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _P, _I64, _P]),

@@ -266,6 +266,31 @@ def _padded_weight(W, ld):
     return buf
 
 
+def _act_backward(g, h, relu, want_bias):
+    """(``g`` through relu's backward as a contiguous tensor, the bias gradient or None): one pass over ``g``
+    (csrc/head.hip k_colsum_part + the fixed-order finish) instead of threshold_backward + a two-stage ATen sum(0)."""
+    gb = None
+    if g.is_cuda and g.dtype == torch.float32 and want_bias and g.dim() == 2 and \
+            g.stride(1) == 1 and os.environ.get("DCTR_GLUE_KERNELS", "1") != "0":
+        lib = L.lib()
+        B, N = g.shape
+        go = torch.empty((B, N), dtype=torch.float32, device=g.device) if relu else None
+        gb = torch.empty((N,), dtype=torch.float32, device=g.device)
+        ws = torch.empty((max(1, lib.dctr_relu_bwd_bias_workspace_floats(B, N)),), dtype=torch.float32, device=g.device)
+        L.check(lib.dctr_relu_bwd_bias(_ptr(g), g.stride(0), _ptr(h) if relu else None,
+                                       h.stride(0) if relu else 0, B, N, _ptr(go), N, _ptr(gb), _ptr(ws),
+                                       L.stream_handle(g.device)), "dctr_relu_bwd_bias")
+        if relu:
+            g = go
+        elif not g.is_contiguous():
+            g = g.contiguous()
+    elif relu:
+        g = torch.ops.aten.threshold_backward(g, h, 0)     # (relu's own backward: one launch)
+    elif not g.is_contiguous():
+        g = g.contiguous()
+    return g, gb
+
+
 class WideLinearFunction(torch.autograd.Function):
     """act(x[:, :K] W^T + b) for a layer too wide for the tower kernels (K > 4096): three library GEMMs (forward, input
     gradient, weight gradient), the two backward ones under ``_TunedGemm``; the relu mask and the bias gradient without
@@ -288,27 +313,7 @@ class WideLinearFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, W, h = ctx.saved_tensors
-        gb = None
-        if g.is_cuda and g.dtype == torch.float32 and ctx.has_bias and ctx.needs_input_grad[2] and g.dim() == 2 and \
-                g.stride(1) == 1 and os.environ.get("DCTR_GLUE_KERNELS", "1") != "0":
-            # relu's backward and the bias gradient's column sums in one pass (csrc/head.hip k_colsum_part + the
-            # fixed-order finish) instead of threshold_backward + a two-stage ATen sum(0)
-            lib = L.lib()
-            B, N = g.shape
-            go = torch.empty((B, N), dtype=torch.float32, device=g.device) if ctx.relu else None
-            gb = torch.empty((N,), dtype=torch.float32, device=g.device)
-            ws = torch.empty((max(1, lib.dctr_relu_bwd_bias_workspace_floats(B, N)),), dtype=torch.float32, device=g.device)
-            L.check(lib.dctr_relu_bwd_bias(_ptr(g), g.stride(0), _ptr(h) if ctx.relu else None,
-                                           h.stride(0) if ctx.relu else 0, B, N, _ptr(go), N, _ptr(gb), _ptr(ws),
-                                           L.stream_handle(g.device)), "dctr_relu_bwd_bias")
-            if ctx.relu:
-                g = go
-            elif not g.is_contiguous():
-                g = g.contiguous()
-        elif ctx.relu:
-            g = torch.ops.aten.threshold_backward(g, h, 0)     # (relu's own backward: one launch)
-        elif not g.is_contiguous():
-            g = g.contiguous()
+        g, gb = _act_backward(g, h, ctx.relu, ctx.has_bias and ctx.needs_input_grad[2])
         gx = gW = None
         with _TunedGemm():
             if ctx.needs_input_grad[0]:
@@ -327,11 +332,111 @@ class WideLinearFunction(torch.autograd.Function):
         return gx, gW, gb, None
 
 
+class PendingPairs(object):
+    """FiBiNET's DNN input ``[Bilinear(senet) | Bilinear(raw) | dense]`` (fibinet.py:82-87) NOT yet computed: what
+    ``BilinearInteraction.fused_pair(..., lazy=True)`` hands to the tower.  ``tower`` then runs pairs and first layer as
+    ONE autograd node (``BilinearWideFunction``: the gradient of the 170 MB product slab is never materialised) when the
+    shapes fit csrc/bilinear_wide.hip, else ``materialize()`` gives the slab and everything runs as before."""
+
+    def __init__(self, meta, raw, senet, dense, weights):
+        self.meta, self.raw, self.senet, self.dense, self.weights = meta, raw, senet, dense, tuple(weights)
+        B, F, D = raw.shape
+        self.shape = (B, F * (F - 1) * D + (dense.shape[1] if dense is not None else 0))
+        self.is_cuda, self.device, self.dtype = raw.is_cuda, raw.device, raw.dtype
+        self.requires_grad = raw.requires_grad or senet.requires_grad or any(w.requires_grad for w in weights)
+
+    def fits(self, W0, relu0):
+        F, D = self.raw.shape[1], self.raw.shape[2]
+        return (self.is_cuda and os.environ.get("DCTR_BILINEAR_WIDE", "1") != "0" and D == 16 and
+                self.meta.n_w == F * (F - 1) // 2 and W0.shape[0] <= 128 and W0.shape[0] % 4 == 0 and
+                W0.shape[1] == self.shape[1] and W0.dtype == torch.float32 and W0.stride(1) == 1 and
+                self.raw.dtype == torch.float32 and
+                4 * 16 * (F * D + 31) * 4 + 4352 + ((F * (F - 1) // 2 + 3) // 4) * 64 <= 158 * 1024)
+
+    def materialize(self):
+        from . import ops as _ops
+        return _ops.BilinearFunction.apply(self.meta, self.raw, self.senet, self.dense, *self.weights)
+
+
+class BilinearWideFunction(torch.autograd.Function):
+    """``act(W0 [Bilinear(V) | Bilinear(E) | dense] + b0)`` as one node.  Forward: the pair kernel writes the DNN input,
+    one library GEMM behind it (as ``BilinearFunction`` + ``WideLinearFunction``).  Backward: the weight gradient's GEMM
+    over the saved DNN input, and ``dctr_bilinear_wide_bwd`` -- gE, gV and the pair weights' gradients straight from
+    ``gh`` and ``W0`` on the matrix cores; no ``gh W0`` GEMM, no gradient slab, no second and third pass over it."""
+
+    @staticmethod
+    def forward(ctx, meta, relu, E, V, dense, W0, b0, *weights):
+        from . import ops as _ops
+        lib = L.lib()
+        E, lde = _ops._rows3(E, "Bilinear input")
+        V, ldv = _ops._rows3(V, "Bilinear second input")
+        B, F, D = E.shape
+        Wf = meta.flat_weights(weights)
+        P = F * (F - 1) // 2
+        n_dense = dense.shape[1] if dense is not None else 0
+        if dense is not None and (dense.stride(1) != 1 or dense.dtype != torch.float32):
+            dense = dense.float().contiguous()
+        width = 2 * P * D + n_dense
+        ld_out = _ops.slab_ld(width)
+        x = torch.empty((B, ld_out), dtype=torch.float32, device=E.device)[:, :width]
+        sched = meta.device_tables(E.device)
+        L.check(lib.dctr_bilinear_fwd(_ptr(E), lde, _ptr(V), ldv, _ptr(Wf), _ptr(sched[2]), sched[2].shape[0], P, F, D, B,
+                                      _ptr(x), ld_out, _ptr(dense), dense.stride(0) if dense is not None else 0,
+                                      n_dense, 2 * P * D, L.stream_handle(E.device)), "dctr_bilinear_fwd")
+        h = torch.addmm(b0, x, W0.t()) if b0 is not None else torch.mm(x, W0.t())
+        if relu:
+            h = torch.relu_(h)
+        ctx.meta, ctx.relu, ctx.has_bias, ctx.n_w_in = meta, bool(relu), b0 is not None, len(weights)
+        ctx.save_for_backward(E, V, Wf, x, W0, h if relu else None)
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops as _ops
+        lib = L.lib()
+        meta = ctx.meta
+        E, V, Wf, x, W0, h = ctx.saved_tensors
+        E, lde = _ops._rows3(E, "Bilinear input")
+        V, ldv = _ops._rows3(V, "Bilinear second input")
+        B, F, D = E.shape
+        P = F * (F - 1) // 2
+        dev = E.device
+        g, gb = _act_backward(g, h, ctx.relu, ctx.has_bias and ctx.needs_input_grad[6])
+        if g.stride(1) != 1 or g.stride(0) % 4 != 0 or g.data_ptr() % 16 != 0:
+            g = g.contiguous()
+        gW0 = None
+        if ctx.needs_input_grad[5]:
+            with _TunedGemm():
+                gW0 = torch.mm(g.t(), x)
+        if gb is None and ctx.has_bias and ctx.needs_input_grad[6]:
+            gb = g.sum(0)
+        gE = torch.empty((B, F, D), dtype=torch.float32, device=dev)
+        gV = torch.empty((B, F, D), dtype=torch.float32, device=dev)
+        gW = torch.empty((meta.n_w, D, D), dtype=torch.float32, device=dev)
+        ws = torch.empty((lib.dctr_bilinear_wide_bwd_workspace_floats(B, P),), dtype=torch.float32, device=dev)
+        sched4, pair_w = meta.wide_tables(dev)
+        L.check(lib.dctr_bilinear_wide_bwd(_ptr(E), lde, _ptr(V), ldv, _ptr(Wf), _ptr(sched4), sched4.shape[0],
+                                           _ptr(pair_w), meta.n_w, P, F, D, B, _ptr(g), g.stride(0), _ptr(W0),
+                                           W0.stride(0), W0.shape[0], _ptr(gE), _ptr(gV), _ptr(gW), _ptr(ws),
+                                           L.stream_handle(dev)), "dctr_bilinear_wide_bwd")
+        return (None, None, gE, gV, None, gW0, gb) + tuple(gW[i] for i in range(ctx.n_w_in))
+
+
 def tower(dnn, dnn_linear, x, K=None, sink=None):
     """``dnn_linear(dnn(x[:, :K]))`` (or ``dnn(x[:, :K])`` when ``dnn_linear`` is None)."""
     spec = tower_layers(dnn, dnn_linear)
     K = x.shape[1] if K is None else K
-    if spec is not None and x.is_cuda and K > 4096 and len(spec[0]) >= 2:
+    pairs = x if isinstance(x, PendingPairs) else None
+    if pairs is not None and not (spec is not None and K == x.shape[1] and K > 4096 and len(spec[0]) >= 2 and
+                                  pairs.fits(spec[0][0][0], spec[0][0][2])):
+        x, pairs = pairs.materialize(), None
+    if pairs is not None:
+        W0, b0, relu0 = spec[0][0]
+        h0 = BilinearWideFunction.apply(pairs.meta, bool(relu0), pairs.raw, pairs.senet, pairs.dense, W0, b0,
+                                        *pairs.weights)
+        layers, w_out = spec[0][1:], spec[1]
+        x, K = h0, W0.shape[0]
+    elif spec is not None and x.is_cuda and K > 4096 and len(spec[0]) >= 2:
         # A very wide FIRST layer (FiBiNET: 10 413 inputs) stays one hipBLASLt GEMM each way; everything behind it -- the
         # remaining layers, dnn_linear, their backward and weight gradients -- runs on the tower kernels over its output
         # (round 4: those small layers were 6 hipBLASLt GEMMs of 8-27 us plus ~10 elementwise / reduce launches per step).

@@ -830,6 +830,26 @@ def tournament_schedule(F, bilinear_type):
     return rows, n // 2, pair_w, n_w
 
 
+def disjoint_groups(rows, width=4):
+    """The pairs of a tournament schedule re-dealt in groups of ``width`` field-disjoint pairs (one per wave of a
+    workgroup, a barrier per group): ``[n_groups][width][4]`` rows ``{i, j, w, k}``, ``i = -1`` for an idle entry.
+    Greedy over the tournament order -- a round is a perfect matching, so only groups that straddle two rounds have to
+    look ahead; deterministic."""
+    rest = [r for r in rows if r[0] >= 0]
+    groups = []
+    while rest:
+        used, grp, keep = set(), [], []
+        for r in rest:
+            if len(grp) < width and r[0] not in used and r[1] not in used:
+                grp.append(r)
+                used.update((r[0], r[1]))
+            else:
+                keep.append(r)
+        rest = keep
+        groups.append(grp + [(-1, -1, 0, 0)] * (width - len(grp)))
+    return groups
+
+
 def slab_ld(width):
     """Row stride (floats) of a wide [B, width] slab whose rows should start on 128-byte lines (DCTR_SLAB_ALIGN=0: dense)."""
     if os.environ.get("DCTR_SLAB_ALIGN", "1") == "0" or width < 1024:
@@ -961,6 +981,7 @@ class BilinearMeta(object):
         d = dict(self.__dict__)
         d["_dev"] = None
         d["_slab"] = None
+        d["_wide"] = None
         return d
 
     def device_tables(self, device):
@@ -973,6 +994,15 @@ class BilinearMeta(object):
                          torch.tensor(self._pair_w, dtype=torch.int32, device=device),
                          torch.tensor(by_k, dtype=torch.int32, device=device).reshape(-1, 4).contiguous())
         return self._dev
+
+    def wide_tables(self, device):
+        """(sched4 ``[n_groups, 4, 4]`` int32, pair_w) on ``device`` for dctr_bilinear_wide_bwd."""
+        dev = getattr(self, "_wide", None)
+        if dev is None or dev[0].device != torch.device(device):
+            groups = disjoint_groups(self._rows)
+            self._wide = (torch.tensor(groups, dtype=torch.int32, device=device).reshape(-1, 4, 4).contiguous(),
+                          self.device_tables(device)[1])
+        return self._wide
 
     def flat_weights(self, weights):
         """``[n_w, D, D]`` slab holding the layer's nn.Linear weights.  The parameters are re-seated ONCE as slices of

@@ -386,9 +386,13 @@ class BilinearInteraction(nn.Module):
         out = _ops.BilinearFunction.apply(self.meta(F), inputs, None, None, *self._weights())
         return out.reshape(B, F * (F - 1) // 2, D)
 
-    def fused_pair(self, raw, senet, dense=None):
+    def fused_pair(self, raw, senet, dense=None, lazy=False):
         """FiBiNET's ``cat(Bilinear(senet), Bilinear(raw))`` flattened, followed by the dense features: the DNN input
-        of fibinet.py:82-87 produced by one launch that loads every weight tile once for both passes."""
+        of fibinet.py:82-87 produced by one launch that loads every weight tile once for both passes.  ``lazy``: hand
+        the tower a ``PendingPairs`` instead (pairs + first tower layer as one autograd node, csrc/bilinear_wide.hip)."""
+        if lazy and raw.is_cuda and self._kernel_fits(raw.shape[1], raw.shape[2]):
+            from .._hip import mlp as _mlp
+            return _mlp.PendingPairs(self.meta(raw.shape[1]), raw, senet, dense, self._weights())
         if not self._kernel_fits(raw.shape[1], raw.shape[2]):
             parts = [self._pairs_torch(senet).flatten(1), self._pairs_torch(raw).flatten(1)]
             return torch.cat(parts + ([dense] if dense is not None else []), dim=1)

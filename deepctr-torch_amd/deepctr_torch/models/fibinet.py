@@ -42,8 +42,10 @@ class FiBiNET(BaseModel):
         plan = self.model_plan()
         gathered, linear_logit, _ = self.fused_inputs(X, want_fm=False, full=True)
         emb, dense = _ops.split_gathered(gathered, plan)                      # views of the gather's output
-        dnn_input = self.Bilinear.fused_pair(emb, self.SE(emb), dense)
-        dnn_logit = self.tower_logit(dnn_input)     # wide first layer on hipBLASLt, the rest on csrc/mlp.hip
+        # (lazy: on the GPU pairs + first tower layer become one autograd node -- the gradient of the product slab is made
+        # where it is consumed, csrc/bilinear_wide.hip; the first layer's forward stays one library GEMM)
+        dnn_input = self.Bilinear.fused_pair(emb, self.SE(emb), dense, lazy=True)
+        dnn_logit = self.tower_logit(dnn_input)     # the layers behind the first on csrc/mlp.hip
         if len(self.linear_feature_columns) > 0 and len(self.dnn_feature_columns) > 0:
             return [linear_logit, dnn_logit]
         elif len(self.linear_feature_columns) == 0:

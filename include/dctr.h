@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 24
+#define DCTR_ABI_VERSION 25
 
 #define DCTR_OK 0
 #define DCTR_EINVAL (-1) /* null / negative / inconsistent argument            */
@@ -536,6 +536,22 @@ int dctr_bilinear_bwd(const float* E, int64_t ld_e, const float* V, int64_t ld_v
                       int32_t P, int32_t F, int32_t D, int32_t B, const float* gout, int64_t ld_g, float* gE,
                       float* gV, float* gW, float* workspace, const int32_t* sched_k, int32_t n_sched_k,
                       dctr_stream_t stream);
+
+/* FiBiNET's bilinear pairs TOGETHER WITH the first tower layer behind them, backward direction (fibinet.py:82-99:
+ * dnn_input = [ Bilinear(senet) | Bilinear(raw) | dense ], h1 = act(W0 dnn_input + b0); core.py:123-133).  Replaces
+ * `gout = gh W0` (a [B, 2 P D] slab) followed by dctr_bilinear_bwd: the gradient of a (16 samples x one pair) piece is
+ * produced on the matrix cores where it is consumed, the slab is neither written nor read.
+ *   gh     [B, H] at gh + b*ld_gh: gradient at the first layer's pre-activation (after the activation's backward)
+ *   W0     [H, >= 2 P D] at W0 + h*ld_w0: the nn.Linear weight; columns [0, P D) belong to V's pairs, [P D, 2 P D) to E's
+ *   sched4 [n_groups][4][4] int32 (device): groups of four field-disjoint pairs {i, j, w, k}, i = -1 for an idle entry
+ *   writes gE, gV [B, F*D] and gW [n_w, D, D]; workspace = dctr_bilinear_wide_bwd_workspace_floats(B, P) floats.
+ *   DCTR_ENOSUP unless D == 16, n_w == P (one weight per pair: "interaction"), H <= 128, H % 4 == 0, 16-byte aligned rows. */
+size_t dctr_bilinear_wide_bwd_workspace_floats(int32_t B, int32_t P);
+int dctr_bilinear_wide_bwd(const float* E, int64_t ld_e, const float* V, int64_t ld_v, const float* Wf,
+                           const int32_t* sched4, int32_t n_groups, const int32_t* pair_w, int32_t n_w, int32_t P,
+                           int32_t F, int32_t D, int32_t B, const float* gh, int64_t ld_gh, const float* W0,
+                           int64_t ld_w0, int32_t H, float* gE, float* gV, float* gW, float* workspace,
+                           dctr_stream_t stream);
 
 /* InnerProductLayer (interaction.py:557-577): out[b, k] = sum_d e_i e_j (reduce != 0) or out[b, k*D + d] = e_i e_j;
  * pair order i < j, i outer.  Backward: gE[b, f, :] = sum_{g != f} gp[b, pair(f, g)] e_g.                    */

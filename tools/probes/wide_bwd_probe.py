@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""dctr_bilinear_wide_bwd alone at the Criteo shape (26 fields x 16, 128 hidden units, batch 4096): kernel time per call
+over hipEvents.  With the diagnostics library (make -C deepctr-torch_amd/csrc diag) DCTR_WIDE_VAR="<PD><VAR>" selects a
+timing variant of the main kernel (VAR bits: 1 no barrier, 2 no partial stores, 4 no ring reloads, 8 no LDS gradient
+writes -- results are wrong then, the time shows what each costs).
+    python tools/probes/wide_bwd_probe.py [variants...]      e.g.  20 21 22 24 28 215 10 30"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "deepctr-torch_amd"))
+import torch
+from deepctr_torch._hip import lib as L
+from deepctr_torch._hip import ops
+
+variants = sys.argv[1:] or ["20"]
+if variants != ["20"] or os.environ.get("DCTR_PROBE_DIAG"):
+    L.use_diag_library()
+lib = L.lib()
+B, F, D, H = int(os.environ.get("B", 4096)), 26, 16, 128
+P = F * (F - 1) // 2
+dev = "cuda:0"
+torch.manual_seed(0)
+meta = ops.BilinearMeta(F, "interaction")
+sched4, pair_w = meta.wide_tables(dev)
+E = torch.randn(B, F, D, device=dev); V = torch.randn(B, F, D, device=dev)
+Wf = torch.randn(P, D, D, device=dev) * 0.3
+gh = torch.randn(B, H, device=dev); W0 = torch.randn(H, 2 * P * D + 13, device=dev) * 0.05
+gE = torch.empty(B, F, D, device=dev); gV = torch.empty_like(gE); gW = torch.empty(P, D, D, device=dev)
+ws = torch.empty(lib.dctr_bilinear_wide_bwd_workspace_floats(B, P), device=dev)
+p = lambda t: ctypes.c_void_p(t.data_ptr())
+def call():
+    L.check(lib.dctr_bilinear_wide_bwd(p(E), F * D, p(V), F * D, p(Wf), p(sched4), sched4.shape[0], p(pair_w), P, P, F, D, B,
+                                       p(gh), H, p(W0), W0.stride(0), H, p(gE), p(gV), p(gW), p(ws),
+                                       L.stream_handle(torch.device(dev))), "wide")
+flop = 2.0 * B * 2 * P * (16 * H + 3 * 256)
+for v in variants:
+    os.environ["DCTR_WIDE_VAR"] = v
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize()
+    n = 30
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        call()
+    b.record(); torch.cuda.synchronize()
+    us = a.elapsed_time(b) * 1e3 / n
+    print("variant %-4s  %8.1f us per call (pack + main + reduce)   %.1f TFLOP/s on the MFMA work" % (v, us, flop / us / 1e6))
