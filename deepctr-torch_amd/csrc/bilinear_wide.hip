@@ -15,21 +15,18 @@
 // step (k_wide_pack: one dwordx4 per lane and 16 hidden units, 1 KB per wave instruction).  The gradient slab is never
 // written or read; the only slab-sized traffic left in the backward is the weight-gradient GEMM's read of P itself.
 //
-// Schedule: groups of four field-disjoint pairs, one per wave, a barrier per group (the rounds of the tournament hold 13
-// pairs at 26 fields: 4 + 4 + 4 + 1 would leave three SIMDs idle for a quarter of every round).  The per-field gradient
-// tiles in LDS are plain read-modify-writes in group order: no float atomics, bit-reproducible.
+// Schedule: groups of eight field-disjoint pairs, one per wave of a 512-thread workgroup, a barrier per group (the
+// rounds of the tournament hold 13 pairs at 26 fields: 8 + 5 would idle three waves in every round).  TWO waves per SIMD:
+// with one, every LDS / memory / vector instruction of a wave is an issue slot its own MFMAs cannot use -- measured 55 %
+// matrix-pipe occupancy with four waves, whatever the order of the instructions.  The per-field gradient tiles in LDS
+// are plain read-modify-writes in group order: no float atomics, bit-reproducible.
 #include "pairwise_tiles.hpp"
 
 namespace {
 
 constexpr int kNQ = 8;          // groups of 16 hidden units: H <= 128
+constexpr int kNW = 8;          // waves per workgroup = pairs per group
 constexpr int kD = 16;          // embedding width of the fused route
-
-inline size_t wide_tile_bytes(int F, int tiles) {
-  int rs = F * kD;
-  rs += (16 - (rs & 31)) & 31;
-  return static_cast<size_t>(tiles) * kSB * rs * sizeof(float);
-}
 
 // W0 [H, ldw] (nn.Linear weight: row h = hidden unit) -> Wpk[kb][q][lane] (dwordx4): component s of lane (g, c) is
 // W0[16 q + 4 g + s][16 kb + c], zero past H.  The MFMA contraction index of step 4 q + s in lane group g is that h.
@@ -75,10 +72,24 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// sched4: [n_groups][4 waves][4] int32 = {i, j, weight index, pair index k}; i = -1: the wave idles in this group.
+// row stride of the LDS tiles: (RS mod 8) == 4 puts the rows 4g + r of the two lane groups g that share an LDS cycle
+// on disjoint bank halves (the 32-mod-16 stride of pairwise.hip leaves every ds_read_b32 of a [4g + r][c] piece 2-way
+// conflicted: 40 % of this kernel's LDS cycles in the first version's counters)
+__device__ __host__ inline int wide_rs(int F) { return F * kD + 4; }
+
+// sched4: [n_groups][8 waves][4] int32 = {i, j, weight index, pair index k}; i = -1: the wave idles in this group.
 // part:   [tiles][P][16][16] per-workgroup partial of gW_k (row e, column d), every (tile, k) written exactly once.
-template <int PD, int VAR = 0>
-__global__ __launch_bounds__(kT) void k_bilinear_bwd_wide(const float* __restrict__ E, int64_t lde,
+//
+// One group of a wave, in issue order (what the first version's variants measured is in the comments):
+//   read-only LDS operands of the pair (x_i twice, x_j)           -- before the long MFMA block: latency hidden
+//   G block: 64 MFMAs; behind the 8 that consume a dwordx4 pair of the ring, the SAME registers are re-loaded for the
+//            next group (in place, one group ahead = ~2 800 cycles): two loads per 256 MFMA cycles -- issuing the 21
+//            loads of a group back to back stalled all four waves of the CU at the same point (-57 us without them)
+//   barrier  -- HERE, not at the end of the group: the previous group's LDS gradient writes drain under the G block
+//            (-32 us without the barrier, -33 without the writes when both sat at the group's end)
+//   gradient tiles' current values (LDS), T / gW / gX_i MFMAs, LDS gradient writes, the partial's stores
+template <int VAR = 0>
+__global__ __launch_bounds__(64 * kNW) void k_bilinear_bwd_wide(const float* __restrict__ E, int64_t lde,
                                                           const float* __restrict__ V, int64_t ldv,
                                                           const float* __restrict__ Wf,
                                                           const int32_t* __restrict__ sched4, int n_groups, int P,
@@ -87,16 +98,18 @@ __global__ __launch_bounds__(kT) void k_bilinear_bwd_wide(const float* __restric
                                                           float* __restrict__ gE, float* __restrict__ gV,
                                                           float* __restrict__ part) {
   extern __shared__ __align__(16) float smem[];
-  const int RS = row_stride(F, kD), W = F * kD;
+  uint64_t k0 = 0, k1 = 0, k2 = 0;
+  if (VAR & 16) k0 = __builtin_amdgcn_s_memtime();
+  const int RS = wide_rs(F), W = F * kD;
   float* xs0 = smem;               // V tile (pass 0: columns [0, 16 P) of the DNN input)
   float* xs1 = xs0 + kSB * RS;     // E tile (pass 1)
   float* gx0 = xs1 + kSB * RS;     // gV
   float* gx1 = gx0 + kSB * RS;     // gE
-  float* tb = gx1 + kSB * RS;      // [4 waves][2 passes][16][17] layout-change scratch (wave-private)
-  int32_t* sch = reinterpret_cast<int32_t*>(tb + 4 * 2 * 16 * 17);   // [n_groups][4][4]
+  float* tb = gx1 + kSB * RS;      // [waves][2 passes][16][17] layout-change scratch (wave-private)
+  int32_t* sch = reinterpret_cast<int32_t*>(tb + kNW * 2 * 16 * 17);   // [n_groups][waves][4]
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * kSB;
-  for (int e = tid; e < 4 * n_groups; e += kT)
+  for (int e = tid; e < kNW * n_groups; e += 64 * kNW)
     *reinterpret_cast<i32x4*>(sch + 4 * e) = *(const DCTR_GLOBAL i32x4*)(sched4 + 4 * e);
   // this lane's A operand of G: gh[b = c][h = 16 q + 4 g + s] (zero past B / H)
   f32x4 ga[kNQ];
@@ -112,85 +125,147 @@ __global__ __launch_bounds__(kT) void k_bilinear_bwd_wide(const float* __restric
     for (int q = 0; q < kNQ; ++q)
       if (!(b < B && 16 * q + 4 * g < H)) ga[q] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  stage_rows(xs0, RS, V, ldv, b0, B, W);
-  stage_rows(xs1, RS, E, lde, b0, B, W);
-  for (int e = tid; e < 2 * kSB * RS; e += kT) gx0[e] = 0.f;
+  if (tid < kT) {                  // (stage_rows deals a tile over kT = 256 threads)
+    stage_rows(xs0, RS, V, ldv, b0, B, W);
+    stage_rows(xs1, RS, E, lde, b0, B, W);
+  }
+  for (int e = tid; e < 2 * kSB * RS; e += 64 * kNW) gx0[e] = 0.f;
   __syncthreads();
   float* tb0 = tb + wv * (2 * 16 * 17);
   float* tb1 = tb0 + 16 * 17;
   auto entry = [&](int gi) {
     PairEnt e;
     const int gc = gi < n_groups ? gi : n_groups - 1;
-    const i32x4 v = *reinterpret_cast<const i32x4*>(sch + 4 * (4 * gc + wv));
+    const i32x4 v = *reinterpret_cast<const i32x4*>(sch + 4 * (kNW * gc + wv));
     e.i = gi < n_groups ? v.x : -1; e.j = v.y; e.wi = v.z; e.k = v.w;
     return e;
   };
-  // ring: the two passes' 16 columns of W0 (8 dwordx4 each) and the pair's own weight tile in both operand layouts
-  f32x4 w0[PD][kNQ], w1[PD][kNQ], wr[PD];
-  float wtr[PD][4];
-  auto issue = [&](int gi, int u) {
-    const PairEnt e = entry(gi);
+  // the two passes' 16 columns of W0 (8 dwordx4 each) and the pair's own weight tile in both operand layouts
+  f32x4 w0[kNQ], w1[kNQ], wr;
+  float wtr[4];
+  auto load_tile = [&](const PairEnt& e) {
+    const float* base = Wf + static_cast<int64_t>(e.wi) * (kD * kD);
+    wr = *(const DCTR_GLOBAL f32x4*)(base + c * kD + 4 * g);                     // W[e = c][d = 4g + s]
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wtr[s] = ldg_f32(base + (4 * g + s) * kD + c);   // W[e = 4g + s][d = c]
+  };
+  {
+    const PairEnt e = entry(0);
     const f32x4* p0 = Wpk + static_cast<int64_t>(e.k) * (kNQ * 64) + lane;
     const f32x4* p1 = Wpk + static_cast<int64_t>(P + e.k) * (kNQ * 64) + lane;
 #pragma unroll
     for (int q = 0; q < kNQ; ++q) {
-      w0[u][q] = *(const DCTR_GLOBAL f32x4*)(p0 + 64 * q);
-      w1[u][q] = *(const DCTR_GLOBAL f32x4*)(p1 + 64 * q);
+      w0[q] = *(const DCTR_GLOBAL f32x4*)(p0 + 64 * q);
+      w1[q] = *(const DCTR_GLOBAL f32x4*)(p1 + 64 * q);
     }
-    const float* base = Wf + static_cast<int64_t>(e.wi) * (kD * kD);
-    wr[u] = *(const DCTR_GLOBAL f32x4*)(base + c * kD + 4 * g);             // W[e = c][d = 4g + s]
-#pragma unroll
-    for (int s = 0; s < 4; ++s) wtr[u][s] = ldg_f32(base + (4 * g + s) * kD + c);   // W[e = 4g + s][d = c]
-  };
-#pragma unroll
-  for (int u = 0; u < PD; ++u) {
-    issue(u, u);
-    __builtin_amdgcn_sched_barrier(0);
+    load_tile(e);
   }
   const int64_t tile = blockIdx.x;
-  auto body = [&](int gi, int u) {
-    const PairEnt en = entry(gi);
-    const bool live = en.i >= 0;
+  // what a group leaves for the next group's MFMA block to finish (the LDS read-modify-writes and the partial's stores)
+  struct Fin {
+    bool live;
+    int oi, oj;            // LDS offsets of the pair's fields: row 4g, columns i * 16 + c / j * 16 + c
+    int64_t ok;            // offset of the pair's partial
+    float gt0[4], gt1[4];  // G (.) t      -> gX_j
+    f32x4 v0, v1;          // (G (.) x_j) W -> gX_i
+    float aw[4];           // gW_k rows 4g + r
+  } fin;
+  fin.live = false;
+  fin.oi = fin.oj = 0;
+  fin.ok = 0;
+  uint64_t tG = 0, tB = 0, tD = 0;     // (VAR & 16: shader cycles in the MFMA block / at the barrier / behind it)
+  // FULL: this wave's pair is live (no branch in the body).  PREV: 1 = fin holds a live pair, 0 = nothing to finish,
+  // 2 = look at fin.live
+  auto group = [&](auto full_tag, auto prev_tag, int gi) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    constexpr int PREV = decltype(prev_tag)::value;
+    const PairEnt en = entry(gi), nx = entry(gi + 1);
+    const bool live = FULL || en.i >= 0;
     const int i = live ? en.i : 0, j = live ? en.j : 0;
-    // every LDS operand of the pair, read before the long MFMA block (an idle wave reads field 0: unused)
+    // (VAR & 32: every group re-reads the first pair's columns -- the same instructions out of the CU's L1)
+    const f32x4* p0 = Wpk + static_cast<int64_t>((VAR & 32) ? 0 : nx.k) * (kNQ * 64) + lane;
+    const f32x4* p1 = Wpk + static_cast<int64_t>((VAR & 32) ? 1 : P + nx.k) * (kNQ * 64) + lane;
+    const bool fin_on = PREV == 1 || (PREV == 2 && fin.live);
+    uint64_t c0 = 0, c1 = 0, c2 = 0;
+    if (VAR & 16) c0 = __builtin_amdgcn_s_memtime();
     f32x4 a[2];
     float xj[2][4], xi[2][4], gj[2][4], gi_[2][4];
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const float* xs = ps ? xs1 : xs0;
-      const float* gx = ps ? gx1 : gx0;
-      a[ps] = *reinterpret_cast<const f32x4*>(xs + c * RS + i * kD + 4 * g);      // x_i[b = c][d = 4g + s]
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        xj[ps][r] = xs[(4 * g + r) * RS + j * kD + c];      // x_j[b = 4g + r][e = c]
-        xi[ps][r] = xs[(4 * g + r) * RS + i * kD + c];      // x_i[b = 4g + r][d = c]
-        gj[ps][r] = gx[(4 * g + r) * RS + j * kD + c];
-        gi_[ps][r] = gx[(4 * g + r) * RS + i * kD + c];
-      }
-    }
-    // G[b = 4g + r][e = c] of both passes: two independent chains of 32
+    // G[b = 4g + r][e = c] of both passes: two independent chains of 32.  Between the MFMAs (8 per step = 256 cycles of
+    // the matrix pipe) everything that does not depend on them issues: the ring's re-loads, the previous pair's LDS
+    // read-modify-writes and stores, this pair's read-only LDS operands
     f32x4 G0 = {0.f, 0.f, 0.f, 0.f}, G1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < kNQ; ++q) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        G0 = mfma16(ga[q][s], w0[u][q][s], G0);
-        G1 = mfma16(ga[q][s], w1[u][q][s], G1);
+        G0 = mfma16(ga[q][s], w0[q][s], G0);
+        G1 = mfma16(ga[q][s], w1[q][s], G1);
       }
-    }
-    const f32x4 wreg = wr[u];
-    float wT[4];
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(VAR & 4)) {
+        w0[q] = *(const DCTR_GLOBAL f32x4*)(p0 + 64 * q);
+        w1[q] = *(const DCTR_GLOBAL f32x4*)(p1 + 64 * q);
+      }
+      if (q == 0 && PREV != 0) {           // (after the previous group's barrier: every older write of these fields is in LDS)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) wT[s] = wtr[u][s];
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(VAR & 4)) issue(gi + PD, u);
-    __builtin_amdgcn_sched_barrier(0);
+        for (int r = 0; r < 4; ++r) {
+          gj[0][r] = gx0[r * RS + fin.oj];
+          gj[1][r] = gx1[r * RS + fin.oj];
+          gi_[0][r] = gx0[r * RS + fin.oi];
+          gi_[1][r] = gx1[r * RS + fin.oi];
+        }
+      }
+      if (q == 2 && PREV != 0 && fin_on && !(VAR & 8)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gx0[r * RS + fin.oj] = gj[0][r] + fin.gt0[r];
+          gx1[r * RS + fin.oj] = gj[1][r] + fin.gt1[r];
+        }
+      }
+      if (q == 3 && PREV != 0 && fin_on && !(VAR & 8)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gx0[r * RS + fin.oi] = gi_[0][r] + fin.v0[r];
+          gx1[r * RS + fin.oi] = gi_[1][r] + fin.v1[r];
+        }
+      }
+      if (q == 4 && PREV != 0 && fin_on && (!(VAR & 2) || fin.aw[0] == 12345.f)) {
+        float* dst = part + fin.ok;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stg_f32(dst + r * kD, fin.aw[r]);
+      }
+      if (q == 5) {                        // read-only LDS operands (an idle wave reads field 0: unused)
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const float* xs = ps ? xs1 : xs0;
+          a[ps] = *reinterpret_cast<const f32x4*>(xs + c * RS + i * kD + 4 * g);      // x_i[b = c][d = 4g + s]
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xj[ps][r] = xs[(4 * g + r) * RS + j * kD + c];  // x_j[b = 4g + r][e = c]
+        }
+      }
+      if (q == 6) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const float* xs = ps ? xs1 : xs0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xi[ps][r] = xs[(4 * g + r) * RS + i * kD + c];  // x_i[b = 4g + r][d = c]
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if ((VAR & 8) && PREV != 0 && gj[0][0] + gj[1][1] + gi_[0][2] + gi_[1][3] + fin.gt0[0] + fin.gt1[1] + fin.v0[2] + fin.v1[3] == 12345.f) gx0[lane] = 1.f;
+    // (an opaque use: the mfma intrinsics are pure, and the compiler otherwise sinks the block's last MFMAs below the
+    // re-loads of their own operands -- overlapping live ranges, a copy at the loop's end that waits for every load)
+    asm volatile("" : "+v"(G0), "+v"(G1));
+    if (VAR & 16) c1 = __builtin_amdgcn_s_memtime();
+    if (!(VAR & 1)) lds_barrier();     // every wave's read-modify-writes of the previous group are in LDS
+    if (VAR & 16) c2 = __builtin_amdgcn_s_memtime();
     // t[b = 4g + r][e = c] = (x_i W^T)
     f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      t0 = mfma16(a[0][s], wreg[s], t0);
-      t1 = mfma16(a[1][s], wreg[s], t1);
+      t0 = mfma16(a[0][s], wr[s], t0);
+      t1 = mfma16(a[1][s], wr[s], t1);
     }
     // u = G (.) x_j in the accumulator layout: the A operand of gW as it is, of gX_i after a transposition in LDS
     float u0[4], u1[4];
@@ -201,11 +276,12 @@ __global__ __launch_bounds__(kT) void k_bilinear_bwd_wide(const float* __restric
       tb0[(4 * g + r) * 17 + c] = u0[r];
       tb1[(4 * g + r) * 17 + c] = u1[r];
     }
-    f32x4 aw = {0.f, 0.f, 0.f, 0.f};       // gW_k[e = 4g + r][d = c], both passes
+    f32x4 aw0 = {0.f, 0.f, 0.f, 0.f}, aw1 = {0.f, 0.f, 0.f, 0.f};       // gW_k[e = 4g + r][d = c], per pass
 #pragma unroll
-    for (int s = 0; s < 4; ++s) aw = mfma16(u0[s], xi[0][s], aw);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) aw = mfma16(u1[s], xi[1][s], aw);
+    for (int s = 0; s < 4; ++s) {
+      aw0 = mfma16(u0[s], xi[0][s], aw0);
+      aw1 = mfma16(u1[s], xi[1][s], aw1);
+    }
     float ua0[4], ua1[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -215,36 +291,78 @@ __global__ __launch_bounds__(kT) void k_bilinear_bwd_wide(const float* __restric
     f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};   // (u W)[b = 4g + r][d = c]
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      v0 = mfma16(ua0[s], wT[s], v0);
-      v1 = mfma16(ua1[s], wT[s], v1);
+      v0 = mfma16(ua0[s], wtr[s], v0);
+      v1 = mfma16(ua1[s], wtr[s], v1);
     }
-    if (live) {
-      if (!(VAR & 8))
+    // the pair's own tile of the next group, into the registers the last MFMAs above have just read (loading them any
+    // earlier makes the loop-carried copy of the old values wait for every load in flight at the loop's head)
+    // (opaque use + compiler-level memory barrier: the loads below are otherwise hoisted above the MFMAs at IR level,
+    // where sched_barrier does not exist)
+    asm volatile("" : "+v"(v0), "+v"(v1) : : "memory");
+    if (!(VAR & 4)) load_tile(nx);
+    __builtin_amdgcn_sched_barrier(0);
+    fin.live = live;
+    fin.oi = 4 * g * RS + i * kD + c;
+    fin.oj = 4 * g * RS + j * kD + c;
+    fin.ok = (tile * P + en.k) * (kD * kD) + (4 * g) * kD + c;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        gx0[(4 * g + r) * RS + j * kD + c] = gj[0][r] + G0[r] * t0[r];
-        gx1[(4 * g + r) * RS + j * kD + c] = gj[1][r] + G1[r] * t1[r];
-        gx0[(4 * g + r) * RS + i * kD + c] = gi_[0][r] + v0[r];
-        gx1[(4 * g + r) * RS + i * kD + c] = gi_[1][r] + v1[r];
-      }
-      float* dst = part + (tile * P + en.k) * (kD * kD) + (4 * g) * kD + c;
-      if (!(VAR & 2) || aw[0] == 12345.f)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) stg_f32(dst + r * kD, aw[r]);
-      if ((VAR & 8) && v0[0] + v1[0] + t0[0] + t1[0] == 12345.f) gx0[lane] = 1.f;
+    for (int r = 0; r < 4; ++r) {
+      fin.gt0[r] = G0[r] * t0[r];
+      fin.gt1[r] = G1[r] * t1[r];
+      fin.aw[r] = aw0[r] + aw1[r];
     }
-    if (!(VAR & 1)) lds_barrier();       // the next group touches other fields' columns of gx
+    fin.v0 = v0;
+    fin.v1 = v1;
+    __builtin_amdgcn_sched_barrier(0);
+    if (VAR & 16) {
+      asm volatile("" : "+v"(fin.v0), "+v"(fin.v1));
+      const uint64_t c3 = __builtin_amdgcn_s_memtime();
+      tG += c1 - c0; tB += c2 - c1; tD += c3 - c2;
+    }
+    if (!(VAR & 1)) lds_barrier();     // (the other half of the waves passes from its MFMA block to this part)
   };
-  for (int gi0 = 0; gi0 < n_groups; gi0 += PD) {
+  // this wave's leading live groups run the branch-free body (a store behind a branch is one the compiler cannot count:
+  // its waits for the ring then fall back to "everything older")
+  int n_live = 0;
+  while (n_live < n_groups && sch[4 * (kNW * n_live + wv)] >= 0) ++n_live;
+  // The two waves of a SIMD run HALF A GROUP APART: between two barriers one is in its MFMA block (64 MFMAs back to
+  // back), the other in the part behind it (24 MFMAs between LDS round trips and dependent vector work).  In step, both
+  // were in the same part at the same time: the matrix pipe 79 % busy in the block, 75 % behind it (phase stamps).
+  // Read-modify-writes of the two halves then never share an interval; each half's four pairs are field-disjoint.
+  if (VAR & 16) k1 = __builtin_amdgcn_s_memtime();
+  if (wv >= kNW / 2 && !(VAR & 1)) lds_barrier();
+  int gi = 0;
+  if (n_live > 0) {
+    group(std::true_type{}, std::integral_constant<int, 0>{}, 0);
+    for (gi = 1; gi < n_live; ++gi) group(std::true_type{}, std::integral_constant<int, 1>{}, gi);
+  }
+  for (; gi < n_groups; ++gi) group(std::false_type{}, std::integral_constant<int, 2>{}, gi);
+  if (VAR & 16) k2 = __builtin_amdgcn_s_memtime();
+  if (wv < kNW / 2 && !(VAR & 1)) lds_barrier();
+  // the last pair's read-modify-writes (after the last group's barriers: the fields' older writes are in LDS)
+  if (fin.live) {
 #pragma unroll
-    for (int u = 0; u < PD; ++u) {
-      if (gi0 + u < n_groups) body(gi0 + u, u);      // (uniform over the workgroup)
-      __builtin_amdgcn_sched_barrier(0);
+    for (int r = 0; r < 4; ++r) {
+      gx0[r * RS + fin.oj] += fin.gt0[r];
+      gx1[r * RS + fin.oj] += fin.gt1[r];
+      gx0[r * RS + fin.oi] += fin.v0[r];
+      gx1[r * RS + fin.oi] += fin.v1[r];
     }
+    float* dst = part + fin.ok;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) stg_f32(dst + r * kD, fin.aw[r]);
+  }
+  __syncthreads();
+  if ((VAR & 16) && lane == 0) {       // per-wave cycle sums, in the first floats of this tile's partials (diagnostics only)
+    float* d = part + tile * P * (kD * kD) + 8 * wv;
+    d[0] = static_cast<float>(tG); d[1] = static_cast<float>(tB); d[2] = static_cast<float>(tD);
+    d[3] = static_cast<float>(n_groups);
+    d[4] = static_cast<float>(k1 - k0); d[5] = static_cast<float>(k2 - k1);
+    d[6] = static_cast<float>(__builtin_amdgcn_s_memtime() - k2);
   }
   // the two gradient tiles leave in dwordx4 pieces (RS and W are multiples of 4)
   const int w4 = W >> 2;
-  for (int e = tid; e < kSB * w4; e += kT) {
+  for (int e = tid; e < kSB * w4; e += 64 * kNW) {
     const int r = e / w4, q = e - r * w4;
     if (b0 + r < B) {
       *(DCTR_GLOBAL f32x4*)(gV + static_cast<int64_t>(b0 + r) * W + 4 * q) =
@@ -307,33 +425,34 @@ extern "C" int dctr_bilinear_wide_bwd(const float* E, int64_t ld_e, const float*
     (void)hipMemsetAsync(gW, 0, sizeof(float) * n_w * kD * kD, s);
     return DCTR_OK;
   }
-  const size_t lds = wide_tile_bytes(F, 4) + 4u * 2 * 16 * 17 * sizeof(float) + static_cast<size_t>(n_groups) * 64;
+  const size_t lds = static_cast<size_t>(4) * kSB * wide_rs(F) * sizeof(float) +
+                     static_cast<size_t>(kNW) * 2 * 16 * 17 * sizeof(float) + static_cast<size_t>(n_groups) * kNW * 16;
   if (lds > 158 * 1024) return DCTR_ENOSUP;
   f32x4* Wpk = reinterpret_cast<f32x4*>(workspace);
   float* part = workspace + wide_pack_floats(P);
   const int KB = 2 * P, tiles = (B + kSB - 1) / kSB;
   k_wide_pack<<<dim3((KB + 3) / 4), dim3(kT), 0, s>>>(W0, ld_w0, H, KB, Wpk);
-#define DCTR_WIDE(...)                                                                                            \
+#define DCTR_WIDE(VAR)                                                                                            \
   do {                                                                                                            \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bilinear_bwd_wide<__VA_ARGS__>),                   \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bilinear_bwd_wide<VAR>),                           \
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                 \
-    k_bilinear_bwd_wide<__VA_ARGS__><<<dim3(tiles), dim3(kT), lds, s>>>(E, ld_e, V, ld_v, Wf, sched4, n_groups, P, \
-                                                                        F, B, gh, ld_gh, H, Wpk, gE, gV, part);   \
+    k_bilinear_bwd_wide<VAR><<<dim3(tiles), dim3(64 * kNW), lds, s>>>(E, ld_e, V, ld_v, Wf, sched4, n_groups, P, F, B, \
+                                                                gh, ld_gh, H, Wpk, gE, gV, part);                 \
   } while (0)
 #ifdef DCTR_DIAG
-  // timing variants (tools/probes/wide_bwd_probe.py; results are wrong for VAR != 0): DCTR_WIDE_VAR = "<PD><VAR>"
+  // timing variants (tools/probes/wide_bwd_probe.py; results are wrong for VAR != 0): DCTR_WIDE_VAR = "2<VAR>"
   const char* e = getenv("DCTR_WIDE_VAR");
-  const int pd = e && e[0] ? e[0] - '0' : 2, var = e && e[0] && e[1] ? atoi(e + 1) : 0;
-  if (pd == 1) DCTR_WIDE(1, 0);
-  else if (pd == 3) DCTR_WIDE(3, 0);
-  else if (var == 1) DCTR_WIDE(2, 1);
-  else if (var == 2) DCTR_WIDE(2, 2);
-  else if (var == 4) DCTR_WIDE(2, 4);
-  else if (var == 8) DCTR_WIDE(2, 8);
-  else if (var == 15) DCTR_WIDE(2, 15);
-  else DCTR_WIDE(2, 0);
+  const int var = e && e[0] && e[1] ? atoi(e + 1) : 0;
+  if (var == 1) DCTR_WIDE(1);
+  else if (var == 2) DCTR_WIDE(2);
+  else if (var == 4) DCTR_WIDE(4);
+  else if (var == 8) DCTR_WIDE(8);
+  else if (var == 15) DCTR_WIDE(15);
+  else if (var == 16) DCTR_WIDE(16);
+  else if (var == 32) DCTR_WIDE(32);
+  else DCTR_WIDE(0);
 #else
-  DCTR_WIDE(2, 0);
+  DCTR_WIDE(0);
 #endif
 #undef DCTR_WIDE
   k_wide_reduce_w<<<dim3(P), dim3(1024), 0, s>>>(part, tiles, P, pair_w, gW);

@@ -351,7 +351,7 @@ class PendingPairs(object):
                 self.meta.n_w == F * (F - 1) // 2 and W0.shape[0] <= 128 and W0.shape[0] % 4 == 0 and
                 W0.shape[1] == self.shape[1] and W0.dtype == torch.float32 and W0.stride(1) == 1 and
                 self.raw.dtype == torch.float32 and
-                4 * 16 * (F * D + 31) * 4 + 4352 + ((F * (F - 1) // 2 + 3) // 4) * 64 <= 158 * 1024)
+                F <= 64 and 4 * 16 * (F * D + 4) * 4 + 8 * 2176 + ((F * (F - 1) // 2) // 4 + 8) * 128 <= 158 * 1024)
 
     def materialize(self):
         from . import ops as _ops

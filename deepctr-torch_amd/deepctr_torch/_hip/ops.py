@@ -830,7 +830,7 @@ def tournament_schedule(F, bilinear_type):
     return rows, n // 2, pair_w, n_w
 
 
-def disjoint_groups(rows, width=4):
+def disjoint_groups(rows, width=8):
     """The pairs of a tournament schedule re-dealt in groups of ``width`` field-disjoint pairs (one per wave of a
     workgroup, a barrier per group): ``[n_groups][width][4]`` rows ``{i, j, w, k}``, ``i = -1`` for an idle entry.
     Greedy over the tournament order -- a round is a perfect matching, so only groups that straddle two rounds have to
@@ -996,11 +996,11 @@ class BilinearMeta(object):
         return self._dev
 
     def wide_tables(self, device):
-        """(sched4 ``[n_groups, 4, 4]`` int32, pair_w) on ``device`` for dctr_bilinear_wide_bwd."""
+        """(groups ``[n_groups, 8, 4]`` int32, pair_w) on ``device`` for dctr_bilinear_wide_bwd."""
         dev = getattr(self, "_wide", None)
         if dev is None or dev[0].device != torch.device(device):
             groups = disjoint_groups(self._rows)
-            self._wide = (torch.tensor(groups, dtype=torch.int32, device=device).reshape(-1, 4, 4).contiguous(),
+            self._wide = (torch.tensor(groups, dtype=torch.int32, device=device).reshape(-1, 8, 4).contiguous(),
                           self.device_tables(device)[1])
         return self._wide
 

@@ -543,7 +543,8 @@ int dctr_bilinear_bwd(const float* E, int64_t ld_e, const float* V, int64_t ld_v
  * produced on the matrix cores where it is consumed, the slab is neither written nor read.
  *   gh     [B, H] at gh + b*ld_gh: gradient at the first layer's pre-activation (after the activation's backward)
  *   W0     [H, >= 2 P D] at W0 + h*ld_w0: the nn.Linear weight; columns [0, P D) belong to V's pairs, [P D, 2 P D) to E's
- *   sched4 [n_groups][4][4] int32 (device): groups of four field-disjoint pairs {i, j, w, k}, i = -1 for an idle entry
+ *   sched4 [n_groups][8][4] int32 (device): groups of eight field-disjoint pairs {i, j, w, k} (one per wave of a
+ *          512-thread workgroup), i = -1 for an idle entry
  *   writes gE, gV [B, F*D] and gW [n_w, D, D]; workspace = dctr_bilinear_wide_bwd_workspace_floats(B, P) floats.
  *   DCTR_ENOSUP unless D == 16, n_w == P (one weight per pair: "interaction"), H <= 128, H % 4 == 0, 16-byte aligned rows. */
 size_t dctr_bilinear_wide_bwd_workspace_floats(int32_t B, int32_t P);

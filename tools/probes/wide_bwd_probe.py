@@ -44,4 +44,13 @@ for v in variants:
         call()
     b.record(); torch.cuda.synchronize()
     us = a.elapsed_time(b) * 1e3 / n
+    if v.endswith("16") and len(v) == 3:      # phase stamps: per-wave cycle sums in the partials' first floats
+        off = lib.dctr_bilinear_wide_bwd_workspace_floats(B, P) - ((B + 15) // 16) * P * 256
+        for t in (0, 100, 255):
+            d = ws[off + t * P * 256: off + t * P * 256 + 64].reshape(8, 8).cpu()
+            ng = float(d[0, 3])
+            print("  tile %3d  cycles per group (MFMA block / barrier / behind it) per wave: " % t +
+                  "  ".join("%d/%d/%d" % (d[w, 0] / ng, d[w, 1] / ng, d[w, 2] / ng) for w in range(8)))
+            print("            whole launch (prologue / loop / behind the loop): " +
+                  "  ".join("%d/%d/%d" % (d[w, 4], d[w, 5], d[w, 6]) for w in (0, 4)))
     print("variant %-4s  %8.1f us per call (pack + main + reduce)   %.1f TFLOP/s on the MFMA work" % (v, us, flop / us / 1e6))
