@@ -10,9 +10,11 @@
 //     gX_j    += G (.) (x_i W_k^T)                          as k_bilinear_bwd_data
 //     gX_i    += (G (.) x_j) W_k
 //     gW_k    += (G (.) x_j)^T x_i                          as k_bilinear_bwd_weight, per-workgroup partials
-// A workgroup owns 16 samples: their gh rows sit in registers as the A operand for the whole launch (32 values per
-// lane), the pair's 16 columns of W0 arrive from L2 through a register ring as the B operand, in a layout packed once per
-// step (k_wide_pack: one dwordx4 per lane and 16 hidden units, 1 KB per wave instruction).  The gradient slab is never
+// A workgroup owns 32 samples of ONE of the two inputs (blockIdx.y: V or E): their gh rows sit in registers as the A
+// operands for the whole launch (2 x 32 values per lane), the pair's 16 columns of W0 arrive from L2 through a register
+// ring as the B operand -- shared by the two 16-sample halves, which halves the L2 stream against one workgroup per 16
+// samples of both inputs (0.68 GB per launch) --, in a layout packed once per step (k_wide_pack: one dwordx4 per lane and
+// 16 hidden units, 1 KB per wave instruction).  The gradient slab is never
 // written or read; the only slab-sized traffic left in the backward is the weight-gradient GEMM's read of P itself.
 //
 // Schedule: groups of eight field-disjoint pairs, one per wave of a 512-thread workgroup, a barrier per group (the
@@ -78,7 +80,7 @@ __device__ __forceinline__ void lds_barrier() {
 __device__ __host__ inline int wide_rs(int F) { return F * kD + 4; }
 
 // sched4: [n_groups][8 waves][4] int32 = {i, j, weight index, pair index k}; i = -1: the wave idles in this group.
-// part:   [tiles][P][16][16] per-workgroup partial of gW_k (row e, column d), every (tile, k) written exactly once.
+// part:   [2 inputs x tiles][P][16][16] per-workgroup partial of gW_k (row e, column d), every one written exactly once.
 //
 // One group of a wave, in issue order (what the first version's variants measured is in the comments):
 //   read-only LDS operands of the pair (x_i twice, x_j)           -- before the long MFMA block: latency hidden
@@ -101,33 +103,86 @@ __global__ __launch_bounds__(64 * kNW) void k_bilinear_bwd_wide(const float* __r
   uint64_t k0 = 0, k1 = 0, k2 = 0;
   if (VAR & 16) k0 = __builtin_amdgcn_s_memtime();
   const int RS = wide_rs(F), W = F * kD;
-  float* xs0 = smem;               // V tile (pass 0: columns [0, 16 P) of the DNN input)
-  float* xs1 = xs0 + kSB * RS;     // E tile (pass 1)
-  float* gx0 = xs1 + kSB * RS;     // gV
-  float* gx1 = gx0 + kSB * RS;     // gE
+  // blockIdx.y: 0 = the V input (columns [0, 16 P) of the DNN input), 1 = the E input (columns [16 P, 32 P))
+  const int pass = blockIdx.y;
+  const float* X = pass ? E : V;
+  const int64_t ldx = pass ? lde : ldv;
+  float* gX = pass ? gE : gV;
+  float* xs0 = smem;               // samples b0 .. b0 + 15
+  float* xs1 = xs0 + kSB * RS;     // samples b0 + 16 .. b0 + 31
+  float* gx0 = xs1 + kSB * RS;     // their gradient tiles
+  float* gx1 = gx0 + kSB * RS;
   float* tb = gx1 + kSB * RS;      // [waves][2 passes][16][17] layout-change scratch (wave-private)
   int32_t* sch = reinterpret_cast<int32_t*>(tb + kNW * 2 * 16 * 17);   // [n_groups][waves][4]
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
-  const int b0 = blockIdx.x * kSB;
+  const int b0 = blockIdx.x * (2 * kSB);
   for (int e = tid; e < kNW * n_groups; e += 64 * kNW)
     *reinterpret_cast<i32x4*>(sch + 4 * e) = *(const DCTR_GLOBAL i32x4*)(sched4 + 4 * e);
-  // this lane's A operand of G: gh[b = c][h = 16 q + 4 g + s] (zero past B / H)
-  f32x4 ga[kNQ];
+  // this lane's A operands of G: gh[b = c (+ 16)][h = 16 q + 4 g + s] (zero past B / H)
+  f32x4 ga0[kNQ], ga1[kNQ];
   {
-    const int b = b0 + c;
-    const float* row = gh + static_cast<int64_t>(b < B ? b : B - 1) * ldgh;
+    const int ba = b0 + c, bb = b0 + kSB + c;
+    const float* rowa = gh + static_cast<int64_t>(ba < B ? ba : B - 1) * ldgh;
+    const float* rowb = gh + static_cast<int64_t>(bb < B ? bb : B - 1) * ldgh;
 #pragma unroll
     for (int q = 0; q < kNQ; ++q) {
       const int h = 16 * q + 4 * g;
-      ga[q] = *(const DCTR_GLOBAL f32x4*)(row + (h < H ? h : 0));
+      ga0[q] = *(const DCTR_GLOBAL f32x4*)(rowa + (h < H ? h : 0));
+      ga1[q] = *(const DCTR_GLOBAL f32x4*)(rowb + (h < H ? h : 0));
     }
 #pragma unroll
-    for (int q = 0; q < kNQ; ++q)
-      if (!(b < B && 16 * q + 4 * g < H)) ga[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < kNQ; ++q) {
+      if (!(ba < B && 16 * q + 4 * g < H)) ga0[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!(bb < B && 16 * q + 4 * g < H)) ga1[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
-  if (tid < kT) {                  // (stage_rows deals a tile over kT = 256 threads)
-    stage_rows(xs0, RS, V, ldv, b0, B, W);
-    stage_rows(xs1, RS, E, lde, b0, B, W);
+  {
+    // each half of the workgroup stages one 16-sample tile (zeros past B): eight UNCONDITIONAL loads per thread in flight
+    // on clamped rows, masked at the LDS write (a predicated load is a branch with its own wait: one round trip each)
+    const int t2 = tid & (kT - 1), half = tid >> 8;
+    float* dst = half ? xs1 : xs0;
+    const int bs = b0 + half * kSB;
+    if ((ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {      // (uniform)
+      const int w4 = W >> 2, n4 = kSB * w4;
+      for (int e0 = t2; e0 < n4; e0 += 8 * kT) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * kT, ec = e < n4 ? e : 0;
+          const int r = ec / w4, q4 = ec - r * w4;
+          const int rr = bs + r < B ? bs + r : B - 1;
+          v[u] = *(const DCTR_GLOBAL f32x4*)(X + static_cast<int64_t>(rr) * ldx + 4 * q4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * kT;
+          if (e < n4) {
+            const int r = e / w4, q4 = e - r * w4;
+            *reinterpret_cast<f32x4*>(dst + r * RS + 4 * q4) = (bs + r < B) ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      }
+    } else {
+      const int n = kSB * W;
+      for (int e0 = t2; e0 < n; e0 += 8 * kT) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * kT, ec = e < n ? e : 0;
+          const int r = ec / W, cc = ec - r * W;
+          const int rr = bs + r < B ? bs + r : B - 1;
+          v[u] = ldg_f32(X + static_cast<int64_t>(rr) * ldx + cc);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * kT;
+          if (e < n) {
+            const int r = e / W, cc = e - r * W;
+            dst[r * RS + cc] = (bs + r < B) ? v[u] : 0.f;
+          }
+        }
+      }
+    }
   }
   for (int e = tid; e < 2 * kSB * RS; e += 64 * kNW) gx0[e] = 0.f;
   __syncthreads();
@@ -140,8 +195,8 @@ __global__ __launch_bounds__(64 * kNW) void k_bilinear_bwd_wide(const float* __r
     e.i = gi < n_groups ? v.x : -1; e.j = v.y; e.wi = v.z; e.k = v.w;
     return e;
   };
-  // the two passes' 16 columns of W0 (8 dwordx4 each) and the pair's own weight tile in both operand layouts
-  f32x4 w0[kNQ], w1[kNQ], wr;
+  // the pair's 16 columns of W0 (8 dwordx4) and the pair's own weight tile in both operand layouts
+  f32x4 w0[kNQ], wr;
   float wtr[4];
   auto load_tile = [&](const PairEnt& e) {
     const float* base = Wf + static_cast<int64_t>(e.wi) * (kD * kD);
@@ -151,16 +206,12 @@ __global__ __launch_bounds__(64 * kNW) void k_bilinear_bwd_wide(const float* __r
   };
   {
     const PairEnt e = entry(0);
-    const f32x4* p0 = Wpk + static_cast<int64_t>(e.k) * (kNQ * 64) + lane;
-    const f32x4* p1 = Wpk + static_cast<int64_t>(P + e.k) * (kNQ * 64) + lane;
+    const f32x4* p0 = Wpk + static_cast<int64_t>(pass * P + e.k) * (kNQ * 64) + lane;
 #pragma unroll
-    for (int q = 0; q < kNQ; ++q) {
-      w0[q] = *(const DCTR_GLOBAL f32x4*)(p0 + 64 * q);
-      w1[q] = *(const DCTR_GLOBAL f32x4*)(p1 + 64 * q);
-    }
+    for (int q = 0; q < kNQ; ++q) w0[q] = *(const DCTR_GLOBAL f32x4*)(p0 + 64 * q);
     load_tile(e);
   }
-  const int64_t tile = blockIdx.x;
+  const int64_t tile = static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x;
   // what a group leaves for the next group's MFMA block to finish (the LDS read-modify-writes and the partial's stores)
   struct Fin {
     bool live;
@@ -183,14 +234,13 @@ __global__ __launch_bounds__(64 * kNW) void k_bilinear_bwd_wide(const float* __r
     const bool live = FULL || en.i >= 0;
     const int i = live ? en.i : 0, j = live ? en.j : 0;
     // (VAR & 32: every group re-reads the first pair's columns -- the same instructions out of the CU's L1)
-    const f32x4* p0 = Wpk + static_cast<int64_t>((VAR & 32) ? 0 : nx.k) * (kNQ * 64) + lane;
-    const f32x4* p1 = Wpk + static_cast<int64_t>((VAR & 32) ? 1 : P + nx.k) * (kNQ * 64) + lane;
+    const f32x4* p0 = Wpk + static_cast<int64_t>((VAR & 32) ? 0 : pass * P + nx.k) * (kNQ * 64) + lane;
     const bool fin_on = PREV == 1 || (PREV == 2 && fin.live);
     uint64_t c0 = 0, c1 = 0, c2 = 0;
     if (VAR & 16) c0 = __builtin_amdgcn_s_memtime();
     f32x4 a[2];
     float xj[2][4], xi[2][4], gj[2][4], gi_[2][4];
-    // G[b = 4g + r][e = c] of both passes: two independent chains of 32.  Between the MFMAs (8 per step = 256 cycles of
+    // G[b = 4g + r][e = c] of both sample halves: two independent chains of 32 over the same B operands.  Between the MFMAs (8 per step = 256 cycles of
     // the matrix pipe) everything that does not depend on them issues: the ring's re-loads, the previous pair's LDS
     // read-modify-writes and stores, this pair's read-only LDS operands
     f32x4 G0 = {0.f, 0.f, 0.f, 0.f}, G1 = {0.f, 0.f, 0.f, 0.f};
@@ -198,14 +248,11 @@ __global__ __launch_bounds__(64 * kNW) void k_bilinear_bwd_wide(const float* __r
     for (int q = 0; q < kNQ; ++q) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        G0 = mfma16(ga[q][s], w0[q][s], G0);
-        G1 = mfma16(ga[q][s], w1[q][s], G1);
+        G0 = mfma16(ga0[q][s], w0[q][s], G0);
+        G1 = mfma16(ga1[q][s], w0[q][s], G1);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (!(VAR & 4)) {
-        w0[q] = *(const DCTR_GLOBAL f32x4*)(p0 + 64 * q);
-        w1[q] = *(const DCTR_GLOBAL f32x4*)(p1 + 64 * q);
-      }
+      if (!(VAR & 4)) w0[q] = *(const DCTR_GLOBAL f32x4*)(p0 + 64 * q);
       if (q == 0 && PREV != 0) {           // (after the previous group's barrier: every older write of these fields is in LDS)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -362,14 +409,11 @@ __global__ __launch_bounds__(64 * kNW) void k_bilinear_bwd_wide(const float* __r
   }
   // the two gradient tiles leave in dwordx4 pieces (RS and W are multiples of 4)
   const int w4 = W >> 2;
-  for (int e = tid; e < kSB * w4; e += 64 * kNW) {
-    const int r = e / w4, q = e - r * w4;
-    if (b0 + r < B) {
-      *(DCTR_GLOBAL f32x4*)(gV + static_cast<int64_t>(b0 + r) * W + 4 * q) =
+  for (int e = tid; e < 2 * kSB * w4; e += 64 * kNW) {
+    const int r = e / w4, q = e - r * w4;      // r < 32: gx1 follows gx0 in LDS
+    if (b0 + r < B)
+      *(DCTR_GLOBAL f32x4*)(gX + static_cast<int64_t>(b0 + r) * W + 4 * q) =
           *reinterpret_cast<const f32x4*>(gx0 + r * RS + 4 * q);
-      *(DCTR_GLOBAL f32x4*)(gE + static_cast<int64_t>(b0 + r) * W + 4 * q) =
-          *reinterpret_cast<const f32x4*>(gx1 + r * RS + 4 * q);
-    }
   }
 }
 
@@ -403,7 +447,7 @@ size_t wide_pack_floats(int P) { return static_cast<size_t>(2) * P * kNQ * 64 * 
 }  // namespace
 
 extern "C" size_t dctr_bilinear_wide_bwd_workspace_floats(int32_t B, int32_t P) {
-  const size_t tiles = static_cast<size_t>((B > 0 ? B : 1) + kSB - 1) / kSB;
+  const size_t tiles = 2 * (static_cast<size_t>((B > 0 ? B : 1) + 2 * kSB - 1) / (2 * kSB));
   return wide_pack_floats(P > 0 ? P : 1) + tiles * (P > 0 ? P : 1) * kD * kD;
 }
 
@@ -430,13 +474,13 @@ extern "C" int dctr_bilinear_wide_bwd(const float* E, int64_t ld_e, const float*
   if (lds > 158 * 1024) return DCTR_ENOSUP;
   f32x4* Wpk = reinterpret_cast<f32x4*>(workspace);
   float* part = workspace + wide_pack_floats(P);
-  const int KB = 2 * P, tiles = (B + kSB - 1) / kSB;
+  const int KB = 2 * P, tiles = (B + 2 * kSB - 1) / (2 * kSB);
   k_wide_pack<<<dim3((KB + 3) / 4), dim3(kT), 0, s>>>(W0, ld_w0, H, KB, Wpk);
 #define DCTR_WIDE(VAR)                                                                                            \
   do {                                                                                                            \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bilinear_bwd_wide<VAR>),                           \
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                 \
-    k_bilinear_bwd_wide<VAR><<<dim3(tiles), dim3(64 * kNW), lds, s>>>(E, ld_e, V, ld_v, Wf, sched4, n_groups, P, F, B, \
+    k_bilinear_bwd_wide<VAR><<<dim3(tiles, 2), dim3(64 * kNW), lds, s>>>(E, ld_e, V, ld_v, Wf, sched4, n_groups, P, F, B, \
                                                                 gh, ld_gh, H, Wpk, gE, gV, part);                 \
   } while (0)
 #ifdef DCTR_DIAG
@@ -455,6 +499,6 @@ extern "C" int dctr_bilinear_wide_bwd(const float* E, int64_t ld_e, const float*
   DCTR_WIDE(0);
 #endif
 #undef DCTR_WIDE
-  k_wide_reduce_w<<<dim3(P), dim3(1024), 0, s>>>(part, tiles, P, pair_w, gW);
+  k_wide_reduce_w<<<dim3(P), dim3(1024), 0, s>>>(part, 2 * tiles, P, pair_w, gW);
   return launch_status();
 }
