@@ -212,37 +212,35 @@ __global__ __launch_bounds__(64 * kNW) void k_bilinear_bwd_wide(const float* __r
     load_tile(e);
   }
   const int64_t tile = static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x;
-  // what a group leaves for the next group's MFMA block to finish (the LDS read-modify-writes and the partial's stores)
-  struct Fin {
-    bool live;
-    int oi, oj;            // LDS offsets of the pair's fields: row 4g, columns i * 16 + c / j * 16 + c
-    int64_t ok;            // offset of the pair's partial
-    float gt0[4], gt1[4];  // G (.) t      -> gX_j
-    f32x4 v0, v1;          // (G (.) x_j) W -> gX_i
-    float aw[4];           // gW_k rows 4g + r
-  } fin;
-  fin.live = false;
-  fin.oi = fin.oj = 0;
-  fin.ok = 0;
   uint64_t tG = 0, tB = 0, tD = 0;     // (VAR & 16: shader cycles in the MFMA block / at the barrier / behind it)
-  // FULL: this wave's pair is live (no branch in the body).  PREV: 1 = fin holds a live pair, 0 = nothing to finish,
-  // 2 = look at fin.live
-  auto group = [&](auto full_tag, auto prev_tag, int gi) {
+  // FULL: this wave's pair is live (no branch in the body: a store behind a branch is one the compiler cannot count, and
+  // its waits for the ring then fall back to "everything older").
+  //
+  // A group of a wave is two parts, and the two waves of a SIMD run HALF A GROUP APART (below): between two barriers one
+  // wave is in part 1, the other in part 2.
+  //   part 1  64 MFMAs back to back (G of both sample halves) and NOTHING else but the ring's re-loads: one dwordx4
+  //           behind every 8 MFMAs, into the registers those 8 have just read (in place, a whole group ahead)
+  //   part 2  everything with latency in it: the pair's LDS operands, T, the transposition of G (.) x_j through LDS,
+  //           gW / gX_i MFMAs, the LDS read-modify-writes of the two fields' gradient rows, the partial's stores, the
+  //           next pair's own weight tile.  24 MFMAs: it ends long before the other wave's part 1 does.
+  // (Measured on the way here, 4 waves in step: matrix pipe 55 % busy whatever the instruction order -- with one wave per
+  // SIMD every LDS / memory / vector instruction is an issue slot its own MFMAs cannot use; 8 waves in step: 79 % in
+  // part 1, 75 % in part 2; the LDS work inside part 1: part 1 at 2 900-3 400 cycles for 2 816 of MFMA.)
+  PairEnt cur = entry(0), nxt = entry(1);
+  auto group = [&](auto full_tag, int gi) {
     constexpr bool FULL = decltype(full_tag)::value;
-    constexpr int PREV = decltype(prev_tag)::value;
-    const PairEnt en = entry(gi), nx = entry(gi + 1);
+    // (VAR & 64: the schedule entries carried in registers from the previous group instead -- measured 3-4 % slower)
+    const PairEnt en = (VAR & 64) ? cur : entry(gi), nx = (VAR & 64) ? nxt : entry(gi + 1);
     const bool live = FULL || en.i >= 0;
     const int i = live ? en.i : 0, j = live ? en.j : 0;
     // (VAR & 32: every group re-reads the first pair's columns -- the same instructions out of the CU's L1)
     const f32x4* p0 = Wpk + static_cast<int64_t>((VAR & 32) ? 0 : pass * P + nx.k) * (kNQ * 64) + lane;
-    const bool fin_on = PREV == 1 || (PREV == 2 && fin.live);
     uint64_t c0 = 0, c1 = 0, c2 = 0;
     if (VAR & 16) c0 = __builtin_amdgcn_s_memtime();
+    // ---- part 1: G[b = 4g + r][e = c] of both sample halves, two independent chains of 32 over the same B operands
+    const int oi = 4 * g * RS + i * kD + c, oj = 4 * g * RS + j * kD + c;
     f32x4 a[2];
     float xj[2][4], xi[2][4], gj[2][4], gi_[2][4];
-    // G[b = 4g + r][e = c] of both sample halves: two independent chains of 32 over the same B operands.  Between the MFMAs (8 per step = 256 cycles of
-    // the matrix pipe) everything that does not depend on them issues: the ring's re-loads, the previous pair's LDS
-    // read-modify-writes and stores, this pair's read-only LDS operands
     f32x4 G0 = {0.f, 0.f, 0.f, 0.f}, G1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < kNQ; ++q) {
@@ -253,60 +251,32 @@ __global__ __launch_bounds__(64 * kNW) void k_bilinear_bwd_wide(const float* __r
       }
       __builtin_amdgcn_sched_barrier(0);
       if (!(VAR & 4)) w0[q] = *(const DCTR_GLOBAL f32x4*)(p0 + 64 * q);
-      if (q == 0 && PREV != 0) {           // (after the previous group's barrier: every older write of these fields is in LDS)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          gj[0][r] = gx0[r * RS + fin.oj];
-          gj[1][r] = gx1[r * RS + fin.oj];
-          gi_[0][r] = gx0[r * RS + fin.oi];
-          gi_[1][r] = gx1[r * RS + fin.oi];
-        }
-      }
-      if (q == 2 && PREV != 0 && fin_on && !(VAR & 8)) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          gx0[r * RS + fin.oj] = gj[0][r] + fin.gt0[r];
-          gx1[r * RS + fin.oj] = gj[1][r] + fin.gt1[r];
-        }
-      }
-      if (q == 3 && PREV != 0 && fin_on && !(VAR & 8)) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          gx0[r * RS + fin.oi] = gi_[0][r] + fin.v0[r];
-          gx1[r * RS + fin.oi] = gi_[1][r] + fin.v1[r];
-        }
-      }
-      if (q == 4 && PREV != 0 && fin_on && (!(VAR & 2) || fin.aw[0] == 12345.f)) {
-        float* dst = part + fin.ok;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) stg_f32(dst + r * kD, fin.aw[r]);
-      }
-      if (q == 5) {                        // read-only LDS operands (an idle wave reads field 0: unused)
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-          const float* xs = ps ? xs1 : xs0;
-          a[ps] = *reinterpret_cast<const f32x4*>(xs + c * RS + i * kD + 4 * g);      // x_i[b = c][d = 4g + s]
-#pragma unroll
-          for (int r = 0; r < 4; ++r) xj[ps][r] = xs[(4 * g + r) * RS + j * kD + c];  // x_j[b = 4g + r][e = c]
-        }
-      }
-      if (q == 6) {
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-          const float* xs = ps ? xs1 : xs0;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) xi[ps][r] = xs[(4 * g + r) * RS + i * kD + c];  // x_i[b = 4g + r][d = c]
-        }
-      }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if ((VAR & 8) && PREV != 0 && gj[0][0] + gj[1][1] + gi_[0][2] + gi_[1][3] + fin.gt0[0] + fin.gt1[1] + fin.v0[2] + fin.v1[3] == 12345.f) gx0[lane] = 1.f;
     // (an opaque use: the mfma intrinsics are pure, and the compiler otherwise sinks the block's last MFMAs below the
     // re-loads of their own operands -- overlapping live ranges, a copy at the loop's end that waits for every load)
     asm volatile("" : "+v"(G0), "+v"(G1));
     if (VAR & 16) c1 = __builtin_amdgcn_s_memtime();
-    if (!(VAR & 1)) lds_barrier();     // every wave's read-modify-writes of the previous group are in LDS
+    if (!(VAR & 1)) lds_barrier();     // the other half of the waves has finished its part 2: its gradient rows are in LDS
     if (VAR & 16) c2 = __builtin_amdgcn_s_memtime();
+    // ---- part 2  (measured and dropped: a raised issue priority for it, 195 against 183 us; the read-only operands
+    // read behind part 1's last MFMAs instead, 18 LDS instructions that lengthen part 1 by 1 000 cycles)
+    if (VAR & 128) __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const float* xs = ps ? xs1 : xs0;
+      const float* gx = ps ? gx1 : gx0;
+      a[ps] = *reinterpret_cast<const f32x4*>(xs + c * RS + i * kD + 4 * g);      // x_i[b = c][d = 4g + s]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xj[ps][r] = xs[r * RS + oj];                     // x_j[b = 4g + r][e = c]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xi[ps][r] = xs[r * RS + oi];                     // x_i[b = 4g + r][d = c]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        gj[ps][r] = gx[r * RS + oj];
+        gi_[ps][r] = gx[r * RS + oi];
+      }
+    }
     // t[b = 4g + r][e = c] = (x_i W^T)
     f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -323,7 +293,7 @@ __global__ __launch_bounds__(64 * kNW) void k_bilinear_bwd_wide(const float* __r
       tb0[(4 * g + r) * 17 + c] = u0[r];
       tb1[(4 * g + r) * 17 + c] = u1[r];
     }
-    f32x4 aw0 = {0.f, 0.f, 0.f, 0.f}, aw1 = {0.f, 0.f, 0.f, 0.f};       // gW_k[e = 4g + r][d = c], per pass
+    f32x4 aw0 = {0.f, 0.f, 0.f, 0.f}, aw1 = {0.f, 0.f, 0.f, 0.f};       // gW_k[e = 4g + r][d = c], per sample half
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       aw0 = mfma16(u0[s], xi[0][s], aw0);
@@ -342,63 +312,52 @@ __global__ __launch_bounds__(64 * kNW) void k_bilinear_bwd_wide(const float* __r
       v1 = mfma16(ua1[s], wtr[s], v1);
     }
     // the pair's own tile of the next group, into the registers the last MFMAs above have just read (loading them any
-    // earlier makes the loop-carried copy of the old values wait for every load in flight at the loop's head)
-    // (opaque use + compiler-level memory barrier: the loads below are otherwise hoisted above the MFMAs at IR level,
-    // where sched_barrier does not exist)
+    // earlier makes the loop-carried copy of the old values wait for every load in flight at the loop's head).  Opaque
+    // use + compiler-level memory barrier: the loads are otherwise hoisted above the MFMAs at IR level, where
+    // sched_barrier does not exist.
     asm volatile("" : "+v"(v0), "+v"(v1) : : "memory");
     if (!(VAR & 4)) load_tile(nx);
     __builtin_amdgcn_sched_barrier(0);
-    fin.live = live;
-    fin.oi = 4 * g * RS + i * kD + c;
-    fin.oj = 4 * g * RS + j * kD + c;
-    fin.ok = (tile * P + en.k) * (kD * kD) + (4 * g) * kD + c;
+    if (live) {
+      if (!(VAR & 8)) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      fin.gt0[r] = G0[r] * t0[r];
-      fin.gt1[r] = G1[r] * t1[r];
-      fin.aw[r] = aw0[r] + aw1[r];
+        for (int r = 0; r < 4; ++r) {
+          gx0[r * RS + oj] = gj[0][r] + G0[r] * t0[r];
+          gx1[r * RS + oj] = gj[1][r] + G1[r] * t1[r];
+          gx0[r * RS + oi] = gi_[0][r] + v0[r];
+          gx1[r * RS + oi] = gi_[1][r] + v1[r];
+        }
+      }
+      float* dst = part + (tile * P + en.k) * (kD * kD) + (4 * g) * kD + c;
+      if (!(VAR & 2) || aw0[0] == 12345.f) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stg_f32(dst + r * kD, aw0[r] + aw1[r]);
+      }
+      if ((VAR & 8) && gj[0][0] + gj[1][1] + gi_[0][2] + gi_[1][3] + t0[0] + t1[1] + v0[2] + v1[3] == 12345.f) gx0[lane] = 1.f;
     }
-    fin.v0 = v0;
-    fin.v1 = v1;
     __builtin_amdgcn_sched_barrier(0);
     if (VAR & 16) {
-      asm volatile("" : "+v"(fin.v0), "+v"(fin.v1));
       const uint64_t c3 = __builtin_amdgcn_s_memtime();
       tG += c1 - c0; tB += c2 - c1; tD += c3 - c2;
     }
-    if (!(VAR & 1)) lds_barrier();     // (the other half of the waves passes from its MFMA block to this part)
+    if (VAR & 128) __builtin_amdgcn_s_setprio(0);
+    if (VAR & 64) {
+      cur = nxt;
+      nxt = entry(gi + 2);
+    }
+    if (!(VAR & 1)) lds_barrier();     // this wave's gradient rows are in LDS; the other half passes to ITS part 2
   };
-  // this wave's leading live groups run the branch-free body (a store behind a branch is one the compiler cannot count:
-  // its waits for the ring then fall back to "everything older")
   int n_live = 0;
   while (n_live < n_groups && sch[4 * (kNW * n_live + wv)] >= 0) ++n_live;
-  // The two waves of a SIMD run HALF A GROUP APART: between two barriers one is in its MFMA block (64 MFMAs back to
-  // back), the other in the part behind it (24 MFMAs between LDS round trips and dependent vector work).  In step, both
-  // were in the same part at the same time: the matrix pipe 79 % busy in the block, 75 % behind it (phase stamps).
-  // Read-modify-writes of the two halves then never share an interval; each half's four pairs are field-disjoint.
   if (VAR & 16) k1 = __builtin_amdgcn_s_memtime();
+  // half a group apart: read-modify-writes of the two halves never share an interval between two barriers, and each
+  // half's four pairs are field-disjoint
   if (wv >= kNW / 2 && !(VAR & 1)) lds_barrier();
   int gi = 0;
-  if (n_live > 0) {
-    group(std::true_type{}, std::integral_constant<int, 0>{}, 0);
-    for (gi = 1; gi < n_live; ++gi) group(std::true_type{}, std::integral_constant<int, 1>{}, gi);
-  }
-  for (; gi < n_groups; ++gi) group(std::false_type{}, std::integral_constant<int, 2>{}, gi);
+  for (; gi < n_live; ++gi) group(std::true_type{}, gi);
+  for (; gi < n_groups; ++gi) group(std::false_type{}, gi);
   if (VAR & 16) k2 = __builtin_amdgcn_s_memtime();
   if (wv < kNW / 2 && !(VAR & 1)) lds_barrier();
-  // the last pair's read-modify-writes (after the last group's barriers: the fields' older writes are in LDS)
-  if (fin.live) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      gx0[r * RS + fin.oj] += fin.gt0[r];
-      gx1[r * RS + fin.oj] += fin.gt1[r];
-      gx0[r * RS + fin.oi] += fin.v0[r];
-      gx1[r * RS + fin.oi] += fin.v1[r];
-    }
-    float* dst = part + fin.ok;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) stg_f32(dst + r * kD, fin.aw[r]);
-  }
   __syncthreads();
   if ((VAR & 16) && lane == 0) {       // per-wave cycle sums, in the first floats of this tile's partials (diagnostics only)
     float* d = part + tile * P * (kD * kD) + 8 * wv;
@@ -494,6 +453,8 @@ extern "C" int dctr_bilinear_wide_bwd(const float* E, int64_t ld_e, const float*
   else if (var == 15) DCTR_WIDE(15);
   else if (var == 16) DCTR_WIDE(16);
   else if (var == 32) DCTR_WIDE(32);
+  else if (var == 64) DCTR_WIDE(64);
+  else if (var == 128) DCTR_WIDE(128);
   else DCTR_WIDE(0);
 #else
   DCTR_WIDE(0);

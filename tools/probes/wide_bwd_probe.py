@@ -32,6 +32,9 @@ def call():
                                        p(gh), H, p(W0), W0.stride(0), H, p(gE), p(gV), p(gW), p(ws),
                                        L.stream_handle(torch.device(dev))), "wide")
 flop = 2.0 * B * 2 * P * (16 * H + 3 * 256)
+for _ in range(40):           # (clocks settle: the first variant timed was 10 % slow otherwise)
+    call()
+torch.cuda.synchronize()
 for v in variants:
     os.environ["DCTR_WIDE_VAR"] = v
     for _ in range(3):
