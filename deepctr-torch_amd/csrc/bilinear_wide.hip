@@ -90,7 +90,10 @@ __device__ __host__ inline int wide_rs(int F) { return F * kD + 4; }
 //   barrier  -- HERE, not at the end of the group: the previous group's LDS gradient writes drain under the G block
 //            (-32 us without the barrier, -33 without the writes when both sat at the group's end)
 //   gradient tiles' current values (LDS), T / gW / gX_i MFMAs, LDS gradient writes, the partial's stores
-template <int VAR = 0>
+// FC: the field count as a compile-time constant (0: read F).  With it every LDS address of a group is one of two
+// per-lane registers (the pair's i / j column) plus an immediate; without, the row and tile offsets are vector adds --
+// 51 of the 83 vector instructions of part 2, each of which waits for a slot between the other wave's MFMAs.
+template <int VAR = 0, int FC = 0>
 __global__ __launch_bounds__(64 * kNW) void k_bilinear_bwd_wide(const float* __restrict__ E, int64_t lde,
                                                           const float* __restrict__ V, int64_t ldv,
                                                           const float* __restrict__ Wf,
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(64 * kNW) void k_bilinear_bwd_wide(const float* __r
   extern __shared__ __align__(16) float smem[];
   uint64_t k0 = 0, k1 = 0, k2 = 0;
   if (VAR & 16) k0 = __builtin_amdgcn_s_memtime();
-  const int RS = wide_rs(F), W = F * kD;
+  const int RS = FC ? wide_rs(FC) : wide_rs(F), W = FC ? FC * kD : F * kD;
   // blockIdx.y: 0 = the V input (columns [0, 16 P) of the DNN input), 1 = the E input (columns [16 P, 32 P))
   const int pass = blockIdx.y;
   const float* X = pass ? E : V;
@@ -435,31 +438,34 @@ extern "C" int dctr_bilinear_wide_bwd(const float* E, int64_t ld_e, const float*
   float* part = workspace + wide_pack_floats(P);
   const int KB = 2 * P, tiles = (B + 2 * kSB - 1) / (2 * kSB);
   k_wide_pack<<<dim3((KB + 3) / 4), dim3(kT), 0, s>>>(W0, ld_w0, H, KB, Wpk);
+#define DCTR_WIDE_F(VAR, FC)                                                                                      \
+  do {                                                                                                            \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bilinear_bwd_wide<VAR, FC>),                       \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                 \
+    k_bilinear_bwd_wide<VAR, FC><<<dim3(tiles, 2), dim3(64 * kNW), lds, s>>>(E, ld_e, V, ld_v, Wf, sched4, n_groups, P, F, \
+                                                                    B, gh, ld_gh, H, Wpk, gE, gV, part);          \
+  } while (0)
+  // (26 fields: the Criteo shape of BASELINE.json; any other count takes the same kernel with F read at run time)
 #define DCTR_WIDE(VAR)                                                                                            \
   do {                                                                                                            \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bilinear_bwd_wide<VAR>),                           \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                 \
-    k_bilinear_bwd_wide<VAR><<<dim3(tiles, 2), dim3(64 * kNW), lds, s>>>(E, ld_e, V, ld_v, Wf, sched4, n_groups, P, F, B, \
-                                                                gh, ld_gh, H, Wpk, gE, gV, part);                 \
+    if (F == 26 && !fc_off) DCTR_WIDE_F(VAR, 26);                                                                 \
+    else DCTR_WIDE_F(VAR, 0);                                                                                     \
   } while (0)
+  bool fc_off = false;
 #ifdef DCTR_DIAG
-  // timing variants (tools/probes/wide_bwd_probe.py; results are wrong for VAR != 0): DCTR_WIDE_VAR = "2<VAR>"
+  // timing variants (tools/probes/wide_bwd_probe.py; results are wrong for VAR != 0): DCTR_WIDE_VAR = "2<VAR>",
+  // "1<VAR>" = the same with F read at run time
   const char* e = getenv("DCTR_WIDE_VAR");
+  fc_off = e && e[0] == '1';
   const int var = e && e[0] && e[1] ? atoi(e + 1) : 0;
-  if (var == 1) DCTR_WIDE(1);
-  else if (var == 2) DCTR_WIDE(2);
-  else if (var == 4) DCTR_WIDE(4);
-  else if (var == 8) DCTR_WIDE(8);
-  else if (var == 15) DCTR_WIDE(15);
-  else if (var == 16) DCTR_WIDE(16);
-  else if (var == 32) DCTR_WIDE(32);
-  else if (var == 64) DCTR_WIDE(64);
-  else if (var == 128) DCTR_WIDE(128);
+  if (var == 15) DCTR_WIDE(15);        // (every other single variant was measured while the kernel was built:
+  else if (var == 16) DCTR_WIDE(16);   //  profiles/r06_bilinear_wide_variants.txt; instantiate them here to repeat that)
   else DCTR_WIDE(0);
 #else
   DCTR_WIDE(0);
 #endif
 #undef DCTR_WIDE
+#undef DCTR_WIDE_F
   k_wide_reduce_w<<<dim3(P), dim3(1024), 0, s>>>(part, 2 * tiles, P, pair_w, gW);
   return launch_status();
 }
