@@ -256,36 +256,42 @@ __global__ __launch_bounds__(64 * kNW) void k_bilinear_bwd_wide(const float* __r
       if (!(VAR & 4)) w0[q] = *(const DCTR_GLOBAL f32x4*)(p0 + 64 * q);
       __builtin_amdgcn_sched_barrier(0);
     }
+    // t[b = 4g + r][e = c] = (x_i W^T): needs nothing of G and nothing behind the barrier -- 8 more MFMAs for this part,
+    // one LDS round trip and 8 dependent MFMAs less for the long part 2
+    a[0] = *reinterpret_cast<const f32x4*>(xs0 + c * RS + i * kD + 4 * g);      // x_i[b = c][d = 4g + s]
+    a[1] = *reinterpret_cast<const f32x4*>(xs1 + c * RS + i * kD + 4 * g);
+    f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      t0 = mfma16(a[0][s], wr[s], t0);
+      t1 = mfma16(a[1][s], wr[s], t1);
+    }
     // (an opaque use: the mfma intrinsics are pure, and the compiler otherwise sinks the block's last MFMAs below the
     // re-loads of their own operands -- overlapping live ranges, a copy at the loop's end that waits for every load)
-    asm volatile("" : "+v"(G0), "+v"(G1));
+    asm volatile("" : "+v"(G0), "+v"(G1), "+v"(t0), "+v"(t1));
     if (VAR & 16) c1 = __builtin_amdgcn_s_memtime();
     if (!(VAR & 1)) lds_barrier();     // the other half of the waves has finished its part 2: its gradient rows are in LDS
     if (VAR & 16) c2 = __builtin_amdgcn_s_memtime();
     // ---- part 2  (measured and dropped: a raised issue priority for it, 195 against 183 us; the read-only operands
     // read behind part 1's last MFMAs instead, 18 LDS instructions that lengthen part 1 by 1 000 cycles)
     if (VAR & 128) __builtin_amdgcn_s_setprio(3);
+    // LDS reads in the order of need: x_j (for u, whose transposition is the longest chain), x_i (gW), the gradient rows
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const float* xs = ps ? xs1 : xs0;
-      const float* gx = ps ? gx1 : gx0;
-      a[ps] = *reinterpret_cast<const f32x4*>(xs + c * RS + i * kD + 4 * g);      // x_i[b = c][d = 4g + s]
-#pragma unroll
-      for (int r = 0; r < 4; ++r) xj[ps][r] = xs[r * RS + oj];                     // x_j[b = 4g + r][e = c]
-#pragma unroll
-      for (int r = 0; r < 4; ++r) xi[ps][r] = xs[r * RS + oi];                     // x_i[b = 4g + r][d = c]
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        gj[ps][r] = gx[r * RS + oj];
-        gi_[ps][r] = gx[r * RS + oi];
-      }
+    for (int r = 0; r < 4; ++r) {
+      xj[0][r] = xs0[r * RS + oj];                     // x_j[b = 4g + r][e = c]
+      xj[1][r] = xs1[r * RS + oj];
     }
-    // t[b = 4g + r][e = c] = (x_i W^T)
-    f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      t0 = mfma16(a[0][s], wr[s], t0);
-      t1 = mfma16(a[1][s], wr[s], t1);
+    for (int r = 0; r < 4; ++r) {
+      xi[0][r] = xs0[r * RS + oi];                     // x_i[b = 4g + r][d = c]
+      xi[1][r] = xs1[r * RS + oi];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      gj[0][r] = gx0[r * RS + oj];
+      gj[1][r] = gx1[r * RS + oj];
+      gi_[0][r] = gx0[r * RS + oi];
+      gi_[1][r] = gx1[r * RS + oi];
     }
     // u = G (.) x_j in the accumulator layout: the A operand of gW as it is, of gX_i after a transposition in LDS
     float u0[4], u1[4];
