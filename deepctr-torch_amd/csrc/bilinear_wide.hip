@@ -32,6 +32,9 @@ constexpr int kD = 16;          // embedding width of the fused route
 
 // W0 [H, ldw] (nn.Linear weight: row h = hidden unit) -> Wpk[kb][q][lane] (dwordx4): component s of lane (g, c) is
 // W0[16 q + 4 g + s][16 kb + c], zero past H.  The MFMA contraction index of step 4 q + s in lane group g is that h.
+// FWD: the forward's layout instead -- component s of lane (g, c) of piece (kb, nb) is W0[16 nb + c][16 kb + 4 g + s]
+// (B operand of y[b][h] += sum_e p[b][e] W0[h][16 kb + e] with the contraction index e = 4 g + s).
+template <bool FWD>
 __global__ __launch_bounds__(kT) void k_wide_pack(const float* __restrict__ W0, int64_t ldw, int H, int KB,
                                                   f32x4* __restrict__ Wpk) {
   __shared__ float t[16 * kNQ][65];
@@ -60,10 +63,17 @@ __global__ __launch_bounds__(kT) void k_wide_pack(const float* __restrict__ W0, 
     const int g = lane >> 4, c = lane & 15;
     if (kb0 + kbl < KB) {
       f32x4 v;
-      v.x = t[16 * q + 4 * g + 0][kbl * 16 + c];
-      v.y = t[16 * q + 4 * g + 1][kbl * 16 + c];
-      v.z = t[16 * q + 4 * g + 2][kbl * 16 + c];
-      v.w = t[16 * q + 4 * g + 3][kbl * 16 + c];
+      if (FWD) {
+        v.x = t[16 * q + c][kbl * 16 + 4 * g + 0];
+        v.y = t[16 * q + c][kbl * 16 + 4 * g + 1];
+        v.z = t[16 * q + c][kbl * 16 + 4 * g + 2];
+        v.w = t[16 * q + c][kbl * 16 + 4 * g + 3];
+      } else {
+        v.x = t[16 * q + 4 * g + 0][kbl * 16 + c];
+        v.y = t[16 * q + 4 * g + 1][kbl * 16 + c];
+        v.z = t[16 * q + 4 * g + 2][kbl * 16 + c];
+        v.w = t[16 * q + 4 * g + 3][kbl * 16 + c];
+      }
       *(DCTR_GLOBAL f32x4*)(Wpk + (static_cast<int64_t>(kb0 + kbl) * kNQ + q) * 64 + lane) = v;
     }
   }
@@ -385,6 +395,221 @@ __global__ __launch_bounds__(64 * kNW) void k_bilinear_bwd_wide(const float* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Forward: h = act(W0 [ pairs(V) | pairs(E) | dense ] + b0) with the pairs made where they are consumed.
+//   t^T[e][b] = sum_d W_k[e][d] x_i[b][d]     (A = the weight tile, B = x_i: the product lands in the A-operand layout
+//   p[b][e]   = t[b][e] x_j[b][e]              of the next MFMA -- lane (g, c) holds p[b = c][e = 4g + s] -- no transposition)
+//   y[b][h]  += sum_e p[b][e] W0[h][16 k + e]  8 column blocks x 4 steps x 2 inputs = 64 MFMAs per pair
+// A workgroup owns 16 samples, a wave every eighth pair (output order) and its own partial y [16, 128] in registers; the
+// eight partials meet once, in LDS, in wave order (fixed order: bit-reproducible).  No barrier and no LDS write inside
+// the pair loop: the two waves of a SIMD drift apart by themselves.  The product slab x is still WRITTEN (one dwordx4
+// per lane, pair and input) for the weight gradient's GEMM of the backward -- but never read by this launch, and the
+// [B, 10 413] x [10 413, 128] library GEMM of the forward is gone.
+template <int FC>
+__global__ __launch_bounds__(64 * kNW) void k_bilinear_fwd_wide(const float* __restrict__ E, int64_t lde,
+                                                                const float* __restrict__ V, int64_t ldv,
+                                                                const float* __restrict__ Wf,
+                                                                const int32_t* __restrict__ sched_k, int P, int F, int B,
+                                                                const f32x4* __restrict__ Wpk,
+                                                                const float* __restrict__ dense, int64_t ldd, int n_dense,
+                                                                float* __restrict__ x, int64_t ldx,
+                                                                float* __restrict__ ypart, int Bp) {
+  extern __shared__ __align__(16) float smem[];
+  const int RS = FC ? wide_rs(FC) : wide_rs(F), W = FC ? FC * kD : F * kD;
+  // blockIdx.y: 0 = the V input (columns [0, 16 P) of the DNN input), 1 = the E input (columns [16 P, 32 P))
+  const int pass = blockIdx.y;
+  const float* X = pass ? E : V;
+  const int64_t ldq = pass ? lde : ldv;
+  float* xs0 = smem;               // samples b0 .. b0 + 15
+  float* xs1 = xs0 + kSB * RS;     // samples b0 + 16 .. b0 + 31
+  int32_t* sch = reinterpret_cast<int32_t*>(xs1 + kSB * RS);   // [P][4] = {i, j, weight index, k}
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int b0 = blockIdx.x * (2 * kSB);
+  for (int e = tid; e < P; e += 64 * kNW)
+    *reinterpret_cast<i32x4*>(sch + 4 * e) = *(const DCTR_GLOBAL i32x4*)(sched_k + 4 * e);
+  {
+    const int t2 = tid & (kT - 1), half = tid >> 8;
+    float* dst = half ? xs1 : xs0;
+    const int bs = b0 + half * kSB;
+    if ((ldq & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {      // (uniform)
+      const int w4 = W >> 2, n4 = kSB * w4;
+      for (int e0 = t2; e0 < n4; e0 += 8 * kT) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * kT, ec = e < n4 ? e : 0;
+          const int r = ec / w4, q4 = ec - r * w4;
+          const int rr = bs + r < B ? bs + r : B - 1;
+          v[u] = *(const DCTR_GLOBAL f32x4*)(X + static_cast<int64_t>(rr) * ldq + 4 * q4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * kT;
+          if (e < n4) {
+            const int r = e / w4, q4 = e - r * w4;
+            *reinterpret_cast<f32x4*>(dst + r * RS + 4 * q4) = (bs + r < B) ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      }
+    } else {
+      const int n = kSB * W;
+      for (int e0 = t2; e0 < n; e0 += 8 * kT) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * kT, ec = e < n ? e : 0;
+          const int r = ec / W, cc = ec - r * W;
+          const int rr = bs + r < B ? bs + r : B - 1;
+          v[u] = ldg_f32(X + static_cast<int64_t>(rr) * ldq + cc);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * kT;
+          if (e < n) {
+            const int r = e / W, cc = e - r * W;
+            dst[r * RS + cc] = (bs + r < B) ? v[u] : 0.f;
+          }
+        }
+      }
+    }
+  }
+  // the dense columns of the DNN input (fibinet.py:86-87): copied behind the pairs (by the V launch row)
+  if (dense && pass == 0)
+    for (int e = tid; e < 2 * kSB * n_dense; e += 64 * kNW) {
+      const int r = e / n_dense, q = e - r * n_dense;
+      if (b0 + r < B)
+        stg_f32(x + static_cast<int64_t>(b0 + r) * ldx + 2 * P * kD + q, ldg_f32(dense + static_cast<int64_t>(b0 + r) * ldd + q));
+    }
+  __syncthreads();
+  const int npw = wv < P ? (P - 1 - wv) / kNW + 1 : 0;      // this wave's pairs: k = wv, wv + 8, ...
+  auto entry = [&](int m) {
+    const int k = wv + kNW * (m < npw ? m : (npw > 0 ? npw - 1 : 0));
+    const i32x4 v = *reinterpret_cast<const i32x4*>(sch + 4 * (k < P ? k : 0));
+    PairEnt e;
+    e.i = v.x; e.j = v.y; e.wi = v.z; e.k = v.w;
+    return e;
+  };
+  // ring: the pair's 16 columns of W0 (8 dwordx4, shared by the two sample halves), the pair's own weight tile as an A operand
+  f32x4 w0[kNQ], wr;
+  f32x4 y0[kNQ], y1[kNQ];
+#pragma unroll
+  for (int q = 0; q < kNQ; ++q) y0[q] = y1[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (npw > 0) {
+    PairEnt en = entry(0);
+    {
+      const f32x4* p0 = Wpk + static_cast<int64_t>(pass * P + en.k) * (kNQ * 64) + lane;
+#pragma unroll
+      for (int q = 0; q < kNQ; ++q) w0[q] = *(const DCTR_GLOBAL f32x4*)(p0 + 64 * q);
+      wr = *(const DCTR_GLOBAL f32x4*)(Wf + static_cast<int64_t>(en.wi) * (kD * kD) + c * kD + 4 * g);   // W[e = c][d = 4g + s]
+    }
+    // x_i as the B operand (x_i[b = c][d = 4g + s]) and x_j in the A-operand layout of the product (x_j[b = c][e = 4g + s])
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(xs0 + c * RS + en.i * kD + 4 * g);
+    f32x4 a1 = *reinterpret_cast<const f32x4*>(xs1 + c * RS + en.i * kD + 4 * g);
+    f32x4 j0 = *reinterpret_cast<const f32x4*>(xs0 + c * RS + en.j * kD + 4 * g);
+    f32x4 j1 = *reinterpret_cast<const f32x4*>(xs1 + c * RS + en.j * kD + 4 * g);
+    f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};     // t^T[e = 4g + r][b = c]
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      t0 = mfma16(wr[s], a0[s], t0);
+      t1 = mfma16(wr[s], a1[s], t1);
+    }
+    f32x4 pa = t0 * j0, pb = t1 * j1;
+    // One pair of a wave: 64 MFMAs into y in four steps of two column blocks x two sample halves (an accumulator is hit
+    // every fourth MFMA); between the steps, in the shadow of the matrix pipe: the ring's re-loads in place, and the
+    // NEXT pair's products -- its LDS operands after step 0, its 8 MFMAs after step 1, its two multiplies after step 2.
+    for (int m = 0; m < npw; ++m) {
+      const PairEnt nx = entry(m + 1);
+      const f32x4* p0 = Wpk + static_cast<int64_t>(pass * P + nx.k) * (kNQ * 64) + lane;
+      // the pair's pieces of the DNN input, for the backward's weight-gradient GEMM.  Unconditional: x holds whole
+      // 32-row tiles (rows past B receive zeros) -- a store behind a branch is one the compiler cannot count, and its
+      // waits for the ring then fall back to "everything older"
+      {
+        float* row = x + static_cast<int64_t>(b0 + c) * ldx + (static_cast<int64_t>(pass) * P + en.k) * kD + 4 * g;
+        *(DCTR_GLOBAL f32x4*)row = pa;
+        *(DCTR_GLOBAL f32x4*)(row + kSB * ldx) = pb;
+      }
+      wr = *(const DCTR_GLOBAL f32x4*)(Wf + static_cast<int64_t>(nx.wi) * (kD * kD) + c * kD + 4 * g);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 pan = pa, pbn = pb;
+#pragma unroll
+      for (int q = 0; q < kNQ; q += 2) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          y0[q] = mfma16(pa[s], w0[q][s], y0[q]);
+          y1[q] = mfma16(pb[s], w0[q][s], y1[q]);
+          y0[q + 1] = mfma16(pa[s], w0[q + 1][s], y0[q + 1]);
+          y1[q + 1] = mfma16(pb[s], w0[q + 1][s], y1[q + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        w0[q] = *(const DCTR_GLOBAL f32x4*)(p0 + 64 * q);
+        w0[q + 1] = *(const DCTR_GLOBAL f32x4*)(p0 + 64 * (q + 1));
+        if (q == 0) {
+          a0 = *reinterpret_cast<const f32x4*>(xs0 + c * RS + nx.i * kD + 4 * g);
+          a1 = *reinterpret_cast<const f32x4*>(xs1 + c * RS + nx.i * kD + 4 * g);
+          j0 = *reinterpret_cast<const f32x4*>(xs0 + c * RS + nx.j * kD + 4 * g);
+          j1 = *reinterpret_cast<const f32x4*>(xs1 + c * RS + nx.j * kD + 4 * g);
+        }
+        if (q == 2) {
+          t0 = f32x4{0.f, 0.f, 0.f, 0.f};
+          t1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            t0 = mfma16(wr[s], a0[s], t0);
+            t1 = mfma16(wr[s], a1[s], t1);
+          }
+        }
+        if (q == 4) {
+          pan = t0 * j0;
+          pbn = t1 * j1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("" : "+v"(y0[0]), "+v"(y0[1]), "+v"(y0[2]), "+v"(y0[3]), "+v"(y0[4]), "+v"(y0[5]), "+v"(y0[6]), "+v"(y0[7]));
+      asm volatile("" : "+v"(y1[0]), "+v"(y1[1]), "+v"(y1[2]), "+v"(y1[3]), "+v"(y1[4]), "+v"(y1[5]), "+v"(y1[6]), "+v"(y1[7]));
+      en = nx;
+      pa = pan;
+      pb = pbn;
+    }
+  }
+  __syncthreads();                 // every wave is done with the row tiles: their LDS becomes the partials' meeting place
+  float* red = smem;               // [waves][32][128 + 4]
+  constexpr int RP = 16 * kNQ + 4;
+#pragma unroll
+  for (int q = 0; q < kNQ; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[(wv * 2 * kSB + 4 * g + r) * RP + 16 * q + c] = y0[q][r];
+      red[(wv * 2 * kSB + kSB + 4 * g + r) * RP + 16 * q + c] = y1[q][r];
+    }
+  __syncthreads();
+  // this input's share of the pre-activation, waves in order (fixed order); k_wide_fwd_finish adds the two inputs' shares
+  for (int o = tid; o < 2 * kSB * 16 * kNQ; o += 64 * kNW) {
+    const int b = o / (16 * kNQ), h = o - b * (16 * kNQ);
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < kNW; ++w) v += red[(w * 2 * kSB + b) * RP + h];
+    if (b0 + b < Bp) stg_f32(ypart + (static_cast<int64_t>(pass) * Bp + b0 + b) * (16 * kNQ) + h, v);
+  }
+}
+
+// h = act((share of V's pairs + share of E's pairs) + dense columns + bias)
+__global__ __launch_bounds__(kT) void k_wide_fwd_finish(const float* __restrict__ ypart, int Bp, int B, int H,
+                                                        const float* __restrict__ dense, int64_t ldd, int n_dense,
+                                                        const float* __restrict__ W0, int64_t ldw0, int dense_col,
+                                                        const float* __restrict__ b0v, int relu,
+                                                        float* __restrict__ hout, int64_t ldh) {
+  const int64_t o = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+  const int b = static_cast<int>(o / (16 * kNQ)), h = static_cast<int>(o - static_cast<int64_t>(b) * (16 * kNQ));
+  if (b >= B || h >= H) return;
+  float v = ldg_f32(ypart + static_cast<int64_t>(b) * (16 * kNQ) + h) +
+            ldg_f32(ypart + (static_cast<int64_t>(Bp) + b) * (16 * kNQ) + h);
+  for (int q = 0; q < n_dense; ++q)
+    v += ldg_f32(dense + static_cast<int64_t>(b) * ldd + q) * ldg_f32(W0 + static_cast<int64_t>(h) * ldw0 + dense_col + q);
+  if (b0v) v += ldg_f32(b0v + h);
+  if (relu) v = v > 0.f ? v : 0.f;
+  stg_f32(hout + static_cast<int64_t>(b) * ldh + h, v);
+}
+
 // gW[pair_w[k]] = sum over the tiles' partials of pair k, fixed order: four slices of the tiles per workgroup, each
 // lane 16 loads in flight, the slices combined in slice order.  (One weight per pair: the "interaction" type.)
 __global__ __launch_bounds__(1024) void k_wide_reduce_w(const float* __restrict__ part, int tiles, int P,
@@ -443,7 +668,7 @@ extern "C" int dctr_bilinear_wide_bwd(const float* E, int64_t ld_e, const float*
   f32x4* Wpk = reinterpret_cast<f32x4*>(workspace);
   float* part = workspace + wide_pack_floats(P);
   const int KB = 2 * P, tiles = (B + 2 * kSB - 1) / (2 * kSB);
-  k_wide_pack<<<dim3((KB + 3) / 4), dim3(kT), 0, s>>>(W0, ld_w0, H, KB, Wpk);
+  k_wide_pack<false><<<dim3((KB + 3) / 4), dim3(kT), 0, s>>>(W0, ld_w0, H, KB, Wpk);
 #define DCTR_WIDE_F(VAR, FC)                                                                                      \
   do {                                                                                                            \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bilinear_bwd_wide<VAR, FC>),                       \
@@ -473,5 +698,48 @@ extern "C" int dctr_bilinear_wide_bwd(const float* E, int64_t ld_e, const float*
 #undef DCTR_WIDE
 #undef DCTR_WIDE_F
   k_wide_reduce_w<<<dim3(P), dim3(1024), 0, s>>>(part, 2 * tiles, P, pair_w, gW);
+  return launch_status();
+}
+
+extern "C" size_t dctr_bilinear_wide_fwd_workspace_floats(int32_t B, int32_t P) {
+  const size_t Bp = (static_cast<size_t>(B > 0 ? B : 1) + 2 * kSB - 1) / (2 * kSB) * (2 * kSB);
+  return wide_pack_floats(P > 0 ? P : 1) + 2 * Bp * 16 * kNQ;
+}
+
+extern "C" int dctr_bilinear_wide_fwd(const float* E, int64_t ld_e, const float* V, int64_t ld_v, const float* Wf,
+                                      const int32_t* sched_k, int32_t P, int32_t F, int32_t D, int32_t B,
+                                      const float* dense, int64_t ld_d, int32_t n_dense, const float* W0, int64_t ld_w0,
+                                      int32_t H, const float* b0, int32_t relu, float* x, int64_t ld_x, float* h,
+                                      int64_t ld_h, float* workspace, dctr_stream_t stream) {
+  if (!E || !V || !Wf || !sched_k || !W0 || !x || !h || !workspace || B < 0 || F < 2 || P <= 0 || H <= 0 || n_dense < 0 ||
+      (n_dense > 0 && !dense))
+    return DCTR_EINVAL;
+  if (D != kD || H > 16 * kNQ || (ld_x & 3) || (reinterpret_cast<uintptr_t>(x) & 15) ||
+      (reinterpret_cast<uintptr_t>(Wf) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15))
+    return DCTR_ENOSUP;
+  if (B == 0) return DCTR_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  size_t lds = static_cast<size_t>(2) * kSB * wide_rs(F) * sizeof(float) + static_cast<size_t>(P) * 16;
+  const size_t lds_red = static_cast<size_t>(kNW) * 2 * kSB * (16 * kNQ + 4) * sizeof(float);
+  if (lds < lds_red) lds = lds_red;
+  if (lds > 158 * 1024) return DCTR_ENOSUP;
+  f32x4* Wpk = reinterpret_cast<f32x4*>(workspace);
+  float* ypart = workspace + wide_pack_floats(P);
+  const int KB = 2 * P, tiles = (B + 2 * kSB - 1) / (2 * kSB), Bp = tiles * 2 * kSB;
+  k_wide_pack<true><<<dim3((KB + 3) / 4), dim3(kT), 0, s>>>(W0, ld_w0, H, KB, Wpk);
+#define DCTR_WIDE_FWD(FC)                                                                                         \
+  do {                                                                                                            \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bilinear_fwd_wide<FC>),                            \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                 \
+    k_bilinear_fwd_wide<FC><<<dim3(tiles, 2), dim3(64 * kNW), lds, s>>>(E, ld_e, V, ld_v, Wf, sched_k, P, F, B, Wpk, \
+                                                                       n_dense > 0 ? dense : nullptr, ld_d, n_dense, x, \
+                                                                       ld_x, ypart, Bp);                          \
+  } while (0)
+  if (F == 26) DCTR_WIDE_FWD(26);
+  else DCTR_WIDE_FWD(0);
+#undef DCTR_WIDE_FWD
+  const int64_t n = static_cast<int64_t>(B) * 16 * kNQ;
+  k_wide_fwd_finish<<<dim3(static_cast<unsigned>((n + kT - 1) / kT)), dim3(kT), 0, s>>>(
+      ypart, Bp, B, H, n_dense > 0 ? dense : nullptr, ld_d, n_dense, W0, ld_w0, 2 * P * kD, b0, relu, h, ld_h);
   return launch_status();
 }

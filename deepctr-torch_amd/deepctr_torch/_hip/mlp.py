@@ -378,14 +378,27 @@ class BilinearWideFunction(torch.autograd.Function):
             dense = dense.float().contiguous()
         width = 2 * P * D + n_dense
         ld_out = _ops.slab_ld(width)
-        x = torch.empty((B, ld_out), dtype=torch.float32, device=E.device)[:, :width]
+        # (whole tiles of 32 rows: the fused forward stores its pairs unconditionally)
+        x = torch.empty(((B + 31) // 32 * 32, ld_out), dtype=torch.float32, device=E.device)[:B, :width]
         sched = meta.device_tables(E.device)
-        L.check(lib.dctr_bilinear_fwd(_ptr(E), lde, _ptr(V), ldv, _ptr(Wf), _ptr(sched[2]), sched[2].shape[0], P, F, D, B,
-                                      _ptr(x), ld_out, _ptr(dense), dense.stride(0) if dense is not None else 0,
-                                      n_dense, 2 * P * D, L.stream_handle(E.device)), "dctr_bilinear_fwd")
-        h = torch.addmm(b0, x, W0.t()) if b0 is not None else torch.mm(x, W0.t())
-        if relu:
-            h = torch.relu_(h)
+        if os.environ.get("DCTR_BILINEAR_WIDE_FWD", "1") != "0" and W0.stride(1) == 1 and ld_out % 4 == 0 and \
+                (b0 is None or (b0.dtype == torch.float32 and b0.is_contiguous())):
+            # pairs and first layer in one launch: the pairs feed the matrix cores from registers; x is a by-product
+            # (the backward's weight-gradient GEMM reads it)
+            h = torch.empty((B, W0.shape[0]), dtype=torch.float32, device=E.device)
+            ws = torch.empty((lib.dctr_bilinear_wide_fwd_workspace_floats(B, P),), dtype=torch.float32, device=E.device)
+            L.check(lib.dctr_bilinear_wide_fwd(_ptr(E), lde, _ptr(V), ldv, _ptr(Wf), _ptr(sched[2]), P, F, D, B,
+                                               _ptr(dense), dense.stride(0) if dense is not None else 0, n_dense,
+                                               _ptr(W0), W0.stride(0), W0.shape[0], _ptr(b0), int(bool(relu)), _ptr(x),
+                                               ld_out, _ptr(h), h.stride(0), _ptr(ws), L.stream_handle(E.device)),
+                    "dctr_bilinear_wide_fwd")
+        else:
+            L.check(lib.dctr_bilinear_fwd(_ptr(E), lde, _ptr(V), ldv, _ptr(Wf), _ptr(sched[2]), sched[2].shape[0], P, F, D,
+                                          B, _ptr(x), ld_out, _ptr(dense), dense.stride(0) if dense is not None else 0,
+                                          n_dense, 2 * P * D, L.stream_handle(E.device)), "dctr_bilinear_fwd")
+            h = torch.addmm(b0, x, W0.t()) if b0 is not None else torch.mm(x, W0.t())
+            if relu:
+                h = torch.relu_(h)
         ctx.meta, ctx.relu, ctx.has_bias, ctx.n_w_in = meta, bool(relu), b0 is not None, len(weights)
         ctx.save_for_backward(E, V, Wf, x, W0, h if relu else None)
         return h

@@ -548,6 +548,19 @@ int dctr_bilinear_bwd(const float* E, int64_t ld_e, const float* V, int64_t ld_v
  *   writes gE, gV [B, F*D] and gW [n_w, D, D]; workspace = dctr_bilinear_wide_bwd_workspace_floats(B, P) floats.
  *   DCTR_ENOSUP unless D == 16, n_w == P (one weight per pair: "interaction"), H <= 128, H % 4 == 0, 16-byte aligned rows. */
 size_t dctr_bilinear_wide_bwd_workspace_floats(int32_t B, int32_t P);
+/* The same node, forward direction: h [B, H] = act(W0 x + b0) with the pairs of x made where they are consumed (no
+ * [B, 2 P D + n_dense] x [.., H] library GEMM).  x (row stride ld_x, 16-byte aligned rows, ALLOCATED for whole tiles of
+ * 32 rows: ceil(B / 32) * 32 rows, the rows past B receive zeros) is still written -- the
+ * backward's weight-gradient GEMM reads it -- with bits equal to dctr_bilinear_fwd's.  sched_k: the pairs in output
+ * order as dctr_bilinear_fwd takes them; relu != 0: act = relu, else identity; b0 nullable.  The eight per-wave partial
+ * sums of a sample's row meet in wave order, the two inputs' shares in input order: bit-reproducible.
+ * workspace = dctr_bilinear_wide_fwd_workspace_floats(B, P) floats.  DCTR_ENOSUP unless D == 16, H <= 128.  (fibinet.py:82-99, interaction.py:140-156, core.py:123-133)           */
+size_t dctr_bilinear_wide_fwd_workspace_floats(int32_t B, int32_t P);
+int dctr_bilinear_wide_fwd(const float* E, int64_t ld_e, const float* V, int64_t ld_v, const float* Wf,
+                           const int32_t* sched_k, int32_t P, int32_t F, int32_t D, int32_t B, const float* dense,
+                           int64_t ld_d, int32_t n_dense, const float* W0, int64_t ld_w0, int32_t H, const float* b0,
+                           int32_t relu, float* x, int64_t ld_x, float* h, int64_t ld_h, float* workspace,
+                           dctr_stream_t stream);
 int dctr_bilinear_wide_bwd(const float* E, int64_t ld_e, const float* V, int64_t ld_v, const float* Wf,
                            const int32_t* sched4, int32_t n_groups, const int32_t* pair_w, int32_t n_w, int32_t P,
                            int32_t F, int32_t D, int32_t B, const float* gh, int64_t ld_gh, const float* W0,

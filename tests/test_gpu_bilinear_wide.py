@@ -4,7 +4,8 @@ BilinearWideFunction) -- fibinet.py:82-99, interaction.py:140-156, core.py:123-1
 The checker is the numpy oracle in fp64 (np_oracle.bilinear_forward / bilinear_backward, pinned to the reference's FiBiNET
 goldens by tests/test_oracle_golden.py) with the first layer ``relu(x W0^T + b0)`` written out beside it: every gradient at
 2e-5 x scale.  The route that materialises the gradient slab (BilinearFunction + WideLinearFunction) must agree at the same
-bar, the forward bit for bit (it is the same two launches), and two runs of the fused backward must give identical bits."""
+bar (its forward -- pair kernel + library GEMM -- within 2e-6 x scale of the fused forward's fixed-order sums), and two runs of
+the fused node must give identical bits, forward and backward."""
 import numpy as np
 import pytest
 import torch
@@ -69,7 +70,7 @@ def test_fused_node_against_the_oracle_and_the_slab_route(B, F, H, nd):
     R = torch.randn(B, H, device=DEV)
     h1, g1 = _run(layer, dnn, E, V, dense, R, lazy=True)
     h0, g0 = _run(layer, dnn, E, V, dense, R, lazy=False)
-    assert torch.equal(h1, h0)
+    _close(h1, h0, "h (fused forward against bilinear kernel + library GEMM)", tol=2e-6)
     # fp64 oracle
     P = F * (F - 1) // 2
     Pn = {"bl.bilinear.%d.weight" % k: _n(p) for k, p in enumerate(layer.parameters())}
@@ -95,11 +96,12 @@ def test_fused_backward_is_bit_reproducible_and_leaves_no_slab():
     B, F, D, H, nd = 300, 26, 16, 128, 13
     layer, dnn, E, V, dense = _setup(B, F, D, H, nd, seed=11)
     R = torch.randn(B, H, device=DEV)
-    _, ga = _run(layer, dnn, E, V, dense, R, lazy=True)
+    ha, ga = _run(layer, dnn, E, V, dense, R, lazy=True)
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats()
     base = torch.cuda.memory_allocated()
-    _, gb = _run(layer, dnn, E, V, dense, R, lazy=True)
+    hb, gb = _run(layer, dnn, E, V, dense, R, lazy=True)
+    assert torch.equal(ha, hb)
     for a, b in zip(ga, gb):
         assert torch.equal(a, b)
     # the backward holds the saved DNN input (one slab) and the per-tile weight partials, never a second [B, 2PD] slab
@@ -140,7 +142,7 @@ def test_fibinet_takes_the_fused_node(monkeypatch):
         loss.backward()
         assert (len(calls) > n0) == (mode == "1")
         res[mode] = (float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
-    assert res["1"][0] == res["0"][0]
+    assert abs(res["1"][0] - res["0"][0]) <= 2e-6 * abs(res["0"][0])      # (two summation orders of the first layer)
     assert res["1"][1].keys() == res["0"][1].keys()
     for n, a in res["1"][1].items():
         _close(a, res["0"][1][n], n, tol=2e-5)
