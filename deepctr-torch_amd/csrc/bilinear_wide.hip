@@ -1,4 +1,5 @@
-// bilinear_wide.hip -- FiBiNET's bilinear pairs TOGETHER WITH the first tower layer behind them, backward direction
+// bilinear_wide.hip -- FiBiNET's bilinear pairs TOGETHER WITH the first tower layer behind them, both directions (the
+// backward first: it is where the traffic was; the forward, k_bilinear_fwd_wide, follows it in this file)
 // (fibinet.py:82-99: dnn_input = [ Bilinear(senet) | Bilinear(raw) | dense ], h1 = relu(W0 dnn_input + b0);
 //  interaction.py:140-156; core.py:123-133).
 //

@@ -359,8 +359,9 @@ class PendingPairs(object):
 
 
 class BilinearWideFunction(torch.autograd.Function):
-    """``act(W0 [Bilinear(V) | Bilinear(E) | dense] + b0)`` as one node.  Forward: the pair kernel writes the DNN input,
-    one library GEMM behind it (as ``BilinearFunction`` + ``WideLinearFunction``).  Backward: the weight gradient's GEMM
+    """``act(W0 [Bilinear(V) | Bilinear(E) | dense] + b0)`` as one node.  Forward: ``dctr_bilinear_wide_fwd`` -- the pairs go
+    to the first layer's MFMAs from registers; the DNN input is written as a by-product for the backward
+    (``DCTR_BILINEAR_WIDE_FWD=0``: pair kernel + library GEMM, as ``BilinearFunction`` + ``WideLinearFunction``).  Backward: the weight gradient's GEMM
     over the saved DNN input, and ``dctr_bilinear_wide_bwd`` -- gE, gV and the pair weights' gradients straight from
     ``gh`` and ``W0`` on the matrix cores; no ``gh W0`` GEMM, no gradient slab, no second and third pass over it."""
 

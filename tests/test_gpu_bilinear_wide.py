@@ -63,7 +63,7 @@ def _run(layer, dnn, E, V, dense, R, lazy):
 
 
 @pytest.mark.parametrize("B,F,H,nd", [(64, 26, 128, 13), (50, 6, 128, 3), (37, 26, 64, 0), (16, 5, 32, 2), (1, 4, 12, 1),
-                                      (200, 9, 128, 5)])
+                                      (200, 9, 128, 5), (40, 9, 12, 0), (33, 12, 100, 7)])
 def test_fused_node_against_the_oracle_and_the_slab_route(B, F, H, nd):
     D = 16
     layer, dnn, E, V, dense = _setup(B, F, D, H, nd, seed=B + F)
