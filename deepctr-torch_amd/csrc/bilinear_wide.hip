@@ -406,8 +406,8 @@ __global__ __launch_bounds__(64 * kNW) void k_bilinear_bwd_wide(const float* __r
 // the pair loop: the two waves of a SIMD drift apart by themselves.  The product slab x is still WRITTEN (one dwordx4
 // per lane, pair and input) for the weight gradient's GEMM of the backward -- but never read by this launch, and the
 // [B, 10 413] x [10 413, 128] library GEMM of the forward is gone.
-template <int FC>
-__global__ __launch_bounds__(64 * kNW) void k_bilinear_fwd_wide(const float* __restrict__ E, int64_t lde,
+template <int FC, int NWF>
+__global__ __launch_bounds__(64 * NWF) void k_bilinear_fwd_wide(const float* __restrict__ E, int64_t lde,
                                                                 const float* __restrict__ V, int64_t ldv,
                                                                 const float* __restrict__ Wf,
                                                                 const int32_t* __restrict__ sched_k, int P, int F, int B,
@@ -426,9 +426,9 @@ __global__ __launch_bounds__(64 * kNW) void k_bilinear_fwd_wide(const float* __r
   int32_t* sch = reinterpret_cast<int32_t*>(xs1 + kSB * RS);   // [P][4] = {i, j, weight index, k}
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * (2 * kSB);
-  for (int e = tid; e < P; e += 64 * kNW)
+  for (int e = tid; e < P; e += 64 * NWF)
     *reinterpret_cast<i32x4*>(sch + 4 * e) = *(const DCTR_GLOBAL i32x4*)(sched_k + 4 * e);
-  {
+  if (tid < 2 * kT) {              // (two groups of 256 threads stage the two tiles)
     const int t2 = tid & (kT - 1), half = tid >> 8;
     float* dst = half ? xs1 : xs0;
     const int bs = b0 + half * kSB;
@@ -476,15 +476,15 @@ __global__ __launch_bounds__(64 * kNW) void k_bilinear_fwd_wide(const float* __r
   }
   // the dense columns of the DNN input (fibinet.py:86-87): copied behind the pairs (by the V launch row)
   if (dense && pass == 0)
-    for (int e = tid; e < 2 * kSB * n_dense; e += 64 * kNW) {
+    for (int e = tid; e < 2 * kSB * n_dense; e += 64 * NWF) {
       const int r = e / n_dense, q = e - r * n_dense;
       if (b0 + r < B)
         stg_f32(x + static_cast<int64_t>(b0 + r) * ldx + 2 * P * kD + q, ldg_f32(dense + static_cast<int64_t>(b0 + r) * ldd + q));
     }
   __syncthreads();
-  const int npw = wv < P ? (P - 1 - wv) / kNW + 1 : 0;      // this wave's pairs: k = wv, wv + 8, ...
+  const int npw = wv < P ? (P - 1 - wv) / NWF + 1 : 0;      // this wave's pairs: k = wv, wv + NWF, ...
   auto entry = [&](int m) {
-    const int k = wv + kNW * (m < npw ? m : (npw > 0 ? npw - 1 : 0));
+    const int k = wv + NWF * (m < npw ? m : (npw > 0 ? npw - 1 : 0));
     const i32x4 v = *reinterpret_cast<const i32x4*>(sch + 4 * (k < P ? k : 0));
     PairEnt e;
     e.i = v.x; e.j = v.y; e.wi = v.z; e.k = v.w;
@@ -573,23 +573,25 @@ __global__ __launch_bounds__(64 * kNW) void k_bilinear_fwd_wide(const float* __r
     }
   }
   __syncthreads();                 // every wave is done with the row tiles: their LDS becomes the partials' meeting place
-  float* red = smem;               // [waves][32][128 + 4]
+  float* red = smem;               // [waves][16][128 + 4], one sample half at a time
   constexpr int RP = 16 * kNQ + 4;
 #pragma unroll
-  for (int q = 0; q < kNQ; ++q)
+  for (int hf = 0; hf < 2; ++hf) {
+    if (hf) __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      red[(wv * 2 * kSB + 4 * g + r) * RP + 16 * q + c] = y0[q][r];
-      red[(wv * 2 * kSB + kSB + 4 * g + r) * RP + 16 * q + c] = y1[q][r];
+    for (int q = 0; q < kNQ; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wv * kSB + 4 * g + r) * RP + 16 * q + c] = hf ? y1[q][r] : y0[q][r];
+    __syncthreads();
+    // this input's share of the pre-activation, waves in order (fixed order); k_wide_fwd_finish adds the two inputs' shares
+    for (int o = tid; o < kSB * 16 * kNQ; o += 64 * NWF) {
+      const int b = o / (16 * kNQ), h = o - b * (16 * kNQ);
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWF; ++w) v += red[(w * kSB + b) * RP + h];
+      const int bb = b0 + hf * kSB + b;
+      if (bb < Bp) stg_f32(ypart + (static_cast<int64_t>(pass) * Bp + bb) * (16 * kNQ) + h, v);
     }
-  __syncthreads();
-  // this input's share of the pre-activation, waves in order (fixed order); k_wide_fwd_finish adds the two inputs' shares
-  for (int o = tid; o < 2 * kSB * 16 * kNQ; o += 64 * kNW) {
-    const int b = o / (16 * kNQ), h = o - b * (16 * kNQ);
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < kNW; ++w) v += red[(w * 2 * kSB + b) * RP + h];
-    if (b0 + b < Bp) stg_f32(ypart + (static_cast<int64_t>(pass) * Bp + b0 + b) * (16 * kNQ) + h, v);
   }
 }
 
@@ -721,7 +723,8 @@ extern "C" int dctr_bilinear_wide_fwd(const float* E, int64_t ld_e, const float*
   if (B == 0) return DCTR_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   size_t lds = static_cast<size_t>(2) * kSB * wide_rs(F) * sizeof(float) + static_cast<size_t>(P) * 16;
-  const size_t lds_red = static_cast<size_t>(kNW) * 2 * kSB * (16 * kNQ + 4) * sizeof(float);
+  constexpr int NWF = 8;           // (12 = three waves per SIMD, 150 registers per lane allow it: 135.1 us against 128.5)
+  const size_t lds_red = static_cast<size_t>(NWF) * kSB * (16 * kNQ + 4) * sizeof(float);
   if (lds < lds_red) lds = lds_red;
   if (lds > 158 * 1024) return DCTR_ENOSUP;
   f32x4* Wpk = reinterpret_cast<f32x4*>(workspace);
@@ -730,9 +733,9 @@ extern "C" int dctr_bilinear_wide_fwd(const float* E, int64_t ld_e, const float*
   k_wide_pack<true><<<dim3((KB + 3) / 4), dim3(kT), 0, s>>>(W0, ld_w0, H, KB, Wpk);
 #define DCTR_WIDE_FWD(FC)                                                                                         \
   do {                                                                                                            \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bilinear_fwd_wide<FC>),                            \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bilinear_fwd_wide<FC, NWF>),                       \
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                 \
-    k_bilinear_fwd_wide<FC><<<dim3(tiles, 2), dim3(64 * kNW), lds, s>>>(E, ld_e, V, ld_v, Wf, sched_k, P, F, B, Wpk, \
+    k_bilinear_fwd_wide<FC, NWF><<<dim3(tiles, 2), dim3(64 * NWF), lds, s>>>(E, ld_e, V, ld_v, Wf, sched_k, P, F, B, Wpk, \
                                                                        n_dense > 0 ? dense : nullptr, ld_d, n_dense, x, \
                                                                        ld_x, ypart, Bp);                          \
   } while (0)
