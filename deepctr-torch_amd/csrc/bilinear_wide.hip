@@ -35,10 +35,30 @@ constexpr int kD = 16;          // embedding width of the fused route
 // W0[16 q + 4 g + s][16 kb + c], zero past H.  The MFMA contraction index of step 4 q + s in lane group g is that h.
 // FWD: the forward's layout instead -- component s of lane (g, c) of piece (kb, nb) is W0[16 nb + c][16 kb + 4 g + s]
 // (B operand of y[b][h] += sum_e p[b][e] W0[h][16 kb + e] with the contraction index e = 4 g + s).
+// One more workgroup (FWD, Wd != NULL): the n_dense columns behind the pairs as a compact [128][32] block -- read where
+// they lie (one 52-byte piece per hidden unit, rows 41 KB apart) by every workgroup of the finishing launch, the same
+// 128 lines were requested 256 times over: 11 us for a 4 us launch.
 template <bool FWD>
 __global__ __launch_bounds__(kT) void k_wide_pack(const float* __restrict__ W0, int64_t ldw, int H, int KB,
-                                                  f32x4* __restrict__ Wpk) {
+                                                  f32x4* __restrict__ Wpk, float* __restrict__ Wd, int n_dense) {
   __shared__ float t[16 * kNQ][65];
+  if (FWD && Wd && blockIdx.x == gridDim.x - 1) {
+    const int n = 16 * kNQ * 32;
+    for (int e0 = threadIdx.x; e0 < n; e0 += 8 * kT) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * kT, h = e >> 5, q = e & 31;
+        v[u] = ldg_f32(W0 + static_cast<int64_t>(h < H ? h : 0) * ldw + KB * 16 + (q < n_dense ? q : 0));
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * kT, h = e >> 5, q = e & 31;
+        Wd[e] = (h < H && q < n_dense) ? v[u] : 0.f;
+      }
+    }
+    return;
+  }
   const int kb0 = blockIdx.x * 4;
   const int tid = threadIdx.x, col = tid & 63, r0 = tid >> 6;
   const int ncol = (KB - kb0) * 16 < 64 ? (KB - kb0) * 16 : 64;
@@ -595,22 +615,56 @@ __global__ __launch_bounds__(64 * NWF) void k_bilinear_fwd_wide(const float* __r
   }
 }
 
-// h = act((share of V's pairs + share of E's pairs) + dense columns + bias)
+// h = act((share of V's pairs + share of E's pairs) + dense columns + bias); Wd: the dense columns' weights, [128][32]
+// A thread keeps its hidden unit's 32 dense weights in registers (zeros past n_dense) and walks 8 of the workgroup's 16
+// samples, whose dense values it reads as broadcast dwordx4 pieces from LDS (as two LDS reads per product this launch
+// was LDS-bound at 10 us).
+constexpr int kFinRows = 16, kFinND = 32;
 __global__ __launch_bounds__(kT) void k_wide_fwd_finish(const float* __restrict__ ypart, int Bp, int B, int H,
                                                         const float* __restrict__ dense, int64_t ldd, int n_dense,
-                                                        const float* __restrict__ W0, int64_t ldw0, int dense_col,
-                                                        const float* __restrict__ b0v, int relu,
-                                                        float* __restrict__ hout, int64_t ldh) {
-  const int64_t o = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
-  const int b = static_cast<int>(o / (16 * kNQ)), h = static_cast<int>(o - static_cast<int64_t>(b) * (16 * kNQ));
-  if (b >= B || h >= H) return;
-  float v = ldg_f32(ypart + static_cast<int64_t>(b) * (16 * kNQ) + h) +
-            ldg_f32(ypart + (static_cast<int64_t>(Bp) + b) * (16 * kNQ) + h);
-  for (int q = 0; q < n_dense; ++q)
-    v += ldg_f32(dense + static_cast<int64_t>(b) * ldd + q) * ldg_f32(W0 + static_cast<int64_t>(h) * ldw0 + dense_col + q);
-  if (b0v) v += ldg_f32(b0v + h);
-  if (relu) v = v > 0.f ? v : 0.f;
-  stg_f32(hout + static_cast<int64_t>(b) * ldh + h, v);
+                                                        const float* __restrict__ Wd, const float* __restrict__ b0v,
+                                                        int relu, float* __restrict__ hout, int64_t ldh) {
+  __shared__ __align__(16) float dn[kFinRows][kFinND + 4];
+  const int tid = threadIdx.x, r0 = blockIdx.x * kFinRows;
+  const int nd = n_dense < kFinND ? n_dense : kFinND;       // (host: n_dense <= kFinND)
+  const int h = tid & (16 * kNQ - 1), rh = tid >> 7;        // (kT = 256 threads: two samples per pass)
+  f32x4 w[kFinND / 4];
+#pragma unroll
+  for (int j = 0; j < kFinND / 4; ++j) w[j] = *(const DCTR_GLOBAL f32x4*)(Wd + h * kFinND + 4 * j);
+  {
+    // (unconditional loads on clamped addresses: a predicated load is a branch with its own wait)
+    float v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + u * kT, r = e >> 5, q = e & 31;
+      v[u] = nd > 0 ? ldg_f32(dense + static_cast<int64_t>(r0 + r < B ? r0 + r : B - 1) * ldd + (q < nd ? q : 0)) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + u * kT, r = e >> 5, q = e & 31;
+      dn[r][q] = (r0 + r < B && q < nd) ? v[u] : 0.f;
+    }
+  }
+  __syncthreads();
+  const float bias = (b0v && h < H) ? ldg_f32(b0v + h) : 0.f;
+#pragma unroll
+  for (int k = 0; k < kFinRows / 2; ++k) {
+    const int r = rh + 2 * k, b = r0 + r;
+    const int bc = b < Bp ? b : Bp - 1;
+    float v = ldg_f32(ypart + static_cast<int64_t>(bc) * (16 * kNQ) + h) +
+              ldg_f32(ypart + (static_cast<int64_t>(Bp) + bc) * (16 * kNQ) + h);
+#pragma unroll
+    for (int j = 0; j < kFinND / 4; ++j) {
+      const f32x4 d = *reinterpret_cast<const f32x4*>(&dn[r][4 * j]);
+      v += d.x * w[j].x;
+      v += d.y * w[j].y;
+      v += d.z * w[j].z;
+      v += d.w * w[j].w;
+    }
+    v += bias;
+    if (relu) v = v > 0.f ? v : 0.f;
+    if (b < B && h < H) stg_f32(hout + static_cast<int64_t>(b) * ldh + h, v);
+  }
 }
 
 // gW[pair_w[k]] = sum over the tiles' partials of pair k, fixed order: four slices of the tiles per workgroup, each
@@ -671,7 +725,7 @@ extern "C" int dctr_bilinear_wide_bwd(const float* E, int64_t ld_e, const float*
   f32x4* Wpk = reinterpret_cast<f32x4*>(workspace);
   float* part = workspace + wide_pack_floats(P);
   const int KB = 2 * P, tiles = (B + 2 * kSB - 1) / (2 * kSB);
-  k_wide_pack<false><<<dim3((KB + 3) / 4), dim3(kT), 0, s>>>(W0, ld_w0, H, KB, Wpk);
+  k_wide_pack<false><<<dim3((KB + 3) / 4), dim3(kT), 0, s>>>(W0, ld_w0, H, KB, Wpk, nullptr, 0);
 #define DCTR_WIDE_F(VAR, FC)                                                                                      \
   do {                                                                                                            \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bilinear_bwd_wide<VAR, FC>),                       \
@@ -706,7 +760,7 @@ extern "C" int dctr_bilinear_wide_bwd(const float* E, int64_t ld_e, const float*
 
 extern "C" size_t dctr_bilinear_wide_fwd_workspace_floats(int32_t B, int32_t P) {
   const size_t Bp = (static_cast<size_t>(B > 0 ? B : 1) + 2 * kSB - 1) / (2 * kSB) * (2 * kSB);
-  return wide_pack_floats(P > 0 ? P : 1) + 2 * Bp * 16 * kNQ;
+  return wide_pack_floats(P > 0 ? P : 1) + 2 * Bp * 16 * kNQ + 16 * kNQ * 32;
 }
 
 extern "C" int dctr_bilinear_wide_fwd(const float* E, int64_t ld_e, const float* V, int64_t ld_v, const float* Wf,
@@ -717,7 +771,7 @@ extern "C" int dctr_bilinear_wide_fwd(const float* E, int64_t ld_e, const float*
   if (!E || !V || !Wf || !sched_k || !W0 || !x || !h || !workspace || B < 0 || F < 2 || P <= 0 || H <= 0 || n_dense < 0 ||
       (n_dense > 0 && !dense))
     return DCTR_EINVAL;
-  if (D != kD || H > 16 * kNQ || (ld_x & 3) || (reinterpret_cast<uintptr_t>(x) & 15) ||
+  if (D != kD || H > 16 * kNQ || n_dense > kFinND || (ld_x & 3) || (reinterpret_cast<uintptr_t>(x) & 15) ||
       (reinterpret_cast<uintptr_t>(Wf) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15))
     return DCTR_ENOSUP;
   if (B == 0) return DCTR_OK;
@@ -730,7 +784,8 @@ extern "C" int dctr_bilinear_wide_fwd(const float* E, int64_t ld_e, const float*
   f32x4* Wpk = reinterpret_cast<f32x4*>(workspace);
   float* ypart = workspace + wide_pack_floats(P);
   const int KB = 2 * P, tiles = (B + 2 * kSB - 1) / (2 * kSB), Bp = tiles * 2 * kSB;
-  k_wide_pack<true><<<dim3((KB + 3) / 4), dim3(kT), 0, s>>>(W0, ld_w0, H, KB, Wpk);
+  float* Wd = ypart + static_cast<size_t>(2) * Bp * 16 * kNQ;
+  k_wide_pack<true><<<dim3((KB + 3) / 4 + 1), dim3(kT), 0, s>>>(W0, ld_w0, H, KB, Wpk, Wd, n_dense);
 #define DCTR_WIDE_FWD(FC)                                                                                         \
   do {                                                                                                            \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bilinear_fwd_wide<FC, NWF>),                       \
@@ -742,8 +797,7 @@ extern "C" int dctr_bilinear_wide_fwd(const float* E, int64_t ld_e, const float*
   if (F == 26) DCTR_WIDE_FWD(26);
   else DCTR_WIDE_FWD(0);
 #undef DCTR_WIDE_FWD
-  const int64_t n = static_cast<int64_t>(B) * 16 * kNQ;
-  k_wide_fwd_finish<<<dim3(static_cast<unsigned>((n + kT - 1) / kT)), dim3(kT), 0, s>>>(
-      ypart, Bp, B, H, n_dense > 0 ? dense : nullptr, ld_d, n_dense, W0, ld_w0, 2 * P * kD, b0, relu, h, ld_h);
+  k_wide_fwd_finish<<<dim3((B + kFinRows - 1) / kFinRows), dim3(kT), 0, s>>>(
+      ypart, Bp, B, H, n_dense > 0 ? dense : nullptr, ld_d, n_dense, Wd, b0, relu, h, ld_h);
   return launch_status();
 }

@@ -382,7 +382,7 @@ class BilinearWideFunction(torch.autograd.Function):
         # (whole tiles of 32 rows: the fused forward stores its pairs unconditionally)
         x = torch.empty(((B + 31) // 32 * 32, ld_out), dtype=torch.float32, device=E.device)[:B, :width]
         sched = meta.device_tables(E.device)
-        if os.environ.get("DCTR_BILINEAR_WIDE_FWD", "1") != "0" and W0.stride(1) == 1 and ld_out % 4 == 0 and \
+        if os.environ.get("DCTR_BILINEAR_WIDE_FWD", "1") != "0" and W0.stride(1) == 1 and ld_out % 4 == 0 and n_dense <= 32 and \
                 (b0 is None or (b0.dtype == torch.float32 and b0.is_contiguous())):
             # pairs and first layer in one launch: the pairs feed the matrix cores from registers; x is a by-product
             # (the backward's weight-gradient GEMM reads it)

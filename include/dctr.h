@@ -554,7 +554,7 @@ size_t dctr_bilinear_wide_bwd_workspace_floats(int32_t B, int32_t P);
  * backward's weight-gradient GEMM reads it -- with bits equal to dctr_bilinear_fwd's.  sched_k: the pairs in output
  * order as dctr_bilinear_fwd takes them; relu != 0: act = relu, else identity; b0 nullable.  The eight per-wave partial
  * sums of a sample's row meet in wave order, the two inputs' shares in input order: bit-reproducible.
- * workspace = dctr_bilinear_wide_fwd_workspace_floats(B, P) floats.  DCTR_ENOSUP unless D == 16, H <= 128.  (fibinet.py:82-99, interaction.py:140-156, core.py:123-133)           */
+ * workspace = dctr_bilinear_wide_fwd_workspace_floats(B, P) floats.  DCTR_ENOSUP unless D == 16, H <= 128, n_dense <= 32.  (fibinet.py:82-99, interaction.py:140-156, core.py:123-133)           */
 size_t dctr_bilinear_wide_fwd_workspace_floats(int32_t B, int32_t P);
 int dctr_bilinear_wide_fwd(const float* E, int64_t ld_e, const float* V, int64_t ld_v, const float* Wf,
                            const int32_t* sched_k, int32_t P, int32_t F, int32_t D, int32_t B, const float* dense,
