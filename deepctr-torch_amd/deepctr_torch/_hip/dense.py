@@ -87,8 +87,6 @@ class DenseSlab(object):
         d["flag_sync"] = False
         d["wgrad_side"] = d["gather_side"] = d["wgrad_on_seg"] = False
         d["_fork_events"] = None
-        d["_wide_events"] = None
-        d["_pending_wide"] = None
         d["inline_done"] = False
         return d
 
@@ -179,26 +177,9 @@ class DenseSlab(object):
         (the stream goes on to carry work the joiner must not wait for)."""
         self._pending = (stream, keep_alive, done)
 
-    def wide_events(self):
-        """The two events of the wide first layer's forked weight-gradient GEMM (they live as long as the slab, like
-        fork_event()'s)."""
-        ev = getattr(self, "_wide_events", None)
-        if ev is None:
-            ev = self._wide_events = [torch.cuda.Event(), torch.cuda.Event()]
-        return ev
-
-    def forked_wide(self, stream, keep_alive, done):
-        """A second, independent fork (mlp.BilinearWideFunction.backward: the weight gradient's library GEMM of a very
-        wide first layer beside the memory-bound rest of the backward and the embedding update); join() waits for both."""
-        self._pending_wide = (stream, keep_alive, done)
-
     def join(self):
         p = self._pending
         self.main_keep = None
-        pw = getattr(self, "_pending_wide", None)
-        if pw is not None:
-            self._pending_wide = None
-            torch.cuda.current_stream(self.flat.device).wait_event(pw[2])
         if p is not None:
             self._pending = None
             cur = torch.cuda.current_stream(self.flat.device)

@@ -368,7 +368,6 @@ class BilinearWideFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, relu, E, V, dense, W0, b0, *weights):
         from . import ops as _ops
-        meta, ctx.sink, ctx.w0_ref = meta if isinstance(meta, tuple) else (meta, None, W0)
         lib = L.lib()
         E, lde = _ops._rows3(E, "Bilinear input")
         V, ldv = _ops._rows3(V, "Bilinear second input")
@@ -419,20 +418,10 @@ class BilinearWideFunction(torch.autograd.Function):
         g, gb = _act_backward(g, h, ctx.relu, ctx.has_bias and ctx.needs_input_grad[6])
         if g.stride(1) != 1 or g.stride(0) % 4 != 0 or g.data_ptr() % 16 != 0:
             g = g.contiguous()
-        # The weight gradient's library GEMM (the one slab-sized read left) on a side stream BEHIND the fused kernel below:
-        # it then runs beside the memory-bound rest of the backward (pair-weight reduction, SENET, the embedding update)
-        # instead of in front of it.  Fused train step only: the GEMM writes into the dense gradient slab, whose join()
-        # in front of the optimizer step waits for it (autograd sees None, like the tower's sink route).
-        sink, gW0, fork_to = ctx.sink, None, None
+        gW0 = None
         if ctx.needs_input_grad[5]:
-            tgt = sink.grad_of(ctx.w0_ref) if (sink is not None and hasattr(sink, "forked_wide")) else None
-            if tgt is not None and g.is_cuda and getattr(sink, "overlap", False) is True and \
-                    os.environ.get("DCTR_WIDE_WGRAD_FORK", "1") != "0" and tgt.dim() == 2 and \
-                    tgt.shape[0] == W0.shape[0] and tgt.shape[1] >= W0.shape[1]:
-                fork_to = tgt
-            else:
-                with _TunedGemm():
-                    gW0 = torch.mm(g.t(), x)
+            with _TunedGemm():
+                gW0 = torch.mm(g.t(), x)
         if gb is None and ctx.has_bias and ctx.needs_input_grad[6]:
             gb = g.sum(0)
         gE = torch.empty((B, F, D), dtype=torch.float32, device=dev)
@@ -444,18 +433,6 @@ class BilinearWideFunction(torch.autograd.Function):
                                            _ptr(pair_w), meta.n_w, P, F, D, B, _ptr(g), g.stride(0), _ptr(W0),
                                            W0.stride(0), W0.shape[0], _ptr(gE), _ptr(gV), _ptr(gW), _ptr(ws),
                                            L.stream_handle(dev)), "dctr_bilinear_wide_bwd")
-        if fork_to is not None:
-            from . import streams as _streams
-            side = _streams.side_stream(dev, "wide")
-            ev_go, ev_done = sink.wide_events()
-            ev_go.record(torch.cuda.current_stream(dev))        # fork point: behind the fused kernel and its reduction
-            side.wait_event(ev_go)
-            with torch.cuda.stream(side):
-                tmp = torch.mm(g.t(), x)
-                fork_to[:, :W0.shape[1]].copy_(tmp)
-                ev_done.record(side)
-            # (everything the forked kernels touch stays allocated until the join: no record_stream bookkeeping)
-            sink.forked_wide(side, (g, x, tmp, fork_to), ev_done)
         return (None, None, gE, gV, None, gW0, gb) + tuple(gW[i] for i in range(ctx.n_w_in))
 
 
@@ -469,7 +446,7 @@ def tower(dnn, dnn_linear, x, K=None, sink=None):
         x, pairs = pairs.materialize(), None
     if pairs is not None:
         W0, b0, relu0 = spec[0][0]
-        h0 = BilinearWideFunction.apply((pairs.meta, sink, W0), bool(relu0), pairs.raw, pairs.senet, pairs.dense, W0, b0,
+        h0 = BilinearWideFunction.apply(pairs.meta, bool(relu0), pairs.raw, pairs.senet, pairs.dense, W0, b0,
                                         *pairs.weights)
         layers, w_out = spec[0][1:], spec[1]
         x, K = h0, W0.shape[0]

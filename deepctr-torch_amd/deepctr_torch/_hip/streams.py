@@ -11,7 +11,7 @@ torch's default one.
 """
 import torch
 
-ROLES = ("capture", "seg", "fork", "stage", "warm", "shard", "sweep", "wide")
+ROLES = ("capture", "seg", "fork", "stage", "warm", "shard", "sweep")
 _STREAMS = {}
 
 
