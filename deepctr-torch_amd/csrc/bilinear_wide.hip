@@ -107,20 +107,17 @@ __device__ __forceinline__ void lds_barrier() {
 
 // row stride of the LDS tiles: (RS mod 8) == 4 puts the rows 4g + r of the two lane groups g that share an LDS cycle
 // on disjoint bank halves (the 32-mod-16 stride of pairwise.hip leaves every ds_read_b32 of a [4g + r][c] piece 2-way
-// conflicted: 40 % of this kernel's LDS cycles in the first version's counters)
+// conflicted: 40 % of the LDS cycles in the first version's counters, SQ_LDS_BANK_CONFLICT 11.4 M -> 3.4 M)
 __device__ __host__ inline int wide_rs(int F) { return F * kD + 4; }
 
 // sched4: [n_groups][8 waves][4] int32 = {i, j, weight index, pair index k}; i = -1: the wave idles in this group.
 // part:   [2 inputs x tiles][P][16][16] per-workgroup partial of gW_k (row e, column d), every one written exactly once.
 //
-// One group of a wave, in issue order (what the first version's variants measured is in the comments):
-//   read-only LDS operands of the pair (x_i twice, x_j)           -- before the long MFMA block: latency hidden
-//   G block: 64 MFMAs; behind the 8 that consume a dwordx4 pair of the ring, the SAME registers are re-loaded for the
-//            next group (in place, one group ahead = ~2 800 cycles): two loads per 256 MFMA cycles -- issuing the 21
-//            loads of a group back to back stalled all four waves of the CU at the same point (-57 us without them)
-//   barrier  -- HERE, not at the end of the group: the previous group's LDS gradient writes drain under the G block
-//            (-32 us without the barrier, -33 without the writes when both sat at the group's end)
-//   gradient tiles' current values (LDS), T / gW / gX_i MFMAs, LDS gradient writes, the partial's stores
+// How the kernel got here (one-box timings of dctr_bilinear_wide_bwd, pack + main + reduce; DESIGN.md §3 has the table):
+// four waves in step, ring two groups deep, program order 240 us -> ring re-loaded in place behind the MFMAs that read
+// it, barrier behind the MFMA block, conflict-free stride 217 -> eight waves 203 -> 32 samples of one input per workgroup
+// 193 -> two parts per group with the waves of a SIMD half a group apart (below), compile-time field count, x_i W^T
+// behind part 1 ~167.  The group's own structure is described at the lambda below.
 // FC: the field count as a compile-time constant (0: read F).  With it every LDS address of a group is one of two
 // per-lane registers (the pair's i / j column) plus an immediate; without, the row and tile offsets are vector adds --
 // 51 of the 83 vector instructions of part 2, each of which waits for a slot between the other wave's MFMAs.
@@ -252,14 +249,16 @@ __global__ __launch_bounds__(64 * kNW) void k_bilinear_bwd_wide(const float* __r
   //
   // A group of a wave is two parts, and the two waves of a SIMD run HALF A GROUP APART (below): between two barriers one
   // wave is in part 1, the other in part 2.
-  //   part 1  64 MFMAs back to back (G of both sample halves) and NOTHING else but the ring's re-loads: one dwordx4
-  //           behind every 8 MFMAs, into the registers those 8 have just read (in place, a whole group ahead)
-  //   part 2  everything with latency in it: the pair's LDS operands, T, the transposition of G (.) x_j through LDS,
-  //           gW / gX_i MFMAs, the LDS read-modify-writes of the two fields' gradient rows, the partial's stores, the
-  //           next pair's own weight tile.  24 MFMAs: it ends long before the other wave's part 1 does.
-  // (Measured on the way here, 4 waves in step: matrix pipe 55 % busy whatever the instruction order -- with one wave per
-  // SIMD every LDS / memory / vector instruction is an issue slot its own MFMAs cannot use; 8 waves in step: 79 % in
-  // part 1, 75 % in part 2; the LDS work inside part 1: part 1 at 2 900-3 400 cycles for 2 816 of MFMA.)
+  //   part 1  64 MFMAs back to back (G of both sample halves) with nothing between them but the ring's re-loads -- one
+  //           dwordx4 behind every 8 MFMAs, into the registers those 8 have just read (in place, a whole group ahead) --
+  //           then t = x_i W^T (2 LDS reads, 8 MFMAs: it needs nothing of G and nothing behind the barrier)
+  //   part 2  everything with latency in it: the pair's other LDS operands in the order of need, the transposition of
+  //           G (.) x_j through LDS, gW / gX_i MFMAs (16), the LDS read-modify-writes of the two fields' gradient rows,
+  //           the partial's stores, the next pair's own weight tile
+  // Phase stamps (DCTR_WIDE_VAR=216): part 1 2 750-3 100 cycles, part 2 3 450-3 700, for 2 816 cycles of MFMA per
+  // interval and SIMD.  (4 waves in step: matrix pipe 55 % busy whatever the instruction order -- with one wave per SIMD
+  // every LDS / memory / vector instruction is an issue slot its own MFMAs cannot use; 8 waves in step: 79 % in part 1,
+  // 75 % in part 2.)
   PairEnt cur = entry(0), nxt = entry(1);
   auto group = [&](auto full_tag, int gi) {
     constexpr bool FULL = decltype(full_tag)::value;
