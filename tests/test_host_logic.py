@@ -128,3 +128,39 @@ def test_committed_bench_line_keeps_the_driver_contract():
         leg = d["other_configs"][name]
         assert leg["roofline"]["bound"] == "mfma" and leg["hip_graph"] and leg["ms_per_step"] > 0
     assert d["roofline"]["traffic"] == d["roofline"]["traffic_detail"]["fetch_raw"] + d["roofline"]["traffic_detail"]["write_raw"]
+
+
+@pytest.mark.parametrize("F", [2, 3, 5, 8, 17, 26, 39])
+@pytest.mark.parametrize("btype", ["interaction", "each", "all"])
+def test_pair_schedules_of_the_bilinear_kernels(F, btype):
+    """The two host tables behind csrc/pairwise.hip / bilinear_wide.hip (interaction.py:140-156: pairs in
+    itertools.combinations order): the round-robin tournament -- every round a perfect matching, every pair once, k the
+    reference's pair index -- and its re-deal in groups of eight field-disjoint pairs for the fused backward (one pair per
+    wave, idle entries only as padding, the tournament's k / weight index carried over)."""
+    import itertools
+    from deepctr_torch._hip.ops import disjoint_groups, tournament_schedule
+    rows, slots, pair_w, n_w = tournament_schedule(F, btype)
+    pairs = list(itertools.combinations(range(F), 2))
+    P = len(pairs)
+    live = [r for r in rows if r[0] >= 0]
+    assert sorted(r[3] for r in live) == list(range(P)) and len(pair_w) == P
+    for (i, j, w, k) in live:
+        assert pairs[k] == (i, j)
+        assert w == (0 if btype == "all" else (i if btype == "each" else k)) == pair_w[k]
+    assert n_w == (1 if btype == "all" else (F if btype == "each" else P))
+    for r0 in range(0, len(rows), slots):                    # a round: no field twice
+        fields = [f for r in rows[r0:r0 + slots] if r[0] >= 0 for f in r[:2]]
+        assert len(fields) == len(set(fields))
+    groups = disjoint_groups(rows)
+    assert all(len(g) == 8 for g in groups)
+    seen = []
+    for g in groups:
+        fields = [f for r in g if r[0] >= 0 for f in r[:2]]
+        assert len(fields) == len(set(fields))               # field-disjoint: the waves' LDS read-modify-writes never meet
+        # the two halves of a group (waves 0-3 / 4-7 run half a group apart) are disjoint among themselves a fortiori
+        seen += [tuple(r) for r in g if r[0] >= 0]
+    assert sorted(seen) == sorted(tuple(r) for r in live)    # every pair exactly once, entries unchanged
+    width = min(8, F // 2)                                   # (F fields hold at most F // 2 disjoint pairs)
+    assert len(groups) <= -(-P // width) + 2                 # greedy stays near the bound
+    if F == 26:
+        assert len(groups) == 41
