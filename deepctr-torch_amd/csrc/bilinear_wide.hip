@@ -537,8 +537,11 @@ __global__ __launch_bounds__(64 * NWF) void k_bilinear_fwd_wide(const float* __r
     // One pair of a wave: 64 MFMAs into y in four steps of two column blocks x two sample halves (an accumulator is hit
     // every fourth MFMA); between the steps, in the shadow of the matrix pipe: the ring's re-loads in place, and the
     // NEXT pair's products -- its LDS operands after step 0, its 8 MFMAs after step 1, its two multiplies after step 2.
+    PairEnt nx = entry(1);
     for (int m = 0; m < npw; ++m) {
-      const PairEnt nx = entry(m + 1);
+      // (the schedule entry after the next: read now, needed at the end of this pair -- read at the head of the pair that
+      // needs it, its LDS round trip stood in front of the pair's first MFMAs)
+      const PairEnt nn = entry(m + 2);
       const f32x4* p0 = Wpk + static_cast<int64_t>(pass * P + nx.k) * (kNQ * 64) + lane;
       // the pair's pieces of the DNN input, for the backward's weight-gradient GEMM.  Unconditional: x holds whole
       // 32-row tiles (rows past B receive zeros) -- a store behind a branch is one the compiler cannot count, and its
@@ -587,6 +590,7 @@ __global__ __launch_bounds__(64 * NWF) void k_bilinear_fwd_wide(const float* __r
       asm volatile("" : "+v"(y0[0]), "+v"(y0[1]), "+v"(y0[2]), "+v"(y0[3]), "+v"(y0[4]), "+v"(y0[5]), "+v"(y0[6]), "+v"(y0[7]));
       asm volatile("" : "+v"(y1[0]), "+v"(y1[1]), "+v"(y1[2]), "+v"(y1[3]), "+v"(y1[4]), "+v"(y1[5]), "+v"(y1[6]), "+v"(y1[7]));
       en = nx;
+      nx = nn;
       pa = pan;
       pb = pbn;
     }
