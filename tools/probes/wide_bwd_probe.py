@@ -1,9 +1,14 @@
 #!/usr/bin/env python
-"""dctr_bilinear_wide_bwd alone at the Criteo shape (26 fields x 16, 128 hidden units, batch 4096): kernel time per call
-over hipEvents.  With the diagnostics library (make -C deepctr-torch_amd/csrc diag) DCTR_WIDE_VAR="<PD><VAR>" selects a
-timing variant of the main kernel (VAR bits: 1 no barrier, 2 no partial stores, 4 no ring reloads, 8 no LDS gradient
-writes -- results are wrong then, the time shows what each costs).
-    python tools/probes/wide_bwd_probe.py [variants...]      e.g.  20 21 22 24 28 215 10 30"""
+"""dctr_bilinear_wide_bwd alone at the Criteo shape (26 fields x 16, 128 hidden units, batch 4096): time per call
+(pack + main + reduce) over hipEvents, after 40 warm-up calls (the first variant timed was 10 % slow otherwise).
+With the diagnostics library (make -C deepctr-torch_amd/csrc diag) DCTR_WIDE_VAR="<2|1><VAR>" selects a timing variant of
+the main kernel ("1...": the field count read at run time instead of the F = 26 instantiation).  The kernel's VAR bits:
+1 no barriers, 2 no partial stores, 4 no ring re-loads, 8 no LDS gradient writes, 16 phase stamps (s_memtime sums per wave:
+MFMA block / barrier / behind it, and prologue / loop / epilogue), 32 ring re-loads out of L1, 64 schedule entries carried
+in registers, 128 part 2 at raised priority -- results are wrong for every bit but 16, the time shows what each costs.  The
+host entry instantiates 0, 15 and 16 (compile time); the single-bit variants of profiles/r06_bilinear_wide_variants.txt were
+measured with their instantiations added to the #ifdef DCTR_DIAG block of dctr_bilinear_wide_bwd.
+    python tools/probes/wide_bwd_probe.py [variants...]      e.g.  20 215 216 10"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "deepctr-torch_amd"))
