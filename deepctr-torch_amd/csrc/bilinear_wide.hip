@@ -39,8 +39,11 @@ constexpr int kD = 16;          // embedding width of the fused route
 // they lie (one 52-byte piece per hidden unit, rows 41 KB apart) by every workgroup of the finishing launch, the same
 // 128 lines were requested 256 times over: 11 us for a 4 us launch.
 template <bool FWD>
+// Wpk2 (FWD, nullable): the backward's layout too, from the same staged tile -- the forward's pack launch then serves
+// the backward of the same step (W0 does not move between the two: autograd's version check guards it).
 __global__ __launch_bounds__(kT) void k_wide_pack(const float* __restrict__ W0, int64_t ldw, int H, int KB,
-                                                  f32x4* __restrict__ Wpk, float* __restrict__ Wd, int n_dense) {
+                                                  f32x4* __restrict__ Wpk, float* __restrict__ Wd, int n_dense,
+                                                  f32x4* __restrict__ Wpk2) {
   __shared__ float t[16 * kNQ][65];
   if (FWD && Wd && blockIdx.x == gridDim.x - 1) {
     const int n = 16 * kNQ * 32;
@@ -96,6 +99,14 @@ __global__ __launch_bounds__(kT) void k_wide_pack(const float* __restrict__ W0, 
         v.w = t[16 * q + 4 * g + 3][kbl * 16 + c];
       }
       *(DCTR_GLOBAL f32x4*)(Wpk + (static_cast<int64_t>(kb0 + kbl) * kNQ + q) * 64 + lane) = v;
+      if (FWD && Wpk2) {
+        f32x4 w;
+        w.x = t[16 * q + 4 * g + 0][kbl * 16 + c];
+        w.y = t[16 * q + 4 * g + 1][kbl * 16 + c];
+        w.z = t[16 * q + 4 * g + 2][kbl * 16 + c];
+        w.w = t[16 * q + 4 * g + 3][kbl * 16 + c];
+        *(DCTR_GLOBAL f32x4*)(Wpk2 + (static_cast<int64_t>(kb0 + kbl) * kNQ + q) * 64 + lane) = w;
+      }
     }
   }
 }
@@ -708,14 +719,15 @@ extern "C" int dctr_bilinear_wide_bwd(const float* E, int64_t ld_e, const float*
                                       const int32_t* sched4, int32_t n_groups, const int32_t* pair_w, int32_t n_w,
                                       int32_t P, int32_t F, int32_t D, int32_t B, const float* gh, int64_t ld_gh,
                                       const float* W0, int64_t ld_w0, int32_t H, float* gE, float* gV, float* gW,
-                                      float* workspace, dctr_stream_t stream) {
+                                      float* workspace, const float* wpk, dctr_stream_t stream) {
   if (!E || !V || !Wf || !sched4 || !pair_w || !gh || !W0 || !gE || !gV || !gW || !workspace || B < 0 || F < 2 ||
       P <= 0 || n_groups <= 0 || n_w <= 0 || H <= 0)
     return DCTR_EINVAL;
   // one weight per pair, 16-wide embeddings, at most 128 hidden units in dwordx4 pieces
   if (D != kD || n_w != P || H > 16 * kNQ || (H & 3) || (ld_gh & 3) || (reinterpret_cast<uintptr_t>(gh) & 15) ||
       (reinterpret_cast<uintptr_t>(Wf) & 15) || (reinterpret_cast<uintptr_t>(gE) & 15) ||
-      (reinterpret_cast<uintptr_t>(gV) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15))
+      (reinterpret_cast<uintptr_t>(gV) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15) ||
+      (reinterpret_cast<uintptr_t>(wpk) & 15))
     return DCTR_ENOSUP;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (B == 0) {
@@ -728,7 +740,8 @@ extern "C" int dctr_bilinear_wide_bwd(const float* E, int64_t ld_e, const float*
   f32x4* Wpk = reinterpret_cast<f32x4*>(workspace);
   float* part = workspace + wide_pack_floats(P);
   const int KB = 2 * P, tiles = (B + 2 * kSB - 1) / (2 * kSB);
-  k_wide_pack<false><<<dim3((KB + 3) / 4), dim3(kT), 0, s>>>(W0, ld_w0, H, KB, Wpk, nullptr, 0);
+  if (wpk) Wpk = reinterpret_cast<f32x4*>(const_cast<float*>(wpk));      // (packed by the forward of this step)
+  else k_wide_pack<false><<<dim3((KB + 3) / 4), dim3(kT), 0, s>>>(W0, ld_w0, H, KB, Wpk, nullptr, 0, nullptr);
 #define DCTR_WIDE_F(VAR, FC)                                                                                      \
   do {                                                                                                            \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bilinear_bwd_wide<VAR, FC>),                       \
@@ -761,6 +774,8 @@ extern "C" int dctr_bilinear_wide_bwd(const float* E, int64_t ld_e, const float*
   return launch_status();
 }
 
+extern "C" size_t dctr_bilinear_wide_pack_floats(int32_t P) { return wide_pack_floats(P > 0 ? P : 1); }
+
 extern "C" size_t dctr_bilinear_wide_fwd_workspace_floats(int32_t B, int32_t P) {
   const size_t Bp = (static_cast<size_t>(B > 0 ? B : 1) + 2 * kSB - 1) / (2 * kSB) * (2 * kSB);
   return wide_pack_floats(P > 0 ? P : 1) + 2 * Bp * 16 * kNQ + 16 * kNQ * 32;
@@ -770,12 +785,13 @@ extern "C" int dctr_bilinear_wide_fwd(const float* E, int64_t ld_e, const float*
                                       const int32_t* sched_k, int32_t P, int32_t F, int32_t D, int32_t B,
                                       const float* dense, int64_t ld_d, int32_t n_dense, const float* W0, int64_t ld_w0,
                                       int32_t H, const float* b0, int32_t relu, float* x, int64_t ld_x, float* h,
-                                      int64_t ld_h, float* workspace, dctr_stream_t stream) {
+                                      int64_t ld_h, float* workspace, float* wpk_bwd, dctr_stream_t stream) {
   if (!E || !V || !Wf || !sched_k || !W0 || !x || !h || !workspace || B < 0 || F < 2 || P <= 0 || H <= 0 || n_dense < 0 ||
       (n_dense > 0 && !dense))
     return DCTR_EINVAL;
   if (D != kD || H > 16 * kNQ || n_dense > kFinND || (ld_x & 3) || (reinterpret_cast<uintptr_t>(x) & 15) ||
-      (reinterpret_cast<uintptr_t>(Wf) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15))
+      (reinterpret_cast<uintptr_t>(Wf) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15) ||
+      (reinterpret_cast<uintptr_t>(wpk_bwd) & 15))
     return DCTR_ENOSUP;
   if (B == 0) return DCTR_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -788,7 +804,8 @@ extern "C" int dctr_bilinear_wide_fwd(const float* E, int64_t ld_e, const float*
   float* ypart = workspace + wide_pack_floats(P);
   const int KB = 2 * P, tiles = (B + 2 * kSB - 1) / (2 * kSB), Bp = tiles * 2 * kSB;
   float* Wd = ypart + static_cast<size_t>(2) * Bp * 16 * kNQ;
-  k_wide_pack<true><<<dim3((KB + 3) / 4 + 1), dim3(kT), 0, s>>>(W0, ld_w0, H, KB, Wpk, Wd, n_dense);
+  k_wide_pack<true><<<dim3((KB + 3) / 4 + 1), dim3(kT), 0, s>>>(W0, ld_w0, H, KB, Wpk, Wd, n_dense,
+                                                               reinterpret_cast<f32x4*>(wpk_bwd));
 #define DCTR_WIDE_FWD(FC)                                                                                         \
   do {                                                                                                            \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bilinear_fwd_wide<FC, NWF>),                       \

@@ -174,9 +174,10 @@ SIGNATURES = {
     "dctr_bilinear_wide_bwd_workspace_floats": (ctypes.c_size_t, [_I32, _I32]),
     "dctr_bilinear_wide_fwd_workspace_floats": (ctypes.c_size_t, [_I32, _I32]),
     "dctr_bilinear_wide_fwd": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _P, _I64, _I32, _P, _I64,
-                                              _I32, _P, _I32, _P, _I64, _P, _I64, _P, _P]),
+                                              _I32, _P, _I32, _P, _I64, _P, _I64, _P, _P, _P]),
     "dctr_bilinear_wide_bwd": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _I64,
-                                              _P, _I64, _I32, _P, _P, _P, _P, _P]),
+                                              _P, _I64, _I32, _P, _P, _P, _P, _P, _P]),
+    "dctr_bilinear_wide_pack_floats": (ctypes.c_size_t, [_I32]),
     "dctr_inner_product_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P]),
     "dctr_inner_product_bwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P, _I64, _P]),
     "dctr_crossnet_vec_fwd": (ctypes.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _P, _I64, _P]),

@@ -382,17 +382,21 @@ class BilinearWideFunction(torch.autograd.Function):
         # (whole tiles of 32 rows: the fused forward stores its pairs unconditionally)
         x = torch.empty(((B + 31) // 32 * 32, ld_out), dtype=torch.float32, device=E.device)[:B, :width]
         sched = meta.device_tables(E.device)
+        wpk_b = None
         if os.environ.get("DCTR_BILINEAR_WIDE_FWD", "1") != "0" and W0.stride(1) == 1 and ld_out % 4 == 0 and n_dense <= 32 and \
                 (b0 is None or (b0.dtype == torch.float32 and b0.is_contiguous())):
             # pairs and first layer in one launch: the pairs feed the matrix cores from registers; x is a by-product
             # (the backward's weight-gradient GEMM reads it)
             h = torch.empty((B, W0.shape[0]), dtype=torch.float32, device=E.device)
             ws = torch.empty((lib.dctr_bilinear_wide_fwd_workspace_floats(B, P),), dtype=torch.float32, device=E.device)
+            if any(ctx.needs_input_grad):
+                # W0 in the backward's operand layout, by the same packing launch
+                wpk_b = torch.empty((lib.dctr_bilinear_wide_pack_floats(P),), dtype=torch.float32, device=E.device)
             L.check(lib.dctr_bilinear_wide_fwd(_ptr(E), lde, _ptr(V), ldv, _ptr(Wf), _ptr(sched[2]), P, F, D, B,
                                                _ptr(dense), dense.stride(0) if dense is not None else 0, n_dense,
                                                _ptr(W0), W0.stride(0), W0.shape[0], _ptr(b0), int(bool(relu)), _ptr(x),
-                                               ld_out, _ptr(h), h.stride(0), _ptr(ws), L.stream_handle(E.device)),
-                    "dctr_bilinear_wide_fwd")
+                                               ld_out, _ptr(h), h.stride(0), _ptr(ws), _ptr(wpk_b),
+                                               L.stream_handle(E.device)), "dctr_bilinear_wide_fwd")
         else:
             L.check(lib.dctr_bilinear_fwd(_ptr(E), lde, _ptr(V), ldv, _ptr(Wf), _ptr(sched[2]), sched[2].shape[0], P, F, D,
                                           B, _ptr(x), ld_out, _ptr(dense), dense.stride(0) if dense is not None else 0,
@@ -401,7 +405,7 @@ class BilinearWideFunction(torch.autograd.Function):
             if relu:
                 h = torch.relu_(h)
         ctx.meta, ctx.relu, ctx.has_bias, ctx.n_w_in = meta, bool(relu), b0 is not None, len(weights)
-        ctx.save_for_backward(E, V, Wf, x, W0, h if relu else None)
+        ctx.save_for_backward(E, V, Wf, x, W0, h if relu else None, wpk_b)
         return h
 
     @staticmethod
@@ -409,7 +413,7 @@ class BilinearWideFunction(torch.autograd.Function):
         from . import ops as _ops
         lib = L.lib()
         meta = ctx.meta
-        E, V, Wf, x, W0, h = ctx.saved_tensors
+        E, V, Wf, x, W0, h, wpk_b = ctx.saved_tensors
         E, lde = _ops._rows3(E, "Bilinear input")
         V, ldv = _ops._rows3(V, "Bilinear second input")
         B, F, D = E.shape
@@ -432,7 +436,7 @@ class BilinearWideFunction(torch.autograd.Function):
         L.check(lib.dctr_bilinear_wide_bwd(_ptr(E), lde, _ptr(V), ldv, _ptr(Wf), _ptr(sched4), sched4.shape[0],
                                            _ptr(pair_w), meta.n_w, P, F, D, B, _ptr(g), g.stride(0), _ptr(W0),
                                            W0.stride(0), W0.shape[0], _ptr(gE), _ptr(gV), _ptr(gW), _ptr(ws),
-                                           L.stream_handle(dev)), "dctr_bilinear_wide_bwd")
+                                           _ptr(wpk_b), L.stream_handle(dev)), "dctr_bilinear_wide_bwd")
         return (None, None, gE, gV, None, gW0, gb) + tuple(gW[i] for i in range(ctx.n_w_in))
 
 

@@ -560,12 +560,16 @@ int dctr_bilinear_wide_fwd(const float* E, int64_t ld_e, const float* V, int64_t
                            const int32_t* sched_k, int32_t P, int32_t F, int32_t D, int32_t B, const float* dense,
                            int64_t ld_d, int32_t n_dense, const float* W0, int64_t ld_w0, int32_t H, const float* b0,
                            int32_t relu, float* x, int64_t ld_x, float* h, int64_t ld_h, float* workspace,
-                           dctr_stream_t stream);
+                           float* wpk_bwd, dctr_stream_t stream);
+/* wpk_bwd (nullable, dctr_bilinear_wide_pack_floats(P) floats, 16-byte aligned): W0 in the BACKWARD's operand layout,
+ * written by the forward's packing launch; handed to dctr_bilinear_wide_bwd as `wpk` (NULL there: it packs W0 itself)
+ * it saves that launch.  Valid as long as W0 is unchanged.                                                           */
+size_t dctr_bilinear_wide_pack_floats(int32_t P);
 int dctr_bilinear_wide_bwd(const float* E, int64_t ld_e, const float* V, int64_t ld_v, const float* Wf,
                            const int32_t* sched4, int32_t n_groups, const int32_t* pair_w, int32_t n_w, int32_t P,
                            int32_t F, int32_t D, int32_t B, const float* gh, int64_t ld_gh, const float* W0,
                            int64_t ld_w0, int32_t H, float* gE, float* gV, float* gW, float* workspace,
-                           dctr_stream_t stream);
+                           const float* wpk, dctr_stream_t stream);
 
 /* InnerProductLayer (interaction.py:557-577): out[b, k] = sum_d e_i e_j (reduce != 0) or out[b, k*D + d] = e_i e_j;
  * pair order i < j, i outer.  Backward: gE[b, f, :] = sum_{g != f} gp[b, pair(f, g)] e_g.                    */

@@ -34,7 +34,7 @@ ws = torch.empty(lib.dctr_bilinear_wide_bwd_workspace_floats(B, P), device=dev)
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 def call():
     L.check(lib.dctr_bilinear_wide_bwd(p(E), F * D, p(V), F * D, p(Wf), p(sched4), sched4.shape[0], p(pair_w), P, P, F, D, B,
-                                       p(gh), H, p(W0), W0.stride(0), H, p(gE), p(gV), p(gW), p(ws),
+                                       p(gh), H, p(W0), W0.stride(0), H, p(gE), p(gV), p(gW), p(ws), None,
                                        L.stream_handle(torch.device(dev))), "wide")
 flop = 2.0 * B * 2 * P * (16 * H + 3 * 256)
 for _ in range(40):           # (clocks settle: the first variant timed was 10 % slow otherwise)
