@@ -397,8 +397,14 @@ __global__ __launch_bounds__(64 * kNW) void k_bilinear_bwd_wide(const float* __r
     }
     if (!(VAR & 1)) lds_barrier();     // this wave's gradient rows are in LDS; the other half passes to ITS part 2
   };
-  int n_live = 0;
-  while (n_live < n_groups && sch[4 * (kNW * n_live + wv)] >= 0) ++n_live;
+  // this wave's leading live groups, 64 groups per ballot (a loop of dependent LDS reads took 2 us of the prologue)
+  int n_live = n_groups;
+  for (int g0 = 0; g0 < n_groups && n_live == n_groups; g0 += 64) {
+    const int gq = g0 + lane;
+    const bool idle = gq < n_groups && sch[4 * (kNW * (gq < n_groups ? gq : 0) + wv)] < 0;
+    const unsigned long long m = __ballot(idle);
+    if (m) n_live = g0 + __builtin_ctzll(m);
+  }
   if (VAR & 16) k1 = __builtin_amdgcn_s_memtime();
   // half a group apart: read-modify-writes of the two halves never share an interval between two barriers, and each
   // half's four pairs are field-disjoint
