@@ -980,8 +980,17 @@ __device__ __forceinline__ float reduce_q4(const float* __restrict__ part, int Q
   return (j & 2) ? hi + lo : lo + hi;                   // (s0 + s1) + (s2 + s3) on all four
 }
 
+__device__ __forceinline__ void reduce_wave_block(const float* __restrict__ part, int Q, int64_t n,
+                                                  float* __restrict__ out, int blk);
+
 __global__ __launch_bounds__(kT) void k_cin_wgrad_reduce(const float* __restrict__ part, int Q, int64_t n,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, int nblk_w,
+                                                         const float* __restrict__ bpart, int nb,
+                                                         float* __restrict__ gbias) {
+  if (static_cast<int>(blockIdx.x) >= nblk_w) {          // (uniform: the bias gradient's workgroups)
+    reduce_wave_block(bpart, Q, nb, gbias, static_cast<int>(blockIdx.x) - nblk_w);
+    return;
+  }
   const int64_t t = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
   const int64_t i = t >> 2;
   const int j = static_cast<int>(t & 3);
@@ -990,10 +999,11 @@ __global__ __launch_bounds__(kT) void k_cin_wgrad_reduce(const float* __restrict
 }
 
 // few outputs, many partials (the bias gradient: n = 128, Q up to 256): one wave per output, lane l adds q = l, l + 64, ...
-// and the 64 sums meet in a butterfly (fixed order)
-__global__ __launch_bounds__(kT) void k_cin_wgrad_reduce_wave(const float* __restrict__ part, int Q, int64_t n,
-                                                              float* __restrict__ out) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * (kT / 64) + (threadIdx.x >> 6);
+// and the 64 sums meet in a butterfly (fixed order).  `blk`: the workgroup's index among the bias workgroups -- they ride
+// behind the weight workgroups of k_cin_wgrad_reduce / _sym (a launch of their own was 5.7 us of latency per layer).
+__device__ __forceinline__ void reduce_wave_block(const float* __restrict__ part, int Q, int64_t n,
+                                                  float* __restrict__ out, int blk) {
+  const int64_t i = static_cast<int64_t>(blk) * (kT / 64) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= n) return;
   float s = 0.f;
@@ -1004,7 +1014,13 @@ __global__ __launch_bounds__(kT) void k_cin_wgrad_reduce_wave(const float* __res
 
 // the same sum for the symmetric layer: part[q][o][pair (h <= m)] -> out[o][h * M + m] and out[o][m * M + h]
 __global__ __launch_bounds__(kT) void k_cin_wgrad_reduce_sym(const float* __restrict__ part, int Q, int O, int M,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, int nblk_w,
+                                                             const float* __restrict__ bpart, int nb,
+                                                             float* __restrict__ gbias) {
+  if (static_cast<int>(blockIdx.x) >= nblk_w) {          // (uniform: the bias gradient's workgroups)
+    reduce_wave_block(bpart, Q, nb, gbias, static_cast<int>(blockIdx.x) - nblk_w);
+    return;
+  }
   const int KP = M * (M + 1) / 2;
   const int64_t n = static_cast<int64_t>(O) * KP;
   const int64_t t = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
@@ -1336,14 +1352,14 @@ extern "C" int dctr_cin_layer_bwd(const float* gA, const float* A, int64_t ld_a,
       switch (ot) { case 1: DCTR_CIN_BW(1); break; case 2: DCTR_CIN_BW(2); break; case 3: DCTR_CIN_BW(3); break; default: DCTR_CIN_BW(4); break; }
 #undef DCTR_CIN_BW
       const int64_t n = static_cast<int64_t>(o_here) * KW;
+      const int nblk_w = static_cast<int>((4 * n + kT - 1) / kT);
+      const int nblk_b = gbias ? (o_here + kT / 64 - 1) / (kT / 64) : 0;      // the bias sums ride in the same launch
       if (sym)
-        k_cin_wgrad_reduce_sym<<<dim3(static_cast<unsigned>((4 * n + kT - 1) / kT)), dim3(kT), 0, s>>>(
-            part, geo.q, o_here, M, gW + static_cast<int64_t>(o0) * K);
+        k_cin_wgrad_reduce_sym<<<dim3(static_cast<unsigned>(nblk_w + nblk_b)), dim3(kT), 0, s>>>(
+            part, geo.q, o_here, M, gW + static_cast<int64_t>(o0) * K, nblk_w, bpart, o_here, gbias ? gbias + o0 : nullptr);
       else
-        k_cin_wgrad_reduce<<<dim3(static_cast<unsigned>((4 * n + kT - 1) / kT)), dim3(kT), 0, s>>>(
-            part, geo.q, n, gW + static_cast<int64_t>(o0) * K);
-      if (gbias)
-        k_cin_wgrad_reduce_wave<<<dim3((o_here + kT / 64 - 1) / (kT / 64)), dim3(kT), 0, s>>>(bpart, geo.q, o_here, gbias + o0);
+        k_cin_wgrad_reduce<<<dim3(static_cast<unsigned>(nblk_w + nblk_b)), dim3(kT), 0, s>>>(
+            part, geo.q, n, gW + static_cast<int64_t>(o0) * K, nblk_w, bpart, o_here, gbias ? gbias + o0 : nullptr);
     }
   }
   return launch_status();
